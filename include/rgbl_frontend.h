@@ -1,0 +1,252 @@
+/* rgbl_frontend.h — C ABI of librgbl_frontend.so: the MI355X-native RGB-L per-frame front end.
+ *
+ * This is the drop-in boundary for the hot path of TUMFTM/ORB_SLAM3_RGBL.  The reference has no FFI
+ * layer; its boundary is the C++ class API of three classes, and each entry point below names the
+ * reference interface it replaces (file:line under /root/reference).  The C++ shims in
+ * orb_slam3_rgbl_amd/shim/ re-create those classes (same names, same signatures) on top of this ABI;
+ * INTEGRATION.md shows the few lines a maintainer changes.
+ *
+ * Conventions
+ *   - plain C types only; no C++/torch/HIP types in any signature (streams travel as void*).
+ *   - every function returns an int status: RGBL_OK (0) or a negative RGBL_ERR_*; the message of the
+ *     last failure on the calling thread is available from rgbl_last_error().  Nothing throws or aborts.
+ *   - "host" entry points take host pointers, are synchronous and fill caller-owned buffers
+ *     (capacity in, count out) — the contract of the reference classes.
+ *   - "_device" entry points take device (HBM) pointers, only ENQUEUE work on the handle's stream and
+ *     return immediately; results are valid after rgbl_*_sync().  They exist so that batches of
+ *     independent frames stay resident in HBM between extract -> depth -> match.
+ *   - a handle owns one HIP stream + scratch memory and is NOT re-entrant (like the reference objects:
+ *     ORBextractor/DepthModule keep per-call state in members); different handles may be driven from
+ *     different threads concurrently.  Matcher entry points are stateless apart from their handle.
+ *   - there is NO CPU fallback: if no gfx950 device is usable, create() fails with RGBL_ERR_NO_DEVICE.
+ */
+#ifndef RGBL_FRONTEND_H
+#define RGBL_FRONTEND_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  RGBL_OK = 0,
+  RGBL_ERR_INVALID = -1,   /* bad argument */
+  RGBL_ERR_NO_DEVICE = -2, /* no usable HIP device */
+  RGBL_ERR_HIP = -3,       /* a HIP runtime call failed */
+  RGBL_ERR_CAPACITY = -4,  /* caller buffer too small; counts are still reported */
+  RGBL_ERR_OVERFLOW = -5,  /* an internal scratch bound was exceeded (never silently truncated) */
+  RGBL_ERR_EMPTY = -6      /* empty image: mirrors ORBextractor::operator() returning -1 */
+};
+
+const char* rgbl_last_error(void);
+/* "hip:gfx950" for the product build.  (The CPU SIMT emulation used by the test-suite reports "emu".) */
+const char* rgbl_backend(void);
+int rgbl_device_count(void);
+
+/* cv::KeyPoint binary layout (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id. */
+typedef struct {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} rgbl_keypoint;
+
+/* ------------------------------------------------------------------------------------------------
+ * ORBextractor            replaces include/ORBextractor.h:49-83, src/ORBextractor.cc:409-469,1086-1195
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rgbl_extractor rgbl_extractor;
+
+typedef struct {
+  int nfeatures;       /* ORBextractor.nFeatures   */
+  float scale_factor;  /* ORBextractor.scaleFactor */
+  int nlevels;         /* ORBextractor.nLevels (<= 16) */
+  int ini_th_fast;     /* ORBextractor.iniThFAST   */
+  int min_th_fast;     /* ORBextractor.minThFAST   */
+  int width, height;   /* image size this handle is built for (<= 4096 x 4096) */
+  int max_batch;       /* frames per batched call (>= 1) */
+} rgbl_extractor_cfg;
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (ORBextractor.h:49-50).  `device` = HIP device ordinal. */
+int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extractor** out);
+void rgbl_extractor_destroy(rgbl_extractor* h);
+
+/* Getters GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares
+ * (ORBextractor.h:61-81) plus mnFeaturesPerLevel and umax; any pointer may be NULL.
+ * Arrays hold nlevels entries (umax16: 16). Computed exactly as ORBextractor.cc:414-468 (fp32). */
+int rgbl_extractor_tables(const rgbl_extractor* h, float* scale, float* inv_scale, float* sigma2,
+                          float* inv_sigma2, int* features_per_level, int* umax16);
+/* Upper bound of keypoints one frame can produce (sum over levels of quota + slack). */
+int rgbl_extractor_max_keypoints(const rgbl_extractor* h);
+
+/* int ORBextractor::operator()(image, mask [ignored], keypoints, descriptors, vLappingArea)
+ * (ORBextractor.h:57-59, ORBextractor.cc:1086-1168).  Host image CV_8UC1 w x h with `stride` bytes per
+ * row; writes up to `cap` keypoints and cap x 32 descriptor bytes, *out_n = number of keypoints,
+ * *out_mono = the reference's return value (monoIndex).  Empty image -> RGBL_ERR_EMPTY, *out_mono=-1. */
+int rgbl_extract(rgbl_extractor* h, const uint8_t* img, int w, int h_, int stride, int lap0, int lap1,
+                 rgbl_keypoint* out_kp, uint8_t* out_desc, int cap, int* out_n, int* out_mono);
+
+/* Batched host variant: `batch` images of identical size, image b at imgs + b*frame_stride bytes.
+ * Outputs for frame b start at out_kp + b*cap and out_desc + b*cap*32; out_n/out_mono hold batch ints. */
+int rgbl_extract_batch(rgbl_extractor* h, const uint8_t* imgs, int batch, int w, int h_, int stride,
+                       size_t frame_stride, int lap0, int lap1, rgbl_keypoint* out_kp,
+                       uint8_t* out_desc, int cap, int* out_n, int* out_mono);
+
+/* Device-resident batch: d_imgs / d_kp / d_desc / d_n / d_mono are device pointers with the same
+ * layout as above (d_n, d_mono: int32[batch]).  Enqueues only; keypoints beyond `cap` are dropped and
+ * flagged: rgbl_extractor_sync() then returns RGBL_ERR_CAPACITY. */
+int rgbl_extract_batch_device(rgbl_extractor* h, const uint8_t* d_imgs, int batch, int w, int h_,
+                              int stride, size_t frame_stride, int lap0, int lap1, rgbl_keypoint* d_kp,
+                              uint8_t* d_desc, int cap, int32_t* d_n, int32_t* d_mono);
+/* Waits for the handle's stream and reports deferred device-side errors (overflow flags). */
+int rgbl_extractor_sync(rgbl_extractor* h);
+
+/* std::vector<cv::Mat> mvImagePyramid (ORBextractor.h:83; read by Frame::ComputeStereoMatches,
+ * Frame.cc:908,998-1013).  Copies level `level` of frame `frame` of the LAST call to host memory.
+ * with_border=1 adds the 19-px BORDER_REFLECT_101 frame the reference keeps around every level
+ * (ORBextractor.cc:1185-1191): dst is then (w+38) x (h+38).  blurred=1 returns the 7x7 Gaussian
+ * working image of ORBextractor.cc:1132-1133 instead (no border). */
+int rgbl_extractor_level_size(const rgbl_extractor* h, int level, int* w, int* h_);
+int rgbl_extractor_get_level(rgbl_extractor* h, int frame, int level, int blurred, int with_border,
+                             uint8_t* dst, int dst_stride);
+/* Test/diagnostic access to the stage between FAST and the quad-tree: the candidates handed to
+ * DistributeOctTree for (frame, level) in the reference's order, coordinates relative to minBorder
+ * (ORBextractor.cc:863-868).  Returns the count through *out_n. */
+int rgbl_extractor_get_candidates(rgbl_extractor* h, int frame, int level, rgbl_keypoint* out, int cap,
+                                  int* out_n);
+
+/* Stream control + per-kernel timing (HIP events on the launch stream) for bench.py. */
+int rgbl_extractor_set_stream(rgbl_extractor* h, void* hip_stream /* hipStream_t, NULL = own */);
+int rgbl_extractor_profile(rgbl_extractor* h, int enable);
+/* Returns the number of distinct kernels; fills up to cap entries. names[i] points to static storage. */
+int rgbl_extractor_profile_read(rgbl_extractor* h, const char** names, double* total_ms, long* launches,
+                                int cap);
+
+/* ------------------------------------------------------------------------------------------------
+ * DepthModule             replaces include/DepthModule.h:45-99, src/DepthModule.cc:50-274
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rgbl_depth rgbl_depth;
+
+enum { /* DepthModule::UpsamlingMethod (DepthModule.h:34-40) */
+  RGBL_UPS_NONE = 0,
+  RGBL_UPS_NEAREST_NEIGHBOR_PIXEL = 1,
+  RGBL_UPS_AVERAGE_FILTERING = 2,
+  RGBL_UPS_INVERSE_DILATION = 3,
+  RGBL_UPS_IPBASIC = 5 /* declared by the reference but never implemented: rejected here too */
+};
+
+typedef struct {
+  float proj[12];      /* LidarProjectionMatrix = K[3x4] * Tr[4x4] (DepthModule.cc:434), row-major */
+  float min_dist;      /* LiDAR.min_dist */
+  float max_dist;      /* LiDAR.max_dist */
+  float mbf;           /* Camera.bf */
+  int method;          /* RGBL_UPS_* */
+  int kernel_w, kernel_h;  /* inverse-dilation structuring element (<= 9 x 9), anchor = centre */
+  uint8_t kernel[81];      /* row-major mask; see rgbl_structuring_element() */
+  int avg_kernel_size;     /* LiDAR.MethodAverageFiltering.KernelSize */
+  float nn_search_radius;  /* LiDAR.MethodNearestNeighborPixel.SearchDistance */
+  int width, height;       /* image size */
+  int max_points;          /* capacity for LiDAR points per scan (reference cap: 250000) */
+  int max_keypoints;       /* capacity for keypoints per frame */
+  int max_batch;
+} rgbl_depth_cfg;
+
+/* DepthModule::DepthModule(yaml, sensor) minus the YAML parsing (that stays in the C++ shim). */
+int rgbl_depth_create(const rgbl_depth_cfg* cfg, int device, rgbl_depth** out);
+void rgbl_depth_destroy(rgbl_depth* h);
+/* LidarProjectionMatrix = CameraMatrix * RotationMatrix with OpenCV GEMM arithmetic (host helper). */
+void rgbl_projection_matrix(const float K3x4[12], const float Tr4x4[16], float out3x4[12]);
+/* cv::getStructuringElement (shape 0 RECT, 1 CROSS, 2 ELLIPSE) and the reference's Diamond tables
+ * (shape 3, DepthModule.h:138-161; only kw is used).  out holds kh*kw bytes. */
+int rgbl_structuring_element(int shape, int kw, int kh, uint8_t* out);
+
+/* void DepthModule::CalculateDepthFromPcd(mvKeys, mvKeysUn, PointCloud, imwidth, imheight)
+ * (DepthModule.h:62, DepthModule.cc:50-79).  cloud = the 4 x n CV_32F matrix of
+ * Examples/RGB-L/rgbl_kitti.cc:151-185 (rows x,y,z,1; `ld` floats between rows).  kp_xy = k pairs
+ * (pt.x, pt.y) of mvKeys, kpun_x = pt.x of mvKeysUn.  Outputs mvDepth / mvuRight (k floats each) and,
+ * if non-NULL, RawDepthMap / ProcessedDepthMap (h*w floats each). */
+int rgbl_depth_compute(rgbl_depth* h, const float* cloud, int n, int ld, int w, int h_,
+                       const float* kp_xy, const float* kpun_x, int k, float* out_depth,
+                       float* out_uright, float* out_raw, float* out_processed);
+
+/* Device-resident batch.  d_cloud: batch scans, scan b at d_cloud + b*cloud_stride floats, each 4 x n
+ * with leading dimension ld.  Keypoints come straight from rgbl_extract_batch_device(): d_kp (frame b
+ * at d_kp + b*kp_cap) and d_n (int32[batch]).  d_kpun_x may be NULL (undistorted == distorted, the
+ * KITTI case, Frame.cc:837-845).  Outputs: d_depth/d_uright float[batch*kp_cap]; d_processed (nullable)
+ * float[batch*h*w]. */
+int rgbl_depth_batch_device(rgbl_depth* h, const float* d_cloud, int batch, int n, int ld,
+                            size_t cloud_stride, int w, int h_, const rgbl_keypoint* d_kp,
+                            const int32_t* d_n, int kp_cap, const float* d_kpun_x, float* d_depth,
+                            float* d_uright, float* d_processed);
+int rgbl_depth_sync(rgbl_depth* h);
+int rgbl_depth_set_stream(rgbl_depth* h, void* hip_stream);
+int rgbl_depth_profile(rgbl_depth* h, int enable);
+int rgbl_depth_profile_read(rgbl_depth* h, const char** names, double* total_ms, long* launches, int cap);
+
+/* ------------------------------------------------------------------------------------------------
+ * ORBmatcher              replaces include/ORBmatcher.h:43,75-76, src/ORBmatcher.cc:907-1146,2058-2074
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rgbl_matcher rgbl_matcher;
+int rgbl_matcher_create(int device, rgbl_matcher** out);
+void rgbl_matcher_destroy(rgbl_matcher* h);
+int rgbl_matcher_sync(rgbl_matcher* h);
+int rgbl_matcher_set_stream(rgbl_matcher* h, void* hip_stream);
+int rgbl_matcher_profile(rgbl_matcher* h, int enable);
+int rgbl_matcher_profile_read(rgbl_matcher* h, const char** names, double* total_ms, long* launches, int cap);
+
+/* static int ORBmatcher::DescriptorDistance(a, b) (ORBmatcher.cc:2058-2074) on two 32-byte rows. Host. */
+int rgbl_descriptor_distance(const uint8_t* a, const uint8_t* b);
+
+/* Hamming brute force: for every row of A the best and second-best row of B, selection rule of
+ * ORBmatcher.cc:283-304 (strict '<': the first minimum wins; distances start at 256, idx at -1).
+ * Host pointers, synchronous.  second_dist may be NULL. */
+int rgbl_hamming_bf(rgbl_matcher* h, const uint8_t* desc_a, int na, const uint8_t* desc_b, int nb,
+                    int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+/* Device batch over frame pairs: descriptors of frame f live at d_desc + f*cap*32 with d_n[f] rows
+ * (the layout rgbl_extract_batch_device() writes).  Pair p matches frame pair_a[p] (queries) against
+ * frame pair_b[p] (train); outputs for pair p start at p*cap. */
+int rgbl_hamming_bf_batch_device(rgbl_matcher* h, const uint8_t* d_desc, const int32_t* d_n, int cap,
+                                 const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs,
+                                 int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist);
+
+/* int ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse)
+ * (ORBmatcher.h:75-76, ORBmatcher.cc:907-1146) on flattened key-frames (mono / stereo pinhole,
+ * mpCamera2 == nullptr).  The shim flattens KeyFrame under its mutexes, computes F12 and the epipole
+ * once (Pinhole.cpp:109-112, ORBmatcher.cc:913-931) and rebuilds the pair vector from matches12. */
+typedef struct {
+  int n;                    /* KeyFrame::N */
+  const uint8_t* desc;      /* mDescriptors, n x 32 */
+  const float* kp_xy;       /* mvKeysUn[i].pt, n x 2 */
+  const int32_t* kp_octave; /* mvKeysUn[i].octave */
+  const float* kp_angle;    /* mvKeysUn[i].angle */
+  const float* uright;      /* mvuRight */
+  const uint8_t* has_mappoint; /* GetMapPoint(i) != NULL */
+  /* mFeatVec (DBoW2::FeatureVector, a std::map<NodeId, vector<unsigned>>) as CSR, node ids ascending */
+  int n_nodes;
+  const int32_t* node_id;
+  const int32_t* node_off;  /* n_nodes + 1 */
+  const int32_t* node_feat; /* feature indices, ascending inside a node */
+} rgbl_keyframe_view;
+
+typedef struct {
+  float F12[9];                 /* K1^-T [t12]x R12 K2^-1, row-major */
+  float epipole[2];             /* ep = project(T2w * Cw1) in image 2 */
+  const float* scale_factors2;  /* pKF2->mvScaleFactors */
+  const float* level_sigma2_2;  /* pKF2->mvLevelSigma2 */
+  int n_levels;
+  int only_stereo;              /* bOnlyStereo */
+  int coarse;                   /* bCoarse */
+  int check_orientation;        /* mbCheckOrientation (false for LocalMapping.cc:412's matcher) */
+} rgbl_triangulation_params;
+
+/* Host pointers, synchronous. matches12 has kf1->n entries (-1 = unmatched); *out_nmatches = return
+ * value of the reference function. */
+int rgbl_search_triangulation(rgbl_matcher* h, const rgbl_keyframe_view* kf1,
+                              const rgbl_keyframe_view* kf2, const rgbl_triangulation_params* prm,
+                              int32_t* matches12, int* out_nmatches);
+/* F12 with the reference's fp32 evaluation order (Pinhole.cpp:109-112); K = {fx, fy, cx, cy}. Host. */
+void rgbl_fundamental(const float K1[4], const float K2[4], const float R12[9], const float t12[3],
+                      float F12[9]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBL_FRONTEND_H */

@@ -1,0 +1,131 @@
+/* oracle.h — C interface of the CPU oracle (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * The oracle is a dependency-free, single-threaded CPU restatement of the RGB-L front-end hot path of
+ * TUMFTM/ORB_SLAM3_RGBL (ORBextractor, DepthModule, ORBmatcher Hamming paths) plus the OpenCV 4.x
+ * primitives those classes delegate to.  It exists to CHECK the HIP path and to be timed as the
+ * `cpu_baseline` of bench.py.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it; the product library (librgbl_frontend.so) never links or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path and cannot be
+ * built here (needs OpenCV/Eigen/Pangolin/Boost; none installed, no network).  The oracle is pinned only
+ * by (a) hand-derived known-answer tests (tests/test_oracle_kat.py), (b) the live glibc for sinf/cosf
+ * and (c) oracle/_ref: the reference's own ORBextractor.cc compiled unmodified against a minimal
+ * cv-compat header whose OpenCV primitives are this oracle's restatements (pins everything that is NOT
+ * OpenCV-internal: cell loop, quad-tree, orientation, steering, packing).
+ */
+#ifndef RGBL_ORACLE_H
+#define RGBL_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same 28-byte layout as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id). */
+typedef struct {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} orc_keypoint;
+
+typedef struct orc_extractor orc_extractor;
+
+/* ORBextractor::ORBextractor (/root/reference/src/ORBextractor.cc:409-469). */
+orc_extractor* orc_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                                    int min_th_fast);
+void orc_extractor_destroy(orc_extractor*);
+/* per-level tables; out arrays hold nlevels entries */
+void orc_extractor_tables(const orc_extractor*, float* scale, float* inv_scale, float* sigma2,
+                          float* inv_sigma2, int* features_per_level, int* umax16);
+
+/* ORBextractor::operator() (/root/reference/src/ORBextractor.cc:1086-1168).
+ * Returns monoIndex, or -1 when the image is empty. *n_out receives the keypoint count (may exceed
+ * cap: then only the first cap records are written and -2 is returned). */
+int orc_extract(orc_extractor*, const uint8_t* img, int w, int h, int stride, int lap0, int lap1,
+                orc_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* Intermediates of the LAST orc_extract call (for stage-by-stage parity checks). */
+int orc_level_size(const orc_extractor*, int level, int* w, int* h);
+void orc_level_image(const orc_extractor*, int level, uint8_t* dst, int dst_stride);   /* un-bordered */
+void orc_level_blurred(const orc_extractor*, int level, uint8_t* dst, int dst_stride); /* valid if level has keypoints */
+/* level image with the 19-px BORDER_REFLECT_101 frame, as mvImagePyramid's parent buffer holds it */
+void orc_level_bordered(const orc_extractor*, int level, uint8_t* dst, int dst_stride);
+/* FAST candidates handed to DistributeOctTree (coordinates relative to minBorder, CPU order) */
+int orc_level_candidates(const orc_extractor*, int level, orc_keypoint* out, int cap);
+/* keypoints per level after distribution+orientation (level coordinates, before scaling) */
+int orc_level_keypoints(const orc_extractor*, int level, orc_keypoint* out, int cap);
+
+/* ---- stand-alone OpenCV-semantics primitives ---- */
+void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh,
+                          int dstride);
+void orc_gaussian_blur7_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+/* cv::FAST(img, kps, threshold, nonmax) TYPE_9_16; returns count */
+int orc_fast(const uint8_t* img, int w, int h, int stride, int threshold, int nonmax, orc_keypoint* out,
+             int cap);
+/* cornerScore<16> with the given seed threshold at pixel (x,y) (needs a 3-px margin) */
+int orc_fast_corner_score(const uint8_t* img, int stride, int x, int y, int threshold);
+float orc_fast_atan2(float y, float x);
+int orc_cv_round_f(float v);
+float orc_ic_angle(const uint8_t* img, int stride, int x, int y);
+void orc_brief(const uint8_t* blurred, int stride, int x, int y, float angle_deg, uint8_t* desc32);
+/* DistributeOctTree on an explicit candidate list; returns count written to out */
+int orc_distribute_octree(const orc_keypoint* cand, int n, int min_x, int max_x, int min_y, int max_y,
+                          int n_features, orc_keypoint* out, int cap);
+
+/* ---- DepthModule (/root/reference/src/DepthModule.cc:50-274) ---- */
+enum { ORC_UPS_NONE = 0, ORC_UPS_NEAREST = 1, ORC_UPS_AVERAGE = 2, ORC_UPS_INVDIL = 3 };
+typedef struct {
+  float proj[12];     /* LidarProjectionMatrix 3x4 row-major */
+  float min_dist, max_dist, mbf;
+  int method;         /* ORC_UPS_* */
+  int kw, kh;         /* inverse dilation structuring element size */
+  uint8_t kernel[81]; /* kh x kw mask, row-major */
+  int avg_ksize;      /* AverageFiltering.KernelSize */
+  float nn_radius;    /* NearestNeighborPixel.SearchDistance */
+} orc_depth_params;
+
+/* cloud: 4 x n row-major (rows x,y,z,1) with leading dimension ld floats.
+ * kp_xy: k pairs (x,y) of mvKeys; kpun_x: k values of mvKeysUn.pt.x.
+ * out_raw/out_processed may be NULL; each is h*w floats. */
+int orc_depth(const orc_depth_params*, const float* cloud, int n, int ld, int w, int h,
+              const float* kp_xy, const float* kpun_x, int k, float* out_depth, float* out_uright,
+              float* out_raw, float* out_processed);
+/* K[3x4] * Tr[4x4] in OpenCV gemm arithmetic (DepthModule.cc:434) */
+void orc_projection_matrix(const float K[12], const float Tr[16], float out[12]);
+/* cv::getStructuringElement for RECT(0)/CROSS(1)/ELLIPSE(2) and the reference's Diamond(3) tables */
+int orc_structuring_element(int shape, int kw, int kh, uint8_t* out);
+
+/* ---- ORBmatcher ---- */
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b); /* ORBmatcher.cc:2058-2074 */
+/* brute force best / second-best (rule of ORBmatcher.cc:283-304: strict '<', first wins) */
+void orc_hamming_bf(const uint8_t* a, int na, const uint8_t* b, int nb, int* best_idx, int* best_dist,
+                    int* second_dist);
+
+typedef struct {
+  /* key-frame 1 and 2, flat */
+  int n1, n2;
+  const uint8_t *desc1, *desc2;        /* n x 32 */
+  const float *kp1_xy, *kp2_xy;        /* n x 2 (undistorted keypoints) */
+  const int *kp1_octave, *kp2_octave;
+  const float *kp1_angle, *kp2_angle;
+  const float *uright1, *uright2;      /* mvuRight */
+  const uint8_t *has_mp1, *has_mp2;    /* MapPoint present */
+  /* FeatureVector as CSR: node ids ascending, offsets (nnodes+1), feature indices */
+  int nnodes1, nnodes2;
+  const int *node_id1, *node_off1, *node_feat1;
+  const int *node_id2, *node_off2, *node_feat2;
+  float F12[9];                        /* row-major, built once by the caller (Pinhole.cpp:109-112) */
+  float ep[2];                         /* epipole in image 2 */
+  const float* scale_factors2;         /* pKF2->mvScaleFactors */
+  const float* level_sigma2_2;         /* pKF2->mvLevelSigma2 */
+  int only_stereo, coarse, check_orientation;
+} orc_tri_input;
+/* ORBmatcher::SearchForTriangulation (ORBmatcher.cc:907-1146): fills matches12[n1] (-1 = none),
+ * returns nmatches. */
+int orc_search_triangulation(const orc_tri_input*, int* matches12);
+/* F12 = K1^-T [t]x R12 K2^-1 with Eigen's evaluation order in fp32 */
+void orc_fundamental(const float K1[4], const float K2[4], const float R12[9], const float t12[3],
+                     float F12[9]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

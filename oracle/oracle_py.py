@@ -1,0 +1,340 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE — see oracle/oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (orb_slam3_rgbl_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liborbslam_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liborbslam_oracle.so"])
+
+
+class DepthParams(C.Structure):
+    _fields_ = [("proj", C.c_float * 12), ("min_dist", C.c_float), ("max_dist", C.c_float),
+                ("mbf", C.c_float), ("method", C.c_int), ("kw", C.c_int), ("kh", C.c_int),
+                ("kernel", C.c_uint8 * 81), ("avg_ksize", C.c_int), ("nn_radius", C.c_float)]
+
+
+class TriInput(C.Structure):
+    _fields_ = [("n1", C.c_int), ("n2", C.c_int),
+                ("desc1", C.c_void_p), ("desc2", C.c_void_p),
+                ("kp1_xy", C.c_void_p), ("kp2_xy", C.c_void_p),
+                ("kp1_octave", C.c_void_p), ("kp2_octave", C.c_void_p),
+                ("kp1_angle", C.c_void_p), ("kp2_angle", C.c_void_p),
+                ("uright1", C.c_void_p), ("uright2", C.c_void_p),
+                ("has_mp1", C.c_void_p), ("has_mp2", C.c_void_p),
+                ("nnodes1", C.c_int), ("nnodes2", C.c_int),
+                ("node_id1", C.c_void_p), ("node_off1", C.c_void_p), ("node_feat1", C.c_void_p),
+                ("node_id2", C.c_void_p), ("node_off2", C.c_void_p), ("node_feat2", C.c_void_p),
+                ("F12", C.c_float * 9), ("ep", C.c_float * 2),
+                ("scale_factors2", C.c_void_p), ("level_sigma2_2", C.c_void_p),
+                ("only_stereo", C.c_int), ("coarse", C.c_int), ("check_orientation", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_extractor_create.restype = C.c_void_p
+        L.orc_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_extractor_destroy.argtypes = [C.c_void_p]
+        L.orc_extractor_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orc_extract.restype = C.c_int
+        L.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.orc_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        for f in ("orc_level_image", "orc_level_blurred", "orc_level_bordered"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+            getattr(L, f).restype = None
+        for f in ("orc_level_candidates", "orc_level_keypoints"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+            getattr(L, f).restype = C.c_int
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                           C.c_int, C.c_int]
+        L.orc_gaussian_blur7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast.restype = C.c_int
+        L.orc_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast_corner_score.restype = C.c_int
+        L.orc_fast_corner_score.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_cv_round_f.restype = C.c_int
+        L.orc_cv_round_f.argtypes = [C.c_float]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_brief.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.orc_distribute_octree.restype = C.c_int
+        L.orc_distribute_octree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_void_p, C.c_int]
+        L.orc_depth.restype = C.c_int
+        L.orc_depth.argtypes = [C.POINTER(DepthParams), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p]
+        L.orc_projection_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_structuring_element.restype = C.c_int
+        L.orc_structuring_element.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_descriptor_distance.restype = C.c_int
+        L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_hamming_bf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]
+        L.orc_search_triangulation.restype = C.c_int
+        L.orc_search_triangulation.argtypes = [C.POINTER(TriInput), C.c_void_p]
+        L.orc_fundamental.argtypes = [C.c_void_p] * 5
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Extractor:
+    """Mirror of ORB_SLAM3::ORBextractor on the oracle."""
+
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=12, min_th=7):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = self.L.orc_extractor_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_extractor_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        per = np.zeros(n, np.int32)
+        umax = np.zeros(16, np.int32)
+        self.L.orc_extractor_tables(self.h, _p(sc), _p(isc), _p(s2), _p(is2), _p(per), _p(umax))
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, per_level=per, umax=umax)
+
+    def __call__(self, img, lapping=(0, 0), cap=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = cap or (self.nfeatures * 2 + 4096)
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        mono = self.L.orc_extract(self.h, _p(img), w, h, img.strides[0], lapping[0], lapping[1],
+                                  _p(kps), _p(desc), cap, C.byref(n))
+        if mono == -2:
+            return self(img, lapping, cap=n.value)
+        return kps[:n.value].copy(), desc[:n.value].copy(), mono
+
+    def level_size(self, l):
+        w, h = C.c_int(), C.c_int()
+        self.L.orc_level_size(self.h, l, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def _level_img(self, fn, l, border=0):
+        w, h = self.level_size(l)
+        out = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+        fn(self.h, l, _p(out), out.strides[0])
+        return out
+
+    def level_image(self, l):
+        return self._level_img(self.L.orc_level_image, l)
+
+    def level_blurred(self, l):
+        return self._level_img(self.L.orc_level_blurred, l)
+
+    def level_bordered(self, l):
+        return self._level_img(self.L.orc_level_bordered, l, 19)
+
+    def _kps(self, fn, l):
+        n = fn(self.h, l, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        fn(self.h, l, _p(out), n)
+        return out[:n]
+
+    def level_candidates(self, l):
+        return self._kps(self.L.orc_level_candidates, l)
+
+    def level_keypoints(self, l):
+        return self._kps(self.L.orc_level_keypoints, l)
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur7(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    lib().orc_gaussian_blur7_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst),
+                                dst.strides[0])
+    return dst
+
+
+def fast(img, threshold, nonmax=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros(cap, KP_DTYPE)
+    n = lib().orc_fast(_p(img), img.shape[1], img.shape[0], img.strides[0], threshold, int(nonmax),
+                       _p(out), cap)
+    return out[:n]
+
+
+def corner_score(img, x, y, threshold):
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib().orc_fast_corner_score(_p(img), img.strides[0], x, y, threshold)
+
+
+def fast_atan2(y, x):
+    return lib().orc_fast_atan2(float(y), float(x))
+
+
+def cv_round(v):
+    return lib().orc_cv_round_f(float(v))
+
+
+def ic_angle(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib().orc_ic_angle(_p(img), img.strides[0], x, y)
+
+
+def brief(blurred, x, y, angle_deg):
+    blurred = np.ascontiguousarray(blurred, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().orc_brief(_p(blurred), blurred.strides[0], x, y, float(angle_deg), _p(d))
+    return d
+
+
+def distribute_octree(cand, min_x, max_x, min_y, max_y, n_features):
+    cand = np.ascontiguousarray(cand, KP_DTYPE)
+    out = np.zeros(max(len(cand), 1), KP_DTYPE)
+    n = lib().orc_distribute_octree(_p(cand), len(cand), min_x, max_x, min_y, max_y, n_features,
+                                    _p(out), len(out))
+    return out[:n]
+
+
+def structuring_element(shape, kw, kh):
+    out = np.zeros(kw * kh, np.uint8)
+    rc = lib().orc_structuring_element(shape, kw, kh, _p(out))
+    if rc != 0:
+        raise ValueError("bad structuring element")
+    return out.reshape(kh, kw)
+
+
+def projection_matrix(K3x4, Tr4x4):
+    K = np.ascontiguousarray(K3x4, np.float32)
+    T = np.ascontiguousarray(Tr4x4, np.float32)
+    out = np.zeros((3, 4), np.float32)
+    lib().orc_projection_matrix(_p(K), _p(T), _p(out))
+    return out
+
+
+def make_depth_params(proj, min_dist=5.0, max_dist=200.0, mbf=100.0, method=3, kernel=None,
+                      avg_ksize=5, nn_radius=7.0):
+    P = DepthParams()
+    proj = np.asarray(proj, np.float32).reshape(12)
+    for i in range(12):
+        P.proj[i] = float(proj[i])
+    P.min_dist, P.max_dist, P.mbf, P.method = min_dist, max_dist, mbf, method
+    if kernel is None:
+        kernel = structuring_element(3, 5, 5)
+    kernel = np.asarray(kernel, np.uint8)
+    P.kh, P.kw = kernel.shape
+    flat = kernel.reshape(-1)
+    for i in range(flat.size):
+        P.kernel[i] = int(flat[i])
+    P.avg_ksize = avg_ksize
+    P.nn_radius = nn_radius
+    return P
+
+
+def depth(P, cloud4xn, w, h, kp_xy, kpun_x, want_maps=True):
+    cloud = np.ascontiguousarray(cloud4xn, np.float32)
+    n = cloud.shape[1]
+    kp_xy = np.ascontiguousarray(kp_xy, np.float32).reshape(-1, 2)
+    kpun_x = np.ascontiguousarray(kpun_x, np.float32)
+    k = kp_xy.shape[0]
+    d = np.zeros(k, np.float32)
+    ur = np.zeros(k, np.float32)
+    raw = np.zeros((h, w), np.float32) if want_maps else None
+    proc = np.zeros((h, w), np.float32) if want_maps else None
+    rc = lib().orc_depth(C.byref(P), _p(cloud), n, cloud.strides[0] // 4, w, h, _p(kp_xy), _p(kpun_x), k,
+                         _p(d), _p(ur), _p(raw), _p(proc))
+    if rc != 0:
+        raise RuntimeError("orc_depth failed")
+    return d, ur, raw, proc
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def hamming_bf(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    na, nb = len(a), len(b)
+    bi = np.zeros(na, np.int32)
+    bd = np.zeros(na, np.int32)
+    sd = np.zeros(na, np.int32)
+    lib().orc_hamming_bf(_p(a), na, _p(b), nb, _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
+
+
+def fundamental(K1, K2, R12, t12):
+    a = [np.ascontiguousarray(v, np.float32) for v in (K1, K2, R12, t12)]
+    F = np.zeros(9, np.float32)
+    lib().orc_fundamental(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(F))
+    return F
+
+
+def search_triangulation(kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, only_stereo=False,
+                         coarse=False, check_orientation=False):
+    """kf = dict(desc, xy, octave, angle, uright, has_mp, node_id, node_off, node_feat)."""
+    keep = []
+
+    def arr(v, dt):
+        a = np.ascontiguousarray(v, dt)
+        keep.append(a)
+        return a.ctypes.data
+
+    T = TriInput()
+    T.n1, T.n2 = len(kf1["desc"]), len(kf2["desc"])
+    for i, kf in ((1, kf1), (2, kf2)):
+        setattr(T, "desc%d" % i, arr(kf["desc"], np.uint8))
+        setattr(T, "kp%d_xy" % i, arr(kf["xy"], np.float32))
+        setattr(T, "kp%d_octave" % i, arr(kf["octave"], np.int32))
+        setattr(T, "kp%d_angle" % i, arr(kf["angle"], np.float32))
+        setattr(T, "uright%d" % i, arr(kf["uright"], np.float32))
+        setattr(T, "has_mp%d" % i, arr(kf["has_mp"], np.uint8))
+        setattr(T, "nnodes%d" % i, len(kf["node_id"]))
+        setattr(T, "node_id%d" % i, arr(kf["node_id"], np.int32))
+        setattr(T, "node_off%d" % i, arr(kf["node_off"], np.int32))
+        setattr(T, "node_feat%d" % i, arr(kf["node_feat"], np.int32))
+    for i in range(9):
+        T.F12[i] = float(F12[i])
+    T.ep[0], T.ep[1] = float(ep[0]), float(ep[1])
+    T.scale_factors2 = arr(scale_factors2, np.float32)
+    T.level_sigma2_2 = arr(level_sigma2_2, np.float32)
+    T.only_stereo, T.coarse, T.check_orientation = int(only_stereo), int(coarse), int(check_orientation)
+    m = np.zeros(T.n1, np.int32)
+    n = lib().orc_search_triangulation(C.byref(T), _p(m))
+    return m, n

@@ -1,0 +1,139 @@
+"""ctypes binding of librgbl_frontend.so (the C ABI declared in include/rgbl_frontend.h).
+
+There is exactly one product library: the hipcc build for gfx950.  `load()` fails loudly when it is
+missing or when no HIP device is usable — there is no CPU fallback.  (`bind(path)` is also used by the
+test-suite to bind the CPU SIMT emulation of the same sources; the product never calls it with that.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librgbl_frontend.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+RGBL_OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_OVERFLOW, ERR_EMPTY = -1, -2, -3, -4, -5, -6
+
+
+class RgblError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rgbl error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ExtractorCfg(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("width", C.c_int),
+                ("height", C.c_int), ("max_batch", C.c_int)]
+
+
+class DepthCfg(C.Structure):
+    _fields_ = [("proj", C.c_float * 12), ("min_dist", C.c_float), ("max_dist", C.c_float),
+                ("mbf", C.c_float), ("method", C.c_int), ("kernel_w", C.c_int), ("kernel_h", C.c_int),
+                ("kernel", C.c_uint8 * 81), ("avg_kernel_size", C.c_int), ("nn_search_radius", C.c_float),
+                ("width", C.c_int), ("height", C.c_int), ("max_points", C.c_int),
+                ("max_keypoints", C.c_int), ("max_batch", C.c_int)]
+
+
+class KeyframeView(C.Structure):
+    _fields_ = [("n", C.c_int), ("desc", C.c_void_p), ("kp_xy", C.c_void_p), ("kp_octave", C.c_void_p),
+                ("kp_angle", C.c_void_p), ("uright", C.c_void_p), ("has_mappoint", C.c_void_p),
+                ("n_nodes", C.c_int), ("node_id", C.c_void_p), ("node_off", C.c_void_p),
+                ("node_feat", C.c_void_p)]
+
+
+class TriangulationParams(C.Structure):
+    _fields_ = [("F12", C.c_float * 9), ("epipole", C.c_float * 2), ("scale_factors2", C.c_void_p),
+                ("level_sigma2_2", C.c_void_p), ("n_levels", C.c_int), ("only_stereo", C.c_int),
+                ("coarse", C.c_int), ("check_orientation", C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol of include/rgbl_frontend.h
+_V, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SYMBOLS = {
+    "rgbl_last_error": (C.c_char_p, []),
+    "rgbl_backend": (C.c_char_p, []),
+    "rgbl_device_count": (_I, []),
+    "rgbl_extractor_create": (_I, [C.POINTER(ExtractorCfg), _I, C.POINTER(_V)]),
+    "rgbl_extractor_destroy": (None, [_V]),
+    "rgbl_extractor_tables": (_I, [_V, _V, _V, _V, _V, _V, _V]),
+    "rgbl_extractor_max_keypoints": (_I, [_V]),
+    "rgbl_extract": (_I, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "rgbl_extract_batch": (_I, [_V, _V, _I, _I, _I, _I, _Z, _I, _I, _V, _V, _I, _V, _V]),
+    "rgbl_extract_batch_device": (_I, [_V, _V, _I, _I, _I, _I, _Z, _I, _I, _V, _V, _I, _V, _V]),
+    "rgbl_extractor_sync": (_I, [_V]),
+    "rgbl_extractor_level_size": (_I, [_V, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "rgbl_extractor_get_level": (_I, [_V, _I, _I, _I, _I, _V, _I]),
+    "rgbl_extractor_get_candidates": (_I, [_V, _I, _I, _V, _I, C.POINTER(_I)]),
+    "rgbl_extractor_set_stream": (_I, [_V, _V]),
+    "rgbl_extractor_profile": (_I, [_V, _I]),
+    "rgbl_extractor_profile_read": (_I, [_V, _V, _V, _V, _I]),
+    "rgbl_depth_create": (_I, [C.POINTER(DepthCfg), _I, C.POINTER(_V)]),
+    "rgbl_depth_destroy": (None, [_V]),
+    "rgbl_projection_matrix": (None, [_V, _V, _V]),
+    "rgbl_structuring_element": (_I, [_I, _I, _I, _V]),
+    "rgbl_depth_compute": (_I, [_V, _V, _I, _I, _I, _I, _V, _V, _I, _V, _V, _V, _V]),
+    "rgbl_depth_batch_device": (_I, [_V, _V, _I, _I, _I, _Z, _I, _I, _V, _V, _I, _V, _V, _V, _V]),
+    "rgbl_depth_sync": (_I, [_V]),
+    "rgbl_depth_set_stream": (_I, [_V, _V]),
+    "rgbl_depth_profile": (_I, [_V, _I]),
+    "rgbl_depth_profile_read": (_I, [_V, _V, _V, _V, _I]),
+    "rgbl_matcher_create": (_I, [_I, C.POINTER(_V)]),
+    "rgbl_matcher_destroy": (None, [_V]),
+    "rgbl_matcher_sync": (_I, [_V]),
+    "rgbl_matcher_set_stream": (_I, [_V, _V]),
+    "rgbl_matcher_profile": (_I, [_V, _I]),
+    "rgbl_matcher_profile_read": (_I, [_V, _V, _V, _V, _I]),
+    "rgbl_descriptor_distance": (_I, [_V, _V]),
+    "rgbl_hamming_bf": (_I, [_V, _V, _I, _V, _I, _V, _V, _V]),
+    "rgbl_hamming_bf_batch_device": (_I, [_V, _V, _V, _I, _V, _V, _I, _V, _V, _V]),
+    "rgbl_search_triangulation": (_I, [_V, C.POINTER(KeyframeView), C.POINTER(KeyframeView),
+                                       C.POINTER(TriangulationParams), _V, C.POINTER(_I)]),
+    "rgbl_fundamental": (None, [_V, _V, _V, _V, _V]),
+}
+
+
+def bind(path):
+    """dlopen `path` and attach the prototypes of every symbol in include/rgbl_frontend.h."""
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def load():
+    """The product library. Raises if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RgblError(ERR_NO_DEVICE, "%s not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                           "(there is no CPU fallback)" % LIB_PATH)
+        _lib = bind(LIB_PATH)
+    return _lib
+
+
+def check(lib, rc):
+    if rc != RGBL_OK:
+        raise RgblError(rc, lib.rgbl_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def read_profile(lib, fn, handle):
+    names = (C.c_char_p * 32)()
+    ms = (C.c_double * 32)()
+    cnt = (C.c_long * 32)()
+    n = fn(handle, C.cast(names, C.c_void_p), C.cast(ms, C.c_void_p), C.cast(cnt, C.c_void_p), 32)
+    return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n, 32))}

@@ -1,0 +1,134 @@
+// common.h — shared host/device helpers for the rgbl front-end kernels (gfx950 / wave64).
+#pragma once
+
+#ifdef RGBL_EMU
+// CPU SIMT emulation used ONLY by the test-suite (tests/emu/hip_emu.h); never part of the product build.
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rgbl_frontend.h"
+
+namespace rgbl {
+
+// ---- error plumbing: the C ABI never throws; every entry point returns a status and records a message
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define RGBL_HIP(expr)                                                                        \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      rgbl::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return RGBL_ERR_HIP;                                                                    \
+    }                                                                                         \
+  } while (0)
+
+#define RGBL_TRY(expr)            \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != RGBL_OK) return rc__; \
+  } while (0)
+
+constexpr int kWave = 64;  // gfx950 wavefront width; hard-coded on purpose
+
+// ---- per-kernel timing (HIP events on the launch stream), used by bench.py's roofline leg
+struct KernelTimer {
+  struct Rec { int id; hipEvent_t a, b; };
+  bool enabled = false;
+  std::vector<Rec> recs;
+  std::vector<double> total_ms;
+  std::vector<long> count;
+  std::vector<std::string> names;
+  int id_of(const char* name) {
+    for (size_t i = 0; i < names.size(); ++i)
+      if (names[i] == name) return (int)i;
+    names.push_back(name);
+    total_ms.push_back(0);
+    count.push_back(0);
+    return (int)names.size() - 1;
+  }
+  void begin(const char* name, hipStream_t s) {
+    if (!enabled) return;
+    Rec r;
+    r.id = id_of(name);
+    hipEventCreate(&r.a);
+    hipEventCreate(&r.b);
+    hipEventRecord(r.a, s);
+    recs.push_back(r);
+  }
+  void end(hipStream_t s) {
+    if (!enabled) return;
+    hipEventRecord(recs.back().b, s);
+  }
+  // call after the stream has been synchronised
+  void collect() {
+    for (Rec& r : recs) {
+      float ms = 0;
+      hipEventSynchronize(r.b);
+      hipEventElapsedTime(&ms, r.a, r.b);
+      total_ms[r.id] += ms;
+      count[r.id] += 1;
+      hipEventDestroy(r.a);
+      hipEventDestroy(r.b);
+    }
+    recs.clear();
+  }
+  void reset() {
+    collect();
+    for (size_t i = 0; i < total_ms.size(); ++i) { total_ms[i] = 0; count[i] = 0; }
+  }
+};
+
+// ---- device helpers ----------------------------------------------------------------------------
+__device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }  // round-half-even
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+__device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ int reflect101(int p, int len) {
+  // BORDER_REFLECT_101 for |overshoot| < len (always true for the 3/19-px borders used here)
+  if (p < 0) p = -p;
+  if (p >= len) p = 2 * (len - 1) - p;
+  return imin(imax(p, 0), len - 1);  // far-out-of-range taps only feed outputs that are never stored
+}
+
+template <class T>
+__device__ __forceinline__ T wave_sum(T v) {
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// Exclusive prefix sum over the 256 work-items of a workgroup (4 waves). `scratch` holds >= 8 values.
+// Returns the exclusive prefix of `v`; *total receives the workgroup sum. Contains two barriers.
+template <class T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* scratch, T* total) {
+  const int lane = lane_id(), w = wave_id();
+  T incl = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    T up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) scratch[w] = incl;
+  __syncthreads();
+  const int nw = (int)((blockDim.x + 63) >> 6);
+  T base = 0, tot = 0;
+  for (int i = 0; i < nw; ++i) {
+    const T s = scratch[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+}  // namespace rgbl

@@ -1,0 +1,482 @@
+// depth.hip — LiDAR depth path: projection + ordered scatter, up-sampling, per-keypoint depth gather.
+//
+// Replaces ORB_SLAM3::DepthModule::CalculateDepthFromPcd and the functions it calls
+// (/root/reference/src/DepthModule.cc:50-274, include/DepthModule.h:34-161).
+//
+// Kernels (B scans per launch, blockIdx.y = frame):
+//   k_project_index   thread per point: u,v,d with the reference's arithmetic (fp64-accumulated 3x4 dot,
+//                     fp32 reciprocal and product); atomicMax(point index) per pixel = "last point wins"
+//   k_project_write   thread per point: the winner of a pixel writes its depth into RawDepthMap
+//   k_inverse_dilate  64x16 tile + halo in LDS: S-x, TOZERO_INV, max over the structuring element, S-x, TOZERO_INV
+//   k_average_filter  k x k box (reflect-101) of depths and of the hit count, ratio as the reference forms it
+//   k_gather_depth    mvDepth / mvuRight from ProcessedDepthMap (truncating index)
+//   k_nn_depth        NearestNeighborPixel: 5x5-chamfer distance to the nearest hit, max depth in the box
+// HBM layout per frame: idx map (u32 h*w) | raw map (f32 h*w) | processed map (f32 h*w).
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace rgbl {
+
+struct ProjParams { float m[12]; float min_dist, max_dist; };
+struct DilateMask { int kw, kh; uint8_t m[81]; };
+
+// DepthModule.cc:115-119 for one point. Returns the pixel index or -1.
+__device__ __forceinline__ int project_point(const ProjParams& P, const float* __restrict__ cloud, int ld, int i, int w,
+                                             int h, float* depth) {
+  const double x = (double)cloud[i], y = (double)cloud[(size_t)ld + i], z = (double)cloud[2 * (size_t)ld + i],
+               o = (double)cloud[3 * (size_t)ld + i];
+  float p[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    // OpenCV's generic GEMM accumulates every dot product in double, k = 0..3, and rounds once
+    double acc = 0.0;
+    acc += (double)P.m[4 * r + 0] * x;
+    acc += (double)P.m[4 * r + 1] * y;
+    acc += (double)P.m[4 * r + 2] * z;
+    acc += (double)P.m[4 * r + 3] * o;
+    p[r] = (float)acc;
+  }
+  const float recip = __fdiv_rn(1.0f, p[2]);
+  const float u = p[0] * recip, v = p[1] * recip, d = p[2];
+  *depth = d;
+  if (u > 0 && v > 0 && u < (float)w && v < (float)h && d > P.min_dist && d < P.max_dist) return (int)v * w + (int)u;
+  return -1;
+}
+
+__global__ __launch_bounds__(256) void k_project_index(ProjParams P, const float* __restrict__ cloud, size_t cloud_stride,
+                                                       int n, int ld, int w, int h, uint32_t* __restrict__ idx_map,
+                                                       size_t map_stride) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int f = blockIdx.y;
+  float d;
+  const int pix = project_point(P, cloud + (size_t)f * cloud_stride, ld, i, w, h, &d);
+  if (pix >= 0) atomicMax(idx_map + (size_t)f * map_stride + pix, (uint32_t)(i + 1));
+}
+
+__global__ __launch_bounds__(256) void k_project_write(ProjParams P, const float* __restrict__ cloud, size_t cloud_stride,
+                                                       int n, int ld, int w, int h, const uint32_t* __restrict__ idx_map,
+                                                       float* __restrict__ raw, size_t map_stride) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int f = blockIdx.y;
+  float d;
+  const int pix = project_point(P, cloud + (size_t)f * cloud_stride, ld, i, w, h, &d);
+  if (pix >= 0 && idx_map[(size_t)f * map_stride + pix] == (uint32_t)(i + 1)) raw[(size_t)f * map_stride + pix] = d;
+}
+
+// grid = (ceil(w/64), ceil(h/16), B), block = 256.
+__global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, const float* __restrict__ raw,
+                                                        float* __restrict__ out, size_t map_stride, int w, int h) {
+  __shared__ float s_inv[24 * 72];
+  const int tid = threadIdx.x, f = blockIdx.z;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+  const int ax = K.kw / 2, ay = K.kh / 2;
+  const int tw = 64 + K.kw - 1, th = 16 + K.kh - 1;
+  const float thr = S - 1;
+  const float* R = raw + (size_t)f * map_stride;
+  for (int i = tid; i < tw * th; i += 256) {
+    const int r = i / tw, c = i - r * tw;
+    const int yy = y0 + r - ay, xx = x0 + c - ax;
+    float v = -FLT_MAX;  // taps outside the image never win (cv::dilate's default border)
+    if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+      const float t = S - R[(size_t)yy * w + xx];
+      v = t > thr ? 0.f : t;  // THRESH_TOZERO_INV
+    }
+    s_inv[r * 72 + c] = v;
+  }
+  __syncthreads();
+  const int x = tid & 63;
+  for (int k = 0; k < 4; ++k) {
+    const int y = (tid >> 6) + 4 * k;
+    if (x0 + x >= w || y0 + y >= h) continue;
+    float m = -FLT_MAX;
+    for (int ky = 0; ky < K.kh; ++ky)
+      for (int kx = 0; kx < K.kw; ++kx)
+        if (K.m[ky * K.kw + kx]) m = fmaxf(m, s_inv[(y + ky) * 72 + x + kx]);
+    const float t = S - m;
+    out[(size_t)f * map_stride + (size_t)(y0 + y) * w + x0 + x] = t > thr ? 0.f : t;
+  }
+}
+
+// grid = (ceil(w/64), ceil(h/16), B), block = 256.  ksize <= 9.
+__global__ __launch_bounds__(256) void k_average_filter(int ksize, const float* __restrict__ raw, float* __restrict__ out,
+                                                        size_t map_stride, int w, int h) {
+  __shared__ float s_in[24 * 72];
+  const int tid = threadIdx.x, f = blockIdx.z;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+  const int a = ksize / 2;
+  const int tw = 64 + ksize - 1, th = 16 + ksize - 1;
+  const float* R = raw + (size_t)f * map_stride;
+  for (int i = tid; i < tw * th; i += 256) {
+    const int r = i / tw, c = i - r * tw;
+    s_in[r * 72 + c] = R[(size_t)reflect101(y0 + r - a, h) * w + reflect101(x0 + c - a, w)];
+  }
+  __syncthreads();
+  const float coef = (float)(1.0 / (double)(ksize * ksize));
+  const int x = tid & 63;
+  for (int k = 0; k < 4; ++k) {
+    const int y = (tid >> 6) + 4 * k;
+    if (x0 + x >= w || y0 + y >= h) continue;
+    float sum = 0.f, cnt = 0.f;
+    for (int ky = 0; ky < ksize; ++ky)
+      for (int kx = 0; kx < ksize; ++kx) {
+        const float v = s_in[(y + ky) * 72 + x + kx];
+        sum = sum + coef * v;
+        cnt = cnt + (v > 0.f ? 1.f : 0.f);
+      }
+    out[(size_t)f * map_stride + (size_t)(y0 + y) * w + x0 + x] = sum * __fdiv_rn((float)(ksize * ksize), cnt);
+  }
+}
+
+// DepthModule.cc:82-104.  Keypoints: x at kp[i*stride], y at kp[i*stride+1]; undistorted x at kpun[i*un_stride].
+__global__ __launch_bounds__(256) void k_gather_depth(const float* __restrict__ map, size_t map_stride, int w,
+                                                      const float* __restrict__ kp, int kp_stride, size_t kp_frame,
+                                                      const float* __restrict__ kpun, int un_stride, size_t un_frame,
+                                                      const int32_t* __restrict__ n_per_frame, int n_fixed, float mbf,
+                                                      float* __restrict__ depth, float* __restrict__ uright, size_t out_frame) {
+  const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+  const int n = n_per_frame ? n_per_frame[f] : n_fixed;
+  if (i >= n) return;
+  const float u = kp[f * kp_frame + (size_t)i * kp_stride], v = kp[f * kp_frame + (size_t)i * kp_stride + 1];
+  const float d = map[(size_t)f * map_stride + (size_t)(int)v * w + (int)u];
+  float od = -1.f, our = -1.f;
+  if (d > 0) {
+    od = d;
+    our = kpun[f * un_frame + (size_t)i * un_stride] - __fdiv_rn(mbf, d);
+  }
+  depth[f * out_frame + i] = od;
+  uright[f * out_frame + i] = our;
+}
+
+// DepthModule.cc:145-198.  The reference runs cv::distanceTransform(DIST_L2, 5x5) over the whole map and then
+// looks at one value per keypoint; the 5x5 chamfer metric has a closed form per displacement, so the distance
+// at a keypoint is the minimum of that form over the hits inside a small window (16.16 fixed point, exact).
+__global__ __launch_bounds__(256) void k_nn_depth(const float* __restrict__ raw, size_t map_stride, int w, int h,
+                                                  const float* __restrict__ kp, int kp_stride, size_t kp_frame,
+                                                  const float* __restrict__ kpun, int un_stride, size_t un_frame,
+                                                  const int32_t* __restrict__ n_per_frame, int n_fixed, float mbf,
+                                                  float radius, float* __restrict__ depth, float* __restrict__ uright,
+                                                  size_t out_frame) {
+  const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+  const int n = n_per_frame ? n_per_frame[f] : n_fixed;
+  if (i >= n) return;
+  const float u = kp[f * kp_frame + (size_t)i * kp_stride], v = kp[f * kp_frame + (size_t)i * kp_stride + 1];
+  const float* R = raw + (size_t)f * map_stride;
+  const int px = (int)u, py = (int)v;
+  const unsigned HV = 65536u, DG = 91750u, LG = 143976u;  // cvRound({1, 1.4, 2.1969} * 2^16)
+  const int win = (int)radius + 2;
+  unsigned best = 0x1fffffffu;  // INT_MAX >> 2, the transform's "infinity"
+  for (int dy = -win; dy <= win; ++dy) {
+    const int yy = py + dy;
+    if (yy < 0 || yy >= h) continue;
+    for (int dx = -win; dx <= win; ++dx) {
+      const int xx = px + dx;
+      if (xx < 0 || xx >= w) continue;
+      if (__float2int_rn(R[(size_t)yy * w + xx]) <= 0) continue;  // convertTo(CV_8U) + THRESH_BINARY_INV
+      int a = dx < 0 ? -dx : dx, b = dy < 0 ? -dy : dy;
+      if (a < b) { const int t = a; a = b; b = t; }
+      const unsigned cost = (2 * b <= a) ? (unsigned)b * LG + (unsigned)(a - 2 * b) * HV
+                                         : (unsigned)(a - b) * LG + (unsigned)(2 * b - a) * DG;
+      best = cost < best ? cost : best;
+    }
+  }
+  int sr = (int)((float)best * (1.f / 65536));
+  float d = 0.f;
+  if (sr >= 0 && (float)sr < radius) {
+    ++sr;
+    const int pad = (int)radius;
+    const int bx = (int)(u + radius - (float)sr) - pad, by = (int)(v + radius - (float)sr) - pad;  // un-padded coordinates
+    float mx = -FLT_MAX;
+    for (int yy = by; yy < by + 2 * sr; ++yy)
+      for (int xx = bx; xx < bx + 2 * sr; ++xx) {
+        const float val = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? R[(size_t)yy * w + xx] : 0.f;
+        mx = fmaxf(mx, val);
+      }
+    d = mx;
+  }
+  float od = -1.f, our = -1.f;
+  if (d > 0) {
+    od = d;
+    our = kpun[f * un_frame + (size_t)i * un_stride] - __fdiv_rn(mbf, d);
+  }
+  depth[f * out_frame + i] = od;
+  uright[f * out_frame + i] = our;
+}
+
+}  // namespace rgbl
+
+using namespace rgbl;
+
+struct rgbl_depth {
+  rgbl_depth_cfg cfg;
+  int device = 0;
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  KernelTimer timer;
+  ProjParams proj;
+  DilateMask mask;
+  size_t map_stride = 0;
+  uint32_t* d_idx = nullptr;  // idx | raw contiguous so one memset clears both
+  float* d_raw = nullptr;
+  float* d_proc = nullptr;
+  float* d_cloud = nullptr;
+  float *d_kp = nullptr, *d_kpun = nullptr, *d_depth = nullptr, *d_uright = nullptr;
+  std::vector<void*> allocs;
+};
+
+namespace {
+template <class T>
+int dalloc(rgbl_depth* e, T** p, size_t count) {
+  RGBL_HIP(hipMalloc(p, std::max<size_t>(count, 1) * sizeof(T)));
+  e->allocs.push_back((void*)*p);
+  return RGBL_OK;
+}
+
+// kp / kpun given as strided float views
+int enqueue_depth(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w, int h,
+                  const float* kp, int kp_stride, size_t kp_frame, const float* kpun, int un_stride, size_t un_frame,
+                  const int32_t* d_n, int n_fixed, int kmax, float* d_depth, float* d_uright, size_t out_frame,
+                  float* d_processed_out) {
+  hipStream_t s = e->stream;
+  const size_t ms = e->map_stride;
+  RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)batch * ms * 2 * sizeof(uint32_t), s));  // idx maps + raw maps
+  if (n > 0) {
+    e->timer.begin("k_project_index", s);
+    hipLaunchKernelGGL(k_project_index, dim3((n + 255) / 256, batch), dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld,
+                       w, h, e->d_idx, ms);
+    e->timer.end(s);
+    e->timer.begin("k_project_write", s);
+    hipLaunchKernelGGL(k_project_write, dim3((n + 255) / 256, batch), dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld,
+                       w, h, e->d_idx, e->d_raw, ms);
+    e->timer.end(s);
+  }
+  float* proc = e->d_proc;
+  const dim3 tiles((w + 63) / 64, (h + 15) / 16, batch);
+  const dim3 kgrid((std::max(kmax, 1) + 255) / 256, batch);
+  switch (e->cfg.method) {
+    case RGBL_UPS_INVERSE_DILATION:
+      e->timer.begin("k_inverse_dilate", s);
+      // opt_max_dist * ParamUpsampling_InverseDilation_ScaleFactor; the scale factor is never parsed (1.0)
+      hipLaunchKernelGGL(k_inverse_dilate, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, proc, ms, w, h);
+      e->timer.end(s);
+      break;
+    case RGBL_UPS_AVERAGE_FILTERING:
+      e->timer.begin("k_average_filter", s);
+      hipLaunchKernelGGL(k_average_filter, tiles, dim3(256), 0, s, e->cfg.avg_kernel_size, e->d_raw, proc, ms, w, h);
+      e->timer.end(s);
+      break;
+    default:
+      break;
+  }
+  if (kmax > 0) {
+    if (e->cfg.method == RGBL_UPS_NEAREST_NEIGHBOR_PIXEL) {
+      e->timer.begin("k_nn_depth", s);
+      hipLaunchKernelGGL(k_nn_depth, kgrid, dim3(256), 0, s, e->d_raw, ms, w, h, kp, kp_stride, kp_frame, kpun, un_stride,
+                         un_frame, d_n, n_fixed, e->cfg.mbf, e->cfg.nn_search_radius, d_depth, d_uright, out_frame);
+      e->timer.end(s);
+    } else {
+      e->timer.begin("k_gather_depth", s);
+      hipLaunchKernelGGL(k_gather_depth, kgrid, dim3(256), 0, s, proc, ms, w, kp, kp_stride, kp_frame, kpun, un_stride,
+                         un_frame, d_n, n_fixed, e->cfg.mbf, d_depth, d_uright, out_frame);
+      e->timer.end(s);
+    }
+  }
+  if (d_processed_out && e->cfg.method != RGBL_UPS_NEAREST_NEIGHBOR_PIXEL)
+    RGBL_HIP(hipMemcpyAsync(d_processed_out, proc, (size_t)batch * ms * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RGBL_HIP(hipGetLastError());
+  return RGBL_OK;
+}
+}  // namespace
+
+extern "C" {
+
+void rgbl_projection_matrix(const float K[12], const float Tr[16], float out[12]) {
+  // cv::Mat product CameraMatrix(3x4) * RotationMatrix(4x4), DepthModule.cc:434: double accumulation per entry
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc += (double)K[4 * r + k] * (double)Tr[4 * k + c];
+      out[4 * r + c] = (float)acc;
+    }
+}
+
+int rgbl_structuring_element(int shape, int kw, int kh, uint8_t* out) {
+  if (!out || kw < 1 || kh < 1 || kw > 9 || kh > 9) { set_error("structuring element must be 1..9 wide/high"); return RGBL_ERR_INVALID; }
+  if (shape == 3) {
+    // DiamondKernelData_{3,5,7,9} (DepthModule.h:138-161): |dx| + |dy| <= r; only KernelSize_u is honoured
+    if (kw != 3 && kw != 5 && kw != 7 && kw != 9) { set_error("invalid kernel size for diamond kernel"); return RGBL_ERR_INVALID; }
+    const int r = kw / 2;
+    for (int y = 0; y < kw; ++y)
+      for (int x = 0; x < kw; ++x) out[y * kw + x] = (abs(x - r) + abs(y - r) <= r) ? 1 : 0;
+    return RGBL_OK;
+  }
+  if (shape < 0 || shape > 2) { set_error("invalid kernel type"); return RGBL_ERR_INVALID; }
+  // cv::getStructuringElement(shape, Size(kw, kh)), anchor at the centre
+  const int ax = kw / 2, ay = kh / 2, r = kh / 2, c = kw / 2;
+  const double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+  for (int i = 0; i < kh; ++i) {
+    int j1 = 0, j2 = 0;
+    if (shape == 0 || (shape == 1 && i == ay)) j2 = kw;
+    else if (shape == 1) { j1 = ax; j2 = j1 + 1; }
+    else {
+      const int dy = i - r;
+      if (abs(dy) <= r) {
+        const int dx = (int)lrint(c * sqrt((r * r - dy * dy) * inv_r2));
+        j1 = std::max(c - dx, 0);
+        j2 = std::min(c + dx + 1, kw);
+      }
+    }
+    for (int j = 0; j < kw; ++j) out[i * kw + j] = (j >= j1 && j < j2) ? 1 : 0;
+  }
+  return RGBL_OK;
+}
+
+int rgbl_depth_create(const rgbl_depth_cfg* cfg, int device, rgbl_depth** out) {
+  if (!cfg || !out) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  *out = nullptr;
+  if (cfg->method == RGBL_UPS_IPBASIC || cfg->method == RGBL_UPS_NONE ||
+      (cfg->method != RGBL_UPS_NEAREST_NEIGHBOR_PIXEL && cfg->method != RGBL_UPS_AVERAGE_FILTERING &&
+       cfg->method != RGBL_UPS_INVERSE_DILATION)) {
+    // DepthModule.cc:562-583: IPBasic / unknown methods make the parse fail and the module a no-op
+    set_error("up-sampling method %d is not implemented (the reference disables the module for it too)", cfg->method);
+    return RGBL_ERR_INVALID;
+  }
+  if (cfg->width < 1 || cfg->height < 1 || cfg->max_points < 1 || cfg->max_keypoints < 1 || cfg->max_batch < 1 ||
+      cfg->kernel_w < 1 || cfg->kernel_w > 9 || cfg->kernel_h < 1 || cfg->kernel_h > 9 ||
+      (cfg->method == RGBL_UPS_AVERAGE_FILTERING && (cfg->avg_kernel_size < 1 || cfg->avg_kernel_size > 9)) ||
+      (cfg->method == RGBL_UPS_NEAREST_NEIGHBOR_PIXEL && !(cfg->nn_search_radius >= 1 && cfg->nn_search_radius <= 64))) {
+    set_error("invalid depth configuration");
+    return RGBL_ERR_INVALID;
+  }
+  if (rgbl_device_count() <= device || device < 0) {
+    set_error("no usable HIP device %d (this library has no CPU fallback)", device);
+    return RGBL_ERR_NO_DEVICE;
+  }
+  RGBL_HIP(hipSetDevice(device));
+  rgbl_depth* e = new rgbl_depth;
+  e->cfg = *cfg;
+  e->device = device;
+  memcpy(e->proj.m, cfg->proj, sizeof(float) * 12);
+  e->proj.min_dist = cfg->min_dist;
+  e->proj.max_dist = cfg->max_dist;
+  e->mask.kw = cfg->kernel_w;
+  e->mask.kh = cfg->kernel_h;
+  memcpy(e->mask.m, cfg->kernel, 81);
+  e->map_stride = (size_t)cfg->width * cfg->height;
+  const size_t B = (size_t)cfg->max_batch;
+  int rc = dalloc(e, &e->d_idx, B * e->map_stride * 2);
+  e->d_raw = rc == RGBL_OK ? reinterpret_cast<float*>(e->d_idx + B * e->map_stride) : nullptr;
+  if (rc == RGBL_OK) rc = dalloc(e, &e->d_proc, B * e->map_stride);
+  if (rc == RGBL_OK) rc = dalloc(e, &e->d_cloud, (size_t)4 * cfg->max_points);
+  if (rc == RGBL_OK) rc = dalloc(e, &e->d_kp, (size_t)2 * cfg->max_keypoints);
+  if (rc == RGBL_OK) rc = dalloc(e, &e->d_kpun, (size_t)cfg->max_keypoints);
+  if (rc == RGBL_OK) rc = dalloc(e, &e->d_depth, (size_t)cfg->max_keypoints);
+  if (rc == RGBL_OK) rc = dalloc(e, &e->d_uright, (size_t)cfg->max_keypoints);
+  if (rc == RGBL_OK && hipStreamCreate(&e->own_stream) != hipSuccess) { set_error("hipStreamCreate failed"); rc = RGBL_ERR_HIP; }
+  if (rc != RGBL_OK) { rgbl_depth_destroy(e); return rc; }
+  e->stream = e->own_stream;
+  *out = e;
+  return RGBL_OK;
+}
+
+void rgbl_depth_destroy(rgbl_depth* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  e->timer.collect();
+  for (void* p : e->allocs) hipFree(p);
+  if (e->own_stream) hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+int rgbl_depth_compute(rgbl_depth* e, const float* cloud, int n, int ld, int w, int h, const float* kp_xy,
+                       const float* kpun_x, int k, float* out_depth, float* out_uright, float* out_raw,
+                       float* out_processed) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  if (w != e->cfg.width || h != e->cfg.height || n < 0 || n > e->cfg.max_points || k < 0 || k > e->cfg.max_keypoints ||
+      (n > 0 && (!cloud || ld < n)) || (k > 0 && (!kp_xy || !kpun_x || !out_depth || !out_uright))) {
+    set_error("depth arguments do not match the handle (%dx%d, %d points, %d keypoints)", e->cfg.width, e->cfg.height,
+              e->cfg.max_points, e->cfg.max_keypoints);
+    return RGBL_ERR_INVALID;
+  }
+  RGBL_HIP(hipSetDevice(e->device));
+  hipStream_t s = e->stream;
+  if (n > 0)
+    RGBL_HIP(hipMemcpy2DAsync(e->d_cloud, sizeof(float) * n, cloud, sizeof(float) * ld, sizeof(float) * n, 4,
+                              hipMemcpyHostToDevice, s));
+  if (k > 0) {
+    RGBL_HIP(hipMemcpyAsync(e->d_kp, kp_xy, sizeof(float) * 2 * k, hipMemcpyHostToDevice, s));
+    RGBL_HIP(hipMemcpyAsync(e->d_kpun, kpun_x, sizeof(float) * k, hipMemcpyHostToDevice, s));
+  }
+  RGBL_TRY(enqueue_depth(e, e->d_cloud, 1, n, n, 0, w, h, e->d_kp, 2, 0, e->d_kpun, 1, 0, nullptr, k, k, e->d_depth,
+                         e->d_uright, 0, nullptr));
+  if (k > 0) {
+    RGBL_HIP(hipMemcpyAsync(out_depth, e->d_depth, sizeof(float) * k, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipMemcpyAsync(out_uright, e->d_uright, sizeof(float) * k, hipMemcpyDeviceToHost, s));
+  }
+  if (out_raw) RGBL_HIP(hipMemcpyAsync(out_raw, e->d_raw, sizeof(float) * e->map_stride, hipMemcpyDeviceToHost, s));
+  if (out_processed && e->cfg.method != RGBL_UPS_NEAREST_NEIGHBOR_PIXEL)
+    RGBL_HIP(hipMemcpyAsync(out_processed, e->d_proc, sizeof(float) * e->map_stride, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipStreamSynchronize(s));
+  e->timer.collect();
+  return RGBL_OK;
+}
+
+int rgbl_depth_batch_device(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w, int h,
+                            const rgbl_keypoint* d_kp, const int32_t* d_n, int kp_cap, const float* d_kpun_x, float* d_depth,
+                            float* d_uright, float* d_processed) {
+  if (!e || !d_cloud || !d_kp || !d_n || !d_depth || !d_uright) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  if (w != e->cfg.width || h != e->cfg.height || batch < 1 || batch > e->cfg.max_batch || n < 0 || ld < n || kp_cap < 1 ||
+      (batch > 1 && cloud_stride < (size_t)3 * ld + n)) {
+    set_error("depth batch arguments do not match the handle");
+    return RGBL_ERR_INVALID;
+  }
+  RGBL_HIP(hipSetDevice(e->device));
+  const float* kp = reinterpret_cast<const float*>(d_kp);
+  const int kstride = (int)(sizeof(rgbl_keypoint) / sizeof(float));
+  const float* kpun = d_kpun_x ? d_kpun_x : kp;
+  return enqueue_depth(e, d_cloud, batch, n, ld, cloud_stride, w, h, kp, kstride, (size_t)kp_cap * kstride, kpun,
+                       d_kpun_x ? 1 : kstride, d_kpun_x ? (size_t)kp_cap : (size_t)kp_cap * kstride, d_n, 0, kp_cap, d_depth,
+                       d_uright, (size_t)kp_cap, d_processed);
+}
+
+int rgbl_depth_sync(rgbl_depth* e) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(e->device));
+  RGBL_HIP(hipStreamSynchronize(e->stream));
+  e->timer.collect();
+  return RGBL_OK;
+}
+int rgbl_depth_set_stream(rgbl_depth* e, void* hip_stream) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipStreamSynchronize(e->stream));
+  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  return RGBL_OK;
+}
+int rgbl_depth_profile(rgbl_depth* e, int enable) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipStreamSynchronize(e->stream));
+  e->timer.reset();
+  e->timer.enabled = enable != 0;
+  return RGBL_OK;
+}
+int rgbl_depth_profile_read(rgbl_depth* e, const char** names, double* total_ms, long* launches, int cap) {
+  if (!e) return 0;
+  hipStreamSynchronize(e->stream);
+  e->timer.collect();
+  const int n = (int)e->timer.names.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    if (names) names[i] = e->timer.names[i].c_str();
+    if (total_ms) total_ms[i] = e->timer.total_ms[i];
+    if (launches) launches[i] = e->timer.count[i];
+  }
+  return n;
+}
+
+}  // extern "C"

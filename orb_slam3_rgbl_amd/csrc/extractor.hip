@@ -1,0 +1,619 @@
+// extractor.hip — host side of the ORB extractor: geometry/tables, HBM scratch, launch sequence, C ABI.
+//
+// Replaces ORB_SLAM3::ORBextractor (/root/reference/include/ORBextractor.h:49-83,
+// /root/reference/src/ORBextractor.cc:409-469, 1086-1195).  The device kernels are in extractor_kernels.h.
+//
+// HBM layout (all buffers are per handle, sized for max_batch frames; frame f at base + f*frame_stride):
+//   pyr    : levels 1..L-1 of the 8-bit pyramid, each level padded to a 64-byte pitch (level 0 is read
+//            straight from the caller's image, it is never copied)
+//   blur   : levels 0..L-1 of the Gaussian working images, same pitches
+//   cells  : one candidate counter per FAST detection cell + cell_cap packed candidates per cell
+//   keys   : two ping-pong arrays of packed keys per level for the quad-tree partitions
+//   nodes  : quad-tree node lists (ping-pong), split counts, expandable lists, sort scratch
+//   kp     : selected keys per level (kcap each) and the per-(frame,level) counts
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "brief_pattern.h"
+#include "extractor_kernels.h"
+
+namespace rgbl {
+
+// ---- thread-local error message ------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+static inline int round_even_f(float v) { return (int)lrintf(v); }
+static inline int round_even_d(double v) { return (int)lrint(v); }
+static inline int floor_f(float v) { int i = (int)v; return i - (v < (float)i); }
+static inline int ceil_f(float v) { int i = (int)v; return i + (v > (float)i); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace rgbl
+
+using namespace rgbl;
+
+struct rgbl_extractor {
+  rgbl_extractor_cfg cfg;
+  int device = 0;
+  int L = 0;
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  KernelTimer timer;
+  std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+  std::vector<int> per_level;
+  UMax umax;
+  std::vector<LevelGeom> geom;
+  BlurTiles blur_tiles;
+  int cells_frame = 0, kp_frame = 0;
+  size_t pyr_frame = 0, slots_frame = 0, keys_frame = 0, nodes_frame = 0, img_frame = 0;
+  int img_pitch = 0;
+  // device memory
+  LevelGeom* d_geom = nullptr;
+  ResizeTab *d_xtab = nullptr, *d_ytab = nullptr;
+  uint8_t* d_rootx = nullptr;
+  int8_t* d_pattern = nullptr;
+  uint8_t *d_img = nullptr, *d_pyr = nullptr, *d_blur = nullptr;
+  uint32_t *d_cellcnt = nullptr, *d_slots = nullptr, *d_keys_a = nullptr, *d_keys_b = nullptr;
+  QNode *d_list_a = nullptr, *d_list_b = nullptr;
+  QDiv* d_div = nullptr;
+  uint32_t *d_todo_a = nullptr, *d_todo_b = nullptr, *d_sval = nullptr;
+  uint64_t* d_skey = nullptr;
+  uint8_t* d_divided = nullptr;
+  uint32_t* d_kpkey = nullptr;
+  int* d_kpcount = nullptr;
+  int* d_err = nullptr;
+  // staging for the host entry points and for the lapping permutation
+  rgbl_keypoint *d_out_kp = nullptr, *d_tmp_kp = nullptr;
+  uint8_t *d_out_desc = nullptr, *d_tmp_desc = nullptr;
+  int32_t *d_out_n = nullptr, *d_out_mono = nullptr;
+  int out_cap = 0;
+  // last call (for get_level / get_candidates)
+  const uint8_t* last_img0 = nullptr;
+  int last_pitch0 = 0;
+  size_t last_frame0 = 0;
+  int last_batch = 0;
+  std::vector<void*> allocs;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(rgbl_extractor* e, T** p, size_t count) {
+  RGBL_HIP(hipMalloc(p, std::max<size_t>(count, 1) * sizeof(T)));
+  e->allocs.push_back((void*)*p);
+  return RGBL_OK;
+}
+
+// cv::resize's coefficient tables for one axis (modules/imgproc/src/resize.cpp, INTER_LINEAR, fixed point)
+void build_resize_tab(int ssize, int dsize, bool clamp_x, std::vector<ResizeTab>& tab) {
+  const double inv_scale = (double)dsize / ssize;
+  const double scale = 1.0 / inv_scale;
+  for (int d = 0; d < dsize; ++d) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = floor_f(f);
+    f -= s;
+    if (clamp_x) {
+      if (s < 0) { f = 0; s = 0; }
+      if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+    }
+    ResizeTab t;
+    t.sofs = s;
+    t.a0 = (int16_t)round_even_f((1.f - f) * 2048);
+    t.a1 = (int16_t)round_even_f(f * 2048);
+    tab.push_back(t);
+  }
+}
+
+int build_geometry(rgbl_extractor* e) {
+  const rgbl_extractor_cfg& c = e->cfg;
+  const int L = c.nlevels;
+  e->L = L;
+  // ---- ORBextractor.cc:414-445 (all fp32)
+  e->scale.assign(L, 1.f); e->sigma2.assign(L, 1.f); e->inv_scale.assign(L, 1.f); e->inv_sigma2.assign(L, 1.f);
+  for (int i = 1; i < L; ++i) {
+    e->scale[i] = e->scale[i - 1] * c.scale_factor;
+    e->sigma2[i] = e->scale[i] * e->scale[i];
+  }
+  for (int i = 0; i < L; ++i) {
+    e->inv_scale[i] = 1.0f / e->scale[i];
+    e->inv_sigma2[i] = 1.0f / e->sigma2[i];
+  }
+  e->per_level.assign(L, 0);
+  const float factor = 1.0f / c.scale_factor;
+  float desired = c.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+  int sum = 0;
+  for (int l = 0; l < L - 1; ++l) {
+    e->per_level[l] = round_even_f(desired);
+    sum += e->per_level[l];
+    desired *= factor;
+  }
+  e->per_level[L - 1] = std::max(c.nfeatures - sum, 0);
+  // ---- umax, ORBextractor.cc:451-468
+  {
+    int* u = e->umax.v;
+    for (int i = 0; i < 16; ++i) u[i] = 0;
+    const int vmax = floor_f(15 * sqrtf(2.f) / 2 + 1), vmin = ceil_f(15 * sqrtf(2.f) / 2);
+    for (int v = 0; v <= vmax; ++v) u[v] = round_even_d(sqrt(225.0 - v * v));
+    for (int v = 15, v0 = 0; v >= vmin; --v) {
+      while (u[v0] == u[v0 + 1]) ++v0;
+      u[v] = v0;
+      ++v0;
+    }
+  }
+  // ---- per-level geometry
+  e->geom.assign(L, LevelGeom());
+  size_t img_off = 0, slot_off = 0, node_off = 0, rootx_off = 0, xtab_off = 0, ytab_off = 0;
+  int cell_off = 0, koff = 0;
+  e->img_pitch = (int)align_up(c.width, 64);
+  e->img_frame = (size_t)e->img_pitch * c.height;
+  int tile_off = 0;
+  for (int l = 0; l < L; ++l) {
+    LevelGeom& g = e->geom[l];
+    memset(&g, 0, sizeof(g));
+    g.w = round_even_f((float)c.width * e->inv_scale[l]);   // ORBextractor.cc:1174-1175
+    g.h = round_even_f((float)c.height * e->inv_scale[l]);
+    g.pitch = (int)align_up(g.w, 64);
+    g.img_off = (uint32_t)img_off;
+    img_off += (size_t)g.pitch * g.h;
+    g.quota = e->per_level[l];
+    g.scale = e->scale[l];
+    g.patch_size = (int)(31 * e->scale[l]);
+    // detection grid, ORBextractor.cc:789-803
+    g.max_bx = g.w - 19 + 3;
+    g.max_by = g.h - 19 + 3;
+    const float width = (float)(g.max_bx - kMinBorder), height = (float)(g.max_by - kMinBorder);
+    g.n_cols = (int)(width / 35.f);
+    g.n_rows = (int)(height / 35.f);
+    if (g.n_cols < 1 || g.n_rows < 1) {
+      set_error("level %d (%dx%d) is smaller than one 35-px detection cell; the reference divides by zero here", l, g.w, g.h);
+      return RGBL_ERR_INVALID;
+    }
+    g.w_cell = (int)ceilf(width / g.n_cols);
+    g.h_cell = (int)ceilf(height / g.n_rows);
+    if (g.w_cell > kCellMax || g.h_cell > kCellMax) {
+      set_error("cell %dx%d exceeds the kernel tile", g.w_cell, g.h_cell);
+      return RGBL_ERR_INVALID;
+    }
+    g.n_cells = g.n_cols * g.n_rows;
+    g.cell_off = cell_off;
+    cell_off += g.n_cells;
+    g.cell_cap = ((g.w_cell + 1) / 2) * ((g.h_cell + 1) / 2);  // strict 3x3 NMS keeps at most one pixel per 2x2
+    g.slot_off = (uint32_t)slot_off;
+    g.key_off = (uint32_t)slot_off;
+    g.key_cap = (uint32_t)((size_t)g.n_cells * g.cell_cap);
+    slot_off += (size_t)g.n_cells * g.cell_cap;
+    // quad-tree roots, ORBextractor.cc:558-577
+    g.n_ini = (int)roundf((float)(g.max_bx - kMinBorder) / (float)(g.max_by - kMinBorder));
+    if (g.n_ini < 1 || g.n_ini > kMaxRoots) {
+      set_error("aspect ratio gives %d quad-tree roots (supported 1..%d; the reference fails for portrait images)", g.n_ini, kMaxRoots);
+      return RGBL_ERR_INVALID;
+    }
+    const float hX = (float)(g.max_bx - kMinBorder) / g.n_ini;
+    for (int i = 0; i <= g.n_ini; ++i) g.root_x[i] = (int)(hX * (float)i);
+    g.rootx_off = (uint32_t)rootx_off;
+    rootx_off += align_up((size_t)(g.max_bx - kMinBorder) + 1, 16);
+    g.kcap = std::max(g.quota, 4 * g.n_ini) + 8;
+    g.koff = koff;
+    koff += g.kcap;
+    g.node_cap = (uint32_t)g.kcap + 16;
+    g.node_off = (uint32_t)node_off;
+    node_off += g.node_cap;
+    g.xtab_off = (uint32_t)xtab_off;
+    g.ytab_off = (uint32_t)ytab_off;
+    if (l > 0) { xtab_off += g.w; ytab_off += g.h; }
+    e->blur_tiles.tile_off[l] = tile_off;
+    e->blur_tiles.tiles_x[l] = (g.w + 63) / 64;
+    tile_off += e->blur_tiles.tiles_x[l] * ((g.h + 15) / 16);
+  }
+  e->blur_tiles.tile_off[L] = tile_off;
+  e->pyr_frame = align_up(img_off, 256);
+  e->cells_frame = cell_off;
+  e->slots_frame = slot_off;
+  e->keys_frame = slot_off;
+  e->nodes_frame = node_off;
+  e->kp_frame = koff;
+  return RGBL_OK;
+}
+
+int upload_tables(rgbl_extractor* e) {
+  const int L = e->L;
+  std::vector<ResizeTab> xt, yt;
+  std::vector<uint8_t> rootx;
+  for (int l = 0; l < L; ++l) {
+    const LevelGeom& g = e->geom[l];
+    if (l > 0) {
+      build_resize_tab(e->geom[l - 1].w, g.w, true, xt);
+      build_resize_tab(e->geom[l - 1].h, g.h, false, yt);
+    }
+    // root node of every x (ORBextractor.cc:585: vpIniNodes[kp.pt.x / hX], float division, truncation)
+    const int width = g.max_bx - kMinBorder;
+    const float hX = (float)width / g.n_ini;
+    rootx.resize(g.rootx_off + align_up((size_t)width + 1, 16), 0);
+    for (int x = 0; x <= width; ++x) {
+      int r = (int)((float)x / hX);
+      rootx[g.rootx_off + x] = (uint8_t)std::min(r, g.n_ini - 1);
+    }
+  }
+  RGBL_TRY(dev_alloc(e, &e->d_geom, L));
+  RGBL_TRY(dev_alloc(e, &e->d_xtab, xt.size()));
+  RGBL_TRY(dev_alloc(e, &e->d_ytab, yt.size()));
+  RGBL_TRY(dev_alloc(e, &e->d_rootx, rootx.size()));
+  RGBL_TRY(dev_alloc(e, &e->d_pattern, 1024));
+  RGBL_HIP(hipMemcpy(e->d_geom, e->geom.data(), sizeof(LevelGeom) * L, hipMemcpyHostToDevice));
+  if (!xt.empty()) RGBL_HIP(hipMemcpy(e->d_xtab, xt.data(), sizeof(ResizeTab) * xt.size(), hipMemcpyHostToDevice));
+  if (!yt.empty()) RGBL_HIP(hipMemcpy(e->d_ytab, yt.data(), sizeof(ResizeTab) * yt.size(), hipMemcpyHostToDevice));
+  RGBL_HIP(hipMemcpy(e->d_rootx, rootx.data(), rootx.size(), hipMemcpyHostToDevice));
+  RGBL_HIP(hipMemcpy(e->d_pattern, kBriefPattern, 1024, hipMemcpyHostToDevice));
+  return RGBL_OK;
+}
+
+int alloc_scratch(rgbl_extractor* e) {
+  const size_t B = (size_t)e->cfg.max_batch;
+  RGBL_TRY(dev_alloc(e, &e->d_img, B * e->img_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_pyr, B * e->pyr_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_blur, B * e->pyr_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_cellcnt, B * e->cells_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_slots, B * e->slots_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_keys_a, B * e->keys_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_keys_b, B * e->keys_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_list_a, B * e->nodes_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_list_b, B * e->nodes_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_div, B * e->nodes_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_todo_a, B * e->nodes_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_todo_b, B * e->nodes_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_skey, B * e->nodes_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_sval, B * e->nodes_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_divided, B * e->nodes_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_kpkey, B * (size_t)e->kp_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_kpcount, B * (size_t)e->L));
+  RGBL_TRY(dev_alloc(e, &e->d_err, 1));
+  RGBL_HIP(hipMemset(e->d_err, 0, sizeof(int)));
+  e->out_cap = e->kp_frame;
+  RGBL_TRY(dev_alloc(e, &e->d_out_kp, B * (size_t)e->out_cap));
+  RGBL_TRY(dev_alloc(e, &e->d_tmp_kp, B * (size_t)e->out_cap));
+  RGBL_TRY(dev_alloc(e, &e->d_out_desc, B * (size_t)e->out_cap * 32));
+  RGBL_TRY(dev_alloc(e, &e->d_tmp_desc, B * (size_t)e->out_cap * 32));
+  RGBL_TRY(dev_alloc(e, &e->d_out_n, B));
+  RGBL_TRY(dev_alloc(e, &e->d_out_mono, B));
+  return RGBL_OK;
+}
+
+// Enqueues the whole extraction of `batch` frames on e->stream. All pointers are device pointers.
+int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int stride, size_t frame_stride,
+                    int lap0, int lap1, rgbl_keypoint* d_kp, uint8_t* d_desc, int cap, int32_t* d_n,
+                    int32_t* d_mono) {
+  const int L = e->L;
+  hipStream_t s = e->stream;
+  e->last_img0 = d_imgs; e->last_pitch0 = stride; e->last_frame0 = frame_stride; e->last_batch = batch;
+
+  // 1. pyramid: level l from level l-1 (ORBextractor.cc:1170-1195)
+  for (int l = 1; l < L; ++l) {
+    const LevelGeom& g = e->geom[l];
+    const LevelGeom& p = e->geom[l - 1];
+    const uint8_t* src = (l == 1) ? d_imgs : e->d_pyr + p.img_off;
+    const int spitch = (l == 1) ? stride : p.pitch;
+    const size_t sframe = (l == 1) ? frame_stride : e->pyr_frame;
+    e->timer.begin("k_resize_linear", s);
+    hipLaunchKernelGGL(k_resize_linear, dim3((g.w + 255) / 256, (g.h + 3) / 4, batch), dim3(256), 0, s, src, spitch,
+                       sframe, p.w, p.h, e->d_pyr + g.img_off, g.pitch, e->pyr_frame, g.w, g.h,
+                       e->d_xtab + g.xtab_off, e->d_ytab + g.ytab_off);
+    e->timer.end(s);
+  }
+  // 2. FAST per detection cell (ORBextractor.cc:806-872)
+  e->timer.begin("k_fast_cells", s);
+  hipLaunchKernelGGL(k_fast_cells, dim3(e->cells_frame, batch), dim3(256), 0, s, e->d_geom, L, d_imgs, stride,
+                     frame_stride, e->d_pyr, e->pyr_frame, e->cfg.ini_th_fast, e->cfg.min_th_fast, e->d_cellcnt,
+                     (size_t)e->cells_frame, e->d_slots, e->slots_frame);
+  e->timer.end(s);
+  // 3. quad-tree distribution (ORBextractor.cc:555-779)
+  OctreeBufs ob;
+  ob.cell_cnt = e->d_cellcnt; ob.cells_frame = (size_t)e->cells_frame;
+  ob.slots = e->d_slots; ob.slots_frame = e->slots_frame;
+  ob.keys_a = e->d_keys_a; ob.keys_b = e->d_keys_b; ob.keys_frame = e->keys_frame;
+  ob.list_a = e->d_list_a; ob.list_b = e->d_list_b; ob.div = e->d_div;
+  ob.todo_a = e->d_todo_a; ob.todo_b = e->d_todo_b; ob.skey = e->d_skey; ob.sval = e->d_sval;
+  ob.divided = e->d_divided; ob.nodes_frame = e->nodes_frame;
+  ob.rootx = e->d_rootx;
+  ob.kp_key = e->d_kpkey; ob.kp_count = e->d_kpcount; ob.kp_frame = (size_t)e->kp_frame;
+  ob.err = e->d_err;
+  e->timer.begin("k_octree", s);
+  hipLaunchKernelGGL(k_octree, dim3(L, batch), dim3(256), 0, s, e->d_geom, L, ob);
+  e->timer.end(s);
+  // 4. Gaussian working images (ORBextractor.cc:1132-1133)
+  e->timer.begin("k_gauss7", s);
+  hipLaunchKernelGGL(k_gauss7, dim3(e->blur_tiles.tile_off[L], batch), dim3(256), 0, s, e->d_geom, L, e->blur_tiles,
+                     d_imgs, stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame);
+  e->timer.end(s);
+  // 5. orientation + descriptors + packing (ORBextractor.cc:894-895, 1136-1165)
+  const bool lapping = lap1 >= 19 && lap1 >= lap0;  // keypoint x is always >= 19: nothing can fall into [lap0, lap1] otherwise
+  rgbl_keypoint* kp_dst = lapping ? e->d_tmp_kp : d_kp;
+  uint8_t* desc_dst = lapping ? e->d_tmp_desc : d_desc;
+  int lap_cap = cap;
+  if (lapping) lap_cap = std::min(cap, e->out_cap);
+  e->timer.begin("k_orient_brief", s);
+  hipLaunchKernelGGL(k_orient_brief, dim3((e->kp_frame + 3) / 4, batch), dim3(256), 0, s, e->d_geom, L, e->umax,
+                     e->d_pattern, d_imgs, stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame,
+                     e->d_kpkey, e->d_kpcount, (size_t)e->kp_frame, kp_dst, desc_dst, lapping ? e->out_cap : cap, d_n,
+                     lapping ? (int32_t*)nullptr : d_mono, e->d_err);
+  e->timer.end(s);
+  if (lapping) {
+    (void)lap_cap;
+    if (cap < e->out_cap) {
+      set_error("vLappingArea packing needs cap >= %d", e->out_cap);
+      return RGBL_ERR_CAPACITY;
+    }
+    e->timer.begin("k_lapping_permute", s);
+    // the temporary arrays use out_cap as their frame stride, the destination uses cap
+    hipLaunchKernelGGL(k_lapping_permute, dim3(batch), dim3(256), 0, s, e->d_tmp_kp, e->d_tmp_desc, e->out_cap, d_kp,
+                       d_desc, cap, d_n, (float)lap0, (float)lap1, d_mono);
+    e->timer.end(s);
+  }
+  RGBL_HIP(hipGetLastError());
+  return RGBL_OK;
+}
+
+int check_device_flags(rgbl_extractor* e) {
+  int flags = 0;
+  RGBL_HIP(hipMemcpy(&flags, e->d_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (flags) {
+    RGBL_HIP(hipMemset(e->d_err, 0, sizeof(int)));
+    if (flags & 3) { set_error("quad-tree scratch overflow (flags=%d)", flags); return RGBL_ERR_OVERFLOW; }
+    set_error("more keypoints than the caller's capacity");
+    return RGBL_ERR_CAPACITY;
+  }
+  return RGBL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rgbl_last_error(void) { return rgbl::last_error(); }
+const char* rgbl_backend(void) {
+#ifdef RGBL_EMU
+  return "emu";
+#else
+  return "hip:gfx950";
+#endif
+}
+int rgbl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extractor** out) {
+  if (!cfg || !out) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  *out = nullptr;
+  if (cfg->nlevels < 1 || cfg->nlevels > kMaxLevels || cfg->nfeatures < 1 || cfg->scale_factor < 1.0f ||
+      cfg->width < 64 || cfg->height < 64 || cfg->width > 4096 || cfg->height > 4096 || cfg->max_batch < 1 ||
+      cfg->min_th_fast < 1 || cfg->ini_th_fast < cfg->min_th_fast || cfg->ini_th_fast > 255) {
+    set_error("invalid extractor configuration");
+    return RGBL_ERR_INVALID;
+  }
+  if (rgbl_device_count() <= device || device < 0) {
+    set_error("no usable HIP device %d (this library has no CPU fallback)", device);
+    return RGBL_ERR_NO_DEVICE;
+  }
+  RGBL_HIP(hipSetDevice(device));
+  rgbl_extractor* e = new rgbl_extractor;
+  e->cfg = *cfg;
+  e->device = device;
+  int rc = build_geometry(e);
+  if (rc == RGBL_OK) rc = upload_tables(e);
+  if (rc == RGBL_OK) rc = alloc_scratch(e);
+  if (rc == RGBL_OK && hipStreamCreate(&e->own_stream) != hipSuccess) { set_error("hipStreamCreate failed"); rc = RGBL_ERR_HIP; }
+  if (rc != RGBL_OK) { rgbl_extractor_destroy(e); return rc; }
+  e->stream = e->own_stream;
+  *out = e;
+  return RGBL_OK;
+}
+
+void rgbl_extractor_destroy(rgbl_extractor* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  e->timer.collect();
+  for (void* p : e->allocs) hipFree(p);
+  if (e->own_stream) hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+int rgbl_extractor_tables(const rgbl_extractor* e, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                          int* per_level, int* umax16) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  for (int i = 0; i < e->L; ++i) {
+    if (scale) scale[i] = e->scale[i];
+    if (inv_scale) inv_scale[i] = e->inv_scale[i];
+    if (sigma2) sigma2[i] = e->sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = e->inv_sigma2[i];
+    if (per_level) per_level[i] = e->per_level[i];
+  }
+  if (umax16) memcpy(umax16, e->umax.v, sizeof(int) * 16);
+  return RGBL_OK;
+}
+
+int rgbl_extractor_max_keypoints(const rgbl_extractor* e) { return e ? e->kp_frame : 0; }
+
+int rgbl_extract_batch_device(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int w, int h, int stride,
+                              size_t frame_stride, int lap0, int lap1, rgbl_keypoint* d_kp, uint8_t* d_desc, int cap,
+                              int32_t* d_n, int32_t* d_mono) {
+  if (!e || !d_imgs || !d_kp || !d_desc || !d_n || !d_mono) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  if (w != e->cfg.width || h != e->cfg.height || batch < 1 || batch > e->cfg.max_batch || stride < w || cap < 1 ||
+      (batch > 1 && frame_stride < (size_t)stride * h)) {
+    set_error("image %dx%d / batch %d does not match the handle (%dx%d, max batch %d)", w, h, batch, e->cfg.width,
+              e->cfg.height, e->cfg.max_batch);
+    return RGBL_ERR_INVALID;
+  }
+  RGBL_HIP(hipSetDevice(e->device));
+  return enqueue_extract(e, d_imgs, batch, stride, frame_stride, lap0, lap1, d_kp, d_desc, cap, d_n, d_mono);
+}
+
+int rgbl_extractor_sync(rgbl_extractor* e) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(e->device));
+  RGBL_HIP(hipStreamSynchronize(e->stream));
+  e->timer.collect();
+  return check_device_flags(e);
+}
+
+int rgbl_extract_batch(rgbl_extractor* e, const uint8_t* imgs, int batch, int w, int h, int stride, size_t frame_stride,
+                       int lap0, int lap1, rgbl_keypoint* out_kp, uint8_t* out_desc, int cap, int* out_n,
+                       int* out_mono) {
+  if (out_n) for (int b = 0; b < std::max(batch, 0); ++b) out_n[b] = 0;
+  if (out_mono) for (int b = 0; b < std::max(batch, 0); ++b) out_mono[b] = -1;
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  if (!imgs || w <= 0 || h <= 0) { set_error("empty image"); return RGBL_ERR_EMPTY; }  // ORBextractor.cc:1090-1091
+  if (!out_kp || !out_desc || !out_n || !out_mono) { set_error("null output"); return RGBL_ERR_INVALID; }
+  if (w != e->cfg.width || h != e->cfg.height || batch < 1 || batch > e->cfg.max_batch || stride < w || cap < 1) {
+    set_error("image %dx%d / batch %d does not match the handle (%dx%d, max batch %d)", w, h, batch, e->cfg.width,
+              e->cfg.height, e->cfg.max_batch);
+    return RGBL_ERR_INVALID;
+  }
+  RGBL_HIP(hipSetDevice(e->device));
+  hipStream_t s = e->stream;
+  for (int b = 0; b < batch; ++b)
+    RGBL_HIP(hipMemcpy2DAsync(e->d_img + (size_t)b * e->img_frame, e->img_pitch, imgs + (size_t)b * frame_stride, stride,
+                              w, h, hipMemcpyHostToDevice, s));
+  RGBL_TRY(enqueue_extract(e, e->d_img, batch, e->img_pitch, e->img_frame, lap0, lap1, e->d_out_kp, e->d_out_desc,
+                           e->out_cap, e->d_out_n, e->d_out_mono));
+  RGBL_HIP(hipMemcpyAsync(out_n, e->d_out_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipMemcpyAsync(out_mono, e->d_out_mono, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipStreamSynchronize(s));
+  e->timer.collect();
+  RGBL_TRY(check_device_flags(e));
+  int rc = RGBL_OK;
+  for (int b = 0; b < batch; ++b) {
+    const int n = out_n[b];
+    const int ncopy = std::min(n, cap);
+    if (n > cap) { set_error("frame %d has %d keypoints, capacity %d", b, n, cap); rc = RGBL_ERR_CAPACITY; }
+    if (n > cap && lap1 >= 19) continue;  // a truncated lapping layout would be meaningless
+    RGBL_HIP(hipMemcpyAsync(out_kp + (size_t)b * cap, e->d_out_kp + (size_t)b * e->out_cap, sizeof(rgbl_keypoint) * ncopy,
+                            hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipMemcpyAsync(out_desc + (size_t)b * cap * 32, e->d_out_desc + (size_t)b * e->out_cap * 32, (size_t)ncopy * 32,
+                            hipMemcpyDeviceToHost, s));
+  }
+  RGBL_HIP(hipStreamSynchronize(s));
+  return rc;
+}
+
+int rgbl_extract(rgbl_extractor* e, const uint8_t* img, int w, int h, int stride, int lap0, int lap1, rgbl_keypoint* out_kp,
+                 uint8_t* out_desc, int cap, int* out_n, int* out_mono) {
+  return rgbl_extract_batch(e, img, 1, w, h, stride, 0, lap0, lap1, out_kp, out_desc, cap, out_n, out_mono);
+}
+
+int rgbl_extractor_level_size(const rgbl_extractor* e, int level, int* w, int* h) {
+  if (!e || level < 0 || level >= e->L) { set_error("bad level"); return RGBL_ERR_INVALID; }
+  if (w) *w = e->geom[level].w;
+  if (h) *h = e->geom[level].h;
+  return RGBL_OK;
+}
+
+int rgbl_extractor_get_level(rgbl_extractor* e, int frame, int level, int blurred, int with_border, uint8_t* dst,
+                             int dst_stride) {
+  if (!e || !dst || level < 0 || level >= e->L || frame < 0 || frame >= e->last_batch) {
+    set_error("bad level/frame");
+    return RGBL_ERR_INVALID;
+  }
+  RGBL_HIP(hipSetDevice(e->device));
+  const LevelGeom& g = e->geom[level];
+  const uint8_t* src;
+  int pitch;
+  if (blurred) { src = e->d_blur + (size_t)frame * e->pyr_frame + g.img_off; pitch = g.pitch; }
+  else if (level == 0) { src = e->last_img0 + (size_t)frame * e->last_frame0; pitch = e->last_pitch0; }
+  else { src = e->d_pyr + (size_t)frame * e->pyr_frame + g.img_off; pitch = g.pitch; }
+  const int border = (with_border && !blurred) ? 19 : 0;
+  RGBL_HIP(hipStreamSynchronize(e->stream));
+  uint8_t* inner = dst + (size_t)border * dst_stride + border;
+  RGBL_HIP(hipMemcpy2DAsync(inner, dst_stride, src, pitch, g.w, g.h, hipMemcpyDeviceToHost, e->stream));
+  RGBL_HIP(hipStreamSynchronize(e->stream));
+  if (border) {
+    // copyMakeBorder(..., BORDER_REFLECT_101 [+BORDER_ISOLATED]) (ORBextractor.cc:1185-1191); host side, it is
+    // only consumed by Frame::ComputeStereoMatches
+    auto refl = [](int p, int len) { while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p; return p; };
+    for (int y = 0; y < g.h; ++y) {
+      uint8_t* row = inner + (size_t)y * dst_stride;
+      for (int x = 1; x <= border; ++x) { row[-x] = row[refl(-x, g.w)]; row[g.w - 1 + x] = row[refl(g.w - 1 + x, g.w)]; }
+    }
+    for (int y = 1; y <= border; ++y) {
+      memcpy(inner + (ptrdiff_t)(-y) * dst_stride - border, inner + (ptrdiff_t)refl(-y, g.h) * dst_stride - border, g.w + 2 * border);
+      memcpy(inner + (ptrdiff_t)(g.h - 1 + y) * dst_stride - border, inner + (ptrdiff_t)refl(g.h - 1 + y, g.h) * dst_stride - border,
+             g.w + 2 * border);
+    }
+  }
+  return RGBL_OK;
+}
+
+int rgbl_extractor_get_candidates(rgbl_extractor* e, int frame, int level, rgbl_keypoint* out, int cap, int* out_n) {
+  if (!e || level < 0 || level >= e->L || frame < 0 || frame >= e->last_batch || !out_n) {
+    set_error("bad level/frame");
+    return RGBL_ERR_INVALID;
+  }
+  RGBL_HIP(hipSetDevice(e->device));
+  RGBL_HIP(hipStreamSynchronize(e->stream));
+  const LevelGeom& g = e->geom[level];
+  std::vector<uint32_t> cnt(g.n_cells);
+  RGBL_HIP(hipMemcpy(cnt.data(), e->d_cellcnt + (size_t)frame * e->cells_frame + g.cell_off, sizeof(uint32_t) * g.n_cells,
+                     hipMemcpyDeviceToHost));
+  std::vector<uint32_t> slots((size_t)g.n_cells * g.cell_cap);
+  RGBL_HIP(hipMemcpy(slots.data(), e->d_slots + (size_t)frame * e->slots_frame + g.slot_off, sizeof(uint32_t) * slots.size(),
+                     hipMemcpyDeviceToHost));
+  int n = 0;
+  for (int c = 0; c < g.n_cells; ++c)
+    for (uint32_t k = 0; k < cnt[c]; ++k, ++n) {
+      if (out && n < cap) {
+        const uint32_t key = slots[(size_t)c * g.cell_cap + k];
+        rgbl_keypoint kp;
+        kp.x = (float)(key & 0xfff); kp.y = (float)((key >> 12) & 0xfff); kp.size = 7.f; kp.angle = -1.f;
+        kp.response = (float)(key >> 24); kp.octave = 0; kp.class_id = -1;
+        out[n] = kp;
+      }
+    }
+  *out_n = n;
+  return RGBL_OK;
+}
+
+int rgbl_extractor_set_stream(rgbl_extractor* e, void* hip_stream) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipStreamSynchronize(e->stream));
+  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  return RGBL_OK;
+}
+
+int rgbl_extractor_profile(rgbl_extractor* e, int enable) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipStreamSynchronize(e->stream));
+  e->timer.reset();
+  e->timer.enabled = enable != 0;
+  return RGBL_OK;
+}
+
+int rgbl_extractor_profile_read(rgbl_extractor* e, const char** names, double* total_ms, long* launches, int cap) {
+  if (!e) return 0;
+  hipStreamSynchronize(e->stream);
+  e->timer.collect();
+  const int n = (int)e->timer.names.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    if (names) names[i] = e->timer.names[i].c_str();
+    if (total_ms) total_ms[i] = e->timer.total_ms[i];
+    if (launches) launches[i] = e->timer.count[i];
+  }
+  return n;
+}
+
+#ifdef RGBL_EMU
+// test hook (emulation build only): the libstdc++ introsort restatement on plain arrays
+void rgbl_test_std_sort(uint64_t* key, uint32_t* val, int n) { rgbl::std_sort_restated(key, val, n); }
+#endif
+
+}  // extern "C"

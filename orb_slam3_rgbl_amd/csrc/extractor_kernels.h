@@ -1,0 +1,917 @@
+// extractor_kernels.h — HIP kernels of the ORB extraction path (gfx950, wave64).
+//
+// One batched launch per stage covers B independent frames (blockIdx.y / .z = frame):
+//   k_resize_linear   level l from level l-1          replaces cv::resize        (ORBextractor.cc:1183)
+//   k_fast_cells      FAST-9/16 score + per-cell NMS + two-threshold choice + ordered compaction
+//                                                     replaces ~900 cv::FAST calls (ORBextractor.cc:806-872)
+//   k_octree          quad-tree distribution          replaces DistributeOctTree (ORBextractor.cc:555-779)
+//   k_gauss7          7x7 sigma-2 fixed-point blur     replaces cv::GaussianBlur  (ORBextractor.cc:1133)
+//   k_orient_brief    IC_Angle + steered BRIEF + pack  replaces ORBextractor.cc:76-146,1149-1165
+//   k_lapping_permute vLappingArea front/back packing  replaces ORBextractor.cc:1153-1162
+// All arithmetic is integer except the orientation polynomial / steering (fp32, fp64 sincos), compiled
+// with -ffp-contract=off.  Results are bit-exact with the CPU oracle.
+#pragma once
+#include "common.h"
+#include "sincos_glibc.h"
+
+namespace rgbl {
+
+constexpr int kMaxLevels = 16;
+constexpr int kMaxRoots = 16;
+constexpr int kMinBorder = 16;  // EDGE_THRESHOLD - 3
+
+struct ResizeTab {  // one output column / row of cv::resize's fixed-point tables
+  int32_t sofs;     // first source index
+  int16_t a0, a1;   // 11-bit weights (sum 2048)
+};
+
+struct LevelGeom {
+  int w, h, pitch;            // level size; pitch of the pyramid / blur buffers (bytes)
+  uint32_t img_off;           // byte offset of this level inside one frame's pyramid (and blur) buffer
+  int quota;                  // mnFeaturesPerLevel[level]
+  int kcap, koff;             // keypoint slots of this level inside one frame's keypoint arrays
+  int n_cols, n_rows, w_cell, h_cell, max_bx, max_by;
+  int n_cells, cell_off, cell_cap;
+  uint32_t slot_off;          // first candidate slot (entries) inside one frame's slot array
+  uint32_t key_off, key_cap;  // quad-tree key buffers (entries) inside one frame
+  uint32_t node_off, node_cap;
+  int n_ini;                  // number of root nodes
+  int root_x[kMaxRoots + 1];  // root node x bounds
+  uint32_t rootx_off;         // byte offset into the root lookup table (index by x relative to minBorder)
+  uint32_t xtab_off, ytab_off;
+  float scale;                // mvScaleFactor[level]
+  int patch_size;             // (int)(31 * scale)
+};
+
+struct UMax { int v[16]; };
+
+struct QNode {  // quad-tree node, 16 bytes
+  uint16_t x0, x1, y0, y1;
+  uint32_t beg;  // first key
+  uint32_t cnt;  // bit 31: keys live in buffer B
+};
+struct QDiv { uint32_t c[4]; };
+
+// candidate / key packing: x (12 bit) | y (12 bit) << 12 | score << 24, coordinates relative to minBorder
+__device__ __forceinline__ uint32_t pack_key(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24); }
+__device__ __forceinline__ int key_x(uint32_t k) { return (int)(k & 0xfff); }
+__device__ __forceinline__ int key_y(uint32_t k) { return (int)((k >> 12) & 0xfff); }
+__device__ __forceinline__ int key_s(uint32_t k) { return (int)(k >> 24); }
+
+// ------------------------------------------------------------------------------------------------
+// cv::resize(INTER_LINEAR, CV_8UC1): 11-bit fixed-point bilinear, each thread makes 4 output pixels.
+// grid = (ceil(dw/256), ceil(dh/4), B), block = 256 (64 x 4).
+__global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict__ src, int spitch,
+                                                       size_t sframe, int sw, int sh,
+                                                       uint8_t* __restrict__ dst, int dpitch, size_t dframe,
+                                                       int dw, int dh, const ResizeTab* __restrict__ xtab,
+                                                       const ResizeTab* __restrict__ ytab) {
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int dx0 = (blockIdx.x * 64 + tx) * 4;
+  const int dy = blockIdx.y * 4 + ty;
+  if (dy >= dh || dx0 >= dw) return;
+  const uint8_t* S = src + (size_t)blockIdx.z * sframe;
+  uint8_t* D = dst + (size_t)blockIdx.z * dframe + (size_t)dy * dpitch;
+  const ResizeTab ry = ytab[dy];
+  const int sy0 = imin(imax(ry.sofs, 0), sh - 1), sy1 = imin(imax(ry.sofs + 1, 0), sh - 1);
+  const uint8_t* S0 = S + (size_t)sy0 * spitch;
+  const uint8_t* S1 = S + (size_t)sy1 * spitch;
+  const int b0 = ry.a0, b1 = ry.a1;
+  uint32_t out = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int dx = dx0 + i;
+    if (dx >= dw) break;
+    const ResizeTab rx = xtab[dx];
+    const int sx = rx.sofs, sx1 = imin(sx + 1, sw - 1);
+    const int h0 = S0[sx] * rx.a0 + S0[sx1] * rx.a1;
+    const int h1 = S1[sx] * rx.a0 + S1[sx1] * rx.a1;
+    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    out |= (uint32_t)(v & 0xff) << (8 * i);
+  }
+  if (dx0 + 3 < dw) {
+    *reinterpret_cast<uint32_t*>(D + dx0) = out;  // dpitch and dx0 are multiples of 4
+  } else {
+    for (int i = 0; dx0 + i < dw; ++i) D[dx0 + i] = (uint8_t)(out >> (8 * i));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 on one detection cell per workgroup.
+constexpr int kCellMax = 72;             // max scanned cell side handled (wCell/hCell <= 72)
+constexpr int kTileP = kCellMax + 8;     // LDS tile pitch (cell + 6 ring margin, padded)
+constexpr int kScoreP = kCellMax + 2;
+
+// Bresenham ring of radius 3, OpenCV order (modules/features2d/src/fast_score.cpp makeOffsets)
+#define RGBL_RING(c, P, k)                                                                            \
+  ((k) == 0 ? (c)[3 * (P)] : (k) == 1 ? (c)[3 * (P) + 1] : (k) == 2 ? (c)[2 * (P) + 2]                \
+   : (k) == 3 ? (c)[(P) + 3] : (k) == 4 ? (c)[3] : (k) == 5 ? (c)[-(P) + 3] : (k) == 6 ? (c)[-2 * (P) + 2] \
+   : (k) == 7 ? (c)[-3 * (P) + 1] : (k) == 8 ? (c)[-3 * (P)] : (k) == 9 ? (c)[-3 * (P) - 1]           \
+   : (k) == 10 ? (c)[-2 * (P) - 2] : (k) == 11 ? (c)[-(P) - 3] : (k) == 12 ? (c)[-3]                  \
+   : (k) == 13 ? (c)[(P) - 3] : (k) == 14 ? (c)[2 * (P) - 2] : (c)[3 * (P) - 1])
+
+// largest t for which the pixel is still a FAST-9/16 corner (== cv cornerScore<16> for corners); <0 if none
+__device__ __forceinline__ int fast_true_score(const uint8_t* c, int P) {
+  const int v = c[0];
+  int d[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) d[k] = v - (int)RGBL_RING(c, P, k);
+  int mn2[16], mx2[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { mn2[k] = imin(d[k], d[(k + 1) & 15]); mx2[k] = imax(d[k], d[(k + 1) & 15]); }
+  int mn4[16], mx4[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { mn4[k] = imin(mn2[k], mn2[(k + 2) & 15]); mx4[k] = imax(mx2[k], mx2[(k + 2) & 15]); }
+  int dark = -256, bright = 256;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int mn9 = imin(imin(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);  // min over ring k..k+8
+    const int mx9 = imax(imax(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+    dark = imax(dark, mn9);
+    bright = imin(bright, mx9);
+  }
+  return imax(dark, -bright) - 1;
+}
+
+// grid = (cells per frame over all levels, B), block = 256.
+__global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict__ geom, int n_levels,
+                                                    const uint8_t* __restrict__ img0, int pitch0,
+                                                    size_t frame0, const uint8_t* __restrict__ pyr,
+                                                    size_t pyr_frame, int ini_th, int min_th,
+                                                    uint32_t* __restrict__ cell_cnt, size_t cells_frame,
+                                                    uint32_t* __restrict__ slots, size_t slots_frame) {
+  __shared__ uint8_t s_tile[(kCellMax + 6) * kTileP];
+  __shared__ uint8_t s_score[(kCellMax + 2) * kScoreP];
+  __shared__ uint16_t s_surv[kCellMax * kCellMax];
+  __shared__ uint32_t s_scan[8];
+  __shared__ int s_nsurv, s_any_ini;
+
+  const int tid = threadIdx.x;
+  const int f = blockIdx.y;
+  int l = 0;
+  while (l + 1 < n_levels && (int)blockIdx.x >= geom[l + 1].cell_off) ++l;
+  const LevelGeom& g = geom[l];
+  const int ci = (int)blockIdx.x - g.cell_off;
+  const int ci_row = ci / g.n_cols, ci_col = ci - ci_row * g.n_cols;
+  uint32_t* my_cnt = cell_cnt + (size_t)f * cells_frame + blockIdx.x;
+
+  const int ini_x = kMinBorder + ci_col * g.w_cell, ini_y = kMinBorder + ci_row * g.h_cell;
+  const int max_x = imin(ini_x + g.w_cell + 6, g.max_bx), max_y = imin(ini_y + g.h_cell + 6, g.max_by);
+  // ORBextractor.cc:810-822: cells starting too close to the border are skipped
+  const int tw = max_x - ini_x, th = max_y - ini_y;
+  const int sw = tw - 6, sh = th - 6;  // scanned (candidate) area of cv::FAST on the sub-image
+  if (ini_x >= g.max_bx - 6 || ini_y >= g.max_by - 3 || sw <= 0 || sh <= 0) {
+    if (tid == 0) *my_cnt = 0;
+    return;
+  }
+  const uint8_t* img = (l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
+  const int pitch = (l == 0) ? pitch0 : g.pitch;
+
+  // ---- stage the (sw+6) x (sh+6) pixel tile and clear the score tile
+  for (int i = tid; i < tw * th; i += 256) {
+    const int y = i / tw, x = i - y * tw;
+    s_tile[y * kTileP + x] = img[(size_t)(ini_y + y) * pitch + ini_x + x];
+  }
+  for (int i = tid; i < (sh + 2) * kScoreP; i += 256) s_score[i] = 0;
+  if (tid == 0) { s_nsurv = 0; s_any_ini = 0; }
+  __syncthreads();
+
+  // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are compacted
+  const int npix = sw * sh;
+  for (int p = tid; p < npix; p += 256) {
+    const int y = p / sw, x = p - y * sw;
+    const uint8_t* c = &s_tile[(y + 3) * kTileP + x + 3];
+    const int v = c[0], lo = v - min_th, hi = v + min_th;
+    bool dark = true, bright = true;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const int a = RGBL_RING(c, kTileP, k), b = RGBL_RING(c, kTileP, k + 8);
+      dark = dark && (a < lo || b < lo);
+      bright = bright && (a > hi || b > hi);
+    }
+    if (dark || bright) {
+      const int pos = atomicAdd(&s_nsurv, 1);
+      s_surv[pos] = (uint16_t)p;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: exact score of the survivors
+  const int nsurv = s_nsurv;
+  for (int i = tid; i < nsurv; i += 256) {
+    const int p = s_surv[i];
+    const int y = p / sw, x = p - y * sw;
+    const int sc = fast_true_score(&s_tile[(y + 3) * kTileP + x + 3], kTileP);
+    if (sc >= min_th) s_score[(y + 1) * kScoreP + x + 1] = (uint8_t)sc;
+  }
+  __syncthreads();
+
+  // ---- phase C: 3x3 strict NMS inside the cell; each thread owns a contiguous run of pixels so the
+  //      compaction below reproduces cv::FAST's row-major emission order
+  const int per = (npix + 255) >> 8;  // <= 21
+  const int p0 = tid * per, p1 = imin(p0 + per, npix);
+  uint32_t keep = 0;
+  bool has_ini = false;
+  for (int p = p0; p < p1; ++p) {
+    const int y = p / sw, x = p - y * sw;
+    const uint8_t* s = &s_score[(y + 1) * kScoreP + x + 1];
+    const int v = s[0];
+    if (v == 0) continue;
+    if (v > s[-1] && v > s[1] && v > s[-kScoreP - 1] && v > s[-kScoreP] && v > s[-kScoreP + 1] &&
+        v > s[kScoreP - 1] && v > s[kScoreP] && v > s[kScoreP + 1]) {
+      keep |= 1u << (p - p0);
+      has_ini = has_ini || v >= ini_th;
+    }
+  }
+  if (has_ini) s_any_ini = 1;
+  __syncthreads();
+  // two-threshold rule of ORBextractor.cc:826-846: the ini-threshold set if it is non-empty, else the min set
+  if (s_any_ini) {
+    for (int p = p0; p < p1; ++p)
+      if (((keep >> (p - p0)) & 1) && s_score[(p / sw + 1) * kScoreP + (p % sw) + 1] < ini_th) keep &= ~(1u << (p - p0));
+  }
+  uint32_t total;
+  uint32_t base = block_exclusive_scan<uint32_t>((uint32_t)__popc(keep), s_scan, &total);
+  uint32_t* out = slots + (size_t)f * slots_frame + g.slot_off + (size_t)ci * g.cell_cap;
+  for (int p = p0; p < p1; ++p) {
+    if (!((keep >> (p - p0)) & 1)) continue;
+    const int y = p / sw, x = p - y * sw;
+    if (base < (uint32_t)g.cell_cap)
+      out[base] = pack_key(ci_col * g.w_cell + 3 + x, ci_row * g.h_cell + 3 + y, s_score[(y + 1) * kScoreP + x + 1]);
+    ++base;
+  }
+  if (tid == 0) *my_cnt = total < (uint32_t)g.cell_cap ? total : (uint32_t)g.cell_cap;  // cap is a proven bound
+}
+
+// ------------------------------------------------------------------------------------------------
+// 7x7 Gaussian, sigma 2, OpenCV's 8.8 fixed-point kernel {18,34,48,56,48,34,18}; BORDER_REFLECT_101.
+// Tile = 64 x 16 outputs per workgroup.  grid = (tiles per frame over all levels, B), block = 256.
+struct BlurTiles { int tile_off[kMaxLevels + 1]; int tiles_x[kMaxLevels]; };
+
+__global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ geom, int n_levels, BlurTiles bt,
+                                                const uint8_t* __restrict__ img0, int pitch0, size_t frame0,
+                                                const uint8_t* __restrict__ pyr, size_t pyr_frame,
+                                                uint8_t* __restrict__ blur, size_t blur_frame) {
+  __shared__ uint8_t s_in[22 * 72];
+  __shared__ uint16_t s_h[22 * 64];
+  const int tid = threadIdx.x, f = blockIdx.y;
+  int l = 0;
+  while (l + 1 < n_levels && (int)blockIdx.x >= bt.tile_off[l + 1]) ++l;
+  const LevelGeom& g = geom[l];
+  const int t = (int)blockIdx.x - bt.tile_off[l];
+  const int ty = t / bt.tiles_x[l], tx = t - ty * bt.tiles_x[l];
+  const int x0 = tx * 64, y0 = ty * 16;
+  const uint8_t* img = (l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
+  const int pitch = (l == 0) ? pitch0 : g.pitch;
+  for (int i = tid; i < 22 * 70; i += 256) {
+    const int r = i / 70, c = i - r * 70;
+    const int yy = reflect101(y0 + r - 3, g.h), xx = reflect101(x0 + c - 3, g.w);
+    s_in[r * 72 + c] = img[(size_t)yy * pitch + xx];
+  }
+  __syncthreads();
+  for (int i = tid; i < 22 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    const uint8_t* p = &s_in[r * 72 + c];
+    s_h[i] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
+  }
+  __syncthreads();
+  const int r = tid >> 4, c4 = (tid & 15) * 4;
+  const int y = y0 + r;
+  if (y >= g.h || x0 + c4 >= g.w) return;
+  uint32_t out = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint16_t* q = &s_h[r * 64 + c4 + i];
+    const uint32_t acc = 18u * (q[0] + q[6 * 64]) + 34u * (q[64] + q[5 * 64]) + 48u * (q[2 * 64] + q[4 * 64]) + 56u * q[3 * 64];
+    out |= ((acc + 32768u) >> 16) << (8 * i);
+  }
+  uint8_t* D = blur + (size_t)f * blur_frame + g.img_off + (size_t)y * g.pitch + x0 + c4;
+  if (x0 + c4 + 3 < g.w) {
+    *reinterpret_cast<uint32_t*>(D) = out;
+  } else {
+    for (int i = 0; x0 + c4 + i < g.w; ++i) D[i] = (uint8_t)(out >> (8 * i));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// libstdc++ std::sort (GCC 11 introsort) re-stated on two parallel arrays, ordering = ascending key.
+// The reference sorts its expandable quad-tree nodes with std::sort + compareNodes (ORBextractor.cc:538-553,
+// :700); nodes with equal (size, UL.x) end up in an order that only the algorithm's exact sequence of
+// swaps determines, and that order decides which nodes get split.  Hence a literal restatement.
+struct SortPair { uint64_t k; uint32_t v; };
+struct SortView {
+  uint64_t* key; uint32_t* val;
+  __host__ __device__ SortPair get(int i) const { SortPair p; p.k = key[i]; p.v = val[i]; return p; }
+  __host__ __device__ void set(int i, SortPair p) const { key[i] = p.k; val[i] = p.v; }
+  __host__ __device__ void swap(int i, int j) const { SortPair a = get(i), b = get(j); set(i, b); set(j, a); }
+  __host__ __device__ bool less(int i, int j) const { return key[i] < key[j]; }
+};
+__host__ __device__ inline void ss_push_heap(const SortView& a, int first, int hole, int top, SortPair value) {
+  int parent = (hole - 1) / 2;
+  while (hole > top && a.key[first + parent] < value.k) {
+    a.set(first + hole, a.get(first + parent));
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  a.set(first + hole, value);
+}
+__host__ __device__ inline void ss_adjust_heap(const SortView& a, int first, int hole, int len, SortPair value) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (a.less(first + child, first + child - 1)) --child;
+    a.set(first + hole, a.get(first + child));
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    a.set(first + hole, a.get(first + child - 1));
+    hole = child - 1;
+  }
+  ss_push_heap(a, first, hole, top, value);
+}
+__host__ __device__ inline void ss_heap_sort(const SortView& a, int first, int last) {
+  const int len = last - first;
+  if (len >= 2) {
+    int parent = (len - 2) / 2;
+    for (;;) {
+      SortPair v = a.get(first + parent);
+      ss_adjust_heap(a, first, parent, len, v);
+      if (parent == 0) break;
+      --parent;
+    }
+  }
+  while (last - first > 1) {
+    --last;
+    SortPair v = a.get(last);
+    a.set(last, a.get(first));
+    ss_adjust_heap(a, first, 0, last - first, v);
+  }
+}
+__host__ __device__ inline void ss_unguarded_linear_insert(const SortView& a, int last) {
+  SortPair v = a.get(last);
+  int next = last - 1;
+  while (v.k < a.key[next]) {
+    a.set(last, a.get(next));
+    last = next;
+    --next;
+  }
+  a.set(last, v);
+}
+__host__ __device__ inline void ss_insertion_sort(const SortView& a, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    if (a.less(i, first)) {
+      SortPair v = a.get(i);
+      for (int j = i; j > first; --j) a.set(j, a.get(j - 1));
+      a.set(first, v);
+    } else {
+      ss_unguarded_linear_insert(a, i);
+    }
+  }
+}
+__host__ __device__ inline void std_sort_restated(uint64_t* key, uint32_t* val, int n) {
+  if (n <= 0) return;
+  SortView a{key, val};
+  int lg = 0;
+  while ((n >> (lg + 1)) != 0) ++lg;
+  int stack_first[64], stack_last[64], stack_depth[64], sp = 0;
+  stack_first[0] = 0; stack_last[0] = n; stack_depth[0] = 2 * lg; sp = 1;
+  while (sp > 0) {
+    --sp;
+    int first = stack_first[sp], last = stack_last[sp], depth = stack_depth[sp];
+    while (last - first > 16) {
+      if (depth == 0) { ss_heap_sort(a, first, last); break; }
+      --depth;
+      // __move_median_to_first(first, first+1, mid, last-1)
+      const int mid = first + (last - first) / 2;
+      const int A = first + 1, B = mid, C = last - 1;
+      if (a.less(A, B)) {
+        if (a.less(B, C)) a.swap(first, B);
+        else if (a.less(A, C)) a.swap(first, C);
+        else a.swap(first, A);
+      } else if (a.less(A, C)) a.swap(first, A);
+      else if (a.less(B, C)) a.swap(first, C);
+      else a.swap(first, B);
+      // __unguarded_partition(first+1, last, pivot = first)
+      int lo = first + 1, hi = last;
+      const uint64_t pivot = a.key[first];
+      for (;;) {
+        while (a.key[lo] < pivot) ++lo;
+        --hi;
+        while (pivot < a.key[hi]) --hi;
+        if (!(lo < hi)) break;
+        a.swap(lo, hi);
+        ++lo;
+      }
+      stack_first[sp] = lo; stack_last[sp] = last; stack_depth[sp] = depth; ++sp;  // right part later
+      last = lo;
+    }
+  }
+  if (n > 16) {
+    ss_insertion_sort(a, 0, 16);
+    for (int i = 16; i < n; ++i) ss_unguarded_linear_insert(a, i);
+  } else {
+    ss_insertion_sort(a, 0, n);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Quad-tree distribution, one workgroup (4 waves) per (level, frame).
+struct OctreeBufs {
+  const uint32_t* cell_cnt; size_t cells_frame;
+  const uint32_t* slots; size_t slots_frame;
+  uint32_t *keys_a, *keys_b; size_t keys_frame;
+  QNode *list_a, *list_b; QDiv* div; uint32_t *todo_a, *todo_b; uint64_t* skey; uint32_t* sval;
+  uint8_t* divided; size_t nodes_frame;
+  const uint8_t* rootx;
+  uint32_t* kp_key; int* kp_count; size_t kp_frame;  // outputs: selected keys per level, counts [B][L]
+  int* err;
+};
+
+__device__ __forceinline__ int quadrant_of(uint32_t key, int mx, int my) {
+  const bool left = key_x(key) < mx, top = key_y(key) < my;
+  return left ? (top ? 0 : 2) : (top ? 1 : 3);
+}
+// wave-cooperative: counts of the node's keys per child quadrant (all lanes get the result)
+__device__ __forceinline__ void node_count(const QNode& nd, const uint32_t* keys_a, const uint32_t* keys_b, uint32_t c[4]) {
+  const uint32_t cnt = nd.cnt & 0x7fffffffu;
+  const uint32_t* src = ((nd.cnt >> 31) ? keys_b : keys_a) + nd.beg;
+  const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+  c[0] = c[1] = c[2] = c[3] = 0;
+  const int lane = lane_id();
+  for (uint32_t base = 0; base < cnt; base += 64) {
+    const bool valid = base + lane < cnt;
+    const int q = valid ? quadrant_of(src[base + lane], mx, my) : -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] += (uint32_t)__popcll(__ballot(q == k));
+  }
+}
+// wave-cooperative stable 4-way partition of the node's keys into the other buffer
+__device__ __forceinline__ void node_place(const QNode& nd, uint32_t* keys_a, uint32_t* keys_b, const uint32_t c[4]) {
+  const uint32_t cnt = nd.cnt & 0x7fffffffu;
+  const bool in_b = (nd.cnt >> 31) != 0;
+  const uint32_t* src = (in_b ? keys_b : keys_a) + nd.beg;
+  uint32_t* dst = (in_b ? keys_a : keys_b) + nd.beg;
+  const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+  uint32_t o[4] = {0, c[0], c[0] + c[1], c[0] + c[1] + c[2]};
+  const int lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+  for (uint32_t base = 0; base < cnt; base += 64) {
+    const bool valid = base + lane < cnt;
+    const uint32_t key = valid ? src[base + lane] : 0u;
+    const int q = valid ? quadrant_of(key, mx, my) : -1;
+    uint32_t my_pos = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long m = __ballot(q == k);
+      if (q == k) my_pos = o[k] + (uint32_t)__popcll(m & lt);
+      o[k] += (uint32_t)__popcll(m);
+    }
+    if (valid) dst[my_pos] = key;
+  }
+}
+__device__ __forceinline__ QNode child_node(const QNode& nd, int q, uint32_t beg, uint32_t cnt) {
+  const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+  QNode c;
+  c.x0 = (uint16_t)((q & 1) ? mx : nd.x0);
+  c.x1 = (uint16_t)((q & 1) ? nd.x1 : mx);
+  c.y0 = (uint16_t)((q & 2) ? my : nd.y0);
+  c.y1 = (uint16_t)((q & 2) ? nd.y1 : my);
+  c.beg = beg;
+  c.cnt = cnt | ((nd.cnt & 0x80000000u) ^ 0x80000000u);  // children live in the other buffer
+  return c;
+}
+
+constexpr int kSortLds = 2048;
+
+// Rebuilds the node list after a set of nodes has been split, reproducing std::list push_front/erase:
+//   new list = [children of the LAST processed node (n4..n1), ..., children of the FIRST processed node]
+//              ++ [all nodes that were not split, in their old order]
+// `proc(rho)` gives the old list position of the rho-th processed node (rho < P); div[rho] its child counts
+// (all zero = node was not split).  Children with more than one key are appended to todo_out in creation
+// order.  Returns (through LDS) the new size and the number of expandable children.
+template <bool kIdentity>
+__device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n, const QDiv* div, int P,
+                                             const uint32_t* sval, int m, uint8_t* divided, uint32_t* todo_out,
+                                             unsigned long long* s_scan, int* s_newn, int* s_nexp) {
+  const int tid = threadIdx.x;
+  // pass 1: totals over processing ranks (children | expandable children << 32)
+  unsigned long long carry = 0;
+  // two sweeps: first totals, then placement (placement needs T)
+  unsigned long long T2 = 0;
+  for (int r0 = 0; r0 < P; r0 += 256) {
+    const int rho = r0 + tid;
+    unsigned long long v = 0;
+    if (rho < P) {
+      const QDiv d = div[rho];
+      for (int q = 0; q < 4; ++q) v += (d.c[q] > 0 ? 1ull : 0ull) + (d.c[q] > 1 ? (1ull << 32) : 0ull);
+    }
+    unsigned long long tot;
+    block_exclusive_scan<unsigned long long>(v, s_scan, &tot);
+    T2 += tot;
+  }
+  const uint32_t T = (uint32_t)(T2 & 0xffffffffu);
+  for (int r0 = 0; r0 < P; r0 += 256) {
+    const int rho = r0 + tid;
+    unsigned long long v = 0;
+    QDiv d; d.c[0] = d.c[1] = d.c[2] = d.c[3] = 0;
+    if (rho < P) {
+      d = div[rho];
+      for (int q = 0; q < 4; ++q) v += (d.c[q] > 0 ? 1ull : 0ull) + (d.c[q] > 1 ? (1ull << 32) : 0ull);
+    }
+    unsigned long long tot;
+    const unsigned long long ex = carry + block_exclusive_scan<unsigned long long>(v, s_scan, &tot);
+    carry += tot;
+    if (rho < P && v != 0) {
+      const int pos = kIdentity ? rho : (int)sval[m - 1 - rho];
+      const QNode nd = cur[pos];
+      uint32_t child_rank = (uint32_t)(ex & 0xffffffffu), exp_rank = (uint32_t)(ex >> 32);
+      uint32_t beg = nd.beg;
+      for (int q = 0; q < 4; ++q) {
+        if (d.c[q] > 0) {
+          const uint32_t idx = T - child_rank - 1;
+          nxt[idx] = child_node(nd, q, beg, d.c[q]);
+          if (d.c[q] > 1) todo_out[exp_rank++] = idx;
+          ++child_rank;
+        }
+        beg += d.c[q];
+      }
+      divided[pos] = 1;
+    }
+  }
+  __syncthreads();
+  // pass 2: surviving nodes keep their relative order behind the children
+  uint32_t kcarry = 0;
+  for (int p0 = 0; p0 < n; p0 += 256) {
+    const int pos = p0 + tid;
+    const uint32_t keep = (pos < n && !divided[pos]) ? 1u : 0u;
+    uint32_t tot;
+    uint32_t* s32 = reinterpret_cast<uint32_t*>(s_scan);
+    const uint32_t ex = kcarry + block_exclusive_scan<uint32_t>(keep, s32, &tot);
+    kcarry += tot;
+    if (keep) nxt[T + ex] = cur[pos];
+  }
+  if (tid == 0) { *s_newn = (int)(T + kcarry); *s_nexp = (int)(T2 >> 32); }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b) {
+  __shared__ unsigned long long s_scan[8];
+  __shared__ unsigned long long s_skey[kSortLds];
+  __shared__ uint32_t s_sval[kSortLds];
+  __shared__ int s_newn, s_nexp, s_n, s_P;
+  __shared__ uint32_t s_rootcnt[kMaxRoots];
+
+  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  const int nw = (int)(blockDim.x >> 6);
+  const int l = blockIdx.x, f = blockIdx.y;
+  const LevelGeom& g = geom[l];
+  uint32_t* keys_a = b.keys_a + (size_t)f * b.keys_frame + g.key_off;
+  uint32_t* keys_b = b.keys_b + (size_t)f * b.keys_frame + g.key_off;
+  const size_t nbase = (size_t)f * b.nodes_frame + g.node_off;
+  QNode* cur = b.list_a + nbase;
+  QNode* nxt = b.list_b + nbase;
+  QDiv* div = b.div + nbase;
+  uint32_t* todo = b.todo_a + nbase;
+  uint32_t* todo_n = b.todo_b + nbase;
+  uint8_t* divided = b.divided + nbase;
+  const int N = g.quota;
+
+  // ---- 0. gather the cell slots into one dense list in the reference's order (cell-major) -> keys_a
+  uint32_t C = 0;
+  {
+    const uint32_t* ccnt = b.cell_cnt + (size_t)f * b.cells_frame + g.cell_off;
+    const uint32_t* slots = b.slots + (size_t)f * b.slots_frame + g.slot_off;
+    for (int c0 = 0; c0 < g.n_cells; c0 += 256) {
+      const int c = c0 + tid;
+      const uint32_t cnt = c < g.n_cells ? ccnt[c] : 0u;
+      uint32_t tot;
+      const uint32_t base = C + block_exclusive_scan<uint32_t>(cnt, reinterpret_cast<uint32_t*>(s_scan), &tot);
+      for (uint32_t k = 0; k < cnt; ++k) keys_a[base + k] = slots[(size_t)c * g.cell_cap + k];
+      C += tot;
+    }
+  }
+  __syncthreads();
+
+  // ---- 1. stable partition into the n_ini root nodes (ORBextractor.cc:582-586) -> keys_b
+  const uint8_t* rootx = b.rootx + g.rootx_off;
+  {
+    uint32_t outpos = 0;
+    for (int r = 0; r < g.n_ini; ++r) {
+      const uint32_t beg = outpos;
+      for (uint32_t base = 0; base < C; base += 256 * 8) {
+        const uint32_t i0 = base + (uint32_t)tid * 8;
+        uint32_t mask = 0;
+        for (int k = 0; k < 8; ++k)
+          if (i0 + k < C && rootx[key_x(keys_a[i0 + k])] == r) mask |= 1u << k;
+        uint32_t tot;
+        uint32_t pos = outpos + block_exclusive_scan<uint32_t>((uint32_t)__popc(mask), reinterpret_cast<uint32_t*>(s_scan), &tot);
+        for (int k = 0; k < 8; ++k)
+          if ((mask >> k) & 1) keys_b[pos++] = keys_a[i0 + k];
+        outpos += tot;
+      }
+      if (tid == 0) s_rootcnt[r] = outpos - beg;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n0 = 0;
+    uint32_t beg = 0;
+    for (int r = 0; r < g.n_ini; ++r) {
+      const uint32_t cnt = s_rootcnt[r];
+      if (cnt > 0) {  // empty roots are erased (ORBextractor.cc:597-598)
+        QNode nd;
+        nd.x0 = (uint16_t)g.root_x[r]; nd.x1 = (uint16_t)g.root_x[r + 1];
+        nd.y0 = 0; nd.y1 = (uint16_t)(g.max_by - kMinBorder);
+        nd.beg = beg; nd.cnt = cnt | 0x80000000u;
+        cur[n0++] = nd;
+      }
+      beg += cnt;
+    }
+    s_n = n0;
+  }
+  __syncthreads();
+  int n = s_n;
+  int m = 0;
+
+  // ---- 2. breadth-first splitting (ORBextractor.cc:608-686)
+  bool finished = (n == 0);
+  bool careful = false;
+  while (!finished) {
+    for (int pos = wave; pos < n; pos += nw) {
+      const QNode nd = cur[pos];
+      QDiv d; d.c[0] = d.c[1] = d.c[2] = d.c[3] = 0;
+      if ((nd.cnt & 0x7fffffffu) > 1) {
+        node_count(nd, keys_a, keys_b, d.c);
+        node_place(nd, keys_a, keys_b, d.c);
+      }
+      if (lane == 0) { div[pos] = d; divided[pos] = 0; }
+    }
+    __syncthreads();
+    rebuild_list<true>(cur, nxt, n, div, n, nullptr, 0, divided, todo_n, s_scan, &s_newn, &s_nexp);
+    const int newn = s_newn, nexp = s_nexp;
+    { QNode* t = cur; cur = nxt; nxt = t; }
+    { uint32_t* t = todo; todo = todo_n; todo_n = t; }
+    const int prev = n;
+    n = newn;
+    m = nexp;
+    if (n > (int)g.node_cap - 8) { if (tid == 0) atomicOr(b.err, 1); finished = true; }
+    else if (n >= N || n == prev) finished = true;
+    else if (n + 3 * nexp > N) { careful = true; break; }
+  }
+
+  // ---- 3. near the quota: split the most populated nodes first (ORBextractor.cc:689-753)
+  while (careful && !finished) {
+    const int prev = n;
+    uint64_t* skey = (m <= kSortLds) ? reinterpret_cast<uint64_t*>(s_skey) : b.skey + nbase;
+    uint32_t* sval = (m <= kSortLds) ? s_sval : b.sval + nbase;
+    for (int j = tid; j < m; j += 256) {
+      const uint32_t pos = todo[j];
+      const QNode nd = cur[pos];
+      skey[j] = ((uint64_t)(nd.cnt & 0x7fffffffu) << 32) | nd.x0;  // compareNodes: (size, UL.x)
+      sval[j] = pos;
+    }
+    for (int p = tid; p < n; p += 256) divided[p] = 0;
+    __syncthreads();
+    if (tid == 0) std_sort_restated(skey, sval, m);
+    __syncthreads();
+    // child counts of every expandable node, rank rho = position counted from the back of the sorted array
+    for (int j = wave; j < m; j += nw) {
+      const QNode nd = cur[sval[j]];
+      QDiv d;
+      node_count(nd, keys_a, keys_b, d.c);
+      if (lane == 0) div[m - 1 - j] = d;
+    }
+    if (tid == 0) s_P = m;
+    __syncthreads();
+    // first rank after which the list has reached the quota (the reference breaks out of its loop there)
+    {
+      long long carry = 0;
+      for (int r0 = 0; r0 < m; r0 += 256) {
+        const int rho = r0 + tid;
+        long long v = 0;
+        if (rho < m) {
+          const QDiv d = div[rho];
+          v = (long long)((d.c[0] > 0) + (d.c[1] > 0) + (d.c[2] > 0) + (d.c[3] > 0)) - 1;
+        }
+        unsigned long long tot;
+        const unsigned long long ex = block_exclusive_scan<unsigned long long>((unsigned long long)v, s_scan, &tot);
+        const long long size_after = (long long)n + carry + (long long)ex + v;
+        if (rho < m && size_after >= N) atomicMin(&s_P, rho + 1);
+        carry += (long long)tot;
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+    const int P = s_P;
+    for (int rho = wave; rho < P; rho += nw) {
+      const QNode nd = cur[sval[m - 1 - rho]];
+      const QDiv d = div[rho];
+      node_place(nd, keys_a, keys_b, d.c);
+    }
+    __syncthreads();
+    rebuild_list<false>(cur, nxt, n, div, P, sval, m, divided, todo_n, s_scan, &s_newn, &s_nexp);
+    { QNode* t = cur; cur = nxt; nxt = t; }
+    { uint32_t* t = todo; todo = todo_n; todo_n = t; }
+    n = s_newn;
+    m = s_nexp;
+    if (n > (int)g.node_cap - 8) { if (tid == 0) atomicOr(b.err, 1); finished = true; }
+    else if (n >= N || n == prev) finished = true;
+  }
+
+  // ---- 4. keep the strongest key of every node, first one on ties (ORBextractor.cc:757-776)
+  uint32_t* out = b.kp_key + (size_t)f * b.kp_frame + g.koff;
+  if (n > g.kcap) { if (tid == 0) atomicOr(b.err, 2); n = g.kcap; }
+  for (int pos = tid; pos < n; pos += 256) {
+    const QNode nd = cur[pos];
+    const uint32_t cnt = nd.cnt & 0x7fffffffu;
+    const uint32_t* src = ((nd.cnt >> 31) ? keys_b : keys_a) + nd.beg;
+    uint32_t best = src[0];
+    for (uint32_t k = 1; k < cnt; ++k) {
+      const uint32_t key = src[k];
+      if (key_s(key) > key_s(best)) best = key;
+    }
+    out[pos] = best;
+  }
+  if (tid == 0) b.kp_count[(size_t)f * n_levels + l] = n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::fastAtan2 (degrees), scalar generic path, fp32 without contraction
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float scale = (float)(180.0 / 3.14159265358979323846);
+  const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale,
+              p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+  const float eps = (float)2.2204460492503131e-16;  // (float)DBL_EPSILON
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = __fdiv_rn(ay, ax + eps);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = __fdiv_rn(ax, ay + eps);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// One wave per keypoint: intensity-centroid angle on the un-blurred level, then the steered BRIEF-256
+// on the blurred level through a 37x37 LDS patch; four __ballot results are descriptor bytes 0-7, 8-15, ...
+// grid = (ceil(kp_frame / 4), B), block = 256.
+__global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restrict__ geom, int n_levels, UMax umax,
+                                                      const int8_t* __restrict__ pattern,
+                                                      const uint8_t* __restrict__ img0, int pitch0, size_t frame0,
+                                                      const uint8_t* __restrict__ pyr, size_t pyr_frame,
+                                                      const uint8_t* __restrict__ blur, size_t blur_frame,
+                                                      const uint32_t* __restrict__ kp_key,
+                                                      const int* __restrict__ kp_count, size_t kp_frame,
+                                                      rgbl_keypoint* __restrict__ out_kp,
+                                                      uint8_t* __restrict__ out_desc, int cap,
+                                                      int32_t* __restrict__ out_n, int32_t* __restrict__ out_mono,
+                                                      int* __restrict__ err) {
+  __shared__ uint8_t s_patch[4][37 * 40];
+  __shared__ int8_t s_pat[1024];
+  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  const int f = blockIdx.y;
+  for (int i = tid; i < 1024; i += 256) s_pat[i] = pattern[i];
+
+  // which (level, index) does this wave own?  slots are laid out level after level with kcap entries each
+  const int slot = blockIdx.x * 4 + wave;
+  int l = 0;
+  while (l + 1 < n_levels && slot >= geom[l + 1].koff) ++l;
+  const LevelGeom& g = geom[l];
+  const int idx = slot - g.koff;
+  const int* cnts = kp_count + (size_t)f * n_levels;
+  bool valid = slot < (int)kp_frame && idx < cnts[l];
+  int dense = idx;  // position in the level-major output order
+  for (int j = 0; j < l; ++j) dense += cnts[j];
+  if (slot == 0 && lane == 0) {
+    int total = 0;
+    for (int j = 0; j < n_levels; ++j) total += cnts[j];
+    out_n[f] = total < cap ? total : cap;
+    if (out_mono) out_mono[f] = total < cap ? total : cap;  // no lapping area: monoIndex == count
+    if (total > cap) atomicOr(err, 4);
+  }
+  if (valid && dense >= cap) valid = false;
+
+  uint32_t key = 0;
+  int x = 0, y = 0;
+  float angle = 0.f;
+  uint8_t* patch = s_patch[wave];
+  if (valid) {
+    key = kp_key[(size_t)f * kp_frame + slot];
+    x = key_x(key) + kMinBorder;
+    y = key_y(key) + kMinBorder;
+    const uint8_t* img = (l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
+    const int pitch = (l == 0) ? pitch0 : g.pitch;
+    // IC_Angle: lanes 0..30 take the rows v = -15..15 of the circular patch
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+      const int v = lane - 15;
+      const int d = umax.v[v < 0 ? -v : v];
+      const uint8_t* row = img + (size_t)(y + v) * pitch + x;
+      int s0 = 0, s1 = 0;
+      for (int u = -d; u <= d; ++u) {
+        const int p = row[u];
+        s0 += p;
+        s1 += u * p;
+      }
+      m10 = s1;
+      m01 = v * s0;
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    angle = fast_atan2_deg((float)m01, (float)m10);
+    // stage the blurred 37x37 neighbourhood
+    const uint8_t* bl = blur + (size_t)f * blur_frame + g.img_off + (size_t)(y - 18) * g.pitch + (x - 18);
+    for (int i = lane; i < 37 * 37; i += 64) {
+      const int r = i / 37, c = i - r * 37;
+      patch[r * 40 + c] = bl[(size_t)r * g.pitch + c];
+    }
+  }
+  __syncthreads();
+  unsigned long long bits[4] = {0, 0, 0, 0};
+  {
+    const float factor_pi = (float)(3.14159265358979323846 / 180.f);
+    const float ang = angle * factor_pi;
+    const float a = glibc_cosf(ang), b = glibc_sinf(ang);
+    const uint8_t* center = patch + 18 * 40 + 18;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int8_t* p = &s_pat[(k * 64 + lane) * 4];
+      const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+      const int t0 = center[cv_round_f(x0 * b + y0 * a) * 40 + cv_round_f(x0 * a - y0 * b)];
+      const int t1 = center[cv_round_f(x1 * b + y1 * a) * 40 + cv_round_f(x1 * a - y1 * b)];
+      bits[k] = __ballot(valid && t0 < t1);
+    }
+  }
+  if (valid && lane < 4) {
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(out_desc + ((size_t)f * cap + dense) * 32);
+    d[lane] = bits[lane];
+  }
+  if (valid && lane == 0) {
+    rgbl_keypoint kp;
+    kp.x = (float)x; kp.y = (float)y;
+    if (l != 0) { kp.x = kp.x * g.scale; kp.y = kp.y * g.scale; }
+    kp.size = (float)g.patch_size;
+    kp.angle = angle;
+    kp.response = (float)key_s(key);
+    kp.octave = l;
+    kp.class_id = -1;
+    out_kp[(size_t)f * cap + dense] = kp;
+  }
+}
+
+// vLappingArea packing (ORBextractor.cc:1153-1162): keypoints with lap0 <= x <= lap1 fill the arrays from
+// the back (in reverse order), all others from the front.  One workgroup per frame.
+__global__ __launch_bounds__(256) void k_lapping_permute(const rgbl_keypoint* __restrict__ in_kp,
+                                                         const uint8_t* __restrict__ in_desc, int in_cap,
+                                                         rgbl_keypoint* __restrict__ out_kp,
+                                                         uint8_t* __restrict__ out_desc, int cap,
+                                                         const int32_t* __restrict__ n_per_frame, float lap0,
+                                                         float lap1, int32_t* __restrict__ out_mono) {
+  __shared__ uint32_t s_scan[8];
+  const int tid = threadIdx.x, f = blockIdx.x;
+  const int n = n_per_frame[f];
+  uint32_t carry = 0;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + tid;
+    rgbl_keypoint kp;
+    kp.x = 0;
+    uint32_t in_lap = 0;
+    if (i < n) {
+      kp = in_kp[(size_t)f * in_cap + i];
+      in_lap = (kp.x >= lap0 && kp.x <= lap1) ? 1u : 0u;
+    }
+    uint32_t tot;
+    const uint32_t before = carry + block_exclusive_scan<uint32_t>(in_lap, s_scan, &tot);
+    carry += tot;
+    if (i < n) {
+      const int dst = in_lap ? (n - 1 - (int)before) : (i - (int)before);
+      out_kp[(size_t)f * cap + dst] = kp;
+      const uint4* s = reinterpret_cast<const uint4*>(in_desc + ((size_t)f * in_cap + i) * 32);
+      uint4* d = reinterpret_cast<uint4*>(out_desc + ((size_t)f * cap + dst) * 32);
+      d[0] = s[0];
+      d[1] = s[1];
+    }
+  }
+  if (tid == 0) out_mono[f] = n - (int)carry;
+}
+
+// unpacks candidate keys into rgbl_keypoint records (diagnostic path of rgbl_extractor_get_candidates)
+__global__ void k_unpack_keys(const uint32_t* __restrict__ keys, int n, rgbl_keypoint* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = keys[i];
+  rgbl_keypoint kp;
+  kp.x = (float)key_x(k); kp.y = (float)key_y(k); kp.size = 7.f; kp.angle = -1.f;
+  kp.response = (float)key_s(k); kp.octave = 0; kp.class_id = -1;
+  out[i] = kp;
+}
+
+}  // namespace rgbl

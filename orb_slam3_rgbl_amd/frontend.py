@@ -1,0 +1,300 @@
+"""Host-side mirror of the reference's front-end classes on top of the C ABI.
+
+Same names, argument meaning and error behaviour as the reference C++ classes (the C++ drop-in shims live
+in orb_slam3_rgbl_amd/shim/); this Python mirror exists so the parity tests read like calls into
+ORB_SLAM3::ORBextractor / DepthModule / ORBmatcher:
+
+  ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)   include/ORBextractor.h:49-83
+      __call__(image, mask, vLappingArea) -> (keypoints, descriptors, monoIndex)
+  DepthModule(params)   .CalculateDepthFromPcd(mvKeys, mvKeysUn, PointCloud, w, h)   include/DepthModule.h:45-99
+  ORBmatcher(nnratio, checkOri)  .DescriptorDistance(a, b)  .SearchForTriangulation(...)   include/ORBmatcher.h:40-87
+
+Every compute call goes through the C ABI into the HIP kernels; nothing here computes on the CPU.
+`lib=` lets the test-suite hand in a differently bound library (the CPU SIMT emulation of the kernels).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+KP_DTYPE = L.KP_DTYPE
+
+UPS_NONE, UPS_NEAREST_NEIGHBOR_PIXEL, UPS_AVERAGE_FILTERING, UPS_INVERSE_DILATION, UPS_IPBASIC = 0, 1, 2, 3, 5
+KERNEL_RECT, KERNEL_CROSS, KERNEL_ELLIPSE, KERNEL_DIAMOND = 0, 1, 2, 3
+
+
+class ORBextractor:
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, max_batch=1,
+                 device=0, lib=None):
+        self.lib = lib or L.load()
+        cfg = L.ExtractorCfg(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, max_batch)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        L.check(self.lib, self.lib.rgbl_extractor_create(C.byref(cfg), device, C.byref(self.h)))
+        self.nlevels = nlevels
+        self.max_keypoints = self.lib.rgbl_extractor_max_keypoints(self.h)
+        n = nlevels
+        self.mvScaleFactor, self.mvInvScaleFactor = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        self.mvLevelSigma2, self.mvInvLevelSigma2 = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        self.mnFeaturesPerLevel, self.umax = np.zeros(n, np.int32), np.zeros(16, np.int32)
+        L.check(self.lib, self.lib.rgbl_extractor_tables(self.h, L.ptr(self.mvScaleFactor), L.ptr(self.mvInvScaleFactor),
+                                                         L.ptr(self.mvLevelSigma2), L.ptr(self.mvInvLevelSigma2),
+                                                         L.ptr(self.mnFeaturesPerLevel), L.ptr(self.umax)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.rgbl_extractor_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # getters of include/ORBextractor.h:61-81
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactor(self):
+        return float(self.cfg.scale_factor)
+
+    def GetScaleFactors(self):
+        return self.mvScaleFactor
+
+    def GetInverseScaleFactors(self):
+        return self.mvInvScaleFactor
+
+    def GetScaleSigmaSquares(self):
+        return self.mvLevelSigma2
+
+    def GetInverseScaleSigmaSquares(self):
+        return self.mvInvLevelSigma2
+
+    def __call__(self, image, mask=None, vLappingArea=(0, 0)):
+        """operator(): returns (keypoints[KP_DTYPE], descriptors[n,32] u8, monoIndex). Empty image -> monoIndex -1."""
+        if image is None or image.size == 0:
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8), -1
+        if image.dtype != np.uint8 or image.ndim != 2:
+            raise TypeError("image must be CV_8UC1")  # the reference asserts image.type() == CV_8UC1
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        h, w = image.shape
+        cap = self.max_keypoints
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n, mono = C.c_int(0), C.c_int(-1)
+        L.check(self.lib, self.lib.rgbl_extract(self.h, L.ptr(image), w, h, image.strides[0], int(vLappingArea[0]),
+                                                int(vLappingArea[1]), L.ptr(kps), L.ptr(desc), cap, C.byref(n),
+                                                C.byref(mono)))
+        return kps[:n.value].copy(), desc[:n.value].copy(), mono.value
+
+    def extract_batch(self, images, vLappingArea=(0, 0)):
+        """images: [B, H, W] u8 contiguous. Returns list of (keypoints, descriptors, monoIndex)."""
+        images = np.ascontiguousarray(images, np.uint8)
+        b, h, w = images.shape
+        cap = self.max_keypoints
+        kps = np.zeros((b, cap), KP_DTYPE)
+        desc = np.zeros((b, cap, 32), np.uint8)
+        n = np.zeros(b, np.int32)
+        mono = np.zeros(b, np.int32)
+        L.check(self.lib, self.lib.rgbl_extract_batch(self.h, L.ptr(images), b, w, h, images.strides[1], images.strides[0],
+                                                      int(vLappingArea[0]), int(vLappingArea[1]), L.ptr(kps), L.ptr(desc),
+                                                      cap, L.ptr(n), L.ptr(mono)))
+        return [(kps[i, :n[i]].copy(), desc[i, :n[i]].copy(), int(mono[i])) for i in range(b)]
+
+    # mvImagePyramid (include/ORBextractor.h:83)
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        L.check(self.lib, self.lib.rgbl_extractor_level_size(self.h, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def image_pyramid(self, level, frame=0, with_border=False, blurred=False):
+        w, h = self.level_size(level)
+        b = 19 if (with_border and not blurred) else 0
+        out = np.zeros((h + 2 * b, w + 2 * b), np.uint8)
+        L.check(self.lib, self.lib.rgbl_extractor_get_level(self.h, frame, level, int(blurred), int(with_border),
+                                                            L.ptr(out), out.strides[0]))
+        return out
+
+    def level_candidates(self, level, frame=0):
+        n = C.c_int(0)
+        L.check(self.lib, self.lib.rgbl_extractor_get_candidates(self.h, frame, level, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), KP_DTYPE)
+        L.check(self.lib, self.lib.rgbl_extractor_get_candidates(self.h, frame, level, L.ptr(out), len(out), C.byref(n)))
+        return out[:n.value]
+
+    def profile(self, enable):
+        L.check(self.lib, self.lib.rgbl_extractor_profile(self.h, int(enable)))
+
+    def profile_read(self):
+        return L.read_profile(self.lib, self.lib.rgbl_extractor_profile_read, self.h)
+
+
+def structuring_element(shape, kw, kh, lib=None):
+    lib = lib or L.load()
+    out = np.zeros(kw * kh, np.uint8)
+    L.check(lib, lib.rgbl_structuring_element(shape, kw, kh, L.ptr(out)))
+    return out.reshape(kh, kw)
+
+
+def projection_matrix(K3x4, Tr4x4, lib=None):
+    lib = lib or L.load()
+    K = np.ascontiguousarray(K3x4, np.float32)
+    T = np.ascontiguousarray(Tr4x4, np.float32)
+    out = np.zeros((3, 4), np.float32)
+    lib.rgbl_projection_matrix(L.ptr(K), L.ptr(T), L.ptr(out))
+    return out
+
+
+class DepthModule:
+    """Mirror of ORB_SLAM3::DepthModule. The YAML keys of Examples/RGB-L/*.yaml arrive as keyword arguments."""
+
+    def __init__(self, LidarProjectionMatrix, width, height, min_dist=5.0, max_dist=200.0, mbf=100.0,
+                 method=UPS_INVERSE_DILATION, kernel_type=KERNEL_DIAMOND, kernel_size_u=5, kernel_size_v=7,
+                 avg_kernel_size=5, nn_search_distance=7.0, max_points=250000, max_keypoints=8192, max_batch=1,
+                 device=0, lib=None):
+        self.lib = lib or L.load()
+        cfg = L.DepthCfg()
+        proj = np.asarray(LidarProjectionMatrix, np.float32).reshape(12)
+        for i in range(12):
+            cfg.proj[i] = float(proj[i])
+        cfg.min_dist, cfg.max_dist, cfg.mbf, cfg.method = min_dist, max_dist, mbf, method
+        if kernel_type == KERNEL_DIAMOND:
+            kernel_size_v = kernel_size_u  # "not considered in Diamond mode" (KITTI00-02.yaml:82)
+        k = structuring_element(kernel_type, kernel_size_u, kernel_size_v, self.lib)
+        cfg.kernel_h, cfg.kernel_w = k.shape
+        for i, v in enumerate(k.reshape(-1)):
+            cfg.kernel[i] = int(v)
+        cfg.avg_kernel_size, cfg.nn_search_radius = avg_kernel_size, nn_search_distance
+        cfg.width, cfg.height = width, height
+        cfg.max_points, cfg.max_keypoints, cfg.max_batch = max_points, max_keypoints, max_batch
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        L.check(self.lib, self.lib.rgbl_depth_create(C.byref(cfg), device, C.byref(self.h)))
+        self.mvDepth = self.mvuRight = self.RawDepthMap = self.ProcessedDepthMap = None
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.rgbl_depth_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def CalculateDepthFromPcd(self, mvKeys, mvKeysUn, PointCloud, imwidth, imheight, want_maps=True):
+        """mvKeys / mvKeysUn: KP_DTYPE arrays (or [k,2] float arrays); PointCloud: 4 x N float32."""
+        def xy(a):
+            if a.dtype == KP_DTYPE:
+                return np.stack([a["x"], a["y"]], 1).astype(np.float32)
+            return np.ascontiguousarray(a, np.float32).reshape(-1, 2)
+        kp = np.ascontiguousarray(xy(mvKeys))
+        un = np.ascontiguousarray(xy(mvKeysUn)[:, 0])
+        cloud = np.asarray(PointCloud, np.float32)
+        if cloud.ndim != 2 or cloud.shape[0] != 4:
+            raise ValueError("PointCloud must be 4 x N (rows x, y, z, 1)")
+        if cloud.strides[1] != 4:
+            cloud = np.ascontiguousarray(cloud)
+        n, k = cloud.shape[1], kp.shape[0]
+        self.mvDepth, self.mvuRight = np.zeros(k, np.float32), np.zeros(k, np.float32)
+        self.RawDepthMap = np.zeros((imheight, imwidth), np.float32) if want_maps else None
+        proc_ok = want_maps and self.cfg.method != UPS_NEAREST_NEIGHBOR_PIXEL
+        self.ProcessedDepthMap = np.zeros((imheight, imwidth), np.float32) if proc_ok else None
+        L.check(self.lib, self.lib.rgbl_depth_compute(self.h, L.ptr(cloud), n, cloud.strides[0] // 4, imwidth, imheight,
+                                                      L.ptr(kp), L.ptr(un), k, L.ptr(self.mvDepth), L.ptr(self.mvuRight),
+                                                      L.ptr(self.RawDepthMap), L.ptr(self.ProcessedDepthMap)))
+
+    def profile(self, enable):
+        L.check(self.lib, self.lib.rgbl_depth_profile(self.h, int(enable)))
+
+    def profile_read(self):
+        return L.read_profile(self.lib, self.lib.rgbl_depth_profile_read, self.h)
+
+
+class ORBmatcher:
+    TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30  # src/ORBmatcher.cc:35-37
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0, lib=None):
+        self.lib = lib or L.load()
+        self.mfNNratio, self.mbCheckOrientation = nnratio, checkOri
+        self.h = C.c_void_p()
+        L.check(self.lib, self.lib.rgbl_matcher_create(device, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.rgbl_matcher_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def DescriptorDistance(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        return self.lib.rgbl_descriptor_distance(L.ptr(a), L.ptr(b))
+
+    def BruteForce(self, descA, descB):
+        """best index / best distance / second-best distance of every row of A in B."""
+        a = np.ascontiguousarray(descA, np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(descB, np.uint8).reshape(-1, 32)
+        bi = np.full(len(a), -1, np.int32)
+        bd = np.full(len(a), 256, np.int32)
+        sd = np.full(len(a), 256, np.int32)
+        L.check(self.lib, self.lib.rgbl_hamming_bf(self.h, L.ptr(a), len(a), L.ptr(b), len(b), L.ptr(bi), L.ptr(bd), L.ptr(sd)))
+        return bi, bd, sd
+
+    def fundamental(self, K1, K2, R12, t12):
+        a = [np.ascontiguousarray(v, np.float32) for v in (K1, K2, R12, t12)]
+        F = np.zeros(9, np.float32)
+        self.lib.rgbl_fundamental(L.ptr(a[0]), L.ptr(a[1]), L.ptr(a[2]), L.ptr(a[3]), L.ptr(F))
+        return F
+
+    def SearchForTriangulation(self, kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, bOnlyStereo=False,
+                               bCoarse=False):
+        """kf = dict(desc, xy, octave, angle, uright, has_mp, node_id, node_off, node_feat).
+        Returns (vMatchedPairs as [m,2] int array in ascending idx1, nmatches)."""
+        keep = []
+
+        def view(kf):
+            v = L.KeyframeView()
+            v.n = len(kf["desc"])
+            for field, key, dt in (("desc", "desc", np.uint8), ("kp_xy", "xy", np.float32),
+                                   ("kp_octave", "octave", np.int32), ("kp_angle", "angle", np.float32),
+                                   ("uright", "uright", np.float32), ("has_mappoint", "has_mp", np.uint8),
+                                   ("node_id", "node_id", np.int32), ("node_off", "node_off", np.int32),
+                                   ("node_feat", "node_feat", np.int32)):
+                a = np.ascontiguousarray(kf[key], dt)
+                keep.append(a)
+                setattr(v, field, a.ctypes.data)
+            v.n_nodes = len(kf["node_id"])
+            return v
+
+        v1, v2 = view(kf1), view(kf2)
+        P = L.TriangulationParams()
+        for i in range(9):
+            P.F12[i] = float(F12[i])
+        P.epipole[0], P.epipole[1] = float(ep[0]), float(ep[1])
+        sf = np.ascontiguousarray(scale_factors2, np.float32)
+        s2 = np.ascontiguousarray(level_sigma2_2, np.float32)
+        P.scale_factors2, P.level_sigma2_2, P.n_levels = sf.ctypes.data, s2.ctypes.data, len(sf)
+        P.only_stereo, P.coarse, P.check_orientation = int(bOnlyStereo), int(bCoarse), int(self.mbCheckOrientation)
+        m12 = np.full(v1.n, -1, np.int32)
+        nm = C.c_int(0)
+        L.check(self.lib, self.lib.rgbl_search_triangulation(self.h, C.byref(v1), C.byref(v2), C.byref(P), L.ptr(m12),
+                                                             C.byref(nm)))
+        idx1 = np.nonzero(m12 >= 0)[0]
+        pairs = np.stack([idx1, m12[idx1]], 1) if len(idx1) else np.zeros((0, 2), np.int64)
+        return pairs, nm.value, m12
+
+    def profile(self, enable):
+        L.check(self.lib, self.lib.rgbl_matcher_profile(self.h, int(enable)))
+
+    def profile_read(self):
+        return L.read_profile(self.lib, self.lib.rgbl_matcher_profile_read, self.h)

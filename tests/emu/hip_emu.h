@@ -1,0 +1,443 @@
+// hip_emu.h — a tiny SIMT emulator so the HIP kernel SOURCES of this repo can be executed on a CPU.
+//
+// TEST INFRASTRUCTURE ONLY.  This container has no GPU and GPU minutes are scarce, so the kernels in
+// orb_slam3_rgbl_amd/csrc/*.hip are additionally compiled by g++ against this header (-DRGBL_EMU) into
+// tests/_build/librgbl_frontend_emu.so, and the CPU test-suite checks their LOGIC against the oracle
+// before anything is sent to a real MI355X.  The emulated library is never shipped, never loaded by the
+// product package and never timed.
+//
+// Model: every workgroup runs on one OS thread; its work-items are ucontext fibers that are resumed
+// round-robin.  __syncthreads() and the wave64 collectives (__ballot/__shfl*) are rendezvous points.
+// The resume order flips between ascending and descending lane order at every rendezvous (or is
+// shuffled, RGBL_EMU_ORDER=shuffle) so that code relying on an accidental execution order, i.e. a
+// missing barrier, tends to fail here instead of passing silently.  Workgroups of one launch are
+// spread over a pool of OS threads; `__shared__` is `static thread_local`, i.e. private to the
+// workgroup currently executing on that OS thread.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct emu_uint3 { unsigned x, y, z; };
+struct uchar4 { unsigned char x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+
+namespace hipemu {
+
+struct Rendezvous {
+  int arrived = 0;
+  unsigned gen = 0;
+};
+
+struct Block;
+struct Fiber {
+  ucontext_t ctx;
+  Block* blk = nullptr;
+  int tid = 0;
+  bool done = false;
+  emu_uint3 tidx{0, 0, 0};
+  char* stack = nullptr;
+};
+
+struct Block {
+  ucontext_t sched;
+  std::vector<Fiber> fibers;
+  int nthreads = 0;
+  int active = 0;               // fibers not yet finished
+  std::vector<int> wave_active; // per wave
+  Rendezvous bar;               // __syncthreads
+  std::vector<Rendezvous> wbar; // per wave collectives
+  std::vector<unsigned long long> slot;  // exchange slots, one per work-item
+  unsigned phase = 0;
+  std::function<void()> body;
+  Fiber* cur = nullptr;
+};
+
+extern thread_local Block* g_blk;
+
+inline Block*& cur_block() { return g_blk; }
+
+void yield_to_scheduler();
+void run_block(Block& b, const dim3& block);
+void launch(const dim3& grid, const dim3& block, const std::function<void()>& body);
+
+}  // namespace hipemu
+
+extern thread_local emu_uint3 threadIdx;
+extern thread_local emu_uint3 blockIdx;
+extern thread_local dim3 blockDim;
+extern thread_local dim3 gridDim;
+
+// ------------------------------------------------------------------ device intrinsics
+namespace hipemu {
+inline void rendezvous(Rendezvous& r, int& active) {
+  unsigned my = r.gen;
+  if (++r.arrived >= active) {
+    r.arrived = 0;
+    ++r.gen;
+    ++cur_block()->phase;
+    return;
+  }
+  while (r.gen == my) yield_to_scheduler();
+}
+inline int lane_id() { return cur_block()->cur->tid & 63; }
+inline int wave_id() { return cur_block()->cur->tid >> 6; }
+
+// all (still running) lanes of the wave deposit a value, then read any lane's value
+template <class F>
+inline unsigned long long wave_collective(unsigned long long mine, F reader) {
+  Block* b = cur_block();
+  const int w = wave_id(), tid = b->cur->tid;
+  b->slot[tid] = mine;
+  rendezvous(b->wbar[2 * w], b->wave_active[w]);
+  unsigned long long res = reader(&b->slot[(size_t)w * 64]);
+  rendezvous(b->wbar[2 * w + 1], b->wave_active[w]);
+  return res;
+}
+inline unsigned long long lane_active_mask() {
+  Block* b = cur_block();
+  const int w = wave_id();
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l) {
+    int t = w * 64 + l;
+    if (t < b->nthreads && !b->fibers[t].done) m |= 1ull << l;
+  }
+  return m;
+}
+}  // namespace hipemu
+
+inline void __syncthreads() {
+  hipemu::Block* b = hipemu::cur_block();
+  hipemu::rendezvous(b->bar, b->active);
+}
+inline unsigned long long __ballot(int pred) {
+  const unsigned long long act = hipemu::lane_active_mask();
+  return hipemu::wave_collective(pred ? 1ull : 0ull, [&](const unsigned long long* s) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+      if (((act >> l) & 1) && s[l]) m |= 1ull << l;
+    return m;
+  });
+}
+template <class T>
+inline T emu_shfl_generic(T v, int src_lane) {
+  static_assert(sizeof(T) <= 8, "shfl type too wide");
+  unsigned long long bits = 0;
+  std::memcpy(&bits, &v, sizeof(T));
+  const int me = hipemu::lane_id();
+  unsigned long long r = hipemu::wave_collective(bits, [&](const unsigned long long* s) {
+    int sl = src_lane;
+    if (sl < 0 || sl > 63) sl = me;
+    return s[sl];
+  });
+  T out;
+  std::memcpy(&out, &r, sizeof(T));
+  return out;
+}
+template <class T> inline T __shfl(T v, int src, int width = 64) {
+  const int me = hipemu::lane_id();
+  const int base = me & ~(width - 1);
+  return emu_shfl_generic(v, base + (src & (width - 1)));
+}
+template <class T> inline T __shfl_xor(T v, int mask, int width = 64) {
+  const int me = hipemu::lane_id();
+  int src = me ^ mask;
+  if ((src & ~(width - 1)) != (me & ~(width - 1))) src = me;
+  return emu_shfl_generic(v, src);
+}
+template <class T> inline T __shfl_up(T v, unsigned delta, int width = 64) {
+  const int me = hipemu::lane_id();
+  int src = me - (int)delta;
+  if (src < (me & ~(width - 1))) src = me;
+  return emu_shfl_generic(v, src);
+}
+template <class T> inline T __shfl_down(T v, unsigned delta, int width = 64) {
+  const int me = hipemu::lane_id();
+  int src = me + (int)delta;
+  if (src > ((me & ~(width - 1)) + width - 1)) src = me;
+  return emu_shfl_generic(v, src);
+}
+
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+inline int __float2int_rn(float v) { return (int)lrintf(v); }
+inline float __fdiv_rn(float a, float b) { return a / b; }
+inline float __fmul_rn(float a, float b) { return a * b; }
+inline float __fadd_rn(float a, float b) { return a + b; }
+inline float __fsub_rn(float a, float b) { return a - b; }
+inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+template <class T> inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <class T> inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+template <class T> inline T atomicAnd(T* p, T v) { return __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
+template <class T> inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+template <class T> inline T atomicCAS(T* p, T cmp, T v) {
+  __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+  return cmp;
+}
+template <class T> inline T atomicMax(T* p, T v) {
+  T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+template <class T> inline T atomicMin(T* p, T v) {
+  T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __threadfence_block() {}
+
+// ------------------------------------------------------------------ host runtime
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
+typedef struct emu_stream* hipStream_t;
+typedef struct emu_event { std::chrono::steady_clock::time_point t; }* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
+                     hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipHostMallocDefault = 0, hipStreamNonBlocking = 1 };
+
+inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipError(emu)"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) {
+  void* q = nullptr;
+  if (posix_memalign(&q, 256, n ? n : 1)) return hipErrorOutOfMemory;
+  *p = (T*)q;
+  return hipSuccess;
+}
+template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = nullptr) {
+  for (size_t y = 0; y < h; ++y) std::memcpy((char*)d + y * dp, (const char*)s + y * sp, w);
+  return hipSuccess;
+}
+inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return hipSuccess;
+}
+
+template <class K, class... Args>
+inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t /*stream*/,
+                               Args... args) {
+  hipemu::launch(grid, block, [=]() { kernel(args...); });
+}
+
+#ifdef HIP_EMU_IMPLEMENTATION
+thread_local emu_uint3 threadIdx, blockIdx;
+thread_local dim3 blockDim, gridDim;
+namespace hipemu {
+thread_local Block* g_blk = nullptr;
+
+void yield_to_scheduler() {
+  Block* b = cur_block();
+  Fiber* f = b->cur;
+  swapcontext(&f->ctx, &b->sched);
+}
+
+static void fiber_entry() {
+  Block* b = cur_block();
+  Fiber* f = b->cur;
+  b->body();
+  f->done = true;
+  // leaving work-items stop participating in barriers / collectives
+  --b->active;
+  const int w = f->tid >> 6;
+  --b->wave_active[w];
+  auto release = [&](Rendezvous& r, int act) {
+    if (act > 0 && r.arrived >= act) { r.arrived = 0; ++r.gen; ++b->phase; }
+  };
+  release(b->bar, b->active);
+  release(b->wbar[2 * w], b->wave_active[w]);
+  release(b->wbar[2 * w + 1], b->wave_active[w]);
+  swapcontext(&f->ctx, &b->sched);
+}
+
+static int order_mode() {
+  static int m = -1;
+  if (m < 0) {
+    const char* e = getenv("RGBL_EMU_ORDER");
+    m = !e ? 0 : !strcmp(e, "asc") ? 1 : !strcmp(e, "desc") ? 2 : !strcmp(e, "shuffle") ? 3 : 0;
+  }
+  return m;
+}
+
+void run_block(Block& b, const dim3& block) {
+  const int T = (int)(block.x * block.y * block.z);
+  const size_t STACK = 96 * 1024;
+  if ((int)b.fibers.size() < T) {
+    const size_t old = b.fibers.size();
+    b.fibers.resize(T);
+    for (size_t i = old; i < b.fibers.size(); ++i) b.fibers[i].stack = (char*)malloc(STACK);
+  }
+  b.nthreads = T;
+  b.active = T;
+  const int nw = (T + 63) / 64;
+  b.wave_active.assign(nw, 0);
+  b.wbar.assign(2 * nw, Rendezvous());
+  b.bar = Rendezvous();
+  b.slot.assign((size_t)nw * 64, 0);
+  b.phase = 0;
+  for (int t = 0; t < T; ++t) {
+    Fiber& f = b.fibers[t];
+    f.blk = &b;
+    f.tid = t;
+    f.done = false;
+    f.tidx.x = t % block.x;
+    f.tidx.y = (t / block.x) % block.y;
+    f.tidx.z = t / (block.x * block.y);
+    ++b.wave_active[t >> 6];
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = STACK;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+  }
+  cur_block() = &b;
+  std::vector<int> order(T);
+  unsigned rng = 12345u + blockIdx.x * 977u;
+  while (b.active > 0) {
+    const int mode = order_mode();
+    const bool desc = mode == 2 || (mode == 0 && (b.phase & 1));
+    for (int i = 0; i < T; ++i) order[i] = desc ? T - 1 - i : i;
+    if (mode == 3)
+      for (int i = T - 1; i > 0; --i) { rng = rng * 1664525u + 1013904223u; std::swap(order[i], order[(rng >> 8) % (i + 1)]); }
+    const unsigned phase0 = b.phase;
+    for (int i = 0; i < T; ++i) {
+      Fiber& f = b.fibers[order[i]];
+      if (f.done) continue;
+      b.cur = &f;
+      threadIdx = f.tidx;
+      swapcontext(&b.sched, &f.ctx);
+      if (mode == 0 && b.phase != phase0) break;  // a rendezvous completed: flip the order
+    }
+  }
+  cur_block() = nullptr;
+}
+
+struct Pool {
+  std::mutex launch_mu;  // one launch at a time
+  std::mutex mu;
+  std::condition_variable cv_start, cv_done;
+  std::vector<std::thread> threads;
+  unsigned long long job_id = 0;
+  int running = 0;
+  // current job
+  dim3 grid, block;
+  const std::function<void()>* body = nullptr;
+  std::atomic<size_t> next{0};
+  size_t nblocks = 0;
+
+  void work() {
+    static thread_local Block blk;  // fiber stacks are reused across blocks and launches
+    blk.body = *body;
+    for (;;) {
+      const size_t id = next.fetch_add(1);
+      if (id >= nblocks) break;
+      blockIdx.x = (unsigned)(id % grid.x);
+      blockIdx.y = (unsigned)((id / grid.x) % grid.y);
+      blockIdx.z = (unsigned)(id / ((size_t)grid.x * grid.y));
+      blockDim = block;
+      gridDim = grid;
+      run_block(blk, block);
+    }
+  }
+  void thread_main() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_start.wait(lk, [&] { return job_id != seen; });
+        seen = job_id;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--running == 0) cv_done.notify_all();
+      }
+    }
+  }
+};
+
+void launch(const dim3& grid, const dim3& block, const std::function<void()>& body) {
+  const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+  if (nblocks == 0) return;
+  static Pool* pool = new Pool;  // leaked on purpose: worker threads live until process exit
+  static int nthreads = [] {
+    const char* e = getenv("RGBL_EMU_THREADS");
+    int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    return n < 1 ? 1 : n;
+  }();
+  std::lock_guard<std::mutex> guard(pool->launch_mu);
+  if (pool->threads.empty())
+    for (int i = 0; i < nthreads; ++i) {
+      pool->threads.emplace_back([=] { pool->thread_main(); });
+      pool->threads.back().detach();
+    }
+  {
+    std::lock_guard<std::mutex> lk(pool->mu);
+    pool->grid = grid;
+    pool->block = block;
+    pool->body = &body;
+    pool->nblocks = nblocks;
+    pool->next = 0;
+    pool->running = nthreads;
+    ++pool->job_id;
+  }
+  pool->cv_start.notify_all();
+  std::unique_lock<std::mutex> lk(pool->mu);
+  pool->cv_done.wait(lk, [&] { return pool->running == 0; });
+}
+}  // namespace hipemu
+#endif  // HIP_EMU_IMPLEMENTATION
