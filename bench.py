@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""bench.py — RGB-L front-end throughput (extract + depth + match) on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic KITTI-resolution RGB-L input that is
+already resident in HBM: ORB extraction (pyramid, FAST, quad-tree, orientation, blur, rBRIEF) of B frames,
+LiDAR depth (projection, inverse dilation, keypoint gather) of the B scans, Hamming brute-force matching
+of every frame against its successor.  Workload = BASELINE.json configs[1] (KITTI-00 RGB-L, nFeatures 2000,
+1241x376, 8 levels, FAST 12/7, InverseDilation Diamond-5); `--workload 4k` selects configs[4].
+
+Launch contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver starts it under
+torch.distributed.run with one rank per GPU (backend nccl == RCCL).  Frames / sequences shard over the
+ranks with no data-path collective; the only communication is the gather of the variable-length
+keypoint/descriptor/depth records to rank 0 at the end of every step (weak scaling).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (w, h, nfeatures, lidar azimuth steps, default batch)
+    "kitti": (1241, 376, 2000, 1900, 64),
+    "4k": (3840, 2160, 8000, 4096, 8),
+}
+LEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 12, 7
+
+
+def level_sizes(w, h):
+    inv = [np.float32(1.0)]
+    sc = np.float32(1.0)
+    for _ in range(1, LEVELS):
+        sc = np.float32(sc * np.float32(SCALE))
+        inv.append(np.float32(1.0) / sc)
+    return [(int(np.rint(np.float32(w) * s)), int(np.rint(np.float32(h) * s))) for s in inv]
+
+
+def algorithmic_bytes(kernel, w, h, n_points, k_per_frame):
+    """Compulsory bytes of ONE frame for one kernel."""
+    px = [a * b for a, b in level_sizes(w, h)]
+    sp = sum(px)
+    table = {
+        "k_resize_linear": (sp - px[-1]) + (sp - px[0]),          # read levels 0..L-2, write levels 1..L-1
+        "k_fast_cells": sp,                                       # every pyramid pixel once
+        "k_gauss7": 2 * sp,                                       # read + write
+        "k_octree": 4 * 2 * k_per_frame * 5,                      # candidate keys in/out (small, latency bound)
+        "k_orient_brief": 60 * k_per_frame,                       # 32 B descriptor + 28 B keypoint out
+        "k_project_index": 16 * n_points,
+        "k_project_write": 16 * n_points + 4 * n_points,
+        "k_inverse_dilate": 8 * w * h,                            # read raw + write processed
+        "k_gather_depth": 12 * k_per_frame,
+        "k_hamming_bf": 32 * 2 * k_per_frame + 8 * k_per_frame,
+    }
+    return table.get(kernel)
+
+
+def cpu_baseline(seq_frames, scans, proj, w, h, nfeatures, budget_s=20.0):
+    """The oracle (CPU port of the reference path), single thread, on a bounded sample of the same workload."""
+    from oracle import oracle_py as O
+    ex = O.Extractor(nfeatures, SCALE, LEVELS, INI_TH, MIN_TH)
+    P = O.make_depth_params(proj)
+    t0 = time.perf_counter()
+    n = 0
+    prev = None
+    stage = [0.0, 0.0, 0.0]
+    for i in range(len(seq_frames)):
+        a = time.perf_counter()
+        kps, desc, _ = ex(seq_frames[i])
+        b = time.perf_counter()
+        kp_xy = np.stack([kps["x"], kps["y"]], 1)
+        O.depth(P, scans[i % len(scans)], w, h, kp_xy, kps["x"], want_maps=False)
+        c = time.perf_counter()
+        if prev is not None:
+            O.hamming_bf(prev, desc)
+        d = time.perf_counter()
+        prev = desc
+        stage[0] += b - a
+        stage[1] += c - b
+        stage[2] += d - c
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return n / dt, n, [s / n * 1e3 for s in stage]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (default: workload specific)")
+    ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from orb_slam3_rgbl_amd import _lib as L
+    from orb_slam3_rgbl_amd import frontend as F
+    from orb_slam3_rgbl_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w, h, nfeatures, n_az, default_batch = WORKLOADS[args.workload]
+    B = args.batch or default_batch
+    lib = L.load()
+
+    # ---- synthetic input, one independent sequence per rank (BASELINE configs[3]: sequences shard over GPUs)
+    seq = synth.Sequence(rank, w, h, n_frames=B)
+    frames = np.stack([seq.frame(i) for i in range(B)])
+    n_scans = min(B, 8)
+    scans = [synth.lidar_scan(rank * 1000 + i, n_az=n_az) for i in range(n_scans)]
+    n_points = scans[0].shape[1]
+    cloud = np.stack([scans[i % n_scans] for i in range(B)])  # [B, 4, N]
+    if args.workload == "kitti":
+        K = synth.KITTI_K
+    else:
+        K = synth.KITTI_K.copy()
+        K[0, 0] = K[1, 1] = 718.856 * w / synth.KITTI_W
+        K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    proj = F.projection_matrix(K, synth.KITTI_TR, lib)
+
+    ex = F.ORBextractor(nfeatures, SCALE, LEVELS, INI_TH, MIN_TH, w, h, max_batch=B, device=local_rank, lib=lib)
+    cap = ex.max_keypoints
+    dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=cap, max_batch=B, device=local_rank, lib=lib)
+    mt = F.ORBmatcher(0.6, False, device=local_rank, lib=lib)
+
+    stream = torch.cuda.current_stream(dev)
+    sptr = C.c_void_p(stream.cuda_stream)
+    L.check(lib, lib.rgbl_extractor_set_stream(ex.h, sptr))
+    L.check(lib, lib.rgbl_depth_set_stream(dm.h, sptr))
+    L.check(lib, lib.rgbl_matcher_set_stream(mt.h, sptr))
+
+    d_imgs = torch.from_numpy(frames).to(dev)
+    d_cloud = torch.from_numpy(cloud).to(dev)
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)       # rgbl_keypoint records (28 B)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_mono = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_depth = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+    d_uright = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+    pair_a = torch.arange(B, dtype=torch.int32, device=dev)
+    pair_b = (pair_a + 1) % B
+    d_bi = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    d_bd = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    d_sd = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    gather_buf = None
+    if world > 1:
+        rec = cap * (28 + 32 + 8) + 4
+        send = torch.zeros((B, rec), dtype=torch.uint8, device=dev)
+        gather_buf = [torch.zeros_like(send) for _ in range(world)] if rank == 0 else None
+
+    def p(t):
+        return C.c_void_p(t.data_ptr())
+
+    def step():
+        L.check(lib, lib.rgbl_extract_batch_device(ex.h, p(d_imgs), B, w, h, w, w * h, 0, 0, p(d_kp), p(d_desc), cap,
+                                                   p(d_n), p(d_mono)))
+        L.check(lib, lib.rgbl_depth_batch_device(dm.h, p(d_cloud), B, n_points, n_points, 4 * n_points, w, h, p(d_kp),
+                                                 p(d_n), cap, None, p(d_depth), p(d_uright), None))
+        L.check(lib, lib.rgbl_hamming_bf_batch_device(mt.h, p(d_desc), p(d_n), cap, p(pair_a), p(pair_b), B, p(d_bi),
+                                                      p(d_bd), p(d_sd)))
+        if world > 1:
+            # the one exchange of the path: variable-length records to rank 0 (padded to cap, counts in front)
+            send[:, :4] = d_n.view(torch.uint8).view(B, 4)
+            send[:, 4:4 + cap * 28] = d_kp.view(torch.uint8).view(B, cap * 28)
+            send[:, 4 + cap * 28:4 + cap * 60] = d_desc.view(B, cap * 32)
+            send[:, 4 + cap * 60:4 + cap * 64] = d_depth.view(torch.uint8).view(B, cap * 4)
+            send[:, 4 + cap * 64:] = d_uright.view(torch.uint8).view(B, cap * 4)
+            dist.gather(send, gather_buf, dst=0)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        L.check(lib, lib.rgbl_extractor_sync(ex.h))  # also surfaces device-side overflow flags
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    sync_all()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    k_mean = float(d_n.float().mean().item())
+
+    # ---- rank 0 at N == 1: roofline of the dominant kernel (HIP events on the launch stream) + CPU baseline
+    roofline = None
+    cpu = None
+    kernels = {}
+    if rank == 0:
+        ex.profile(True); dm.profile(True); mt.profile(True)
+        prof_steps = 3
+        for _ in range(prof_steps):
+            step()
+        sync_all()
+        for src in (ex.profile_read(), dm.profile_read(), mt.profile_read()):
+            kernels.update(src)
+        ex.profile(False); dm.profile(False); mt.profile(False)
+        total_ms = sum(v[0] for v in kernels.values())
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        ms_sum, launches = kernels[dom]
+        per_step_ms = ms_sum / prof_steps                      # all launches of that kernel in one step
+        per_launch_ms = ms_sum / max(launches, 1)
+        ab = algorithmic_bytes(dom, w, h, n_points, k_mean)
+        achieved = (ab * B) / (per_step_ms * 1e-3) / 1e9 if ab else None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
+                    "avg_launch_ms": per_launch_ms, "launches_per_step": launches / prof_steps,
+                    "algorithmic_bytes_per_frame": ab, "frames_per_launch": B,
+                    "kernel_share_of_gpu_time": ms_sum / total_ms if total_ms else None,
+                    "kernels_ms_per_step": {k: v[0] / prof_steps for k, v in sorted(kernels.items())}}
+        if world == 1 and not args.no_cpu_baseline:
+            n_cpu = min(B, 256)
+            fps, n_done, stage_ms = cpu_baseline(frames[:n_cpu], scans, proj, w, h, nfeatures, args.cpu_budget)
+            cpu = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "%d synthetic %dx%d frames + scans, extract+depth+match, oracle/ (CPU restatement of the "
+                             "reference path, g++ -O2, 1 thread = the reference's one-extractor-thread-per-image model)"
+                             % (n_done, w, h),
+                   "ms_per_frame": {"extract": stage_ms[0], "depth": stage_ms[1], "match": stage_ms[2]},
+                   "host_cores_available": os.cpu_count()}
+
+    if rank == 0:
+        total_frames = world * B * args.steps
+        out = {
+            "metric": "RGB-L front-end frames/sec (extract+depth+match)",
+            "value": total_frames / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "KITTI-00 RGB-L cfg2 (synthetic stand-in)" if args.workload == "kitti"
+                       else "4K synthetic cfg5", "image": [w, h], "nfeatures": nfeatures, "levels": LEVELS,
+                       "lidar_points": n_points, "frames_per_gpu_per_step": B, "keypoints_per_frame": k_mean,
+                       "match": "Hamming brute force, frame i vs i+1", "upsampling": "InverseDilation Diamond 5",
+                       "inputs": "resident in HBM", "parallelism": "frames/sequences sharded, %d rank(s)" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,41 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+TESTS = os.path.dirname(os.path.abspath(__file__))
+if TESTS not in sys.path:
+    sys.path.insert(0, TESTS)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle_py
+    oracle_py.build()
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def emu_lib(oracle):
+    """The kernel sources compiled against the CPU SIMT emulator (test infrastructure, see tests/emu)."""
+    from orb_slam3_rgbl_amd import _lib
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "orb_slam3_rgbl_amd", "csrc"), "emu"])
+    return _lib.bind(os.path.join(TESTS, "_build", "librgbl_frontend_emu.so"))
+
+
+@pytest.fixture(scope="session")
+def gpu_lib(oracle):
+    """The product library on a real device. Fails loudly (no fallback) if it is missing or no GPU is visible."""
+    from orb_slam3_rgbl_amd import _lib
+    lib = _lib.load()
+    assert lib.rgbl_backend() == b"hip:gfx950"
+    assert lib.rgbl_device_count() >= 1, "no HIP device visible: GPU tests must not silently pass"
+    return lib

@@ -1,0 +1,293 @@
+"""Parity checks shared by the GPU tests (product library on a real MI355X, `-m gpu`) and by the CPU
+tests that run the same kernel sources under the SIMT emulator.  Every check compares the HIP path,
+called through the C ABI, with the CPU oracle on identical seeded inputs.  Integer / byte / index results
+must be bit-exact; float results are compared bit-for-bit as well unless a tolerance is stated."""
+import numpy as np
+
+from oracle import oracle_py as O
+from orb_slam3_rgbl_amd import frontend as F
+from orb_slam3_rgbl_amd import synth
+
+KP_FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def assert_keypoints_equal(kps, okps, what=""):
+    assert len(kps) == len(okps), "%s: %d keypoints vs oracle %d" % (what, len(kps), len(okps))
+    for f in KP_FIELDS:
+        assert np.array_equal(bits(kps[f]), bits(okps[f])), "%s: keypoint field %s differs" % (what, f)
+
+
+def check_extractor(lib, w, h, nfeatures, frames=(0,), ini=12, mn=7, nlevels=8, seq=0, lapping=(0, 0), stages=False):
+    ex = F.ORBextractor(nfeatures, 1.2, nlevels, ini, mn, w, h, lib=lib)
+    orc = O.Extractor(nfeatures, 1.2, nlevels, ini, mn)
+    t = orc.tables()
+    for k, a in (("scale", ex.mvScaleFactor), ("inv_scale", ex.mvInvScaleFactor), ("sigma2", ex.mvLevelSigma2),
+                 ("inv_sigma2", ex.mvInvLevelSigma2), ("per_level", ex.mnFeaturesPerLevel), ("umax", ex.umax)):
+        assert np.array_equal(bits(t[k]), bits(a)), k
+    s = synth.Sequence(seq, w, h, n_frames=max(frames) + 1)
+    total = 0
+    for fr in frames:
+        img = s.frame(fr)
+        kps, desc, mono = ex(img, None, lapping)
+        okps, odesc, omono = orc(img, lapping)
+        assert_keypoints_equal(kps, okps, "frame %d" % fr)
+        assert np.array_equal(desc, odesc), "frame %d: descriptors differ" % fr
+        assert mono == omono, "monoIndex %d vs %d" % (mono, omono)
+        total += len(kps)
+        if stages:
+            for l in range(nlevels):
+                assert np.array_equal(ex.image_pyramid(l), orc.level_image(l)), "pyramid level %d" % l
+                assert np.array_equal(ex.image_pyramid(l, with_border=True), orc.level_bordered(l)), "border %d" % l
+                if len(orc.level_keypoints(l)):
+                    assert np.array_equal(ex.image_pyramid(l, blurred=True), orc.level_blurred(l)), "blur level %d" % l
+                c, oc = ex.level_candidates(l), orc.level_candidates(l)
+                assert len(c) == len(oc), "level %d: %d candidates vs %d" % (l, len(c), len(oc))
+                for f in ("x", "y", "response"):
+                    assert np.array_equal(c[f], oc[f]), "level %d candidate %s" % (l, f)
+    ex.close()
+    return total
+
+
+def check_extractor_batch(lib, w, h, nfeatures, batch, ini=12, mn=7, seq=1):
+    """The batched entry point must give, frame by frame, what the single-frame entry point gives."""
+    ex = F.ORBextractor(nfeatures, 1.2, 8, ini, mn, w, h, max_batch=batch, lib=lib)
+    orc = O.Extractor(nfeatures, 1.2, 8, ini, mn)
+    s = synth.Sequence(seq, w, h, n_frames=batch)
+    imgs = np.stack([s.frame(i) for i in range(batch)])
+    res = ex.extract_batch(imgs)
+    for i, (kps, desc, mono) in enumerate(res):
+        okps, odesc, omono = orc(imgs[i])
+        assert_keypoints_equal(kps, okps, "batch frame %d" % i)
+        assert np.array_equal(desc, odesc)
+        assert mono == omono
+    ex.close()
+
+
+def check_extractor_edge_cases(lib, w=160, h=120):
+    ex = F.ORBextractor(300, 1.2, 4, 20, 7, w, h, lib=lib)
+    orc = O.Extractor(300, 1.2, 4, 20, 7)
+    # empty image -> -1 (ORBextractor.cc:1090-1091)
+    kps, desc, mono = ex(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(kps) == 0
+    # constant image -> no corners at all
+    flat = np.full((h, w), 77, np.uint8)
+    kps, desc, mono = ex(flat)
+    assert len(kps) == 0 and mono == 0
+    assert len(orc(flat)[0]) == 0
+    # low-contrast texture: only the minThFAST fallback fires in most cells
+    rng = np.random.default_rng(5)
+    low = (100 + 9 * (rng.random((h, w)) > 0.97)).astype(np.uint8)
+    kps, desc, mono = ex(low)
+    okps, odesc, omono = orc(low)
+    assert_keypoints_equal(kps, okps, "low contrast")
+    assert np.array_equal(desc, odesc)
+    # saturated checkerboard: plateaus of equal scores (strict NMS suppresses both neighbours)
+    yy, xx = np.mgrid[0:h, 0:w]
+    chk = (((yy // 6) + (xx // 6)) % 2 * 255).astype(np.uint8)
+    kps, desc, mono = ex(chk)
+    okps, odesc, omono = orc(chk)
+    assert_keypoints_equal(kps, okps, "checkerboard")
+    assert np.array_equal(desc, odesc)
+    # non-contiguous rows (stride > width)
+    big = np.zeros((h, w + 37), np.uint8)
+    img = synth.Sequence(9, w, h, 1).frame(0)
+    big[:, :w] = img
+    kps, desc, mono = ex(big[:, :w])
+    okps, odesc, omono = orc(img)
+    assert_keypoints_equal(kps, okps, "strided")
+    assert np.array_equal(desc, odesc)
+    ex.close()
+
+
+def kitti_projection(lib):
+    proj = F.projection_matrix(synth.KITTI_K, synth.KITTI_TR, lib)
+    assert np.array_equal(bits(proj), bits(O.projection_matrix(synth.KITTI_K, synth.KITTI_TR)))
+    return proj
+
+
+def check_depth(lib, method, w=synth.KITTI_W, h=synth.KITTI_H, seed=0, n_az=1900, kernel=(F.KERNEL_DIAMOND, 5, 7),
+                n_kp=1500):
+    proj = kitti_projection(lib)
+    if w != synth.KITTI_W:  # rescale the principal point so that the scan still hits the image
+        K = synth.KITTI_K.copy()
+        K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+        K[0, 0] = K[1, 1] = 718.856 * w / synth.KITTI_W
+        proj = F.projection_matrix(K, synth.KITTI_TR, lib)
+    cloud = synth.lidar_scan(seed, n_az=n_az)
+    rng = np.random.default_rng(seed + 17)
+    kp_xy = np.stack([rng.uniform(19, w - 20, n_kp), rng.uniform(19, h - 20, n_kp)], 1).astype(np.float32)
+    kp_xy[: n_kp // 2] = np.floor(kp_xy[: n_kp // 2])  # level-0 keypoints are integers, higher levels are not
+    kpun = kp_xy.copy()
+    kpun[:, 0] += rng.uniform(-1, 1, n_kp).astype(np.float32)
+    shape, ku, kv = kernel
+    dm = F.DepthModule(proj, w, h, method=method, kernel_type=shape, kernel_size_u=ku, kernel_size_v=kv,
+                       max_points=max(cloud.shape[1], 1), max_keypoints=max(n_kp, 1), lib=lib)
+    dm.CalculateDepthFromPcd(kp_xy, kpun, cloud, w, h)
+    ok = O.structuring_element(shape, ku, ku if shape == F.KERNEL_DIAMOND else kv)
+    P = O.make_depth_params(proj, method=method, kernel=ok)
+    d, ur, raw, proc = O.depth(P, cloud, w, h, kp_xy, kpun[:, 0])
+    # projection + ordered scatter: bit-exact (stated tolerance in BASELINE.md is 1e-6 rel; we demand 0)
+    assert np.array_equal(bits(dm.RawDepthMap), bits(raw)), "RawDepthMap"
+    assert (raw > 0).sum() > 100
+    if dm.ProcessedDepthMap is not None:
+        a, b = dm.ProcessedDepthMap, proc
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.array_equal(bits(np.nan_to_num(a)), bits(np.nan_to_num(b))), "ProcessedDepthMap"
+    assert np.array_equal(bits(dm.mvDepth), bits(d)), "mvDepth"
+    assert np.array_equal(bits(dm.mvuRight), bits(ur)), "mvuRight"
+    n_valid = int((d > 0).sum())
+    dm.close()
+    return n_valid
+
+
+def check_depth_edge_cases(lib, w=96, h=64):
+    K = np.array([[80, 0, w / 2, 0], [0, 80, h / 2, 0], [0, 0, 1, 0]], np.float32)
+    Tr = np.eye(4, dtype=np.float32)  # camera frame == lidar frame: z forward
+    proj = F.projection_matrix(K, Tr, lib)
+    dm = F.DepthModule(proj, w, h, max_points=64, max_keypoints=16, lib=lib)
+    P = O.make_depth_params(proj)
+    kp = np.array([[48, 32], [10.7, 5.2], [0.5, 0.5]], np.float32)
+
+    def run(cloud):
+        dm.CalculateDepthFromPcd(kp, kp, cloud, w, h)
+        d, ur, raw, proc = O.depth(P, cloud, w, h, kp, kp[:, 0])
+        assert np.array_equal(bits(dm.RawDepthMap), bits(raw))
+        assert np.array_equal(bits(dm.ProcessedDepthMap), bits(proc))
+        assert np.array_equal(bits(dm.mvDepth), bits(d)) and np.array_equal(bits(dm.mvuRight), bits(ur))
+        return raw, d
+
+    # three points on one pixel: the LAST one wins, not the nearest (DepthModule.cc:123-137)
+    c = np.array([[0, 0, 0], [0, 0, 0], [30, 10, 20], [1, 1, 1]], np.float32)
+    raw, d = run(c)
+    assert raw[32, 48] == 20.0 and d[0] > 0
+    # rejected: z <= min_dist, z >= max_dist, behind the camera, u exactly 0
+    c = np.array([[0, 0, 0, -6.0], [0, 0, 0, 0], [5.0, 200.0, -10.0, 10.0], [1, 1, 1, 1]], np.float32)
+    raw, d = run(c)
+    assert (raw > 0).sum() == 0 and (d == -1).all()
+    # depth > max_dist - 1 vanishes in the inverse dilation (TOZERO_INV), 199.0 survives
+    c = np.array([[0, 20.0], [0, 0], [199.5, 199.0], [1, 1]], np.float32)
+    raw, d = run(c)
+    assert (raw > 0).sum() == 2
+    # empty scan
+    raw, d = run(np.zeros((4, 0), np.float32))
+    assert (d == -1).all()
+    # no keypoints
+    dm.CalculateDepthFromPcd(np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), c, w, h)
+    assert len(dm.mvDepth) == 0
+    dm.close()
+
+
+def check_matcher_bf(lib, na=777, nb=700, seed=3):
+    m = F.ORBmatcher(0.6, False, lib=lib)
+    a = synth.descriptors(na, seed)
+    b, _ = synth.perturbed_descriptors(np.resize(a, (max(nb, 1), 32)), seed=seed + 1)
+    b = b[:nb]
+    bi, bd, sd = m.BruteForce(a, b)
+    obi, obd, osd = O.hamming_bf(a, b)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd) and np.array_equal(sd, osd)
+    for i in range(0, min(na, nb), 97):
+        assert m.DescriptorDistance(a[i], b[i]) == O.descriptor_distance(a[i], b[i])
+    m.close()
+
+
+def check_matcher_known_answers(lib):
+    m = F.ORBmatcher(0.6, False, lib=lib)
+    z = np.zeros((1, 32), np.uint8)
+    o = np.full((1, 32), 255, np.uint8)
+    assert m.DescriptorDistance(z[0], o[0]) == 256 and m.DescriptorDistance(z[0], z[0]) == 0
+    # duplicates in the train set: the FIRST minimum wins (strict '<'), second-best equals best
+    train = np.concatenate([o, z, z, o])
+    bi, bd, sd = m.BruteForce(z, train)
+    assert (bi[0], bd[0], sd[0]) == (1, 0, 0)
+    # single-bit flips
+    for bit in (0, 7, 8, 255):
+        t = z.copy()
+        t[0, bit // 8] = 1 << (bit % 8)
+        bi, bd, sd = m.BruteForce(t, np.concatenate([o, z]))
+        assert (bi[0], bd[0], sd[0]) == (1, 1, 255)
+    # empty train set: nothing found
+    bi, bd, sd = m.BruteForce(z, np.zeros((0, 32), np.uint8))
+    assert (bi[0], bd[0], sd[0]) == (-1, 256, 256)
+    m.close()
+
+
+def make_triangulation_case(n=1500, seed=11, n_nodes=100):
+    rng = np.random.default_rng(seed)
+    a = synth.descriptors(n, seed)
+    b, perm = synth.perturbed_descriptors(a, flip_p=0.04, seed=seed + 1)
+    # a few exact duplicates in image 2 to exercise "ties -> later candidate wins"
+    dup = rng.integers(0, n, 40)
+    b[dup] = b[(dup + 1) % n]
+    key1 = (a[:, 0].astype(np.int64) * 131 + a[:, 1] * 31 + a[:, 2]) % n_nodes
+    key2 = key1[perm]  # a feature of image 2 falls into the node of the feature it was derived from
+    key2[dup] = key2[(dup + 1) % n]
+
+    def csr(key):
+        order = np.argsort(key, kind="stable").astype(np.int32)
+        ids, cnt = np.unique(key, return_counts=True)
+        off = np.zeros(len(ids) + 1, np.int32)
+        off[1:] = np.cumsum(cnt)
+        return ids.astype(np.int32), off, order
+
+    xy1 = np.stack([rng.uniform(20, 1200, n), rng.uniform(20, 350, n)], 1).astype(np.float32)
+    disp = rng.uniform(2, 60, n).astype(np.float32)
+    xy2 = xy1[perm].copy()
+    xy2[:, 0] -= disp[perm]
+    xy2[:, 1] += rng.normal(0, 1.2, n).astype(np.float32)  # some pairs violate the epipolar bound
+    oct1 = rng.integers(0, 8, n).astype(np.int32)
+    oct2 = rng.integers(0, 8, n).astype(np.int32)
+    ang1 = rng.uniform(0, 360, n).astype(np.float32)
+    ang2 = (ang1[perm] + rng.normal(0, 25, n)).astype(np.float32) % 360
+    ur1 = np.where(rng.random(n) < 0.5, xy1[:, 0] - 5, -1).astype(np.float32)
+    ur2 = np.where(rng.random(n) < 0.5, xy2[:, 0] - 5, -1).astype(np.float32)
+    mp1 = (rng.random(n) < 0.3).astype(np.uint8)
+    mp2 = (rng.random(n) < 0.3).astype(np.uint8)
+    id1, off1, f1 = csr(key1)
+    id2, off2, f2 = csr(key2)
+    # drop a few nodes from each side so the merge walk has to skip
+    keep1 = rng.random(len(id1)) < 0.9
+    keep2 = rng.random(len(id2)) < 0.9
+
+    def drop(ids, off, feat, keep):
+        nid, noff, nfeat = [], [0], []
+        for i, k in enumerate(keep):
+            if k:
+                nid.append(ids[i])
+                nfeat.extend(feat[off[i]:off[i + 1]])
+                noff.append(len(nfeat))
+        return np.array(nid, np.int32), np.array(noff, np.int32), np.array(nfeat, np.int32)
+
+    id1, off1, f1 = drop(id1, off1, f1, keep1)
+    id2, off2, f2 = drop(id2, off2, f2, keep2)
+    kf1 = dict(desc=a, xy=xy1, octave=oct1, angle=ang1, uright=ur1, has_mp=mp1, node_id=id1, node_off=off1, node_feat=f1)
+    kf2 = dict(desc=b, xy=xy2, octave=oct2, angle=ang2, uright=ur2, has_mp=mp2, node_id=id2, node_off=off2, node_feat=f2)
+    K = np.array([718.856, 718.856, 607.1928, 185.2157], np.float32)
+    R = np.eye(3, dtype=np.float32).reshape(9)
+    t = np.array([-0.54, 0.002, 0.001], np.float32)
+    ep = np.array([900.0, 185.0], np.float32)  # inside the image so the epipole guard rejects some pairs
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    return kf1, kf2, K, R, t, ep, sf, (sf * sf).astype(np.float32)
+
+
+def check_triangulation(lib, n=1500, seed=11):
+    kf1, kf2, K, R, t, ep, sf, s2 = make_triangulation_case(n, seed)
+    total = 0
+    for check_ori in (False, True):
+        m = F.ORBmatcher(0.6, check_ori, lib=lib)
+        Fm = m.fundamental(K, K, R, t)
+        assert np.array_equal(bits(Fm), bits(O.fundamental(K, K, R, t)))
+        for only_stereo in (False, True):
+            for coarse in (False, True):
+                pairs, nm, m12 = m.SearchForTriangulation(kf1, kf2, Fm, ep, sf, s2, only_stereo, coarse)
+                om12, onm = O.search_triangulation(kf1, kf2, Fm, ep, sf, s2, only_stereo, coarse, check_ori)
+                assert np.array_equal(m12, om12), "matches differ (ori=%s stereo=%s coarse=%s)" % (check_ori, only_stereo, coarse)
+                assert nm == onm == len(pairs)
+                total += nm
+        m.close()
+    assert total > 100  # the case must actually produce matches
+    return total

@@ -1,0 +1,62 @@
+"""The same parity checks as tests/test_parity_gpu.py, executed on the CPU by running the kernel SOURCES
+under the SIMT emulator of tests/emu (small sizes).  This checks kernel logic, not the MI355X."""
+import os
+
+import pytest
+
+import parity_checks as pc
+from orb_slam3_rgbl_amd import frontend as F
+
+
+def test_extractor_small(emu_lib):
+    pc.check_extractor(emu_lib, 400, 300, 600, frames=(0, 1), stages=True)
+
+
+def test_extractor_kitti_frame(emu_lib):
+    pc.check_extractor(emu_lib, 1241, 376, 2000, frames=(0,), stages=True)
+
+
+def test_extractor_lapping_and_thresholds(emu_lib):
+    pc.check_extractor(emu_lib, 480, 320, 700, frames=(0,), ini=20, mn=7, seq=5, lapping=(0, 250))
+
+
+def test_extractor_batch(emu_lib):
+    pc.check_extractor_batch(emu_lib, 360, 280, 500, batch=3)
+
+
+def test_extractor_edge_cases(emu_lib):
+    pc.check_extractor_edge_cases(emu_lib)
+
+
+@pytest.mark.parametrize("order", ["asc", "desc", "shuffle"])
+def test_extractor_is_schedule_independent(emu_lib, order):
+    # the emulator resumes work-items in a different order: a missing barrier would show up here
+    os.environ["RGBL_EMU_ORDER"] = order
+    try:
+        pc.check_extractor(emu_lib, 420, 300, 900, frames=(0,), seq=2)
+    finally:
+        os.environ.pop("RGBL_EMU_ORDER", None)
+
+
+@pytest.mark.parametrize("method", [F.UPS_INVERSE_DILATION, F.UPS_AVERAGE_FILTERING, F.UPS_NEAREST_NEIGHBOR_PIXEL])
+def test_depth(emu_lib, method):
+    assert pc.check_depth(emu_lib, method, w=620, h=188, n_az=900, n_kp=400) > 10
+
+
+def test_depth_kernels(emu_lib):
+    for kernel in ((F.KERNEL_RECT, 3, 5), (F.KERNEL_CROSS, 5, 5), (F.KERNEL_ELLIPSE, 7, 5), (F.KERNEL_DIAMOND, 9, 9)):
+        pc.check_depth(emu_lib, F.UPS_INVERSE_DILATION, w=620, h=188, n_az=600, kernel=kernel, seed=3, n_kp=200)
+
+
+def test_depth_edge_cases(emu_lib):
+    pc.check_depth_edge_cases(emu_lib)
+
+
+def test_matcher(emu_lib):
+    pc.check_matcher_known_answers(emu_lib)
+    pc.check_matcher_bf(emu_lib, 300, 280)
+    pc.check_matcher_bf(emu_lib, 1, 33)
+
+
+def test_search_for_triangulation(emu_lib):
+    pc.check_triangulation(emu_lib, 600, seed=11)

@@ -1,0 +1,94 @@
+"""Parity tests proper: the HIP path on a real MI355X, called through the C ABI, against the CPU oracle."""
+import numpy as np
+import pytest
+
+import parity_checks as pc
+from orb_slam3_rgbl_amd import frontend as F
+from orb_slam3_rgbl_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_extractor_kitti_cfg2_bit_exact(gpu_lib):
+    # BASELINE.json configs[1]: KITTI-size frames, nFeatures = 2000, FAST 12/7, bit-exact vs CPU
+    n = pc.check_extractor(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000, frames=range(6), stages=False)
+    assert n > 6 * 1900
+
+
+def test_extractor_stages_kitti(gpu_lib):
+    pc.check_extractor(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000, frames=(0,), seq=2, stages=True)
+
+
+def test_extractor_cfg1_nfeatures_1000(gpu_lib):
+    pc.check_extractor(gpu_lib, synth.KITTI_W, synth.KITTI_H, 1000, frames=(0, 1), seq=3)
+
+
+def test_extractor_stereo_thresholds(gpu_lib):
+    # Examples/Stereo/KITTI00-02.yaml: iniThFAST 20 / minThFAST 7
+    pc.check_extractor(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000, frames=(0, 1), ini=20, mn=7, seq=4)
+
+
+def test_extractor_lapping_area(gpu_lib):
+    # the mono constructor passes vLappingArea = {0, 1000} (Frame.cc:401)
+    pc.check_extractor(gpu_lib, 752, 480, 1000, frames=(0,), seq=5, lapping=(0, 400))
+
+
+def test_extractor_batch_equals_single(gpu_lib):
+    pc.check_extractor_batch(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000, batch=8)
+
+
+def test_extractor_other_shapes(gpu_lib):
+    pc.check_extractor(gpu_lib, 752, 480, 1200, frames=(0,), seq=6, stages=True)      # EuRoC
+    pc.check_extractor(gpu_lib, 640, 480, 1000, frames=(0,), seq=7, nlevels=5)
+    pc.check_extractor(gpu_lib, 1226, 370, 2000, frames=(0,), seq=8)                  # KITTI 04-12
+
+
+def test_extractor_edge_cases(gpu_lib):
+    pc.check_extractor_edge_cases(gpu_lib)
+
+
+def test_extractor_4k_cfg5(gpu_lib):
+    # BASELINE.json configs[4]: 3840x2160, nFeatures = 8000
+    pc.check_extractor(gpu_lib, 3840, 2160, 8000, frames=(0,), seq=9)
+
+
+@pytest.mark.parametrize("method", [F.UPS_INVERSE_DILATION, F.UPS_AVERAGE_FILTERING, F.UPS_NEAREST_NEIGHBOR_PIXEL])
+def test_depth_kitti(gpu_lib, method):
+    assert pc.check_depth(gpu_lib, method) > 50
+
+
+def test_depth_kernels_and_sizes(gpu_lib):
+    for kernel in ((F.KERNEL_RECT, 3, 5), (F.KERNEL_CROSS, 5, 5), (F.KERNEL_ELLIPSE, 7, 5), (F.KERNEL_DIAMOND, 9, 9),
+                   (F.KERNEL_DIAMOND, 3, 3)):
+        pc.check_depth(gpu_lib, F.UPS_INVERSE_DILATION, kernel=kernel, seed=3)
+    pc.check_depth(gpu_lib, F.UPS_INVERSE_DILATION, w=3840, h=2160, n_az=4096, seed=4, n_kp=8000)  # cfg 5: 262144 points
+
+
+def test_depth_edge_cases(gpu_lib):
+    pc.check_depth_edge_cases(gpu_lib)
+
+
+def test_matcher_bf(gpu_lib):
+    pc.check_matcher_known_answers(gpu_lib)
+    pc.check_matcher_bf(gpu_lib, 2000, 2000)
+    pc.check_matcher_bf(gpu_lib, 8000, 8000, seed=5)   # cfg 5
+    pc.check_matcher_bf(gpu_lib, 1, 333)
+    pc.check_matcher_bf(gpu_lib, 257, 1)
+
+
+def test_search_for_triangulation(gpu_lib):
+    pc.check_triangulation(gpu_lib, 2000, seed=11)
+    pc.check_triangulation(gpu_lib, 8000, seed=12)
+
+
+def test_hamming_match_of_consecutive_frames_is_symmetric_property(gpu_lib):
+    # size-independent property at full size: matching A against A gives the identity with distance 0
+    ex = F.ORBextractor(2000, 1.2, 8, 12, 7, synth.KITTI_W, synth.KITTI_H, lib=gpu_lib)
+    kps, desc, _ = ex(synth.Sequence(0).frame(0))
+    m = F.ORBmatcher(lib=gpu_lib)
+    bi, bd, sd = m.BruteForce(desc, desc)
+    assert (bd == 0).all()
+    # identical descriptors can exist: the first one wins
+    first = np.array([np.nonzero((desc == d).all(1))[0][0] for d in desc[:200]])
+    assert np.array_equal(bi[:200], first)
+    ex.close(); m.close()
