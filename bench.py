@@ -107,7 +107,7 @@ def main():
 
     from orb_slam3_rgbl_amd import _lib as L
     from orb_slam3_rgbl_amd import frontend as F
-    from orb_slam3_rgbl_amd import synth
+    from orb_slam3_rgbl_amd import sharding, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -144,11 +144,16 @@ def main():
     dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=cap, max_batch=B, device=local_rank, lib=lib)
     mt = F.ORBmatcher(0.6, False, device=local_rank, lib=lib)
 
-    stream = torch.cuda.current_stream(dev)
-    sptr = C.c_void_p(stream.cuda_stream)
-    L.check(lib, lib.rgbl_extractor_set_stream(ex.h, sptr))
-    L.check(lib, lib.rgbl_depth_set_stream(dm.h, sptr))
-    L.check(lib, lib.rgbl_matcher_set_stream(mt.h, sptr))
+    # Three HIP streams (one per handle): the LiDAR projection / up-sampling does not depend on the keypoints and
+    # overlaps with the extraction; ordering between the handles is expressed with HIP events (rgbl_stream_wait).
+    s_ex = C.c_void_p(lib.rgbl_extractor_stream(ex.h))
+    s_dm = C.c_void_p(lib.rgbl_depth_stream(dm.h))
+    s_mt = C.c_void_p(lib.rgbl_matcher_stream(mt.h))
+    comm_stream = torch.cuda.Stream(dev) if world > 1 else None
+    s_comm = C.c_void_p(comm_stream.cuda_stream) if world > 1 else None
+
+    def wait(waiter, signaler):
+        L.check(lib, lib.rgbl_stream_wait(waiter, signaler))
 
     d_imgs = torch.from_numpy(frames).to(dev)
     d_cloud = torch.from_numpy(cloud).to(dev)
@@ -165,28 +170,33 @@ def main():
     d_sd = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     gather_buf = None
     if world > 1:
-        rec = cap * (28 + 32 + 8) + 4
-        send = torch.zeros((B, rec), dtype=torch.uint8, device=dev)
+        send = torch.zeros((B, sharding.record_bytes(cap)), dtype=torch.uint8, device=dev)
         gather_buf = [torch.zeros_like(send) for _ in range(world)] if rank == 0 else None
 
     def p(t):
         return C.c_void_p(t.data_ptr())
 
     def step():
+        # the consumers of the previous step must be done before the extractor overwrites d_kp / d_desc / d_n
+        wait(s_ex, s_dm)
+        wait(s_ex, s_mt)
+        if world > 1:
+            wait(s_ex, s_comm)
+        L.check(lib, lib.rgbl_depth_project_batch_device(dm.h, p(d_cloud), B, n_points, n_points, 4 * n_points, w, h, None))
         L.check(lib, lib.rgbl_extract_batch_device(ex.h, p(d_imgs), B, w, h, w, w * h, 0, 0, p(d_kp), p(d_desc), cap,
                                                    p(d_n), p(d_mono)))
-        L.check(lib, lib.rgbl_depth_batch_device(dm.h, p(d_cloud), B, n_points, n_points, 4 * n_points, w, h, p(d_kp),
-                                                 p(d_n), cap, None, p(d_depth), p(d_uright), None))
+        wait(s_dm, s_ex)
+        L.check(lib, lib.rgbl_depth_gather_batch_device(dm.h, B, w, h, p(d_kp), p(d_n), cap, None, p(d_depth), p(d_uright)))
+        wait(s_mt, s_ex)
         L.check(lib, lib.rgbl_hamming_bf_batch_device(mt.h, p(d_desc), p(d_n), cap, p(pair_a), p(pair_b), B, p(d_bi),
                                                       p(d_bd), p(d_sd)))
         if world > 1:
             # the one exchange of the path: variable-length records to rank 0 (padded to cap, counts in front)
-            send[:, :4] = d_n.view(torch.uint8).view(B, 4)
-            send[:, 4:4 + cap * 28] = d_kp.view(torch.uint8).view(B, cap * 28)
-            send[:, 4 + cap * 28:4 + cap * 60] = d_desc.view(B, cap * 32)
-            send[:, 4 + cap * 60:4 + cap * 64] = d_depth.view(torch.uint8).view(B, cap * 4)
-            send[:, 4 + cap * 64:] = d_uright.view(torch.uint8).view(B, cap * 4)
-            dist.gather(send, gather_buf, dst=0)
+            wait(s_comm, s_dm)
+            wait(s_comm, s_mt)
+            with torch.cuda.stream(comm_stream):
+                sharding.pack_records(d_n, d_kp, d_desc, d_depth, d_uright, out=send)
+                sharding.gather_records(send, gather_buf, dst=0)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -213,6 +223,31 @@ def main():
         elapsed = float(t.item())
 
     k_mean = float(d_n.float().mean().item())
+
+    # ---- parity spot check of what the timed pipeline produced (two frames against the CPU oracle)
+    spot = None
+    if rank == 0:
+        from oracle import oracle_py as O
+        orc = O.Extractor(nfeatures, SCALE, LEVELS, INI_TH, MIN_TH)
+        P = O.make_depth_params(proj)
+        h_n = d_n.cpu().numpy()
+        ok = True
+        for fi in (0, B - 1):
+            n = int(h_n[fi])
+            kps = d_kp[fi, :n].cpu().numpy().view(np.uint32)
+            okps, odesc, _ = orc(frames[fi])
+            ok &= n == len(okps) and np.array_equal(kps, okps.view(np.uint32).reshape(n, 7))
+            ok &= np.array_equal(d_desc[fi, :n].cpu().numpy(), odesc)
+            od, our, _, _ = O.depth(P, cloud[fi], w, h, np.stack([okps["x"], okps["y"]], 1), okps["x"], want_maps=False)
+            ok &= np.array_equal(d_depth[fi, :n].cpu().numpy().view(np.uint32), od.view(np.uint32))
+            ok &= np.array_equal(d_uright[fi, :n].cpu().numpy().view(np.uint32), our.view(np.uint32))
+            nxt = (fi + 1) % B
+            ndesc = orc(frames[nxt])[1]
+            obi, obd, osd = O.hamming_bf(odesc, ndesc)
+            ok &= np.array_equal(d_bi[fi, :n].cpu().numpy(), obi) and np.array_equal(d_bd[fi, :n].cpu().numpy(), obd)
+            ok &= np.array_equal(d_sd[fi, :n].cpu().numpy(), osd)
+        spot = "bit-exact vs CPU oracle on frames 0 and %d (keypoints, descriptors, depth, uRight, matches)" % (B - 1) if ok \
+            else "MISMATCH vs CPU oracle"
 
     # ---- rank 0 at N == 1: roofline of the dominant kernel (HIP events on the launch stream) + CPU baseline
     roofline = None
@@ -270,6 +305,7 @@ def main():
                        "lidar_points": n_points, "frames_per_gpu_per_step": B, "keypoints_per_frame": k_mean,
                        "match": "Hamming brute force, frame i vs i+1", "upsampling": "InverseDilation Diamond 5",
                        "inputs": "resident in HBM", "parallelism": "frames/sequences sharded, %d rank(s)" % world},
+            "parity_spot_check": spot,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

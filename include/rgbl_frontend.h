@@ -115,6 +115,10 @@ int rgbl_extractor_get_candidates(rgbl_extractor* h, int frame, int level, rgbl_
 
 /* Stream control + per-kernel timing (HIP events on the launch stream) for bench.py. */
 int rgbl_extractor_set_stream(rgbl_extractor* h, void* hip_stream /* hipStream_t, NULL = own */);
+void* rgbl_extractor_stream(rgbl_extractor* h); /* hipStream_t currently used by the handle */
+/* Device-side ordering between handles without a host sync: work enqueued on `waiter_stream` after this call
+ * starts only when everything enqueued on `signaler_stream` before this call has finished (HIP event). */
+int rgbl_stream_wait(void* waiter_stream, void* signaler_stream);
 int rgbl_extractor_profile(rgbl_extractor* h, int enable);
 /* Returns the number of distinct kernels; fills up to cap entries. names[i] points to static storage. */
 int rgbl_extractor_profile_read(rgbl_extractor* h, const char** names, double* total_ms, long* launches,
@@ -176,7 +180,15 @@ int rgbl_depth_batch_device(rgbl_depth* h, const float* d_cloud, int batch, int 
                             size_t cloud_stride, int w, int h_, const rgbl_keypoint* d_kp,
                             const int32_t* d_n, int kp_cap, const float* d_kpun_x, float* d_depth,
                             float* d_uright, float* d_processed);
+/* The two halves of the call above, for overlap: the projection / up-sampling half does not depend on the
+ * keypoints, so it can run on the depth handle's stream while the extractor is still busy on its own. */
+int rgbl_depth_project_batch_device(rgbl_depth* h, const float* d_cloud, int batch, int n, int ld,
+                                    size_t cloud_stride, int w, int h_, float* d_processed);
+int rgbl_depth_gather_batch_device(rgbl_depth* h, int batch, int w, int h_, const rgbl_keypoint* d_kp,
+                                   const int32_t* d_n, int kp_cap, const float* d_kpun_x, float* d_depth,
+                                   float* d_uright);
 int rgbl_depth_sync(rgbl_depth* h);
+void* rgbl_depth_stream(rgbl_depth* h); /* hipStream_t currently used by the handle */
 int rgbl_depth_set_stream(rgbl_depth* h, void* hip_stream);
 int rgbl_depth_profile(rgbl_depth* h, int enable);
 int rgbl_depth_profile_read(rgbl_depth* h, const char** names, double* total_ms, long* launches, int cap);
@@ -189,6 +201,7 @@ int rgbl_matcher_create(int device, rgbl_matcher** out);
 void rgbl_matcher_destroy(rgbl_matcher* h);
 int rgbl_matcher_sync(rgbl_matcher* h);
 int rgbl_matcher_set_stream(rgbl_matcher* h, void* hip_stream);
+void* rgbl_matcher_stream(rgbl_matcher* h);
 int rgbl_matcher_profile(rgbl_matcher* h, int enable);
 int rgbl_matcher_profile_read(rgbl_matcher* h, const char** names, double* total_ms, long* launches, int cap);
 

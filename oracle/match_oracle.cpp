@@ -173,3 +173,16 @@ int orc_search_triangulation(const orc_tri_input* in, int* matches12) {
 }
 
 }  // extern "C"
+
+// std::sort of (key, value) pairs with a comparator that looks at the key only — the literal libstdc++
+// behaviour the quad-tree relies on for nodes with equal (size, UL.x).  Used to pin the product's
+// restatement of the introsort (tests/test_introsort.py).
+#include <algorithm>
+#include <utility>
+extern "C" void orc_std_sort_pairs(uint64_t* key, uint32_t* val, int n) {
+  std::vector<std::pair<uint64_t, uint32_t>> v(n);
+  for (int i = 0; i < n; ++i) v[i] = std::make_pair(key[i], val[i]);
+  std::sort(v.begin(), v.end(),
+            [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a.first < b.first; });
+  for (int i = 0; i < n; ++i) { key[i] = v[i].first; val[i] = v[i].second; }
+}

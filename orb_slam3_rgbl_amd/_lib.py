@@ -78,7 +78,13 @@ SYMBOLS = {
     "rgbl_structuring_element": (_I, [_I, _I, _I, _V]),
     "rgbl_depth_compute": (_I, [_V, _V, _I, _I, _I, _I, _V, _V, _I, _V, _V, _V, _V]),
     "rgbl_depth_batch_device": (_I, [_V, _V, _I, _I, _I, _Z, _I, _I, _V, _V, _I, _V, _V, _V, _V]),
+    "rgbl_depth_project_batch_device": (_I, [_V, _V, _I, _I, _I, _Z, _I, _I, _V]),
+    "rgbl_depth_gather_batch_device": (_I, [_V, _I, _I, _I, _V, _V, _I, _V, _V, _V]),
     "rgbl_depth_sync": (_I, [_V]),
+    "rgbl_depth_stream": (_V, [_V]),
+    "rgbl_extractor_stream": (_V, [_V]),
+    "rgbl_matcher_stream": (_V, [_V]),
+    "rgbl_stream_wait": (_I, [_V, _V]),
     "rgbl_depth_set_stream": (_I, [_V, _V]),
     "rgbl_depth_profile": (_I, [_V, _I]),
     "rgbl_depth_profile_read": (_I, [_V, _V, _V, _V, _I]),

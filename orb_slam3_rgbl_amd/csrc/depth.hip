@@ -238,11 +238,9 @@ int dalloc(rgbl_depth* e, T** p, size_t count) {
   return RGBL_OK;
 }
 
-// kp / kpun given as strided float views
-int enqueue_depth(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w, int h,
-                  const float* kp, int kp_stride, size_t kp_frame, const float* kpun, int un_stride, size_t un_frame,
-                  const int32_t* d_n, int n_fixed, int kmax, float* d_depth, float* d_uright, size_t out_frame,
-                  float* d_processed_out) {
+// Part 1 (independent of the keypoints): projection + ordered scatter + dense up-sampling.
+int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w, int h,
+                 float* d_processed_out) {
   hipStream_t s = e->stream;
   const size_t ms = e->map_stride;
   RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)batch * ms * 2 * sizeof(uint32_t), s));  // idx maps + raw maps
@@ -256,39 +254,47 @@ int enqueue_depth(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld,
                        w, h, e->d_idx, e->d_raw, ms);
     e->timer.end(s);
   }
-  float* proc = e->d_proc;
   const dim3 tiles((w + 63) / 64, (h + 15) / 16, batch);
-  const dim3 kgrid((std::max(kmax, 1) + 255) / 256, batch);
   switch (e->cfg.method) {
     case RGBL_UPS_INVERSE_DILATION:
       e->timer.begin("k_inverse_dilate", s);
       // opt_max_dist * ParamUpsampling_InverseDilation_ScaleFactor; the scale factor is never parsed (1.0)
-      hipLaunchKernelGGL(k_inverse_dilate, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, proc, ms, w, h);
+      hipLaunchKernelGGL(k_inverse_dilate, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, e->d_proc, ms, w, h);
       e->timer.end(s);
       break;
     case RGBL_UPS_AVERAGE_FILTERING:
       e->timer.begin("k_average_filter", s);
-      hipLaunchKernelGGL(k_average_filter, tiles, dim3(256), 0, s, e->cfg.avg_kernel_size, e->d_raw, proc, ms, w, h);
+      hipLaunchKernelGGL(k_average_filter, tiles, dim3(256), 0, s, e->cfg.avg_kernel_size, e->d_raw, e->d_proc, ms, w, h);
       e->timer.end(s);
       break;
     default:
       break;
   }
-  if (kmax > 0) {
-    if (e->cfg.method == RGBL_UPS_NEAREST_NEIGHBOR_PIXEL) {
-      e->timer.begin("k_nn_depth", s);
-      hipLaunchKernelGGL(k_nn_depth, kgrid, dim3(256), 0, s, e->d_raw, ms, w, h, kp, kp_stride, kp_frame, kpun, un_stride,
-                         un_frame, d_n, n_fixed, e->cfg.mbf, e->cfg.nn_search_radius, d_depth, d_uright, out_frame);
-      e->timer.end(s);
-    } else {
-      e->timer.begin("k_gather_depth", s);
-      hipLaunchKernelGGL(k_gather_depth, kgrid, dim3(256), 0, s, proc, ms, w, kp, kp_stride, kp_frame, kpun, un_stride,
-                         un_frame, d_n, n_fixed, e->cfg.mbf, d_depth, d_uright, out_frame);
-      e->timer.end(s);
-    }
-  }
   if (d_processed_out && e->cfg.method != RGBL_UPS_NEAREST_NEIGHBOR_PIXEL)
-    RGBL_HIP(hipMemcpyAsync(d_processed_out, proc, (size_t)batch * ms * sizeof(float), hipMemcpyDeviceToDevice, s));
+    RGBL_HIP(hipMemcpyAsync(d_processed_out, e->d_proc, (size_t)batch * ms * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RGBL_HIP(hipGetLastError());
+  return RGBL_OK;
+}
+
+// Part 2: depth / virtual right coordinate of every keypoint. kp / kpun are strided float views.
+int enqueue_keypoints(rgbl_depth* e, int batch, int w, int h, const float* kp, int kp_stride, size_t kp_frame,
+                      const float* kpun, int un_stride, size_t un_frame, const int32_t* d_n, int n_fixed, int kmax,
+                      float* d_depth, float* d_uright, size_t out_frame) {
+  if (kmax <= 0) return RGBL_OK;
+  hipStream_t s = e->stream;
+  const size_t ms = e->map_stride;
+  const dim3 kgrid((kmax + 255) / 256, batch);
+  if (e->cfg.method == RGBL_UPS_NEAREST_NEIGHBOR_PIXEL) {
+    e->timer.begin("k_nn_depth", s);
+    hipLaunchKernelGGL(k_nn_depth, kgrid, dim3(256), 0, s, e->d_raw, ms, w, h, kp, kp_stride, kp_frame, kpun, un_stride,
+                       un_frame, d_n, n_fixed, e->cfg.mbf, e->cfg.nn_search_radius, d_depth, d_uright, out_frame);
+    e->timer.end(s);
+  } else {
+    e->timer.begin("k_gather_depth", s);
+    hipLaunchKernelGGL(k_gather_depth, kgrid, dim3(256), 0, s, e->d_proc, ms, w, kp, kp_stride, kp_frame, kpun, un_stride,
+                       un_frame, d_n, n_fixed, e->cfg.mbf, d_depth, d_uright, out_frame);
+    e->timer.end(s);
+  }
   RGBL_HIP(hipGetLastError());
   return RGBL_OK;
 }
@@ -414,8 +420,8 @@ int rgbl_depth_compute(rgbl_depth* e, const float* cloud, int n, int ld, int w, 
     RGBL_HIP(hipMemcpyAsync(e->d_kp, kp_xy, sizeof(float) * 2 * k, hipMemcpyHostToDevice, s));
     RGBL_HIP(hipMemcpyAsync(e->d_kpun, kpun_x, sizeof(float) * k, hipMemcpyHostToDevice, s));
   }
-  RGBL_TRY(enqueue_depth(e, e->d_cloud, 1, n, n, 0, w, h, e->d_kp, 2, 0, e->d_kpun, 1, 0, nullptr, k, k, e->d_depth,
-                         e->d_uright, 0, nullptr));
+  RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr));
+  RGBL_TRY(enqueue_keypoints(e, 1, w, h, e->d_kp, 2, 0, e->d_kpun, 1, 0, nullptr, k, k, e->d_depth, e->d_uright, 0));
   if (k > 0) {
     RGBL_HIP(hipMemcpyAsync(out_depth, e->d_depth, sizeof(float) * k, hipMemcpyDeviceToHost, s));
     RGBL_HIP(hipMemcpyAsync(out_uright, e->d_uright, sizeof(float) * k, hipMemcpyDeviceToHost, s));
@@ -428,12 +434,22 @@ int rgbl_depth_compute(rgbl_depth* e, const float* cloud, int n, int ld, int w, 
   return RGBL_OK;
 }
 
-int rgbl_depth_batch_device(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w, int h,
-                            const rgbl_keypoint* d_kp, const int32_t* d_n, int kp_cap, const float* d_kpun_x, float* d_depth,
-                            float* d_uright, float* d_processed) {
-  if (!e || !d_cloud || !d_kp || !d_n || !d_depth || !d_uright) { set_error("null argument"); return RGBL_ERR_INVALID; }
-  if (w != e->cfg.width || h != e->cfg.height || batch < 1 || batch > e->cfg.max_batch || n < 0 || ld < n || kp_cap < 1 ||
+int rgbl_depth_project_batch_device(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w,
+                                    int h, float* d_processed) {
+  if (!e || !d_cloud) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  if (w != e->cfg.width || h != e->cfg.height || batch < 1 || batch > e->cfg.max_batch || n < 0 || ld < n ||
       (batch > 1 && cloud_stride < (size_t)3 * ld + n)) {
+    set_error("depth batch arguments do not match the handle");
+    return RGBL_ERR_INVALID;
+  }
+  RGBL_HIP(hipSetDevice(e->device));
+  return enqueue_maps(e, d_cloud, batch, n, ld, cloud_stride, w, h, d_processed);
+}
+
+int rgbl_depth_gather_batch_device(rgbl_depth* e, int batch, int w, int h, const rgbl_keypoint* d_kp, const int32_t* d_n,
+                                   int kp_cap, const float* d_kpun_x, float* d_depth, float* d_uright) {
+  if (!e || !d_kp || !d_n || !d_depth || !d_uright) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  if (w != e->cfg.width || h != e->cfg.height || batch < 1 || batch > e->cfg.max_batch || kp_cap < 1) {
     set_error("depth batch arguments do not match the handle");
     return RGBL_ERR_INVALID;
   }
@@ -441,10 +457,19 @@ int rgbl_depth_batch_device(rgbl_depth* e, const float* d_cloud, int batch, int 
   const float* kp = reinterpret_cast<const float*>(d_kp);
   const int kstride = (int)(sizeof(rgbl_keypoint) / sizeof(float));
   const float* kpun = d_kpun_x ? d_kpun_x : kp;
-  return enqueue_depth(e, d_cloud, batch, n, ld, cloud_stride, w, h, kp, kstride, (size_t)kp_cap * kstride, kpun,
-                       d_kpun_x ? 1 : kstride, d_kpun_x ? (size_t)kp_cap : (size_t)kp_cap * kstride, d_n, 0, kp_cap, d_depth,
-                       d_uright, (size_t)kp_cap, d_processed);
+  return enqueue_keypoints(e, batch, w, h, kp, kstride, (size_t)kp_cap * kstride, kpun, d_kpun_x ? 1 : kstride,
+                           d_kpun_x ? (size_t)kp_cap : (size_t)kp_cap * kstride, d_n, 0, kp_cap, d_depth, d_uright,
+                           (size_t)kp_cap);
 }
+
+int rgbl_depth_batch_device(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w, int h,
+                            const rgbl_keypoint* d_kp, const int32_t* d_n, int kp_cap, const float* d_kpun_x, float* d_depth,
+                            float* d_uright, float* d_processed) {
+  RGBL_TRY(rgbl_depth_project_batch_device(e, d_cloud, batch, n, ld, cloud_stride, w, h, d_processed));
+  return rgbl_depth_gather_batch_device(e, batch, w, h, d_kp, d_n, kp_cap, d_kpun_x, d_depth, d_uright);
+}
+
+void* rgbl_depth_stream(rgbl_depth* e) { return e ? (void*)e->stream : nullptr; }
 
 int rgbl_depth_sync(rgbl_depth* e) {
   if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }

@@ -590,6 +590,19 @@ int rgbl_extractor_set_stream(rgbl_extractor* e, void* hip_stream) {
   return RGBL_OK;
 }
 
+void* rgbl_extractor_stream(rgbl_extractor* e) { return e ? (void*)e->stream : nullptr; }
+
+int rgbl_stream_wait(void* waiter, void* signaler) {
+  // everything enqueued on `signaler` so far must finish before work enqueued on `waiter` after this call starts
+  if (waiter == signaler) return RGBL_OK;
+  hipEvent_t ev;
+  RGBL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  RGBL_HIP(hipEventRecord(ev, (hipStream_t)signaler));
+  RGBL_HIP(hipStreamWaitEvent((hipStream_t)waiter, ev, 0));
+  RGBL_HIP(hipEventDestroy(ev));  // released by the runtime once the recorded work has completed
+  return RGBL_OK;
+}
+
 int rgbl_extractor_profile(rgbl_extractor* e, int enable) {
   if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipStreamSynchronize(e->stream));
@@ -617,3 +630,8 @@ void rgbl_test_std_sort(uint64_t* key, uint32_t* val, int n) { rgbl::std_sort_re
 #endif
 
 }  // extern "C"
+
+#ifdef RGBL_EMU
+// test hooks (emulation build only)
+extern "C" void rgbl_test_sincosf(float x, float* s, float* c) { *s = rgbl::glibc_sinf(x); *c = rgbl::glibc_cosf(x); }
+#endif

@@ -189,6 +189,7 @@ int rgbl_matcher_set_stream(rgbl_matcher* m, void* hip_stream) {
   m->stream = hip_stream ? (hipStream_t)hip_stream : m->own_stream;
   return RGBL_OK;
 }
+void* rgbl_matcher_stream(rgbl_matcher* m) { return m ? (void*)m->stream : nullptr; }
 int rgbl_matcher_profile(rgbl_matcher* m, int enable) {
   if (!m) { set_error("null handle"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipStreamSynchronize(m->stream));

@@ -1,0 +1,70 @@
+"""The C-ABI library loads and exports every symbol include/rgbl_frontend.h declares (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "rgbl_frontend.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rgbl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    from orb_slam3_rgbl_amd import _lib
+    assert declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_product_library_exports_every_declared_symbol():
+    from orb_slam3_rgbl_amd import _lib
+    import __graft_entry__ as g
+    if not os.path.exists(_lib.LIB_PATH):
+        g.build()
+    lib = _lib.bind(_lib.LIB_PATH)  # raises AttributeError on a missing export
+    for name in declared_symbols():
+        assert hasattr(lib, name)
+    assert lib.rgbl_backend() == b"hip:gfx950"
+
+
+def test_no_cpu_fallback_without_a_device():
+    """Without a GPU the product library must refuse to create handles instead of computing on the host."""
+    from orb_slam3_rgbl_amd import _lib
+    lib = _lib.load()
+    if lib.rgbl_device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    cfg = _lib.ExtractorCfg(1000, 1.2, 8, 20, 7, 640, 480, 1)
+    h = C.c_void_p()
+    assert lib.rgbl_extractor_create(C.byref(cfg), 0, C.byref(h)) == _lib.ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.rgbl_last_error()
+    m = C.c_void_p()
+    assert lib.rgbl_matcher_create(0, C.byref(m)) == _lib.ERR_NO_DEVICE
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "orb_slam3_rgbl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".cc", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle_py" not in txt and "liborbslam_oracle" not in txt and "oracle/" not in txt.replace("oracle/cvcompat", ""), f
+
+
+def test_invalid_arguments_are_reported_not_thrown(emu_lib):
+    from orb_slam3_rgbl_amd import _lib
+    lib = emu_lib
+    h = C.c_void_p()
+    bad = _lib.ExtractorCfg(1000, 1.2, 40, 20, 7, 640, 480, 1)  # too many levels
+    assert lib.rgbl_extractor_create(C.byref(bad), 0, C.byref(h)) == _lib.ERR_INVALID
+    portrait = _lib.ExtractorCfg(1000, 1.2, 4, 20, 7, 200, 900, 1)  # round(w/h) == 0 roots: the reference divides by zero
+    assert lib.rgbl_extractor_create(C.byref(portrait), 0, C.byref(h)) == _lib.ERR_INVALID
+    small = _lib.ExtractorCfg(1000, 1.2, 8, 20, 7, 160, 120, 1)  # top levels smaller than one detection cell
+    assert lib.rgbl_extractor_create(C.byref(small), 0, C.byref(h)) == _lib.ERR_INVALID
+    d = _lib.DepthCfg()
+    d.method, d.width, d.height, d.max_points, d.max_keypoints, d.max_batch, d.kernel_w, d.kernel_h = 5, 64, 64, 10, 10, 1, 5, 5
+    assert lib.rgbl_depth_create(C.byref(d), 0, C.byref(h)) == _lib.ERR_INVALID  # IPBasic: never implemented upstream
+    assert lib.rgbl_structuring_element(3, 4, 4, None) == _lib.ERR_INVALID
