@@ -1,0 +1,120 @@
+// Shim of ORB_SLAM3::ORBextractor over the C ABI (include/rgbl_frontend.h). Replaces
+// /root/reference/src/ORBextractor.cc; all pixel work happens in the HIP kernels.
+#include "ORBextractor.h"
+
+#include <math.h>
+
+#include <iostream>
+
+#include "../../include/rgbl_frontend.h"
+
+namespace ORB_SLAM3 {
+
+static_assert(sizeof(cv::KeyPoint) == sizeof(rgbl_keypoint), "cv::KeyPoint must be layout compatible with rgbl_keypoint");
+
+ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
+    : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST) {
+  // The per-level tables are pure host arithmetic (ORBextractor.cc:414-430) and must exist before the first
+  // image arrives: every Frame copies them (Frame.cc:110-116).  The handle recomputes the same values.
+  mvScaleFactor.resize(nlevels);
+  mvLevelSigma2.resize(nlevels);
+  mvScaleFactor[0] = 1.0f;
+  mvLevelSigma2[0] = 1.0f;
+  for (int i = 1; i < nlevels; i++) {
+    mvScaleFactor[i] = mvScaleFactor[i - 1] * _scaleFactor;
+    mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i];
+  }
+  mvInvScaleFactor.resize(nlevels);
+  mvInvLevelSigma2.resize(nlevels);
+  for (int i = 0; i < nlevels; i++) {
+    mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i];
+    mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i];
+  }
+  mvImagePyramid.resize(nlevels);
+}
+
+ORBextractor::~ORBextractor() { rgbl_extractor_destroy(mpHandle); }
+
+void ORBextractor::EnsureHandle(int width, int height) {
+  if (mpHandle && width == mHandleW && height == mHandleH) return;
+  rgbl_extractor_destroy(mpHandle);
+  mpHandle = nullptr;
+  rgbl_extractor_cfg cfg;
+  cfg.nfeatures = nfeatures;
+  cfg.scale_factor = (float)scaleFactor;
+  cfg.nlevels = nlevels;
+  cfg.ini_th_fast = iniThFAST;
+  cfg.min_th_fast = minThFAST;
+  cfg.width = width;
+  cfg.height = height;
+  cfg.max_batch = 1;
+  if (rgbl_extractor_create(&cfg, device, &mpHandle) != RGBL_OK) {
+    std::cerr << "[ORBextractor] " << rgbl_last_error() << std::endl;  // the reference reports on stdout/stderr, never throws
+    mpHandle = nullptr;
+    return;
+  }
+  mHandleW = width;
+  mHandleH = height;
+  mnFeaturesPerLevel.resize(nlevels);
+  umax.resize(16);
+  rgbl_extractor_tables(mpHandle, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
+                        mvInvLevelSigma2.data(), mnFeaturesPerLevel.data(), umax.data());
+}
+
+int ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                             cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
+#ifdef RGBL_HAVE_OPENCV
+  if (_image.empty()) return -1;
+  cv::Mat image = _image.getMat();
+#else
+  if (_image.empty()) return -1;
+  const cv::Mat& image = _image;
+#endif
+  if (image.type() != CV_8UC1) {
+    std::cerr << "[ORBextractor] image must be CV_8UC1" << std::endl;
+    return -1;
+  }
+  EnsureHandle(image.cols, image.rows);
+  if (!mpHandle) return -1;
+  const int cap = rgbl_extractor_max_keypoints(mpHandle);
+  _keypoints = std::vector<cv::KeyPoint>(cap);
+  cv::Mat desc(cap, 32, CV_8U);
+  int n = 0, mono = -1;
+  const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+  const int rc = rgbl_extract(mpHandle, image.data, image.cols, image.rows, (int)image.step, lap0, lap1,
+                              reinterpret_cast<rgbl_keypoint*>(_keypoints.data()), desc.data, cap, &n, &mono);
+  if (rc != RGBL_OK) {
+    std::cerr << "[ORBextractor] " << rgbl_last_error() << std::endl;
+    _keypoints.clear();
+    return -1;
+  }
+  _keypoints.resize(n);
+#ifdef RGBL_HAVE_OPENCV
+  if (n == 0) _descriptors.release();
+  else desc.rowRange(0, n).copyTo(_descriptors);
+#else
+  if (n == 0) _descriptors.release();
+  else {
+    _descriptors.create(n, 32, CV_8U);
+    memcpy(_descriptors.data, desc.data, (size_t)n * 32);
+  }
+#endif
+  if (keepPyramid) {
+    mvPyramidStorage.resize(nlevels);
+    for (int l = 0; l < nlevels; ++l) {
+      int w = 0, h = 0;
+      rgbl_extractor_level_size(mpHandle, l, &w, &h);
+      cv::Mat& full = mvPyramidStorage[l];
+      full.create(h + 38, w + 38, CV_8UC1);
+      rgbl_extractor_get_level(mpHandle, 0, l, 0, 1, full.data, (int)full.step);
+#ifdef RGBL_HAVE_OPENCV
+      mvImagePyramid[l] = full(cv::Rect(19, 19, w, h));  // an ROI inside the bordered buffer, like the reference
+#else
+      mvImagePyramid[l] = cv::Mat(h, w, CV_8UC1, full.data + 19 * full.step + 19, full.step);
+#endif
+    }
+  }
+  return mono;
+}
+
+}  // namespace ORB_SLAM3

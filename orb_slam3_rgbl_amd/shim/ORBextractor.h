@@ -1,0 +1,59 @@
+// Drop-in replacement of /root/reference/include/ORBextractor.h: same class name, constructor, operator(),
+// getters and public mvImagePyramid — the members System/Tracking/Frame touch — running on librgbl_frontend.so.
+#ifndef ORBEXTRACTOR_H
+#define ORBEXTRACTOR_H
+
+#include <vector>
+
+#include "cv_compat.h"
+
+struct rgbl_extractor;
+
+namespace ORB_SLAM3 {
+
+class ORBextractor {
+ public:
+  enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+  ~ORBextractor();
+  ORBextractor(const ORBextractor&) = delete;
+  ORBextractor& operator=(const ORBextractor&) = delete;
+
+  // Compute the ORB features and descriptors on an image (mask is ignored, as in the reference).
+  // Returns monoIndex; -1 for an empty image.
+  int operator()(cv::InputArray _image, cv::InputArray _mask, std::vector<cv::KeyPoint>& _keypoints,
+                 cv::OutputArray _descriptors, std::vector<int>& vLappingArea);
+
+  int inline GetLevels() { return nlevels; }
+  float inline GetScaleFactor() { return scaleFactor; }
+  std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+  std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+  std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+  std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+  // Filled (device -> host, with the 19-px reflect-101 frame) only when keepPyramid is set: its single consumer
+  // is Frame::ComputeStereoMatches (Frame.cc:908,998-1013); RGB-L / mono never read it.
+  std::vector<cv::Mat> mvImagePyramid;
+  bool keepPyramid = false;
+  int device = 0;  // HIP device ordinal, may be changed before the first call
+
+ protected:
+  void EnsureHandle(int width, int height);
+
+  int nfeatures;
+  double scaleFactor;
+  int nlevels;
+  int iniThFAST;
+  int minThFAST;
+  std::vector<int> mnFeaturesPerLevel;
+  std::vector<int> umax;
+  std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+
+  rgbl_extractor* mpHandle = nullptr;
+  int mHandleW = 0, mHandleH = 0;
+  std::vector<cv::Mat> mvPyramidStorage;
+};
+
+}  // namespace ORB_SLAM3
+#endif

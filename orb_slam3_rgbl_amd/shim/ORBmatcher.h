@@ -1,0 +1,146 @@
+// Drop-in replacement of the Hamming paths of /root/reference/include/ORBmatcher.h on librgbl_frontend.so:
+//   static DescriptorDistance(a, b)                                  (ORBmatcher.h:43,  ORBmatcher.cc:2058-2074)
+//   SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse)   (ORBmatcher.h:75-76, :907-1146)
+// The other Search*/Fuse members of the reference class are untouched (SURVEY.md §8(f) lists them as "next");
+// in the ORB_SLAM3 tree this header is merged into the existing one, see INTEGRATION.md.
+//
+// SearchForTriangulation is a member template so that this file does not need KeyFrame.h / Sophus / DBoW2 here:
+// it only uses the public KeyFrame members the reference function itself touches (mFeatVec, GetMapPoint, mvuRight,
+// mvKeysUn, mDescriptors, N, NLeft, mpCamera, mpCamera2, GetPose, GetPoseInverse, GetCameraCenter, mvScaleFactors,
+// mvLevelSigma2), so `matcher.SearchForTriangulation(mpCurrentKeyFrame, pKF2, vMatchedIndices, false, bCoarse)`
+// (LocalMapping.cc:466) compiles unchanged.
+#ifndef ORBMATCHER_H
+#define ORBMATCHER_H
+
+#include <stdint.h>
+
+#include <iostream>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "../../include/rgbl_frontend.h"
+#include "cv_compat.h"
+
+namespace ORB_SLAM3 {
+
+class ORBmatcher {
+ public:
+  ORBmatcher(float nnratio = 0.6, bool checkOri = true, int device = 0) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {
+    if (rgbl_matcher_create(device, &mpHandle) != RGBL_OK) {
+      std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
+      mpHandle = nullptr;
+    }
+  }
+  ~ORBmatcher() { rgbl_matcher_destroy(mpHandle); }
+  ORBmatcher(const ORBmatcher&) = delete;
+  ORBmatcher& operator=(const ORBmatcher&) = delete;
+
+  // Computes the Hamming distance between two ORB descriptors (rows of 32 bytes).
+  static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
+    return rgbl_descriptor_distance(a.ptr<uint8_t>(), b.ptr<uint8_t>());
+  }
+
+  // Matching to triangulate new MapPoints. Check Epipolar Constraint.
+  template <class KeyFrameT>
+  int SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                             const bool bOnlyStereo, const bool bCoarse = false) {
+    vMatchedPairs.clear();
+    if (!mpHandle) return 0;
+    if (pKF1->mpCamera2 || pKF2->mpCamera2 || pKF1->NLeft != -1 || pKF2->NLeft != -1) {
+      std::cerr << "[ORBmatcher] SearchForTriangulation: fisheye stereo rigs (mpCamera2) are not covered by the device path" << std::endl;
+      return 0;
+    }
+    // relative pose and epipole, ORBmatcher.cc:913-931
+    auto T12 = pKF1->GetPose() * pKF2->GetPoseInverse();
+    auto R = T12.rotationMatrix();
+    auto t = T12.translation();
+    auto C2 = pKF2->GetPose() * pKF1->GetCameraCenter();
+    auto ep = pKF2->mpCamera->project(C2);
+    float R12[9], t12[3], K1[4], K2[4];
+    for (int i = 0; i < 3; ++i) {
+      t12[i] = t(i);
+      for (int j = 0; j < 3; ++j) R12[3 * i + j] = R(i, j);
+    }
+    for (int i = 0; i < 4; ++i) {
+      K1[i] = pKF1->mpCamera->getParameter(i);
+      K2[i] = pKF2->mpCamera->getParameter(i);
+    }
+    rgbl_triangulation_params prm;
+    rgbl_fundamental(K1, K2, R12, t12, prm.F12);  // constant per key-frame pair (the reference rebuilds it per candidate)
+    prm.epipole[0] = ep(0);
+    prm.epipole[1] = ep(1);
+    prm.scale_factors2 = pKF2->mvScaleFactors.data();
+    prm.level_sigma2_2 = pKF2->mvLevelSigma2.data();
+    prm.n_levels = (int)pKF2->mvScaleFactors.size();
+    prm.only_stereo = bOnlyStereo;
+    prm.coarse = bCoarse;
+    prm.check_orientation = mbCheckOrientation;
+
+    Flat f1, f2;
+    Flatten(pKF1, f1);
+    Flatten(pKF2, f2);
+    std::vector<int32_t> vMatches12(f1.view.n, -1);
+    int nmatches = 0;
+    if (rgbl_search_triangulation(mpHandle, &f1.view, &f2.view, &prm, vMatches12.data(), &nmatches) != RGBL_OK) {
+      std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
+      return 0;
+    }
+    vMatchedPairs.reserve(nmatches);
+    for (size_t i = 0, iend = vMatches12.size(); i < iend; i++) {
+      if (vMatches12[i] < 0) continue;
+      vMatchedPairs.push_back(std::make_pair(i, (size_t)vMatches12[i]));
+    }
+    return nmatches;
+  }
+
+  static const int TH_LOW = 50;
+  static const int TH_HIGH = 100;
+  static const int HISTO_LENGTH = 30;
+
+ protected:
+  struct Flat {
+    std::vector<float> xy, angle;
+    std::vector<int32_t> octave, node_id, node_off, node_feat;
+    std::vector<uint8_t> has_mp;
+    rgbl_keyframe_view view;
+  };
+  // Snapshot of the key-frame state the kernel needs; GetMapPoint() takes the key-frame's own mutex per call,
+  // exactly as the reference's inner loops do (KeyFrame.cc:373-377).
+  template <class KeyFrameT>
+  static void Flatten(KeyFrameT* kf, Flat& f) {
+    const int n = kf->N;
+    f.xy.resize(2 * (size_t)n); f.angle.resize(n); f.octave.resize(n); f.has_mp.resize(n);
+    for (int i = 0; i < n; ++i) {
+      f.xy[2 * i] = kf->mvKeysUn[i].pt.x;
+      f.xy[2 * i + 1] = kf->mvKeysUn[i].pt.y;
+      f.angle[i] = kf->mvKeysUn[i].angle;
+      f.octave[i] = kf->mvKeysUn[i].octave;
+      f.has_mp[i] = kf->GetMapPoint(i) ? 1 : 0;
+    }
+    f.node_off.assign(1, 0);
+    for (auto it = kf->mFeatVec.begin(); it != kf->mFeatVec.end(); ++it) {  // std::map: node ids ascend
+      f.node_id.push_back((int32_t)it->first);
+      for (size_t k = 0; k < it->second.size(); ++k) f.node_feat.push_back((int32_t)it->second[k]);
+      f.node_off.push_back((int32_t)f.node_feat.size());
+    }
+    f.view.n = n;
+    f.view.desc = kf->mDescriptors.template ptr<uint8_t>();
+    f.view.kp_xy = f.xy.data();
+    f.view.kp_octave = f.octave.data();
+    f.view.kp_angle = f.angle.data();
+    f.view.uright = kf->mvuRight.data();
+    f.view.has_mappoint = f.has_mp.data();
+    f.view.n_nodes = (int)f.node_id.size();
+    f.view.node_id = f.node_id.data();
+    f.view.node_off = f.node_off.data();
+    f.view.node_feat = f.node_feat.data();
+  }
+
+  float mfNNratio;
+  bool mbCheckOrientation;
+  rgbl_matcher* mpHandle = nullptr;
+};
+
+}  // namespace ORB_SLAM3
+#endif

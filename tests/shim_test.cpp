@@ -1,0 +1,144 @@
+// Exercises the C++ drop-in shims (orb_slam3_rgbl_amd/shim) the way System/Tracking/Frame/LocalMapping use the
+// reference classes, and dumps the results for the Python side to compare with the oracle.
+//   shim_test <yaml> <image.raw> <w> <h> <cloud.raw> <n> <tri.bin> <out.bin>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "DepthModule.h"
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+
+// ---- minimal stand-ins for the Sophus / camera / KeyFrame members SearchForTriangulation touches
+struct V3 { float v[3]; float operator()(int i) const { return v[i]; } };
+struct V2 { float v[2]; float operator()(int i) const { return v[i]; } };
+struct M3 { float m[9]; float operator()(int i, int j) const { return m[3 * i + j]; } };
+struct SE3 {
+  M3 R; V3 t;
+  M3 rotationMatrix() const { return R; }
+  V3 translation() const { return t; }
+  SE3 operator*(const SE3& o) const {
+    SE3 r;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) r.R.m[3 * i + j] = R.m[3 * i] * o.R.m[j] + R.m[3 * i + 1] * o.R.m[3 + j] + R.m[3 * i + 2] * o.R.m[6 + j];
+      r.t.v[i] = R.m[3 * i] * o.t.v[0] + R.m[3 * i + 1] * o.t.v[1] + R.m[3 * i + 2] * o.t.v[2] + t.v[i];
+    }
+    return r;
+  }
+  V3 operator*(const V3& p) const {
+    V3 r;
+    for (int i = 0; i < 3; ++i) r.v[i] = R.m[3 * i] * p.v[0] + R.m[3 * i + 1] * p.v[1] + R.m[3 * i + 2] * p.v[2] + t.v[i];
+    return r;
+  }
+};
+struct Camera {
+  float p[4];
+  float getParameter(int i) const { return p[i]; }
+  V2 project(const V3& c) const { V2 r; r.v[0] = p[0] * c.v[0] / c.v[2] + p[2]; r.v[1] = p[1] * c.v[1] / c.v[2] + p[3]; return r; }
+};
+struct MapPoint {};
+struct KeyFrame {
+  int N = 0, NLeft = -1;
+  Camera* mpCamera = nullptr; Camera* mpCamera2 = nullptr;
+  std::map<unsigned, std::vector<unsigned> > mFeatVec;
+  std::vector<cv::KeyPoint> mvKeysUn;
+  std::vector<float> mvuRight, mvScaleFactors, mvLevelSigma2;
+  std::vector<MapPoint*> mvpMapPoints;
+  cv::Mat mDescriptors;
+  SE3 Tcw, Twc;
+  MapPoint* GetMapPoint(size_t i) { return mvpMapPoints[i]; }
+  SE3 GetPose() { return Tcw; }
+  SE3 GetPoseInverse() { return Twc; }
+  V3 GetCameraCenter() { return Twc.t; }
+};
+
+template <class T> static bool rd(FILE* f, T* p, size_t n) { return fread(p, sizeof(T), n, f) == n; }
+template <class T> static void wr(FILE* f, const T* p, size_t n) { fwrite(p, sizeof(T), n, f); }
+
+static bool load_kf(FILE* f, KeyFrame& kf, Camera* cam, MapPoint* some) {
+  int n, nn;
+  if (!rd(f, &n, 1)) return false;
+  kf.N = n; kf.mpCamera = cam;
+  kf.mDescriptors.create(n, 32, CV_8U);
+  rd(f, kf.mDescriptors.data, (size_t)n * 32);
+  kf.mvKeysUn.resize(n); kf.mvuRight.resize(n); kf.mvpMapPoints.resize(n);
+  std::vector<float> xy(2 * n), ang(n); std::vector<int> oct(n); std::vector<unsigned char> mp(n);
+  rd(f, xy.data(), 2 * n); rd(f, oct.data(), n); rd(f, ang.data(), n); rd(f, kf.mvuRight.data(), n); rd(f, mp.data(), n);
+  for (int i = 0; i < n; ++i) {
+    kf.mvKeysUn[i].pt.x = xy[2 * i]; kf.mvKeysUn[i].pt.y = xy[2 * i + 1]; kf.mvKeysUn[i].octave = oct[i]; kf.mvKeysUn[i].angle = ang[i];
+    kf.mvpMapPoints[i] = mp[i] ? some : nullptr;
+  }
+  rd(f, &nn, 1);
+  std::vector<int> id(nn), off(nn + 1);
+  rd(f, id.data(), nn); rd(f, off.data(), nn + 1);
+  std::vector<int> feat(off[nn]);
+  rd(f, feat.data(), off[nn]);
+  for (int k = 0; k < nn; ++k) kf.mFeatVec[(unsigned)id[k]] = std::vector<unsigned>(feat.begin() + off[k], feat.begin() + off[k + 1]);
+  kf.mvScaleFactors.resize(8); kf.mvLevelSigma2.resize(8);
+  rd(f, kf.mvScaleFactors.data(), 8); rd(f, kf.mvLevelSigma2.data(), 8);
+  rd(f, kf.Tcw.R.m, 9); rd(f, kf.Tcw.t.v, 3); rd(f, kf.Twc.R.m, 9); rd(f, kf.Twc.t.v, 3);
+  return true;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 9) return 2;
+  const int w = atoi(argv[3]), h = atoi(argv[4]), n = atoi(argv[6]);
+  cv::Mat im(h, w, CV_8UC1);
+  FILE* f = fopen(argv[2], "rb");
+  if (!f || !rd(f, im.data, (size_t)w * h)) return 3;
+  fclose(f);
+  cv::Mat pcd(4, n, CV_32F);
+  f = fopen(argv[5], "rb");
+  if (!f || !rd(f, pcd.ptr<float>(), (size_t)4 * n)) return 4;
+  fclose(f);
+  FILE* out = fopen(argv[8], "wb");
+
+  // --- as Tracking::ParseORBParamFile + Frame::ExtractORB (Tracking.cc:1281, Frame.cc:508-515)
+  ORB_SLAM3::ORBextractor extractor(2000, 1.2f, 8, 12, 7);
+  extractor.keepPyramid = true;
+  std::vector<cv::KeyPoint> keys;
+  cv::Mat desc;
+  std::vector<int> vLapping = {0, 0};
+  const int mono = extractor(im, cv::Mat(), keys, desc, vLapping);
+  const int nk = (int)keys.size();
+  wr(out, &mono, 1); wr(out, &nk, 1);
+  wr(out, keys.data(), nk); wr(out, desc.data, (size_t)nk * 32);
+  std::vector<float> sf = extractor.GetScaleFactors();
+  wr(out, sf.data(), sf.size());
+  const cv::Mat& p3 = extractor.mvImagePyramid[3];
+  wr(out, &p3.cols, 1); wr(out, &p3.rows, 1);
+  for (int r = -19; r < p3.rows + 19; ++r) wr(out, p3.data + (ptrdiff_t)r * (ptrdiff_t)p3.step - 19, p3.cols + 38);  // incl. the border
+  cv::Mat empty;
+  std::vector<cv::KeyPoint> k2; cv::Mat d2;
+  const int mono_empty = extractor(empty, cv::Mat(), k2, d2, vLapping);
+  wr(out, &mono_empty, 1);
+
+  // --- as System (System.cc:220-221) + Frame (Frame.cc:331-333)
+  ORB_SLAM3::DepthModule depth(argv[1], 6);
+  depth.CalculateDepthFromPcd(keys, keys, pcd, w, h);
+  const int nd = (int)depth.mvDepth.size();
+  wr(out, &nd, 1);
+  wr(out, depth.mvDepth.data(), nd); wr(out, depth.mvuRight.data(), nd);
+  wr(out, depth.ProcessedDepthMap.ptr<float>(), (size_t)w * h);
+  wr(out, depth.LidarProjectionMatrix.ptr<float>(), 12);
+
+  // --- as LocalMapping::CreateNewMapPoints (LocalMapping.cc:412,466)
+  f = fopen(argv[7], "rb");
+  Camera cam; MapPoint some; KeyFrame kf1, kf2;
+  if (!f || !rd(f, cam.p, 4) || !load_kf(f, kf1, &cam, &some) || !load_kf(f, kf2, &cam, &some)) return 5;
+  fclose(f);
+  ORB_SLAM3::ORBmatcher matcher(0.6, false);
+  std::vector<std::pair<size_t, size_t> > pairs;
+  const int nm = matcher.SearchForTriangulation(&kf1, &kf2, pairs, false, false);
+  const int np = (int)pairs.size();
+  wr(out, &nm, 1); wr(out, &np, 1);
+  for (auto& pr : pairs) { int a = (int)pr.first, b = (int)pr.second; wr(out, &a, 1); wr(out, &b, 1); }
+  const int dd = ORB_SLAM3::ORBmatcher::DescriptorDistance(kf1.mDescriptors.row(0), kf2.mDescriptors.row(0));
+  wr(out, &dd, 1);
+  fclose(out);
+  printf("shim_test ok: %d keypoints, %d depths, %d triangulation matches\n", nk, nd, nm);
+  return 0;
+}
