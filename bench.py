@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--serial", action="store_true", help="one stream for all handles (clean per-kernel timings)")
     args = ap.parse_args()
 
     import torch
@@ -146,6 +147,10 @@ def main():
 
     # Three HIP streams (one per handle): the LiDAR projection / up-sampling does not depend on the keypoints and
     # overlaps with the extraction; ordering between the handles is expressed with HIP events (rgbl_stream_wait).
+    if args.serial:
+        one = C.c_void_p(lib.rgbl_extractor_stream(ex.h))
+        L.check(lib, lib.rgbl_depth_set_stream(dm.h, one))
+        L.check(lib, lib.rgbl_matcher_set_stream(mt.h, one))
     s_ex = C.c_void_p(lib.rgbl_extractor_stream(ex.h))
     s_dm = C.c_void_p(lib.rgbl_depth_stream(dm.h))
     s_mt = C.c_void_p(lib.rgbl_matcher_stream(mt.h))

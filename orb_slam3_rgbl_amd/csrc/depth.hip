@@ -71,16 +71,33 @@ __global__ __launch_bounds__(256) void k_project_write(ProjParams P, const float
   if (pix >= 0 && idx_map[(size_t)f * map_stride + pix] == (uint32_t)(i + 1)) raw[(size_t)f * map_stride + pix] = d;
 }
 
+// Inverse dilation (DepthModule.cc:265-273): P = S - raw, TOZERO_INV(S-1), dilate, S - P, TOZERO_INV(S-1).
+// 64x16 output tile per workgroup; the inverted tile + halo is staged in LDS.
+// kRadius > 0: the reference's Diamond structuring element |dx|+|dy| <= kRadius with compile-time taps (all
+// LDS reads of a pixel are issued back to back); kRadius == 0: arbitrary mask, tap offsets held in LDS.
 // grid = (ceil(w/64), ceil(h/16), B), block = 256.
+template <int kRadius>
 __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, const float* __restrict__ raw,
                                                         float* __restrict__ out, size_t map_stride, int w, int h) {
   __shared__ float s_inv[24 * 72];
+  __shared__ int s_tap[81];
+  __shared__ int s_ntap;
   const int tid = threadIdx.x, f = blockIdx.z;
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
-  const int ax = K.kw / 2, ay = K.kh / 2;
-  const int tw = 64 + K.kw - 1, th = 16 + K.kh - 1;
+  const int ax = kRadius > 0 ? kRadius : K.kw / 2, ay = kRadius > 0 ? kRadius : K.kh / 2;
+  const int tw = kRadius > 0 ? 64 + 2 * kRadius : 64 + K.kw - 1, th = kRadius > 0 ? 16 + 2 * kRadius : 16 + K.kh - 1;
   const float thr = S - 1;
   const float* R = raw + (size_t)f * map_stride;
+  if (kRadius == 0 && tid < 64) {
+    // compact the mask (<= 81 entries) into a tap list with two ballots of wave 0
+    const int n = K.kw * K.kh, i1 = tid + 64;
+    const bool on0 = tid < n && K.m[tid] != 0, on1 = i1 < n && K.m[i1 < 81 ? i1 : 0] != 0;
+    const unsigned long long m0 = __ballot(on0), m1 = __ballot(on1);
+    const unsigned long long lt = lanemask_lt();
+    if (on0) s_tap[__popcll(m0 & lt)] = (tid / K.kw) * 72 + (tid % K.kw);
+    if (on1) s_tap[__popcll(m0) + __popcll(m1 & lt)] = (i1 / K.kw) * 72 + (i1 % K.kw);
+    if (tid == 0) s_ntap = __popcll(m0) + __popcll(m1);
+  }
   for (int i = tid; i < tw * th; i += 256) {
     const int r = i / tw, c = i - r * tw;
     const int yy = y0 + r - ay, xx = x0 + c - ax;
@@ -97,9 +114,18 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
     const int y = (tid >> 6) + 4 * k;
     if (x0 + x >= w || y0 + y >= h) continue;
     float m = -FLT_MAX;
-    for (int ky = 0; ky < K.kh; ++ky)
-      for (int kx = 0; kx < K.kw; ++kx)
-        if (K.m[ky * K.kw + kx]) m = fmaxf(m, s_inv[(y + ky) * 72 + x + kx]);
+    if (kRadius > 0) {
+#pragma unroll
+      for (int dy = -kRadius; dy <= kRadius; ++dy) {
+        const int span = kRadius - (dy < 0 ? -dy : dy);
+#pragma unroll
+        for (int dx = -span; dx <= span; ++dx) m = fmaxf(m, s_inv[(y + kRadius + dy) * 72 + x + kRadius + dx]);
+      }
+    } else {
+      const int nt = s_ntap;
+      const float* base = &s_inv[y * 72 + x];
+      for (int t = 0; t < nt; ++t) m = fmaxf(m, base[s_tap[t]]);
+    }
     const float t = S - m;
     out[(size_t)f * map_stride + (size_t)(y0 + y) * w + x0 + x] = t > thr ? 0.f : t;
   }
@@ -221,6 +247,7 @@ struct rgbl_depth {
   KernelTimer timer;
   ProjParams proj;
   DilateMask mask;
+  int diamond_radius = 0;  // > 0 when the mask is the reference's Diamond of that radius (compile-time taps)
   size_t map_stride = 0;
   uint32_t* d_idx = nullptr;  // idx | raw contiguous so one memset clears both
   float* d_raw = nullptr;
@@ -259,7 +286,13 @@ int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, 
     case RGBL_UPS_INVERSE_DILATION:
       e->timer.begin("k_inverse_dilate", s);
       // opt_max_dist * ParamUpsampling_InverseDilation_ScaleFactor; the scale factor is never parsed (1.0)
-      hipLaunchKernelGGL(k_inverse_dilate, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, e->d_proc, ms, w, h);
+      switch (e->diamond_radius) {
+        case 1: hipLaunchKernelGGL(k_inverse_dilate<1>, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, e->d_proc, ms, w, h); break;
+        case 2: hipLaunchKernelGGL(k_inverse_dilate<2>, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, e->d_proc, ms, w, h); break;
+        case 3: hipLaunchKernelGGL(k_inverse_dilate<3>, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, e->d_proc, ms, w, h); break;
+        case 4: hipLaunchKernelGGL(k_inverse_dilate<4>, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, e->d_proc, ms, w, h); break;
+        default: hipLaunchKernelGGL(k_inverse_dilate<0>, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, e->d_proc, ms, w, h); break;
+      }
       e->timer.end(s);
       break;
     case RGBL_UPS_AVERAGE_FILTERING:
@@ -374,6 +407,14 @@ int rgbl_depth_create(const rgbl_depth_cfg* cfg, int device, rgbl_depth** out) {
   e->mask.kw = cfg->kernel_w;
   e->mask.kh = cfg->kernel_h;
   memcpy(e->mask.m, cfg->kernel, 81);
+  if (cfg->kernel_w == cfg->kernel_h && (cfg->kernel_w & 1) && cfg->kernel_w >= 3) {
+    const int r = cfg->kernel_w / 2;
+    bool diamond = true;
+    for (int y = 0; y < cfg->kernel_w; ++y)
+      for (int x = 0; x < cfg->kernel_w; ++x)
+        diamond = diamond && ((cfg->kernel[y * cfg->kernel_w + x] != 0) == (abs(x - r) + abs(y - r) <= r));
+    if (diamond) e->diamond_radius = r;
+  }
   e->map_stride = (size_t)cfg->width * cfg->height;
   const size_t B = (size_t)cfg->max_batch;
   int rc = dalloc(e, &e->d_idx, B * e->map_stride * 2);

@@ -210,10 +210,10 @@ int build_geometry(rgbl_extractor* e) {
     node_off += g.node_cap;
     g.xtab_off = (uint32_t)xtab_off;
     g.ytab_off = (uint32_t)ytab_off;
-    if (l > 0) { xtab_off += g.w; ytab_off += g.h; }
+    if (l > 0) { xtab_off += align_up(g.w, 4); ytab_off += g.h; }  // 32-byte aligned x tables (one read per 4 columns)
     e->blur_tiles.tile_off[l] = tile_off;
-    e->blur_tiles.tiles_x[l] = (g.w + 63) / 64;
-    tile_off += e->blur_tiles.tiles_x[l] * ((g.h + 15) / 16);
+    e->blur_tiles.tiles_x[l] = (g.w + kBlurTW - 1) / kBlurTW;
+    tile_off += e->blur_tiles.tiles_x[l] * ((g.h + kBlurTH - 1) / kBlurTH);
   }
   e->blur_tiles.tile_off[L] = tile_off;
   e->pyr_frame = align_up(img_off, 256);
@@ -232,6 +232,7 @@ int upload_tables(rgbl_extractor* e) {
   for (int l = 0; l < L; ++l) {
     const LevelGeom& g = e->geom[l];
     if (l > 0) {
+      xt.resize(g.xtab_off);
       build_resize_tab(e->geom[l - 1].w, g.w, true, xt);
       build_resize_tab(e->geom[l - 1].h, g.h, false, yt);
     }
@@ -245,7 +246,7 @@ int upload_tables(rgbl_extractor* e) {
     }
   }
   RGBL_TRY(dev_alloc(e, &e->d_geom, L));
-  RGBL_TRY(dev_alloc(e, &e->d_xtab, xt.size()));
+  RGBL_TRY(dev_alloc(e, &e->d_xtab, xt.size() + 8));
   RGBL_TRY(dev_alloc(e, &e->d_ytab, yt.size()));
   RGBL_TRY(dev_alloc(e, &e->d_rootx, rootx.size()));
   RGBL_TRY(dev_alloc(e, &e->d_pattern, 1024));
@@ -260,8 +261,8 @@ int upload_tables(rgbl_extractor* e) {
 int alloc_scratch(rgbl_extractor* e) {
   const size_t B = (size_t)e->cfg.max_batch;
   RGBL_TRY(dev_alloc(e, &e->d_img, B * e->img_frame));
-  RGBL_TRY(dev_alloc(e, &e->d_pyr, B * e->pyr_frame));
-  RGBL_TRY(dev_alloc(e, &e->d_blur, B * e->pyr_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_pyr, B * e->pyr_frame + 256));  // slack: 8-byte source reads may run past a row end
+  RGBL_TRY(dev_alloc(e, &e->d_blur, B * e->pyr_frame + 256));
   RGBL_TRY(dev_alloc(e, &e->d_cellcnt, B * e->cells_frame));
   RGBL_TRY(dev_alloc(e, &e->d_slots, B * e->slots_frame));
   RGBL_TRY(dev_alloc(e, &e->d_keys_a, B * e->keys_frame));

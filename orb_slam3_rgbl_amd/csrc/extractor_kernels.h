@@ -59,8 +59,16 @@ __device__ __forceinline__ int key_y(uint32_t k) { return (int)((k >> 12) & 0xff
 __device__ __forceinline__ int key_s(uint32_t k) { return (int)(k >> 24); }
 
 // ------------------------------------------------------------------------------------------------
-// cv::resize(INTER_LINEAR, CV_8UC1): 11-bit fixed-point bilinear, each thread makes 4 output pixels.
-// grid = (ceil(dw/256), ceil(dh/4), B), block = 256 (64 x 4).
+// cv::resize(INTER_LINEAR, CV_8UC1): 11-bit fixed-point bilinear, each work-item makes 4 output pixels of one
+// row.  The 4 outputs read a short run of source pixels (about 6 at scale 1.2) from two rows: those are fetched
+// as two 32-bit words per row (8 bytes from the first source column) instead of 16 byte loads; the coefficient
+// table entries of the 4 columns are one 32-byte read.  grid = (ceil(dw/256), ceil(dh/4), B), block = 256 (64 x 4).
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);  // level 0 may have an odd row stride: gfx950 global loads need no alignment
+  return v;
+}
+
 __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict__ src, int spitch,
                                                        size_t sframe, int sw, int sh,
                                                        uint8_t* __restrict__ dst, int dpitch, size_t dframe,
@@ -77,19 +85,47 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
   const uint8_t* S0 = S + (size_t)sy0 * spitch;
   const uint8_t* S1 = S + (size_t)sy1 * spitch;
   const int b0 = ry.a0, b1 = ry.a1;
+  ResizeTab rx[4];
+  if (dx0 + 3 < dw) {
+    const uint4* t4 = reinterpret_cast<const uint4*>(xtab + dx0);  // table offsets are padded to 4 entries
+    const uint4 q0 = t4[0], q1 = t4[1];
+    rx[0].sofs = (int)q0.x; rx[0].a0 = (int16_t)(q0.y & 0xffff); rx[0].a1 = (int16_t)(q0.y >> 16);
+    rx[1].sofs = (int)q0.z; rx[1].a0 = (int16_t)(q0.w & 0xffff); rx[1].a1 = (int16_t)(q0.w >> 16);
+    rx[2].sofs = (int)q1.x; rx[2].a0 = (int16_t)(q1.y & 0xffff); rx[2].a1 = (int16_t)(q1.y >> 16);
+    rx[3].sofs = (int)q1.z; rx[3].a0 = (int16_t)(q1.w & 0xffff); rx[3].a1 = (int16_t)(q1.w >> 16);
+  } else {
+    for (int i = 0; i < 4; ++i) rx[i] = xtab[imin(dx0 + i, dw - 1)];
+  }
+  const int sxa = rx[0].sofs;
   uint32_t out = 0;
+  if (dx0 + 3 < dw && rx[3].sofs + 1 - sxa <= 7 && sxa + 8 <= sw) {
+    const unsigned long long r0 = (unsigned long long)load_u32_unaligned(S0 + sxa) | ((unsigned long long)load_u32_unaligned(S0 + sxa + 4) << 32);
+    const unsigned long long r1 = (unsigned long long)load_u32_unaligned(S1 + sxa) | ((unsigned long long)load_u32_unaligned(S1 + sxa + 4) << 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sh8 = 8 * (rx[i].sofs - sxa);
+      const int p00 = (int)((r0 >> sh8) & 0xff), p01 = (int)((r0 >> (sh8 + 8)) & 0xff);
+      const int p10 = (int)((r1 >> sh8) & 0xff), p11 = (int)((r1 >> (sh8 + 8)) & 0xff);
+      const int h0 = p00 * rx[i].a0 + p01 * rx[i].a1;
+      const int h1 = p10 * rx[i].a0 + p11 * rx[i].a1;
+      const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      out |= (uint32_t)(v & 0xff) << (8 * i);
+    }
+    *reinterpret_cast<uint32_t*>(D + dx0) = out;  // dpitch and dx0 are multiples of 4
+    return;
+  }
+  // row ends / large scale factors: byte path
   for (int i = 0; i < 4; ++i) {
     const int dx = dx0 + i;
     if (dx >= dw) break;
-    const ResizeTab rx = xtab[dx];
-    const int sx = rx.sofs, sx1 = imin(sx + 1, sw - 1);
-    const int h0 = S0[sx] * rx.a0 + S0[sx1] * rx.a1;
-    const int h1 = S1[sx] * rx.a0 + S1[sx1] * rx.a1;
+    const int sx = rx[i].sofs, sx1 = imin(sx + 1, sw - 1);
+    const int h0 = S0[sx] * rx[i].a0 + S0[sx1] * rx[i].a1;
+    const int h1 = S1[sx] * rx[i].a0 + S1[sx1] * rx[i].a1;
     const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
     out |= (uint32_t)(v & 0xff) << (8 * i);
   }
   if (dx0 + 3 < dw) {
-    *reinterpret_cast<uint32_t*>(D + dx0) = out;  // dpitch and dx0 are multiples of 4
+    *reinterpret_cast<uint32_t*>(D + dx0) = out;
   } else {
     for (int i = 0; dx0 + i < dw; ++i) D[dx0 + i] = (uint8_t)(out >> (8 * i));
   }
@@ -139,7 +175,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
                                                     size_t pyr_frame, int ini_th, int min_th,
                                                     uint32_t* __restrict__ cell_cnt, size_t cells_frame,
                                                     uint32_t* __restrict__ slots, size_t slots_frame) {
-  __shared__ uint8_t s_tile[(kCellMax + 6) * kTileP];
+  __shared__ uint32_t s_tile_w[(kCellMax + 6) * kTileP / 4];
+  uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile_w);
   __shared__ uint8_t s_score[(kCellMax + 2) * kScoreP];
   __shared__ uint16_t s_surv[kCellMax * kCellMax];
   __shared__ uint32_t s_scan[8];
@@ -167,9 +204,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   const int pitch = (l == 0) ? pitch0 : g.pitch;
 
   // ---- stage the (sw+6) x (sh+6) pixel tile and clear the score tile
-  for (int i = tid; i < tw * th; i += 256) {
-    const int y = i / tw, x = i - y * tw;
-    s_tile[y * kTileP + x] = img[(size_t)(ini_y + y) * pitch + ini_x + x];
+  {
+    const int nwords = (tw + 3) >> 2;  // reads at most 3 bytes past the tile, still >= 13 px inside the row
+    for (int i = tid; i < nwords * th; i += 256) {
+      const int y = i / nwords, k = i - y * nwords;
+      s_tile_w[(y * kTileP >> 2) + k] = load_u32_unaligned(img + (size_t)(ini_y + y) * pitch + ini_x + 4 * k);
+    }
   }
   for (int i = tid; i < (sh + 2) * kScoreP; i += 256) s_score[i] = 0;
   if (tid == 0) { s_nsurv = 0; s_any_ini = 0; }
@@ -244,51 +284,91 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 // 7x7 Gaussian, sigma 2, OpenCV's 8.8 fixed-point kernel {18,34,48,56,48,34,18}; BORDER_REFLECT_101.
-// Tile = 64 x 16 outputs per workgroup.  grid = (tiles per frame over all levels, B), block = 256.
+// Tile = 128 x 32 outputs per workgroup.  Pass 1 reads the source rows straight from HBM as three 32-bit
+// words per 4 pixels and leaves the horizontal sums (exact 16-bit 8.8 values) in LDS; pass 2 gives every
+// work-item a 4 x 4 output block: ten 8-byte LDS reads, four 32-bit stores.
+// grid = (tiles per frame over all levels, B), block = 256.
+constexpr int kBlurTW = 128, kBlurTH = 32;
 struct BlurTiles { int tile_off[kMaxLevels + 1]; int tiles_x[kMaxLevels]; };
 
 __global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ geom, int n_levels, BlurTiles bt,
                                                 const uint8_t* __restrict__ img0, int pitch0, size_t frame0,
                                                 const uint8_t* __restrict__ pyr, size_t pyr_frame,
                                                 uint8_t* __restrict__ blur, size_t blur_frame) {
-  __shared__ uint8_t s_in[22 * 72];
-  __shared__ uint16_t s_h[22 * 64];
+  __shared__ uint32_t s_h[(kBlurTH + 6) * (kBlurTW / 2)];  // two 16-bit horizontal sums per word
   const int tid = threadIdx.x, f = blockIdx.y;
   int l = 0;
   while (l + 1 < n_levels && (int)blockIdx.x >= bt.tile_off[l + 1]) ++l;
   const LevelGeom& g = geom[l];
   const int t = (int)blockIdx.x - bt.tile_off[l];
   const int ty = t / bt.tiles_x[l], tx = t - ty * bt.tiles_x[l];
-  const int x0 = tx * 64, y0 = ty * 16;
+  const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
   const uint8_t* img = (l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
   const int pitch = (l == 0) ? pitch0 : g.pitch;
-  for (int i = tid; i < 22 * 70; i += 256) {
-    const int r = i / 70, c = i - r * 70;
-    const int yy = reflect101(y0 + r - 3, g.h), xx = reflect101(x0 + c - 3, g.w);
-    s_in[r * 72 + c] = img[(size_t)yy * pitch + xx];
-  }
-  __syncthreads();
-  for (int i = tid; i < 22 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const uint8_t* p = &s_in[r * 72 + c];
-    s_h[i] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
-  }
-  __syncthreads();
-  const int r = tid >> 4, c4 = (tid & 15) * 4;
-  const int y = y0 + r;
-  if (y >= g.h || x0 + c4 >= g.w) return;
-  uint32_t out = 0;
+  const int W = g.w, H = g.h;
+
+  for (int task = tid; task < (kBlurTH + 6) * 32; task += 256) {
+    const int r = task >> 5, cg = task & 31;
+    const int x = x0 + 4 * cg;
+    if (x >= W) continue;
+    const uint8_t* row = img + (size_t)reflect101(y0 + r - 3, H) * pitch;
+    uint32_t w0, w1, w2;  // pixels x-4 .. x+7
+    if (x >= 4 && x + 8 <= W) {
+      w0 = load_u32_unaligned(row + x - 4);
+      w1 = load_u32_unaligned(row + x);
+      w2 = load_u32_unaligned(row + x + 4);
+    } else {
+      w0 = w1 = w2 = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint16_t* q = &s_h[r * 64 + c4 + i];
-    const uint32_t acc = 18u * (q[0] + q[6 * 64]) + 34u * (q[64] + q[5 * 64]) + 48u * (q[2 * 64] + q[4 * 64]) + 56u * q[3 * 64];
-    out |= ((acc + 32768u) >> 16) << (8 * i);
+      for (int k = 0; k < 4; ++k) {
+        w0 |= (uint32_t)row[reflect101(x - 4 + k, W)] << (8 * k);
+        w1 |= (uint32_t)row[reflect101(x + k, W)] << (8 * k);
+        w2 |= (uint32_t)row[reflect101(x + 4 + k, W)] << (8 * k);
+      }
+    }
+    int p[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      p[k] = (w0 >> (8 * k)) & 0xff;
+      p[4 + k] = (w1 >> (8 * k)) & 0xff;
+      p[8 + k] = (w2 >> (8 * k)) & 0xff;
+    }
+    uint32_t hs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      hs[i] = (uint32_t)(18 * (p[i + 1] + p[i + 7]) + 34 * (p[i + 2] + p[i + 6]) + 48 * (p[i + 3] + p[i + 5]) + 56 * p[i + 4]);
+    uint2 v;
+    v.x = hs[0] | (hs[1] << 16);
+    v.y = hs[2] | (hs[3] << 16);
+    *reinterpret_cast<uint2*>(&s_h[r * (kBlurTW / 2) + 2 * cg]) = v;
   }
-  uint8_t* D = blur + (size_t)f * blur_frame + g.img_off + (size_t)y * g.pitch + x0 + c4;
-  if (x0 + c4 + 3 < g.w) {
-    *reinterpret_cast<uint32_t*>(D) = out;
-  } else {
-    for (int i = 0; x0 + c4 + i < g.w; ++i) D[i] = (uint8_t)(out >> (8 * i));
+  __syncthreads();
+  const int cg = tid & 31, rg = tid >> 5;
+  const int x = x0 + 4 * cg;
+  if (x >= W) return;
+  uint32_t hv[10][4];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    const uint2 v = *reinterpret_cast<const uint2*>(&s_h[(4 * rg + j) * (kBlurTW / 2) + 2 * cg]);
+    hv[j][0] = v.x & 0xffff; hv[j][1] = v.x >> 16; hv[j][2] = v.y & 0xffff; hv[j][3] = v.y >> 16;
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const int y = y0 + 4 * rg + o;
+    if (y >= H) break;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t acc = 18u * (hv[o][i] + hv[o + 6][i]) + 34u * (hv[o + 1][i] + hv[o + 5][i]) +
+                           48u * (hv[o + 2][i] + hv[o + 4][i]) + 56u * hv[o + 3][i];
+      out |= ((acc + 32768u) >> 16) << (8 * i);
+    }
+    uint8_t* D = blur + (size_t)f * blur_frame + g.img_off + (size_t)y * g.pitch + x;
+    if (x + 3 < W) {
+      *reinterpret_cast<uint32_t*>(D) = out;
+    } else {
+      for (int i = 0; x + i < W; ++i) D[i] = (uint8_t)(out >> (8 * i));
+    }
   }
 }
 
@@ -774,7 +854,8 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
                                                       uint8_t* __restrict__ out_desc, int cap,
                                                       int32_t* __restrict__ out_n, int32_t* __restrict__ out_mono,
                                                       int* __restrict__ err) {
-  __shared__ uint8_t s_patch[4][37 * 40];
+  __shared__ uint32_t s_patch_w[4][37 * 10];  // blurred 37x37 neighbourhood, 40-byte rows
+  __shared__ uint32_t s_raw_w[4][31 * 8];     // un-blurred 31x31 neighbourhood, 32-byte rows
   __shared__ int8_t s_pat[1024];
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int f = blockIdx.y;
@@ -801,20 +882,36 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
 
   uint32_t key = 0;
   int x = 0, y = 0;
-  float angle = 0.f;
-  uint8_t* patch = s_patch[wave];
+  uint8_t* patch = reinterpret_cast<uint8_t*>(s_patch_w[wave]);
+  const uint8_t* rawp = reinterpret_cast<const uint8_t*>(s_raw_w[wave]);
   if (valid) {
     key = kp_key[(size_t)f * kp_frame + slot];
     x = key_x(key) + kMinBorder;
     y = key_y(key) + kMinBorder;
     const uint8_t* img = (l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
     const int pitch = (l == 0) ? pitch0 : g.pitch;
+    // both neighbourhoods are fetched as 32-bit words (keypoints sit >= 19 px inside the level, so x-18..x+21 and
+    // x-15..x+16 stay inside the row pitch)
+    const uint8_t* src = img + (size_t)(y - 15) * pitch + (x - 15);
+    for (int i = lane; i < 31 * 8; i += 64) {
+      const int r = i >> 3, c = i & 7;
+      s_raw_w[wave][i] = load_u32_unaligned(src + (size_t)r * pitch + 4 * c);
+    }
+    const uint8_t* bl = blur + (size_t)f * blur_frame + g.img_off + (size_t)(y - 18) * g.pitch + (x - 18);
+    for (int i = lane; i < 37 * 10; i += 64) {
+      const int r = i / 10, c = i - r * 10;
+      s_patch_w[wave][i] = load_u32_unaligned(bl + (size_t)r * g.pitch + 4 * c);
+    }
+  }
+  __syncthreads();
+  float angle = 0.f;
+  {
     // IC_Angle: lanes 0..30 take the rows v = -15..15 of the circular patch
     int m10 = 0, m01 = 0;
-    if (lane < 31) {
+    if (valid && lane < 31) {
       const int v = lane - 15;
       const int d = umax.v[v < 0 ? -v : v];
-      const uint8_t* row = img + (size_t)(y + v) * pitch + x;
+      const uint8_t* row = rawp + lane * 32 + 15;
       int s0 = 0, s1 = 0;
       for (int u = -d; u <= d; ++u) {
         const int p = row[u];
@@ -827,14 +924,7 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     angle = fast_atan2_deg((float)m01, (float)m10);
-    // stage the blurred 37x37 neighbourhood
-    const uint8_t* bl = blur + (size_t)f * blur_frame + g.img_off + (size_t)(y - 18) * g.pitch + (x - 18);
-    for (int i = lane; i < 37 * 37; i += 64) {
-      const int r = i / 37, c = i - r * 37;
-      patch[r * 40 + c] = bl[(size_t)r * g.pitch + c];
-    }
   }
-  __syncthreads();
   unsigned long long bits[4] = {0, 0, 0, 0};
   {
     const float factor_pi = (float)(3.14159265358979323846 / 180.f);

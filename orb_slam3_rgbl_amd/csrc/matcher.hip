@@ -25,29 +25,59 @@ __device__ __forceinline__ int hamming256(const unsigned long long q[4], const u
   return __popcll(q[0] ^ t[0]) + __popcll(q[1] ^ t[1]) + __popcll(q[2] ^ t[2]) + __popcll(q[3] ^ t[3]);
 }
 
-// grid = (ceil(cap/256), n_pairs), block = 256.
+// A workgroup owns 64 query descriptors (one per lane, 4 x u64 in VGPRs).  Its four waves split the train set
+// into four contiguous index ranges; inside a wave the train descriptor address is wave-uniform, so it is
+// fetched with scalar loads and broadcast to the 64 lanes.  The partial (best, index, second) triples are merged
+// through LDS in range order, which reproduces the sequential scan: strict '<', the first minimum wins, the
+// second-best is the second smallest distance counted with multiplicity.
+// grid = (ceil(cap/64), n_pairs), block = 256.
 __global__ __launch_bounds__(256) void k_hamming_bf(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_rows,
                                                     int cap, const int32_t* __restrict__ pair_a,
                                                     const int32_t* __restrict__ pair_b, int32_t* __restrict__ best_idx,
                                                     int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist) {
+  __shared__ int s_d1[4][64], s_d2[4][64], s_idx[4][64];
   const int p = blockIdx.y;
   const int fa = pair_a ? pair_a[p] : 0, fb = pair_b ? pair_b[p] : 1;
   const int na = n_rows[fa], nb = n_rows[fb];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= na) return;
-  const unsigned long long* A = reinterpret_cast<const unsigned long long*>(desc + ((size_t)fa * cap + i) * 32);
+  if ((int)blockIdx.x * 64 >= na) return;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(wave_id());  // make the train range provably wave-uniform
+  const int i = blockIdx.x * 64 + lane;
+  const bool valid = i < na;
+  const unsigned long long* A = reinterpret_cast<const unsigned long long*>(desc + ((size_t)fa * cap + (valid ? i : 0)) * 32);
   const unsigned long long* B = reinterpret_cast<const unsigned long long*>(desc + (size_t)fb * cap * 32);
   const unsigned long long q[4] = {A[0], A[1], A[2], A[3]};
+  const int chunk = (nb + 3) >> 2;
+  const int j0 = wave * chunk, j1 = imin(j0 + chunk, nb);
   int d1 = 256, d2 = 256, idx = -1;
-  for (int j = 0; j < nb; ++j) {
-    const int d = hamming256(q, B + 4 * (size_t)j);
-    if (d < d1) { d2 = d1; d1 = d; idx = j; }
-    else if (d < d2) { d2 = d; }
+  int j = j0;
+  for (; j + 4 <= j1; j += 4) {
+    const unsigned long long* t = B + 4 * (size_t)j;
+    const int e0 = hamming256(q, t), e1 = hamming256(q, t + 4), e2 = hamming256(q, t + 8), e3 = hamming256(q, t + 12);
+    if (e0 < d1) { d2 = d1; d1 = e0; idx = j; } else if (e0 < d2) { d2 = e0; }
+    if (e1 < d1) { d2 = d1; d1 = e1; idx = j + 1; } else if (e1 < d2) { d2 = e1; }
+    if (e2 < d1) { d2 = d1; d1 = e2; idx = j + 2; } else if (e2 < d2) { d2 = e2; }
+    if (e3 < d1) { d2 = d1; d1 = e3; idx = j + 3; } else if (e3 < d2) { d2 = e3; }
   }
-  const size_t o = (size_t)p * cap + i;
-  best_idx[o] = idx;
-  best_dist[o] = d1;
-  if (second_dist) second_dist[o] = d2;
+  for (; j < j1; ++j) {
+    const int d = hamming256(q, B + 4 * (size_t)j);
+    if (d < d1) { d2 = d1; d1 = d; idx = j; } else if (d < d2) { d2 = d; }
+  }
+  s_d1[wave][lane] = d1;
+  s_d2[wave][lane] = d2;
+  s_idx[wave][lane] = idx;
+  __syncthreads();
+  if (wave == 0 && valid) {
+    for (int w = 1; w < 4; ++w) {
+      const int e1 = s_d1[w][lane], e2 = s_d2[w][lane], eidx = s_idx[w][lane];
+      if (e1 < d1) { d2 = imin(d1, e2); d1 = e1; idx = eidx; }  // a strictly smaller distance in a later range
+      else { d2 = imin(d2, e1); }                               // ties keep the earlier index
+    }
+    const size_t o = (size_t)p * cap + i;
+    best_idx[o] = idx;
+    best_dist[o] = d1;
+    if (second_dist) second_dist[o] = d2;
+  }
 }
 
 struct TriDev {
@@ -232,7 +262,7 @@ int rgbl_hamming_bf_batch_device(rgbl_matcher* m, const uint8_t* d_desc, const i
   if (n_pairs == 0) return RGBL_OK;
   RGBL_HIP(hipSetDevice(m->device));
   m->timer.begin("k_hamming_bf", m->stream);
-  hipLaunchKernelGGL(k_hamming_bf, dim3((cap + 255) / 256, n_pairs), dim3(256), 0, m->stream, d_desc, d_n, cap, d_pair_a,
+  hipLaunchKernelGGL(k_hamming_bf, dim3((cap + 63) / 64, n_pairs), dim3(256), 0, m->stream, d_desc, d_n, cap, d_pair_a,
                      d_pair_b, d_best_idx, d_best_dist, d_second_dist);
   m->timer.end(m->stream);
   RGBL_HIP(hipGetLastError());
@@ -262,7 +292,7 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   RGBL_HIP(hipMemcpyAsync(d_n, counts, sizeof(counts), hipMemcpyHostToDevice, s));
   m->timer.begin("k_hamming_bf", s);
   // pair_a/pair_b == NULL selects the fixed pair (frame 0 -> frame 1)
-  hipLaunchKernelGGL(k_hamming_bf, dim3((na + 255) / 256, 1), dim3(256), 0, s, d_desc, d_n, cap, (const int32_t*)nullptr,
+  hipLaunchKernelGGL(k_hamming_bf, dim3((na + 63) / 64, 1), dim3(256), 0, s, d_desc, d_n, cap, (const int32_t*)nullptr,
                      (const int32_t*)nullptr, d_bi, d_bd, d_sd);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());

@@ -185,6 +185,7 @@ template <class T> inline T __shfl_down(T v, unsigned delta, int width = 64) {
   return emu_shfl_generic(v, src);
 }
 
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // wave-uniform by construction where it is used
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
