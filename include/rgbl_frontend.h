@@ -113,6 +113,10 @@ int rgbl_extractor_get_level(rgbl_extractor* h, int frame, int level, int blurre
 int rgbl_extractor_get_candidates(rgbl_extractor* h, int frame, int level, rgbl_keypoint* out, int cap,
                                   int* out_n);
 
+/* Diagnostics: with RGBL_OCTREE_STAMPS set in the environment the quad-tree kernel leaves 16 cycle-counter stamps
+ * per (frame, level) workgroup; this copies them out. */
+int rgbl_extractor_debug_stamps(rgbl_extractor* h, unsigned long long* out, int count);
+
 /* Stream control + per-kernel timing (HIP events on the launch stream) for bench.py. */
 int rgbl_extractor_set_stream(rgbl_extractor* h, void* hip_stream /* hipStream_t, NULL = own */);
 void* rgbl_extractor_stream(rgbl_extractor* h); /* hipStream_t currently used by the handle */

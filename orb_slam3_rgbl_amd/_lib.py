@@ -69,6 +69,7 @@ SYMBOLS = {
     "rgbl_extractor_level_size": (_I, [_V, _I, C.POINTER(_I), C.POINTER(_I)]),
     "rgbl_extractor_get_level": (_I, [_V, _I, _I, _I, _I, _V, _I]),
     "rgbl_extractor_get_candidates": (_I, [_V, _I, _I, _V, _I, C.POINTER(_I)]),
+    "rgbl_extractor_debug_stamps": (_I, [_V, _V, _I]),
     "rgbl_extractor_set_stream": (_I, [_V, _V]),
     "rgbl_extractor_profile": (_I, [_V, _I]),
     "rgbl_extractor_profile_read": (_I, [_V, _V, _V, _V, _I]),

@@ -89,6 +89,13 @@ struct KernelTimer {
 
 // ---- device helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }  // round-half-even
+__device__ __forceinline__ unsigned long long rgbl_clock() {
+#ifdef RGBL_EMU
+  return 0;
+#else
+  return (unsigned long long)__builtin_readcyclecounter();
+#endif
+}
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

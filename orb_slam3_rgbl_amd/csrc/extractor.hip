@@ -13,6 +13,7 @@
 //   kp     : selected keys per level (kcap each) and the per-(frame,level) counts
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -72,6 +73,7 @@ struct rgbl_extractor {
   uint32_t* d_kpkey = nullptr;
   int* d_kpcount = nullptr;
   int* d_err = nullptr;
+  unsigned long long* d_dbg = nullptr;
   // staging for the host entry points and for the lapping permutation
   rgbl_keypoint *d_out_kp = nullptr, *d_tmp_kp = nullptr;
   uint8_t *d_out_desc = nullptr, *d_tmp_desc = nullptr;
@@ -278,6 +280,7 @@ int alloc_scratch(rgbl_extractor* e) {
   RGBL_TRY(dev_alloc(e, &e->d_kpkey, B * (size_t)e->kp_frame));
   RGBL_TRY(dev_alloc(e, &e->d_kpcount, B * (size_t)e->L));
   RGBL_TRY(dev_alloc(e, &e->d_err, 1));
+  RGBL_TRY(dev_alloc(e, &e->d_dbg, B * (size_t)e->L * 16));
   RGBL_HIP(hipMemset(e->d_err, 0, sizeof(int)));
   e->out_cap = e->kp_frame;
   RGBL_TRY(dev_alloc(e, &e->d_out_kp, B * (size_t)e->out_cap));
@@ -327,6 +330,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   ob.rootx = e->d_rootx;
   ob.kp_key = e->d_kpkey; ob.kp_count = e->d_kpcount; ob.kp_frame = (size_t)e->kp_frame;
   ob.err = e->d_err;
+  ob.dbg = getenv("RGBL_OCTREE_STAMPS") ? e->d_dbg : nullptr;
   e->timer.begin("k_octree", s);
   hipLaunchKernelGGL(k_octree, dim3(L, batch), dim3(256), 0, s, e->d_geom, L, ob);
   e->timer.end(s);
@@ -584,6 +588,14 @@ int rgbl_extractor_get_candidates(rgbl_extractor* e, int frame, int level, rgbl_
   return RGBL_OK;
 }
 
+int rgbl_extractor_debug_stamps(rgbl_extractor* e, unsigned long long* out, int count) {
+  if (!e || !out) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipStreamSynchronize(e->stream));
+  const size_t n = std::min((size_t)count, (size_t)e->cfg.max_batch * e->L * 16);
+  RGBL_HIP(hipMemcpy(out, e->d_dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return RGBL_OK;
+}
+
 int rgbl_extractor_set_stream(rgbl_extractor* e, void* hip_stream) {
   if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipStreamSynchronize(e->stream));
@@ -628,6 +640,9 @@ int rgbl_extractor_profile_read(rgbl_extractor* e, const char** names, double* t
 #ifdef RGBL_EMU
 // test hook (emulation build only): the libstdc++ introsort restatement on plain arrays
 void rgbl_test_std_sort(uint64_t* key, uint32_t* val, int n) { rgbl::std_sort_restated(key, val, n); }
+void rgbl_test_block_sort(uint64_t* key, uint32_t* val, int n) {
+  hipLaunchKernelGGL(rgbl::k_test_block_sort, dim3(1), dim3(256), 0, (hipStream_t) nullptr, key, val, n);
+}
 #endif
 
 }  // extern "C"

@@ -507,6 +507,7 @@ struct OctreeBufs {
   const uint8_t* rootx;
   uint32_t* kp_key; int* kp_count; size_t kp_frame;  // outputs: selected keys per level, counts [B][L]
   int* err;
+  unsigned long long* dbg;  // optional: 16 cycle-counter stamps per (frame, level) workgroup (diagnostics)
 };
 
 __device__ __forceinline__ int quadrant_of(uint32_t key, int mx, int my) {
@@ -563,7 +564,128 @@ __device__ __forceinline__ QNode child_node(const QNode& nd, int q, uint32_t beg
   return c;
 }
 
-constexpr int kSortLds = 2048;
+constexpr int kSortLds = 2048;     // largest expandable-node list sorted in LDS by the whole workgroup
+constexpr int kSortRanges = 160;   // > kSortLds / 17: pending ranges of more than 16 elements are disjoint
+
+struct SortRanges { int first[kSortRanges], last[kSortRanges], depth[kSortRanges]; };
+
+// Workgroup version of std_sort_restated().  libstdc++'s introsort partitions disjoint ranges independently, so
+// every pending range is partitioned by its own work-item (rounds = recursion depth), and the closing insertion
+// sort never moves an element out of its <= 16-element leaf (left part <= pivot <= right part), i.e. it is a
+// stable sort of every leaf: done here as a rank computation, one work-item per element.
+// key/val may be read up to 4 entries outside [0, m) (padding required on both sides).
+__device__ __forceinline__ void block_sort_restated(uint64_t* key, uint32_t* val, int m, uint16_t* seg_first,
+                                                    uint16_t* seg_last, SortRanges* ra, SortRanges* rb, int* s_cnt) {
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_cnt[0] = s_cnt[1] = 0;
+    if (m > 16) {
+      int lg = 0;
+      while ((m >> (lg + 1)) != 0) ++lg;
+      ra->first[0] = 0; ra->last[0] = m; ra->depth[0] = 2 * lg;
+      s_cnt[0] = 1;
+    }
+  }
+  if (m <= 16)
+    for (int i = tid; i < m; i += 256) { seg_first[i] = 0; seg_last[i] = (uint16_t)m; }
+  __syncthreads();
+  SortRanges* cur = ra;
+  SortRanges* nxt = rb;
+  int ci = 0;
+  const SortView a{key, val};
+  for (;;) {
+    const int nr = s_cnt[ci];
+    if (nr == 0) break;
+    for (int r = tid; r < nr; r += 256) {
+      const int first = cur->first[r], last = cur->last[r];
+      int depth = cur->depth[r];
+      if (depth == 0) {  // __partial_sort(first, last, last): heap sort, the range is final afterwards
+        ss_heap_sort(a, first, last);
+        for (int i = first; i < last; ++i) { seg_first[i] = (uint16_t)i; seg_last[i] = (uint16_t)(i + 1); }
+        continue;
+      }
+      --depth;
+      const int mid = first + (last - first) / 2;
+      const int A = first + 1, B = mid, C = last - 1;
+      if (a.less(A, B)) {
+        if (a.less(B, C)) a.swap(first, B);
+        else if (a.less(A, C)) a.swap(first, C);
+        else a.swap(first, A);
+      } else if (a.less(A, C)) a.swap(first, A);
+      else if (a.less(B, C)) a.swap(first, C);
+      else a.swap(first, B);
+      int lo = first + 1, hi = last;
+      const uint64_t pivot = key[first];
+      for (;;) {
+        for (;;) {  // while (key[lo] < pivot) ++lo;  four reads in flight
+          const uint64_t k0 = key[lo], k1 = key[lo + 1], k2 = key[lo + 2], k3 = key[lo + 3];
+          if (!(k0 < pivot)) break;
+          ++lo;
+          if (!(k1 < pivot)) break;
+          ++lo;
+          if (!(k2 < pivot)) break;
+          ++lo;
+          if (!(k3 < pivot)) break;
+          ++lo;
+        }
+        --hi;
+        for (;;) {  // while (pivot < key[hi]) --hi;
+          const uint64_t k0 = key[hi], k1 = key[hi - 1], k2 = key[hi - 2], k3 = key[hi - 3];
+          if (!(pivot < k0)) break;
+          --hi;
+          if (!(pivot < k1)) break;
+          --hi;
+          if (!(pivot < k2)) break;
+          --hi;
+          if (!(pivot < k3)) break;
+          --hi;
+        }
+        if (!(lo < hi)) break;
+        a.swap(lo, hi);
+        ++lo;
+      }
+      const int sub_first[2] = {first, lo}, sub_last[2] = {lo, last};
+      for (int k = 0; k < 2; ++k) {
+        const int f0 = sub_first[k], l0 = sub_last[k];
+        if (l0 - f0 > 16) {
+          const int slot = atomicAdd(&s_cnt[1 - ci], 1);
+          nxt->first[slot] = f0; nxt->last[slot] = l0; nxt->depth[slot] = depth;
+        } else {
+          for (int i = f0; i < l0; ++i) { seg_first[i] = (uint16_t)f0; seg_last[i] = (uint16_t)l0; }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_cnt[ci] = 0;
+    { SortRanges* t = cur; cur = nxt; nxt = t; }
+    ci ^= 1;
+    __syncthreads();
+  }
+  // stable sort of every leaf (== __final_insertion_sort)
+  uint64_t mk[kSortLds / 256];
+  uint32_t mv[kSortLds / 256];
+  int dest[kSortLds / 256];
+#pragma unroll
+  for (int k = 0; k < kSortLds / 256; ++k) {
+    const int i = tid + 256 * k;
+    dest[k] = -1;
+    if (i < m) {
+      const int f0 = seg_first[i], l0 = seg_last[i];
+      const uint64_t kk = key[i];
+      int rank = 0;
+      for (int j = f0; j < l0; ++j) {
+        const uint64_t kj = key[j];
+        rank += (kj < kk || (kj == kk && j < i)) ? 1 : 0;
+      }
+      mk[k] = kk; mv[k] = val[i]; dest[k] = f0 + rank;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kSortLds / 256; ++k)
+    if (dest[k] >= 0) { key[dest[k]] = mk[k]; val[dest[k]] = mv[k]; }
+  __syncthreads();
+}
 
 // Rebuilds the node list after a set of nodes has been split, reproducing std::list push_front/erase:
 //   new list = [children of the LAST processed node (n4..n1), ..., children of the FIRST processed node]
@@ -638,10 +760,16 @@ __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n
 
 __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b) {
   __shared__ unsigned long long s_scan[8];
-  __shared__ unsigned long long s_skey[kSortLds];
+  __shared__ unsigned long long s_skey_pad[kSortLds + 8];  // 4 entries of read slack on both sides
   __shared__ uint32_t s_sval[kSortLds];
+  __shared__ uint16_t s_seg_first[kSortLds], s_seg_last[kSortLds];
+  __shared__ SortRanges s_ra, s_rb;
+  __shared__ int s_sort_cnt[2];
+  unsigned long long* s_skey = s_skey_pad + 4;
   __shared__ int s_newn, s_nexp, s_n, s_P;
   __shared__ uint32_t s_rootcnt[kMaxRoots];
+#define RGBL_STAMP(k) do { if (b.dbg && threadIdx.x == 0) b.dbg[((size_t)blockIdx.y * n_levels + blockIdx.x) * 16 + (k)] = rgbl_clock(); } while (0)
+  RGBL_STAMP(0);
 
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int nw = (int)(blockDim.x >> 6);
@@ -674,6 +802,7 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
   }
   __syncthreads();
 
+  RGBL_STAMP(1);
   // ---- 1. stable partition into the n_ini root nodes (ORBextractor.cc:582-586) -> keys_b
   const uint8_t* rootx = b.rootx + g.rootx_off;
   {
@@ -715,6 +844,7 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
   int n = s_n;
   int m = 0;
 
+  RGBL_STAMP(2);
   // ---- 2. breadth-first splitting (ORBextractor.cc:608-686)
   bool finished = (n == 0);
   bool careful = false;
@@ -741,6 +871,7 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
     else if (n + 3 * nexp > N) { careful = true; break; }
   }
 
+  RGBL_STAMP(3);
   // ---- 3. near the quota: split the most populated nodes first (ORBextractor.cc:689-753)
   while (careful && !finished) {
     const int prev = n;
@@ -754,7 +885,10 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
     }
     for (int p = tid; p < n; p += 256) divided[p] = 0;
     __syncthreads();
-    if (tid == 0) std_sort_restated(skey, sval, m);
+    RGBL_STAMP(8);
+    if (m <= kSortLds) block_sort_restated(skey, sval, m, s_seg_first, s_seg_last, &s_ra, &s_rb, s_sort_cnt);
+    else if (tid == 0) std_sort_restated(skey, sval, m);
+    RGBL_STAMP(9);
     __syncthreads();
     // child counts of every expandable node, rank rho = position counted from the back of the sorted array
     for (int j = wave; j < m; j += nw) {
@@ -800,6 +934,7 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
     else if (n >= N || n == prev) finished = true;
   }
 
+  RGBL_STAMP(4);
   // ---- 4. keep the strongest key of every node, first one on ties (ORBextractor.cc:757-776)
   uint32_t* out = b.kp_key + (size_t)f * b.kp_frame + g.koff;
   if (n > g.kcap) { if (tid == 0) atomicOr(b.err, 2); n = g.kcap; }
@@ -815,6 +950,8 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
     out[pos] = best;
   }
   if (tid == 0) b.kp_count[(size_t)f * n_levels + l] = n;
+  RGBL_STAMP(5);
+  if (b.dbg && tid == 0) { b.dbg[((size_t)f * n_levels + l) * 16 + 6] = C; b.dbg[((size_t)f * n_levels + l) * 16 + 7] = (unsigned long long)n; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -991,6 +1128,20 @@ __global__ __launch_bounds__(256) void k_lapping_permute(const rgbl_keypoint* __
     }
   }
   if (tid == 0) out_mono[f] = n - (int)carry;
+}
+
+// test hook: the workgroup sort on plain arrays (n <= kSortLds)
+__global__ __launch_bounds__(256) void k_test_block_sort(uint64_t* key, uint32_t* val, int n) {
+  __shared__ unsigned long long s_skey_pad[kSortLds + 8];
+  __shared__ uint32_t s_sval[kSortLds];
+  __shared__ uint16_t s_seg_first[kSortLds], s_seg_last[kSortLds];
+  __shared__ SortRanges s_ra, s_rb;
+  __shared__ int s_sort_cnt[2];
+  unsigned long long* s_skey = s_skey_pad + 4;
+  for (int i = threadIdx.x; i < n; i += 256) { s_skey[i] = key[i]; s_sval[i] = val[i]; }
+  __syncthreads();
+  block_sort_restated(reinterpret_cast<uint64_t*>(s_skey), s_sval, n, s_seg_first, s_seg_last, &s_ra, &s_rb, s_sort_cnt);
+  for (int i = threadIdx.x; i < n; i += 256) { key[i] = s_skey[i]; val[i] = s_sval[i]; }
 }
 
 // unpacks candidate keys into rgbl_keypoint records (diagnostic path of rgbl_extractor_get_candidates)

@@ -49,7 +49,8 @@ class Sequence:
         self.margin_x, self.margin_y = 3 * n_frames + 8, n_frames + 8
         rng = np.random.default_rng(0xC0FFEE + 7919 * seq_id)
         if n_shapes is None:
-            n_shapes = int(round(400 * (w * h) / float(KITTI_W * KITTI_H)))
+            # ~1200 shapes at KITTI size give 8-10k FAST candidates on level 0, the density SURVEY.md 8(d) targets
+            n_shapes = int(round(1200 * (w * h) / float(KITTI_W * KITTI_H)))
         self.scene = _scene(rng, w + self.margin_x, h + self.margin_y, n_shapes)
 
     def frame(self, t):

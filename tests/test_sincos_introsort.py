@@ -28,6 +28,11 @@ def _sort_both(emu_lib, oracle, key, val):
     emu_lib.rgbl_test_std_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     oracle.lib().orc_std_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     emu_lib.rgbl_test_std_sort(k1.ctypes.data, v1.ctypes.data, len(k1))
+    if len(key) <= 2048:  # the workgroup-parallel form used by the quad-tree kernel must agree as well
+        k3, v3 = key.copy(), val.copy()
+        emu_lib.rgbl_test_block_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        emu_lib.rgbl_test_block_sort(k3.ctypes.data, v3.ctypes.data, len(k3))
+        assert np.array_equal(k3, k1) and np.array_equal(v3, v1), "block sort differs from the serial restatement"
     oracle.lib().orc_std_sort_pairs(k2.ctypes.data, v2.ctypes.data, len(k2))
     assert np.array_equal(k1, k2)
     assert np.array_equal(v1, v2), "tie order differs from std::sort"
