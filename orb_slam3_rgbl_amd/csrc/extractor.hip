@@ -208,6 +208,10 @@ int build_geometry(rgbl_extractor* e) {
     g.koff = koff;
     koff += g.kcap;
     g.node_cap = (uint32_t)g.kcap + 16;
+    if (g.node_cap > 65535u) {  // list positions travel as 16-bit payloads in the quad-tree's sort
+      set_error("nfeatures too large: level %d would need %u quad-tree nodes (limit 65535)", l, g.node_cap);
+      return RGBL_ERR_INVALID;
+    }
     g.node_off = (uint32_t)node_off;
     node_off += g.node_cap;
     g.xtab_off = (uint32_t)xtab_off;

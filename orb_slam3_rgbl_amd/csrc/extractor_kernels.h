@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
 // FAST-9/16 on one detection cell per workgroup.
 constexpr int kCellMax = 72;             // max scanned cell side handled (wCell/hCell <= 72)
 constexpr int kTileP = kCellMax + 8;     // LDS tile pitch (cell + 6 ring margin, padded)
-constexpr int kScoreP = kCellMax + 2;
+constexpr int kScoreP = kCellMax + 4;     // score tile pitch (cell + 1-px zero frame), multiple of 4
 
 // Bresenham ring of radius 3, OpenCV order (modules/features2d/src/fast_score.cpp makeOffsets)
 #define RGBL_RING(c, P, k)                                                                            \
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
                                                     uint32_t* __restrict__ slots, size_t slots_frame) {
   __shared__ uint32_t s_tile_w[(kCellMax + 6) * kTileP / 4];
   uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile_w);
-  __shared__ uint8_t s_score[(kCellMax + 2) * kScoreP];
+  __shared__ uint32_t s_score_w[(kCellMax + 2) * kScoreP / 4];
+  uint8_t* s_score = reinterpret_cast<uint8_t*>(s_score_w);
   __shared__ uint16_t s_surv[kCellMax * kCellMax];
   __shared__ uint32_t s_scan[8];
   __shared__ int s_nsurv, s_any_ini;
@@ -204,21 +205,23 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   const int pitch = (l == 0) ? pitch0 : g.pitch;
 
   // ---- stage the (sw+6) x (sh+6) pixel tile and clear the score tile
+  const int npix = sw * sh;
+  const uint32_t magic = 0xFFFFFFFFu / (uint32_t)sw + 1u;  // p / sw == __umulhi(p, magic) for p < 2^16
   {
     const int nwords = (tw + 3) >> 2;  // reads at most 3 bytes past the tile, still >= 13 px inside the row
+    const uint32_t wmagic = 0xFFFFFFFFu / (uint32_t)nwords + 1u;
     for (int i = tid; i < nwords * th; i += 256) {
-      const int y = i / nwords, k = i - y * nwords;
+      const int y = (int)__umulhi((uint32_t)i, wmagic), k = i - y * nwords;
       s_tile_w[(y * kTileP >> 2) + k] = load_u32_unaligned(img + (size_t)(ini_y + y) * pitch + ini_x + 4 * k);
     }
   }
-  for (int i = tid; i < (sh + 2) * kScoreP; i += 256) s_score[i] = 0;
+  for (int i = tid; i < (sh + 2) * (kScoreP / 4); i += 256) s_score_w[i] = 0;
   if (tid == 0) { s_nsurv = 0; s_any_ini = 0; }
   __syncthreads();
 
   // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are compacted
-  const int npix = sw * sh;
   for (int p = tid; p < npix; p += 256) {
-    const int y = p / sw, x = p - y * sw;
+    const int y = (int)__umulhi((uint32_t)p, magic), x = p - y * sw;
     const uint8_t* c = &s_tile[(y + 3) * kTileP + x + 3];
     const int v = c[0], lo = v - min_th, hi = v + min_th;
     bool dark = true, bright = true;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   const int nsurv = s_nsurv;
   for (int i = tid; i < nsurv; i += 256) {
     const int p = s_surv[i];
-    const int y = p / sw, x = p - y * sw;
+    const int y = (int)__umulhi((uint32_t)p, magic), x = p - y * sw;
     const int sc = fast_true_score(&s_tile[(y + 3) * kTileP + x + 3], kTileP);
     if (sc >= min_th) s_score[(y + 1) * kScoreP + x + 1] = (uint8_t)sc;
   }
@@ -249,35 +252,38 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   //      compaction below reproduces cv::FAST's row-major emission order
   const int per = (npix + 255) >> 8;  // <= 21
   const int p0 = tid * per, p1 = imin(p0 + per, npix);
-  uint32_t keep = 0;
-  bool has_ini = false;
-  for (int p = p0; p < p1; ++p) {
-    const int y = p / sw, x = p - y * sw;
-    const uint8_t* s = &s_score[(y + 1) * kScoreP + x + 1];
-    const int v = s[0];
-    if (v == 0) continue;
-    if (v > s[-1] && v > s[1] && v > s[-kScoreP - 1] && v > s[-kScoreP] && v > s[-kScoreP + 1] &&
-        v > s[kScoreP - 1] && v > s[kScoreP] && v > s[kScoreP + 1]) {
-      keep |= 1u << (p - p0);
-      has_ini = has_ini || v >= ini_th;
+  const int y_first = (int)__umulhi((uint32_t)p0, magic), x_first = p0 - y_first * sw;
+  uint32_t keep = 0, keep_ini = 0;
+  {
+    int x = x_first, y = y_first;
+    for (int p = p0; p < p1; ++p) {
+      const uint8_t* s = &s_score[(y + 1) * kScoreP + x + 1];
+      const int v = s[0];
+      if (v != 0 && v > s[-1] && v > s[1] && v > s[-kScoreP - 1] && v > s[-kScoreP] && v > s[-kScoreP + 1] &&
+          v > s[kScoreP - 1] && v > s[kScoreP] && v > s[kScoreP + 1]) {
+        keep |= 1u << (p - p0);
+        if (v >= ini_th) keep_ini |= 1u << (p - p0);
+      }
+      if (++x == sw) { x = 0; ++y; }
     }
   }
-  if (has_ini) s_any_ini = 1;
+  if (keep_ini) s_any_ini = 1;
   __syncthreads();
   // two-threshold rule of ORBextractor.cc:826-846: the ini-threshold set if it is non-empty, else the min set
-  if (s_any_ini) {
-    for (int p = p0; p < p1; ++p)
-      if (((keep >> (p - p0)) & 1) && s_score[(p / sw + 1) * kScoreP + (p % sw) + 1] < ini_th) keep &= ~(1u << (p - p0));
-  }
+  if (s_any_ini) keep = keep_ini;
   uint32_t total;
   uint32_t base = block_exclusive_scan<uint32_t>((uint32_t)__popc(keep), s_scan, &total);
-  uint32_t* out = slots + (size_t)f * slots_frame + g.slot_off + (size_t)ci * g.cell_cap;
-  for (int p = p0; p < p1; ++p) {
-    if (!((keep >> (p - p0)) & 1)) continue;
-    const int y = p / sw, x = p - y * sw;
-    if (base < (uint32_t)g.cell_cap)
-      out[base] = pack_key(ci_col * g.w_cell + 3 + x, ci_row * g.h_cell + 3 + y, s_score[(y + 1) * kScoreP + x + 1]);
-    ++base;
+  if (keep) {
+    uint32_t* out = slots + (size_t)f * slots_frame + g.slot_off + (size_t)ci * g.cell_cap;
+    int x = x_first, y = y_first;
+    for (int p = p0; p < p1; ++p) {
+      if ((keep >> (p - p0)) & 1) {
+        if (base < (uint32_t)g.cell_cap)
+          out[base] = pack_key(ci_col * g.w_cell + 3 + x, ci_row * g.h_cell + 3 + y, s_score[(y + 1) * kScoreP + x + 1]);
+        ++base;
+      }
+      if (++x == sw) { x = 0; ++y; }
+    }
   }
   if (tid == 0) *my_cnt = total < (uint32_t)g.cell_cap ? total : (uint32_t)g.cell_cap;  // cap is a proven bound
 }
@@ -573,9 +579,55 @@ struct SortRanges { int first[kSortRanges], last[kSortRanges], depth[kSortRanges
 // every pending range is partitioned by its own work-item (rounds = recursion depth), and the closing insertion
 // sort never moves an element out of its <= 16-element leaf (left part <= pivot <= right part), i.e. it is a
 // stable sort of every leaf: done here as a rank computation, one work-item per element.
-// key/val may be read up to 4 entries outside [0, m) (padding required on both sides).
-__device__ __forceinline__ void block_sort_restated(uint64_t* key, uint32_t* val, int m, uint16_t* seg_first,
-                                                    uint16_t* seg_last, SortRanges* ra, SortRanges* rb, int* s_cnt) {
+// Elements are single 64-bit words: sort key in bits 63..16, payload (list position) in bits 15..0; only the key
+// takes part in comparisons.  w may be read up to 4 entries outside [0, m) (padding required on both sides).
+__device__ __forceinline__ bool pk_less(uint64_t a, uint64_t b) { return (a >> 16) < (b >> 16); }
+
+__device__ __forceinline__ void pk_push_heap(uint64_t* w, int first, int hole, int top, uint64_t value) {
+  int parent = (hole - 1) / 2;
+  while (hole > top && pk_less(w[first + parent], value)) {
+    w[first + hole] = w[first + parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  w[first + hole] = value;
+}
+__device__ __forceinline__ void pk_adjust_heap(uint64_t* w, int first, int hole, int len, uint64_t value) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (pk_less(w[first + child], w[first + child - 1])) --child;
+    w[first + hole] = w[first + child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    w[first + hole] = w[first + child - 1];
+    hole = child - 1;
+  }
+  pk_push_heap(w, first, hole, top, value);
+}
+__device__ __forceinline__ void pk_heap_sort(uint64_t* w, int first, int last) {
+  const int len = last - first;
+  if (len >= 2) {
+    int parent = (len - 2) / 2;
+    for (;;) {
+      pk_adjust_heap(w, first, parent, len, w[first + parent]);
+      if (parent == 0) break;
+      --parent;
+    }
+  }
+  while (last - first > 1) {
+    --last;
+    const uint64_t v = w[last];
+    w[last] = w[first];
+    pk_adjust_heap(w, first, 0, last - first, v);
+  }
+}
+
+__device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t* seg_first, uint16_t* seg_last,
+                                                    SortRanges* ra, SortRanges* rb, int* s_cnt) {
   const int tid = threadIdx.x;
   if (tid == 0) {
     s_cnt[0] = s_cnt[1] = 0;
@@ -592,7 +644,6 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* key, uint32_t* val
   SortRanges* cur = ra;
   SortRanges* nxt = rb;
   int ci = 0;
-  const SortView a{key, val};
   for (;;) {
     const int nr = s_cnt[ci];
     if (nr == 0) break;
@@ -600,48 +651,51 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* key, uint32_t* val
       const int first = cur->first[r], last = cur->last[r];
       int depth = cur->depth[r];
       if (depth == 0) {  // __partial_sort(first, last, last): heap sort, the range is final afterwards
-        ss_heap_sort(a, first, last);
+        pk_heap_sort(w, first, last);
         for (int i = first; i < last; ++i) { seg_first[i] = (uint16_t)i; seg_last[i] = (uint16_t)(i + 1); }
         continue;
       }
       --depth;
-      const int mid = first + (last - first) / 2;
-      const int A = first + 1, B = mid, C = last - 1;
-      if (a.less(A, B)) {
-        if (a.less(B, C)) a.swap(first, B);
-        else if (a.less(A, C)) a.swap(first, C);
-        else a.swap(first, A);
-      } else if (a.less(A, C)) a.swap(first, A);
-      else if (a.less(B, C)) a.swap(first, C);
-      else a.swap(first, B);
+      // __move_median_to_first(first, first+1, mid, last-1)
+      const int A = first + 1, B = first + (last - first) / 2, C = last - 1;
+      const uint64_t wf = w[first], wa = w[A], wb = w[B], wc = w[C];
+      int X;
+      if (pk_less(wa, wb)) X = pk_less(wb, wc) ? B : (pk_less(wa, wc) ? C : A);
+      else X = pk_less(wa, wc) ? A : (pk_less(wb, wc) ? C : B);
+      const uint64_t pivot = X == A ? wa : (X == B ? wb : wc);
+      w[first] = pivot;
+      w[X] = wf;
+      // __unguarded_partition(first+1, last, pivot); the scans keep four LDS reads in flight and hand the
+      // element they stop at to the swap, which therefore is two plain stores
       int lo = first + 1, hi = last;
-      const uint64_t pivot = key[first];
       for (;;) {
-        for (;;) {  // while (key[lo] < pivot) ++lo;  four reads in flight
-          const uint64_t k0 = key[lo], k1 = key[lo + 1], k2 = key[lo + 2], k3 = key[lo + 3];
-          if (!(k0 < pivot)) break;
+        uint64_t klo, khi;
+        for (;;) {
+          const uint64_t k0 = w[lo], k1 = w[lo + 1], k2 = w[lo + 2], k3 = w[lo + 3];
+          klo = k0; if (!pk_less(k0, pivot)) break;
           ++lo;
-          if (!(k1 < pivot)) break;
+          klo = k1; if (!pk_less(k1, pivot)) break;
           ++lo;
-          if (!(k2 < pivot)) break;
+          klo = k2; if (!pk_less(k2, pivot)) break;
           ++lo;
-          if (!(k3 < pivot)) break;
+          klo = k3; if (!pk_less(k3, pivot)) break;
           ++lo;
         }
         --hi;
-        for (;;) {  // while (pivot < key[hi]) --hi;
-          const uint64_t k0 = key[hi], k1 = key[hi - 1], k2 = key[hi - 2], k3 = key[hi - 3];
-          if (!(pivot < k0)) break;
+        for (;;) {
+          const uint64_t k0 = w[hi], k1 = w[hi - 1], k2 = w[hi - 2], k3 = w[hi - 3];
+          khi = k0; if (!pk_less(pivot, k0)) break;
           --hi;
-          if (!(pivot < k1)) break;
+          khi = k1; if (!pk_less(pivot, k1)) break;
           --hi;
-          if (!(pivot < k2)) break;
+          khi = k2; if (!pk_less(pivot, k2)) break;
           --hi;
-          if (!(pivot < k3)) break;
+          khi = k3; if (!pk_less(pivot, k3)) break;
           --hi;
         }
         if (!(lo < hi)) break;
-        a.swap(lo, hi);
+        w[lo] = khi;
+        w[hi] = klo;
         ++lo;
       }
       const int sub_first[2] = {first, lo}, sub_last[2] = {lo, last};
@@ -662,8 +716,7 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* key, uint32_t* val
     __syncthreads();
   }
   // stable sort of every leaf (== __final_insertion_sort)
-  uint64_t mk[kSortLds / 256];
-  uint32_t mv[kSortLds / 256];
+  uint64_t mine[kSortLds / 256];
   int dest[kSortLds / 256];
 #pragma unroll
   for (int k = 0; k < kSortLds / 256; ++k) {
@@ -671,19 +724,20 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* key, uint32_t* val
     dest[k] = -1;
     if (i < m) {
       const int f0 = seg_first[i], l0 = seg_last[i];
-      const uint64_t kk = key[i];
+      const uint64_t kk = w[i];
       int rank = 0;
       for (int j = f0; j < l0; ++j) {
-        const uint64_t kj = key[j];
-        rank += (kj < kk || (kj == kk && j < i)) ? 1 : 0;
+        const uint64_t kj = w[j];
+        rank += (pk_less(kj, kk) || (!pk_less(kk, kj) && j < i)) ? 1 : 0;
       }
-      mk[k] = kk; mv[k] = val[i]; dest[k] = f0 + rank;
+      mine[k] = kk;
+      dest[k] = f0 + rank;
     }
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < kSortLds / 256; ++k)
-    if (dest[k] >= 0) { key[dest[k]] = mk[k]; val[dest[k]] = mv[k]; }
+    if (dest[k] >= 0) w[dest[k]] = mine[k];
   __syncthreads();
 }
 
@@ -875,21 +929,34 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
   // ---- 3. near the quota: split the most populated nodes first (ORBextractor.cc:689-753)
   while (careful && !finished) {
     const int prev = n;
-    uint64_t* skey = (m <= kSortLds) ? reinterpret_cast<uint64_t*>(s_skey) : b.skey + nbase;
+    // compareNodes orders by (size, UL.x); equal keys end up in libstdc++'s introsort order
     uint32_t* sval = (m <= kSortLds) ? s_sval : b.sval + nbase;
-    for (int j = tid; j < m; j += 256) {
-      const uint32_t pos = todo[j];
-      const QNode nd = cur[pos];
-      skey[j] = ((uint64_t)(nd.cnt & 0x7fffffffu) << 32) | nd.x0;  // compareNodes: (size, UL.x)
-      sval[j] = pos;
-    }
     for (int p = tid; p < n; p += 256) divided[p] = 0;
-    __syncthreads();
-    RGBL_STAMP(8);
-    if (m <= kSortLds) block_sort_restated(skey, sval, m, s_seg_first, s_seg_last, &s_ra, &s_rb, s_sort_cnt);
-    else if (tid == 0) std_sort_restated(skey, sval, m);
-    RGBL_STAMP(9);
-    __syncthreads();
+    if (m <= kSortLds) {
+      uint64_t* w = reinterpret_cast<uint64_t*>(s_skey);
+      for (int j = tid; j < m; j += 256) {
+        const uint32_t pos = todo[j];
+        const QNode nd = cur[pos];
+        w[j] = ((uint64_t)(nd.cnt & 0x7fffffffu) << 28) | ((uint64_t)nd.x0 << 16) | pos;  // x0 < 4096, pos < 65536
+      }
+      __syncthreads();
+      RGBL_STAMP(8);
+      block_sort_restated(w, m, s_seg_first, s_seg_last, &s_ra, &s_rb, s_sort_cnt);
+      RGBL_STAMP(9);
+      for (int j = tid; j < m; j += 256) sval[j] = (uint32_t)(w[j] & 0xffffu);
+      __syncthreads();
+    } else {
+      uint64_t* skey = b.skey + nbase;
+      for (int j = tid; j < m; j += 256) {
+        const uint32_t pos = todo[j];
+        const QNode nd = cur[pos];
+        skey[j] = ((uint64_t)(nd.cnt & 0x7fffffffu) << 32) | nd.x0;
+        sval[j] = pos;
+      }
+      __syncthreads();
+      if (tid == 0) std_sort_restated(skey, sval, m);
+      __syncthreads();
+    }
     // child counts of every expandable node, rank rho = position counted from the back of the sorted array
     for (int j = wave; j < m; j += nw) {
       const QNode nd = cur[sval[j]];
@@ -1130,18 +1197,17 @@ __global__ __launch_bounds__(256) void k_lapping_permute(const rgbl_keypoint* __
   if (tid == 0) out_mono[f] = n - (int)carry;
 }
 
-// test hook: the workgroup sort on plain arrays (n <= kSortLds)
+// test hook: the workgroup sort on plain arrays (n <= kSortLds, key < 2^48, val < 2^16)
 __global__ __launch_bounds__(256) void k_test_block_sort(uint64_t* key, uint32_t* val, int n) {
   __shared__ unsigned long long s_skey_pad[kSortLds + 8];
-  __shared__ uint32_t s_sval[kSortLds];
   __shared__ uint16_t s_seg_first[kSortLds], s_seg_last[kSortLds];
   __shared__ SortRanges s_ra, s_rb;
   __shared__ int s_sort_cnt[2];
-  unsigned long long* s_skey = s_skey_pad + 4;
-  for (int i = threadIdx.x; i < n; i += 256) { s_skey[i] = key[i]; s_sval[i] = val[i]; }
+  uint64_t* w = reinterpret_cast<uint64_t*>(s_skey_pad + 4);
+  for (int i = threadIdx.x; i < n; i += 256) w[i] = (key[i] << 16) | (val[i] & 0xffffu);
   __syncthreads();
-  block_sort_restated(reinterpret_cast<uint64_t*>(s_skey), s_sval, n, s_seg_first, s_seg_last, &s_ra, &s_rb, s_sort_cnt);
-  for (int i = threadIdx.x; i < n; i += 256) { key[i] = s_skey[i]; val[i] = s_sval[i]; }
+  block_sort_restated(w, n, s_seg_first, s_seg_last, &s_ra, &s_rb, s_sort_cnt);
+  for (int i = threadIdx.x; i < n; i += 256) { key[i] = w[i] >> 16; val[i] = (uint32_t)(w[i] & 0xffffu); }
 }
 
 // unpacks candidate keys into rgbl_keypoint records (diagnostic path of rgbl_extractor_get_candidates)
