@@ -108,6 +108,18 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return imin(imax(p, 0), len - 1);  // far-out-of-range taps only feed outputs that are never stored
 }
 
+// Orders LDS traffic between the lanes of ONE wave (cross-lane hand-off through LDS without a workgroup barrier):
+// on gfx950 the lanes run in lockstep, so this only has to stop the compiler from moving memory operations.
+__device__ __forceinline__ void wave_sync() {
+#ifdef RGBL_EMU
+  (void)__ballot(1);  // the emulator's lanes are independent fibers: rendezvous
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 template <class T>
 __device__ __forceinline__ T wave_sum(T v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

@@ -336,7 +336,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   ob.err = e->d_err;
   ob.dbg = getenv("RGBL_OCTREE_STAMPS") ? e->d_dbg : nullptr;
   e->timer.begin("k_octree", s);
-  hipLaunchKernelGGL(k_octree, dim3(L, batch), dim3(256), 0, s, e->d_geom, L, ob);
+  hipLaunchKernelGGL(k_octree, dim3(L, batch), dim3(kOctBS), 0, s, e->d_geom, L, ob);
   e->timer.end(s);
   // 4. Gaussian working images (ORBextractor.cc:1132-1133)
   e->timer.begin("k_gauss7", s);
@@ -645,7 +645,7 @@ int rgbl_extractor_profile_read(rgbl_extractor* e, const char** names, double* t
 // test hook (emulation build only): the libstdc++ introsort restatement on plain arrays
 void rgbl_test_std_sort(uint64_t* key, uint32_t* val, int n) { rgbl::std_sort_restated(key, val, n); }
 void rgbl_test_block_sort(uint64_t* key, uint32_t* val, int n) {
-  hipLaunchKernelGGL(rgbl::k_test_block_sort, dim3(1), dim3(256), 0, (hipStream_t) nullptr, key, val, n);
+  hipLaunchKernelGGL(rgbl::k_test_block_sort, dim3(1), dim3(rgbl::kOctBS), 0, (hipStream_t) nullptr, key, val, n);
 }
 #endif
 

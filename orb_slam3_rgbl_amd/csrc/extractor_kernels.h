@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
 
   // ---- stage the (sw+6) x (sh+6) pixel tile and clear the score tile
   const int npix = sw * sh;
-  const uint32_t magic = 0xFFFFFFFFu / (uint32_t)sw + 1u;  // p / sw == __umulhi(p, magic) for p < 2^16
+  // p / sw == __umulhi(p, magic) for p < 2^16; a one-pixel-wide last cell (sw == 1) would overflow the magic
+  const uint32_t magic = sw > 1 ? 0xFFFFFFFFu / (uint32_t)sw + 1u : 0u;
+#define RGBL_DIV_SW(p) (sw > 1 ? (int)__umulhi((uint32_t)(p), magic) : (int)(p))
   {
     const int nwords = (tw + 3) >> 2;  // reads at most 3 bytes past the tile, still >= 13 px inside the row
     const uint32_t wmagic = 0xFFFFFFFFu / (uint32_t)nwords + 1u;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
 
   // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are compacted
   for (int p = tid; p < npix; p += 256) {
-    const int y = (int)__umulhi((uint32_t)p, magic), x = p - y * sw;
+    const int y = RGBL_DIV_SW(p), x = p - y * sw;
     const uint8_t* c = &s_tile[(y + 3) * kTileP + x + 3];
     const int v = c[0], lo = v - min_th, hi = v + min_th;
     bool dark = true, bright = true;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   const int nsurv = s_nsurv;
   for (int i = tid; i < nsurv; i += 256) {
     const int p = s_surv[i];
-    const int y = (int)__umulhi((uint32_t)p, magic), x = p - y * sw;
+    const int y = RGBL_DIV_SW(p), x = p - y * sw;
     const int sc = fast_true_score(&s_tile[(y + 3) * kTileP + x + 3], kTileP);
     if (sc >= min_th) s_score[(y + 1) * kScoreP + x + 1] = (uint8_t)sc;
   }
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   //      compaction below reproduces cv::FAST's row-major emission order
   const int per = (npix + 255) >> 8;  // <= 21
   const int p0 = tid * per, p1 = imin(p0 + per, npix);
-  const int y_first = (int)__umulhi((uint32_t)p0, magic), x_first = p0 - y_first * sw;
+  const int y_first = RGBL_DIV_SW(p0), x_first = p0 - y_first * sw;
   uint32_t keep = 0, keep_ini = 0;
   {
     int x = x_first, y = y_first;
@@ -570,6 +572,7 @@ __device__ __forceinline__ QNode child_node(const QNode& nd, int q, uint32_t beg
   return c;
 }
 
+constexpr int kOctBS = 1024;        // work-items per quad-tree workgroup (16 waves hide the dependent-load latency)
 constexpr int kSortLds = 2048;     // largest expandable-node list sorted in LDS by the whole workgroup
 constexpr int kSortRanges = 160;   // > kSortLds / 17: pending ranges of more than 16 elements are disjoint
 
@@ -626,9 +629,18 @@ __device__ __forceinline__ void pk_heap_sort(uint64_t* w, int first, int last) {
   }
 }
 
+// Hoare's partition visits every element once and never revisits a swapped slot, so its outcome is a function of
+// the ORIGINAL range: with L = ascending positions whose key is >= pivot and R = descending positions whose key
+// is <= pivot, it swaps the pairs (L_i, R_i) while L_i < R_i and returns the first unswapped stop of the left
+// scan.  A wave therefore partitions a range with two ballot-compacted position lists and parallel swaps instead
+// of a serial scan; the four waves of the workgroup take different ranges of the same recursion depth.
+// seg_first / seg_last double as the L / R lists of the range being partitioned (a leaf is only labelled once
+// its range is final).
 __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t* seg_first, uint16_t* seg_last,
                                                     SortRanges* ra, SortRanges* rb, int* s_cnt) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  const int nw = (int)(blockDim.x >> 6);
+  const unsigned long long lt = lanemask_lt();
   if (tid == 0) {
     s_cnt[0] = s_cnt[1] = 0;
     if (m > 16) {
@@ -639,7 +651,7 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t
     }
   }
   if (m <= 16)
-    for (int i = tid; i < m; i += 256) { seg_first[i] = 0; seg_last[i] = (uint16_t)m; }
+    for (int i = tid; i < m; i += kOctBS) { seg_first[i] = 0; seg_last[i] = (uint16_t)m; }
   __syncthreads();
   SortRanges* cur = ra;
   SortRanges* nxt = rb;
@@ -647,65 +659,79 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t
   for (;;) {
     const int nr = s_cnt[ci];
     if (nr == 0) break;
-    for (int r = tid; r < nr; r += 256) {
+    for (int r = wave; r < nr; r += nw) {
       const int first = cur->first[r], last = cur->last[r];
       int depth = cur->depth[r];
       if (depth == 0) {  // __partial_sort(first, last, last): heap sort, the range is final afterwards
-        pk_heap_sort(w, first, last);
-        for (int i = first; i < last; ++i) { seg_first[i] = (uint16_t)i; seg_last[i] = (uint16_t)(i + 1); }
+        if (lane == 0) pk_heap_sort(w, first, last);
+        for (int i = first + lane; i < last; i += 64) { seg_first[i] = (uint16_t)i; seg_last[i] = (uint16_t)(i + 1); }
         continue;
       }
       --depth;
-      // __move_median_to_first(first, first+1, mid, last-1)
+      // __move_median_to_first(first, first+1, mid, last-1), evaluated redundantly by every lane
       const int A = first + 1, B = first + (last - first) / 2, C = last - 1;
       const uint64_t wf = w[first], wa = w[A], wb = w[B], wc = w[C];
       int X;
       if (pk_less(wa, wb)) X = pk_less(wb, wc) ? B : (pk_less(wa, wc) ? C : A);
       else X = pk_less(wa, wc) ? A : (pk_less(wb, wc) ? C : B);
       const uint64_t pivot = X == A ? wa : (X == B ? wb : wc);
-      w[first] = pivot;
-      w[X] = wf;
-      // __unguarded_partition(first+1, last, pivot); the scans keep four LDS reads in flight and hand the
-      // element they stop at to the swap, which therefore is two plain stores
-      int lo = first + 1, hi = last;
-      for (;;) {
-        uint64_t klo, khi;
-        for (;;) {
-          const uint64_t k0 = w[lo], k1 = w[lo + 1], k2 = w[lo + 2], k3 = w[lo + 3];
-          klo = k0; if (!pk_less(k0, pivot)) break;
-          ++lo;
-          klo = k1; if (!pk_less(k1, pivot)) break;
-          ++lo;
-          klo = k2; if (!pk_less(k2, pivot)) break;
-          ++lo;
-          klo = k3; if (!pk_less(k3, pivot)) break;
-          ++lo;
-        }
-        --hi;
-        for (;;) {
-          const uint64_t k0 = w[hi], k1 = w[hi - 1], k2 = w[hi - 2], k3 = w[hi - 3];
-          khi = k0; if (!pk_less(pivot, k0)) break;
-          --hi;
-          khi = k1; if (!pk_less(pivot, k1)) break;
-          --hi;
-          khi = k2; if (!pk_less(pivot, k2)) break;
-          --hi;
-          khi = k3; if (!pk_less(pivot, k3)) break;
-          --hi;
-        }
-        if (!(lo < hi)) break;
-        w[lo] = khi;
-        w[hi] = klo;
-        ++lo;
+      wave_sync();
+      if (lane == 0) { w[first] = pivot; w[X] = wf; }
+      wave_sync();
+      // L: ascending positions in (first, last) with !(key < pivot)
+      int cnt_l = 0;
+      for (int base = first + 1; base < last; base += 64) {
+        const int p = base + lane;
+        const bool f = p < last && !pk_less(w[p < last ? p : first], pivot);
+        const unsigned long long mask = __ballot(f);
+        if (f) seg_first[first + cnt_l + __popcll(mask & lt)] = (uint16_t)p;
+        cnt_l += __popcll(mask);
       }
-      const int sub_first[2] = {first, lo}, sub_last[2] = {lo, last};
+      // R: descending positions in (first, last) with !(pivot < key)
+      int cnt_r = 0;
+      for (int top = last - 1; top > first; top -= 64) {
+        const int p = top - lane;
+        const bool f = p > first && !pk_less(pivot, w[p > first ? p : first]);
+        const unsigned long long mask = __ballot(f);
+        if (f) seg_last[first + cnt_r + __popcll(mask & lt)] = (uint16_t)p;
+        cnt_r += __popcll(mask);
+      }
+      wave_sync();
+      // number of swaps: pairs with L_i < R_i (a prefix, both lists are monotone)
+      const int lim = imin(cnt_l, cnt_r);
+      int nswap = 0;
+      for (int base = 0; base < lim; base += 64) {
+        const int i = base + lane;
+        const bool ok = i < lim && seg_first[first + (i < lim ? i : 0)] < seg_last[first + (i < lim ? i : 0)];
+        const int c = __popcll(__ballot(ok));
+        nswap += c;
+        if (c < 64) break;
+      }
+      for (int i = lane; i < nswap; i += 64) {
+        const int pl = seg_first[first + i], pr = seg_last[first + i];
+        const uint64_t x = w[pl], y = w[pr];
+        w[pl] = y;
+        w[pr] = x;
+      }
+      int cut;
+      if (nswap > 0) {
+        const int pr = seg_last[first + nswap - 1];
+        const int pl = nswap < cnt_l ? (int)seg_first[first + nswap] : 0x7fffffff;
+        cut = pl < pr ? pl : pr;
+      } else {
+        cut = seg_first[first];
+      }
+      wave_sync();  // every lane is done with the L / R lists before leaves are labelled over them
+      const int sub_first[2] = {first, cut}, sub_last[2] = {cut, last};
       for (int k = 0; k < 2; ++k) {
         const int f0 = sub_first[k], l0 = sub_last[k];
         if (l0 - f0 > 16) {
-          const int slot = atomicAdd(&s_cnt[1 - ci], 1);
-          nxt->first[slot] = f0; nxt->last[slot] = l0; nxt->depth[slot] = depth;
+          if (lane == 0) {
+            const int slot = atomicAdd(&s_cnt[1 - ci], 1);
+            nxt->first[slot] = f0; nxt->last[slot] = l0; nxt->depth[slot] = depth;
+          }
         } else {
-          for (int i = f0; i < l0; ++i) { seg_first[i] = (uint16_t)f0; seg_last[i] = (uint16_t)l0; }
+          for (int i = f0 + lane; i < l0; i += 64) { seg_first[i] = (uint16_t)f0; seg_last[i] = (uint16_t)l0; }
         }
       }
     }
@@ -716,11 +742,11 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t
     __syncthreads();
   }
   // stable sort of every leaf (== __final_insertion_sort)
-  uint64_t mine[kSortLds / 256];
-  int dest[kSortLds / 256];
+  uint64_t mine[kSortLds / kOctBS];
+  int dest[kSortLds / kOctBS];
 #pragma unroll
-  for (int k = 0; k < kSortLds / 256; ++k) {
-    const int i = tid + 256 * k;
+  for (int k = 0; k < kSortLds / kOctBS; ++k) {
+    const int i = tid + kOctBS * k;
     dest[k] = -1;
     if (i < m) {
       const int f0 = seg_first[i], l0 = seg_last[i];
@@ -736,7 +762,7 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kSortLds / 256; ++k)
+  for (int k = 0; k < kSortLds / kOctBS; ++k)
     if (dest[k] >= 0) w[dest[k]] = mine[k];
   __syncthreads();
 }
@@ -756,7 +782,7 @@ __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n
   unsigned long long carry = 0;
   // two sweeps: first totals, then placement (placement needs T)
   unsigned long long T2 = 0;
-  for (int r0 = 0; r0 < P; r0 += 256) {
+  for (int r0 = 0; r0 < P; r0 += kOctBS) {
     const int rho = r0 + tid;
     unsigned long long v = 0;
     if (rho < P) {
@@ -768,7 +794,7 @@ __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n
     T2 += tot;
   }
   const uint32_t T = (uint32_t)(T2 & 0xffffffffu);
-  for (int r0 = 0; r0 < P; r0 += 256) {
+  for (int r0 = 0; r0 < P; r0 += kOctBS) {
     const int rho = r0 + tid;
     unsigned long long v = 0;
     QDiv d; d.c[0] = d.c[1] = d.c[2] = d.c[3] = 0;
@@ -799,7 +825,7 @@ __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n
   __syncthreads();
   // pass 2: surviving nodes keep their relative order behind the children
   uint32_t kcarry = 0;
-  for (int p0 = 0; p0 < n; p0 += 256) {
+  for (int p0 = 0; p0 < n; p0 += kOctBS) {
     const int pos = p0 + tid;
     const uint32_t keep = (pos < n && !divided[pos]) ? 1u : 0u;
     uint32_t tot;
@@ -812,8 +838,8 @@ __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b) {
-  __shared__ unsigned long long s_scan[8];
+__global__ __launch_bounds__(kOctBS) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b) {
+  __shared__ unsigned long long s_scan[32];
   __shared__ unsigned long long s_skey_pad[kSortLds + 8];  // 4 entries of read slack on both sides
   __shared__ uint32_t s_sval[kSortLds];
   __shared__ uint16_t s_seg_first[kSortLds], s_seg_last[kSortLds];
@@ -845,7 +871,7 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
   {
     const uint32_t* ccnt = b.cell_cnt + (size_t)f * b.cells_frame + g.cell_off;
     const uint32_t* slots = b.slots + (size_t)f * b.slots_frame + g.slot_off;
-    for (int c0 = 0; c0 < g.n_cells; c0 += 256) {
+    for (int c0 = 0; c0 < g.n_cells; c0 += kOctBS) {
       const int c = c0 + tid;
       const uint32_t cnt = c < g.n_cells ? ccnt[c] : 0u;
       uint32_t tot;
@@ -863,7 +889,7 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
     uint32_t outpos = 0;
     for (int r = 0; r < g.n_ini; ++r) {
       const uint32_t beg = outpos;
-      for (uint32_t base = 0; base < C; base += 256 * 8) {
+      for (uint32_t base = 0; base < C; base += kOctBS * 8) {
         const uint32_t i0 = base + (uint32_t)tid * 8;
         uint32_t mask = 0;
         for (int k = 0; k < 8; ++k)
@@ -931,10 +957,10 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
     const int prev = n;
     // compareNodes orders by (size, UL.x); equal keys end up in libstdc++'s introsort order
     uint32_t* sval = (m <= kSortLds) ? s_sval : b.sval + nbase;
-    for (int p = tid; p < n; p += 256) divided[p] = 0;
+    for (int p = tid; p < n; p += kOctBS) divided[p] = 0;
     if (m <= kSortLds) {
       uint64_t* w = reinterpret_cast<uint64_t*>(s_skey);
-      for (int j = tid; j < m; j += 256) {
+      for (int j = tid; j < m; j += kOctBS) {
         const uint32_t pos = todo[j];
         const QNode nd = cur[pos];
         w[j] = ((uint64_t)(nd.cnt & 0x7fffffffu) << 28) | ((uint64_t)nd.x0 << 16) | pos;  // x0 < 4096, pos < 65536
@@ -943,11 +969,11 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
       RGBL_STAMP(8);
       block_sort_restated(w, m, s_seg_first, s_seg_last, &s_ra, &s_rb, s_sort_cnt);
       RGBL_STAMP(9);
-      for (int j = tid; j < m; j += 256) sval[j] = (uint32_t)(w[j] & 0xffffu);
+      for (int j = tid; j < m; j += kOctBS) sval[j] = (uint32_t)(w[j] & 0xffffu);
       __syncthreads();
     } else {
       uint64_t* skey = b.skey + nbase;
-      for (int j = tid; j < m; j += 256) {
+      for (int j = tid; j < m; j += kOctBS) {
         const uint32_t pos = todo[j];
         const QNode nd = cur[pos];
         skey[j] = ((uint64_t)(nd.cnt & 0x7fffffffu) << 32) | nd.x0;
@@ -969,7 +995,7 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
     // first rank after which the list has reached the quota (the reference breaks out of its loop there)
     {
       long long carry = 0;
-      for (int r0 = 0; r0 < m; r0 += 256) {
+      for (int r0 = 0; r0 < m; r0 += kOctBS) {
         const int rho = r0 + tid;
         long long v = 0;
         if (rho < m) {
@@ -1005,7 +1031,7 @@ __global__ __launch_bounds__(256) void k_octree(const LevelGeom* __restrict__ ge
   // ---- 4. keep the strongest key of every node, first one on ties (ORBextractor.cc:757-776)
   uint32_t* out = b.kp_key + (size_t)f * b.kp_frame + g.koff;
   if (n > g.kcap) { if (tid == 0) atomicOr(b.err, 2); n = g.kcap; }
-  for (int pos = tid; pos < n; pos += 256) {
+  for (int pos = tid; pos < n; pos += kOctBS) {
     const QNode nd = cur[pos];
     const uint32_t cnt = nd.cnt & 0x7fffffffu;
     const uint32_t* src = ((nd.cnt >> 31) ? keys_b : keys_a) + nd.beg;
@@ -1198,16 +1224,16 @@ __global__ __launch_bounds__(256) void k_lapping_permute(const rgbl_keypoint* __
 }
 
 // test hook: the workgroup sort on plain arrays (n <= kSortLds, key < 2^48, val < 2^16)
-__global__ __launch_bounds__(256) void k_test_block_sort(uint64_t* key, uint32_t* val, int n) {
+__global__ __launch_bounds__(kOctBS) void k_test_block_sort(uint64_t* key, uint32_t* val, int n) {
   __shared__ unsigned long long s_skey_pad[kSortLds + 8];
   __shared__ uint16_t s_seg_first[kSortLds], s_seg_last[kSortLds];
   __shared__ SortRanges s_ra, s_rb;
   __shared__ int s_sort_cnt[2];
   uint64_t* w = reinterpret_cast<uint64_t*>(s_skey_pad + 4);
-  for (int i = threadIdx.x; i < n; i += 256) w[i] = (key[i] << 16) | (val[i] & 0xffffu);
+  for (int i = threadIdx.x; i < n; i += kOctBS) w[i] = (key[i] << 16) | (val[i] & 0xffffu);
   __syncthreads();
   block_sort_restated(w, n, s_seg_first, s_seg_last, &s_ra, &s_rb, s_sort_cnt);
-  for (int i = threadIdx.x; i < n; i += 256) { key[i] = w[i] >> 16; val[i] = (uint32_t)(w[i] & 0xffffu); }
+  for (int i = threadIdx.x; i < n; i += kOctBS) { key[i] = w[i] >> 16; val[i] = (uint32_t)(w[i] & 0xffffu); }
 }
 
 // unpacks candidate keys into rgbl_keypoint records (diagnostic path of rgbl_extractor_get_candidates)

@@ -20,6 +20,12 @@ def test_extractor_lapping_and_thresholds(emu_lib):
     pc.check_extractor(emu_lib, 480, 320, 700, frames=(0,), ini=20, mn=7, seq=5, lapping=(0, 250))
 
 
+def test_extractor_one_pixel_wide_border_cells(emu_lib):
+    # widths / heights of the form 36k + 3 make the last detection cell exactly one pixel wide (KITTI 04-12 is 1226)
+    pc.check_extractor(emu_lib, 1227, 150, 1500, frames=(0,), nlevels=2, seq=12, stages=True)
+    pc.check_extractor(emu_lib, 700, 1227, 1500, frames=(0,), nlevels=2, seq=13, stages=True)
+
+
 def test_extractor_batch(emu_lib):
     pc.check_extractor_batch(emu_lib, 360, 280, 500, batch=3)
 
