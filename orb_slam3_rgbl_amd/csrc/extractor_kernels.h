@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   __shared__ uint16_t s_surv[kCellMax * kCellMax];
   __shared__ uint32_t s_scan[8];
   __shared__ int s_nsurv, s_any_ini;
+  __shared__ uint32_t s_keep[(kCellMax * kCellMax + 31) / 32], s_keep_ini[(kCellMax * kCellMax + 31) / 32];
 
   const int tid = threadIdx.x;
   const int f = blockIdx.y;
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   }
   for (int i = tid; i < (sh + 2) * (kScoreP / 4); i += 256) s_score_w[i] = 0;
   if (tid == 0) { s_nsurv = 0; s_any_ini = 0; }
+  if (tid < (kCellMax * kCellMax + 31) / 32) { s_keep[tid] = 0; s_keep_ini[tid] = 0; }
   __syncthreads();
 
   // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are compacted
@@ -250,41 +252,37 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   }
   __syncthreads();
 
-  // ---- phase C: 3x3 strict NMS inside the cell; each thread owns a contiguous run of pixels so the
-  //      compaction below reproduces cv::FAST's row-major emission order
-  const int per = (npix + 255) >> 8;  // <= 21
-  const int p0 = tid * per, p1 = imin(p0 + per, npix);
-  const int y_first = RGBL_DIV_SW(p0), x_first = p0 - y_first * sw;
-  uint32_t keep = 0, keep_ini = 0;
-  {
-    int x = x_first, y = y_first;
-    for (int p = p0; p < p1; ++p) {
-      const uint8_t* s = &s_score[(y + 1) * kScoreP + x + 1];
-      const int v = s[0];
-      if (v != 0 && v > s[-1] && v > s[1] && v > s[-kScoreP - 1] && v > s[-kScoreP] && v > s[-kScoreP + 1] &&
-          v > s[kScoreP - 1] && v > s[kScoreP] && v > s[kScoreP + 1]) {
-        keep |= 1u << (p - p0);
-        if (v >= ini_th) keep_ini |= 1u << (p - p0);
-      }
-      if (++x == sw) { x = 0; ++y; }
+  // ---- phase C: 3x3 strict NMS inside the cell, only for the pixels that have a score; survivors of the NMS
+  //      set a bit in a row-major bitmap (one for the min threshold, one for the ini threshold)
+  for (int i = tid; i < nsurv; i += 256) {
+    const int p = s_surv[i];
+    const int y = RGBL_DIV_SW(p), x = p - y * sw;
+    const uint8_t* s = &s_score[(y + 1) * kScoreP + x + 1];
+    const int v = s[0];
+    if (v != 0 && v > s[-1] && v > s[1] && v > s[-kScoreP - 1] && v > s[-kScoreP] && v > s[-kScoreP + 1] &&
+        v > s[kScoreP - 1] && v > s[kScoreP] && v > s[kScoreP + 1]) {
+      atomicOr(&s_keep[p >> 5], 1u << (p & 31));
+      if (v >= ini_th) { atomicOr(&s_keep_ini[p >> 5], 1u << (p & 31)); s_any_ini = 1; }
     }
   }
-  if (keep_ini) s_any_ini = 1;
   __syncthreads();
-  // two-threshold rule of ORBextractor.cc:826-846: the ini-threshold set if it is non-empty, else the min set
-  if (s_any_ini) keep = keep_ini;
+  // two-threshold rule of ORBextractor.cc:826-846: the ini-threshold set if it is non-empty, else the min set.
+  // Ordered compaction: bitmap word t belongs to work-item t, bits ascend = cv::FAST's row-major emission order.
+  const int nbw = (npix + 31) >> 5;  // <= 162
+  uint32_t word = 0;
+  if (tid < nbw) word = s_any_ini ? s_keep_ini[tid] : s_keep[tid];
   uint32_t total;
-  uint32_t base = block_exclusive_scan<uint32_t>((uint32_t)__popc(keep), s_scan, &total);
-  if (keep) {
+  uint32_t base = block_exclusive_scan<uint32_t>((uint32_t)__popc(word), s_scan, &total);
+  if (word) {
     uint32_t* out = slots + (size_t)f * slots_frame + g.slot_off + (size_t)ci * g.cell_cap;
-    int x = x_first, y = y_first;
-    for (int p = p0; p < p1; ++p) {
-      if ((keep >> (p - p0)) & 1) {
-        if (base < (uint32_t)g.cell_cap)
-          out[base] = pack_key(ci_col * g.w_cell + 3 + x, ci_row * g.h_cell + 3 + y, s_score[(y + 1) * kScoreP + x + 1]);
-        ++base;
-      }
-      if (++x == sw) { x = 0; ++y; }
+    while (word) {
+      const int bit = __ffs((int)word) - 1;
+      word &= word - 1;
+      const int p = tid * 32 + bit;
+      const int y = RGBL_DIV_SW(p), x = p - y * sw;
+      if (base < (uint32_t)g.cell_cap)
+        out[base] = pack_key(ci_col * g.w_cell + 3 + x, ci_row * g.h_cell + 3 + y, s_score[(y + 1) * kScoreP + x + 1]);
+      ++base;
     }
   }
   if (tid == 0) *my_cnt = total < (uint32_t)g.cell_cap ? total : (uint32_t)g.cell_cap;  // cap is a proven bound
@@ -572,7 +570,7 @@ __device__ __forceinline__ QNode child_node(const QNode& nd, int q, uint32_t beg
   return c;
 }
 
-constexpr int kOctBS = 1024;        // work-items per quad-tree workgroup (16 waves hide the dependent-load latency)
+constexpr int kOctBS = 512;         // work-items per quad-tree workgroup (16 waves hide the dependent-load latency)
 constexpr int kSortLds = 2048;     // largest expandable-node list sorted in LDS by the whole workgroup
 constexpr int kSortRanges = 160;   // > kSortLds / 17: pending ranges of more than 16 elements are disjoint
 
@@ -1086,10 +1084,8 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
                                                       int* __restrict__ err) {
   __shared__ uint32_t s_patch_w[4][37 * 10];  // blurred 37x37 neighbourhood, 40-byte rows
   __shared__ uint32_t s_raw_w[4][31 * 8];     // un-blurred 31x31 neighbourhood, 32-byte rows
-  __shared__ int8_t s_pat[1024];
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int f = blockIdx.y;
-  for (int i = tid; i < 1024; i += 256) s_pat[i] = pattern[i];
 
   // which (level, index) does this wave own?  slots are laid out level after level with kcap entries each
   const int slot = blockIdx.x * 4 + wave;
@@ -1163,8 +1159,10 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
     const uint8_t* center = patch + 18 * 40 + 18;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int8_t* p = &s_pat[(k * 64 + lane) * 4];
-      const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+      // pattern pair (x0, y0, x1, y1) of this lane: one coalesced 4-byte read per lane, signed bytes
+      const uint32_t pw = reinterpret_cast<const uint32_t*>(pattern)[k * 64 + lane];
+      const float x0 = (float)(int8_t)(pw & 0xff), y0 = (float)(int8_t)((pw >> 8) & 0xff),
+                  x1 = (float)(int8_t)((pw >> 16) & 0xff), y1 = (float)(int8_t)(pw >> 24);
       const int t0 = center[cv_round_f(x0 * b + y0 * a) * 40 + cv_round_f(x0 * a - y0 * b)];
       const int t1 = center[cv_round_f(x1 * b + y1 * a) * 40 + cv_round_f(x1 * a - y1 * b)];
       bits[k] = __ballot(valid && t0 < t1);
