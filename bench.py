@@ -27,8 +27,8 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (w, h, nfeatures, lidar azimuth steps, default batch)
-    "kitti": (1241, 376, 2000, 1900, 64),
-    "4k": (3840, 2160, 8000, 4096, 8),
+    "kitti": (1241, 376, 2000, 1900, 256),
+    "4k": (3840, 2160, 8000, 4096, 16),
 }
 LEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 12, 7
 
@@ -162,46 +162,66 @@ def main():
 
     d_imgs = torch.from_numpy(frames).to(dev)
     d_cloud = torch.from_numpy(cloud).to(dev)
-    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)       # rgbl_keypoint records (28 B)
-    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_mono = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_depth = torch.zeros((B, cap), dtype=torch.float32, device=dev)
-    d_uright = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+    # Two output sets (ping-pong): the matcher / depth gather of step k read set k%2 while the extractor of step k+1
+    # already fills the other one; HIP events mark "set free again" (rgbl_event_*).
+    class OutSet:
+        def __init__(self):
+            self.kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)   # rgbl_keypoint records (28 B)
+            self.desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+            self.n = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.mono = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.depth = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+            self.uright = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+            self.bi = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+            self.bd = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+            self.sd = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+            self.ev = {}
+            for name in ("extracted", "depth_done", "match_done", "comm_done"):
+                e = C.c_void_p()
+                L.check(lib, lib.rgbl_event_create(C.byref(e)))
+                self.ev[name] = e
+
+    sets = [OutSet(), OutSet()]
     pair_a = torch.arange(B, dtype=torch.int32, device=dev)
     pair_b = (pair_a + 1) % B
-    d_bi = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-    d_bd = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-    d_sd = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     gather_buf = None
     if world > 1:
-        send = torch.zeros((B, sharding.record_bytes(cap)), dtype=torch.uint8, device=dev)
-        gather_buf = [torch.zeros_like(send) for _ in range(world)] if rank == 0 else None
+        send = [torch.zeros((B, sharding.record_bytes(cap)), dtype=torch.uint8, device=dev) for _ in range(2)]
+        gather_buf = [torch.zeros_like(send[0]) for _ in range(world)] if rank == 0 else None
+    step_no = [0]
 
     def p(t):
         return C.c_void_p(t.data_ptr())
 
     def step():
-        # the consumers of the previous step must be done before the extractor overwrites d_kp / d_desc / d_n
-        wait(s_ex, s_dm)
-        wait(s_ex, s_mt)
+        o = sets[step_no[0] % 2]
+        # this set's readers of two steps ago must be done before the extractor overwrites it
+        L.check(lib, lib.rgbl_event_wait(s_ex, o.ev["depth_done"]))
+        L.check(lib, lib.rgbl_event_wait(s_ex, o.ev["match_done"]))
         if world > 1:
-            wait(s_ex, s_comm)
+            L.check(lib, lib.rgbl_event_wait(s_ex, o.ev["comm_done"]))
+        L.check(lib, lib.rgbl_extract_batch_device(ex.h, p(d_imgs), B, w, h, w, w * h, 0, 0, p(o.kp), p(o.desc), cap,
+                                                   p(o.n), p(o.mono)))
+        L.check(lib, lib.rgbl_event_record(o.ev["extracted"], s_ex))
+        # LiDAR projection + up-sampling: independent of the keypoints, runs concurrently on the depth stream
         L.check(lib, lib.rgbl_depth_project_batch_device(dm.h, p(d_cloud), B, n_points, n_points, 4 * n_points, w, h, None))
-        L.check(lib, lib.rgbl_extract_batch_device(ex.h, p(d_imgs), B, w, h, w, w * h, 0, 0, p(d_kp), p(d_desc), cap,
-                                                   p(d_n), p(d_mono)))
-        wait(s_dm, s_ex)
-        L.check(lib, lib.rgbl_depth_gather_batch_device(dm.h, B, w, h, p(d_kp), p(d_n), cap, None, p(d_depth), p(d_uright)))
-        wait(s_mt, s_ex)
-        L.check(lib, lib.rgbl_hamming_bf_batch_device(mt.h, p(d_desc), p(d_n), cap, p(pair_a), p(pair_b), B, p(d_bi),
-                                                      p(d_bd), p(d_sd)))
+        L.check(lib, lib.rgbl_event_wait(s_dm, o.ev["extracted"]))
+        L.check(lib, lib.rgbl_depth_gather_batch_device(dm.h, B, w, h, p(o.kp), p(o.n), cap, None, p(o.depth), p(o.uright)))
+        L.check(lib, lib.rgbl_event_record(o.ev["depth_done"], s_dm))
+        L.check(lib, lib.rgbl_event_wait(s_mt, o.ev["extracted"]))
+        L.check(lib, lib.rgbl_hamming_bf_batch_device(mt.h, p(o.desc), p(o.n), cap, p(pair_a), p(pair_b), B, p(o.bi),
+                                                      p(o.bd), p(o.sd)))
+        L.check(lib, lib.rgbl_event_record(o.ev["match_done"], s_mt))
         if world > 1:
             # the one exchange of the path: variable-length records to rank 0 (padded to cap, counts in front)
-            wait(s_comm, s_dm)
-            wait(s_comm, s_mt)
+            L.check(lib, lib.rgbl_event_wait(s_comm, o.ev["depth_done"]))
+            L.check(lib, lib.rgbl_event_wait(s_comm, o.ev["match_done"]))
             with torch.cuda.stream(comm_stream):
-                sharding.pack_records(d_n, d_kp, d_desc, d_depth, d_uright, out=send)
-                sharding.gather_records(send, gather_buf, dst=0)
+                sbuf = send[step_no[0] % 2]
+                sharding.pack_records(o.n, o.kp, o.desc, o.depth, o.uright, out=sbuf)
+                sharding.gather_records(sbuf, gather_buf, dst=0)
+            L.check(lib, lib.rgbl_event_record(o.ev["comm_done"], s_comm))
+        step_no[0] += 1
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -227,6 +247,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    last = sets[(step_no[0] - 1) % 2]
+    d_n, d_kp, d_desc, d_depth, d_uright, d_bi, d_bd, d_sd = (last.n, last.kp, last.desc, last.depth, last.uright, last.bi,
+                                                               last.bd, last.sd)
     k_mean = float(d_n.float().mean().item())
 
     # ---- parity spot check of what the timed pipeline produced (two frames against the CPU oracle)

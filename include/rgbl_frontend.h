@@ -123,6 +123,14 @@ void* rgbl_extractor_stream(rgbl_extractor* h); /* hipStream_t currently used by
 /* Device-side ordering between handles without a host sync: work enqueued on `waiter_stream` after this call
  * starts only when everything enqueued on `signaler_stream` before this call has finished (HIP event). */
 int rgbl_stream_wait(void* waiter_stream, void* signaler_stream);
+/* The same with explicit, reusable HIP events: record marks a point on a stream, wait makes later work on another
+ * stream start only after that point (a never-recorded event does not block). Enables software pipelining across
+ * batches: e.g. the extractor may overwrite an output buffer as soon as the event recorded behind its last reader
+ * has fired, while the matcher still works on the other buffer. */
+int rgbl_event_create(void** out_event);
+void rgbl_event_destroy(void* event);
+int rgbl_event_record(void* event, void* stream);
+int rgbl_event_wait(void* stream, void* event);
 int rgbl_extractor_profile(rgbl_extractor* h, int enable);
 /* Returns the number of distinct kernels; fills up to cap entries. names[i] points to static storage. */
 int rgbl_extractor_profile_read(rgbl_extractor* h, const char** names, double* total_ms, long* launches,

@@ -86,6 +86,10 @@ SYMBOLS = {
     "rgbl_extractor_stream": (_V, [_V]),
     "rgbl_matcher_stream": (_V, [_V]),
     "rgbl_stream_wait": (_I, [_V, _V]),
+    "rgbl_event_create": (_I, [C.POINTER(_V)]),
+    "rgbl_event_destroy": (None, [_V]),
+    "rgbl_event_record": (_I, [_V, _V]),
+    "rgbl_event_wait": (_I, [_V, _V]),
     "rgbl_depth_set_stream": (_I, [_V, _V]),
     "rgbl_depth_profile": (_I, [_V, _I]),
     "rgbl_depth_profile_read": (_I, [_V, _V, _V, _V, _I]),

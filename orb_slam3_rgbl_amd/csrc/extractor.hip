@@ -49,6 +49,8 @@ struct rgbl_extractor {
   int device = 0;
   int L = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
+  hipStream_t aux_stream = nullptr;  // the Gaussian working images only depend on the pyramid: they overlap FAST + quad-tree
+  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
   KernelTimer timer;
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> per_level;
@@ -317,6 +319,14 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
                        e->d_xtab + g.xtab_off, e->d_ytab + g.ytab_off);
     e->timer.end(s);
   }
+  // 4. Gaussian working images (ORBextractor.cc:1132-1133) on the auxiliary stream, concurrently with 2. and 3.
+  RGBL_HIP(hipEventRecord(e->ev_pyr, s));
+  RGBL_HIP(hipStreamWaitEvent(e->aux_stream, e->ev_pyr, 0));
+  e->timer.begin("k_gauss7", e->aux_stream);
+  hipLaunchKernelGGL(k_gauss7, dim3(e->blur_tiles.tile_off[L], batch), dim3(256), 0, e->aux_stream, e->d_geom, L,
+                     e->blur_tiles, d_imgs, stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame);
+  e->timer.end(e->aux_stream);
+  RGBL_HIP(hipEventRecord(e->ev_blur, e->aux_stream));
   // 2. FAST per detection cell (ORBextractor.cc:806-872)
   e->timer.begin("k_fast_cells", s);
   hipLaunchKernelGGL(k_fast_cells, dim3(e->cells_frame, batch), dim3(256), 0, s, e->d_geom, L, d_imgs, stride,
@@ -338,12 +348,8 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   e->timer.begin("k_octree", s);
   hipLaunchKernelGGL(k_octree, dim3(L, batch), dim3(kOctBS), 0, s, e->d_geom, L, ob);
   e->timer.end(s);
-  // 4. Gaussian working images (ORBextractor.cc:1132-1133)
-  e->timer.begin("k_gauss7", s);
-  hipLaunchKernelGGL(k_gauss7, dim3(e->blur_tiles.tile_off[L], batch), dim3(256), 0, s, e->d_geom, L, e->blur_tiles,
-                     d_imgs, stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame);
-  e->timer.end(s);
-  // 5. orientation + descriptors + packing (ORBextractor.cc:894-895, 1136-1165)
+  // 5. orientation + descriptors + packing (ORBextractor.cc:894-895, 1136-1165); needs the blurred levels
+  RGBL_HIP(hipStreamWaitEvent(s, e->ev_blur, 0));
   const bool lapping = lap1 >= 19 && lap1 >= lap0;  // keypoint x is always >= 19: nothing can fall into [lap0, lap1] otherwise
   rgbl_keypoint* kp_dst = lapping ? e->d_tmp_kp : d_kp;
   uint8_t* desc_dst = lapping ? e->d_tmp_desc : d_desc;
@@ -421,7 +427,12 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
   int rc = build_geometry(e);
   if (rc == RGBL_OK) rc = upload_tables(e);
   if (rc == RGBL_OK) rc = alloc_scratch(e);
-  if (rc == RGBL_OK && hipStreamCreate(&e->own_stream) != hipSuccess) { set_error("hipStreamCreate failed"); rc = RGBL_ERR_HIP; }
+  if (rc == RGBL_OK && (hipStreamCreate(&e->own_stream) != hipSuccess || hipStreamCreate(&e->aux_stream) != hipSuccess ||
+                        hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming) != hipSuccess)) {
+    set_error("hipStreamCreate failed");
+    rc = RGBL_ERR_HIP;
+  }
   if (rc != RGBL_OK) { rgbl_extractor_destroy(e); return rc; }
   e->stream = e->own_stream;
   *out = e;
@@ -434,6 +445,9 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   if (e->stream) hipStreamSynchronize(e->stream);
   e->timer.collect();
   for (void* p : e->allocs) hipFree(p);
+  if (e->aux_stream) { hipStreamSynchronize(e->aux_stream); hipStreamDestroy(e->aux_stream); }
+  if (e->ev_pyr) hipEventDestroy(e->ev_pyr);
+  if (e->ev_blur) hipEventDestroy(e->ev_blur);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -617,6 +631,25 @@ int rgbl_stream_wait(void* waiter, void* signaler) {
   RGBL_HIP(hipEventRecord(ev, (hipStream_t)signaler));
   RGBL_HIP(hipStreamWaitEvent((hipStream_t)waiter, ev, 0));
   RGBL_HIP(hipEventDestroy(ev));  // released by the runtime once the recorded work has completed
+  return RGBL_OK;
+}
+
+int rgbl_event_create(void** ev) {
+  if (!ev) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  hipEvent_t e;
+  RGBL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *ev = (void*)e;
+  return RGBL_OK;
+}
+void rgbl_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int rgbl_event_record(void* ev, void* stream) {
+  if (!ev) { set_error("null event"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+  return RGBL_OK;
+}
+int rgbl_event_wait(void* stream, void* ev) {
+  if (!ev) { set_error("null event"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
   return RGBL_OK;
 }
 
