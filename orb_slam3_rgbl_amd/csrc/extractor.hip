@@ -268,7 +268,7 @@ int upload_tables(rgbl_extractor* e) {
 
 int alloc_scratch(rgbl_extractor* e) {
   const size_t B = (size_t)e->cfg.max_batch;
-  RGBL_TRY(dev_alloc(e, &e->d_img, B * e->img_frame));
+  RGBL_TRY(dev_alloc(e, &e->d_img, B * e->img_frame + 256));
   RGBL_TRY(dev_alloc(e, &e->d_pyr, B * e->pyr_frame + 256));  // slack: 8-byte source reads may run past a row end
   RGBL_TRY(dev_alloc(e, &e->d_blur, B * e->pyr_frame + 256));
   RGBL_TRY(dev_alloc(e, &e->d_cellcnt, B * e->cells_frame));
@@ -505,10 +505,21 @@ int rgbl_extract_batch(rgbl_extractor* e, const uint8_t* imgs, int batch, int w,
   }
   RGBL_HIP(hipSetDevice(e->device));
   hipStream_t s = e->stream;
-  for (int b = 0; b < batch; ++b)
-    RGBL_HIP(hipMemcpy2DAsync(e->d_img + (size_t)b * e->img_frame, e->img_pitch, imgs + (size_t)b * frame_stride, stride,
-                              w, h, hipMemcpyHostToDevice, s));
-  RGBL_TRY(enqueue_extract(e, e->d_img, batch, e->img_pitch, e->img_frame, lap0, lap1, e->d_out_kp, e->d_out_desc,
+  // Host -> device staging.  The kernels accept any row stride, so a frame whose rows are at most img_pitch apart
+  // is moved with ONE linear copy and read with the caller's stride (a 2-D copy from pageable memory degenerates
+  // into one transfer per row: 376 transfers per KITTI frame).
+  int dev_stride = e->img_pitch;
+  if (stride <= e->img_pitch) {
+    dev_stride = stride;
+    const size_t bytes = (size_t)(h - 1) * stride + w;  // never read past the caller's last row
+    for (int b = 0; b < batch; ++b)
+      RGBL_HIP(hipMemcpyAsync(e->d_img + (size_t)b * e->img_frame, imgs + (size_t)b * frame_stride, bytes, hipMemcpyHostToDevice, s));
+  } else {
+    for (int b = 0; b < batch; ++b)
+      RGBL_HIP(hipMemcpy2DAsync(e->d_img + (size_t)b * e->img_frame, e->img_pitch, imgs + (size_t)b * frame_stride, stride,
+                                w, h, hipMemcpyHostToDevice, s));
+  }
+  RGBL_TRY(enqueue_extract(e, e->d_img, batch, dev_stride, e->img_frame, lap0, lap1, e->d_out_kp, e->d_out_desc,
                            e->out_cap, e->d_out_n, e->d_out_mono));
   RGBL_HIP(hipMemcpyAsync(out_n, e->d_out_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
   RGBL_HIP(hipMemcpyAsync(out_mono, e->d_out_mono, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
@@ -558,8 +569,14 @@ int rgbl_extractor_get_level(rgbl_extractor* e, int frame, int level, int blurre
   const int border = (with_border && !blurred) ? 19 : 0;
   RGBL_HIP(hipStreamSynchronize(e->stream));
   uint8_t* inner = dst + (size_t)border * dst_stride + border;
-  RGBL_HIP(hipMemcpy2DAsync(inner, dst_stride, src, pitch, g.w, g.h, hipMemcpyDeviceToHost, e->stream));
-  RGBL_HIP(hipStreamSynchronize(e->stream));
+  {
+    // one linear device -> host transfer, rows are re-strided on the host (a 2-D copy into pageable memory is one
+    // transfer per row)
+    std::vector<uint8_t> tmp((size_t)pitch * (g.h - 1) + g.w);
+    RGBL_HIP(hipMemcpyAsync(tmp.data(), src, tmp.size(), hipMemcpyDeviceToHost, e->stream));
+    RGBL_HIP(hipStreamSynchronize(e->stream));
+    for (int y = 0; y < g.h; ++y) memcpy(inner + (size_t)y * dst_stride, tmp.data() + (size_t)y * pitch, g.w);
+  }
   if (border) {
     // copyMakeBorder(..., BORDER_REFLECT_101 [+BORDER_ISOLATED]) (ORBextractor.cc:1185-1191); host side, it is
     // only consumed by Frame::ComputeStereoMatches

@@ -27,15 +27,22 @@ __device__ __forceinline__ int hamming256(const unsigned long long q[4], const u
 
 // A workgroup owns 64 query descriptors (one per lane, 4 x u64 in VGPRs).  Its four waves split the train set
 // into four contiguous index ranges; inside a wave the train descriptor address is wave-uniform, so it is
-// fetched with scalar loads and broadcast to the 64 lanes.  The partial (best, index, second) triples are merged
-// through LDS in range order, which reproduces the sequential scan: strict '<', the first minimum wins, the
-// second-best is the second smallest distance counted with multiplicity.
-// grid = (ceil(cap/64), n_pairs), block = 256.
+// fetched with scalar loads and broadcast to the 64 lanes.  Best and second-best are tracked on packed words
+// (distance << 16 | train index): min() then implements the reference's "strict '<', first minimum wins" and the
+// second-best is the second smallest word, whose distance part is the second smallest distance counted with
+// multiplicity.  The four partial results are merged through LDS with the same two operations.
+// grid = (ceil(cap/64), n_pairs), block = 256.  Requires train counts < 65536.
+__device__ __forceinline__ void bf_track(uint32_t& best, uint32_t& second, uint32_t cur) {
+  const uint32_t hi = best > cur ? best : cur;
+  best = best < cur ? best : cur;
+  second = second < hi ? second : hi;
+}
+
 __global__ __launch_bounds__(256) void k_hamming_bf(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_rows,
                                                     int cap, const int32_t* __restrict__ pair_a,
                                                     const int32_t* __restrict__ pair_b, int32_t* __restrict__ best_idx,
                                                     int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist) {
-  __shared__ int s_d1[4][64], s_d2[4][64], s_idx[4][64];
+  __shared__ uint32_t s_best[4][64], s_second[4][64];
   const int p = blockIdx.y;
   const int fa = pair_a ? pair_a[p] : 0, fb = pair_b ? pair_b[p] : 1;
   const int na = n_rows[fa], nb = n_rows[fb];
@@ -49,34 +56,33 @@ __global__ __launch_bounds__(256) void k_hamming_bf(const uint8_t* __restrict__ 
   const unsigned long long q[4] = {A[0], A[1], A[2], A[3]};
   const int chunk = (nb + 3) >> 2;
   const int j0 = wave * chunk, j1 = imin(j0 + chunk, nb);
-  int d1 = 256, d2 = 256, idx = -1;
+  const uint32_t kNone = (256u << 16) | 0xffffu;
+  uint32_t best = kNone, second = kNone;
   int j = j0;
-  for (; j + 4 <= j1; j += 4) {
+  for (; j + 8 <= j1; j += 8) {
     const unsigned long long* t = B + 4 * (size_t)j;
-    const int e0 = hamming256(q, t), e1 = hamming256(q, t + 4), e2 = hamming256(q, t + 8), e3 = hamming256(q, t + 12);
-    if (e0 < d1) { d2 = d1; d1 = e0; idx = j; } else if (e0 < d2) { d2 = e0; }
-    if (e1 < d1) { d2 = d1; d1 = e1; idx = j + 1; } else if (e1 < d2) { d2 = e1; }
-    if (e2 < d1) { d2 = d1; d1 = e2; idx = j + 2; } else if (e2 < d2) { d2 = e2; }
-    if (e3 < d1) { d2 = d1; d1 = e3; idx = j + 3; } else if (e3 < d2) { d2 = e3; }
+    uint32_t e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) e[u] = ((uint32_t)hamming256(q, t + 4 * u) << 16) | (uint32_t)(j + u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) bf_track(best, second, e[u]);
   }
-  for (; j < j1; ++j) {
-    const int d = hamming256(q, B + 4 * (size_t)j);
-    if (d < d1) { d2 = d1; d1 = d; idx = j; } else if (d < d2) { d2 = d; }
-  }
-  s_d1[wave][lane] = d1;
-  s_d2[wave][lane] = d2;
-  s_idx[wave][lane] = idx;
+  for (; j < j1; ++j) bf_track(best, second, ((uint32_t)hamming256(q, B + 4 * (size_t)j) << 16) | (uint32_t)j);
+  s_best[wave][lane] = best;
+  s_second[wave][lane] = second;
   __syncthreads();
   if (wave == 0 && valid) {
     for (int w = 1; w < 4; ++w) {
-      const int e1 = s_d1[w][lane], e2 = s_d2[w][lane], eidx = s_idx[w][lane];
-      if (e1 < d1) { d2 = imin(d1, e2); d1 = e1; idx = eidx; }  // a strictly smaller distance in a later range
-      else { d2 = imin(d2, e1); }                               // ties keep the earlier index
+      const uint32_t ob = s_best[w][lane], os = s_second[w][lane];
+      const uint32_t hi = best > ob ? best : ob;
+      best = best < ob ? best : ob;
+      second = second < os ? second : os;
+      second = second < hi ? second : hi;
     }
     const size_t o = (size_t)p * cap + i;
-    best_idx[o] = idx;
-    best_dist[o] = d1;
-    if (second_dist) second_dist[o] = d2;
+    best_idx[o] = best == kNone ? -1 : (int32_t)(best & 0xffffu);
+    best_dist[o] = (int32_t)(best >> 16);
+    if (second_dist) second_dist[o] = (int32_t)(second >> 16);
   }
 }
 
@@ -255,7 +261,7 @@ int rgbl_descriptor_distance(const uint8_t* a, const uint8_t* b) {
 int rgbl_hamming_bf_batch_device(rgbl_matcher* m, const uint8_t* d_desc, const int32_t* d_n, int cap, const int32_t* d_pair_a,
                                  const int32_t* d_pair_b, int n_pairs, int32_t* d_best_idx, int32_t* d_best_dist,
                                  int32_t* d_second_dist) {
-  if (!m || !d_desc || !d_n || !d_pair_a || !d_pair_b || !d_best_idx || !d_best_dist || cap < 1 || n_pairs < 0) {
+  if (!m || !d_desc || !d_n || !d_pair_a || !d_pair_b || !d_best_idx || !d_best_dist || cap < 1 || cap > 65535 || n_pairs < 0) {
     set_error("invalid argument");
     return RGBL_ERR_INVALID;
   }
@@ -271,7 +277,7 @@ int rgbl_hamming_bf_batch_device(rgbl_matcher* m, const uint8_t* d_desc, const i
 
 int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_t* desc_b, int nb, int32_t* best_idx,
                     int32_t* best_dist, int32_t* second_dist) {
-  if (!m || na < 0 || nb < 0 || (na > 0 && (!desc_a || !best_idx || !best_dist)) || (nb > 0 && !desc_b)) {
+  if (!m || na < 0 || nb < 0 || nb > 65535 || (na > 0 && (!desc_a || !best_idx || !best_dist)) || (nb > 0 && !desc_b)) {
     set_error("invalid argument");
     return RGBL_ERR_INVALID;
   }
