@@ -61,6 +61,27 @@ def algorithmic_bytes(kernel, w, h, n_points, k_per_frame):
     return table.get(kernel)
 
 
+def pmc_traffic(kernel, frames_per_launch, profile_batch=256):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_*.csv:
+    FETCH_SIZE + WRITE_SIZE, KB -> bytes; separate --pmc runs of this same command at the default batch of 256).
+    Raw counter values: MI355X_MICROARCH.md notes FETCH_SIZE can under-report wide (16 B/lane) loads by 2x; these
+    kernels read 4 B/lane, for which the counter is uncalibrated.  None when the profiles are not present."""
+    total = 0.0
+    for name in ("r01_pmc_fetch_size.csv", "r01_pmc_write_size.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            return None
+        found = False
+        for line in open(path).read().splitlines()[1:]:
+            cols = line.split(",")
+            if cols[0].endswith(kernel) or cols[0] == kernel:
+                total += float(cols[3]) * 1024.0
+                found = True
+        if not found:
+            return None
+    return total * frames_per_launch / profile_batch
+
+
 def cpu_baseline(seq_frames, scans, proj, w, h, nfeatures, budget_s=20.0):
     """The oracle (CPU port of the reference path), single thread, on a bounded sample of the same workload."""
     from oracle import oracle_py as O
@@ -282,6 +303,12 @@ def main():
     cpu = None
     kernels = {}
     if rank == 0:
+        # per-kernel timing leg: one stream for everything, so that the HIP-event brackets around each launch are not
+        # stretched by other kernels running concurrently
+        one = C.c_void_p(lib.rgbl_extractor_stream(ex.h))
+        L.check(lib, lib.rgbl_depth_set_stream(dm.h, one))
+        L.check(lib, lib.rgbl_matcher_set_stream(mt.h, one))
+        s_dm.value = s_mt.value = one.value
         ex.profile(True); dm.profile(True); mt.profile(True)
         prof_steps = 3
         for _ in range(prof_steps):
@@ -298,7 +325,7 @@ def main():
         ab = algorithmic_bytes(dom, w, h, n_points, k_mean)
         achieved = (ab * B) / (per_step_ms * 1e-3) / 1e9 if ab else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
+                    "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(dom, B),
                     "avg_launch_ms": per_launch_ms, "launches_per_step": launches / prof_steps,
                     "algorithmic_bytes_per_frame": ab, "frames_per_launch": B,
                     "kernel_share_of_gpu_time": ms_sum / total_ms if total_ms else None,

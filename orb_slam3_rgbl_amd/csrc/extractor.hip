@@ -320,13 +320,18 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
     e->timer.end(s);
   }
   // 4. Gaussian working images (ORBextractor.cc:1132-1133) on the auxiliary stream, concurrently with 2. and 3.
-  RGBL_HIP(hipEventRecord(e->ev_pyr, s));
-  RGBL_HIP(hipStreamWaitEvent(e->aux_stream, e->ev_pyr, 0));
-  e->timer.begin("k_gauss7", e->aux_stream);
-  hipLaunchKernelGGL(k_gauss7, dim3(e->blur_tiles.tile_off[L], batch), dim3(256), 0, e->aux_stream, e->d_geom, L,
-                     e->blur_tiles, d_imgs, stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame);
-  e->timer.end(e->aux_stream);
-  RGBL_HIP(hipEventRecord(e->ev_blur, e->aux_stream));
+  //    (while per-kernel timing is on, everything stays on one stream so the event brackets are not contended)
+  const bool overlap = !e->timer.enabled;
+  hipStream_t bs = overlap ? e->aux_stream : s;
+  if (overlap) {
+    RGBL_HIP(hipEventRecord(e->ev_pyr, s));
+    RGBL_HIP(hipStreamWaitEvent(bs, e->ev_pyr, 0));
+  }
+  e->timer.begin("k_gauss7", bs);
+  hipLaunchKernelGGL(k_gauss7, dim3(e->blur_tiles.tile_off[L], batch), dim3(256), 0, bs, e->d_geom, L, e->blur_tiles, d_imgs,
+                     stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame);
+  e->timer.end(bs);
+  if (overlap) RGBL_HIP(hipEventRecord(e->ev_blur, bs));
   // 2. FAST per detection cell (ORBextractor.cc:806-872)
   e->timer.begin("k_fast_cells", s);
   hipLaunchKernelGGL(k_fast_cells, dim3(e->cells_frame, batch), dim3(256), 0, s, e->d_geom, L, d_imgs, stride,
@@ -349,7 +354,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   hipLaunchKernelGGL(k_octree, dim3(L, batch), dim3(kOctBS), 0, s, e->d_geom, L, ob);
   e->timer.end(s);
   // 5. orientation + descriptors + packing (ORBextractor.cc:894-895, 1136-1165); needs the blurred levels
-  RGBL_HIP(hipStreamWaitEvent(s, e->ev_blur, 0));
+  if (overlap) RGBL_HIP(hipStreamWaitEvent(s, e->ev_blur, 0));
   const bool lapping = lap1 >= 19 && lap1 >= lap0;  // keypoint x is always >= 19: nothing can fall into [lap0, lap1] otherwise
   rgbl_keypoint* kp_dst = lapping ? e->d_tmp_kp : d_kp;
   uint8_t* desc_dst = lapping ? e->d_tmp_desc : d_desc;
