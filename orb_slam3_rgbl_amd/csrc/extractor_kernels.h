@@ -1132,15 +1132,22 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
   __syncthreads();
   float angle = 0.f;
   {
-    // IC_Angle: lanes 0..30 take the rows v = -15..15 of the circular patch
+    // IC_Angle (ORBextractor.cc:76-101): integer moments over the rows v = -15..15 of the circular patch
     int m10 = 0, m01 = 0;
-    if (valid && lane < 31) {
-      const int v = lane - 15;
+    if (valid && lane < 62) {
+      // two lanes per row; the half row is read as four 32-bit LDS words (all in flight together) and the bytes
+      // outside the circle (|u| > umax[|v|]) are masked, instead of a data-dependent byte loop
+      const int r = lane >> 1, v = r - 15, half = lane & 1;
       const int d = umax.v[v < 0 ? -v : v];
-      const uint8_t* row = rawp + lane * 32 + 15;
+      const uint32_t* roww = s_raw_w[wave] + r * 8 + half * 4;  // bytes u = -15..0 (half 0) or 1..16 (half 1)
+      const uint32_t w0 = roww[0], w1 = roww[1], w2 = roww[2], w3 = roww[3];
+      const uint32_t ws[4] = {w0, w1, w2, w3};
       int s0 = 0, s1 = 0;
-      for (int u = -d; u <= d; ++u) {
-        const int p = row[u];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int u = half ? k + 1 : k - 15;
+        const int au = u < 0 ? -u : u;
+        const int p = (au <= d && u <= 15) ? (int)((ws[k >> 2] >> (8 * (k & 3))) & 0xff) : 0;
         s0 += p;
         s1 += u * p;
       }
