@@ -570,6 +570,63 @@ __device__ __forceinline__ QNode child_node(const QNode& nd, int q, uint32_t beg
   return c;
 }
 
+// Whole-workgroup version of node_count + node_place for very large nodes (4K frames start with two root nodes of
+// ~75 k keys each; one wave per node would leave the rest of the workgroup idle).  Counting is work-item strided
+// with one reduction; placement walks the keys in chunks of one workgroup, the stable rank of a key inside its
+// quadrant = running total + counts of the earlier waves of the chunk (LDS) + ballot rank inside the wave.
+constexpr int kCoopMin = 2048;  // nodes with at least this many keys are split by the whole workgroup
+
+template <int BS>
+__device__ __forceinline__ void block_split(const QNode& nd, uint32_t* keys_a, uint32_t* keys_b, uint32_t c[4],
+                                            unsigned long long* s_scan, uint32_t (*s_wcnt)[4]) {
+  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  constexpr int NW = BS / 64;
+  const uint32_t cnt = nd.cnt & 0x7fffffffu;
+  const bool in_b = (nd.cnt >> 31) != 0;
+  const uint32_t* src = (in_b ? keys_b : keys_a) + nd.beg;
+  uint32_t* dst = (in_b ? keys_a : keys_b) + nd.beg;
+  const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+  unsigned long long c01 = 0, c23 = 0;
+  for (uint32_t i = tid; i < cnt; i += BS) {
+    const int q = quadrant_of(src[i], mx, my);
+    c01 += q == 0 ? 1ull : (q == 1 ? (1ull << 32) : 0ull);
+    c23 += q == 2 ? 1ull : (q == 3 ? (1ull << 32) : 0ull);
+  }
+  unsigned long long t01, t23;
+  block_exclusive_scan<unsigned long long>(c01, s_scan, &t01);
+  block_exclusive_scan<unsigned long long>(c23, s_scan, &t23);
+  c[0] = (uint32_t)(t01 & 0xffffffffu); c[1] = (uint32_t)(t01 >> 32);
+  c[2] = (uint32_t)(t23 & 0xffffffffu); c[3] = (uint32_t)(t23 >> 32);
+  uint32_t o[4] = {0, c[0], c[0] + c[1], c[0] + c[1] + c[2]};  // running write position per quadrant
+  const unsigned long long lt = lanemask_lt();
+  for (uint32_t base = 0; base < cnt; base += BS) {
+    const uint32_t i = base + tid;
+    const bool valid = i < cnt;
+    const uint32_t key = valid ? src[i] : 0u;
+    const int q = valid ? quadrant_of(key, mx, my) : -1;
+    uint32_t rank_in_wave = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long mask = __ballot(q == k);
+      if (q == k) rank_in_wave = (uint32_t)__popcll(mask & lt);
+      if (lane == 0) s_wcnt[wave][k] = (uint32_t)__popcll(mask);
+    }
+    __syncthreads();
+    uint32_t before = 0, chunk_total[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      for (int w = 0; w < NW; ++w) {
+        const uint32_t v = s_wcnt[w][k];
+        if (k == q && w < wave) before += v;
+        chunk_total[k] += v;
+      }
+    if (valid) dst[o[q] + before + rank_in_wave] = key;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] += chunk_total[k];
+    __syncthreads();
+  }
+}
+
 constexpr int kOctBS = 512;         // work-items per quad-tree workgroup (16 waves hide the dependent-load latency)
 constexpr int kSortLds = 2048;     // largest expandable-node list sorted in LDS by the whole workgroup
 constexpr int kSortRanges = 160;   // > kSortLds / 17: pending ranges of more than 16 elements are disjoint
@@ -844,7 +901,10 @@ __global__ __launch_bounds__(kOctBS) void k_octree(const LevelGeom* __restrict__
   __shared__ SortRanges s_ra, s_rb;
   __shared__ int s_sort_cnt[2];
   unsigned long long* s_skey = s_skey_pad + 4;
-  __shared__ int s_newn, s_nexp, s_n, s_P;
+  __shared__ int s_newn, s_nexp, s_n, s_P, s_nbig;
+  constexpr int kMaxBig = 64;
+  __shared__ int s_big[kMaxBig];
+  __shared__ uint32_t s_wcnt[kOctBS / 64][4];
   __shared__ uint32_t s_rootcnt[kMaxRoots];
 #define RGBL_STAMP(k) do { if (b.dbg && threadIdx.x == 0) b.dbg[((size_t)blockIdx.y * n_levels + blockIdx.x) * 16 + (k)] = rgbl_clock(); } while (0)
   RGBL_STAMP(0);
@@ -927,10 +987,30 @@ __global__ __launch_bounds__(kOctBS) void k_octree(const LevelGeom* __restrict__
   bool finished = (n == 0);
   bool careful = false;
   while (!finished) {
+    // very large nodes: one after the other, whole workgroup each
+    if (tid == 0) s_nbig = 0;
+    __syncthreads();
+    for (int pos = tid; pos < n; pos += kOctBS)
+      if ((cur[pos].cnt & 0x7fffffffu) >= (uint32_t)kCoopMin) {
+        const int k = atomicAdd(&s_nbig, 1);
+        if (k < kMaxBig) s_big[k] = pos;
+      }
+    __syncthreads();
+    const int nbig = s_nbig <= kMaxBig ? s_nbig : 0;  // more than kMaxBig big nodes: leave all of them to the waves
+    for (int k = 0; k < nbig; ++k) {
+      const int pos = s_big[k];
+      const QNode nd = cur[pos];
+      QDiv d;
+      block_split<kOctBS>(nd, keys_a, keys_b, d.c, s_scan, s_wcnt);
+      if (tid == 0) { div[pos] = d; divided[pos] = 0; }
+    }
+    // everything else: one wave per node
     for (int pos = wave; pos < n; pos += nw) {
       const QNode nd = cur[pos];
+      const uint32_t cnt = nd.cnt & 0x7fffffffu;
+      if (cnt >= (uint32_t)kCoopMin && nbig > 0) continue;  // already split above
       QDiv d; d.c[0] = d.c[1] = d.c[2] = d.c[3] = 0;
-      if ((nd.cnt & 0x7fffffffu) > 1) {
+      if (cnt > 1) {
         node_count(nd, keys_a, keys_b, d.c);
         node_place(nd, keys_a, keys_b, d.c);
       }

@@ -66,3 +66,8 @@ def test_matcher(emu_lib):
 
 def test_search_for_triangulation(emu_lib):
     pc.check_triangulation(emu_lib, 600, seed=11)
+
+
+def test_extractor_large_nodes_take_the_cooperative_split(emu_lib):
+    # ~40 k candidates under one quad-tree root: the first iterations go through the workgroup-wide split
+    pc.check_extractor(emu_lib, 1500, 1100, 3000, frames=(0,), nlevels=2, seq=14, stages=True)
