@@ -893,7 +893,7 @@ __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kOctBS) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b) {
+__global__ __launch_bounds__(kOctBS, 4) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b) {
   __shared__ unsigned long long s_scan[32];
   __shared__ unsigned long long s_skey_pad[kSortLds + 8];  // 4 entries of read slack on both sides
   __shared__ uint32_t s_sval[kSortLds];
