@@ -113,6 +113,24 @@ int rgbl_extractor_get_level(rgbl_extractor* h, int frame, int level, int blurre
 int rgbl_extractor_get_candidates(rgbl_extractor* h, int frame, int level, rgbl_keypoint* out, int cap,
                                   int* out_n);
 
+/* void Frame::ComputeStereoMatches() (src/Frame.cc:901-1071): for every left keypoint the best
+ * right keypoint in its row band (Hamming, strict '<', octave +-1, disparity window from mb / mbf), 11x11 SAD
+ * sub-pixel refinement over 11 shifts on the left keypoint's pyramid level, parabola fit, median*2.1 outlier cut.
+ * `left` / `right` are the two extractor handles whose LAST extract call processed the left / right image(s): their
+ * resident pyramids are read directly (the reference reads mpORBextractor{Left,Right}->mvImagePyramid), so the stereo
+ * path needs no pyramid download.  Outputs mvuRight / mvDepth (-1 = no match).
+ * Host variant: frame 0 of the last call, host arrays, synchronous.  Device variant: the layout of
+ * rgbl_extract_batch_device() for both sides (frame b at + b*cap), enqueued on the left handle's stream. */
+int rgbl_stereo_matches(rgbl_extractor* left, rgbl_extractor* right, const rgbl_keypoint* kp_left,
+                        const uint8_t* desc_left, int n_left, const rgbl_keypoint* kp_right,
+                        const uint8_t* desc_right, int n_right, float mb, float mbf, float* out_uright,
+                        float* out_depth);
+int rgbl_stereo_matches_batch_device(rgbl_extractor* left, rgbl_extractor* right, int batch,
+                                     const rgbl_keypoint* d_kp_left, const uint8_t* d_desc_left,
+                                     const int32_t* d_n_left, const rgbl_keypoint* d_kp_right,
+                                     const uint8_t* d_desc_right, const int32_t* d_n_right, int cap, float mb,
+                                     float mbf, float* d_uright, float* d_depth);
+
 /* Diagnostics: with RGBL_OCTREE_STAMPS set in the environment the quad-tree kernel leaves 16 cycle-counter stamps
  * per (frame, level) workgroup; this copies them out. */
 int rgbl_extractor_debug_stamps(rgbl_extractor* h, unsigned long long* out, int count);

@@ -53,6 +53,14 @@ int orc_level_candidates(const orc_extractor*, int level, orc_keypoint* out, int
 /* keypoints per level after distribution+orientation (level coordinates, before scaling) */
 int orc_level_keypoints(const orc_extractor*, int level, orc_keypoint* out, int cap);
 
+/* Frame::ComputeStereoMatches (/root/reference/src/Frame.cc:901-1071): left/right are extractors whose LAST
+ * orc_extract call saw the left/right image (their pyramids are read like mvImagePyramid).  Fills mvuRight /
+ * mvDepth (n_left floats each, -1 = no match). */
+void orc_stereo_matches(const orc_extractor* left, const orc_extractor* right, const orc_keypoint* kp_left,
+                        const uint8_t* desc_left, int n_left, const orc_keypoint* kp_right,
+                        const uint8_t* desc_right, int n_right, float mb, float mbf, float* out_uright,
+                        float* out_depth);
+
 /* ---- stand-alone OpenCV-semantics primitives ---- */
 void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh,
                           int dstride);

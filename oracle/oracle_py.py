@@ -66,6 +66,9 @@ def lib():
         for f in ("orc_level_candidates", "orc_level_keypoints"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
             getattr(L, f).restype = C.c_int
+        L.orc_stereo_matches.restype = None
+        L.orc_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                            C.c_int, C.c_int]
         L.orc_gaussian_blur7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -171,6 +174,19 @@ class Extractor:
 
     def level_keypoints(self, l):
         return self._kps(self.L.orc_level_keypoints, l)
+
+
+def stereo_matches(ex_left, ex_right, kpl, dl, kpr, dr, mb, mbf):
+    """Frame::ComputeStereoMatches on two Extractor objects that just processed the left / right image."""
+    kpl = np.ascontiguousarray(kpl, KP_DTYPE)
+    kpr = np.ascontiguousarray(kpr, KP_DTYPE)
+    dl = np.ascontiguousarray(dl, np.uint8)
+    dr = np.ascontiguousarray(dr, np.uint8)
+    ur = np.zeros(len(kpl), np.float32)
+    dp = np.zeros(len(kpl), np.float32)
+    lib().orc_stereo_matches(ex_left.h, ex_right.h, _p(kpl), _p(dl), len(kpl), _p(kpr), _p(dr), len(kpr), float(mb), float(mbf),
+                             _p(ur), _p(dp))
+    return ur, dp
 
 
 def resize_linear(src, dw, dh):

@@ -604,3 +604,107 @@ int orc_distribute_octree(const orc_keypoint* cand, int n, int min_x, int max_x,
 }
 
 }  // extern "C"
+
+// ================================================================= Frame::ComputeStereoMatches
+// Restates /root/reference/src/Frame.cc:901-1071 literally (row table, Hamming search with strict '<', 11x11 SAD
+// over 11 shifts on the pyramid level of the left keypoint, parabola fit, median-based outlier cut with std::sort).
+// mvImagePyramid[level] is a view into a buffer with a 19-px reflect-101 frame, so reads slightly outside the
+// level are defined; pyr_at() reproduces that.
+namespace {
+inline int pyr_at(const Image& im, int x, int y) { return im.row(reflect101(y, im.h))[reflect101(x, im.w)]; }
+inline int hamming_words(const uint8_t* a, const uint8_t* b) {
+  int d = 0;
+  for (int i = 0; i < 32; ++i) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+  return d;
+}
+}  // namespace
+
+extern "C" void orc_stereo_matches(const orc_extractor* L, const orc_extractor* R, const orc_keypoint* kpl,
+                                   const uint8_t* dl, int N, const orc_keypoint* kpr, const uint8_t* dr, int Nr,
+                                   float mb, float mbf, float* uright, float* depth) {
+  for (int i = 0; i < N; ++i) { uright[i] = -1.0f; depth[i] = -1.0f; }
+  const int TH_HIGH = 100, TH_LOW = 50;
+  const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+  const int nRows = L->pyr[0].h;
+  std::vector<std::vector<size_t>> rows(nRows);
+  for (int iR = 0; iR < Nr; ++iR) {
+    const float kpY = kpr[iR].y;
+    const float r = 2.0f * L->scale[kpr[iR].octave];
+    const int maxr = (int)std::ceil(kpY + r);
+    const int minr = (int)std::floor(kpY - r);
+    for (int yi = minr; yi <= maxr; ++yi)
+      if (yi >= 0 && yi < nRows) rows[yi].push_back(iR);  // (the reference indexes unchecked)
+  }
+  const float minZ = mb, minD = 0, maxD = mbf / minZ;
+  std::vector<std::pair<int, int>> dist_idx;
+  for (int iL = 0; iL < N; ++iL) {
+    const orc_keypoint& kpL = kpl[iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const std::vector<size_t>& cand = rows[(size_t)vL];
+    if (cand.empty()) continue;
+    const float minU = uL - maxD, maxU = uL - minD;
+    if (maxU < 0) continue;
+    int bestDist = TH_HIGH;
+    size_t bestIdxR = 0;
+    for (size_t iC = 0; iC < cand.size(); ++iC) {
+      const size_t iR = cand[iC];
+      const orc_keypoint& kR = kpr[iR];
+      if (kR.octave < levelL - 1 || kR.octave > levelL + 1) continue;
+      const float uR = kR.x;
+      if (uR >= minU && uR <= maxU) {
+        const int dist = hamming_words(dl + 32 * (size_t)iL, dr + 32 * iR);
+        if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+      }
+    }
+    if (bestDist < thOrbDist) {
+      const float uR0 = kpr[bestIdxR].x;
+      const float scaleFactor = L->inv_scale[kpL.octave];
+      const float scaleduL = std::round(kpL.x * scaleFactor);
+      const float scaledvL = std::round(kpL.y * scaleFactor);
+      const float scaleduR0 = std::round(uR0 * scaleFactor);
+      const int w = 5, Lw = 5;
+      const Image& IL = L->pyr[kpL.octave];
+      const Image& IR = R->pyr[kpL.octave];
+      int best = INT32_MAX, bestinc = 0;
+      float vDists[2 * 5 + 1];
+      const float iniu = scaleduR0 + Lw - w;
+      const float endu = scaleduR0 + Lw + w + 1;
+      if (iniu < 0 || endu >= IR.w) continue;
+      const int yl0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w);
+      for (int inc = -Lw; inc <= Lw; ++inc) {
+        const int xr0 = (int)(scaleduR0 + inc - w);
+        int sad = 0;
+        for (int yy = 0; yy < 2 * w + 1; ++yy)
+          for (int xx = 0; xx < 2 * w + 1; ++xx) sad += std::abs(pyr_at(IL, xl0 + xx, yl0 + yy) - pyr_at(IR, xr0 + xx, yl0 + yy));
+        const float dist = (float)sad;  // cv::norm(IL, IR, NORM_L1)
+        if (dist < best) { best = (int)dist; bestinc = inc; }
+        vDists[Lw + inc] = dist;
+      }
+      if (bestinc == -Lw || bestinc == Lw) continue;
+      const float dist1 = vDists[Lw + bestinc - 1], dist2 = vDists[Lw + bestinc], dist3 = vDists[Lw + bestinc + 1];
+      const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+      if (deltaR < -1 || deltaR > 1) continue;
+      float bestuR = L->scale[kpL.octave] * ((float)scaleduR0 + (float)bestinc + deltaR);
+      float disparity = (uL - bestuR);
+      if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) {
+          disparity = 0.01;
+          bestuR = uL - 0.01;
+        }
+        depth[iL] = mbf / disparity;
+        uright[iL] = bestuR;
+        dist_idx.push_back(std::pair<int, int>(best, iL));
+      }
+    }
+  }
+  if (dist_idx.empty()) return;  // the reference reads vDistIdx[0] of an empty vector here (undefined behaviour)
+  std::sort(dist_idx.begin(), dist_idx.end());
+  const float median = dist_idx[dist_idx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  for (int i = (int)dist_idx.size() - 1; i >= 0; --i) {
+    if (dist_idx[i].first < thDist) break;
+    uright[dist_idx[i].second] = -1;
+    depth[dist_idx[i].second] = -1;
+  }
+}

@@ -69,6 +69,8 @@ SYMBOLS = {
     "rgbl_extractor_level_size": (_I, [_V, _I, C.POINTER(_I), C.POINTER(_I)]),
     "rgbl_extractor_get_level": (_I, [_V, _I, _I, _I, _I, _V, _I]),
     "rgbl_extractor_get_candidates": (_I, [_V, _I, _I, _V, _I, C.POINTER(_I)]),
+    "rgbl_stereo_matches": (_I, [_V, _V, _V, _V, _I, _V, _V, _I, _F, _F, _V, _V]),
+    "rgbl_stereo_matches_batch_device": (_I, [_V, _V, _I, _V, _V, _V, _V, _V, _V, _I, _F, _F, _V, _V]),
     "rgbl_extractor_debug_stamps": (_I, [_V, _V, _I]),
     "rgbl_extractor_set_stream": (_I, [_V, _V]),
     "rgbl_extractor_profile": (_I, [_V, _I]),

@@ -75,6 +75,10 @@ struct rgbl_extractor {
   uint32_t* d_kpkey = nullptr;
   int* d_kpcount = nullptr;
   int* d_err = nullptr;
+  int32_t* d_stereo_sad = nullptr;  // ComputeStereoMatches scratch (grow-only)
+  size_t stereo_sad_count = 0;
+  void* d_stereo_stage = nullptr;
+  size_t stereo_stage_bytes = 0;
   unsigned long long* d_dbg = nullptr;
   // staging for the host entry points and for the lapping permutation
   rgbl_keypoint *d_out_kp = nullptr, *d_tmp_kp = nullptr;
@@ -450,6 +454,8 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   if (e->stream) hipStreamSynchronize(e->stream);
   e->timer.collect();
   for (void* p : e->allocs) hipFree(p);
+  if (e->d_stereo_sad) hipFree(e->d_stereo_sad);
+  if (e->d_stereo_stage) hipFree(e->d_stereo_stage);
   if (e->aux_stream) { hipStreamSynchronize(e->aux_stream); hipStreamDestroy(e->aux_stream); }
   if (e->ev_pyr) hipEventDestroy(e->ev_pyr);
   if (e->ev_blur) hipEventDestroy(e->ev_blur);
@@ -672,6 +678,104 @@ int rgbl_event_record(void* ev, void* stream) {
 int rgbl_event_wait(void* stream, void* ev) {
   if (!ev) { set_error("null event"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
+  return RGBL_OK;
+}
+
+// ---- Frame::ComputeStereoMatches (Frame.cc:901-1071) ---------------------------------------------------------
+static int stereo_enqueue(rgbl_extractor* L, rgbl_extractor* R, int batch, const rgbl_keypoint* d_kpl, const uint8_t* d_dl,
+                          const int32_t* d_nl, const rgbl_keypoint* d_kpr, const uint8_t* d_dr, const int32_t* d_nr, int cap,
+                          float mb, float mbf, float* d_uright, float* d_depth) {
+  if (L->cfg.width != R->cfg.width || L->cfg.height != R->cfg.height || L->L != R->L || L->device != R->device ||
+      L->cfg.scale_factor != R->cfg.scale_factor) {
+    set_error("left and right extractor differ in geometry");
+    return RGBL_ERR_INVALID;
+  }
+  if (batch < 1 || batch > L->last_batch || batch > R->last_batch || !L->last_img0 || !R->last_img0) {
+    set_error("stereo matching needs both extractors to have processed this batch (pyramids resident)");
+    return RGBL_ERR_INVALID;
+  }
+  if (!(mb > 0) || cap < 1) { set_error("invalid stereo parameters"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(L->device));
+  const size_t need = (size_t)batch * cap;
+  if (need > L->stereo_sad_count) {
+    RGBL_HIP(hipStreamSynchronize(L->stream));
+    if (L->d_stereo_sad) RGBL_HIP(hipFree(L->d_stereo_sad));
+    L->d_stereo_sad = nullptr;
+    RGBL_HIP(hipMalloc(&L->d_stereo_sad, need * sizeof(int32_t)));
+    L->stereo_sad_count = need;
+  }
+  RGBL_TRY(rgbl_stream_wait((void*)L->stream, (void*)R->stream));  // the right pyramid and keypoints must be complete
+  ScaleTables st;
+  for (int i = 0; i < kMaxLevels; ++i) { st.scale[i] = i < L->L ? L->scale[i] : 1.f; st.inv_scale[i] = i < L->L ? L->inv_scale[i] : 1.f; }
+  PyrView pl{L->last_img0, L->last_pitch0, L->last_frame0, L->d_pyr, L->pyr_frame};
+  PyrView pr{R->last_img0, R->last_pitch0, R->last_frame0, R->d_pyr, R->pyr_frame};
+  hipStream_t s = L->stream;
+  L->timer.begin("k_stereo_match", s);
+  hipLaunchKernelGGL(k_stereo_match, dim3((cap + 255) / 256, batch), dim3(256), 0, s, L->d_geom, st, pl, pr, d_kpl, d_dl, d_nl,
+                     d_kpr, d_dr, d_nr, cap, mb, mbf, L->cfg.height, d_uright, d_depth, L->d_stereo_sad);
+  L->timer.end(s);
+  L->timer.begin("k_stereo_filter", s);
+  hipLaunchKernelGGL(k_stereo_filter, dim3(batch), dim3(256), 0, s, d_nl, cap, L->d_stereo_sad, d_uright, d_depth);
+  L->timer.end(s);
+  RGBL_HIP(hipGetLastError());
+  return RGBL_OK;
+}
+
+int rgbl_stereo_matches_batch_device(rgbl_extractor* left, rgbl_extractor* right, int batch, const rgbl_keypoint* d_kp_left,
+                                     const uint8_t* d_desc_left, const int32_t* d_n_left, const rgbl_keypoint* d_kp_right,
+                                     const uint8_t* d_desc_right, const int32_t* d_n_right, int cap, float mb, float mbf,
+                                     float* d_uright, float* d_depth) {
+  if (!left || !right || !d_kp_left || !d_desc_left || !d_n_left || !d_kp_right || !d_desc_right || !d_n_right || !d_uright ||
+      !d_depth) {
+    set_error("null argument");
+    return RGBL_ERR_INVALID;
+  }
+  return stereo_enqueue(left, right, batch, d_kp_left, d_desc_left, d_n_left, d_kp_right, d_desc_right, d_n_right, cap, mb, mbf,
+                        d_uright, d_depth);
+}
+
+int rgbl_stereo_matches(rgbl_extractor* left, rgbl_extractor* right, const rgbl_keypoint* kp_left, const uint8_t* desc_left,
+                        int n_left, const rgbl_keypoint* kp_right, const uint8_t* desc_right, int n_right, float mb, float mbf,
+                        float* out_uright, float* out_depth) {
+  if (!left || !right || n_left < 0 || n_right < 0 || (n_left > 0 && (!kp_left || !desc_left || !out_uright || !out_depth)) ||
+      (n_right > 0 && (!kp_right || !desc_right))) {
+    set_error("invalid argument");
+    return RGBL_ERR_INVALID;
+  }
+  if (n_left == 0) return RGBL_OK;
+  RGBL_HIP(hipSetDevice(left->device));
+  const int cap = std::max(std::max(n_left, n_right), 1);
+  const size_t rec = (size_t)cap * (sizeof(rgbl_keypoint) + 32);
+  const size_t bytes = 2 * rec + 256 + 2 * (size_t)cap * sizeof(float) + 1024;
+  if (bytes > left->stereo_stage_bytes) {
+    RGBL_HIP(hipStreamSynchronize(left->stream));
+    if (left->d_stereo_stage) RGBL_HIP(hipFree(left->d_stereo_stage));
+    left->d_stereo_stage = nullptr;
+    RGBL_HIP(hipMalloc(&left->d_stereo_stage, bytes));
+    left->stereo_stage_bytes = bytes;
+  }
+  uint8_t* base = (uint8_t*)left->d_stereo_stage;
+  rgbl_keypoint* d_kpl = (rgbl_keypoint*)base;
+  rgbl_keypoint* d_kpr = (rgbl_keypoint*)(base + (size_t)cap * sizeof(rgbl_keypoint));
+  uint8_t* d_dl = base + 2 * (size_t)cap * sizeof(rgbl_keypoint);
+  uint8_t* d_dr = d_dl + (size_t)cap * 32;
+  int32_t* d_n = (int32_t*)(d_dr + (size_t)cap * 32);
+  float* d_u = (float*)((uint8_t*)d_n + 256);
+  float* d_d = d_u + cap;
+  hipStream_t s = left->stream;
+  const int32_t counts[2] = {n_left, n_right};
+  RGBL_HIP(hipMemcpyAsync(d_kpl, kp_left, sizeof(rgbl_keypoint) * n_left, hipMemcpyHostToDevice, s));
+  RGBL_HIP(hipMemcpyAsync(d_dl, desc_left, (size_t)32 * n_left, hipMemcpyHostToDevice, s));
+  if (n_right > 0) {
+    RGBL_HIP(hipMemcpyAsync(d_kpr, kp_right, sizeof(rgbl_keypoint) * n_right, hipMemcpyHostToDevice, s));
+    RGBL_HIP(hipMemcpyAsync(d_dr, desc_right, (size_t)32 * n_right, hipMemcpyHostToDevice, s));
+  }
+  RGBL_HIP(hipMemcpyAsync(d_n, counts, sizeof(counts), hipMemcpyHostToDevice, s));
+  RGBL_TRY(stereo_enqueue(left, right, 1, d_kpl, d_dl, d_n, d_kpr, d_dr, d_n + 1, cap, mb, mbf, d_u, d_d));
+  RGBL_HIP(hipMemcpyAsync(out_uright, d_u, sizeof(float) * n_left, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipMemcpyAsync(out_depth, d_d, sizeof(float) * n_left, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipStreamSynchronize(s));
+  left->timer.collect();
   return RGBL_OK;
 }
 

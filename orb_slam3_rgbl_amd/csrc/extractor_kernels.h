@@ -1321,6 +1321,164 @@ __global__ __launch_bounds__(kOctBS) void k_test_block_sort(uint64_t* key, uint3
   for (int i = threadIdx.x; i < n; i += kOctBS) { key[i] = w[i] >> 16; val[i] = (uint32_t)(w[i] & 0xffffu); }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches (/root/reference/src/Frame.cc:901-1071), SURVEY.md 8(f) row f1.
+//   k_stereo_match   one work-item per left keypoint: candidates = right keypoints whose row band
+//                    [floor(y - 2 s), ceil(y + 2 s)] contains the left row, octave within +-1, u inside the disparity
+//                    window; visited in ascending index order with strict '<' (== the reference's row table);
+//                    then the 11x11 SAD over 11 shifts on the left keypoint's pyramid level, parabola fit.
+//   k_stereo_filter  one workgroup per frame: median of the accepted SADs by a two-level histogram, outlier cut.
+struct ScaleTables { float scale[kMaxLevels], inv_scale[kMaxLevels]; };
+struct PyrView { const uint8_t* img0; int pitch0; size_t frame0; const uint8_t* pyr; size_t pyr_frame; };
+
+__device__ __forceinline__ int pyr_px(const uint8_t* base, int pitch, int w, int h, int x, int y) {
+  return base[(size_t)reflect101(y, h) * pitch + reflect101(x, w)];  // the reference reads a reflect-101 bordered buffer
+}
+
+__global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restrict__ geom, ScaleTables st, PyrView PL, PyrView PR,
+                                                      const rgbl_keypoint* __restrict__ kpl, const uint8_t* __restrict__ dl,
+                                                      const int32_t* __restrict__ nl, const rgbl_keypoint* __restrict__ kpr,
+                                                      const uint8_t* __restrict__ dr, const int32_t* __restrict__ nr, int cap,
+                                                      float mb, float mbf, int n_rows, float* __restrict__ uright,
+                                                      float* __restrict__ depth, int32_t* __restrict__ sad_out) {
+  const int f = blockIdx.y;
+  const int iL = blockIdx.x * 256 + threadIdx.x;
+  const int N = nl[f], Nr = nr[f];
+  if (iL >= N) return;
+  const size_t o = (size_t)f * cap + iL;
+  const rgbl_keypoint kL = kpl[o];
+  float out_u = -1.0f, out_d = -1.0f;
+  int out_sad = -1;
+  const float minD = 0, maxD = __fdiv_rn(mbf, mb);
+  const float uL = kL.x, vL = kL.y;
+  const int levelL = kL.octave;
+  const int row = (int)vL;
+  const float minU = uL - maxD, maxU = uL - minD;
+  if (!(maxU < 0) && row >= 0 && row < n_rows) {
+    const unsigned long long* D = reinterpret_cast<const unsigned long long*>(dl + o * 32);
+    const unsigned long long q0 = D[0], q1 = D[1], q2 = D[2], q3 = D[3];
+    int bestDist = 100 /* TH_HIGH */, bestIdxR = 0;
+    const rgbl_keypoint* KR = kpr + (size_t)f * cap;
+    const unsigned long long* DR = reinterpret_cast<const unsigned long long*>(dr + (size_t)f * cap * 32);
+    for (int iR = 0; iR < Nr; ++iR) {
+      const float kpY = KR[iR].y, uR = KR[iR].x;
+      const int octR = KR[iR].octave;
+      const float r = 2.0f * st.scale[octR];
+      const int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
+      if (row < minr || row > maxr) continue;
+      if (octR < levelL - 1 || octR > levelL + 1) continue;
+      if (!(uR >= minU && uR <= maxU)) continue;
+      const unsigned long long* t = DR + 4 * (size_t)iR;
+      const int dist = __popcll(q0 ^ t[0]) + __popcll(q1 ^ t[1]) + __popcll(q2 ^ t[2]) + __popcll(q3 ^ t[3]);
+      if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+    }
+    if (bestDist < 75 /* (TH_HIGH + TH_LOW) / 2 */) {
+      const float uR0 = KR[bestIdxR].x;
+      const float scaleFactor = st.inv_scale[levelL];
+      const float scaleduL = roundf(kL.x * scaleFactor), scaledvL = roundf(kL.y * scaleFactor);
+      const float scaleduR0 = roundf(uR0 * scaleFactor);
+      const LevelGeom& g = geom[levelL];
+      const int w = 5, Lw = 5;
+      const float iniu = scaleduR0 + Lw - w, endu = scaleduR0 + Lw + w + 1;
+      if (!(iniu < 0 || endu >= (float)g.w)) {
+        const uint8_t* IL = levelL == 0 ? PL.img0 + (size_t)f * PL.frame0 : PL.pyr + (size_t)f * PL.pyr_frame + g.img_off;
+        const uint8_t* IR = levelL == 0 ? PR.img0 + (size_t)f * PR.frame0 : PR.pyr + (size_t)f * PR.pyr_frame + g.img_off;
+        const int pl = levelL == 0 ? PL.pitch0 : g.pitch, pr = levelL == 0 ? PR.pitch0 : g.pitch;
+        const int yl0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w), xr0 = (int)(scaleduR0 - Lw - w);
+        int sad[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) sad[k] = 0;
+        for (int yy = 0; yy < 11; ++yy) {
+          int a[11], b[21];
+#pragma unroll
+          for (int xx = 0; xx < 11; ++xx) a[xx] = pyr_px(IL, pl, g.w, g.h, xl0 + xx, yl0 + yy);
+#pragma unroll
+          for (int xx = 0; xx < 21; ++xx) b[xx] = pyr_px(IR, pr, g.w, g.h, xr0 + xx, yl0 + yy);
+#pragma unroll
+          for (int k = 0; k < 11; ++k)
+#pragma unroll
+            for (int xx = 0; xx < 11; ++xx) { const int d = a[xx] - b[xx + k]; sad[k] += d < 0 ? -d : d; }
+        }
+        int best = 0x7fffffff, bestinc = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k)
+          if ((float)sad[k] < (float)best) { best = sad[k]; bestinc = k - Lw; }
+        if (!(bestinc == -Lw || bestinc == Lw)) {
+          float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+          for (int k = 1; k < 10; ++k)
+            if (k - Lw == bestinc) { dist1 = (float)sad[k - 1]; dist2 = (float)sad[k]; dist3 = (float)sad[k + 1]; }
+          const float deltaR = __fdiv_rn(dist1 - dist3, 2.0f * (dist1 + dist3 - 2.0f * dist2));
+          if (!(deltaR < -1 || deltaR > 1)) {
+            float bestuR = st.scale[levelL] * (scaleduR0 + (float)bestinc + deltaR);
+            float disparity = uL - bestuR;
+            if (disparity >= minD && disparity < maxD) {
+              if (disparity <= 0) {
+                disparity = 0.01f;
+                bestuR = (float)((double)uL - 0.01);
+              }
+              out_d = __fdiv_rn(mbf, disparity);
+              out_u = bestuR;
+              out_sad = best;
+            }
+          }
+        }
+      }
+    }
+  }
+  uright[o] = out_u;
+  depth[o] = out_d;
+  sad_out[o] = out_sad;
+}
+
+__global__ __launch_bounds__(256) void k_stereo_filter(const int32_t* __restrict__ nl, int cap, const int32_t* __restrict__ sad,
+                                                       float* __restrict__ uright, float* __restrict__ depth) {
+  __shared__ int s_hist[256];
+  __shared__ int s_bin, s_rank, s_nacc;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int N = nl[f];
+  const int32_t* S = sad + (size_t)f * cap;
+  s_hist[tid] = 0;
+  if (tid == 0) s_nacc = 0;
+  __syncthreads();
+  int acc = 0;
+  for (int i = tid; i < N; i += 256) {
+    const int v = S[i];
+    if (v >= 0) { atomicAdd(&s_hist[imin(v >> 7, 255)], 1); ++acc; }
+  }
+  if (acc) atomicAdd(&s_nacc, acc);
+  __syncthreads();
+  const int nacc = s_nacc;
+  if (nacc == 0) return;  // the reference would index an empty vector here (undefined behaviour)
+  if (tid == 0) {
+    int k = nacc / 2, cum = 0, b = 0;
+    for (; b < 256; ++b) { if (cum + s_hist[b] > k) break; cum += s_hist[b]; }
+    s_bin = b; s_rank = k - cum;
+  }
+  __syncthreads();
+  const int b1 = s_bin, k1 = s_rank;
+  __syncthreads();
+  s_hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < N; i += 256) {
+    const int v = S[i];
+    if (v >= 0 && imin(v >> 7, 255) == b1) atomicAdd(&s_hist[v & 127], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int cum = 0, b = 0;
+    for (; b < 128; ++b) { if (cum + s_hist[b] > k1) break; cum += s_hist[b]; }
+    s_bin = b1 * 128 + b;
+  }
+  __syncthreads();
+  const float median = (float)s_bin;
+  const float thDist = 1.5f * 1.4f * median;
+  for (int i = tid; i < N; i += 256) {
+    const int v = S[i];
+    if (v >= 0 && !((float)v < thDist)) { uright[(size_t)f * cap + i] = -1.0f; depth[(size_t)f * cap + i] = -1.0f; }
+  }
+}
+
 // unpacks candidate keys into rgbl_keypoint records (diagnostic path of rgbl_extractor_get_candidates)
 __global__ void k_unpack_keys(const uint32_t* __restrict__ keys, int n, rgbl_keypoint* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -132,6 +132,21 @@ class ORBextractor:
         return L.read_profile(self.lib, self.lib.rgbl_extractor_profile_read, self.h)
 
 
+def ComputeStereoMatches(extractorLeft, extractorRight, mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mb, mbf):
+    """Frame::ComputeStereoMatches (src/Frame.cc:901-1071). Both extractors must just have processed the left / right
+    image (their device-resident pyramids are read). Returns (mvuRight, mvDepth)."""
+    lib = extractorLeft.lib
+    kl = np.ascontiguousarray(mvKeys, KP_DTYPE)
+    kr = np.ascontiguousarray(mvKeysRight, KP_DTYPE)
+    dl = np.ascontiguousarray(mDescriptors, np.uint8).reshape(-1, 32)
+    dr = np.ascontiguousarray(mDescriptorsRight, np.uint8).reshape(-1, 32)
+    ur = np.full(len(kl), -1, np.float32)
+    dp = np.full(len(kl), -1, np.float32)
+    L.check(lib, lib.rgbl_stereo_matches(extractorLeft.h, extractorRight.h, L.ptr(kl), L.ptr(dl), len(kl), L.ptr(kr), L.ptr(dr),
+                                         len(kr), float(mb), float(mbf), L.ptr(ur), L.ptr(dp)))
+    return ur, dp
+
+
 def structuring_element(shape, kw, kh, lib=None):
     lib = lib or L.load()
     out = np.zeros(kw * kh, np.uint8)

@@ -37,6 +37,9 @@ class ORBextractor {
   std::vector<cv::Mat> mvImagePyramid;
   bool keepPyramid = false;
   int device = 0;  // HIP device ordinal, may be changed before the first call
+  // The C-ABI handle (pyramids of the last image stay resident in it): Frame::ComputeStereoMatches hands the left
+  // and the right handle to rgbl_stereo_matches() instead of reading mvImagePyramid on the host.
+  rgbl_extractor* Handle() const { return mpHandle; }
 
  protected:
   void EnsureHandle(int width, int height);

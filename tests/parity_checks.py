@@ -291,3 +291,42 @@ def check_triangulation(lib, n=1500, seed=11):
         m.close()
     assert total > 100  # the case must actually produce matches
     return total
+
+
+def stereo_pair(seq, w, h, frame=0, disparity_scale=1.0):
+    """A rectified synthetic stereo pair: the right view is the scene shifted horizontally (constant plus a smooth
+    vertical-gradient disparity) with its own sensor noise."""
+    sq = synth.Sequence(seq, w + 128, h, n_frames=frame + 1)
+    full = sq.frame(frame).astype(np.int32)
+    left = full[:, 64:64 + w]
+    right = np.empty_like(left)
+    for y in range(h):  # disparity grows towards the bottom of the image (near ground), 4 .. ~40 px
+        d = int(round(disparity_scale * (4 + 36.0 * y / h)))
+        right[y] = full[y, 64 + d:64 + d + w]
+    rng = np.random.default_rng(seq * 77 + frame)
+    right = np.clip(right + np.rint(1.5 * rng.standard_normal(right.shape)).astype(np.int32), 0, 255)
+    return left.astype(np.uint8), right.astype(np.uint8)
+
+
+def check_stereo_matches(lib, w=synth.KITTI_W, h=synth.KITTI_H, nfeatures=2000, ini=20, mn=7, seq=30, mb=0.54, mbf=386.1448):
+    """Frame::ComputeStereoMatches: left/right extraction on the device, then matching with the resident pyramids."""
+    left, right = stereo_pair(seq, w, h)
+    exl = F.ORBextractor(nfeatures, 1.2, 8, ini, mn, w, h, lib=lib)
+    exr = F.ORBextractor(nfeatures, 1.2, 8, ini, mn, w, h, lib=lib)
+    ol, orr = O.Extractor(nfeatures, 1.2, 8, ini, mn), O.Extractor(nfeatures, 1.2, 8, ini, mn)
+    kl, dl, _ = exl(left)
+    kr, dr, _ = exr(right)
+    okl, odl, _ = ol(left)
+    okr, odr, _ = orr(right)
+    assert_keypoints_equal(kl, okl, "left")
+    assert_keypoints_equal(kr, okr, "right")
+    ur, dp = F.ComputeStereoMatches(exl, exr, kl, dl, kr, dr, mb, mbf)
+    our, odp = O.stereo_matches(ol, orr, okl, odl, okr, odr, mb, mbf)
+    assert np.array_equal(bits(ur), bits(our)), "mvuRight"
+    assert np.array_equal(bits(dp), bits(odp)), "mvDepth"
+    n = int((odp > 0).sum())
+    # no right keypoints at all / no left keypoints
+    ur0, dp0 = F.ComputeStereoMatches(exl, exr, kl, dl, kr[:0], dr[:0], mb, mbf)
+    assert (ur0 == -1).all() and (dp0 == -1).all()
+    exl.close(); exr.close()
+    return n

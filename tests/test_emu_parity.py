@@ -71,3 +71,7 @@ def test_search_for_triangulation(emu_lib):
 def test_extractor_large_nodes_take_the_cooperative_split(emu_lib):
     # ~40 k candidates under one quad-tree root: the first iterations go through the workgroup-wide split
     pc.check_extractor(emu_lib, 1500, 1100, 3000, frames=(0,), nlevels=2, seq=14, stages=True)
+
+
+def test_compute_stereo_matches(emu_lib):
+    assert pc.check_stereo_matches(emu_lib, w=640, h=300, nfeatures=1200) > 150

@@ -92,3 +92,9 @@ def test_hamming_match_of_consecutive_frames_is_symmetric_property(gpu_lib):
     first = np.array([np.nonzero((desc == d).all(1))[0][0] for d in desc[:200]])
     assert np.array_equal(bi[:200], first)
     ex.close(); m.close()
+
+
+def test_compute_stereo_matches(gpu_lib):
+    # Frame::ComputeStereoMatches on the resident pyramids of the two extractors
+    assert pc.check_stereo_matches(gpu_lib) > 400                       # KITTI stereo thresholds 20/7
+    assert pc.check_stereo_matches(gpu_lib, w=752, h=480, nfeatures=1200, seq=31, mb=0.11, mbf=47.9) > 100   # EuRoC-like
