@@ -59,25 +59,25 @@ struct KernelTimer {
     if (!enabled) return;
     Rec r;
     r.id = id_of(name);
-    hipEventCreate(&r.a);
-    hipEventCreate(&r.b);
-    hipEventRecord(r.a, s);
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, s);
     recs.push_back(r);
   }
   void end(hipStream_t s) {
     if (!enabled) return;
-    hipEventRecord(recs.back().b, s);
+    (void)hipEventRecord(recs.back().b, s);
   }
   // call after the stream has been synchronised
   void collect() {
     for (Rec& r : recs) {
       float ms = 0;
-      hipEventSynchronize(r.b);
-      hipEventElapsedTime(&ms, r.a, r.b);
+      (void)hipEventSynchronize(r.b);
+      (void)hipEventElapsedTime(&ms, r.a, r.b);
       total_ms[r.id] += ms;
       count[r.id] += 1;
-      hipEventDestroy(r.a);
-      hipEventDestroy(r.b);
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
     }
     recs.clear();
   }

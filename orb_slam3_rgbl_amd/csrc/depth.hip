@@ -434,11 +434,11 @@ int rgbl_depth_create(const rgbl_depth_cfg* cfg, int device, rgbl_depth** out) {
 
 void rgbl_depth_destroy(rgbl_depth* e) {
   if (!e) return;
-  hipSetDevice(e->device);
-  if (e->stream) hipStreamSynchronize(e->stream);
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
   e->timer.collect();
-  for (void* p : e->allocs) hipFree(p);
-  if (e->own_stream) hipStreamDestroy(e->own_stream);
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
 
@@ -534,7 +534,7 @@ int rgbl_depth_profile(rgbl_depth* e, int enable) {
 }
 int rgbl_depth_profile_read(rgbl_depth* e, const char** names, double* total_ms, long* launches, int cap) {
   if (!e) return 0;
-  hipStreamSynchronize(e->stream);
+  (void)hipStreamSynchronize(e->stream);
   e->timer.collect();
   const int n = (int)e->timer.names.size();
   for (int i = 0; i < n && i < cap; ++i) {

@@ -450,16 +450,16 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
 
 void rgbl_extractor_destroy(rgbl_extractor* e) {
   if (!e) return;
-  hipSetDevice(e->device);
-  if (e->stream) hipStreamSynchronize(e->stream);
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
   e->timer.collect();
-  for (void* p : e->allocs) hipFree(p);
-  if (e->d_stereo_sad) hipFree(e->d_stereo_sad);
-  if (e->d_stereo_stage) hipFree(e->d_stereo_stage);
-  if (e->aux_stream) { hipStreamSynchronize(e->aux_stream); hipStreamDestroy(e->aux_stream); }
-  if (e->ev_pyr) hipEventDestroy(e->ev_pyr);
-  if (e->ev_blur) hipEventDestroy(e->ev_blur);
-  if (e->own_stream) hipStreamDestroy(e->own_stream);
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->d_stereo_sad) (void)hipFree(e->d_stereo_sad);
+  if (e->d_stereo_stage) (void)hipFree(e->d_stereo_stage);
+  if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
+  if (e->ev_pyr) (void)hipEventDestroy(e->ev_pyr);
+  if (e->ev_blur) (void)hipEventDestroy(e->ev_blur);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
 
@@ -789,7 +789,7 @@ int rgbl_extractor_profile(rgbl_extractor* e, int enable) {
 
 int rgbl_extractor_profile_read(rgbl_extractor* e, const char** names, double* total_ms, long* launches, int cap) {
   if (!e) return 0;
-  hipStreamSynchronize(e->stream);
+  (void)hipStreamSynchronize(e->stream);
   e->timer.collect();
   const int n = (int)e->timer.names.size();
   for (int i = 0; i < n && i < cap; ++i) {

@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
                                                       int* __restrict__ err) {
   __shared__ uint32_t s_patch_w[4][37 * 10];  // blurred 37x37 neighbourhood, 40-byte rows
   __shared__ uint32_t s_raw_w[4][31 * 8];     // un-blurred 31x31 neighbourhood, 32-byte rows
-  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  const int lane = lane_id(), wave = wave_id();
   const int f = blockIdx.y;
 
   // which (level, index) does this wave own?  slots are laid out level after level with kcap entries each
@@ -1189,7 +1189,6 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
   uint32_t key = 0;
   int x = 0, y = 0;
   uint8_t* patch = reinterpret_cast<uint8_t*>(s_patch_w[wave]);
-  const uint8_t* rawp = reinterpret_cast<const uint8_t*>(s_raw_w[wave]);
   if (valid) {
     key = kp_key[(size_t)f * kp_frame + slot];
     x = key_x(key) + kMinBorder;

@@ -204,11 +204,11 @@ int rgbl_matcher_create(int device, rgbl_matcher** out) {
 
 void rgbl_matcher_destroy(rgbl_matcher* m) {
   if (!m) return;
-  hipSetDevice(m->device);
-  hipStreamSynchronize(m->stream);
+  (void)hipSetDevice(m->device);
+  (void)hipStreamSynchronize(m->stream);
   m->timer.collect();
-  if (m->d_buf) hipFree(m->d_buf);
-  if (m->own_stream) hipStreamDestroy(m->own_stream);
+  if (m->d_buf) (void)hipFree(m->d_buf);
+  if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   delete m;
 }
 
@@ -235,7 +235,7 @@ int rgbl_matcher_profile(rgbl_matcher* m, int enable) {
 }
 int rgbl_matcher_profile_read(rgbl_matcher* m, const char** names, double* total_ms, long* launches, int cap) {
   if (!m) return 0;
-  hipStreamSynchronize(m->stream);
+  (void)hipStreamSynchronize(m->stream);
   m->timer.collect();
   const int n = (int)m->timer.names.size();
   for (int i = 0; i < n && i < cap; ++i) {
