@@ -24,6 +24,7 @@
 #define CV_PI 3.1415926535897932384626433832795
 #define CV_8U 0
 #define CV_8UC1 0
+#define CV_16U 2
 #define CV_32F 5
 
 typedef unsigned char uchar;
@@ -63,6 +64,7 @@ struct KeyPointsFilter {  // only referenced by the dead ComputeKeyPointsOld
   static void retainBest(std::vector<KeyPoint>&, int) { assert(!"KeyPointsFilter::retainBest is not provided"); }
 };
 
+struct MatExpr;  // depth_api.hpp: eagerly evaluated expression result with cv::MatExpr's assignment semantics
 class Mat {
  public:
   int rows, cols;
@@ -71,6 +73,14 @@ class Mat {
   Mat() : rows(0), cols(0), step(0), data(nullptr), type_(0) {}
   Mat(int r, int c, int type) : Mat() { create(r, c, type); }
   Mat(Size s, int type) : Mat() { create(s.height, s.width, type); }
+  Mat(Size s, int type, void* user) : rows(s.height), cols(s.width), step(0), data((uchar*)user), type_(type) { step = (size_t)cols * elemSize(); }
+  inline Mat(const MatExpr& e);
+  inline Mat& operator=(const MatExpr& e);  // writes INTO an existing same-shape Mat (so `m.row(0) = expr` works)
+  inline MatExpr mul(const Mat& m, double scale = 1) const;
+  inline void convertTo(Mat& dst, int rtype) const;
+  static inline Mat ones(int r, int c, int type);
+  static Mat zeros(Size s, int type) { return Mat(s, type); }
+  Size size() const { return Size(cols, rows); }
   void create(int r, int c, int type) {
     if (data && r == rows && c == cols && type == type_) return;
     rows = r; cols = c; type_ = type;
@@ -79,7 +89,7 @@ class Mat {
     data = buf_.get();
   }
   static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
-  size_t elemSize() const { return type_ == CV_32F ? 4 : 1; }
+  size_t elemSize() const { return type_ == CV_32F ? 4 : type_ == CV_16U ? 2 : 1; }
   size_t step1() const { return step / elemSize(); }
   int type() const { return type_; }
   bool empty() const { return data == nullptr || rows * cols == 0; }
@@ -149,3 +159,5 @@ inline void GaussianBlur(const Mat& src_, Mat& dst, Size ksize, double sx, doubl
 }
 
 }  // namespace cv
+
+#include "depth_api.hpp"  // what the reference's src/DepthModule.cc needs on top

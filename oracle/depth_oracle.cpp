@@ -222,12 +222,27 @@ int orc_depth(const orc_depth_params* P, const float* cloud, int n, int ld, int 
   return 0;
 }
 
+void orc_distance_transform_l2_5x5(const uint8_t* src, int w, int h, int stride, float* dst) {
+  std::vector<uint8_t> zero_mask((size_t)w * h);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) zero_mask[(size_t)y * w + x] = src[(size_t)y * stride + x] == 0;
+  std::vector<float> dist;
+  distance_transform_5x5(zero_mask, w, h, dist);
+  std::memcpy(dst, dist.data(), sizeof(float) * dist.size());
+}
+
 void orc_projection_matrix(const float K[12], const float Tr[16], float out[12]) {
+  // DepthModule.cc:434 `CameraMatrix(3x4) * RotationMatrix(4x4)`: cv::gemm's small-matrix special case
+  // (flags == 0, inner length 4 == D.cols; matmul.simd.hpp gemmImpl) keeps FLOAT temporaries,
+  // t = a0*b0 + a1*b1 + a2*b2 + a3*b3 in one expression.  That translation unit is dispatched for AVX2 / AVX-512
+  // and compiled with the compiler's default contraction, so on every FMA-capable x86-64 / aarch64 host the value is
+  // the fma chain below (an SSE-only host would round each product separately; the generic double-accumulating
+  // path is NOT taken for this shape).  Platform-dependent in the reference itself; see DESIGN.md section 4.
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 4; ++c) {
-      double acc = 0.0;
-      for (int k = 0; k < 4; ++k) acc += (double)K[4 * r + k] * (double)Tr[4 * k + c];
-      out[4 * r + c] = (float)acc;
+      float t = K[4 * r + 0] * Tr[c];
+      for (int k = 1; k < 4; ++k) t = fmaf(K[4 * r + k], Tr[4 * k + c], t);
+      out[4 * r + c] = t;
     }
 }
 

@@ -9,9 +9,10 @@
  * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path and cannot be
  * built here (needs OpenCV/Eigen/Pangolin/Boost; none installed, no network).  The oracle is pinned only
  * by (a) hand-derived known-answer tests (tests/test_oracle_kat.py), (b) the live glibc for sinf/cosf
- * and (c) oracle/_ref: the reference's own ORBextractor.cc compiled unmodified against a minimal
- * cv-compat header whose OpenCV primitives are this oracle's restatements (pins everything that is NOT
- * OpenCV-internal: cell loop, quad-tree, orientation, steering, packing).
+ * and (c) oracle/_ref: the reference's own ORBextractor.cc and DepthModule.cc compiled unmodified against a
+ * minimal cv-compat header whose OpenCV primitives are restatements (pins everything that is NOT
+ * OpenCV-internal: cell loop, quad-tree, orientation, steering, packing; settings parsing, projection loop,
+ * up-sampling chains, keypoint depth).  The ORBmatcher paths have known-answer tests only.
  */
 #ifndef RGBL_ORACLE_H
 #define RGBL_ORACLE_H
@@ -98,6 +99,8 @@ int orc_depth(const orc_depth_params*, const float* cloud, int n, int ld, int w,
               float* out_raw, float* out_processed);
 /* K[3x4] * Tr[4x4] in OpenCV gemm arithmetic (DepthModule.cc:434) */
 void orc_projection_matrix(const float K[12], const float Tr[16], float out[12]);
+/* cv::distanceTransform(src u8, dst f32, labels, DIST_L2, DIST_MASK_5): distance to the nearest ZERO pixel of src */
+void orc_distance_transform_l2_5x5(const uint8_t* src, int w, int h, int stride, float* dst);
 /* cv::getStructuringElement for RECT(0)/CROSS(1)/ELLIPSE(2) and the reference's Diamond(3) tables */
 int orc_structuring_element(int shape, int kw, int kh, uint8_t* out);
 

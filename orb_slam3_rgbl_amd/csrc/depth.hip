@@ -336,12 +336,15 @@ int enqueue_keypoints(rgbl_depth* e, int batch, int w, int h, const float* kp, i
 extern "C" {
 
 void rgbl_projection_matrix(const float K[12], const float Tr[16], float out[12]) {
-  // cv::Mat product CameraMatrix(3x4) * RotationMatrix(4x4), DepthModule.cc:434: double accumulation per entry
+  // cv::Mat product CameraMatrix(3x4) * RotationMatrix(4x4), DepthModule.cc:434.  cv::gemm takes its small-matrix
+  // special case for this shape (inner length 4 == output width): float temporaries, one expression
+  // a0*b0 + a1*b1 + a2*b2 + a3*b3, contracted to an fma chain by the dispatched AVX2 / AVX-512 / NEON builds
+  // every FMA-capable host runs.  (The generic double-accumulating GEMM is what the 3x4 * 4xN projection uses.)
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 4; ++c) {
-      double acc = 0.0;
-      for (int k = 0; k < 4; ++k) acc += (double)K[4 * r + k] * (double)Tr[4 * k + c];
-      out[4 * r + c] = (float)acc;
+      float t = K[4 * r + 0] * Tr[c];
+      for (int k = 1; k < 4; ++k) t = fmaf(K[4 * r + k], Tr[4 * k + c], t);
+      out[4 * r + c] = t;
     }
 }
 

@@ -12,6 +12,7 @@ import pytest
 
 from oracle import oracle_py as O
 from orb_slam3_rgbl_amd import synth
+from yaml_cases import PARSE_CASES, yaml_with
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_orbextractor.so")
@@ -67,3 +68,140 @@ def test_reference_source_on_degenerate_images(ref):
     okps, odesc, omono = O.Extractor(800, 1.2, 4, 20, 7)(chk)
     assert len(kps) == len(okps) and np.array_equal(desc, odesc)
     assert np.array_equal(kps["x"], okps["x"]) and np.array_equal(kps["angle"].view(np.uint32), okps["angle"].view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's own src/DepthModule.cc (oracle/_ref/libref_depthmodule.so) versus the restated oracle: YAML
+# parsing and its failure modes, K * Tr, projection loop, the three up-sampling chains, keypoint depth / uRight.
+REF_DEPTH_SO = os.path.join(ROOT, "oracle", "_ref", "libref_depthmodule.so")
+_F = C.c_float
+
+
+@pytest.fixture(scope="module")
+def refdepth(oracle):
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    if not os.path.exists(REF_DEPTH_SO):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    lib = C.CDLL(REF_DEPTH_SO)
+    lib.ref_depth_create.restype = C.c_void_p
+    lib.ref_depth_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
+    lib.ref_depth_destroy.argtypes = [C.c_void_p]
+    lib.ref_depth_compute.restype = C.c_int
+    lib.ref_depth_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return lib
+
+
+class RefDepth:
+    def __init__(self, lib, path):
+        self.lib = lib
+        a, b = C.c_int(-1), C.c_int(-1)
+        self.proj = np.zeros((3, 4), np.float32)
+        self.h = lib.ref_depth_create(path.encode(), 5, C.byref(a), C.byref(b), self.proj.ctypes.data)
+        self.parsed = (bool(a.value), bool(b.value))
+
+    def __call__(self, cloud, w, h, kp_xy, kpun_x):
+        cloud = np.ascontiguousarray(cloud, np.float32)
+        k = len(kpun_x)
+        d, ur = np.zeros(k, np.float32), np.zeros(k, np.float32)
+        raw, proc = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+        rc = self.lib.ref_depth_compute(self.h, cloud.ctypes.data, cloud.shape[1], cloud.strides[0] // 4, w, h,
+                                        kp_xy.ctypes.data, kpun_x.ctypes.data, k, d.ctypes.data, ur.ctypes.data,
+                                        raw.ctypes.data, proc.ctypes.data)
+        return rc, d, ur, raw, proc
+
+    def close(self):
+        self.lib.ref_depth_destroy(self.h)
+
+
+def keypoints_for(w, h, k, seed):
+    rng = np.random.default_rng(seed)
+    xy = np.stack([rng.uniform(0, w - 1, k), rng.uniform(0, h - 1, k)], 1).astype(np.float32)
+    xy[: k // 2] = np.floor(xy[: k // 2])          # level-0 keypoints have integer coordinates
+    xy[0], xy[1], xy[2] = (0, 0), (w - 1, h - 1), (w - 1, 0)
+    un = (xy[:, 0] + rng.uniform(-0.5, 0.5, k)).astype(np.float32)
+    return np.ascontiguousarray(xy), un
+
+
+bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+METHOD_ID = {"NearestNeighborPixel": 1, "AverageFiltering": 2, "InverseDilation": 3}
+SHAPE_ID = {"Rectangle": 0, "Cross": 1, "Ellipse": 2, "Diamond": 3}
+
+
+@pytest.mark.parametrize("method,ktype,ku,kv,extra", [
+    ("InverseDilation", "Diamond", 5, 7, {}),                 # the KITTI default (v is ignored for diamonds)
+    ("InverseDilation", "Diamond", 9, 9, {}),
+    ("InverseDilation", "Rectangle", 3, 5, {}),
+    ("InverseDilation", "Ellipse", 7, 5, {}),
+    ("InverseDilation", "Cross", 5, 3, {}),
+    ("AverageFiltering", "Diamond", 5, 5, {"LiDAR.MethodAverageFiltering.KernelSize": "3.0"}),
+    ("AverageFiltering", "Diamond", 5, 5, {"LiDAR.MethodAverageFiltering.KernelSize": "5.0"}),
+    ("NearestNeighborPixel", "Diamond", 5, 5, {}),
+    ("NearestNeighborPixel", "Diamond", 5, 5, {"LiDAR.MethodNearestNeighborPixel.SearchDistance": "3.0"}),
+])
+def test_reference_depthmodule_agrees_with_oracle(refdepth, tmp_path, method, ktype, ku, kv, extra):
+    w, h = 1241, 376
+    edits = {"LiDAR.Method": '"%s"' % method, "LiDAR.MethodInverseDilation.KernelType": '"%s"' % ktype,
+             "LiDAR.MethodInverseDilation.KernelSize_u": "%d.0" % ku, "LiDAR.MethodInverseDilation.KernelSize_v": "%d.0" % kv}
+    edits.update(extra)
+    R = RefDepth(refdepth, yaml_with(tmp_path, "s.yaml", edits))
+    assert R.parsed == (True, True)
+    oproj = O.projection_matrix(synth.KITTI_K, synth.KITTI_TR)
+    assert np.array_equal(bits(R.proj), bits(oproj)), "K * Tr (DepthModule.cc:434)"
+    P = O.make_depth_params(oproj, 5.0, 200.0, 100.0, METHOD_ID[method], O.structuring_element(SHAPE_ID[ktype], ku, ku if ktype == "Diamond" else kv),
+                            avg_ksize=int(float(extra.get("LiDAR.MethodAverageFiltering.KernelSize", "5.0"))),
+                            nn_radius=float(extra.get("LiDAR.MethodNearestNeighborPixel.SearchDistance", "7.0")))
+    for seed in (0, 1):
+        cloud = synth.lidar_scan(seed)
+        xy, un = keypoints_for(w, h, 1500, seed)
+        rc, d, ur, raw, proc = R(cloud, w, h, xy, un)
+        od, our, oraw, oproc = O.depth(P, cloud, w, h, xy, un)
+        assert np.array_equal(bits(raw), bits(oraw)), "RawDepthMap"
+        assert (oraw > 0).sum() > 5000
+        if method == "NearestNeighborPixel":
+            assert rc in (0, 2)      # this method never writes ProcessedDepthMap
+        else:
+            assert rc == 0
+            assert np.array_equal(bits(proc), bits(oproc)), "ProcessedDepthMap"
+        assert np.array_equal(bits(d), bits(od)) and np.array_equal(bits(ur), bits(our))
+        assert (d > 0).sum() > 100
+    R.close()
+
+
+def test_reference_depthmodule_second_frame_reuses_buffers(refdepth, tmp_path):
+    """`ProcessedDepthMap = S - RawDepthMap` assigns INTO the previous frame's buffer from the second call on."""
+    w, h = 620, 188
+    R = RefDepth(refdepth, yaml_with(tmp_path, "s.yaml"))
+    K = synth.KITTI_K.copy()
+    oproj = O.projection_matrix(synth.KITTI_K, synth.KITTI_TR)
+    P = O.make_depth_params(oproj, 5.0, 200.0, 100.0, 3, O.structuring_element(3, 5, 5))
+    for seed in (3, 4, 5):
+        cloud = synth.lidar_scan(seed, n_rings=32, n_az=700)
+        xy, un = keypoints_for(w, h, 300, seed)
+        rc, d, ur, raw, proc = R(cloud, w, h, xy, un)
+        od, our, oraw, oproc = O.depth(P, cloud, w, h, xy, un)
+        assert rc == 0 and np.array_equal(bits(proc), bits(oproc)) and np.array_equal(bits(d), bits(od))
+    R.close()
+    del K
+
+
+@pytest.mark.parametrize("edits,drop,expect", PARSE_CASES)
+def test_reference_depthmodule_parse_failures_match_the_shim_rules(refdepth, tmp_path, edits, drop, expect):
+    """The reference's own parser, run on broken settings files; orb_slam3_rgbl_amd/shim/DepthModule.cc encodes the
+    same outcomes (tests/test_shim.py exercises that side)."""
+    R = RefDepth(refdepth, yaml_with(tmp_path, "bad.yaml", edits, drop))
+    lidar_ok, ups_ok = R.parsed
+    assert lidar_ok == expect[0]
+    if expect[1] is not None:
+        assert ups_ok == expect[1]
+    if expect[1] is None:
+        # the reference runs ParseUpsamplingParameters on an UNINITIALISED SelectedUpsamlingMethod after a failed
+        # LiDAR parse (DepthModule.cc:38-39); whatever that yields, the module stays disabled
+        pass
+    if not (lidar_ok and ups_ok) or edits.get("LiDAR.Method") == '"None"':
+        xy, un = keypoints_for(64, 48, 10, 0)
+        rc, *_ = R(synth.lidar_scan(0, 4, 50), 64, 48, xy, un)
+        assert rc == -1          # disabled module / method None: no keypoint depth is produced
+    R.close()

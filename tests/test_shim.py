@@ -5,6 +5,7 @@ import os
 import pytest
 
 import shim_driver
+from yaml_cases import PARSE_CASES, yaml_with
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -20,3 +21,20 @@ def test_cpp_shims_on_mi355x(gpu_lib, tmp_path):
     exe = os.path.join(ROOT, "tests", "_build", "shim_test_gpu")
     shim_driver.build(os.path.join(ROOT, "orb_slam3_rgbl_amd"), "rgbl_frontend", exe)
     shim_driver.run_and_check(exe, str(tmp_path))
+
+
+def test_shim_depthmodule_parse_outcomes(emu_lib, tmp_path):
+    """Settings-file failure modes of the drop-in DepthModule == the reference parser's (same table that
+    tests/test_reference_build.py checks against the reference source itself)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "_build", "shim_test_emu")
+    shim_driver.build(os.path.join(ROOT, "tests", "_build"), "rgbl_frontend_emu", exe)
+    for i, (edits, drop, expect) in enumerate(PARSE_CASES):
+        res = subprocess.run([exe, "--parse", yaml_with(tmp_path, "c%d.yaml" % i, edits, drop)], capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stdout + res.stderr
+        flags = int(res.stdout.strip().splitlines()[-1].split()[1])
+        assert bool(flags & 1) == expect[0], (edits, drop, res.stdout)
+        if expect[1] is not None:
+            assert bool(flags & 2) == expect[1], (edits, drop, res.stdout)
+        else:
+            assert not (flags & 1)
