@@ -133,9 +133,8 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
 
 // ------------------------------------------------------------------------------------------------
 // FAST-9/16 on one detection cell per workgroup.
-constexpr int kCellMax = 72;             // max scanned cell side handled (wCell/hCell <= 72)
-constexpr int kTileP = kCellMax + 8;     // LDS tile pitch (cell + 6 ring margin, padded)
-constexpr int kScoreP = kCellMax + 4;     // score tile pitch (cell + 1-px zero frame), multiple of 4
+constexpr int kCellMax = 72;        // max scanned cell side handled (wCell/hCell <= 72: levels at least 35 px wide)
+constexpr int kCellSmall = 48;      // the common case (cells of 35..48 px): 11 KB of LDS instead of 24 KB per workgroup
 
 // Bresenham ring of radius 3, OpenCV order (modules/features2d/src/fast_score.cpp makeOffsets)
 #define RGBL_RING(c, P, k)                                                                            \
@@ -168,30 +167,36 @@ __device__ __forceinline__ int fast_true_score(const uint8_t* c, int P) {
   return imax(dark, -bright) - 1;
 }
 
-// grid = (cells per frame over all levels, B), block = 256.
+// grid = (cells per frame over all levels, B), block = 256.  CM = compile-time bound of the scanned cell side: the
+// LDS tiles are sized by it, and LDS is what limits the workgroups per CU (6 at CM = 72, 8 = the wave limit at CM = 48).
+template <int CM>
 __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict__ geom, int n_levels,
                                                     const uint8_t* __restrict__ img0, int pitch0,
                                                     size_t frame0, const uint8_t* __restrict__ pyr,
                                                     size_t pyr_frame, int ini_th, int min_th,
                                                     uint32_t* __restrict__ cell_cnt, size_t cells_frame,
                                                     uint32_t* __restrict__ slots, size_t slots_frame) {
-  __shared__ uint32_t s_tile_w[(kCellMax + 6) * kTileP / 4];
+  constexpr int kTileP = CM + 8;   // LDS tile pitch (cell + 6 ring margin, padded)
+  constexpr int kScoreP = CM + 4;  // score tile pitch (cell + 1-px zero frame), multiple of 4
+  constexpr int kBitWords = (CM * CM + 31) / 32;
+  static_assert(kBitWords <= 256, "one bitmap word per work-item");
+  __shared__ uint32_t s_tile_w[(CM + 6) * kTileP / 4];
   uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile_w);
-  __shared__ uint32_t s_score_w[(kCellMax + 2) * kScoreP / 4];
+  __shared__ uint32_t s_score_w[(CM + 2) * kScoreP / 4];
   uint8_t* s_score = reinterpret_cast<uint8_t*>(s_score_w);
-  __shared__ uint16_t s_surv[kCellMax * kCellMax];
+  __shared__ uint16_t s_surv[CM * CM];
   __shared__ uint32_t s_scan[8];
   __shared__ int s_nsurv, s_any_ini;
-  __shared__ uint32_t s_keep[(kCellMax * kCellMax + 31) / 32], s_keep_ini[(kCellMax * kCellMax + 31) / 32];
+  __shared__ uint32_t s_keep[kBitWords], s_keep_ini[kBitWords];
 
   const int tid = threadIdx.x;
-  const int f = blockIdx.y;
+  const int bx = blockIdx.x, f = blockIdx.y;
   int l = 0;
-  while (l + 1 < n_levels && (int)blockIdx.x >= geom[l + 1].cell_off) ++l;
+  while (l + 1 < n_levels && bx >= geom[l + 1].cell_off) ++l;
   const LevelGeom& g = geom[l];
-  const int ci = (int)blockIdx.x - g.cell_off;
+  const int ci = bx - g.cell_off;
   const int ci_row = ci / g.n_cols, ci_col = ci - ci_row * g.n_cols;
-  uint32_t* my_cnt = cell_cnt + (size_t)f * cells_frame + blockIdx.x;
+  uint32_t* my_cnt = cell_cnt + (size_t)f * cells_frame + bx;
 
   const int ini_x = kMinBorder + ci_col * g.w_cell, ini_y = kMinBorder + ci_row * g.h_cell;
   const int max_x = imin(ini_x + g.w_cell + 6, g.max_bx), max_y = imin(ini_y + g.h_cell + 6, g.max_by);
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   }
   for (int i = tid; i < (sh + 2) * (kScoreP / 4); i += 256) s_score_w[i] = 0;
   if (tid == 0) { s_nsurv = 0; s_any_ini = 0; }
-  if (tid < (kCellMax * kCellMax + 31) / 32) { s_keep[tid] = 0; s_keep_ini[tid] = 0; }
+  if (tid < kBitWords) { s_keep[tid] = 0; s_keep_ini[tid] = 0; }
   __syncthreads();
 
   // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are compacted
@@ -302,11 +307,11 @@ __global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ ge
                                                 const uint8_t* __restrict__ pyr, size_t pyr_frame,
                                                 uint8_t* __restrict__ blur, size_t blur_frame) {
   __shared__ uint32_t s_h[(kBlurTH + 6) * (kBlurTW / 2)];  // two 16-bit horizontal sums per word
-  const int tid = threadIdx.x, f = blockIdx.y;
+  const int tid = threadIdx.x, bx = blockIdx.x, f = blockIdx.y;
   int l = 0;
-  while (l + 1 < n_levels && (int)blockIdx.x >= bt.tile_off[l + 1]) ++l;
+  while (l + 1 < n_levels && bx >= bt.tile_off[l + 1]) ++l;
   const LevelGeom& g = geom[l];
-  const int t = (int)blockIdx.x - bt.tile_off[l];
+  const int t = bx - bt.tile_off[l];
   const int ty = t / bt.tiles_x[l], tx = t - ty * bt.tiles_x[l];
   const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
   const uint8_t* img = (l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
@@ -627,7 +632,10 @@ __device__ __forceinline__ void block_split(const QNode& nd, uint32_t* keys_a, u
   }
 }
 
-constexpr int kOctBS = 512;         // work-items per quad-tree workgroup (16 waves hide the dependent-load latency)
+// work-items per quad-tree workgroup: a (level, frame) problem is one dependent chain, so a wider group shortens the
+// chain (fewer strides per pass) while a narrower one lets more problems share a CU (VGPRs allow 4 waves per SIMD):
+// kOctWide when the batch cannot fill the chip anyway, kOctNarrow when there are plenty of (level, frame) problems.
+constexpr int kOctWide = 512, kOctNarrow = 256;
 constexpr int kSortLds = 2048;     // largest expandable-node list sorted in LDS by the whole workgroup
 constexpr int kSortRanges = 160;   // > kSortLds / 17: pending ranges of more than 16 elements are disjoint
 
@@ -691,6 +699,7 @@ __device__ __forceinline__ void pk_heap_sort(uint64_t* w, int first, int last) {
 // of a serial scan; the four waves of the workgroup take different ranges of the same recursion depth.
 // seg_first / seg_last double as the L / R lists of the range being partitioned (a leaf is only labelled once
 // its range is final).
+template <int BS>
 __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t* seg_first, uint16_t* seg_last,
                                                     SortRanges* ra, SortRanges* rb, int* s_cnt) {
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
@@ -706,7 +715,7 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t
     }
   }
   if (m <= 16)
-    for (int i = tid; i < m; i += kOctBS) { seg_first[i] = 0; seg_last[i] = (uint16_t)m; }
+    for (int i = tid; i < m; i += BS) { seg_first[i] = 0; seg_last[i] = (uint16_t)m; }
   __syncthreads();
   SortRanges* cur = ra;
   SortRanges* nxt = rb;
@@ -797,11 +806,11 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t
     __syncthreads();
   }
   // stable sort of every leaf (== __final_insertion_sort)
-  uint64_t mine[kSortLds / kOctBS];
-  int dest[kSortLds / kOctBS];
+  uint64_t mine[kSortLds / BS];
+  int dest[kSortLds / BS];
 #pragma unroll
-  for (int k = 0; k < kSortLds / kOctBS; ++k) {
-    const int i = tid + kOctBS * k;
+  for (int k = 0; k < kSortLds / BS; ++k) {
+    const int i = tid + BS * k;
     dest[k] = -1;
     if (i < m) {
       const int f0 = seg_first[i], l0 = seg_last[i];
@@ -817,7 +826,7 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kSortLds / kOctBS; ++k)
+  for (int k = 0; k < kSortLds / BS; ++k)
     if (dest[k] >= 0) w[dest[k]] = mine[k];
   __syncthreads();
 }
@@ -828,7 +837,7 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t
 // `proc(rho)` gives the old list position of the rho-th processed node (rho < P); div[rho] its child counts
 // (all zero = node was not split).  Children with more than one key are appended to todo_out in creation
 // order.  Returns (through LDS) the new size and the number of expandable children.
-template <bool kIdentity>
+template <bool kIdentity, int BS>
 __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n, const QDiv* div, int P,
                                              const uint32_t* sval, int m, uint8_t* divided, uint32_t* todo_out,
                                              unsigned long long* s_scan, int* s_newn, int* s_nexp) {
@@ -837,7 +846,7 @@ __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n
   unsigned long long carry = 0;
   // two sweeps: first totals, then placement (placement needs T)
   unsigned long long T2 = 0;
-  for (int r0 = 0; r0 < P; r0 += kOctBS) {
+  for (int r0 = 0; r0 < P; r0 += BS) {
     const int rho = r0 + tid;
     unsigned long long v = 0;
     if (rho < P) {
@@ -849,7 +858,7 @@ __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n
     T2 += tot;
   }
   const uint32_t T = (uint32_t)(T2 & 0xffffffffu);
-  for (int r0 = 0; r0 < P; r0 += kOctBS) {
+  for (int r0 = 0; r0 < P; r0 += BS) {
     const int rho = r0 + tid;
     unsigned long long v = 0;
     QDiv d; d.c[0] = d.c[1] = d.c[2] = d.c[3] = 0;
@@ -880,7 +889,7 @@ __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n
   __syncthreads();
   // pass 2: surviving nodes keep their relative order behind the children
   uint32_t kcarry = 0;
-  for (int p0 = 0; p0 < n; p0 += kOctBS) {
+  for (int p0 = 0; p0 < n; p0 += BS) {
     const int pos = p0 + tid;
     const uint32_t keep = (pos < n && !divided[pos]) ? 1u : 0u;
     uint32_t tot;
@@ -893,7 +902,8 @@ __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kOctBS, 4) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b) {
+template <int BS>
+__global__ __launch_bounds__(BS, 4) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b) {
   __shared__ unsigned long long s_scan[32];
   __shared__ unsigned long long s_skey_pad[kSortLds + 8];  // 4 entries of read slack on both sides
   __shared__ uint32_t s_sval[kSortLds];
@@ -904,7 +914,7 @@ __global__ __launch_bounds__(kOctBS, 4) void k_octree(const LevelGeom* __restric
   __shared__ int s_newn, s_nexp, s_n, s_P, s_nbig;
   constexpr int kMaxBig = 64;
   __shared__ int s_big[kMaxBig];
-  __shared__ uint32_t s_wcnt[kOctBS / 64][4];
+  __shared__ uint32_t s_wcnt[BS / 64][4];
   __shared__ uint32_t s_rootcnt[kMaxRoots];
 #define RGBL_STAMP(k) do { if (b.dbg && threadIdx.x == 0) b.dbg[((size_t)blockIdx.y * n_levels + blockIdx.x) * 16 + (k)] = rgbl_clock(); } while (0)
   RGBL_STAMP(0);
@@ -929,7 +939,7 @@ __global__ __launch_bounds__(kOctBS, 4) void k_octree(const LevelGeom* __restric
   {
     const uint32_t* ccnt = b.cell_cnt + (size_t)f * b.cells_frame + g.cell_off;
     const uint32_t* slots = b.slots + (size_t)f * b.slots_frame + g.slot_off;
-    for (int c0 = 0; c0 < g.n_cells; c0 += kOctBS) {
+    for (int c0 = 0; c0 < g.n_cells; c0 += BS) {
       const int c = c0 + tid;
       const uint32_t cnt = c < g.n_cells ? ccnt[c] : 0u;
       uint32_t tot;
@@ -947,7 +957,7 @@ __global__ __launch_bounds__(kOctBS, 4) void k_octree(const LevelGeom* __restric
     uint32_t outpos = 0;
     for (int r = 0; r < g.n_ini; ++r) {
       const uint32_t beg = outpos;
-      for (uint32_t base = 0; base < C; base += kOctBS * 8) {
+      for (uint32_t base = 0; base < C; base += BS * 8) {
         const uint32_t i0 = base + (uint32_t)tid * 8;
         uint32_t mask = 0;
         for (int k = 0; k < 8; ++k)
@@ -990,7 +1000,7 @@ __global__ __launch_bounds__(kOctBS, 4) void k_octree(const LevelGeom* __restric
     // very large nodes: one after the other, whole workgroup each
     if (tid == 0) s_nbig = 0;
     __syncthreads();
-    for (int pos = tid; pos < n; pos += kOctBS)
+    for (int pos = tid; pos < n; pos += BS)
       if ((cur[pos].cnt & 0x7fffffffu) >= (uint32_t)kCoopMin) {
         const int k = atomicAdd(&s_nbig, 1);
         if (k < kMaxBig) s_big[k] = pos;
@@ -1001,7 +1011,7 @@ __global__ __launch_bounds__(kOctBS, 4) void k_octree(const LevelGeom* __restric
       const int pos = s_big[k];
       const QNode nd = cur[pos];
       QDiv d;
-      block_split<kOctBS>(nd, keys_a, keys_b, d.c, s_scan, s_wcnt);
+      block_split<BS>(nd, keys_a, keys_b, d.c, s_scan, s_wcnt);
       if (tid == 0) { div[pos] = d; divided[pos] = 0; }
     }
     // everything else: one wave per node
@@ -1017,7 +1027,7 @@ __global__ __launch_bounds__(kOctBS, 4) void k_octree(const LevelGeom* __restric
       if (lane == 0) { div[pos] = d; divided[pos] = 0; }
     }
     __syncthreads();
-    rebuild_list<true>(cur, nxt, n, div, n, nullptr, 0, divided, todo_n, s_scan, &s_newn, &s_nexp);
+    rebuild_list<true, BS>(cur, nxt, n, div, n, nullptr, 0, divided, todo_n, s_scan, &s_newn, &s_nexp);
     const int newn = s_newn, nexp = s_nexp;
     { QNode* t = cur; cur = nxt; nxt = t; }
     { uint32_t* t = todo; todo = todo_n; todo_n = t; }
@@ -1035,23 +1045,23 @@ __global__ __launch_bounds__(kOctBS, 4) void k_octree(const LevelGeom* __restric
     const int prev = n;
     // compareNodes orders by (size, UL.x); equal keys end up in libstdc++'s introsort order
     uint32_t* sval = (m <= kSortLds) ? s_sval : b.sval + nbase;
-    for (int p = tid; p < n; p += kOctBS) divided[p] = 0;
+    for (int p = tid; p < n; p += BS) divided[p] = 0;
     if (m <= kSortLds) {
       uint64_t* w = reinterpret_cast<uint64_t*>(s_skey);
-      for (int j = tid; j < m; j += kOctBS) {
+      for (int j = tid; j < m; j += BS) {
         const uint32_t pos = todo[j];
         const QNode nd = cur[pos];
         w[j] = ((uint64_t)(nd.cnt & 0x7fffffffu) << 28) | ((uint64_t)nd.x0 << 16) | pos;  // x0 < 4096, pos < 65536
       }
       __syncthreads();
       RGBL_STAMP(8);
-      block_sort_restated(w, m, s_seg_first, s_seg_last, &s_ra, &s_rb, s_sort_cnt);
+      block_sort_restated<BS>(w, m, s_seg_first, s_seg_last, &s_ra, &s_rb, s_sort_cnt);
       RGBL_STAMP(9);
-      for (int j = tid; j < m; j += kOctBS) sval[j] = (uint32_t)(w[j] & 0xffffu);
+      for (int j = tid; j < m; j += BS) sval[j] = (uint32_t)(w[j] & 0xffffu);
       __syncthreads();
     } else {
       uint64_t* skey = b.skey + nbase;
-      for (int j = tid; j < m; j += kOctBS) {
+      for (int j = tid; j < m; j += BS) {
         const uint32_t pos = todo[j];
         const QNode nd = cur[pos];
         skey[j] = ((uint64_t)(nd.cnt & 0x7fffffffu) << 32) | nd.x0;
@@ -1073,7 +1083,7 @@ __global__ __launch_bounds__(kOctBS, 4) void k_octree(const LevelGeom* __restric
     // first rank after which the list has reached the quota (the reference breaks out of its loop there)
     {
       long long carry = 0;
-      for (int r0 = 0; r0 < m; r0 += kOctBS) {
+      for (int r0 = 0; r0 < m; r0 += BS) {
         const int rho = r0 + tid;
         long long v = 0;
         if (rho < m) {
@@ -1096,7 +1106,7 @@ __global__ __launch_bounds__(kOctBS, 4) void k_octree(const LevelGeom* __restric
       node_place(nd, keys_a, keys_b, d.c);
     }
     __syncthreads();
-    rebuild_list<false>(cur, nxt, n, div, P, sval, m, divided, todo_n, s_scan, &s_newn, &s_nexp);
+    rebuild_list<false, BS>(cur, nxt, n, div, P, sval, m, divided, todo_n, s_scan, &s_newn, &s_nexp);
     { QNode* t = cur; cur = nxt; nxt = t; }
     { uint32_t* t = todo; todo = todo_n; todo_n = t; }
     n = s_newn;
@@ -1109,7 +1119,7 @@ __global__ __launch_bounds__(kOctBS, 4) void k_octree(const LevelGeom* __restric
   // ---- 4. keep the strongest key of every node, first one on ties (ORBextractor.cc:757-776)
   uint32_t* out = b.kp_key + (size_t)f * b.kp_frame + g.koff;
   if (n > g.kcap) { if (tid == 0) atomicOr(b.err, 2); n = g.kcap; }
-  for (int pos = tid; pos < n; pos += kOctBS) {
+  for (int pos = tid; pos < n; pos += BS) {
     const QNode nd = cur[pos];
     const uint32_t cnt = nd.cnt & 0x7fffffffu;
     const uint32_t* src = ((nd.cnt >> 31) ? keys_b : keys_a) + nd.beg;
@@ -1165,10 +1175,10 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
   __shared__ uint32_t s_patch_w[4][37 * 10];  // blurred 37x37 neighbourhood, 40-byte rows
   __shared__ uint32_t s_raw_w[4][31 * 8];     // un-blurred 31x31 neighbourhood, 32-byte rows
   const int lane = lane_id(), wave = wave_id();
-  const int f = blockIdx.y;
+  const int bx = blockIdx.x, f = blockIdx.y;
 
   // which (level, index) does this wave own?  slots are laid out level after level with kcap entries each
-  const int slot = blockIdx.x * 4 + wave;
+  const int slot = bx * 4 + wave;
   int l = 0;
   while (l + 1 < n_levels && slot >= geom[l + 1].koff) ++l;
   const LevelGeom& g = geom[l];
@@ -1185,6 +1195,12 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
     if (total > cap) atomicOr(err, 4);
   }
   if (valid && dense >= cap) valid = false;
+
+  // the lane's four pattern pairs (x0, y0, x1, y1 as signed bytes): requested first so that their latency hides
+  // behind the patch loads instead of following the orientation
+  uint32_t pw[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pw[k] = reinterpret_cast<const uint32_t*>(pattern)[k * 64 + lane];
 
   uint32_t key = 0;
   int x = 0, y = 0;
@@ -1245,10 +1261,8 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
     const uint8_t* center = patch + 18 * 40 + 18;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      // pattern pair (x0, y0, x1, y1) of this lane: one coalesced 4-byte read per lane, signed bytes
-      const uint32_t pw = reinterpret_cast<const uint32_t*>(pattern)[k * 64 + lane];
-      const float x0 = (float)(int8_t)(pw & 0xff), y0 = (float)(int8_t)((pw >> 8) & 0xff),
-                  x1 = (float)(int8_t)((pw >> 16) & 0xff), y1 = (float)(int8_t)(pw >> 24);
+      const float x0 = (float)(int8_t)(pw[k] & 0xff), y0 = (float)(int8_t)((pw[k] >> 8) & 0xff),
+                  x1 = (float)(int8_t)((pw[k] >> 16) & 0xff), y1 = (float)(int8_t)(pw[k] >> 24);
       const int t0 = center[cv_round_f(x0 * b + y0 * a) * 40 + cv_round_f(x0 * a - y0 * b)];
       const int t1 = center[cv_round_f(x1 * b + y1 * a) * 40 + cv_round_f(x1 * a - y1 * b)];
       bits[k] = __ballot(valid && t0 < t1);
@@ -1308,16 +1322,16 @@ __global__ __launch_bounds__(256) void k_lapping_permute(const rgbl_keypoint* __
 }
 
 // test hook: the workgroup sort on plain arrays (n <= kSortLds, key < 2^48, val < 2^16)
-__global__ __launch_bounds__(kOctBS) void k_test_block_sort(uint64_t* key, uint32_t* val, int n) {
+__global__ __launch_bounds__(kOctWide) void k_test_block_sort(uint64_t* key, uint32_t* val, int n) {
   __shared__ unsigned long long s_skey_pad[kSortLds + 8];
   __shared__ uint16_t s_seg_first[kSortLds], s_seg_last[kSortLds];
   __shared__ SortRanges s_ra, s_rb;
   __shared__ int s_sort_cnt[2];
   uint64_t* w = reinterpret_cast<uint64_t*>(s_skey_pad + 4);
-  for (int i = threadIdx.x; i < n; i += kOctBS) w[i] = (key[i] << 16) | (val[i] & 0xffffu);
+  for (int i = threadIdx.x; i < n; i += kOctWide) w[i] = (key[i] << 16) | (val[i] & 0xffffu);
   __syncthreads();
-  block_sort_restated(w, n, s_seg_first, s_seg_last, &s_ra, &s_rb, s_sort_cnt);
-  for (int i = threadIdx.x; i < n; i += kOctBS) { key[i] = w[i] >> 16; val[i] = (uint32_t)(w[i] & 0xffffu); }
+  block_sort_restated<kOctWide>(w, n, s_seg_first, s_seg_last, &s_ra, &s_rb, s_sort_cnt);
+  for (int i = threadIdx.x; i < n; i += kOctWide) { key[i] = w[i] >> 16; val[i] = (uint32_t)(w[i] & 0xffffu); }
 }
 
 // ------------------------------------------------------------------------------------------------

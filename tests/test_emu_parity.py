@@ -75,3 +75,14 @@ def test_extractor_large_nodes_take_the_cooperative_split(emu_lib):
 
 def test_compute_stereo_matches(emu_lib):
     assert pc.check_stereo_matches(emu_lib, w=640, h=300, nfeatures=1200) > 150
+
+
+@pytest.mark.parametrize("wg", ["256", "512"])
+def test_extractor_both_quadtree_workgroup_widths(emu_lib, wg):
+    # the launch picks the 256-wide group for big batches and the 512-wide one otherwise; RGBL_OCTREE_WG pins it
+    os.environ["RGBL_OCTREE_WG"] = wg
+    try:
+        pc.check_extractor(emu_lib, 520, 360, 1000, frames=(0,), seq=7, stages=True)
+        pc.check_extractor(emu_lib, 1500, 1100, 3000, frames=(0,), nlevels=1, seq=14)   # cooperative split + LDS sort sizes
+    finally:
+        os.environ.pop("RGBL_OCTREE_WG", None)

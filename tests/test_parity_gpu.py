@@ -37,6 +37,12 @@ def test_extractor_batch_equals_single(gpu_lib):
     pc.check_extractor_batch(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000, batch=8)
 
 
+def test_extractor_large_batch_every_frame(gpu_lib):
+    # 160 frames x 8 levels: the quad-tree launch switches to its 256-wide workgroups (>= 1024 problems);
+    # every frame is compared with the oracle
+    pc.check_extractor_batch(gpu_lib, 480, 320, 700, batch=160, seq=9)
+
+
 def test_extractor_other_shapes(gpu_lib):
     pc.check_extractor(gpu_lib, 752, 480, 1200, frames=(0,), seq=6, stages=True)      # EuRoC
     pc.check_extractor(gpu_lib, 640, 480, 1000, frames=(0,), seq=7, nlevels=5)
