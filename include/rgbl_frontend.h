@@ -99,6 +99,21 @@ int rgbl_extract_batch_device(rgbl_extractor* h, const uint8_t* d_imgs, int batc
 /* Waits for the handle's stream and reports deferred device-side errors (overflow flags). */
 int rgbl_extractor_sync(rgbl_extractor* h);
 
+/* Ingest in front of the extractor: the cv::cvtColor of Tracking::GrabImageRGBL
+ * (src/Tracking.cc:1567-1580; also GrabImageStereo / GrabImageMonocular :1469-1556).  8-bit, 3 or 4 interleaved channels
+ * -> gray with OpenCV 4.x' fixed-point weights (R 9798, G 19235, B 3735, 15 bits, + 2^14 before the shift).
+ * blue_first = 1 is COLOR_BGR2GRAY / COLOR_BGRA2GRAY (settings `Camera.RGB: 0`), 0 is COLOR_RGB2GRAY / COLOR_RGBA2GRAY.
+ * Device variant: enqueued on the extractor's stream, so a following rgbl_extract_batch_device() on d_gray is ordered
+ * behind it; frame b at d_src + b*src_frame_stride / d_gray + b*gray_frame_stride (bytes). */
+int rgbl_cvt_gray_batch_device(rgbl_extractor* h, const uint8_t* d_src, int batch, int channels, int blue_first, int w,
+                               int h_, int src_stride, size_t src_frame_stride, uint8_t* d_gray, int gray_stride,
+                               size_t gray_frame_stride);
+/* cvtColor + operator() in one call on a host colour image (channels 1 = already gray: plain rgbl_extract).
+ * out_gray (nullable, gray_stride bytes per row) receives mImGray, which Tracking keeps for the viewer. */
+int rgbl_extract_color(rgbl_extractor* h, const uint8_t* img, int channels, int blue_first, int w, int h_, int stride,
+                       int lap0, int lap1, rgbl_keypoint* out_kp, uint8_t* out_desc, int cap, int* out_n, int* out_mono,
+                       uint8_t* out_gray, int gray_stride);
+
 /* std::vector<cv::Mat> mvImagePyramid (ORBextractor.h:83; read by Frame::ComputeStereoMatches,
  * Frame.cc:908,998-1013).  Copies level `level` of frame `frame` of the LAST call to host memory.
  * with_border=1 adds the 19-px BORDER_REFLECT_101 frame the reference keeps around every level
@@ -201,6 +216,13 @@ int rgbl_depth_compute(rgbl_depth* h, const float* cloud, int n, int ld, int w, 
                        const float* kp_xy, const float* kpun_x, int k, float* out_depth,
                        float* out_uright, float* out_raw, float* out_processed);
 
+/* The same on a scan as it lies in a KITTI velodyne .bin file: n records (x, y, z, reflectance).  Replaces
+ * LoadPointcloudBinaryMat's repack to 4 x n (Examples/RGB-L/rgbl_kitti.cc:151-185: reflectance dropped, homogeneous
+ * coordinate 1) plus CalculateDepthFromPcd; SURVEY.md 8(f) row f3. */
+int rgbl_depth_compute_xyzi(rgbl_depth* h, const float* xyzi, int n, int w, int h_, const float* kp_xy,
+                            const float* kpun_x, int k, float* out_depth, float* out_uright, float* out_raw,
+                            float* out_processed);
+
 /* Device-resident batch.  d_cloud: batch scans, scan b at d_cloud + b*cloud_stride floats, each 4 x n
  * with leading dimension ld.  Keypoints come straight from rgbl_extract_batch_device(): d_kp (frame b
  * at d_kp + b*kp_cap) and d_n (int32[batch]).  d_kpun_x may be NULL (undistorted == distorted, the
@@ -214,6 +236,10 @@ int rgbl_depth_batch_device(rgbl_depth* h, const float* d_cloud, int batch, int 
  * keypoints, so it can run on the depth handle's stream while the extractor is still busy on its own. */
 int rgbl_depth_project_batch_device(rgbl_depth* h, const float* d_cloud, int batch, int n, int ld,
                                     size_t cloud_stride, int w, int h_, float* d_processed);
+/* projection half for scans in the .bin layout: scan b = n float4 records at d_xyzi + b*scan_stride floats
+ * (16-byte aligned, scan_stride a multiple of 4) */
+int rgbl_depth_project_xyzi_batch_device(rgbl_depth* h, const float* d_xyzi, int batch, int n, size_t scan_stride, int w,
+                                         int h_, float* d_processed);
 int rgbl_depth_gather_batch_device(rgbl_depth* h, int batch, int w, int h_, const rgbl_keypoint* d_kp,
                                    const int32_t* d_n, int kp_cap, const float* d_kpun_x, float* d_depth,
                                    float* d_uright);

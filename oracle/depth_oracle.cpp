@@ -277,3 +277,14 @@ int orc_structuring_element(int shape, int kw, int kh, uint8_t* out) {
 }
 
 }  // extern "C"
+
+// LoadPointcloudBinaryMat (/root/reference/Examples/RGB-L/rgbl_kitti.cc:151-185): n records (x, y, z, reflectance) of a
+// KITTI velodyne .bin file -> the 4 x n CV_32F matrix with rows x, y, z, 1 that CalculateDepthFromPcd receives.
+extern "C" void orc_kitti_bin_to_cloud(const float* xyzi, int n, float* cloud4xn) {
+  for (int i = 0; i < n; ++i) {
+    cloud4xn[i] = xyzi[4 * (size_t)i];
+    cloud4xn[(size_t)n + i] = xyzi[4 * (size_t)i + 1];
+    cloud4xn[2 * (size_t)n + i] = xyzi[4 * (size_t)i + 2];
+    cloud4xn[3 * (size_t)n + i] = 1.0f;
+  }
+}

@@ -79,6 +79,12 @@ void orc_brief(const uint8_t* blurred, int stride, int x, int y, float angle_deg
 int orc_distribute_octree(const orc_keypoint* cand, int n, int min_x, int max_x, int min_y, int max_y,
                           int n_features, orc_keypoint* out, int cap);
 
+/* ---- ingest either side of the path ---- */
+/* cv::cvtColor 8-bit {RGB,BGR,RGBA,BGRA} -> gray, OpenCV 4.x 15-bit weights (Tracking.cc:1567-1580) */
+void orc_cvt_gray(const uint8_t* src, int channels, int blue_first, int w, int h, int sstride, uint8_t* dst, int dstride);
+/* LoadPointcloudBinaryMat (Examples/RGB-L/rgbl_kitti.cc:151-185): n x (x,y,z,r) -> 4 x n rows x,y,z,1 */
+void orc_kitti_bin_to_cloud(const float* xyzi, int n, float* cloud4xn);
+
 /* ---- DepthModule (/root/reference/src/DepthModule.cc:50-274) ---- */
 enum { ORC_UPS_NONE = 0, ORC_UPS_NEAREST = 1, ORC_UPS_AVERAGE = 2, ORC_UPS_INVDIL = 3 };
 typedef struct {

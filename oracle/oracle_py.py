@@ -72,6 +72,10 @@ def lib():
         L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                            C.c_int, C.c_int]
         L.orc_gaussian_blur7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_cvt_gray.restype = None
+        L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_kitti_bin_to_cloud.restype = None
+        L.orc_kitti_bin_to_cloud.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_fast.restype = C.c_int
         L.orc_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_fast_corner_score.restype = C.c_int
@@ -244,6 +248,22 @@ def distribute_octree(cand, min_x, max_x, min_y, max_y, n_features):
     n = lib().orc_distribute_octree(_p(cand), len(cand), min_x, max_x, min_y, max_y, n_features,
                                     _p(out), len(out))
     return out[:n]
+
+
+def cvt_gray(img, mbRGB):
+    """cv::cvtColor(COLOR_RGB(A)2GRAY if mbRGB else COLOR_BGR(A)2GRAY) on an H x W x {3,4} u8 image."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, ch = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_cvt_gray(_p(img), ch, 0 if mbRGB else 1, w, h, img.strides[0], _p(out), out.strides[0])
+    return out
+
+
+def kitti_bin_to_cloud(xyzi):
+    pts = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+    out = np.zeros((4, pts.shape[0]), np.float32)
+    lib().orc_kitti_bin_to_cloud(_p(pts), pts.shape[0], _p(out))
+    return out
 
 
 def structuring_element(shape, kw, kh):

@@ -708,3 +708,19 @@ extern "C" void orc_stereo_matches(const orc_extractor* L, const orc_extractor* 
     depth[dist_idx[i].second] = -1;
   }
 }
+
+// ---- ingest --------------------------------------------------------------------------------
+// cv::cvtColor(src, dst, COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) for CV_8U, the call of Tracking::GrabImageRGBL
+// (/root/reference/src/Tracking.cc:1567-1580).  OpenCV 4.x (color_rgb.simd.hpp, RGB2Gray<uchar>): 15-bit weights
+// RY15 = 9798, GY15 = 19235, BY15 = 3735, dst = CV_DESCALE(b*BY + g*GY + r*RY, 15) = (sum + (1 << 14)) >> 15.
+// (OpenCV 3.x used 14-bit weights 4899 / 9617 / 1868; the reference requires >= 4.4.)  PARITY UNPINNED: restated.
+extern "C" void orc_cvt_gray(const uint8_t* src, int channels, int blue_first, int w, int h, int sstride, uint8_t* dst,
+                             int dstride) {
+  const int RY = 9798, GY = 19235, BY = 3735;
+  const int w0 = blue_first ? BY : RY, w2 = blue_first ? RY : BY;
+  for (int y = 0; y < h; ++y) {
+    const uint8_t* s = src + (size_t)y * sstride;
+    uint8_t* d = dst + (size_t)y * dstride;
+    for (int x = 0; x < w; ++x, s += channels) d[x] = (uint8_t)((s[0] * w0 + s[1] * GY + s[2] * w2 + (1 << 14)) >> 15);
+  }
+}

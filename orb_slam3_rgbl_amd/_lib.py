@@ -69,6 +69,8 @@ SYMBOLS = {
     "rgbl_extractor_level_size": (_I, [_V, _I, C.POINTER(_I), C.POINTER(_I)]),
     "rgbl_extractor_get_level": (_I, [_V, _I, _I, _I, _I, _V, _I]),
     "rgbl_extractor_get_candidates": (_I, [_V, _I, _I, _V, _I, C.POINTER(_I)]),
+    "rgbl_cvt_gray_batch_device": (_I, [_V, _V, _I, _I, _I, _I, _I, _I, _Z, _V, _I, _Z]),
+    "rgbl_extract_color": (_I, [_V, _V, _I, _I, _I, _I, _I, _I, _I, _V, _V, _I, C.POINTER(_I), C.POINTER(_I), _V, _I]),
     "rgbl_stereo_matches": (_I, [_V, _V, _V, _V, _I, _V, _V, _I, _F, _F, _V, _V]),
     "rgbl_stereo_matches_batch_device": (_I, [_V, _V, _I, _V, _V, _V, _V, _V, _V, _I, _F, _F, _V, _V]),
     "rgbl_extractor_debug_stamps": (_I, [_V, _V, _I]),
@@ -79,6 +81,8 @@ SYMBOLS = {
     "rgbl_depth_destroy": (None, [_V]),
     "rgbl_projection_matrix": (None, [_V, _V, _V]),
     "rgbl_structuring_element": (_I, [_I, _I, _I, _V]),
+    "rgbl_depth_compute_xyzi": (_I, [_V, _V, _I, _I, _I, _V, _V, _I, _V, _V, _V, _V]),
+    "rgbl_depth_project_xyzi_batch_device": (_I, [_V, _V, _I, _I, _Z, _I, _I, _V]),
     "rgbl_depth_compute": (_I, [_V, _V, _I, _I, _I, _I, _V, _V, _I, _V, _V, _V, _V]),
     "rgbl_depth_batch_device": (_I, [_V, _V, _I, _I, _I, _Z, _I, _I, _V, _V, _I, _V, _V, _V, _V]),
     "rgbl_depth_project_batch_device": (_I, [_V, _V, _I, _I, _I, _Z, _I, _I, _V]),

@@ -27,10 +27,19 @@ struct ProjParams { float m[12]; float min_dist, max_dist; };
 struct DilateMask { int kw, kh; uint8_t m[81]; };
 
 // DepthModule.cc:115-119 for one point. Returns the pixel index or -1.
+// kXyzi: the scan is still in the KITTI velodyne .bin layout (x, y, z, reflectance per point, one 16-byte load);
+// the reference's loader drops the reflectance and sets the homogeneous coordinate to 1 (rgbl_kitti.cc:151-185).
+template <bool kXyzi>
 __device__ __forceinline__ int project_point(const ProjParams& P, const float* __restrict__ cloud, int ld, int i, int w,
                                              int h, float* depth) {
-  const double x = (double)cloud[i], y = (double)cloud[(size_t)ld + i], z = (double)cloud[2 * (size_t)ld + i],
-               o = (double)cloud[3 * (size_t)ld + i];
+  double x, y, z, o;
+  if (kXyzi) {
+    const float4 q = reinterpret_cast<const float4*>(cloud)[i];
+    x = (double)q.x; y = (double)q.y; z = (double)q.z; o = 1.0;
+  } else {
+    x = (double)cloud[i]; y = (double)cloud[(size_t)ld + i]; z = (double)cloud[2 * (size_t)ld + i];
+    o = (double)cloud[3 * (size_t)ld + i];
+  }
   float p[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
@@ -49,6 +58,7 @@ __device__ __forceinline__ int project_point(const ProjParams& P, const float* _
   return -1;
 }
 
+template <bool kXyzi>
 __global__ __launch_bounds__(256) void k_project_index(ProjParams P, const float* __restrict__ cloud, size_t cloud_stride,
                                                        int n, int ld, int w, int h, uint32_t* __restrict__ idx_map,
                                                        size_t map_stride) {
@@ -56,10 +66,11 @@ __global__ __launch_bounds__(256) void k_project_index(ProjParams P, const float
   if (i >= n) return;
   const int f = blockIdx.y;
   float d;
-  const int pix = project_point(P, cloud + (size_t)f * cloud_stride, ld, i, w, h, &d);
+  const int pix = project_point<kXyzi>(P, cloud + (size_t)f * cloud_stride, ld, i, w, h, &d);
   if (pix >= 0) atomicMax(idx_map + (size_t)f * map_stride + pix, (uint32_t)(i + 1));
 }
 
+template <bool kXyzi>
 __global__ __launch_bounds__(256) void k_project_write(ProjParams P, const float* __restrict__ cloud, size_t cloud_stride,
                                                        int n, int ld, int w, int h, const uint32_t* __restrict__ idx_map,
                                                        float* __restrict__ raw, size_t map_stride) {
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(256) void k_project_write(ProjParams P, const float
   if (i >= n) return;
   const int f = blockIdx.y;
   float d;
-  const int pix = project_point(P, cloud + (size_t)f * cloud_stride, ld, i, w, h, &d);
+  const int pix = project_point<kXyzi>(P, cloud + (size_t)f * cloud_stride, ld, i, w, h, &d);
   if (pix >= 0 && idx_map[(size_t)f * map_stride + pix] == (uint32_t)(i + 1)) raw[(size_t)f * map_stride + pix] = d;
 }
 
@@ -267,18 +278,19 @@ int dalloc(rgbl_depth* e, T** p, size_t count) {
 
 // Part 1 (independent of the keypoints): projection + ordered scatter + dense up-sampling.
 int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w, int h,
-                 float* d_processed_out) {
+                 float* d_processed_out, bool xyzi = false) {
   hipStream_t s = e->stream;
   const size_t ms = e->map_stride;
   RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)batch * ms * 2 * sizeof(uint32_t), s));  // idx maps + raw maps
   if (n > 0) {
     e->timer.begin("k_project_index", s);
-    hipLaunchKernelGGL(k_project_index, dim3((n + 255) / 256, batch), dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld,
-                       w, h, e->d_idx, ms);
+    const dim3 pgrid((n + 255) / 256, batch);
+    if (xyzi) hipLaunchKernelGGL(k_project_index<true>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms);
+    else hipLaunchKernelGGL(k_project_index<false>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms);
     e->timer.end(s);
     e->timer.begin("k_project_write", s);
-    hipLaunchKernelGGL(k_project_write, dim3((n + 255) / 256, batch), dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld,
-                       w, h, e->d_idx, e->d_raw, ms);
+    if (xyzi) hipLaunchKernelGGL(k_project_write<true>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, e->d_raw, ms);
+    else hipLaunchKernelGGL(k_project_write<false>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, e->d_raw, ms);
     e->timer.end(s);
   }
   const dim3 tiles((w + 63) / 64, (h + 15) / 16, batch);
@@ -445,26 +457,27 @@ void rgbl_depth_destroy(rgbl_depth* e) {
   delete e;
 }
 
-int rgbl_depth_compute(rgbl_depth* e, const float* cloud, int n, int ld, int w, int h, const float* kp_xy,
-                       const float* kpun_x, int k, float* out_depth, float* out_uright, float* out_raw,
-                       float* out_processed) {
+static int depth_compute_host(rgbl_depth* e, const float* cloud, int n, int ld, bool xyzi, int w, int h, const float* kp_xy,
+                              const float* kpun_x, int k, float* out_depth, float* out_uright, float* out_raw,
+                              float* out_processed) {
   if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
   if (w != e->cfg.width || h != e->cfg.height || n < 0 || n > e->cfg.max_points || k < 0 || k > e->cfg.max_keypoints ||
-      (n > 0 && (!cloud || ld < n)) || (k > 0 && (!kp_xy || !kpun_x || !out_depth || !out_uright))) {
+      (n > 0 && (!cloud || (!xyzi && ld < n))) || (k > 0 && (!kp_xy || !kpun_x || !out_depth || !out_uright))) {
     set_error("depth arguments do not match the handle (%dx%d, %d points, %d keypoints)", e->cfg.width, e->cfg.height,
               e->cfg.max_points, e->cfg.max_keypoints);
     return RGBL_ERR_INVALID;
   }
   RGBL_HIP(hipSetDevice(e->device));
   hipStream_t s = e->stream;
-  if (n > 0)
-    RGBL_HIP(hipMemcpy2DAsync(e->d_cloud, sizeof(float) * n, cloud, sizeof(float) * ld, sizeof(float) * n, 4,
-                              hipMemcpyHostToDevice, s));
+  if (n > 0) {
+    if (xyzi) RGBL_HIP(hipMemcpyAsync(e->d_cloud, cloud, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, s));
+    else RGBL_HIP(hipMemcpy2DAsync(e->d_cloud, sizeof(float) * n, cloud, sizeof(float) * ld, sizeof(float) * n, 4, hipMemcpyHostToDevice, s));
+  }
   if (k > 0) {
     RGBL_HIP(hipMemcpyAsync(e->d_kp, kp_xy, sizeof(float) * 2 * k, hipMemcpyHostToDevice, s));
     RGBL_HIP(hipMemcpyAsync(e->d_kpun, kpun_x, sizeof(float) * k, hipMemcpyHostToDevice, s));
   }
-  RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr));
+  RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi));
   RGBL_TRY(enqueue_keypoints(e, 1, w, h, e->d_kp, 2, 0, e->d_kpun, 1, 0, nullptr, k, k, e->d_depth, e->d_uright, 0));
   if (k > 0) {
     RGBL_HIP(hipMemcpyAsync(out_depth, e->d_depth, sizeof(float) * k, hipMemcpyDeviceToHost, s));
@@ -476,6 +489,30 @@ int rgbl_depth_compute(rgbl_depth* e, const float* cloud, int n, int ld, int w, 
   RGBL_HIP(hipStreamSynchronize(s));
   e->timer.collect();
   return RGBL_OK;
+}
+
+int rgbl_depth_compute(rgbl_depth* e, const float* cloud, int n, int ld, int w, int h, const float* kp_xy,
+                       const float* kpun_x, int k, float* out_depth, float* out_uright, float* out_raw,
+                       float* out_processed) {
+  return depth_compute_host(e, cloud, n, ld, false, w, h, kp_xy, kpun_x, k, out_depth, out_uright, out_raw, out_processed);
+}
+
+// the scan as it lies in a KITTI velodyne .bin file (LoadPointcloudBinaryMat, rgbl_kitti.cc:151-185)
+int rgbl_depth_compute_xyzi(rgbl_depth* e, const float* xyzi, int n, int w, int h, const float* kp_xy, const float* kpun_x,
+                            int k, float* out_depth, float* out_uright, float* out_raw, float* out_processed) {
+  return depth_compute_host(e, xyzi, n, n, true, w, h, kp_xy, kpun_x, k, out_depth, out_uright, out_raw, out_processed);
+}
+
+int rgbl_depth_project_xyzi_batch_device(rgbl_depth* e, const float* d_xyzi, int batch, int n, size_t scan_stride, int w, int h,
+                                         float* d_processed) {
+  if (!e || !d_xyzi) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  if (w != e->cfg.width || h != e->cfg.height || batch < 1 || batch > e->cfg.max_batch || n < 0 ||
+      (batch > 1 && (scan_stride < (size_t)4 * n || (scan_stride & 3))) || ((uintptr_t)d_xyzi & 15)) {
+    set_error("xyzi batch: scans must be 16-byte aligned, scan_stride a multiple of 4 floats and >= 4 n");
+    return RGBL_ERR_INVALID;
+  }
+  RGBL_HIP(hipSetDevice(e->device));
+  return enqueue_maps(e, d_xyzi, batch, n, n, scan_stride, w, h, d_processed, true);
 }
 
 int rgbl_depth_project_batch_device(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w,

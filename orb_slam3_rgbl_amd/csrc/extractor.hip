@@ -80,6 +80,8 @@ struct rgbl_extractor {
   int32_t* d_stereo_sad = nullptr;  // ComputeStereoMatches scratch (grow-only)
   size_t stereo_sad_count = 0;
   void* d_stereo_stage = nullptr;
+  void* d_color = nullptr;  // staging of one host colour frame (rgbl_extract_color), allocated on first use
+  size_t color_bytes = 0;
   size_t stereo_stage_bytes = 0;
   unsigned long long* d_dbg = nullptr;
   // staging for the host entry points and for the lapping permutation
@@ -466,6 +468,7 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->d_stereo_sad) (void)hipFree(e->d_stereo_sad);
   if (e->d_stereo_stage) (void)hipFree(e->d_stereo_stage);
+  if (e->d_color) (void)hipFree(e->d_color);
   if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
   if (e->ev_pyr) (void)hipEventDestroy(e->ev_pyr);
   if (e->ev_blur) (void)hipEventDestroy(e->ev_blur);
@@ -511,6 +514,32 @@ int rgbl_extractor_sync(rgbl_extractor* e) {
   return check_device_flags(e);
 }
 
+// the frames already sit in e->d_img (row stride dev_stride): extraction, then the results back to the host
+static int run_staged(rgbl_extractor* e, int batch, int dev_stride, int lap0, int lap1, rgbl_keypoint* out_kp,
+                      uint8_t* out_desc, int cap, int* out_n, int* out_mono) {
+  hipStream_t s = e->stream;
+  RGBL_TRY(enqueue_extract(e, e->d_img, batch, dev_stride, e->img_frame, lap0, lap1, e->d_out_kp, e->d_out_desc,
+                           e->out_cap, e->d_out_n, e->d_out_mono));
+  RGBL_HIP(hipMemcpyAsync(out_n, e->d_out_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipMemcpyAsync(out_mono, e->d_out_mono, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipStreamSynchronize(s));
+  e->timer.collect();
+  RGBL_TRY(check_device_flags(e));
+  int rc = RGBL_OK;
+  for (int b = 0; b < batch; ++b) {
+    const int n = out_n[b];
+    const int ncopy = std::min(n, cap);
+    if (n > cap) { set_error("frame %d has %d keypoints, capacity %d", b, n, cap); rc = RGBL_ERR_CAPACITY; }
+    if (n > cap && lap1 >= 19) continue;  // a truncated lapping layout would be meaningless
+    RGBL_HIP(hipMemcpyAsync(out_kp + (size_t)b * cap, e->d_out_kp + (size_t)b * e->out_cap, sizeof(rgbl_keypoint) * ncopy,
+                            hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipMemcpyAsync(out_desc + (size_t)b * cap * 32, e->d_out_desc + (size_t)b * e->out_cap * 32, (size_t)ncopy * 32,
+                            hipMemcpyDeviceToHost, s));
+  }
+  RGBL_HIP(hipStreamSynchronize(s));
+  return rc;
+}
+
 int rgbl_extract_batch(rgbl_extractor* e, const uint8_t* imgs, int batch, int w, int h, int stride, size_t frame_stride,
                        int lap0, int lap1, rgbl_keypoint* out_kp, uint8_t* out_desc, int cap, int* out_n,
                        int* out_mono) {
@@ -540,31 +569,72 @@ int rgbl_extract_batch(rgbl_extractor* e, const uint8_t* imgs, int batch, int w,
       RGBL_HIP(hipMemcpy2DAsync(e->d_img + (size_t)b * e->img_frame, e->img_pitch, imgs + (size_t)b * frame_stride, stride,
                                 w, h, hipMemcpyHostToDevice, s));
   }
-  RGBL_TRY(enqueue_extract(e, e->d_img, batch, dev_stride, e->img_frame, lap0, lap1, e->d_out_kp, e->d_out_desc,
-                           e->out_cap, e->d_out_n, e->d_out_mono));
-  RGBL_HIP(hipMemcpyAsync(out_n, e->d_out_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipMemcpyAsync(out_mono, e->d_out_mono, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipStreamSynchronize(s));
-  e->timer.collect();
-  RGBL_TRY(check_device_flags(e));
-  int rc = RGBL_OK;
-  for (int b = 0; b < batch; ++b) {
-    const int n = out_n[b];
-    const int ncopy = std::min(n, cap);
-    if (n > cap) { set_error("frame %d has %d keypoints, capacity %d", b, n, cap); rc = RGBL_ERR_CAPACITY; }
-    if (n > cap && lap1 >= 19) continue;  // a truncated lapping layout would be meaningless
-    RGBL_HIP(hipMemcpyAsync(out_kp + (size_t)b * cap, e->d_out_kp + (size_t)b * e->out_cap, sizeof(rgbl_keypoint) * ncopy,
-                            hipMemcpyDeviceToHost, s));
-    RGBL_HIP(hipMemcpyAsync(out_desc + (size_t)b * cap * 32, e->d_out_desc + (size_t)b * e->out_cap * 32, (size_t)ncopy * 32,
-                            hipMemcpyDeviceToHost, s));
-  }
-  RGBL_HIP(hipStreamSynchronize(s));
-  return rc;
+  return run_staged(e, batch, dev_stride, lap0, lap1, out_kp, out_desc, cap, out_n, out_mono);
 }
 
 int rgbl_extract(rgbl_extractor* e, const uint8_t* img, int w, int h, int stride, int lap0, int lap1, rgbl_keypoint* out_kp,
                  uint8_t* out_desc, int cap, int* out_n, int* out_mono) {
   return rgbl_extract_batch(e, img, 1, w, h, stride, 0, lap0, lap1, out_kp, out_desc, cap, out_n, out_mono);
+}
+
+// ---- ingest: cv::cvtColor in front of the extractor --------------------------------------------
+static int enqueue_cvt_gray(rgbl_extractor* e, const uint8_t* d_src, int batch, int channels, int blue_first, int w, int h,
+                            int src_stride, size_t src_frame, uint8_t* d_gray, int gray_stride, size_t gray_frame) {
+  // COLOR_BGR2GRAY weights channel 0 as blue, COLOR_RGB2GRAY as red (OpenCV 4.x: RY15 9798, GY15 19235, BY15 3735)
+  const int w0 = blue_first ? 3735 : 9798, w2 = blue_first ? 9798 : 3735;
+  const dim3 grid((w + 255) / 256, (h + 3) / 4, batch);
+  e->timer.begin("k_cvt_gray", e->stream);
+  if (channels == 3) hipLaunchKernelGGL(k_cvt_gray<3>, grid, dim3(256), 0, e->stream, d_src, src_stride, src_frame, w, h, w0, w2, d_gray, gray_stride, gray_frame);
+  else hipLaunchKernelGGL(k_cvt_gray<4>, grid, dim3(256), 0, e->stream, d_src, src_stride, src_frame, w, h, w0, w2, d_gray, gray_stride, gray_frame);
+  e->timer.end(e->stream);
+  RGBL_HIP(hipGetLastError());
+  return RGBL_OK;
+}
+
+int rgbl_cvt_gray_batch_device(rgbl_extractor* e, const uint8_t* d_src, int batch, int channels, int blue_first, int w, int h,
+                               int src_stride, size_t src_frame_stride, uint8_t* d_gray, int gray_stride,
+                               size_t gray_frame_stride) {
+  if (!e || !d_src || !d_gray) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  if ((channels != 3 && channels != 4) || w < 1 || h < 1 || batch < 1 || src_stride < w * channels || gray_stride < w ||
+      (batch > 1 && (src_frame_stride < (size_t)src_stride * h || gray_frame_stride < (size_t)gray_stride * h))) {
+    set_error("cvtColor: %d channels, %dx%d, strides %d / %d are not a valid 8-bit colour batch", channels, w, h, src_stride, gray_stride);
+    return RGBL_ERR_INVALID;
+  }
+  RGBL_HIP(hipSetDevice(e->device));
+  return enqueue_cvt_gray(e, d_src, batch, channels, blue_first, w, h, src_stride, src_frame_stride, d_gray, gray_stride,
+                          gray_frame_stride);
+}
+
+int rgbl_extract_color(rgbl_extractor* e, const uint8_t* img, int channels, int blue_first, int w, int h, int stride, int lap0,
+                       int lap1, rgbl_keypoint* out_kp, uint8_t* out_desc, int cap, int* out_n, int* out_mono,
+                       uint8_t* out_gray, int gray_stride) {
+  if (out_n) *out_n = 0;
+  if (out_mono) *out_mono = -1;
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  if (!img || w <= 0 || h <= 0) { set_error("empty image"); return RGBL_ERR_EMPTY; }
+  if (!out_kp || !out_desc || !out_n || !out_mono) { set_error("null output"); return RGBL_ERR_INVALID; }
+  if (channels == 1) {  // GrabImageRGBL leaves single-channel input alone
+    if (out_gray) for (int y = 0; y < h; ++y) memcpy(out_gray + (size_t)y * gray_stride, img + (size_t)y * stride, w);
+    return rgbl_extract(e, img, w, h, stride, lap0, lap1, out_kp, out_desc, cap, out_n, out_mono);
+  }
+  if ((channels != 3 && channels != 4) || w != e->cfg.width || h != e->cfg.height || stride < w * channels || cap < 1 ||
+      (out_gray && gray_stride < w)) {
+    set_error("colour image %dx%dx%d does not match the handle (%dx%d)", w, h, channels, e->cfg.width, e->cfg.height);
+    return RGBL_ERR_INVALID;
+  }
+  RGBL_HIP(hipSetDevice(e->device));
+  hipStream_t s = e->stream;
+  const size_t need = (size_t)stride * h + 16;
+  if (need > e->color_bytes) {  // first colour frame (or a wider stride): grown once, kept
+    if (e->d_color) RGBL_HIP(hipFree(e->d_color));
+    e->d_color = nullptr; e->color_bytes = 0;
+    RGBL_HIP(hipMalloc(&e->d_color, need));
+    e->color_bytes = need;
+  }
+  RGBL_HIP(hipMemcpyAsync(e->d_color, img, (size_t)(h - 1) * stride + (size_t)w * channels, hipMemcpyHostToDevice, s));
+  RGBL_TRY(enqueue_cvt_gray(e, (const uint8_t*)e->d_color, 1, channels, blue_first, w, h, stride, 0, e->d_img, e->img_pitch, 0));
+  if (out_gray) RGBL_HIP(hipMemcpy2DAsync(out_gray, gray_stride, e->d_img, e->img_pitch, w, h, hipMemcpyDeviceToHost, s));
+  return run_staged(e, 1, e->img_pitch, lap0, lap1, out_kp, out_desc, cap, out_n, out_mono);
 }
 
 int rgbl_extractor_level_size(const rgbl_extractor* e, int level, int* w, int* h) {

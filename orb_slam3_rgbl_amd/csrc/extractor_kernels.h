@@ -1492,6 +1492,48 @@ __global__ __launch_bounds__(256) void k_stereo_filter(const int32_t* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// cv::cvtColor(COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) on 8-bit images, the call in front of the extractor
+// (Tracking::GrabImageRGBL, Tracking.cc:1567-1580).  OpenCV 4.x fixed point: 15-bit weights R 9798, G 19235, B 3735,
+// gray = (c0*w0 + c1*GY + c2*w2 + 2^14) >> 15.  Work-item = 4 output pixels (12 or 16 source bytes as 32-bit words,
+// one 32-bit store).  grid = (ceil(w/256), ceil(h/4), B), block = 256 (64 x 4).
+template <int kChannels>
+__global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t* __restrict__ src, int spitch, size_t sframe, int w, int h,
+                                                  int w0, int w2, uint8_t* __restrict__ dst, int dpitch, size_t dframe) {
+  const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x0 >= w || y >= h) return;
+  const uint8_t* S = src + (size_t)blockIdx.z * sframe + (size_t)y * spitch + (size_t)x0 * kChannels;
+  uint8_t* D = dst + (size_t)blockIdx.z * dframe + (size_t)y * dpitch + x0;
+  constexpr int kGY = 19235;
+  if (x0 + 3 < w) {
+    uint32_t out = 0;
+    if (kChannels == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t q = load_u32_unaligned(S + 4 * i);
+        const int v = (int)(((q & 0xff) * (uint32_t)w0 + ((q >> 8) & 0xff) * (uint32_t)kGY + ((q >> 16) & 0xff) * (uint32_t)w2 + (1u << 14)) >> 15);
+        out |= (uint32_t)v << (8 * i);
+      }
+    } else {
+      const uint32_t q0 = load_u32_unaligned(S), q1 = load_u32_unaligned(S + 4), q2 = load_u32_unaligned(S + 8);
+      const uint32_t px[4] = {q0 & 0xffffffu, (q0 >> 24) | ((q1 & 0xffffu) << 8), (q1 >> 16) | ((q2 & 0xffu) << 16), q2 >> 8};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t q = px[i];
+        const int v = (int)(((q & 0xff) * (uint32_t)w0 + ((q >> 8) & 0xff) * (uint32_t)kGY + ((q >> 16) & 0xff) * (uint32_t)w2 + (1u << 14)) >> 15);
+        out |= (uint32_t)v << (8 * i);
+      }
+    }
+    if ((dpitch & 3) == 0) *reinterpret_cast<uint32_t*>(D) = out;  // x0 is a multiple of 4
+    else { D[0] = (uint8_t)out; D[1] = (uint8_t)(out >> 8); D[2] = (uint8_t)(out >> 16); D[3] = (uint8_t)(out >> 24); }
+    return;
+  }
+  for (int i = 0; x0 + i < w; ++i) {  // row end: byte path, never reads past the last pixel
+    const uint8_t* q = S + i * kChannels;
+    D[i] = (uint8_t)(((uint32_t)q[0] * (uint32_t)w0 + (uint32_t)q[1] * (uint32_t)kGY + (uint32_t)q[2] * (uint32_t)w2 + (1u << 14)) >> 15);
+  }
+}
+
 // unpacks candidate keys into rgbl_keypoint records (diagnostic path of rgbl_extractor_get_candidates)
 __global__ void k_unpack_keys(const uint32_t* __restrict__ keys, int n, rgbl_keypoint* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

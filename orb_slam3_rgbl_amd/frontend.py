@@ -90,6 +90,22 @@ class ORBextractor:
                                                 C.byref(mono)))
         return kps[:n.value].copy(), desc[:n.value].copy(), mono.value
 
+    def extract_color(self, image, mbRGB, vLappingArea=(0, 0)):
+        """Tracking::GrabImageRGBL's cvtColor (Tracking.cc:1567-1580) + operator() on an H x W x {3,4} 8-bit image.
+        mbRGB (settings `Camera.RGB`) selects COLOR_RGB(A)2GRAY, otherwise COLOR_BGR(A)2GRAY.
+        Returns (keypoints, descriptors, monoIndex, mImGray)."""
+        image = np.ascontiguousarray(image, np.uint8)
+        h, w, ch = image.shape
+        cap = self.max_keypoints
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        gray = np.zeros((h, w), np.uint8)
+        n, mono = C.c_int(0), C.c_int(-1)
+        L.check(self.lib, self.lib.rgbl_extract_color(self.h, L.ptr(image), ch, 0 if mbRGB else 1, w, h, image.strides[0],
+                                                      int(vLappingArea[0]), int(vLappingArea[1]), L.ptr(kps), L.ptr(desc), cap,
+                                                      C.byref(n), C.byref(mono), L.ptr(gray), gray.strides[0]))
+        return kps[:n.value].copy(), desc[:n.value].copy(), mono.value, gray
+
     def extract_batch(self, images, vLappingArea=(0, 0)):
         """images: [B, H, W] u8 contiguous. Returns list of (keypoints, descriptors, monoIndex)."""
         images = np.ascontiguousarray(images, np.uint8)
@@ -222,6 +238,25 @@ class DepthModule:
         L.check(self.lib, self.lib.rgbl_depth_compute(self.h, L.ptr(cloud), n, cloud.strides[0] // 4, imwidth, imheight,
                                                       L.ptr(kp), L.ptr(un), k, L.ptr(self.mvDepth), L.ptr(self.mvuRight),
                                                       L.ptr(self.RawDepthMap), L.ptr(self.ProcessedDepthMap)))
+
+    def CalculateDepthFromKittiBin(self, mvKeys, mvKeysUn, xyzi, imwidth, imheight, want_maps=True):
+        """The scan as read from a KITTI velodyne .bin file: N x 4 float32 (x, y, z, reflectance) - what
+        LoadPointcloudBinaryMat (Examples/RGB-L/rgbl_kitti.cc:151-185) turns into the 4 x N matrix, without the repack."""
+        def xy(a):
+            if a.dtype == KP_DTYPE:
+                return np.stack([a["x"], a["y"]], 1).astype(np.float32)
+            return np.ascontiguousarray(a, np.float32).reshape(-1, 2)
+        kp = np.ascontiguousarray(xy(mvKeys))
+        un = np.ascontiguousarray(xy(mvKeysUn)[:, 0])
+        pts = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+        n, k = pts.shape[0], kp.shape[0]
+        self.mvDepth, self.mvuRight = np.zeros(k, np.float32), np.zeros(k, np.float32)
+        self.RawDepthMap = np.zeros((imheight, imwidth), np.float32) if want_maps else None
+        proc_ok = want_maps and self.cfg.method != UPS_NEAREST_NEIGHBOR_PIXEL
+        self.ProcessedDepthMap = np.zeros((imheight, imwidth), np.float32) if proc_ok else None
+        L.check(self.lib, self.lib.rgbl_depth_compute_xyzi(self.h, L.ptr(pts), n, imwidth, imheight, L.ptr(kp), L.ptr(un), k,
+                                                           L.ptr(self.mvDepth), L.ptr(self.mvuRight), L.ptr(self.RawDepthMap),
+                                                           L.ptr(self.ProcessedDepthMap)))
 
     def profile(self, enable):
         L.check(self.lib, self.lib.rgbl_depth_profile(self.h, int(enable)))

@@ -220,6 +220,18 @@ void DepthModule::EnsureHandle(int width, int height, int nPoints, int nKeys) {
 
 void DepthModule::CalculateDepthFromPcd(std::vector<cv::KeyPoint> mvKeys, std::vector<cv::KeyPoint> mvKeysUn,
                                         const cv::Mat& PointCloud, const int imwidth, const int imheight) {
+  Compute(mvKeys, mvKeysUn, PointCloud.ptr<float>(), PointCloud.cols, (int)(PointCloud.step / sizeof(float)), false, imwidth, imheight);
+}
+
+// The scan exactly as read from a KITTI velodyne .bin file (nPoints records x, y, z, reflectance): what the example's
+// LoadPointcloudBinaryMat (Examples/RGB-L/rgbl_kitti.cc:151-185) repacks into the 4 x N matrix, without the repack.
+void DepthModule::CalculateDepthFromKittiBin(const std::vector<cv::KeyPoint>& mvKeys, const std::vector<cv::KeyPoint>& mvKeysUn,
+                                             const float* xyzi, const int nPoints, const int imwidth, const int imheight) {
+  Compute(mvKeys, mvKeysUn, xyzi, nPoints, nPoints, true, imwidth, imheight);
+}
+
+void DepthModule::Compute(const std::vector<cv::KeyPoint>& mvKeys, const std::vector<cv::KeyPoint>& mvKeysUn, const float* cloud,
+                          int nPoints, int ld, bool xyzi, int imwidth, int imheight) {
   if (!b_parse_LiDARUpsampling || !b_parse_LiDAR) {
     std::cout << "*Cannot perform LiDAR Upsampling since parameters were missing in the config file.*" << std::endl;
     return;
@@ -233,7 +245,7 @@ void DepthModule::CalculateDepthFromPcd(std::vector<cv::KeyPoint> mvKeys, std::v
     return;
   }
   const int N = (int)mvKeys.size();
-  EnsureHandle(imwidth, imheight, PointCloud.cols, N);
+  EnsureHandle(imwidth, imheight, nPoints, N);
   if (!mpHandle) return;
   std::vector<float> kp_xy(2 * (size_t)N), kpun_x(N);
   for (int i = 0; i < N; ++i) {
@@ -252,8 +264,10 @@ void DepthModule::CalculateDepthFromPcd(std::vector<cv::KeyPoint> mvKeys, std::v
       proc = ProcessedDepthMap.ptr<float>();
     }
   }
-  const int rc = rgbl_depth_compute(mpHandle, PointCloud.ptr<float>(), PointCloud.cols, (int)(PointCloud.step / sizeof(float)),
-                                    imwidth, imheight, kp_xy.data(), kpun_x.data(), N, mvDepth.data(), mvuRight.data(), raw, proc);
+  const int rc = xyzi ? rgbl_depth_compute_xyzi(mpHandle, cloud, nPoints, imwidth, imheight, kp_xy.data(), kpun_x.data(), N,
+                                                mvDepth.data(), mvuRight.data(), raw, proc)
+                      : rgbl_depth_compute(mpHandle, cloud, nPoints, ld, imwidth, imheight, kp_xy.data(), kpun_x.data(), N,
+                                           mvDepth.data(), mvuRight.data(), raw, proc);
   if (rc != RGBL_OK) std::cout << "*" << rgbl_last_error() << "*" << std::endl;
 }
 

@@ -26,6 +26,10 @@ class DepthModule {
   // Depth value handler, manages the depth calculation for each frame (DepthModule.cc:50-79).
   void CalculateDepthFromPcd(std::vector<cv::KeyPoint> mvKeys, std::vector<cv::KeyPoint> mvKeysUn,
                              const cv::Mat& PointCloud, const int imwidth, const int imheight);
+  // Same, on the raw contents of a KITTI velodyne .bin file (nPoints x {x, y, z, reflectance}): replaces the example's
+  // LoadPointcloudBinaryMat repack (Examples/RGB-L/rgbl_kitti.cc:151-185) + CalculateDepthFromPcd.
+  void CalculateDepthFromKittiBin(const std::vector<cv::KeyPoint>& mvKeys, const std::vector<cv::KeyPoint>& mvKeysUn,
+                                  const float* xyzi, const int nPoints, const int imwidth, const int imheight);
 
   cv::Mat LidarProjectionMatrix;  // 3x4, CV_32F
   cv::Mat RawDepthMap;
@@ -41,6 +45,8 @@ class DepthModule {
   bool ParseRGBLParameters(const std::string& strSettingPath);
   bool ParseUpsamplingParameters(const std::string& strSettingPath);
   void EnsureHandle(int width, int height, int nPoints, int nKeys);
+  void Compute(const std::vector<cv::KeyPoint>& mvKeys, const std::vector<cv::KeyPoint>& mvKeysUn, const float* cloud, int nPoints,
+               int ld, bool xyzi, int imwidth, int imheight);
 
   bool b_parse_LiDAR, b_parse_LiDARUpsampling;
   float mbf;

@@ -99,6 +99,41 @@ int ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, st
     memcpy(_descriptors.data, desc.data, (size_t)n * 32);
   }
 #endif
+  FillPyramid();
+  return mono;
+}
+
+int ORBextractor::ExtractColor(const unsigned char* data, int channels, int step, int width, int height, bool bRGB,
+                               cv::Mat& imGray, std::vector<cv::KeyPoint>& _keypoints, cv::Mat& _descriptors,
+                               std::vector<int>& vLappingArea) {
+  if (!data || width <= 0 || height <= 0) return -1;
+  EnsureHandle(width, height);
+  if (!mpHandle) return -1;
+  const int cap = rgbl_extractor_max_keypoints(mpHandle);
+  _keypoints = std::vector<cv::KeyPoint>(cap);
+  cv::Mat desc(cap, 32, CV_8U);
+  imGray.create(height, width, CV_8UC1);
+  int n = 0, mono = -1;
+  const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+  const int rc = rgbl_extract_color(mpHandle, data, channels, bRGB ? 0 : 1, width, height, step, lap0, lap1,
+                                    reinterpret_cast<rgbl_keypoint*>(_keypoints.data()), desc.data, cap, &n, &mono, imGray.data,
+                                    (int)imGray.step);
+  if (rc != RGBL_OK) {
+    std::cerr << "[ORBextractor] " << rgbl_last_error() << std::endl;
+    _keypoints.clear();
+    return -1;
+  }
+  _keypoints.resize(n);
+  if (n == 0) _descriptors.release();
+  else {
+    _descriptors.create(n, 32, CV_8U);
+    memcpy(_descriptors.data, desc.data, (size_t)n * 32);
+  }
+  FillPyramid();
+  return mono;
+}
+
+void ORBextractor::FillPyramid() {
   if (keepPyramid) {
     mvPyramidStorage.resize(nlevels);
     for (int l = 0; l < nlevels; ++l) {
@@ -114,7 +149,6 @@ int ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, st
 #endif
     }
   }
-  return mono;
 }
 
 }  // namespace ORB_SLAM3

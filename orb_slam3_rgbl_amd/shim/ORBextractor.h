@@ -25,6 +25,11 @@ class ORBextractor {
   int operator()(cv::InputArray _image, cv::InputArray _mask, std::vector<cv::KeyPoint>& _keypoints,
                  cv::OutputArray _descriptors, std::vector<int>& vLappingArea);
 
+  // cvtColor + operator() in one device round trip (Tracking::GrabImageRGBL, Tracking.cc:1567-1580): `data` is an
+  // 8-bit image with 3 or 4 interleaved channels (1 = already gray), bRGB = Tracking::mbRGB.  imGray receives mImGray.
+  int ExtractColor(const unsigned char* data, int channels, int step, int width, int height, bool bRGB, cv::Mat& imGray,
+                   std::vector<cv::KeyPoint>& _keypoints, cv::Mat& _descriptors, std::vector<int>& vLappingArea);
+
   int inline GetLevels() { return nlevels; }
   float inline GetScaleFactor() { return scaleFactor; }
   std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
@@ -43,6 +48,7 @@ class ORBextractor {
 
  protected:
   void EnsureHandle(int width, int height);
+  void FillPyramid();
 
   int nfeatures;
   double scaleFactor;

@@ -5,6 +5,7 @@ must be bit-exact; float results are compared bit-for-bit as well unless a toler
 import numpy as np
 
 from oracle import oracle_py as O
+from orb_slam3_rgbl_amd import _lib as L
 from orb_slam3_rgbl_amd import frontend as F
 from orb_slam3_rgbl_amd import synth
 
@@ -330,3 +331,91 @@ def check_stereo_matches(lib, w=synth.KITTI_W, h=synth.KITTI_H, nfeatures=2000, 
     assert (ur0 == -1).all() and (dp0 == -1).all()
     exl.close(); exr.close()
     return n
+
+
+# ---- ingest either side of the path ------------------------------------------------------------
+def color_frame(seed, w, h, channels):
+    """A colour image whose channels differ (shifted / inverted copies of a synthetic gray frame plus noise)."""
+    g = synth.Sequence(seed, w, h, 1).frame(0).astype(np.int32)
+    rng = np.random.default_rng(seed + 99)
+    img = np.empty((h, w, channels), np.uint8)
+    img[..., 0] = np.clip(g + rng.integers(-20, 21, g.shape), 0, 255)
+    img[..., 1] = np.clip(np.roll(g, 3, axis=1) * 3 // 4 + 30, 0, 255)
+    img[..., 2] = np.clip(255 - np.roll(g, -2, axis=0) // 2 + rng.integers(-9, 10, g.shape), 0, 255)
+    if channels == 4:
+        img[..., 3] = rng.integers(0, 256, g.shape)  # alpha must be ignored
+    return img
+
+
+def check_ingest_color(lib, w, h, nfeatures=600, seed=3):
+    """cvtColor + operator(): mImGray and the keypoints must equal oracle cvtColor followed by the oracle extractor."""
+    ex = F.ORBextractor(nfeatures, 1.2, 8, 12, 7, w, h, lib=lib)
+    orc = O.Extractor(nfeatures, 1.2, 8, 12, 7)
+    n = 0
+    for channels in (3, 4):
+        for mbRGB in (True, False):
+            img = color_frame(seed + channels, w, h, channels)
+            kps, desc, mono, gray = ex.extract_color(img, mbRGB)
+            ogray = O.cvt_gray(img, mbRGB)
+            assert np.array_equal(gray, ogray), "mImGray (%d channels, RGB=%s)" % (channels, mbRGB)
+            okps, odesc, omono = orc(ogray)
+            assert_keypoints_equal(kps, okps, "colour %d/%s" % (channels, mbRGB))
+            assert np.array_equal(desc, odesc) and mono == omono
+            n += len(kps)
+    # a strided view (ROI of a wider image) and an already-gray input
+    wide = color_frame(seed, w + 13, h, 3)
+    roi = wide[:, 5:5 + w]
+    kps, desc, mono, gray = ex.extract_color(np.ascontiguousarray(roi), True)
+    assert np.array_equal(gray, O.cvt_gray(np.ascontiguousarray(roi), True))
+    g1 = synth.Sequence(seed, w, h, 1).frame(0)
+    kps, desc, mono, gray = ex.extract_color(g1[..., None], True)
+    okps, odesc, omono = orc(g1)
+    assert np.array_equal(gray, g1) and np.array_equal(desc, odesc)
+    ex.close()
+    return n
+
+
+def check_ingest_color_device_batch(lib, w=1241, h=376, batch=3):
+    """rgbl_cvt_gray_batch_device on odd strides / widths: every byte against the oracle (needs torch + a device)."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    ex = F.ORBextractor(500, 1.2, 8, 12, 7, w, h, max_batch=batch, lib=lib)
+    for channels, blue_first in ((3, 1), (3, 0), (4, 1), (4, 0)):
+        imgs = np.stack([color_frame(20 + b, w, h, channels) for b in range(batch)])
+        d_src = torch.from_numpy(imgs).to(dev)
+        gstride = w + 3  # odd gray stride: the kernel falls back to byte stores
+        d_gray = torch.zeros((batch, h, gstride), dtype=torch.uint8, device=dev)
+        L.check(lib, lib.rgbl_cvt_gray_batch_device(ex.h, C.c_void_p(d_src.data_ptr()), batch, channels, blue_first, w, h,
+                                                    w * channels, w * h * channels, C.c_void_p(d_gray.data_ptr()), gstride,
+                                                    h * gstride))
+        L.check(lib, lib.rgbl_extractor_sync(ex.h))
+        got = d_gray.cpu().numpy()
+        for b in range(batch):
+            assert np.array_equal(got[b, :, :w], O.cvt_gray(imgs[b], not blue_first))
+            assert not got[b, :, w:].any()
+    ex.close()
+
+
+def check_ingest_kitti_bin(lib, method=F.UPS_INVERSE_DILATION, w=620, h=188, n_az=900, n_kp=300, seed=5):
+    """The .bin layout (x, y, z, reflectance) must give exactly what the 4 x N path gives on the repacked scan."""
+    K = synth.KITTI_K.copy()
+    K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    K[0, 0] = K[1, 1] = 718.856 * w / synth.KITTI_W
+    proj = F.projection_matrix(K, synth.KITTI_TR, lib)
+    cloud = synth.lidar_scan(seed, n_az=n_az)
+    rng = np.random.default_rng(seed)
+    xyzi = np.ascontiguousarray(np.concatenate([cloud[:3].T, rng.random((cloud.shape[1], 1), np.float32)], 1))  # reflectance != 1
+    assert np.array_equal(O.kitti_bin_to_cloud(xyzi), cloud)
+    kp = np.stack([rng.uniform(0, w - 1, n_kp), rng.uniform(0, h - 1, n_kp)], 1).astype(np.float32)
+    dm = F.DepthModule(proj, w, h, method=method, max_points=cloud.shape[1], max_keypoints=n_kp, lib=lib)
+    dm.CalculateDepthFromKittiBin(kp, kp, xyzi, w, h)
+    P = O.make_depth_params(proj, method=method)
+    d, ur, raw, proc = O.depth(P, O.kitti_bin_to_cloud(xyzi), w, h, kp, kp[:, 0])
+    assert np.array_equal(bits(dm.RawDepthMap), bits(raw))
+    if dm.ProcessedDepthMap is not None:
+        assert np.array_equal(bits(np.nan_to_num(dm.ProcessedDepthMap)), bits(np.nan_to_num(proc)))
+    assert np.array_equal(bits(dm.mvDepth), bits(d)) and np.array_equal(bits(dm.mvuRight), bits(ur))
+    n_valid = int((d > 0).sum())
+    dm.close()
+    return n_valid

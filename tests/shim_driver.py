@@ -80,6 +80,12 @@ def run_and_check(exe, tmp):
     mvDepth, mvuRight = take(np.float32, nd), take(np.float32, nd)
     processed = take(np.float32, w * h).reshape(h, w)
     proj = take(np.float32, 12).reshape(3, 4)
+    nb = take(np.int32, 1)[0]
+    binDepth, binURight = take(np.float32, nb), take(np.float32, nb)
+    mono_col, nc = take(np.int32, 2)
+    kcol = take(O.KP_DTYPE, nc)
+    dcol = take(np.uint8, nc * 32).reshape(nc, 32)
+    gray = take(np.uint8, w * h).reshape(h, w)
     nm, npairs = take(np.int32, 2)
     pairs = take(np.int32, 2 * npairs).reshape(npairs, 2)
     dd = take(np.int32, 1)[0]
@@ -97,6 +103,14 @@ def run_and_check(exe, tmp):
     d, ur, raw, proc = O.depth(P, cloud, w, h, np.stack([okps["x"], okps["y"]], 1), okps["x"])
     assert nd == nk and np.array_equal(pc.bits(mvDepth), pc.bits(d)) and np.array_equal(pc.bits(mvuRight), pc.bits(ur))
     assert np.array_equal(pc.bits(processed), pc.bits(proc))
+    # ingest: the .bin layout gives the same depths; cvtColor + extraction == oracle cvtColor, then the oracle extractor
+    assert nb == nk and np.array_equal(pc.bits(binDepth), pc.bits(d)) and np.array_equal(pc.bits(binURight), pc.bits(ur))
+    col = np.stack([img, 255 - img, (img // 2 + (np.arange(w) % 50)[None, :]).astype(np.uint8)], 2)
+    ogray = O.cvt_gray(col, True)
+    assert np.array_equal(gray, ogray)
+    ck, cd, cm = orc(ogray)
+    pc.assert_keypoints_equal(kcol, ck, "shim ExtractColor")
+    assert np.array_equal(dcol, cd) and mono_col == cm and nc > 500
     # triangulation: F12 / epipole as the shim derives them from the poses
     T12 = T1w @ Tw2
     F = O.fundamental(K, K, T12[:3, :3].reshape(9), T12[:3, 3])

@@ -136,6 +136,33 @@ int main(int argc, char** argv) {
   wr(out, depth.ProcessedDepthMap.ptr<float>(), (size_t)w * h);
   wr(out, depth.LidarProjectionMatrix.ptr<float>(), 12);
 
+  // --- ingest: the .bin layout straight into the depth module, cvtColor + extraction in one call
+  {
+    std::vector<float> xyzi((size_t)4 * n);
+    for (int i = 0; i < n; ++i) {
+      xyzi[4 * i] = pcd.ptr<float>(0)[i]; xyzi[4 * i + 1] = pcd.ptr<float>(1)[i]; xyzi[4 * i + 2] = pcd.ptr<float>(2)[i];
+      xyzi[4 * i + 3] = 0.25f + (i % 7) * 0.1f;  // reflectance: must not matter
+    }
+    depth.CalculateDepthFromKittiBin(keys, keys, xyzi.data(), n, w, h);
+    const int nb = (int)depth.mvDepth.size();
+    wr(out, &nb, 1);
+    wr(out, depth.mvDepth.data(), nb); wr(out, depth.mvuRight.data(), nb);
+    std::vector<unsigned char> bgr((size_t)3 * w * h);
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        const int g = im.data[(size_t)y * im.step + x];
+        unsigned char* q = &bgr[((size_t)y * w + x) * 3];
+        q[0] = (unsigned char)g; q[1] = (unsigned char)(255 - g); q[2] = (unsigned char)(g / 2 + (x % 50));
+      }
+    cv::Mat gray, dcol;
+    std::vector<cv::KeyPoint> kcol;
+    const int mono_col = extractor.ExtractColor(bgr.data(), 3, 3 * w, w, h, /*bRGB=*/true, gray, kcol, dcol, vLapping);
+    const int nc = (int)kcol.size();
+    wr(out, &mono_col, 1); wr(out, &nc, 1);
+    wr(out, kcol.data(), nc); wr(out, dcol.data, (size_t)nc * 32);
+    for (int y = 0; y < h; ++y) wr(out, gray.data + (size_t)y * gray.step, w);
+  }
+
   // --- as LocalMapping::CreateNewMapPoints (LocalMapping.cc:412,466)
   f = fopen(argv[7], "rb");
   Camera cam; MapPoint some; KeyFrame kf1, kf2;

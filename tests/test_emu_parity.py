@@ -86,3 +86,12 @@ def test_extractor_both_quadtree_workgroup_widths(emu_lib, wg):
         pc.check_extractor(emu_lib, 1500, 1100, 3000, frames=(0,), nlevels=1, seq=14)   # cooperative split + LDS sort sizes
     finally:
         os.environ.pop("RGBL_OCTREE_WG", None)
+
+
+def test_ingest_cvtcolor_then_extract(emu_lib):
+    assert pc.check_ingest_color(emu_lib, 402, 300) > 1000
+
+
+def test_ingest_kitti_bin_layout(emu_lib):
+    assert pc.check_ingest_kitti_bin(emu_lib) > 10
+    assert pc.check_ingest_kitti_bin(emu_lib, method=F.UPS_NEAREST_NEIGHBOR_PIXEL, seed=6) > 10

@@ -283,3 +283,26 @@ def test_triangulation_tie_goes_to_the_later_candidate():
     # epipole guard: mono-mono candidates closer than 10*sqrt(scale) px to the epipole are skipped
     m, n = O.search_triangulation(kf1, kf2, F, [92, 100], sf, sf, coarse=True)
     assert n == 0
+
+
+def test_cvtcolor_gray_known_answers():
+    """cv::cvtColor 8-bit RGB/BGR(A) -> gray, OpenCV 4.x: (9798 R + 19235 G + 3735 B + 2^14) >> 15 (weights sum to 2^15)."""
+    assert 9798 + 19235 + 3735 == 1 << 15
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 77], [1, 1, 1], [254, 255, 255]]], np.uint8)
+    rgb = O.cvt_gray(px, True)[0]
+    bgr = O.cvt_gray(px, False)[0]
+    assert rgb.tolist() == [255, 0, 76, 150, 29, (10 * 9798 + 200 * 19235 + 77 * 3735 + 16384) >> 15, 1, 255]
+    assert bgr.tolist() == [255, 0, 29, 150, 76, (10 * 3735 + 200 * 19235 + 77 * 9798 + 16384) >> 15, 1, 255]
+    # the alpha channel is ignored; rows honour the stride
+    rng = np.random.default_rng(1)
+    img4 = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    ref = ((img4[..., 0].astype(np.int64) * 9798 + img4[..., 1].astype(np.int64) * 19235 + img4[..., 2].astype(np.int64) * 3735 + 16384) >> 15)
+    assert np.array_equal(O.cvt_gray(img4, True), ref.astype(np.uint8))
+    assert np.array_equal(O.cvt_gray(img4[..., :3].copy(), True), ref.astype(np.uint8))
+
+
+def test_kitti_bin_repack():
+    pts = np.arange(20, dtype=np.float32).reshape(5, 4)
+    cloud = O.kitti_bin_to_cloud(pts)
+    assert cloud.shape == (4, 5)
+    assert np.array_equal(cloud[:3], pts[:, :3].T) and np.array_equal(cloud[3], np.ones(5, np.float32))

@@ -104,3 +104,13 @@ def test_compute_stereo_matches(gpu_lib):
     # Frame::ComputeStereoMatches on the resident pyramids of the two extractors
     assert pc.check_stereo_matches(gpu_lib) > 400                       # KITTI stereo thresholds 20/7
     assert pc.check_stereo_matches(gpu_lib, w=752, h=480, nfeatures=1200, seq=31, mb=0.11, mbf=47.9) > 100   # EuRoC-like
+
+
+def test_ingest_cvtcolor_then_extract(gpu_lib):
+    assert pc.check_ingest_color(gpu_lib, synth.KITTI_W, synth.KITTI_H, nfeatures=2000) > 4000
+    pc.check_ingest_color_device_batch(gpu_lib)
+
+
+def test_ingest_kitti_bin_layout(gpu_lib):
+    assert pc.check_ingest_kitti_bin(gpu_lib, w=synth.KITTI_W, h=synth.KITTI_H, n_az=1900, n_kp=1500) > 50
+    assert pc.check_ingest_kitti_bin(gpu_lib, method=F.UPS_AVERAGE_FILTERING, seed=8) > 10
