@@ -1,0 +1,168 @@
+// Stand-in for the slice of Eigen / Sophus that the reference's src/ORBmatcher.cc uses (TEST INFRASTRUCTURE; see
+// oracle/Makefile target `ref`): fixed-size float vectors / 3x3 matrices and SE3f / Sim3f with a unit quaternion +
+// translation, with the arithmetic the real libraries perform:
+//   * SE3f * point = q._transformVector(p) + t, Eigen's formula  uv = 2 (q.vec x p);  p + w uv + q.vec x uv
+//   * SE3f * SE3f  = (q1 q2 renormalised, q1 * t2 + t1);  inverse = (q^-1, -(q^-1 * t))
+//   * rotationMatrix() = Eigen's Quaternion::toRotationMatrix()
+// fp32 throughout, compiled without contraction like the rest of the oracle.
+#pragma once
+#include <math.h>
+
+namespace Eigen {
+template <int N> struct Vec {
+  float v[N];
+  Vec() { for (int i = 0; i < N; ++i) v[i] = 0.f; }
+  Vec(float a, float b) { static_assert(N == 2, ""); v[0] = a; v[1] = b; }
+  Vec(float a, float b, float c) { static_assert(N == 3, ""); v[0] = a; v[1] = b; v[2] = c; }
+  float& operator()(int i) { return v[i]; }
+  float operator()(int i) const { return v[i]; }
+  float& operator[](int i) { return v[i]; }
+  float operator[](int i) const { return v[i]; }
+  Vec operator-(const Vec& o) const { Vec r; for (int i = 0; i < N; ++i) r.v[i] = v[i] - o.v[i]; return r; }
+  Vec operator+(const Vec& o) const { Vec r; for (int i = 0; i < N; ++i) r.v[i] = v[i] + o.v[i]; return r; }
+  Vec operator-() const { Vec r; for (int i = 0; i < N; ++i) r.v[i] = -v[i]; return r; }
+  Vec operator/(float s) const { Vec r; for (int i = 0; i < N; ++i) r.v[i] = v[i] / s; return r; }
+  Vec operator*(float s) const { Vec r; for (int i = 0; i < N; ++i) r.v[i] = v[i] * s; return r; }
+  float dot(const Vec& o) const { float s = v[0] * o.v[0]; for (int i = 1; i < N; ++i) s += v[i] * o.v[i]; return s; }
+  float squaredNorm() const { return dot(*this); }
+  float norm() const { return sqrtf(squaredNorm()); }
+  Vec cross(const Vec& o) const {
+    static_assert(N == 3, "");
+    return Vec(v[1] * o.v[2] - v[2] * o.v[1], v[2] * o.v[0] - v[0] * o.v[2], v[0] * o.v[1] - v[1] * o.v[0]);
+  }
+};
+template <int N> inline Vec<N> operator*(float s, const Vec<N>& a) { return a * s; }
+typedef Vec<2> Vector2f;
+typedef Vec<3> Vector3f;
+
+struct Matrix3f {
+  float m[9];  // row-major
+  Matrix3f() { for (int i = 0; i < 9; ++i) m[i] = 0.f; }
+  static Matrix3f Identity() { Matrix3f r; r.m[0] = r.m[4] = r.m[8] = 1.f; return r; }
+  float& operator()(int i, int j) { return m[3 * i + j]; }
+  float operator()(int i, int j) const { return m[3 * i + j]; }
+  Vector3f operator*(const Vector3f& p) const {
+    return Vector3f(m[0] * p(0) + m[1] * p(1) + m[2] * p(2), m[3] * p(0) + m[4] * p(1) + m[5] * p(2), m[6] * p(0) + m[7] * p(1) + m[8] * p(2));
+  }
+  Matrix3f operator*(const Matrix3f& o) const {
+    Matrix3f r;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) r.m[3 * i + j] = m[3 * i] * o.m[j] + m[3 * i + 1] * o.m[3 + j] + m[3 * i + 2] * o.m[6 + j];
+    return r;
+  }
+  Matrix3f transpose() const { Matrix3f r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[3 * i + j] = m[3 * j + i]; return r; }
+};
+
+struct Quaternionf {
+  float x, y, z, w;
+  Quaternionf() : x(0), y(0), z(0), w(1) {}
+  Quaternionf(float w_, float x_, float y_, float z_) : x(x_), y(y_), z(z_), w(w_) {}
+  Vector3f vec() const { return Vector3f(x, y, z); }
+  // QuaternionBase::_transformVector
+  Vector3f operator*(const Vector3f& p) const {
+    Vector3f uv = vec().cross(p);
+    uv = uv + uv;
+    return p + w * uv + vec().cross(uv);
+  }
+  // quaternion product (Eigen's internal::quat_product, scalar path)
+  Quaternionf operator*(const Quaternionf& b) const {
+    return Quaternionf(w * b.w - x * b.x - y * b.y - z * b.z, w * b.x + x * b.w + y * b.z - z * b.y,
+                       w * b.y + y * b.w + z * b.x - x * b.z, w * b.z + z * b.w + x * b.y - y * b.x);
+  }
+  Quaternionf conjugate() const { return Quaternionf(w, -x, -y, -z); }
+  float squaredNorm() const { return x * x + y * y + z * z + w * w; }
+  void normalize() { const float n = sqrtf(squaredNorm()); x /= n; y /= n; z /= n; w /= n; }
+  // QuaternionBase::toRotationMatrix
+  Matrix3f toRotationMatrix() const {
+    Matrix3f r;
+    const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
+                tzz = tz * z;
+    r(0, 0) = 1.f - (tyy + tzz); r(0, 1) = txy - twz; r(0, 2) = txz + twy;
+    r(1, 0) = txy + twz; r(1, 1) = 1.f - (txx + tzz); r(1, 2) = tyz - twx;
+    r(2, 0) = txz - twy; r(2, 1) = tyz + twx; r(2, 2) = 1.f - (txx + tyy);
+    return r;
+  }
+  // Quaternion(Matrix3) : internal::quaternionbase_assign_impl (Shepperd's method as Eigen writes it)
+  static Quaternionf FromMatrix(const Matrix3f& a) {
+    Quaternionf q;
+    float t = a(0, 0) + a(1, 1) + a(2, 2);
+    if (t > 0.f) {
+      t = sqrtf(t + 1.f);
+      q.w = 0.5f * t;
+      t = 0.5f / t;
+      q.x = (a(2, 1) - a(1, 2)) * t; q.y = (a(0, 2) - a(2, 0)) * t; q.z = (a(1, 0) - a(0, 1)) * t;
+    } else {
+      int i = 0;
+      if (a(1, 1) > a(0, 0)) i = 1;
+      if (a(2, 2) > a(i, i)) i = 2;
+      const int j = (i + 1) % 3, k = (j + 1) % 3;
+      t = sqrtf(a(i, i) - a(j, j) - a(k, k) + 1.f);
+      float c[3];
+      c[i] = 0.5f * t;
+      t = 0.5f / t;
+      q.w = (a(k, j) - a(j, k)) * t;
+      c[j] = (a(j, i) + a(i, j)) * t;
+      c[k] = (a(k, i) + a(i, k)) * t;
+      q.x = c[0]; q.y = c[1]; q.z = c[2];
+    }
+    return q;
+  }
+};
+}  // namespace Eigen
+
+namespace Sophus {
+template <class T> class SE3;
+template <> class SE3<float> {
+ public:
+  SE3() {}
+  SE3(const Eigen::Matrix3f& R, const Eigen::Vector3f& t) : q_(Eigen::Quaternionf::FromMatrix(R)), t_(t) { q_.normalize(); }
+  SE3(const Eigen::Quaternionf& q, const Eigen::Vector3f& t) : q_(q), t_(t) { q_.normalize(); }
+  const Eigen::Quaternionf& unit_quaternion() const { return q_; }
+  Eigen::Matrix3f rotationMatrix() const { return q_.toRotationMatrix(); }
+  const Eigen::Vector3f& translation() const { return t_; }
+  Eigen::Vector3f operator*(const Eigen::Vector3f& p) const { return q_ * p + t_; }
+  SE3 operator*(const SE3& o) const {
+    SE3 r;
+    r.q_ = q_ * o.q_;
+    // SO3 product: renormalise only when the squared norm drifted (Sophus so3.hpp operator*)
+    const float sn = r.q_.squaredNorm();
+    if (sn != 1.f) { const float s = 2.f / (1.f + sn); r.q_.x *= s; r.q_.y *= s; r.q_.z *= s; r.q_.w *= s; }
+    r.t_ = q_ * o.t_ + t_;
+    return r;
+  }
+  SE3 inverse() const {
+    SE3 r;
+    r.q_ = q_.conjugate();
+    r.t_ = r.q_ * (-t_);
+    return r;
+  }
+ private:
+  Eigen::Quaternionf q_;
+  Eigen::Vector3f t_;
+};
+typedef SE3<float> SE3f;
+
+template <class T> class Sim3;
+template <> class Sim3<float> {
+ public:
+  Sim3() : s_(1.f) {}
+  Sim3(float s, const Eigen::Quaternionf& q, const Eigen::Vector3f& t) : q_(q), t_(t), s_(s) {}
+  Eigen::Matrix3f rotationMatrix() const { return q_.toRotationMatrix(); }
+  const Eigen::Vector3f& translation() const { return t_; }
+  float scale() const { return s_; }
+  Eigen::Vector3f operator*(const Eigen::Vector3f& p) const { return s_ * (q_ * p) + t_; }
+  Sim3 inverse() const {
+    Sim3 r;
+    r.q_ = q_.conjugate();
+    r.s_ = 1.f / s_;
+    r.t_ = -(r.s_ * (r.q_ * t_));
+    return r;
+  }
+ private:
+  Eigen::Quaternionf q_;
+  Eigen::Vector3f t_;
+  float s_;
+};
+typedef Sim3<float> Sim3f;
+}  // namespace Sophus

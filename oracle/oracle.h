@@ -9,10 +9,10 @@
  * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path and cannot be
  * built here (needs OpenCV/Eigen/Pangolin/Boost; none installed, no network).  The oracle is pinned only
  * by (a) hand-derived known-answer tests (tests/test_oracle_kat.py), (b) the live glibc for sinf/cosf
- * and (c) oracle/_ref: the reference's own ORBextractor.cc and DepthModule.cc compiled unmodified against a
- * minimal cv-compat header whose OpenCV primitives are restatements (pins everything that is NOT
- * OpenCV-internal: cell loop, quad-tree, orientation, steering, packing; settings parsing, projection loop,
- * up-sampling chains, keypoint depth).  The ORBmatcher paths have known-answer tests only.
+ * and (c) oracle/_ref: the reference's own ORBextractor.cc, DepthModule.cc and ORBmatcher.cc compiled unmodified
+ * against minimal stand-ins for OpenCV / Eigen / Sophus / the SLAM data classes (pins everything that is NOT
+ * library-internal: cell loop, quad-tree, orientation, steering, packing; settings parsing, projection loop,
+ * up-sampling chains, keypoint depth; the matchers' candidate order, masks, thresholds and tie rules).
  */
 #ifndef RGBL_ORACLE_H
 #define RGBL_ORACLE_H

@@ -1,0 +1,174 @@
+// ref_matcher_glue.cpp — bodies of the stand-in classes of cvcompat/orbslam_types.h plus C entry points around the
+// reference's OWN ORB_SLAM3::ORBmatcher, compiled from /root/reference/src/ORBmatcher.cc (unmodified, where it lies).
+// TEST INFRASTRUCTURE (oracle/Makefile target `ref`).
+#include <math.h>
+#include <string.h>
+
+#include "ORBmatcher.h"  // /root/reference/include (orbslam_types.h is force-included in front of it)
+#include "oracle.h"
+
+namespace ORB_SLAM3 {
+
+float Frame::mnMinX = 0, Frame::mnMinY = 0, Frame::mnMaxX = 0, Frame::mnMaxY = 0;
+
+// Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:107-129); the fundamental matrix through the oracle's
+// restatement of K1^-T [t12]x R12 K2^-1
+bool GeometricCamera::epipolarConstrain(GeometricCamera* other, const cv::KeyPoint& kp1, const cv::KeyPoint& kp2,
+                                        const Eigen::Matrix3f& R12, const Eigen::Vector3f& t12, const float sigmaLevel,
+                                        const float unc) {
+  const float K1[4] = {fx, fy, cx, cy}, K2[4] = {other->fx, other->fy, other->cx, other->cy};
+  float F12[9];
+  orc_fundamental(K1, K2, R12.m, t12.v, F12);
+  const float a = kp1.pt.x * F12[0] + kp1.pt.y * F12[3] + F12[6];
+  const float b = kp1.pt.x * F12[1] + kp1.pt.y * F12[4] + F12[7];
+  const float c = kp1.pt.x * F12[2] + kp1.pt.y * F12[5] + F12[8];
+  const float num = a * kp2.pt.x + b * kp2.pt.y + c;
+  const float den = a * a + b * b;
+  if (den == 0) return false;
+  const float dsqr = num * num / den;
+  return dsqr < 3.84 * unc;
+}
+
+// MapPoint::PredictScale (src/MapPoint.cc:514-546)
+int MapPoint::PredictScale(const float& currentDist, KeyFrame* pKF) {
+  const float ratio = mfMaxDistance / currentDist;
+  int nScale = ceil(log(ratio) / pKF->mfLogScaleFactor);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= pKF->mnScaleLevels) nScale = pKF->mnScaleLevels - 1;
+  return nScale;
+}
+int MapPoint::PredictScale(const float& currentDist, Frame* pF) {
+  const float ratio = mfMaxDistance / currentDist;
+  int nScale = ceil(log(ratio) / pF->mfLogScaleFactor);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+  return nScale;
+}
+
+// Frame::AssignFeaturesToGrid + PosInGrid (src/Frame.cc:475-506, 815-825)
+void FeatureGrid::Build(const std::vector<cv::KeyPoint>& keysUn) {
+  for (int i = 0; i < FRAME_GRID_COLS; ++i)
+    for (int j = 0; j < FRAME_GRID_ROWS; ++j) cells[i][j].clear();
+  for (size_t i = 0; i < keysUn.size(); ++i) {
+    const cv::KeyPoint& kp = keysUn[i];
+    const int posX = round((kp.pt.x - mnMinX) * mfGridElementWidthInv);
+    const int posY = round((kp.pt.y - mnMinY) * mfGridElementHeightInv);
+    if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) continue;
+    cells[posX][posY].push_back(i);
+  }
+}
+
+// Frame::GetFeaturesInArea (src/Frame.cc:747-813); KeyFrame::GetFeaturesInArea (src/KeyFrame.cc) is the same walk
+// without the level test
+std::vector<size_t> FeatureGrid::Query(const std::vector<cv::KeyPoint>& keysUn, float x, float y, float r, int minLevel,
+                                       int maxLevel) const {
+  std::vector<size_t> vIndices;
+  const float factorX = r, factorY = r;
+  const int nMinCellX = std::max(0, (int)floor((x - mnMinX - factorX) * mfGridElementWidthInv));
+  if (nMinCellX >= FRAME_GRID_COLS) return vIndices;
+  const int nMaxCellX = std::min((int)FRAME_GRID_COLS - 1, (int)ceil((x - mnMinX + factorX) * mfGridElementWidthInv));
+  if (nMaxCellX < 0) return vIndices;
+  const int nMinCellY = std::max(0, (int)floor((y - mnMinY - factorY) * mfGridElementHeightInv));
+  if (nMinCellY >= FRAME_GRID_ROWS) return vIndices;
+  const int nMaxCellY = std::min((int)FRAME_GRID_ROWS - 1, (int)ceil((y - mnMinY + factorY) * mfGridElementHeightInv));
+  if (nMaxCellY < 0) return vIndices;
+  const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+    for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+      const std::vector<size_t>& vCell = cells[ix][iy];
+      for (size_t j = 0, jend = vCell.size(); j < jend; j++) {
+        const cv::KeyPoint& kpUn = keysUn[vCell[j]];
+        if (bCheckLevels) {
+          if (kpUn.octave < minLevel) continue;
+          if (maxLevel >= 0)
+            if (kpUn.octave > maxLevel) continue;
+        }
+        const float distx = kpUn.pt.x - x, disty = kpUn.pt.y - y;
+        if (fabs(distx) < factorX && fabs(disty) < factorY) vIndices.push_back(vCell[j]);
+      }
+    }
+  return vIndices;
+}
+
+}  // namespace ORB_SLAM3
+
+using namespace ORB_SLAM3;
+
+namespace {
+struct KfArrays {  // one key-frame as flat arrays (the layout of orc_tri_input / rgbl_keyframe_view)
+  int n;
+  const uint8_t* desc;
+  const float* kp_xy;
+  const int* kp_octave;
+  const float* kp_angle;
+  const float* uright;
+  const uint8_t* has_mp;
+  int nnodes;
+  const int *node_id, *node_off, *node_feat;
+};
+
+void fill_keyframe(KeyFrame& kf, const KfArrays& a, GeometricCamera* cam, MapPoint* some, const float* scale_factors,
+                   const float* level_sigma2, int n_levels, const float q[4], const float t[3]) {
+  kf.N = a.n;
+  kf.mpCamera = cam;
+  kf.fx = cam->fx; kf.fy = cam->fy; kf.cx = cam->cx; kf.cy = cam->cy;
+  kf.mDescriptors = cv::Mat(a.n, 32, CV_8U);
+  if (a.n) memcpy(kf.mDescriptors.data, a.desc, (size_t)a.n * 32);
+  kf.mvKeysUn.resize(a.n);
+  kf.mvuRight.assign(a.uright, a.uright + a.n);
+  kf.mvpMapPoints.resize(a.n);
+  for (int i = 0; i < a.n; ++i) {
+    kf.mvKeysUn[i].pt.x = a.kp_xy[2 * i];
+    kf.mvKeysUn[i].pt.y = a.kp_xy[2 * i + 1];
+    kf.mvKeysUn[i].octave = a.kp_octave[i];
+    kf.mvKeysUn[i].angle = a.kp_angle[i];
+    kf.mvpMapPoints[i] = a.has_mp[i] ? some : nullptr;
+  }
+  for (int k = 0; k < a.nnodes; ++k)
+    kf.mFeatVec[(unsigned)a.node_id[k]] = std::vector<unsigned>(a.node_feat + a.node_off[k], a.node_feat + a.node_off[k + 1]);
+  kf.mvScaleFactors.assign(scale_factors, scale_factors + n_levels);
+  kf.mvLevelSigma2.assign(level_sigma2, level_sigma2 + n_levels);
+  kf.mTcw = Sophus::SE3f(Eigen::Quaternionf(q[3], q[0], q[1], q[2]), Eigen::Vector3f(t[0], t[1], t[2]));
+  kf.mTwc = kf.mTcw.inverse();
+}
+}  // namespace
+
+extern "C" {
+
+int ref_descriptor_distance(const uint8_t* a, const uint8_t* b) {
+  cv::Mat ma(1, 32, CV_8U), mb(1, 32, CV_8U);
+  memcpy(ma.data, a, 32);
+  memcpy(mb.data, b, 32);
+  return ORBmatcher::DescriptorDistance(ma, mb);
+}
+
+// ORBmatcher(nnratio, checkOri).SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse).
+// Poses as unit quaternion (x, y, z, w) + translation of Tcw.  Besides the pairs it returns what the function derives
+// from the poses with the stand-in SE3 arithmetic (R12, t12, the epipole), so that the restated oracle can be run on
+// identical inputs.
+int ref_search_triangulation(const KfArrays* a1, const KfArrays* a2, const float K[4], const float* scale_factors,
+                             const float* level_sigma2, int n_levels, const float q1[4], const float t1[3], const float q2[4],
+                             const float t2[3], int only_stereo, int coarse, int check_orientation, int* matches12,
+                             float out_R12[9], float out_t12[3], float out_ep[2]) {
+  GeometricCamera cam;
+  cam.fx = K[0]; cam.fy = K[1]; cam.cx = K[2]; cam.cy = K[3];
+  MapPoint some;
+  KeyFrame kf1, kf2;
+  fill_keyframe(kf1, *a1, &cam, &some, scale_factors, level_sigma2, n_levels, q1, t1);
+  fill_keyframe(kf2, *a2, &cam, &some, scale_factors, level_sigma2, n_levels, q2, t2);
+  ORBmatcher matcher(0.6f, check_orientation != 0);
+  std::vector<std::pair<size_t, size_t> > pairs;
+  const int nm = matcher.SearchForTriangulation(&kf1, &kf2, pairs, only_stereo != 0, coarse != 0);
+  for (int i = 0; i < a1->n; ++i) matches12[i] = -1;
+  for (const auto& pr : pairs) matches12[pr.first] = (int)pr.second;
+  // the same expressions as ORBmatcher.cc:914-931
+  const Sophus::SE3f T12 = kf1.GetPose() * kf2.GetPoseInverse();
+  const Eigen::Matrix3f R12 = T12.rotationMatrix();
+  memcpy(out_R12, R12.m, sizeof(float) * 9);
+  memcpy(out_t12, T12.translation().v, sizeof(float) * 3);
+  const Eigen::Vector2f ep = cam.project(kf2.GetPose() * kf1.GetCameraCenter());
+  out_ep[0] = ep(0); out_ep[1] = ep(1);
+  return nm;
+}
+
+}  // extern "C"

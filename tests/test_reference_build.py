@@ -205,3 +205,86 @@ def test_reference_depthmodule_parse_failures_match_the_shim_rules(refdepth, tmp
         rc, *_ = R(synth.lidar_scan(0, 4, 50), 64, 48, xy, un)
         assert rc == -1          # disabled module / method None: no keypoint depth is produced
     R.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's own src/ORBmatcher.cc (oracle/_ref/libref_orbmatcher.so; MapPoint / KeyFrame / Frame / Sophus / DBoW2
+# are the plain stand-ins of oracle/cvcompat/orbslam_types.h) versus the restated oracle.
+REF_MATCHER_SO = os.path.join(ROOT, "oracle", "_ref", "libref_orbmatcher.so")
+
+
+class KfArrays(C.Structure):
+    _fields_ = [("n", C.c_int), ("desc", C.c_void_p), ("kp_xy", C.c_void_p), ("kp_octave", C.c_void_p), ("kp_angle", C.c_void_p),
+                ("uright", C.c_void_p), ("has_mp", C.c_void_p), ("nnodes", C.c_int), ("node_id", C.c_void_p),
+                ("node_off", C.c_void_p), ("node_feat", C.c_void_p)]
+
+
+@pytest.fixture(scope="module")
+def refmatcher(oracle):
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    if not os.path.exists(REF_MATCHER_SO):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    lib = C.CDLL(REF_MATCHER_SO)
+    lib.ref_descriptor_distance.restype = C.c_int
+    lib.ref_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ref_search_triangulation.restype = C.c_int
+    lib.ref_search_triangulation.argtypes = [C.POINTER(KfArrays), C.POINTER(KfArrays)] + [C.c_void_p] * 3 + [C.c_int] + \
+        [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p] * 4
+    return lib
+
+
+def kf_arrays(kf, keep):
+    a = KfArrays()
+    def arr(v, dt):
+        x = np.ascontiguousarray(v, dt)
+        keep.append(x)
+        return x.ctypes.data
+    a.n = len(kf["desc"])
+    a.desc, a.kp_xy = arr(kf["desc"], np.uint8), arr(kf["xy"], np.float32)
+    a.kp_octave, a.kp_angle = arr(kf["octave"], np.int32), arr(kf["angle"], np.float32)
+    a.uright, a.has_mp = arr(kf["uright"], np.float32), arr(kf["has_mp"], np.uint8)
+    a.nnodes = len(kf["node_id"])
+    a.node_id, a.node_off, a.node_feat = arr(kf["node_id"], np.int32), arr(kf["node_off"], np.int32), arr(kf["node_feat"], np.int32)
+    return a
+
+
+def test_reference_descriptor_distance(refmatcher):
+    from orb_slam3_rgbl_amd import synth as S
+    a = S.descriptors(300, 5)
+    b, _ = S.perturbed_descriptors(a, flip_p=0.2, seed=6)
+    for i in range(300):
+        assert refmatcher.ref_descriptor_distance(a[i].ctypes.data, b[i].ctypes.data) == O.descriptor_distance(a[i], b[i])
+    z, f = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    assert refmatcher.ref_descriptor_distance(z.ctypes.data, f.ctypes.data) == 256
+    assert refmatcher.ref_descriptor_distance(f.ctypes.data, f.ctypes.data) == 0
+
+
+@pytest.mark.parametrize("seed,only_stereo,coarse,check_ori", [
+    (11, False, False, False),    # LocalMapping::CreateNewMapPoints calls it like this (ORBmatcher(0.6, false))
+    (12, False, True, False),     # bCoarse: no epipolar test
+    (13, True, False, False),     # bOnlyStereo
+    (14, False, False, True),     # orientation histogram on (dead code in the reference's callers, alive in the function)
+    (15, True, True, True),
+])
+def test_reference_search_for_triangulation_agrees_with_oracle(refmatcher, seed, only_stereo, coarse, check_ori):
+    import parity_checks as pc
+    kf1, kf2, Kc, _, _, _, sf, s2 = pc.make_triangulation_case(1200, seed=seed)
+    keep = []
+    a1, a2 = kf_arrays(kf1, keep), kf_arrays(kf2, keep)
+    # camera 1 at the origin; camera 2 rotated a little and placed so that camera 1 projects into image 2 (epipole guard active)
+    ang = 0.03
+    q1, t1 = np.array([0, 0, 0, 1], np.float32), np.zeros(3, np.float32)
+    q2 = np.array([0, np.sin(ang / 2), 0, np.cos(ang / 2)], np.float32)
+    t2 = np.array([-0.3, 0.01, 1.0], np.float32)
+    m = np.zeros(a1.n, np.int32)
+    R12, t12, ep = np.zeros(9, np.float32), np.zeros(3, np.float32), np.zeros(2, np.float32)
+    nm = refmatcher.ref_search_triangulation(C.byref(a1), C.byref(a2), Kc.ctypes.data, sf.ctypes.data, s2.ctypes.data, 8,
+                                             q1.ctypes.data, t1.ctypes.data, q2.ctypes.data, t2.ctypes.data, int(only_stereo),
+                                             int(coarse), int(check_ori), m.ctypes.data, R12.ctypes.data, t12.ctypes.data,
+                                             ep.ctypes.data)
+    assert 0 < ep[0] < 1241 and 0 < ep[1] < 376
+    F = O.fundamental(Kc, Kc, R12, t12)
+    om, onm = O.search_triangulation(kf1, kf2, F, ep, sf, s2, only_stereo, coarse, check_ori)
+    assert nm == onm and np.array_equal(m, om)
+    assert nm > 5
