@@ -311,6 +311,40 @@ typedef struct {
 int rgbl_search_triangulation(rgbl_matcher* h, const rgbl_keyframe_view* kf1,
                               const rgbl_keyframe_view* kf2, const rgbl_triangulation_params* prm,
                               int32_t* matches12, int* out_nmatches);
+/* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono)
+ * (include/ORBmatcher.h:48, src/ORBmatcher.cc:1676-1887; callers Tracking::TrackWithMotionModel, src/Tracking.cc:2917-2934):
+ * the matcher that runs on every tracked frame.  Single-camera frames (Nleft == -1: RGB-L, RGB-D, stereo, mono pinhole).
+ * Includes Frame::GetFeaturesInArea / AssignFeaturesToGrid / PosInGrid (src/Frame.cc:747-825, 475-506).  SURVEY.md 8(f) row f2.
+ * CurrentFrame.mvpMapPoints is expected to be all NULL on entry, as Tracking.cc:2913 leaves it. */
+typedef struct {
+  int n1;                      /* LastFrame.N */
+  const uint8_t* valid1;       /* LastFrame.mvpMapPoints[i] != NULL && !LastFrame.mvbOutlier[i] */
+  const float* world_pos1;     /* pMP->GetWorldPos(), 3 floats per feature */
+  const uint8_t* mp_desc1;     /* pMP->GetDescriptor(), 32 bytes per feature */
+  const uint8_t* mp_observed1; /* pMP->Observations() > 0: such a point blocks the feature it is assigned to (:1745-1747) */
+  const int32_t* octave1;      /* LastFrame.mvKeys[i].octave */
+  const float* angle1;         /* LastFrame.mvKeysUn[i].angle */
+  int n2;                      /* CurrentFrame.N (<= 65535) */
+  const float* kp2_xy;         /* CurrentFrame.mvKeysUn[i].pt */
+  const int32_t* kp2_octave;
+  const float* kp2_angle;
+  const float* uright2;        /* CurrentFrame.mvuRight */
+  const uint8_t* desc2;        /* CurrentFrame.mDescriptors */
+  float grid[6];               /* Frame::mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv */
+  float Tcw_q[4], Tcw_t[3];    /* CurrentFrame.GetPose(): unit_quaternion() as (x, y, z, w), translation() */
+  float Tlw_q[4], Tlw_t[3];    /* LastFrame.GetPose() */
+  float K[4];                  /* fx, fy, cx, cy of CurrentFrame.mpCamera (Pinhole::project) */
+  float mb, mbf;               /* CurrentFrame.mb, mbf */
+  const float* scale_factors;  /* CurrentFrame.mvScaleFactors */
+  int n_levels;
+  float th;
+  int mono;                    /* bMono */
+  int check_orientation;       /* mbCheckOrientation */
+} rgbl_projection_input;
+/* Host pointers, synchronous.  match2 has n2 entries: the index of the LastFrame feature whose map point the call leaves
+ * in CurrentFrame.mvpMapPoints[i2], or -1.  *out_nmatches = return value of the reference function. */
+int rgbl_search_by_projection(rgbl_matcher* h, const rgbl_projection_input* in, int32_t* match2, int* out_nmatches);
+
 /* F12 with the reference's fp32 evaluation order (Pinhole.cpp:109-112); K = {fx, fy, cx, cy}. Host. */
 void rgbl_fundamental(const float K1[4], const float K2[4], const float R12[9], const float t12[3],
                       float F12[9]);

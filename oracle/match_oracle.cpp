@@ -14,6 +14,7 @@
 namespace {
 const int TH_LOW = 50;
 const int HISTO_LENGTH = 30;
+const int TH_HIGH = 100;  // ORBmatcher.cc:35
 
 inline int hamming256(const uint8_t* a, const uint8_t* b) {
   // the reference's SWAR bit count over 8 little-endian 32-bit words
@@ -185,4 +186,117 @@ extern "C" void orc_std_sort_pairs(uint64_t* key, uint32_t* val, int n) {
   std::sort(v.begin(), v.end(),
             [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a.first < b.first; });
   for (int i = 0; i < n; ++i) { key[i] = v[i].first; val[i] = v[i].second; }
+}
+
+// ---- ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), /root/reference/src/ORBmatcher.cc:1676-1887 ----
+// (single camera, Nleft == -1) with Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea (src/Frame.cc:475-506,
+// 815-825, 747-813) and the Eigen / Sophus arithmetic spelled out: SE3f * p = q._transformVector(p) + t,
+// inverse().translation() = q^-1 * (-t).  fp32, no contraction.
+namespace {
+struct V3 { float x, y, z; };
+inline V3 cross(const V3& a, const V3& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline V3 quat_rotate(const float q[4], const V3& p) {  // q = (x, y, z, w); Eigen QuaternionBase::_transformVector
+  const V3 u = {q[0], q[1], q[2]};
+  V3 uv = cross(u, p);
+  uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
+  const V3 c = cross(u, uv);
+  return {p.x + q[3] * uv.x + c.x, p.y + q[3] * uv.y + c.y, p.z + q[3] * uv.z + c.z};
+}
+inline V3 se3_apply(const float q[4], const float t[3], const V3& p) {
+  const V3 r = quat_rotate(q, p);
+  return {r.x + t[0], r.y + t[1], r.z + t[2]};
+}
+}  // namespace
+
+extern "C" int orc_search_by_projection(const orc_projection_input* in, int* match2) {
+  const int COLS = 64, ROWS = 48;  // FRAME_GRID_COLS / FRAME_GRID_ROWS (Frame.h:46-47)
+  const float mnMinX = in->grid[0], mnMinY = in->grid[1], mnMaxX = in->grid[2], mnMaxY = in->grid[3];
+  const float invW = in->grid[4], invH = in->grid[5];
+  // AssignFeaturesToGrid
+  std::vector<std::vector<int>> cells((size_t)COLS * ROWS);
+  for (int i = 0; i < in->n2; ++i) {
+    const int px = (int)roundf((in->kp2_xy[2 * i] - mnMinX) * invW), py = (int)roundf((in->kp2_xy[2 * i + 1] - mnMinY) * invH);
+    if (px < 0 || px >= COLS || py < 0 || py >= ROWS) continue;
+    cells[(size_t)px * ROWS + py].push_back(i);
+  }
+  // twc = Tcw.inverse().translation(); tlc = Tlw * twc
+  const float qinv[4] = {-in->Tcw_q[0], -in->Tcw_q[1], -in->Tcw_q[2], in->Tcw_q[3]};
+  const V3 twc = quat_rotate(qinv, V3{-in->Tcw_t[0], -in->Tcw_t[1], -in->Tcw_t[2]});
+  const V3 tlc = se3_apply(in->Tlw_q, in->Tlw_t, twc);
+  const bool bForward = tlc.z > in->mb && !in->mono;
+  const bool bBackward = -tlc.z > in->mb && !in->mono;
+
+  std::vector<int> holder(in->n2, -1);  // CurrentFrame.mvpMapPoints as "index of the LastFrame feature" (all NULL on entry)
+  std::vector<int> rot_hist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  int nmatches = 0;
+  for (int i = 0; i < in->n1; ++i) {
+    if (!in->valid1[i]) continue;
+    const V3 xw = {in->world_pos1[3 * i], in->world_pos1[3 * i + 1], in->world_pos1[3 * i + 2]};
+    const V3 xc = se3_apply(in->Tcw_q, in->Tcw_t, xw);
+    const float invzc = (float)(1.0 / (double)xc.z);
+    if (invzc < 0) continue;
+    const float u = in->K[0] * xc.x / xc.z + in->K[2], v = in->K[1] * xc.y / xc.z + in->K[3];  // Pinhole::project
+    if (u < mnMinX || u > mnMaxX) continue;
+    if (v < mnMinY || v > mnMaxY) continue;
+    const int oct = in->octave1[i];
+    const float radius = in->th * in->scale_factors[oct];
+    int minLevel, maxLevel;
+    if (bForward) { minLevel = oct; maxLevel = -1; }
+    else if (bBackward) { minLevel = 0; maxLevel = oct; }
+    else { minLevel = oct - 1; maxLevel = oct + 1; }
+    // GetFeaturesInArea
+    if (!(u == u) || !(v == v)) continue;  // NaN: the cell range is empty on every platform we know of
+    const int nMinCellX = std::max(0, (int)floorf((u - mnMinX - radius) * invW));
+    if (nMinCellX >= COLS) continue;
+    const int nMaxCellX = std::min(COLS - 1, (int)ceilf((u - mnMinX + radius) * invW));
+    if (nMaxCellX < 0) continue;
+    const int nMinCellY = std::max(0, (int)floorf((v - mnMinY - radius) * invH));
+    if (nMinCellY >= ROWS) continue;
+    const int nMaxCellY = std::min(ROWS - 1, (int)ceilf((v - mnMinY + radius) * invH));
+    if (nMaxCellY < 0) continue;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    int bestDist = 256, bestIdx2 = -1;
+    const uint8_t* dMP = in->mp_desc1 + 32 * (size_t)i;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+      for (int iy = nMinCellY; iy <= nMaxCellY; ++iy)
+        for (int i2 : cells[(size_t)ix * ROWS + iy]) {
+          if (bCheckLevels) {
+            if (in->kp2_octave[i2] < minLevel) continue;
+            if (maxLevel >= 0 && in->kp2_octave[i2] > maxLevel) continue;
+          }
+          const float distx = in->kp2_xy[2 * i2] - u, disty = in->kp2_xy[2 * i2 + 1] - v;
+          if (!(fabsf(distx) < radius && fabsf(disty) < radius)) continue;
+          // a feature holding a map point with observations is taken (ORBmatcher.cc:1745-1747)
+          if (holder[i2] >= 0 && in->mp_observed1[holder[i2]]) continue;
+          if (in->uright2[i2] > 0) {
+            const float ur = u - in->mbf * invzc;
+            const float er = fabsf(ur - in->uright2[i2]);
+            if (er > radius) continue;
+          }
+          const int dist = hamming256(dMP, in->desc2 + 32 * (size_t)i2);
+          if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+    if (bestDist <= TH_HIGH) {
+      holder[bestIdx2] = i;
+      ++nmatches;
+      if (in->check_orientation) {
+        float rot = in->angle1[i] - in->kp2_angle[bestIdx2];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rot_hist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (in->check_orientation) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    three_maxima(rot_hist, HISTO_LENGTH, i1, i2, i3);
+    for (int i = 0; i < HISTO_LENGTH; ++i) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int idx2 : rot_hist[i]) { holder[idx2] = -1; --nmatches; }  // a feature listed twice is counted twice
+    }
+  }
+  for (int i = 0; i < in->n2; ++i) match2[i] = holder[i];
+  return nmatches;
 }

@@ -138,6 +138,38 @@ typedef struct {
 /* ORBmatcher::SearchForTriangulation (ORBmatcher.cc:907-1146): fills matches12[n1] (-1 = none),
  * returns nmatches. */
 int orc_search_triangulation(const orc_tri_input*, int* matches12);
+
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+ * (/root/reference/src/ORBmatcher.cc:1676-1887, single-camera case Nleft == -1) with
+ * Frame::GetFeaturesInArea / AssignFeaturesToGrid / PosInGrid (src/Frame.cc:747-825, 475-506).  Flat arrays: */
+typedef struct {
+  int n1;                      /* LastFrame.N */
+  const uint8_t* valid1;       /* mvpMapPoints[i] != NULL && !mvbOutlier[i] */
+  const float* world_pos1;     /* pMP->GetWorldPos(), 3 floats per feature */
+  const uint8_t* mp_desc1;     /* pMP->GetDescriptor(), 32 bytes per feature */
+  const uint8_t* mp_observed1; /* pMP->Observations() > 0 (such a point blocks the feature it is assigned to) */
+  const int32_t* octave1;      /* LastFrame.mvKeys[i].octave */
+  const float* angle1;         /* LastFrame.mvKeysUn[i].angle */
+  int n2;                      /* CurrentFrame.N */
+  const float* kp2_xy;         /* CurrentFrame.mvKeysUn[i].pt */
+  const int32_t* kp2_octave;
+  const float* kp2_angle;
+  const float* uright2;        /* CurrentFrame.mvuRight */
+  const uint8_t* desc2;        /* CurrentFrame.mDescriptors */
+  float grid[6];               /* mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv */
+  float Tcw_q[4], Tcw_t[3];    /* CurrentFrame.GetPose(): unit quaternion (x, y, z, w) and translation */
+  float Tlw_q[4], Tlw_t[3];    /* LastFrame.GetPose() */
+  float K[4];                  /* fx, fy, cx, cy of CurrentFrame.mpCamera (Pinhole) */
+  float mb, mbf;
+  const float* scale_factors;  /* CurrentFrame.mvScaleFactors */
+  int n_levels;
+  float th;
+  int mono;                    /* bMono */
+  int check_orientation;       /* mbCheckOrientation */
+} orc_projection_input;
+/* match2[i2] = index of the LastFrame feature whose map point ends up in CurrentFrame.mvpMapPoints[i2], or -1.
+ * Returns nmatches exactly as the reference counts it. */
+int orc_search_by_projection(const orc_projection_input* in, int* match2);
 /* F12 = K1^-T [t]x R12 K2^-1 with Eigen's evaluation order in fp32 */
 void orc_fundamental(const float K1[4], const float K2[4], const float R12[9], const float t12[3],
                      float F12[9]);

@@ -27,6 +27,49 @@ class DepthParams(C.Structure):
                 ("kernel", C.c_uint8 * 81), ("avg_ksize", C.c_int), ("nn_radius", C.c_float)]
 
 
+class ProjectionInput(C.Structure):
+    """orc_projection_input == rgbl_projection_input (same layout)."""
+    _fields_ = [("n1", C.c_int), ("valid1", C.c_void_p), ("world_pos1", C.c_void_p), ("mp_desc1", C.c_void_p),
+                ("mp_observed1", C.c_void_p), ("octave1", C.c_void_p), ("angle1", C.c_void_p),
+                ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p), ("kp2_angle", C.c_void_p),
+                ("uright2", C.c_void_p), ("desc2", C.c_void_p), ("grid", C.c_float * 6),
+                ("Tcw_q", C.c_float * 4), ("Tcw_t", C.c_float * 3), ("Tlw_q", C.c_float * 4), ("Tlw_t", C.c_float * 3),
+                ("K", C.c_float * 4), ("mb", C.c_float), ("mbf", C.c_float), ("scale_factors", C.c_void_p),
+                ("n_levels", C.c_int), ("th", C.c_float), ("mono", C.c_int), ("check_orientation", C.c_int)]
+
+
+def make_projection_input(case, th, mono, check_orientation, keep):
+    """case: dict from tests/parity_checks.make_projection_case; keep: list that keeps the arrays alive."""
+    def arr(v, dt):
+        a = np.ascontiguousarray(v, dt)
+        keep.append(a)
+        return a.ctypes.data
+    P = ProjectionInput()
+    P.n1 = len(case["valid1"])
+    P.valid1, P.world_pos1 = arr(case["valid1"], np.uint8), arr(case["world_pos1"], np.float32)
+    P.mp_desc1, P.mp_observed1 = arr(case["mp_desc1"], np.uint8), arr(case["mp_observed1"], np.uint8)
+    P.octave1, P.angle1 = arr(case["octave1"], np.int32), arr(case["angle1"], np.float32)
+    P.n2 = len(case["kp2_xy"])
+    P.kp2_xy, P.kp2_octave = arr(case["kp2_xy"], np.float32), arr(case["kp2_octave"], np.int32)
+    P.kp2_angle, P.uright2, P.desc2 = arr(case["kp2_angle"], np.float32), arr(case["uright2"], np.float32), arr(case["desc2"], np.uint8)
+    for name, n in (("grid", 6), ("Tcw_q", 4), ("Tcw_t", 3), ("Tlw_q", 4), ("Tlw_t", 3), ("K", 4)):
+        for i in range(n):
+            getattr(P, name)[i] = float(case[name][i])
+    P.mb, P.mbf = float(case["mb"]), float(case["mbf"])
+    P.scale_factors = arr(case["scale_factors"], np.float32)
+    P.n_levels = len(case["scale_factors"])
+    P.th, P.mono, P.check_orientation = float(th), int(mono), int(check_orientation)
+    return P
+
+
+def search_by_projection(case, th=7.0, mono=False, check_orientation=True):
+    keep = []
+    P = make_projection_input(case, th, mono, check_orientation, keep)
+    m = np.zeros(P.n2, np.int32)
+    n = lib().orc_search_by_projection(C.byref(P), _p(m))
+    return m, n
+
+
 class TriInput(C.Structure):
     _fields_ = [("n1", C.c_int), ("n2", C.c_int),
                 ("desc1", C.c_void_p), ("desc2", C.c_void_p),
@@ -76,6 +119,8 @@ def lib():
         L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_kitti_bin_to_cloud.restype = None
         L.orc_kitti_bin_to_cloud.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_search_by_projection.restype = C.c_int
+        L.orc_search_by_projection.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_fast.restype = C.c_int
         L.orc_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_fast_corner_score.restype = C.c_int

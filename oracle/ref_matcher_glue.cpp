@@ -172,3 +172,53 @@ int ref_search_triangulation(const KfArrays* a1, const KfArrays* a2, const float
 }
 
 }  // extern "C"
+
+// ORBmatcher(0.9, checkOri).SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1676-1887), single camera.
+// The flat layout is orc_projection_input's; one MapPoint object per valid LastFrame feature.
+extern "C" int ref_search_by_projection(const orc_projection_input* in, int* match2) {
+  GeometricCamera cam;
+  cam.fx = in->K[0]; cam.fy = in->K[1]; cam.cx = in->K[2]; cam.cy = in->K[3];
+  Frame last, cur;
+  std::vector<MapPoint> points(in->n1);
+  last.N = in->n1;
+  last.mvKeys.resize(in->n1); last.mvKeysUn.resize(in->n1);
+  last.mvpMapPoints.assign(in->n1, nullptr);
+  last.mvbOutlier.assign(in->n1, false);
+  for (int i = 0; i < in->n1; ++i) {
+    last.mvKeys[i].octave = last.mvKeysUn[i].octave = in->octave1[i];
+    last.mvKeys[i].angle = last.mvKeysUn[i].angle = in->angle1[i];
+    if (!in->valid1[i]) continue;
+    MapPoint& mp = points[i];
+    mp.mWorldPos = Eigen::Vector3f(in->world_pos1[3 * i], in->world_pos1[3 * i + 1], in->world_pos1[3 * i + 2]);
+    mp.mDescriptor = cv::Mat(1, 32, CV_8U);
+    memcpy(mp.mDescriptor.data, in->mp_desc1 + 32 * (size_t)i, 32);
+    mp.nObs = in->mp_observed1[i] ? 3 : 0;
+    last.mvpMapPoints[i] = &mp;
+  }
+  last.mTcw = Sophus::SE3f(Eigen::Quaternionf(in->Tlw_q[3], in->Tlw_q[0], in->Tlw_q[1], in->Tlw_q[2]),
+                           Eigen::Vector3f(in->Tlw_t[0], in->Tlw_t[1], in->Tlw_t[2]));
+  cur.N = in->n2;
+  cur.mpCamera = &cam;
+  cur.mb = in->mb; cur.mbf = in->mbf;
+  cur.mvKeysUn.resize(in->n2);
+  for (int i = 0; i < in->n2; ++i) {
+    cur.mvKeysUn[i].pt.x = in->kp2_xy[2 * i]; cur.mvKeysUn[i].pt.y = in->kp2_xy[2 * i + 1];
+    cur.mvKeysUn[i].octave = in->kp2_octave[i]; cur.mvKeysUn[i].angle = in->kp2_angle[i];
+  }
+  cur.mvKeys = cur.mvKeysUn;
+  cur.mvuRight.assign(in->uright2, in->uright2 + in->n2);
+  cur.mDescriptors = cv::Mat(in->n2, 32, CV_8U);
+  if (in->n2) memcpy(cur.mDescriptors.data, in->desc2, (size_t)in->n2 * 32);
+  cur.mvScaleFactors.assign(in->scale_factors, in->scale_factors + in->n_levels);
+  cur.mvpMapPoints.assign(in->n2, nullptr);  // Tracking::TrackWithMotionModel clears them before the call (Tracking.cc:2913)
+  cur.mTcw = Sophus::SE3f(Eigen::Quaternionf(in->Tcw_q[3], in->Tcw_q[0], in->Tcw_q[1], in->Tcw_q[2]),
+                          Eigen::Vector3f(in->Tcw_t[0], in->Tcw_t[1], in->Tcw_t[2]));
+  Frame::mnMinX = cur.grid.mnMinX = in->grid[0]; Frame::mnMinY = cur.grid.mnMinY = in->grid[1];
+  Frame::mnMaxX = cur.grid.mnMaxX = in->grid[2]; Frame::mnMaxY = cur.grid.mnMaxY = in->grid[3];
+  cur.grid.mfGridElementWidthInv = in->grid[4]; cur.grid.mfGridElementHeightInv = in->grid[5];
+  cur.grid.Build(cur.mvKeysUn);
+  ORBmatcher matcher(0.9f, in->check_orientation != 0);
+  const int nm = matcher.SearchByProjection(cur, last, in->th, in->mono != 0);
+  for (int i = 0; i < in->n2; ++i) match2[i] = cur.mvpMapPoints[i] ? (int)(cur.mvpMapPoints[i] - points.data()) : -1;
+  return nm;
+}

@@ -52,6 +52,17 @@ class TriangulationParams(C.Structure):
                 ("coarse", C.c_int), ("check_orientation", C.c_int)]
 
 
+class ProjectionInput(C.Structure):
+    """rgbl_projection_input (ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) as flat arrays)."""
+    _fields_ = [("n1", C.c_int), ("valid1", C.c_void_p), ("world_pos1", C.c_void_p), ("mp_desc1", C.c_void_p),
+                ("mp_observed1", C.c_void_p), ("octave1", C.c_void_p), ("angle1", C.c_void_p),
+                ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p), ("kp2_angle", C.c_void_p),
+                ("uright2", C.c_void_p), ("desc2", C.c_void_p), ("grid", C.c_float * 6),
+                ("Tcw_q", C.c_float * 4), ("Tcw_t", C.c_float * 3), ("Tlw_q", C.c_float * 4), ("Tlw_t", C.c_float * 3),
+                ("K", C.c_float * 4), ("mb", C.c_float), ("mbf", C.c_float), ("scale_factors", C.c_void_p),
+                ("n_levels", C.c_int), ("th", C.c_float), ("mono", C.c_int), ("check_orientation", C.c_int)]
+
+
 # name -> (restype, argtypes); every symbol of include/rgbl_frontend.h
 _V, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SYMBOLS = {
@@ -110,6 +121,7 @@ SYMBOLS = {
     "rgbl_hamming_bf_batch_device": (_I, [_V, _V, _V, _I, _V, _V, _I, _V, _V, _V]),
     "rgbl_search_triangulation": (_I, [_V, C.POINTER(KeyframeView), C.POINTER(KeyframeView),
                                        C.POINTER(TriangulationParams), _V, C.POINTER(_I)]),
+    "rgbl_search_by_projection": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_fundamental": (None, [_V, _V, _V, _V, _V]),
 }
 

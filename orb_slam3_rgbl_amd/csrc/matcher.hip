@@ -11,6 +11,7 @@
 //   k_search_triangulation one workgroup per BoW node shared by both key-frames, one query feature per
 //                         work-item, the node's candidate bucket is walked in index order (ties -> later
 //                         candidate wins, as in the reference) with the eligibility masks and epipolar test.
+#include <limits.h>
 #include <math.h>
 #include <string.h>
 
@@ -141,6 +142,242 @@ __global__ __launch_bounds__(256) void k_search_triangulation(TriDev T) {
       if (ok) { best_idx2 = idx2; best_dist = dist; }
     }
     if (best_idx2 >= 0) T.matches12[idx1] = best_idx2;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+// (/root/reference/src/ORBmatcher.cc:1676-1887, single camera) with Frame::AssignFeaturesToGrid,
+// PosInGrid and GetFeaturesInArea (src/Frame.cc:475-506, 815-825, 747-813).
+//
+// The reference walks the LastFrame map points in index order, and a point with observations BLOCKS the feature it is
+// assigned to for every later point: a sequential greedy assignment.  Three kernels:
+//   k_proj_grid        one workgroup: AssignFeaturesToGrid as a counting sort
+//   k_proj_candidates  work-item per map point: projection, search window, Hamming distance to every feature in the
+//                      window; the VIABLE candidates (distance <= TH_HIGH - nothing else can ever be assigned) are kept
+//                      as (distance, cell order, feature) keys - the minimum key is the reference's "first minimum"
+//   k_proj_resolve     one workgroup resolves the greedy order in rounds: an unresolved point takes the smallest key
+//                      whose feature is not held by a lower-index blocker; it is FINAL once no unresolved lower-index
+//                      blocker still has that feature among its viable candidates (min_unres).  Finals commit, the
+//                      rest try again.  The lowest unresolved index is final in every round, so the loop terminates,
+//                      and induction over the index shows the result is the sequential one.
+constexpr int kProjMaxLevels = 16;
+constexpr int kProjCand = 16;  // viable candidates kept per point; a point with more re-scans its window (kProjOverflow)
+constexpr int kProjOverflow = 0x80;
+struct ProjDev {
+  int n1, n2;
+  const uint8_t* valid1;
+  const float* wpos1;
+  const uint8_t* mpdesc1;
+  const uint8_t* obs1;
+  const int32_t* oct1;
+  const float* xy2;
+  const int32_t* oct2;
+  const float* ur2;
+  const uint8_t* desc2;
+  float grid[6], q[4], t[3], K[4], mbf, th, scale[kProjMaxLevels];
+  int forward, backward;
+  // scratch
+  uint32_t* cell_start;      // kGridCells + 1
+  uint16_t* cell_items;      // n2 feature indices grouped by grid cell
+  int32_t* taken_by;         // n2: index of the blocker holding the feature (INT_MAX = free)
+  int32_t* min_unres;        // n2
+  float4* win;               // n1: u, v, radius, ur (= u - mbf * invzc)
+  int4* rng;                 // n1: cell x range, cell y range (lo | hi << 8), minLevel, maxLevel
+  unsigned long long* cand;  // n1 * kProjCand keys
+  uint8_t* ncand;            // n1: number of keys | kProjOverflow
+  uint8_t* state;            // n1: 0 unresolved, 1 resolved, 2 final this round
+  int32_t* choice;           // n1: best CurrentFrame feature or -1
+};
+constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;  // FRAME_GRID_COLS / ROWS (Frame.h:46-47)
+constexpr int kProjBS = 512;
+
+__host__ __device__ __forceinline__ void quat_rotate(const float q[4], float px, float py, float pz, float* rx, float* ry, float* rz) {
+  // Eigen QuaternionBase::_transformVector: uv = 2 (q.vec x p); p + w uv + q.vec x uv
+  float ux = q[1] * pz - q[2] * py, uy = q[2] * px - q[0] * pz, uz = q[0] * py - q[1] * px;
+  ux = ux + ux; uy = uy + uy; uz = uz + uz;
+  const float cx = q[1] * uz - q[2] * uy, cy = q[2] * ux - q[0] * uz, cz = q[0] * uy - q[1] * ux;
+  *rx = px + q[3] * ux + cx; *ry = py + q[3] * uy + cy; *rz = pz + q[3] * uz + cz;
+}
+
+// visits the candidates of a point that pass the static tests of GetFeaturesInArea + the stereo check (ORBmatcher.cc:1749-1755)
+template <class F>
+__device__ __forceinline__ void for_candidates(const ProjDev& P, const float4& w, const int4& r, F&& f) {
+  const int x0 = r.x & 0xff, x1 = r.x >> 8, y0 = r.y & 0xff, y1 = r.y >> 8;
+  const bool check_levels = (r.z > 0) || (r.w >= 0);
+  for (int ix = x0; ix <= x1; ++ix)
+    for (int iy = y0; iy <= y1; ++iy) {
+      const int cell = ix * kGridRows + iy;
+      const uint32_t kb = P.cell_start[cell], ke = P.cell_start[cell + 1];
+      for (uint32_t k = kb; k < ke; ++k) {
+        const int c = P.cell_items[k];
+        if (check_levels) {
+          const int o = P.oct2[c];
+          if (o < r.z) continue;
+          if (r.w >= 0 && o > r.w) continue;
+        }
+        const float dx = P.xy2[2 * c] - w.x, dy = P.xy2[2 * c + 1] - w.y;
+        if (!(fabsf(dx) < w.z && fabsf(dy) < w.z)) continue;
+        const float ur = P.ur2[c];
+        if (ur > 0 && fabsf(w.w - ur) > w.z) continue;
+        f(c, cell);
+      }
+    }
+}
+__device__ __forceinline__ unsigned long long proj_key(int dist, int cell, int c) {
+  // strict '<' over the traversal (cells x-major, feature index inside a cell) == minimum of this key
+  return ((unsigned long long)dist << 32) | ((unsigned long long)cell << 16) | (unsigned)c;
+}
+
+// grid = 1, block = kProjBS
+__global__ __launch_bounds__(kProjBS) void k_proj_grid(ProjDev P) {
+  __shared__ uint32_t s_fill[kGridCells];
+  __shared__ uint32_t s_scan[kProjBS / 64 + 1];
+  const int tid = threadIdx.x;
+  for (int c = tid; c < kGridCells; c += kProjBS) s_fill[c] = 0;
+  __syncthreads();
+  for (int c = tid; c < P.n2; c += kProjBS) {
+    const int px = (int)roundf((P.xy2[2 * c] - P.grid[0]) * P.grid[4]), py = (int)roundf((P.xy2[2 * c + 1] - P.grid[1]) * P.grid[5]);
+    if (px >= 0 && px < kGridCols && py >= 0 && py < kGridRows) atomicAdd(&s_fill[px * kGridRows + py], 1u);
+    P.taken_by[c] = INT_MAX;
+  }
+  __syncthreads();
+  uint32_t carry = 0;
+  for (int c0 = 0; c0 < kGridCells; c0 += kProjBS) {
+    const int c = c0 + tid;
+    const uint32_t v = c < kGridCells ? s_fill[c] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan<uint32_t>(v, s_scan, &tot);
+    __syncthreads();
+    if (c < kGridCells) { P.cell_start[c] = carry + ex; s_fill[c] = carry + ex; }
+    carry += tot;
+  }
+  if (tid == 0) P.cell_start[kGridCells] = carry;
+  __syncthreads();
+  for (int c = tid; c < P.n2; c += kProjBS) {
+    const int px = (int)roundf((P.xy2[2 * c] - P.grid[0]) * P.grid[4]), py = (int)roundf((P.xy2[2 * c + 1] - P.grid[1]) * P.grid[5]);
+    if (px >= 0 && px < kGridCols && py >= 0 && py < kGridRows) P.cell_items[atomicAdd(&s_fill[px * kGridRows + py], 1u)] = (uint16_t)c;
+  }
+}
+
+// grid = ceil(n1 / 64), block = 64: projection and search window of every LastFrame map point (ORBmatcher.cc:1696-1735),
+// then its viable candidates
+__global__ __launch_bounds__(64) void k_proj_candidates(ProjDev P) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= P.n1) return;
+  uint8_t st = 1;
+  int n = 0;
+  P.choice[i] = -1;
+  if (P.valid1[i]) {
+    float x, y, z;
+    quat_rotate(P.q, P.wpos1[3 * i], P.wpos1[3 * i + 1], P.wpos1[3 * i + 2], &x, &y, &z);
+    x += P.t[0]; y += P.t[1]; z += P.t[2];
+    const float invzc = (float)(1.0 / (double)z);
+    const float u = __fdiv_rn(P.K[0] * x, z) + P.K[2], v = __fdiv_rn(P.K[1] * y, z) + P.K[3];
+    // NaN / inf coordinates never produce candidates in the reference either (empty cell range)
+    if (!(invzc < 0) && u == u && v == v && !(u < P.grid[0] || u > P.grid[2]) && !(v < P.grid[1] || v > P.grid[3])) {
+      const int oct = P.oct1[i];
+      const float radius = P.th * P.scale[oct];
+      int min_level, max_level;
+      if (P.forward) { min_level = oct; max_level = -1; }
+      else if (P.backward) { min_level = 0; max_level = oct; }
+      else { min_level = oct - 1; max_level = oct + 1; }
+      const int x0 = imax(0, (int)floorf((u - P.grid[0] - radius) * P.grid[4]));
+      const int x1 = imin(kGridCols - 1, (int)ceilf((u - P.grid[0] + radius) * P.grid[4]));
+      const int y0 = imax(0, (int)floorf((v - P.grid[1] - radius) * P.grid[5]));
+      const int y1 = imin(kGridRows - 1, (int)ceilf((v - P.grid[1] + radius) * P.grid[5]));
+      if (x0 < kGridCols && x1 >= 0 && y0 < kGridRows && y1 >= 0) {
+        const float4 w = make_float4(u, v, radius, u - P.mbf * invzc);
+        const int4 r = make_int4(x0 | (x1 << 8), y0 | (y1 << 8), min_level, max_level);
+        P.win[i] = w;
+        P.rng[i] = r;
+        const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
+        const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+        int total = 0;
+        for_candidates(P, w, r, [&](int c, int cell) {
+          const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
+          if (dist > 100 /* TH_HIGH */) return;
+          if (total < kProjCand) P.cand[(size_t)i * kProjCand + total] = proj_key(dist, cell, c);
+          ++total;
+        });
+        n = total <= kProjCand ? total : (kProjCand | kProjOverflow);
+        st = total > 0 ? 0 : 1;  // no viable candidate: bestDist > TH_HIGH whatever the others do
+      }
+    }
+  }
+  P.ncand[i] = (uint8_t)n;
+  P.state[i] = st;
+}
+
+// smallest key of point i among the features not held by a lower-index blocker (~0 = none)
+__device__ __forceinline__ unsigned long long proj_best(const ProjDev& P, int i) {
+  unsigned long long best = ~0ull;
+  const int n = P.ncand[i];
+  if (!(n & kProjOverflow)) {
+    for (int k = 0; k < n; ++k) {
+      const unsigned long long key = P.cand[(size_t)i * kProjCand + k];
+      if (P.taken_by[(int)(key & 0xffffu)] >= i && key < best) best = key;
+    }
+    return best;
+  }
+  const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
+  const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+  for_candidates(P, P.win[i], P.rng[i], [&](int c, int cell) {
+    if (P.taken_by[c] < i) return;
+    const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
+    if (dist > 100) return;
+    const unsigned long long key = proj_key(dist, cell, c);
+    if (key < best) best = key;
+  });
+  return best;
+}
+
+// grid = 1, block = kProjBS
+__global__ __launch_bounds__(kProjBS) void k_proj_resolve(ProjDev P) {
+  __shared__ int s_unres;
+  const int tid = threadIdx.x;
+  for (int round = 0; round <= P.n1; ++round) {
+    for (int c = tid; c < P.n2; c += kProjBS) P.min_unres[c] = INT_MAX;
+    if (tid == 0) s_unres = 0;
+    __syncthreads();
+    // every unresolved blocker announces itself on the features it may still take
+    for (int i = tid; i < P.n1; i += kProjBS) {
+      if (P.state[i] != 0 || !P.obs1[i]) continue;
+      const int n = P.ncand[i];
+      if (!(n & kProjOverflow)) {
+        for (int k = 0; k < n; ++k) {
+          const int c = (int)(P.cand[(size_t)i * kProjCand + k] & 0xffffu);
+          if (P.taken_by[c] >= i) atomicMin(&P.min_unres[c], i);
+        }
+      } else {
+        const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
+        const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+        for_candidates(P, P.win[i], P.rng[i], [&](int c, int) {
+          if (P.taken_by[c] < i) return;
+          if (hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)) <= 100) atomicMin(&P.min_unres[c], i);
+        });
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < P.n1; i += kProjBS) {
+      if (P.state[i] != 0) continue;
+      const unsigned long long best = proj_best(P, i);
+      const int c = (int)(best & 0xffffu);
+      if (best == ~0ull) { P.state[i] = 2; P.choice[i] = -1; }           // everything viable is taken: no match
+      else if (P.min_unres[c] >= i) { P.state[i] = 2; P.choice[i] = c; }  // nobody in front of i can still take c
+      else atomicAdd(&s_unres, 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < P.n1; i += kProjBS) {
+      if (P.state[i] != 2) continue;
+      P.state[i] = 1;
+      const int c = P.choice[i];
+      if (c >= 0 && P.obs1[i]) P.taken_by[c] = i;  // two blockers can never become final on one feature in the same round
+    }
+    __syncthreads();
+    if (s_unres == 0) break;
+    __syncthreads();
   }
 }
 
@@ -433,6 +670,123 @@ int rgbl_search_triangulation(rgbl_matcher* m, const rgbl_keyframe_view* k1, con
     for (int i = 0; i < 30; ++i) {
       if (i == i1 || i == i2 || i == i3) continue;
       for (int idx1 : hist[i]) { matches12[idx1] = -1; --nmatches; }
+    }
+  }
+  *out_nmatches = nmatches;
+  return RGBL_OK;
+}
+
+// rotation-consistency bins that survive: ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:2012-2053)
+static void three_maxima(const std::vector<int>* hist, int L, int& i1, int& i2, int& i3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  i1 = i2 = i3 = -1;
+  for (int i = 0; i < L; ++i) {
+    const int sz = (int)hist[i].size();
+    if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+    else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+    else if (sz > max3) { max3 = sz; i3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { i3 = -1; }
+}
+
+int rgbl_search_by_projection(rgbl_matcher* m, const rgbl_projection_input* in, int32_t* match2, int* out_nmatches) {
+  if (!m || !in || !match2 || !out_nmatches || in->n1 < 0 || in->n2 < 0 || in->n2 > 65535 || in->n_levels < 1 ||
+      in->n_levels > kProjMaxLevels) {
+    set_error("invalid argument (CurrentFrame may hold at most 65535 features, %d pyramid levels)", kProjMaxLevels);
+    return RGBL_ERR_INVALID;
+  }
+  *out_nmatches = 0;
+  const int n1 = in->n1, n2 = in->n2;
+  for (int i = 0; i < n2; ++i) match2[i] = -1;
+  if (n1 == 0 || n2 == 0) return RGBL_OK;
+  for (int i = 0; i < n1; ++i)
+    if (in->valid1[i] && (in->octave1[i] < 0 || in->octave1[i] >= in->n_levels)) { set_error("octave out of range"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(m->device));
+  size_t need = pad256(n1) * 2 + pad256((size_t)n1 * 12) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 8) +
+                pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 3 +
+                pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 + pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) +
+                pad256((size_t)(kGridCells + 1) * 4);
+  RGBL_TRY(ensure_arena(m, need));
+  Arena A{m->d_buf};
+  hipStream_t s = m->stream;
+  ProjDev P;
+  P.n1 = n1; P.n2 = n2;
+  RGBL_TRY(upload(A, s, &P.valid1, in->valid1, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.obs1, in->mp_observed1, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.wpos1, in->world_pos1, (size_t)n1 * 3));
+  RGBL_TRY(upload(A, s, &P.mpdesc1, in->mp_desc1, (size_t)n1 * 32));
+  RGBL_TRY(upload(A, s, &P.oct1, in->octave1, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.xy2, in->kp2_xy, (size_t)n2 * 2));
+  RGBL_TRY(upload(A, s, &P.oct2, in->kp2_octave, (size_t)n2));
+  RGBL_TRY(upload(A, s, &P.ur2, in->uright2, (size_t)n2));
+  RGBL_TRY(upload(A, s, &P.desc2, in->desc2, (size_t)n2 * 32));
+  P.cell_start = A.take<uint32_t>(kGridCells + 1);
+  P.cell_items = A.take<uint16_t>(n2);
+  P.taken_by = A.take<int32_t>(n2);
+  P.min_unres = A.take<int32_t>(n2);
+  P.win = A.take<float4>(n1);
+  P.rng = A.take<int4>(n1);
+  P.cand = A.take<unsigned long long>((size_t)n1 * kProjCand);
+  P.ncand = A.take<uint8_t>(n1);
+  P.state = A.take<uint8_t>(n1);
+  P.choice = A.take<int32_t>(n1);
+  memcpy(P.grid, in->grid, sizeof(P.grid));
+  memcpy(P.q, in->Tcw_q, sizeof(P.q));
+  memcpy(P.t, in->Tcw_t, sizeof(P.t));
+  memcpy(P.K, in->K, sizeof(P.K));
+  P.mbf = in->mbf;
+  P.th = in->th;
+  for (int l = 0; l < kProjMaxLevels; ++l) P.scale[l] = l < in->n_levels ? in->scale_factors[l] : 1.f;
+  {
+    // bForward / bBackward (ORBmatcher.cc:1686-1694): tlc = Tlw * Tcw.inverse().translation(), Sophus / Eigen arithmetic
+    const float qi[4] = {-in->Tcw_q[0], -in->Tcw_q[1], -in->Tcw_q[2], in->Tcw_q[3]};
+    float wx, wy, wz, lx, ly, lz;
+    quat_rotate(qi, -in->Tcw_t[0], -in->Tcw_t[1], -in->Tcw_t[2], &wx, &wy, &wz);
+    quat_rotate(in->Tlw_q, wx, wy, wz, &lx, &ly, &lz);
+    lz += in->Tlw_t[2];
+    (void)lx; (void)ly;
+    P.forward = (lz > in->mb && !in->mono) ? 1 : 0;
+    P.backward = (-lz > in->mb && !in->mono) ? 1 : 0;
+  }
+  m->timer.begin("k_proj_grid", s);
+  hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
+  m->timer.end(s);
+  m->timer.begin("k_proj_candidates", s);
+  hipLaunchKernelGGL(k_proj_candidates, dim3((n1 + 63) / 64), dim3(64), 0, s, P);
+  m->timer.end(s);
+  m->timer.begin("k_proj_resolve", s);
+  hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(kProjBS), 0, s, P);
+  m->timer.end(s);
+  RGBL_HIP(hipGetLastError());
+  std::vector<int32_t> choice(n1);
+  RGBL_HIP(hipMemcpyAsync(choice.data(), P.choice, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipStreamSynchronize(s));
+  m->timer.collect();
+  // what the loop leaves in CurrentFrame.mvpMapPoints (a later point overwrites an unobserved earlier one), the match
+  // count, and the rotation-consistency pass (ORBmatcher.cc:1768-1790, 1860-1884)
+  int nmatches = 0;
+  std::vector<int> hist[30];
+  const float factor = 1.0f / 30;
+  for (int i = 0; i < n1; ++i) {
+    const int c = choice[i];
+    if (c < 0) continue;
+    match2[c] = i;
+    ++nmatches;
+    if (in->check_orientation) {
+      float rot = in->angle1[i] - in->kp2_angle[c];
+      if (rot < 0.0) rot += 360.0f;
+      int bin = (int)roundf(rot * factor);
+      if (bin == 30) bin = 0;
+      if (bin >= 0 && bin < 30) hist[bin].push_back(c);
+    }
+  }
+  if (in->check_orientation) {
+    int i1, i2, i3;
+    three_maxima(hist, 30, i1, i2, i3);
+    for (int i = 0; i < 30; ++i) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int c : hist[i]) { match2[c] = -1; --nmatches; }  // a feature chosen twice is un-counted twice, as in the reference
     }
   }
   *out_nmatches = nmatches;

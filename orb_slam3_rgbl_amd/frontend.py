@@ -306,6 +306,38 @@ class ORBmatcher:
         self.lib.rgbl_fundamental(L.ptr(a[0]), L.ptr(a[1]), L.ptr(a[2]), L.ptr(a[3]), L.ptr(F))
         return F
 
+    def SearchByProjection(self, frames, th, bMono):
+        """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1676-1887).
+        frames: dict with the LastFrame arrays valid1, world_pos1, mp_desc1, mp_observed1, octave1, angle1, the CurrentFrame
+        arrays kp2_xy, kp2_octave, kp2_angle, uright2, desc2, and grid[6], Tcw_q/Tcw_t, Tlw_q/Tlw_t, K[4], mb, mbf,
+        scale_factors.  Returns (match2: LastFrame feature index per CurrentFrame feature or -1, nmatches)."""
+        keep = []
+
+        def arr(v, dt):
+            a = np.ascontiguousarray(v, dt)
+            keep.append(a)
+            return a.ctypes.data
+        P = L.ProjectionInput()
+        P.n1 = len(frames["valid1"])
+        P.valid1, P.world_pos1 = arr(frames["valid1"], np.uint8), arr(frames["world_pos1"], np.float32)
+        P.mp_desc1, P.mp_observed1 = arr(frames["mp_desc1"], np.uint8), arr(frames["mp_observed1"], np.uint8)
+        P.octave1, P.angle1 = arr(frames["octave1"], np.int32), arr(frames["angle1"], np.float32)
+        P.n2 = len(frames["kp2_xy"])
+        P.kp2_xy, P.kp2_octave = arr(frames["kp2_xy"], np.float32), arr(frames["kp2_octave"], np.int32)
+        P.kp2_angle, P.uright2 = arr(frames["kp2_angle"], np.float32), arr(frames["uright2"], np.float32)
+        P.desc2 = arr(frames["desc2"], np.uint8)
+        for name, n in (("grid", 6), ("Tcw_q", 4), ("Tcw_t", 3), ("Tlw_q", 4), ("Tlw_t", 3), ("K", 4)):
+            for i in range(n):
+                getattr(P, name)[i] = float(frames[name][i])
+        P.mb, P.mbf = float(frames["mb"]), float(frames["mbf"])
+        P.scale_factors = arr(frames["scale_factors"], np.float32)
+        P.n_levels = len(frames["scale_factors"])
+        P.th, P.mono, P.check_orientation = float(th), int(bMono), int(self.mbCheckOrientation)
+        match2 = np.zeros(P.n2, np.int32)
+        n = C.c_int(0)
+        L.check(self.lib, self.lib.rgbl_search_by_projection(self.h, C.byref(P), L.ptr(match2), C.byref(n)))
+        return match2, n.value
+
     def SearchForTriangulation(self, kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, bOnlyStereo=False,
                                bCoarse=False):
         """kf = dict(desc, xy, octave, angle, uright, has_mp, node_id, node_off, node_feat).

@@ -1,6 +1,7 @@
 // Drop-in replacement of the Hamming paths of /root/reference/include/ORBmatcher.h on librgbl_frontend.so:
 //   static DescriptorDistance(a, b)                                  (ORBmatcher.h:43,  ORBmatcher.cc:2058-2074)
 //   SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse)   (ORBmatcher.h:75-76, :907-1146)
+//   SearchByProjection(CurrentFrame, LastFrame, th, bMono)           (ORBmatcher.h:48,  ORBmatcher.cc:1676-1887)
 // The other Search*/Fuse members of the reference class are untouched (SURVEY.md §8(f) lists them as "next");
 // in the ORB_SLAM3 tree this header is merged into the existing one, see INTEGRATION.md.
 //
@@ -13,6 +14,7 @@
 #define ORBMATCHER_H
 
 #include <stdint.h>
+#include <string.h>
 
 #include <iostream>
 #include <mutex>
@@ -91,6 +93,71 @@ class ORBmatcher {
       if (vMatches12[i] < 0) continue;
       vMatchedPairs.push_back(std::make_pair(i, (size_t)vMatches12[i]));
     }
+    return nmatches;
+  }
+
+  // Project MapPoints tracked in last frame into the current frame and search matches.  Used to track from previous
+  // frame (Tracking::TrackWithMotionModel, Tracking.cc:2917-2934).  ORBmatcher.h:48, ORBmatcher.cc:1676-1887.
+  // A member template for the same reason as above; it reads the Frame / MapPoint members the reference loop reads
+  // (mvpMapPoints, mvbOutlier, mvKeys, mvKeysUn, mvuRight, mDescriptors, mvScaleFactors, mb, mbf, Nleft, GetPose(),
+  // mpCamera->getParameter(), the static grid bounds; MapPoint::GetWorldPos / GetDescriptor / Observations) and writes
+  // CurrentFrame.mvpMapPoints, which must be all NULL on entry as Tracking.cc:2913 leaves it.
+  template <class FrameT>
+  int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono) {
+    if (!mpHandle) return 0;
+    if (CurrentFrame.Nleft != -1 || LastFrame.Nleft != -1) {
+      std::cerr << "[ORBmatcher] SearchByProjection: fisheye stereo rigs (Nleft != -1) are not covered by the device path" << std::endl;
+      return 0;
+    }
+    const int n1 = LastFrame.N, n2 = CurrentFrame.N;
+    std::vector<uint8_t> valid(n1, 0), observed(n1, 0), desc1((size_t)n1 * 32, 0);
+    std::vector<float> pos((size_t)n1 * 3, 0.f), angle1(n1), xy2((size_t)n2 * 2), angle2(n2);
+    std::vector<int32_t> oct1(n1), oct2(n2);
+    for (int i = 0; i < n1; ++i) {
+      oct1[i] = LastFrame.mvKeys[i].octave;
+      angle1[i] = LastFrame.mvKeysUn[i].angle;
+      auto* pMP = LastFrame.mvpMapPoints[i];
+      if (!pMP || LastFrame.mvbOutlier[i]) continue;
+      valid[i] = 1;
+      const auto x3Dw = pMP->GetWorldPos();
+      for (int k = 0; k < 3; ++k) pos[3 * (size_t)i + k] = x3Dw(k);
+      const cv::Mat dMP = pMP->GetDescriptor();
+      memcpy(&desc1[(size_t)i * 32], dMP.ptr<uint8_t>(), 32);
+      observed[i] = pMP->Observations() > 0 ? 1 : 0;
+    }
+    for (int i = 0; i < n2; ++i) {
+      xy2[2 * (size_t)i] = CurrentFrame.mvKeysUn[i].pt.x;
+      xy2[2 * (size_t)i + 1] = CurrentFrame.mvKeysUn[i].pt.y;
+      oct2[i] = CurrentFrame.mvKeysUn[i].octave;
+      angle2[i] = CurrentFrame.mvKeysUn[i].angle;
+    }
+    rgbl_projection_input in;
+    in.n1 = n1; in.valid1 = valid.data(); in.world_pos1 = pos.data(); in.mp_desc1 = desc1.data();
+    in.mp_observed1 = observed.data(); in.octave1 = oct1.data(); in.angle1 = angle1.data();
+    in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.kp2_angle = angle2.data();
+    in.uright2 = CurrentFrame.mvuRight.data(); in.desc2 = CurrentFrame.mDescriptors.template ptr<uint8_t>();
+    in.grid[0] = FrameT::mnMinX; in.grid[1] = FrameT::mnMinY; in.grid[2] = FrameT::mnMaxX; in.grid[3] = FrameT::mnMaxY;
+    in.grid[4] = FrameT::mfGridElementWidthInv; in.grid[5] = FrameT::mfGridElementHeightInv;
+    const auto Tcw = CurrentFrame.GetPose();
+    const auto Tlw = LastFrame.GetPose();
+    in.Tcw_q[0] = Tcw.unit_quaternion().x(); in.Tcw_q[1] = Tcw.unit_quaternion().y(); in.Tcw_q[2] = Tcw.unit_quaternion().z();
+    in.Tcw_q[3] = Tcw.unit_quaternion().w();
+    in.Tlw_q[0] = Tlw.unit_quaternion().x(); in.Tlw_q[1] = Tlw.unit_quaternion().y(); in.Tlw_q[2] = Tlw.unit_quaternion().z();
+    in.Tlw_q[3] = Tlw.unit_quaternion().w();
+    for (int k = 0; k < 3; ++k) { in.Tcw_t[k] = Tcw.translation()(k); in.Tlw_t[k] = Tlw.translation()(k); }
+    for (int k = 0; k < 4; ++k) in.K[k] = CurrentFrame.mpCamera->getParameter(k);
+    in.mb = CurrentFrame.mb; in.mbf = CurrentFrame.mbf;
+    in.scale_factors = CurrentFrame.mvScaleFactors.data();
+    in.n_levels = (int)CurrentFrame.mvScaleFactors.size();
+    in.th = th; in.mono = bMono; in.check_orientation = mbCheckOrientation;
+    std::vector<int32_t> match2(n2, -1);
+    int nmatches = 0;
+    if (rgbl_search_by_projection(mpHandle, &in, match2.data(), &nmatches) != RGBL_OK) {
+      std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
+      return 0;
+    }
+    for (int i2 = 0; i2 < n2; ++i2)
+      if (match2[i2] >= 0) CurrentFrame.mvpMapPoints[i2] = LastFrame.mvpMapPoints[match2[i2]];
     return nmatches;
   }
 

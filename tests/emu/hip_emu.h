@@ -48,6 +48,9 @@ struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
+struct int4 { int x, y, z, w; };
+inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+inline int4 make_int4(int x, int y, int z, int w) { int4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
 namespace hipemu {
 

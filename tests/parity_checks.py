@@ -419,3 +419,123 @@ def check_ingest_kitti_bin(lib, method=F.UPS_INVERSE_DILATION, w=620, h=188, n_a
     n_valid = int((d > 0).sum())
     dm.close()
     return n_valid
+
+
+# ---- ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) -------------------------
+def _quat(axis, angle):
+    axis = np.asarray(axis, np.float64)
+    axis = axis / np.linalg.norm(axis)
+    return np.concatenate([axis * np.sin(angle / 2), [np.cos(angle / 2)]]).astype(np.float32)
+
+
+def _rot(q):
+    x, y, z, w = [float(v) for v in q]
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def make_projection_case(n1=1800, n2=2000, seed=21, motion="forward", w=synth.KITTI_W, h=synth.KITTI_H):
+    """A LastFrame with map points and a CurrentFrame whose features they should re-find.  Clusters of near-identical
+    current features and several map points aiming at the same feature exercise the 'feature already holds an observed
+    map point' rule (later points fall back to their second choice); unobserved (temporal) points get overwritten."""
+    rng = np.random.default_rng(seed)
+    K = np.array([718.856, 718.856, 607.1928, 185.2157], np.float32)
+    xy2 = np.stack([rng.uniform(5, w - 5, n2), rng.uniform(5, h - 5, n2)], 1).astype(np.float32)
+    desc2 = synth.descriptors(n2, seed)
+    # clusters: copies of a feature a few pixels away with almost the same descriptor
+    ncl = n2 // 10
+    src = rng.integers(0, n2, ncl)
+    dst = rng.permutation(n2)[:ncl]
+    xy2[dst] = xy2[src] + rng.uniform(-4, 4, (ncl, 2)).astype(np.float32)
+    flips = rng.random((ncl, 256)) < 0.02
+    desc2[dst] = desc2[src] ^ np.packbits(flips, axis=1, bitorder="little")
+    xy2[:, 0] = np.clip(xy2[:, 0], 1, w - 2)
+    xy2[:, 1] = np.clip(xy2[:, 1], 1, h - 2)
+    oct2 = rng.integers(0, 8, n2).astype(np.int32)
+    oct2[dst] = oct2[src]
+    ang2 = rng.uniform(0, 360, n2).astype(np.float32)
+    depth2 = rng.uniform(4, 70, n2)
+    mbf = 386.1448
+    uright2 = np.where(rng.random(n2) < 0.6, xy2[:, 0] - mbf / depth2 + rng.normal(0, 1.0, n2), -1).astype(np.float32)
+    # poses
+    qc = _quat([0.1, 1.0, 0.05], 0.02)
+    tc = np.array([0.05, -0.02, 0.3], np.float32)
+    dz = {"forward": 0.9, "backward": -0.9, "none": 0.05}[motion]
+    ql = _quat([0.0, 1.0, 0.0], 0.01)
+    Rc, Rl = _rot(qc), _rot(ql)
+    Cc = -Rc.T @ tc.astype(np.float64)                       # current camera centre in the world
+    # last camera: dz metres behind (forward motion) along its own optical axis
+    tl = (-Rl @ Cc + np.array([0.02, 0.0, dz])).astype(np.float32)
+    # map points: most aim at a current feature (several at the same one), the rest are elsewhere
+    target = rng.integers(0, n2, n1)
+    target[: n1 // 6] = target[n1 // 6: 2 * (n1 // 6)]        # duplicates
+    aimed = rng.random(n1) < 0.8
+    z = depth2[target] * rng.uniform(0.97, 1.03, n1)
+    uv = xy2[target] + rng.normal(0, 1.5, (n1, 2))
+    uv[~aimed] = np.stack([rng.uniform(-50, w + 50, (~aimed).sum()), rng.uniform(-50, h + 50, (~aimed).sum())], 1)
+    z[rng.random(n1) < 0.03] *= -1                            # behind the camera
+    xc = np.stack([(uv[:, 0] - K[2]) / K[0] * z, (uv[:, 1] - K[3]) / K[1] * z, z], 1)
+    world = ((xc - tc.astype(np.float64)) @ Rc).astype(np.float32)   # Rc^T (xc - tc)
+    flips = rng.random((n1, 256)) < 0.03
+    mp_desc = desc2[target] ^ np.packbits(flips, axis=1, bitorder="little")
+    mp_desc[~aimed] = synth.descriptors(int((~aimed).sum()), seed + 1)
+    oct1 = np.clip(oct2[target] + rng.integers(-1, 2, n1), 0, 7).astype(np.int32)
+    ang1 = ((ang2[target] + rng.normal(0, 20, n1)) % 360).astype(np.float32)
+    ang1[rng.random(n1) < 0.1] = rng.uniform(0, 360, 1).astype(np.float32)[0]
+    gw, gh = np.float32(w), np.float32(h)
+    grid = np.array([0, 0, gw, gh, np.float32(64) / (gw - np.float32(0)), np.float32(48) / (gh - np.float32(0))], np.float32)
+    return dict(valid1=(rng.random(n1) < 0.9).astype(np.uint8), world_pos1=world, mp_desc1=mp_desc,
+                mp_observed1=(rng.random(n1) < 0.75).astype(np.uint8), octave1=oct1, angle1=ang1,
+                kp2_xy=xy2, kp2_octave=oct2, kp2_angle=ang2, uright2=uright2, desc2=desc2, grid=grid,
+                Tcw_q=qc, Tcw_t=tc, Tlw_q=ql, Tlw_t=tl, K=K, mb=0.54, mbf=mbf,
+                scale_factors=(1.2 ** np.arange(8)).astype(np.float32))
+
+
+def check_search_by_projection(lib, seed=21, motion="forward", th=7.0, mono=False, check_ori=True, n1=1800, n2=2000):
+    case = make_projection_case(n1, n2, seed, motion)
+    mt = F.ORBmatcher(0.9, check_ori, lib=lib)
+    m, n = mt.SearchByProjection(case, th, mono)
+    om, on = O.search_by_projection(case, th, mono, check_ori)
+    assert n == on and np.array_equal(m, om), "SearchByProjection (seed %d, %s, th %g)" % (seed, motion, th)
+    mt.close()
+    return n
+
+
+def check_search_by_projection_edge_cases(lib):
+    mt = F.ORBmatcher(0.9, True, lib=lib)
+    # (a) nothing to match
+    case = make_projection_case(50, 60, 3)
+    empty = dict(case, valid1=np.zeros(50, np.uint8))
+    m, n = mt.SearchByProjection(empty, 7.0, False)
+    assert n == 0 and (m == -1).all()
+    none1 = {k: (v[:0] if k in ("valid1", "world_pos1", "mp_desc1", "mp_observed1", "octave1", "angle1") else v) for k, v in case.items()}
+    m, n = mt.SearchByProjection(none1, 7.0, False)
+    assert n == 0 and (m == -1).all()
+    # (b) a long blocking chain: 300 observed map points, all projecting into one 6-px cluster of 40 identical features
+    rng = np.random.default_rng(9)
+    case = make_projection_case(300, 400, 5, "none")
+    c0 = np.array([600.0, 180.0], np.float32)
+    case["kp2_xy"][:40] = c0 + rng.uniform(-3, 3, (40, 2)).astype(np.float32)
+    case["desc2"][:40] = case["desc2"][0]
+    case["kp2_octave"][:40] = 2
+    case["uright2"][:40] = -1
+    K, qc, tc = case["K"], case["Tcw_q"], case["Tcw_t"]
+    z = rng.uniform(10, 20, 300)
+    uv = c0 + rng.uniform(-2, 2, (300, 2))
+    xc = np.stack([(uv[:, 0] - K[2]) / K[0] * z, (uv[:, 1] - K[3]) / K[1] * z, z], 1)
+    case["world_pos1"] = ((xc - tc.astype(np.float64)) @ _rot(qc)).astype(np.float32)
+    case["mp_desc1"] = np.repeat(case["desc2"][:1], 300, 0)
+    case["octave1"] = np.full(300, 2, np.int32)
+    case["valid1"] = np.ones(300, np.uint8)
+    case["mp_observed1"] = (rng.random(300) < 0.9).astype(np.uint8)
+    for th in (7.0, 30.0):
+        m, n = mt.SearchByProjection(case, th, False)
+        om, on = O.search_by_projection(case, th, False, True)
+        assert n == on and np.array_equal(m, om)
+    mt2 = F.ORBmatcher(0.9, False, lib=lib)
+    m, n = mt2.SearchByProjection(case, 7.0, False)
+    om, on = O.search_by_projection(case, 7.0, False, False)
+    assert n == on and np.array_equal(m, om) and (m[:40] >= 0).sum() >= 35   # the cluster fills up one by one
+    mt.close()
+    mt2.close()

@@ -54,9 +54,21 @@ def run_and_check(exe, tmp):
         f.write(K.astype(np.float32).tobytes())
         write_kf(f, kf1, sf, s2, T1w, np.linalg.inv(T1w).astype(np.float32))
         write_kf(f, kf2, sf, s2, T2w, Tw2)
+    case = pc.make_projection_case(1500, 1700, seed=33, motion="forward")
+    with open(os.path.join(tmp, "proj.bin"), "wb") as f:
+        f.write(struct.pack("<iifii", len(case["valid1"]), len(case["kp2_xy"]), 7.0, 0, 1))
+        hdr = np.concatenate([case["grid"], case["Tcw_q"], case["Tcw_t"], case["Tlw_q"], case["Tlw_t"], case["K"],
+                              [case["mb"], case["mbf"]], case["scale_factors"]]).astype(np.float32)
+        assert hdr.size == 34
+        f.write(hdr.tobytes())
+        for key, dt in (("valid1", np.uint8), ("world_pos1", np.float32), ("mp_desc1", np.uint8), ("mp_observed1", np.uint8),
+                        ("octave1", np.int32), ("angle1", np.float32), ("kp2_xy", np.float32), ("kp2_octave", np.int32),
+                        ("kp2_angle", np.float32), ("uright2", np.float32), ("desc2", np.uint8)):
+            f.write(np.ascontiguousarray(case[key], dt).tobytes())
     out = os.path.join(tmp, "out.bin")
     res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "KITTI00-02.yaml"), os.path.join(tmp, "img.raw"), str(w), str(h),
-                          os.path.join(tmp, "cloud.raw"), str(cloud.shape[1]), os.path.join(tmp, "tri.bin"), out],
+                          os.path.join(tmp, "cloud.raw"), str(cloud.shape[1]), os.path.join(tmp, "tri.bin"), out,
+                          os.path.join(tmp, "proj.bin")],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "Lidar Method: InverseDilation" in res.stdout
@@ -89,7 +101,11 @@ def run_and_check(exe, tmp):
     nm, npairs = take(np.int32, 2)
     pairs = take(np.int32, 2 * npairs).reshape(npairs, 2)
     dd = take(np.int32, 1)[0]
+    nproj, n2p = take(np.int32, 2)
+    proj_match = take(np.int32, n2p)
     assert pos == len(buf)
+    om, onm = O.search_by_projection(case, 7.0, False, True)
+    assert nproj == onm and np.array_equal(proj_match, om) and nproj > 200
 
     orc = O.Extractor(2000, 1.2, 8, 12, 7)
     okps, odesc, omono = orc(img)

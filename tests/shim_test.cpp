@@ -56,6 +56,35 @@ struct KeyFrame {
   V3 GetCameraCenter() { return Twc.t; }
 };
 
+// ---- stand-ins for the Frame / MapPoint members SearchByProjection touches
+struct Quat { float qx, qy, qz, qw; float x() const { return qx; } float y() const { return qy; } float z() const { return qz; } float w() const { return qw; } };
+struct QPose {
+  Quat q; V3 t;
+  const Quat& unit_quaternion() const { return q; }
+  const V3& translation() const { return t; }
+};
+struct TrackedPoint {
+  V3 pos; cv::Mat desc; int nObs = 0;
+  V3 GetWorldPos() { return pos; }
+  cv::Mat GetDescriptor() { return desc; }
+  int Observations() { return nObs; }
+};
+struct TestFrame {
+  int N = 0, Nleft = -1;
+  float mb = 0, mbf = 0;
+  Camera* mpCamera = nullptr;
+  std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+  std::vector<float> mvuRight, mvScaleFactors;
+  std::vector<TrackedPoint*> mvpMapPoints;
+  std::vector<bool> mvbOutlier;
+  cv::Mat mDescriptors;
+  QPose pose;
+  QPose GetPose() const { return pose; }
+  static float mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+};
+float TestFrame::mnMinX, TestFrame::mnMinY, TestFrame::mnMaxX, TestFrame::mnMaxY, TestFrame::mfGridElementWidthInv,
+    TestFrame::mfGridElementHeightInv;
+
 template <class T> static bool rd(FILE* f, T* p, size_t n) { return fread(p, sizeof(T), n, f) == n; }
 template <class T> static void wr(FILE* f, const T* p, size_t n) { fwrite(p, sizeof(T), n, f); }
 
@@ -176,6 +205,47 @@ int main(int argc, char** argv) {
   for (auto& pr : pairs) { int a = (int)pr.first, b = (int)pr.second; wr(out, &a, 1); wr(out, &b, 1); }
   const int dd = ORB_SLAM3::ORBmatcher::DescriptorDistance(kf1.mDescriptors.row(0), kf2.mDescriptors.row(0));
   wr(out, &dd, 1);
+  // --- as Tracking::TrackWithMotionModel (Tracking.cc:2913-2934): SearchByProjection(mCurrentFrame, mLastFrame, th, bMono)
+  if (argc > 9) {
+    f = fopen(argv[9], "rb");
+    int n1 = 0, n2 = 0, mono = 0, ori = 0;
+    float th = 0, hdr[6 + 7 + 7 + 4 + 2 + 8];
+    if (!f || !rd(f, &n1, 1) || !rd(f, &n2, 1) || !rd(f, &th, 1) || !rd(f, &mono, 1) || !rd(f, &ori, 1) || !rd(f, hdr, 34)) return 6;
+    std::vector<unsigned char> valid(n1), obs(n1), d1((size_t)n1 * 32), d2((size_t)n2 * 32);
+    std::vector<float> pos((size_t)n1 * 3), ang1(n1), xy2((size_t)n2 * 2), ang2(n2), ur2(n2);
+    std::vector<int> o1(n1), o2(n2);
+    rd(f, valid.data(), n1); rd(f, pos.data(), (size_t)n1 * 3); rd(f, d1.data(), (size_t)n1 * 32); rd(f, obs.data(), n1);
+    rd(f, o1.data(), n1); rd(f, ang1.data(), n1); rd(f, xy2.data(), (size_t)n2 * 2); rd(f, o2.data(), n2); rd(f, ang2.data(), n2);
+    rd(f, ur2.data(), n2); rd(f, d2.data(), (size_t)n2 * 32);
+    fclose(f);
+    TestFrame::mnMinX = hdr[0]; TestFrame::mnMinY = hdr[1]; TestFrame::mnMaxX = hdr[2]; TestFrame::mnMaxY = hdr[3];
+    TestFrame::mfGridElementWidthInv = hdr[4]; TestFrame::mfGridElementHeightInv = hdr[5];
+    Camera pcam; for (int k = 0; k < 4; ++k) pcam.p[k] = hdr[20 + k];
+    TestFrame last, cur;
+    std::vector<TrackedPoint> pts(n1);
+    last.N = n1; last.mvKeys.resize(n1); last.mvKeysUn.resize(n1); last.mvpMapPoints.assign(n1, nullptr); last.mvbOutlier.assign(n1, false);
+    for (int i = 0; i < n1; ++i) {
+      last.mvKeys[i].octave = o1[i]; last.mvKeysUn[i].angle = ang1[i];
+      if (!valid[i]) { if (i % 2) last.mvbOutlier[i] = true, last.mvpMapPoints[i] = &pts[i]; continue; }  // outliers and NULLs
+      pts[i].pos = V3{{pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]}};
+      pts[i].desc.create(1, 32, CV_8U); memcpy(pts[i].desc.data, &d1[(size_t)i * 32], 32);
+      pts[i].nObs = obs[i] ? 2 : 0;
+      last.mvpMapPoints[i] = &pts[i];
+    }
+    last.pose.q = Quat{hdr[13], hdr[14], hdr[15], hdr[16]}; last.pose.t = V3{{hdr[17], hdr[18], hdr[19]}};
+    cur.N = n2; cur.mpCamera = &pcam; cur.mb = hdr[24]; cur.mbf = hdr[25];
+    cur.mvKeysUn.resize(n2);
+    for (int i = 0; i < n2; ++i) { cur.mvKeysUn[i].pt.x = xy2[2 * i]; cur.mvKeysUn[i].pt.y = xy2[2 * i + 1]; cur.mvKeysUn[i].octave = o2[i]; cur.mvKeysUn[i].angle = ang2[i]; }
+    cur.mvKeys = cur.mvKeysUn; cur.mvuRight = ur2;
+    cur.mDescriptors.create(n2, 32, CV_8U); memcpy(cur.mDescriptors.data, d2.data(), (size_t)n2 * 32);
+    cur.mvScaleFactors.assign(hdr + 26, hdr + 34);
+    cur.mvpMapPoints.assign(n2, nullptr);
+    cur.pose.q = Quat{hdr[6], hdr[7], hdr[8], hdr[9]}; cur.pose.t = V3{{hdr[10], hdr[11], hdr[12]}};
+    ORB_SLAM3::ORBmatcher tracker(0.9, ori != 0);
+    const int nproj = tracker.SearchByProjection(cur, last, th, mono != 0);
+    wr(out, &nproj, 1); wr(out, &n2, 1);
+    for (int i = 0; i < n2; ++i) { const int idx = cur.mvpMapPoints[i] ? (int)(cur.mvpMapPoints[i] - pts.data()) : -1; wr(out, &idx, 1); }
+  }
   fclose(out);
   printf("shim_test ok: %d keypoints, %d depths, %d triangulation matches\n", nk, nd, nm);
   return 0;

@@ -95,3 +95,14 @@ def test_ingest_cvtcolor_then_extract(emu_lib):
 def test_ingest_kitti_bin_layout(emu_lib):
     assert pc.check_ingest_kitti_bin(emu_lib) > 10
     assert pc.check_ingest_kitti_bin(emu_lib, method=F.UPS_NEAREST_NEIGHBOR_PIXEL, seed=6) > 10
+
+
+@pytest.mark.parametrize("seed,motion,th,mono,ori", [(21, "forward", 7.0, False, True), (23, "backward", 15.0, False, True),
+                                                     (24, "none", 30.0, True, False)])
+def test_search_by_projection(emu_lib, seed, motion, th, mono, ori):
+    assert pc.check_search_by_projection(emu_lib, seed, motion, th, mono, ori, n1=700, n2=800) > 100
+
+
+def test_search_by_projection_edge_cases(emu_lib):
+    pc.check_search_by_projection_edge_cases(emu_lib)
+    assert pc.check_search_by_projection(emu_lib, 22, "forward", 15.0, False, True) > 300   # full-size frame pair

@@ -114,3 +114,14 @@ def test_ingest_cvtcolor_then_extract(gpu_lib):
 def test_ingest_kitti_bin_layout(gpu_lib):
     assert pc.check_ingest_kitti_bin(gpu_lib, w=synth.KITTI_W, h=synth.KITTI_H, n_az=1900, n_kp=1500) > 50
     assert pc.check_ingest_kitti_bin(gpu_lib, method=F.UPS_AVERAGE_FILTERING, seed=8) > 10
+
+
+@pytest.mark.parametrize("seed,motion,th,mono,ori", [(21, "forward", 7.0, False, True), (22, "forward", 15.0, False, True),
+                                                     (23, "backward", 7.0, False, True), (24, "none", 30.0, True, False)])
+def test_search_by_projection(gpu_lib, seed, motion, th, mono, ori):
+    assert pc.check_search_by_projection(gpu_lib, seed, motion, th, mono, ori) > 300
+
+
+def test_search_by_projection_edge_cases(gpu_lib):
+    pc.check_search_by_projection_edge_cases(gpu_lib)
+    assert pc.check_search_by_projection(gpu_lib, 27, "forward", 7.0, False, True, n1=7000, n2=8000) > 1000   # 4K-sized frames

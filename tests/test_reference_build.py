@@ -288,3 +288,27 @@ def test_reference_search_for_triangulation_agrees_with_oracle(refmatcher, seed,
     om, onm = O.search_triangulation(kf1, kf2, F, ep, sf, s2, only_stereo, coarse, check_ori)
     assert nm == onm and np.array_equal(m, om)
     assert nm > 5
+
+
+@pytest.mark.parametrize("seed,motion,th,mono,check_ori", [
+    (21, "forward", 7.0, False, True),     # RGB-L / stereo tracking: Tracking.cc:2917-2920 (th = 7)
+    (22, "forward", 15.0, False, True),
+    (23, "backward", 7.0, False, True),
+    (24, "none", 15.0, False, True),
+    (25, "forward", 15.0, True, True),     # bMono: level band +-1 regardless of the motion
+    (26, "none", 30.0, False, False),      # the retry with a wider window, orientation check off
+])
+def test_reference_search_by_projection_agrees_with_oracle(refmatcher, seed, motion, th, mono, check_ori):
+    import parity_checks as pc
+    case = pc.make_projection_case(seed=seed, motion=motion)
+    keep = []
+    P = O.make_projection_input(case, th, mono, check_ori, keep)
+    m = np.zeros(P.n2, np.int32)
+    refmatcher.ref_search_by_projection.restype = C.c_int
+    refmatcher.ref_search_by_projection.argtypes = [C.c_void_p, C.c_void_p]
+    nm = refmatcher.ref_search_by_projection(C.byref(P), m.ctypes.data)
+    om, onm = O.search_by_projection(case, th, mono, check_ori)
+    assert nm == onm and np.array_equal(m, om)
+    assert nm > 300
+    # the scenario must exercise the sequential rule: some map point did not get its nearest-descriptor feature
+    assert (m >= 0).sum() <= nm
