@@ -330,6 +330,17 @@ def main():
                     "algorithmic_bytes_per_frame": ab, "frames_per_launch": B,
                     "kernel_share_of_gpu_time": ms_sum / total_ms if total_ms else None,
                     "kernels_ms_per_step": {k: v[0] / prof_steps for k, v in sorted(kernels.items())}}
+        # achieved-HBM fraction of every kernel of the step (algorithmic bytes / its own time), north_star's per-kernel report
+        per_kernel = {}
+        step_bytes = 0.0
+        for k, v in sorted(kernels.items()):
+            kb = algorithmic_bytes(k, w, h, n_points, k_mean)
+            if kb and v[0] > 0:
+                gbs = kb * B / (v[0] / prof_steps * 1e-3) / 1e9
+                per_kernel[k] = {"GB/s": round(gbs, 1), "frac": round(gbs / 8000.0, 4)}
+                step_bytes += kb * B
+        roofline["per_kernel_hbm"] = per_kernel
+        roofline["step_algorithmic_GB/s"] = round(step_bytes / (elapsed / args.steps) / 1e9, 1)
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = min(B, 256)
             fps, n_done, stage_ms = cpu_baseline(frames[:n_cpu], scans, proj, w, h, nfeatures, args.cpu_budget)

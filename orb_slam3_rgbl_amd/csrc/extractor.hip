@@ -376,7 +376,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   int lap_cap = cap;
   if (lapping) lap_cap = std::min(cap, e->out_cap);
   e->timer.begin("k_orient_brief", s);
-  hipLaunchKernelGGL(k_orient_brief, dim3((e->kp_frame + 3) / 4, batch), dim3(256), 0, s, e->d_geom, L, e->umax,
+  hipLaunchKernelGGL(k_orient_brief, dim3((e->kp_frame + 4 * kKpPerWave - 1) / (4 * kKpPerWave), batch), dim3(256), 0, s, e->d_geom, L, e->umax,
                      e->d_pattern, d_imgs, stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame,
                      e->d_kpkey, e->d_kpcount, (size_t)e->kp_frame, kp_dst, desc_dst, lapping ? e->out_cap : cap, d_n,
                      lapping ? (int32_t*)nullptr : d_mono, e->d_err);

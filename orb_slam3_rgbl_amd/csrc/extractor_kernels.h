@@ -1158,9 +1158,24 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
-// One wave per keypoint: intensity-centroid angle on the un-blurred level, then the steered BRIEF-256
-// on the blurred level through a 37x37 LDS patch; four __ballot results are descriptor bytes 0-7, 8-15, ...
-// grid = (ceil(kp_frame / 4), B), block = 256.
+// Orientation + descriptor.  A wave owns kKpPerWave consecutive keypoint slots.  The pixel work of a keypoint (the moments
+// of the 31x31 circular patch, the 256 steered comparisons on the blurred 37x37 patch) is spread over the 64 lanes, one
+// keypoint after the other; everything that is ONE value per keypoint - slot -> (level, index), fastAtan2, the
+// double-precision sin / cos, the keypoint record - is evaluated once with lane k working for keypoint k, instead of
+// being replicated over all lanes of a one-keypoint wave (it was two thirds of the issued instructions).
+// Four __ballot results per keypoint are descriptor bytes 0-7, 8-15, 16-23, 24-31.
+// grid = (ceil(kp_frame / (4 * kKpPerWave)), B), block = 256.
+constexpr int kKpPerWave = 4;
+
+__device__ __forceinline__ int bcast_i(int v, int k) {  // value of lane k, wave-uniform (k is a constant after unrolling)
+#ifdef RGBL_EMU
+  return __shfl(v, k);
+#else
+  return __builtin_amdgcn_readlane(v, k);
+#endif
+}
+__device__ __forceinline__ float bcast_f(float v, int k) { return __int_as_float(bcast_i(__float_as_int(v), k)); }
+
 __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restrict__ geom, int n_levels, UMax umax,
                                                       const int8_t* __restrict__ pattern,
                                                       const uint8_t* __restrict__ img0, int pitch0, size_t frame0,
@@ -1176,18 +1191,18 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
   __shared__ uint32_t s_raw_w[4][31 * 8];     // un-blurred 31x31 neighbourhood, 32-byte rows
   const int lane = lane_id(), wave = wave_id();
   const int bx = blockIdx.x, f = blockIdx.y;
-
-  // which (level, index) does this wave own?  slots are laid out level after level with kcap entries each
-  const int slot = bx * 4 + wave;
-  int l = 0;
-  while (l + 1 < n_levels && slot >= geom[l + 1].koff) ++l;
-  const LevelGeom& g = geom[l];
-  const int idx = slot - g.koff;
   const int* cnts = kp_count + (size_t)f * n_levels;
-  bool valid = slot < (int)kp_frame && idx < cnts[l];
+
+  // ---- lane k < kKpPerWave: which (level, index) is slot s0 + k?  slots are laid out level after level, kcap entries each
+  const int s0 = (bx * 4 + wave) * kKpPerWave;
+  const int slot = s0 + (lane < kKpPerWave ? lane : 0);
+  int l = 0;
+  for (int j = 1; j < n_levels; ++j) l += (slot >= geom[j].koff) ? 1 : 0;  // koff ascends with the level
+  const int idx = slot - geom[l].koff;
+  bool valid = lane < kKpPerWave && slot < (int)kp_frame && idx < cnts[l];
   int dense = idx;  // position in the level-major output order
-  for (int j = 0; j < l; ++j) dense += cnts[j];
-  if (slot == 0 && lane == 0) {
+  for (int j = 0; j < n_levels; ++j) dense += (j < l) ? cnts[j] : 0;
+  if (s0 == 0 && lane == 0) {
     int total = 0;
     for (int j = 0; j < n_levels; ++j) total += cnts[j];
     out_n[f] = total < cap ? total : cap;
@@ -1195,86 +1210,120 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
     if (total > cap) atomicOr(err, 4);
   }
   if (valid && dense >= cap) valid = false;
+  const uint32_t key = valid ? kp_key[(size_t)f * kp_frame + slot] : 0u;
+  const int kx = key_x(key) + kMinBorder, ky = key_y(key) + kMinBorder;
+  const unsigned long long vmask = __ballot(valid);
+  if (vmask == 0) return;  // wave-uniform
 
-  // the lane's four pattern pairs (x0, y0, x1, y1 as signed bytes): requested first so that their latency hides
-  // behind the patch loads instead of following the orientation
+  // the lane's four pattern pairs (x0, y0, x1, y1 as signed bytes), the same for every keypoint
   uint32_t pw[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) pw[k] = reinterpret_cast<const uint32_t*>(pattern)[k * 64 + lane];
 
-  uint32_t key = 0;
-  int x = 0, y = 0;
-  uint8_t* patch = reinterpret_cast<uint8_t*>(s_patch_w[wave]);
-  if (valid) {
-    key = kp_key[(size_t)f * kp_frame + slot];
-    x = key_x(key) + kMinBorder;
-    y = key_y(key) + kMinBorder;
-    const uint8_t* img = (l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
-    const int pitch = (l == 0) ? pitch0 : g.pitch;
-    // both neighbourhoods are fetched as 32-bit words (keypoints sit >= 19 px inside the level, so x-18..x+21 and
-    // x-15..x+16 stay inside the row pitch)
+  // ---- all patch words of all keypoints are requested first (one exposed memory latency per wave instead of one per
+  //      keypoint and pass): 4 + 6 registers per keypoint.  Keypoints sit >= 19 px inside the level, so x-15..x+16 and
+  //      x-18..x+21 stay inside the row pitch.
+  uint32_t rawreg[kKpPerWave][4], blreg[kKpPerWave][6];
+#pragma unroll
+  for (int k = 0; k < kKpPerWave; ++k) {
+    if (!((vmask >> k) & 1)) continue;  // wave-uniform
+    const int lk = bcast_i(l, k), x = bcast_i(kx, k), y = bcast_i(ky, k);
+    const LevelGeom& g = geom[lk];
+    const uint8_t* img = (lk == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
+    const int pitch = (lk == 0) ? pitch0 : g.pitch;
     const uint8_t* src = img + (size_t)(y - 15) * pitch + (x - 15);
-    for (int i = lane; i < 31 * 8; i += 64) {
-      const int r = i >> 3, c = i & 7;
-      s_raw_w[wave][i] = load_u32_unaligned(src + (size_t)r * pitch + 4 * c);
-    }
-    const uint8_t* bl = blur + (size_t)f * blur_frame + g.img_off + (size_t)(y - 18) * g.pitch + (x - 18);
-    for (int i = lane; i < 37 * 10; i += 64) {
-      const int r = i / 10, c = i - r * 10;
-      s_patch_w[wave][i] = load_u32_unaligned(bl + (size_t)r * g.pitch + 4 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = lane + 64 * j;
+      rawreg[k][j] = i < 31 * 8 ? load_u32_unaligned(src + (size_t)(i >> 3) * pitch + 4 * (i & 7)) : 0u;
     }
   }
-  __syncthreads();
-  float angle = 0.f;
-  {
-    // IC_Angle (ORBextractor.cc:76-101): integer moments over the rows v = -15..15 of the circular patch
+#pragma unroll
+  for (int k = 0; k < kKpPerWave; ++k) {
+    if (!((vmask >> k) & 1)) continue;
+    const int lk = bcast_i(l, k), x = bcast_i(kx, k), y = bcast_i(ky, k);
+    const LevelGeom& g = geom[lk];
+    const uint8_t* bl = blur + (size_t)f * blur_frame + g.img_off + (size_t)(y - 18) * g.pitch + (x - 18);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int i = lane + 64 * j;
+      const int r = i / 10, c = i - r * 10;
+      blreg[k][j] = i < 37 * 10 ? load_u32_unaligned(bl + (size_t)r * g.pitch + 4 * c) : 0u;
+    }
+  }
+
+  // ---- pass 1, keypoint after keypoint: IC_Angle moments (ORBextractor.cc:76-101) over the rows v = -15..15
+  int my_m10 = 0, my_m01 = 0;
+#pragma unroll
+  for (int k = 0; k < kKpPerWave; ++k) {
+    if (!((vmask >> k) & 1)) continue;  // wave-uniform
+    wave_sync();  // the previous keypoint's readers are done with the buffer
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j < 31 * 8) s_raw_w[wave][lane + 64 * j] = rawreg[k][j];
+    wave_sync();
     int m10 = 0, m01 = 0;
-    if (valid && lane < 62) {
+    if (lane < 62) {
       // two lanes per row; the half row is read as four 32-bit LDS words (all in flight together) and the bytes
       // outside the circle (|u| > umax[|v|]) are masked, instead of a data-dependent byte loop
       const int r = lane >> 1, v = r - 15, half = lane & 1;
       const int d = umax.v[v < 0 ? -v : v];
       const uint32_t* roww = s_raw_w[wave] + r * 8 + half * 4;  // bytes u = -15..0 (half 0) or 1..16 (half 1)
-      const uint32_t w0 = roww[0], w1 = roww[1], w2 = roww[2], w3 = roww[3];
-      const uint32_t ws[4] = {w0, w1, w2, w3};
-      int s0 = 0, s1 = 0;
+      const uint32_t ws[4] = {roww[0], roww[1], roww[2], roww[3]};
+      int sum0 = 0, sum1 = 0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int u = half ? k + 1 : k - 15;
+      for (int q = 0; q < 16; ++q) {
+        const int u = half ? q + 1 : q - 15;
         const int au = u < 0 ? -u : u;
-        const int p = (au <= d && u <= 15) ? (int)((ws[k >> 2] >> (8 * (k & 3))) & 0xff) : 0;
-        s0 += p;
-        s1 += u * p;
+        const int p = (au <= d && u <= 15) ? (int)((ws[q >> 2] >> (8 * (q & 3))) & 0xff) : 0;
+        sum0 += p;
+        sum1 += u * p;
       }
-      m10 = s1;
-      m01 = v * s0;
+      m10 = sum1;
+      m01 = v * sum0;
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
-    angle = fast_atan2_deg((float)m01, (float)m10);
+    if (lane == k) { my_m10 = m10; my_m01 = m01; }
   }
-  unsigned long long bits[4] = {0, 0, 0, 0};
-  {
-    const float factor_pi = (float)(3.14159265358979323846 / 180.f);
-    const float ang = angle * factor_pi;
-    const float a = glibc_cosf(ang), b = glibc_sinf(ang);
-    const uint8_t* center = patch + 18 * 40 + 18;
+
+  // ---- once per keypoint, lane k for keypoint k: orientation and the steering coefficients
+  const float angle = fast_atan2_deg((float)my_m01, (float)my_m10);
+  const float factor_pi = (float)(3.14159265358979323846 / 180.f);
+  const float ang = angle * factor_pi;
+  const float ca = glibc_cosf(ang), sb = glibc_sinf(ang);
+
+  // ---- pass 2, keypoint after keypoint: steered BRIEF-256 on the blurred level through a 37x37 LDS patch
+  const uint8_t* patch = reinterpret_cast<const uint8_t*>(s_patch_w[wave]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float x0 = (float)(int8_t)(pw[k] & 0xff), y0 = (float)(int8_t)((pw[k] >> 8) & 0xff),
-                  x1 = (float)(int8_t)((pw[k] >> 16) & 0xff), y1 = (float)(int8_t)(pw[k] >> 24);
+  for (int k = 0; k < kKpPerWave; ++k) {
+    if (!((vmask >> k) & 1)) continue;  // wave-uniform
+    const int dk = bcast_i(dense, k);
+    const float a = bcast_f(ca, k), b = bcast_f(sb, k);
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      if (lane + 64 * j < 37 * 10) s_patch_w[wave][lane + 64 * j] = blreg[k][j];
+    wave_sync();
+    const uint8_t* center = patch + 18 * 40 + 18;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float x0 = (float)(int8_t)(pw[q] & 0xff), y0 = (float)(int8_t)((pw[q] >> 8) & 0xff),
+                  x1 = (float)(int8_t)((pw[q] >> 16) & 0xff), y1 = (float)(int8_t)(pw[q] >> 24);
       const int t0 = center[cv_round_f(x0 * b + y0 * a) * 40 + cv_round_f(x0 * a - y0 * b)];
       const int t1 = center[cv_round_f(x1 * b + y1 * a) * 40 + cv_round_f(x1 * a - y1 * b)];
-      bits[k] = __ballot(valid && t0 < t1);
+      bits[q] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(out_desc + ((size_t)f * cap + dk) * 32);
+      d[lane] = bits[lane];
     }
   }
-  if (valid && lane < 4) {
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(out_desc + ((size_t)f * cap + dense) * 32);
-    d[lane] = bits[lane];
-  }
-  if (valid && lane == 0) {
+  if (valid) {
+    const LevelGeom& g = geom[l];
     rgbl_keypoint kp;
-    kp.x = (float)x; kp.y = (float)y;
+    kp.x = (float)kx; kp.y = (float)ky;
     if (l != 0) { kp.x = kp.x * g.scale; kp.y = kp.y * g.scale; }
     kp.size = (float)g.patch_size;
     kp.angle = angle;
