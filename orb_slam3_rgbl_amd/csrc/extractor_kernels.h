@@ -563,6 +563,80 @@ __device__ __forceinline__ void node_place(const QNode& nd, uint32_t* keys_a, ui
     if (valid) dst[my_pos] = key;
   }
 }
+// first 64 keys of a node, one per lane (0 beyond the end)
+__device__ __forceinline__ uint32_t node_first_keys(const QNode& nd, const uint32_t* keys_a, const uint32_t* keys_b) {
+  const uint32_t cnt = nd.cnt & 0x7fffffffu;
+  const uint32_t* src = ((nd.cnt >> 31) ? keys_b : keys_a) + nd.beg;
+  return (uint32_t)lane_id() < cnt ? src[lane_id()] : 0u;
+}
+// count + place of a node whose first 64 keys (key0) are already in registers: nodes of at most 64 keys - nearly all of
+// them after the first two rounds - are split without touching their keys again
+__device__ __forceinline__ void node_split(const QNode& nd, uint32_t key0, uint32_t* keys_a, uint32_t* keys_b, uint32_t c[4]) {
+  const uint32_t cnt = nd.cnt & 0x7fffffffu;
+  if (cnt > 64) {
+    node_count(nd, keys_a, keys_b, c);
+    node_place(nd, keys_a, keys_b, c);
+    return;
+  }
+  uint32_t* dst = (((nd.cnt >> 31) != 0) ? keys_a : keys_b) + nd.beg;
+  const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+  const int lane = lane_id();
+  const bool valid = (uint32_t)lane < cnt;
+  const int q = valid ? quadrant_of(key0, mx, my) : -1;
+  const unsigned long long lt = lanemask_lt();
+  unsigned long long m[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { m[k] = __ballot(q == k); c[k] = (uint32_t)__popcll(m[k]); }
+  const uint32_t o[4] = {0, c[0], c[0] + c[1], c[0] + c[1] + c[2]};
+  if (valid) dst[o[q] + (uint32_t)__popcll(m[q] & lt)] = key0;
+}
+// the two halves separately (the quota phase counts every expandable node first and places only some of them)
+__device__ __forceinline__ void node_count_k0(const QNode& nd, uint32_t key0, const uint32_t* keys_a, const uint32_t* keys_b, uint32_t c[4]) {
+  const uint32_t cnt = nd.cnt & 0x7fffffffu;
+  if (cnt > 64) { node_count(nd, keys_a, keys_b, c); return; }
+  const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+  const int q = (uint32_t)lane_id() < cnt ? quadrant_of(key0, mx, my) : -1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c[k] = (uint32_t)__popcll(__ballot(q == k));
+}
+__device__ __forceinline__ void node_place_k0(const QNode& nd, uint32_t key0, uint32_t* keys_a, uint32_t* keys_b, const uint32_t c[4]) {
+  const uint32_t cnt = nd.cnt & 0x7fffffffu;
+  if (cnt > 64) { node_place(nd, keys_a, keys_b, c); return; }
+  uint32_t* dst = (((nd.cnt >> 31) != 0) ? keys_a : keys_b) + nd.beg;
+  const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+  const bool valid = (uint32_t)lane_id() < cnt;
+  const int q = valid ? quadrant_of(key0, mx, my) : -1;
+  const unsigned long long lt = lanemask_lt();
+  const uint32_t o[4] = {0, c[0], c[0] + c[1], c[0] + c[1] + c[2]};
+  uint32_t my_pos = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long m = __ballot(q == k);
+    if (q == k) my_pos = o[k] + (uint32_t)__popcll(m & lt);
+  }
+  if (valid) dst[my_pos] = key0;
+}
+// Wave-strided walk over nodes with the dependent loads taken off the critical path: while node t is processed, the
+// descriptor of node t + 2 strides and the keys of node t + 1 stride are already in flight (a node costs three dependent
+// global loads otherwise: position -> descriptor -> keys).  pos_of(t) = list position of the t-th node; body(t, node, key0).
+template <class PosOf, class Body>
+__device__ __forceinline__ void for_nodes_pipelined(const QNode* cur, int first, int count, int stride, const uint32_t* keys_a,
+                                                    const uint32_t* keys_b, PosOf&& pos_of, Body&& body) {
+  QNode nd_a, nd_b;
+  nd_a.x0 = nd_a.x1 = nd_a.y0 = nd_a.y1 = 0; nd_a.beg = 0; nd_a.cnt = 0;
+  nd_b = nd_a;
+  if (first < count) nd_a = cur[pos_of(first)];
+  if (first + stride < count) nd_b = cur[pos_of(first + stride)];
+  uint32_t key_a = first < count ? node_first_keys(nd_a, keys_a, keys_b) : 0u;
+  for (int t = first; t < count; t += stride) {
+    QNode nd_c = nd_a;
+    if (t + 2 * stride < count) nd_c = cur[pos_of(t + 2 * stride)];
+    const uint32_t key_b = t + stride < count ? node_first_keys(nd_b, keys_a, keys_b) : 0u;
+    body(t, nd_a, key_a);
+    nd_a = nd_b; key_a = key_b; nd_b = nd_c;
+  }
+}
+
 __device__ __forceinline__ QNode child_node(const QNode& nd, int q, uint32_t beg, uint32_t cnt) {
   const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
   QNode c;
@@ -1015,17 +1089,13 @@ __global__ __launch_bounds__(BS, 4) void k_octree(const LevelGeom* __restrict__ 
       if (tid == 0) { div[pos] = d; divided[pos] = 0; }
     }
     // everything else: one wave per node
-    for (int pos = wave; pos < n; pos += nw) {
-      const QNode nd = cur[pos];
+    for_nodes_pipelined(cur, wave, n, nw, keys_a, keys_b, [](int t) { return t; }, [&](int pos, const QNode& nd, uint32_t key0) {
       const uint32_t cnt = nd.cnt & 0x7fffffffu;
-      if (cnt >= (uint32_t)kCoopMin && nbig > 0) continue;  // already split above
+      if (cnt >= (uint32_t)kCoopMin && nbig > 0) return;  // already split above
       QDiv d; d.c[0] = d.c[1] = d.c[2] = d.c[3] = 0;
-      if (cnt > 1) {
-        node_count(nd, keys_a, keys_b, d.c);
-        node_place(nd, keys_a, keys_b, d.c);
-      }
+      if (cnt > 1) node_split(nd, key0, keys_a, keys_b, d.c);
       if (lane == 0) { div[pos] = d; divided[pos] = 0; }
-    }
+    });
     __syncthreads();
     rebuild_list<true, BS>(cur, nxt, n, div, n, nullptr, 0, divided, todo_n, s_scan, &s_newn, &s_nexp);
     const int newn = s_newn, nexp = s_nexp;
@@ -1072,12 +1142,11 @@ __global__ __launch_bounds__(BS, 4) void k_octree(const LevelGeom* __restrict__ 
       __syncthreads();
     }
     // child counts of every expandable node, rank rho = position counted from the back of the sorted array
-    for (int j = wave; j < m; j += nw) {
-      const QNode nd = cur[sval[j]];
+    for_nodes_pipelined(cur, wave, m, nw, keys_a, keys_b, [&](int j) { return (int)sval[j]; }, [&](int j, const QNode& nd, uint32_t key0) {
       QDiv d;
-      node_count(nd, keys_a, keys_b, d.c);
+      node_count_k0(nd, key0, keys_a, keys_b, d.c);
       if (lane == 0) div[m - 1 - j] = d;
-    }
+    });
     if (tid == 0) s_P = m;
     __syncthreads();
     // first rank after which the list has reached the quota (the reference breaks out of its loop there)
@@ -1100,11 +1169,11 @@ __global__ __launch_bounds__(BS, 4) void k_octree(const LevelGeom* __restrict__ 
     }
     __syncthreads();
     const int P = s_P;
-    for (int rho = wave; rho < P; rho += nw) {
-      const QNode nd = cur[sval[m - 1 - rho]];
+    for_nodes_pipelined(cur, wave, P, nw, keys_a, keys_b, [&](int rho) { return (int)sval[m - 1 - rho]; },
+                        [&](int rho, const QNode& nd, uint32_t key0) {
       const QDiv d = div[rho];
-      node_place(nd, keys_a, keys_b, d.c);
-    }
+      node_place_k0(nd, key0, keys_a, keys_b, d.c);
+    });
     __syncthreads();
     rebuild_list<false, BS>(cur, nxt, n, div, P, sval, m, divided, todo_n, s_scan, &s_newn, &s_nexp);
     { QNode* t = cur; cur = nxt; nxt = t; }
