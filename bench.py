@@ -172,6 +172,10 @@ def main():
         one = C.c_void_p(lib.rgbl_extractor_stream(ex.h))
         L.check(lib, lib.rgbl_depth_set_stream(dm.h, one))
         L.check(lib, lib.rgbl_matcher_set_stream(mt.h, one))
+        # per-kernel HIP-event brackets on from the first step: the extractor then keeps its Gaussian on the main
+        # stream as well, so every launch of the run is serialised - the mode `rocprofv3 --kernel-trace --stats` is
+        # recorded in (profiles/), whose average durations are the ones the roofline leg below measures
+        ex.profile(True); dm.profile(True); mt.profile(True)
     s_ex = C.c_void_p(lib.rgbl_extractor_stream(ex.h))
     s_dm = C.c_void_p(lib.rgbl_depth_stream(dm.h))
     s_mt = C.c_void_p(lib.rgbl_matcher_stream(mt.h))

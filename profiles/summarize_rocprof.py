@@ -10,8 +10,12 @@ import sys
 
 
 def short(name):
-    name = name.split("(")[0]
-    return name.replace("rgbl::", "")
+    name = name.split("(")[0].replace("rgbl::", "")
+    if name.startswith("void "):
+        name = name[5:]
+    if name.startswith("k_"):  # our kernels: drop the template arguments (k_fast_cells<48> -> k_fast_cells)
+        name = name.split("<")[0]
+    return name
 
 
 def stats(db, out):
