@@ -345,6 +345,35 @@ typedef struct {
  * in CurrentFrame.mvpMapPoints[i2], or -1.  *out_nmatches = return value of the reference function. */
 int rgbl_search_by_projection(rgbl_matcher* h, const rgbl_projection_input* in, int32_t* match2, int* out_nmatches);
 
+/* int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints,
+ * const float thFarPoints) (include/ORBmatcher.h:45, src/ORBmatcher.cc:43-213 with RadiusByViewingCos :215-221; caller
+ * Tracking::SearchLocalPoints, src/Tracking.cc:3370-3450): the local map points that Frame::isInFrustum found visible are
+ * searched around their predicted projection - best / second-best Hamming distance, ratio test inside one pyramid level.
+ * Single-camera frames.  SURVEY.md 8(f) row f2. */
+typedef struct {
+  int n1;                      /* vpMapPoints.size() */
+  const uint8_t* valid1;       /* pMP->mbTrackInView && !(bFarPoints && pMP->mTrackDepth > thFarPoints) && !pMP->isBad() */
+  const float* proj1;          /* pMP->mTrackProjX, mTrackProjY, mTrackProjXR: 3 floats per point */
+  const int32_t* level1;       /* pMP->mnTrackScaleLevel */
+  const float* view_cos1;      /* pMP->mTrackViewCos */
+  const uint8_t* mp_desc1;     /* pMP->GetDescriptor(), 32 bytes per point */
+  const uint8_t* mp_observed1; /* pMP->Observations() > 0 */
+  int n2;                      /* F.N (<= 65535) */
+  const float* kp2_xy;         /* F.mvKeysUn[i].pt */
+  const int32_t* kp2_octave;
+  const float* uright2;        /* F.mvuRight */
+  const uint8_t* desc2;        /* F.mDescriptors */
+  const uint8_t* blocked2;     /* F.mvpMapPoints[i] != NULL && ->Observations() > 0 on entry (nullable: none) */
+  float grid[6];               /* Frame::mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv */
+  const float* scale_factors;  /* F.mvScaleFactors */
+  int n_levels;
+  float th;
+  float nnratio;               /* mfNNratio */
+} rgbl_local_points_input;
+/* Host pointers, synchronous.  match2 (n2 entries): index of the map point the call stores in F.mvpMapPoints[i2], or -1
+ * (entry left as it was).  *out_nmatches = return value of the reference function. */
+int rgbl_search_local_points(rgbl_matcher* h, const rgbl_local_points_input* in, int32_t* match2, int* out_nmatches);
+
 /* F12 with the reference's fp32 evaluation order (Pinhole.cpp:109-112); K = {fx, fy, cx, cy}. Host. */
 void rgbl_fundamental(const float K1[4], const float K2[4], const float R12[9], const float t12[3],
                       float F12[9]);

@@ -300,3 +300,75 @@ extern "C" int orc_search_by_projection(const orc_projection_input* in, int* mat
   for (int i = 0; i < in->n2; ++i) match2[i] = holder[i];
   return nmatches;
 }
+
+// ---- ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints), ORBmatcher.cc:43-213 ----
+// (single camera) with RadiusByViewingCos (:215-221) and Frame::GetFeaturesInArea (src/Frame.cc:747-813)
+extern "C" int orc_search_local_points(const orc_local_points_input* in, int* match2) {
+  const int COLS = 64, ROWS = 48;
+  const float mnMinX = in->grid[0], mnMinY = in->grid[1], invW = in->grid[4], invH = in->grid[5];
+  std::vector<std::vector<int>> cells((size_t)COLS * ROWS);
+  for (int i = 0; i < in->n2; ++i) {
+    const int px = (int)roundf((in->kp2_xy[2 * i] - mnMinX) * invW), py = (int)roundf((in->kp2_xy[2 * i + 1] - mnMinY) * invH);
+    if (px < 0 || px >= COLS || py < 0 || py >= ROWS) continue;
+    cells[(size_t)px * ROWS + py].push_back(i);
+  }
+  std::vector<int> holder(in->n2, -1);  // map point assigned by THIS call
+  const bool bFactor = in->th != 1.0;
+  int nmatches = 0;
+  for (int i = 0; i < in->n1; ++i) {
+    if (!in->valid1[i]) continue;
+    const int nPredictedLevel = in->level1[i];
+    float r = in->view_cos1[i] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos
+    if (bFactor) r *= in->th;
+    const float x = in->proj1[3 * i], y = in->proj1[3 * i + 1], xr = in->proj1[3 * i + 2];
+    const float radius = r * in->scale_factors[nPredictedLevel];
+    const int minLevel = nPredictedLevel - 1, maxLevel = nPredictedLevel;
+    if (!(x == x) || !(y == y)) continue;
+    const int nMinCellX = std::max(0, (int)floorf((x - mnMinX - radius) * invW));
+    if (nMinCellX >= COLS) continue;
+    const int nMaxCellX = std::min(COLS - 1, (int)ceilf((x - mnMinX + radius) * invW));
+    if (nMaxCellX < 0) continue;
+    const int nMinCellY = std::max(0, (int)floorf((y - mnMinY - radius) * invH));
+    if (nMinCellY >= ROWS) continue;
+    const int nMaxCellY = std::min(ROWS - 1, (int)ceilf((y - mnMinY + radius) * invH));
+    if (nMaxCellY < 0) continue;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    bool any = false;
+    const uint8_t* d1 = in->mp_desc1 + 32 * (size_t)i;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+      for (int iy = nMinCellY; iy <= nMaxCellY; ++iy)
+        for (int idx : cells[(size_t)ix * ROWS + iy]) {
+          if (bCheckLevels) {
+            if (in->kp2_octave[idx] < minLevel) continue;
+            if (maxLevel >= 0 && in->kp2_octave[idx] > maxLevel) continue;
+          }
+          const float distx = in->kp2_xy[2 * idx] - x, disty = in->kp2_xy[2 * idx + 1] - y;
+          if (!(fabsf(distx) < radius && fabsf(disty) < radius)) continue;
+          any = true;
+          // F.mvpMapPoints[idx] holds a point with observations: on entry, or assigned earlier in this loop
+          if (in->blocked2[idx] && holder[idx] < 0) continue;
+          if (holder[idx] >= 0 && in->mp_observed1[holder[idx]]) continue;
+          if (in->uright2[idx] > 0) {
+            const float er = fabsf(xr - in->uright2[idx]);
+            if (er > radius) continue;
+          }
+          const int dist = hamming256(d1, in->desc2 + 32 * (size_t)idx);
+          if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = in->kp2_octave[idx]; bestIdx = idx;
+          } else if (dist < bestDist2) {
+            bestLevel2 = in->kp2_octave[idx]; bestDist2 = dist;
+          }
+        }
+    if (!any) continue;
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && (float)bestDist > in->nnratio * (float)bestDist2) continue;
+      if (bestLevel != bestLevel2 || (float)bestDist <= in->nnratio * (float)bestDist2) {
+        holder[bestIdx] = i;
+        ++nmatches;
+      }
+    }
+  }
+  for (int i = 0; i < in->n2; ++i) match2[i] = holder[i];
+  return nmatches;
+}

@@ -170,6 +170,32 @@ typedef struct {
 /* match2[i2] = index of the LastFrame feature whose map point ends up in CurrentFrame.mvpMapPoints[i2], or -1.
  * Returns nmatches exactly as the reference counts it. */
 int orc_search_by_projection(const orc_projection_input* in, int* match2);
+
+/* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)
+ * (/root/reference/src/ORBmatcher.cc:43-213, single camera; called by Tracking::SearchLocalPoints, Tracking.cc:3447):
+ * local map points that Frame::isInFrustum found visible are searched around their predicted projection. */
+typedef struct {
+  int n1;                      /* vpMapPoints.size() */
+  const uint8_t* valid1;       /* mbTrackInView && !(bFarPoints && mTrackDepth > thFarPoints) && !isBad() */
+  const float* proj1;          /* mTrackProjX, mTrackProjY, mTrackProjXR: 3 floats per point */
+  const int32_t* level1;       /* mnTrackScaleLevel */
+  const float* view_cos1;      /* mTrackViewCos */
+  const uint8_t* mp_desc1;     /* GetDescriptor(), 32 bytes per point */
+  const uint8_t* mp_observed1; /* Observations() > 0 */
+  int n2;                      /* F.N */
+  const float* kp2_xy;         /* F.mvKeysUn[i].pt */
+  const int32_t* kp2_octave;
+  const float* uright2;        /* F.mvuRight */
+  const uint8_t* desc2;        /* F.mDescriptors */
+  const uint8_t* blocked2;     /* F.mvpMapPoints[i] != NULL && ->Observations() > 0 on entry */
+  float grid[6];               /* mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv */
+  const float* scale_factors;  /* F.mvScaleFactors */
+  int n_levels;
+  float th;
+  float nnratio;               /* mfNNratio */
+} orc_local_points_input;
+/* match2[i2] = index of the map point the call assigns to F.mvpMapPoints[i2], or -1 (left as it was). Returns nmatches. */
+int orc_search_local_points(const orc_local_points_input* in, int* match2);
 /* F12 = K1^-T [t]x R12 K2^-1 with Eigen's evaluation order in fp32 */
 void orc_fundamental(const float K1[4], const float K2[4], const float R12[9], const float t12[3],
                      float F12[9]);

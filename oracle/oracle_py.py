@@ -70,6 +70,44 @@ def search_by_projection(case, th=7.0, mono=False, check_orientation=True):
     return m, n
 
 
+class LocalPointsInput(C.Structure):
+    """orc_local_points_input == rgbl_local_points_input (same layout)."""
+    _fields_ = [("n1", C.c_int), ("valid1", C.c_void_p), ("proj1", C.c_void_p), ("level1", C.c_void_p),
+                ("view_cos1", C.c_void_p), ("mp_desc1", C.c_void_p), ("mp_observed1", C.c_void_p),
+                ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p), ("uright2", C.c_void_p),
+                ("desc2", C.c_void_p), ("blocked2", C.c_void_p), ("grid", C.c_float * 6), ("scale_factors", C.c_void_p),
+                ("n_levels", C.c_int), ("th", C.c_float), ("nnratio", C.c_float)]
+
+
+def make_local_points_input(case, th, nnratio, keep):
+    def arr(v, dt):
+        a = np.ascontiguousarray(v, dt)
+        keep.append(a)
+        return a.ctypes.data
+    P = LocalPointsInput()
+    P.n1 = len(case["valid1"])
+    P.valid1, P.proj1, P.level1 = arr(case["valid1"], np.uint8), arr(case["proj1"], np.float32), arr(case["level1"], np.int32)
+    P.view_cos1, P.mp_desc1 = arr(case["view_cos1"], np.float32), arr(case["mp_desc1"], np.uint8)
+    P.mp_observed1 = arr(case["mp_observed1"], np.uint8)
+    P.n2 = len(case["kp2_xy"])
+    P.kp2_xy, P.kp2_octave = arr(case["kp2_xy"], np.float32), arr(case["kp2_octave"], np.int32)
+    P.uright2, P.desc2, P.blocked2 = arr(case["uright2"], np.float32), arr(case["desc2"], np.uint8), arr(case["blocked2"], np.uint8)
+    for i in range(6):
+        P.grid[i] = float(case["grid"][i])
+    P.scale_factors = arr(case["scale_factors"], np.float32)
+    P.n_levels = len(case["scale_factors"])
+    P.th, P.nnratio = float(th), float(nnratio)
+    return P
+
+
+def search_local_points(case, th=1.0, nnratio=0.8):
+    keep = []
+    P = make_local_points_input(case, th, nnratio, keep)
+    m = np.zeros(P.n2, np.int32)
+    n = lib().orc_search_local_points(C.byref(P), _p(m))
+    return m, n
+
+
 class TriInput(C.Structure):
     _fields_ = [("n1", C.c_int), ("n2", C.c_int),
                 ("desc1", C.c_void_p), ("desc2", C.c_void_p),
@@ -119,6 +157,8 @@ def lib():
         L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_kitti_bin_to_cloud.restype = None
         L.orc_kitti_bin_to_cloud.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_search_local_points.restype = C.c_int
+        L.orc_search_local_points.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_search_by_projection.restype = C.c_int
         L.orc_search_by_projection.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_fast.restype = C.c_int

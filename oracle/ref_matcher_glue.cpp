@@ -222,3 +222,52 @@ extern "C" int ref_search_by_projection(const orc_projection_input* in, int* mat
   for (int i = 0; i < in->n2; ++i) match2[i] = cur.mvpMapPoints[i] ? (int)(cur.mvpMapPoints[i] - points.data()) : -1;
   return nm;
 }
+
+// ORBmatcher(nnratio, true).SearchByProjection(F, vpMapPoints, th, bFarPoints = false, thFarPoints) (ORBmatcher.cc:43-213).
+// valid1 folds mbTrackInView / isBad; features blocked on entry hold a dummy point with observations.
+extern "C" int ref_search_local_points(const orc_local_points_input* in, int* match2) {
+  GeometricCamera cam;
+  Frame F;
+  std::vector<MapPoint> points(in->n1);
+  std::vector<MapPoint*> vp(in->n1);
+  for (int i = 0; i < in->n1; ++i) {
+    MapPoint& mp = points[i];
+    mp.mbTrackInView = in->valid1[i] != 0;
+    mp.mbTrackInViewR = false;
+    mp.mTrackProjX = in->proj1[3 * i]; mp.mTrackProjY = in->proj1[3 * i + 1]; mp.mTrackProjXR = in->proj1[3 * i + 2];
+    mp.mnTrackScaleLevel = in->level1[i];
+    mp.mTrackViewCos = in->view_cos1[i];
+    mp.mDescriptor = cv::Mat(1, 32, CV_8U);
+    memcpy(mp.mDescriptor.data, in->mp_desc1 + 32 * (size_t)i, 32);
+    mp.nObs = in->mp_observed1[i] ? 3 : 0;
+    vp[i] = &mp;
+  }
+  MapPoint old_point;
+  old_point.nObs = 5;
+  F.N = in->n2;
+  F.mpCamera = &cam;
+  F.mvKeysUn.resize(in->n2);
+  for (int i = 0; i < in->n2; ++i) {
+    F.mvKeysUn[i].pt.x = in->kp2_xy[2 * i]; F.mvKeysUn[i].pt.y = in->kp2_xy[2 * i + 1];
+    F.mvKeysUn[i].octave = in->kp2_octave[i];
+  }
+  F.mvKeys = F.mvKeysUn;
+  F.mvuRight.assign(in->uright2, in->uright2 + in->n2);
+  F.mDescriptors = cv::Mat(in->n2, 32, CV_8U);
+  if (in->n2) memcpy(F.mDescriptors.data, in->desc2, (size_t)in->n2 * 32);
+  F.mvScaleFactors.assign(in->scale_factors, in->scale_factors + in->n_levels);
+  F.mvpMapPoints.assign(in->n2, nullptr);
+  for (int i = 0; i < in->n2; ++i)
+    if (in->blocked2[i]) F.mvpMapPoints[i] = &old_point;
+  Frame::mnMinX = F.grid.mnMinX = in->grid[0]; Frame::mnMinY = F.grid.mnMinY = in->grid[1];
+  Frame::mnMaxX = F.grid.mnMaxX = in->grid[2]; Frame::mnMaxY = F.grid.mnMaxY = in->grid[3];
+  F.grid.mfGridElementWidthInv = in->grid[4]; F.grid.mfGridElementHeightInv = in->grid[5];
+  F.grid.Build(F.mvKeysUn);
+  ORBmatcher matcher(in->nnratio, true);
+  const int nm = matcher.SearchByProjection(F, vp, in->th, false, 50.0f);
+  for (int i = 0; i < in->n2; ++i) {
+    MapPoint* p = F.mvpMapPoints[i];
+    match2[i] = (p && p != &old_point) ? (int)(p - points.data()) : -1;
+  }
+  return nm;
+}

@@ -63,6 +63,15 @@ class ProjectionInput(C.Structure):
                 ("n_levels", C.c_int), ("th", C.c_float), ("mono", C.c_int), ("check_orientation", C.c_int)]
 
 
+class LocalPointsInput(C.Structure):
+    """rgbl_local_points_input (ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...) as flat arrays)."""
+    _fields_ = [("n1", C.c_int), ("valid1", C.c_void_p), ("proj1", C.c_void_p), ("level1", C.c_void_p),
+                ("view_cos1", C.c_void_p), ("mp_desc1", C.c_void_p), ("mp_observed1", C.c_void_p),
+                ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p), ("uright2", C.c_void_p),
+                ("desc2", C.c_void_p), ("blocked2", C.c_void_p), ("grid", C.c_float * 6), ("scale_factors", C.c_void_p),
+                ("n_levels", C.c_int), ("th", C.c_float), ("nnratio", C.c_float)]
+
+
 # name -> (restype, argtypes); every symbol of include/rgbl_frontend.h
 _V, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SYMBOLS = {
@@ -122,6 +131,7 @@ SYMBOLS = {
     "rgbl_search_triangulation": (_I, [_V, C.POINTER(KeyframeView), C.POINTER(KeyframeView),
                                        C.POINTER(TriangulationParams), _V, C.POINTER(_I)]),
     "rgbl_search_by_projection": (_I, [_V, _V, _V, C.POINTER(_I)]),
+    "rgbl_search_local_points": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_fundamental": (None, [_V, _V, _V, _V, _V]),
 }
 

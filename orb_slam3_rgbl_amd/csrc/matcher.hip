@@ -178,6 +178,12 @@ struct ProjDev {
   const uint8_t* desc2;
   float grid[6], q[4], t[3], K[4], mbf, th, scale[kProjMaxLevels];
   int forward, backward;
+  // the vpMapPoints overload (ORBmatcher.cc:43-213) instead of wpos1 / oct1 / q / t / K:
+  const float* proj1;        // mTrackProjX, mTrackProjY, mTrackProjXR
+  const int32_t* level1;     // mnTrackScaleLevel
+  const float* viewcos1;     // mTrackViewCos
+  const uint8_t* blocked2;   // feature holds an observed map point on entry (nullptr: none)
+  float nnratio;
   // scratch
   uint32_t* cell_start;      // kGridCells + 1
   uint16_t* cell_items;      // n2 feature indices grouped by grid cell
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(kProjBS) void k_proj_grid(ProjDev P) {
   for (int c = tid; c < P.n2; c += kProjBS) {
     const int px = (int)roundf((P.xy2[2 * c] - P.grid[0]) * P.grid[4]), py = (int)roundf((P.xy2[2 * c + 1] - P.grid[1]) * P.grid[5]);
     if (px >= 0 && px < kGridCols && py >= 0 && py < kGridRows) atomicAdd(&s_fill[px * kGridRows + py], 1u);
-    P.taken_by[c] = INT_MAX;
+    P.taken_by[c] = (P.blocked2 && P.blocked2[c]) ? -1 : INT_MAX;  // -1: held by a point from before the call
   }
   __syncthreads();
   uint32_t carry = 0;
@@ -258,6 +264,17 @@ __global__ __launch_bounds__(kProjBS) void k_proj_grid(ProjDev P) {
   for (int c = tid; c < P.n2; c += kProjBS) {
     const int px = (int)roundf((P.xy2[2 * c] - P.grid[0]) * P.grid[4]), py = (int)roundf((P.xy2[2 * c + 1] - P.grid[1]) * P.grid[5]);
     if (px >= 0 && px < kGridCols && py >= 0 && py < kGridRows) P.cell_items[atomicAdd(&s_fill[px * kGridRows + py], 1u)] = (uint16_t)c;
+  }
+  __syncthreads();
+  // ascending feature index inside every cell = the push_back order of AssignFeaturesToGrid (cells hold a handful of items)
+  for (int cell = tid; cell < kGridCells; cell += kProjBS) {
+    const uint32_t b = P.cell_start[cell], e = s_fill[cell];
+    for (uint32_t i = b + 1; i < e; ++i) {
+      const uint16_t v = P.cell_items[i];
+      uint32_t j = i;
+      while (j > b && P.cell_items[j - 1] > v) { P.cell_items[j] = P.cell_items[j - 1]; --j; }
+      P.cell_items[j] = v;
+    }
   }
 }
 
@@ -374,6 +391,124 @@ __global__ __launch_bounds__(kProjBS) void k_proj_resolve(ProjDev P) {
       P.state[i] = 1;
       const int c = P.choice[i];
       if (c >= 0 && P.obs1[i]) P.taken_by[c] = i;  // two blockers can never become final on one feature in the same round
+    }
+    __syncthreads();
+    if (s_unres == 0) break;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, ...) (ORBmatcher.cc:43-213; single camera),
+// the matcher of Tracking::SearchLocalPoints.  Same greedy order and blocking rule as above, but a point's decision is
+// best AND second-best distance with their pyramid levels (ratio test only inside one level), so the candidates are
+// kept in traversal order (distance << 32 | level << 16 | feature) and the sequential scan is replayed on the available
+// ones; a point is final once no unresolved lower-index blocker can still take ANY of its available candidates.
+struct LocalScan {
+  int best_dist = 256, best_level = -1, best_dist2 = 256, best_level2 = -1, best_idx = -1;
+  __device__ __forceinline__ void visit(int dist, int level, int c) {  // ORBmatcher.cc:104-122
+    if (dist < best_dist) { best_dist2 = best_dist; best_dist = dist; best_level2 = best_level; best_level = level; best_idx = c; }
+    else if (dist < best_dist2) { best_level2 = level; best_dist2 = dist; }
+  }
+  __device__ __forceinline__ int accept(float nnratio) const {  // ORBmatcher.cc:125-141; feature index or -1
+    if (best_dist > 100 /* TH_HIGH */) return -1;
+    if (best_level == best_level2 && (float)best_dist > nnratio * (float)best_dist2) return -1;
+    return best_idx;
+  }
+};
+
+// grid = ceil(n1 / 64), block = 64
+__global__ __launch_bounds__(64) void k_local_candidates(ProjDev P) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= P.n1) return;
+  uint8_t st = 1;
+  int n = 0;
+  P.choice[i] = -1;
+  if (P.valid1[i]) {
+    const int level = P.level1[i];
+    float r = (double)P.viewcos1[i] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos: the literal is a double in the reference
+    if (P.th != 1.0f) r *= P.th;
+    const float x = P.proj1[3 * i], y = P.proj1[3 * i + 1];
+    const float radius = r * P.scale[level];
+    if (x == x && y == y) {
+      const int x0 = imax(0, (int)floorf((x - P.grid[0] - radius) * P.grid[4]));
+      const int x1 = imin(kGridCols - 1, (int)ceilf((x - P.grid[0] + radius) * P.grid[4]));
+      const int y0 = imax(0, (int)floorf((y - P.grid[1] - radius) * P.grid[5]));
+      const int y1 = imin(kGridRows - 1, (int)ceilf((y - P.grid[1] + radius) * P.grid[5]));
+      if (x0 < kGridCols && x1 >= 0 && y0 < kGridRows && y1 >= 0) {
+        const float4 w = make_float4(x, y, radius, P.proj1[3 * i + 2]);
+        const int4 rg = make_int4(x0 | (x1 << 8), y0 | (y1 << 8), level - 1, level);
+        P.win[i] = w;
+        P.rng[i] = rg;
+        const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
+        const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+        int total = 0;
+        for_candidates(P, w, rg, [&](int c, int) {
+          if (total < kProjCand) {
+            const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
+            P.cand[(size_t)i * kProjCand + total] = ((unsigned long long)dist << 32) | ((unsigned long long)P.oct2[c] << 16) | (unsigned)c;
+          }
+          ++total;
+        });
+        n = total <= kProjCand ? total : (kProjCand | kProjOverflow);
+        st = total > 0 ? 0 : 1;
+      }
+    }
+  }
+  P.ncand[i] = (uint8_t)n;
+  P.state[i] = st;
+}
+
+// visits the candidates of point i that no lower-index blocker holds, in traversal order: f(dist, level, c)
+template <class F>
+__device__ __forceinline__ void local_available(const ProjDev& P, int i, F&& f) {
+  const int n = P.ncand[i];
+  if (!(n & kProjOverflow)) {
+    for (int k = 0; k < n; ++k) {
+      const unsigned long long key = P.cand[(size_t)i * kProjCand + k];
+      const int c = (int)(key & 0xffffu);
+      if (P.taken_by[c] >= i) f((int)(key >> 32), (int)((key >> 16) & 0xffffu), c);
+    }
+    return;
+  }
+  const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
+  const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+  for_candidates(P, P.win[i], P.rng[i], [&](int c, int) {
+    if (P.taken_by[c] < i) return;
+    f(hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)), P.oct2[c], c);
+  });
+}
+
+// grid = 1, block = kProjBS
+__global__ __launch_bounds__(kProjBS) void k_local_resolve(ProjDev P) {
+  __shared__ int s_unres;
+  const int tid = threadIdx.x;
+  for (int round = 0; round <= P.n1; ++round) {
+    for (int c = tid; c < P.n2; c += kProjBS) P.min_unres[c] = INT_MAX;
+    if (tid == 0) s_unres = 0;
+    __syncthreads();
+    for (int i = tid; i < P.n1; i += kProjBS) {
+      if (P.state[i] != 0 || !P.obs1[i]) continue;
+      local_available(P, i, [&](int dist, int, int c) { if (dist <= 100) atomicMin(&P.min_unres[c], i); });
+    }
+    __syncthreads();
+    for (int i = tid; i < P.n1; i += kProjBS) {
+      if (P.state[i] != 0) continue;
+      LocalScan sc;
+      bool settled = true;
+      local_available(P, i, [&](int dist, int level, int c) {
+        sc.visit(dist, level, c);
+        if (P.min_unres[c] < i) settled = false;  // somebody in front of i may still take this feature
+      });
+      if (settled) { P.state[i] = 2; P.choice[i] = sc.accept(P.nnratio); }
+      else atomicAdd(&s_unres, 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < P.n1; i += kProjBS) {
+      if (P.state[i] != 2) continue;
+      P.state[i] = 1;
+      const int c = P.choice[i];
+      if (c >= 0 && P.obs1[i]) P.taken_by[c] = i;
     }
     __syncthreads();
     if (s_unres == 0) break;
@@ -712,6 +847,7 @@ int rgbl_search_by_projection(rgbl_matcher* m, const rgbl_projection_input* in, 
   hipStream_t s = m->stream;
   ProjDev P;
   P.n1 = n1; P.n2 = n2;
+  P.proj1 = nullptr; P.level1 = nullptr; P.viewcos1 = nullptr; P.blocked2 = nullptr; P.nnratio = 0.f;
   RGBL_TRY(upload(A, s, &P.valid1, in->valid1, (size_t)n1));
   RGBL_TRY(upload(A, s, &P.obs1, in->mp_observed1, (size_t)n1));
   RGBL_TRY(upload(A, s, &P.wpos1, in->world_pos1, (size_t)n1 * 3));
@@ -789,6 +925,75 @@ int rgbl_search_by_projection(rgbl_matcher* m, const rgbl_projection_input* in, 
       for (int c : hist[i]) { match2[c] = -1; --nmatches; }  // a feature chosen twice is un-counted twice, as in the reference
     }
   }
+  *out_nmatches = nmatches;
+  return RGBL_OK;
+}
+
+int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in, int32_t* match2, int* out_nmatches) {
+  if (!m || !in || !match2 || !out_nmatches || in->n1 < 0 || in->n2 < 0 || in->n2 > 65535 || in->n_levels < 1 ||
+      in->n_levels > kProjMaxLevels) {
+    set_error("invalid argument (the frame may hold at most 65535 features, %d pyramid levels)", kProjMaxLevels);
+    return RGBL_ERR_INVALID;
+  }
+  *out_nmatches = 0;
+  const int n1 = in->n1, n2 = in->n2;
+  for (int i = 0; i < n2; ++i) match2[i] = -1;
+  if (n1 == 0 || n2 == 0) return RGBL_OK;
+  for (int i = 0; i < n1; ++i)
+    if (in->valid1[i] && (in->level1[i] < 0 || in->level1[i] >= in->n_levels)) { set_error("predicted level out of range"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(m->device));
+  size_t need = pad256(n1) * 2 + pad256((size_t)n1 * 12) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) * 2 + pad256((size_t)n2 * 8) +
+                pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256(n2) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 2 +
+                pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 + pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) +
+                pad256((size_t)(kGridCells + 1) * 4);
+  RGBL_TRY(ensure_arena(m, need));
+  Arena A{m->d_buf};
+  hipStream_t s = m->stream;
+  ProjDev P;
+  memset(&P, 0, sizeof(P));
+  P.n1 = n1; P.n2 = n2;
+  RGBL_TRY(upload(A, s, &P.valid1, in->valid1, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.obs1, in->mp_observed1, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.proj1, in->proj1, (size_t)n1 * 3));
+  RGBL_TRY(upload(A, s, &P.mpdesc1, in->mp_desc1, (size_t)n1 * 32));
+  RGBL_TRY(upload(A, s, &P.level1, in->level1, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.viewcos1, in->view_cos1, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.xy2, in->kp2_xy, (size_t)n2 * 2));
+  RGBL_TRY(upload(A, s, &P.oct2, in->kp2_octave, (size_t)n2));
+  RGBL_TRY(upload(A, s, &P.ur2, in->uright2, (size_t)n2));
+  RGBL_TRY(upload(A, s, &P.desc2, in->desc2, (size_t)n2 * 32));
+  if (in->blocked2) RGBL_TRY(upload(A, s, &P.blocked2, in->blocked2, (size_t)n2));
+  P.cell_start = A.take<uint32_t>(kGridCells + 1);
+  P.cell_items = A.take<uint16_t>(n2);
+  P.taken_by = A.take<int32_t>(n2);
+  P.min_unres = A.take<int32_t>(n2);
+  P.win = A.take<float4>(n1);
+  P.rng = A.take<int4>(n1);
+  P.cand = A.take<unsigned long long>((size_t)n1 * kProjCand);
+  P.ncand = A.take<uint8_t>(n1);
+  P.state = A.take<uint8_t>(n1);
+  P.choice = A.take<int32_t>(n1);
+  memcpy(P.grid, in->grid, sizeof(P.grid));
+  P.th = in->th;
+  P.nnratio = in->nnratio;
+  for (int l = 0; l < kProjMaxLevels; ++l) P.scale[l] = l < in->n_levels ? in->scale_factors[l] : 1.f;
+  m->timer.begin("k_proj_grid", s);
+  hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
+  m->timer.end(s);
+  m->timer.begin("k_local_candidates", s);
+  hipLaunchKernelGGL(k_local_candidates, dim3((n1 + 63) / 64), dim3(64), 0, s, P);
+  m->timer.end(s);
+  m->timer.begin("k_local_resolve", s);
+  hipLaunchKernelGGL(k_local_resolve, dim3(1), dim3(kProjBS), 0, s, P);
+  m->timer.end(s);
+  RGBL_HIP(hipGetLastError());
+  std::vector<int32_t> choice(n1);
+  RGBL_HIP(hipMemcpyAsync(choice.data(), P.choice, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipStreamSynchronize(s));
+  m->timer.collect();
+  int nmatches = 0;
+  for (int i = 0; i < n1; ++i)
+    if (choice[i] >= 0) { match2[choice[i]] = i; ++nmatches; }  // a later point overwrites an unobserved earlier one
   *out_nmatches = nmatches;
   return RGBL_OK;
 }

@@ -338,6 +338,35 @@ class ORBmatcher:
         L.check(self.lib, self.lib.rgbl_search_by_projection(self.h, C.byref(P), L.ptr(match2), C.byref(n)))
         return match2, n.value
 
+    def SearchLocalPoints(self, pts, th):
+        """ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) (ORBmatcher.cc:43-213), the call of
+        Tracking::SearchLocalPoints.  pts: dict with the map point arrays valid1, proj1 [n,3] (mTrackProjX, mTrackProjY,
+        mTrackProjXR), level1, view_cos1, mp_desc1, mp_observed1, the frame arrays kp2_xy, kp2_octave, uright2, desc2,
+        blocked2, and grid[6], scale_factors.  Returns (match2: map point index per frame feature or -1, nmatches)."""
+        keep = []
+
+        def arr(v, dt):
+            a = np.ascontiguousarray(v, dt)
+            keep.append(a)
+            return a.ctypes.data
+        P = L.LocalPointsInput()
+        P.n1 = len(pts["valid1"])
+        P.valid1, P.proj1, P.level1 = arr(pts["valid1"], np.uint8), arr(pts["proj1"], np.float32), arr(pts["level1"], np.int32)
+        P.view_cos1, P.mp_desc1 = arr(pts["view_cos1"], np.float32), arr(pts["mp_desc1"], np.uint8)
+        P.mp_observed1 = arr(pts["mp_observed1"], np.uint8)
+        P.n2 = len(pts["kp2_xy"])
+        P.kp2_xy, P.kp2_octave = arr(pts["kp2_xy"], np.float32), arr(pts["kp2_octave"], np.int32)
+        P.uright2, P.desc2, P.blocked2 = arr(pts["uright2"], np.float32), arr(pts["desc2"], np.uint8), arr(pts["blocked2"], np.uint8)
+        for i in range(6):
+            P.grid[i] = float(pts["grid"][i])
+        P.scale_factors = arr(pts["scale_factors"], np.float32)
+        P.n_levels = len(pts["scale_factors"])
+        P.th, P.nnratio = float(th), float(self.mfNNratio)
+        match2 = np.zeros(P.n2, np.int32)
+        n = C.c_int(0)
+        L.check(self.lib, self.lib.rgbl_search_local_points(self.h, C.byref(P), L.ptr(match2), C.byref(n)))
+        return match2, n.value
+
     def SearchForTriangulation(self, kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, bOnlyStereo=False,
                                bCoarse=False):
         """kf = dict(desc, xy, octave, angle, uright, has_mp, node_id, node_off, node_feat).

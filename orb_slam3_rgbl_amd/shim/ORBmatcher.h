@@ -2,6 +2,7 @@
 //   static DescriptorDistance(a, b)                                  (ORBmatcher.h:43,  ORBmatcher.cc:2058-2074)
 //   SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse)   (ORBmatcher.h:75-76, :907-1146)
 //   SearchByProjection(CurrentFrame, LastFrame, th, bMono)           (ORBmatcher.h:48,  ORBmatcher.cc:1676-1887)
+//   SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints)  (ORBmatcher.h:45,  ORBmatcher.cc:43-213)
 // The other Search*/Fuse members of the reference class are untouched (SURVEY.md §8(f) lists them as "next");
 // in the ORB_SLAM3 tree this header is merged into the existing one, see INTEGRATION.md.
 //
@@ -158,6 +159,61 @@ class ORBmatcher {
     }
     for (int i2 = 0; i2 < n2; ++i2)
       if (match2[i2] >= 0) CurrentFrame.mvpMapPoints[i2] = LastFrame.mvpMapPoints[match2[i2]];
+    return nmatches;
+  }
+
+  // Search matches between Frame keypoints and projected MapPoints.  Used to track the local map (Tracking::SearchLocalPoints,
+  // Tracking.cc:3370-3450).  ORBmatcher.h:45, ORBmatcher.cc:43-213.  Reads what Frame::isInFrustum left in every MapPoint
+  // (mbTrackInView, mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos, mTrackDepth) and writes F.mvpMapPoints.
+  template <class FrameT, class MapPointT>
+  int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th = 3, const bool bFarPoints = false,
+                         const float thFarPoints = 50.0f) {
+    if (!mpHandle) return 0;
+    if (F.Nleft != -1) {
+      std::cerr << "[ORBmatcher] SearchByProjection: fisheye stereo rigs (Nleft != -1) are not covered by the device path" << std::endl;
+      return 0;
+    }
+    const int n1 = (int)vpMapPoints.size(), n2 = F.N;
+    std::vector<uint8_t> valid(n1, 0), observed(n1, 0), desc1((size_t)n1 * 32, 0), blocked(n2, 0);
+    std::vector<float> proj((size_t)n1 * 3, 0.f), vcos(n1, 0.f), xy2((size_t)n2 * 2);
+    std::vector<int32_t> level(n1, 0), oct2(n2);
+    for (int i = 0; i < n1; ++i) {
+      MapPointT* pMP = vpMapPoints[i];
+      if (!pMP->mbTrackInView) continue;  // (mbTrackInViewR only matters for two-camera frames)
+      if (bFarPoints && pMP->mTrackDepth > thFarPoints) continue;
+      if (pMP->isBad()) continue;
+      valid[i] = 1;
+      proj[3 * (size_t)i] = pMP->mTrackProjX; proj[3 * (size_t)i + 1] = pMP->mTrackProjY; proj[3 * (size_t)i + 2] = pMP->mTrackProjXR;
+      level[i] = pMP->mnTrackScaleLevel;
+      vcos[i] = pMP->mTrackViewCos;
+      const cv::Mat d = pMP->GetDescriptor();
+      memcpy(&desc1[(size_t)i * 32], d.ptr<uint8_t>(), 32);
+      observed[i] = pMP->Observations() > 0 ? 1 : 0;
+    }
+    for (int i = 0; i < n2; ++i) {
+      xy2[2 * (size_t)i] = F.mvKeysUn[i].pt.x;
+      xy2[2 * (size_t)i + 1] = F.mvKeysUn[i].pt.y;
+      oct2[i] = F.mvKeysUn[i].octave;
+      blocked[i] = (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;
+    }
+    rgbl_local_points_input in;
+    in.n1 = n1; in.valid1 = valid.data(); in.proj1 = proj.data(); in.level1 = level.data(); in.view_cos1 = vcos.data();
+    in.mp_desc1 = desc1.data(); in.mp_observed1 = observed.data();
+    in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.uright2 = F.mvuRight.data();
+    in.desc2 = F.mDescriptors.template ptr<uint8_t>(); in.blocked2 = blocked.data();
+    in.grid[0] = FrameT::mnMinX; in.grid[1] = FrameT::mnMinY; in.grid[2] = FrameT::mnMaxX; in.grid[3] = FrameT::mnMaxY;
+    in.grid[4] = FrameT::mfGridElementWidthInv; in.grid[5] = FrameT::mfGridElementHeightInv;
+    in.scale_factors = F.mvScaleFactors.data();
+    in.n_levels = (int)F.mvScaleFactors.size();
+    in.th = th; in.nnratio = mfNNratio;
+    std::vector<int32_t> match2(n2, -1);
+    int nmatches = 0;
+    if (rgbl_search_local_points(mpHandle, &in, match2.data(), &nmatches) != RGBL_OK) {
+      std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
+      return 0;
+    }
+    for (int i2 = 0; i2 < n2; ++i2)
+      if (match2[i2] >= 0) F.mvpMapPoints[i2] = vpMapPoints[match2[i2]];
     return nmatches;
   }
 

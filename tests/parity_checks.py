@@ -539,3 +539,68 @@ def check_search_by_projection_edge_cases(lib):
     assert n == on and np.array_equal(m, om) and (m[:40] >= 0).sum() >= 35   # the cluster fills up one by one
     mt.close()
     mt2.close()
+
+
+# ---- ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...) = Tracking::SearchLocalPoints -------------------------------
+def make_local_points_case(n1=3000, n2=2000, seed=41, w=synth.KITTI_W, h=synth.KITTI_H):
+    """Local map points with predicted projections (what Frame::isInFrustum leaves in the MapPoint) against a frame in which
+    a part of the features already holds tracked points.  Clusters of look-alike features make the ratio test bite,
+    several map points aim at the same feature (the later one is blocked and falls back or fails its ratio test)."""
+    rng = np.random.default_rng(seed)
+    xy2 = np.stack([rng.uniform(5, w - 5, n2), rng.uniform(5, h - 5, n2)], 1).astype(np.float32)
+    desc2 = synth.descriptors(n2, seed)
+    ncl = n2 // 6
+    src = rng.integers(0, n2, ncl)
+    dst = rng.permutation(n2)[:ncl]
+    xy2[dst] = xy2[src] + rng.uniform(-3, 3, (ncl, 2)).astype(np.float32)
+    flips = rng.random((ncl, 256)) < rng.choice([0.01, 0.05, 0.15], ncl)[:, None]
+    desc2[dst] = desc2[src] ^ np.packbits(flips, axis=1, bitorder="little")
+    xy2[:, 0] = np.clip(xy2[:, 0], 1, w - 2)
+    xy2[:, 1] = np.clip(xy2[:, 1], 1, h - 2)
+    oct2 = rng.integers(0, 8, n2).astype(np.int32)
+    oct2[dst] = np.where(rng.random(ncl) < 0.7, oct2[src], np.clip(oct2[src] - 1, 0, 7))
+    depth2 = rng.uniform(4, 70, n2)
+    mbf = 386.1448
+    uright2 = np.where(rng.random(n2) < 0.6, xy2[:, 0] - mbf / depth2, -1).astype(np.float32)
+    blocked2 = (rng.random(n2) < 0.3).astype(np.uint8)          # already tracked by the motion model
+    target = rng.integers(0, n2, n1)
+    target[: n1 // 5] = target[n1 // 5: 2 * (n1 // 5)]
+    aimed = rng.random(n1) < 0.8
+    uv = xy2[target] + rng.normal(0, 1.0, (n1, 2)).astype(np.float32)
+    uv[~aimed] = np.stack([rng.uniform(0, w, (~aimed).sum()), rng.uniform(0, h, (~aimed).sum())], 1)
+    xr = (uv[:, 0] - mbf / depth2[target] + rng.normal(0, 1.5, n1)).astype(np.float32)
+    proj = np.concatenate([uv, xr[:, None]], 1).astype(np.float32)
+    level = np.clip(oct2[target] + rng.integers(0, 2, n1), 0, 7).astype(np.int32)   # window accepts level-1 .. level
+    flips = rng.random((n1, 256)) < 0.04
+    mp_desc = desc2[target] ^ np.packbits(flips, axis=1, bitorder="little")
+    mp_desc[~aimed] = synth.descriptors(int((~aimed).sum()), seed + 1)
+    gw, gh = np.float32(w), np.float32(h)
+    grid = np.array([0, 0, gw, gh, np.float32(64) / gw, np.float32(48) / gh], np.float32)
+    return dict(valid1=(rng.random(n1) < 0.85).astype(np.uint8), proj1=proj, level1=level,
+                view_cos1=np.where(rng.random(n1) < 0.5, 0.9995, 0.9).astype(np.float32), mp_desc1=mp_desc,
+                mp_observed1=(rng.random(n1) < 0.9).astype(np.uint8), kp2_xy=xy2, kp2_octave=oct2, uright2=uright2, desc2=desc2,
+                blocked2=blocked2, grid=grid, scale_factors=(1.2 ** np.arange(8)).astype(np.float32))
+
+
+def check_search_local_points(lib, seed=41, th=1.0, nnratio=0.8, n1=3000, n2=2000):
+    case = make_local_points_case(n1, n2, seed)
+    mt = F.ORBmatcher(nnratio, True, lib=lib)
+    m, n = mt.SearchLocalPoints(case, th)
+    om, on = O.search_local_points(case, th, nnratio)
+    assert n == on and np.array_equal(m, om), "SearchByProjection(F, vpMapPoints) (seed %d, th %g)" % (seed, th)
+    # a dense cluster: more candidates per point than the per-point list holds (window re-scan path)
+    case = make_local_points_case(400, 500, seed + 1)
+    rng = np.random.default_rng(seed)
+    case["kp2_xy"][:60] = np.array([400.0, 200.0], np.float32) + rng.uniform(-4, 4, (60, 2)).astype(np.float32)
+    case["kp2_octave"][:60] = 1
+    case["desc2"][:60] = case["desc2"][0] ^ np.packbits(rng.random((60, 256)) < 0.03, axis=1, bitorder="little")
+    case["uright2"][:60] = -1
+    case["proj1"][:200, :2] = np.array([400.0, 200.0], np.float32) + rng.uniform(-2, 2, (200, 2)).astype(np.float32)
+    case["level1"][:200] = 1
+    case["mp_desc1"][:200] = case["desc2"][0]
+    case["valid1"][:200] = 1
+    m2, n2_ = mt.SearchLocalPoints(case, 3.0)
+    om2, on2 = O.search_local_points(case, 3.0, nnratio)
+    assert n2_ == on2 and np.array_equal(m2, om2)
+    mt.close()
+    return n

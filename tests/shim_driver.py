@@ -65,10 +65,18 @@ def run_and_check(exe, tmp):
                         ("octave1", np.int32), ("angle1", np.float32), ("kp2_xy", np.float32), ("kp2_octave", np.int32),
                         ("kp2_angle", np.float32), ("uright2", np.float32), ("desc2", np.uint8)):
             f.write(np.ascontiguousarray(case[key], dt).tobytes())
+    lcase = pc.make_local_points_case(2500, 1800, seed=47)
+    with open(os.path.join(tmp, "local.bin"), "wb") as f:
+        f.write(struct.pack("<iiff", len(lcase["valid1"]), len(lcase["kp2_xy"]), 3.0, 0.8))
+        f.write(np.concatenate([lcase["grid"], lcase["scale_factors"]]).astype(np.float32).tobytes())
+        for key, dt in (("valid1", np.uint8), ("proj1", np.float32), ("level1", np.int32), ("view_cos1", np.float32),
+                        ("mp_desc1", np.uint8), ("mp_observed1", np.uint8), ("kp2_xy", np.float32), ("kp2_octave", np.int32),
+                        ("uright2", np.float32), ("desc2", np.uint8), ("blocked2", np.uint8)):
+            f.write(np.ascontiguousarray(lcase[key], dt).tobytes())
     out = os.path.join(tmp, "out.bin")
     res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "KITTI00-02.yaml"), os.path.join(tmp, "img.raw"), str(w), str(h),
                           os.path.join(tmp, "cloud.raw"), str(cloud.shape[1]), os.path.join(tmp, "tri.bin"), out,
-                          os.path.join(tmp, "proj.bin")],
+                          os.path.join(tmp, "proj.bin"), os.path.join(tmp, "local.bin")],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "Lidar Method: InverseDilation" in res.stdout
@@ -103,7 +111,11 @@ def run_and_check(exe, tmp):
     dd = take(np.int32, 1)[0]
     nproj, n2p = take(np.int32, 2)
     proj_match = take(np.int32, n2p)
+    nloc, n2l = take(np.int32, 2)
+    local_match = take(np.int32, n2l)
     assert pos == len(buf)
+    olm, oln = O.search_local_points(lcase, 3.0, 0.8)
+    assert nloc == oln and np.array_equal(local_match, olm) and nloc > 150
     om, onm = O.search_by_projection(case, 7.0, False, True)
     assert nproj == onm and np.array_equal(proj_match, om) and nproj > 200
 

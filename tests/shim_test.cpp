@@ -65,6 +65,10 @@ struct QPose {
 };
 struct TrackedPoint {
   V3 pos; cv::Mat desc; int nObs = 0;
+  bool mbTrackInView = false, mbTrackInViewR = false, bad = false;
+  float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackDepth = 0, mTrackViewCos = 0;
+  int mnTrackScaleLevel = 0;
+  bool isBad() { return bad; }
   V3 GetWorldPos() { return pos; }
   cv::Mat GetDescriptor() { return desc; }
   int Observations() { return nObs; }
@@ -245,6 +249,51 @@ int main(int argc, char** argv) {
     const int nproj = tracker.SearchByProjection(cur, last, th, mono != 0);
     wr(out, &nproj, 1); wr(out, &n2, 1);
     for (int i = 0; i < n2; ++i) { const int idx = cur.mvpMapPoints[i] ? (int)(cur.mvpMapPoints[i] - pts.data()) : -1; wr(out, &idx, 1); }
+  }
+  // --- as Tracking::SearchLocalPoints (Tracking.cc:3428-3447): matcher.SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th, ...)
+  if (argc > 10) {
+    f = fopen(argv[10], "rb");
+    int n1 = 0, n2 = 0;
+    float th = 0, ratio = 0, hdr[6 + 8];
+    if (!f || !rd(f, &n1, 1) || !rd(f, &n2, 1) || !rd(f, &th, 1) || !rd(f, &ratio, 1) || !rd(f, hdr, 14)) return 7;
+    std::vector<unsigned char> valid(n1), obs(n1), d1((size_t)n1 * 32), d2((size_t)n2 * 32), blocked(n2);
+    std::vector<float> proj((size_t)n1 * 3), vcos(n1), xy2((size_t)n2 * 2), ur2(n2);
+    std::vector<int> lev(n1), o2(n2);
+    rd(f, valid.data(), n1); rd(f, proj.data(), (size_t)n1 * 3); rd(f, lev.data(), n1); rd(f, vcos.data(), n1);
+    rd(f, d1.data(), (size_t)n1 * 32); rd(f, obs.data(), n1); rd(f, xy2.data(), (size_t)n2 * 2); rd(f, o2.data(), n2);
+    rd(f, ur2.data(), n2); rd(f, d2.data(), (size_t)n2 * 32); rd(f, blocked.data(), n2);
+    fclose(f);
+    TestFrame::mnMinX = hdr[0]; TestFrame::mnMinY = hdr[1]; TestFrame::mnMaxX = hdr[2]; TestFrame::mnMaxY = hdr[3];
+    TestFrame::mfGridElementWidthInv = hdr[4]; TestFrame::mfGridElementHeightInv = hdr[5];
+    std::vector<TrackedPoint> pts(n1);
+    std::vector<TrackedPoint*> vp(n1);
+    for (int i = 0; i < n1; ++i) {
+      TrackedPoint& p = pts[i];
+      p.mbTrackInView = valid[i] != 0;
+      if (!valid[i] && i % 3 == 0) { p.mbTrackInView = true; p.bad = true; }  // bad points are skipped as well
+      p.mTrackProjX = proj[3 * i]; p.mTrackProjY = proj[3 * i + 1]; p.mTrackProjXR = proj[3 * i + 2];
+      p.mnTrackScaleLevel = lev[i]; p.mTrackViewCos = vcos[i];
+      p.desc.create(1, 32, CV_8U); memcpy(p.desc.data, &d1[(size_t)i * 32], 32);
+      p.nObs = obs[i] ? 4 : 0;
+      vp[i] = &p;
+    }
+    TrackedPoint old_point; old_point.nObs = 7;
+    TestFrame F;
+    F.N = n2; F.mvKeysUn.resize(n2);
+    for (int i = 0; i < n2; ++i) { F.mvKeysUn[i].pt.x = xy2[2 * i]; F.mvKeysUn[i].pt.y = xy2[2 * i + 1]; F.mvKeysUn[i].octave = o2[i]; }
+    F.mvuRight = ur2;
+    F.mDescriptors.create(n2, 32, CV_8U); memcpy(F.mDescriptors.data, d2.data(), (size_t)n2 * 32);
+    F.mvScaleFactors.assign(hdr + 6, hdr + 14);
+    F.mvpMapPoints.assign(n2, nullptr);
+    for (int i = 0; i < n2; ++i) if (blocked[i]) F.mvpMapPoints[i] = &old_point;
+    ORB_SLAM3::ORBmatcher local(ratio, true);
+    const int nloc = local.SearchByProjection(F, vp, th);
+    wr(out, &nloc, 1); wr(out, &n2, 1);
+    for (int i = 0; i < n2; ++i) {
+      TrackedPoint* p = F.mvpMapPoints[i];
+      const int idx = (p && p != &old_point) ? (int)(p - pts.data()) : -1;
+      wr(out, &idx, 1);
+    }
   }
   fclose(out);
   printf("shim_test ok: %d keypoints, %d depths, %d triangulation matches\n", nk, nd, nm);

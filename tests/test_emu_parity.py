@@ -106,3 +106,8 @@ def test_search_by_projection(emu_lib, seed, motion, th, mono, ori):
 def test_search_by_projection_edge_cases(emu_lib):
     pc.check_search_by_projection_edge_cases(emu_lib)
     assert pc.check_search_by_projection(emu_lib, 22, "forward", 15.0, False, True) > 300   # full-size frame pair
+
+
+@pytest.mark.parametrize("seed,th,ratio", [(41, 1.0, 0.8), (42, 3.0, 0.8), (45, 15.0, 0.7)])
+def test_search_local_points(emu_lib, seed, th, ratio):
+    assert pc.check_search_local_points(emu_lib, seed, th, ratio, n1=1200, n2=900) > 50

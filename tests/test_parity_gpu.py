@@ -125,3 +125,8 @@ def test_search_by_projection(gpu_lib, seed, motion, th, mono, ori):
 def test_search_by_projection_edge_cases(gpu_lib):
     pc.check_search_by_projection_edge_cases(gpu_lib)
     assert pc.check_search_by_projection(gpu_lib, 27, "forward", 7.0, False, True, n1=7000, n2=8000) > 1000   # 4K-sized frames
+
+
+@pytest.mark.parametrize("seed,th,ratio", [(41, 1.0, 0.8), (42, 3.0, 0.8), (43, 5.0, 0.8), (45, 15.0, 0.7)])
+def test_search_local_points(gpu_lib, seed, th, ratio):
+    assert pc.check_search_local_points(gpu_lib, seed, th, ratio) > 200

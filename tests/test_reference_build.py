@@ -312,3 +312,22 @@ def test_reference_search_by_projection_agrees_with_oracle(refmatcher, seed, mot
     assert nm > 300
     # the scenario must exercise the sequential rule: some map point did not get its nearest-descriptor feature
     assert (m >= 0).sum() <= nm
+
+
+@pytest.mark.parametrize("seed,th,nnratio", [(41, 1.0, 0.8), (42, 3.0, 0.8), (43, 5.0, 0.8), (44, 1.0, 0.9), (45, 15.0, 0.7)])
+def test_reference_search_local_points_agrees_with_oracle(refmatcher, seed, th, nnratio):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) as Tracking::SearchLocalPoints calls it (Tracking.cc:3428-3447:
+    th = 1, 3 after a relocalisation, 5 / 6 / 10 / 15 in the IMU cases; ORBmatcher(0.8))."""
+    import parity_checks as pc
+    case = pc.make_local_points_case(seed=seed)
+    keep = []
+    P = O.make_local_points_input(case, th, nnratio, keep)
+    m = np.zeros(P.n2, np.int32)
+    refmatcher.ref_search_local_points.restype = C.c_int
+    refmatcher.ref_search_local_points.argtypes = [C.c_void_p, C.c_void_p]
+    nm = refmatcher.ref_search_local_points(C.byref(P), m.ctypes.data)
+    om, onm = O.search_local_points(case, th, nnratio)
+    assert nm == onm and np.array_equal(m, om)
+    assert nm > 200
+    free = dict(case, blocked2=np.zeros_like(case["blocked2"]), mp_observed1=np.zeros_like(case["mp_observed1"]))
+    assert not np.array_equal(O.search_local_points(free, th, nnratio)[0], om)   # the blocking rule matters in this scenario
