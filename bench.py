@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (w, h, nfeatures, lidar azimuth steps, default batch)
     "kitti": (1241, 376, 2000, 1900, 256),
-    "4k": (3840, 2160, 8000, 4096, 16),
+    "4k": (3840, 2160, 8000, 4096, 64),
 }
 LEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 12, 7
 
