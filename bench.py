@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (w, h, nfeatures, lidar azimuth steps, default batch)
-    "kitti": (1241, 376, 2000, 1900, 256),
+    "kitti": (1241, 376, 2000, 1900, 512),
     "4k": (3840, 2160, 8000, 4096, 64),
 }
 LEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 12, 7
@@ -61,9 +61,9 @@ def algorithmic_bytes(kernel, w, h, n_points, k_per_frame):
     return table.get(kernel)
 
 
-def pmc_traffic(kernel, frames_per_launch, profile_batch=256):
+def pmc_traffic(kernel, frames_per_launch, profile_batch=512):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_*.csv:
-    FETCH_SIZE + WRITE_SIZE, KB -> bytes; separate --pmc runs of this same command at the default batch of 256).
+    FETCH_SIZE + WRITE_SIZE, KB -> bytes; separate --pmc runs of this same command at the default batch of 512).
     Raw counter values: MI355X_MICROARCH.md notes FETCH_SIZE can under-report wide (16 B/lane) loads by 2x; these
     kernels read 4 B/lane, for which the counter is uncalibrated.  None when the profiles are not present."""
     total = 0.0
