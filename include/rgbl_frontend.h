@@ -374,6 +374,32 @@ typedef struct {
  * (entry left as it was).  *out_nmatches = return value of the reference function. */
 int rgbl_search_local_points(rgbl_matcher* h, const rgbl_local_points_input* in, int32_t* match2, int* out_nmatches);
 
+/* ------------------------------------------------------------------------------------------------
+ * ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>)    SURVEY.md 8(f) row f4
+ *   replaces the per-feature descent of Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:828-835,
+ *   src/KeyFrame.cc:98-107: mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4)),
+ *   Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1255, FORB.cpp:79-98.  The tree lives on the device.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rgbl_vocabulary rgbl_vocabulary;
+/* ORBVocabulary::loadFromTextFile (TemplatedVocabulary.h:1338-1425; System.cc:115): the ORBvoc.txt format. */
+int rgbl_vocabulary_load_text(const char* path, int device, rgbl_vocabulary** out);
+/* The same from flat arrays: node 0 = root, children of node i = child[child_off[i] .. child_off[i+1]) in file order,
+ * 32-byte node descriptors, Node::weight, Node::word_id (leaves). */
+int rgbl_vocabulary_create(int n_nodes, int L, const int32_t* child_off, const int32_t* child, const uint8_t* desc,
+                           const double* weight, const int32_t* word_id, int device, rgbl_vocabulary** out);
+void rgbl_vocabulary_destroy(rgbl_vocabulary* v);
+int rgbl_vocabulary_info(const rgbl_vocabulary* v, int* k, int* L, int* n_nodes, int* n_words);
+/* transform(features, BowVector, FeatureVector, levelsup).  Host pointers, synchronous.  BowVector as ascending word ids +
+ * values (TF-IDF, L1-normalised doubles), FeatureVector as ascending node ids + CSR offsets (n_nodes + 1) + feature
+ * indices (ascending inside a node).  RGBL_ERR_CAPACITY when cap_words / cap_nodes (n is always enough) are too small. */
+int rgbl_bow_transform(rgbl_vocabulary* v, const uint8_t* desc, int n, int levelsup, uint32_t* word_id, double* word_val,
+                       int cap_words, int* n_words, uint32_t* node_id, int32_t* node_off, uint32_t* node_feat, int cap_nodes,
+                       int* n_nodes);
+/* Device-resident batch, descent only: the descriptors of rgbl_extract_batch_device() (frame b at d_desc + b*cap*32, d_n
+ * counts) -> per feature word id, word weight, node id at level L - levelsup.  Enqueued on hip_stream (NULL: own stream). */
+int rgbl_bow_descend_batch_device(rgbl_vocabulary* v, void* hip_stream, const uint8_t* d_desc, const int32_t* d_n, int batch,
+                                  int cap, int levelsup, int32_t* d_word, double* d_weight, int32_t* d_node);
+
 /* F12 with the reference's fp32 evaluation order (Pinhole.cpp:109-112); K = {fx, fy, cx, cy}. Host. */
 void rgbl_fundamental(const float K1[4], const float K2[4], const float R12[9], const float t12[3],
                       float F12[9]);

@@ -266,6 +266,12 @@ class FileNode {
   operator int() const { return kind_ == INT || kind_ == REAL ? cvRound(num_) : kind_ == NONE ? 0 : 0x7fffffff; }
   operator float() const { return (float)real(); }
   operator double() const { return real(); }
+  // sequences / maps (the yml vocabulary format of DBoW2's save / load): never present in the flat settings files read
+  // here, provided so that the reference's vendored DBoW2 compiles; its text loader (loadFromTextFile) is what runs
+  FileNode operator[](const char*) const { return FileNode(); }
+  FileNode operator[](const std::string&) const { return FileNode(); }
+  FileNode operator[](int) const { return FileNode(); }
+  size_t size() const { return 0; }
  private:
   int kind_;
   double num_;
@@ -274,8 +280,10 @@ class FileNode {
 
 class FileStorage {
  public:
-  enum { READ = 0 };
-  FileStorage(const std::string& path, int) {
+  enum { READ = 0, WRITE = 1 };
+  template <class T> FileStorage& operator<<(const T&) { return *this; }  // WRITE mode is a sink
+  FileStorage(const std::string& path, int mode) {
+    if (mode != READ) return;
     std::ifstream f(path);
     opened_ = f.good();
     std::string line;

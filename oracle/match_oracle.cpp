@@ -372,3 +372,29 @@ extern "C" int orc_search_local_points(const orc_local_points_input* in, int* ma
   for (int i = 0; i < in->n2; ++i) match2[i] = holder[i];
   return nmatches;
 }
+
+// ---- DBoW2 vocabulary descent, Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1208-1255 ----
+extern "C" void orc_bow_descend(const orc_vocabulary* v, const uint8_t* desc, int n, int levelsup, int32_t* word, double* weight,
+                                int32_t* node) {
+  const int nid_level = v->L - levelsup;
+  for (int i = 0; i < n; ++i) {
+    const uint8_t* f = desc + 32 * (size_t)i;
+    int nid = 0;  // root when nid_level <= 0 (a leaf above nid_level leaves the reference's value uninitialised)
+    int final_id = 0, current_level = 0;
+    do {
+      ++current_level;
+      const int b = v->child_off[final_id], e = v->child_off[final_id + 1];
+      final_id = v->child[b];
+      int best_d = hamming256(f, v->desc + 32 * (size_t)final_id);
+      for (int k = b + 1; k < e; ++k) {
+        const int id = v->child[k];
+        const int d = hamming256(f, v->desc + 32 * (size_t)id);
+        if (d < best_d) { best_d = d; final_id = id; }
+      }
+      if (current_level == nid_level) nid = final_id;
+    } while (v->child_off[final_id] != v->child_off[final_id + 1]);
+    word[i] = v->word_id[final_id];
+    weight[i] = v->weight[final_id];
+    node[i] = nid;
+  }
+}

@@ -79,6 +79,22 @@ void orc_brief(const uint8_t* blurred, int stride, int x, int y, float angle_deg
 int orc_distribute_octree(const orc_keypoint* cand, int n, int min_x, int max_x, int min_y, int max_y,
                           int n_features, orc_keypoint* out, int cap);
 
+/* ---- DBoW2 vocabulary descent: TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup)
+ * (/root/reference/Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1208-1255) with FORB::distance (FORB.cpp:79-98), as
+ * Frame::ComputeBoW uses it (src/Frame.cc:828-835, levelsup = 4).  The tree as flat arrays: node 0 is the root, the children
+ * of node i are child[child_off[i] .. child_off[i+1]) in the order of the vocabulary file, a leaf has no children. */
+typedef struct {
+  int n_nodes, L;               /* m_nodes.size(), depth levels m_L */
+  const int32_t* child_off;     /* n_nodes + 1 */
+  const int32_t* child;         /* n_nodes - 1 */
+  const uint8_t* desc;          /* 32 bytes per node */
+  const double* weight;         /* Node::weight (WordValue) */
+  const int32_t* word_id;       /* Node::word_id of the leaves */
+} orc_vocabulary;
+/* per feature: word id, weight of the word, node id at level L - levelsup (0 = root when that level is <= 0) */
+void orc_bow_descend(const orc_vocabulary* v, const uint8_t* desc, int n, int levelsup, int32_t* word, double* weight,
+                     int32_t* node);
+
 /* ---- ingest either side of the path ---- */
 /* cv::cvtColor 8-bit {RGB,BGR,RGBA,BGRA} -> gray, OpenCV 4.x 15-bit weights (Tracking.cc:1567-1580) */
 void orc_cvt_gray(const uint8_t* src, int channels, int blue_first, int w, int h, int sstride, uint8_t* dst, int dstride);

@@ -108,6 +108,47 @@ def search_local_points(case, th=1.0, nnratio=0.8):
     return m, n
 
 
+class Vocabulary(C.Structure):
+    _fields_ = [("n_nodes", C.c_int), ("L", C.c_int), ("child_off", C.c_void_p), ("child", C.c_void_p), ("desc", C.c_void_p),
+                ("weight", C.c_void_p), ("word_id", C.c_void_p)]
+
+
+def bow_from_descent(word, weight, node):
+    """BowVector / FeatureVector of TemplatedVocabulary::transform(features, v, fv, levelsup) (TemplatedVocabulary.h:1127-1192,
+    TF_IDF + L1_NORM as in ORBvoc.txt) from the per-feature descent: weights of a word accumulate in feature order
+    (BowVector::addWeight), the L1 norm is summed in ascending word order (BowVector::normalize), features whose word is
+    stopped (weight 0) are dropped, FeatureVector keeps ascending feature indices per node."""
+    bow, fv = {}, {}
+    for i, (w, wt, nd) in enumerate(zip(word, weight, node)):
+        if wt > 0:
+            bow[int(w)] = bow.get(int(w), 0.0) + float(wt)
+            fv.setdefault(int(nd), []).append(i)
+    ids = sorted(bow)
+    vals = np.array([bow[k] for k in ids], np.float64)
+    norm = 0.0
+    for v in vals:
+        norm += abs(float(v))
+    if norm > 0.0:
+        vals = vals / norm
+    nids = sorted(fv)
+    off = np.zeros(len(nids) + 1, np.int32)
+    for j, k in enumerate(nids):
+        off[j + 1] = off[j] + len(fv[k])
+    feats = np.array([i for k in nids for i in fv[k]], np.uint32)
+    return np.array(ids, np.uint32), vals, np.array(nids, np.uint32), off, feats
+
+
+def bow_transform(varr, desc, levelsup=4):
+    """varr: synth.vocabulary_arrays(...). Returns (word ids, values, node ids, node offsets, feature indices)."""
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = len(desc)
+    keep = [np.ascontiguousarray(varr[k]) for k in ("child_off", "child", "desc", "weight", "word_id")]
+    V = Vocabulary(varr["n_nodes"], varr["L"], *[a.ctypes.data for a in keep])
+    word, weight, node = np.zeros(n, np.int32), np.zeros(n, np.float64), np.zeros(n, np.int32)
+    lib().orc_bow_descend(C.byref(V), _p(desc), n, levelsup, _p(word), _p(weight), _p(node))
+    return bow_from_descent(word, weight, node)
+
+
 class TriInput(C.Structure):
     _fields_ = [("n1", C.c_int), ("n2", C.c_int),
                 ("desc1", C.c_void_p), ("desc2", C.c_void_p),
@@ -157,6 +198,8 @@ def lib():
         L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_kitti_bin_to_cloud.restype = None
         L.orc_kitti_bin_to_cloud.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_bow_descend.restype = None
+        L.orc_bow_descend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_search_local_points.restype = C.c_int
         L.orc_search_local_points.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_search_by_projection.restype = C.c_int

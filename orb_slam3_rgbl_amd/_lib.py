@@ -132,6 +132,12 @@ SYMBOLS = {
                                        C.POINTER(TriangulationParams), _V, C.POINTER(_I)]),
     "rgbl_search_by_projection": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_search_local_points": (_I, [_V, _V, _V, C.POINTER(_I)]),
+    "rgbl_vocabulary_load_text": (_I, [C.c_char_p, _I, C.POINTER(_V)]),
+    "rgbl_vocabulary_create": (_I, [_I, _I, _V, _V, _V, _V, _V, _I, C.POINTER(_V)]),
+    "rgbl_vocabulary_destroy": (None, [_V]),
+    "rgbl_vocabulary_info": (_I, [_V, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "rgbl_bow_transform": (_I, [_V, _V, _I, _I, _V, _V, _I, C.POINTER(_I), _V, _V, _V, _I, C.POINTER(_I)]),
+    "rgbl_bow_descend_batch_device": (_I, [_V, _V, _V, _V, _I, _I, _I, _V, _V, _V]),
     "rgbl_fundamental": (None, [_V, _V, _V, _V, _V]),
 }
 

@@ -12,10 +12,12 @@
 //                         work-item, the node's candidate bucket is walked in index order (ties -> later
 //                         candidate wins, as in the reference) with the eligibility masks and epipolar test.
 #include <limits.h>
+#include <stdio.h>
 #include <math.h>
 #include <string.h>
 
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -516,6 +518,50 @@ __global__ __launch_bounds__(kProjBS) void k_local_resolve(ProjDev P) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// DBoW2 vocabulary descent: TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup)
+// (/root/reference/Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1208-1255) with FORB::distance (FORB.cpp:79-98), the
+// per-feature part of Frame::ComputeBoW (src/Frame.cc:828-835).  Work-item per feature: L levels, at each level the
+// child with the smallest Hamming distance (strict '<', first child wins ties).  The tree is resident on the device:
+// children CSR in file order, 32-byte node descriptors.
+struct VocDev {
+  int n_nodes, L;
+  const int32_t* child_off;
+  const int32_t* child;
+  const uint8_t* desc;
+  const double* weight;
+  const int32_t* word_id;
+};
+// grid = (ceil(cap / 256), frames), block = 256; d_n == nullptr: every frame holds `cap` features
+__global__ __launch_bounds__(256) void k_bow_descend(VocDev V, const uint8_t* __restrict__ desc, const int32_t* __restrict__ d_n,
+                                                     int cap, int levelsup, int32_t* __restrict__ word, double* __restrict__ weight,
+                                                     int32_t* __restrict__ node) {
+  const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+  const int n = d_n ? d_n[f] : cap;
+  if (i >= n || i >= cap) return;
+  const size_t o = (size_t)f * cap + i;
+  const unsigned long long* D = reinterpret_cast<const unsigned long long*>(desc + o * 32);
+  const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+  const int nid_level = V.L - levelsup;
+  int nid = 0, final_id = 0, current_level = 0;
+  int b = V.child_off[0], e = V.child_off[1];
+  while (b != e) {  // an inner node
+    ++current_level;
+    int best_d = 257;
+    for (int k = b; k < e; ++k) {
+      const int id = V.child[k];
+      const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(V.desc + (size_t)id * 32));
+      if (dist < best_d) { best_d = dist; final_id = id; }
+    }
+    if (current_level == nid_level) nid = final_id;
+    b = V.child_off[final_id];
+    e = V.child_off[final_id + 1];
+  }
+  word[o] = V.word_id[final_id];
+  weight[o] = V.weight[final_id];
+  node[o] = nid;
+}
+
 }  // namespace rgbl
 
 using namespace rgbl;
@@ -995,6 +1041,219 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
   for (int i = 0; i < n1; ++i)
     if (choice[i] >= 0) { match2[choice[i]] = i; ++nmatches; }  // a later point overwrites an unobserved earlier one
   *out_nmatches = nmatches;
+  return RGBL_OK;
+}
+
+// ---- vocabulary handle -----------------------------------------------------------------------------------------------
+struct rgbl_vocabulary {
+  int device = 0, k = 0, L = 0, n_nodes = 0, n_words = 0;
+  VocDev dev{};
+  std::vector<void*> allocs;
+  hipStream_t stream = nullptr;
+  // staging for the host entry point (grown on demand)
+  uint8_t* d_desc = nullptr; int32_t* d_word = nullptr; double* d_weight = nullptr; int32_t* d_node = nullptr; int stage_cap = 0;
+};
+
+static int voc_upload(rgbl_vocabulary* v, int n_nodes, int L, const int32_t* child_off, const int32_t* child, const uint8_t* desc,
+                      const double* weight, const int32_t* word_id) {
+  auto up = [&](const void* src, size_t bytes, const void** dst) -> int {
+    void* p = nullptr;
+    RGBL_HIP(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+    v->allocs.push_back(p);
+    RGBL_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    *dst = p;
+    return RGBL_OK;
+  };
+  v->n_nodes = n_nodes; v->L = L;
+  v->dev.n_nodes = n_nodes; v->dev.L = L;
+  RGBL_TRY(up(child_off, sizeof(int32_t) * ((size_t)n_nodes + 1), (const void**)&v->dev.child_off));
+  RGBL_TRY(up(child, sizeof(int32_t) * (size_t)std::max(n_nodes - 1, 1), (const void**)&v->dev.child));
+  RGBL_TRY(up(desc, (size_t)n_nodes * 32, (const void**)&v->dev.desc));
+  RGBL_TRY(up(weight, sizeof(double) * (size_t)n_nodes, (const void**)&v->dev.weight));
+  RGBL_TRY(up(word_id, sizeof(int32_t) * (size_t)n_nodes, (const void**)&v->dev.word_id));
+  RGBL_HIP(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+  return RGBL_OK;
+}
+
+static int voc_new(int device, rgbl_vocabulary** out) {
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device: librgbl_frontend has no CPU fallback"); return RGBL_ERR_NO_DEVICE; }
+  if (device < 0 || device >= ndev) { set_error("device %d out of range", device); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(device));
+  rgbl_vocabulary* v = new rgbl_vocabulary;
+  v->device = device;
+  *out = v;
+  return RGBL_OK;
+}
+
+void rgbl_vocabulary_destroy(rgbl_vocabulary* v) {
+  if (!v) return;
+  (void)hipSetDevice(v->device);
+  for (void* p : v->allocs) (void)hipFree(p);
+  if (v->d_desc) (void)hipFree(v->d_desc);
+  if (v->d_word) (void)hipFree(v->d_word);
+  if (v->d_weight) (void)hipFree(v->d_weight);
+  if (v->d_node) (void)hipFree(v->d_node);
+  if (v->stream) (void)hipStreamDestroy(v->stream);
+  delete v;
+}
+
+int rgbl_vocabulary_create(int n_nodes, int L, const int32_t* child_off, const int32_t* child, const uint8_t* desc,
+                           const double* weight, const int32_t* word_id, int device, rgbl_vocabulary** out) {
+  if (!out) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  *out = nullptr;
+  if (n_nodes < 2 || L < 1 || !child_off || !child || !desc || !weight || !word_id || child_off[0] != 0 ||
+      child_off[n_nodes] != n_nodes - 1 || child_off[1] == 0) {
+    set_error("vocabulary: the tree needs a root with children and n_nodes - 1 child entries");
+    return RGBL_ERR_INVALID;
+  }
+  rgbl_vocabulary* v = nullptr;
+  RGBL_TRY(voc_new(device, &v));
+  int nw = 0, kmax = 0;
+  for (int i = 0; i < n_nodes; ++i) {
+    kmax = std::max(kmax, child_off[i + 1] - child_off[i]);
+    nw += child_off[i + 1] == child_off[i];
+  }
+  v->k = kmax; v->n_words = nw;
+  const int rc = voc_upload(v, n_nodes, L, child_off, child, desc, weight, word_id);
+  if (rc != RGBL_OK) { rgbl_vocabulary_destroy(v); return rc; }
+  *out = v;
+  return RGBL_OK;
+}
+
+// ORBVocabulary::loadFromTextFile (TemplatedVocabulary.h:1338-1425): "k L scoring weighting", then one node per line
+// "parent is_leaf d0 .. d31 weight", node ids in file order starting at 1, word ids handed out to the leaves in file order.
+// Only L1_NORM / TF_IDF files (ORBvoc.txt: "10 6 0 0") are accepted.  A trailing empty line is ignored here (the reference
+// turns it into an extra child of the root with an unset descriptor).
+int rgbl_vocabulary_load_text(const char* path, int device, rgbl_vocabulary** out) {
+  if (!out || !path) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  *out = nullptr;
+  FILE* f = fopen(path, "r");
+  if (!f) { set_error("cannot open vocabulary file %s", path); return RGBL_ERR_INVALID; }
+  int k = 0, L = 0, n1 = -1, n2 = -1;
+  if (fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4 || k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) {
+    fclose(f);
+    set_error("Vocabulary loading failure: This is not a correct text file!");
+    return RGBL_ERR_INVALID;
+  }
+  if (n1 != 0 || n2 != 0) { fclose(f); set_error("only L1_NORM / TF_IDF vocabularies (scoring 0, weighting 0) are supported"); return RGBL_ERR_INVALID; }
+  std::vector<int32_t> parent(1, 0), word(1, -1);
+  std::vector<uint8_t> desc(32, 0), leaf(1, 0);
+  std::vector<double> weight(1, 0.0);
+  int nw = 0;
+  for (;;) {
+    int pid, is_leaf;
+    if (fscanf(f, "%d %d", &pid, &is_leaf) != 2) break;
+    const int nid = (int)parent.size();
+    if (pid < 0 || pid >= nid) { fclose(f); set_error("vocabulary: node %d names parent %d", nid, pid); return RGBL_ERR_INVALID; }
+    uint8_t d[32];
+    for (int j = 0; j < 32; ++j) { int b; if (fscanf(f, "%d", &b) != 1) { fclose(f); set_error("vocabulary: truncated node %d", nid); return RGBL_ERR_INVALID; } d[j] = (uint8_t)b; }
+    double w;
+    if (fscanf(f, "%lf", &w) != 1) { fclose(f); set_error("vocabulary: truncated node %d", nid); return RGBL_ERR_INVALID; }
+    parent.push_back(pid); leaf.push_back(is_leaf > 0); weight.push_back(w);
+    desc.insert(desc.end(), d, d + 32);
+    word.push_back(is_leaf > 0 ? nw++ : -1);
+  }
+  fclose(f);
+  const int n = (int)parent.size();
+  if (n < 2) { set_error("vocabulary: no nodes"); return RGBL_ERR_INVALID; }
+  std::vector<int32_t> off(n + 1, 0), child(n - 1), fill(n, 0);
+  for (int i = 1; i < n; ++i) ++off[parent[i] + 1];
+  for (int i = 0; i < n; ++i) off[i + 1] += off[i];
+  for (int i = 1; i < n; ++i) child[off[parent[i]] + fill[parent[i]]++] = i;
+  for (int i = 1; i < n; ++i)
+    if (leaf[i] && off[i + 1] != off[i]) { set_error("vocabulary: leaf %d has children", i); return RGBL_ERR_INVALID; }
+  const int rc = rgbl_vocabulary_create(n, L, off.data(), child.data(), desc.data(), weight.data(), word.data(), device, out);
+  if (rc == RGBL_OK) (*out)->k = k;
+  return rc;
+}
+
+int rgbl_vocabulary_info(const rgbl_vocabulary* v, int* k, int* L, int* n_nodes, int* n_words) {
+  if (!v) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  if (k) *k = v->k;
+  if (L) *L = v->L;
+  if (n_nodes) *n_nodes = v->n_nodes;
+  if (n_words) *n_words = v->n_words;
+  return RGBL_OK;
+}
+
+int rgbl_bow_descend_batch_device(rgbl_vocabulary* v, void* hip_stream, const uint8_t* d_desc, const int32_t* d_n, int batch, int cap,
+                                  int levelsup, int32_t* d_word, double* d_weight, int32_t* d_node) {
+  if (!v || !d_desc || !d_word || !d_weight || !d_node || batch < 1 || cap < 1) { set_error("invalid argument"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(v->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : v->stream;
+  hipLaunchKernelGGL(k_bow_descend, dim3((cap + 255) / 256, batch), dim3(256), 0, s, v->dev, d_desc, d_n, cap, levelsup, d_word,
+                     d_weight, d_node);
+  RGBL_HIP(hipGetLastError());
+  return RGBL_OK;
+}
+
+// void TemplatedVocabulary::transform(const std::vector<TDescriptor>& features, BowVector& v, FeatureVector& fv, int levelsup)
+// (TemplatedVocabulary.h:1127-1192) for TF_IDF / L1_NORM: BowVector::addWeight in feature order, L1 normalisation summed in
+// ascending word order, FeatureVector::addFeature with ascending feature indices; stopped words (weight 0) are dropped.
+int rgbl_bow_transform(rgbl_vocabulary* v, const uint8_t* desc, int n, int levelsup, uint32_t* word_id, double* word_val,
+                       int cap_words, int* n_words, uint32_t* node_id, int32_t* node_off, uint32_t* node_feat, int cap_nodes,
+                       int* n_nodes) {
+  if (!v || !n_words || !n_nodes || n < 0 || (n > 0 && !desc)) { set_error("invalid argument"); return RGBL_ERR_INVALID; }
+  *n_words = 0; *n_nodes = 0;
+  if (n == 0) { if (node_off && cap_nodes >= 0) node_off[0] = 0; return RGBL_OK; }
+  RGBL_HIP(hipSetDevice(v->device));
+  if (n > v->stage_cap) {
+    if (v->d_desc) { (void)hipFree(v->d_desc); (void)hipFree(v->d_word); (void)hipFree(v->d_weight); (void)hipFree(v->d_node); }
+    v->d_desc = nullptr; v->stage_cap = 0;
+    const int cap = std::max(n, 4096);
+    RGBL_HIP(hipMalloc(&v->d_desc, (size_t)cap * 32));
+    RGBL_HIP(hipMalloc(&v->d_word, sizeof(int32_t) * (size_t)cap));
+    RGBL_HIP(hipMalloc(&v->d_weight, sizeof(double) * (size_t)cap));
+    RGBL_HIP(hipMalloc(&v->d_node, sizeof(int32_t) * (size_t)cap));
+    v->stage_cap = cap;
+  }
+  hipStream_t s = v->stream;
+  RGBL_HIP(hipMemcpyAsync(v->d_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_bow_descend, dim3((n + 255) / 256, 1), dim3(256), 0, s, v->dev, v->d_desc, (const int32_t*)nullptr, n, levelsup,
+                     v->d_word, v->d_weight, v->d_node);
+  RGBL_HIP(hipGetLastError());
+  std::vector<int32_t> word(n), node(n);
+  std::vector<double> weight(n);
+  RGBL_HIP(hipMemcpyAsync(word.data(), v->d_word, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipMemcpyAsync(weight.data(), v->d_weight, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipMemcpyAsync(node.data(), v->d_node, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipStreamSynchronize(s));
+  // the two std::map containers of the reference, as sorted (key, payload) runs
+  std::vector<std::pair<uint32_t, int> > wf, nf;  // (word | node, feature)
+  for (int i = 0; i < n; ++i)
+    if (weight[i] > 0) { wf.push_back(std::make_pair((uint32_t)word[i], i)); nf.push_back(std::make_pair((uint32_t)node[i], i)); }
+  std::stable_sort(wf.begin(), wf.end(), [](const std::pair<uint32_t, int>& a, const std::pair<uint32_t, int>& b) { return a.first < b.first; });
+  std::stable_sort(nf.begin(), nf.end(), [](const std::pair<uint32_t, int>& a, const std::pair<uint32_t, int>& b) { return a.first < b.first; });
+  int nw = 0, nn = 0;
+  for (size_t a = 0; a < wf.size();) {
+    size_t b = a;
+    double acc = 0.0;
+    bool first = true;
+    for (; b < wf.size() && wf[b].first == wf[a].first; ++b) { acc = first ? weight[wf[b].second] : acc + weight[wf[b].second]; first = false; }
+    if (nw < cap_words && word_id && word_val) { word_id[nw] = wf[a].first; word_val[nw] = acc; }
+    ++nw;
+    a = b;
+  }
+  for (size_t a = 0; a < nf.size();) {
+    size_t b = a;
+    while (b < nf.size() && nf[b].first == nf[a].first) ++b;
+    if (nn < cap_nodes && node_id && node_off && node_feat) {
+      node_id[nn] = nf[a].first;
+      node_off[nn] = (int32_t)a;
+      for (size_t q = a; q < b; ++q) node_feat[q] = (uint32_t)nf[q].second;
+    }
+    ++nn;
+    a = b;
+  }
+  *n_words = nw; *n_nodes = nn;
+  if (nw > cap_words || nn > cap_nodes) { set_error("BoW transform: %d words / %d nodes exceed the output capacity", nw, nn); return RGBL_ERR_CAPACITY; }
+  if (node_off) node_off[nn] = (int32_t)nf.size();
+  double norm = 0.0;  // BowVector::normalize(L1)
+  for (int i = 0; i < nw; ++i) norm += fabs(word_val[i]);
+  if (norm > 0.0)
+    for (int i = 0; i < nw; ++i) word_val[i] /= norm;
   return RGBL_OK;
 }
 

@@ -409,3 +409,57 @@ class ORBmatcher:
 
     def profile_read(self):
         return L.read_profile(self.lib, self.lib.rgbl_matcher_profile_read, self.h)
+
+
+class ORBVocabulary:
+    """DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/ORBVocabulary.h) on the device: loadFromTextFile +
+    transform(features, BowVector, FeatureVector, levelsup) as Frame::ComputeBoW calls it (src/Frame.cc:828-835)."""
+
+    def __init__(self, device=0, lib=None):
+        self.lib = lib or L.load()
+        self.device = device
+        self.h = C.c_void_p()
+
+    def loadFromTextFile(self, path):
+        self.close()
+        rc = self.lib.rgbl_vocabulary_load_text(str(path).encode(), self.device, C.byref(self.h))
+        if rc != L.RGBL_OK:
+            self.h = C.c_void_p()
+            return False
+        return True
+
+    def from_arrays(self, arrays):
+        """arrays: synth.vocabulary_arrays(...) layout (n_nodes, L, child_off, child, desc, weight, word_id)."""
+        self.close()
+        keep = [np.ascontiguousarray(arrays[k]) for k in ("child_off", "child", "desc", "weight", "word_id")]
+        L.check(self.lib, self.lib.rgbl_vocabulary_create(arrays["n_nodes"], arrays["L"], *[L.ptr(a) for a in keep], self.device,
+                                                          C.byref(self.h)))
+        return self
+
+    def info(self):
+        k, lv, nn, nw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        L.check(self.lib, self.lib.rgbl_vocabulary_info(self.h, C.byref(k), C.byref(lv), C.byref(nn), C.byref(nw)))
+        return dict(k=k.value, L=lv.value, n_nodes=nn.value, n_words=nw.value)
+
+    def transform(self, features, levelsup=4):
+        """features: [n, 32] u8.  Returns (BowVector word ids, BowVector values, FeatureVector node ids, node offsets,
+        feature indices)."""
+        desc = np.ascontiguousarray(features, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        wid, wval = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.float64)
+        nid, noff, nfeat = np.zeros(max(n, 1), np.uint32), np.zeros(n + 1, np.int32), np.zeros(max(n, 1), np.uint32)
+        nw, nn = C.c_int(0), C.c_int(0)
+        L.check(self.lib, self.lib.rgbl_bow_transform(self.h, L.ptr(desc), n, levelsup, L.ptr(wid), L.ptr(wval), n, C.byref(nw),
+                                                      L.ptr(nid), L.ptr(noff), L.ptr(nfeat), n, C.byref(nn)))
+        return wid[:nw.value].copy(), wval[:nw.value].copy(), nid[:nn.value].copy(), noff[:nn.value + 1].copy(), nfeat[:noff[nn.value]].copy()
+
+    def close(self):
+        if self.h:
+            self.lib.rgbl_vocabulary_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -124,3 +124,65 @@ def feature_vector(desc, n_nodes=100):
     off = np.zeros(len(ids) + 1, np.int32)
     off[1:] = np.cumsum(counts)
     return ids.astype(np.int32), off, order.astype(np.int32)
+
+
+def make_vocabulary(k=10, L=4, seed=0, stop_fraction=0.02):
+    """A synthetic DBoW2 vocabulary tree of the ORBvoc.txt shape (k-ary, L levels below the root; ORBvoc itself is k = 10,
+    L = 6): children are their parent's descriptor with ~6 % of the bits flipped, a few inner nodes have fewer than k
+    children (k-means clusters can run empty), idf weights are positive with a few stopped (zero) words.
+    Returns dict(k, L, parent[int32], is_leaf[uint8], desc[n,32], weight[float64]) in file order (node id = row + 1)."""
+    rng = np.random.default_rng(0xB0D + seed)
+    parent, leaf, desc, weight = [], [], [], []
+    root_desc = np.packbits(rng.integers(0, 2, 256, dtype=np.uint8), bitorder="little")
+    level_nodes = [(0, root_desc)]          # (node id, descriptor)
+    next_id = 1
+    for level in range(1, L + 1):
+        nxt = []
+        for pid, pdesc in level_nodes:
+            nk = k if rng.random() > 0.1 else int(rng.integers(2, k + 1))
+            for _ in range(nk):
+                flips = rng.random(256) < (0.06 if level > 1 else 0.5)
+                d = pdesc ^ np.packbits(flips, bitorder="little")
+                parent.append(pid)
+                leaf.append(1 if level == L else 0)
+                desc.append(d)
+                weight.append(0.0 if (level == L and rng.random() < stop_fraction) else float(rng.uniform(0.5, 9.0)) if level == L else 0.0)
+                nxt.append((next_id, d))
+                next_id += 1
+        level_nodes = nxt
+    return dict(k=k, L=L, parent=np.array(parent, np.int32), is_leaf=np.array(leaf, np.uint8),
+                desc=np.stack(desc).astype(np.uint8), weight=np.array(weight, np.float64))
+
+
+def write_vocabulary_text(path, voc):
+    """The text format TemplatedVocabulary::loadFromTextFile reads (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1425):
+    'k L scoring weighting' (0 0 = L1_NORM, TF_IDF as in ORBvoc.txt), then 'parent is_leaf d0 .. d31 weight' per node."""
+    lines = ["%d %d 0 0" % (voc["k"], voc["L"])]
+    for p, lf, d, w in zip(voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"]):
+        lines.append("%d %d %s %r" % (p, lf, " ".join(str(int(b)) for b in d), float(w)))
+    with open(path, "w") as f:
+        # no newline after the last node: the reference's loader turns a trailing empty line into one more child of the
+        # root with an unset descriptor (its `while(!f.eof())` loop, TemplatedVocabulary.h:1378-1420)
+        f.write("\n".join(lines))
+
+
+def vocabulary_arrays(voc):
+    """Flat tree arrays (children CSR in file order, node 0 = root) shared by the oracle and the C ABI."""
+    n = len(voc["parent"]) + 1
+    counts = np.zeros(n, np.int64)
+    np.add.at(counts, voc["parent"], 1)
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum(counts)
+    child = np.zeros(n - 1, np.int32)
+    fill = off[:-1].copy()
+    for i, p in enumerate(voc["parent"]):
+        child[fill[p]] = i + 1
+        fill[p] += 1
+    desc = np.zeros((n, 32), np.uint8)
+    desc[1:] = voc["desc"]
+    weight = np.zeros(n, np.float64)
+    weight[1:] = voc["weight"]
+    word_id = np.full(n, -1, np.int32)
+    leaves = np.nonzero(voc["is_leaf"])[0] + 1
+    word_id[leaves] = np.arange(len(leaves), dtype=np.int32)   # word ids are handed out in file order
+    return dict(n_nodes=n, L=voc["L"], child_off=off, child=child, desc=desc, weight=weight, word_id=word_id)

@@ -604,3 +604,36 @@ def check_search_local_points(lib, seed=41, th=1.0, nnratio=0.8, n1=3000, n2=200
     assert n2_ == on2 and np.array_equal(m2, om2)
     mt.close()
     return n
+
+
+# ---- DBoW2 vocabulary transform ----------------------------------------------------------------------
+def check_bow_transform(lib, tmp_dir, k=10, L=4, levelsup=2, seed=0, n_feat=2000):
+    voc = synth.make_vocabulary(k, L, seed)
+    varr = synth.vocabulary_arrays(voc)
+    path = str(tmp_dir) + "/voc_%d.txt" % seed
+    synth.write_vocabulary_text(path, voc)
+    rng = np.random.default_rng(seed)
+    leaves = voc["desc"][voc["is_leaf"] > 0]
+    pick = leaves[rng.integers(0, len(leaves), n_feat * 3 // 4)]
+    desc = np.ascontiguousarray(np.concatenate([pick ^ np.packbits(rng.random((len(pick), 256)) < 0.03, axis=1, bitorder="little"),
+                                                synth.descriptors(n_feat - len(pick), seed)]))
+    want = O.bow_transform(varr, desc, levelsup)
+    for source in ("text", "arrays"):
+        V = F.ORBVocabulary(lib=lib)
+        if source == "text":
+            assert V.loadFromTextFile(path)
+        else:
+            V.from_arrays(varr)
+        info = V.info()
+        assert info["L"] == L and info["n_nodes"] == varr["n_nodes"] and info["n_words"] == int(voc["is_leaf"].sum())
+        got = V.transform(desc, levelsup)
+        for g, w, name in zip(got, want, ("word ids", "word values", "node ids", "node offsets", "feature indices")):
+            if name == "word values":
+                assert np.array_equal(g.view(np.uint64), w.view(np.uint64)), name
+            else:
+                assert np.array_equal(g, w), name
+        assert len(V.transform(desc[:0], levelsup)[0]) == 0
+        V.close()
+    V = F.ORBVocabulary(lib=lib)
+    assert not V.loadFromTextFile(str(tmp_dir) + "/does_not_exist.txt")
+    return len(want[0])

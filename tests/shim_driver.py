@@ -73,10 +73,12 @@ def run_and_check(exe, tmp):
                         ("mp_desc1", np.uint8), ("mp_observed1", np.uint8), ("kp2_xy", np.float32), ("kp2_octave", np.int32),
                         ("uright2", np.float32), ("desc2", np.uint8), ("blocked2", np.uint8)):
             f.write(np.ascontiguousarray(lcase[key], dt).tobytes())
+    voc = synth.make_vocabulary(10, 3, seed=5)
+    synth.write_vocabulary_text(os.path.join(tmp, "voc.txt"), voc)
     out = os.path.join(tmp, "out.bin")
     res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "KITTI00-02.yaml"), os.path.join(tmp, "img.raw"), str(w), str(h),
                           os.path.join(tmp, "cloud.raw"), str(cloud.shape[1]), os.path.join(tmp, "tri.bin"), out,
-                          os.path.join(tmp, "proj.bin"), os.path.join(tmp, "local.bin")],
+                          os.path.join(tmp, "proj.bin"), os.path.join(tmp, "local.bin"), os.path.join(tmp, "voc.txt")],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "Lidar Method: InverseDilation" in res.stdout
@@ -113,7 +115,20 @@ def run_and_check(exe, tmp):
     proj_match = take(np.int32, n2p)
     nloc, n2l = take(np.int32, 2)
     local_match = take(np.int32, n2l)
+    nw = take(np.int32, 1)[0]
+    bow = np.frombuffer(buf, np.dtype([("id", "<u4"), ("val", "<f8")]), nw, pos)
+    pos += bow.nbytes
+    nn = take(np.int32, 1)[0]
+    fv = []
+    for _ in range(nn):
+        nid, cnt = take(np.uint32, 1)[0], take(np.int32, 1)[0]
+        fv.append((int(nid), take(np.uint32, cnt).copy()))
     assert pos == len(buf)
+    wid, wval, onid, onoff, onfeat = O.bow_transform(synth.vocabulary_arrays(voc), desc, 2)   # desc == the oracle's, checked below
+    assert np.array_equal(bow["id"], wid) and np.array_equal(bow["val"].view(np.uint64), wval.view(np.uint64)) and nw > 50
+    assert [f[0] for f in fv] == onid.tolist()
+    for j, (_, feats) in enumerate(fv):
+        assert np.array_equal(feats, onfeat[onoff[j]:onoff[j + 1]])
     olm, oln = O.search_local_points(lcase, 3.0, 0.8)
     assert nloc == oln and np.array_equal(local_match, olm) and nloc > 150
     om, onm = O.search_by_projection(case, 7.0, False, True)

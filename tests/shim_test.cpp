@@ -12,6 +12,7 @@
 #include "DepthModule.h"
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
+#include "ORBVocabulary.h"
 
 // ---- minimal stand-ins for the Sophus / camera / KeyFrame members SearchForTriangulation touches
 struct V3 { float v[3]; float operator()(int i) const { return v[i]; } };
@@ -294,6 +295,21 @@ int main(int argc, char** argv) {
       const int idx = (p && p != &old_point) ? (int)(p - pts.data()) : -1;
       wr(out, &idx, 1);
     }
+  }
+  // --- as Frame::ComputeBoW (Frame.cc:828-835): mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4)
+  if (argc > 11) {
+    ORB_SLAM3::DeviceORBVocabulary voc;
+    if (!voc.loadFromTextFile(argv[11])) return 8;
+    std::vector<cv::Mat> vCurrentDesc(nk);
+    for (int i = 0; i < nk; ++i) vCurrentDesc[i] = cv::Mat(1, 32, CV_8U, desc.data + (size_t)i * 32, 32);
+    std::map<unsigned, double> bow;
+    std::map<unsigned, std::vector<unsigned> > featvec;
+    voc.transform(vCurrentDesc, bow, featvec, 2);
+    const int nw = (int)bow.size(), nn = (int)featvec.size();
+    wr(out, &nw, 1);
+    for (auto& kv : bow) { wr(out, &kv.first, 1); wr(out, &kv.second, 1); }
+    wr(out, &nn, 1);
+    for (auto& kv : featvec) { const int c = (int)kv.second.size(); wr(out, &kv.first, 1); wr(out, &c, 1); wr(out, kv.second.data(), c); }
   }
   fclose(out);
   printf("shim_test ok: %d keypoints, %d depths, %d triangulation matches\n", nk, nd, nm);

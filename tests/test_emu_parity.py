@@ -111,3 +111,8 @@ def test_search_by_projection_edge_cases(emu_lib):
 @pytest.mark.parametrize("seed,th,ratio", [(41, 1.0, 0.8), (42, 3.0, 0.8), (45, 15.0, 0.7)])
 def test_search_local_points(emu_lib, seed, th, ratio):
     assert pc.check_search_local_points(emu_lib, seed, th, ratio, n1=1200, n2=900) > 50
+
+
+def test_bow_transform(emu_lib, tmp_path):
+    assert pc.check_bow_transform(emu_lib, tmp_path, 10, 3, 2, seed=1, n_feat=600) > 100
+    assert pc.check_bow_transform(emu_lib, tmp_path, 6, 4, 4, seed=2, n_feat=400) > 100    # levelsup >= L: every feature under the root

@@ -130,3 +130,8 @@ def test_search_by_projection_edge_cases(gpu_lib):
 @pytest.mark.parametrize("seed,th,ratio", [(41, 1.0, 0.8), (42, 3.0, 0.8), (43, 5.0, 0.8), (45, 15.0, 0.7)])
 def test_search_local_points(gpu_lib, seed, th, ratio):
     assert pc.check_search_local_points(gpu_lib, seed, th, ratio) > 200
+
+
+def test_bow_transform(gpu_lib, tmp_path):
+    assert pc.check_bow_transform(gpu_lib, tmp_path, 10, 4, 2, seed=0) > 500
+    assert pc.check_bow_transform(gpu_lib, tmp_path, 10, 5, 4, seed=3, n_feat=8000) > 2000   # 111 k nodes

@@ -331,3 +331,60 @@ def test_reference_search_local_points_agrees_with_oracle(refmatcher, seed, th, 
     assert nm > 200
     free = dict(case, blocked2=np.zeros_like(case["blocked2"]), mp_observed1=np.zeros_like(case["mp_observed1"]))
     assert not np.array_equal(O.search_local_points(free, th, nnratio)[0], om)   # the blocking rule matters in this scenario
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's own vendored DBoW2 (oracle/_ref/libref_dbow2.so): vocabulary text loader + transform (Frame::ComputeBoW).
+REF_DBOW2_SO = os.path.join(ROOT, "oracle", "_ref", "libref_dbow2.so")
+
+
+@pytest.fixture(scope="module")
+def refdbow(oracle):
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    if not os.path.exists(REF_DBOW2_SO):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    lib = C.CDLL(REF_DBOW2_SO)
+    lib.ref_voc_load_text.restype = C.c_void_p
+    lib.ref_voc_load_text.argtypes = [C.c_char_p]
+    lib.ref_voc_destroy.argtypes = [C.c_void_p]
+    lib.ref_voc_transform.restype = C.c_int
+    lib.ref_voc_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
+                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    return lib
+
+
+def ref_transform(lib, h, desc, levelsup):
+    n = len(desc)
+    wid, wval = np.zeros(n, np.uint32), np.zeros(n, np.float64)
+    nid, noff, nfeat = np.zeros(n, np.uint32), np.zeros(n + 1, np.int32), np.zeros(n, np.uint32)
+    nw, nn = C.c_int(0), C.c_int(0)
+    rc = lib.ref_voc_transform(h, desc.ctypes.data, n, levelsup, n, wid.ctypes.data, wval.ctypes.data, C.byref(nw), n,
+                               nid.ctypes.data, noff.ctypes.data, nfeat.ctypes.data, C.byref(nn))
+    assert rc == 0
+    return wid[:nw.value], wval[:nw.value], nid[:nn.value], noff[:nn.value + 1], nfeat[:noff[nn.value]]
+
+
+@pytest.mark.parametrize("k,L,levelsup,seed", [(10, 4, 2, 0), (10, 3, 4, 1), (6, 5, 4, 2), (10, 4, 4, 3)])
+def test_reference_dbow2_transform_agrees_with_oracle(refdbow, tmp_path, k, L, levelsup, seed):
+    voc = synth.make_vocabulary(k, L, seed)
+    path = str(tmp_path / "voc.txt")
+    synth.write_vocabulary_text(path, voc)
+    h = refdbow.ref_voc_load_text(path.encode())
+    assert h
+    varr = synth.vocabulary_arrays(voc)
+    # features: perturbed copies of leaf descriptors (they land in the neighbourhood of their word) plus random ones
+    rng = np.random.default_rng(seed)
+    leaves = voc["desc"][voc["is_leaf"] > 0]
+    pick = leaves[rng.integers(0, len(leaves), 1500)]
+    desc = np.ascontiguousarray(np.concatenate([pick ^ np.packbits(rng.random((1500, 256)) < 0.03, axis=1, bitorder="little"),
+                                                synth.descriptors(500, seed)]))
+    got = ref_transform(refdbow, h, desc, levelsup)
+    want = O.bow_transform(varr, desc, levelsup)
+    for g, w, name in zip(got, want, ("word ids", "word values", "node ids", "node offsets", "feature indices")):
+        if name == "word values":
+            assert np.array_equal(g.view(np.uint64), w.view(np.uint64)), name   # doubles, bit for bit
+        else:
+            assert np.array_equal(g, w), name
+    assert len(got[0]) > 200 and abs(got[1].sum() - 1.0) < 1e-9
+    refdbow.ref_voc_destroy(h)
