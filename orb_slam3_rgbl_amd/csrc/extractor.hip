@@ -50,7 +50,7 @@ struct rgbl_extractor {
   int L = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
   hipStream_t aux_stream = nullptr;  // the Gaussian working images only depend on the pyramid: they overlap FAST + quad-tree
-  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
+  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_fast0 = nullptr;
   KernelTimer timer;
   int octree_wg = 0;  // 0 = choose per launch; RGBL_OCTREE_WG=256|512 pins the quad-tree workgroup width (tuning / tests)
   int max_cell = 0;  // largest detection-cell side over the levels: selects the k_fast_cells instantiation
@@ -315,6 +315,37 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   hipStream_t s = e->stream;
   e->last_img0 = d_imgs; e->last_pitch0 = stride; e->last_frame0 = frame_stride; e->last_batch = batch;
 
+  // cells of at most kCellSmall px (every level of the usual image sizes) take the small-LDS instantiation
+  auto fast = e->max_cell <= kCellSmall ? k_fast_cells<kCellSmall> : k_fast_cells<kCellMax>;
+  auto launch_fast = [&](hipStream_t st, int cell_begin, int cell_end) {
+    if (cell_end <= cell_begin) return;
+    e->timer.begin("k_fast_cells", st);
+    hipLaunchKernelGGL(fast, dim3(cell_end - cell_begin, batch), dim3(256), 0, st, e->d_geom, L, d_imgs, stride, frame_stride,
+                       e->d_pyr, e->pyr_frame, e->cfg.ini_th_fast, e->cfg.min_th_fast, e->d_cellcnt, (size_t)e->cells_frame,
+                       e->d_slots, e->slots_frame, cell_begin);
+    e->timer.end(st);
+  };
+  auto launch_gauss = [&](hipStream_t st, int tile_begin, int tile_end) {
+    if (tile_end <= tile_begin) return;
+    e->timer.begin("k_gauss7", st);
+    hipLaunchKernelGGL(k_gauss7, dim3(tile_end - tile_begin, batch), dim3(256), 0, st, e->d_geom, L, e->blur_tiles, d_imgs, stride,
+                       frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame, tile_begin);
+    e->timer.end(st);
+  };
+  // Level 0 of the pyramid is the input image itself: its FAST cells (a third of all pixels) and its Gaussian do not
+  // wait for the resize chain - seven short dependent launches that leave most of the chip idle - but run next to it
+  // on the auxiliary stream.  (While per-kernel timing is on, everything stays on one stream so that the event
+  // brackets are not contended.)
+  const bool overlap = !e->timer.enabled;
+  hipStream_t bs = overlap ? e->aux_stream : s;
+  const int cells0 = L > 1 ? e->geom[1].cell_off : e->cells_frame, tiles0 = e->blur_tiles.tile_off[1];
+  if (overlap) {
+    RGBL_HIP(hipEventRecord(e->ev_start, s));
+    RGBL_HIP(hipStreamWaitEvent(bs, e->ev_start, 0));
+    launch_fast(bs, 0, cells0);
+    RGBL_HIP(hipEventRecord(e->ev_fast0, bs));
+    launch_gauss(bs, 0, tiles0);
+  }
   // 1. pyramid: level l from level l-1 (ORBextractor.cc:1170-1195)
   for (int l = 1; l < L; ++l) {
     const LevelGeom& g = e->geom[l];
@@ -328,27 +359,22 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
                        e->d_xtab + g.xtab_off, e->d_ytab + g.ytab_off);
     e->timer.end(s);
   }
-  // 4. Gaussian working images (ORBextractor.cc:1132-1133) on the auxiliary stream, concurrently with 2. and 3.
-  //    (while per-kernel timing is on, everything stays on one stream so the event brackets are not contended)
-  const bool overlap = !e->timer.enabled;
-  hipStream_t bs = overlap ? e->aux_stream : s;
+  // 4. Gaussian working images (ORBextractor.cc:1132-1133) of the upper levels, on the auxiliary stream next to 2. and 3.
   if (overlap) {
     RGBL_HIP(hipEventRecord(e->ev_pyr, s));
     RGBL_HIP(hipStreamWaitEvent(bs, e->ev_pyr, 0));
+    launch_gauss(bs, tiles0, e->blur_tiles.tile_off[L]);
+    RGBL_HIP(hipEventRecord(e->ev_blur, bs));
+  } else {
+    launch_gauss(s, 0, e->blur_tiles.tile_off[L]);
   }
-  e->timer.begin("k_gauss7", bs);
-  hipLaunchKernelGGL(k_gauss7, dim3(e->blur_tiles.tile_off[L], batch), dim3(256), 0, bs, e->d_geom, L, e->blur_tiles, d_imgs,
-                     stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame);
-  e->timer.end(bs);
-  if (overlap) RGBL_HIP(hipEventRecord(e->ev_blur, bs));
   // 2. FAST per detection cell (ORBextractor.cc:806-872)
-  e->timer.begin("k_fast_cells", s);
-  // cells of at most kCellSmall px (every level of the usual image sizes) take the small-LDS instantiation
-  auto fast = e->max_cell <= kCellSmall ? k_fast_cells<kCellSmall> : k_fast_cells<kCellMax>;
-  hipLaunchKernelGGL(fast, dim3(e->cells_frame, batch), dim3(256), 0, s, e->d_geom, L, d_imgs, stride,
-                     frame_stride, e->d_pyr, e->pyr_frame, e->cfg.ini_th_fast, e->cfg.min_th_fast, e->d_cellcnt,
-                     (size_t)e->cells_frame, e->d_slots, e->slots_frame);
-  e->timer.end(s);
+  if (overlap) {
+    launch_fast(s, cells0, e->cells_frame);
+    RGBL_HIP(hipStreamWaitEvent(s, e->ev_fast0, 0));
+  } else {
+    launch_fast(s, 0, e->cells_frame);
+  }
   // 3. quad-tree distribution (ORBextractor.cc:555-779)
   OctreeBufs ob;
   ob.cell_cnt = e->d_cellcnt; ob.cells_frame = (size_t)e->cells_frame;
@@ -450,7 +476,9 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
   if (rc == RGBL_OK) rc = alloc_scratch(e);
   if (rc == RGBL_OK && (hipStreamCreate(&e->own_stream) != hipSuccess || hipStreamCreate(&e->aux_stream) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming) != hipSuccess)) {
+                        hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&e->ev_fast0, hipEventDisableTiming) != hipSuccess)) {
     set_error("hipStreamCreate failed");
     rc = RGBL_ERR_HIP;
   }
@@ -472,6 +500,8 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
   if (e->ev_pyr) (void)hipEventDestroy(e->ev_pyr);
   if (e->ev_blur) (void)hipEventDestroy(e->ev_blur);
+  if (e->ev_start) (void)hipEventDestroy(e->ev_start);
+  if (e->ev_fast0) (void)hipEventDestroy(e->ev_fast0);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }

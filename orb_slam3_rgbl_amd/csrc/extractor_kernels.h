@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
                                                     size_t frame0, const uint8_t* __restrict__ pyr,
                                                     size_t pyr_frame, int ini_th, int min_th,
                                                     uint32_t* __restrict__ cell_cnt, size_t cells_frame,
-                                                    uint32_t* __restrict__ slots, size_t slots_frame) {
+                                                    uint32_t* __restrict__ slots, size_t slots_frame, int cell_begin) {
   constexpr int kTileP = CM + 8;   // LDS tile pitch (cell + 6 ring margin, padded)
   constexpr int kScoreP = CM + 4;  // score tile pitch (cell + 1-px zero frame), multiple of 4
   constexpr int kBitWords = (CM * CM + 31) / 32;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   __shared__ uint32_t s_keep[kBitWords], s_keep_ini[kBitWords];
 
   const int tid = threadIdx.x;
-  const int bx = blockIdx.x, f = blockIdx.y;
+  const int bx = blockIdx.x + cell_begin, f = blockIdx.y;  // the launch covers the cells cell_begin .. cell_begin + gridDim.x
   int l = 0;
   while (l + 1 < n_levels && bx >= geom[l + 1].cell_off) ++l;
   const LevelGeom& g = geom[l];
@@ -305,9 +305,9 @@ struct BlurTiles { int tile_off[kMaxLevels + 1]; int tiles_x[kMaxLevels]; };
 __global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ geom, int n_levels, BlurTiles bt,
                                                 const uint8_t* __restrict__ img0, int pitch0, size_t frame0,
                                                 const uint8_t* __restrict__ pyr, size_t pyr_frame,
-                                                uint8_t* __restrict__ blur, size_t blur_frame) {
+                                                uint8_t* __restrict__ blur, size_t blur_frame, int tile_begin) {
   __shared__ uint32_t s_h[(kBlurTH + 6) * (kBlurTW / 2)];  // two 16-bit horizontal sums per word
-  const int tid = threadIdx.x, bx = blockIdx.x, f = blockIdx.y;
+  const int tid = threadIdx.x, bx = blockIdx.x + tile_begin, f = blockIdx.y;
   int l = 0;
   while (l + 1 < n_levels && bx >= bt.tile_off[l + 1]) ++l;
   const LevelGeom& g = geom[l];
