@@ -332,6 +332,28 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
                        frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame, tile_begin);
     e->timer.end(st);
   };
+  // buffers of the quad-tree distribution (ORBextractor.cc:555-779)
+  OctreeBufs ob;
+  ob.cell_cnt = e->d_cellcnt; ob.cells_frame = (size_t)e->cells_frame;
+  ob.slots = e->d_slots; ob.slots_frame = e->slots_frame;
+  ob.keys_a = e->d_keys_a; ob.keys_b = e->d_keys_b; ob.keys_frame = e->keys_frame;
+  ob.list_a = e->d_list_a; ob.list_b = e->d_list_b; ob.div = e->d_div;
+  ob.todo_a = e->d_todo_a; ob.todo_b = e->d_todo_b; ob.skey = e->d_skey; ob.sval = e->d_sval;
+  ob.divided = e->d_divided; ob.nodes_frame = e->nodes_frame;
+  ob.rootx = e->d_rootx;
+  ob.kp_key = e->d_kpkey; ob.kp_count = e->d_kpcount; ob.kp_frame = (size_t)e->kp_frame;
+  ob.err = e->d_err;
+  ob.dbg = getenv("RGBL_OCTREE_STAMPS") ? e->d_dbg : nullptr;
+  // 4 narrow workgroups fit a CU: once the (level, frame) problems can fill the chip that way, occupancy beats
+  // per-problem latency (KITTI, 256 frames: 0.57 -> 0.48 ms); small batches keep the wide group (4K, 16 frames: 2.8 vs 4.1 ms)
+  const bool narrow = e->octree_wg ? e->octree_wg == kOctNarrow : (long)L * batch >= 1024;
+  auto launch_octree = [&](hipStream_t st, int level_begin, int level_end) {
+    if (level_end <= level_begin) return;
+    e->timer.begin("k_octree", st);
+    if (narrow) hipLaunchKernelGGL(k_octree<kOctNarrow>, dim3(level_end - level_begin, batch), dim3(kOctNarrow), 0, st, e->d_geom, L, ob, level_begin);
+    else hipLaunchKernelGGL(k_octree<kOctWide>, dim3(level_end - level_begin, batch), dim3(kOctWide), 0, st, e->d_geom, L, ob, level_begin);
+    e->timer.end(st);
+  };
   // Level 0 of the pyramid is the input image itself: its FAST cells (a third of all pixels) and its Gaussian do not
   // wait for the resize chain - seven short dependent launches that leave most of the chip idle - but run next to it
   // on the auxiliary stream.  (While per-kernel timing is on, everything stays on one stream so that the event
@@ -343,6 +365,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
     RGBL_HIP(hipEventRecord(e->ev_start, s));
     RGBL_HIP(hipStreamWaitEvent(bs, e->ev_start, 0));
     launch_fast(bs, 0, cells0);
+    launch_octree(bs, 0, 1);  // the longest dependent chains of the quad-tree start as early as they can
     RGBL_HIP(hipEventRecord(e->ev_fast0, bs));
     launch_gauss(bs, 0, tiles0);
   }
@@ -371,29 +394,16 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   // 2. FAST per detection cell (ORBextractor.cc:806-872)
   if (overlap) {
     launch_fast(s, cells0, e->cells_frame);
-    RGBL_HIP(hipStreamWaitEvent(s, e->ev_fast0, 0));
   } else {
     launch_fast(s, 0, e->cells_frame);
   }
-  // 3. quad-tree distribution (ORBextractor.cc:555-779)
-  OctreeBufs ob;
-  ob.cell_cnt = e->d_cellcnt; ob.cells_frame = (size_t)e->cells_frame;
-  ob.slots = e->d_slots; ob.slots_frame = e->slots_frame;
-  ob.keys_a = e->d_keys_a; ob.keys_b = e->d_keys_b; ob.keys_frame = e->keys_frame;
-  ob.list_a = e->d_list_a; ob.list_b = e->d_list_b; ob.div = e->d_div;
-  ob.todo_a = e->d_todo_a; ob.todo_b = e->d_todo_b; ob.skey = e->d_skey; ob.sval = e->d_sval;
-  ob.divided = e->d_divided; ob.nodes_frame = e->nodes_frame;
-  ob.rootx = e->d_rootx;
-  ob.kp_key = e->d_kpkey; ob.kp_count = e->d_kpcount; ob.kp_frame = (size_t)e->kp_frame;
-  ob.err = e->d_err;
-  ob.dbg = getenv("RGBL_OCTREE_STAMPS") ? e->d_dbg : nullptr;
-  e->timer.begin("k_octree", s);
-  // 4 narrow workgroups fit a CU: once the (level, frame) problems can fill the chip that way, occupancy beats
-  // per-problem latency (KITTI, 256 frames: 0.57 -> 0.48 ms); small batches keep the wide group (4K, 16 frames: 2.8 vs 4.1 ms)
-  const bool narrow = e->octree_wg ? e->octree_wg == kOctNarrow : (long)L * batch >= 1024;
-  if (narrow) hipLaunchKernelGGL(k_octree<kOctNarrow>, dim3(L, batch), dim3(kOctNarrow), 0, s, e->d_geom, L, ob);
-  else hipLaunchKernelGGL(k_octree<kOctWide>, dim3(L, batch), dim3(kOctWide), 0, s, e->d_geom, L, ob);
-  e->timer.end(s);
+  // 3. quad-tree distribution (ORBextractor.cc:555-779) of the remaining levels (level 0 went with its FAST cells above)
+  if (overlap) {
+    launch_octree(s, 1, L);
+    RGBL_HIP(hipStreamWaitEvent(s, e->ev_fast0, 0));
+  } else {
+    launch_octree(s, 0, L);
+  }
   // 5. orientation + descriptors + packing (ORBextractor.cc:894-895, 1136-1165); needs the blurred levels
   if (overlap) RGBL_HIP(hipStreamWaitEvent(s, e->ev_blur, 0));
   const bool lapping = lap1 >= 19 && lap1 >= lap0;  // keypoint x is always >= 19: nothing can fall into [lap0, lap1] otherwise

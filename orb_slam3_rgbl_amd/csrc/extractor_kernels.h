@@ -977,7 +977,7 @@ __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n
 }
 
 template <int BS>
-__global__ __launch_bounds__(BS, 4) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b) {
+__global__ __launch_bounds__(BS, 4) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b, int level_begin) {
   __shared__ unsigned long long s_scan[32];
   __shared__ unsigned long long s_skey_pad[kSortLds + 8];  // 4 entries of read slack on both sides
   __shared__ uint32_t s_sval[kSortLds];
@@ -990,12 +990,12 @@ __global__ __launch_bounds__(BS, 4) void k_octree(const LevelGeom* __restrict__ 
   __shared__ int s_big[kMaxBig];
   __shared__ uint32_t s_wcnt[BS / 64][4];
   __shared__ uint32_t s_rootcnt[kMaxRoots];
-#define RGBL_STAMP(k) do { if (b.dbg && threadIdx.x == 0) b.dbg[((size_t)blockIdx.y * n_levels + blockIdx.x) * 16 + (k)] = rgbl_clock(); } while (0)
+#define RGBL_STAMP(k) do { if (b.dbg && threadIdx.x == 0) b.dbg[((size_t)blockIdx.y * n_levels + blockIdx.x + level_begin) * 16 + (k)] = rgbl_clock(); } while (0)
   RGBL_STAMP(0);
 
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int nw = (int)(blockDim.x >> 6);
-  const int l = blockIdx.x, f = blockIdx.y;
+  const int l = blockIdx.x + level_begin, f = blockIdx.y;  // the launch covers the levels level_begin .. level_begin + gridDim.x
   const LevelGeom& g = geom[l];
   uint32_t* keys_a = b.keys_a + (size_t)f * b.keys_frame + g.key_off;
   uint32_t* keys_b = b.keys_b + (size_t)f * b.keys_frame + g.key_off;
