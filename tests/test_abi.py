@@ -68,3 +68,46 @@ def test_invalid_arguments_are_reported_not_thrown(emu_lib):
     d.method, d.width, d.height, d.max_points, d.max_keypoints, d.max_batch, d.kernel_w, d.kernel_h = 5, 64, 64, 10, 10, 1, 5, 5
     assert lib.rgbl_depth_create(C.byref(d), 0, C.byref(h)) == _lib.ERR_INVALID  # IPBasic: never implemented upstream
     assert lib.rgbl_structuring_element(3, 4, 4, None) == _lib.ERR_INVALID
+
+
+def test_invalid_arguments_of_the_matcher_entry_points(emu_lib, tmp_path):
+    """The tracking matchers and the vocabulary reject bad input with a status code and a message (never throw)."""
+    import numpy as np
+    from orb_slam3_rgbl_amd import _lib, frontend as F, synth
+    import parity_checks as pc
+    lib = emu_lib
+    mt = F.ORBmatcher(0.9, True, lib=lib)
+    case = pc.make_projection_case(40, 50, 3)
+    bad = dict(case, octave1=np.full(40, 9, np.int32))            # octave beyond the scale table
+    with pytest.raises(_lib.RgblError):
+        mt.SearchByProjection(bad, 7.0, False)
+    lcase = pc.make_local_points_case(40, 50, 3)
+    bad = dict(lcase, level1=np.full(40, -1, np.int32))
+    with pytest.raises(_lib.RgblError):
+        mt.SearchLocalPoints(bad, 1.0)
+    n = _lib.C.c_int(0)
+    assert lib.rgbl_search_by_projection(mt.h, None, None, _lib.C.byref(n)) == _lib.ERR_INVALID
+    assert lib.rgbl_search_local_points(mt.h, None, None, _lib.C.byref(n)) == _lib.ERR_INVALID
+    mt.close()
+    # vocabulary files
+    h = _lib.C.c_void_p()
+    p = tmp_path / "bad.txt"
+    p.write_text("10 6 0 0 extra\n")
+    assert lib.rgbl_vocabulary_load_text(str(p).encode(), 0, _lib.C.byref(h)) == _lib.ERR_INVALID      # no nodes
+    p.write_text("40 6 0 0\n")
+    assert lib.rgbl_vocabulary_load_text(str(p).encode(), 0, _lib.C.byref(h)) == _lib.ERR_INVALID      # k out of range, as upstream
+    assert b"not a correct text file" in lib.rgbl_last_error()
+    p.write_text("10 3 2 0\n0 1 " + " ".join(["0"] * 32) + " 1.0")
+    assert lib.rgbl_vocabulary_load_text(str(p).encode(), 0, _lib.C.byref(h)) == _lib.ERR_INVALID      # scoring other than L1_NORM
+    p.write_text("10 3 0 0\n5 1 " + " ".join(["0"] * 32) + " 1.0")
+    assert lib.rgbl_vocabulary_load_text(str(p).encode(), 0, _lib.C.byref(h)) == _lib.ERR_INVALID      # parent that does not exist yet
+    voc = synth.make_vocabulary(4, 2, 0)
+    V = F.ORBVocabulary(lib=lib).from_arrays(synth.vocabulary_arrays(voc))
+    nw, nn = _lib.C.c_int(0), _lib.C.c_int(0)
+    desc = synth.descriptors(50, 1)
+    wid, wval = np.zeros(2, np.uint32), np.zeros(2, np.float64)
+    nid, noff, nfeat = np.zeros(50, np.uint32), np.zeros(51, np.int32), np.zeros(50, np.uint32)
+    rc = lib.rgbl_bow_transform(V.h, desc.ctypes.data, 50, 1, wid.ctypes.data, wval.ctypes.data, 2, _lib.C.byref(nw), nid.ctypes.data,
+                                noff.ctypes.data, nfeat.ctypes.data, 50, _lib.C.byref(nn))
+    assert rc == _lib.ERR_CAPACITY and nw.value > 2      # capacity too small: reported, count returned
+    V.close()
