@@ -281,7 +281,13 @@ int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, 
                  float* d_processed_out, bool xyzi = false) {
   hipStream_t s = e->stream;
   const size_t ms = e->map_stride;
-  RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)batch * ms * 2 * sizeof(uint32_t), s));  // idx maps + raw maps
+  // idx maps (max_batch of them) are followed by the raw maps: one memset clears both when the batch is full
+  if (batch == e->cfg.max_batch) {
+    RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)batch * ms * 2 * sizeof(uint32_t), s));
+  } else {
+    RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)batch * ms * sizeof(uint32_t), s));
+    RGBL_HIP(hipMemsetAsync(e->d_raw, 0, (size_t)batch * ms * sizeof(float), s));
+  }
   if (n > 0) {
     e->timer.begin("k_project_index", s);
     const dim3 pgrid((n + 255) / 256, batch);

@@ -637,3 +637,60 @@ def check_bow_transform(lib, tmp_dir, k=10, L=4, levelsup=2, seed=0, n_feat=2000
     V = F.ORBVocabulary(lib=lib)
     assert not V.loadFromTextFile(str(tmp_dir) + "/does_not_exist.txt")
     return len(want[0])
+
+
+def check_depth_partial_batches(lib, dev=None, w=310, h=94):
+    """A handle sized for 4 scans used with 2, then 3, then 1: every call must start from cleared maps (regression: the raw
+    maps follow max_batch index maps, a single memset sized by the current batch missed them).
+    dev: torch device for the product library; None = the emulator, whose 'device' pointers are host pointers."""
+    import ctypes as C
+    K = synth.KITTI_K.copy()
+    K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    K[0, 0] = K[1, 1] = 718.856 * w / synth.KITTI_W
+    proj = F.projection_matrix(K, synth.KITTI_TR, lib)
+    scans = [synth.lidar_scan(30 + i, n_rings=32, n_az=400) for i in range(4)]
+    n = scans[0].shape[1]
+    cap = 64
+    rng = np.random.default_rng(2)
+    dm = F.DepthModule(proj, w, h, max_points=n, max_keypoints=cap, max_batch=4, lib=lib)
+    P = O.make_depth_params(proj)
+    if dev is not None:
+        import torch
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        down = lambda t: t.cpu().numpy()
+    else:
+        up = lambda a: np.ascontiguousarray(a).copy()
+        ptr = lambda a: C.c_void_p(a.ctypes.data)
+        down = lambda a: a
+    for batch, first in ((2, 0), (3, 1), (1, 3), (4, 0)):
+        cloud = np.stack([scans[(first + b) % 4] for b in range(batch)])
+        kps = np.zeros((batch, cap), O.KP_DTYPE)
+        kps["x"] = rng.uniform(0, w - 1, (batch, cap)).astype(np.float32)
+        kps["y"] = rng.uniform(0, h - 1, (batch, cap)).astype(np.float32)
+        cnt = np.full(batch, cap, np.int32)
+        d_cloud, d_kp, d_n = up(cloud), up(kps.view(np.float32).reshape(batch, cap, 7)), up(cnt)
+        d_depth, d_ur = up(np.zeros((batch, cap), np.float32)), up(np.zeros((batch, cap), np.float32))
+        d_proc = up(np.zeros((batch, h, w), np.float32))
+        L.check(lib, lib.rgbl_depth_batch_device(dm.h, ptr(d_cloud), batch, n, n, 4 * n, w, h, ptr(d_kp), ptr(d_n), cap, None,
+                                                 ptr(d_depth), ptr(d_ur), ptr(d_proc)))
+        L.check(lib, lib.rgbl_depth_sync(dm.h))
+        for b in range(batch):
+            od, our, oraw, oproc = O.depth(P, cloud[b], w, h, np.stack([kps["x"][b], kps["y"][b]], 1), kps["x"][b])
+            assert np.array_equal(bits(down(d_proc)[b]), bits(oproc)), "processed map, batch %d frame %d" % (batch, b)
+            assert np.array_equal(bits(down(d_depth)[b]), bits(od)) and np.array_equal(bits(down(d_ur)[b]), bits(our))
+    dm.close()
+
+
+def check_extractor_partial_batches(lib, w=400, h=300, nfeatures=500):
+    """One handle sized for 4 frames, called with 2, 3, 1 and 4 frames: every frame must equal the oracle."""
+    ex = F.ORBextractor(nfeatures, 1.2, 8, 12, 7, w, h, max_batch=4, lib=lib)
+    orc = O.Extractor(nfeatures, 1.2, 8, 12, 7)
+    s = synth.Sequence(17, w, h, n_frames=6)
+    for batch, first in ((2, 0), (3, 2), (1, 5), (4, 1)):
+        imgs = np.stack([s.frame((first + b) % 6) for b in range(batch)])
+        for b, (kps, desc, mono) in enumerate(ex.extract_batch(imgs)):
+            okps, odesc, omono = orc(imgs[b])
+            assert_keypoints_equal(kps, okps, "partial batch %d frame %d" % (batch, b))
+            assert np.array_equal(desc, odesc) and mono == omono
+    ex.close()

@@ -116,3 +116,11 @@ def test_search_local_points(emu_lib, seed, th, ratio):
 def test_bow_transform(emu_lib, tmp_path):
     assert pc.check_bow_transform(emu_lib, tmp_path, 10, 3, 2, seed=1, n_feat=600) > 100
     assert pc.check_bow_transform(emu_lib, tmp_path, 6, 4, 4, seed=2, n_feat=400) > 100    # levelsup >= L: every feature under the root
+
+
+def test_depth_partial_batches(emu_lib):
+    pc.check_depth_partial_batches(emu_lib)
+
+
+def test_extractor_partial_batches(emu_lib):
+    pc.check_extractor_partial_batches(emu_lib, 360, 280, 400)

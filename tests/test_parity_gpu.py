@@ -135,3 +135,12 @@ def test_search_local_points(gpu_lib, seed, th, ratio):
 def test_bow_transform(gpu_lib, tmp_path):
     assert pc.check_bow_transform(gpu_lib, tmp_path, 10, 4, 2, seed=0) > 500
     assert pc.check_bow_transform(gpu_lib, tmp_path, 10, 5, 4, seed=3, n_feat=8000) > 2000   # 111 k nodes
+
+
+def test_depth_partial_batches(gpu_lib):
+    import torch
+    pc.check_depth_partial_batches(gpu_lib, torch.device("cuda", 0), w=620, h=188)
+
+
+def test_extractor_partial_batches(gpu_lib):
+    pc.check_extractor_partial_batches(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000)
