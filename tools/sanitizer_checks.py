@@ -1,0 +1,31 @@
+"""The emulator parity checks against a sanitizer build of the kernel sources (see tools/sanitize_emu.sh)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from orb_slam3_rgbl_amd import _lib as L, frontend as F
+import parity_checks as pc
+lib = L.bind(os.environ["RGBL_SANITIZED_LIB"])
+which = sys.argv[1]
+if which == "extract":
+    pc.check_extractor(lib, 400, 300, 600, frames=(0,), stages=True)
+    pc.check_extractor_partial_batches(lib, 360, 280, 400)
+elif which == "depth":
+    for m in (F.UPS_INVERSE_DILATION, F.UPS_AVERAGE_FILTERING, F.UPS_NEAREST_NEIGHBOR_PIXEL):
+        pc.check_depth(lib, m, w=620, h=188, n_az=900, n_kp=400)
+    pc.check_depth_edge_cases(lib)
+    pc.check_depth_partial_batches(lib)
+    pc.check_ingest_kitti_bin(lib)
+elif which == "match":
+    pc.check_matcher_bf(lib, 300, 280)
+    pc.check_triangulation(lib, 600, seed=11)
+    pc.check_search_by_projection(lib, 21, "forward", 7.0, False, True, n1=700, n2=800)
+    pc.check_search_by_projection_edge_cases(lib)
+    pc.check_search_local_points(lib, 41, 1.0, 0.8, n1=1200, n2=900)
+    import tempfile
+    pc.check_bow_transform(lib, tempfile.mkdtemp(), 10, 3, 2, seed=1, n_feat=600)
+elif which == "misc":
+    pc.check_stereo_matches(lib, w=640, h=300, nfeatures=1200)
+    pc.check_ingest_color(lib, 402, 300)
+    pc.check_extractor_edge_cases(lib)
+print("asan run", which, "done")
