@@ -694,3 +694,21 @@ def check_extractor_partial_batches(lib, w=400, h=300, nfeatures=500):
             assert_keypoints_equal(kps, okps, "partial batch %d frame %d" % (batch, b))
             assert np.array_equal(desc, odesc) and mono == omono
     ex.close()
+
+
+def check_extractor_under_load(lib, w=synth.KITTI_W, h=synth.KITTI_H, nfeatures=2000, batch=256, distinct=8, rounds=3):
+    """The bench-sized batch (all workgroups of every kernel in flight, both extractor streams busy): every one of the
+    `batch` frames - `distinct` different images repeated - must come out identical to the oracle, call after call."""
+    ex = F.ORBextractor(nfeatures, 1.2, 8, 12, 7, w, h, max_batch=batch, lib=lib)
+    orc = O.Extractor(nfeatures, 1.2, 8, 12, 7)
+    s = synth.Sequence(23, w, h, n_frames=distinct)
+    base = [s.frame(i) for i in range(distinct)]
+    want = [orc(img) for img in base]
+    imgs = np.stack([base[i % distinct] for i in range(batch)])
+    for r in range(rounds):
+        res = ex.extract_batch(imgs)
+        for i, (kps, desc, mono) in enumerate(res):
+            okps, odesc, omono = want[i % distinct]
+            assert_keypoints_equal(kps, okps, "round %d frame %d" % (r, i))
+            assert np.array_equal(desc, odesc) and mono == omono
+    ex.close()
