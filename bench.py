@@ -343,7 +343,8 @@ def main():
         P = O.make_depth_params(proj)
         h_n = d_n.cpu().numpy()
         ok = True
-        for fi in (0, B - 1):
+        spot_frames = sorted({0, B // 3, 2 * B // 3, B - 1})
+        for fi in spot_frames:
             n = int(h_n[fi])
             kps = d_kp[fi, :n].cpu().numpy().view(np.uint32)
             okps, odesc, _ = orc(frames[fi])
@@ -357,8 +358,8 @@ def main():
             obi, obd, osd = O.hamming_bf(odesc, ndesc)
             ok &= np.array_equal(d_bi[fi, :n].cpu().numpy(), obi) and np.array_equal(d_bd[fi, :n].cpu().numpy(), obd)
             ok &= np.array_equal(d_sd[fi, :n].cpu().numpy(), osd)
-        spot = "bit-exact vs CPU oracle on frames 0 and %d (keypoints, descriptors, depth, uRight, matches)" % (B - 1) if ok \
-            else "MISMATCH vs CPU oracle"
+        spot = "bit-exact vs CPU oracle on frames %s (keypoints, descriptors, depth, uRight, matches)" % \
+            ", ".join(str(v) for v in spot_frames) if ok else "MISMATCH vs CPU oracle"
 
     # ---- rank 0 at N == 1: roofline of the dominant kernel (HIP events on the launch stream) + CPU baseline
     roofline = None
