@@ -311,6 +311,15 @@ typedef struct {
 int rgbl_search_triangulation(rgbl_matcher* h, const rgbl_keyframe_view* kf1,
                               const rgbl_keyframe_view* kf2, const rgbl_triangulation_params* prm,
                               int32_t* matches12, int* out_nmatches);
+/* int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) (include/ORBmatcher.h:57,
+ * src/ORBmatcher.cc:223-425; callers Tracking::TrackReferenceKeyFrame, src/Tracking.cc:2798-2810, and Relocalization).
+ * Single-camera frames.  kf: the key-frame (has_mappoint = GetMapPointMatches()[i] != NULL && !isBad(), kp_angle =
+ * mvKeysUn[i].angle, FeatureVector as CSR); frame: F.mDescriptors, kp_angle = F.mvKeys[i].angle, F.mFeatVec (the other
+ * fields of the view are not read).  match_f (frame->n entries): index of the key-frame feature whose map point ends up
+ * in vpMapPointMatches[i], or -1.  Host pointers, synchronous. */
+int rgbl_search_by_bow(rgbl_matcher* h, const rgbl_keyframe_view* kf, const rgbl_keyframe_view* frame, float nnratio,
+                       int check_orientation, int32_t* match_f, int* out_nmatches);
+
 /* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono)
  * (include/ORBmatcher.h:48, src/ORBmatcher.cc:1676-1887; callers Tracking::TrackWithMotionModel, src/Tracking.cc:2917-2934):
  * the matcher that runs on every tracked frame.  Single-camera frames (Nleft == -1: RGB-L, RGB-D, stereo, mono pinhole).

@@ -398,3 +398,51 @@ extern "C" void orc_bow_descend(const orc_vocabulary* v, const uint8_t* desc, in
     node[i] = nid;
   }
 }
+
+// ---- ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&), /root/reference/src/ORBmatcher.cc:223-425 (Nleft == -1) ----
+extern "C" int orc_search_by_bow(const orc_tri_input* in, float nnratio, int check_orientation, int* match2) {
+  for (int i = 0; i < in->n2; ++i) match2[i] = -1;
+  std::vector<int> rot_hist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  int nmatches = 0;
+  int a = 0, b = 0;
+  while (a < in->nnodes1 && b < in->nnodes2) {
+    if (in->node_id1[a] < in->node_id2[b]) { ++a; continue; }  // lower_bound on a sorted map
+    if (in->node_id1[a] > in->node_id2[b]) { ++b; continue; }
+    for (int p = in->node_off1[a]; p < in->node_off1[a + 1]; ++p) {
+      const int realIdxKF = in->node_feat1[p];
+      if (!in->has_mp1[realIdxKF]) continue;  // no map point, or a bad one
+      const uint8_t* dKF = in->desc1 + 32 * (size_t)realIdxKF;
+      int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+      for (int q = in->node_off2[b]; q < in->node_off2[b + 1]; ++q) {
+        const int realIdxF = in->node_feat2[q];
+        if (match2[realIdxF] >= 0) continue;
+        const int dist = hamming256(dKF, in->desc2 + 32 * (size_t)realIdxF);
+        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+        else if (dist < bestDist2) bestDist2 = dist;
+      }
+      if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+        match2[bestIdxF] = realIdxKF;
+        if (check_orientation) {
+          float rot = in->kp1_angle[realIdxKF] - in->kp2_angle[bestIdxF];
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)roundf(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rot_hist[bin].push_back(bestIdxF);
+        }
+        ++nmatches;
+      }
+    }
+    ++a;
+    ++b;
+  }
+  if (check_orientation) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    three_maxima(rot_hist, HISTO_LENGTH, i1, i2, i3);
+    for (int i = 0; i < HISTO_LENGTH; ++i) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int idx : rot_hist[i]) { match2[idx] = -1; --nmatches; }
+    }
+  }
+  return nmatches;
+}

@@ -155,6 +155,12 @@ typedef struct {
  * returns nmatches. */
 int orc_search_triangulation(const orc_tri_input*, int* matches12);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
+ * (/root/reference/src/ORBmatcher.cc:223-425, single camera; Tracking::TrackReferenceKeyFrame, Tracking.cc:2798-2810).
+ * Both sides in the orc_tri_input layout (kf = *1, frame = *2; has_mp1 = "map point present and not bad"; angle2 = F.mvKeys[].angle).
+ * match2[i2] = index of the key-frame feature whose map point ends up in vpMapPointMatches[i2], or -1.  Returns nmatches. */
+int orc_search_by_bow(const orc_tri_input* in, float nnratio, int check_orientation, int* match2);
+
 /* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
  * (/root/reference/src/ORBmatcher.cc:1676-1887, single-camera case Nleft == -1) with
  * Frame::GetFeaturesInArea / AssignFeaturesToGrid / PosInGrid (src/Frame.cc:747-825, 475-506).  Flat arrays: */

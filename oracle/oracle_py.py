@@ -200,6 +200,8 @@ def lib():
         L.orc_kitti_bin_to_cloud.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_bow_descend.restype = None
         L.orc_bow_descend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_search_by_bow.restype = C.c_int
+        L.orc_search_by_bow.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p]
         L.orc_search_local_points.restype = C.c_int
         L.orc_search_local_points.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_search_by_projection.restype = C.c_int
@@ -468,6 +470,33 @@ def fundamental(K1, K2, R12, t12):
     F = np.zeros(9, np.float32)
     lib().orc_fundamental(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(F))
     return F
+
+
+def search_by_bow(kf, frame, nnratio=0.7, check_orientation=True):
+    """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches).  kf / frame: dicts as for search_triangulation (kf["has_mp"] = map
+    point present and not bad).  Returns (match per frame feature: key-frame feature index or -1, nmatches)."""
+    keep = []
+
+    def arr(v, dt):
+        a = np.ascontiguousarray(v, dt)
+        keep.append(a)
+        return a.ctypes.data
+    T = TriInput()
+    T.n1, T.n2 = len(kf["desc"]), len(frame["desc"])
+    for i, d in ((1, kf), (2, frame)):
+        setattr(T, "desc%d" % i, arr(d["desc"], np.uint8))
+        setattr(T, "kp%d_xy" % i, arr(d["xy"], np.float32))
+        setattr(T, "kp%d_octave" % i, arr(d["octave"], np.int32))
+        setattr(T, "kp%d_angle" % i, arr(d["angle"], np.float32))
+        setattr(T, "uright%d" % i, arr(d["uright"], np.float32))
+        setattr(T, "has_mp%d" % i, arr(d["has_mp"], np.uint8))
+        setattr(T, "nnodes%d" % i, len(d["node_id"]))
+        setattr(T, "node_id%d" % i, arr(d["node_id"], np.int32))
+        setattr(T, "node_off%d" % i, arr(d["node_off"], np.int32))
+        setattr(T, "node_feat%d" % i, arr(d["node_feat"], np.int32))
+    m = np.zeros(T.n2, np.int32)
+    n = lib().orc_search_by_bow(C.byref(T), C.c_float(nnratio), int(check_orientation), _p(m))
+    return m, n
 
 
 def search_triangulation(kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, only_stereo=False,

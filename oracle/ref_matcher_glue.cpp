@@ -271,3 +271,38 @@ extern "C" int ref_search_local_points(const orc_local_points_input* in, int* ma
   }
   return nm;
 }
+
+// ORBmatcher(nnratio, checkOri).SearchByBoW(pKF, F, vpMapPointMatches) (ORBmatcher.cc:223-425), single camera.
+extern "C" int ref_search_by_bow(const KfArrays* kfa, const KfArrays* fra, float nnratio, int check_orientation, int* match2) {
+  GeometricCamera cam;
+  std::vector<MapPoint> pts(kfa->n);
+  KeyFrame kf;
+  kf.N = kfa->n;
+  kf.mpCamera = &cam;
+  kf.mDescriptors = cv::Mat(kfa->n, 32, CV_8U);
+  if (kfa->n) memcpy(kf.mDescriptors.data, kfa->desc, (size_t)kfa->n * 32);
+  kf.mvKeysUn.resize(kfa->n);
+  kf.mvpMapPoints.assign(kfa->n, nullptr);
+  for (int i = 0; i < kfa->n; ++i) {
+    kf.mvKeysUn[i].angle = kfa->kp_angle[i];
+    if (kfa->has_mp[i] == 1) kf.mvpMapPoints[i] = &pts[i];
+    else if (kfa->has_mp[i] == 2) { pts[i].bad = true; kf.mvpMapPoints[i] = &pts[i]; }  // present but bad: skipped as well
+  }
+  for (int k = 0; k < kfa->nnodes; ++k)
+    kf.mFeatVec[(unsigned)kfa->node_id[k]] = std::vector<unsigned>(kfa->node_feat + kfa->node_off[k], kfa->node_feat + kfa->node_off[k + 1]);
+  Frame F;
+  F.N = fra->n;
+  F.mpCamera = &cam;
+  F.mvKeys.resize(fra->n);
+  for (int i = 0; i < fra->n; ++i) F.mvKeys[i].angle = fra->kp_angle[i];
+  F.mvKeysUn = F.mvKeys;
+  F.mDescriptors = cv::Mat(fra->n, 32, CV_8U);
+  if (fra->n) memcpy(F.mDescriptors.data, fra->desc, (size_t)fra->n * 32);
+  for (int k = 0; k < fra->nnodes; ++k)
+    F.mFeatVec[(unsigned)fra->node_id[k]] = std::vector<unsigned>(fra->node_feat + fra->node_off[k], fra->node_feat + fra->node_off[k + 1]);
+  ORBmatcher matcher(nnratio, check_orientation != 0);
+  std::vector<MapPoint*> vpMapPointMatches;
+  const int nm = matcher.SearchByBoW(&kf, F, vpMapPointMatches);
+  for (int i = 0; i < fra->n; ++i) match2[i] = vpMapPointMatches[i] ? (int)(vpMapPointMatches[i] - pts.data()) : -1;
+  return nm;
+}

@@ -130,6 +130,7 @@ SYMBOLS = {
     "rgbl_hamming_bf_batch_device": (_I, [_V, _V, _V, _I, _V, _V, _I, _V, _V, _V]),
     "rgbl_search_triangulation": (_I, [_V, C.POINTER(KeyframeView), C.POINTER(KeyframeView),
                                        C.POINTER(TriangulationParams), _V, C.POINTER(_I)]),
+    "rgbl_search_by_bow": (_I, [_V, _V, _V, _F, _I, _V, C.POINTER(_I)]),
     "rgbl_search_by_projection": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_search_local_points": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_vocabulary_load_text": (_I, [C.c_char_p, _I, C.POINTER(_V)]),

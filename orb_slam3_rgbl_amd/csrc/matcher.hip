@@ -562,6 +562,65 @@ __global__ __launch_bounds__(256) void k_bow_descend(VocDev V, const uint8_t* __
   node[o] = nid;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (ORBmatcher.cc:223-425, single
+// camera), the matcher of Tracking::TrackReferenceKeyFrame.  The vocabulary nodes shared by both FeatureVectors are
+// independent problems (a feature lives in exactly one node), inside a node the key-frame features are visited in
+// bucket order and a frame feature that got a match is skipped by all later ones.  One wave per shared node: the
+// key-frame features one after the other, the frame bucket spread over the lanes; best / second-best with the
+// reference's order rules = minimum of (distance << 16 | bucket position) and the second order statistic.
+struct BowDev {
+  const uint8_t* desc1; const uint8_t* desc2;
+  const uint8_t* valid1;
+  const int32_t *off1, *feat1, *off2, *feat2, *pair_n1, *pair_n2;
+  float nnratio;
+  int32_t* match1;  // per key-frame feature: the frame feature it took, or -1
+  int32_t* match2;  // per frame feature: the key-frame feature, or -1
+};
+constexpr int kBowBucket = 16384;  // frame features of one node tracked in LDS (one byte each)
+
+// grid = shared nodes, block = 64
+__global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
+  __shared__ uint8_t s_taken[kBowBucket];
+  const int np = blockIdx.x, lane = threadIdx.x;
+  const int a = T.pair_n1[np], b = T.pair_n2[np];
+  const int b1 = T.off1[a], e1 = T.off1[a + 1], b2 = T.off2[b], n2 = T.off2[b + 1] - b2;
+  for (int j = lane; j < n2; j += 64) s_taken[j] = 0;
+  wave_sync();
+  for (int p = b1; p < e1; ++p) {
+    const int idx1 = T.feat1[p];
+    if (!T.valid1[idx1]) continue;  // wave-uniform
+    const unsigned long long* D1 = reinterpret_cast<const unsigned long long*>(T.desc1 + (size_t)idx1 * 32);
+    const unsigned long long q[4] = {D1[0], D1[1], D1[2], D1[3]};
+    uint32_t best = 0xffffffffu;  // dist << 16 | bucket position
+    int second = 256;
+    for (int j = lane; j < n2; j += 64) {
+      if (s_taken[j]) continue;
+      const int idx2 = T.feat2[b2 + j];
+      const int dist = hamming256(q, reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)idx2 * 32));
+      const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)j;
+      if (key < best) { if (best != 0xffffffffu) second = (int)(best >> 16); best = key; }
+      else if (dist < second) second = dist;
+    }
+    // wave-wide: the smallest key, and the smallest distance among everything else
+    uint32_t wbest = best;
+    for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)wbest, m); wbest = o < wbest ? o : wbest; }
+    int other = best == wbest ? second : (best == 0xffffffffu ? 256 : (int)(best >> 16));
+    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(other, m); other = o < other ? o : other; }
+    if (wbest == 0xffffffffu) continue;
+    const int best_dist = (int)(wbest >> 16), pos = (int)(wbest & 0xffffu);
+    if (best_dist <= 50 /* TH_LOW */ && (float)best_dist < T.nnratio * (float)other) {
+      if (lane == 0) {
+        const int idx2 = T.feat2[b2 + pos];
+        s_taken[pos] = 1;
+        T.match1[idx1] = idx2;
+        T.match2[idx2] = idx1;
+      }
+      wave_sync();
+    }
+  }
+}
+
 }  // namespace rgbl
 
 using namespace rgbl;
@@ -1254,6 +1313,87 @@ int rgbl_bow_transform(rgbl_vocabulary* v, const uint8_t* desc, int n, int level
   for (int i = 0; i < nw; ++i) norm += fabs(word_val[i]);
   if (norm > 0.0)
     for (int i = 0; i < nw; ++i) word_val[i] /= norm;
+  return RGBL_OK;
+}
+
+int rgbl_search_by_bow(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_keyframe_view* fr, float nnratio,
+                       int check_orientation, int32_t* match_f, int* out_nmatches) {
+  if (!m || !kf || !fr || !match_f || !out_nmatches || kf->n < 0 || fr->n < 0) { set_error("invalid argument"); return RGBL_ERR_INVALID; }
+  *out_nmatches = 0;
+  const int n1 = kf->n, n2 = fr->n;
+  for (int i = 0; i < n2; ++i) match_f[i] = -1;
+  // merge walk of the two sorted FeatureVectors (ORBmatcher.cc:243-246, 388-401)
+  std::vector<int32_t> pa, pb;
+  for (int a = 0, b = 0; a < kf->n_nodes && b < fr->n_nodes;) {
+    if (kf->node_id[a] == fr->node_id[b]) { pa.push_back(a++); pb.push_back(b++); }
+    else if (kf->node_id[a] < fr->node_id[b]) ++a;
+    else ++b;
+  }
+  const int npairs = (int)pa.size();
+  std::vector<int32_t> match1(n1, -1);
+  if (npairs > 0 && n1 > 0 && n2 > 0) {
+    for (int p = 0; p < npairs; ++p)
+      if (fr->node_off[pb[p] + 1] - fr->node_off[pb[p]] > kBowBucket) {
+        set_error("SearchByBoW: a vocabulary node holds more than %d frame features", kBowBucket);
+        return RGBL_ERR_CAPACITY;
+      }
+    RGBL_HIP(hipSetDevice(m->device));
+    const int nf1 = kf->node_off[kf->n_nodes], nf2 = fr->node_off[fr->n_nodes];
+    size_t need = pad256((size_t)n1 * 32) + pad256((size_t)n2 * 32) + pad256(n1) + pad256((size_t)(kf->n_nodes + 1) * 4) +
+                  pad256((size_t)nf1 * 4) + pad256((size_t)(fr->n_nodes + 1) * 4) + pad256((size_t)nf2 * 4) +
+                  2 * pad256((size_t)npairs * 4) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 4);
+    RGBL_TRY(ensure_arena(m, need));
+    Arena A{m->d_buf};
+    hipStream_t s = m->stream;
+    BowDev T;
+    RGBL_TRY(upload(A, s, &T.desc1, kf->desc, (size_t)n1 * 32));
+    RGBL_TRY(upload(A, s, &T.desc2, fr->desc, (size_t)n2 * 32));
+    RGBL_TRY(upload(A, s, &T.valid1, kf->has_mappoint, (size_t)n1));
+    RGBL_TRY(upload(A, s, &T.off1, kf->node_off, (size_t)kf->n_nodes + 1));
+    RGBL_TRY(upload(A, s, &T.feat1, kf->node_feat, (size_t)nf1));
+    RGBL_TRY(upload(A, s, &T.off2, fr->node_off, (size_t)fr->n_nodes + 1));
+    RGBL_TRY(upload(A, s, &T.feat2, fr->node_feat, (size_t)nf2));
+    RGBL_TRY(upload(A, s, &T.pair_n1, pa.data(), (size_t)npairs));
+    RGBL_TRY(upload(A, s, &T.pair_n2, pb.data(), (size_t)npairs));
+    T.match1 = A.take<int32_t>(n1);
+    T.match2 = A.take<int32_t>(n2);
+    T.nnratio = nnratio;
+    RGBL_HIP(hipMemsetAsync(T.match1, 0xff, sizeof(int32_t) * n1, s));
+    RGBL_HIP(hipMemsetAsync(T.match2, 0xff, sizeof(int32_t) * n2, s));
+    m->timer.begin("k_search_by_bow", s);
+    hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(64), 0, s, T);
+    m->timer.end(s);
+    RGBL_HIP(hipGetLastError());
+    RGBL_HIP(hipMemcpyAsync(match1.data(), T.match1, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipMemcpyAsync(match_f, T.match2, sizeof(int32_t) * n2, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipStreamSynchronize(s));
+    m->timer.collect();
+  }
+  int nmatches = 0;
+  for (int i = 0; i < n2; ++i) nmatches += match_f[i] >= 0;
+  if (check_orientation) {
+    // rotation histogram in the order the reference fills it: node by node, key-frame bucket order (ORBmatcher.cc:331-343)
+    std::vector<int> hist[30];
+    const float factor = 1.0f / 30;
+    for (int p = 0; p < npairs; ++p)
+      for (int q = kf->node_off[pa[p]]; q < kf->node_off[pa[p] + 1]; ++q) {
+        const int idx1 = kf->node_feat[q];
+        const int idx2 = match1[idx1];
+        if (idx2 < 0) continue;
+        float rot = kf->kp_angle[idx1] - fr->kp_angle[idx2];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == 30) bin = 0;
+        if (bin >= 0 && bin < 30) hist[bin].push_back(idx2);
+      }
+    int i1, i2, i3;
+    three_maxima(hist, 30, i1, i2, i3);
+    for (int i = 0; i < 30; ++i) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int idx2 : hist[i]) { match_f[idx2] = -1; --nmatches; }
+    }
+  }
+  *out_nmatches = nmatches;
   return RGBL_OK;
 }
 

@@ -367,6 +367,33 @@ class ORBmatcher:
         L.check(self.lib, self.lib.rgbl_search_local_points(self.h, C.byref(P), L.ptr(match2), C.byref(n)))
         return match2, n.value
 
+    @staticmethod
+    def _view(kf, keep):
+        v = L.KeyframeView()
+        v.n = len(kf["desc"])
+        for field, key, dt in (("desc", "desc", np.uint8), ("kp_xy", "xy", np.float32),
+                               ("kp_octave", "octave", np.int32), ("kp_angle", "angle", np.float32),
+                               ("uright", "uright", np.float32), ("has_mappoint", "has_mp", np.uint8),
+                               ("node_id", "node_id", np.int32), ("node_off", "node_off", np.int32),
+                               ("node_feat", "node_feat", np.int32)):
+            a = np.ascontiguousarray(kf[key], dt)
+            keep.append(a)
+            setattr(v, field, a.ctypes.data)
+        v.n_nodes = len(kf["node_id"])
+        return v
+
+    def SearchByBoW(self, kf, frame):
+        """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (ORBmatcher.cc:223-425).  kf / frame: dicts as for
+        SearchForTriangulation; kf["has_mp"] = map point present and not bad.  Returns (per frame feature the key-frame
+        feature whose map point it gets, or -1; nmatches)."""
+        keep = []
+        v1, v2 = self._view(kf, keep), self._view(frame, keep)
+        m = np.full(v2.n, -1, np.int32)
+        nm = C.c_int(0)
+        L.check(self.lib, self.lib.rgbl_search_by_bow(self.h, C.byref(v1), C.byref(v2), float(self.mfNNratio),
+                                                      int(self.mbCheckOrientation), L.ptr(m), C.byref(nm)))
+        return m, nm.value
+
     def SearchForTriangulation(self, kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, bOnlyStereo=False,
                                bCoarse=False):
         """kf = dict(desc, xy, octave, angle, uright, has_mp, node_id, node_off, node_feat).

@@ -3,6 +3,7 @@
 //   SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse)   (ORBmatcher.h:75-76, :907-1146)
 //   SearchByProjection(CurrentFrame, LastFrame, th, bMono)           (ORBmatcher.h:48,  ORBmatcher.cc:1676-1887)
 //   SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints)  (ORBmatcher.h:45,  ORBmatcher.cc:43-213)
+//   SearchByBoW(pKF, F, vpMapPointMatches)                           (ORBmatcher.h:57,  ORBmatcher.cc:223-425)
 // The other Search*/Fuse members of the reference class are untouched (SURVEY.md §8(f) lists them as "next");
 // in the ORB_SLAM3 tree this header is merged into the existing one, see INTEGRATION.md.
 //
@@ -94,6 +95,43 @@ class ORBmatcher {
       if (vMatches12[i] < 0) continue;
       vMatchedPairs.push_back(std::make_pair(i, (size_t)vMatches12[i]));
     }
+    return nmatches;
+  }
+
+  // Search matches between MapPoints in a KeyFrame and ORB in a Frame.  Brute force constrained to ORB that belong to the same
+  // vocabulary node (at a certain level).  Used in Relocalisation and Loop Detection (and Tracking::TrackReferenceKeyFrame,
+  // Tracking.cc:2798-2810).  ORBmatcher.h:57, ORBmatcher.cc:223-425.
+  template <class KeyFrameT, class FrameT, class MapPointT>
+  int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches) {
+    const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPointT*>(F.N, static_cast<MapPointT*>(NULL));
+    if (!mpHandle) return 0;
+    if (F.Nleft != -1 || pKF->mpCamera2) {
+      std::cerr << "[ORBmatcher] SearchByBoW: fisheye stereo rigs are not covered by the device path" << std::endl;
+      return 0;
+    }
+    Flat fk, ff;
+    const int n1 = pKF->N, n2 = F.N;
+    fk.xy.assign(2 * (size_t)n1, 0.f); fk.angle.resize(n1); fk.octave.assign(n1, 0); fk.has_mp.resize(n1);
+    for (int i = 0; i < n1; ++i) {
+      fk.angle[i] = pKF->mvKeysUn[i].angle;
+      fk.has_mp[i] = (vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad()) ? 1 : 0;
+    }
+    ff.xy.assign(2 * (size_t)n2, 0.f); ff.angle.resize(n2); ff.octave.assign(n2, 0); ff.has_mp.assign(n2, 0);
+    for (int i = 0; i < n2; ++i) ff.angle[i] = F.mvKeys[i].angle;
+    FlattenFeatVec(pKF->mFeatVec, fk);
+    FlattenFeatVec(F.mFeatVec, ff);
+    std::vector<float> ur1(n1, -1.f), ur2(n2, -1.f);
+    FillView(fk, n1, pKF->mDescriptors.template ptr<uint8_t>(), ur1.data());
+    FillView(ff, n2, F.mDescriptors.template ptr<uint8_t>(), ur2.data());
+    std::vector<int32_t> match(n2, -1);
+    int nmatches = 0;
+    if (rgbl_search_by_bow(mpHandle, &fk.view, &ff.view, mfNNratio, mbCheckOrientation, match.data(), &nmatches) != RGBL_OK) {
+      std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
+      return 0;
+    }
+    for (int i = 0; i < n2; ++i)
+      if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];
     return nmatches;
   }
 
@@ -253,6 +291,30 @@ class ORBmatcher {
     f.view.kp_octave = f.octave.data();
     f.view.kp_angle = f.angle.data();
     f.view.uright = kf->mvuRight.data();
+    f.view.has_mappoint = f.has_mp.data();
+    f.view.n_nodes = (int)f.node_id.size();
+    f.view.node_id = f.node_id.data();
+    f.view.node_off = f.node_off.data();
+    f.view.node_feat = f.node_feat.data();
+  }
+
+  template <class FeatVecT>
+  static void FlattenFeatVec(const FeatVecT& fv, Flat& f) {
+    f.node_id.clear(); f.node_feat.clear();
+    f.node_off.assign(1, 0);
+    for (auto it = fv.begin(); it != fv.end(); ++it) {  // std::map: node ids ascend
+      f.node_id.push_back((int32_t)it->first);
+      for (size_t k = 0; k < it->second.size(); ++k) f.node_feat.push_back((int32_t)it->second[k]);
+      f.node_off.push_back((int32_t)f.node_feat.size());
+    }
+  }
+  static void FillView(Flat& f, int n, const uint8_t* desc, const float* uright) {
+    f.view.n = n;
+    f.view.desc = desc;
+    f.view.kp_xy = f.xy.data();
+    f.view.kp_octave = f.octave.data();
+    f.view.kp_angle = f.angle.data();
+    f.view.uright = uright;
     f.view.has_mappoint = f.has_mp.data();
     f.view.n_nodes = (int)f.node_id.size();
     f.view.node_id = f.node_id.data();

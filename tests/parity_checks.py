@@ -712,3 +712,15 @@ def check_extractor_under_load(lib, w=synth.KITTI_W, h=synth.KITTI_H, nfeatures=
             assert_keypoints_equal(kps, okps, "round %d frame %d" % (r, i))
             assert np.array_equal(desc, odesc) and mono == omono
     ex.close()
+
+
+def check_search_by_bow(lib, seed=51, nnratio=0.7, check_ori=True, n=1500, nodes=100):
+    kf, fr, *_ = make_triangulation_case(n, seed=seed, n_nodes=nodes)
+    rng = np.random.default_rng(seed)
+    kf = dict(kf, has_mp=(rng.random(n) < 0.7).astype(np.uint8))
+    mt = F.ORBmatcher(nnratio, check_ori, lib=lib)
+    m, nm = mt.SearchByBoW(kf, fr)
+    om, onm = O.search_by_bow(kf, fr, nnratio, check_ori)
+    assert nm == onm and np.array_equal(m, om), "SearchByBoW (seed %d)" % seed
+    mt.close()
+    return nm

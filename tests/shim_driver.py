@@ -111,6 +111,8 @@ def run_and_check(exe, tmp):
     nm, npairs = take(np.int32, 2)
     pairs = take(np.int32, 2 * npairs).reshape(npairs, 2)
     dd = take(np.int32, 1)[0]
+    nbow, n2b = take(np.int32, 2)
+    bow_match = take(np.int32, n2b)
     nproj, n2p = take(np.int32, 2)
     proj_match = take(np.int32, n2p)
     nloc, n2l = take(np.int32, 2)
@@ -164,3 +166,5 @@ def run_and_check(exe, tmp):
     assert nm == onm == npairs and np.array_equal(pairs[:, 0], idx1) and np.array_equal(pairs[:, 1], om12[idx1])
     assert nm > 20
     assert dd == O.descriptor_distance(kf1["desc"][0], kf2["desc"][0])
+    obm, obn = O.search_by_bow(kf1, kf2, 0.7, True)
+    assert nbow == obn and np.array_equal(bow_match, obm) and nbow > 50

@@ -41,9 +41,11 @@ struct Camera {
   float getParameter(int i) const { return p[i]; }
   V2 project(const V3& c) const { V2 r; r.v[0] = p[0] * c.v[0] / c.v[2] + p[2]; r.v[1] = p[1] * c.v[1] / c.v[2] + p[3]; return r; }
 };
-struct MapPoint {};
+struct MapPoint { bool isBad() { return false; } };
 struct KeyFrame {
-  int N = 0, NLeft = -1;
+  int N = 0, NLeft = -1, Nleft = -1;  // Nleft / mvKeys: the members SearchByBoW reads when a KeyFrame stands in for a Frame
+  std::vector<cv::KeyPoint> mvKeys;
+  std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
   Camera* mpCamera = nullptr; Camera* mpCamera2 = nullptr;
   std::map<unsigned, std::vector<unsigned> > mFeatVec;
   std::vector<cv::KeyPoint> mvKeysUn;
@@ -210,6 +212,18 @@ int main(int argc, char** argv) {
   for (auto& pr : pairs) { int a = (int)pr.first, b = (int)pr.second; wr(out, &a, 1); wr(out, &b, 1); }
   const int dd = ORB_SLAM3::ORBmatcher::DescriptorDistance(kf1.mDescriptors.row(0), kf2.mDescriptors.row(0));
   wr(out, &dd, 1);
+  {
+    // --- as Tracking::TrackReferenceKeyFrame (Tracking.cc:2798-2810): matcher(0.7, true).SearchByBoW(mpReferenceKF, mCurrentFrame, vpMapPointMatches)
+    kf2.mvKeys = kf2.mvKeysUn;
+    ORB_SLAM3::ORBmatcher bow(0.7, true);
+    std::vector<MapPoint*> vpMapPointMatches;
+    std::vector<MapPoint> own(kf1.N);
+    for (int i = 0; i < kf1.N; ++i) if (kf1.mvpMapPoints[i]) kf1.mvpMapPoints[i] = &own[i];  // distinct points: indices can be read back
+    const int nbow = bow.SearchByBoW(&kf1, kf2, vpMapPointMatches);
+    const int n2b = (int)vpMapPointMatches.size();
+    wr(out, &nbow, 1); wr(out, &n2b, 1);
+    for (int i = 0; i < n2b; ++i) { const int idx = vpMapPointMatches[i] ? (int)(vpMapPointMatches[i] - own.data()) : -1; wr(out, &idx, 1); }
+  }
   // --- as Tracking::TrackWithMotionModel (Tracking.cc:2913-2934): SearchByProjection(mCurrentFrame, mLastFrame, th, bMono)
   if (argc > 9) {
     f = fopen(argv[9], "rb");

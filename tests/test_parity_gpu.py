@@ -148,3 +148,8 @@ def test_extractor_partial_batches(gpu_lib):
 
 def test_extractor_under_full_load(gpu_lib):
     pc.check_extractor_under_load(gpu_lib)
+
+
+@pytest.mark.parametrize("seed,ratio,ori,nodes", [(51, 0.7, True, 100), (52, 0.7, False, 100), (53, 0.9, True, 30), (54, 0.6, True, 1)])
+def test_search_by_bow(gpu_lib, seed, ratio, ori, nodes):
+    assert pc.check_search_by_bow(gpu_lib, seed, ratio, ori, n=2000, nodes=nodes) > 100

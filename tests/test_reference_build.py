@@ -388,3 +388,22 @@ def test_reference_dbow2_transform_agrees_with_oracle(refdbow, tmp_path, k, L, l
             assert np.array_equal(g, w), name
     assert len(got[0]) > 200 and abs(got[1].sum() - 1.0) < 1e-9
     refdbow.ref_voc_destroy(h)
+
+
+@pytest.mark.parametrize("seed,nnratio,check_ori,nodes", [(51, 0.7, True, 100), (52, 0.7, False, 100), (53, 0.9, True, 30), (54, 0.6, True, 1)])
+def test_reference_search_by_bow_agrees_with_oracle(refmatcher, seed, nnratio, check_ori, nodes):
+    """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) as Tracking::TrackReferenceKeyFrame calls it (ORBmatcher(0.7, true))."""
+    import parity_checks as pc
+    kf, fr, *_ = pc.make_triangulation_case(1500, seed=seed, n_nodes=nodes)
+    rng = np.random.default_rng(seed)
+    state = rng.choice([0, 1, 2], len(kf["desc"]), p=[0.25, 0.65, 0.1]).astype(np.uint8)   # none / good / bad map point
+    keep = []
+    a1 = kf_arrays(dict(kf, has_mp=state), keep)
+    a2 = kf_arrays(fr, keep)
+    m = np.zeros(a2.n, np.int32)
+    refmatcher.ref_search_by_bow.restype = C.c_int
+    refmatcher.ref_search_by_bow.argtypes = [C.POINTER(KfArrays), C.POINTER(KfArrays), C.c_float, C.c_int, C.c_void_p]
+    nm = refmatcher.ref_search_by_bow(C.byref(a1), C.byref(a2), C.c_float(nnratio), int(check_ori), m.ctypes.data)
+    om, onm = O.search_by_bow(dict(kf, has_mp=(state == 1).astype(np.uint8)), fr, nnratio, check_ori)
+    assert nm == onm and np.array_equal(m, om)
+    assert nm > 100
