@@ -52,6 +52,14 @@ struct rgbl_extractor {
   hipStream_t aux_stream = nullptr;  // the Gaussian working images only depend on the pyramid: they overlap FAST + quad-tree
   hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_fast0 = nullptr;
   KernelTimer timer;
+  // hipGraph of the host-pointer path (all device pointers of that path are the handle's own buffers, so one captured
+  // launch sequence can be replayed): key = (batch, row stride, lapping area, stream)
+#ifndef RGBL_EMU
+  hipGraphExec_t graph_exec = nullptr;
+#endif
+  int graph_batch = 0, graph_stride = 0, graph_lap0 = 0, graph_lap1 = 0;
+  hipStream_t graph_stream = nullptr;
+  bool graph_ok = true;  // RGBL_GRAPH=0 or a failed capture switch the replay off
   int octree_wg = 0;  // 0 = choose per launch; RGBL_OCTREE_WG=256|512 pins the quad-tree workgroup width (tuning / tests)
   int max_cell = 0;  // largest detection-cell side over the levels: selects the k_fast_cells instantiation
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
@@ -479,6 +487,7 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
   RGBL_HIP(hipSetDevice(device));
   rgbl_extractor* e = new rgbl_extractor;
   e->cfg = *cfg;
+  if (const char* v = getenv("RGBL_GRAPH")) e->graph_ok = atoi(v) != 0;
   if (const char* v = getenv("RGBL_OCTREE_WG")) { const int wg = atoi(v); if (wg == kOctNarrow || wg == kOctWide) e->octree_wg = wg; }
   e->device = device;
   int rc = build_geometry(e);
@@ -507,6 +516,9 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   if (e->d_stereo_sad) (void)hipFree(e->d_stereo_sad);
   if (e->d_stereo_stage) (void)hipFree(e->d_stereo_stage);
   if (e->d_color) (void)hipFree(e->d_color);
+#ifndef RGBL_EMU
+  if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+#endif
   if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
   if (e->ev_pyr) (void)hipEventDestroy(e->ev_pyr);
   if (e->ev_blur) (void)hipEventDestroy(e->ev_blur);
@@ -554,12 +566,51 @@ int rgbl_extractor_sync(rgbl_extractor* e) {
   return check_device_flags(e);
 }
 
+// The host-pointer path launches ~15 short kernels on two streams per call; for a single frame the gaps between dependent
+// launches are a fifth of the latency.  The sequence is captured once into a hipGraph (both streams: the event fork / join
+// inside enqueue_extract becomes graph edges) and replayed on the following calls.
+static int enqueue_extract_staged(rgbl_extractor* e, int batch, int dev_stride, int lap0, int lap1) {
+#ifndef RGBL_EMU
+  hipStream_t s = e->stream;
+  if (e->graph_ok && !e->timer.enabled) {
+    const bool hit = e->graph_exec && e->graph_batch == batch && e->graph_stride == dev_stride && e->graph_lap0 == lap0 &&
+                     e->graph_lap1 == lap1 && e->graph_stream == s;
+    if (!hit) {
+      if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const int rc = enqueue_extract(e, e->d_img, batch, dev_stride, e->img_frame, lap0, lap1, e->d_out_kp, e->d_out_desc, e->out_cap,
+                                       e->d_out_n, e->d_out_mono);
+        const hipError_t end = hipStreamEndCapture(s, &graph);
+        if (rc == RGBL_OK && end == hipSuccess && graph && hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+          e->graph_batch = batch; e->graph_stride = dev_stride; e->graph_lap0 = lap0; e->graph_lap1 = lap1; e->graph_stream = s;
+        } else {
+          e->graph_exec = nullptr;
+          e->graph_ok = false;  // fall back to plain launches for the rest of the handle's life
+          (void)hipGetLastError();
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+      } else {
+        e->graph_ok = false;
+        (void)hipGetLastError();
+      }
+    }
+    if (e->graph_exec) {
+      e->last_img0 = e->d_img; e->last_pitch0 = dev_stride; e->last_frame0 = e->img_frame; e->last_batch = batch;
+      RGBL_HIP(hipGraphLaunch(e->graph_exec, s));
+      return RGBL_OK;
+    }
+  }
+#endif
+  return enqueue_extract(e, e->d_img, batch, dev_stride, e->img_frame, lap0, lap1, e->d_out_kp, e->d_out_desc, e->out_cap, e->d_out_n,
+                         e->d_out_mono);
+}
+
 // the frames already sit in e->d_img (row stride dev_stride): extraction, then the results back to the host
 static int run_staged(rgbl_extractor* e, int batch, int dev_stride, int lap0, int lap1, rgbl_keypoint* out_kp,
                       uint8_t* out_desc, int cap, int* out_n, int* out_mono) {
   hipStream_t s = e->stream;
-  RGBL_TRY(enqueue_extract(e, e->d_img, batch, dev_stride, e->img_frame, lap0, lap1, e->d_out_kp, e->d_out_desc,
-                           e->out_cap, e->d_out_n, e->d_out_mono));
+  RGBL_TRY(enqueue_extract_staged(e, batch, dev_stride, lap0, lap1));
   RGBL_HIP(hipMemcpyAsync(out_n, e->d_out_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
   RGBL_HIP(hipMemcpyAsync(out_mono, e->d_out_mono, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
   RGBL_HIP(hipStreamSynchronize(s));

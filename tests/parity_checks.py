@@ -696,6 +696,23 @@ def check_extractor_partial_batches(lib, w=400, h=300, nfeatures=500):
     ex.close()
 
 
+def check_extractor_replay(lib, w=400, h=300, nfeatures=500):
+    """The host-pointer path replays a captured launch graph when (batch, stride, lapping area) repeat: different images
+    through the same handle, a lapping-area change and a batch change in between, must all equal the oracle."""
+    ex = F.ORBextractor(nfeatures, 1.2, 8, 12, 7, w, h, max_batch=2, lib=lib)
+    orc = O.Extractor(nfeatures, 1.2, 8, 12, 7)
+    s = synth.Sequence(29, w, h, n_frames=8)
+    plan = [((0, 0), 1)] * 3 + [((100, 200), 1)] * 2 + [((0, 0), 2)] * 2 + [((0, 0), 1)] * 2
+    for i, (lap, batch) in enumerate(plan):
+        imgs = np.stack([s.frame((i + b) % 8) for b in range(batch)])
+        res = ex.extract_batch(imgs, lap) if batch > 1 else [ex(imgs[0], None, lap)]
+        for b, (kps, desc, mono) in enumerate(res):
+            okps, odesc, omono = orc(imgs[b], lap)
+            assert_keypoints_equal(kps, okps, "replay call %d frame %d" % (i, b))
+            assert np.array_equal(desc, odesc) and mono == omono
+    ex.close()
+
+
 def check_extractor_under_load(lib, w=synth.KITTI_W, h=synth.KITTI_H, nfeatures=2000, batch=256, distinct=8, rounds=3):
     """The bench-sized batch (all workgroups of every kernel in flight, both extractor streams busy): every one of the
     `batch` frames - `distinct` different images repeated - must come out identical to the oracle, call after call."""

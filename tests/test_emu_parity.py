@@ -126,6 +126,10 @@ def test_extractor_partial_batches(emu_lib):
     pc.check_extractor_partial_batches(emu_lib, 360, 280, 400)
 
 
+def test_extractor_replay(emu_lib):
+    pc.check_extractor_replay(emu_lib, 360, 280, 400)
+
+
 @pytest.mark.parametrize("seed,ratio,ori,nodes", [(51, 0.7, True, 100), (53, 0.9, True, 30), (54, 0.6, False, 1)])
 def test_search_by_bow(emu_lib, seed, ratio, ori, nodes):
     assert pc.check_search_by_bow(emu_lib, seed, ratio, ori, n=700, nodes=nodes) > 30

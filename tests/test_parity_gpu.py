@@ -146,6 +146,10 @@ def test_extractor_partial_batches(gpu_lib):
     pc.check_extractor_partial_batches(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000)
 
 
+def test_extractor_replay(gpu_lib):
+    pc.check_extractor_replay(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000)
+
+
 def test_extractor_under_full_load(gpu_lib):
     pc.check_extractor_under_load(gpu_lib)
 
