@@ -178,15 +178,16 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
                                                     uint32_t* __restrict__ slots, size_t slots_frame, int cell_begin) {
   constexpr int kTileP = CM + 8;   // LDS tile pitch (cell + 6 ring margin, padded)
   constexpr int kScoreP = CM + 4;  // score tile pitch (cell + 1-px zero frame), multiple of 4
-  constexpr int kBitWords = (CM * CM + 31) / 32;
+  constexpr int kBitWords = (CM * CM + 63) / 64 * 2;  // bitmap words, an even number: the compaction reads them in pairs
+  constexpr int kCornerCap = 512;                     // pixels with a score kept as a list for the NMS (all survivors are scanned beyond that)
   static_assert(kBitWords <= 256, "one bitmap word per work-item");
   __shared__ uint32_t s_tile_w[(CM + 6) * kTileP / 4];
   uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile_w);
   __shared__ uint32_t s_score_w[(CM + 2) * kScoreP / 4];
   uint8_t* s_score = reinterpret_cast<uint8_t*>(s_score_w);
   __shared__ uint16_t s_surv[CM * CM];
-  __shared__ uint32_t s_scan[8];
-  __shared__ int s_nsurv, s_any_ini;
+  __shared__ uint16_t s_corner[kCornerCap];
+  __shared__ int s_nsurv, s_ncorner, s_any_ini;
   __shared__ uint32_t s_keep[kBitWords], s_keep_ini[kBitWords];
 
   const int tid = threadIdx.x;
@@ -212,26 +213,31 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
 
   // ---- stage the (sw+6) x (sh+6) pixel tile and clear the score tile
   const int npix = sw * sh;
-  // p / sw == __umulhi(p, magic) for p < 2^16; a one-pixel-wide last cell (sw == 1) would overflow the magic
-  const uint32_t magic = sw > 1 ? 0xFFFFFFFFu / (uint32_t)sw + 1u : 0u;
-#define RGBL_DIV_SW(p) (sw > 1 ? (int)__umulhi((uint32_t)(p), magic) : (int)(p))
+  // p / sw == (p * ceil(2^20 / sw)) >> 20 while p * sw < 2^20 (p < 72 * 72, sw <= 72); the product stays below 2^27.
+  // 24-bit multiplies: v_mul_u32_u24 issues at the full VALU rate, v_mul_hi_u32 / v_mul_lo_u32 at a quarter of it.
+  const uint32_t magic = (0x100000u + (uint32_t)sw - 1u) / (uint32_t)sw;
+#define RGBL_DIV_SW(p) ((int)(__umul24((uint32_t)(p), magic) >> 20))
+#define RGBL_MUL_SW(y) ((int)__umul24((uint32_t)(y), (uint32_t)sw))
+  // pixel p = y * sw + x of the scanned area inside the two LDS tiles
+#define RGBL_TILE_AT(p, y) ((p) + (int)__umul24((uint32_t)(y), (uint32_t)(kTileP - sw)) + 3 * kTileP + 3)
+#define RGBL_SCORE_AT(p, y) ((p) + (int)__umul24((uint32_t)(y), (uint32_t)(kScoreP - sw)) + kScoreP + 1)
   {
     const int nwords = (tw + 3) >> 2;  // reads at most 3 bytes past the tile, still >= 13 px inside the row
-    const uint32_t wmagic = 0xFFFFFFFFu / (uint32_t)nwords + 1u;
+    const uint32_t wmagic = (0x100000u + (uint32_t)nwords - 1u) / (uint32_t)nwords;
     for (int i = tid; i < nwords * th; i += 256) {
-      const int y = (int)__umulhi((uint32_t)i, wmagic), k = i - y * nwords;
+      const int y = (int)(__umul24((uint32_t)i, wmagic) >> 20), k = i - (int)__umul24((uint32_t)y, (uint32_t)nwords);
       s_tile_w[(y * kTileP >> 2) + k] = load_u32_unaligned(img + (size_t)(ini_y + y) * pitch + ini_x + 4 * k);
     }
   }
   for (int i = tid; i < (sh + 2) * (kScoreP / 4); i += 256) s_score_w[i] = 0;
-  if (tid == 0) { s_nsurv = 0; s_any_ini = 0; }
+  if (tid == 0) { s_nsurv = 0; s_ncorner = 0; s_any_ini = 0; }
   if (tid < kBitWords) { s_keep[tid] = 0; s_keep_ini[tid] = 0; }
   __syncthreads();
 
   // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are compacted
   for (int p = tid; p < npix; p += 256) {
-    const int y = RGBL_DIV_SW(p), x = p - y * sw;
-    const uint8_t* c = &s_tile[(y + 3) * kTileP + x + 3];
+    const int y = RGBL_DIV_SW(p);
+    const uint8_t* c = &s_tile[RGBL_TILE_AT(p, y)];
     const int v = c[0], lo = v - min_th, hi = v + min_th;
     bool dark = true, bright = true;
 #pragma unroll
@@ -247,22 +253,28 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   }
   __syncthreads();
 
-  // ---- phase B: exact score of the survivors
+  // ---- phase B: exact score of the survivors; the few that are corners (score >= min threshold) are listed
   const int nsurv = s_nsurv;
   for (int i = tid; i < nsurv; i += 256) {
     const int p = s_surv[i];
-    const int y = RGBL_DIV_SW(p), x = p - y * sw;
-    const int sc = fast_true_score(&s_tile[(y + 3) * kTileP + x + 3], kTileP);
-    if (sc >= min_th) s_score[(y + 1) * kScoreP + x + 1] = (uint8_t)sc;
+    const int y = RGBL_DIV_SW(p);
+    const int sc = fast_true_score(&s_tile[RGBL_TILE_AT(p, y)], kTileP);
+    if (sc >= min_th) {
+      s_score[RGBL_SCORE_AT(p, y)] = (uint8_t)sc;
+      const int pos = atomicAdd(&s_ncorner, 1);
+      if (pos < kCornerCap) s_corner[pos] = (uint16_t)p;
+    }
   }
   __syncthreads();
 
-  // ---- phase C: 3x3 strict NMS inside the cell, only for the pixels that have a score; survivors of the NMS
+  // ---- phase C: 3x3 strict NMS inside the cell over the pixels that have a score; survivors of the NMS
   //      set a bit in a row-major bitmap (one for the min threshold, one for the ini threshold)
-  for (int i = tid; i < nsurv; i += 256) {
-    const int p = s_surv[i];
-    const int y = RGBL_DIV_SW(p), x = p - y * sw;
-    const uint8_t* s = &s_score[(y + 1) * kScoreP + x + 1];
+  const bool listed = s_ncorner <= kCornerCap;
+  const int ncheck = listed ? s_ncorner : nsurv;
+  for (int i = tid; i < ncheck; i += 256) {
+    const int p = listed ? s_corner[i] : s_surv[i];
+    const int y = RGBL_DIV_SW(p);
+    const uint8_t* s = &s_score[RGBL_SCORE_AT(p, y)];
     const int v = s[0];
     if (v != 0 && v > s[-1] && v > s[1] && v > s[-kScoreP - 1] && v > s[-kScoreP] && v > s[-kScoreP + 1] &&
         v > s[kScoreP - 1] && v > s[kScoreP] && v > s[kScoreP + 1]) {
@@ -272,25 +284,44 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   }
   __syncthreads();
   // two-threshold rule of ORBextractor.cc:826-846: the ini-threshold set if it is non-empty, else the min set.
-  // Ordered compaction: bitmap word t belongs to work-item t, bits ascend = cv::FAST's row-major emission order.
-  const int nbw = (npix + 31) >> 5;  // <= 162
-  uint32_t word = 0;
-  if (tid < nbw) word = s_any_ini ? s_keep_ini[tid] : s_keep[tid];
-  uint32_t total;
-  uint32_t base = block_exclusive_scan<uint32_t>((uint32_t)__popc(word), s_scan, &total);
-  if (word) {
-    uint32_t* out = slots + (size_t)f * slots_frame + g.slot_off + (size_t)ci * g.cell_cap;
-    while (word) {
-      const int bit = __ffs((int)word) - 1;
-      word &= word - 1;
-      const int p = tid * 32 + bit;
-      const int y = RGBL_DIV_SW(p), x = p - y * sw;
-      if (base < (uint32_t)g.cell_cap)
-        out[base] = pack_key(ci_col * g.w_cell + 3 + x, ci_row * g.h_cell + 3 + y, s_score[(y + 1) * kScoreP + x + 1]);
-      ++base;
+  // Ordered compaction by the first wave alone (no further barrier; the other waves are done): a lane owns 64 bitmap
+  // bits, ascending bits = cv::FAST's row-major emission order.  The ordered pixel list goes through LDS (the survivor
+  // list's space) so that the keys leave with one coalesced store per 64 keypoints.
+  if (wave_id() != 0) return;
+  {
+    const int lane = lane_id();
+    const uint32_t* keep = s_any_ini ? s_keep_ini : s_keep;
+    const int npairs = (npix + 63) >> 6;  // <= 81
+    uint16_t* s_list = s_surv;
+    uint32_t total = 0;
+    for (int w0 = 0; w0 < npairs; w0 += 64) {
+      const int t = w0 + lane;
+      unsigned long long word = 0;
+      if (t < npairs) word = (unsigned long long)keep[2 * t] | ((unsigned long long)keep[2 * t + 1] << 32);
+      const uint32_t cnt = (uint32_t)__popcll(word);
+      uint32_t incl = cnt;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+      }
+      uint32_t pos = total + incl - cnt;
+      while (word) {
+        const int bit = __ffsll((long long)word) - 1;
+        word &= word - 1;
+        s_list[pos++] = (uint16_t)(t * 64 + bit);
+      }
+      total += __shfl(incl, 63);
     }
+    wave_sync();
+    const uint32_t n_out = total < (uint32_t)g.cell_cap ? total : (uint32_t)g.cell_cap;  // cap is a proven bound
+    uint32_t* out = slots + (size_t)f * slots_frame + g.slot_off + (size_t)ci * g.cell_cap;
+    for (uint32_t i = lane; i < n_out; i += 64) {
+      const int p = s_list[i];
+      const int y = RGBL_DIV_SW(p), x = p - RGBL_MUL_SW(y);
+      out[i] = pack_key(ci_col * g.w_cell + 3 + x, ci_row * g.h_cell + 3 + y, s_score[RGBL_SCORE_AT(p, y)]);
+    }
+    if (lane == 0) *my_cnt = n_out;
   }
-  if (tid == 0) *my_cnt = total < (uint32_t)g.cell_cap ? total : (uint32_t)g.cell_cap;  // cap is a proven bound
 }
 
 // ------------------------------------------------------------------------------------------------
