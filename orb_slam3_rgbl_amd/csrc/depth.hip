@@ -61,13 +61,14 @@ __device__ __forceinline__ int project_point(const ProjParams& P, const float* _
 template <bool kXyzi>
 __global__ __launch_bounds__(256) void k_project_index(ProjParams P, const float* __restrict__ cloud, size_t cloud_stride,
                                                        int n, int ld, int w, int h, uint32_t* __restrict__ idx_map,
-                                                       size_t map_stride) {
+                                                       size_t map_stride, float* __restrict__ pt_depth, size_t pt_stride) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int f = blockIdx.y;
   float d;
   const int pix = project_point<kXyzi>(P, cloud + (size_t)f * cloud_stride, ld, i, w, h, &d);
   if (pix >= 0) atomicMax(idx_map + (size_t)f * map_stride + pix, (uint32_t)(i + 1));
+  if (pt_depth) pt_depth[(size_t)f * pt_stride + i] = d;  // read back through the index map by k_inverse_dilate<., true>
 }
 
 template <bool kXyzi>
@@ -87,9 +88,12 @@ __global__ __launch_bounds__(256) void k_project_write(ProjParams P, const float
 // kRadius > 0: the reference's Diamond structuring element |dx|+|dy| <= kRadius with compile-time taps (all
 // LDS reads of a pixel are issued back to back); kRadius == 0: arbitrary mask, tap offsets held in LDS.
 // grid = (ceil(w/64), ceil(h/16), B), block = 256.
-template <int kRadius>
+// kIndexed: the raw depth map is never written; a pixel's raw depth is looked up as pt_depth[idx_map[pixel] - 1]
+// (0 where no point fell), which saves the map's zero fill, k_project_write and one map-sized round trip through HBM.
+template <int kRadius, bool kIndexed>
 __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, const float* __restrict__ raw,
-                                                        float* __restrict__ out, size_t map_stride, int w, int h) {
+                                                        const uint32_t* __restrict__ idx_map, const float* __restrict__ pt_depth,
+                                                        size_t pt_stride, float* __restrict__ out, size_t map_stride, int w, int h) {
   __shared__ float s_inv[24 * 72];
   __shared__ int s_tap[81];
   __shared__ int s_ntap;
@@ -98,7 +102,9 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
   const int ax = kRadius > 0 ? kRadius : K.kw / 2, ay = kRadius > 0 ? kRadius : K.kh / 2;
   const int tw = kRadius > 0 ? 64 + 2 * kRadius : 64 + K.kw - 1, th = kRadius > 0 ? 16 + 2 * kRadius : 16 + K.kh - 1;
   const float thr = S - 1;
-  const float* R = raw + (size_t)f * map_stride;
+  const float* R = kIndexed ? nullptr : raw + (size_t)f * map_stride;
+  const uint32_t* I = kIndexed ? idx_map + (size_t)f * map_stride : nullptr;
+  const float* D = kIndexed ? pt_depth + (size_t)f * pt_stride : nullptr;
   if (kRadius == 0 && tid < 64) {
     // compact the mask (<= 81 entries) into a tap list with two ballots of wave 0
     const int n = K.kw * K.kh, i1 = tid + 64;
@@ -114,7 +120,14 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
     const int yy = y0 + r - ay, xx = x0 + c - ax;
     float v = -FLT_MAX;  // taps outside the image never win (cv::dilate's default border)
     if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
-      const float t = S - R[(size_t)yy * w + xx];
+      float r;
+      if (kIndexed) {
+        const uint32_t id = I[(size_t)yy * w + xx];
+        r = id ? D[id - 1] : 0.f;
+      } else {
+        r = R[(size_t)yy * w + xx];
+      }
+      const float t = S - r;
       v = t > thr ? 0.f : t;  // THRESH_TOZERO_INV
     }
     s_inv[r * 72 + c] = v;
@@ -262,6 +275,7 @@ struct rgbl_depth {
   size_t map_stride = 0;
   uint32_t* d_idx = nullptr;  // idx | raw contiguous so one memset clears both
   float* d_raw = nullptr;
+  float* d_ptdepth = nullptr;  // depth of every projected point (max_batch x max_points), for the raw-map-free path
   float* d_proc = nullptr;
   float* d_cloud = nullptr;
   float *d_kp = nullptr, *d_kpun = nullptr, *d_depth = nullptr, *d_uright = nullptr;
@@ -278,11 +292,18 @@ int dalloc(rgbl_depth* e, T** p, size_t count) {
 
 // Part 1 (independent of the keypoints): projection + ordered scatter + dense up-sampling.
 int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w, int h,
-                 float* d_processed_out, bool xyzi = false) {
+                 float* d_processed_out, bool xyzi = false, bool need_raw = true) {
   hipStream_t s = e->stream;
   const size_t ms = e->map_stride;
+  // the inverse dilation can read the points' depths through the index map: no raw map unless the caller wants it
+  // (device batches may bring more points per scan than the host staging size the per-point buffer was sized for)
+  const bool indexed = e->cfg.method == RGBL_UPS_INVERSE_DILATION && !need_raw && n <= e->cfg.max_points;
+  float* pt_depth = indexed ? e->d_ptdepth : nullptr;
+  const size_t pt_stride = (size_t)e->cfg.max_points;
   // idx maps (max_batch of them) are followed by the raw maps: one memset clears both when the batch is full
-  if (batch == e->cfg.max_batch) {
+  if (indexed) {
+    RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)batch * ms * sizeof(uint32_t), s));
+  } else if (batch == e->cfg.max_batch) {
     RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)batch * ms * 2 * sizeof(uint32_t), s));
   } else {
     RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)batch * ms * sizeof(uint32_t), s));
@@ -291,26 +312,41 @@ int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, 
   if (n > 0) {
     e->timer.begin("k_project_index", s);
     const dim3 pgrid((n + 255) / 256, batch);
-    if (xyzi) hipLaunchKernelGGL(k_project_index<true>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms);
-    else hipLaunchKernelGGL(k_project_index<false>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms);
+    if (xyzi) hipLaunchKernelGGL(k_project_index<true>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms, pt_depth, pt_stride);
+    else hipLaunchKernelGGL(k_project_index<false>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms, pt_depth, pt_stride);
     e->timer.end(s);
-    e->timer.begin("k_project_write", s);
-    if (xyzi) hipLaunchKernelGGL(k_project_write<true>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, e->d_raw, ms);
-    else hipLaunchKernelGGL(k_project_write<false>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, e->d_raw, ms);
-    e->timer.end(s);
+    if (!indexed) {
+      e->timer.begin("k_project_write", s);
+      if (xyzi) hipLaunchKernelGGL(k_project_write<true>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, e->d_raw, ms);
+      else hipLaunchKernelGGL(k_project_write<false>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, e->d_raw, ms);
+      e->timer.end(s);
+    }
   }
   const dim3 tiles((w + 63) / 64, (h + 15) / 16, batch);
   switch (e->cfg.method) {
     case RGBL_UPS_INVERSE_DILATION:
       e->timer.begin("k_inverse_dilate", s);
       // opt_max_dist * ParamUpsampling_InverseDilation_ScaleFactor; the scale factor is never parsed (1.0)
-      switch (e->diamond_radius) {
-        case 1: hipLaunchKernelGGL(k_inverse_dilate<1>, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, e->d_proc, ms, w, h); break;
-        case 2: hipLaunchKernelGGL(k_inverse_dilate<2>, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, e->d_proc, ms, w, h); break;
-        case 3: hipLaunchKernelGGL(k_inverse_dilate<3>, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, e->d_proc, ms, w, h); break;
-        case 4: hipLaunchKernelGGL(k_inverse_dilate<4>, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, e->d_proc, ms, w, h); break;
-        default: hipLaunchKernelGGL(k_inverse_dilate<0>, tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, e->d_proc, ms, w, h); break;
+#define RGBL_DILATE(R, I) hipLaunchKernelGGL((k_inverse_dilate<R, I>), tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, \
+                                            e->d_idx, e->d_ptdepth, pt_stride, e->d_proc, ms, w, h)
+      if (indexed) {
+        switch (e->diamond_radius) {
+          case 1: RGBL_DILATE(1, true); break;
+          case 2: RGBL_DILATE(2, true); break;
+          case 3: RGBL_DILATE(3, true); break;
+          case 4: RGBL_DILATE(4, true); break;
+          default: RGBL_DILATE(0, true); break;
+        }
+      } else {
+        switch (e->diamond_radius) {
+          case 1: RGBL_DILATE(1, false); break;
+          case 2: RGBL_DILATE(2, false); break;
+          case 3: RGBL_DILATE(3, false); break;
+          case 4: RGBL_DILATE(4, false); break;
+          default: RGBL_DILATE(0, false); break;
+        }
       }
+#undef RGBL_DILATE
       e->timer.end(s);
       break;
     case RGBL_UPS_AVERAGE_FILTERING:
@@ -442,6 +478,7 @@ int rgbl_depth_create(const rgbl_depth_cfg* cfg, int device, rgbl_depth** out) {
   e->d_raw = rc == RGBL_OK ? reinterpret_cast<float*>(e->d_idx + B * e->map_stride) : nullptr;
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_proc, B * e->map_stride);
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_cloud, (size_t)4 * cfg->max_points);
+  if (rc == RGBL_OK) rc = dalloc(e, &e->d_ptdepth, B * (size_t)cfg->max_points);
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_kp, (size_t)2 * cfg->max_keypoints);
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_kpun, (size_t)cfg->max_keypoints);
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_depth, (size_t)cfg->max_keypoints);
@@ -483,7 +520,7 @@ static int depth_compute_host(rgbl_depth* e, const float* cloud, int n, int ld, 
     RGBL_HIP(hipMemcpyAsync(e->d_kp, kp_xy, sizeof(float) * 2 * k, hipMemcpyHostToDevice, s));
     RGBL_HIP(hipMemcpyAsync(e->d_kpun, kpun_x, sizeof(float) * k, hipMemcpyHostToDevice, s));
   }
-  RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi));
+  RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi, out_raw != nullptr));
   RGBL_TRY(enqueue_keypoints(e, 1, w, h, e->d_kp, 2, 0, e->d_kpun, 1, 0, nullptr, k, k, e->d_depth, e->d_uright, 0));
   if (k > 0) {
     RGBL_HIP(hipMemcpyAsync(out_depth, e->d_depth, sizeof(float) * k, hipMemcpyDeviceToHost, s));
@@ -518,7 +555,7 @@ int rgbl_depth_project_xyzi_batch_device(rgbl_depth* e, const float* d_xyzi, int
     return RGBL_ERR_INVALID;
   }
   RGBL_HIP(hipSetDevice(e->device));
-  return enqueue_maps(e, d_xyzi, batch, n, n, scan_stride, w, h, d_processed, true);
+  return enqueue_maps(e, d_xyzi, batch, n, n, scan_stride, w, h, d_processed, true, false);
 }
 
 int rgbl_depth_project_batch_device(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w,
@@ -530,7 +567,7 @@ int rgbl_depth_project_batch_device(rgbl_depth* e, const float* d_cloud, int bat
     return RGBL_ERR_INVALID;
   }
   RGBL_HIP(hipSetDevice(e->device));
-  return enqueue_maps(e, d_cloud, batch, n, ld, cloud_stride, w, h, d_processed);
+  return enqueue_maps(e, d_cloud, batch, n, ld, cloud_stride, w, h, d_processed, false, false);
 }
 
 int rgbl_depth_gather_batch_device(rgbl_depth* e, int batch, int w, int h, const rgbl_keypoint* d_kp, const int32_t* d_n,
