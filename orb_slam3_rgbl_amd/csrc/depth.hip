@@ -58,16 +58,23 @@ __device__ __forceinline__ int project_point(const ProjParams& P, const float* _
   return -1;
 }
 
+// index map entry = generation << kIdxBits | point index + 1: the indexed path does not clear the map between calls
+constexpr int kIdxBits = 20;
+constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1u;
+
 template <bool kXyzi>
 __global__ __launch_bounds__(256) void k_project_index(ProjParams P, const float* __restrict__ cloud, size_t cloud_stride,
                                                        int n, int ld, int w, int h, uint32_t* __restrict__ idx_map,
-                                                       size_t map_stride, float* __restrict__ pt_depth, size_t pt_stride) {
+                                                       size_t map_stride, float* __restrict__ pt_depth, size_t pt_stride,
+                                                       uint32_t tag) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int f = blockIdx.y;
   float d;
   const int pix = project_point<kXyzi>(P, cloud + (size_t)f * cloud_stride, ld, i, w, h, &d);
-  if (pix >= 0) atomicMax(idx_map + (size_t)f * map_stride + pix, (uint32_t)(i + 1));
+  // the last point index wins (DepthModule.cc:123-137 scatters in order); tag = this call's generation in the bits above
+  // kIdxBits, larger than whatever earlier calls left in the map (0 when the map was cleared instead)
+  if (pix >= 0) atomicMax(idx_map + (size_t)f * map_stride + pix, tag | (uint32_t)(i + 1));
   if (pt_depth) pt_depth[(size_t)f * pt_stride + i] = d;  // read back through the index map by k_inverse_dilate<., true>
 }
 
@@ -93,7 +100,8 @@ __global__ __launch_bounds__(256) void k_project_write(ProjParams P, const float
 template <int kRadius, bool kIndexed>
 __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, const float* __restrict__ raw,
                                                         const uint32_t* __restrict__ idx_map, const float* __restrict__ pt_depth,
-                                                        size_t pt_stride, float* __restrict__ out, size_t map_stride, int w, int h) {
+                                                        size_t pt_stride, uint32_t tag, float* __restrict__ out, size_t map_stride,
+                                                        int w, int h) {
   __shared__ float s_inv[24 * 72];
   __shared__ int s_tap[81];
   __shared__ int s_ntap;
@@ -122,8 +130,8 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
     if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
       float r;
       if (kIndexed) {
-        const uint32_t id = I[(size_t)yy * w + xx];
-        r = id ? D[id - 1] : 0.f;
+        const uint32_t id = I[(size_t)yy * w + xx];  // entries of earlier generations are empty pixels
+        r = (id & ~kIdxMask) == tag && (id & kIdxMask) ? D[(id & kIdxMask) - 1] : 0.f;
       } else {
         r = R[(size_t)yy * w + xx];
       }
@@ -275,6 +283,8 @@ struct rgbl_depth {
   size_t map_stride = 0;
   uint32_t* d_idx = nullptr;  // idx | raw contiguous so one memset clears both
   float* d_raw = nullptr;
+  uint32_t idx_gen = 0;        // generation of the index maps' newest entries; 0 = cleared / untagged content
+  uint32_t max_gen = (1u << (32 - 20)) - 1u;  // RGBL_DEPTH_MAX_GEN lowers it (tests of the wrap-around)
   float* d_ptdepth = nullptr;  // depth of every projected point (max_batch x max_points), for the raw-map-free path
   float* d_proc = nullptr;
   float* d_cloud = nullptr;
@@ -297,23 +307,33 @@ int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, 
   const size_t ms = e->map_stride;
   // the inverse dilation can read the points' depths through the index map: no raw map unless the caller wants it
   // (device batches may bring more points per scan than the host staging size the per-point buffer was sized for)
-  const bool indexed = e->cfg.method == RGBL_UPS_INVERSE_DILATION && !need_raw && n <= e->cfg.max_points;
+  const bool indexed = e->cfg.method == RGBL_UPS_INVERSE_DILATION && !need_raw && n <= e->cfg.max_points && (uint32_t)n < kIdxMask;
   float* pt_depth = indexed ? e->d_ptdepth : nullptr;
   const size_t pt_stride = (size_t)e->cfg.max_points;
   // idx maps (max_batch of them) are followed by the raw maps: one memset clears both when the batch is full
+  uint32_t tag = 0;
   if (indexed) {
-    RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)batch * ms * sizeof(uint32_t), s));
+    // every call stamps its entries with a new generation, so the maps are cleared once per max_gen calls only
+    if (e->idx_gen == 0 || e->idx_gen >= e->max_gen) {
+      RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)e->cfg.max_batch * ms * sizeof(uint32_t), s));
+      e->idx_gen = 1;
+    } else {
+      ++e->idx_gen;
+    }
+    tag = e->idx_gen << kIdxBits;
   } else if (batch == e->cfg.max_batch) {
+    e->idx_gen = 0;  // untagged entries: the next indexed call starts from cleared maps
     RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)batch * ms * 2 * sizeof(uint32_t), s));
   } else {
+    e->idx_gen = 0;
     RGBL_HIP(hipMemsetAsync(e->d_idx, 0, (size_t)batch * ms * sizeof(uint32_t), s));
     RGBL_HIP(hipMemsetAsync(e->d_raw, 0, (size_t)batch * ms * sizeof(float), s));
   }
   if (n > 0) {
     e->timer.begin("k_project_index", s);
     const dim3 pgrid((n + 255) / 256, batch);
-    if (xyzi) hipLaunchKernelGGL(k_project_index<true>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms, pt_depth, pt_stride);
-    else hipLaunchKernelGGL(k_project_index<false>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms, pt_depth, pt_stride);
+    if (xyzi) hipLaunchKernelGGL(k_project_index<true>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms, pt_depth, pt_stride, tag);
+    else hipLaunchKernelGGL(k_project_index<false>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms, pt_depth, pt_stride, tag);
     e->timer.end(s);
     if (!indexed) {
       e->timer.begin("k_project_write", s);
@@ -328,7 +348,7 @@ int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, 
       e->timer.begin("k_inverse_dilate", s);
       // opt_max_dist * ParamUpsampling_InverseDilation_ScaleFactor; the scale factor is never parsed (1.0)
 #define RGBL_DILATE(R, I) hipLaunchKernelGGL((k_inverse_dilate<R, I>), tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, \
-                                            e->d_idx, e->d_ptdepth, pt_stride, e->d_proc, ms, w, h)
+                                            e->d_idx, e->d_ptdepth, pt_stride, tag, e->d_proc, ms, w, h)
       if (indexed) {
         switch (e->diamond_radius) {
           case 1: RGBL_DILATE(1, true); break;
@@ -483,6 +503,7 @@ int rgbl_depth_create(const rgbl_depth_cfg* cfg, int device, rgbl_depth** out) {
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_kpun, (size_t)cfg->max_keypoints);
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_depth, (size_t)cfg->max_keypoints);
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_uright, (size_t)cfg->max_keypoints);
+  if (const char* v = getenv("RGBL_DEPTH_MAX_GEN")) e->max_gen = (uint32_t)std::min(std::max(atoi(v), 1), (int)e->max_gen);
   if (rc == RGBL_OK && hipStreamCreate(&e->own_stream) != hipSuccess) { set_error("hipStreamCreate failed"); rc = RGBL_ERR_HIP; }
   if (rc != RGBL_OK) { rgbl_depth_destroy(e); return rc; }
   e->stream = e->own_stream;

@@ -141,6 +141,11 @@ def check_depth(lib, method, w=synth.KITTI_W, h=synth.KITTI_H, seed=0, n_az=1900
         assert np.array_equal(bits(np.nan_to_num(a)), bits(np.nan_to_num(b))), "ProcessedDepthMap"
     assert np.array_equal(bits(dm.mvDepth), bits(d)), "mvDepth"
     assert np.array_equal(bits(dm.mvuRight), bits(ur)), "mvuRight"
+    # the same call without the maps (what Frame needs): the inverse dilation then never materialises the raw map
+    dm.CalculateDepthFromPcd(kp_xy, kpun, cloud, w, h, want_maps=False)
+    assert np.array_equal(bits(dm.mvDepth), bits(d)) and np.array_equal(bits(dm.mvuRight), bits(ur)), "mvDepth without maps"
+    dm.CalculateDepthFromPcd(kp_xy, kpun, cloud, w, h)  # and back: the raw map must come out clean again
+    assert np.array_equal(bits(dm.RawDepthMap), bits(raw)), "RawDepthMap after a map-free call"
     n_valid = int((d > 0).sum())
     dm.close()
     return n_valid
@@ -639,11 +644,17 @@ def check_bow_transform(lib, tmp_dir, k=10, L=4, levelsup=2, seed=0, n_feat=2000
     return len(want[0])
 
 
-def check_depth_partial_batches(lib, dev=None, w=310, h=94):
-    """A handle sized for 4 scans used with 2, then 3, then 1: every call must start from cleared maps (regression: the raw
-    maps follow max_batch index maps, a single memset sized by the current batch missed them).
+def check_depth_partial_batches(lib, dev=None, w=310, h=94, max_gen=None):
+    """A handle sized for 4 scans used with 2, then 3, then 1 ...: every call must see empty maps (regression: the raw
+    maps follow max_batch index maps, a single memset sized by the current batch missed them).  The map-free path does not
+    clear its index maps but stamps a generation on the entries: max_gen (RGBL_DEPTH_MAX_GEN) makes the generation counter
+    wrap within the test, and a host call that wants the maps (plain, cleared index map) sits in the middle.
     dev: torch device for the product library; None = the emulator, whose 'device' pointers are host pointers."""
     import ctypes as C
+    import os
+    saved = os.environ.get("RGBL_DEPTH_MAX_GEN")
+    if max_gen is not None:
+        os.environ["RGBL_DEPTH_MAX_GEN"] = str(max_gen)
     K = synth.KITTI_K.copy()
     K[0, 2], K[1, 2] = w / 2.0, h / 2.0
     K[0, 0] = K[1, 1] = 718.856 * w / synth.KITTI_W
@@ -652,7 +663,14 @@ def check_depth_partial_batches(lib, dev=None, w=310, h=94):
     n = scans[0].shape[1]
     cap = 64
     rng = np.random.default_rng(2)
-    dm = F.DepthModule(proj, w, h, max_points=n, max_keypoints=cap, max_batch=4, lib=lib)
+    try:
+        dm = F.DepthModule(proj, w, h, max_points=n, max_keypoints=cap, max_batch=4, lib=lib)
+    finally:
+        if max_gen is not None:
+            if saved is None:
+                del os.environ["RGBL_DEPTH_MAX_GEN"]
+            else:
+                os.environ["RGBL_DEPTH_MAX_GEN"] = saved
     P = O.make_depth_params(proj)
     if dev is not None:
         import torch
@@ -663,7 +681,13 @@ def check_depth_partial_batches(lib, dev=None, w=310, h=94):
         up = lambda a: np.ascontiguousarray(a).copy()
         ptr = lambda a: C.c_void_p(a.ctypes.data)
         down = lambda a: a
-    for batch, first in ((2, 0), (3, 1), (1, 3), (4, 0)):
+    for step, (batch, first) in enumerate(((2, 0), (3, 1), (1, 3), (4, 0), (2, 2), (4, 1), (1, 0), (3, 3), (4, 2))):
+        if step == 4:  # single-scan host call with the maps, through the same handle
+            hk = np.stack([rng.uniform(0, w - 1, cap), rng.uniform(0, h - 1, cap)], 1).astype(np.float32)
+            dm.CalculateDepthFromPcd(hk, hk, scans[2], w, h)
+            od, our, oraw, oproc = O.depth(P, scans[2], w, h, hk, hk[:, 0])
+            assert np.array_equal(bits(dm.RawDepthMap), bits(oraw)) and np.array_equal(bits(dm.ProcessedDepthMap), bits(oproc))
+            assert np.array_equal(bits(dm.mvDepth), bits(od))
         cloud = np.stack([scans[(first + b) % 4] for b in range(batch)])
         kps = np.zeros((batch, cap), O.KP_DTYPE)
         kps["x"] = rng.uniform(0, w - 1, (batch, cap)).astype(np.float32)

@@ -122,6 +122,11 @@ def test_depth_partial_batches(emu_lib):
     pc.check_depth_partial_batches(emu_lib)
 
 
+@pytest.mark.parametrize("max_gen", [1, 2, 3])
+def test_depth_generation_wrap(emu_lib, max_gen):
+    pc.check_depth_partial_batches(emu_lib, max_gen=max_gen)
+
+
 def test_extractor_partial_batches(emu_lib):
     pc.check_extractor_partial_batches(emu_lib, 360, 280, 400)
 

@@ -142,6 +142,12 @@ def test_depth_partial_batches(gpu_lib):
     pc.check_depth_partial_batches(gpu_lib, torch.device("cuda", 0), w=620, h=188)
 
 
+@pytest.mark.parametrize("max_gen", [1, 2, 3])
+def test_depth_generation_wrap(gpu_lib, max_gen):
+    import torch
+    pc.check_depth_partial_batches(gpu_lib, torch.device("cuda", 0), w=620, h=188, max_gen=max_gen)
+
+
 def test_extractor_partial_batches(gpu_lib):
     pc.check_extractor_partial_batches(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000)
 
