@@ -69,6 +69,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
   return v;
 }
 
+template <int kResizeRows>  // output rows per work-item
 __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict__ src, int spitch,
                                                        size_t sframe, int sw, int sh,
                                                        uint8_t* __restrict__ dst, int dpitch, size_t dframe,
@@ -76,58 +77,76 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
                                                        const ResizeTab* __restrict__ ytab) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int dx0 = (blockIdx.x * 64 + tx) * 4;
-  const int dy = blockIdx.y * 4 + ty;
-  if (dy >= dh || dx0 >= dw) return;
+  const int dy0 = (blockIdx.y * 4 + ty) * kResizeRows;
+  if (dy0 >= dh || dx0 >= dw) return;
   const uint8_t* S = src + (size_t)blockIdx.z * sframe;
-  uint8_t* D = dst + (size_t)blockIdx.z * dframe + (size_t)dy * dpitch;
-  const ResizeTab ry = ytab[dy];
-  const int sy0 = imin(imax(ry.sofs, 0), sh - 1), sy1 = imin(imax(ry.sofs + 1, 0), sh - 1);
-  const uint8_t* S0 = S + (size_t)sy0 * spitch;
-  const uint8_t* S1 = S + (size_t)sy1 * spitch;
-  const int b0 = ry.a0, b1 = ry.a1;
-  ResizeTab rx[4];
-  if (dx0 + 3 < dw) {
-    const uint4* t4 = reinterpret_cast<const uint4*>(xtab + dx0);  // table offsets are padded to 4 entries
-    const uint4 q0 = t4[0], q1 = t4[1];
-    rx[0].sofs = (int)q0.x; rx[0].a0 = (int16_t)(q0.y & 0xffff); rx[0].a1 = (int16_t)(q0.y >> 16);
-    rx[1].sofs = (int)q0.z; rx[1].a0 = (int16_t)(q0.w & 0xffff); rx[1].a1 = (int16_t)(q0.w >> 16);
-    rx[2].sofs = (int)q1.x; rx[2].a0 = (int16_t)(q1.y & 0xffff); rx[2].a1 = (int16_t)(q1.y >> 16);
-    rx[3].sofs = (int)q1.z; rx[3].a0 = (int16_t)(q1.w & 0xffff); rx[3].a1 = (int16_t)(q1.w >> 16);
-  } else {
-    for (int i = 0; i < 4; ++i) rx[i] = xtab[imin(dx0 + i, dw - 1)];
-  }
-  const int sxa = rx[0].sofs;
-  uint32_t out = 0;
-  if (dx0 + 3 < dw && rx[3].sofs + 1 - sxa <= 7 && sxa + 8 <= sw) {
-    const unsigned long long r0 = (unsigned long long)load_u32_unaligned(S0 + sxa) | ((unsigned long long)load_u32_unaligned(S0 + sxa + 4) << 32);
-    const unsigned long long r1 = (unsigned long long)load_u32_unaligned(S1 + sxa) | ((unsigned long long)load_u32_unaligned(S1 + sxa + 4) << 32);
+  uint8_t* D = dst + (size_t)blockIdx.z * dframe + (size_t)dy0 * dpitch;
+  // both coefficient tables are requested before either is used (one round trip, not two); the x table is padded to a
+  // multiple of 4 entries per level, entries at or past dw are never used
+  const uint4* t4 = reinterpret_cast<const uint4*>(xtab + dx0);
+  const uint4 q0 = t4[0], q1 = t4[1];
+  // the kResizeRows rows' vertical taps; rows past the image repeat the last one (computed, not stored)
+  ResizeTab ry[kResizeRows];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int sh8 = 8 * (rx[i].sofs - sxa);
-      const int p00 = (int)((r0 >> sh8) & 0xff), p01 = (int)((r0 >> (sh8 + 8)) & 0xff);
-      const int p10 = (int)((r1 >> sh8) & 0xff), p11 = (int)((r1 >> (sh8 + 8)) & 0xff);
-      const int h0 = p00 * rx[i].a0 + p01 * rx[i].a1;
-      const int h1 = p10 * rx[i].a0 + p11 * rx[i].a1;
-      const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-      out |= (uint32_t)(v & 0xff) << (8 * i);
+  for (int r = 0; r < kResizeRows; ++r) ry[r] = ytab[imin(dy0 + r, dh - 1)];
+  ResizeTab rx[4];
+  rx[0].sofs = (int)q0.x; rx[0].a0 = (int16_t)(q0.y & 0xffff); rx[0].a1 = (int16_t)(q0.y >> 16);
+  rx[1].sofs = (int)q0.z; rx[1].a0 = (int16_t)(q0.w & 0xffff); rx[1].a1 = (int16_t)(q0.w >> 16);
+  rx[2].sofs = (int)q1.x; rx[2].a0 = (int16_t)(q1.y & 0xffff); rx[2].a1 = (int16_t)(q1.y >> 16);
+  rx[3].sofs = (int)q1.z; rx[3].a0 = (int16_t)(q1.w & 0xffff); rx[3].a1 = (int16_t)(q1.w >> 16);
+  const int sxa = rx[0].sofs;
+  if (dx0 + 3 < dw && rx[3].sofs + 1 - sxa <= 7 && sxa + 8 <= sw) {
+    // all 4 kResizeRows source words are requested before the first one is used: a wave keeps 4 KB in flight, the
+    // kernel is bound by the round trips per byte otherwise (one row per work-item ran at 1.2 TB/s)
+    unsigned long long r0[kResizeRows], r1[kResizeRows];
+#pragma unroll
+    for (int r = 0; r < kResizeRows; ++r) {
+      const int sy0 = imin(imax(ry[r].sofs, 0), sh - 1), sy1 = imin(imax(ry[r].sofs + 1, 0), sh - 1);
+      const uint8_t* S0 = S + (size_t)sy0 * spitch + sxa;
+      const uint8_t* S1 = S + (size_t)sy1 * spitch + sxa;
+      r0[r] = (unsigned long long)load_u32_unaligned(S0) | ((unsigned long long)load_u32_unaligned(S0 + 4) << 32);
+      r1[r] = (unsigned long long)load_u32_unaligned(S1) | ((unsigned long long)load_u32_unaligned(S1 + 4) << 32);
     }
-    *reinterpret_cast<uint32_t*>(D + dx0) = out;  // dpitch and dx0 are multiples of 4
+#pragma unroll
+    for (int r = 0; r < kResizeRows; ++r) {
+      const int b0 = ry[r].a0, b1 = ry[r].a1;
+      uint32_t out = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int sh8 = 8 * (rx[i].sofs - sxa);
+        const int p00 = (int)((r0[r] >> sh8) & 0xff), p01 = (int)((r0[r] >> (sh8 + 8)) & 0xff);
+        const int p10 = (int)((r1[r] >> sh8) & 0xff), p11 = (int)((r1[r] >> (sh8 + 8)) & 0xff);
+        const int h0 = p00 * rx[i].a0 + p01 * rx[i].a1;
+        const int h1 = p10 * rx[i].a0 + p11 * rx[i].a1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        out |= (uint32_t)(v & 0xff) << (8 * i);
+      }
+      if (dy0 + r < dh) *reinterpret_cast<uint32_t*>(D + (size_t)r * dpitch + dx0) = out;  // dpitch and dx0 are multiples of 4
+    }
     return;
   }
   // row ends / large scale factors: byte path
-  for (int i = 0; i < 4; ++i) {
-    const int dx = dx0 + i;
-    if (dx >= dw) break;
-    const int sx = rx[i].sofs, sx1 = imin(sx + 1, sw - 1);
-    const int h0 = S0[sx] * rx[i].a0 + S0[sx1] * rx[i].a1;
-    const int h1 = S1[sx] * rx[i].a0 + S1[sx1] * rx[i].a1;
-    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-    out |= (uint32_t)(v & 0xff) << (8 * i);
-  }
-  if (dx0 + 3 < dw) {
-    *reinterpret_cast<uint32_t*>(D + dx0) = out;
-  } else {
-    for (int i = 0; dx0 + i < dw; ++i) D[dx0 + i] = (uint8_t)(out >> (8 * i));
+  for (int r = 0; r < kResizeRows && dy0 + r < dh; ++r) {
+    const int sy0 = imin(imax(ry[r].sofs, 0), sh - 1), sy1 = imin(imax(ry[r].sofs + 1, 0), sh - 1);
+    const uint8_t* S0 = S + (size_t)sy0 * spitch;
+    const uint8_t* S1 = S + (size_t)sy1 * spitch;
+    const int b0 = ry[r].a0, b1 = ry[r].a1;
+    uint8_t* Dr = D + (size_t)r * dpitch;
+    uint32_t out = 0;
+    for (int i = 0; i < 4; ++i) {
+      const int dx = dx0 + i;
+      if (dx >= dw) break;
+      const int sx = rx[i].sofs, sx1 = imin(sx + 1, sw - 1);
+      const int h0 = S0[sx] * rx[i].a0 + S0[sx1] * rx[i].a1;
+      const int h1 = S1[sx] * rx[i].a0 + S1[sx1] * rx[i].a1;
+      const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      out |= (uint32_t)(v & 0xff) << (8 * i);
+    }
+    if (dx0 + 3 < dw) {
+      *reinterpret_cast<uint32_t*>(Dr + dx0) = out;
+    } else {
+      for (int i = 0; dx0 + i < dw; ++i) Dr[dx0 + i] = (uint8_t)(out >> (8 * i));
+    }
   }
 }
 
