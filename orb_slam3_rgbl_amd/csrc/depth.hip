@@ -123,22 +123,57 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
     if (on1) s_tap[__popcll(m0) + __popcll(m1 & lt)] = (i1 / K.kw) * 72 + (i1 % K.kw);
     if (tid == 0) s_ntap = __popcll(m0) + __popcll(m1);
   }
-  for (int i = tid; i < tw * th; i += 256) {
-    const int r = i / tw, c = i - r * tw;
-    const int yy = y0 + r - ay, xx = x0 + c - ax;
-    float v = -FLT_MAX;  // taps outside the image never win (cv::dilate's default border)
-    if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
-      float r;
-      if (kIndexed) {
-        const uint32_t id = I[(size_t)yy * w + xx];  // entries of earlier generations are empty pixels
-        r = (id & ~kIdxMask) == tag && (id & kIdxMask) ? D[(id & kIdxMask) - 1] : 0.f;
-      } else {
-        r = R[(size_t)yy * w + xx];
-      }
-      const float t = S - r;
-      v = t > thr ? 0.f : t;  // THRESH_TOZERO_INV
+  // raw depth of tile element i (0 = empty pixel); taps outside the image never win (cv::dilate's default border)
+  auto inverted = [&](bool inside, float r) {
+    const float t = S - r;
+    return inside ? (t > thr ? 0.f : t) : -FLT_MAX;  // THRESH_TOZERO_INV
+  };
+  if (kRadius > 0) {
+    // compile-time tile: every load of a work-item's 5-6 elements is requested before the first is used, the indexed
+    // variant then requests all its depth look-ups together (the kernel is bound by round trips, not by bytes)
+    constexpr int kTw = 64 + 2 * kRadius, kTh = 16 + 2 * kRadius, kIter = (kTw * kTh + 255) / 256;
+    bool inside[kIter];
+    size_t at[kIter];
+    float raw_v[kIter];
+    uint32_t id[kIter];
+#pragma unroll
+    for (int j = 0; j < kIter; ++j) {
+      const int i = tid + 256 * j;
+      const int r = i / kTw, c = i - r * kTw;
+      const int yy = y0 + r - kRadius, xx = x0 + c - kRadius;
+      inside[j] = i < kTw * kTh && yy >= 0 && yy < h && xx >= 0 && xx < w;
+      at[j] = inside[j] ? (size_t)yy * w + xx : 0;
+      if (kIndexed) id[j] = inside[j] ? I[at[j]] : 0u;
+      else raw_v[j] = inside[j] ? R[at[j]] : 0.f;
     }
-    s_inv[r * 72 + c] = v;
+    if (kIndexed) {
+#pragma unroll
+      for (int j = 0; j < kIter; ++j) {
+        const bool hit = (id[j] & ~kIdxMask) == tag && (id[j] & kIdxMask);  // entries of earlier generations are empty pixels
+        raw_v[j] = hit ? D[(id[j] & kIdxMask) - 1] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kIter; ++j) {
+      const int i = tid + 256 * j;
+      if (i < kTw * kTh) s_inv[(i / kTw) * 72 + (i % kTw)] = inverted(inside[j], raw_v[j]);
+    }
+  } else {
+    for (int i = tid; i < tw * th; i += 256) {
+      const int r = i / tw, c = i - r * tw;
+      const int yy = y0 + r - ay, xx = x0 + c - ax;
+      const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;
+      float rv = 0.f;
+      if (in) {
+        if (kIndexed) {
+          const uint32_t e = I[(size_t)yy * w + xx];
+          rv = (e & ~kIdxMask) == tag && (e & kIdxMask) ? D[(e & kIdxMask) - 1] : 0.f;
+        } else {
+          rv = R[(size_t)yy * w + xx];
+        }
+      }
+      s_inv[r * 72 + c] = inverted(in, rv);
+    }
   }
   __syncthreads();
   const int x = tid & 63;
