@@ -29,17 +29,21 @@ struct DilateMask { int kw, kh; uint8_t m[81]; };
 // DepthModule.cc:115-119 for one point. Returns the pixel index or -1.
 // kXyzi: the scan is still in the KITTI velodyne .bin layout (x, y, z, reflectance per point, one 16-byte load);
 // the reference's loader drops the reflectance and sets the homogeneous coordinate to 1 (rgbl_kitti.cc:151-185).
+struct CloudPoint { float x, y, z, o; };
 template <bool kXyzi>
-__device__ __forceinline__ int project_point(const ProjParams& P, const float* __restrict__ cloud, int ld, int i, int w,
-                                             int h, float* depth) {
-  double x, y, z, o;
+__device__ __forceinline__ CloudPoint load_point(const float* __restrict__ cloud, int ld, int i) {
+  CloudPoint c;
   if (kXyzi) {
     const float4 q = reinterpret_cast<const float4*>(cloud)[i];
-    x = (double)q.x; y = (double)q.y; z = (double)q.z; o = 1.0;
+    c.x = q.x; c.y = q.y; c.z = q.z; c.o = 1.0f;
   } else {
-    x = (double)cloud[i]; y = (double)cloud[(size_t)ld + i]; z = (double)cloud[2 * (size_t)ld + i];
-    o = (double)cloud[3 * (size_t)ld + i];
+    c.x = cloud[i]; c.y = cloud[(size_t)ld + i]; c.z = cloud[2 * (size_t)ld + i]; c.o = cloud[3 * (size_t)ld + i];
   }
+  return c;
+}
+
+__device__ __forceinline__ int project_loaded(const ProjParams& P, const CloudPoint& c, int w, int h, float* depth) {
+  const double x = (double)c.x, y = (double)c.y, z = (double)c.z, o = (double)c.o;
   float p[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
@@ -58,8 +62,15 @@ __device__ __forceinline__ int project_point(const ProjParams& P, const float* _
   return -1;
 }
 
+template <bool kXyzi>
+__device__ __forceinline__ int project_point(const ProjParams& P, const float* __restrict__ cloud, int ld, int i, int w,
+                                             int h, float* depth) {
+  return project_loaded(P, load_point<kXyzi>(cloud, ld, i), w, h, depth);
+}
+
 // index map entry = generation << kIdxBits | point index + 1: the indexed path does not clear the map between calls
 constexpr int kIdxBits = 20;
+constexpr int kProjectPts = 4;  // points per work-item of k_project_index
 constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1u;
 
 template <bool kXyzi>
@@ -67,15 +78,24 @@ __global__ __launch_bounds__(256) void k_project_index(ProjParams P, const float
                                                        int n, int ld, int w, int h, uint32_t* __restrict__ idx_map,
                                                        size_t map_stride, float* __restrict__ pt_depth, size_t pt_stride,
                                                        uint32_t tag) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  // kProjectPts points per work-item, all of them requested before the first is used
   const int f = blockIdx.y;
-  float d;
-  const int pix = project_point<kXyzi>(P, cloud + (size_t)f * cloud_stride, ld, i, w, h, &d);
-  // the last point index wins (DepthModule.cc:123-137 scatters in order); tag = this call's generation in the bits above
-  // kIdxBits, larger than whatever earlier calls left in the map (0 when the map was cleared instead)
-  if (pix >= 0) atomicMax(idx_map + (size_t)f * map_stride + pix, tag | (uint32_t)(i + 1));
-  if (pt_depth) pt_depth[(size_t)f * pt_stride + i] = d;  // read back through the index map by k_inverse_dilate<., true>
+  const float* C = cloud + (size_t)f * cloud_stride;
+  const int i0 = blockIdx.x * (256 * kProjectPts) + threadIdx.x;
+  CloudPoint c[kProjectPts];
+#pragma unroll
+  for (int j = 0; j < kProjectPts; ++j) c[j] = load_point<kXyzi>(C, ld, imin(i0 + 256 * j, n - 1));
+#pragma unroll
+  for (int j = 0; j < kProjectPts; ++j) {
+    const int i = i0 + 256 * j;
+    if (i >= n) break;
+    float d;
+    const int pix = project_loaded(P, c[j], w, h, &d);
+    // the last point index wins (DepthModule.cc:123-137 scatters in order); tag = this call's generation in the bits above
+    // kIdxBits, larger than whatever earlier calls left in the map (0 when the map was cleared instead)
+    if (pix >= 0) atomicMax(idx_map + (size_t)f * map_stride + pix, tag | (uint32_t)(i + 1));
+    if (pt_depth) pt_depth[(size_t)f * pt_stride + i] = d;  // read back through the index map by k_inverse_dilate<., true>
+  }
 }
 
 template <bool kXyzi>
@@ -366,9 +386,9 @@ int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, 
   }
   if (n > 0) {
     e->timer.begin("k_project_index", s);
-    const dim3 pgrid((n + 255) / 256, batch);
-    if (xyzi) hipLaunchKernelGGL(k_project_index<true>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms, pt_depth, pt_stride, tag);
-    else hipLaunchKernelGGL(k_project_index<false>, pgrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms, pt_depth, pt_stride, tag);
+    const dim3 pgrid((n + 255) / 256, batch), igrid((n + 256 * kProjectPts - 1) / (256 * kProjectPts), batch);
+    if (xyzi) hipLaunchKernelGGL(k_project_index<true>, igrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms, pt_depth, pt_stride, tag);
+    else hipLaunchKernelGGL(k_project_index<false>, igrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms, pt_depth, pt_stride, tag);
     e->timer.end(s);
     if (!indexed) {
       e->timer.begin("k_project_write", s);
