@@ -153,6 +153,9 @@ int rgbl_extractor_debug_stamps(rgbl_extractor* h, unsigned long long* out, int 
 /* Stream control + per-kernel timing (HIP events on the launch stream) for bench.py. */
 int rgbl_extractor_set_stream(rgbl_extractor* h, void* hip_stream /* hipStream_t, NULL = own */);
 void* rgbl_extractor_stream(rgbl_extractor* h); /* hipStream_t currently used by the handle */
+/* the handle's second, internal stream (level-0 FAST / quad-tree and the Gaussian run there next to the resize chain);
+ * other handles may queue work behind it with rgbl_*_set_stream */
+void* rgbl_extractor_aux_stream(rgbl_extractor* h);
 /* Device-side ordering between handles without a host sync: work enqueued on `waiter_stream` after this call
  * starts only when everything enqueued on `signaler_stream` before this call has finished (HIP event). */
 int rgbl_stream_wait(void* waiter_stream, void* signaler_stream);

@@ -110,6 +110,7 @@ SYMBOLS = {
     "rgbl_depth_sync": (_I, [_V]),
     "rgbl_depth_stream": (_V, [_V]),
     "rgbl_extractor_stream": (_V, [_V]),
+    "rgbl_extractor_aux_stream": (_V, [_V]),
     "rgbl_matcher_stream": (_V, [_V]),
     "rgbl_stream_wait": (_I, [_V, _V]),
     "rgbl_event_create": (_I, [C.POINTER(_V)]),

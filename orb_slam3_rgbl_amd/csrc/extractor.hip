@@ -829,6 +829,7 @@ int rgbl_extractor_set_stream(rgbl_extractor* e, void* hip_stream) {
 }
 
 void* rgbl_extractor_stream(rgbl_extractor* e) { return e ? (void*)e->stream : nullptr; }
+void* rgbl_extractor_aux_stream(rgbl_extractor* e) { return e ? (void*)e->aux_stream : nullptr; }
 
 int rgbl_stream_wait(void* waiter, void* signaler) {
   // everything enqueued on `signaler` so far must finish before work enqueued on `waiter` after this call starts
