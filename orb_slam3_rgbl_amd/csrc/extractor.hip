@@ -386,15 +386,9 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
     const int spitch = (l == 1) ? stride : p.pitch;
     const size_t sframe = (l == 1) ? frame_stride : e->pyr_frame;
     e->timer.begin("k_resize_linear", s);
-#define RGBL_RESIZE(R) hipLaunchKernelGGL(k_resize_linear<R>, dim3((g.w + 255) / 256, (g.h + 4 * R - 1) / (4 * R), batch), dim3(256), 0, s, src, \
-                                          spitch, sframe, p.w, p.h, e->d_pyr + g.img_off, g.pitch, e->pyr_frame, g.w, g.h,                  \
-                                          e->d_xtab + g.xtab_off, e->d_ytab + g.ytab_off)
-    switch (e->resize_rows) {
-      case 1: RGBL_RESIZE(1); break;
-      case 2: RGBL_RESIZE(2); break;
-      default: RGBL_RESIZE(4); break;
-    }
-#undef RGBL_RESIZE
+    hipLaunchKernelGGL(k_resize_linear, dim3((g.w + 255) / 256, (g.h + 4 * kResizeRows - 1) / (4 * kResizeRows), batch), dim3(256),
+                       0, s, src, spitch, sframe, p.w, p.h, e->d_pyr + g.img_off, g.pitch, e->pyr_frame, g.w, g.h,
+                       e->d_xtab + g.xtab_off, e->d_ytab + g.ytab_off);
     e->timer.end(s);
   }
   // 4. Gaussian working images (ORBextractor.cc:1132-1133) of the upper levels, on the auxiliary stream next to 2. and 3.
@@ -495,7 +489,6 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
   rgbl_extractor* e = new rgbl_extractor;
   e->cfg = *cfg;
   if (const char* v = getenv("RGBL_GRAPH")) e->graph_ok = atoi(v) != 0;
-  if (const char* v = getenv("RGBL_RESIZE_ROWS")) e->resize_rows = atoi(v);
   if (const char* v = getenv("RGBL_OCTREE_WG")) { const int wg = atoi(v); if (wg == kOctNarrow || wg == kOctWide) e->octree_wg = wg; }
   e->device = device;
   int rc = build_geometry(e);

@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
   return v;
 }
 
-template <int kResizeRows>  // output rows per work-item
+constexpr int kResizeRows = 4;  // output rows per work-item (1 / 2 / 4 measured: 4 is 6 % ahead of 1 on the whole step)
 __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict__ src, int spitch,
                                                        size_t sframe, int sw, int sh,
                                                        uint8_t* __restrict__ dst, int dpitch, size_t dframe,
