@@ -362,6 +362,39 @@ int rgbl_search_by_projection(rgbl_matcher* h, const rgbl_projection_input* in, 
  * Tracking::SearchLocalPoints, src/Tracking.cc:3370-3450): the local map points that Frame::isInFrustum found visible are
  * searched around their predicted projection - best / second-best Hamming distance, ratio test inside one pyramid level.
  * Single-camera frames.  SURVEY.md 8(f) row f2. */
+/* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, const float th,
+ * const int ORBdist) (include/ORBmatcher.h:51, src/ORBmatcher.cc:1889-2010; caller Tracking::Relocalization,
+ * src/Tracking.cc:3723-3752).  Single-camera frames.  The caller (shim) evaluates what needs the MapPoint objects:
+ * valid1 and MapPoint::PredictScale (src/MapPoint.cc:531-546, a logf and a ceil); projection, window search, the greedy
+ * assignment in key-frame index order and the rotation histogram are done here. */
+typedef struct {
+  int n1;                      /* pKF->GetMapPointMatches().size() */
+  const uint8_t* valid1;       /* pMP != NULL && !pMP->isBad() && !sAlreadyFound.count(pMP) &&
+                                  minDistance <= |x3Dw - Ow| <= maxDistance (GetMin/MaxDistanceInvariance) */
+  const float* world_pos1;     /* pMP->GetWorldPos(), 3 floats per point */
+  const uint8_t* mp_desc1;     /* pMP->GetDescriptor(), 32 bytes per point */
+  const int32_t* level1;       /* pMP->PredictScale(dist3D, &CurrentFrame) */
+  const float* angle1;         /* pKF->mvKeysUn[i].angle */
+  int n2;                      /* CurrentFrame.N (<= 65535) */
+  const float* kp2_xy;         /* CurrentFrame.mvKeysUn[i].pt */
+  const int32_t* kp2_octave;
+  const float* kp2_angle;
+  const uint8_t* desc2;        /* CurrentFrame.mDescriptors */
+  const uint8_t* occupied2;    /* CurrentFrame.mvpMapPoints[i] != NULL on entry (nullable: none) */
+  float grid[6];               /* Frame::mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv */
+  float Tcw_q[4], Tcw_t[3];    /* CurrentFrame.GetPose(): unit_quaternion() as (x, y, z, w), translation() */
+  float K[4];                  /* fx, fy, cx, cy of CurrentFrame.mpCamera (Pinhole::project) */
+  const float* scale_factors;  /* CurrentFrame.mvScaleFactors */
+  int n_levels;
+  float th;
+  int orb_dist;                /* ORBdist, 0..255 */
+  int check_orientation;       /* mbCheckOrientation */
+} rgbl_keyframe_projection_input;
+/* Host pointers, synchronous.  match2 (n2 entries): index of the key-frame feature whose map point the call stores in
+ * CurrentFrame.mvpMapPoints[i2], or -1 (entry left as it was).  *out_nmatches = return value of the reference function. */
+int rgbl_search_by_projection_keyframe(rgbl_matcher* h, const rgbl_keyframe_projection_input* in, int32_t* match2,
+                                       int* out_nmatches);
+
 typedef struct {
   int n1;                      /* vpMapPoints.size() */
   const uint8_t* valid1;       /* pMP->mbTrackInView && !(bFarPoints && pMP->mTrackDepth > thFarPoints) && !pMP->isBad() */

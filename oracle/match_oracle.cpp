@@ -301,6 +301,116 @@ extern "C" int orc_search_by_projection(const orc_projection_input* in, int* mat
   return nmatches;
 }
 
+// ---- ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist), ORBmatcher.cc:1889-2010 ----
+namespace {
+// the part of the loop body that needs the MapPoint object (:1908-1937 without the projection): -1 = skipped, else PredictScale
+int kf_point_level(const orc_kf_projection_input* in, int i, const V3& Ow) {
+  if (!in->has_mp1[i] || in->bad1[i] || in->found1[i]) return -1;
+  const V3 PO = {in->world_pos1[3 * i] - Ow.x, in->world_pos1[3 * i + 1] - Ow.y, in->world_pos1[3 * i + 2] - Ow.z};
+  // Eigen's norm(): sqrt of the unrolled 3-term sum x*x + (y*y + z*z)
+  const float dist3D = sqrtf(PO.x * PO.x + (PO.y * PO.y + PO.z * PO.z));
+  const float maxDistance = 1.2f * in->max_dist1[i], minDistance = 0.8f * in->min_dist1[i];
+  if (dist3D < minDistance || dist3D > maxDistance) return -1;
+  // MapPoint::PredictScale(dist3D, &CurrentFrame)
+  const float ratio = in->max_dist1[i] / dist3D;
+  int nScale = (int)ceil(logf(ratio) / in->log_scale_factor);  // ceil(float) promotes to double: exact
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= in->n_levels) nScale = in->n_levels - 1;
+  return nScale;
+}
+V3 camera_centre(const orc_kf_projection_input* in) {  // Tcw.inverse().translation()
+  const float qinv[4] = {-in->Tcw_q[0], -in->Tcw_q[1], -in->Tcw_q[2], in->Tcw_q[3]};
+  return quat_rotate(qinv, V3{-in->Tcw_t[0], -in->Tcw_t[1], -in->Tcw_t[2]});
+}
+}  // namespace
+
+extern "C" void orc_kf_projection_prepass(const orc_kf_projection_input* in, uint8_t* valid1, int32_t* level1) {
+  const V3 Ow = camera_centre(in);
+  for (int i = 0; i < in->n1; ++i) {
+    const int l = kf_point_level(in, i, Ow);
+    valid1[i] = l >= 0;
+    level1[i] = l >= 0 ? l : 0;
+  }
+}
+
+extern "C" int orc_search_by_projection_kf(const orc_kf_projection_input* in, int* match2) {
+  const int COLS = 64, ROWS = 48;
+  const float mnMinX = in->grid[0], mnMinY = in->grid[1], mnMaxX = in->grid[2], mnMaxY = in->grid[3];
+  const float invW = in->grid[4], invH = in->grid[5];
+  std::vector<std::vector<int>> cells((size_t)COLS * ROWS);
+  for (int i = 0; i < in->n2; ++i) {
+    const int px = (int)roundf((in->kp2_xy[2 * i] - mnMinX) * invW), py = (int)roundf((in->kp2_xy[2 * i + 1] - mnMinY) * invH);
+    if (px < 0 || px >= COLS || py < 0 || py >= ROWS) continue;
+    cells[(size_t)px * ROWS + py].push_back(i);
+  }
+  const V3 Ow = camera_centre(in);
+  // CurrentFrame.mvpMapPoints: -2 = a map point from before the call, >= 0 = index of the key-frame feature, -1 = NULL
+  std::vector<int> holder(in->n2, -1);
+  for (int i = 0; i < in->n2; ++i)
+    if (in->occupied2 && in->occupied2[i]) holder[i] = -2;
+  std::vector<int> rot_hist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  int nmatches = 0;
+  for (int i = 0; i < in->n1; ++i) {
+    if (!in->has_mp1[i] || in->bad1[i] || in->found1[i]) continue;
+    const V3 xw = {in->world_pos1[3 * i], in->world_pos1[3 * i + 1], in->world_pos1[3 * i + 2]};
+    const V3 xc = se3_apply(in->Tcw_q, in->Tcw_t, xw);
+    const float u = in->K[0] * xc.x / xc.z + in->K[2], v = in->K[1] * xc.y / xc.z + in->K[3];  // Pinhole::project
+    if (u < mnMinX || u > mnMaxX) continue;
+    if (v < mnMinY || v > mnMaxY) continue;
+    const int nPredictedLevel = kf_point_level(in, i, Ow);
+    if (nPredictedLevel < 0) continue;
+    const float radius = in->th * in->scale_factors[nPredictedLevel];
+    const int minLevel = nPredictedLevel - 1, maxLevel = nPredictedLevel + 1;
+    if (!(u == u) || !(v == v)) continue;
+    const int nMinCellX = std::max(0, (int)floorf((u - mnMinX - radius) * invW));
+    if (nMinCellX >= COLS) continue;
+    const int nMaxCellX = std::min(COLS - 1, (int)ceilf((u - mnMinX + radius) * invW));
+    if (nMaxCellX < 0) continue;
+    const int nMinCellY = std::max(0, (int)floorf((v - mnMinY - radius) * invH));
+    if (nMinCellY >= ROWS) continue;
+    const int nMaxCellY = std::min(ROWS - 1, (int)ceilf((v - mnMinY + radius) * invH));
+    if (nMaxCellY < 0) continue;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    int bestDist = 256, bestIdx2 = -1;
+    const uint8_t* dMP = in->mp_desc1 + 32 * (size_t)i;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+      for (int iy = nMinCellY; iy <= nMaxCellY; ++iy)
+        for (int i2 : cells[(size_t)ix * ROWS + iy]) {
+          if (bCheckLevels) {
+            if (in->kp2_octave[i2] < minLevel) continue;
+            if (maxLevel >= 0 && in->kp2_octave[i2] > maxLevel) continue;
+          }
+          const float distx = in->kp2_xy[2 * i2] - u, disty = in->kp2_xy[2 * i2 + 1] - v;
+          if (!(fabsf(distx) < radius && fabsf(disty) < radius)) continue;
+          if (holder[i2] != -1) continue;  // CurrentFrame.mvpMapPoints[i2] (:1949-1950)
+          const int dist = hamming256(dMP, in->desc2 + 32 * (size_t)i2);
+          if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+    if (bestDist <= in->orb_dist) {
+      holder[bestIdx2] = i;
+      ++nmatches;
+      if (in->check_orientation) {
+        float rot = in->angle1[i] - in->kp2_angle[bestIdx2];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rot_hist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (in->check_orientation) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    three_maxima(rot_hist, HISTO_LENGTH, i1, i2, i3);
+    for (int i = 0; i < HISTO_LENGTH; ++i) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int idx2 : rot_hist[i]) { holder[idx2] = -1; --nmatches; }
+    }
+  }
+  for (int i = 0; i < in->n2; ++i) match2[i] = holder[i] >= 0 ? holder[i] : -1;
+  return nmatches;
+}
+
 // ---- ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints), ORBmatcher.cc:43-213 ----
 // (single camera) with RadiusByViewingCos (:215-221) and Frame::GetFeaturesInArea (src/Frame.cc:747-813)
 extern "C" int orc_search_local_points(const orc_local_points_input* in, int* match2) {

@@ -193,6 +193,43 @@ typedef struct {
  * Returns nmatches exactly as the reference counts it. */
 int orc_search_by_projection(const orc_projection_input* in, int* match2);
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+ * (/root/reference/src/ORBmatcher.cc:1889-2010, single camera; Tracking::Relocalization) with MapPoint::PredictScale
+ * (src/MapPoint.cc:531-546) and GetMin/MaxDistanceInvariance (src/MapPoint.cc:502-512).  Flat arrays, the key frame's map
+ * points as the reference sees them: */
+typedef struct {
+  int n1;                      /* pKF->GetMapPointMatches().size() */
+  const uint8_t* has_mp1;      /* vpMPs[i] != NULL */
+  const uint8_t* bad1;         /* pMP->isBad() */
+  const uint8_t* found1;       /* sAlreadyFound.count(pMP) */
+  const float* world_pos1;     /* pMP->GetWorldPos() */
+  const uint8_t* mp_desc1;     /* pMP->GetDescriptor() */
+  const float* min_dist1;      /* pMP->mfMinDistance (GetMinDistanceInvariance = 0.8f * it) */
+  const float* max_dist1;      /* pMP->mfMaxDistance (GetMaxDistanceInvariance = 1.2f * it; PredictScale uses it raw) */
+  const float* angle1;         /* pKF->mvKeysUn[i].angle */
+  int n2;
+  const float* kp2_xy;         /* CurrentFrame.mvKeysUn[i].pt */
+  const int32_t* kp2_octave;
+  const float* kp2_angle;
+  const uint8_t* desc2;
+  const uint8_t* occupied2;    /* CurrentFrame.mvpMapPoints[i] != NULL on entry */
+  float grid[6];
+  float Tcw_q[4], Tcw_t[3];
+  float K[4];
+  const float* scale_factors;
+  int n_levels;
+  float log_scale_factor;      /* CurrentFrame.mfLogScaleFactor */
+  float th;
+  int orb_dist;
+  int check_orientation;
+} orc_kf_projection_input;
+/* match2[i2] = index of the key-frame feature whose map point the call stores in CurrentFrame.mvpMapPoints[i2], or -1 (left
+ * as it was).  Returns nmatches. */
+int orc_search_by_projection_kf(const orc_kf_projection_input* in, int* match2);
+/* What the caller of the C ABI (the shim) evaluates with the MapPoint objects: valid1[i] (good, not found yet, distance to
+ * the camera centre inside the invariance range) and level1[i] = PredictScale. */
+void orc_kf_projection_prepass(const orc_kf_projection_input* in, uint8_t* valid1, int32_t* level1);
+
 /* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)
  * (/root/reference/src/ORBmatcher.cc:43-213, single camera; called by Tracking::SearchLocalPoints, Tracking.cc:3447):
  * local map points that Frame::isInFrustum found visible are searched around their predicted projection. */

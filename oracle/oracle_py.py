@@ -70,6 +70,61 @@ def search_by_projection(case, th=7.0, mono=False, check_orientation=True):
     return m, n
 
 
+class KfProjectionInput(C.Structure):
+    """orc_kf_projection_input: the key frame's map points as the reference sees them."""
+    _fields_ = [("n1", C.c_int), ("has_mp1", C.c_void_p), ("bad1", C.c_void_p), ("found1", C.c_void_p),
+                ("world_pos1", C.c_void_p), ("mp_desc1", C.c_void_p), ("min_dist1", C.c_void_p), ("max_dist1", C.c_void_p),
+                ("angle1", C.c_void_p), ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p),
+                ("kp2_angle", C.c_void_p), ("desc2", C.c_void_p), ("occupied2", C.c_void_p), ("grid", C.c_float * 6),
+                ("Tcw_q", C.c_float * 4), ("Tcw_t", C.c_float * 3), ("K", C.c_float * 4), ("scale_factors", C.c_void_p),
+                ("n_levels", C.c_int), ("log_scale_factor", C.c_float), ("th", C.c_float), ("orb_dist", C.c_int),
+                ("check_orientation", C.c_int)]
+
+
+def make_kf_projection_input(case, th, orb_dist, check_orientation, keep):
+    """case: dict from tests/parity_checks.make_relocalization_case."""
+    def arr(v, dt):
+        a = np.ascontiguousarray(v, dt)
+        keep.append(a)
+        return a.ctypes.data
+    P = KfProjectionInput()
+    P.n1 = len(case["has_mp1"])
+    P.has_mp1, P.bad1, P.found1 = arr(case["has_mp1"], np.uint8), arr(case["bad1"], np.uint8), arr(case["found1"], np.uint8)
+    P.world_pos1, P.mp_desc1 = arr(case["world_pos1"], np.float32), arr(case["mp_desc1"], np.uint8)
+    P.min_dist1, P.max_dist1 = arr(case["min_dist1"], np.float32), arr(case["max_dist1"], np.float32)
+    P.angle1 = arr(case["angle1"], np.float32)
+    P.n2 = len(case["kp2_xy"])
+    P.kp2_xy, P.kp2_octave = arr(case["kp2_xy"], np.float32), arr(case["kp2_octave"], np.int32)
+    P.kp2_angle, P.desc2 = arr(case["kp2_angle"], np.float32), arr(case["desc2"], np.uint8)
+    P.occupied2 = arr(case["occupied2"], np.uint8)
+    for name, n in (("grid", 6), ("Tcw_q", 4), ("Tcw_t", 3), ("K", 4)):
+        for i in range(n):
+            getattr(P, name)[i] = float(case[name][i])
+    P.scale_factors = arr(case["scale_factors"], np.float32)
+    P.n_levels = len(case["scale_factors"])
+    P.log_scale_factor = float(case["log_scale_factor"])
+    P.th, P.orb_dist, P.check_orientation = float(th), int(orb_dist), int(check_orientation)
+    return P
+
+
+def search_by_projection_kf(case, th=15.0, orb_dist=100, check_orientation=True):
+    keep = []
+    P = make_kf_projection_input(case, th, orb_dist, check_orientation, keep)
+    m = np.zeros(P.n2, np.int32)
+    n = lib().orc_search_by_projection_kf(C.byref(P), _p(m))
+    return m, n
+
+
+def kf_projection_prepass(case):
+    """valid1 / level1 as the caller of rgbl_search_by_projection_keyframe has to provide them."""
+    keep = []
+    P = make_kf_projection_input(case, 1.0, 100, True, keep)
+    valid = np.zeros(P.n1, np.uint8)
+    level = np.zeros(P.n1, np.int32)
+    lib().orc_kf_projection_prepass(C.byref(P), _p(valid), _p(level))
+    return valid, level
+
+
 class LocalPointsInput(C.Structure):
     """orc_local_points_input == rgbl_local_points_input (same layout)."""
     _fields_ = [("n1", C.c_int), ("valid1", C.c_void_p), ("proj1", C.c_void_p), ("level1", C.c_void_p),

@@ -223,6 +223,65 @@ extern "C" int ref_search_by_projection(const orc_projection_input* in, int* mat
   return nm;
 }
 
+// ORBmatcher(0.9, checkOri).SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1889-2010), single
+// camera.  One MapPoint object per key-frame feature that has one; features occupied on entry hold a dummy point.
+extern "C" int ref_search_by_projection_kf(const orc_kf_projection_input* in, int* match2) {
+  GeometricCamera cam;
+  cam.fx = in->K[0]; cam.fy = in->K[1]; cam.cx = in->K[2]; cam.cy = in->K[3];
+  KeyFrame kf;
+  Frame cur;
+  std::vector<MapPoint> points(in->n1);
+  MapPoint before;
+  std::set<MapPoint*> found;
+  kf.N = in->n1;
+  kf.mvKeysUn.resize(in->n1);
+  kf.mvpMapPoints.assign(in->n1, nullptr);
+  for (int i = 0; i < in->n1; ++i) {
+    kf.mvKeysUn[i].angle = in->angle1[i];
+    if (!in->has_mp1[i]) continue;
+    MapPoint& mp = points[i];
+    mp.mWorldPos = Eigen::Vector3f(in->world_pos1[3 * i], in->world_pos1[3 * i + 1], in->world_pos1[3 * i + 2]);
+    mp.mDescriptor = cv::Mat(1, 32, CV_8U);
+    memcpy(mp.mDescriptor.data, in->mp_desc1 + 32 * (size_t)i, 32);
+    mp.bad = in->bad1[i] != 0;
+    mp.mfMinDistance = in->min_dist1[i];
+    mp.mfMaxDistance = in->max_dist1[i];
+    kf.mvpMapPoints[i] = &mp;
+    if (in->found1[i]) found.insert(&mp);
+  }
+  kf.mvKeys = kf.mvKeysUn;
+  cur.N = in->n2;
+  cur.mpCamera = &cam;
+  cur.mvKeysUn.resize(in->n2);
+  for (int i = 0; i < in->n2; ++i) {
+    cur.mvKeysUn[i].pt.x = in->kp2_xy[2 * i]; cur.mvKeysUn[i].pt.y = in->kp2_xy[2 * i + 1];
+    cur.mvKeysUn[i].octave = in->kp2_octave[i]; cur.mvKeysUn[i].angle = in->kp2_angle[i];
+  }
+  cur.mvKeys = cur.mvKeysUn;
+  cur.mvuRight.assign(in->n2, -1.f);
+  cur.mDescriptors = cv::Mat(in->n2, 32, CV_8U);
+  if (in->n2) memcpy(cur.mDescriptors.data, in->desc2, (size_t)in->n2 * 32);
+  cur.mvScaleFactors.assign(in->scale_factors, in->scale_factors + in->n_levels);
+  cur.mnScaleLevels = in->n_levels;
+  cur.mfLogScaleFactor = in->log_scale_factor;
+  cur.mvpMapPoints.assign(in->n2, nullptr);
+  for (int i = 0; i < in->n2; ++i)
+    if (in->occupied2 && in->occupied2[i]) cur.mvpMapPoints[i] = &before;
+  cur.mTcw = Sophus::SE3f(Eigen::Quaternionf(in->Tcw_q[3], in->Tcw_q[0], in->Tcw_q[1], in->Tcw_q[2]),
+                          Eigen::Vector3f(in->Tcw_t[0], in->Tcw_t[1], in->Tcw_t[2]));
+  Frame::mnMinX = cur.grid.mnMinX = in->grid[0]; Frame::mnMinY = cur.grid.mnMinY = in->grid[1];
+  Frame::mnMaxX = cur.grid.mnMaxX = in->grid[2]; Frame::mnMaxY = cur.grid.mnMaxY = in->grid[3];
+  cur.grid.mfGridElementWidthInv = in->grid[4]; cur.grid.mfGridElementHeightInv = in->grid[5];
+  cur.grid.Build(cur.mvKeysUn);
+  ORBmatcher matcher(0.9f, in->check_orientation != 0);
+  const int nm = matcher.SearchByProjection(cur, &kf, found, in->th, in->orb_dist);
+  for (int i = 0; i < in->n2; ++i) {
+    MapPoint* p = cur.mvpMapPoints[i];
+    match2[i] = (p && p != &before) ? (int)(p - points.data()) : -1;
+  }
+  return nm;
+}
+
 // ORBmatcher(nnratio, true).SearchByProjection(F, vpMapPoints, th, bFarPoints = false, thFarPoints) (ORBmatcher.cc:43-213).
 // valid1 folds mbTrackInView / isBad; features blocked on entry hold a dummy point with observations.
 extern "C" int ref_search_local_points(const orc_local_points_input* in, int* match2) {

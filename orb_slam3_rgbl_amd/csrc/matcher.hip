@@ -180,6 +180,8 @@ struct ProjDev {
   const uint8_t* desc2;
   float grid[6], q[4], t[3], K[4], mbf, th, scale[kProjMaxLevels];
   int forward, backward;
+  int skip_behind;           // 1: points with 1/z < 0 are skipped (Frame-to-Frame overload, :1709-1712); the key-frame overload has no such test
+  int max_dist;              // a candidate is viable up to this Hamming distance (TH_HIGH / ORBdist)
   // the vpMapPoints overload (ORBmatcher.cc:43-213) instead of wpos1 / oct1 / q / t / K:
   const float* proj1;        // mTrackProjX, mTrackProjY, mTrackProjXR
   const int32_t* level1;     // mnTrackScaleLevel
@@ -227,7 +229,7 @@ __device__ __forceinline__ void for_candidates(const ProjDev& P, const float4& w
         }
         const float dx = P.xy2[2 * c] - w.x, dy = P.xy2[2 * c + 1] - w.y;
         if (!(fabsf(dx) < w.z && fabsf(dy) < w.z)) continue;
-        const float ur = P.ur2[c];
+        const float ur = P.ur2 ? P.ur2[c] : -1.f;  // no stereo coordinate test in the key-frame overload
         if (ur > 0 && fabsf(w.w - ur) > w.z) continue;
         f(c, cell);
       }
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(64) void k_proj_candidates(ProjDev P) {
     const float invzc = (float)(1.0 / (double)z);
     const float u = __fdiv_rn(P.K[0] * x, z) + P.K[2], v = __fdiv_rn(P.K[1] * y, z) + P.K[3];
     // NaN / inf coordinates never produce candidates in the reference either (empty cell range)
-    if (!(invzc < 0) && u == u && v == v && !(u < P.grid[0] || u > P.grid[2]) && !(v < P.grid[1] || v > P.grid[3])) {
+    if (!(P.skip_behind && invzc < 0) && u == u && v == v && !(u < P.grid[0] || u > P.grid[2]) && !(v < P.grid[1] || v > P.grid[3])) {
       const int oct = P.oct1[i];
       const float radius = P.th * P.scale[oct];
       int min_level, max_level;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(64) void k_proj_candidates(ProjDev P) {
         int total = 0;
         for_candidates(P, w, r, [&](int c, int cell) {
           const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
-          if (dist > 100 /* TH_HIGH */) return;
+          if (dist > P.max_dist) return;
           if (total < kProjCand) P.cand[(size_t)i * kProjCand + total] = proj_key(dist, cell, c);
           ++total;
         });
@@ -345,7 +347,7 @@ __device__ __forceinline__ unsigned long long proj_best(const ProjDev& P, int i)
   for_candidates(P, P.win[i], P.rng[i], [&](int c, int cell) {
     if (P.taken_by[c] < i) return;
     const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
-    if (dist > 100) return;
+    if (dist > P.max_dist) return;
     const unsigned long long key = proj_key(dist, cell, c);
     if (key < best) best = key;
   });
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(kProjBS) void k_proj_resolve(ProjDev P) {
         const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
         for_candidates(P, P.win[i], P.rng[i], [&](int c, int) {
           if (P.taken_by[c] < i) return;
-          if (hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)) <= 100) atomicMin(&P.min_unres[c], i);
+          if (hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)) <= P.max_dist) atomicMin(&P.min_unres[c], i);
         });
       }
     }
@@ -930,21 +932,28 @@ static void three_maxima(const std::vector<int>* hist, int L, int& i1, int& i2, 
   else if (max3 < 0.1f * (float)max1) { i3 = -1; }
 }
 
-int rgbl_search_by_projection(rgbl_matcher* m, const rgbl_projection_input* in, int32_t* match2, int* out_nmatches) {
-  if (!m || !in || !match2 || !out_nmatches || in->n1 < 0 || in->n2 < 0 || in->n2 > 65535 || in->n_levels < 1 ||
-      in->n_levels > kProjMaxLevels) {
-    set_error("invalid argument (CurrentFrame may hold at most 65535 features, %d pyramid levels)", kProjMaxLevels);
-    return RGBL_ERR_INVALID;
-  }
+// what the two greedy, best-only projection matchers (Frame-to-Frame and key-frame-to-Frame) hand to the kernels
+namespace {
+struct ProjHost {
+  int n1, n2, n_levels;
+  const uint8_t *valid1, *obs1 /* nullptr: every point blocks */, *mpdesc1, *desc2, *blocked2 /* nullable */;
+  const float *wpos1, *angle1, *xy2, *angle2, *ur2 /* nullable */, *scale_factors;
+  const int32_t *oct1, *oct2;
+  const float *grid, *Tcw_q, *Tcw_t, *K;
+  float mbf, th;
+  int forward, backward, skip_behind, max_dist, check_orientation;
+};
+
+int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* out_nmatches) {
   *out_nmatches = 0;
-  const int n1 = in->n1, n2 = in->n2;
+  const int n1 = in.n1, n2 = in.n2;
   for (int i = 0; i < n2; ++i) match2[i] = -1;
   if (n1 == 0 || n2 == 0) return RGBL_OK;
   for (int i = 0; i < n1; ++i)
-    if (in->valid1[i] && (in->octave1[i] < 0 || in->octave1[i] >= in->n_levels)) { set_error("octave out of range"); return RGBL_ERR_INVALID; }
+    if (in.valid1[i] && (in.oct1[i] < 0 || in.oct1[i] >= in.n_levels)) { set_error("octave out of range"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipSetDevice(m->device));
   size_t need = pad256(n1) * 2 + pad256((size_t)n1 * 12) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 8) +
-                pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 3 +
+                pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 3 + pad256(n2) +
                 pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 + pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) +
                 pad256((size_t)(kGridCells + 1) * 4);
   RGBL_TRY(ensure_arena(m, need));
@@ -952,16 +961,20 @@ int rgbl_search_by_projection(rgbl_matcher* m, const rgbl_projection_input* in, 
   hipStream_t s = m->stream;
   ProjDev P;
   P.n1 = n1; P.n2 = n2;
-  P.proj1 = nullptr; P.level1 = nullptr; P.viewcos1 = nullptr; P.blocked2 = nullptr; P.nnratio = 0.f;
-  RGBL_TRY(upload(A, s, &P.valid1, in->valid1, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.obs1, in->mp_observed1, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.wpos1, in->world_pos1, (size_t)n1 * 3));
-  RGBL_TRY(upload(A, s, &P.mpdesc1, in->mp_desc1, (size_t)n1 * 32));
-  RGBL_TRY(upload(A, s, &P.oct1, in->octave1, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.xy2, in->kp2_xy, (size_t)n2 * 2));
-  RGBL_TRY(upload(A, s, &P.oct2, in->kp2_octave, (size_t)n2));
-  RGBL_TRY(upload(A, s, &P.ur2, in->uright2, (size_t)n2));
-  RGBL_TRY(upload(A, s, &P.desc2, in->desc2, (size_t)n2 * 32));
+  P.proj1 = nullptr; P.level1 = nullptr; P.viewcos1 = nullptr; P.blocked2 = nullptr; P.ur2 = nullptr; P.nnratio = 0.f;
+  std::vector<uint8_t> all_block;
+  const uint8_t* obs1 = in.obs1;
+  if (!obs1) { all_block.assign(n1, 1); obs1 = all_block.data(); }
+  RGBL_TRY(upload(A, s, &P.valid1, in.valid1, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.obs1, obs1, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.wpos1, in.wpos1, (size_t)n1 * 3));
+  RGBL_TRY(upload(A, s, &P.mpdesc1, in.mpdesc1, (size_t)n1 * 32));
+  RGBL_TRY(upload(A, s, &P.oct1, in.oct1, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.xy2, in.xy2, (size_t)n2 * 2));
+  RGBL_TRY(upload(A, s, &P.oct2, in.oct2, (size_t)n2));
+  if (in.ur2) RGBL_TRY(upload(A, s, &P.ur2, in.ur2, (size_t)n2));
+  if (in.blocked2) RGBL_TRY(upload(A, s, &P.blocked2, in.blocked2, (size_t)n2));
+  RGBL_TRY(upload(A, s, &P.desc2, in.desc2, (size_t)n2 * 32));
   P.cell_start = A.take<uint32_t>(kGridCells + 1);
   P.cell_items = A.take<uint16_t>(n2);
   P.taken_by = A.take<int32_t>(n2);
@@ -972,24 +985,15 @@ int rgbl_search_by_projection(rgbl_matcher* m, const rgbl_projection_input* in, 
   P.ncand = A.take<uint8_t>(n1);
   P.state = A.take<uint8_t>(n1);
   P.choice = A.take<int32_t>(n1);
-  memcpy(P.grid, in->grid, sizeof(P.grid));
-  memcpy(P.q, in->Tcw_q, sizeof(P.q));
-  memcpy(P.t, in->Tcw_t, sizeof(P.t));
-  memcpy(P.K, in->K, sizeof(P.K));
-  P.mbf = in->mbf;
-  P.th = in->th;
-  for (int l = 0; l < kProjMaxLevels; ++l) P.scale[l] = l < in->n_levels ? in->scale_factors[l] : 1.f;
-  {
-    // bForward / bBackward (ORBmatcher.cc:1686-1694): tlc = Tlw * Tcw.inverse().translation(), Sophus / Eigen arithmetic
-    const float qi[4] = {-in->Tcw_q[0], -in->Tcw_q[1], -in->Tcw_q[2], in->Tcw_q[3]};
-    float wx, wy, wz, lx, ly, lz;
-    quat_rotate(qi, -in->Tcw_t[0], -in->Tcw_t[1], -in->Tcw_t[2], &wx, &wy, &wz);
-    quat_rotate(in->Tlw_q, wx, wy, wz, &lx, &ly, &lz);
-    lz += in->Tlw_t[2];
-    (void)lx; (void)ly;
-    P.forward = (lz > in->mb && !in->mono) ? 1 : 0;
-    P.backward = (-lz > in->mb && !in->mono) ? 1 : 0;
-  }
+  memcpy(P.grid, in.grid, sizeof(P.grid));
+  memcpy(P.q, in.Tcw_q, sizeof(P.q));
+  memcpy(P.t, in.Tcw_t, sizeof(P.t));
+  memcpy(P.K, in.K, sizeof(P.K));
+  P.mbf = in.mbf;
+  P.th = in.th;
+  for (int l = 0; l < kProjMaxLevels; ++l) P.scale[l] = l < in.n_levels ? in.scale_factors[l] : 1.f;
+  P.forward = in.forward; P.backward = in.backward;
+  P.skip_behind = in.skip_behind; P.max_dist = in.max_dist;
   m->timer.begin("k_proj_grid", s);
   hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
   m->timer.end(s);
@@ -1005,7 +1009,7 @@ int rgbl_search_by_projection(rgbl_matcher* m, const rgbl_projection_input* in, 
   RGBL_HIP(hipStreamSynchronize(s));
   m->timer.collect();
   // what the loop leaves in CurrentFrame.mvpMapPoints (a later point overwrites an unobserved earlier one), the match
-  // count, and the rotation-consistency pass (ORBmatcher.cc:1768-1790, 1860-1884)
+  // count, and the rotation-consistency pass (ORBmatcher.cc:1768-1790, 1860-1884 / 1961-2006)
   int nmatches = 0;
   std::vector<int> hist[30];
   const float factor = 1.0f / 30;
@@ -1014,15 +1018,15 @@ int rgbl_search_by_projection(rgbl_matcher* m, const rgbl_projection_input* in, 
     if (c < 0) continue;
     match2[c] = i;
     ++nmatches;
-    if (in->check_orientation) {
-      float rot = in->angle1[i] - in->kp2_angle[c];
+    if (in.check_orientation) {
+      float rot = in.angle1[i] - in.angle2[c];
       if (rot < 0.0) rot += 360.0f;
       int bin = (int)roundf(rot * factor);
       if (bin == 30) bin = 0;
       if (bin >= 0 && bin < 30) hist[bin].push_back(c);
     }
   }
-  if (in->check_orientation) {
+  if (in.check_orientation) {
     int i1, i2, i3;
     three_maxima(hist, 30, i1, i2, i3);
     for (int i = 0; i < 30; ++i) {
@@ -1032,6 +1036,62 @@ int rgbl_search_by_projection(rgbl_matcher* m, const rgbl_projection_input* in, 
   }
   *out_nmatches = nmatches;
   return RGBL_OK;
+}
+}  // namespace
+
+int rgbl_search_by_projection(rgbl_matcher* m, const rgbl_projection_input* in, int32_t* match2, int* out_nmatches) {
+  if (!m || !in || !match2 || !out_nmatches || in->n1 < 0 || in->n2 < 0 || in->n2 > 65535 || in->n_levels < 1 ||
+      in->n_levels > kProjMaxLevels) {
+    set_error("invalid argument (CurrentFrame may hold at most 65535 features, %d pyramid levels)", kProjMaxLevels);
+    return RGBL_ERR_INVALID;
+  }
+  ProjHost h{};
+  h.n1 = in->n1; h.n2 = in->n2; h.n_levels = in->n_levels;
+  h.valid1 = in->valid1; h.obs1 = in->mp_observed1; h.mpdesc1 = in->mp_desc1; h.desc2 = in->desc2; h.blocked2 = nullptr;
+  h.wpos1 = in->world_pos1; h.angle1 = in->angle1; h.xy2 = in->kp2_xy; h.angle2 = in->kp2_angle; h.ur2 = in->uright2;
+  h.scale_factors = in->scale_factors; h.oct1 = in->octave1; h.oct2 = in->kp2_octave;
+  h.grid = in->grid; h.Tcw_q = in->Tcw_q; h.Tcw_t = in->Tcw_t; h.K = in->K;
+  h.mbf = in->mbf; h.th = in->th;
+  {
+    // bForward / bBackward (ORBmatcher.cc:1686-1694): tlc = Tlw * Tcw.inverse().translation(), Sophus / Eigen arithmetic
+    const float qi[4] = {-in->Tcw_q[0], -in->Tcw_q[1], -in->Tcw_q[2], in->Tcw_q[3]};
+    float wx, wy, wz, lx, ly, lz;
+    quat_rotate(qi, -in->Tcw_t[0], -in->Tcw_t[1], -in->Tcw_t[2], &wx, &wy, &wz);
+    quat_rotate(in->Tlw_q, wx, wy, wz, &lx, &ly, &lz);
+    lz += in->Tlw_t[2];
+    (void)lx; (void)ly;
+    h.forward = (lz > in->mb && !in->mono) ? 1 : 0;
+    h.backward = (-lz > in->mb && !in->mono) ? 1 : 0;
+  }
+  h.skip_behind = 1;
+  h.max_dist = 100;  // TH_HIGH
+  h.check_orientation = in->check_orientation;
+  return projection_core(m, h, match2, out_nmatches);
+}
+
+// int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+// (src/ORBmatcher.cc:1889-2010): the same greedy best-only search; every matched feature is occupied for the points after it
+// (CurrentFrame.mvpMapPoints[i2] != NULL, :1949-1950), as are the features that hold a map point on entry; levels
+// [predicted - 1, predicted + 1], radius th * scale[predicted], no stereo-coordinate test and no test of the sign of the depth.
+int rgbl_search_by_projection_keyframe(rgbl_matcher* m, const rgbl_keyframe_projection_input* in, int32_t* match2,
+                                       int* out_nmatches) {
+  if (!m || !in || !match2 || !out_nmatches || in->n1 < 0 || in->n2 < 0 || in->n2 > 65535 || in->n_levels < 1 ||
+      in->n_levels > kProjMaxLevels || in->orb_dist < 0 || in->orb_dist > 255) {
+    set_error("invalid argument (CurrentFrame may hold at most 65535 features, %d pyramid levels, ORBdist 0..255)", kProjMaxLevels);
+    return RGBL_ERR_INVALID;
+  }
+  ProjHost h{};
+  h.n1 = in->n1; h.n2 = in->n2; h.n_levels = in->n_levels;
+  h.valid1 = in->valid1; h.obs1 = nullptr; h.mpdesc1 = in->mp_desc1; h.desc2 = in->desc2; h.blocked2 = in->occupied2;
+  h.wpos1 = in->world_pos1; h.angle1 = in->angle1; h.xy2 = in->kp2_xy; h.angle2 = in->kp2_angle; h.ur2 = nullptr;
+  h.scale_factors = in->scale_factors; h.oct1 = in->level1; h.oct2 = in->kp2_octave;
+  h.grid = in->grid; h.Tcw_q = in->Tcw_q; h.Tcw_t = in->Tcw_t; h.K = in->K;
+  h.mbf = 0.f; h.th = in->th;
+  h.forward = 0; h.backward = 0;  // levels predicted - 1 ... predicted + 1
+  h.skip_behind = 0;
+  h.max_dist = in->orb_dist;
+  h.check_orientation = in->check_orientation;
+  return projection_core(m, h, match2, out_nmatches);
 }
 
 int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in, int32_t* match2, int* out_nmatches) {

@@ -338,6 +338,53 @@ class ORBmatcher:
         L.check(self.lib, self.lib.rgbl_search_by_projection(self.h, C.byref(P), L.ptr(match2), C.byref(n)))
         return match2, n.value
 
+    @staticmethod
+    def PredictScale(dist3D, mfMaxDistance, mfLogScaleFactor, mnScaleLevels):
+        """MapPoint::PredictScale(currentDist, Frame*) (src/MapPoint.cc:531-546) for arrays: ceil(logf(max / dist) / logScale),
+        clamped to the pyramid; logf is the C library's (what std::log(float) calls), not numpy's."""
+        libm = C.CDLL("libm.so.6")
+        libm.logf.restype, libm.logf.argtypes = C.c_float, [C.c_float]
+        d = np.asarray(dist3D, np.float32)
+        ratio = np.asarray(mfMaxDistance, np.float32) / d
+        lsf = np.float32(mfLogScaleFactor)
+        out = np.zeros(len(d), np.int32)
+        for i, r in enumerate(ratio):
+            q = np.float32(libm.logf(float(r))) / lsf
+            n = int(np.ceil(q)) if np.isfinite(q) else (0 if q < 0 else int(mnScaleLevels))
+            out[i] = min(max(n, 0), int(mnScaleLevels) - 1)
+        return out
+
+    def SearchByProjectionKeyFrame(self, kf, th, ORBdist):
+        """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1889-2010), the matcher
+        of Tracking::Relocalization.  kf: dict with the key-frame map point arrays valid1 (has a good map point that is not in
+        sAlreadyFound and whose distance to the camera centre is inside its scale-invariance range), world_pos1, mp_desc1,
+        level1 (PredictScale), angle1, the CurrentFrame arrays kp2_xy, kp2_octave, kp2_angle, desc2, occupied2, and grid[6],
+        Tcw_q / Tcw_t, K[4], scale_factors.  Returns (match2: key-frame feature index per frame feature or -1, nmatches)."""
+        keep = []
+
+        def arr(v, dt):
+            a = np.ascontiguousarray(v, dt)
+            keep.append(a)
+            return a.ctypes.data
+        P = L.KeyFrameProjectionInput()
+        P.n1 = len(kf["valid1"])
+        P.valid1, P.world_pos1 = arr(kf["valid1"], np.uint8), arr(kf["world_pos1"], np.float32)
+        P.mp_desc1, P.level1, P.angle1 = arr(kf["mp_desc1"], np.uint8), arr(kf["level1"], np.int32), arr(kf["angle1"], np.float32)
+        P.n2 = len(kf["kp2_xy"])
+        P.kp2_xy, P.kp2_octave = arr(kf["kp2_xy"], np.float32), arr(kf["kp2_octave"], np.int32)
+        P.kp2_angle, P.desc2 = arr(kf["kp2_angle"], np.float32), arr(kf["desc2"], np.uint8)
+        P.occupied2 = arr(kf["occupied2"], np.uint8)
+        for name, n in (("grid", 6), ("Tcw_q", 4), ("Tcw_t", 3), ("K", 4)):
+            for i in range(n):
+                getattr(P, name)[i] = float(kf[name][i])
+        P.scale_factors = arr(kf["scale_factors"], np.float32)
+        P.n_levels = len(kf["scale_factors"])
+        P.th, P.orb_dist, P.check_orientation = float(th), int(ORBdist), int(self.mbCheckOrientation)
+        match2 = np.zeros(P.n2, np.int32)
+        n = C.c_int(0)
+        L.check(self.lib, self.lib.rgbl_search_by_projection_keyframe(self.h, C.byref(P), L.ptr(match2), C.byref(n)))
+        return match2, n.value
+
     def SearchLocalPoints(self, pts, th):
         """ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) (ORBmatcher.cc:43-213), the call of
         Tracking::SearchLocalPoints.  pts: dict with the map point arrays valid1, proj1 [n,3] (mTrackProjX, mTrackProjY,

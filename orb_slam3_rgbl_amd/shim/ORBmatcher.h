@@ -21,6 +21,7 @@
 #include <iostream>
 #include <mutex>
 #include <utility>
+#include <set>
 #include <vector>
 
 #include "../../include/rgbl_frontend.h"
@@ -197,6 +198,71 @@ class ORBmatcher {
     }
     for (int i2 = 0; i2 < n2; ++i2)
       if (match2[i2] >= 0) CurrentFrame.mvpMapPoints[i2] = LastFrame.mvpMapPoints[match2[i2]];
+    return nmatches;
+  }
+
+  // Project MapPoints seen in KeyFrame into the Frame and search matches.  Used in relocalisation (Tracking::Relocalization,
+  // Tracking.cc:3723-3752).  ORBmatcher.h:51, ORBmatcher.cc:1889-2010.  What needs the MapPoint objects is evaluated here
+  // exactly as the reference loop does (isBad, sAlreadyFound, the scale-invariance range around |x3Dw - Ow|, PredictScale);
+  // projection, window search and the assignment in key-frame index order run on the device.
+  template <class FrameT, class KeyFrameT, class MapPointT>
+  int SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const std::set<MapPointT*>& sAlreadyFound, const float th,
+                         const int ORBdist) {
+    if (!mpHandle) return 0;
+    if (CurrentFrame.Nleft != -1) {
+      std::cerr << "[ORBmatcher] SearchByProjection: fisheye stereo rigs (Nleft != -1) are not covered by the device path" << std::endl;
+      return 0;
+    }
+    const auto Tcw = CurrentFrame.GetPose();
+    const auto Ow = Tcw.inverse().translation();
+    const std::vector<MapPointT*> vpMPs = pKF->GetMapPointMatches();
+    const int n1 = (int)vpMPs.size(), n2 = CurrentFrame.N;
+    std::vector<uint8_t> valid(n1, 0), desc1((size_t)n1 * 32, 0), occupied(n2, 0);
+    std::vector<float> pos((size_t)n1 * 3, 0.f), angle1(n1, 0.f), xy2((size_t)n2 * 2), angle2(n2);
+    std::vector<int32_t> level1(n1, 0), oct2(n2);
+    for (int i = 0; i < n1; ++i) {
+      angle1[i] = pKF->mvKeysUn[i].angle;
+      MapPointT* pMP = vpMPs[i];
+      if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+      const auto x3Dw = pMP->GetWorldPos();
+      const auto PO = x3Dw - Ow;
+      const float dist3D = PO.norm();
+      if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) continue;
+      valid[i] = 1;
+      level1[i] = pMP->PredictScale(dist3D, &CurrentFrame);
+      for (int k = 0; k < 3; ++k) pos[3 * (size_t)i + k] = x3Dw(k);
+      const cv::Mat dMP = pMP->GetDescriptor();
+      memcpy(&desc1[(size_t)i * 32], dMP.ptr<uint8_t>(), 32);
+    }
+    for (int i = 0; i < n2; ++i) {
+      xy2[2 * (size_t)i] = CurrentFrame.mvKeysUn[i].pt.x;
+      xy2[2 * (size_t)i + 1] = CurrentFrame.mvKeysUn[i].pt.y;
+      oct2[i] = CurrentFrame.mvKeysUn[i].octave;
+      angle2[i] = CurrentFrame.mvKeysUn[i].angle;
+      occupied[i] = CurrentFrame.mvpMapPoints[i] ? 1 : 0;
+    }
+    rgbl_keyframe_projection_input in;
+    in.n1 = n1; in.valid1 = valid.data(); in.world_pos1 = pos.data(); in.mp_desc1 = desc1.data();
+    in.level1 = level1.data(); in.angle1 = angle1.data();
+    in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.kp2_angle = angle2.data();
+    in.desc2 = CurrentFrame.mDescriptors.template ptr<uint8_t>(); in.occupied2 = occupied.data();
+    in.grid[0] = FrameT::mnMinX; in.grid[1] = FrameT::mnMinY; in.grid[2] = FrameT::mnMaxX; in.grid[3] = FrameT::mnMaxY;
+    in.grid[4] = FrameT::mfGridElementWidthInv; in.grid[5] = FrameT::mfGridElementHeightInv;
+    in.Tcw_q[0] = Tcw.unit_quaternion().x(); in.Tcw_q[1] = Tcw.unit_quaternion().y(); in.Tcw_q[2] = Tcw.unit_quaternion().z();
+    in.Tcw_q[3] = Tcw.unit_quaternion().w();
+    for (int k = 0; k < 3; ++k) in.Tcw_t[k] = Tcw.translation()(k);
+    for (int k = 0; k < 4; ++k) in.K[k] = CurrentFrame.mpCamera->getParameter(k);
+    in.scale_factors = CurrentFrame.mvScaleFactors.data();
+    in.n_levels = (int)CurrentFrame.mvScaleFactors.size();
+    in.th = th; in.orb_dist = ORBdist; in.check_orientation = mbCheckOrientation;
+    std::vector<int32_t> match2(n2, -1);
+    int nmatches = 0;
+    if (rgbl_search_by_projection_keyframe(mpHandle, &in, match2.data(), &nmatches) != RGBL_OK) {
+      std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
+      return 0;
+    }
+    for (int i2 = 0; i2 < n2; ++i2)
+      if (match2[i2] >= 0) CurrentFrame.mvpMapPoints[i2] = vpMPs[match2[i2]];
     return nmatches;
   }
 

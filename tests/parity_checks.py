@@ -507,6 +507,66 @@ def check_search_by_projection(lib, seed=21, motion="forward", th=7.0, mono=Fals
     return n
 
 
+def make_relocalization_case(n1=1500, n2=2000, seed=61):
+    """A key frame whose map points are searched in a frame with a (PnP-refined) pose: SearchByProjection(CurrentFrame, pKF,
+    sAlreadyFound, th, ORBdist).  Built on the Frame-to-Frame case: same clusters / duplicate targets; on top of it points
+    without a map point, bad and already-found ones, scale-invariance ranges that exclude some points, features of the
+    frame that hold a map point on entry, and points behind the camera (the overload does not test the sign of the depth)."""
+    c = make_projection_case(n1, n2, seed, "none")
+    rng = np.random.default_rng(seed + 1000)
+    qc, tc = c["Tcw_q"], c["Tcw_t"]
+    Rc = _rot(qc)
+    Ow = (-Rc.T @ tc.astype(np.float64))
+    dist = np.linalg.norm(c["world_pos1"].astype(np.float64) - Ow, axis=1)
+    # mfMaxDistance = dist * scale^level of the observation that made the point: predicted levels spread over the pyramid
+    lvl = c["octave1"].astype(np.int64)                          # near the octave of the feature the point aims at
+    max_d = (dist * 1.2 ** lvl * rng.uniform(0.85, 1.0, n1)).astype(np.float32)
+    min_d = (max_d / np.float32(1.2 ** 7)).astype(np.float32)
+    far = rng.random(n1) < 0.05
+    max_d[far] = (dist[far] * 0.5).astype(np.float32)          # outside the invariance range (too far)
+    near = rng.random(n1) < 0.03
+    min_d[near] = (dist[near] * 2.0).astype(np.float32)        # too close
+    return dict(has_mp1=(rng.random(n1) < 0.85).astype(np.uint8), bad1=(rng.random(n1) < 0.05).astype(np.uint8),
+                found1=(rng.random(n1) < 0.15).astype(np.uint8), world_pos1=c["world_pos1"], mp_desc1=c["mp_desc1"],
+                min_dist1=min_d, max_dist1=max_d, angle1=c["angle1"], kp2_xy=c["kp2_xy"], kp2_octave=c["kp2_octave"],
+                kp2_angle=c["kp2_angle"], desc2=c["desc2"], occupied2=(rng.random(n2) < 0.1).astype(np.uint8),
+                grid=c["grid"], Tcw_q=qc, Tcw_t=tc, K=c["K"], scale_factors=c["scale_factors"],
+                log_scale_factor=np.float32(np.log(np.float32(1.2))))
+
+
+def relocalization_prepass(case):
+    """What the shim evaluates with the MapPoint objects, written with numpy float32 + the C library's logf
+    (F.ORBmatcher.PredictScale): must equal the oracle's prepass bit for bit."""
+    q, t = np.asarray(case["Tcw_q"], np.float32), np.asarray(case["Tcw_t"], np.float32)
+
+    def rotate(qv, p):  # Eigen QuaternionBase::_transformVector in float32
+        u = np.float32(2) * np.cross(qv[:3], p).astype(np.float32)
+        return (p + qv[3] * u + np.cross(qv[:3], u).astype(np.float32)).astype(np.float32)
+    qinv = np.array([-q[0], -q[1], -q[2], q[3]], np.float32)
+    Ow = rotate(qinv, (-t).astype(np.float32))
+    PO = (np.asarray(case["world_pos1"], np.float32) - Ow).astype(np.float32)
+    sq = (PO * PO).astype(np.float32)
+    dist = np.sqrt((sq[:, 0] + (sq[:, 1] + sq[:, 2]).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    max_inv = (np.float32(1.2) * case["max_dist1"]).astype(np.float32)
+    min_inv = (np.float32(0.8) * case["min_dist1"]).astype(np.float32)
+    valid = (case["has_mp1"] != 0) & (case["bad1"] == 0) & (case["found1"] == 0) & ~(dist < min_inv) & ~(dist > max_inv)
+    level = F.ORBmatcher.PredictScale(dist, case["max_dist1"], case["log_scale_factor"], len(case["scale_factors"]))
+    return valid.astype(np.uint8), np.where(valid, level, 0).astype(np.int32)
+
+
+def check_search_by_projection_keyframe(lib, seed=61, th=15.0, orb_dist=100, check_ori=True, n1=1500, n2=2000):
+    case = make_relocalization_case(n1, n2, seed)
+    valid, level = relocalization_prepass(case)
+    ovalid, olevel = O.kf_projection_prepass(case)
+    assert np.array_equal(valid, ovalid) and np.array_equal(level[valid != 0], olevel[valid != 0]), "relocalisation prepass"
+    mt = F.ORBmatcher(0.9, check_ori, lib=lib)
+    m, n = mt.SearchByProjectionKeyFrame(dict(case, valid1=valid, level1=level), th, orb_dist)
+    om, on = O.search_by_projection_kf(case, th, orb_dist, check_ori)
+    assert n == on and np.array_equal(m, om), "SearchByProjection(Frame, KeyFrame) (seed %d, th %g, ORBdist %d)" % (seed, th, orb_dist)
+    mt.close()
+    return n
+
+
 def check_search_by_projection_edge_cases(lib):
     mt = F.ORBmatcher(0.9, True, lib=lib)
     # (a) nothing to match

@@ -73,12 +73,25 @@ def run_and_check(exe, tmp):
                         ("mp_desc1", np.uint8), ("mp_observed1", np.uint8), ("kp2_xy", np.float32), ("kp2_octave", np.int32),
                         ("uright2", np.float32), ("desc2", np.uint8), ("blocked2", np.uint8)):
             f.write(np.ascontiguousarray(lcase[key], dt).tobytes())
+    rcase = pc.make_relocalization_case(1400, 1600, seed=71)
+    with open(os.path.join(tmp, "reloc.bin"), "wb") as f:
+        f.write(struct.pack("<iifii", len(rcase["has_mp1"]), len(rcase["kp2_xy"]), 10.0, 100, 1))
+        hdr = np.concatenate([rcase["grid"], rcase["Tcw_q"], rcase["Tcw_t"], rcase["K"], rcase["scale_factors"],
+                              [rcase["log_scale_factor"]]]).astype(np.float32)
+        assert hdr.size == 26
+        f.write(hdr.tobytes())
+        for key, dt in (("has_mp1", np.uint8), ("bad1", np.uint8), ("found1", np.uint8), ("world_pos1", np.float32),
+                        ("mp_desc1", np.uint8), ("min_dist1", np.float32), ("max_dist1", np.float32), ("angle1", np.float32),
+                        ("kp2_xy", np.float32), ("kp2_octave", np.int32), ("kp2_angle", np.float32), ("desc2", np.uint8),
+                        ("occupied2", np.uint8)):
+            f.write(np.ascontiguousarray(rcase[key], dt).tobytes())
     voc = synth.make_vocabulary(10, 3, seed=5)
     synth.write_vocabulary_text(os.path.join(tmp, "voc.txt"), voc)
     out = os.path.join(tmp, "out.bin")
     res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "KITTI00-02.yaml"), os.path.join(tmp, "img.raw"), str(w), str(h),
                           os.path.join(tmp, "cloud.raw"), str(cloud.shape[1]), os.path.join(tmp, "tri.bin"), out,
-                          os.path.join(tmp, "proj.bin"), os.path.join(tmp, "local.bin"), os.path.join(tmp, "voc.txt")],
+                          os.path.join(tmp, "proj.bin"), os.path.join(tmp, "local.bin"), os.path.join(tmp, "voc.txt"),
+                          os.path.join(tmp, "reloc.bin")],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "Lidar Method: InverseDilation" in res.stdout
@@ -125,7 +138,11 @@ def run_and_check(exe, tmp):
     for _ in range(nn):
         nid, cnt = take(np.uint32, 1)[0], take(np.int32, 1)[0]
         fv.append((int(nid), take(np.uint32, cnt).copy()))
+    nreloc, n2r = take(np.int32, 2)
+    reloc_match = take(np.int32, n2r)
     assert pos == len(buf)
+    orm, orn = O.search_by_projection_kf(rcase, 10.0, 100, True)
+    assert nreloc == orn and np.array_equal(reloc_match, orm) and nreloc > 150
     wid, wval, onid, onoff, onfeat = O.bow_transform(synth.vocabulary_arrays(voc), desc, 2)   # desc == the oracle's, checked below
     assert np.array_equal(bow["id"], wid) and np.array_equal(bow["val"].view(np.uint64), wval.view(np.uint64)) and nw > 50
     assert [f[0] for f in fv] == onid.tolist()

@@ -2,10 +2,12 @@
 // reference classes, and dumps the results for the Python side to compare with the oracle.
 //   shim_test <yaml> <image.raw> <w> <h> <cloud.raw> <n> <tri.bin> <out.bin>
 //   shim_test --parse <yaml>      prints the DepthModule parse flags (bit 0 LiDAR, bit 1 up-sampling)
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -61,13 +63,35 @@ struct KeyFrame {
 
 // ---- stand-ins for the Frame / MapPoint members SearchByProjection touches
 struct Quat { float qx, qy, qz, qw; float x() const { return qx; } float y() const { return qy; } float z() const { return qz; } float w() const { return qw; } };
+struct V3n : V3 {  // what Eigen's "a - b" offers the relocalisation matcher: norm() as sqrt of the unrolled sum x*x + (y*y + z*z)
+  V3n(const V3& a) : V3(a) {}
+  float norm() const { return sqrtf(v[0] * v[0] + (v[1] * v[1] + v[2] * v[2])); }
+};
+static V3n operator-(const V3& a, const V3& b) { return V3n(V3{{a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2]}}); }
 struct QPose {
   Quat q; V3 t;
   const Quat& unit_quaternion() const { return q; }
   const V3& translation() const { return t; }
+  // Sophus SE3::inverse(): (q^-1, q^-1 * (-t)), the rotation as Eigen's QuaternionBase::_transformVector
+  QPose inverse() const {
+    const float c[4] = {-q.qx, -q.qy, -q.qz, q.qw};
+    const float p[3] = {-t.v[0], -t.v[1], -t.v[2]};
+    float ux = c[1] * p[2] - c[2] * p[1], uy = c[2] * p[0] - c[0] * p[2], uz = c[0] * p[1] - c[1] * p[0];
+    ux = ux + ux; uy = uy + uy; uz = uz + uz;
+    const float cx = c[1] * uz - c[2] * uy, cy = c[2] * ux - c[0] * uz, cz = c[0] * uy - c[1] * ux;
+    QPose r;
+    r.q = Quat{c[0], c[1], c[2], c[3]};
+    r.t = V3{{p[0] + c[3] * ux + cx, p[1] + c[3] * uy + cy, p[2] + c[3] * uz + cz}};
+    return r;
+  }
 };
+struct TestFrame;
 struct TrackedPoint {
   V3 pos; cv::Mat desc; int nObs = 0;
+  float mfMinDistance = 0, mfMaxDistance = 0;
+  float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
+  float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+  int PredictScale(const float& currentDist, TestFrame* pF);  // MapPoint.cc:531-546
   bool mbTrackInView = false, mbTrackInViewR = false, bad = false;
   float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackDepth = 0, mTrackViewCos = 0;
   int mnTrackScaleLevel = 0;
@@ -78,7 +102,8 @@ struct TrackedPoint {
 };
 struct TestFrame {
   int N = 0, Nleft = -1;
-  float mb = 0, mbf = 0;
+  float mb = 0, mbf = 0, mfLogScaleFactor = 0;
+  int mnScaleLevels = 0;
   Camera* mpCamera = nullptr;
   std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
   std::vector<float> mvuRight, mvScaleFactors;
@@ -91,6 +116,18 @@ struct TestFrame {
 };
 float TestFrame::mnMinX, TestFrame::mnMinY, TestFrame::mnMaxX, TestFrame::mnMaxY, TestFrame::mfGridElementWidthInv,
     TestFrame::mfGridElementHeightInv;
+int TrackedPoint::PredictScale(const float& currentDist, TestFrame* pF) {
+  const float ratio = mfMaxDistance / currentDist;
+  int nScale = ceil(log(ratio) / pF->mfLogScaleFactor);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+  return nScale;
+}
+struct RelocKeyFrame {
+  std::vector<cv::KeyPoint> mvKeysUn;
+  std::vector<TrackedPoint*> mps;
+  std::vector<TrackedPoint*> GetMapPointMatches() { return mps; }
+};
 
 template <class T> static bool rd(FILE* f, T* p, size_t n) { return fread(p, sizeof(T), n, f) == n; }
 template <class T> static void wr(FILE* f, const T* p, size_t n) { fwrite(p, sizeof(T), n, f); }
@@ -324,6 +361,56 @@ int main(int argc, char** argv) {
     for (auto& kv : bow) { wr(out, &kv.first, 1); wr(out, &kv.second, 1); }
     wr(out, &nn, 1);
     for (auto& kv : featvec) { const int c = (int)kv.second.size(); wr(out, &kv.first, 1); wr(out, &c, 1); wr(out, kv.second.data(), c); }
+  }
+  // --- as Tracking::Relocalization (Tracking.cc:3723-3752): matcher2.SearchByProjection(mCurrentFrame, vpCandidateKFs[i], sFound, 10, 100)
+  if (argc > 12) {
+    f = fopen(argv[12], "rb");
+    int n1 = 0, n2 = 0, orb_dist = 0, ori = 0;
+    float th = 0, hdr[6 + 7 + 4 + 8 + 1];
+    if (!f || !rd(f, &n1, 1) || !rd(f, &n2, 1) || !rd(f, &th, 1) || !rd(f, &orb_dist, 1) || !rd(f, &ori, 1) || !rd(f, hdr, 26)) return 9;
+    std::vector<unsigned char> has(n1), bad(n1), found(n1), d1((size_t)n1 * 32), d2((size_t)n2 * 32), occ(n2);
+    std::vector<float> pos((size_t)n1 * 3), mind(n1), maxd(n1), ang1(n1), xy2((size_t)n2 * 2), ang2(n2);
+    std::vector<int> o2(n2);
+    rd(f, has.data(), n1); rd(f, bad.data(), n1); rd(f, found.data(), n1); rd(f, pos.data(), (size_t)n1 * 3);
+    rd(f, d1.data(), (size_t)n1 * 32); rd(f, mind.data(), n1); rd(f, maxd.data(), n1); rd(f, ang1.data(), n1);
+    rd(f, xy2.data(), (size_t)n2 * 2); rd(f, o2.data(), n2); rd(f, ang2.data(), n2); rd(f, d2.data(), (size_t)n2 * 32); rd(f, occ.data(), n2);
+    fclose(f);
+    TestFrame::mnMinX = hdr[0]; TestFrame::mnMinY = hdr[1]; TestFrame::mnMaxX = hdr[2]; TestFrame::mnMaxY = hdr[3];
+    TestFrame::mfGridElementWidthInv = hdr[4]; TestFrame::mfGridElementHeightInv = hdr[5];
+    Camera pcam; for (int k = 0; k < 4; ++k) pcam.p[k] = hdr[13 + k];
+    std::vector<TrackedPoint> pts(n1);
+    TrackedPoint before;
+    RelocKeyFrame kf;
+    std::set<TrackedPoint*> sFound;
+    kf.mvKeysUn.resize(n1); kf.mps.assign(n1, nullptr);
+    for (int i = 0; i < n1; ++i) {
+      kf.mvKeysUn[i].angle = ang1[i];
+      if (!has[i]) continue;
+      TrackedPoint& p = pts[i];
+      p.pos = V3{{pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]}};
+      p.desc.create(1, 32, CV_8U); memcpy(p.desc.data, &d1[(size_t)i * 32], 32);
+      p.bad = bad[i] != 0; p.mfMinDistance = mind[i]; p.mfMaxDistance = maxd[i];
+      kf.mps[i] = &p;
+      if (found[i]) sFound.insert(&p);
+    }
+    TestFrame cur;
+    cur.N = n2; cur.mpCamera = &pcam;
+    cur.mvKeysUn.resize(n2);
+    for (int i = 0; i < n2; ++i) { cur.mvKeysUn[i].pt.x = xy2[2 * i]; cur.mvKeysUn[i].pt.y = xy2[2 * i + 1]; cur.mvKeysUn[i].octave = o2[i]; cur.mvKeysUn[i].angle = ang2[i]; }
+    cur.mDescriptors.create(n2, 32, CV_8U); memcpy(cur.mDescriptors.data, d2.data(), (size_t)n2 * 32);
+    cur.mvScaleFactors.assign(hdr + 17, hdr + 25);
+    cur.mnScaleLevels = 8; cur.mfLogScaleFactor = hdr[25];
+    cur.mvpMapPoints.assign(n2, nullptr);
+    for (int i = 0; i < n2; ++i) if (occ[i]) cur.mvpMapPoints[i] = &before;
+    cur.pose.q = Quat{hdr[6], hdr[7], hdr[8], hdr[9]}; cur.pose.t = V3{{hdr[10], hdr[11], hdr[12]}};
+    ORB_SLAM3::ORBmatcher matcher2(0.9, ori != 0);
+    const int nreloc = matcher2.SearchByProjection(cur, &kf, sFound, th, orb_dist);
+    wr(out, &nreloc, 1); wr(out, &n2, 1);
+    for (int i = 0; i < n2; ++i) {
+      TrackedPoint* p = cur.mvpMapPoints[i];
+      const int idx = (p && p != &before) ? (int)(p - pts.data()) : -1;
+      wr(out, &idx, 1);
+    }
   }
   fclose(out);
   printf("shim_test ok: %d keypoints, %d depths, %d triangulation matches\n", nk, nd, nm);

@@ -88,6 +88,13 @@ def test_invalid_arguments_of_the_matcher_entry_points(emu_lib, tmp_path):
     n = _lib.C.c_int(0)
     assert lib.rgbl_search_by_projection(mt.h, None, None, _lib.C.byref(n)) == _lib.ERR_INVALID
     assert lib.rgbl_search_local_points(mt.h, None, None, _lib.C.byref(n)) == _lib.ERR_INVALID
+    assert lib.rgbl_search_by_projection_keyframe(mt.h, None, None, _lib.C.byref(n)) == _lib.ERR_INVALID
+    rcase = pc.make_relocalization_case(40, 50, 3)
+    rcase = dict(rcase, valid1=np.ones(40, np.uint8), level1=np.zeros(40, np.int32))
+    with pytest.raises(_lib.RgblError):
+        mt.SearchByProjectionKeyFrame(rcase, 10.0, 256)                      # ORBdist = 256 would index mvpMapPoints[-1] upstream
+    with pytest.raises(_lib.RgblError):
+        mt.SearchByProjectionKeyFrame(dict(rcase, level1=np.full(40, 8, np.int32)), 10.0, 100)
     mt.close()
     # vocabulary files
     h = _lib.C.c_void_p()

@@ -108,6 +108,11 @@ def test_search_by_projection_edge_cases(emu_lib):
     assert pc.check_search_by_projection(emu_lib, 22, "forward", 15.0, False, True) > 300   # full-size frame pair
 
 
+@pytest.mark.parametrize("seed,th,orb_dist,ori", [(61, 10.0, 100, True), (62, 3.0, 64, True), (63, 15.0, 100, False)])
+def test_search_by_projection_keyframe(emu_lib, seed, th, orb_dist, ori):
+    assert pc.check_search_by_projection_keyframe(emu_lib, seed, th, orb_dist, ori, n1=900, n2=1000) > 60
+
+
 @pytest.mark.parametrize("seed,th,ratio", [(41, 1.0, 0.8), (42, 3.0, 0.8), (45, 15.0, 0.7)])
 def test_search_local_points(emu_lib, seed, th, ratio):
     assert pc.check_search_local_points(emu_lib, seed, th, ratio, n1=1200, n2=900) > 50

@@ -127,6 +127,11 @@ def test_search_by_projection_edge_cases(gpu_lib):
     assert pc.check_search_by_projection(gpu_lib, 27, "forward", 7.0, False, True, n1=7000, n2=8000) > 1000   # 4K-sized frames
 
 
+@pytest.mark.parametrize("seed,th,orb_dist,ori", [(61, 10.0, 100, True), (62, 3.0, 64, True), (63, 15.0, 100, False), (64, 10.0, 255, True)])
+def test_search_by_projection_keyframe(gpu_lib, seed, th, orb_dist, ori):
+    assert pc.check_search_by_projection_keyframe(gpu_lib, seed, th, orb_dist, ori) > 150
+
+
 @pytest.mark.parametrize("seed,th,ratio", [(41, 1.0, 0.8), (42, 3.0, 0.8), (43, 5.0, 0.8), (45, 15.0, 0.7)])
 def test_search_local_points(gpu_lib, seed, th, ratio):
     assert pc.check_search_local_points(gpu_lib, seed, th, ratio) > 200

@@ -314,6 +314,35 @@ def test_reference_search_by_projection_agrees_with_oracle(refmatcher, seed, mot
     assert (m >= 0).sum() <= nm
 
 
+@pytest.mark.parametrize("seed,th,orb_dist,check_ori", [
+    (61, 10.0, 100, True),    # Tracking::Relocalization, first widening: ORBmatcher(0.9, true).SearchByProjection(F, pKF, sFound, 10, 100)
+    (62, 3.0, 64, True),      # second: th = 3, ORBdist = 64 (Tracking.cc:3723-3752)
+    (63, 15.0, 100, False),
+    (64, 10.0, 255, True),
+])
+def test_reference_search_by_projection_keyframe_agrees_with_oracle(refmatcher, seed, th, orb_dist, check_ori):
+    """The real ORBmatcher::SearchByProjection(Frame&, KeyFrame*, set, th, ORBdist) on stand-in Frame / KeyFrame / MapPoint
+    objects (PredictScale and the invariance range as in MapPoint.cc) against the restatement, and the restated prepass
+    against what the reference call actually used."""
+    import parity_checks as pc
+    case = pc.make_relocalization_case(seed=seed)
+    keep = []
+    P = O.make_kf_projection_input(case, th, orb_dist, check_ori, keep)
+    m = np.zeros(P.n2, np.int32)
+    refmatcher.ref_search_by_projection_kf.restype = C.c_int
+    refmatcher.ref_search_by_projection_kf.argtypes = [C.c_void_p, C.c_void_p]
+    nm = refmatcher.ref_search_by_projection_kf(C.byref(P), m.ctypes.data)
+    om, onm = O.search_by_projection_kf(case, th, orb_dist, check_ori)
+    assert nm == onm and np.array_equal(m, om)
+    assert nm > 150
+    # scenario coverage: occupied features stay untouched, found / bad points are never assigned
+    assert not np.any((m >= 0) & (case["occupied2"] != 0))
+    used = m[m >= 0]
+    assert not np.any(case["found1"][used]) and not np.any(case["bad1"][used]) and np.all(case["has_mp1"][used])
+    free = dict(case, occupied2=np.zeros_like(case["occupied2"]))
+    assert not np.array_equal(O.search_by_projection_kf(free, th, orb_dist, check_ori)[0], om)
+
+
 @pytest.mark.parametrize("seed,th,nnratio", [(41, 1.0, 0.8), (42, 3.0, 0.8), (43, 5.0, 0.8), (44, 1.0, 0.9), (45, 15.0, 0.7)])
 def test_reference_search_local_points_agrees_with_oracle(refmatcher, seed, th, nnratio):
     """ORBmatcher::SearchByProjection(F, vpMapPoints, th) as Tracking::SearchLocalPoints calls it (Tracking.cc:3428-3447:
