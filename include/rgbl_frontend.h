@@ -323,6 +323,14 @@ int rgbl_search_triangulation(rgbl_matcher* h, const rgbl_keyframe_view* kf1,
 int rgbl_search_by_bow(rgbl_matcher* h, const rgbl_keyframe_view* kf, const rgbl_keyframe_view* frame, float nnratio,
                        int check_orientation, int32_t* match_f, int* out_nmatches);
 
+/* int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (include/ORBmatcher.h:58,
+ * src/ORBmatcher.cc:765-905; callers LoopClosing::DetectCommonRegionsFromBoW / DetectAndReffineSim3FromLastKF and
+ * Tracking's relocalisation of the multi-map case).  Both views: has_mappoint = GetMapPointMatches()[i] != NULL && !isBad(),
+ * kp_angle = mvKeysUn[i].angle, FeatureVector as CSR.  match12 (kf1->n entries): index of the kf2 feature whose map point ends
+ * up in vpMatches12[i], or -1.  Host pointers, synchronous. */
+int rgbl_search_by_bow_keyframes(rgbl_matcher* h, const rgbl_keyframe_view* kf1, const rgbl_keyframe_view* kf2, float nnratio,
+                                 int check_orientation, int32_t* match12, int* out_nmatches);
+
 /* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono)
  * (include/ORBmatcher.h:48, src/ORBmatcher.cc:1676-1887; callers Tracking::TrackWithMotionModel, src/Tracking.cc:2917-2934):
  * the matcher that runs on every tracked frame.  Single-camera frames (Nleft == -1: RGB-L, RGB-D, stereo, mono pinhole).

@@ -510,6 +510,55 @@ extern "C" void orc_bow_descend(const orc_vocabulary* v, const uint8_t* desc, in
 }
 
 // ---- ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&), /root/reference/src/ORBmatcher.cc:223-425 (Nleft == -1) ----
+extern "C" int orc_search_by_bow_kf(const orc_tri_input* in, float nnratio, int check_orientation, int* match12) {
+  for (int i = 0; i < in->n1; ++i) match12[i] = -1;
+  std::vector<bool> vbMatched2(in->n2, false);
+  std::vector<int> rot_hist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  int nmatches = 0;
+  int a = 0, b = 0;
+  while (a < in->nnodes1 && b < in->nnodes2) {
+    if (in->node_id1[a] < in->node_id2[b]) { ++a; continue; }
+    if (in->node_id1[a] > in->node_id2[b]) { ++b; continue; }
+    for (int p = in->node_off1[a]; p < in->node_off1[a + 1]; ++p) {
+      const int idx1 = in->node_feat1[p];
+      if (!in->has_mp1[idx1]) continue;  // !pMP1 || pMP1->isBad()
+      const uint8_t* d1 = in->desc1 + 32 * (size_t)idx1;
+      int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+      for (int q = in->node_off2[b]; q < in->node_off2[b + 1]; ++q) {
+        const int idx2 = in->node_feat2[q];
+        if (vbMatched2[idx2] || !in->has_mp2[idx2]) continue;
+        const int dist = hamming256(d1, in->desc2 + 32 * (size_t)idx2);
+        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+        else if (dist < bestDist2) bestDist2 = dist;
+      }
+      if (bestDist1 < TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+        match12[idx1] = bestIdx2;
+        vbMatched2[bestIdx2] = true;
+        if (check_orientation) {
+          float rot = in->kp1_angle[idx1] - in->kp2_angle[bestIdx2];
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)roundf(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rot_hist[bin].push_back(idx1);
+        }
+        ++nmatches;
+      }
+    }
+    ++a;
+    ++b;
+  }
+  if (check_orientation) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    three_maxima(rot_hist, HISTO_LENGTH, i1, i2, i3);
+    for (int i = 0; i < HISTO_LENGTH; ++i) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int idx : rot_hist[i]) { match12[idx] = -1; --nmatches; }
+    }
+  }
+  return nmatches;
+}
+
 extern "C" int orc_search_by_bow(const orc_tri_input* in, float nnratio, int check_orientation, int* match2) {
   for (int i = 0; i < in->n2; ++i) match2[i] = -1;
   std::vector<int> rot_hist[HISTO_LENGTH];

@@ -160,6 +160,10 @@ int orc_search_triangulation(const orc_tri_input*, int* matches12);
  * Both sides in the orc_tri_input layout (kf = *1, frame = *2; has_mp1 = "map point present and not bad"; angle2 = F.mvKeys[].angle).
  * match2[i2] = index of the key-frame feature whose map point ends up in vpMapPointMatches[i2], or -1.  Returns nmatches. */
 int orc_search_by_bow(const orc_tri_input* in, float nnratio, int check_orientation, int* match2);
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (/root/reference/src/ORBmatcher.cc:765-905).
+ * Both key frames in the orc_tri_input layout (has_mp = map point present and not bad, angle = mvKeysUn[].angle).
+ * match12[i1] = index of the kf2 feature whose map point ends up in vpMatches12[i1], or -1.  Returns nmatches. */
+int orc_search_by_bow_kf(const orc_tri_input* in, float nnratio, int check_orientation, int* match12);
 
 /* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
  * (/root/reference/src/ORBmatcher.cc:1676-1887, single-camera case Nleft == -1) with

@@ -527,7 +527,7 @@ def fundamental(K1, K2, R12, t12):
     return F
 
 
-def search_by_bow(kf, frame, nnratio=0.7, check_orientation=True):
+def search_by_bow(kf, frame, nnratio=0.7, check_orientation=True, keyframes=False):
     """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches).  kf / frame: dicts as for search_triangulation (kf["has_mp"] = map
     point present and not bad).  Returns (match per frame feature: key-frame feature index or -1, nmatches)."""
     keep = []
@@ -549,9 +549,18 @@ def search_by_bow(kf, frame, nnratio=0.7, check_orientation=True):
         setattr(T, "node_id%d" % i, arr(d["node_id"], np.int32))
         setattr(T, "node_off%d" % i, arr(d["node_off"], np.int32))
         setattr(T, "node_feat%d" % i, arr(d["node_feat"], np.int32))
+    if keyframes:
+        m = np.zeros(T.n1, np.int32)
+        n = lib().orc_search_by_bow_kf(C.byref(T), C.c_float(nnratio), int(check_orientation), _p(m))
+        return m, n
     m = np.zeros(T.n2, np.int32)
     n = lib().orc_search_by_bow(C.byref(T), C.c_float(nnratio), int(check_orientation), _p(m))
     return m, n
+
+
+def search_by_bow_kf(kf1, kf2, nnratio=0.75, check_orientation=True):
+    """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12).  Returns (match per kf1 feature: kf2 feature index or -1, nmatches)."""
+    return search_by_bow(kf1, kf2, nnratio, check_orientation, keyframes=True)
 
 
 def search_triangulation(kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, only_stereo=False,

@@ -365,3 +365,33 @@ extern "C" int ref_search_by_bow(const KfArrays* kfa, const KfArrays* fra, float
   for (int i = 0; i < fra->n; ++i) match2[i] = vpMapPointMatches[i] ? (int)(vpMapPointMatches[i] - pts.data()) : -1;
   return nm;
 }
+
+// ORBmatcher(nnratio, checkOri).SearchByBoW(pKF1, pKF2, vpMatches12) (ORBmatcher.cc:765-905); has_mp: 0 none, 1 good, 2 bad.
+extern "C" int ref_search_by_bow_kf(const KfArrays* a1, const KfArrays* a2, float nnratio, int check_orientation, int* match12) {
+  GeometricCamera cam;
+  std::vector<MapPoint> pts1(a1->n), pts2(a2->n);
+  KeyFrame kf[2];
+  const KfArrays* src[2] = {a1, a2};
+  std::vector<MapPoint>* pts[2] = {&pts1, &pts2};
+  for (int s = 0; s < 2; ++s) {
+    const KfArrays* a = src[s];
+    kf[s].N = a->n;
+    kf[s].mpCamera = &cam;
+    kf[s].mDescriptors = cv::Mat(a->n, 32, CV_8U);
+    if (a->n) memcpy(kf[s].mDescriptors.data, a->desc, (size_t)a->n * 32);
+    kf[s].mvKeysUn.resize(a->n);
+    kf[s].mvpMapPoints.assign(a->n, nullptr);
+    for (int i = 0; i < a->n; ++i) {
+      kf[s].mvKeysUn[i].angle = a->kp_angle[i];
+      if (a->has_mp[i] == 1) kf[s].mvpMapPoints[i] = &(*pts[s])[i];
+      else if (a->has_mp[i] == 2) { (*pts[s])[i].bad = true; kf[s].mvpMapPoints[i] = &(*pts[s])[i]; }
+    }
+    for (int k = 0; k < a->nnodes; ++k)
+      kf[s].mFeatVec[(unsigned)a->node_id[k]] = std::vector<unsigned>(a->node_feat + a->node_off[k], a->node_feat + a->node_off[k + 1]);
+  }
+  ORBmatcher matcher(nnratio, check_orientation != 0);
+  std::vector<MapPoint*> vpMatches12;
+  const int nm = matcher.SearchByBoW(&kf[0], &kf[1], vpMatches12);
+  for (int i = 0; i < a1->n; ++i) match12[i] = vpMatches12[i] ? (int)(vpMatches12[i] - pts2.data()) : -1;
+  return nm;
+}

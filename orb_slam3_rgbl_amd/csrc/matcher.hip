@@ -574,8 +574,10 @@ __global__ __launch_bounds__(256) void k_bow_descend(VocDev V, const uint8_t* __
 struct BowDev {
   const uint8_t* desc1; const uint8_t* desc2;
   const uint8_t* valid1;
+  const uint8_t* valid2;  // candidates must hold a good map point as well (the key-frame / key-frame overload), or nullptr
   const int32_t *off1, *feat1, *off2, *feat2, *pair_n1, *pair_n2;
   float nnratio;
+  int max_best;           // largest accepted best distance: TH_LOW ("<=", :315) or TH_LOW - 1 ("<", :854)
   int32_t* match1;  // per key-frame feature: the frame feature it took, or -1
   int32_t* match2;  // per frame feature: the key-frame feature, or -1
 };
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
   const int np = blockIdx.x, lane = threadIdx.x;
   const int a = T.pair_n1[np], b = T.pair_n2[np];
   const int b1 = T.off1[a], e1 = T.off1[a + 1], b2 = T.off2[b], n2 = T.off2[b + 1] - b2;
-  for (int j = lane; j < n2; j += 64) s_taken[j] = 0;
+  for (int j = lane; j < n2; j += 64) s_taken[j] = (T.valid2 && !T.valid2[T.feat2[b2 + j]]) ? 1 : 0;
   wave_sync();
   for (int p = b1; p < e1; ++p) {
     const int idx1 = T.feat1[p];
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
     for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(other, m); other = o < other ? o : other; }
     if (wbest == 0xffffffffu) continue;
     const int best_dist = (int)(wbest >> 16), pos = (int)(wbest & 0xffffu);
-    if (best_dist <= 50 /* TH_LOW */ && (float)best_dist < T.nnratio * (float)other) {
+    if (best_dist <= T.max_best && (float)best_dist < T.nnratio * (float)other) {
       if (lane == 0) {
         const int idx2 = T.feat2[b2 + pos];
         s_taken[pos] = 1;
@@ -1376,61 +1378,76 @@ int rgbl_bow_transform(rgbl_vocabulary* v, const uint8_t* desc, int n, int level
   return RGBL_OK;
 }
 
-int rgbl_search_by_bow(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_keyframe_view* fr, float nnratio,
-                       int check_orientation, int32_t* match_f, int* out_nmatches) {
-  if (!m || !kf || !fr || !match_f || !out_nmatches || kf->n < 0 || fr->n < 0) { set_error("invalid argument"); return RGBL_ERR_INVALID; }
-  *out_nmatches = 0;
+// device part of both SearchByBoW overloads: match1[idx1] = feature of `fr` taken by key-frame feature idx1 (or -1), match2 the
+// inverse; pa / pb = the shared vocabulary nodes in merge order
+static int bow_core(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_keyframe_view* fr, float nnratio, bool second_needs_mp,
+                    int max_best, std::vector<int32_t>& pa, std::vector<int32_t>& pb, std::vector<int32_t>& match1,
+                    std::vector<int32_t>& match2) {
   const int n1 = kf->n, n2 = fr->n;
-  for (int i = 0; i < n2; ++i) match_f[i] = -1;
+  match1.assign(n1, -1);
+  match2.assign(n2, -1);
   // merge walk of the two sorted FeatureVectors (ORBmatcher.cc:243-246, 388-401)
-  std::vector<int32_t> pa, pb;
+  pa.clear(); pb.clear();
   for (int a = 0, b = 0; a < kf->n_nodes && b < fr->n_nodes;) {
     if (kf->node_id[a] == fr->node_id[b]) { pa.push_back(a++); pb.push_back(b++); }
     else if (kf->node_id[a] < fr->node_id[b]) ++a;
     else ++b;
   }
   const int npairs = (int)pa.size();
-  std::vector<int32_t> match1(n1, -1);
-  if (npairs > 0 && n1 > 0 && n2 > 0) {
-    for (int p = 0; p < npairs; ++p)
-      if (fr->node_off[pb[p] + 1] - fr->node_off[pb[p]] > kBowBucket) {
-        set_error("SearchByBoW: a vocabulary node holds more than %d frame features", kBowBucket);
-        return RGBL_ERR_CAPACITY;
-      }
-    RGBL_HIP(hipSetDevice(m->device));
-    const int nf1 = kf->node_off[kf->n_nodes], nf2 = fr->node_off[fr->n_nodes];
-    size_t need = pad256((size_t)n1 * 32) + pad256((size_t)n2 * 32) + pad256(n1) + pad256((size_t)(kf->n_nodes + 1) * 4) +
-                  pad256((size_t)nf1 * 4) + pad256((size_t)(fr->n_nodes + 1) * 4) + pad256((size_t)nf2 * 4) +
-                  2 * pad256((size_t)npairs * 4) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 4);
-    RGBL_TRY(ensure_arena(m, need));
-    Arena A{m->d_buf};
-    hipStream_t s = m->stream;
-    BowDev T;
-    RGBL_TRY(upload(A, s, &T.desc1, kf->desc, (size_t)n1 * 32));
-    RGBL_TRY(upload(A, s, &T.desc2, fr->desc, (size_t)n2 * 32));
-    RGBL_TRY(upload(A, s, &T.valid1, kf->has_mappoint, (size_t)n1));
-    RGBL_TRY(upload(A, s, &T.off1, kf->node_off, (size_t)kf->n_nodes + 1));
-    RGBL_TRY(upload(A, s, &T.feat1, kf->node_feat, (size_t)nf1));
-    RGBL_TRY(upload(A, s, &T.off2, fr->node_off, (size_t)fr->n_nodes + 1));
-    RGBL_TRY(upload(A, s, &T.feat2, fr->node_feat, (size_t)nf2));
-    RGBL_TRY(upload(A, s, &T.pair_n1, pa.data(), (size_t)npairs));
-    RGBL_TRY(upload(A, s, &T.pair_n2, pb.data(), (size_t)npairs));
-    T.match1 = A.take<int32_t>(n1);
-    T.match2 = A.take<int32_t>(n2);
-    T.nnratio = nnratio;
-    RGBL_HIP(hipMemsetAsync(T.match1, 0xff, sizeof(int32_t) * n1, s));
-    RGBL_HIP(hipMemsetAsync(T.match2, 0xff, sizeof(int32_t) * n2, s));
-    m->timer.begin("k_search_by_bow", s);
-    hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(64), 0, s, T);
-    m->timer.end(s);
-    RGBL_HIP(hipGetLastError());
-    RGBL_HIP(hipMemcpyAsync(match1.data(), T.match1, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
-    RGBL_HIP(hipMemcpyAsync(match_f, T.match2, sizeof(int32_t) * n2, hipMemcpyDeviceToHost, s));
-    RGBL_HIP(hipStreamSynchronize(s));
-    m->timer.collect();
-  }
+  if (npairs == 0 || n1 == 0 || n2 == 0) return RGBL_OK;
+  for (int p = 0; p < npairs; ++p)
+    if (fr->node_off[pb[p] + 1] - fr->node_off[pb[p]] > kBowBucket) {
+      set_error("SearchByBoW: a vocabulary node holds more than %d features of the second set", kBowBucket);
+      return RGBL_ERR_CAPACITY;
+    }
+  RGBL_HIP(hipSetDevice(m->device));
+  const int nf1 = kf->node_off[kf->n_nodes], nf2 = fr->node_off[fr->n_nodes];
+  size_t need = pad256((size_t)n1 * 32) + pad256((size_t)n2 * 32) + pad256(n1) + pad256(n2) + pad256((size_t)(kf->n_nodes + 1) * 4) +
+                pad256((size_t)nf1 * 4) + pad256((size_t)(fr->n_nodes + 1) * 4) + pad256((size_t)nf2 * 4) +
+                2 * pad256((size_t)npairs * 4) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 4);
+  RGBL_TRY(ensure_arena(m, need));
+  Arena A{m->d_buf};
+  hipStream_t s = m->stream;
+  BowDev T;
+  T.valid2 = nullptr;
+  RGBL_TRY(upload(A, s, &T.desc1, kf->desc, (size_t)n1 * 32));
+  RGBL_TRY(upload(A, s, &T.desc2, fr->desc, (size_t)n2 * 32));
+  RGBL_TRY(upload(A, s, &T.valid1, kf->has_mappoint, (size_t)n1));
+  if (second_needs_mp) RGBL_TRY(upload(A, s, &T.valid2, fr->has_mappoint, (size_t)n2));
+  RGBL_TRY(upload(A, s, &T.off1, kf->node_off, (size_t)kf->n_nodes + 1));
+  RGBL_TRY(upload(A, s, &T.feat1, kf->node_feat, (size_t)nf1));
+  RGBL_TRY(upload(A, s, &T.off2, fr->node_off, (size_t)fr->n_nodes + 1));
+  RGBL_TRY(upload(A, s, &T.feat2, fr->node_feat, (size_t)nf2));
+  RGBL_TRY(upload(A, s, &T.pair_n1, pa.data(), (size_t)npairs));
+  RGBL_TRY(upload(A, s, &T.pair_n2, pb.data(), (size_t)npairs));
+  T.match1 = A.take<int32_t>(n1);
+  T.match2 = A.take<int32_t>(n2);
+  T.nnratio = nnratio;
+  T.max_best = max_best;
+  RGBL_HIP(hipMemsetAsync(T.match1, 0xff, sizeof(int32_t) * n1, s));
+  RGBL_HIP(hipMemsetAsync(T.match2, 0xff, sizeof(int32_t) * n2, s));
+  m->timer.begin("k_search_by_bow", s);
+  hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(64), 0, s, T);
+  m->timer.end(s);
+  RGBL_HIP(hipGetLastError());
+  RGBL_HIP(hipMemcpyAsync(match1.data(), T.match1, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipMemcpyAsync(match2.data(), T.match2, sizeof(int32_t) * n2, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipStreamSynchronize(s));
+  m->timer.collect();
+  return RGBL_OK;
+}
+
+int rgbl_search_by_bow(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_keyframe_view* fr, float nnratio,
+                       int check_orientation, int32_t* match_f, int* out_nmatches) {
+  if (!m || !kf || !fr || !match_f || !out_nmatches || kf->n < 0 || fr->n < 0) { set_error("invalid argument"); return RGBL_ERR_INVALID; }
+  *out_nmatches = 0;
+  const int n2 = fr->n;
+  for (int i = 0; i < n2; ++i) match_f[i] = -1;
+  std::vector<int32_t> pa, pb, match1, match2;
+  RGBL_TRY(bow_core(m, kf, fr, nnratio, false, 50 /* <= TH_LOW */, pa, pb, match1, match2));
+  const int npairs = (int)pa.size();
   int nmatches = 0;
-  for (int i = 0; i < n2; ++i) nmatches += match_f[i] >= 0;
+  for (int i = 0; i < n2; ++i) { match_f[i] = match2[i]; nmatches += match_f[i] >= 0; }
   if (check_orientation) {
     // rotation histogram in the order the reference fills it: node by node, key-frame bucket order (ORBmatcher.cc:331-343)
     std::vector<int> hist[30];
@@ -1451,6 +1468,44 @@ int rgbl_search_by_bow(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl
     for (int i = 0; i < 30; ++i) {
       if (i == i1 || i == i2 || i == i3) continue;
       for (int idx2 : hist[i]) { match_f[idx2] = -1; --nmatches; }
+    }
+  }
+  *out_nmatches = nmatches;
+  return RGBL_OK;
+}
+
+// int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:765-905):
+// both sides need a good map point, the best distance must be < TH_LOW, the result is indexed by the first key frame.
+int rgbl_search_by_bow_keyframes(rgbl_matcher* m, const rgbl_keyframe_view* kf1, const rgbl_keyframe_view* kf2, float nnratio,
+                                 int check_orientation, int32_t* match12, int* out_nmatches) {
+  if (!m || !kf1 || !kf2 || !match12 || !out_nmatches || kf1->n < 0 || kf2->n < 0) { set_error("invalid argument"); return RGBL_ERR_INVALID; }
+  *out_nmatches = 0;
+  const int n1 = kf1->n;
+  for (int i = 0; i < n1; ++i) match12[i] = -1;
+  std::vector<int32_t> pa, pb, match1, match2;
+  RGBL_TRY(bow_core(m, kf1, kf2, nnratio, true, 49 /* < TH_LOW */, pa, pb, match1, match2));
+  const int npairs = (int)pa.size();
+  int nmatches = 0;
+  for (int i = 0; i < n1; ++i) { match12[i] = match1[i]; nmatches += match12[i] >= 0; }
+  if (check_orientation) {
+    std::vector<int> hist[30];
+    const float factor = 1.0f / 30;
+    for (int p = 0; p < npairs; ++p)
+      for (int q = kf1->node_off[pa[p]]; q < kf1->node_off[pa[p] + 1]; ++q) {
+        const int idx1 = kf1->node_feat[q];
+        const int idx2 = match1[idx1];
+        if (idx2 < 0) continue;
+        float rot = kf1->kp_angle[idx1] - kf2->kp_angle[idx2];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == 30) bin = 0;
+        if (bin >= 0 && bin < 30) hist[bin].push_back(idx1);
+      }
+    int i1, i2, i3;
+    three_maxima(hist, 30, i1, i2, i3);
+    for (int i = 0; i < 30; ++i) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int idx1 : hist[i]) { match12[idx1] = -1; --nmatches; }
     }
   }
   *out_nmatches = nmatches;

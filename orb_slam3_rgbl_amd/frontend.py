@@ -441,6 +441,18 @@ class ORBmatcher:
                                                       int(self.mbCheckOrientation), L.ptr(m), C.byref(nm)))
         return m, nm.value
 
+    def SearchByBoWKeyFrames(self, kf1, kf2):
+        """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (ORBmatcher.cc:765-905).  kf1 / kf2: dicts as for
+        SearchForTriangulation, has_mp = map point present and not bad, angle = mvKeysUn[].angle.  Returns (per kf1 feature the
+        kf2 feature whose map point it gets, or -1; nmatches)."""
+        keep = []
+        v1, v2 = self._view(kf1, keep), self._view(kf2, keep)
+        m = np.full(v1.n, -1, np.int32)
+        nm = C.c_int(0)
+        L.check(self.lib, self.lib.rgbl_search_by_bow_keyframes(self.h, C.byref(v1), C.byref(v2), float(self.mfNNratio),
+                                                                int(self.mbCheckOrientation), L.ptr(m), C.byref(nm)))
+        return m, nm.value
+
     def SearchForTriangulation(self, kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, bOnlyStereo=False,
                                bCoarse=False):
         """kf = dict(desc, xy, octave, angle, uright, has_mp, node_id, node_off, node_feat).

@@ -136,6 +136,47 @@ class ORBmatcher {
     return nmatches;
   }
 
+  // Matching between the MapPoints of two KeyFrames through the vocabulary (LoopClosing's place recognition and the merge /
+  // relocalisation of the multi-map case).  ORBmatcher.h:58, ORBmatcher.cc:765-905.
+  template <class KeyFrameT, class MapPointT>
+  int SearchByBoW(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12) {
+    const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const std::vector<MapPointT*> vpMapPoints2 = pKF2->GetMapPointMatches();
+    vpMatches12 = std::vector<MapPointT*>(vpMapPoints1.size(), static_cast<MapPointT*>(NULL));
+    if (!mpHandle) return 0;
+    if (pKF1->NLeft != -1 || pKF2->NLeft != -1) {
+      std::cerr << "[ORBmatcher] SearchByBoW: fisheye stereo rigs are not covered by the device path" << std::endl;
+      return 0;
+    }
+    Flat f1, f2;
+    KeyFrameT* kfs[2] = {pKF1, pKF2};
+    const std::vector<MapPointT*>* mps[2] = {&vpMapPoints1, &vpMapPoints2};
+    Flat* flat[2] = {&f1, &f2};
+    std::vector<float> ur[2];
+    for (int s = 0; s < 2; ++s) {
+      const int n = (int)mps[s]->size();
+      Flat& f = *flat[s];
+      f.xy.assign(2 * (size_t)n, 0.f); f.angle.resize(n); f.octave.assign(n, 0); f.has_mp.resize(n);
+      for (int i = 0; i < n; ++i) {
+        f.angle[i] = kfs[s]->mvKeysUn[i].angle;
+        MapPointT* pMP = (*mps[s])[i];
+        f.has_mp[i] = (pMP && !pMP->isBad()) ? 1 : 0;
+      }
+      FlattenFeatVec(kfs[s]->mFeatVec, f);
+      ur[s].assign(n, -1.f);
+      FillView(f, n, kfs[s]->mDescriptors.template ptr<uint8_t>(), ur[s].data());
+    }
+    std::vector<int32_t> match(vpMapPoints1.size(), -1);
+    int nmatches = 0;
+    if (rgbl_search_by_bow_keyframes(mpHandle, &f1.view, &f2.view, mfNNratio, mbCheckOrientation, match.data(), &nmatches) != RGBL_OK) {
+      std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
+      return 0;
+    }
+    for (size_t i = 0; i < match.size(); ++i)
+      if (match[i] >= 0) vpMatches12[i] = vpMapPoints2[match[i]];
+    return nmatches;
+  }
+
   // Project MapPoints tracked in last frame into the current frame and search matches.  Used to track from previous
   // frame (Tracking::TrackWithMotionModel, Tracking.cc:2917-2934).  ORBmatcher.h:48, ORBmatcher.cc:1676-1887.
   // A member template for the same reason as above; it reads the Frame / MapPoint members the reference loop reads

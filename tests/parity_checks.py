@@ -825,3 +825,16 @@ def check_search_by_bow(lib, seed=51, nnratio=0.7, check_ori=True, n=1500, nodes
     assert nm == onm and np.array_equal(m, om), "SearchByBoW (seed %d)" % seed
     mt.close()
     return nm
+
+
+def check_search_by_bow_keyframes(lib, seed=81, nnratio=0.75, check_ori=True, n=1500, nodes=100):
+    kf1, kf2, *_ = make_triangulation_case(n, seed=seed, n_nodes=nodes)
+    rng = np.random.default_rng(seed)
+    kf1 = dict(kf1, has_mp=(rng.random(n) < 0.8).astype(np.uint8))
+    kf2 = dict(kf2, has_mp=(rng.random(len(kf2["desc"])) < 0.8).astype(np.uint8))
+    mt = F.ORBmatcher(nnratio, check_ori, lib=lib)
+    m, nm = mt.SearchByBoWKeyFrames(kf1, kf2)
+    om, onm = O.search_by_bow_kf(kf1, kf2, nnratio, check_ori)
+    assert nm == onm and np.array_equal(m, om), "SearchByBoW(KF, KF) (seed %d)" % seed
+    mt.close()
+    return nm

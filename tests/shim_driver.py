@@ -140,7 +140,11 @@ def run_and_check(exe, tmp):
         fv.append((int(nid), take(np.uint32, cnt).copy()))
     nreloc, n2r = take(np.int32, 2)
     reloc_match = take(np.int32, n2r)
+    nkk, n1k = take(np.int32, 2)
+    kk_match = take(np.int32, n1k)
     assert pos == len(buf)
+    okk, onkk = O.search_by_bow_kf(kf1, kf2, 0.75, True)
+    assert nkk == onkk and np.array_equal(kk_match, okk) and nkk > 50
     orm, orn = O.search_by_projection_kf(rcase, 10.0, 100, True)
     assert nreloc == orn and np.array_equal(reloc_match, orm) and nreloc > 150
     wid, wval, onid, onoff, onfeat = O.bow_transform(synth.vocabulary_arrays(voc), desc, 2)   # desc == the oracle's, checked below

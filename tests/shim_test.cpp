@@ -412,6 +412,18 @@ int main(int argc, char** argv) {
       wr(out, &idx, 1);
     }
   }
+  {
+    // --- as LoopClosing::DetectCommonRegionsFromBoW (LoopClosing.cc): ORBmatcher(0.9 / 0.75, true).SearchByBoW(pKF1, pKF2, vpMatches12)
+    std::vector<MapPoint> own1(kf1.N), own2(kf2.N);
+    for (int i = 0; i < kf1.N; ++i) if (kf1.mvpMapPoints[i]) kf1.mvpMapPoints[i] = &own1[i];
+    for (int i = 0; i < kf2.N; ++i) if (kf2.mvpMapPoints[i]) kf2.mvpMapPoints[i] = &own2[i];
+    ORB_SLAM3::ORBmatcher loop(0.75, true);
+    std::vector<MapPoint*> vpMatches12;
+    const int nkk = loop.SearchByBoW(&kf1, &kf2, vpMatches12);
+    const int n1k = (int)vpMatches12.size();
+    wr(out, &nkk, 1); wr(out, &n1k, 1);
+    for (int i = 0; i < n1k; ++i) { const int idx = vpMatches12[i] ? (int)(vpMatches12[i] - own2.data()) : -1; wr(out, &idx, 1); }
+  }
   fclose(out);
   printf("shim_test ok: %d keypoints, %d depths, %d triangulation matches\n", nk, nd, nm);
   return 0;

@@ -168,3 +168,8 @@ def test_extractor_under_full_load(gpu_lib):
 @pytest.mark.parametrize("seed,ratio,ori,nodes", [(51, 0.7, True, 100), (52, 0.7, False, 100), (53, 0.9, True, 30), (54, 0.6, True, 1)])
 def test_search_by_bow(gpu_lib, seed, ratio, ori, nodes):
     assert pc.check_search_by_bow(gpu_lib, seed, ratio, ori, n=2000, nodes=nodes) > 100
+
+
+@pytest.mark.parametrize("seed,ratio,ori,nodes", [(81, 0.75, True, 100), (82, 0.9, False, 30), (84, 0.8, True, 1)])
+def test_search_by_bow_keyframes(gpu_lib, seed, ratio, ori, nodes):
+    assert pc.check_search_by_bow_keyframes(gpu_lib, seed, ratio, ori, n=2000, nodes=nodes) > 50

@@ -419,6 +419,28 @@ def test_reference_dbow2_transform_agrees_with_oracle(refdbow, tmp_path, k, L, l
     refdbow.ref_voc_destroy(h)
 
 
+@pytest.mark.parametrize("seed,nnratio,check_ori,nodes", [(81, 0.75, True, 100), (82, 0.9, True, 100), (83, 0.75, False, 30), (84, 0.8, True, 1)])
+def test_reference_search_by_bow_keyframes_agrees_with_oracle(refmatcher, seed, nnratio, check_ori, nodes):
+    """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (LoopClosing: ORBmatcher(0.9, true) / (0.75, true))."""
+    import parity_checks as pc
+    kf1, kf2, *_ = pc.make_triangulation_case(1500, seed=seed, n_nodes=nodes)
+    rng = np.random.default_rng(seed)
+    s1 = rng.choice([0, 1, 2], len(kf1["desc"]), p=[0.15, 0.75, 0.1]).astype(np.uint8)   # none / good / bad map point
+    s2 = rng.choice([0, 1, 2], len(kf2["desc"]), p=[0.15, 0.75, 0.1]).astype(np.uint8)
+    keep = []
+    a1 = kf_arrays(dict(kf1, has_mp=s1), keep)
+    a2 = kf_arrays(dict(kf2, has_mp=s2), keep)
+    m = np.zeros(a1.n, np.int32)
+    refmatcher.ref_search_by_bow_kf.restype = C.c_int
+    refmatcher.ref_search_by_bow_kf.argtypes = [C.POINTER(KfArrays), C.POINTER(KfArrays), C.c_float, C.c_int, C.c_void_p]
+    nm = refmatcher.ref_search_by_bow_kf(C.byref(a1), C.byref(a2), C.c_float(nnratio), int(check_ori), m.ctypes.data)
+    om, onm = O.search_by_bow_kf(dict(kf1, has_mp=(s1 == 1).astype(np.uint8)), dict(kf2, has_mp=(s2 == 1).astype(np.uint8)), nnratio, check_ori)
+    assert nm == onm and np.array_equal(m, om)
+    assert nm > 100
+    used = m[m >= 0]
+    assert np.all(s2[used] == 1) and len(set(used.tolist())) == len(used)      # only good map points, every kf2 feature at most once
+
+
 @pytest.mark.parametrize("seed,nnratio,check_ori,nodes", [(51, 0.7, True, 100), (52, 0.7, False, 100), (53, 0.9, True, 30), (54, 0.6, True, 1)])
 def test_reference_search_by_bow_agrees_with_oracle(refmatcher, seed, nnratio, check_ori, nodes):
     """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) as Tracking::TrackReferenceKeyFrame calls it (ORBmatcher(0.7, true))."""
