@@ -403,6 +403,36 @@ typedef struct {
 int rgbl_search_by_projection_keyframe(rgbl_matcher* h, const rgbl_keyframe_projection_input* in, int32_t* match2,
                                        int* out_nmatches);
 
+/* The search inside int ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const float th, const bool bRight)
+ * (include/ORBmatcher.h:83, src/ORBmatcher.cc:1148-1338, bRight = false; caller LocalMapping::SearchInNeighbors,
+ * src/LocalMapping.cc:737-879, twice per neighbour key frame).  Every map point finds its best feature independently of
+ * the others; what the loop then does with a match (MapPoint::Replace / AddObservation, KeyFrame::AddMapPoint) mutates the
+ * caller's objects and stays in the shim, as do the tests that need the MapPoint object. */
+typedef struct {
+  int n1;                         /* vpMapPoints.size() */
+  const uint8_t* valid1;          /* pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF) && minDistance <= dist3D <= maxDistance &&
+                                     !(PO.dot(Pn) < 0.5 * dist3D) */
+  const float* world_pos1;        /* pMP->GetWorldPos() */
+  const uint8_t* mp_desc1;        /* pMP->GetDescriptor() */
+  const int32_t* level1;          /* pMP->PredictScale(dist3D, pKF) */
+  int n2;                         /* pKF->N (<= 65535) */
+  const float* kp2_xy;            /* pKF->mvKeysUn[i].pt */
+  const int32_t* kp2_octave;
+  const float* uright2;           /* pKF->mvuRight */
+  const uint8_t* desc2;           /* pKF->mDescriptors */
+  float grid[6];                  /* pKF->mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv */
+  float Tcw_q[4], Tcw_t[3];       /* pKF->GetPose() */
+  float K[4];                     /* fx, fy, cx, cy (pKF->mpCamera->project) */
+  float bf;                       /* pKF->mbf */
+  const float* scale_factors;     /* pKF->mvScaleFactors */
+  const float* inv_level_sigma2;  /* pKF->mvInvLevelSigma2 */
+  int n_levels;
+  float th;
+} rgbl_fuse_input;
+/* Host pointers, synchronous.  best_idx[i] = the key-frame feature point i would be fused with (bestDist <= TH_LOW), or -1;
+ * best_dist (nullable) = bestDist, 256 when the point had no candidate. */
+int rgbl_fuse_search(rgbl_matcher* h, const rgbl_fuse_input* in, int32_t* best_idx, int32_t* best_dist);
+
 typedef struct {
   int n1;                      /* vpMapPoints.size() */
   const uint8_t* valid1;       /* pMP->mbTrackInView && !(bFarPoints && pMP->mTrackDepth > thFarPoints) && !pMP->isBad() */

@@ -69,7 +69,9 @@ class MapPoint {
   bool IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }
   std::tuple<int, int> GetIndexInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) ? std::tuple<int, int>(mObservations[pKF], -1) : std::tuple<int, int>(-1, -1); }
   void AddObservation(KeyFrame* pKF, int idx) { mObservations[pKF] = idx; ++nObs; }
-  void Replace(MapPoint*) {}
+  // MapPoint::Replace rewires observations between map objects; the stand-in only records the call (who, with whom)
+  static std::vector<std::pair<MapPoint*, MapPoint*>>* replace_log;
+  void Replace(MapPoint* pMP) { if (replace_log) replace_log->push_back(std::make_pair(this, pMP)); }
 };
 
 // Frame::GetFeaturesInArea / KeyFrame::GetFeaturesInArea (src/Frame.cc:747-813, src/KeyFrame.cc:604-666) over a grid built

@@ -411,6 +411,93 @@ extern "C" int orc_search_by_projection_kf(const orc_kf_projection_input* in, in
   return nmatches;
 }
 
+// ---- the per-point search of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight = false), ORBmatcher.cc:1148-1338 ----
+namespace {
+// the tests of the loop body that need the MapPoint object and do not depend on the projection: -1 = skipped, else PredictScale
+int fuse_point_level(const orc_fuse_input* in, int i) {
+  if (!in->has_mp1[i] || in->bad1[i] || in->in_kf1[i]) return -1;
+  const V3 PO = {in->world_pos1[3 * i] - in->Ow[0], in->world_pos1[3 * i + 1] - in->Ow[1], in->world_pos1[3 * i + 2] - in->Ow[2]};
+  const float dist3D = sqrtf(PO.x * PO.x + (PO.y * PO.y + PO.z * PO.z));  // Eigen norm(): unrolled 3-term sum
+  const float maxDistance = 1.2f * in->max_dist1[i], minDistance = 0.8f * in->min_dist1[i];
+  if (dist3D < minDistance || dist3D > maxDistance) return -1;
+  // viewing angle below 60 degrees: PO.dot(Pn) < 0.5 * dist3D (float dot, double comparison)
+  const float dot = PO.x * in->normal1[3 * i] + (PO.y * in->normal1[3 * i + 1] + PO.z * in->normal1[3 * i + 2]);
+  if ((double)dot < 0.5 * (double)dist3D) return -1;
+  const float ratio = in->max_dist1[i] / dist3D;
+  int nScale = (int)ceil(logf(ratio) / in->log_scale_factor);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= in->n_levels) nScale = in->n_levels - 1;
+  return nScale;
+}
+}  // namespace
+
+extern "C" void orc_fuse_prepass(const orc_fuse_input* in, uint8_t* valid1, int32_t* level1) {
+  for (int i = 0; i < in->n1; ++i) {
+    const int l = fuse_point_level(in, i);
+    valid1[i] = l >= 0;
+    level1[i] = l >= 0 ? l : 0;
+  }
+}
+
+extern "C" int orc_fuse_search(const orc_fuse_input* in, int* best_idx) {
+  const int COLS = 64, ROWS = 48;
+  const float mnMinX = in->grid[0], mnMinY = in->grid[1], mnMaxX = in->grid[2], mnMaxY = in->grid[3];
+  const float invW = in->grid[4], invH = in->grid[5];
+  std::vector<std::vector<int>> cells((size_t)COLS * ROWS);
+  for (int i = 0; i < in->n2; ++i) {
+    const int px = (int)roundf((in->kp2_xy[2 * i] - mnMinX) * invW), py = (int)roundf((in->kp2_xy[2 * i + 1] - mnMinY) * invH);
+    if (px < 0 || px >= COLS || py < 0 || py >= ROWS) continue;
+    cells[(size_t)px * ROWS + py].push_back(i);
+  }
+  int nFused = 0;
+  for (int i = 0; i < in->n1; ++i) {
+    best_idx[i] = -1;
+    if (!in->has_mp1[i] || in->bad1[i] || in->in_kf1[i]) continue;
+    const V3 p3Dw = {in->world_pos1[3 * i], in->world_pos1[3 * i + 1], in->world_pos1[3 * i + 2]};
+    const V3 p3Dc = se3_apply(in->Tcw_q, in->Tcw_t, p3Dw);
+    if (p3Dc.z < 0.0f) continue;
+    const float invz = 1 / p3Dc.z;
+    const float u = in->K[0] * p3Dc.x / p3Dc.z + in->K[2], v = in->K[1] * p3Dc.y / p3Dc.z + in->K[3];
+    if (!(u >= mnMinX && u < mnMaxX && v >= mnMinY && v < mnMaxY)) continue;  // KeyFrame::IsInImage
+    const float ur = u - in->bf * invz;
+    const int nPredictedLevel = fuse_point_level(in, i);
+    if (nPredictedLevel < 0) continue;
+    const float radius = in->th * in->scale_factors[nPredictedLevel];
+    const int nMinCellX = std::max(0, (int)floorf((u - mnMinX - radius) * invW));
+    if (nMinCellX >= COLS) continue;
+    const int nMaxCellX = std::min(COLS - 1, (int)ceilf((u - mnMinX + radius) * invW));
+    if (nMaxCellX < 0) continue;
+    const int nMinCellY = std::max(0, (int)floorf((v - mnMinY - radius) * invH));
+    if (nMinCellY >= ROWS) continue;
+    const int nMaxCellY = std::min(ROWS - 1, (int)ceilf((v - mnMinY + radius) * invH));
+    if (nMaxCellY < 0) continue;
+    const uint8_t* dMP = in->mp_desc1 + 32 * (size_t)i;
+    int bestDist = 256, bestIdx = -1;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+      for (int iy = nMinCellY; iy <= nMaxCellY; ++iy)
+        for (int idx : cells[(size_t)ix * ROWS + iy]) {
+          const float kpx = in->kp2_xy[2 * idx], kpy = in->kp2_xy[2 * idx + 1];
+          if (!(fabsf(kpx - u) < radius && fabsf(kpy - v) < radius)) continue;
+          const int kpLevel = in->kp2_octave[idx];
+          if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+          if (in->uright2[idx] >= 0) {
+            const float kpr = in->uright2[idx];
+            const float ex = u - kpx, ey = v - kpy, er = ur - kpr;
+            const float e2 = ex * ex + ey * ey + er * er;
+            if (e2 * in->inv_level_sigma2[kpLevel] > 7.8) continue;
+          } else {
+            const float ex = u - kpx, ey = v - kpy;
+            const float e2 = ex * ex + ey * ey;
+            if (e2 * in->inv_level_sigma2[kpLevel] > 5.99) continue;
+          }
+          const int dist = hamming256(dMP, in->desc2 + 32 * (size_t)idx);
+          if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+    if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; ++nFused; }
+  }
+  return nFused;
+}
+
 // ---- ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints), ORBmatcher.cc:43-213 ----
 // (single camera) with RadiusByViewingCos (:215-221) and Frame::GetFeaturesInArea (src/Frame.cc:747-813)
 extern "C" int orc_search_local_points(const orc_local_points_input* in, int* match2) {

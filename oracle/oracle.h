@@ -234,6 +234,40 @@ int orc_search_by_projection_kf(const orc_kf_projection_input* in, int* match2);
  * the camera centre inside the invariance range) and level1[i] = PredictScale. */
 void orc_kf_projection_prepass(const orc_kf_projection_input* in, uint8_t* valid1, int32_t* level1);
 
+/* The per-point search of ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th, bRight = false)
+ * (/root/reference/src/ORBmatcher.cc:1148-1338, single camera) with KeyFrame::GetFeaturesInArea / IsInImage
+ * (src/KeyFrame.cc:704-753) and MapPoint::PredictScale(dist, KeyFrame*) (src/MapPoint.cc:514-529). */
+typedef struct {
+  int n1;                      /* vpMapPoints.size() */
+  const uint8_t* has_mp1;      /* vpMapPoints[i] != NULL */
+  const uint8_t* bad1;         /* pMP->isBad() */
+  const uint8_t* in_kf1;       /* pMP->IsInKeyFrame(pKF) */
+  const float* world_pos1;
+  const float* normal1;        /* pMP->GetNormal() */
+  const uint8_t* mp_desc1;
+  const float* min_dist1;      /* mfMinDistance */
+  const float* max_dist1;      /* mfMaxDistance */
+  int n2;
+  const float* kp2_xy;         /* pKF->mvKeysUn[i].pt */
+  const int32_t* kp2_octave;
+  const float* uright2;
+  const uint8_t* desc2;
+  float grid[6];
+  float Tcw_q[4], Tcw_t[3];
+  float Ow[3];                 /* pKF->GetCameraCenter() */
+  float K[4];
+  float bf;
+  const float* scale_factors;
+  const float* inv_level_sigma2;
+  int n_levels;
+  float log_scale_factor;      /* pKF->mfLogScaleFactor */
+  float th;
+} orc_fuse_input;
+/* best_idx[i] = bestIdx of point i when bestDist <= TH_LOW, else -1 (also for skipped points).  Returns nFused. */
+int orc_fuse_search(const orc_fuse_input* in, int* best_idx);
+/* valid1 / level1 as the caller of rgbl_fuse_search has to provide them. */
+void orc_fuse_prepass(const orc_fuse_input* in, uint8_t* valid1, int32_t* level1);
+
 /* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)
  * (/root/reference/src/ORBmatcher.cc:43-213, single camera; called by Tracking::SearchLocalPoints, Tracking.cc:3447):
  * local map points that Frame::isInFrustum found visible are searched around their predicted projection. */

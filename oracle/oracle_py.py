@@ -125,6 +125,60 @@ def kf_projection_prepass(case):
     return valid, level
 
 
+class FuseInput(C.Structure):
+    """orc_fuse_input: the candidate map points of ORBmatcher::Fuse as the reference sees them."""
+    _fields_ = [("n1", C.c_int), ("has_mp1", C.c_void_p), ("bad1", C.c_void_p), ("in_kf1", C.c_void_p),
+                ("world_pos1", C.c_void_p), ("normal1", C.c_void_p), ("mp_desc1", C.c_void_p), ("min_dist1", C.c_void_p),
+                ("max_dist1", C.c_void_p), ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p),
+                ("uright2", C.c_void_p), ("desc2", C.c_void_p), ("grid", C.c_float * 6), ("Tcw_q", C.c_float * 4),
+                ("Tcw_t", C.c_float * 3), ("Ow", C.c_float * 3), ("K", C.c_float * 4), ("bf", C.c_float),
+                ("scale_factors", C.c_void_p), ("inv_level_sigma2", C.c_void_p), ("n_levels", C.c_int),
+                ("log_scale_factor", C.c_float), ("th", C.c_float)]
+
+
+def make_fuse_input(case, th, keep):
+    """case: dict from tests/parity_checks.make_fuse_case."""
+    def arr(v, dt):
+        a = np.ascontiguousarray(v, dt)
+        keep.append(a)
+        return a.ctypes.data
+    P = FuseInput()
+    P.n1 = len(case["has_mp1"])
+    P.has_mp1, P.bad1, P.in_kf1 = arr(case["has_mp1"], np.uint8), arr(case["bad1"], np.uint8), arr(case["in_kf1"], np.uint8)
+    P.world_pos1, P.normal1 = arr(case["world_pos1"], np.float32), arr(case["normal1"], np.float32)
+    P.mp_desc1 = arr(case["mp_desc1"], np.uint8)
+    P.min_dist1, P.max_dist1 = arr(case["min_dist1"], np.float32), arr(case["max_dist1"], np.float32)
+    P.n2 = len(case["kp2_xy"])
+    P.kp2_xy, P.kp2_octave = arr(case["kp2_xy"], np.float32), arr(case["kp2_octave"], np.int32)
+    P.uright2, P.desc2 = arr(case["uright2"], np.float32), arr(case["desc2"], np.uint8)
+    for name, n in (("grid", 6), ("Tcw_q", 4), ("Tcw_t", 3), ("Ow", 3), ("K", 4)):
+        for i in range(n):
+            getattr(P, name)[i] = float(case[name][i])
+    P.bf = float(case["bf"])
+    P.scale_factors, P.inv_level_sigma2 = arr(case["scale_factors"], np.float32), arr(case["inv_level_sigma2"], np.float32)
+    P.n_levels = len(case["scale_factors"])
+    P.log_scale_factor = float(case["log_scale_factor"])
+    P.th = float(th)
+    return P
+
+
+def fuse_search(case, th=3.0):
+    keep = []
+    P = make_fuse_input(case, th, keep)
+    best = np.zeros(P.n1, np.int32)
+    n = lib().orc_fuse_search(C.byref(P), _p(best))
+    return best, n
+
+
+def fuse_prepass(case):
+    keep = []
+    P = make_fuse_input(case, 3.0, keep)
+    valid = np.zeros(P.n1, np.uint8)
+    level = np.zeros(P.n1, np.int32)
+    lib().orc_fuse_prepass(C.byref(P), _p(valid), _p(level))
+    return valid, level
+
+
 class LocalPointsInput(C.Structure):
     """orc_local_points_input == rgbl_local_points_input (same layout)."""
     _fields_ = [("n1", C.c_int), ("valid1", C.c_void_p), ("proj1", C.c_void_p), ("level1", C.c_void_p),

@@ -29,6 +29,8 @@ bool GeometricCamera::epipolarConstrain(GeometricCamera* other, const cv::KeyPoi
   return dsqr < 3.84 * unc;
 }
 
+std::vector<std::pair<MapPoint*, MapPoint*>>* MapPoint::replace_log = nullptr;
+
 // MapPoint::PredictScale (src/MapPoint.cc:514-546)
 int MapPoint::PredictScale(const float& currentDist, KeyFrame* pKF) {
   const float ratio = mfMaxDistance / currentDist;
@@ -394,4 +396,86 @@ extern "C" int ref_search_by_bow_kf(const KfArrays* a1, const KfArrays* a2, floa
   const int nm = matcher.SearchByBoW(&kf[0], &kf[1], vpMatches12);
   for (int i = 0; i < a1->n; ++i) match12[i] = vpMatches12[i] ? (int)(vpMatches12[i] - pts2.data()) : -1;
   return nm;
+}
+
+// ORBmatcher(0.6, true).Fuse(pKF, vpMapPoints, th) (ORBmatcher.cc:1148-1338) on stand-in objects.  kf_state2: 0 = the feature
+// has no map point, 1 = a good one with more observations than the candidates, 2 = a good one with fewer, 3 = a bad one
+// (all four branches of :1305-1322 are taken).  best_idx[i] = the feature the reference fused point i with, read back from
+// what it did to the objects (AddObservation / Replace), or -1.
+extern "C" int ref_fuse(const orc_fuse_input* in, const uint8_t* kf_state2, int* best_idx) {
+  GeometricCamera cam;
+  cam.fx = in->K[0]; cam.fy = in->K[1]; cam.cx = in->K[2]; cam.cy = in->K[3];
+  KeyFrame kf;
+  std::vector<MapPoint> points(in->n1), owned(in->n2);
+  std::vector<MapPoint*> vp(in->n1, nullptr);
+  kf.N = in->n2;
+  kf.mpCamera = &cam;
+  kf.fx = in->K[0]; kf.fy = in->K[1]; kf.cx = in->K[2]; kf.cy = in->K[3]; kf.mbf = in->bf;
+  kf.mvKeysUn.resize(in->n2);
+  kf.mvpMapPoints.assign(in->n2, nullptr);
+  for (int i = 0; i < in->n2; ++i) {
+    kf.mvKeysUn[i].pt.x = in->kp2_xy[2 * i]; kf.mvKeysUn[i].pt.y = in->kp2_xy[2 * i + 1];
+    kf.mvKeysUn[i].octave = in->kp2_octave[i];
+    if (kf_state2[i]) {
+      owned[i].nObs = kf_state2[i] == 1 ? 9 : 1;
+      owned[i].bad = kf_state2[i] == 3;
+      kf.mvpMapPoints[i] = &owned[i];
+    }
+  }
+  kf.mvKeys = kf.mvKeysUn;
+  kf.mvuRight.assign(in->uright2, in->uright2 + in->n2);
+  kf.mDescriptors = cv::Mat(in->n2, 32, CV_8U);
+  if (in->n2) memcpy(kf.mDescriptors.data, in->desc2, (size_t)in->n2 * 32);
+  kf.mvScaleFactors.assign(in->scale_factors, in->scale_factors + in->n_levels);
+  kf.mvInvLevelSigma2.assign(in->inv_level_sigma2, in->inv_level_sigma2 + in->n_levels);
+  kf.mnScaleLevels = in->n_levels;
+  kf.mfLogScaleFactor = in->log_scale_factor;
+  kf.mTcw = Sophus::SE3f(Eigen::Quaternionf(in->Tcw_q[3], in->Tcw_q[0], in->Tcw_q[1], in->Tcw_q[2]),
+                         Eigen::Vector3f(in->Tcw_t[0], in->Tcw_t[1], in->Tcw_t[2]));
+  kf.mTwc = Sophus::SE3f(Eigen::Quaternionf(1.f, 0.f, 0.f, 0.f), Eigen::Vector3f(in->Ow[0], in->Ow[1], in->Ow[2]));  // only its translation is read
+  kf.grid.mnMinX = in->grid[0]; kf.grid.mnMinY = in->grid[1]; kf.grid.mnMaxX = in->grid[2]; kf.grid.mnMaxY = in->grid[3];
+  kf.grid.mfGridElementWidthInv = in->grid[4]; kf.grid.mfGridElementHeightInv = in->grid[5];
+  kf.grid.Build(kf.mvKeysUn);
+  for (int i = 0; i < in->n1; ++i) {
+    if (!in->has_mp1[i]) continue;
+    MapPoint& mp = points[i];
+    mp.mWorldPos = Eigen::Vector3f(in->world_pos1[3 * i], in->world_pos1[3 * i + 1], in->world_pos1[3 * i + 2]);
+    mp.mNormal = Eigen::Vector3f(in->normal1[3 * i], in->normal1[3 * i + 1], in->normal1[3 * i + 2]);
+    mp.mDescriptor = cv::Mat(1, 32, CV_8U);
+    memcpy(mp.mDescriptor.data, in->mp_desc1 + 32 * (size_t)i, 32);
+    mp.bad = in->bad1[i] != 0;
+    mp.mfMinDistance = in->min_dist1[i];
+    mp.mfMaxDistance = in->max_dist1[i];
+    mp.nObs = 4;
+    if (in->in_kf1[i]) mp.mObservations[&kf] = 0;
+    vp[i] = &mp;
+  }
+  std::vector<std::pair<MapPoint*, MapPoint*>> log;
+  MapPoint::replace_log = &log;
+  ORBmatcher matcher(0.6f, true);
+  const int nFused = matcher.Fuse(&kf, vp, in->th);
+  MapPoint::replace_log = nullptr;
+  for (int i = 0; i < in->n1; ++i) {
+    best_idx[i] = -1;
+    if (!vp[i] || in->in_kf1[i]) continue;
+    auto it = points[i].mObservations.find(&kf);
+    if (it != points[i].mObservations.end()) best_idx[i] = it->second;  // AddObservation(pKF, bestIdx)
+  }
+  // pMP->Replace(pMPinKF) or pMPinKF->Replace(pMP): the one of the two that sits in the key frame (one of its own points, or
+  // an earlier candidate that was added to a free feature) names the feature, the other one is the point being fused
+  auto feature_of = [&](MapPoint* p) -> int {
+    if (p >= owned.data() && p < owned.data() + in->n2) return (int)(p - owned.data());
+    const int i = (int)(p - points.data());
+    if (in->in_kf1[i]) return -1;
+    auto it = p->mObservations.find(&kf);
+    return (it != p->mObservations.end() && kf.mvpMapPoints[it->second] == p) ? it->second : -1;
+  };
+  for (auto& pr : log) {
+    const int fa = feature_of(pr.first), fb = feature_of(pr.second);
+    MapPoint* cand = fa >= 0 ? pr.second : pr.first;
+    const int feat = fa >= 0 ? fa : fb;
+    if (cand >= points.data() && cand < points.data() + in->n1 && best_idx[cand - points.data()] < 0) best_idx[cand - points.data()] = feat;
+  }
+  // a feature holding a bad map point: the match counts (nFused++) but nothing is recorded (best_idx stays -1)
+  return nFused;
 }

@@ -73,6 +73,15 @@ class KeyFrameProjectionInput(C.Structure):
                 ("n_levels", C.c_int), ("th", C.c_float), ("orb_dist", C.c_int), ("check_orientation", C.c_int)]
 
 
+class FuseInput(C.Structure):
+    """rgbl_fuse_input (the per-point search of ORBmatcher::Fuse(pKF, vpMapPoints, th))."""
+    _fields_ = [("n1", C.c_int), ("valid1", C.c_void_p), ("world_pos1", C.c_void_p), ("mp_desc1", C.c_void_p),
+                ("level1", C.c_void_p), ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p),
+                ("uright2", C.c_void_p), ("desc2", C.c_void_p), ("grid", C.c_float * 6), ("Tcw_q", C.c_float * 4),
+                ("Tcw_t", C.c_float * 3), ("K", C.c_float * 4), ("bf", C.c_float), ("scale_factors", C.c_void_p),
+                ("inv_level_sigma2", C.c_void_p), ("n_levels", C.c_int), ("th", C.c_float)]
+
+
 class LocalPointsInput(C.Structure):
     """rgbl_local_points_input (ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...) as flat arrays)."""
     _fields_ = [("n1", C.c_int), ("valid1", C.c_void_p), ("proj1", C.c_void_p), ("level1", C.c_void_p),
@@ -145,6 +154,7 @@ SYMBOLS = {
     "rgbl_search_by_bow_keyframes": (_I, [_V, _V, _V, _F, _I, _V, C.POINTER(_I)]),
     "rgbl_search_by_projection": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_search_local_points": (_I, [_V, _V, _V, C.POINTER(_I)]),
+    "rgbl_fuse_search": (_I, [_V, _V, _V, _V]),
     "rgbl_search_by_projection_keyframe": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_vocabulary_load_text": (_I, [C.c_char_p, _I, C.POINTER(_V)]),
     "rgbl_vocabulary_create": (_I, [_I, _I, _V, _V, _V, _V, _V, _I, C.POINTER(_V)]),

@@ -403,6 +403,71 @@ __global__ __launch_bounds__(kProjBS) void k_proj_resolve(ProjDev P) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The search of ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th, bRight = false)
+// (/root/reference/src/ORBmatcher.cc:1148-1338, single camera) with KeyFrame::GetFeaturesInArea / IsInImage
+// (src/KeyFrame.cc:704-753): every map point looks for its best feature on its own - what the loop does with a match
+// (Replace / AddObservation / AddMapPoint) changes MapPoint and KeyFrame objects and stays with the caller.
+// Uses ProjDev: wpos1, mpdesc1, oct1 (= predicted level), valid1, the grid of k_proj_grid, q / t / K, mbf, th, scale;
+// cand[i] receives the best (distance, cell order, feature) key or ~0.
+struct FuseDev { float inv_sigma2[kProjMaxLevels]; };
+
+// grid = ceil(n1 / 64), block = 64
+__global__ __launch_bounds__(64) void k_fuse_search(ProjDev P, FuseDev Fz) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= P.n1) return;
+  unsigned long long best = ~0ull;
+  if (P.valid1[i]) {
+    float x, y, z;
+    quat_rotate(P.q, P.wpos1[3 * i], P.wpos1[3 * i + 1], P.wpos1[3 * i + 2], &x, &y, &z);
+    x += P.t[0]; y += P.t[1]; z += P.t[2];
+    if (!(z < 0.0f)) {  // depth must be positive (:1201-1206)
+      const float invz = __fdiv_rn(1.0f, z);
+      const float u = __fdiv_rn(P.K[0] * x, z) + P.K[2], v = __fdiv_rn(P.K[1] * y, z) + P.K[3];
+      if (u >= P.grid[0] && u < P.grid[2] && v >= P.grid[1] && v < P.grid[3]) {  // KeyFrame::IsInImage
+        const float ur = u - P.mbf * invz;
+        const int level = P.oct1[i];
+        const float radius = P.th * P.scale[level];
+        const int x0 = imax(0, (int)floorf((u - P.grid[0] - radius) * P.grid[4]));
+        const int x1 = imin(kGridCols - 1, (int)ceilf((u - P.grid[0] + radius) * P.grid[4]));
+        const int y0 = imax(0, (int)floorf((v - P.grid[1] - radius) * P.grid[5]));
+        const int y1 = imin(kGridRows - 1, (int)ceilf((v - P.grid[1] + radius) * P.grid[5]));
+        if (x0 < kGridCols && x1 >= 0 && y0 < kGridRows && y1 >= 0) {
+          const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
+          const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+          for (int ix = x0; ix <= x1; ++ix)
+            for (int iy = y0; iy <= y1; ++iy) {
+              const int cell = ix * kGridRows + iy;
+              const uint32_t kb = P.cell_start[cell], ke = P.cell_start[cell + 1];
+              for (uint32_t k = kb; k < ke; ++k) {
+                const int c = P.cell_items[k];
+                const float kpx = P.xy2[2 * c], kpy = P.xy2[2 * c + 1];
+                if (!(fabsf(kpx - u) < radius && fabsf(kpy - v) < radius)) continue;
+                const int kl = P.oct2[c];
+                if (kl < level - 1 || kl > level) continue;
+                // reprojection error gate, chi-square at 95 % with 3 / 2 degrees of freedom (:1262-1288)
+                const float ex = u - kpx, ey = v - kpy;
+                const float kpr = P.ur2[c];
+                if (kpr >= 0) {
+                  const float er = ur - kpr;
+                  const float e2 = ex * ex + ey * ey + er * er;
+                  if ((double)(e2 * Fz.inv_sigma2[kl]) > 7.8) continue;
+                } else {
+                  const float e2 = ex * ex + ey * ey;
+                  if ((double)(e2 * Fz.inv_sigma2[kl]) > 5.99) continue;
+                }
+                const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
+                const unsigned long long key = proj_key(dist, cell, c);
+                if (key < best) best = key;  // strict '<' over the traversal order
+              }
+            }
+        }
+      }
+    }
+  }
+  P.cand[i] = best;
+}
+
+// ------------------------------------------------------------------------------------------------
 // ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, ...) (ORBmatcher.cc:43-213; single camera),
 // the matcher of Tracking::SearchLocalPoints.  Same greedy order and blocking rule as above, but a point's decision is
 // best AND second-best distance with their pyramid levels (ratio test only inside one level), so the candidates are
@@ -1094,6 +1159,68 @@ int rgbl_search_by_projection_keyframe(rgbl_matcher* m, const rgbl_keyframe_proj
   h.max_dist = in->orb_dist;
   h.check_orientation = in->check_orientation;
   return projection_core(m, h, match2, out_nmatches);
+}
+
+int rgbl_fuse_search(rgbl_matcher* m, const rgbl_fuse_input* in, int32_t* best_idx, int32_t* best_dist) {
+  if (!m || !in || !best_idx || in->n1 < 0 || in->n2 < 0 || in->n2 > 65535 || in->n_levels < 1 || in->n_levels > kProjMaxLevels) {
+    set_error("invalid argument (the key frame may hold at most 65535 features, %d pyramid levels)", kProjMaxLevels);
+    return RGBL_ERR_INVALID;
+  }
+  const int n1 = in->n1, n2 = in->n2;
+  for (int i = 0; i < n1; ++i) { best_idx[i] = -1; if (best_dist) best_dist[i] = 256; }
+  if (n1 == 0 || n2 == 0) return RGBL_OK;
+  for (int i = 0; i < n1; ++i)
+    if (in->valid1[i] && (in->level1[i] < 0 || in->level1[i] >= in->n_levels)) { set_error("predicted level out of range"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(m->device));
+  size_t need = pad256(n1) + pad256((size_t)n1 * 12) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 8) +
+                pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 2 +
+                pad256((size_t)n1 * 8) + pad256((size_t)(kGridCells + 1) * 4);
+  RGBL_TRY(ensure_arena(m, need));
+  Arena A{m->d_buf};
+  hipStream_t s = m->stream;
+  ProjDev P{};
+  P.n1 = n1; P.n2 = n2;
+  RGBL_TRY(upload(A, s, &P.valid1, in->valid1, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.wpos1, in->world_pos1, (size_t)n1 * 3));
+  RGBL_TRY(upload(A, s, &P.mpdesc1, in->mp_desc1, (size_t)n1 * 32));
+  RGBL_TRY(upload(A, s, &P.oct1, in->level1, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.xy2, in->kp2_xy, (size_t)n2 * 2));
+  RGBL_TRY(upload(A, s, &P.oct2, in->kp2_octave, (size_t)n2));
+  RGBL_TRY(upload(A, s, &P.ur2, in->uright2, (size_t)n2));
+  RGBL_TRY(upload(A, s, &P.desc2, in->desc2, (size_t)n2 * 32));
+  P.cell_start = A.take<uint32_t>(kGridCells + 1);
+  P.cell_items = A.take<uint16_t>(n2);
+  P.taken_by = A.take<int32_t>(n2);  // written by k_proj_grid, not used by the fuse search
+  P.cand = A.take<unsigned long long>(n1);
+  memcpy(P.grid, in->grid, sizeof(P.grid));
+  memcpy(P.q, in->Tcw_q, sizeof(P.q));
+  memcpy(P.t, in->Tcw_t, sizeof(P.t));
+  memcpy(P.K, in->K, sizeof(P.K));
+  P.mbf = in->bf;
+  P.th = in->th;
+  FuseDev Fz;
+  for (int l = 0; l < kProjMaxLevels; ++l) {
+    P.scale[l] = l < in->n_levels ? in->scale_factors[l] : 1.f;
+    Fz.inv_sigma2[l] = l < in->n_levels ? in->inv_level_sigma2[l] : 1.f;
+  }
+  m->timer.begin("k_proj_grid", s);
+  hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
+  m->timer.end(s);
+  m->timer.begin("k_fuse_search", s);
+  hipLaunchKernelGGL(k_fuse_search, dim3((n1 + 63) / 64), dim3(64), 0, s, P, Fz);
+  m->timer.end(s);
+  RGBL_HIP(hipGetLastError());
+  std::vector<unsigned long long> keys(n1);
+  RGBL_HIP(hipMemcpyAsync(keys.data(), P.cand, sizeof(unsigned long long) * n1, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipStreamSynchronize(s));
+  m->timer.collect();
+  for (int i = 0; i < n1; ++i) {
+    if (keys[i] == ~0ull) continue;
+    const int dist = (int)(keys[i] >> 32);
+    if (best_dist) best_dist[i] = dist;
+    if (dist <= 50 /* TH_LOW */) best_idx[i] = (int)(keys[i] & 0xffffu);
+  }
+  return RGBL_OK;
 }
 
 int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in, int32_t* match2, int* out_nmatches) {

@@ -385,6 +385,37 @@ class ORBmatcher:
         L.check(self.lib, self.lib.rgbl_search_by_projection_keyframe(self.h, C.byref(P), L.ptr(match2), C.byref(n)))
         return match2, n.value
 
+    def FuseSearch(self, case, th=3.0):
+        """The search of ORBmatcher::Fuse(pKF, vpMapPoints, th) (ORBmatcher.cc:1148-1338): for every candidate map point the
+        key-frame feature it would be fused with (bestDist <= TH_LOW) or -1, and bestDist.  case: dict with valid1 (map point
+        present, good, not yet in the key frame, inside its scale-invariance range, seen under less than 60 degrees),
+        world_pos1, mp_desc1, level1 (PredictScale), the key-frame arrays kp2_xy, kp2_octave, uright2, desc2, and grid[6],
+        Tcw_q / Tcw_t, K[4], bf, scale_factors, inv_level_sigma2."""
+        keep = []
+
+        def arr(v, dt):
+            a = np.ascontiguousarray(v, dt)
+            keep.append(a)
+            return a.ctypes.data
+        P = L.FuseInput()
+        P.n1 = len(case["valid1"])
+        P.valid1, P.world_pos1 = arr(case["valid1"], np.uint8), arr(case["world_pos1"], np.float32)
+        P.mp_desc1, P.level1 = arr(case["mp_desc1"], np.uint8), arr(case["level1"], np.int32)
+        P.n2 = len(case["kp2_xy"])
+        P.kp2_xy, P.kp2_octave = arr(case["kp2_xy"], np.float32), arr(case["kp2_octave"], np.int32)
+        P.uright2, P.desc2 = arr(case["uright2"], np.float32), arr(case["desc2"], np.uint8)
+        for name, n in (("grid", 6), ("Tcw_q", 4), ("Tcw_t", 3), ("K", 4)):
+            for i in range(n):
+                getattr(P, name)[i] = float(case[name][i])
+        P.bf = float(case["bf"])
+        P.scale_factors, P.inv_level_sigma2 = arr(case["scale_factors"], np.float32), arr(case["inv_level_sigma2"], np.float32)
+        P.n_levels = len(case["scale_factors"])
+        P.th = float(th)
+        best = np.zeros(P.n1, np.int32)
+        dist = np.zeros(P.n1, np.int32)
+        L.check(self.lib, self.lib.rgbl_fuse_search(self.h, C.byref(P), L.ptr(best), L.ptr(dist)))
+        return best, dist
+
     def SearchLocalPoints(self, pts, th):
         """ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) (ORBmatcher.cc:43-213), the call of
         Tracking::SearchLocalPoints.  pts: dict with the map point arrays valid1, proj1 [n,3] (mTrackProjX, mTrackProjY,

@@ -307,6 +307,86 @@ class ORBmatcher {
     return nmatches;
   }
 
+  // Project MapPoints into KeyFrame and search for duplicated MapPoints (LocalMapping::SearchInNeighbors, LocalMapping.cc:737-879).
+  // ORBmatcher.h:83, ORBmatcher.cc:1148-1338.  The tests that need the MapPoint object are evaluated here as the reference
+  // loop does, the search of all points runs on the device (a point's search does not depend on what the loop did with the
+  // points before it), then the loop's bookkeeping - Replace / AddObservation / AddMapPoint, ORBmatcher.cc:1303-1325 - is
+  // applied in order; a point that an earlier step of that bookkeeping put into the key frame or made bad is skipped, as the
+  // reference's tests at the top of its loop body would.
+  template <class KeyFrameT, class MapPointT>
+  int Fuse(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints, const float th = 3.0, const bool bRight = false) {
+    if (!mpHandle) return 0;
+    if (bRight || pKF->NLeft != -1) {
+      std::cerr << "[ORBmatcher] Fuse: fisheye stereo rigs are not covered by the device path" << std::endl;
+      return 0;
+    }
+    const auto Tcw = pKF->GetPose();
+    const auto Ow = pKF->GetCameraCenter();
+    const int n1 = (int)vpMapPoints.size(), n2 = pKF->N;
+    std::vector<uint8_t> valid(n1, 0), desc1((size_t)n1 * 32, 0);
+    std::vector<float> pos((size_t)n1 * 3, 0.f), xy2((size_t)n2 * 2);
+    std::vector<int32_t> level1(n1, 0), oct2(n2);
+    for (int i = 0; i < n1; ++i) {
+      MapPointT* pMP = vpMapPoints[i];
+      if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+      const auto p3Dw = pMP->GetWorldPos();
+      const auto PO = p3Dw - Ow;
+      const float dist3D = PO.norm();
+      if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) continue;
+      const auto Pn = pMP->GetNormal();
+      if (PO.dot(Pn) < 0.5 * dist3D) continue;  // viewing angle must be less than 60 deg
+      valid[i] = 1;
+      level1[i] = pMP->PredictScale(dist3D, pKF);
+      for (int k = 0; k < 3; ++k) pos[3 * (size_t)i + k] = p3Dw(k);
+      const cv::Mat dMP = pMP->GetDescriptor();
+      memcpy(&desc1[(size_t)i * 32], dMP.ptr<uint8_t>(), 32);
+    }
+    for (int i = 0; i < n2; ++i) {
+      xy2[2 * (size_t)i] = pKF->mvKeysUn[i].pt.x;
+      xy2[2 * (size_t)i + 1] = pKF->mvKeysUn[i].pt.y;
+      oct2[i] = pKF->mvKeysUn[i].octave;
+    }
+    rgbl_fuse_input in;
+    in.n1 = n1; in.valid1 = valid.data(); in.world_pos1 = pos.data(); in.mp_desc1 = desc1.data(); in.level1 = level1.data();
+    in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.uright2 = pKF->mvuRight.data();
+    in.desc2 = pKF->mDescriptors.template ptr<uint8_t>();
+    in.grid[0] = pKF->mnMinX; in.grid[1] = pKF->mnMinY; in.grid[2] = pKF->mnMaxX; in.grid[3] = pKF->mnMaxY;
+    in.grid[4] = pKF->mfGridElementWidthInv; in.grid[5] = pKF->mfGridElementHeightInv;
+    in.Tcw_q[0] = Tcw.unit_quaternion().x(); in.Tcw_q[1] = Tcw.unit_quaternion().y(); in.Tcw_q[2] = Tcw.unit_quaternion().z();
+    in.Tcw_q[3] = Tcw.unit_quaternion().w();
+    for (int k = 0; k < 3; ++k) in.Tcw_t[k] = Tcw.translation()(k);
+    for (int k = 0; k < 4; ++k) in.K[k] = pKF->mpCamera->getParameter(k);
+    in.bf = pKF->mbf;
+    in.scale_factors = pKF->mvScaleFactors.data();
+    in.inv_level_sigma2 = pKF->mvInvLevelSigma2.data();
+    in.n_levels = (int)pKF->mvScaleFactors.size();
+    in.th = th;
+    std::vector<int32_t> best(n1, -1);
+    if (rgbl_fuse_search(mpHandle, &in, best.data(), NULL) != RGBL_OK) {
+      std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
+      return 0;
+    }
+    int nFused = 0;
+    for (int i = 0; i < n1; ++i) {
+      if (best[i] < 0) continue;
+      MapPointT* pMP = vpMapPoints[i];
+      if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+      // If there is already a MapPoint replace otherwise add new measurement
+      MapPointT* pMPinKF = pKF->GetMapPoint(best[i]);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) {
+          if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+          else pMPinKF->Replace(pMP);
+        }
+      } else {
+        pMP->AddObservation(pKF, best[i]);
+        pKF->AddMapPoint(pMP, best[i]);
+      }
+      nFused++;
+    }
+    return nFused;
+  }
+
   // Search matches between Frame keypoints and projected MapPoints.  Used to track the local map (Tracking::SearchLocalPoints,
   // Tracking.cc:3370-3450).  ORBmatcher.h:45, ORBmatcher.cc:43-213.  Reads what Frame::isInFrustum left in every MapPoint
   // (mbTrackInView, mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos, mTrackDepth) and writes F.mvpMapPoints.

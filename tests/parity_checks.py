@@ -838,3 +838,60 @@ def check_search_by_bow_keyframes(lib, seed=81, nnratio=0.75, check_ori=True, n=
     assert nm == onm and np.array_equal(m, om), "SearchByBoW(KF, KF) (seed %d)" % seed
     mt.close()
     return nm
+
+
+def make_fuse_case(n1=2500, n2=2000, seed=91):
+    """Map points of neighbouring key frames projected into a key frame (LocalMapping::SearchInNeighbors -> ORBmatcher::Fuse):
+    built on the relocalisation case (same clusters, points behind the camera, invariance ranges) plus normals (some seen
+    under more than 60 degrees), points already in the key frame, stereo / mono key-frame features (both chi-square gates)."""
+    c = make_relocalization_case(n1, n2, seed)
+    base = make_projection_case(n1, n2, seed, "none")
+    rng = np.random.default_rng(seed + 2000)
+    q, t = c["Tcw_q"], c["Tcw_t"]
+    Rc = _rot(q)
+    Ow = (-Rc.T @ t.astype(np.float64)).astype(np.float32)
+    PO = c["world_pos1"].astype(np.float64) - Ow
+    dist = np.linalg.norm(PO, axis=1, keepdims=True)
+    normal = PO / np.maximum(dist, 1e-6) + rng.normal(0, 0.35, PO.shape)       # roughly towards the camera ...
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    flip = rng.random(n1) < 0.08
+    normal[flip] *= -1                                                           # ... some from behind
+    sf = c["scale_factors"]
+    return dict(has_mp1=c["has_mp1"], bad1=c["bad1"], in_kf1=(rng.random(n1) < 0.1).astype(np.uint8),
+                world_pos1=c["world_pos1"], normal1=normal.astype(np.float32), mp_desc1=c["mp_desc1"],
+                min_dist1=c["min_dist1"], max_dist1=c["max_dist1"], kp2_xy=c["kp2_xy"], kp2_octave=c["kp2_octave"],
+                uright2=base["uright2"], desc2=c["desc2"], grid=c["grid"], Tcw_q=q, Tcw_t=t, Ow=Ow, K=c["K"],
+                bf=np.float32(base["mbf"]), scale_factors=sf,
+                inv_level_sigma2=(np.float32(1.0) / (sf * sf).astype(np.float32)).astype(np.float32),
+                log_scale_factor=c["log_scale_factor"])
+
+
+def fuse_prepass(case):
+    """The tests of the Fuse loop that need the MapPoint object, numpy float32 + the C library's logf."""
+    Ow = np.asarray(case["Ow"], np.float32)
+    PO = (np.asarray(case["world_pos1"], np.float32) - Ow).astype(np.float32)
+    sq = (PO * PO).astype(np.float32)
+    dist = np.sqrt((sq[:, 0] + (sq[:, 1] + sq[:, 2]).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    Pn = np.asarray(case["normal1"], np.float32)
+    pr = (PO * Pn).astype(np.float32)
+    dot = (pr[:, 0] + (pr[:, 1] + pr[:, 2]).astype(np.float32)).astype(np.float32)
+    max_inv = (np.float32(1.2) * case["max_dist1"]).astype(np.float32)
+    min_inv = (np.float32(0.8) * case["min_dist1"]).astype(np.float32)
+    valid = ((case["has_mp1"] != 0) & (case["bad1"] == 0) & (case["in_kf1"] == 0) & ~(dist < min_inv) & ~(dist > max_inv) &
+             ~(dot.astype(np.float64) < 0.5 * dist.astype(np.float64)))
+    level = F.ORBmatcher.PredictScale(dist, case["max_dist1"], case["log_scale_factor"], len(case["scale_factors"]))
+    return valid.astype(np.uint8), np.where(valid, level, 0).astype(np.int32)
+
+
+def check_fuse_search(lib, seed=91, th=3.0, n1=2500, n2=2000):
+    case = make_fuse_case(n1, n2, seed)
+    valid, level = fuse_prepass(case)
+    ovalid, olevel = O.fuse_prepass(case)
+    assert np.array_equal(valid, ovalid) and np.array_equal(level[valid != 0], olevel[valid != 0]), "fuse prepass"
+    mt = F.ORBmatcher(0.6, True, lib=lib)
+    best, dist = mt.FuseSearch(dict(case, valid1=valid, level1=level), th)
+    obest, on = O.fuse_search(case, th)
+    assert np.array_equal(best, obest), "Fuse search (seed %d, th %g)" % (seed, th)
+    assert int((best >= 0).sum()) == on and np.all(dist[best >= 0] <= 50) and np.all((dist[best < 0] > 50))
+    mt.close()
+    return on

@@ -85,13 +85,26 @@ def run_and_check(exe, tmp):
                         ("kp2_xy", np.float32), ("kp2_octave", np.int32), ("kp2_angle", np.float32), ("desc2", np.uint8),
                         ("occupied2", np.uint8)):
             f.write(np.ascontiguousarray(rcase[key], dt).tobytes())
+    fcase = pc.make_fuse_case(2000, 1600, seed=95)
+    fstate = np.random.default_rng(95).choice([0, 1, 2, 3], len(fcase["kp2_xy"]), p=[0.5, 0.2, 0.2, 0.1]).astype(np.uint8)
+    with open(os.path.join(tmp, "fuse.bin"), "wb") as f:
+        f.write(struct.pack("<iif", len(fcase["has_mp1"]), len(fcase["kp2_xy"]), 3.0))
+        hdr = np.concatenate([fcase["grid"], fcase["Tcw_q"], fcase["Tcw_t"], fcase["Ow"], fcase["K"], [fcase["bf"]],
+                              fcase["scale_factors"], fcase["inv_level_sigma2"], [fcase["log_scale_factor"]]]).astype(np.float32)
+        assert hdr.size == 38
+        f.write(hdr.tobytes())
+        for key, dt in (("has_mp1", np.uint8), ("bad1", np.uint8), ("in_kf1", np.uint8), ("world_pos1", np.float32),
+                        ("normal1", np.float32), ("mp_desc1", np.uint8), ("min_dist1", np.float32), ("max_dist1", np.float32),
+                        ("kp2_xy", np.float32), ("kp2_octave", np.int32), ("uright2", np.float32), ("desc2", np.uint8)):
+            f.write(np.ascontiguousarray(fcase[key], dt).tobytes())
+        f.write(fstate.tobytes())
     voc = synth.make_vocabulary(10, 3, seed=5)
     synth.write_vocabulary_text(os.path.join(tmp, "voc.txt"), voc)
     out = os.path.join(tmp, "out.bin")
     res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "KITTI00-02.yaml"), os.path.join(tmp, "img.raw"), str(w), str(h),
                           os.path.join(tmp, "cloud.raw"), str(cloud.shape[1]), os.path.join(tmp, "tri.bin"), out,
                           os.path.join(tmp, "proj.bin"), os.path.join(tmp, "local.bin"), os.path.join(tmp, "voc.txt"),
-                          os.path.join(tmp, "reloc.bin")],
+                          os.path.join(tmp, "reloc.bin"), os.path.join(tmp, "fuse.bin")],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "Lidar Method: InverseDilation" in res.stdout
@@ -142,7 +155,11 @@ def run_and_check(exe, tmp):
     reloc_match = take(np.int32, n2r)
     nkk, n1k = take(np.int32, 2)
     kk_match = take(np.int32, n1k)
+    nfused, nq = take(np.int32, 2)
+    fused_with = take(np.int32, nq)
     assert pos == len(buf)
+    ofb, onf = O.fuse_search(fcase, 3.0)
+    assert nfused == onf and np.array_equal(fused_with, ofb[ofb >= 0]) and nfused > 150   # in order: one GetMapPoint per fused point
     okk, onkk = O.search_by_bow_kf(kf1, kf2, 0.75, True)
     assert nkk == onkk and np.array_equal(kk_match, okk) and nkk > 50
     orm, orn = O.search_by_projection_kf(rcase, 10.0, 100, True)

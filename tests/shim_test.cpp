@@ -66,6 +66,7 @@ struct Quat { float qx, qy, qz, qw; float x() const { return qx; } float y() con
 struct V3n : V3 {  // what Eigen's "a - b" offers the relocalisation matcher: norm() as sqrt of the unrolled sum x*x + (y*y + z*z)
   V3n(const V3& a) : V3(a) {}
   float norm() const { return sqrtf(v[0] * v[0] + (v[1] * v[1] + v[2] * v[2])); }
+  float dot(const V3& o) const { return v[0] * o.v[0] + (v[1] * o.v[1] + v[2] * o.v[2]); }
 };
 static V3n operator-(const V3& a, const V3& b) { return V3n(V3{{a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2]}}); }
 struct QPose {
@@ -121,6 +122,46 @@ int TrackedPoint::PredictScale(const float& currentDist, TestFrame* pF) {
   int nScale = ceil(log(ratio) / pF->mfLogScaleFactor);
   if (nScale < 0) nScale = 0;
   else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+  return nScale;
+}
+// ---- stand-ins for what ORBmatcher::Fuse touches
+struct FuseKF;
+struct FusePoint {
+  V3 pos, normal; cv::Mat desc; bool bad = false, in_kf = false; int nObs = 4;
+  float mfMinDistance = 0, mfMaxDistance = 0;
+  bool isBad() { return bad; }
+  bool IsInKeyFrame(FuseKF*) { return in_kf; }
+  V3 GetWorldPos() { return pos; }
+  V3 GetNormal() { return normal; }
+  cv::Mat GetDescriptor() { return desc; }
+  int Observations() { return nObs; }
+  float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
+  float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+  int PredictScale(const float& currentDist, FuseKF* pKF);
+  void AddObservation(FuseKF*, int) { in_kf = true; ++nObs; }
+  void Replace(FusePoint*) {}  // rewires the map; the test reads the fused feature from FuseKF::GetMapPoint's log
+};
+struct FuseKF {
+  int N = 0, NLeft = -1;
+  float mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0, mbf = 0, mfLogScaleFactor = 0;
+  int mnScaleLevels = 0;
+  Camera* mpCamera = nullptr;
+  std::vector<cv::KeyPoint> mvKeysUn;
+  std::vector<float> mvuRight, mvScaleFactors, mvInvLevelSigma2;
+  std::vector<FusePoint*> mps;
+  std::vector<int> queried;  // every GetMapPoint(idx) of the bookkeeping loop = the feature a point was fused with
+  cv::Mat mDescriptors;
+  QPose pose; V3 Ow;
+  QPose GetPose() { return pose; }
+  V3 GetCameraCenter() { return Ow; }
+  FusePoint* GetMapPoint(size_t idx) { queried.push_back((int)idx); return mps[idx]; }
+  void AddMapPoint(FusePoint* p, size_t idx) { mps[idx] = p; }
+};
+int FusePoint::PredictScale(const float& currentDist, FuseKF* pKF) {
+  const float ratio = mfMaxDistance / currentDist;
+  int nScale = ceil(log(ratio) / pKF->mfLogScaleFactor);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= pKF->mnScaleLevels) nScale = pKF->mnScaleLevels - 1;
   return nScale;
 }
 struct RelocKeyFrame {
@@ -423,6 +464,50 @@ int main(int argc, char** argv) {
     const int n1k = (int)vpMatches12.size();
     wr(out, &nkk, 1); wr(out, &n1k, 1);
     for (int i = 0; i < n1k; ++i) { const int idx = vpMatches12[i] ? (int)(vpMatches12[i] - own2.data()) : -1; wr(out, &idx, 1); }
+  }
+  // --- as LocalMapping::SearchInNeighbors (LocalMapping.cc:737-879): matcher.Fuse(pKFi, vpMapPointMatches)
+  if (argc > 13) {
+    f = fopen(argv[13], "rb");
+    int n1 = 0, n2 = 0;
+    float th = 0, hdr[6 + 7 + 3 + 4 + 1 + 8 + 8 + 1];
+    if (!f || !rd(f, &n1, 1) || !rd(f, &n2, 1) || !rd(f, &th, 1) || !rd(f, hdr, 38)) return 10;
+    std::vector<unsigned char> has(n1), bad(n1), inkf(n1), d1((size_t)n1 * 32), d2((size_t)n2 * 32), state(n2);
+    std::vector<float> pos((size_t)n1 * 3), nor((size_t)n1 * 3), mind(n1), maxd(n1), xy2((size_t)n2 * 2), ur2(n2);
+    std::vector<int> o2(n2);
+    rd(f, has.data(), n1); rd(f, bad.data(), n1); rd(f, inkf.data(), n1); rd(f, pos.data(), (size_t)n1 * 3); rd(f, nor.data(), (size_t)n1 * 3);
+    rd(f, d1.data(), (size_t)n1 * 32); rd(f, mind.data(), n1); rd(f, maxd.data(), n1);
+    rd(f, xy2.data(), (size_t)n2 * 2); rd(f, o2.data(), n2); rd(f, ur2.data(), n2); rd(f, d2.data(), (size_t)n2 * 32); rd(f, state.data(), n2);
+    fclose(f);
+    Camera pcam; for (int k = 0; k < 4; ++k) pcam.p[k] = hdr[16 + k];
+    FuseKF kf;
+    kf.N = n2; kf.mpCamera = &pcam;
+    kf.mnMinX = hdr[0]; kf.mnMinY = hdr[1]; kf.mnMaxX = hdr[2]; kf.mnMaxY = hdr[3]; kf.mfGridElementWidthInv = hdr[4]; kf.mfGridElementHeightInv = hdr[5];
+    kf.pose.q = Quat{hdr[6], hdr[7], hdr[8], hdr[9]}; kf.pose.t = V3{{hdr[10], hdr[11], hdr[12]}};
+    kf.Ow = V3{{hdr[13], hdr[14], hdr[15]}};
+    kf.mbf = hdr[20];
+    kf.mvScaleFactors.assign(hdr + 21, hdr + 29); kf.mvInvLevelSigma2.assign(hdr + 29, hdr + 37);
+    kf.mnScaleLevels = 8; kf.mfLogScaleFactor = hdr[37];
+    kf.mvKeysUn.resize(n2);
+    for (int i = 0; i < n2; ++i) { kf.mvKeysUn[i].pt.x = xy2[2 * i]; kf.mvKeysUn[i].pt.y = xy2[2 * i + 1]; kf.mvKeysUn[i].octave = o2[i]; }
+    kf.mvuRight = ur2;
+    kf.mDescriptors.create(n2, 32, CV_8U); memcpy(kf.mDescriptors.data, d2.data(), (size_t)n2 * 32);
+    std::vector<FusePoint> owned(n2), pts(n1);
+    kf.mps.assign(n2, nullptr);
+    for (int i = 0; i < n2; ++i)
+      if (state[i]) { owned[i].nObs = state[i] == 1 ? 9 : 1; owned[i].bad = state[i] == 3; owned[i].in_kf = true; kf.mps[i] = &owned[i]; }
+    std::vector<FusePoint*> vp(n1, nullptr);
+    for (int i = 0; i < n1; ++i) {
+      if (!has[i]) continue;
+      FusePoint& p = pts[i];
+      p.pos = V3{{pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]}}; p.normal = V3{{nor[3 * i], nor[3 * i + 1], nor[3 * i + 2]}};
+      p.desc.create(1, 32, CV_8U); memcpy(p.desc.data, &d1[(size_t)i * 32], 32);
+      p.bad = bad[i] != 0; p.in_kf = inkf[i] != 0; p.mfMinDistance = mind[i]; p.mfMaxDistance = maxd[i];
+      vp[i] = &p;
+    }
+    ORB_SLAM3::ORBmatcher fuser(0.6, true);
+    const int nFused = fuser.Fuse(&kf, vp, th);
+    const int nq = (int)kf.queried.size();
+    wr(out, &nFused, 1); wr(out, &nq, 1); wr(out, kf.queried.data(), nq);
   }
   fclose(out);
   printf("shim_test ok: %d keypoints, %d depths, %d triangulation matches\n", nk, nd, nm);

@@ -148,3 +148,8 @@ def test_search_by_bow(emu_lib, seed, ratio, ori, nodes):
 @pytest.mark.parametrize("seed,ratio,ori,nodes", [(81, 0.75, True, 100), (82, 0.9, False, 30), (84, 0.8, True, 1)])
 def test_search_by_bow_keyframes(emu_lib, seed, ratio, ori, nodes):
     assert pc.check_search_by_bow_keyframes(emu_lib, seed, ratio, ori, n=800, nodes=nodes) > 50
+
+
+@pytest.mark.parametrize("seed,th", [(91, 3.0), (93, 4.0), (94, 1.5)])
+def test_fuse_search(emu_lib, seed, th):
+    assert pc.check_fuse_search(emu_lib, seed, th, n1=1200, n2=1000) > 80

@@ -458,3 +458,29 @@ def test_reference_search_by_bow_agrees_with_oracle(refmatcher, seed, nnratio, c
     om, onm = O.search_by_bow(dict(kf, has_mp=(state == 1).astype(np.uint8)), fr, nnratio, check_ori)
     assert nm == onm and np.array_equal(m, om)
     assert nm > 100
+
+
+@pytest.mark.parametrize("seed,th", [(91, 3.0), (92, 3.0), (93, 4.0), (94, 1.5)])
+def test_reference_fuse_agrees_with_oracle(refmatcher, seed, th):
+    """The real ORBmatcher::Fuse(pKF, vpMapPoints, th) (LocalMapping::SearchInNeighbors: ORBmatcher().Fuse(pKFi, vpMapPointMatches),
+    th = 3) on stand-in objects: which feature every point was fused with is read back from what the function did to them
+    (AddObservation / the recorded Replace calls) and must be the restatement's bestIdx; nFused must agree."""
+    import parity_checks as pc
+    case = pc.make_fuse_case(seed=seed)
+    rng = np.random.default_rng(seed)
+    state = rng.choice([0, 1, 2, 3], len(case["kp2_xy"]), p=[0.5, 0.2, 0.2, 0.1]).astype(np.uint8)
+    keep = []
+    P = O.make_fuse_input(case, th, keep)
+    best = np.zeros(P.n1, np.int32)
+    refmatcher.ref_fuse.restype = C.c_int
+    refmatcher.ref_fuse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    nf = refmatcher.ref_fuse(C.byref(P), state.ctypes.data, best.ctypes.data)
+    obest, onf = O.fuse_search(case, th)
+    assert nf == onf and nf > 200
+    seen = best >= 0
+    assert np.array_equal(best[seen], obest[seen])
+    # matches the reference counted but left no trace of: the feature held a bad map point (ORBmatcher.cc:1308)
+    silent = (~seen) & (obest >= 0)
+    assert np.all(state[obest[silent]] == 3) and seen.sum() + silent.sum() == nf
+    for s in (0, 1, 2):
+        assert np.any(state[obest[seen]] == s)          # AddObservation and both Replace directions were exercised
