@@ -36,9 +36,14 @@ __device__ __forceinline__ int hamming256(const unsigned long long q[4], const u
 // multiplicity.  The four partial results are merged through LDS with the same two operations.
 // grid = (ceil(cap/64), n_pairs), block = 256.  Requires train counts < 65536.
 __device__ __forceinline__ void bf_track(uint32_t& best, uint32_t& second, uint32_t cur) {
+  // best <= second always: the new second is the median of (best, cur, second) - one v_med3_u32 instead of max + min
+#ifdef RGBL_EMU
   const uint32_t hi = best > cur ? best : cur;
-  best = best < cur ? best : cur;
   second = second < hi ? second : hi;
+#else
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(second) : "v"(best), "v"(cur), "v"(second));
+#endif
+  best = best < cur ? best : cur;
 }
 
 __global__ __launch_bounds__(256) void k_hamming_bf(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_rows,
