@@ -114,6 +114,17 @@ int rgbl_extract_color(rgbl_extractor* h, const uint8_t* img, int channels, int 
                        int lap0, int lap1, rgbl_keypoint* out_kp, uint8_t* out_desc, int cap, int* out_n, int* out_mono,
                        uint8_t* out_gray, int gray_stride);
 
+/* Frame::UndistortKeyPoints / the corner undistortion of Frame::ComputeImageBounds (src/Frame.cc:837-870, 872-900):
+ * cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) - normalise, OpenCV's 5 fixed-point iterations of the inverse
+ * Brown-Conrady model in double, re-project with the same K.  K = fx, fy, cx, cy; dist = k1, k2, p1, p2[, k3] (n_dist 4 or 5).
+ * SURVEY.md 8(f) row f3.  The reference skips the call when mDistCoef[0] == 0 (the KITTI settings); the shim keeps that test.
+ * Host pointers, synchronous: n (x, y) pairs in, n pairs out (in place allowed). */
+int rgbl_undistort_points(rgbl_extractor* h, const float* xy, int n, const float K[4], const float* dist, int n_dist, float* out_xy);
+/* The keypoints of rgbl_extract_batch_device() (frame b at d_kp + b*cap, d_n counts) -> their undistorted coordinates,
+ * d_xy_un[b][i] = (x, y) as 2 floats (cap pairs per frame); enqueued on the handle's stream. */
+int rgbl_undistort_keypoints_batch_device(rgbl_extractor* h, const rgbl_keypoint* d_kp, const int32_t* d_n, int batch, int cap,
+                                          const float K[4], const float* dist, int n_dist, float* d_xy_un);
+
 /* std::vector<cv::Mat> mvImagePyramid (ORBextractor.h:83; read by Frame::ComputeStereoMatches,
  * Frame.cc:908,998-1013).  Copies level `level` of frame `frame` of the LAST call to host memory.
  * with_border=1 adds the 19-px BORDER_REFLECT_101 frame the reference keeps around every level

@@ -100,6 +100,10 @@ class Mat {
   Mat row(int r) const { return rowRange(r, r + 1); }
   template <class T> T& at(int r, int c) { return ((T*)(data + (size_t)r * step))[c]; }
   template <class T> const T& at(int r, int c) const { return ((const T*)(data + (size_t)r * step))[c]; }
+  // element i of a vector stored as a row or as a column (cv::Mat::at(int i0))
+  template <class T> T& at(int i) { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
+  template <class T> const T& at(int i) const { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
+  size_t total() const { return (size_t)rows * cols; }
   template <class T> T* ptr(int r = 0) { return (T*)(data + (size_t)r * step); }
   template <class T> const T* ptr(int r = 0) const { return (const T*)(data + (size_t)r * step); }
   uchar* ptr(int r = 0) { return data + (size_t)r * step; }

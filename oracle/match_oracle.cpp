@@ -301,6 +301,39 @@ extern "C" int orc_search_by_projection(const orc_projection_input* in, int* mat
   return nmatches;
 }
 
+// ---- Frame::UndistortKeyPoints, Frame.cc:837-870 = cv::undistortPoints(src, dst, K, D, noArray(), P = K) ----
+// OpenCV 4.x cvUndistortPointsInternal: double arithmetic, k[0..4] = k1 k2 p1 p2 k3, k[5..13] = 0, tilt model off (identity),
+// R = identity so RR = P * R = K, criteria = 5 iterations (no epsilon test).
+extern "C" void orc_undistort_points(const float* xy, int n, const float K[4], const float* dist, int n_dist, float* out_xy) {
+  double k[14] = {0};
+  for (int i = 0; i < n_dist && i < 5; ++i) k[i] = (double)dist[i];
+  const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+  const double ifx = 1. / fx, ify = 1. / fy;
+  const double RR[3][3] = {{fx, 0, cx}, {0, fy, cy}, {0, 0, 1}};
+  for (int i = 0; i < n; ++i) {
+    double x = xy[2 * i], y = xy[2 * i + 1], x0, y0;
+    const double u = x, v = y;
+    x = (x - cx) * ifx;
+    y = (y - cy) * ify;
+    x0 = x; y0 = y;  // invMatTilt = identity: vecUntilt = (x, y, 1), invProj = 1
+    for (int j = 0;; j++) {
+      if (j >= 5) break;
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+      const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+      const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+    const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+    const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+    out_xy[2 * i] = (float)(xx * ww);
+    out_xy[2 * i + 1] = (float)(yy * ww);
+  }
+}
+
 // ---- ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist), ORBmatcher.cc:1889-2010 ----
 namespace {
 // the part of the loop body that needs the MapPoint object (:1908-1937 without the projection): -1 = skipped, else PredictScale

@@ -197,6 +197,11 @@ typedef struct {
  * Returns nmatches exactly as the reference counts it. */
 int orc_search_by_projection(const orc_projection_input* in, int* match2);
 
+/* Frame::UndistortKeyPoints (/root/reference/src/Frame.cc:837-870): cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK).
+ * OpenCV-internal arithmetic (cvUndistortPointsInternal with TermCriteria(MAX_ITER, 5, 0.01)), restated from upstream
+ * knowledge - parity unpinned, like the other cv:: primitives.  K = fx, fy, cx, cy; dist = k1, k2, p1, p2[, k3]. */
+void orc_undistort_points(const float* xy, int n, const float K[4], const float* dist, int n_dist, float* out_xy);
+
 /* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
  * (/root/reference/src/ORBmatcher.cc:1889-2010, single camera; Tracking::Relocalization) with MapPoint::PredictScale
  * (src/MapPoint.cc:531-546) and GetMin/MaxDistanceInvariance (src/MapPoint.cc:502-512).  Flat arrays, the key frame's map

@@ -649,3 +649,13 @@ def search_triangulation(kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, only
     m = np.zeros(T.n1, np.int32)
     n = lib().orc_search_triangulation(C.byref(T), _p(m))
     return m, n
+
+
+def undistort_points(xy, K, dist):
+    """cv::undistortPoints(xy, K, dist, R = I, P = K) as Frame::UndistortKeyPoints calls it."""
+    a = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    k = np.ascontiguousarray(K, np.float32)
+    d = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros_like(a)
+    lib().orc_undistort_points(_p(a), len(a), _p(k), _p(d), len(d), _p(out))
+    return out

@@ -128,6 +128,8 @@ SYMBOLS = {
     "rgbl_depth_gather_batch_device": (_I, [_V, _I, _I, _I, _V, _V, _I, _V, _V, _V]),
     "rgbl_depth_sync": (_I, [_V]),
     "rgbl_depth_stream": (_V, [_V]),
+    "rgbl_undistort_points": (_I, [_V, _V, _I, _V, _V, _I, _V]),
+    "rgbl_undistort_keypoints_batch_device": (_I, [_V, _V, _V, _I, _I, _V, _V, _I, _V]),
     "rgbl_extractor_stream": (_V, [_V]),
     "rgbl_extractor_aux_stream": (_V, [_V]),
     "rgbl_matcher_stream": (_V, [_V]),

@@ -697,6 +697,49 @@ int rgbl_cvt_gray_batch_device(rgbl_extractor* e, const uint8_t* d_src, int batc
                           gray_frame_stride);
 }
 
+static int undistort_params(const float K[4], const float* dist, int n_dist, UndistortParams* U) {
+  if (!K || !dist || (n_dist != 4 && n_dist != 5) || K[0] == 0.f || K[1] == 0.f) {
+    set_error("undistort: K = (fx, fy, cx, cy) with non-zero focal lengths and 4 or 5 distortion coefficients (k1, k2, p1, p2[, k3])");
+    return RGBL_ERR_INVALID;
+  }
+  U->fx = K[0]; U->fy = K[1]; U->cx = K[2]; U->cy = K[3];
+  for (int i = 0; i < 5; ++i) U->k[i] = i < n_dist ? (double)dist[i] : 0.0;
+  return RGBL_OK;
+}
+
+int rgbl_undistort_keypoints_batch_device(rgbl_extractor* e, const rgbl_keypoint* d_kp, const int32_t* d_n, int batch, int cap,
+                                          const float K[4], const float* dist, int n_dist, float* d_xy_un) {
+  if (!e || !d_kp || !d_n || !d_xy_un || batch < 1 || cap < 1) { set_error("null / empty argument"); return RGBL_ERR_INVALID; }
+  UndistortParams U;
+  RGBL_TRY(undistort_params(K, dist, n_dist, &U));
+  RGBL_HIP(hipSetDevice(e->device));
+  e->timer.begin("k_undistort", e->stream);
+  hipLaunchKernelGGL(k_undistort, dim3((cap + 255) / 256, batch), dim3(256), 0, e->stream, U, reinterpret_cast<const float*>(d_kp), 7,
+                     (size_t)cap * 7, d_n, 0, d_xy_un, 2, (size_t)cap * 2);
+  e->timer.end(e->stream);
+  RGBL_HIP(hipGetLastError());
+  return RGBL_OK;
+}
+
+int rgbl_undistort_points(rgbl_extractor* e, const float* xy, int n, const float K[4], const float* dist, int n_dist, float* out_xy) {
+  if (!e || n < 0 || (n > 0 && (!xy || !out_xy))) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  UndistortParams U;
+  RGBL_TRY(undistort_params(K, dist, n_dist, &U));
+  if (n == 0) return RGBL_OK;
+  const size_t room = (size_t)e->cfg.max_batch * e->out_cap * sizeof(rgbl_keypoint);  // staging: the two keypoint buffers
+  if ((size_t)n * 2 * sizeof(float) > room) { set_error("undistort: at most %zu points per call with this handle", room / 8); return RGBL_ERR_CAPACITY; }
+  RGBL_HIP(hipSetDevice(e->device));
+  hipStream_t s = e->stream;
+  float* d_in = reinterpret_cast<float*>(e->d_tmp_kp);
+  float* d_out = reinterpret_cast<float*>(e->d_out_kp);
+  RGBL_HIP(hipMemcpyAsync(d_in, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256, 1), dim3(256), 0, s, U, d_in, 2, (size_t)0, (const int32_t*)nullptr, n, d_out, 2, (size_t)0);
+  RGBL_HIP(hipGetLastError());
+  RGBL_HIP(hipMemcpyAsync(out_xy, d_out, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipStreamSynchronize(s));
+  return RGBL_OK;
+}
+
 int rgbl_extract_color(rgbl_extractor* e, const uint8_t* img, int channels, int blue_first, int w, int h, int stride, int lap0,
                        int lap1, rgbl_keypoint* out_kp, uint8_t* out_desc, int cap, int* out_n, int* out_mono,
                        uint8_t* out_gray, int gray_stride) {

@@ -1703,6 +1703,50 @@ __global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t* __restrict__ sr
 }
 
 // unpacks candidate keys into rgbl_keypoint records (diagnostic path of rgbl_extractor_get_candidates)
+// ------------------------------------------------------------------------------------------------
+// Frame::UndistortKeyPoints (src/Frame.cc:837-870) = cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK):
+// normalise, 5 fixed-point iterations of the inverse Brown-Conrady model (OpenCV's cvUndistortPointsInternal with its default
+// TermCriteria(MAX_ITER, 5, 0.01), all in double, the operations in OpenCV's order), re-project with P = K.  SURVEY 8(f) row f3.
+struct UndistortParams { double fx, fy, cx, cy, k[5]; };  // k1, k2, p1, p2, k3 (0 when mDistCoef has 4 entries)
+
+__host__ __device__ __forceinline__ void undistort_point(const UndistortParams& U, float px, float py, float* ox, float* oy) {
+  const double ifx = 1. / U.fx, ify = 1. / U.fy;
+  double x = (double)px, y = (double)py;
+  const double u = x, v = y;
+  x = (x - U.cx) * ifx;
+  y = (y - U.cy) * ify;
+  const double x0 = x, y0 = y;
+  for (int j = 0; j < 5; ++j) {
+    const double r2 = x * x + y * y;
+    // k[5..7] (the rational model) and k[8..11] (thin prism) are zero for the 4 / 5 coefficients ORB-SLAM3 passes
+    const double icdist = (1 + ((0. * r2 + 0.) * r2 + 0.) * r2) / (1 + ((U.k[4] * r2 + U.k[1]) * r2 + U.k[0]) * r2);
+    if (icdist < 0) { x = (u - U.cx) * ifx; y = (v - U.cy) * ify; break; }
+    const double deltaX = 2 * U.k[2] * x * y + U.k[3] * (r2 + 2 * x * x) + 0. * r2 + 0. * r2 * r2;
+    const double deltaY = U.k[2] * (r2 + 2 * y * y) + 2 * U.k[3] * x * y + 0. * r2 + 0. * r2 * r2;
+    x = (x0 - deltaX) * icdist;
+    y = (y0 - deltaY) * icdist;
+  }
+  // RR = P(3x3) * R = K: xx = fx x + 0 y + cx, yy = 0 x + fy y + cy, ww = 1 / (0 x + 0 y + 1)
+  const double xx = U.fx * x + 0. * y + U.cx, yy = 0. * x + U.fy * y + U.cy, ww = 1. / (0. * x + 0. * y + 1.);
+  *ox = (float)(xx * ww);
+  *oy = (float)(yy * ww);
+}
+
+// in / out: strided (x, y) float pairs (stride in floats: 2 for plain arrays, 7 for rgbl_keypoint records); grid = (ceil(cap/256), B)
+__global__ __launch_bounds__(256) void k_undistort(UndistortParams U, const float* __restrict__ in, int in_stride, size_t in_frame,
+                                                   const int32_t* __restrict__ n_per_frame, int n_fixed, float* __restrict__ out,
+                                                   int out_stride, size_t out_frame) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const int n = n_per_frame ? n_per_frame[f] : n_fixed;
+  if (i >= n) return;
+  const float* p = in + (size_t)f * in_frame + (size_t)i * in_stride;
+  float* q = out + (size_t)f * out_frame + (size_t)i * out_stride;
+  float ox, oy;
+  undistort_point(U, p[0], p[1], &ox, &oy);
+  q[0] = ox;
+  q[1] = oy;
+}
+
 __global__ void k_unpack_keys(const uint32_t* __restrict__ keys, int n, rgbl_keypoint* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -141,6 +141,18 @@ class ORBextractor:
         L.check(self.lib, self.lib.rgbl_extractor_get_candidates(self.h, frame, level, L.ptr(out), len(out), C.byref(n)))
         return out[:n.value]
 
+    def UndistortKeyPoints(self, xy, K, mDistCoef):
+        """Frame::UndistortKeyPoints (Frame.cc:837-870): mvKeysUn coordinates for mvKeys coordinates xy [n,2]; K = (fx, fy, cx, cy).
+        As in the reference, nothing is computed when mDistCoef[0] == 0."""
+        a = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        d = np.ascontiguousarray(mDistCoef, np.float32).reshape(-1)
+        if d[0] == 0.0:
+            return a.copy()
+        k = np.ascontiguousarray(K, np.float32)
+        out = np.zeros_like(a)
+        L.check(self.lib, self.lib.rgbl_undistort_points(self.h, L.ptr(a), len(a), L.ptr(k), L.ptr(d), len(d), L.ptr(out)))
+        return out
+
     def profile(self, enable):
         L.check(self.lib, self.lib.rgbl_extractor_profile(self.h, int(enable)))
 

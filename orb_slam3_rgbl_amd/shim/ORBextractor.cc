@@ -133,6 +133,26 @@ int ORBextractor::ExtractColor(const unsigned char* data, int channels, int step
   return mono;
 }
 
+void ORBextractor::UndistortKeyPoints(const std::vector<cv::KeyPoint>& mvKeys, const cv::Mat& K, const cv::Mat& mDistCoef,
+                                      std::vector<cv::KeyPoint>& mvKeysUn) {
+  mvKeysUn = mvKeys;
+  const int n = (int)mvKeys.size(), nd = (int)mDistCoef.total();
+  if (n == 0 || nd < 1 || mDistCoef.at<float>(0) == 0.0) return;
+  if (!mpHandle || (nd != 4 && nd != 5)) {
+    std::cerr << "[ORBextractor] UndistortKeyPoints needs an extractor that has processed an image and 4 or 5 coefficients" << std::endl;
+    return;
+  }
+  std::vector<float> xy(2 * (size_t)n), dist(nd);
+  for (int i = 0; i < n; ++i) { xy[2 * i] = mvKeys[i].pt.x; xy[2 * i + 1] = mvKeys[i].pt.y; }
+  for (int i = 0; i < nd; ++i) dist[i] = mDistCoef.at<float>(i);
+  const float k[4] = {K.at<float>(0, 0), K.at<float>(1, 1), K.at<float>(0, 2), K.at<float>(1, 2)};
+  if (rgbl_undistort_points(mpHandle, xy.data(), n, k, dist.data(), nd, xy.data()) != RGBL_OK) {
+    std::cerr << "[ORBextractor] " << rgbl_last_error() << std::endl;
+    return;
+  }
+  for (int i = 0; i < n; ++i) { mvKeysUn[i].pt.x = xy[2 * i]; mvKeysUn[i].pt.y = xy[2 * i + 1]; }
+}
+
 void ORBextractor::FillPyramid() {
   if (keepPyramid) {
     mvPyramidStorage.resize(nlevels);

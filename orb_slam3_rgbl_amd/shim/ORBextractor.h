@@ -30,6 +30,12 @@ class ORBextractor {
   int ExtractColor(const unsigned char* data, int channels, int step, int width, int height, bool bRGB, cv::Mat& imGray,
                    std::vector<cv::KeyPoint>& _keypoints, cv::Mat& _descriptors, std::vector<int>& vLappingArea);
 
+  // Frame::UndistortKeyPoints (Frame.cc:837-870) on the device the keypoints came from: mvKeysUn = mvKeys with
+  // cv::undistortPoints(pt, K, mDistCoef, noArray(), K) applied; a plain copy when mDistCoef[0] == 0, as in the reference.
+  // K: 3x3 CV_32F (Pinhole::toK()), mDistCoef: 4x1 or 5x1 CV_32F.  Call after operator() (the handle exists by then).
+  void UndistortKeyPoints(const std::vector<cv::KeyPoint>& mvKeys, const cv::Mat& K, const cv::Mat& mDistCoef,
+                          std::vector<cv::KeyPoint>& mvKeysUn);
+
   int inline GetLevels() { return nlevels; }
   float inline GetScaleFactor() { return scaleFactor; }
   std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }

@@ -64,6 +64,9 @@ class Mat {
   template <class T> const T* ptr(int r = 0) const { return (const T*)(data + step * (size_t)r); }
   template <class T> T& at(int r, int c) { return ptr<T>(r)[c]; }
   template <class T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }
+  template <class T> T& at(int i) { return rows == 1 ? ptr<T>(0)[i] : ptr<T>(i)[0]; }  // element of a row or column vector
+  template <class T> const T& at(int i) const { return rows == 1 ? ptr<T>(0)[i] : ptr<T>(i)[0]; }
+  size_t total() const { return (size_t)rows * cols; }
   Mat row(int r) const { Mat m(1, cols, type_, data + step * (size_t)r, step); m.own_ = own_; return m; }
   Mat clone() const {
     Mat m(rows, cols, type_);

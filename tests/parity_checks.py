@@ -895,3 +895,55 @@ def check_fuse_search(lib, seed=91, th=3.0, n1=2500, n2=2000):
     assert int((best >= 0).sum()) == on and np.all(dist[best >= 0] <= 50) and np.all((dist[best < 0] > 50))
     mt.close()
     return on
+
+
+def check_undistort(lib, dev=None, w=752, h=480):
+    """Frame::UndistortKeyPoints with the EuRoC cam0 intrinsics / distortion (Examples/Stereo-Inertial/EuRoC.yaml) and a
+    5-coefficient fisheye-ish set: host entry point and the device batch variant against the oracle, bit for bit; and a
+    sanity property - distorting the result again lands on the input."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    ex = F.ORBextractor(500, 1.2, 8, 20, 7, w, h, max_batch=2, lib=lib)
+    for K, dist in (((458.654, 457.296, 367.215, 248.375), (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)),
+                    ((380.0, 379.5, 370.2, 243.1), (-0.15, 0.03, 1e-3, -5e-4, -0.002)),
+                    ((718.856, 718.856, 607.19, 185.2), (1e-9, 0.0, 0.0, 0.0))):
+        xy = np.stack([rng.uniform(-20, w + 20, 3000), rng.uniform(-20, h + 20, 3000)], 1).astype(np.float32)
+        xy[:4] = [[0, 0], [w, 0], [0, h], [w, h]]                  # Frame::ComputeImageBounds' corners
+        got = ex.UndistortKeyPoints(xy, K, dist)
+        want = O.undistort_points(xy, K, dist)
+        assert np.array_equal(bits(got), bits(want)), "undistortPoints"
+        # re-distort (forward Brown-Conrady model) and compare with the input where the iteration converged
+        fx, fy, cx, cy = K
+        k = list(dist) + [0.0] * (5 - len(dist))
+        x, y = (want[:, 0].astype(np.float64) - cx) / fx, (want[:, 1].astype(np.float64) - cy) / fy
+        r2 = x * x + y * y
+        cd = 1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2
+        xd = x * cd + 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x)
+        yd = y * cd + k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y
+        back = np.stack([xd * fx + cx, yd * fy + cy], 1)
+        inner = (np.abs(xy[:, 0] - cx) < 0.2 * w) & (np.abs(xy[:, 1] - cy) < 0.2 * h)   # 5 iterations: converged near the centre only
+        assert np.abs(back - xy)[inner].max() < 0.01
+    # device batch variant on keypoint records
+    kp = np.zeros((2, 300), O.KP_DTYPE)
+    kp["x"] = rng.uniform(0, w, (2, 300)).astype(np.float32)
+    kp["y"] = rng.uniform(0, h, (2, 300)).astype(np.float32)
+    cnt = np.array([300, 123], np.int32)
+    K = np.array([458.654, 457.296, 367.215, 248.375], np.float32)
+    dist = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], np.float32)
+    if dev is not None:
+        import torch
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        down = lambda t: t.cpu().numpy()
+    else:
+        up = lambda a: np.ascontiguousarray(a).copy()
+        ptr = lambda a: C.c_void_p(a.ctypes.data)
+        down = lambda a: a
+    d_kp, d_n, d_out = up(kp.view(np.float32).reshape(2, 300, 7)), up(cnt), up(np.zeros((2, 300, 2), np.float32))
+    L.check(lib, lib.rgbl_undistort_keypoints_batch_device(ex.h, ptr(d_kp), ptr(d_n), 2, 300, L.ptr(K), L.ptr(dist), 4, ptr(d_out)))
+    L.check(lib, lib.rgbl_extractor_sync(ex.h))
+    out = down(d_out)
+    for b in range(2):
+        want = O.undistort_points(np.stack([kp["x"][b], kp["y"][b]], 1)[:cnt[b]], K, dist)
+        assert np.array_equal(bits(out[b, :cnt[b]]), bits(want)) and not out[b, cnt[b]:].any()
+    ex.close()

@@ -134,6 +134,7 @@ def run_and_check(exe, tmp):
     kcol = take(O.KP_DTYPE, nc)
     dcol = take(np.uint8, nc * 32).reshape(nc, 32)
     gray = take(np.uint8, w * h).reshape(h, w)
+    kun = take(np.float32, 2 * nc).reshape(nc, 2)
     nm, npairs = take(np.int32, 2)
     pairs = take(np.int32, 2 * npairs).reshape(npairs, 2)
     dd = take(np.int32, 1)[0]
@@ -162,6 +163,9 @@ def run_and_check(exe, tmp):
     assert nfused == onf and np.array_equal(fused_with, ofb[ofb >= 0]) and nfused > 150   # in order: one GetMapPoint per fused point
     okk, onkk = O.search_by_bow_kf(kf1, kf2, 0.75, True)
     assert nkk == onkk and np.array_equal(kk_match, okk) and nkk > 50
+    oun = O.undistort_points(np.stack([kcol["x"], kcol["y"]], 1), (458.654, 457.296, 367.215, 248.375),
+                             (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05))
+    assert np.array_equal(pc.bits(kun), pc.bits(oun)) and nc > 500
     orm, orn = O.search_by_projection_kf(rcase, 10.0, 100, True)
     assert nreloc == orn and np.array_equal(reloc_match, orm) and nreloc > 150
     wid, wval, onid, onoff, onfeat = O.bow_transform(synth.vocabulary_arrays(voc), desc, 2)   # desc == the oracle's, checked below

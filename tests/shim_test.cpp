@@ -275,6 +275,16 @@ int main(int argc, char** argv) {
     wr(out, &mono_col, 1); wr(out, &nc, 1);
     wr(out, kcol.data(), nc); wr(out, dcol.data, (size_t)nc * 32);
     for (int y = 0; y < h; ++y) wr(out, gray.data + (size_t)y * gray.step, w);
+    // --- as Frame::UndistortKeyPoints (Frame.cc:837-870) with the EuRoC cam0 model
+    cv::Mat Kmat(3, 3, CV_32F), dist(4, 1, CV_32F);
+    for (int i = 0; i < 9; ++i) Kmat.at<float>(i / 3, i % 3) = 0.f;
+    Kmat.at<float>(0, 0) = 458.654f; Kmat.at<float>(1, 1) = 457.296f; Kmat.at<float>(0, 2) = 367.215f; Kmat.at<float>(1, 2) = 248.375f;
+    Kmat.at<float>(2, 2) = 1.f;
+    const float dc[4] = {-0.28340811f, 0.07395907f, 0.00019359f, 1.76187114e-05f};
+    for (int i = 0; i < 4; ++i) dist.at<float>(i) = dc[i];
+    std::vector<cv::KeyPoint> kun;
+    extractor.UndistortKeyPoints(kcol, Kmat, dist, kun);
+    for (int i = 0; i < nc; ++i) { wr(out, &kun[i].pt.x, 1); wr(out, &kun[i].pt.y, 1); }
   }
 
   // --- as LocalMapping::CreateNewMapPoints (LocalMapping.cc:412,466)

@@ -153,3 +153,7 @@ def test_search_by_bow_keyframes(emu_lib, seed, ratio, ori, nodes):
 @pytest.mark.parametrize("seed,th", [(91, 3.0), (93, 4.0), (94, 1.5)])
 def test_fuse_search(emu_lib, seed, th):
     assert pc.check_fuse_search(emu_lib, seed, th, n1=1200, n2=1000) > 80
+
+
+def test_undistort_keypoints(emu_lib):
+    pc.check_undistort(emu_lib)

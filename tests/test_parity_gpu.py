@@ -178,3 +178,8 @@ def test_search_by_bow_keyframes(gpu_lib, seed, ratio, ori, nodes):
 @pytest.mark.parametrize("seed,th", [(91, 3.0), (93, 4.0), (94, 1.5)])
 def test_fuse_search(gpu_lib, seed, th):
     assert pc.check_fuse_search(gpu_lib, seed, th) > 80
+
+
+def test_undistort_keypoints(gpu_lib):
+    import torch
+    pc.check_undistort(gpu_lib, torch.device("cuda", 0))
