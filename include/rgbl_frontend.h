@@ -414,6 +414,13 @@ typedef struct {
 int rgbl_search_by_projection_keyframe(rgbl_matcher* h, const rgbl_keyframe_projection_input* in, int32_t* match2,
                                        int* out_nmatches);
 
+/* void MapPoint::ComputeDistinctiveDescriptors() (src/MapPoint.cc:329-403; called after every new observation / fusion, e.g.
+ * LocalMapping.cc:333,691, Tracking.cc:2437) for a batch of map points: the N x N ORBmatcher::DescriptorDistance table of a point's
+ * observed descriptors, and the row with the least median.  desc: the rows vDescriptors collects, point p = rows off[p] ..
+ * off[p+1]) in the order the reference pushes them (off[0] = 0, at most 65535 per point).  best[p] = BestIdx inside the point's
+ * own list (the descriptor to clone into mDescriptor), -1 for a point with no descriptor.  Host pointers, synchronous. */
+int rgbl_distinctive_descriptors(rgbl_matcher* h, const uint8_t* desc, const int32_t* off, int n_points, int32_t* best);
+
 /* The search inside int ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const float th, const bool bRight)
  * (include/ORBmatcher.h:83, src/ORBmatcher.cc:1148-1338, bRight = false; caller LocalMapping::SearchInNeighbors,
  * src/LocalMapping.cc:737-879, twice per neighbour key frame).  Every map point finds its best feature independently of

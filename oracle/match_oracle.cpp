@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <climits>
 #include <vector>
 
 namespace {
@@ -299,6 +300,32 @@ extern "C" int orc_search_by_projection(const orc_projection_input* in, int* mat
   }
   for (int i = 0; i < in->n2; ++i) match2[i] = holder[i];
   return nmatches;
+}
+
+// ---- MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:329-403 ----
+extern "C" void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int n_points, int32_t* best) {
+  for (int p = 0; p < n_points; ++p) {
+    const size_t N = (size_t)(off[p + 1] - off[p]);
+    if (N == 0) { best[p] = -1; continue; }
+    const uint8_t* D = desc + 32 * (size_t)off[p];
+    std::vector<float> Distances(N * N);
+    for (size_t i = 0; i < N; i++) {
+      Distances[i * N + i] = 0;
+      for (size_t j = i + 1; j < N; j++) {
+        const int distij = hamming256(D + 32 * i, D + 32 * j);
+        Distances[i * N + j] = distij;
+        Distances[j * N + i] = distij;
+      }
+    }
+    int BestMedian = INT_MAX, BestIdx = 0;
+    for (size_t i = 0; i < N; i++) {
+      std::vector<int> vDists(Distances.begin() + i * N, Distances.begin() + (i + 1) * N);
+      std::sort(vDists.begin(), vDists.end());
+      const int median = vDists[0.5 * (N - 1)];
+      if (median < BestMedian) { BestMedian = median; BestIdx = (int)i; }
+    }
+    best[p] = BestIdx;
+  }
 }
 
 // ---- Frame::UndistortKeyPoints, Frame.cc:837-870 = cv::undistortPoints(src, dst, K, D, noArray(), P = K) ----

@@ -197,6 +197,11 @@ typedef struct {
  * Returns nmatches exactly as the reference counts it. */
 int orc_search_by_projection(const orc_projection_input* in, int* match2);
 
+/* MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:329-403) for a batch: descriptors of point p = rows
+ * off[p] .. off[p+1]); best[p] = BestIdx (float distance table, std::sort of every row, median at (size_t)(0.5 * (N - 1)),
+ * strict '<'), -1 for an empty list. */
+void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int n_points, int32_t* best);
+
 /* Frame::UndistortKeyPoints (/root/reference/src/Frame.cc:837-870): cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK).
  * OpenCV-internal arithmetic (cvUndistortPointsInternal with TermCriteria(MAX_ITER, 5, 0.01)), restated from upstream
  * knowledge - parity unpinned, like the other cv:: primitives.  K = fx, fy, cx, cy; dist = k1, k2, p1, p2[, k3]. */

@@ -659,3 +659,15 @@ def undistort_points(xy, K, dist):
     out = np.zeros_like(a)
     lib().orc_undistort_points(_p(a), len(a), _p(k), _p(d), len(d), _p(out))
     return out
+
+
+def distinctive_descriptors(descriptor_lists):
+    """MapPoint::ComputeDistinctiveDescriptors for a batch: BestIdx per list (-1 when empty)."""
+    off = np.zeros(len(descriptor_lists) + 1, np.int32)
+    for i, d in enumerate(descriptor_lists):
+        off[i + 1] = off[i] + len(d)
+    desc = (np.concatenate([np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in descriptor_lists])
+            if off[-1] else np.zeros((1, 32), np.uint8))
+    best = np.zeros(len(descriptor_lists), np.int32)
+    lib().orc_distinctive_descriptors(_p(desc), _p(off), len(descriptor_lists), _p(best))
+    return best

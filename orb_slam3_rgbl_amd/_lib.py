@@ -157,6 +157,7 @@ SYMBOLS = {
     "rgbl_search_by_projection": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_search_local_points": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_fuse_search": (_I, [_V, _V, _V, _V]),
+    "rgbl_distinctive_descriptors": (_I, [_V, _V, _V, _I, _V]),
     "rgbl_search_by_projection_keyframe": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_vocabulary_load_text": (_I, [C.c_char_p, _I, C.POINTER(_V)]),
     "rgbl_vocabulary_create": (_I, [_I, _I, _V, _V, _V, _V, _V, _I, C.POINTER(_V)]),

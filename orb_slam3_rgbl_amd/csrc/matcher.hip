@@ -94,6 +94,40 @@ __global__ __launch_bounds__(256) void k_hamming_bf(const uint8_t* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:329-403) for a batch of map points: among the
+// N descriptors that observe a point, the one with the least median Hamming distance to all N (its own 0 included; median =
+// sorted row[(size_t)(0.5 * (N - 1))]; strict '<' over the rows, so the first minimum wins).
+// One wave per point, one row per lane (rows in chunks of 64); the other descriptor of a pair is wave-uniform and comes
+// through scalar loads.  The k-th smallest of a row is found by bisection on the value range 0..256 (9 counting passes that
+// recompute the distances: N is a few dozen, nothing is stored).
+// grid = points, block = 64
+__global__ __launch_bounds__(64) void k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ off, int32_t* __restrict__ best) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int b = off[p], n = off[p + 1] - b;
+  if (n <= 0) { if (lane == 0) best[p] = -1; return; }
+  const unsigned long long* D = reinterpret_cast<const unsigned long long*>(desc) + 4 * (size_t)b;
+  const int k = (n - 1) >> 1;  // (size_t)(0.5 * (N - 1))
+  uint32_t wbest = 0xffffffffu;  // median << 16 | row
+  for (int r0 = 0; r0 < n; r0 += 64) {
+    const int i = r0 + lane;
+    const bool live = i < n;
+    const unsigned long long* Q = D + 4 * (size_t)(live ? i : 0);
+    const unsigned long long q[4] = {Q[0], Q[1], Q[2], Q[3]};
+    int lo = 0, hi = 256;
+    for (int it = 0; it < 9; ++it) {  // 257 possible values
+      const int mid = (lo + hi) >> 1;
+      int c = 0;
+      for (int j = 0; j < n; ++j) c += hamming256(q, D + 4 * (size_t)j) <= mid ? 1 : 0;
+      if (c >= k + 1) hi = mid; else lo = mid + 1;
+    }
+    uint32_t key = live ? ((uint32_t)lo << 16) | (uint32_t)i : 0xffffffffu;
+    for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)key, m); key = o < key ? o : key; }
+    wbest = key < wbest ? key : wbest;
+  }
+  if (lane == 0) best[p] = (int32_t)(wbest & 0xffffu);
+}
+
 struct TriDev {
   const uint8_t *desc1, *desc2;
   const float *xy1, *xy2;
@@ -1164,6 +1198,32 @@ int rgbl_search_by_projection_keyframe(rgbl_matcher* m, const rgbl_keyframe_proj
   h.max_dist = in->orb_dist;
   h.check_orientation = in->check_orientation;
   return projection_core(m, h, match2, out_nmatches);
+}
+
+int rgbl_distinctive_descriptors(rgbl_matcher* m, const uint8_t* desc, const int32_t* off, int n_points, int32_t* best) {
+  if (!m || !off || !best || n_points < 0) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  if (n_points == 0) return RGBL_OK;
+  const int total = off[n_points];
+  for (int p = 0; p < n_points; ++p)
+    if (off[p + 1] < off[p] || off[p + 1] - off[p] > 65535) { set_error("offsets must ascend, at most 65535 observations per point"); return RGBL_ERR_INVALID; }
+  if (off[0] != 0 || (total > 0 && !desc)) { set_error("offsets start at 0; descriptors missing"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(m->device));
+  RGBL_TRY(ensure_arena(m, pad256((size_t)total * 32) + pad256((size_t)(n_points + 1) * 4) + pad256((size_t)n_points * 4)));
+  Arena A{m->d_buf};
+  hipStream_t s = m->stream;
+  const uint8_t* d_desc = nullptr;
+  const int32_t* d_off = nullptr;
+  if (total > 0) RGBL_TRY(upload(A, s, &d_desc, desc, (size_t)total * 32));
+  RGBL_TRY(upload(A, s, &d_off, off, (size_t)n_points + 1));
+  int32_t* d_best = A.take<int32_t>(n_points);
+  m->timer.begin("k_distinctive", s);
+  hipLaunchKernelGGL(k_distinctive, dim3(n_points), dim3(64), 0, s, d_desc, d_off, d_best);
+  m->timer.end(s);
+  RGBL_HIP(hipGetLastError());
+  RGBL_HIP(hipMemcpyAsync(best, d_best, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipStreamSynchronize(s));
+  m->timer.collect();
+  return RGBL_OK;
 }
 
 int rgbl_fuse_search(rgbl_matcher* m, const rgbl_fuse_input* in, int32_t* best_idx, int32_t* best_dist) {

@@ -428,6 +428,19 @@ class ORBmatcher:
         L.check(self.lib, self.lib.rgbl_fuse_search(self.h, C.byref(P), L.ptr(best), L.ptr(dist)))
         return best, dist
 
+    def ComputeDistinctiveDescriptors(self, descriptor_lists):
+        """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403) for a batch: descriptor_lists = one [n_i, 32] uint8 array
+        per map point (its observed descriptors in the reference's order).  Returns BestIdx per point (-1 for an empty list)."""
+        off = np.zeros(len(descriptor_lists) + 1, np.int32)
+        for i, d in enumerate(descriptor_lists):
+            off[i + 1] = off[i] + len(d)
+        desc = (np.concatenate([np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in descriptor_lists])
+                if off[-1] else np.zeros((0, 32), np.uint8))
+        best = np.zeros(len(descriptor_lists), np.int32)
+        L.check(self.lib, self.lib.rgbl_distinctive_descriptors(self.h, L.ptr(desc) if off[-1] else None, L.ptr(off),
+                                                                len(descriptor_lists), L.ptr(best)))
+        return best
+
     def SearchLocalPoints(self, pts, th):
         """ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) (ORBmatcher.cc:43-213), the call of
         Tracking::SearchLocalPoints.  pts: dict with the map point arrays valid1, proj1 [n,3] (mTrackProjX, mTrackProjY,

@@ -136,6 +136,22 @@ class ORBmatcher {
     return nmatches;
   }
 
+  // The table and the selection of MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:370-398): BestIdx among the observed
+  // descriptors (1 x 32 CV_8U rows, in the order the reference collects them), -1 for an empty list.
+  int DistinctiveDescriptor(const std::vector<cv::Mat>& vDescriptors) {
+    if (!mpHandle || vDescriptors.empty()) return vDescriptors.empty() ? -1 : 0;
+    const int n = (int)vDescriptors.size();
+    std::vector<uint8_t> rows((size_t)n * 32);
+    for (int i = 0; i < n; ++i) memcpy(&rows[(size_t)i * 32], vDescriptors[i].template ptr<uint8_t>(), 32);
+    const int32_t off[2] = {0, n};
+    int32_t best = 0;
+    if (rgbl_distinctive_descriptors(mpHandle, rows.data(), off, 1, &best) != RGBL_OK) {
+      std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
+      return 0;
+    }
+    return best;
+  }
+
   // Matching between the MapPoints of two KeyFrames through the vocabulary (LoopClosing's place recognition and the merge /
   // relocalisation of the multi-map case).  ORBmatcher.h:58, ORBmatcher.cc:765-905.
   template <class KeyFrameT, class MapPointT>

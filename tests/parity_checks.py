@@ -947,3 +947,28 @@ def check_undistort(lib, dev=None, w=752, h=480):
         want = O.undistort_points(np.stack([kp["x"][b], kp["y"][b]], 1)[:cnt[b]], K, dist)
         assert np.array_equal(bits(out[b, :cnt[b]]), bits(want)) and not out[b, cnt[b]:].any()
     ex.close()
+
+
+def check_distinctive_descriptors(lib, seed=101, n_points=400):
+    """Batched MapPoint::ComputeDistinctiveDescriptors: observation counts 0 .. 200 (typical 2 .. 30), exact duplicates (ties
+    between rows: the first minimum must win), near-duplicates of a common ancestor as real observations are."""
+    rng = np.random.default_rng(seed)
+    lists = []
+    for p in range(n_points):
+        n = int(rng.choice([0, 1, 2, 3, 5, 8, 13, 21, 34, 65, 130, 200], p=[.02, .05, .1, .13, .2, .2, .12, .08, .05, .03, .01, .01]))
+        base = synth.descriptors(1, seed * 1000 + p)[0]
+        d = np.repeat(base[None], n, 0)
+        flips = rng.random((n, 256)) < rng.uniform(0.01, 0.2)
+        d = d ^ np.packbits(flips, axis=1, bitorder="little")
+        if n > 3 and p % 3 == 0:
+            d[rng.integers(0, n)] = d[rng.integers(0, n)]          # exact duplicate rows
+        if n > 2 and p % 7 == 0:
+            d[:] = d[0]                                            # all equal: BestIdx must be 0
+        lists.append(d)
+    mt = F.ORBmatcher(0.6, True, lib=lib)
+    got = mt.ComputeDistinctiveDescriptors(lists)
+    want = O.distinctive_descriptors(lists)
+    assert np.array_equal(got, want), "ComputeDistinctiveDescriptors (seed %d)" % seed
+    assert mt.ComputeDistinctiveDescriptors([]).size == 0
+    mt.close()
+    return int((want >= 0).sum())

@@ -158,7 +158,10 @@ def run_and_check(exe, tmp):
     kk_match = take(np.int32, n1k)
     nfused, nq = take(np.int32, 2)
     fused_with = take(np.int32, nq)
+    best_desc = take(np.int32, 1)[0]
     assert pos == len(buf)
+    rows = [kf1["desc"][i * 3 % len(kf1["desc"])] for i in range(25)]
+    assert best_desc == O.distinctive_descriptors([np.stack(rows)])[0]
     ofb, onf = O.fuse_search(fcase, 3.0)
     assert nfused == onf and np.array_equal(fused_with, ofb[ofb >= 0]) and nfused > 150   # in order: one GetMapPoint per fused point
     okk, onkk = O.search_by_bow_kf(kf1, kf2, 0.75, True)

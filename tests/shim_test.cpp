@@ -519,6 +519,14 @@ int main(int argc, char** argv) {
     const int nq = (int)kf.queried.size();
     wr(out, &nFused, 1); wr(out, &nq, 1); wr(out, kf.queried.data(), nq);
   }
+  {
+    // --- as MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403) on 25 observed descriptors
+    std::vector<cv::Mat> vDescriptors;
+    for (int i = 0; i < 25 && i < kf1.N; ++i) vDescriptors.push_back(kf1.mDescriptors.row(i * 3 % kf1.N));
+    ORB_SLAM3::ORBmatcher any(0.6, true);
+    const int bestIdx = any.DistinctiveDescriptor(vDescriptors);
+    wr(out, &bestIdx, 1);
+  }
   fclose(out);
   printf("shim_test ok: %d keypoints, %d depths, %d triangulation matches\n", nk, nd, nm);
   return 0;

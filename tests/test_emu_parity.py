@@ -157,3 +157,7 @@ def test_fuse_search(emu_lib, seed, th):
 
 def test_undistort_keypoints(emu_lib):
     pc.check_undistort(emu_lib)
+
+
+def test_distinctive_descriptors(emu_lib):
+    assert pc.check_distinctive_descriptors(emu_lib, 101, 150) > 75

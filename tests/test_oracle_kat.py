@@ -306,3 +306,30 @@ def test_kitti_bin_repack():
     cloud = O.kitti_bin_to_cloud(pts)
     assert cloud.shape == (4, 5)
     assert np.array_equal(cloud[:3], pts[:, :3].T) and np.array_equal(cloud[3], np.ones(5, np.float32))
+
+
+def test_distinctive_descriptor_known_answers():
+    """MapPoint::ComputeDistinctiveDescriptors: median = sorted row[(N - 1) // 2] with the row's own zero in it; strict '<'."""
+    z = np.zeros(32, np.uint8)
+
+    def d(nbits):  # descriptor at Hamming distance nbits from zero
+        v = np.zeros(256, np.uint8); v[:nbits] = 1
+        return np.packbits(v, bitorder="little")
+    # N = 1: itself; N = 2: medians are row[0] = 0 for both -> first wins
+    assert O.distinctive_descriptors([[z], [d(7), z]]).tolist() == [0, 0]
+    # N = 3 on a line 0 -- 10 -- 30 (nested bit sets): rows sorted {0,10,30}, {0,10,20}, {0,20,30}; median index 1 -> 10, 10, 20
+    assert O.distinctive_descriptors([[d(0), d(10), d(30)]]).tolist() == [0]
+    # ... and with the middle one first it still wins by being first among equals
+    assert O.distinctive_descriptors([[d(10), d(0), d(30)]]).tolist() == [0]
+    # N = 4: median index (4-1)//2 = 1.  points 0, 2, 4, 100: rows {0,2,4,100} {0,2,2,98} {0,2,4,96} {0,96,98,100} -> medians 2,2,2,96
+    assert O.distinctive_descriptors([[d(100), d(0), d(2), d(4)]]).tolist() == [1]
+    # independent numpy restatement on random lists
+    rng = np.random.default_rng(5)
+    lists = [rng.integers(0, 256, (n, 32), dtype=np.uint8) for n in (5, 6, 17, 40)]
+    want = []
+    for L_ in lists:
+        bits_ = np.unpackbits(L_, axis=1)
+        dist = (bits_[:, None, :] != bits_[None, :, :]).sum(2)
+        med = np.sort(dist, axis=1)[:, (len(L_) - 1) // 2]
+        want.append(int(np.argmin(med)))
+    assert O.distinctive_descriptors(lists).tolist() == want

@@ -183,3 +183,7 @@ def test_fuse_search(gpu_lib, seed, th):
 def test_undistort_keypoints(gpu_lib):
     import torch
     pc.check_undistort(gpu_lib, torch.device("cuda", 0))
+
+
+def test_distinctive_descriptors(gpu_lib):
+    assert pc.check_distinctive_descriptors(gpu_lib, 101, 2000) > 1000
