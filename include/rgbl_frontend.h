@@ -414,6 +414,33 @@ typedef struct {
 int rgbl_search_by_projection_keyframe(rgbl_matcher* h, const rgbl_keyframe_projection_input* in, int32_t* match2,
                                        int* out_nmatches);
 
+/* The per-point search of the Sim3-based loop-closing matchers: ORBmatcher::Fuse(KeyFrame* pKF, Sophus::Sim3f& Scw, const
+ * vector<MapPoint*>& vpPoints, float th, vector<MapPoint*>& vpReplacePoint) (include/ORBmatcher.h:86, src/ORBmatcher.cc:1340-1455)
+ * and both directions of SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (include/ORBmatcher.h:79, src/ORBmatcher.cc:1457-1674).
+ * The caller (shim) applies its Sophus objects and evaluates the tests on the MapPoint objects; from the camera-frame
+ * coordinates on - positive depth, projection, KeyFrame::IsInImage, the window of radius th * scale[level], octaves level - 1
+ * ... level, the smallest Hamming distance - everything is done here, every point on its own. */
+typedef struct {
+  int n1;
+  const uint8_t* valid1;       /* the point passed the caller's tests (NULL / bad / already matched / invariance range / viewing angle) */
+  const float* cam_pos1;       /* the point in the key frame's camera frame (Tcw * p3Dw, resp. S21 * (T1w * p3Dw)), 3 floats */
+  const uint8_t* mp_desc1;     /* pMP->GetDescriptor() */
+  const int32_t* level1;       /* pMP->PredictScale(dist3D, pKF) */
+  int n2;                      /* pKF->N (<= 65535) */
+  const float* kp2_xy;         /* pKF->mvKeysUn[i].pt */
+  const int32_t* kp2_octave;
+  const uint8_t* desc2;
+  float grid[6];               /* pKF->mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv */
+  float K[4];                  /* fx, fy, cx, cy */
+  const float* scale_factors;
+  int n_levels;
+  float th;
+  int proj_form;               /* 0: Pinhole::project (fx x / z + cx) as in Fuse; 1: invz = 1.0 / z, fx (x invz) + cx as in SearchBySim3 */
+  int max_dist;                /* TH_LOW (Fuse) / TH_HIGH (SearchBySim3) */
+} rgbl_project_search_input;
+/* Host pointers, synchronous.  best_idx[i] = key-frame feature with the smallest distance (<= max_dist) or -1; best_dist nullable. */
+int rgbl_project_search(rgbl_matcher* h, const rgbl_project_search_input* in, int32_t* best_idx, int32_t* best_dist);
+
 /* void MapPoint::ComputeDistinctiveDescriptors() (src/MapPoint.cc:329-403; called after every new observation / fusion, e.g.
  * LocalMapping.cc:333,691, Tracking.cc:2437) for a batch of map points: the N x N ORBmatcher::DescriptorDistance table of a point's
  * observed descriptors, and the row with the least median.  desc: the rows vDescriptors collects, point p = rows off[p] ..

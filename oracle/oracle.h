@@ -197,6 +197,29 @@ typedef struct {
  * Returns nmatches exactly as the reference counts it. */
 int orc_search_by_projection(const orc_projection_input* in, int* match2);
 
+/* The per-point search of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (/root/reference/src/ORBmatcher.cc:1340-1455,
+ * from "Depth must be positive" to the threshold test) and of either direction of SearchBySim3 (:1497-1566 / :1575-1649), on
+ * points that already are in the key frame's camera frame.  Same layout as rgbl_project_search_input. */
+typedef struct {
+  int n1;
+  const uint8_t* valid1;
+  const float* cam_pos1;
+  const uint8_t* mp_desc1;
+  const int32_t* level1;
+  int n2;
+  const float* kp2_xy;
+  const int32_t* kp2_octave;
+  const uint8_t* desc2;
+  float grid[6];
+  float K[4];
+  const float* scale_factors;
+  int n_levels;
+  float th;
+  int proj_form;   /* 0: Pinhole::project; 1: invz = 1.0 / z (double), u = fx * (x * invz) + cx */
+  int max_dist;
+} orc_project_search_input;
+void orc_project_search(const orc_project_search_input* in, int* best_idx, int* best_dist);
+
 /* MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:329-403) for a batch: descriptors of point p = rows
  * off[p] .. off[p+1]); best[p] = BestIdx (float distance table, std::sort of every row, median at (size_t)(0.5 * (N - 1)),
  * strict '<'), -1 for an empty list. */

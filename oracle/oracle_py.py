@@ -671,3 +671,36 @@ def distinctive_descriptors(descriptor_lists):
     best = np.zeros(len(descriptor_lists), np.int32)
     lib().orc_distinctive_descriptors(_p(desc), _p(off), len(descriptor_lists), _p(best))
     return best
+
+
+class ProjectSearchInput(C.Structure):
+    _fields_ = [("n1", C.c_int), ("valid1", C.c_void_p), ("cam_pos1", C.c_void_p), ("mp_desc1", C.c_void_p),
+                ("level1", C.c_void_p), ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p),
+                ("desc2", C.c_void_p), ("grid", C.c_float * 6), ("K", C.c_float * 4), ("scale_factors", C.c_void_p),
+                ("n_levels", C.c_int), ("th", C.c_float), ("proj_form", C.c_int), ("max_dist", C.c_int)]
+
+
+def project_search(case, th, proj_form, max_dist):
+    """The per-point search of Fuse(pKF, Scw, ...) / SearchBySim3 on camera-frame points; returns (best_idx, best_dist)."""
+    keep = []
+
+    def arr(v, dt):
+        a = np.ascontiguousarray(v, dt)
+        keep.append(a)
+        return a.ctypes.data
+    P = ProjectSearchInput()
+    P.n1 = len(case["valid1"])
+    P.valid1, P.cam_pos1 = arr(case["valid1"], np.uint8), arr(case["cam_pos1"], np.float32)
+    P.mp_desc1, P.level1 = arr(case["mp_desc1"], np.uint8), arr(case["level1"], np.int32)
+    P.n2 = len(case["kp2_xy"])
+    P.kp2_xy, P.kp2_octave, P.desc2 = arr(case["kp2_xy"], np.float32), arr(case["kp2_octave"], np.int32), arr(case["desc2"], np.uint8)
+    for name, n in (("grid", 6), ("K", 4)):
+        for i in range(n):
+            getattr(P, name)[i] = float(case[name][i])
+    P.scale_factors = arr(case["scale_factors"], np.float32)
+    P.n_levels = len(case["scale_factors"])
+    P.th, P.proj_form, P.max_dist = float(th), int(proj_form), int(max_dist)
+    best = np.zeros(P.n1, np.int32)
+    dist = np.zeros(P.n1, np.int32)
+    lib().orc_project_search(C.byref(P), _p(best), _p(dist))
+    return best, dist

@@ -479,3 +479,116 @@ extern "C" int ref_fuse(const orc_fuse_input* in, const uint8_t* kf_state2, int*
   // a feature holding a bad map point: the match counts (nFused++) but nothing is recorded (best_idx stays -1)
   return nFused;
 }
+
+// One side of the Sim3 matchers: a key frame (features, grid) and the map points its features hold, already expressed in the
+// common camera frame (all poses of the call are identities, so the world frame IS that frame and the Sophus / Eigen transform
+// arithmetic - third-party code - is exact and out of the picture).
+struct Sim3Side {
+  int n;
+  const float* kp_xy; const int32_t* kp_octave; const uint8_t* desc;
+  const uint8_t* mp_state;    // per feature: 0 no map point, 1 good, 2 bad
+  const float* mp_pos;        // 3 floats per feature
+  const float* mp_normal;     // 3 floats per feature (Fuse only)
+  const uint8_t* mp_desc;     // MapPoint::GetDescriptor(), 32 bytes per feature
+  const float *mp_min_dist, *mp_max_dist;
+};
+static void build_side(const Sim3Side& a, const float K[4], const float grid[6], const float* scale_factors, int n_levels,
+                       float log_scale_factor, GeometricCamera* cam, KeyFrame& kf, std::vector<MapPoint>& pts) {
+  kf.N = a.n;
+  kf.mpCamera = cam;
+  kf.fx = K[0]; kf.fy = K[1]; kf.cx = K[2]; kf.cy = K[3];
+  kf.mvKeysUn.resize(a.n);
+  kf.mvpMapPoints.assign(a.n, nullptr);
+  pts.assign(a.n, MapPoint());
+  for (int i = 0; i < a.n; ++i) {
+    kf.mvKeysUn[i].pt.x = a.kp_xy[2 * i]; kf.mvKeysUn[i].pt.y = a.kp_xy[2 * i + 1]; kf.mvKeysUn[i].octave = a.kp_octave[i];
+    if (!a.mp_state[i]) continue;
+    MapPoint& mp = pts[i];
+    mp.bad = a.mp_state[i] == 2;
+    mp.mWorldPos = Eigen::Vector3f(a.mp_pos[3 * i], a.mp_pos[3 * i + 1], a.mp_pos[3 * i + 2]);
+    if (a.mp_normal) mp.mNormal = Eigen::Vector3f(a.mp_normal[3 * i], a.mp_normal[3 * i + 1], a.mp_normal[3 * i + 2]);
+    mp.mDescriptor = cv::Mat(1, 32, CV_8U);
+    memcpy(mp.mDescriptor.data, a.mp_desc + 32 * (size_t)i, 32);
+    mp.mfMinDistance = a.mp_min_dist[i]; mp.mfMaxDistance = a.mp_max_dist[i];
+    mp.nObs = 3;
+    mp.mObservations[&kf] = i;
+    kf.mvpMapPoints[i] = &mp;
+  }
+  kf.mvKeys = kf.mvKeysUn;
+  kf.mvuRight.assign(a.n, -1.f);
+  kf.mDescriptors = cv::Mat(a.n, 32, CV_8U);
+  if (a.n) memcpy(kf.mDescriptors.data, a.desc, (size_t)a.n * 32);
+  kf.mvScaleFactors.assign(scale_factors, scale_factors + n_levels);
+  kf.mnScaleLevels = n_levels;
+  kf.mfLogScaleFactor = log_scale_factor;
+  kf.mTcw = Sophus::SE3f(Eigen::Quaternionf(1.f, 0.f, 0.f, 0.f), Eigen::Vector3f(0.f, 0.f, 0.f));
+  kf.mTwc = kf.mTcw;
+  kf.grid.mnMinX = grid[0]; kf.grid.mnMinY = grid[1]; kf.grid.mnMaxX = grid[2]; kf.grid.mnMaxY = grid[3];
+  kf.grid.mfGridElementWidthInv = grid[4]; kf.grid.mfGridElementHeightInv = grid[5];
+  kf.grid.Build(kf.mvKeysUn);
+}
+
+// ORBmatcher(0.75, true).SearchBySim3(pKF1, pKF2, vpMatches12, S12 = identity, th) (ORBmatcher.cc:1457-1674).
+// prior12[i1] >= 0: vpMatches12[i1] holds the map point of KF2's feature prior12[i1] on entry.  match12[i1] = KF2 feature or -1.
+extern "C" int ref_search_by_sim3(const Sim3Side* a1, const Sim3Side* a2, const float K[4], const float grid[6],
+                                  const float* scale_factors, int n_levels, float log_scale_factor, float th, const int* prior12,
+                                  int* match12) {
+  GeometricCamera cam;
+  cam.fx = K[0]; cam.fy = K[1]; cam.cx = K[2]; cam.cy = K[3];
+  KeyFrame kf1, kf2;
+  std::vector<MapPoint> p1, p2;
+  build_side(*a1, K, grid, scale_factors, n_levels, log_scale_factor, &cam, kf1, p1);
+  build_side(*a2, K, grid, scale_factors, n_levels, log_scale_factor, &cam, kf2, p2);
+  std::vector<MapPoint*> vpMatches12(a1->n, nullptr);
+  for (int i = 0; i < a1->n; ++i)
+    if (prior12[i] >= 0) vpMatches12[i] = &p2[prior12[i]];
+  Sophus::Sim3f S12(1.f, Eigen::Quaternionf(1.f, 0.f, 0.f, 0.f), Eigen::Vector3f(0.f, 0.f, 0.f));
+  ORBmatcher matcher(0.75f, true);
+  const int nFound = matcher.SearchBySim3(&kf1, &kf2, vpMatches12, S12, th);
+  for (int i = 0; i < a1->n; ++i) match12[i] = vpMatches12[i] ? (int)(vpMatches12[i] - p2.data()) : -1;
+  return nFound;
+}
+
+// ORBmatcher(0.8).Fuse(pKF, Scw = identity, vpPoints, th, vpReplacePoint) (ORBmatcher.cc:1340-1455).  The candidate points are
+// a Sim3Side of their own (mp_state 1 / 2 = good / bad; every entry is a point); kf_state2 as in ref_fuse.
+// fused[i] = feature the point was fused with (AddObservation or vpReplacePoint), -1 otherwise.
+extern "C" int ref_fuse_sim3(const Sim3Side* cand, const uint8_t* in_kf1, const Sim3Side* kfa, const uint8_t* kf_state2,
+                             const float K[4], const float grid[6], const float* scale_factors, int n_levels,
+                             float log_scale_factor, float th, int* fused) {
+  GeometricCamera cam;
+  cam.fx = K[0]; cam.fy = K[1]; cam.cx = K[2]; cam.cy = K[3];
+  KeyFrame kf, other;
+  std::vector<MapPoint> owned, pts;
+  Sim3Side bare = *kfa;
+  std::vector<uint8_t> none(kfa->n, 0);
+  bare.mp_state = none.data();
+  build_side(bare, K, grid, scale_factors, n_levels, log_scale_factor, &cam, kf, owned);
+  for (int i = 0; i < kfa->n; ++i)
+    if (kf_state2[i]) { owned[i].nObs = 5; owned[i].bad = kf_state2[i] == 3; kf.mvpMapPoints[i] = &owned[i]; }
+  build_side(*cand, K, grid, scale_factors, n_levels, log_scale_factor, &cam, other, pts);  // only to construct the points
+  std::vector<MapPoint*> vp(cand->n), vpReplacePoint(cand->n, nullptr);
+  for (int i = 0; i < cand->n; ++i) {
+    vp[i] = &pts[i];
+    pts[i].mObservations.clear();
+    if (in_kf1[i]) {  // a candidate that the key frame already holds
+      const int slot = kfa->n - 1 - (i % kfa->n);
+      kf.mvpMapPoints[slot] = &pts[i];
+      pts[i].mObservations[&kf] = slot;
+    }
+  }
+  Sophus::Sim3f Scw(1.f, Eigen::Quaternionf(1.f, 0.f, 0.f, 0.f), Eigen::Vector3f(0.f, 0.f, 0.f));
+  ORBmatcher matcher(0.8f, true);
+  const int nFused = matcher.Fuse(&kf, Scw, vp, th, vpReplacePoint);
+  for (int i = 0; i < cand->n; ++i) {
+    fused[i] = -1;
+    if (vpReplacePoint[i]) {
+      MapPoint* q = vpReplacePoint[i];
+      if (q >= owned.data() && q < owned.data() + kfa->n) fused[i] = (int)(q - owned.data());
+      else { auto it = q->mObservations.find(&kf); fused[i] = it != q->mObservations.end() ? it->second : -3; }
+    } else if (!in_kf1[i]) {
+      auto it = pts[i].mObservations.find(&kf);
+      if (it != pts[i].mObservations.end()) fused[i] = it->second;
+    }
+  }
+  return nFused;
+}

@@ -82,6 +82,14 @@ class FuseInput(C.Structure):
                 ("inv_level_sigma2", C.c_void_p), ("n_levels", C.c_int), ("th", C.c_float)]
 
 
+class ProjectSearchInput(C.Structure):
+    """rgbl_project_search_input (the per-point search of Fuse(pKF, Scw, ...) and SearchBySim3)."""
+    _fields_ = [("n1", C.c_int), ("valid1", C.c_void_p), ("cam_pos1", C.c_void_p), ("mp_desc1", C.c_void_p),
+                ("level1", C.c_void_p), ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p),
+                ("desc2", C.c_void_p), ("grid", C.c_float * 6), ("K", C.c_float * 4), ("scale_factors", C.c_void_p),
+                ("n_levels", C.c_int), ("th", C.c_float), ("proj_form", C.c_int), ("max_dist", C.c_int)]
+
+
 class LocalPointsInput(C.Structure):
     """rgbl_local_points_input (ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...) as flat arrays)."""
     _fields_ = [("n1", C.c_int), ("valid1", C.c_void_p), ("proj1", C.c_void_p), ("level1", C.c_void_p),
@@ -157,6 +165,7 @@ SYMBOLS = {
     "rgbl_search_by_projection": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_search_local_points": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_fuse_search": (_I, [_V, _V, _V, _V]),
+    "rgbl_project_search": (_I, [_V, _V, _V, _V]),
     "rgbl_distinctive_descriptors": (_I, [_V, _V, _V, _I, _V]),
     "rgbl_search_by_projection_keyframe": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_vocabulary_load_text": (_I, [C.c_char_p, _I, C.POINTER(_V)]),

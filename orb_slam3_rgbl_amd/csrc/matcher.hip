@@ -448,7 +448,12 @@ __global__ __launch_bounds__(kProjBS) void k_proj_resolve(ProjDev P) {
 // (Replace / AddObservation / AddMapPoint) changes MapPoint and KeyFrame objects and stays with the caller.
 // Uses ProjDev: wpos1, mpdesc1, oct1 (= predicted level), valid1, the grid of k_proj_grid, q / t / K, mbf, th, scale;
 // cand[i] receives the best (distance, cell order, feature) key or ~0.
-struct FuseDev { float inv_sigma2[kProjMaxLevels]; };
+struct FuseDev {
+  float inv_sigma2[kProjMaxLevels];
+  int cam_frame;  // 1: wpos1 already holds camera-frame coordinates (the caller applied its SE3 / Sim3)
+  int proj_form;  // 0: Pinhole::project, fx x / z + cx; 1: invz = (float)(1.0 / z), fx (x invz) + cx (SearchBySim3, :1508-1513)
+  int chi2_gate;  // 1: the reprojection-error gates of Fuse(pKF, vpMapPoints, th)
+};
 
 // grid = ceil(n1 / 64), block = 64
 __global__ __launch_bounds__(64) void k_fuse_search(ProjDev P, FuseDev Fz) {
@@ -457,11 +462,17 @@ __global__ __launch_bounds__(64) void k_fuse_search(ProjDev P, FuseDev Fz) {
   unsigned long long best = ~0ull;
   if (P.valid1[i]) {
     float x, y, z;
-    quat_rotate(P.q, P.wpos1[3 * i], P.wpos1[3 * i + 1], P.wpos1[3 * i + 2], &x, &y, &z);
-    x += P.t[0]; y += P.t[1]; z += P.t[2];
+    if (Fz.cam_frame) {
+      x = P.wpos1[3 * i]; y = P.wpos1[3 * i + 1]; z = P.wpos1[3 * i + 2];
+    } else {
+      quat_rotate(P.q, P.wpos1[3 * i], P.wpos1[3 * i + 1], P.wpos1[3 * i + 2], &x, &y, &z);
+      x += P.t[0]; y += P.t[1]; z += P.t[2];
+    }
     if (!(z < 0.0f)) {  // depth must be positive (:1201-1206)
-      const float invz = __fdiv_rn(1.0f, z);
-      const float u = __fdiv_rn(P.K[0] * x, z) + P.K[2], v = __fdiv_rn(P.K[1] * y, z) + P.K[3];
+      const float invz = Fz.proj_form == 1 ? (float)(1.0 / (double)z) : __fdiv_rn(1.0f, z);
+      float u, v;
+      if (Fz.proj_form == 1) { u = P.K[0] * (x * invz) + P.K[2]; v = P.K[1] * (y * invz) + P.K[3]; }
+      else { u = __fdiv_rn(P.K[0] * x, z) + P.K[2]; v = __fdiv_rn(P.K[1] * y, z) + P.K[3]; }
       if (u >= P.grid[0] && u < P.grid[2] && v >= P.grid[1] && v < P.grid[3]) {  // KeyFrame::IsInImage
         const float ur = u - P.mbf * invz;
         const int level = P.oct1[i];
@@ -485,8 +496,9 @@ __global__ __launch_bounds__(64) void k_fuse_search(ProjDev P, FuseDev Fz) {
                 if (kl < level - 1 || kl > level) continue;
                 // reprojection error gate, chi-square at 95 % with 3 / 2 degrees of freedom (:1262-1288)
                 const float ex = u - kpx, ey = v - kpy;
-                const float kpr = P.ur2[c];
-                if (kpr >= 0) {
+                const float kpr = P.ur2 ? P.ur2[c] : -1.f;
+                if (!Fz.chi2_gate) {
+                } else if (kpr >= 0) {
                   const float er = ur - kpr;
                   const float e2 = ex * ex + ey * ey + er * er;
                   if ((double)(e2 * Fz.inv_sigma2[kl]) > 7.8) continue;
@@ -1226,7 +1238,8 @@ int rgbl_distinctive_descriptors(rgbl_matcher* m, const uint8_t* desc, const int
   return RGBL_OK;
 }
 
-int rgbl_fuse_search(rgbl_matcher* m, const rgbl_fuse_input* in, int32_t* best_idx, int32_t* best_dist) {
+static int fuse_core(rgbl_matcher* m, const rgbl_fuse_input* in, int cam_frame, int proj_form, int chi2_gate, int max_dist,
+                     int32_t* best_idx, int32_t* best_dist) {
   if (!m || !in || !best_idx || in->n1 < 0 || in->n2 < 0 || in->n2 > 65535 || in->n_levels < 1 || in->n_levels > kProjMaxLevels) {
     set_error("invalid argument (the key frame may hold at most 65535 features, %d pyramid levels)", kProjMaxLevels);
     return RGBL_ERR_INVALID;
@@ -1251,7 +1264,7 @@ int rgbl_fuse_search(rgbl_matcher* m, const rgbl_fuse_input* in, int32_t* best_i
   RGBL_TRY(upload(A, s, &P.oct1, in->level1, (size_t)n1));
   RGBL_TRY(upload(A, s, &P.xy2, in->kp2_xy, (size_t)n2 * 2));
   RGBL_TRY(upload(A, s, &P.oct2, in->kp2_octave, (size_t)n2));
-  RGBL_TRY(upload(A, s, &P.ur2, in->uright2, (size_t)n2));
+  if (in->uright2) RGBL_TRY(upload(A, s, &P.ur2, in->uright2, (size_t)n2));
   RGBL_TRY(upload(A, s, &P.desc2, in->desc2, (size_t)n2 * 32));
   P.cell_start = A.take<uint32_t>(kGridCells + 1);
   P.cell_items = A.take<uint16_t>(n2);
@@ -1264,6 +1277,7 @@ int rgbl_fuse_search(rgbl_matcher* m, const rgbl_fuse_input* in, int32_t* best_i
   P.mbf = in->bf;
   P.th = in->th;
   FuseDev Fz;
+  Fz.cam_frame = cam_frame; Fz.proj_form = proj_form; Fz.chi2_gate = chi2_gate;
   for (int l = 0; l < kProjMaxLevels; ++l) {
     P.scale[l] = l < in->n_levels ? in->scale_factors[l] : 1.f;
     Fz.inv_sigma2[l] = l < in->n_levels ? in->inv_level_sigma2[l] : 1.f;
@@ -1283,9 +1297,35 @@ int rgbl_fuse_search(rgbl_matcher* m, const rgbl_fuse_input* in, int32_t* best_i
     if (keys[i] == ~0ull) continue;
     const int dist = (int)(keys[i] >> 32);
     if (best_dist) best_dist[i] = dist;
-    if (dist <= 50 /* TH_LOW */) best_idx[i] = (int)(keys[i] & 0xffffu);
+    if (dist <= max_dist) best_idx[i] = (int)(keys[i] & 0xffffu);
   }
   return RGBL_OK;
+}
+
+int rgbl_fuse_search(rgbl_matcher* m, const rgbl_fuse_input* in, int32_t* best_idx, int32_t* best_dist) {
+  return fuse_core(m, in, 0, 0, 1, 50 /* TH_LOW */, best_idx, best_dist);
+}
+
+// The per-point search shared by ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:1340-1455:
+// Pinhole::project, best <= TH_LOW) and by both directions of SearchBySim3 (:1457-1674: invz = 1.0 / z, best <= TH_HIGH): the
+// caller has already moved the points into the key frame's camera frame with its SE3 / Sim3 objects.
+int rgbl_project_search(rgbl_matcher* m, const rgbl_project_search_input* in, int32_t* best_idx, int32_t* best_dist) {
+  if (!in || (in->proj_form != 0 && in->proj_form != 1) || in->max_dist < 0 || in->max_dist > 255) {
+    set_error("invalid argument (proj_form 0 / 1, max_dist 0..255)");
+    return RGBL_ERR_INVALID;
+  }
+  rgbl_fuse_input f{};
+  f.n1 = in->n1; f.valid1 = in->valid1; f.world_pos1 = in->cam_pos1; f.mp_desc1 = in->mp_desc1; f.level1 = in->level1;
+  f.n2 = in->n2; f.kp2_xy = in->kp2_xy; f.kp2_octave = in->kp2_octave; f.uright2 = nullptr; f.desc2 = in->desc2;
+  memcpy(f.grid, in->grid, sizeof(f.grid));
+  f.Tcw_q[3] = 1.f;
+  memcpy(f.K, in->K, sizeof(f.K));
+  f.bf = 0.f;
+  f.scale_factors = in->scale_factors;
+  f.inv_level_sigma2 = in->scale_factors;  // not read without the chi-square gate
+  f.n_levels = in->n_levels;
+  f.th = in->th;
+  return fuse_core(m, &f, 1, in->proj_form, 0, in->max_dist, best_idx, best_dist);
 }
 
 int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in, int32_t* match2, int* out_nmatches) {

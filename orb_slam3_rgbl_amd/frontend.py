@@ -441,6 +441,34 @@ class ORBmatcher:
                                                                 len(descriptor_lists), L.ptr(best)))
         return best
 
+    def ProjectSearch(self, case, th, proj_form, max_dist):
+        """The per-point search of Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (proj_form 0, max_dist TH_LOW) and of both
+        directions of SearchBySim3 (proj_form 1, max_dist TH_HIGH): case has valid1, cam_pos1 (points already in the key
+        frame's camera frame), mp_desc1, level1, kp2_xy, kp2_octave, desc2, grid[6], K[4], scale_factors.
+        Returns (best feature per point or -1, best distance)."""
+        keep = []
+
+        def arr(v, dt):
+            a = np.ascontiguousarray(v, dt)
+            keep.append(a)
+            return a.ctypes.data
+        P = L.ProjectSearchInput()
+        P.n1 = len(case["valid1"])
+        P.valid1, P.cam_pos1 = arr(case["valid1"], np.uint8), arr(case["cam_pos1"], np.float32)
+        P.mp_desc1, P.level1 = arr(case["mp_desc1"], np.uint8), arr(case["level1"], np.int32)
+        P.n2 = len(case["kp2_xy"])
+        P.kp2_xy, P.kp2_octave, P.desc2 = arr(case["kp2_xy"], np.float32), arr(case["kp2_octave"], np.int32), arr(case["desc2"], np.uint8)
+        for name, n in (("grid", 6), ("K", 4)):
+            for i in range(n):
+                getattr(P, name)[i] = float(case[name][i])
+        P.scale_factors = arr(case["scale_factors"], np.float32)
+        P.n_levels = len(case["scale_factors"])
+        P.th, P.proj_form, P.max_dist = float(th), int(proj_form), int(max_dist)
+        best = np.zeros(P.n1, np.int32)
+        dist = np.zeros(P.n1, np.int32)
+        L.check(self.lib, self.lib.rgbl_project_search(self.h, C.byref(P), L.ptr(best), L.ptr(dist)))
+        return best, dist
+
     def SearchLocalPoints(self, pts, th):
         """ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) (ORBmatcher.cc:43-213), the call of
         Tracking::SearchLocalPoints.  pts: dict with the map point arrays valid1, proj1 [n,3] (mTrackProjX, mTrackProjY,

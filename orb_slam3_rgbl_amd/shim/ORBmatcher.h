@@ -22,6 +22,7 @@
 #include <mutex>
 #include <utility>
 #include <set>
+#include <tuple>
 #include <vector>
 
 #include "../../include/rgbl_frontend.h"
@@ -403,6 +404,132 @@ class ORBmatcher {
     return nFused;
   }
 
+  // Project MapPoints into KeyFrame using a given Sim3 and search for duplicated MapPoints (LoopClosing::SearchAndFuse).
+  // ORBmatcher.h:86, ORBmatcher.cc:1340-1455.  The Sophus objects are applied here exactly as the reference does
+  // (Tcw = SE3(Scw.rotationMatrix(), Scw.translation() / Scw.scale())), the search of all points runs on the device, the
+  // loop's bookkeeping (vpReplacePoint / AddObservation / AddMapPoint) is applied in order.
+  template <class KeyFrameT, class Sim3T, class MapPointT>
+  int Fuse(KeyFrameT* pKF, Sim3T& Scw, const std::vector<MapPointT*>& vpPoints, float th, std::vector<MapPointT*>& vpReplacePoint) {
+    if (!mpHandle) return 0;
+    typedef decltype(pKF->GetPose()) SE3T;
+    const SE3T Tcw(Scw.rotationMatrix(), Scw.translation() / Scw.scale());
+    const auto Ow = Tcw.inverse().translation();
+    const std::set<MapPointT*> spAlreadyFound = pKF->GetMapPoints();
+    const int n1 = (int)vpPoints.size(), n2 = pKF->N;
+    std::vector<uint8_t> valid(n1, 0), desc1((size_t)n1 * 32, 0);
+    std::vector<float> pos((size_t)n1 * 3, 0.f);
+    std::vector<int32_t> level1(n1, 0);
+    for (int i = 0; i < n1; ++i) {
+      MapPointT* pMP = vpPoints[i];
+      if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+      const auto p3Dw = pMP->GetWorldPos();
+      const auto p3Dc = Tcw * p3Dw;
+      const auto PO = p3Dw - Ow;
+      const float dist3D = PO.norm();
+      if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) continue;
+      const auto Pn = pMP->GetNormal();
+      if (PO.dot(Pn) < 0.5 * dist3D) continue;
+      valid[i] = 1;
+      level1[i] = pMP->PredictScale(dist3D, pKF);
+      for (int k = 0; k < 3; ++k) pos[3 * (size_t)i + k] = p3Dc(k);
+      const cv::Mat dMP = pMP->GetDescriptor();
+      memcpy(&desc1[(size_t)i * 32], dMP.ptr<uint8_t>(), 32);
+    }
+    std::vector<int32_t> best;
+    if (!ProjectSearch(pKF, valid, pos, desc1, level1, th, 0, 50 /* TH_LOW */, best)) return 0;
+    int nFused = 0;
+    for (int i = 0; i < n1; ++i) {
+      if (best[i] < 0) continue;
+      MapPointT* pMP = vpPoints[i];
+      MapPointT* pMPinKF = pKF->GetMapPoint(best[i]);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) vpReplacePoint[i] = pMPinKF;
+      } else {
+        pMP->AddObservation(pKF, best[i]);
+        pKF->AddMapPoint(pMP, best[i]);
+      }
+      nFused++;
+    }
+    (void)n2;
+    return nFused;
+  }
+
+  // Search matches between MapPoints seen in KF1 and KF2 transforming by a Sim3 [s12*R12|t12] (LoopClosing).
+  // ORBmatcher.h:79, ORBmatcher.cc:1457-1674: two directed searches on the device, the mutual-agreement pass here.
+  template <class KeyFrameT, class MapPointT, class Sim3T>
+  int SearchBySim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12, const Sim3T& S12, const float th) {
+    if (!mpHandle) return 0;
+    const auto T1w = pKF1->GetPose();
+    const auto T2w = pKF2->GetPose();
+    const Sim3T S21 = S12.inverse();
+    const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const std::vector<MapPointT*> vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
+    std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+    for (int i = 0; i < N1; i++) {
+      MapPointT* pMP = vpMatches12[i];
+      if (pMP) {
+        vbAlreadyMatched1[i] = true;
+        const int idx2 = std::get<0>(pMP->GetIndexInKeyFrame(pKF2));
+        if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+      }
+    }
+    std::vector<int32_t> vnMatch1, vnMatch2;
+    {
+      std::vector<uint8_t> valid(N1, 0), desc((size_t)N1 * 32, 0);
+      std::vector<float> pos((size_t)N1 * 3, 0.f);
+      std::vector<int32_t> level(N1, 0);
+      for (int i1 = 0; i1 < N1; i1++) {
+        MapPointT* pMP = vpMapPoints1[i1];
+        if (!pMP || vbAlreadyMatched1[i1] || pMP->isBad()) continue;
+        const auto p3Dw = pMP->GetWorldPos();
+        const auto p3Dc1 = T1w * p3Dw;
+        const auto p3Dc2 = S21 * p3Dc1;
+        const float dist3D = p3Dc2.norm();
+        if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) continue;
+        valid[i1] = 1;
+        level[i1] = pMP->PredictScale(dist3D, pKF2);
+        for (int k = 0; k < 3; ++k) pos[3 * (size_t)i1 + k] = p3Dc2(k);
+        const cv::Mat dMP = pMP->GetDescriptor();
+        memcpy(&desc[(size_t)i1 * 32], dMP.ptr<uint8_t>(), 32);
+      }
+      if (!ProjectSearch(pKF2, valid, pos, desc, level, th, 1, 100 /* TH_HIGH */, vnMatch1)) return 0;
+    }
+    {
+      std::vector<uint8_t> valid(N2, 0), desc((size_t)N2 * 32, 0);
+      std::vector<float> pos((size_t)N2 * 3, 0.f);
+      std::vector<int32_t> level(N2, 0);
+      for (int i2 = 0; i2 < N2; i2++) {
+        MapPointT* pMP = vpMapPoints2[i2];
+        if (!pMP || vbAlreadyMatched2[i2] || pMP->isBad()) continue;
+        const auto p3Dw = pMP->GetWorldPos();
+        const auto p3Dc2 = T2w * p3Dw;
+        const auto p3Dc1 = S12 * p3Dc2;
+        const float dist3D = p3Dc1.norm();
+        if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) continue;
+        valid[i2] = 1;
+        level[i2] = pMP->PredictScale(dist3D, pKF1);
+        for (int k = 0; k < 3; ++k) pos[3 * (size_t)i2 + k] = p3Dc1(k);
+        const cv::Mat dMP = pMP->GetDescriptor();
+        memcpy(&desc[(size_t)i2 * 32], dMP.ptr<uint8_t>(), 32);
+      }
+      if (!ProjectSearch(pKF1, valid, pos, desc, level, th, 1, 100 /* TH_HIGH */, vnMatch2)) return 0;
+    }
+    // Check agreement
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {
+      const int idx2 = vnMatch1[i1];
+      if (idx2 >= 0) {
+        const int idx1 = vnMatch2[idx2];
+        if (idx1 == i1) {
+          vpMatches12[i1] = vpMapPoints2[idx2];
+          nFound++;
+        }
+      }
+    }
+    return nFound;
+  }
+
   // Search matches between Frame keypoints and projected MapPoints.  Used to track the local map (Tracking::SearchLocalPoints,
   // Tracking.cc:3370-3450).  ORBmatcher.h:45, ORBmatcher.cc:43-213.  Reads what Frame::isInFrustum left in every MapPoint
   // (mbTrackInView, mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos, mTrackDepth) and writes F.mvpMapPoints.
@@ -499,6 +626,35 @@ class ORBmatcher {
     f.view.node_id = f.node_id.data();
     f.view.node_off = f.node_off.data();
     f.view.node_feat = f.node_feat.data();
+  }
+
+  // camera-frame points against the features of pKF (rgbl_project_search); false on a device error
+  template <class KeyFrameT>
+  bool ProjectSearch(KeyFrameT* pKF, const std::vector<uint8_t>& valid, const std::vector<float>& pos, const std::vector<uint8_t>& desc,
+                     const std::vector<int32_t>& level, float th, int proj_form, int max_dist, std::vector<int32_t>& best) {
+    const int n1 = (int)valid.size(), n2 = pKF->N;
+    std::vector<float> xy2((size_t)n2 * 2);
+    std::vector<int32_t> oct2(n2);
+    for (int i = 0; i < n2; ++i) {
+      xy2[2 * (size_t)i] = pKF->mvKeysUn[i].pt.x;
+      xy2[2 * (size_t)i + 1] = pKF->mvKeysUn[i].pt.y;
+      oct2[i] = pKF->mvKeysUn[i].octave;
+    }
+    rgbl_project_search_input in;
+    in.n1 = n1; in.valid1 = valid.data(); in.cam_pos1 = pos.data(); in.mp_desc1 = desc.data(); in.level1 = level.data();
+    in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.desc2 = pKF->mDescriptors.template ptr<uint8_t>();
+    in.grid[0] = pKF->mnMinX; in.grid[1] = pKF->mnMinY; in.grid[2] = pKF->mnMaxX; in.grid[3] = pKF->mnMaxY;
+    in.grid[4] = pKF->mfGridElementWidthInv; in.grid[5] = pKF->mfGridElementHeightInv;
+    in.K[0] = pKF->fx; in.K[1] = pKF->fy; in.K[2] = pKF->cx; in.K[3] = pKF->cy;
+    in.scale_factors = pKF->mvScaleFactors.data();
+    in.n_levels = (int)pKF->mvScaleFactors.size();
+    in.th = th; in.proj_form = proj_form; in.max_dist = max_dist;
+    best.assign(n1, -1);
+    if (rgbl_project_search(mpHandle, &in, best.data(), NULL) != RGBL_OK) {
+      std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
+      return false;
+    }
+    return true;
   }
 
   template <class FeatVecT>

@@ -972,3 +972,120 @@ def check_distinctive_descriptors(lib, seed=101, n_points=400):
     assert mt.ComputeDistinctiveDescriptors([]).size == 0
     mt.close()
     return int((want >= 0).sum())
+
+
+def make_project_search_case(n1=2500, n2=2000, seed=111):
+    """Camera-frame map points over a key frame (what Fuse(pKF, Scw, ...) and SearchBySim3 hand to the search): the fuse case with
+    the points moved into the camera frame in float64 and rounded once (the product and the oracle both start from these)."""
+    c = make_fuse_case(n1, n2, seed)
+    valid, level = fuse_prepass(c)
+    R = _rot(c["Tcw_q"]).astype(np.float64)
+    cam = (c["world_pos1"].astype(np.float64) @ R.T + c["Tcw_t"].astype(np.float64)).astype(np.float32)
+    return dict(valid1=valid, cam_pos1=cam, mp_desc1=c["mp_desc1"], level1=level, kp2_xy=c["kp2_xy"], kp2_octave=c["kp2_octave"],
+                desc2=c["desc2"], grid=c["grid"], K=c["K"], scale_factors=c["scale_factors"])
+
+
+def check_project_search(lib, seed=111, th=4.0, proj_form=0, max_dist=50, n1=2500, n2=2000):
+    case = make_project_search_case(n1, n2, seed)
+    mt = F.ORBmatcher(0.75, True, lib=lib)
+    best, dist = mt.ProjectSearch(case, th, proj_form, max_dist)
+    obest, odist = O.project_search(case, th, proj_form, max_dist)
+    assert np.array_equal(best, obest) and np.array_equal(dist, odist), "project search (seed %d, form %d)" % (seed, proj_form)
+    mt.close()
+    return int((best >= 0).sum())
+
+
+def camera_prepass(cam_pos, min_dist, max_dist, log_scale_factor, n_levels, normal=None):
+    """dist3D = |p3Dc| (SearchBySim3) resp. |p3Dw - Ow| with Ow = 0, the invariance range, the optional viewing-angle test and
+    PredictScale, in numpy float32 + the C library's logf: what the shims evaluate with the MapPoint objects."""
+    P = np.asarray(cam_pos, np.float32)
+    sq = (P * P).astype(np.float32)
+    dist = np.sqrt((sq[:, 0] + (sq[:, 1] + sq[:, 2]).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    valid = ~(dist < (np.float32(0.8) * min_dist).astype(np.float32)) & ~(dist > (np.float32(1.2) * max_dist).astype(np.float32))
+    if normal is not None:
+        pr = (P * np.asarray(normal, np.float32)).astype(np.float32)
+        dot = (pr[:, 0] + (pr[:, 1] + pr[:, 2]).astype(np.float32)).astype(np.float32)
+        valid &= ~(dot.astype(np.float64) < 0.5 * dist.astype(np.float64))
+    level = F.ORBmatcher.PredictScale(dist, max_dist, log_scale_factor, n_levels)
+    return valid, np.where(valid, level, 0).astype(np.int32)
+
+
+def make_sim3_case(n=1500, seed=121, w=synth.KITTI_W, h=synth.KITTI_H):
+    """Two key frames that see the same place (all poses identities, so one common camera frame): KF2's features are KF1's,
+    permuted, moved by a pixel or two and with a few descriptor bits flipped; every feature's map point sits on the ray of its
+    counterpart in the OTHER key frame, so that the two directed searches of SearchBySim3 mostly agree.  Some features have no
+    or a bad map point, some points fall outside their invariance range, some lie behind the camera."""
+    rng = np.random.default_rng(seed)
+    K = np.array([718.856, 718.856, 607.1928, 185.2157], np.float32)
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    xy1 = np.stack([rng.uniform(20, w - 20, n), rng.uniform(20, h - 20, n)], 1).astype(np.float32)
+    oct1 = rng.integers(0, 8, n).astype(np.int32)
+    desc1 = synth.descriptors(n, seed)
+    perm = rng.permutation(n)
+    inv = np.argsort(perm)                                   # feature i1 of KF1 <-> feature inv[i1] of KF2
+    xy2 = (xy1[perm] + rng.normal(0, 1.0, (n, 2))).astype(np.float32)
+    oct2 = oct1[perm].copy()
+    desc2 = desc1[perm] ^ np.packbits(rng.random((n, 256)) < 0.03, axis=1, bitorder="little")
+
+    def side(xy_self, octave, desc, xy_other, partner):
+        z = rng.uniform(4, 60, n)
+        z[rng.random(n) < 0.03] *= -1
+        tgt = xy_other[partner] + rng.normal(0, 1.0, (n, 2))
+        pos = np.stack([(tgt[:, 0] - K[2]) / K[0] * z, (tgt[:, 1] - K[3]) / K[1] * z, z], 1).astype(np.float32)
+        dist = np.linalg.norm(pos.astype(np.float64), axis=1)
+        lvl = np.clip(octave + rng.integers(0, 2, n), 0, 7)   # predicted level = octave or octave + 1: band [l - 1, l] holds the octave
+        max_d = (dist * 1.2 ** lvl * rng.uniform(0.86, 0.99, n)).astype(np.float32)
+        min_d = (max_d / np.float32(1.2 ** 7)).astype(np.float32)
+        far = rng.random(n) < 0.04
+        max_d[far] = (dist[far] * 0.5).astype(np.float32)
+        normal = -pos / np.maximum(np.linalg.norm(pos, axis=1, keepdims=True), 1e-6) + rng.normal(0, 0.3, pos.shape)
+        normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+        normal = -normal if False else normal
+        state = rng.choice([0, 1, 2], n, p=[0.12, 0.8, 0.08]).astype(np.uint8)
+        mp_desc = desc ^ np.packbits(rng.random((n, 256)) < 0.02, axis=1, bitorder="little")
+        return dict(kp_xy=xy_self, kp_octave=octave, desc=desc, mp_state=state, mp_pos=pos, mp_normal=(-normal).astype(np.float32),
+                    mp_desc=mp_desc, mp_min_dist=min_d, mp_max_dist=max_d)
+    a1 = side(xy1, oct1, desc1, xy2, inv)
+    a2 = side(xy2, oct2, desc2, xy1, perm)
+    gw, gh = np.float32(w), np.float32(h)
+    grid = np.array([0, 0, gw, gh, np.float32(64) / gw, np.float32(48) / gh], np.float32)
+    prior = np.where(rng.random(n) < 0.1, inv, -1).astype(np.int32)      # matches found earlier (by SearchByBoW)
+    return dict(a1=a1, a2=a2, K=K, grid=grid, scale_factors=sf, log_scale_factor=np.float32(np.log(np.float32(1.2))), prior12=prior, inv=inv)
+
+
+def sim3_direction(case, src, dst, already, th):
+    """One directed search of SearchBySim3 (ORBmatcher.cc:1497-1566) as input of the C ABI / the oracle."""
+    a, b = case[src], case[dst]
+    valid, level = camera_prepass(a["mp_pos"], a["mp_min_dist"], a["mp_max_dist"], case["log_scale_factor"], len(case["scale_factors"]))
+    valid &= (a["mp_state"] == 1) & ~already
+    return dict(valid1=valid.astype(np.uint8), cam_pos1=a["mp_pos"], mp_desc1=a["mp_desc"], level1=level, kp2_xy=b["kp_xy"],
+                kp2_octave=b["kp_octave"], desc2=b["desc"], grid=case["grid"], K=case["K"], scale_factors=case["scale_factors"])
+
+
+def search_by_sim3(case, th, search):
+    """SearchBySim3 on top of a per-point search function(case, th, proj_form, max_dist) -> (best_idx, best_dist)."""
+    n1, n2 = len(case["a1"]["kp_xy"]), len(case["a2"]["kp_xy"])
+    prior = case["prior12"]
+    am1 = prior >= 0
+    am2 = np.zeros(n2, bool)
+    # vbAlreadyMatched2[idx2] for idx2 = GetIndexInKeyFrame(pKF2) of the prior match (the map point of KF2's feature prior[i])
+    am2[prior[am1]] = True
+    m1, _ = search(sim3_direction(case, "a1", "a2", am1, th), th, 1, 100)
+    m2, _ = search(sim3_direction(case, "a2", "a1", am2, th), th, 1, 100)
+    out = prior.copy()
+    found = 0
+    for i1 in range(n1):
+        if m1[i1] >= 0 and m2[m1[i1]] == i1:
+            out[i1] = m1[i1]
+            found += 1
+    return out, found
+
+
+def check_search_by_sim3(lib, seed=121, th=7.5, n=1500):
+    case = make_sim3_case(n, seed)
+    mt = F.ORBmatcher(0.75, True, lib=lib)
+    got, ng = search_by_sim3(case, th, mt.ProjectSearch)
+    want, nw = search_by_sim3(case, th, O.project_search)
+    assert ng == nw and np.array_equal(got, want), "SearchBySim3 (seed %d)" % seed
+    mt.close()
+    return nw

@@ -98,13 +98,25 @@ def run_and_check(exe, tmp):
                         ("kp2_xy", np.float32), ("kp2_octave", np.int32), ("uright2", np.float32), ("desc2", np.uint8)):
             f.write(np.ascontiguousarray(fcase[key], dt).tobytes())
         f.write(fstate.tobytes())
+    scase = pc.make_sim3_case(1200, seed=141)
+    with open(os.path.join(tmp, "sim3.bin"), "wb") as f:
+        f.write(struct.pack("<iff", len(scase["a1"]["kp_xy"]), 7.5, 4.0))
+        hdr = np.concatenate([scase["K"], scase["grid"], scase["scale_factors"], [scase["log_scale_factor"]]]).astype(np.float32)
+        assert hdr.size == 19
+        f.write(hdr.tobytes())
+        for side in ("a1", "a2"):
+            for key, dt in (("kp_xy", np.float32), ("kp_octave", np.int32), ("desc", np.uint8), ("mp_state", np.uint8),
+                            ("mp_pos", np.float32), ("mp_normal", np.float32), ("mp_desc", np.uint8), ("mp_min_dist", np.float32),
+                            ("mp_max_dist", np.float32)):
+                f.write(np.ascontiguousarray(scase[side][key], dt).tobytes())
+        f.write(np.ascontiguousarray(scase["prior12"], np.int32).tobytes())
     voc = synth.make_vocabulary(10, 3, seed=5)
     synth.write_vocabulary_text(os.path.join(tmp, "voc.txt"), voc)
     out = os.path.join(tmp, "out.bin")
     res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "KITTI00-02.yaml"), os.path.join(tmp, "img.raw"), str(w), str(h),
                           os.path.join(tmp, "cloud.raw"), str(cloud.shape[1]), os.path.join(tmp, "tri.bin"), out,
                           os.path.join(tmp, "proj.bin"), os.path.join(tmp, "local.bin"), os.path.join(tmp, "voc.txt"),
-                          os.path.join(tmp, "reloc.bin"), os.path.join(tmp, "fuse.bin")],
+                          os.path.join(tmp, "reloc.bin"), os.path.join(tmp, "fuse.bin"), os.path.join(tmp, "sim3.bin")],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "Lidar Method: InverseDilation" in res.stdout
@@ -159,7 +171,23 @@ def run_and_check(exe, tmp):
     nfused, nq = take(np.int32, 2)
     fused_with = take(np.int32, nq)
     best_desc = take(np.int32, 1)[0]
+    nsim, n1s = take(np.int32, 2)
+    sim_match = take(np.int32, n1s)
+    nfs, nqs = take(np.int32, 2)
+    fused_sim = take(np.int32, nqs)
     assert pos == len(buf)
+    osm, osn = pc.search_by_sim3(scase, 7.5, O.project_search)
+    assert nsim == osn and np.array_equal(sim_match, osm) and nsim > 200
+    # Fuse(pKF2, Scw = I, points of KF1, 4): candidates = the features of KF1 that hold a point, in index order
+    a1, a2 = scase["a1"], scase["a2"]
+    sel = np.nonzero(a1["mp_state"])[0]
+    fvalid, flevel = pc.camera_prepass(a1["mp_pos"][sel], a1["mp_min_dist"][sel], a1["mp_max_dist"][sel], scase["log_scale_factor"], 8,
+                                       normal=a1["mp_normal"][sel])
+    fvalid &= a1["mp_state"][sel] == 1
+    fbest, _ = O.project_search(dict(valid1=fvalid.astype(np.uint8), cam_pos1=a1["mp_pos"][sel], mp_desc1=a1["mp_desc"][sel], level1=flevel,
+                                     kp2_xy=a2["kp_xy"], kp2_octave=a2["kp_octave"], desc2=a2["desc"], grid=scase["grid"], K=scase["K"],
+                                     scale_factors=scase["scale_factors"]), 4.0, 0, 50)
+    assert nfs == int((fbest >= 0).sum()) and np.array_equal(fused_sim, fbest[fbest >= 0]) and nfs > 200
     rows = [kf1["desc"][i * 3 % len(kf1["desc"])] for i in range(25)]
     assert best_desc == O.distinctive_descriptors([np.stack(rows)])[0]
     ofb, onf = O.fuse_search(fcase, 3.0)

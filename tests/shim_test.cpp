@@ -8,6 +8,7 @@
 
 #include <map>
 #include <set>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -158,6 +159,75 @@ struct FuseKF {
   void AddMapPoint(FusePoint* p, size_t idx) { mps[idx] = p; }
 };
 int FusePoint::PredictScale(const float& currentDist, FuseKF* pKF) {
+  const float ratio = mfMaxDistance / currentDist;
+  int nScale = ceil(log(ratio) / pKF->mfLogScaleFactor);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= pKF->mnScaleLevels) nScale = pKF->mnScaleLevels - 1;
+  return nScale;
+}
+// ---- stand-ins for the Sim3 matchers (SearchBySim3, Fuse(pKF, Scw, ...)): matrix-form transforms, exact for the identities used
+static V3 operator/(const V3& a, float s) { return V3{{a.v[0] / s, a.v[1] / s, a.v[2] / s}}; }
+struct TestSE3 {
+  M3 R; V3 t;
+  TestSE3() { for (int i = 0; i < 9; ++i) R.m[i] = (i % 4 == 0) ? 1.f : 0.f; t = V3{{0, 0, 0}}; }
+  TestSE3(const M3& R_, const V3& t_) : R(R_), t(t_) {}
+  V3n operator*(const V3& p) const {
+    V3 r;
+    for (int i = 0; i < 3; ++i) r.v[i] = R.m[3 * i] * p.v[0] + R.m[3 * i + 1] * p.v[1] + R.m[3 * i + 2] * p.v[2] + t.v[i];
+    return V3n(r);
+  }
+  TestSE3 inverse() const {
+    TestSE3 r;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.R.m[3 * i + j] = R.m[3 * j + i];
+    for (int i = 0; i < 3; ++i) r.t.v[i] = -(r.R.m[3 * i] * t.v[0] + r.R.m[3 * i + 1] * t.v[1] + r.R.m[3 * i + 2] * t.v[2]);
+    return r;
+  }
+  V3 translation() const { return t; }
+};
+struct TestSim3 {
+  TestSE3 T; float s = 1.f;
+  M3 rotationMatrix() const { return T.R; }
+  V3 translation() const { return T.t; }
+  float scale() const { return s; }
+  TestSim3 inverse() const { TestSim3 r; r.T = T.inverse(); r.s = 1.f / s; for (int i = 0; i < 3; ++i) r.T.t.v[i] *= r.s; return r; }
+  V3n operator*(const V3& p) const {
+    V3 q;
+    for (int i = 0; i < 3; ++i) q.v[i] = s * (T.R.m[3 * i] * p.v[0] + T.R.m[3 * i + 1] * p.v[1] + T.R.m[3 * i + 2] * p.v[2]) + T.t.v[i];
+    return V3n(q);
+  }
+};
+struct SimKF;
+struct SimPoint {
+  V3 pos, normal; cv::Mat desc; bool bad = false; int nObs = 3;
+  float mfMinDistance = 0, mfMaxDistance = 0;
+  SimKF* home = nullptr; int home_idx = -1;
+  bool isBad() { return bad; }
+  V3 GetWorldPos() { return pos; }
+  V3 GetNormal() { return normal; }
+  cv::Mat GetDescriptor() { return desc; }
+  float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
+  float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+  int PredictScale(const float& currentDist, SimKF* pKF);
+  std::tuple<int, int> GetIndexInKeyFrame(SimKF* pKF) { return std::tuple<int, int>(pKF == home ? home_idx : -1, -1); }
+  void AddObservation(SimKF* pKF, int idx) { home = pKF; home_idx = idx; }
+};
+struct SimKF {
+  int N = 0;
+  float mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+  float fx = 0, fy = 0, cx = 0, cy = 0, mfLogScaleFactor = 0;
+  int mnScaleLevels = 0;
+  std::vector<cv::KeyPoint> mvKeysUn;
+  std::vector<float> mvScaleFactors;
+  std::vector<SimPoint*> mps;
+  std::vector<int> queried;
+  cv::Mat mDescriptors;
+  TestSE3 GetPose() { return TestSE3(); }
+  std::vector<SimPoint*> GetMapPointMatches() { return mps; }
+  std::set<SimPoint*> GetMapPoints() { std::set<SimPoint*> r; for (SimPoint* p : mps) if (p) r.insert(p); return r; }
+  SimPoint* GetMapPoint(size_t idx) { queried.push_back((int)idx); return mps[idx]; }
+  void AddMapPoint(SimPoint* p, size_t idx) { mps[idx] = p; }
+};
+int SimPoint::PredictScale(const float& currentDist, SimKF* pKF) {
   const float ratio = mfMaxDistance / currentDist;
   int nScale = ceil(log(ratio) / pKF->mfLogScaleFactor);
   if (nScale < 0) nScale = 0;
@@ -526,6 +596,57 @@ int main(int argc, char** argv) {
     ORB_SLAM3::ORBmatcher any(0.6, true);
     const int bestIdx = any.DistinctiveDescriptor(vDescriptors);
     wr(out, &bestIdx, 1);
+  }
+  // --- as LoopClosing: matcher.SearchBySim3(mpCurrentKF, pKF, vpMapPointMatches, gScm, 7.5) and matcher.Fuse(pKFi, Scw, vpPoints, 4, vpReplacePoints)
+  if (argc > 14) {
+    f = fopen(argv[14], "rb");
+    int n = 0;
+    float th_sim = 0, th_fuse = 0, hdr[4 + 6 + 8 + 1];
+    if (!f || !rd(f, &n, 1) || !rd(f, &th_sim, 1) || !rd(f, &th_fuse, 1) || !rd(f, hdr, 19)) return 11;
+    SimKF kf[2];
+    std::vector<SimPoint> pts[2];
+    for (int s2 = 0; s2 < 2; ++s2) {
+      std::vector<float> xy(2 * (size_t)n), pos(3 * (size_t)n), nor(3 * (size_t)n), mind(n), maxd(n);
+      std::vector<int> oct(n);
+      std::vector<unsigned char> d((size_t)n * 32), st(n), md((size_t)n * 32);
+      rd(f, xy.data(), 2 * (size_t)n); rd(f, oct.data(), n); rd(f, d.data(), (size_t)n * 32); rd(f, st.data(), n); rd(f, pos.data(), 3 * (size_t)n);
+      rd(f, nor.data(), 3 * (size_t)n); rd(f, md.data(), (size_t)n * 32); rd(f, mind.data(), n); rd(f, maxd.data(), n);
+      SimKF& k = kf[s2];
+      k.N = n; k.fx = hdr[0]; k.fy = hdr[1]; k.cx = hdr[2]; k.cy = hdr[3];
+      k.mnMinX = hdr[4]; k.mnMinY = hdr[5]; k.mnMaxX = hdr[6]; k.mnMaxY = hdr[7]; k.mfGridElementWidthInv = hdr[8]; k.mfGridElementHeightInv = hdr[9];
+      k.mvScaleFactors.assign(hdr + 10, hdr + 18); k.mnScaleLevels = 8; k.mfLogScaleFactor = hdr[18];
+      k.mvKeysUn.resize(n); k.mps.assign(n, nullptr);
+      k.mDescriptors.create(n, 32, CV_8U); memcpy(k.mDescriptors.data, d.data(), (size_t)n * 32);
+      pts[s2].assign(n, SimPoint());
+      for (int i = 0; i < n; ++i) {
+        k.mvKeysUn[i].pt.x = xy[2 * i]; k.mvKeysUn[i].pt.y = xy[2 * i + 1]; k.mvKeysUn[i].octave = oct[i];
+        if (!st[i]) continue;
+        SimPoint& p = pts[s2][i];
+        p.bad = st[i] == 2; p.pos = V3{{pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]}}; p.normal = V3{{nor[3 * i], nor[3 * i + 1], nor[3 * i + 2]}};
+        p.desc.create(1, 32, CV_8U); memcpy(p.desc.data, &md[(size_t)i * 32], 32);
+        p.mfMinDistance = mind[i]; p.mfMaxDistance = maxd[i]; p.home = &k; p.home_idx = i;
+        k.mps[i] = &p;
+      }
+    }
+    std::vector<int> prior(n);
+    rd(f, prior.data(), n);
+    fclose(f);
+    std::vector<SimPoint*> vpMatches12(n, nullptr);
+    for (int i = 0; i < n; ++i) if (prior[i] >= 0) vpMatches12[i] = &pts[1][prior[i]];
+    TestSim3 S12;
+    ORB_SLAM3::ORBmatcher loop2(0.75, true);
+    const int nFound = loop2.SearchBySim3(&kf[0], &kf[1], vpMatches12, S12, th_sim);
+    wr(out, &nFound, 1); wr(out, &n, 1);
+    for (int i = 0; i < n; ++i) { const int idx = vpMatches12[i] ? (int)(vpMatches12[i] - pts[1].data()) : -1; wr(out, &idx, 1); }
+    // Fuse: the good and bad points of KF1 as candidates, projected into KF2
+    std::vector<SimPoint*> vpPoints, vpReplace;
+    for (int i = 0; i < n; ++i) if (kf[0].mps[i]) vpPoints.push_back(kf[0].mps[i]);
+    vpReplace.assign(vpPoints.size(), nullptr);
+    kf[1].queried.clear();
+    TestSim3 Scw;
+    const int nFusedS = loop2.Fuse(&kf[1], Scw, vpPoints, th_fuse, vpReplace);
+    const int nq = (int)kf[1].queried.size();
+    wr(out, &nFusedS, 1); wr(out, &nq, 1); wr(out, kf[1].queried.data(), nq);
   }
   fclose(out);
   printf("shim_test ok: %d keypoints, %d depths, %d triangulation matches\n", nk, nd, nm);

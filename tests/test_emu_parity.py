@@ -161,3 +161,13 @@ def test_undistort_keypoints(emu_lib):
 
 def test_distinctive_descriptors(emu_lib):
     assert pc.check_distinctive_descriptors(emu_lib, 101, 150) > 75
+
+
+@pytest.mark.parametrize("seed,th,form,maxd", [(111, 4.0, 0, 50), (112, 7.5, 1, 100), (113, 3.0, 1, 100)])
+def test_project_search(emu_lib, seed, th, form, maxd):
+    assert pc.check_project_search(emu_lib, seed, th, form, maxd, n1=1200, n2=1000) > 80
+
+
+@pytest.mark.parametrize("seed,th", [(121, 7.5), (123, 3.0)])
+def test_search_by_sim3(emu_lib, seed, th):
+    assert pc.check_search_by_sim3(emu_lib, seed, th, n=800) > 150

@@ -187,3 +187,13 @@ def test_undistort_keypoints(gpu_lib):
 
 def test_distinctive_descriptors(gpu_lib):
     assert pc.check_distinctive_descriptors(gpu_lib, 101, 2000) > 1000
+
+
+@pytest.mark.parametrize("seed,th,form,maxd", [(111, 4.0, 0, 50), (112, 7.5, 1, 100), (113, 3.0, 1, 100)])
+def test_project_search(gpu_lib, seed, th, form, maxd):
+    assert pc.check_project_search(gpu_lib, seed, th, form, maxd) > 80
+
+
+@pytest.mark.parametrize("seed,th", [(121, 7.5), (123, 3.0)])
+def test_search_by_sim3(gpu_lib, seed, th):
+    assert pc.check_search_by_sim3(gpu_lib, seed, th) > 150

@@ -484,3 +484,80 @@ def test_reference_fuse_agrees_with_oracle(refmatcher, seed, th):
     assert np.all(state[obest[silent]] == 3) and seen.sum() + silent.sum() == nf
     for s in (0, 1, 2):
         assert np.any(state[obest[seen]] == s)          # AddObservation and both Replace directions were exercised
+
+
+class Sim3Side(C.Structure):
+    _fields_ = [("n", C.c_int), ("kp_xy", C.c_void_p), ("kp_octave", C.c_void_p), ("desc", C.c_void_p), ("mp_state", C.c_void_p),
+                ("mp_pos", C.c_void_p), ("mp_normal", C.c_void_p), ("mp_desc", C.c_void_p), ("mp_min_dist", C.c_void_p),
+                ("mp_max_dist", C.c_void_p)]
+
+
+def sim3_side(d, keep):
+    a = Sim3Side()
+    a.n = len(d["kp_xy"])
+    for f, dt in (("kp_xy", np.float32), ("kp_octave", np.int32), ("desc", np.uint8), ("mp_state", np.uint8), ("mp_pos", np.float32),
+                  ("mp_normal", np.float32), ("mp_desc", np.uint8), ("mp_min_dist", np.float32), ("mp_max_dist", np.float32)):
+        arr = np.ascontiguousarray(d[f], dt)
+        keep.append(arr)
+        setattr(a, f, arr.ctypes.data)
+    return a
+
+
+@pytest.mark.parametrize("seed,th", [(121, 7.5), (122, 7.5), (123, 3.0), (124, 10.0)])
+def test_reference_search_by_sim3_agrees_with_oracle(refmatcher, seed, th):
+    """The real ORBmatcher::SearchBySim3 (LoopClosing: matcher.SearchBySim3(mpCurrentKF, pKF, vpMapPointMatches, gScm, 7.5)) with
+    identity poses against two oracle per-point searches + the mutual-agreement pass; the prepass written in numpy (invariance
+    range, PredictScale on |p3Dc|) is thereby held to what the reference evaluated on the stand-in MapPoint objects."""
+    import parity_checks as pc
+    case = pc.make_sim3_case(seed=seed)
+    keep = []
+    a1, a2 = sim3_side(case["a1"], keep), sim3_side(case["a2"], keep)
+    K, grid, sf = (np.ascontiguousarray(case[k], np.float32) for k in ("K", "grid", "scale_factors"))
+    prior = np.ascontiguousarray(case["prior12"], np.int32)
+    m = np.zeros(a1.n, np.int32)
+    refmatcher.ref_search_by_sim3.restype = C.c_int
+    refmatcher.ref_search_by_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                              C.c_void_p, C.c_void_p]
+    nf = refmatcher.ref_search_by_sim3(C.byref(a1), C.byref(a2), K.ctypes.data, grid.ctypes.data, sf.ctypes.data, len(sf),
+                                       C.c_float(float(case["log_scale_factor"])), C.c_float(th), prior.ctypes.data, m.ctypes.data)
+    om, onf = pc.search_by_sim3(case, th, O.project_search)
+    assert nf == onf and np.array_equal(m, om)
+    assert nf > 300
+    new = (m >= 0) & (prior < 0)
+    assert np.mean(m[new] == case["inv"][new]) > 0.95          # the agreed matches are the true counterparts
+
+
+@pytest.mark.parametrize("seed,th", [(131, 4.0), (132, 4.0), (133, 2.5)])
+def test_reference_fuse_sim3_agrees_with_oracle(refmatcher, seed, th):
+    """The real ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (LoopClosing::SearchAndFuse, th = 4) with an identity Scw."""
+    import parity_checks as pc
+    case = pc.make_sim3_case(seed=seed)
+    rng = np.random.default_rng(seed)
+    cand = dict(case["a1"])
+    cand["mp_state"] = np.where(cand["mp_state"] == 0, 1, cand["mp_state"]).astype(np.uint8)   # every entry of vpPoints is a point
+    in_kf = (rng.random(len(cand["kp_xy"])) < 0.08).astype(np.uint8)
+    state2 = rng.choice([0, 1, 3], len(case["a2"]["kp_xy"]), p=[0.5, 0.4, 0.1]).astype(np.uint8)
+    keep = []
+    c, kfa = sim3_side(cand, keep), sim3_side(case["a2"], keep)
+    K, grid, sf = (np.ascontiguousarray(case[k], np.float32) for k in ("K", "grid", "scale_factors"))
+    fused = np.zeros(c.n, np.int32)
+    refmatcher.ref_fuse_sim3.restype = C.c_int
+    refmatcher.ref_fuse_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_float, C.c_float, C.c_void_p]
+    nf = refmatcher.ref_fuse_sim3(C.byref(c), in_kf.ctypes.data, C.byref(kfa), state2.ctypes.data, K.ctypes.data, grid.ctypes.data,
+                                  sf.ctypes.data, len(sf), C.c_float(float(case["log_scale_factor"])), C.c_float(th), fused.ctypes.data)
+    valid, level = pc.camera_prepass(cand["mp_pos"], cand["mp_min_dist"], cand["mp_max_dist"], case["log_scale_factor"], len(sf),
+                                     normal=cand["mp_normal"])
+    valid &= (cand["mp_state"] == 1) & (in_kf == 0)
+    search = dict(valid1=valid.astype(np.uint8), cam_pos1=cand["mp_pos"], mp_desc1=cand["mp_desc"], level1=level,
+                  kp2_xy=case["a2"]["kp_xy"], kp2_octave=case["a2"]["kp_octave"], desc2=case["a2"]["desc"], grid=grid, K=K, scale_factors=sf)
+    obest, _ = O.project_search(search, th, 0, 50)
+    assert nf == int((obest >= 0).sum()) and nf > 300
+    seen = fused >= 0
+    assert np.array_equal(fused[seen], obest[seen])
+    silent = (~seen) & (obest >= 0)                            # the feature held a bad map point: counted, nothing recorded
+    holds_bad = state2 == 3
+    n2 = len(state2)
+    for i in np.nonzero(in_kf)[0]:                             # the glue parks the candidates the key frame "already has" in its last slots
+        holds_bad[n2 - 1 - (i % n2)] = cand["mp_state"][i] == 2
+    assert np.all(holds_bad[obest[silent]])
