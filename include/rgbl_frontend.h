@@ -435,11 +435,22 @@ typedef struct {
   const float* scale_factors;
   int n_levels;
   float th;
-  int proj_form;               /* 0: Pinhole::project (fx x / z + cx) as in Fuse; 1: invz = 1.0 / z, fx (x invz) + cx as in SearchBySim3 */
+  int proj_form;               /* 0: Pinhole::project (fx x / z + cx) as in Fuse; 1: invz = 1.0 / z (double), fx (x invz) + cx as in
+                                  SearchBySim3; 2 (rgbl_search_by_projection_sim3 only): invz = 1 / z in float */
   int max_dist;                /* TH_LOW (Fuse) / TH_HIGH (SearchBySim3) */
 } rgbl_project_search_input;
 /* Host pointers, synchronous.  best_idx[i] = key-frame feature with the smallest distance (<= max_dist) or -1; best_dist nullable. */
 int rgbl_project_search(rgbl_matcher* h, const rgbl_project_search_input* in, int32_t* best_idx, int32_t* best_dist);
+
+/* int ORBmatcher::SearchByProjection(KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>& vpPoints,
+ * vector<MapPoint*>& vpMatched, int th, float ratioHamming) (include/ORBmatcher.h:61, src/ORBmatcher.cc:427-532; proj_form 0) and
+ * the overload that also fills vpMatchedKF (include/ORBmatcher.h:65, src/ORBmatcher.cc:534-646; proj_form 2: invz = 1 / z in
+ * float), the matchers of LoopClosing::FindMatchesByProjection.  Input as for rgbl_project_search (camera-frame points, the
+ * caller's tests folded into valid1, max_dist = floor(TH_LOW * ratioHamming)); matched2[i] != 0: vpMatched[i] != NULL on entry
+ * (nullable).  Points are taken in index order and a matched feature is skipped by the points after it.
+ * match2 (n2 entries): index of the point stored in vpMatched[i2] by this call, or -1.  Host pointers, synchronous. */
+int rgbl_search_by_projection_sim3(rgbl_matcher* h, const rgbl_project_search_input* in, const uint8_t* matched2, int32_t* match2,
+                                   int* out_nmatches);
 
 /* void MapPoint::ComputeDistinctiveDescriptors() (src/MapPoint.cc:329-403; called after every new observation / fusion, e.g.
  * LocalMapping.cc:333,691, Tracking.cc:2437) for a batch of map points: the N x N ORBmatcher::DescriptorDistance table of a point's

@@ -355,6 +355,66 @@ extern "C" void orc_project_search(const orc_project_search_input* in, int* best
   }
 }
 
+// ---- SearchByProjection(pKF, Scw, vpPoints, [vpPointsKFs,] vpMatched, [vpMatchedKF,] th, ratioHamming), ORBmatcher.cc:427-646 ----
+extern "C" int orc_search_by_projection_sim3(const orc_project_search_input* in, const uint8_t* matched2, int* match2) {
+  const int COLS = 64, ROWS = 48;
+  const float mnMinX = in->grid[0], mnMinY = in->grid[1], mnMaxX = in->grid[2], mnMaxY = in->grid[3];
+  const float invW = in->grid[4], invH = in->grid[5];
+  const float fx = in->K[0], fy = in->K[1], cx = in->K[2], cy = in->K[3];
+  std::vector<std::vector<int>> cells((size_t)COLS * ROWS);
+  for (int i = 0; i < in->n2; ++i) {
+    const int px = (int)roundf((in->kp2_xy[2 * i] - mnMinX) * invW), py = (int)roundf((in->kp2_xy[2 * i + 1] - mnMinY) * invH);
+    if (px < 0 || px >= COLS || py < 0 || py >= ROWS) continue;
+    cells[(size_t)px * ROWS + py].push_back(i);
+  }
+  std::vector<int> vpMatched(in->n2, -1);  // -2: matched before the call
+  for (int i = 0; i < in->n2; ++i)
+    if (matched2 && matched2[i]) vpMatched[i] = -2;
+  int nmatches = 0;
+  for (int iMP = 0; iMP < in->n1; ++iMP) {
+    if (!in->valid1[iMP]) continue;
+    const float X = in->cam_pos1[3 * iMP], Y = in->cam_pos1[3 * iMP + 1], Z = in->cam_pos1[3 * iMP + 2];
+    if (Z < 0.0) continue;
+    float u, v;
+    if (in->proj_form == 2) {
+      const float invz = 1 / Z;
+      const float x = X * invz, y = Y * invz;
+      u = fx * x + cx; v = fy * y + cy;
+    } else {
+      u = fx * X / Z + cx; v = fy * Y / Z + cy;
+    }
+    if (!(u >= mnMinX && u < mnMaxX && v >= mnMinY && v < mnMaxY)) continue;
+    const int nPredictedLevel = in->level1[iMP];
+    const float radius = in->th * in->scale_factors[nPredictedLevel];
+    const int nMinCellX = std::max(0, (int)floorf((u - mnMinX - radius) * invW));
+    if (nMinCellX >= COLS) continue;
+    const int nMaxCellX = std::min(COLS - 1, (int)ceilf((u - mnMinX + radius) * invW));
+    if (nMaxCellX < 0) continue;
+    const int nMinCellY = std::max(0, (int)floorf((v - mnMinY - radius) * invH));
+    if (nMinCellY >= ROWS) continue;
+    const int nMaxCellY = std::min(ROWS - 1, (int)ceilf((v - mnMinY + radius) * invH));
+    if (nMaxCellY < 0) continue;
+    const uint8_t* dMP = in->mp_desc1 + 32 * (size_t)iMP;
+    int bestDist = 256, bestIdx = -1;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+      for (int iy = nMinCellY; iy <= nMaxCellY; ++iy)
+        for (int idx : cells[(size_t)ix * ROWS + iy]) {
+          if (!(fabsf(in->kp2_xy[2 * idx] - u) < radius && fabsf(in->kp2_xy[2 * idx + 1] - v) < radius)) continue;
+          if (vpMatched[idx] != -1) continue;
+          const int kpLevel = in->kp2_octave[idx];
+          if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+          const int dist = hamming256(dMP, in->desc2 + 32 * (size_t)idx);
+          if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+    if (bestDist <= in->max_dist) {  // <= TH_LOW * ratioHamming
+      vpMatched[bestIdx] = iMP;
+      ++nmatches;
+    }
+  }
+  for (int i = 0; i < in->n2; ++i) match2[i] = vpMatched[i] >= 0 ? vpMatched[i] : -1;
+  return nmatches;
+}
+
 // ---- MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:329-403 ----
 extern "C" void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int n_points, int32_t* best) {
   for (int p = 0; p < n_points; ++p) {

@@ -219,6 +219,11 @@ typedef struct {
   int max_dist;
 } orc_project_search_input;
 void orc_project_search(const orc_project_search_input* in, int* best_idx, int* best_dist);
+/* ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming) (/root/reference/src/ORBmatcher.cc:427-532,
+ * proj_form 0) and the vpPointsKFs overload (:534-646, proj_form 2: invz = 1 / z in float), from "Depth must be positive" on,
+ * on camera-frame points; matched2 = vpMatched[i] != NULL on entry.  match2[i2] = point stored in vpMatched[i2] or -1.
+ * Returns nmatches. */
+int orc_search_by_projection_sim3(const orc_project_search_input* in, const uint8_t* matched2, int* match2);
 
 /* MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:329-403) for a batch: descriptors of point p = rows
  * off[p] .. off[p+1]); best[p] = BestIdx (float distance table, std::sort of every row, median at (size_t)(0.5 * (N - 1)),

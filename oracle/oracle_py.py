@@ -680,7 +680,7 @@ class ProjectSearchInput(C.Structure):
                 ("n_levels", C.c_int), ("th", C.c_float), ("proj_form", C.c_int), ("max_dist", C.c_int)]
 
 
-def project_search(case, th, proj_form, max_dist):
+def project_search(case, th, proj_form, max_dist, matched2=None):
     """The per-point search of Fuse(pKF, Scw, ...) / SearchBySim3 on camera-frame points; returns (best_idx, best_dist)."""
     keep = []
 
@@ -700,7 +700,17 @@ def project_search(case, th, proj_form, max_dist):
     P.scale_factors = arr(case["scale_factors"], np.float32)
     P.n_levels = len(case["scale_factors"])
     P.th, P.proj_form, P.max_dist = float(th), int(proj_form), int(max_dist)
+    if matched2 is not None:
+        m2 = np.ascontiguousarray(matched2, np.uint8)
+        match = np.zeros(P.n2, np.int32)
+        n = lib().orc_search_by_projection_sim3(C.byref(P), _p(m2), _p(match))
+        return match, n
     best = np.zeros(P.n1, np.int32)
     dist = np.zeros(P.n1, np.int32)
     lib().orc_project_search(C.byref(P), _p(best), _p(dist))
     return best, dist
+
+
+def search_by_projection_sim3(case, matched2, th, proj_form, max_dist):
+    """The greedy search of SearchByProjection(pKF, Scw, ...) on camera-frame points; returns (match2, nmatches)."""
+    return project_search(case, th, proj_form, max_dist, matched2=matched2)

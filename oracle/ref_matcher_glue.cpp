@@ -592,3 +592,45 @@ extern "C" int ref_fuse_sim3(const Sim3Side* cand, const uint8_t* in_kf1, const 
   }
   return nFused;
 }
+
+// ORBmatcher(0.75, true).SearchByProjection(pKF, Scw = identity, vpPoints, vpMatched, th, ratioHamming) (ORBmatcher.cc:427-532;
+// with_kfs = 0) or the overload with vpPointsKFs / vpMatchedKF (:534-646; with_kfs = 1).  cand: the candidate points (every
+// entry a point, mp_state 1 / 2); found1[i]: the point already sits in vpMatched on entry (at feature matched_slot);
+// matched2[i]: vpMatched[i] != NULL on entry.  match2[i2] = candidate stored in vpMatched[i2] by the call, or -1.
+extern "C" int ref_search_by_projection_sim3(const Sim3Side* cand, const uint8_t* found1, const Sim3Side* kfa, const uint8_t* matched2,
+                                             const float K[4], const float grid[6], const float* scale_factors, int n_levels,
+                                             float log_scale_factor, int th, float ratioHamming, int with_kfs, int* match2) {
+  GeometricCamera cam;
+  cam.fx = K[0]; cam.fy = K[1]; cam.cx = K[2]; cam.cy = K[3];
+  KeyFrame kf, other, marker;
+  std::vector<MapPoint> owned, pts;
+  Sim3Side bare = *kfa;
+  std::vector<uint8_t> none(kfa->n, 0);
+  bare.mp_state = none.data();
+  build_side(bare, K, grid, scale_factors, n_levels, log_scale_factor, &cam, kf, owned);
+  build_side(*cand, K, grid, scale_factors, n_levels, log_scale_factor, &cam, other, pts);
+  MapPoint before;
+  std::vector<MapPoint*> vp(cand->n), vpMatched(kfa->n, nullptr);
+  std::vector<KeyFrame*> vpKFs(cand->n, &other), vpMatchedKF(kfa->n, nullptr);
+  for (int i = 0; i < kfa->n; ++i)
+    if (matched2[i]) vpMatched[i] = &before;
+  int slot = 0;
+  for (int i = 0; i < cand->n; ++i) {
+    vp[i] = &pts[i];
+    if (found1[i]) {  // spAlreadyFound: put the point itself into an entry that is matched on entry
+      while (slot < kfa->n && !matched2[slot]) ++slot;
+      if (slot < kfa->n) vpMatched[slot++] = &pts[i];
+    }
+  }
+  Sophus::Sim3f Scw(1.f, Eigen::Quaternionf(1.f, 0.f, 0.f, 0.f), Eigen::Vector3f(0.f, 0.f, 0.f));
+  ORBmatcher matcher(0.75f, true);
+  std::vector<MapPoint*> entry = vpMatched;
+  const int nm = with_kfs ? matcher.SearchByProjection(&kf, Scw, vp, vpKFs, vpMatched, vpMatchedKF, th, ratioHamming)
+                          : matcher.SearchByProjection(&kf, Scw, vp, vpMatched, th, ratioHamming);
+  for (int i = 0; i < kfa->n; ++i) {
+    match2[i] = -1;
+    if (vpMatched[i] && vpMatched[i] != entry[i]) match2[i] = (int)(vpMatched[i] - pts.data());
+    if (with_kfs && match2[i] >= 0 && vpMatchedKF[i] != &other) match2[i] = -3;  // the key frame of the point must come along
+  }
+  return nm;
+}

@@ -166,6 +166,7 @@ SYMBOLS = {
     "rgbl_search_local_points": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_fuse_search": (_I, [_V, _V, _V, _V]),
     "rgbl_project_search": (_I, [_V, _V, _V, _V]),
+    "rgbl_search_by_projection_sim3": (_I, [_V, _V, _V, _V, C.POINTER(_I)]),
     "rgbl_distinctive_descriptors": (_I, [_V, _V, _V, _I, _V]),
     "rgbl_search_by_projection_keyframe": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_vocabulary_load_text": (_I, [C.c_char_p, _I, C.POINTER(_V)]),

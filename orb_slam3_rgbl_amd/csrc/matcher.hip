@@ -221,6 +221,8 @@ struct ProjDev {
   int forward, backward;
   int skip_behind;           // 1: points with 1/z < 0 are skipped (Frame-to-Frame overload, :1709-1712); the key-frame overload has no such test
   int max_dist;              // a candidate is viable up to this Hamming distance (TH_HIGH / ORBdist)
+  int sim3_mode;             // SearchByProjection(pKF, Scw, ...): wpos1 = camera-frame points, depth z < 0 skipped, KeyFrame::IsInImage,
+                             // octaves predicted - 1 ... predicted; 1: Pinhole::project, 2: invz = 1 / z, fx (x invz) + cx
   // the vpMapPoints overload (ORBmatcher.cc:43-213) instead of wpos1 / oct1 / q / t / K:
   const float* proj1;        // mTrackProjX, mTrackProjY, mTrackProjXR
   const int32_t* level1;     // mnTrackScaleLevel
@@ -331,16 +333,30 @@ __global__ __launch_bounds__(64) void k_proj_candidates(ProjDev P) {
   P.choice[i] = -1;
   if (P.valid1[i]) {
     float x, y, z;
-    quat_rotate(P.q, P.wpos1[3 * i], P.wpos1[3 * i + 1], P.wpos1[3 * i + 2], &x, &y, &z);
-    x += P.t[0]; y += P.t[1]; z += P.t[2];
+    if (P.sim3_mode) {
+      x = P.wpos1[3 * i]; y = P.wpos1[3 * i + 1]; z = P.wpos1[3 * i + 2];
+    } else {
+      quat_rotate(P.q, P.wpos1[3 * i], P.wpos1[3 * i + 1], P.wpos1[3 * i + 2], &x, &y, &z);
+      x += P.t[0]; y += P.t[1]; z += P.t[2];
+    }
     const float invzc = (float)(1.0 / (double)z);
-    const float u = __fdiv_rn(P.K[0] * x, z) + P.K[2], v = __fdiv_rn(P.K[1] * y, z) + P.K[3];
+    float u, v;
+    if (P.sim3_mode == 2) {
+      const float invz = __fdiv_rn(1.0f, z);
+      u = P.K[0] * (x * invz) + P.K[2]; v = P.K[1] * (y * invz) + P.K[3];
+    } else {
+      u = __fdiv_rn(P.K[0] * x, z) + P.K[2]; v = __fdiv_rn(P.K[1] * y, z) + P.K[3];
+    }
     // NaN / inf coordinates never produce candidates in the reference either (empty cell range)
-    if (!(P.skip_behind && invzc < 0) && u == u && v == v && !(u < P.grid[0] || u > P.grid[2]) && !(v < P.grid[1] || v > P.grid[3])) {
+    const bool in_view = P.sim3_mode ? (!(z < 0.0f) && u >= P.grid[0] && u < P.grid[2] && v >= P.grid[1] && v < P.grid[3])
+                                     : (!(P.skip_behind && invzc < 0) && u == u && v == v && !(u < P.grid[0] || u > P.grid[2]) &&
+                                        !(v < P.grid[1] || v > P.grid[3]));
+    if (in_view) {
       const int oct = P.oct1[i];
       const float radius = P.th * P.scale[oct];
       int min_level, max_level;
-      if (P.forward) { min_level = oct; max_level = -1; }
+      if (P.sim3_mode) { min_level = oct - 1; max_level = oct; }
+      else if (P.forward) { min_level = oct; max_level = -1; }
       else if (P.backward) { min_level = 0; max_level = oct; }
       else { min_level = oct - 1; max_level = oct + 1; }
       const int x0 = imax(0, (int)floorf((u - P.grid[0] - radius) * P.grid[4]));
@@ -1060,6 +1076,7 @@ struct ProjHost {
   const float *grid, *Tcw_q, *Tcw_t, *K;
   float mbf, th;
   int forward, backward, skip_behind, max_dist, check_orientation;
+  int sim3_mode;  // 0, or 1 / 2 = the projection form of the SearchByProjection(pKF, Scw, ...) overloads (wpos1 = camera-frame points)
 };
 
 int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* out_nmatches) {
@@ -1112,6 +1129,7 @@ int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* o
   for (int l = 0; l < kProjMaxLevels; ++l) P.scale[l] = l < in.n_levels ? in.scale_factors[l] : 1.f;
   P.forward = in.forward; P.backward = in.backward;
   P.skip_behind = in.skip_behind; P.max_dist = in.max_dist;
+  P.sim3_mode = in.sim3_mode;
   m->timer.begin("k_proj_grid", s);
   hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
   m->timer.end(s);
@@ -1300,6 +1318,32 @@ static int fuse_core(rgbl_matcher* m, const rgbl_fuse_input* in, int cam_frame, 
     if (dist <= max_dist) best_idx[i] = (int)(keys[i] & 0xffffu);
   }
   return RGBL_OK;
+}
+
+// int ORBmatcher::SearchByProjection(KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>&
+// vpMatched, int th, float ratioHamming) (src/ORBmatcher.cc:427-532) and its overload with vpPointsKFs / vpMatchedKF (:534-646):
+// the greedy best-only search again - a matched feature (vpMatched[idx] != NULL, on entry or set by an earlier point) is
+// skipped by the points after it - on camera-frame points.
+int rgbl_search_by_projection_sim3(rgbl_matcher* m, const rgbl_project_search_input* in, const uint8_t* matched2, int32_t* match2,
+                                   int* out_nmatches) {
+  if (!m || !in || !match2 || !out_nmatches || in->n1 < 0 || in->n2 < 0 || in->n2 > 65535 || in->n_levels < 1 ||
+      in->n_levels > kProjMaxLevels || (in->proj_form != 0 && in->proj_form != 2) || in->max_dist < 0 || in->max_dist > 255) {
+    set_error("invalid argument (at most 65535 features, %d pyramid levels, proj_form 0 / 2, max_dist 0..255)", kProjMaxLevels);
+    return RGBL_ERR_INVALID;
+  }
+  const float ident_q[4] = {0.f, 0.f, 0.f, 1.f}, zero_t[3] = {0.f, 0.f, 0.f};
+  ProjHost h{};
+  h.n1 = in->n1; h.n2 = in->n2; h.n_levels = in->n_levels;
+  h.valid1 = in->valid1; h.obs1 = nullptr; h.mpdesc1 = in->mp_desc1; h.desc2 = in->desc2; h.blocked2 = matched2;
+  h.wpos1 = in->cam_pos1; h.angle1 = nullptr; h.xy2 = in->kp2_xy; h.angle2 = nullptr; h.ur2 = nullptr;
+  h.scale_factors = in->scale_factors; h.oct1 = in->level1; h.oct2 = in->kp2_octave;
+  h.grid = in->grid; h.Tcw_q = ident_q; h.Tcw_t = zero_t; h.K = in->K;
+  h.mbf = 0.f; h.th = in->th;
+  h.forward = 0; h.backward = 0; h.skip_behind = 0;
+  h.max_dist = in->max_dist;
+  h.check_orientation = 0;
+  h.sim3_mode = in->proj_form == 0 ? 1 : 2;
+  return projection_core(m, h, match2, out_nmatches);
 }
 
 int rgbl_fuse_search(rgbl_matcher* m, const rgbl_fuse_input* in, int32_t* best_idx, int32_t* best_dist) {

@@ -469,6 +469,34 @@ class ORBmatcher:
         L.check(self.lib, self.lib.rgbl_project_search(self.h, C.byref(P), L.ptr(best), L.ptr(dist)))
         return best, dist
 
+    def SearchByProjectionSim3(self, case, matched2, th, proj_form, max_dist):
+        """The greedy search of ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming) (proj_form 0) and of
+        its vpPointsKFs overload (proj_form 2), max_dist = floor(TH_LOW * ratioHamming); case as for ProjectSearch, matched2 =
+        vpMatched[i] != NULL on entry.  Returns (point index stored in vpMatched[i2] by the call or -1, nmatches)."""
+        keep = []
+
+        def arr(v, dt):
+            a = np.ascontiguousarray(v, dt)
+            keep.append(a)
+            return a.ctypes.data
+        P = L.ProjectSearchInput()
+        P.n1 = len(case["valid1"])
+        P.valid1, P.cam_pos1 = arr(case["valid1"], np.uint8), arr(case["cam_pos1"], np.float32)
+        P.mp_desc1, P.level1 = arr(case["mp_desc1"], np.uint8), arr(case["level1"], np.int32)
+        P.n2 = len(case["kp2_xy"])
+        P.kp2_xy, P.kp2_octave, P.desc2 = arr(case["kp2_xy"], np.float32), arr(case["kp2_octave"], np.int32), arr(case["desc2"], np.uint8)
+        for name, n in (("grid", 6), ("K", 4)):
+            for i in range(n):
+                getattr(P, name)[i] = float(case[name][i])
+        P.scale_factors = arr(case["scale_factors"], np.float32)
+        P.n_levels = len(case["scale_factors"])
+        P.th, P.proj_form, P.max_dist = float(th), int(proj_form), int(max_dist)
+        m2 = np.ascontiguousarray(matched2, np.uint8)
+        match = np.zeros(P.n2, np.int32)
+        n = C.c_int(0)
+        L.check(self.lib, self.lib.rgbl_search_by_projection_sim3(self.h, C.byref(P), L.ptr(m2), L.ptr(match), C.byref(n)))
+        return match, n.value
+
     def SearchLocalPoints(self, pts, th):
         """ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) (ORBmatcher.cc:43-213), the call of
         Tracking::SearchLocalPoints.  pts: dict with the map point arrays valid1, proj1 [n,3] (mTrackProjX, mTrackProjY,

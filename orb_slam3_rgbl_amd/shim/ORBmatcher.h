@@ -15,6 +15,7 @@
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -454,6 +455,29 @@ class ORBmatcher {
     return nFused;
   }
 
+  // Project MapPoints using a Similarity Transformation and search matches.  Used in loop detection
+  // (LoopClosing::FindMatchesByProjection).  ORBmatcher.h:61 / :65, ORBmatcher.cc:427-532 / 534-646.
+  template <class KeyFrameT, class Sim3T, class MapPointT>
+  int SearchByProjection(KeyFrameT* pKF, Sim3T& Scw, const std::vector<MapPointT*>& vpPoints, std::vector<MapPointT*>& vpMatched,
+                         int th, float ratioHamming = 1.0) {
+    std::vector<int32_t> match2;
+    int nmatches = 0;
+    if (!SearchSim3Greedy(pKF, Scw, vpPoints, vpMatched, th, ratioHamming, 0, match2, nmatches)) return 0;
+    for (size_t i2 = 0; i2 < match2.size(); ++i2)
+      if (match2[i2] >= 0) vpMatched[i2] = vpPoints[match2[i2]];
+    return nmatches;
+  }
+  template <class KeyFrameT, class Sim3T, class MapPointT>
+  int SearchByProjection(KeyFrameT* pKF, Sim3T& Scw, const std::vector<MapPointT*>& vpPoints, const std::vector<KeyFrameT*>& vpPointsKFs,
+                         std::vector<MapPointT*>& vpMatched, std::vector<KeyFrameT*>& vpMatchedKF, int th, float ratioHamming = 1.0) {
+    std::vector<int32_t> match2;
+    int nmatches = 0;
+    if (!SearchSim3Greedy(pKF, Scw, vpPoints, vpMatched, th, ratioHamming, 2, match2, nmatches)) return 0;
+    for (size_t i2 = 0; i2 < match2.size(); ++i2)
+      if (match2[i2] >= 0) { vpMatched[i2] = vpPoints[match2[i2]]; vpMatchedKF[i2] = vpPointsKFs[match2[i2]]; }
+    return nmatches;
+  }
+
   // Search matches between MapPoints seen in KF1 and KF2 transforming by a Sim3 [s12*R12|t12] (LoopClosing).
   // ORBmatcher.h:79, ORBmatcher.cc:1457-1674: two directed searches on the device, the mutual-agreement pass here.
   template <class KeyFrameT, class MapPointT, class Sim3T>
@@ -626,6 +650,66 @@ class ORBmatcher {
     f.view.node_id = f.node_id.data();
     f.view.node_off = f.node_off.data();
     f.view.node_feat = f.node_feat.data();
+  }
+
+  // the part the two SearchByProjection(pKF, Scw, ...) overloads share: the reference's tests on the MapPoint objects, then the
+  // greedy search on the device (proj_form 0: Pinhole::project as in :465, 2: invz = 1 / p3Dc(2) as in :575-580)
+  template <class KeyFrameT, class Sim3T, class MapPointT>
+  bool SearchSim3Greedy(KeyFrameT* pKF, Sim3T& Scw, const std::vector<MapPointT*>& vpPoints, const std::vector<MapPointT*>& vpMatched,
+                        int th, float ratioHamming, int proj_form, std::vector<int32_t>& match2, int& nmatches) {
+    nmatches = 0;
+    if (!mpHandle) return false;
+    typedef decltype(pKF->GetPose()) SE3T;
+    const SE3T Tcw(Scw.rotationMatrix(), Scw.translation() / Scw.scale());
+    const auto Ow = Tcw.inverse().translation();
+    std::set<MapPointT*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+    spAlreadyFound.erase(static_cast<MapPointT*>(NULL));
+    const int n1 = (int)vpPoints.size(), n2 = pKF->N;
+    std::vector<uint8_t> valid(n1, 0), desc1((size_t)n1 * 32, 0), matched(n2, 0);
+    std::vector<float> pos((size_t)n1 * 3, 0.f), xy2((size_t)n2 * 2);
+    std::vector<int32_t> level1(n1, 0), oct2(n2);
+    for (int i = 0; i < n1; ++i) {
+      MapPointT* pMP = vpPoints[i];
+      if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+      const auto p3Dw = pMP->GetWorldPos();
+      const auto p3Dc = Tcw * p3Dw;
+      const auto PO = p3Dw - Ow;
+      const float dist = PO.norm();
+      if (dist < pMP->GetMinDistanceInvariance() || dist > pMP->GetMaxDistanceInvariance()) continue;
+      const auto Pn = pMP->GetNormal();
+      if (PO.dot(Pn) < 0.5 * dist) continue;
+      valid[i] = 1;
+      level1[i] = pMP->PredictScale(dist, pKF);
+      for (int k = 0; k < 3; ++k) pos[3 * (size_t)i + k] = p3Dc(k);
+      const cv::Mat dMP = pMP->GetDescriptor();
+      memcpy(&desc1[(size_t)i * 32], dMP.ptr<uint8_t>(), 32);
+    }
+    for (int i = 0; i < n2; ++i) {
+      xy2[2 * (size_t)i] = pKF->mvKeysUn[i].pt.x;
+      xy2[2 * (size_t)i + 1] = pKF->mvKeysUn[i].pt.y;
+      oct2[i] = pKF->mvKeysUn[i].octave;
+      matched[i] = vpMatched[i] ? 1 : 0;
+    }
+    rgbl_project_search_input in;
+    in.n1 = n1; in.valid1 = valid.data(); in.cam_pos1 = pos.data(); in.mp_desc1 = desc1.data(); in.level1 = level1.data();
+    in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.desc2 = pKF->mDescriptors.template ptr<uint8_t>();
+    in.grid[0] = pKF->mnMinX; in.grid[1] = pKF->mnMinY; in.grid[2] = pKF->mnMaxX; in.grid[3] = pKF->mnMaxY;
+    in.grid[4] = pKF->mfGridElementWidthInv; in.grid[5] = pKF->mfGridElementHeightInv;
+    in.K[0] = pKF->fx; in.K[1] = pKF->fy; in.K[2] = pKF->cx; in.K[3] = pKF->cy;
+    in.scale_factors = pKF->mvScaleFactors.data();
+    in.n_levels = (int)pKF->mvScaleFactors.size();
+    in.th = (float)th;  // radius = th * scale: int times float in the reference
+    in.proj_form = proj_form;
+    const float limit = 50 /* TH_LOW */ * ratioHamming;  // bestDist <= TH_LOW * ratioHamming, an int against a float
+    in.max_dist = limit >= 255.f ? 255 : (limit < 0.f ? -1 : (int)floorf(limit));
+    match2.assign(n2, -1);
+    if (in.max_dist < 0) return true;
+    if (rgbl_search_by_projection_sim3(mpHandle, &in, matched.data(), match2.data(), &nmatches) != RGBL_OK) {
+      std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
+      nmatches = 0;
+      return false;
+    }
+    return true;
   }
 
   // camera-frame points against the features of pKF (rgbl_project_search); false on a device error

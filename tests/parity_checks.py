@@ -1089,3 +1089,18 @@ def check_search_by_sim3(lib, seed=121, th=7.5, n=1500):
     assert ng == nw and np.array_equal(got, want), "SearchBySim3 (seed %d)" % seed
     mt.close()
     return nw
+
+
+def check_search_by_projection_sim3(lib, seed=151, th=8, proj_form=0, ratio=1.5, n1=2500, n2=2000):
+    case = make_project_search_case(n1, n2, seed)
+    rng = np.random.default_rng(seed)
+    matched2 = (rng.random(n2) < 0.12).astype(np.uint8)
+    max_dist = int(np.floor(np.float32(50) * np.float32(ratio)))
+    mt = F.ORBmatcher(0.75, True, lib=lib)
+    m, n = mt.SearchByProjectionSim3(case, matched2, th, proj_form, max_dist)
+    om, on = O.search_by_projection_sim3(case, matched2, th, proj_form, max_dist)
+    assert n == on and np.array_equal(m, om), "SearchByProjection(KF, Sim3) (seed %d, form %d)" % (seed, proj_form)
+    free, _ = O.search_by_projection_sim3(case, np.zeros(n2, np.uint8), th, proj_form, max_dist)
+    assert not np.array_equal(free, om)
+    mt.close()
+    return on

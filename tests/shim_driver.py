@@ -175,6 +175,10 @@ def run_and_check(exe, tmp):
     sim_match = take(np.int32, n1s)
     nfs, nqs = take(np.int32, 2)
     fused_sim = take(np.int32, nqs)
+    greedy = []
+    for _ in range(2):
+        nms = take(np.int32, 1)[0]
+        greedy.append((nms, take(np.int32, n1s).copy()))
     assert pos == len(buf)
     osm, osn = pc.search_by_sim3(scase, 7.5, O.project_search)
     assert nsim == osn and np.array_equal(sim_match, osm) and nsim > 200
@@ -188,6 +192,15 @@ def run_and_check(exe, tmp):
                                      kp2_xy=a2["kp_xy"], kp2_octave=a2["kp_octave"], desc2=a2["desc"], grid=scase["grid"], K=scase["K"],
                                      scale_factors=scase["scale_factors"]), 4.0, 0, 50)
     assert nfs == int((fbest >= 0).sum()) and np.array_equal(fused_sim, fbest[fbest >= 0]) and nfs > 200
+    matched2 = np.zeros(len(a2["kp_xy"]), np.uint8)
+    matched2[::9] = 1
+    gcase = dict(valid1=fvalid.astype(np.uint8), cam_pos1=a1["mp_pos"][sel], mp_desc1=a1["mp_desc"][sel], level1=flevel,
+                 kp2_xy=a2["kp_xy"], kp2_octave=a2["kp_octave"], desc2=a2["desc"], grid=scase["grid"], K=scase["K"],
+                 scale_factors=scase["scale_factors"])
+    for (nms, gm), (th_g, ratio_g, form_g) in zip(greedy, ((8, 1.5, 0), (30, 1.0, 2))):
+        ogm, ogn = O.search_by_projection_sim3(gcase, matched2, float(th_g), form_g, int(np.floor(np.float32(50) * np.float32(ratio_g))))
+        want = np.where(ogm >= 0, sel[np.maximum(ogm, 0)], -1)        # candidate index -> feature index of KF1 (the shim test's pointer base)
+        assert nms == ogn and np.array_equal(gm, want) and nms > 150
     rows = [kf1["desc"][i * 3 % len(kf1["desc"])] for i in range(25)]
     assert best_desc == O.distinctive_descriptors([np.stack(rows)])[0]
     ofb, onf = O.fuse_search(fcase, 3.0)

@@ -647,6 +647,25 @@ int main(int argc, char** argv) {
     const int nFusedS = loop2.Fuse(&kf[1], Scw, vpPoints, th_fuse, vpReplace);
     const int nq = (int)kf[1].queried.size();
     wr(out, &nFusedS, 1); wr(out, &nq, 1); wr(out, kf[1].queried.data(), nq);
+    // --- as LoopClosing::FindMatchesByProjection: SearchByProjection(pKF, Scw, vpPoints, [vpPointsKFs,] vpMatched, [vpMatchedKF,] th, ratio)
+    for (int form = 0; form < 2; ++form) {
+      SimKF fresh = kf[1];                       // Fuse above added points to kf[1]: start from the features alone
+      fresh.mps.assign(n, nullptr);
+      std::vector<SimPoint*> vpMatched(n, nullptr);
+      std::vector<SimKF*> vpPointsKFs(vpPoints.size(), &kf[0]), vpMatchedKF(n, nullptr);
+      for (int i = 0; i < n; i += 9) vpMatched[i] = &pts[1][i];   // matched before the call
+      TestSim3 Sid;
+      const int nms = form == 0 ? loop2.SearchByProjection(&fresh, Sid, vpPoints, vpMatched, 8, 1.5f)
+                                : loop2.SearchByProjection(&fresh, Sid, vpPoints, vpPointsKFs, vpMatched, vpMatchedKF, 30, 1.0f);
+      wr(out, &nms, 1);
+      for (int i = 0; i < n; ++i) {
+        SimPoint* p = vpMatched[i];
+        int idx = -1;
+        if (p && !(i % 9 == 0 && p == &pts[1][i])) idx = (int)(p - pts[0].data());
+        if (form == 1 && idx >= 0 && vpMatchedKF[i] != &kf[0]) idx = -3;
+        wr(out, &idx, 1);
+      }
+    }
   }
   fclose(out);
   printf("shim_test ok: %d keypoints, %d depths, %d triangulation matches\n", nk, nd, nm);

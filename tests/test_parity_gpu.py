@@ -197,3 +197,8 @@ def test_project_search(gpu_lib, seed, th, form, maxd):
 @pytest.mark.parametrize("seed,th", [(121, 7.5), (123, 3.0)])
 def test_search_by_sim3(gpu_lib, seed, th):
     assert pc.check_search_by_sim3(gpu_lib, seed, th) > 150
+
+
+@pytest.mark.parametrize("seed,th,form,ratio", [(151, 8, 0, 1.5), (152, 30, 2, 1.0), (153, 3, 0, 2.5)])
+def test_search_by_projection_sim3(gpu_lib, seed, th, form, ratio):
+    assert pc.check_search_by_projection_sim3(gpu_lib, seed, th, form, ratio) > 80

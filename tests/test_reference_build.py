@@ -561,3 +561,36 @@ def test_reference_fuse_sim3_agrees_with_oracle(refmatcher, seed, th):
     for i in np.nonzero(in_kf)[0]:                             # the glue parks the candidates the key frame "already has" in its last slots
         holds_bad[n2 - 1 - (i % n2)] = cand["mp_state"][i] == 2
     assert np.all(holds_bad[obest[silent]])
+
+
+@pytest.mark.parametrize("seed,th,ratio,with_kfs", [(161, 8, 1.5, 0), (162, 30, 1.0, 1), (163, 3, 2.5, 1), (164, 8, 1.0, 0)])
+def test_reference_search_by_projection_sim3_agrees_with_oracle(refmatcher, seed, th, ratio, with_kfs):
+    """The real ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, [vpPointsKFs,] vpMatched, [vpMatchedKF,] th, ratioHamming)
+    (LoopClosing::FindMatchesByProjection: th 3 / 8 / 30, ratio 1 / 1.5 / 2.5) with an identity Scw."""
+    import parity_checks as pc
+    case = pc.make_sim3_case(seed=seed)
+    rng = np.random.default_rng(seed)
+    cand = dict(case["a1"])
+    cand["mp_state"] = np.where(cand["mp_state"] == 0, 1, cand["mp_state"]).astype(np.uint8)
+    n1, n2 = len(cand["kp_xy"]), len(case["a2"]["kp_xy"])
+    matched2 = (rng.random(n2) < 0.12).astype(np.uint8)
+    found = np.zeros(n1, np.uint8)
+    found[rng.permutation(n1)[: int(matched2.sum()) // 2]] = 1          # half of the entry matches are candidates of this call
+    keep = []
+    c, kfa = sim3_side(cand, keep), sim3_side(case["a2"], keep)
+    K, grid, sf = (np.ascontiguousarray(case[k], np.float32) for k in ("K", "grid", "scale_factors"))
+    m = np.zeros(n2, np.int32)
+    refmatcher.ref_search_by_projection_sim3.restype = C.c_int
+    refmatcher.ref_search_by_projection_sim3.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    nm = refmatcher.ref_search_by_projection_sim3(C.byref(c), found.ctypes.data, C.byref(kfa), matched2.ctypes.data, K.ctypes.data,
+                                                  grid.ctypes.data, sf.ctypes.data, len(sf), C.c_float(float(case["log_scale_factor"])),
+                                                  int(th), C.c_float(ratio), int(with_kfs), m.ctypes.data)
+    valid, level = pc.camera_prepass(cand["mp_pos"], cand["mp_min_dist"], cand["mp_max_dist"], case["log_scale_factor"], len(sf),
+                                     normal=cand["mp_normal"])
+    valid &= (cand["mp_state"] == 1) & (found == 0)
+    search = dict(valid1=valid.astype(np.uint8), cam_pos1=cand["mp_pos"], mp_desc1=cand["mp_desc"], level1=level,
+                  kp2_xy=case["a2"]["kp_xy"], kp2_octave=case["a2"]["kp_octave"], desc2=case["a2"]["desc"], grid=grid, K=K, scale_factors=sf)
+    max_dist = int(np.floor(np.float32(50) * np.float32(ratio)))
+    om, onm = O.search_by_projection_sim3(search, matched2, float(th), 2 if with_kfs else 0, max_dist)
+    assert nm == onm and np.array_equal(m, om)
+    assert nm > 300 and not np.any((m >= 0) & (matched2 != 0))
