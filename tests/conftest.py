@@ -1,3 +1,4 @@
+import fcntl
 import os
 import subprocess
 import sys
@@ -27,7 +28,10 @@ def oracle():
 def emu_lib(oracle):
     """The kernel sources compiled against the CPU SIMT emulator (test infrastructure, see tests/emu)."""
     from orb_slam3_rgbl_amd import _lib
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "orb_slam3_rgbl_amd", "csrc"), "emu"])
+    os.makedirs(os.path.join(TESTS, "_build"), exist_ok=True)
+    with open(os.path.join(TESTS, "_build", ".lock"), "w") as lock:  # pytest-xdist workers build it once, not at once
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "orb_slam3_rgbl_amd", "csrc"), "emu"])
     return _lib.bind(os.path.join(TESTS, "_build", "librgbl_frontend_emu.so"))
 
 
