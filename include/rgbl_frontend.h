@@ -513,6 +513,32 @@ typedef struct {
  * (entry left as it was).  *out_nmatches = return value of the reference function. */
 int rgbl_search_local_points(rgbl_matcher* h, const rgbl_local_points_input* in, int32_t* match2, int* out_nmatches);
 
+/* ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12,
+ * int windowSize)    /root/reference/include/ORBmatcher.h:72, src/ORBmatcher.cc:648-763 (Tracking::MonocularInitialization,
+ * src/Tracking.cc:2526; not on the RGB-L / stereo path - built so that every search routine of ORBmatcher has a device form).
+ * Level-0 features of F1 look for their best / second-best F2 feature of level 0 inside a window around vbPrevMatched; a
+ * feature takes a candidate over from an earlier one when it is strictly closer (vMatchedDistance), rotation histogram. */
+typedef struct {
+  int n1;                     /* F1.mvKeysUn.size() */
+  const int32_t* kp1_octave;  /* F1.mvKeysUn[i].octave (>= 0) */
+  const float* kp1_angle;     /* F1.mvKeysUn[i].angle */
+  const uint8_t* desc1;       /* F1.mDescriptors */
+  int n2;                     /* F2.mvKeysUn.size() (<= 65535) */
+  const float* kp2_xy;        /* F2.mvKeysUn[i].pt */
+  const int32_t* kp2_octave;
+  const float* kp2_angle;
+  const uint8_t* desc2;       /* F2.mDescriptors */
+  float grid[6];              /* Frame::mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv */
+  int window_size;
+  float nnratio;              /* mfNNratio */
+  int check_orientation;      /* mbCheckOrientation */
+} rgbl_initialization_input;
+/* Host pointers, synchronous.  prev_matched (2 floats per F1 feature) = vbPrevMatched, read as the window centres and
+ * updated for the matched features like the reference does; matches12 (n1 entries) = vnMatches12; *out_nmatches = the
+ * return value. */
+int rgbl_search_for_initialization(rgbl_matcher* h, const rgbl_initialization_input* in, float* prev_matched, int32_t* matches12,
+                                   int* out_nmatches);
+
 /* ------------------------------------------------------------------------------------------------
  * ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>)    SURVEY.md 8(f) row f4
  *   replaces the per-feature descent of Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:828-835,

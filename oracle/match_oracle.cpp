@@ -865,3 +865,82 @@ extern "C" int orc_search_by_bow(const orc_tri_input* in, float nnratio, int che
   }
   return nmatches;
 }
+
+// ---- ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), ORBmatcher.cc:648-763 ----
+// with Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) (src/Frame.cc:747-813) over AssignFeaturesToGrid's cells
+extern "C" int orc_search_for_initialization(const orc_initialization_input* in, float* prev_matched, int* matches12) {
+  const int COLS = 64, ROWS = 48;
+  const float mnMinX = in->grid[0], mnMinY = in->grid[1], invW = in->grid[4], invH = in->grid[5];
+  std::vector<std::vector<int>> cells((size_t)COLS * ROWS);
+  for (int i = 0; i < in->n2; ++i) {
+    const int px = (int)roundf((in->kp2_xy[2 * i] - mnMinX) * invW), py = (int)roundf((in->kp2_xy[2 * i + 1] - mnMinY) * invH);
+    if (px < 0 || px >= COLS || py < 0 || py >= ROWS) continue;
+    cells[(size_t)px * ROWS + py].push_back(i);
+  }
+  int nmatches = 0;
+  for (int i = 0; i < in->n1; ++i) matches12[i] = -1;
+  std::vector<int> rot_hist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  std::vector<int> vMatchedDistance(in->n2, INT_MAX), vnMatches21(in->n2, -1);
+  for (int i1 = 0; i1 < in->n1; ++i1) {
+    const int level1 = in->kp1_octave[i1];
+    if (level1 > 0) continue;
+    const float x = prev_matched[2 * i1], y = prev_matched[2 * i1 + 1], r = (float)in->window_size;
+    const int minLevel = level1, maxLevel = level1;
+    if (!(x == x) || !(y == y)) continue;
+    const int nMinCellX = std::max(0, (int)floorf((x - mnMinX - r) * invW));
+    if (nMinCellX >= COLS) continue;
+    const int nMaxCellX = std::min(COLS - 1, (int)ceilf((x - mnMinX + r) * invW));
+    if (nMaxCellX < 0) continue;
+    const int nMinCellY = std::max(0, (int)floorf((y - mnMinY - r) * invH));
+    if (nMinCellY >= ROWS) continue;
+    const int nMaxCellY = std::min(ROWS - 1, (int)ceilf((y - mnMinY + r) * invH));
+    if (nMaxCellY < 0) continue;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    const uint8_t* d1 = in->desc1 + 32 * (size_t)i1;
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+      for (int iy = nMinCellY; iy <= nMaxCellY; ++iy)
+        for (int i2 : cells[(size_t)ix * ROWS + iy]) {
+          if (bCheckLevels) {
+            if (in->kp2_octave[i2] < minLevel) continue;
+            if (maxLevel >= 0 && in->kp2_octave[i2] > maxLevel) continue;
+          }
+          const float distx = in->kp2_xy[2 * i2] - x, disty = in->kp2_xy[2 * i2 + 1] - y;
+          if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+          const int dist = hamming256(d1, in->desc2 + 32 * (size_t)i2);
+          if (vMatchedDistance[i2] <= dist) continue;
+          if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+    if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * in->nnratio) {
+      if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; --nmatches; }
+      matches12[i1] = bestIdx2;
+      vnMatches21[bestIdx2] = i1;
+      vMatchedDistance[bestIdx2] = bestDist;
+      ++nmatches;
+      if (in->check_orientation) {
+        float rot = in->kp1_angle[i1] - in->kp2_angle[bestIdx2];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rot_hist[bin].push_back(i1);
+      }
+    }
+  }
+  if (in->check_orientation) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    three_maxima(rot_hist, HISTO_LENGTH, i1, i2, i3);
+    for (int i = 0; i < HISTO_LENGTH; ++i) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int idx1 : rot_hist[i])
+        if (matches12[idx1] >= 0) { matches12[idx1] = -1; --nmatches; }
+    }
+  }
+  for (int i1 = 0; i1 < in->n1; ++i1)
+    if (matches12[i1] >= 0) {
+      prev_matched[2 * i1] = in->kp2_xy[2 * matches12[i1]];
+      prev_matched[2 * i1 + 1] = in->kp2_xy[2 * matches12[i1] + 1];
+    }
+  return nmatches;
+}

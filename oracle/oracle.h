@@ -331,6 +331,25 @@ typedef struct {
 } orc_local_points_input;
 /* match2[i2] = index of the map point the call assigns to F.mvpMapPoints[i2], or -1 (left as it was). Returns nmatches. */
 int orc_search_local_points(const orc_local_points_input* in, int* match2);
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
+ * (/root/reference/src/ORBmatcher.cc:648-763) with Frame::GetFeaturesInArea (src/Frame.cc:747-813). */
+typedef struct {
+  int n1;
+  const int32_t* kp1_octave;
+  const float* kp1_angle;
+  const uint8_t* desc1;
+  int n2;
+  const float* kp2_xy;
+  const int32_t* kp2_octave;
+  const float* kp2_angle;
+  const uint8_t* desc2;
+  float grid[6];
+  int window_size;
+  float nnratio;
+  int check_orientation;
+} orc_initialization_input;
+/* prev_matched: in / out (2 floats per F1 feature); matches12: n1 entries. Returns nmatches. */
+int orc_search_for_initialization(const orc_initialization_input* in, float* prev_matched, int* matches12);
 /* F12 = K1^-T [t]x R12 K2^-1 with Eigen's evaluation order in fp32 */
 void orc_fundamental(const float K1[4], const float K2[4], const float R12[9], const float t12[3],
                      float F12[9]);

@@ -217,6 +217,41 @@ def search_local_points(case, th=1.0, nnratio=0.8):
     return m, n
 
 
+class InitializationInput(C.Structure):
+    """orc_initialization_input == rgbl_initialization_input (same layout)."""
+    _fields_ = [("n1", C.c_int), ("kp1_octave", C.c_void_p), ("kp1_angle", C.c_void_p), ("desc1", C.c_void_p),
+                ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p), ("kp2_angle", C.c_void_p),
+                ("desc2", C.c_void_p), ("grid", C.c_float * 6), ("window_size", C.c_int), ("nnratio", C.c_float),
+                ("check_orientation", C.c_int)]
+
+
+def make_initialization_input(case, window, nnratio, check_orientation, keep, cls=InitializationInput):
+    def arr(v, dt):
+        a = np.ascontiguousarray(v, dt)
+        keep.append(a)
+        return a.ctypes.data
+    P = cls()
+    P.n1 = len(case["kp1_octave"])
+    P.kp1_octave, P.kp1_angle, P.desc1 = arr(case["kp1_octave"], np.int32), arr(case["kp1_angle"], np.float32), arr(case["desc1"], np.uint8)
+    P.n2 = len(case["kp2_xy"])
+    P.kp2_xy, P.kp2_octave = arr(case["kp2_xy"], np.float32), arr(case["kp2_octave"], np.int32)
+    P.kp2_angle, P.desc2 = arr(case["kp2_angle"], np.float32), arr(case["desc2"], np.uint8)
+    for i in range(6):
+        P.grid[i] = float(case["grid"][i])
+    P.window_size, P.nnratio, P.check_orientation = int(window), float(nnratio), int(check_orientation)
+    return P
+
+
+def search_for_initialization(case, window=100, nnratio=0.9, check_orientation=True):
+    """Returns (vnMatches12, updated vbPrevMatched, nmatches)."""
+    keep = []
+    P = make_initialization_input(case, window, nnratio, check_orientation, keep)
+    prev = np.ascontiguousarray(case["prev_matched"], np.float32).copy()
+    m = np.zeros(P.n1, np.int32)
+    n = lib().orc_search_for_initialization(C.byref(P), _p(prev), _p(m))
+    return m, prev, n
+
+
 class Vocabulary(C.Structure):
     _fields_ = [("n_nodes", C.c_int), ("L", C.c_int), ("child_off", C.c_void_p), ("child", C.c_void_p), ("desc", C.c_void_p),
                 ("weight", C.c_void_p), ("word_id", C.c_void_p)]
@@ -311,6 +346,8 @@ def lib():
         L.orc_bow_descend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_search_by_bow.restype = C.c_int
         L.orc_search_by_bow.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+        L.orc_search_for_initialization.restype = C.c_int
+        L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_search_local_points.restype = C.c_int
         L.orc_search_local_points.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_search_by_projection.restype = C.c_int

@@ -634,3 +634,32 @@ extern "C" int ref_search_by_projection_sim3(const Sim3Side* cand, const uint8_t
   }
   return nm;
 }
+
+// ORBmatcher(nnratio, checkOri).SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:648-763)
+extern "C" int ref_search_for_initialization(const orc_initialization_input* in, float* prev_matched, int* matches12) {
+  Frame F1, F2;
+  F1.N = in->n1;
+  F1.mvKeysUn.resize(in->n1);
+  for (int i = 0; i < in->n1; ++i) { F1.mvKeysUn[i].octave = in->kp1_octave[i]; F1.mvKeysUn[i].angle = in->kp1_angle[i]; }
+  F1.mDescriptors = cv::Mat(in->n1, 32, CV_8U);
+  if (in->n1) memcpy(F1.mDescriptors.data, in->desc1, (size_t)in->n1 * 32);
+  F2.N = in->n2;
+  F2.mvKeysUn.resize(in->n2);
+  for (int i = 0; i < in->n2; ++i) {
+    F2.mvKeysUn[i].pt.x = in->kp2_xy[2 * i]; F2.mvKeysUn[i].pt.y = in->kp2_xy[2 * i + 1];
+    F2.mvKeysUn[i].octave = in->kp2_octave[i]; F2.mvKeysUn[i].angle = in->kp2_angle[i];
+  }
+  F2.mDescriptors = cv::Mat(in->n2, 32, CV_8U);
+  if (in->n2) memcpy(F2.mDescriptors.data, in->desc2, (size_t)in->n2 * 32);
+  Frame::mnMinX = F2.grid.mnMinX = in->grid[0]; Frame::mnMinY = F2.grid.mnMinY = in->grid[1];
+  Frame::mnMaxX = F2.grid.mnMaxX = in->grid[2]; Frame::mnMaxY = F2.grid.mnMaxY = in->grid[3];
+  F2.grid.mfGridElementWidthInv = in->grid[4]; F2.grid.mfGridElementHeightInv = in->grid[5];
+  F2.grid.Build(F2.mvKeysUn);
+  std::vector<cv::Point2f> prev(in->n1);
+  for (int i = 0; i < in->n1; ++i) { prev[i].x = prev_matched[2 * i]; prev[i].y = prev_matched[2 * i + 1]; }
+  std::vector<int> m12;
+  ORBmatcher matcher(in->nnratio, in->check_orientation != 0);
+  const int nm = matcher.SearchForInitialization(F1, F2, prev, m12, in->window_size);
+  for (int i = 0; i < in->n1; ++i) { matches12[i] = m12[i]; prev_matched[2 * i] = prev[i].x; prev_matched[2 * i + 1] = prev[i].y; }
+  return nm;
+}

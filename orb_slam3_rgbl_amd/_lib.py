@@ -99,6 +99,14 @@ class LocalPointsInput(C.Structure):
                 ("n_levels", C.c_int), ("th", C.c_float), ("nnratio", C.c_float)]
 
 
+class InitializationInput(C.Structure):
+    """rgbl_initialization_input (ORBmatcher::SearchForInitialization as flat arrays)."""
+    _fields_ = [("n1", C.c_int), ("kp1_octave", C.c_void_p), ("kp1_angle", C.c_void_p), ("desc1", C.c_void_p),
+                ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p), ("kp2_angle", C.c_void_p),
+                ("desc2", C.c_void_p), ("grid", C.c_float * 6), ("window_size", C.c_int), ("nnratio", C.c_float),
+                ("check_orientation", C.c_int)]
+
+
 # name -> (restype, argtypes); every symbol of include/rgbl_frontend.h
 _V, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SYMBOLS = {
@@ -164,6 +172,7 @@ SYMBOLS = {
     "rgbl_search_by_bow_keyframes": (_I, [_V, _V, _V, _F, _I, _V, C.POINTER(_I)]),
     "rgbl_search_by_projection": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_search_local_points": (_I, [_V, _V, _V, C.POINTER(_I)]),
+    "rgbl_search_for_initialization": (_I, [_V, _V, _V, _V, C.POINTER(_I)]),
     "rgbl_fuse_search": (_I, [_V, _V, _V, _V]),
     "rgbl_project_search": (_I, [_V, _V, _V, _V]),
     "rgbl_search_by_projection_sim3": (_I, [_V, _V, _V, _V, C.POINTER(_I)]),

@@ -234,6 +234,7 @@ struct ProjDev {
   uint16_t* cell_items;      // n2 feature indices grouped by grid cell
   int32_t* taken_by;         // n2: index of the blocker holding the feature (INT_MAX = free)
   int32_t* min_unres;        // n2
+  int32_t* owner;            // n2: SearchForInitialization's vnMatches21
   float4* win;               // n1: u, v, radius, ur (= u - mbf * invzc)
   int4* rng;                 // n1: cell x range, cell y range (lo | hi << 8), minLevel, maxLevel
   unsigned long long* cand;  // n1 * kProjCand keys
@@ -645,6 +646,114 @@ __global__ __launch_bounds__(kProjBS) void k_local_resolve(ProjDev P) {
       P.state[i] = 1;
       const int c = P.choice[i];
       if (c >= 0 && P.obs1[i]) P.taken_by[c] = i;
+    }
+    __syncthreads();
+    if (s_unres == 0) break;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
+// (/root/reference/src/ORBmatcher.cc:648-763; Tracking::MonocularInitialization, Tracking.cc:2526) with
+// Frame::GetFeaturesInArea(x, y, windowSize, 0, 0) (src/Frame.cc:747-813).  The loop is sequential through
+// vMatchedDistance: a level-0 feature of F1 skips every F2 candidate that an earlier feature already holds at a distance
+// <= its own, and takes a candidate over from its holder otherwise.  vMatchedDistance only ever decreases, and only the
+// candidates below `max_dist + 1` = the smallest d > TH_LOW with (float)d * mfNNratio > TH_LOW can change a decision (a larger
+// second-best passes the ratio test like INT_MAX does, a larger best fails TH_LOW), so: the candidates of that range are
+// kept in traversal order (ProjDev: proj1 = vbPrevMatched (2 floats), mpdesc1 = F1 descriptors, oct1 = F1 octaves,
+// taken_by = vMatchedDistance, owner = vnMatches21), and a feature is final once no unresolved lower-index feature shares
+// one of its still-available candidates - two features that share one resolve in index order, exactly the order of the loop.
+template <class F>
+__device__ __forceinline__ void init_available(const ProjDev& P, int i, F&& f) {  // f(dist, c) in traversal order
+  const int n = P.ncand[i];
+  if (!(n & kProjOverflow)) {
+    for (int k = 0; k < n; ++k) {
+      const unsigned long long key = P.cand[(size_t)i * kProjCand + k];
+      const int c = (int)(key & 0xffffu), dist = (int)(key >> 32);
+      if (P.taken_by[c] > dist) f(dist, c);  // vMatchedDistance[i2] <= dist: continue (:689-690)
+    }
+    return;
+  }
+  const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
+  const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+  for_candidates(P, P.win[i], P.rng[i], [&](int c, int) {
+    const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
+    if (dist <= P.max_dist && P.taken_by[c] > dist) f(dist, c);
+  });
+}
+
+// grid = ceil(n1 / 64), block = 64
+__global__ __launch_bounds__(64) void k_init_candidates(ProjDev P) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= P.n1) return;
+  uint8_t st = 1;
+  int n = 0;
+  P.choice[i] = -1;
+  const float x = P.proj1[2 * i], y = P.proj1[2 * i + 1];
+  if (P.oct1[i] == 0 && x == x && y == y) {  // level1 > 0: continue (:664-666)
+    const float radius = P.th;
+    const int x0 = imax(0, (int)floorf((x - P.grid[0] - radius) * P.grid[4]));
+    const int x1 = imin(kGridCols - 1, (int)ceilf((x - P.grid[0] + radius) * P.grid[4]));
+    const int y0 = imax(0, (int)floorf((y - P.grid[1] - radius) * P.grid[5]));
+    const int y1 = imin(kGridRows - 1, (int)ceilf((y - P.grid[1] + radius) * P.grid[5]));
+    if (x0 < kGridCols && x1 >= 0 && y0 < kGridRows && y1 >= 0) {
+      const float4 w = make_float4(x, y, radius, 0.f);
+      const int4 rg = make_int4(x0 | (x1 << 8), y0 | (y1 << 8), 0, 0);  // minLevel = maxLevel = level1 = 0
+      P.win[i] = w;
+      P.rng[i] = rg;
+      const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
+      const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+      int total = 0;
+      for_candidates(P, w, rg, [&](int c, int) {
+        const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
+        if (dist > P.max_dist) return;
+        if (total < kProjCand) P.cand[(size_t)i * kProjCand + total] = ((unsigned long long)dist << 32) | (unsigned)c;
+        ++total;
+      });
+      n = total <= kProjCand ? total : (kProjCand | kProjOverflow);
+      st = total > 0 ? 0 : 1;
+    }
+  }
+  P.ncand[i] = (uint8_t)n;
+  P.state[i] = st;
+}
+
+// grid = 1, block = kProjBS
+__global__ __launch_bounds__(kProjBS) void k_init_resolve(ProjDev P) {
+  __shared__ int s_unres;
+  const int tid = threadIdx.x;
+  for (int c = tid; c < P.n2; c += kProjBS) P.owner[c] = -1;
+  for (int round = 0; round <= P.n1; ++round) {
+    for (int c = tid; c < P.n2; c += kProjBS) P.min_unres[c] = INT_MAX;
+    if (tid == 0) s_unres = 0;
+    __syncthreads();
+    for (int i = tid; i < P.n1; i += kProjBS) {
+      if (P.state[i] != 0) continue;
+      init_available(P, i, [&](int, int c) { atomicMin(&P.min_unres[c], i); });
+    }
+    __syncthreads();
+    for (int i = tid; i < P.n1; i += kProjBS) {
+      if (P.state[i] != 0) continue;
+      int best = INT_MAX, best2 = INT_MAX, best_idx = -1;
+      bool settled = true;
+      init_available(P, i, [&](int dist, int c) {
+        if (dist < best) { best2 = best; best = dist; best_idx = c; }  // :692-701
+        else if (dist < best2) best2 = dist;
+        if (P.min_unres[c] < i) settled = false;
+      });
+      if (!settled) { atomicAdd(&s_unres, 1); continue; }
+      const bool ok = best <= 50 /* TH_LOW */ && (float)best < (float)best2 * P.nnratio;  // :704-706
+      P.state[i] = 2;
+      P.choice[i] = ok ? best_idx : -1;
+      P.win[i].w = __int_as_float(best);
+    }
+    __syncthreads();
+    for (int i = tid; i < P.n1; i += kProjBS) {
+      if (P.state[i] != 2) continue;
+      P.state[i] = 1;
+      const int c = P.choice[i];
+      if (c >= 0) { P.taken_by[c] = __float_as_int(P.win[i].w); P.owner[c] = i; }  // vMatchedDistance, vnMatches21 (:713-715)
     }
     __syncthreads();
     if (s_unres == 0) break;
@@ -1437,6 +1546,103 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
   int nmatches = 0;
   for (int i = 0; i < n1; ++i)
     if (choice[i] >= 0) { match2[choice[i]] = i; ++nmatches; }  // a later point overwrites an unobserved earlier one
+  *out_nmatches = nmatches;
+  return RGBL_OK;
+}
+
+int rgbl_search_for_initialization(rgbl_matcher* m, const rgbl_initialization_input* in, float* prev_matched, int32_t* matches12,
+                                   int* out_nmatches) {
+  if (!m || !in || !out_nmatches || in->n1 < 0 || in->n2 < 0 || in->n2 > 65535 || (in->n1 > 0 && (!prev_matched || !matches12))) {
+    set_error("invalid argument (the second frame may hold at most 65535 features)");
+    return RGBL_ERR_INVALID;
+  }
+  *out_nmatches = 0;
+  const int n1 = in->n1, n2 = in->n2;
+  for (int i = 0; i < n1; ++i) matches12[i] = -1;
+  if (n1 == 0 || n2 == 0) return RGBL_OK;
+  for (int i = 0; i < n1; ++i)
+    if (in->kp1_octave[i] < 0) { set_error("negative octave"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(m->device));
+  size_t need = pad256((size_t)n1 * 8) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 8) + pad256((size_t)n2 * 4) +
+                pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 3 + pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 +
+                pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) + pad256((size_t)(kGridCells + 1) * 4);
+  RGBL_TRY(ensure_arena(m, need));
+  Arena A{m->d_buf};
+  hipStream_t s = m->stream;
+  ProjDev P;
+  memset(&P, 0, sizeof(P));
+  P.n1 = n1; P.n2 = n2;
+  RGBL_TRY(upload(A, s, &P.proj1, prev_matched, (size_t)n1 * 2));
+  RGBL_TRY(upload(A, s, &P.mpdesc1, in->desc1, (size_t)n1 * 32));
+  RGBL_TRY(upload(A, s, &P.oct1, in->kp1_octave, (size_t)n1));
+  RGBL_TRY(upload(A, s, &P.xy2, in->kp2_xy, (size_t)n2 * 2));
+  RGBL_TRY(upload(A, s, &P.oct2, in->kp2_octave, (size_t)n2));
+  RGBL_TRY(upload(A, s, &P.desc2, in->desc2, (size_t)n2 * 32));
+  P.cell_start = A.take<uint32_t>(kGridCells + 1);
+  P.cell_items = A.take<uint16_t>(n2);
+  P.taken_by = A.take<int32_t>(n2);
+  P.min_unres = A.take<int32_t>(n2);
+  P.owner = A.take<int32_t>(n2);
+  P.win = A.take<float4>(n1);
+  P.rng = A.take<int4>(n1);
+  P.cand = A.take<unsigned long long>((size_t)n1 * kProjCand);
+  P.ncand = A.take<uint8_t>(n1);
+  P.state = A.take<uint8_t>(n1);
+  P.choice = A.take<int32_t>(n1);
+  memcpy(P.grid, in->grid, sizeof(P.grid));
+  P.th = (float)in->window_size;  // GetFeaturesInArea takes r as const float&
+  P.nnratio = in->nnratio;
+  // candidates at or above v cannot change a decision: as best they fail TH_LOW, as second-best they pass the ratio test
+  // for every best <= TH_LOW
+  int v = 51;
+  while (v <= 256 && !((float)v * in->nnratio > 50.0f)) ++v;
+  P.max_dist = v - 1;
+  m->timer.begin("k_proj_grid", s);
+  hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
+  m->timer.end(s);
+  m->timer.begin("k_init_candidates", s);
+  hipLaunchKernelGGL(k_init_candidates, dim3((n1 + 63) / 64), dim3(64), 0, s, P);
+  m->timer.end(s);
+  m->timer.begin("k_init_resolve", s);
+  hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(kProjBS), 0, s, P);
+  m->timer.end(s);
+  RGBL_HIP(hipGetLastError());
+  std::vector<int32_t> choice(n1), owner(n2);
+  RGBL_HIP(hipMemcpyAsync(choice.data(), P.choice, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipMemcpyAsync(owner.data(), P.owner, sizeof(int32_t) * n2, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipStreamSynchronize(s));
+  m->timer.collect();
+  // a feature whose match was taken over later stays in the rotation histogram (pushed at match time, :720-730) but
+  // holds no match any more (:708-712); nmatches always equals the number of entries >= 0
+  std::vector<int> hist[30];
+  const float factor = 1.0f / 30;
+  for (int i = 0; i < n1; ++i) {
+    const int c = choice[i];
+    if (c < 0) continue;
+    if (owner[c] == i) matches12[i] = c;
+    if (in->check_orientation) {
+      float rot = in->kp1_angle[i] - in->kp2_angle[c];
+      if (rot < 0.0) rot += 360.0f;
+      int bin = (int)roundf(rot * factor);
+      if (bin == 30) bin = 0;
+      if (bin >= 0 && bin < 30) hist[bin].push_back(i);
+    }
+  }
+  if (in->check_orientation) {
+    int i1, i2, i3;
+    three_maxima(hist, 30, i1, i2, i3);
+    for (int b = 0; b < 30; ++b) {
+      if (b == i1 || b == i2 || b == i3) continue;
+      for (int i : hist[b]) matches12[i] = -1;
+    }
+  }
+  int nmatches = 0;
+  for (int i = 0; i < n1; ++i)
+    if (matches12[i] >= 0) {  // "Update prev matched" (:757-760)
+      ++nmatches;
+      prev_matched[2 * i] = in->kp2_xy[2 * matches12[i]];
+      prev_matched[2 * i + 1] = in->kp2_xy[2 * matches12[i] + 1];
+    }
   *out_nmatches = nmatches;
   return RGBL_OK;
 }

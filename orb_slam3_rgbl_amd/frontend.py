@@ -526,6 +526,32 @@ class ORBmatcher:
         L.check(self.lib, self.lib.rgbl_search_local_points(self.h, C.byref(P), L.ptr(match2), C.byref(n)))
         return match2, n.value
 
+    def SearchForInitialization(self, case, windowSize=100):
+        """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:648-763).
+        case: dict with kp1_octave, kp1_angle, desc1, prev_matched [n1,2] (vbPrevMatched), kp2_xy, kp2_octave, kp2_angle,
+        desc2, grid[6].  Returns (vnMatches12, the updated vbPrevMatched, nmatches)."""
+        keep = []
+
+        def arr(v, dt):
+            a = np.ascontiguousarray(v, dt)
+            keep.append(a)
+            return a.ctypes.data
+        P = L.InitializationInput()
+        P.n1 = len(case["kp1_octave"])
+        P.kp1_octave, P.kp1_angle = arr(case["kp1_octave"], np.int32), arr(case["kp1_angle"], np.float32)
+        P.desc1 = arr(case["desc1"], np.uint8)
+        P.n2 = len(case["kp2_xy"])
+        P.kp2_xy, P.kp2_octave = arr(case["kp2_xy"], np.float32), arr(case["kp2_octave"], np.int32)
+        P.kp2_angle, P.desc2 = arr(case["kp2_angle"], np.float32), arr(case["desc2"], np.uint8)
+        for i in range(6):
+            P.grid[i] = float(case["grid"][i])
+        P.window_size, P.nnratio, P.check_orientation = int(windowSize), float(self.mfNNratio), int(self.mbCheckOrientation)
+        prev = np.ascontiguousarray(case["prev_matched"], np.float32).copy()
+        m12 = np.zeros(P.n1, np.int32)
+        n = C.c_int(0)
+        L.check(self.lib, self.lib.rgbl_search_for_initialization(self.h, C.byref(P), L.ptr(prev), L.ptr(m12), C.byref(n)))
+        return m12, prev, n.value
+
     @staticmethod
     def _view(kf, keep):
         v = L.KeyframeView()

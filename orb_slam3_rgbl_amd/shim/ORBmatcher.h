@@ -609,6 +609,49 @@ class ORBmatcher {
     return nmatches;
   }
 
+  // Matching for the Map Initialization (only used in the monocular case).  ORBmatcher.h:72, ORBmatcher.cc:648-763
+  // (Tracking::MonocularInitialization, Tracking.cc:2525-2526).  Reads F1.mvKeysUn / mDescriptors and F2's, reads and updates
+  // vbPrevMatched, fills vnMatches12.
+  template <class FrameT>
+  int SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
+                              int windowSize = 10) {
+    const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
+    vnMatches12 = std::vector<int>(n1, -1);
+    if (!mpHandle) return 0;
+    if (F2.Nleft != -1) {
+      std::cerr << "[ORBmatcher] SearchForInitialization: fisheye stereo rigs (Nleft != -1) are not covered by the device path" << std::endl;
+      return 0;
+    }
+    std::vector<float> ang1(n1), xy2((size_t)n2 * 2), ang2(n2), prev((size_t)n1 * 2);
+    std::vector<int32_t> oct1(n1), oct2(n2);
+    for (int i = 0; i < n1; ++i) {
+      oct1[i] = F1.mvKeysUn[i].octave; ang1[i] = F1.mvKeysUn[i].angle;
+      prev[2 * (size_t)i] = vbPrevMatched[i].x; prev[2 * (size_t)i + 1] = vbPrevMatched[i].y;
+    }
+    for (int i = 0; i < n2; ++i) {
+      xy2[2 * (size_t)i] = F2.mvKeysUn[i].pt.x; xy2[2 * (size_t)i + 1] = F2.mvKeysUn[i].pt.y;
+      oct2[i] = F2.mvKeysUn[i].octave; ang2[i] = F2.mvKeysUn[i].angle;
+    }
+    rgbl_initialization_input in;
+    in.n1 = n1; in.kp1_octave = oct1.data(); in.kp1_angle = ang1.data(); in.desc1 = F1.mDescriptors.template ptr<uint8_t>();
+    in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.kp2_angle = ang2.data();
+    in.desc2 = F2.mDescriptors.template ptr<uint8_t>();
+    in.grid[0] = FrameT::mnMinX; in.grid[1] = FrameT::mnMinY; in.grid[2] = FrameT::mnMaxX; in.grid[3] = FrameT::mnMaxY;
+    in.grid[4] = FrameT::mfGridElementWidthInv; in.grid[5] = FrameT::mfGridElementHeightInv;
+    in.window_size = windowSize; in.nnratio = mfNNratio; in.check_orientation = mbCheckOrientation ? 1 : 0;
+    int nmatches = 0;
+    std::vector<int32_t> m12(n1, -1);
+    if (rgbl_search_for_initialization(mpHandle, &in, prev.data(), m12.data(), &nmatches) != RGBL_OK) {
+      std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
+      return 0;
+    }
+    for (int i = 0; i < n1; ++i) {
+      vnMatches12[i] = m12[i];
+      if (m12[i] >= 0) vbPrevMatched[i] = F2.mvKeysUn[m12[i]].pt;  // "Update prev matched" (:757-760)
+    }
+    return nmatches;
+  }
+
   static const int TH_LOW = 50;
   static const int TH_HIGH = 100;
   static const int HISTO_LENGTH = 30;

@@ -671,6 +671,84 @@ def check_search_local_points(lib, seed=41, th=1.0, nnratio=0.8, n1=3000, n2=200
     return n
 
 
+# ---- ORBmatcher::SearchForInitialization (monocular initialisation) ------------------------------------------------------
+def make_initialization_case(n1=5000, seed=61, w=synth.KITTI_W, h=synth.KITTI_H, motion=(14.0, -6.0)):
+    """Two monocular frames: F2's features are F1's moved by `motion` plus noise, descriptors with a few flipped bits;
+    vbPrevMatched = F1's positions (Tracking.cc:2493-2495).  Look-alike neighbours make the ratio test bite, and pairs of F1
+    features aim at one F2 feature with the later one closer, so that matches are taken over (vMatchedDistance)."""
+    rng = np.random.default_rng(seed)
+    xy1 = np.stack([rng.uniform(5, w - 5, n1), rng.uniform(5, h - 5, n1)], 1).astype(np.float32)
+    oct1 = rng.choice(8, n1, p=[0.45, 0.2, 0.1, 0.08, 0.06, 0.05, 0.03, 0.03]).astype(np.int32)
+    desc1 = synth.descriptors(n1, seed)
+    ang1 = rng.uniform(0, 360, n1).astype(np.float32)
+    n2 = n1
+    perm = rng.permutation(n1)                      # F2 feature j comes from F1 feature perm[j]
+    xy2 = (xy1[perm] + np.array(motion, np.float32) + rng.normal(0, 1.5, (n2, 2))).astype(np.float32)
+    oct2 = oct1[perm].copy()
+    oct2[rng.random(n2) < 0.1] = 1
+    rate = rng.choice([0.01, 0.04, 0.1, 0.3], n2, p=[0.3, 0.4, 0.2, 0.1])
+    desc2 = desc1[perm] ^ np.packbits(rng.random((n2, 256)) < rate[:, None], axis=1, bitorder="little")
+    dang = np.where(rng.random(n2) < 0.8, rng.normal(5, 3, n2), rng.uniform(0, 360, n2))
+    ang2 = np.mod(ang1[perm] - dang, 360).astype(np.float32)
+    # look-alike neighbours in F2 (second-best close to best)
+    ncl = n2 // 8
+    src = rng.integers(0, n2, ncl)
+    dst = rng.permutation(n2)[:ncl]
+    xy2[dst] = xy2[src] + rng.uniform(-20, 20, (ncl, 2)).astype(np.float32)
+    oct2[dst] = oct2[src]
+    desc2[dst] = desc2[src] ^ np.packbits(rng.random((ncl, 256)) < rng.choice([0.01, 0.06], ncl)[:, None], axis=1, bitorder="little")
+    # take-overs: F1 feature a (lower index) resembles what F1 feature b (higher index) matches even better
+    inv = np.empty(n1, np.int64)
+    inv[perm] = np.arange(n1)
+    pairs = rng.permutation(n1)[: 2 * (n1 // 10)].reshape(-1, 2)
+    a, b = pairs.min(1), pairs.max(1)
+    oct1[a] = 0; oct1[b] = 0
+    c = inv[b]
+    oct2[c] = 0
+    xy1[a] = xy1[b] + rng.uniform(-30, 30, (len(a), 2)).astype(np.float32)
+    desc2[c] = desc1[b] ^ np.packbits(rng.random((len(a), 256)) < 0.02, axis=1, bitorder="little")
+    desc1[a] = desc2[c] ^ np.packbits(rng.random((len(a), 256)) < rng.choice([0.03, 0.08], len(a))[:, None], axis=1, bitorder="little")
+    xy2[:, 0] = np.clip(xy2[:, 0], 1, w - 2)
+    xy2[:, 1] = np.clip(xy2[:, 1], 1, h - 2)
+    prev = xy1.copy()
+    prev[rng.random(n1) < 0.01] = np.float32(-500)   # window outside of the grid
+    gw, gh = np.float32(w), np.float32(h)
+    grid = np.array([0, 0, gw, gh, np.float32(64) / gw, np.float32(48) / gh], np.float32)
+    return dict(kp1_octave=oct1, kp1_angle=ang1, desc1=desc1, prev_matched=prev, kp2_xy=xy2, kp2_octave=oct2, kp2_angle=ang2,
+                desc2=desc2, grid=grid)
+
+
+def check_search_for_initialization(lib, seed=61, window=100, nnratio=0.9, check_orientation=True, n1=5000):
+    case = make_initialization_case(n1, seed)
+    mt = F.ORBmatcher(nnratio, check_orientation, lib=lib)
+    m, prev, n = mt.SearchForInitialization(case, window)
+    om, oprev, on = O.search_for_initialization(case, window, nnratio, check_orientation)
+    assert n == on and np.array_equal(m, om), "SearchForInitialization (seed %d, window %d)" % (seed, window)
+    assert np.array_equal(prev.view(np.uint32), oprev.view(np.uint32))
+    # the second call of the initialiser starts from the updated vbPrevMatched
+    case2 = dict(case, prev_matched=prev)
+    m2, prev2, n2 = mt.SearchForInitialization(case2, window // 2)
+    om2, oprev2, on2 = O.search_for_initialization(case2, window // 2, nnratio, check_orientation)
+    assert n2 == on2 and np.array_equal(m2, om2) and np.array_equal(prev2.view(np.uint32), oprev2.view(np.uint32))
+    # a dense look-alike cluster: more deciding candidates than the per-feature list holds (window re-scan path)
+    rng = np.random.default_rng(seed + 7)
+    small = make_initialization_case(600, seed + 1)
+    small["kp2_xy"][:80] = np.array([400.0, 200.0], np.float32) + rng.uniform(-30, 30, (80, 2)).astype(np.float32)
+    small["kp2_octave"][:80] = 0
+    small["desc2"][:80] = small["desc2"][0] ^ np.packbits(rng.random((80, 256)) < 0.03, axis=1, bitorder="little")
+    small["prev_matched"][:150] = np.array([400.0, 200.0], np.float32) + rng.uniform(-10, 10, (150, 2)).astype(np.float32)
+    small["kp1_octave"][:150] = 0
+    small["desc1"][:150] = small["desc2"][0] ^ np.packbits(rng.random((150, 256)) < 0.02, axis=1, bitorder="little")
+    for ratio in (nnratio, 1.5):
+        mt2 = F.ORBmatcher(ratio, check_orientation, lib=lib)
+        m3, prev3, n3 = mt2.SearchForInitialization(small, window)
+        om3, oprev3, on3 = O.search_for_initialization(small, window, ratio, check_orientation)
+        assert n3 == on3 and np.array_equal(m3, om3) and np.array_equal(prev3.view(np.uint32), oprev3.view(np.uint32))
+        mt2.close()
+    mt.close()
+    return n
+
+
 # ---- DBoW2 vocabulary transform (SURVEY 8(f) row f4) ----------------------------------------------------------------------
 def check_bow_transform(lib, tmp_dir, k=10, L=4, levelsup=2, seed=0, n_feat=2000):
     voc = synth.make_vocabulary(k, L, seed)

@@ -110,13 +110,21 @@ def run_and_check(exe, tmp):
                             ("mp_max_dist", np.float32)):
                 f.write(np.ascontiguousarray(scase[side][key], dt).tobytes())
         f.write(np.ascontiguousarray(scase["prior12"], np.int32).tobytes())
+    icase = pc.make_initialization_case(3000, seed=151)
+    with open(os.path.join(tmp, "init.bin"), "wb") as f:
+        f.write(struct.pack("<iii", len(icase["kp1_octave"]), len(icase["kp2_xy"]), 100))
+        f.write(np.ascontiguousarray(icase["grid"], np.float32).tobytes())
+        for key, dt in (("kp1_octave", np.int32), ("kp1_angle", np.float32), ("desc1", np.uint8), ("prev_matched", np.float32),
+                        ("kp2_xy", np.float32), ("kp2_octave", np.int32), ("kp2_angle", np.float32), ("desc2", np.uint8)):
+            f.write(np.ascontiguousarray(icase[key], dt).tobytes())
     voc = synth.make_vocabulary(10, 3, seed=5)
     synth.write_vocabulary_text(os.path.join(tmp, "voc.txt"), voc)
     out = os.path.join(tmp, "out.bin")
     res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "KITTI00-02.yaml"), os.path.join(tmp, "img.raw"), str(w), str(h),
                           os.path.join(tmp, "cloud.raw"), str(cloud.shape[1]), os.path.join(tmp, "tri.bin"), out,
                           os.path.join(tmp, "proj.bin"), os.path.join(tmp, "local.bin"), os.path.join(tmp, "voc.txt"),
-                          os.path.join(tmp, "reloc.bin"), os.path.join(tmp, "fuse.bin"), os.path.join(tmp, "sim3.bin")],
+                          os.path.join(tmp, "reloc.bin"), os.path.join(tmp, "fuse.bin"), os.path.join(tmp, "sim3.bin"),
+                          os.path.join(tmp, "init.bin")],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "Lidar Method: InverseDilation" in res.stdout
@@ -179,7 +187,12 @@ def run_and_check(exe, tmp):
     for _ in range(2):
         nms = take(np.int32, 1)[0]
         greedy.append((nms, take(np.int32, n1s).copy()))
+    ninit, n1i = take(np.int32, 2)
+    init_match = take(np.int32, n1i)
+    init_prev = take(np.float32, 2 * n1i).reshape(n1i, 2)
     assert pos == len(buf)
+    oim, oiprev, oin = O.search_for_initialization(icase, 100, 0.9, True)
+    assert ninit == oin and np.array_equal(init_match, oim) and np.array_equal(pc.bits(init_prev), pc.bits(oiprev)) and ninit > 300
     osm, osn = pc.search_by_sim3(scase, 7.5, O.project_search)
     assert nsim == osn and np.array_equal(sim_match, osm) and nsim > 200
     # Fuse(pKF2, Scw = I, points of KF1, 4): candidates = the features of KF1 that hold a point, in index order

@@ -667,6 +667,36 @@ int main(int argc, char** argv) {
       }
     }
   }
+  // --- as Tracking::MonocularInitialization (Tracking.cc:2525-2526): ORBmatcher(0.9, true).SearchForInitialization(F1, F2, prev, m12, 100)
+  if (argc > 15) {
+    f = fopen(argv[15], "rb");
+    int n1 = 0, n2 = 0, window = 0;
+    float hdr[6];
+    if (!f || !rd(f, &n1, 1) || !rd(f, &n2, 1) || !rd(f, &window, 1) || !rd(f, hdr, 6)) return 8;
+    std::vector<int> o1(n1), o2(n2);
+    std::vector<float> a1(n1), prev((size_t)n1 * 2), xy2((size_t)n2 * 2), a2(n2);
+    std::vector<unsigned char> d1((size_t)n1 * 32), d2((size_t)n2 * 32);
+    rd(f, o1.data(), n1); rd(f, a1.data(), n1); rd(f, d1.data(), (size_t)n1 * 32); rd(f, prev.data(), (size_t)n1 * 2);
+    rd(f, xy2.data(), (size_t)n2 * 2); rd(f, o2.data(), n2); rd(f, a2.data(), n2); rd(f, d2.data(), (size_t)n2 * 32);
+    fclose(f);
+    TestFrame::mnMinX = hdr[0]; TestFrame::mnMinY = hdr[1]; TestFrame::mnMaxX = hdr[2]; TestFrame::mnMaxY = hdr[3];
+    TestFrame::mfGridElementWidthInv = hdr[4]; TestFrame::mfGridElementHeightInv = hdr[5];
+    TestFrame F1, F2;
+    F1.N = n1; F1.mvKeysUn.resize(n1);
+    for (int i = 0; i < n1; ++i) { F1.mvKeysUn[i].pt.x = prev[2 * i]; F1.mvKeysUn[i].pt.y = prev[2 * i + 1]; F1.mvKeysUn[i].octave = o1[i]; F1.mvKeysUn[i].angle = a1[i]; }
+    F1.mDescriptors.create(n1, 32, CV_8U); memcpy(F1.mDescriptors.data, d1.data(), (size_t)n1 * 32);
+    F2.N = n2; F2.mvKeysUn.resize(n2);
+    for (int i = 0; i < n2; ++i) { F2.mvKeysUn[i].pt.x = xy2[2 * i]; F2.mvKeysUn[i].pt.y = xy2[2 * i + 1]; F2.mvKeysUn[i].octave = o2[i]; F2.mvKeysUn[i].angle = a2[i]; }
+    F2.mDescriptors.create(n2, 32, CV_8U); memcpy(F2.mDescriptors.data, d2.data(), (size_t)n2 * 32);
+    std::vector<cv::Point2f> vbPrevMatched(n1);
+    for (int i = 0; i < n1; ++i) { vbPrevMatched[i].x = prev[2 * i]; vbPrevMatched[i].y = prev[2 * i + 1]; }
+    std::vector<int> vnMatches12;
+    ORB_SLAM3::ORBmatcher init(0.9, true);
+    const int ninit = init.SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, window);
+    wr(out, &ninit, 1); wr(out, &n1, 1);
+    wr(out, vnMatches12.data(), n1);
+    for (int i = 0; i < n1; ++i) { wr(out, &vbPrevMatched[i].x, 1); wr(out, &vbPrevMatched[i].y, 1); }
+  }
   fclose(out);
   printf("shim_test ok: %d keypoints, %d depths, %d triangulation matches\n", nk, nd, nm);
   return 0;

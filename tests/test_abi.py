@@ -89,6 +89,10 @@ def test_invalid_arguments_of_the_matcher_entry_points(emu_lib, tmp_path):
     assert lib.rgbl_search_by_projection(mt.h, None, None, _lib.C.byref(n)) == _lib.ERR_INVALID
     assert lib.rgbl_search_local_points(mt.h, None, None, _lib.C.byref(n)) == _lib.ERR_INVALID
     assert lib.rgbl_search_by_projection_keyframe(mt.h, None, None, _lib.C.byref(n)) == _lib.ERR_INVALID
+    icase = pc.make_initialization_case(60, 3)
+    with pytest.raises(_lib.RgblError):
+        mt.SearchForInitialization(dict(icase, kp1_octave=np.full(60, -1, np.int32)), 100)
+    assert lib.rgbl_search_for_initialization(mt.h, None, None, None, _lib.C.byref(n)) == _lib.ERR_INVALID
     rcase = pc.make_relocalization_case(40, 50, 3)
     rcase = dict(rcase, valid1=np.ones(40, np.uint8), level1=np.zeros(40, np.int32))
     with pytest.raises(_lib.RgblError):

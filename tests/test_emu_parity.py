@@ -118,6 +118,11 @@ def test_search_local_points(emu_lib, seed, th, ratio):
     assert pc.check_search_local_points(emu_lib, seed, th, ratio, n1=1200, n2=900) > 50
 
 
+@pytest.mark.parametrize("seed,window,ratio,ori", [(61, 100, 0.9, True), (62, 100, 0.9, False), (63, 30, 0.6, True), (64, 200, 1.0, True)])
+def test_search_for_initialization(emu_lib, seed, window, ratio, ori):
+    assert pc.check_search_for_initialization(emu_lib, seed, window, ratio, ori, n1=2500) > 300
+
+
 def test_bow_transform(emu_lib, tmp_path):
     assert pc.check_bow_transform(emu_lib, tmp_path, 10, 3, 2, seed=1, n_feat=600) > 100
     assert pc.check_bow_transform(emu_lib, tmp_path, 6, 4, 4, seed=2, n_feat=400) > 100    # levelsup >= L: every feature under the root

@@ -137,6 +137,13 @@ def test_search_local_points(gpu_lib, seed, th, ratio):
     assert pc.check_search_local_points(gpu_lib, seed, th, ratio) > 200
 
 
+@pytest.mark.parametrize("seed,window,ratio,ori", [(61, 100, 0.9, True), (62, 100, 0.9, False), (63, 30, 0.6, True), (64, 200, 1.0, True),
+                                                   (65, 100, 0.9, True)])
+def test_search_for_initialization(gpu_lib, seed, window, ratio, ori):
+    n1 = 10000 if seed == 65 else 5000          # Tracking builds the initialisation extractor with 5 * nFeatures (Tracking.cc:601)
+    assert pc.check_search_for_initialization(gpu_lib, seed, window, ratio, ori, n1=n1) > 600
+
+
 def test_bow_transform(gpu_lib, tmp_path):
     assert pc.check_bow_transform(gpu_lib, tmp_path, 10, 4, 2, seed=0) > 500
     assert pc.check_bow_transform(gpu_lib, tmp_path, 10, 5, 4, seed=3, n_feat=8000) > 2000   # 111 k nodes

@@ -362,6 +362,41 @@ def test_reference_search_local_points_agrees_with_oracle(refmatcher, seed, th, 
     assert not np.array_equal(O.search_local_points(free, th, nnratio)[0], om)   # the blocking rule matters in this scenario
 
 
+@pytest.mark.parametrize("seed,window,nnratio,ori", [(61, 100, 0.9, True), (62, 100, 0.9, False), (63, 30, 0.6, True),
+                                                     (64, 200, 1.0, True), (65, 100, 1.5, True)])
+def test_reference_search_for_initialization_agrees_with_oracle(refmatcher, seed, window, nnratio, ori):
+    """ORBmatcher::SearchForInitialization as Tracking::MonocularInitialization calls it (Tracking.cc:2525-2526:
+    ORBmatcher(0.9, true), windowSize 100); the scenario takes matches over (vMatchedDistance) several hundred times."""
+    import parity_checks as pc
+    case = pc.make_initialization_case(5000, seed)
+    keep = []
+    P = O.make_initialization_input(case, window, nnratio, ori, keep)
+    prev = case["prev_matched"].copy()
+    m = np.zeros(P.n1, np.int32)
+    refmatcher.ref_search_for_initialization.restype = C.c_int
+    refmatcher.ref_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    nm = refmatcher.ref_search_for_initialization(C.byref(P), prev.ctypes.data, m.ctypes.data)
+    om, oprev, onm = O.search_for_initialization(case, window, nnratio, ori)
+    assert nm == onm and np.array_equal(m, om) and np.array_equal(prev.view(np.uint32), oprev.view(np.uint32))
+    assert nm > 600 and nm == int((m >= 0).sum())
+    assert np.all(case["kp1_octave"][m >= 0] == 0) and np.all(case["kp2_octave"][m[m >= 0]] == 0)   # level 0 only
+    assert len(np.unique(m[m >= 0])) == nm                                                          # one holder per F2 feature
+    # features that lost their match to a later, closer one: unmatched although a partner within TH_LOW exists that a
+    # higher-index feature holds at a smaller distance
+    if not ori:
+        lost = 0
+        d1, d2 = case["desc1"], case["desc2"]
+        holders = np.nonzero(m >= 0)[0]
+        for a in np.nonzero((m < 0) & (case["kp1_octave"] == 0))[0][:400]:
+            later = holders[holders > a]
+            c = m[later]
+            da = np.unpackbits(d1[a][None, :] ^ d2[c], axis=1).sum(1)
+            db = np.unpackbits(d1[later] ^ d2[c], axis=1).sum(1)
+            near = (np.abs(case["kp2_xy"][c] - case["prev_matched"][a]) < window).all(1)
+            lost += bool(((da <= 50) & (db < da) & near).any())
+        assert lost > 50
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # The reference's own vendored DBoW2 (oracle/_ref/libref_dbow2.so): vocabulary text loader + transform (Frame::ComputeBoW).
 REF_DBOW2_SO = os.path.join(ROOT, "oracle", "_ref", "libref_dbow2.so")

@@ -22,6 +22,7 @@ elif which == "match":
     pc.check_search_by_projection(lib, 21, "forward", 7.0, False, True, n1=700, n2=800)
     pc.check_search_by_projection_edge_cases(lib)
     pc.check_search_local_points(lib, 41, 1.0, 0.8, n1=1200, n2=900)
+    pc.check_search_for_initialization(lib, 61, 100, 0.9, True, n1=1500)
     import tempfile
     pc.check_bow_transform(lib, tempfile.mkdtemp(), 10, 3, 2, seed=1, n_feat=600)
 elif which == "misc":
