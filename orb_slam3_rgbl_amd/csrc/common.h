@@ -96,6 +96,33 @@ __device__ __forceinline__ unsigned long long rgbl_clock() {
   return (unsigned long long)__builtin_readcyclecounter();
 #endif
 }
+// integer dot products and byte shuffles of the VALU (v_dot4_u32_u8, v_dot2_u32_u16, v_alignbyte_b32, v_perm_b32)
+__device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {  // sum of the four byte products + c
+#ifdef RGBL_EMU
+  for (int k = 0; k < 4; ++k) c += ((a >> (8 * k)) & 0xffu) * ((b >> (8 * k)) & 0xffu);
+  return c;
+#else
+  return __builtin_amdgcn_udot4(a, b, c, false);
+#endif
+}
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {  // sum of the two 16-bit products + c
+#ifdef RGBL_EMU
+  return c + (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16);
+#else
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  us2 x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  return __builtin_amdgcn_udot2(x, y, c, false);
+#endif
+}
+__device__ __forceinline__ uint32_t align_bytes(uint32_t hi, uint32_t lo, int shift) {  // bytes shift .. shift + 3 of hi:lo
+#ifdef RGBL_EMU
+  return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * (shift & 3)));
+#else
+  return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)shift);
+#endif
+}
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

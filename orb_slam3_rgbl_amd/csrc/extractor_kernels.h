@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
     const uint32_t wmagic = (0x100000u + (uint32_t)nwords - 1u) / (uint32_t)nwords;
     for (int i = tid; i < nwords * th; i += 256) {
       const int y = (int)(__umul24((uint32_t)i, wmagic) >> 20), k = i - (int)__umul24((uint32_t)y, (uint32_t)nwords);
-      s_tile_w[(y * kTileP >> 2) + k] = load_u32_unaligned(img + (size_t)(ini_y + y) * pitch + ini_x + 4 * k);
+      // row and pitch are far below 2^24 and a level far below 4 GB: one full-rate 24-bit multiply instead of a 64-bit one
+      s_tile_w[(y * kTileP >> 2) + k] = load_u32_unaligned(img + (__umul24((uint32_t)(ini_y + y), (uint32_t)pitch) + (uint32_t)(ini_x + 4 * k)));
     }
   }
   for (int i = tid; i < (sh + 2) * (kScoreP / 4); i += 256) s_score_w[i] = 0;
@@ -425,6 +426,106 @@ __global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ ge
       out |= ((acc + 32768u) >> 16) << (8 * i);
     }
     uint8_t* D = blur + (size_t)f * blur_frame + g.img_off + (size_t)y * g.pitch + x;
+    if (x + 3 < W) {
+      *reinterpret_cast<uint32_t*>(D) = out;
+    } else {
+      for (int i = 0; x + i < W; ++i) D[i] = (uint8_t)(out >> (8 * i));
+    }
+  }
+}
+
+// The same filter on the VALU's integer dot products.  Horizontal: a work-item owns 4 output columns of two rows; the
+// seven taps of an output are two v_dot4_u32_u8 over byte-aligned windows (v_alignbyte_b32) of the row's three words with
+// the weights {18,34,48,56} / {48,34,18,0}.  The exact 16-bit sums of the two rows share a word (row pair j = rows 2j,
+// 2j + 1), so the vertical pass is four v_dot2_u32_u16 per output over five such words, the rounding constant being the
+// initial accumulator: even output rows take the weights (18,34)(48,56)(48,34)(18,0), odd ones (0,18)(34,48)(56,48)(34,18).
+// Same integers as above, about 10 instead of 25 VALU instructions per pixel.
+__global__ __launch_bounds__(256) void k_gauss7_dot(const LevelGeom* __restrict__ geom, int n_levels, BlurTiles bt,
+                                                    const uint8_t* __restrict__ img0, int pitch0, size_t frame0,
+                                                    const uint8_t* __restrict__ pyr, size_t pyr_frame,
+                                                    uint8_t* __restrict__ blur, size_t blur_frame, int tile_begin) {
+  constexpr int kPairs = (kBlurTH + 6) / 2;       // 19 row pairs
+  __shared__ uint32_t s_p[kPairs * kBlurTW];      // [pair][column]: sum of row 2j | sum of row 2j + 1 << 16
+  const int tid = threadIdx.x, bx = blockIdx.x + tile_begin, f = blockIdx.y;
+  int l = 0;
+  while (l + 1 < n_levels && bx >= bt.tile_off[l + 1]) ++l;
+  const LevelGeom& g = geom[l];
+  const int t = bx - bt.tile_off[l];
+  const int ty = t / bt.tiles_x[l], tx = t - ty * bt.tiles_x[l];
+  const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
+  const uint8_t* img = (l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
+  const int pitch = (l == 0) ? pitch0 : g.pitch;
+  const int W = g.w, H = g.h;
+  const uint32_t kWA = 18u | (34u << 8) | (48u << 16) | (56u << 24), kWB = 48u | (34u << 8) | (18u << 16);
+
+  for (int task = tid; task < kPairs * 32; task += 256) {
+    const int j = task >> 5, cg = task & 31;
+    const int x = x0 + 4 * cg;
+    if (x >= W) continue;
+    uint32_t w[2][3];  // per row the pixels x-4 .. x+7
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const uint8_t* row = img + __umul24((uint32_t)reflect101(y0 + 2 * j + rr - 3, H), (uint32_t)pitch);
+      if (x >= 4 && x + 8 <= W) {
+        w[rr][0] = load_u32_unaligned(row + x - 4);
+        w[rr][1] = load_u32_unaligned(row + x);
+        w[rr][2] = load_u32_unaligned(row + x + 4);
+      } else {
+        w[rr][0] = w[rr][1] = w[rr][2] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          w[rr][0] |= (uint32_t)row[reflect101(x - 4 + k, W)] << (8 * k);
+          w[rr][1] |= (uint32_t)row[reflect101(x + k, W)] << (8 * k);
+          w[rr][2] |= (uint32_t)row[reflect101(x + 4 + k, W)] << (8 * k);
+        }
+      }
+    }
+    uint32_t hs[2][4];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // output x + i: pixels x+i-3 .. x+i+3 = bytes i+1 .. i+7 of the 12
+        const uint32_t lo = i == 3 ? w[rr][1] : align_bytes(w[rr][1], w[rr][0], i + 1);
+        const uint32_t hi = i == 3 ? w[rr][2] : align_bytes(w[rr][2], w[rr][1], i + 1);
+        hs[rr][i] = udot4(lo, kWA, udot4(hi, kWB, 0u));
+      }
+    }
+    uint4 v;
+    v.x = hs[0][0] | (hs[1][0] << 16); v.y = hs[0][1] | (hs[1][1] << 16);
+    v.z = hs[0][2] | (hs[1][2] << 16); v.w = hs[0][3] | (hs[1][3] << 16);
+    *reinterpret_cast<uint4*>(&s_p[j * kBlurTW + 4 * cg]) = v;
+  }
+  __syncthreads();
+  const int cg = tid & 31, rg = tid >> 5;
+  const int x = x0 + 4 * cg;
+  if (x >= W) return;
+  uint32_t pv[5][4];  // row pairs 2 rg .. 2 rg + 4 = the tile rows 4 rg .. 4 rg + 9
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const uint4 v = *reinterpret_cast<const uint4*>(&s_p[(2 * rg + j) * kBlurTW + 4 * cg]);
+    pv[j][0] = v.x; pv[j][1] = v.y; pv[j][2] = v.z; pv[j][3] = v.w;
+  }
+  const uint32_t kE0 = 18u | (34u << 16), kE1 = 48u | (56u << 16), kE2 = 48u | (34u << 16), kE3 = 18u;
+  const uint32_t kO0 = 18u << 16, kO1 = 34u | (48u << 16), kO2 = 56u | (48u << 16), kO3 = 34u | (18u << 16);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const int y = y0 + 4 * rg + o;
+    if (y >= H) break;
+    const int b = o >> 1;  // first row pair of the window
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t acc = 32768u;
+      if ((o & 1) == 0) {
+        acc = udot2(pv[b][i], kE0, acc); acc = udot2(pv[b + 1][i], kE1, acc);
+        acc = udot2(pv[b + 2][i], kE2, acc); acc = udot2(pv[b + 3][i], kE3, acc);
+      } else {
+        acc = udot2(pv[b][i], kO0, acc); acc = udot2(pv[b + 1][i], kO1, acc);
+        acc = udot2(pv[b + 2][i], kO2, acc); acc = udot2(pv[b + 3][i], kO3, acc);
+      }
+      out |= (acc >> 16) << (8 * i);
+    }
+    uint8_t* D = blur + (size_t)f * blur_frame + g.img_off + (__umul24((uint32_t)y, (uint32_t)g.pitch) + (uint32_t)x);
     if (x + 3 < W) {
       *reinterpret_cast<uint32_t*>(D) = out;
     } else {
@@ -1371,6 +1472,22 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
     }
   }
 
+  // what depends on the lane only: its row v and half, the bytes of its 16 that lie inside the circle (|u| <= umax[|v|];
+  // u = 16 does not exist), the weights u + 15 resp. u of the bytes
+  uint32_t ic_mask[4] = {0u, 0u, 0u, 0u}, ic_coef[4];
+  int ic_off;
+  {
+    const int v = (lane >> 1) - 15, half = lane & 1;
+    const int d = umax.v[lane < 62 ? (v < 0 ? -v : v) : 0];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const bool in = half ? (q + 1 <= d) : (15 - q <= d);
+      ic_mask[q >> 2] |= in ? (0xffu << (8 * (q & 3))) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ic_coef[j] = 0x03020100u + 0x04040404u * (uint32_t)j + (half ? 0x01010101u : 0u);
+    ic_off = half ? 0 : 15;
+  }
   // ---- pass 1, keypoint after keypoint: IC_Angle moments (ORBextractor.cc:76-101) over the rows v = -15..15
   int my_m10 = 0, my_m01 = 0;
 #pragma unroll
@@ -1383,23 +1500,18 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
     wave_sync();
     int m10 = 0, m01 = 0;
     if (lane < 62) {
-      // two lanes per row; the half row is read as four 32-bit LDS words (all in flight together) and the bytes
-      // outside the circle (|u| > umax[|v|]) are masked, instead of a data-dependent byte loop
-      const int r = lane >> 1, v = r - 15, half = lane & 1;
-      const int d = umax.v[v < 0 ? -v : v];
-      const uint32_t* roww = s_raw_w[wave] + r * 8 + half * 4;  // bytes u = -15..0 (half 0) or 1..16 (half 1)
-      const uint32_t ws[4] = {roww[0], roww[1], roww[2], roww[3]};
-      int sum0 = 0, sum1 = 0;
+      // two lanes per row; the half row is read as four 32-bit LDS words (all in flight together), the bytes outside the
+      // circle are masked and both sums are integer dot products (v_dot4_u32_u8) of the masked words
+      const uint32_t* roww = s_raw_w[wave] + (lane >> 1) * 8 + (lane & 1) * 4;  // bytes u = -15..0 (half 0) or 1..16 (half 1)
+      uint32_t sum0 = 0, sum1 = 0;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int u = half ? q + 1 : q - 15;
-        const int au = u < 0 ? -u : u;
-        const int p = (au <= d && u <= 15) ? (int)((ws[q >> 2] >> (8 * (q & 3))) & 0xff) : 0;
-        sum0 += p;
-        sum1 += u * p;
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t wm = roww[j] & ic_mask[j];
+        sum0 = udot4(wm, 0x01010101u, sum0);
+        sum1 = udot4(wm, ic_coef[j], sum1);
       }
-      m10 = sum1;
-      m01 = v * sum0;
+      m10 = (int)sum1 - ic_off * (int)sum0;   // sum of u p with u = q - 15 (half 0) or q + 1 (half 1)
+      m01 = ((lane >> 1) - 15) * (int)sum0;
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);

@@ -25,7 +25,21 @@
 namespace rgbl {
 
 __device__ __forceinline__ int hamming256(const unsigned long long q[4], const unsigned long long* __restrict__ t) {
-  return __popcll(q[0] ^ t[0]) + __popcll(q[1] ^ t[1]) + __popcll(q[2] ^ t[2]) + __popcll(q[3] ^ t[3]);
+  // one accumulating chain of eight 32-bit popcounts (v_bcnt_u32_b32 adds its second operand for free); four 64-bit
+  // popcounts cost the same eight v_bcnt plus two adds for the partial sums
+  // (written as inline assembly: the compiler re-balances a chain of ctpop + add into a tree with three v_add3 per distance)
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long x = q[k] ^ t[k];
+#ifdef RGBL_EMU
+    acc += (uint32_t)__builtin_popcountll(x);
+#else
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(acc) : "v"((uint32_t)x), "v"(acc));
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(acc) : "v"((uint32_t)(x >> 32)), "v"(acc));
+#endif
+  }
+  return (int)acc;
 }
 
 // A workgroup owns 64 query descriptors (one per lane, 4 x u64 in VGPRs).  Its four waves split the train set
@@ -69,9 +83,12 @@ __global__ __launch_bounds__(256) void k_hamming_bf(const uint8_t* __restrict__ 
   int j = j0;
   for (; j + 8 <= j1; j += 8) {
     const unsigned long long* t = B + 4 * (size_t)j;
+    unsigned long long tt[32];  // the eight train descriptors first (wave-uniform: four s_load_dwordx16), then the arithmetic
+#pragma unroll
+    for (int u = 0; u < 32; ++u) tt[u] = t[u];
     uint32_t e[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) e[u] = ((uint32_t)hamming256(q, t + 4 * u) << 16) | (uint32_t)(j + u);
+    for (int u = 0; u < 8; ++u) e[u] = ((uint32_t)hamming256(q, tt + 4 * u) << 16) | (uint32_t)(j + u);
 #pragma unroll
     for (int u = 0; u < 8; ++u) bf_track(best, second, e[u]);
   }
