@@ -63,7 +63,6 @@ struct rgbl_extractor {
   int octree_wg = 0;
   int resize_rows = 4;  // output rows per work-item of k_resize_linear (RGBL_RESIZE_ROWS: 1, 2 or 4)  // 0 = choose per launch; RGBL_OCTREE_WG=256|512 pins the quad-tree workgroup width (tuning / tests)
   int max_cell = 0;  // largest detection-cell side over the levels: selects the k_fast_cells instantiation
-  bool gauss_dot = true;  // k_gauss7_dot (integer dot products) instead of k_gauss7; RGBL_GAUSS_DOT=0 selects the latter
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> per_level;
   UMax umax;
@@ -261,6 +260,7 @@ int upload_tables(rgbl_extractor* e) {
     if (l > 0) {
       xt.resize(g.xtab_off);
       build_resize_tab(e->geom[l - 1].w, g.w, true, xt);
+      while (xt.size() % 4) xt.push_back(xt.back());  // the partial last group of a row computes (and stores into the row padding) copies of the last column
       build_resize_tab(e->geom[l - 1].h, g.h, false, yt);
     }
     // root node of every x (ORBextractor.cc:585: vpIniNodes[kp.pt.x / hX], float division, truncation)
@@ -338,7 +338,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   auto launch_gauss = [&](hipStream_t st, int tile_begin, int tile_end) {
     if (tile_end <= tile_begin) return;
     e->timer.begin("k_gauss7", st);
-    hipLaunchKernelGGL(e->gauss_dot ? k_gauss7_dot : k_gauss7, dim3(tile_end - tile_begin, batch), dim3(256), 0, st, e->d_geom, L,
+    hipLaunchKernelGGL(k_gauss7, dim3(tile_end - tile_begin, batch), dim3(256), 0, st, e->d_geom, L,
                        e->blur_tiles, d_imgs, stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame, tile_begin);
     e->timer.end(st);
   };
@@ -490,7 +490,6 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
   rgbl_extractor* e = new rgbl_extractor;
   e->cfg = *cfg;
   if (const char* v = getenv("RGBL_GRAPH")) e->graph_ok = atoi(v) != 0;
-  if (const char* v = getenv("RGBL_GAUSS_DOT")) e->gauss_dot = atoi(v) != 0;
   if (const char* v = getenv("RGBL_OCTREE_WG")) { const int wg = atoi(v); if (wg == kOctNarrow || wg == kOctWide) e->octree_wg = wg; }
   e->device = device;
   int rc = build_geometry(e);

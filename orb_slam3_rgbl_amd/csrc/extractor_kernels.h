@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
   const uint8_t* S = src + (size_t)blockIdx.z * sframe;
   uint8_t* D = dst + (size_t)blockIdx.z * dframe + (size_t)dy0 * dpitch;
   // both coefficient tables are requested before either is used (one round trip, not two); the x table is padded to a
-  // multiple of 4 entries per level, entries at or past dw are never used
+  // multiple of 4 entries per level with copies of the last entry
   const uint4* t4 = reinterpret_cast<const uint4*>(xtab + dx0);
   const uint4 q0 = t4[0], q1 = t4[1];
   // the kResizeRows rows' vertical taps; rows past the image repeat the last one (computed, not stored)
@@ -94,8 +94,11 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
   rx[1].sofs = (int)q0.z; rx[1].a0 = (int16_t)(q0.w & 0xffff); rx[1].a1 = (int16_t)(q0.w >> 16);
   rx[2].sofs = (int)q1.x; rx[2].a0 = (int16_t)(q1.y & 0xffff); rx[2].a1 = (int16_t)(q1.y >> 16);
   rx[3].sofs = (int)q1.z; rx[3].a0 = (int16_t)(q1.w & 0xffff); rx[3].a1 = (int16_t)(q1.w >> 16);
-  const int sxa = rx[0].sofs;
-  if (dx0 + 3 < dw && rx[3].sofs + 1 - sxa <= 7 && sxa + 8 <= sw) {
+  // the 8-byte source window starts at the first column's source pixel, pulled back at the end of the row so that it stays
+  // inside it; the x table is padded with copies of its last entry and the level's row pitch with 64-byte alignment, so the
+  // last (partial) group of a row takes this path too and stores a full word
+  const int sxa = imin(rx[0].sofs, sw - 8);
+  if (sw >= 8 && rx[3].sofs + 1 - sxa <= 7) {
     // all 4 kResizeRows source words are requested before the first one is used: a wave keeps 4 KB in flight, the
     // kernel is bound by the round trips per byte otherwise (one row per work-item ran at 1.2 TB/s)
     unsigned long long r0[kResizeRows], r1[kResizeRows];
@@ -348,99 +351,18 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
 // 7x7 Gaussian, sigma 2, OpenCV's 8.8 fixed-point kernel {18,34,48,56,48,34,18}; BORDER_REFLECT_101.
 // Tile = 128 x 32 outputs per workgroup.  Pass 1 reads the source rows straight from HBM as three 32-bit
 // words per 4 pixels and leaves the horizontal sums (exact 16-bit 8.8 values) in LDS; pass 2 gives every
-// work-item a 4 x 4 output block: ten 8-byte LDS reads, four 32-bit stores.
+// work-item a 4 x 4 output block: five 16-byte LDS reads, four 32-bit stores.
 // grid = (tiles per frame over all levels, B), block = 256.
 constexpr int kBlurTW = 128, kBlurTH = 32;
 struct BlurTiles { int tile_off[kMaxLevels + 1]; int tiles_x[kMaxLevels]; };
 
-__global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ geom, int n_levels, BlurTiles bt,
-                                                const uint8_t* __restrict__ img0, int pitch0, size_t frame0,
-                                                const uint8_t* __restrict__ pyr, size_t pyr_frame,
-                                                uint8_t* __restrict__ blur, size_t blur_frame, int tile_begin) {
-  __shared__ uint32_t s_h[(kBlurTH + 6) * (kBlurTW / 2)];  // two 16-bit horizontal sums per word
-  const int tid = threadIdx.x, bx = blockIdx.x + tile_begin, f = blockIdx.y;
-  int l = 0;
-  while (l + 1 < n_levels && bx >= bt.tile_off[l + 1]) ++l;
-  const LevelGeom& g = geom[l];
-  const int t = bx - bt.tile_off[l];
-  const int ty = t / bt.tiles_x[l], tx = t - ty * bt.tiles_x[l];
-  const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
-  const uint8_t* img = (l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
-  const int pitch = (l == 0) ? pitch0 : g.pitch;
-  const int W = g.w, H = g.h;
-
-  for (int task = tid; task < (kBlurTH + 6) * 32; task += 256) {
-    const int r = task >> 5, cg = task & 31;
-    const int x = x0 + 4 * cg;
-    if (x >= W) continue;
-    const uint8_t* row = img + (size_t)reflect101(y0 + r - 3, H) * pitch;
-    uint32_t w0, w1, w2;  // pixels x-4 .. x+7
-    if (x >= 4 && x + 8 <= W) {
-      w0 = load_u32_unaligned(row + x - 4);
-      w1 = load_u32_unaligned(row + x);
-      w2 = load_u32_unaligned(row + x + 4);
-    } else {
-      w0 = w1 = w2 = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        w0 |= (uint32_t)row[reflect101(x - 4 + k, W)] << (8 * k);
-        w1 |= (uint32_t)row[reflect101(x + k, W)] << (8 * k);
-        w2 |= (uint32_t)row[reflect101(x + 4 + k, W)] << (8 * k);
-      }
-    }
-    int p[12];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      p[k] = (w0 >> (8 * k)) & 0xff;
-      p[4 + k] = (w1 >> (8 * k)) & 0xff;
-      p[8 + k] = (w2 >> (8 * k)) & 0xff;
-    }
-    uint32_t hs[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      hs[i] = (uint32_t)(18 * (p[i + 1] + p[i + 7]) + 34 * (p[i + 2] + p[i + 6]) + 48 * (p[i + 3] + p[i + 5]) + 56 * p[i + 4]);
-    uint2 v;
-    v.x = hs[0] | (hs[1] << 16);
-    v.y = hs[2] | (hs[3] << 16);
-    *reinterpret_cast<uint2*>(&s_h[r * (kBlurTW / 2) + 2 * cg]) = v;
-  }
-  __syncthreads();
-  const int cg = tid & 31, rg = tid >> 5;
-  const int x = x0 + 4 * cg;
-  if (x >= W) return;
-  uint32_t hv[10][4];
-#pragma unroll
-  for (int j = 0; j < 10; ++j) {
-    const uint2 v = *reinterpret_cast<const uint2*>(&s_h[(4 * rg + j) * (kBlurTW / 2) + 2 * cg]);
-    hv[j][0] = v.x & 0xffff; hv[j][1] = v.x >> 16; hv[j][2] = v.y & 0xffff; hv[j][3] = v.y >> 16;
-  }
-#pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    const int y = y0 + 4 * rg + o;
-    if (y >= H) break;
-    uint32_t out = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t acc = 18u * (hv[o][i] + hv[o + 6][i]) + 34u * (hv[o + 1][i] + hv[o + 5][i]) +
-                           48u * (hv[o + 2][i] + hv[o + 4][i]) + 56u * hv[o + 3][i];
-      out |= ((acc + 32768u) >> 16) << (8 * i);
-    }
-    uint8_t* D = blur + (size_t)f * blur_frame + g.img_off + (size_t)y * g.pitch + x;
-    if (x + 3 < W) {
-      *reinterpret_cast<uint32_t*>(D) = out;
-    } else {
-      for (int i = 0; x + i < W; ++i) D[i] = (uint8_t)(out >> (8 * i));
-    }
-  }
-}
-
-// The same filter on the VALU's integer dot products.  Horizontal: a work-item owns 4 output columns of two rows; the
+// The filter runs on the VALU's integer dot products.  Horizontal: a work-item owns 4 output columns of two rows; the
 // seven taps of an output are two v_dot4_u32_u8 over byte-aligned windows (v_alignbyte_b32) of the row's three words with
 // the weights {18,34,48,56} / {48,34,18,0}.  The exact 16-bit sums of the two rows share a word (row pair j = rows 2j,
 // 2j + 1), so the vertical pass is four v_dot2_u32_u16 per output over five such words, the rounding constant being the
 // initial accumulator: even output rows take the weights (18,34)(48,56)(48,34)(18,0), odd ones (0,18)(34,48)(56,48)(34,18).
-// Same integers as above, about 10 instead of 25 VALU instructions per pixel.
-__global__ __launch_bounds__(256) void k_gauss7_dot(const LevelGeom* __restrict__ geom, int n_levels, BlurTiles bt,
+// About 10 VALU instructions per pixel (shifts, masks and multiply-adds on unpacked bytes took 25).
+__global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ geom, int n_levels, BlurTiles bt,
                                                     const uint8_t* __restrict__ img0, int pitch0, size_t frame0,
                                                     const uint8_t* __restrict__ pyr, size_t pyr_frame,
                                                     uint8_t* __restrict__ blur, size_t blur_frame, int tile_begin) {
@@ -458,28 +380,8 @@ __global__ __launch_bounds__(256) void k_gauss7_dot(const LevelGeom* __restrict_
   const int W = g.w, H = g.h;
   const uint32_t kWA = 18u | (34u << 8) | (48u << 16) | (56u << 24), kWB = 48u | (34u << 8) | (18u << 16);
 
-  for (int task = tid; task < kPairs * 32; task += 256) {
-    const int j = task >> 5, cg = task & 31;
-    const int x = x0 + 4 * cg;
-    if (x >= W) continue;
-    uint32_t w[2][3];  // per row the pixels x-4 .. x+7
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const uint8_t* row = img + __umul24((uint32_t)reflect101(y0 + 2 * j + rr - 3, H), (uint32_t)pitch);
-      if (x >= 4 && x + 8 <= W) {
-        w[rr][0] = load_u32_unaligned(row + x - 4);
-        w[rr][1] = load_u32_unaligned(row + x);
-        w[rr][2] = load_u32_unaligned(row + x + 4);
-      } else {
-        w[rr][0] = w[rr][1] = w[rr][2] = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          w[rr][0] |= (uint32_t)row[reflect101(x - 4 + k, W)] << (8 * k);
-          w[rr][1] |= (uint32_t)row[reflect101(x + k, W)] << (8 * k);
-          w[rr][2] |= (uint32_t)row[reflect101(x + 4 + k, W)] << (8 * k);
-        }
-      }
-    }
+  // one row pair x four columns: seven-tap sums of both rows from their three words each, stored as one 128-bit LDS write
+  auto h_sums = [&](const uint32_t (&w)[2][3], int j, int cg) {
     uint32_t hs[2][4];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -494,6 +396,46 @@ __global__ __launch_bounds__(256) void k_gauss7_dot(const LevelGeom* __restrict_
     v.x = hs[0][0] | (hs[1][0] << 16); v.y = hs[0][1] | (hs[1][1] << 16);
     v.z = hs[0][2] | (hs[1][2] << 16); v.w = hs[0][3] | (hs[1][3] << 16);
     *reinterpret_cast<uint4*>(&s_p[j * kBlurTW + 4 * cg]) = v;
+  };
+  // interior column groups: all six words requested before the first use.  The groups that touch the left or right border
+  // of the level are left to a second, compacted pass - inside this loop two lanes per wave would drag the other 62 through
+  // the byte-wise path in every iteration of every tile in the first and last tile column.
+  for (int task = tid; task < kPairs * 32; task += 256) {
+    const int j = task >> 5, cg = task & 31;
+    const int x = x0 + 4 * cg;
+    if (x < 4 || x + 8 > W) continue;
+    const uint8_t* row0 = img + __umul24((uint32_t)reflect101(y0 + 2 * j - 3, H), (uint32_t)pitch) + x;
+    const uint8_t* row1 = img + __umul24((uint32_t)reflect101(y0 + 2 * j - 2, H), (uint32_t)pitch) + x;
+    uint32_t w[2][3];
+    w[0][0] = load_u32_unaligned(row0 - 4); w[0][1] = load_u32_unaligned(row0); w[0][2] = load_u32_unaligned(row0 + 4);
+    w[1][0] = load_u32_unaligned(row1 - 4); w[1][1] = load_u32_unaligned(row1); w[1][2] = load_u32_unaligned(row1 + 4);
+    h_sums(w, j, cg);
+  }
+  // border column groups of this tile: group 0 of the first tile column, and the groups with x + 8 > W (at most two)
+  {
+    const int cg_last = imin(31, (W - 1 - x0) >> 2);                    // last group that holds a pixel of the level
+    const int cg_r0 = imax(0, imin(cg_last + 1, ((W - 8 - x0) >> 2) + 1));  // first group with x + 8 > W (W >= 8 always)
+    const int n_right = (x0 + 4 * cg_r0 + 8 > W) ? cg_last - cg_r0 + 1 : 0;
+    const int n_left = (x0 == 0 && cg_r0 > 0) ? 1 : 0;                  // x = 0 < 4 (when it is not a right-border group too)
+    const int n_edge = n_left + n_right;
+    for (int task = tid; task < kPairs * n_edge; task += 256) {
+      const int j = task / n_edge, e = task - j * n_edge;
+      const int cg = e < n_left ? 0 : cg_r0 + (e - n_left);
+      const int x = x0 + 4 * cg;
+      uint32_t w[2][3];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const uint8_t* row = img + __umul24((uint32_t)reflect101(y0 + 2 * j + rr - 3, H), (uint32_t)pitch);
+        w[rr][0] = w[rr][1] = w[rr][2] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          w[rr][0] |= (uint32_t)row[reflect101(x - 4 + k, W)] << (8 * k);
+          w[rr][1] |= (uint32_t)row[reflect101(x + k, W)] << (8 * k);
+          w[rr][2] |= (uint32_t)row[reflect101(x + 4 + k, W)] << (8 * k);
+        }
+      }
+      h_sums(w, j, cg);
+    }
   }
   __syncthreads();
   const int cg = tid & 31, rg = tid >> 5;
@@ -1451,11 +1393,11 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
     const LevelGeom& g = geom[lk];
     const uint8_t* img = (lk == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
     const int pitch = (lk == 0) ? pitch0 : g.pitch;
-    const uint8_t* src = img + (size_t)(y - 15) * pitch + (x - 15);
+    const uint8_t* src = img + (size_t)(y - 15) * pitch + (x - 15);  // wave-uniform
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int i = lane + 64 * j;
-      rawreg[k][j] = i < 31 * 8 ? load_u32_unaligned(src + (size_t)(i >> 3) * pitch + 4 * (i & 7)) : 0u;
+      const int i = lane + 64 * j;  // row offsets as full-rate 24-bit multiplies (a 64-bit multiply-add costs four issue slots)
+      rawreg[k][j] = i < 31 * 8 ? load_u32_unaligned(src + (__umul24((uint32_t)(i >> 3), (uint32_t)pitch) + (uint32_t)(4 * (i & 7)))) : 0u;
     }
   }
 #pragma unroll
@@ -1468,7 +1410,7 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
     for (int j = 0; j < 6; ++j) {
       const int i = lane + 64 * j;
       const int r = i / 10, c = i - r * 10;
-      blreg[k][j] = i < 37 * 10 ? load_u32_unaligned(bl + (size_t)r * g.pitch + 4 * c) : 0u;
+      blreg[k][j] = i < 37 * 10 ? load_u32_unaligned(bl + (__umul24((uint32_t)r, (uint32_t)g.pitch) + (uint32_t)(4 * c))) : 0u;
     }
   }
 

@@ -77,6 +77,13 @@ def test_compute_stereo_matches(emu_lib):
     assert pc.check_stereo_matches(emu_lib, w=640, h=300, nfeatures=1200) > 150
 
 
+def test_extractor_partial_tiles_and_reflected_borders(emu_lib):
+    # widths that leave a partial last column group / tile (the Gaussian's border pass, the resize's pulled-back window)
+    pc.check_extractor(emu_lib, 517, 389, 700, frames=(0,), seq=3, stages=True)
+    pc.check_extractor(emu_lib, 333, 217, 500, frames=(0,), nlevels=5, seq=4, stages=True)
+    pc.check_extractor(emu_lib, 514, 300, 600, frames=(0,), nlevels=6, seq=5, stages=True)
+
+
 @pytest.mark.parametrize("wg", ["256", "512"])
 def test_extractor_both_quadtree_workgroup_widths(emu_lib, wg):
     # the launch picks the 256-wide group for big batches and the 512-wide one otherwise; RGBL_OCTREE_WG pins it

@@ -8,11 +8,11 @@ OUT=$PWD/gpurun_out
 ( time timeout 540 python -m pytest tests -m gpu -q -n 4 ) > $OUT/tests.log 2>&1
 tail -3 $OUT/tests.log
 timeout 200 python bench.py > $OUT/bench_dot1.json 2> $OUT/bench_dot1.err
-RGBL_GAUSS_DOT=0 timeout 120 python bench.py --no-cpu-baseline > $OUT/bench_dot0.json 2> $OUT/bench_dot0.err
-RGBL_GAUSS_DOT=0 timeout 120 python -m pytest tests/test_parity_gpu.py -q -k "extractor" -n 4 > $OUT/tests_dot0.log 2>&1
+
+
 python - <<'PY'
 import json
-for n in ("bench_dot1", "bench_dot0"):
+for n in ("bench_dot1",):
     try:
         d = json.loads(open("gpurun_out/%s.json" % n).read().strip().splitlines()[-1])
         print(n, round(d["value"]), d["parity_spot_check"], {k: round(v, 3) for k, v in d["roofline"]["kernels_ms_per_step"].items()})
