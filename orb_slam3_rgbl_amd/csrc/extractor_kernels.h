@@ -1378,9 +1378,13 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
   if (vmask == 0) return;  // wave-uniform
 
   // the lane's four pattern pairs (x0, y0, x1, y1 as signed bytes), the same for every keypoint
-  uint32_t pw[4];
+  f32x2 px[4], py[4];  // (x0, x1) and (y0, y1) of the lane's pairs
 #pragma unroll
-  for (int k = 0; k < 4; ++k) pw[k] = reinterpret_cast<const uint32_t*>(pattern)[k * 64 + lane];
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t pw = reinterpret_cast<const uint32_t*>(pattern)[k * 64 + lane];
+    px[k] = f32x2{(float)(int8_t)(pw & 0xff), (float)(int8_t)((pw >> 16) & 0xff)};
+    py[k] = f32x2{(float)(int8_t)((pw >> 8) & 0xff), (float)(int8_t)(pw >> 24)};
+  }
 
   // ---- all patch words of all keypoints are requested first (one exposed memory latency per wave instead of one per
   //      keypoint and pass): 4 + 6 registers per keypoint.  Keypoints sit >= 19 px inside the level, so x-15..x+16 and
@@ -1478,14 +1482,22 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
     for (int j = 0; j < 6; ++j)
       if (lane + 64 * j < 37 * 10) s_patch_w[wave][lane + 64 * j] = blreg[k][j];
     wave_sync();
-    const uint8_t* center = patch + 18 * 40 + 18;
+    // Two points of a pair side by side in packed fp32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per instruction,
+    // no contraction): x a - y b and x b + y a as in computeOrbDescriptor (ORBextractor.cc:118-119).  cvRound = adding
+    // 1.5 * 2^23 (round-half-even lands in the mantissa; |coordinate| < 2^22); the two biased integers go straight into
+    // one 24-bit multiply-add, the biases leave with one constant.
+    const f32x2 av = {a, a}, bv = {b, b}, magic = {12582912.0f, 12582912.0f};
+    constexpr int kBias = 0x400000 * 40 + 0x4B400000;  // (low 24 bits of the biased row) * 40 + the biased column
     unsigned long long bits[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float x0 = (float)(int8_t)(pw[q] & 0xff), y0 = (float)(int8_t)((pw[q] >> 8) & 0xff),
-                  x1 = (float)(int8_t)((pw[q] >> 16) & 0xff), y1 = (float)(int8_t)(pw[q] >> 24);
-      const int t0 = center[cv_round_f(x0 * b + y0 * a) * 40 + cv_round_f(x0 * a - y0 * b)];
-      const int t1 = center[cv_round_f(x1 * b + y1 * a) * 40 + cv_round_f(x1 * a - y1 * b)];
+      const f32x2 rx = px[q] * av - py[q] * bv;
+      const f32x2 ry = px[q] * bv + py[q] * av;
+      const f32x2 cx = rx + magic, cy = ry + magic;
+      const int i0 = __mul24(__float_as_int(cy[0]), 40) + __float_as_int(cx[0]) - kBias;
+      const int i1 = __mul24(__float_as_int(cy[1]), 40) + __float_as_int(cx[1]) - kBias;
+      const int t0 = patch[18 * 40 + 18 + i0];
+      const int t1 = patch[18 * 40 + 18 + i1];
       bits[q] = __ballot(t0 < t1);
     }
     if (lane < 4) {

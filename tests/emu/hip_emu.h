@@ -51,6 +51,7 @@ struct float4 { float x, y, z, w; };
 struct int4 { int x, y, z, w; };
 inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 inline int4 make_int4(int x, int y, int z, int w) { int4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
 namespace hipemu {
 
@@ -190,6 +191,7 @@ template <class T> inline T __shfl_down(T v, unsigned delta, int width = 64) {
 
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // wave-uniform by construction where it is used
 inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+inline int __mul24(int a, int b) { return (int)((unsigned)(((a << 8) >> 8)) * (unsigned)(((b << 8) >> 8))); }  // signed 24-bit operands
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
