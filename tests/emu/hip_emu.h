@@ -191,7 +191,10 @@ template <class T> inline T __shfl_down(T v, unsigned delta, int width = 64) {
 
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // wave-uniform by construction where it is used
 inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
-inline int __mul24(int a, int b) { return (int)((unsigned)(((a << 8) >> 8)) * (unsigned)(((b << 8) >> 8))); }  // signed 24-bit operands
+inline int __mul24(int a, int b) {  // signed 24-bit operands
+  const int x = (int)((unsigned)a << 8) >> 8, y = (int)((unsigned)b << 8) >> 8;
+  return (int)((unsigned)x * (unsigned)y);
+}
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

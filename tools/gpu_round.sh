@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call: GPU parity tests, the bench line (both Gaussian variants), rocprofv3 kernel stats and the two HBM counter
+# One gpurun call: GPU parity tests, the bench line, rocprofv3 kernel stats and the two HBM counter
 # passes.  Everything lands in gpurun_out/.  Usage: gpurun --timeout 1080 -- 'bash tools/gpu_round.sh'
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
@@ -7,12 +7,12 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 ( time timeout 540 python -m pytest tests -m gpu -q -n 4 ) > $OUT/tests.log 2>&1
 tail -3 $OUT/tests.log
-timeout 200 python bench.py > $OUT/bench_dot1.json 2> $OUT/bench_dot1.err
+timeout 200 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 
 
 python - <<'PY'
 import json
-for n in ("bench_dot1",):
+for n in ("bench",):
     try:
         d = json.loads(open("gpurun_out/%s.json" % n).read().strip().splitlines()[-1])
         print(n, round(d["value"]), d["parity_spot_check"], {k: round(v, 3) for k, v in d["roofline"]["kernels_ms_per_step"].items()})
