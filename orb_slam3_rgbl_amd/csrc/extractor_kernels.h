@@ -128,14 +128,18 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
     }
     return;
   }
-  // row ends / large scale factors: byte path
-  for (int r = 0; r < kResizeRows && dy0 + r < dh; ++r) {
+  // large scale factors / sources narrower than 8 px: byte path (unrolled with compile-time r: a run-time index into ry[]
+  // makes the compiler park the array in LDS, 16 KB per workgroup, for the common path as well)
+#pragma unroll
+  for (int r = 0; r < kResizeRows; ++r) {
+    if (dy0 + r >= dh) break;
     const int sy0 = imin(imax(ry[r].sofs, 0), sh - 1), sy1 = imin(imax(ry[r].sofs + 1, 0), sh - 1);
     const uint8_t* S0 = S + (size_t)sy0 * spitch;
     const uint8_t* S1 = S + (size_t)sy1 * spitch;
     const int b0 = ry[r].a0, b1 = ry[r].a1;
     uint8_t* Dr = D + (size_t)r * dpitch;
     uint32_t out = 0;
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int dx = dx0 + i;
       if (dx >= dw) break;
