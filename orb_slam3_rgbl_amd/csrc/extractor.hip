@@ -60,8 +60,7 @@ struct rgbl_extractor {
   int graph_batch = 0, graph_stride = 0, graph_lap0 = 0, graph_lap1 = 0;
   hipStream_t graph_stream = nullptr;
   bool graph_ok = true;  // RGBL_GRAPH=0 or a failed capture switch the replay off
-  int octree_wg = 0;
-  int resize_rows = 4;  // output rows per work-item of k_resize_linear (RGBL_RESIZE_ROWS: 1, 2 or 4)  // 0 = choose per launch; RGBL_OCTREE_WG=256|512 pins the quad-tree workgroup width (tuning / tests)
+  int octree_wg = 0;  // 0 = choose per launch; RGBL_OCTREE_WG=256|512 pins the quad-tree workgroup width (tuning / tests)
   int max_cell = 0;  // largest detection-cell side over the levels: selects the k_fast_cells instantiation
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> per_level;
@@ -387,7 +386,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
     const int spitch = (l == 1) ? stride : p.pitch;
     const size_t sframe = (l == 1) ? frame_stride : e->pyr_frame;
     e->timer.begin("k_resize_linear", s);
-    hipLaunchKernelGGL(k_resize_linear, dim3((g.w + 255) / 256, (g.h + 4 * kResizeRows - 1) / (4 * kResizeRows), batch), dim3(256),
+    hipLaunchKernelGGL(k_resize_linear, dim3((g.w + 4 * kResizeLanes - 1) / (4 * kResizeLanes), (g.h + 4 * kResizeRows - 1) / (4 * kResizeRows), batch), dim3(kResizeWG),
                        0, s, src, spitch, sframe, p.w, p.h, e->d_pyr + g.img_off, g.pitch, e->pyr_frame, g.w, g.h,
                        e->d_xtab + g.xtab_off, e->d_ytab + g.ytab_off);
     e->timer.end(s);
