@@ -154,6 +154,23 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// Sum of an int over the 64 lanes as a wave-uniform value: four DPP steps inside the rows of 16 (quad swaps, half-row and
+// row mirror), two row broadcasts, one v_readlane - register-file traffic only (wave_sum's __shfl_xor is six ds_bpermute
+// round trips through the LDS crossbar).
+__device__ __forceinline__ int wave_sum_uniform(int v) {
+#ifdef RGBL_EMU
+  return __shfl(wave_sum(v), 0);
+#else
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);  // row_mirror: every lane holds its row's sum
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+#endif
+}
+
 // Exclusive prefix sum over the 256 work-items of a workgroup (4 waves). `scratch` holds >= 8 values.
 // Returns the exclusive prefix of `v`; *total receives the workgroup sum. Contains two barriers.
 template <class T>

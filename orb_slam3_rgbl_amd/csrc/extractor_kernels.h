@@ -1467,8 +1467,8 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
       m10 = (int)sum1 - ic_off * (int)sum0;   // sum of u p with u = q - 15 (half 0) or q + 1 (half 1)
       m01 = ((lane >> 1) - 15) * (int)sum0;
     }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
+    m10 = wave_sum_uniform(m10);
+    m01 = wave_sum_uniform(m01);
     if (lane == k) { my_m10 = m10; my_m01 = m01; }
   }
 
