@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_project_write(ProjParams P, const float
 // 64x16 output tile per workgroup; the inverted tile + halo is staged in LDS.
 // kRadius > 0: the reference's Diamond structuring element |dx|+|dy| <= kRadius with compile-time taps (all
 // LDS reads of a pixel are issued back to back); kRadius == 0: arbitrary mask, tap offsets held in LDS.
-// grid = (ceil(w/64), ceil(h/16), B), block = 256.
+// grid = (ceil(w/64), ceil(h/32), B), block = 256.
 // kIndexed: the raw depth map is never written; a pixel's raw depth is looked up as pt_depth[idx_map[pixel] - 1]
 // (0 where no point fell), which saves the map's zero fill, k_project_write and one map-sized round trip through HBM.
 template <int kRadius, bool kIndexed>
@@ -122,13 +122,14 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
                                                         const uint32_t* __restrict__ idx_map, const float* __restrict__ pt_depth,
                                                         size_t pt_stride, uint32_t tag, float* __restrict__ out, size_t map_stride,
                                                         int w, int h) {
-  __shared__ float s_inv[24 * 72];
+  constexpr int kTileH = 32;  // 64 x 32 outputs per workgroup: (68 x 36) / 2048 = 1.20 tile elements read per output at radius 2 (1.33 with 16 rows)
+  __shared__ float s_inv[(kTileH + 8) * 72];
   __shared__ int s_tap[81];
   __shared__ int s_ntap;
   const int tid = threadIdx.x, f = blockIdx.z;
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * kTileH;
   const int ax = kRadius > 0 ? kRadius : K.kw / 2, ay = kRadius > 0 ? kRadius : K.kh / 2;
-  const int tw = kRadius > 0 ? 64 + 2 * kRadius : 64 + K.kw - 1, th = kRadius > 0 ? 16 + 2 * kRadius : 16 + K.kh - 1;
+  const int tw = kRadius > 0 ? 64 + 2 * kRadius : 64 + K.kw - 1, th = kRadius > 0 ? kTileH + 2 * kRadius : kTileH + K.kh - 1;
   const float thr = S - 1;
   const float* R = kIndexed ? nullptr : raw + (size_t)f * map_stride;
   const uint32_t* I = kIndexed ? idx_map + (size_t)f * map_stride : nullptr;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
   if (kRadius > 0) {
     // compile-time tile: every load of a work-item's 5-6 elements is requested before the first is used, the indexed
     // variant then requests all its depth look-ups together (the kernel is bound by round trips, not by bytes)
-    constexpr int kTw = 64 + 2 * kRadius, kTh = 16 + 2 * kRadius, kIter = (kTw * kTh + 255) / 256;
+    constexpr int kTw = 64 + 2 * kRadius, kTh = kTileH + 2 * kRadius, kIter = (kTw * kTh + 255) / 256;
     bool inside[kIter];
     size_t at[kIter];
     float raw_v[kIter];
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
   }
   __syncthreads();
   const int x = tid & 63;
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < kTileH / 4; ++k) {
     const int y = (tid >> 6) + 4 * k;
     if (x0 + x >= w || y0 + y >= h) continue;
     float m = -FLT_MAX;
@@ -398,11 +399,12 @@ int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, 
     }
   }
   const dim3 tiles((w + 63) / 64, (h + 15) / 16, batch);
+  const dim3 dilate_tiles((w + 63) / 64, (h + 31) / 32, batch);  // k_inverse_dilate works on 64 x 32 tiles
   switch (e->cfg.method) {
     case RGBL_UPS_INVERSE_DILATION:
       e->timer.begin("k_inverse_dilate", s);
       // opt_max_dist * ParamUpsampling_InverseDilation_ScaleFactor; the scale factor is never parsed (1.0)
-#define RGBL_DILATE(R, I) hipLaunchKernelGGL((k_inverse_dilate<R, I>), tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, \
+#define RGBL_DILATE(R, I) hipLaunchKernelGGL((k_inverse_dilate<R, I>), dilate_tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, \
                                             e->d_idx, e->d_ptdepth, pt_stride, tag, e->d_proc, ms, w, h)
       if (indexed) {
         switch (e->diamond_radius) {
