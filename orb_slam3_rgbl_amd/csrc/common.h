@@ -96,6 +96,13 @@ __device__ __forceinline__ unsigned long long rgbl_clock() {
   return (unsigned long long)__builtin_readcyclecounter();
 #endif
 }
+#ifdef RGBL_EMU
+typedef emu_v4i v4i;    // matrix-core operand: 16 signed bytes per lane
+typedef emu_v16i v16i;  // matrix-core accumulator of a 32 x 32 tile: 16 x i32 per lane
+#else
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+#endif
 typedef float f32x2 __attribute__((vector_size(8)));  // two fp32 lanes of one packed VALU operation
 // integer dot products and byte shuffles of the VALU (v_dot4_u32_u8, v_dot2_u32_u16, v_alignbyte_b32, v_perm_b32)
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {  // sum of the four byte products + c

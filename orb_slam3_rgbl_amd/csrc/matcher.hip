@@ -13,6 +13,7 @@
 //                         candidate wins, as in the reference) with the eligibility masks and epipolar test.
 #include <limits.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <math.h>
 #include <string.h>
 
@@ -108,6 +109,171 @@ __global__ __launch_bounds__(256) void k_hamming_bf(const uint8_t* __restrict__ 
     best_idx[o] = best == kNone ? -1 : (int32_t)(best & 0xffffu);
     best_dist[o] = (int32_t)(best >> 16);
     if (second_dist) second_dist[o] = (int32_t)(second >> 16);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same all-pairs scan on the matrix cores.  With the bits of a descriptor expanded to signed bytes,
+//   train bit a -> 64 (1 - 2a),   query bit b -> -64 (1 - 2b),
+// a 256-long i8 dot product is 4096 (#different - #equal) = 8192 * hamming - 2^20: v_mfma_i32_32x32x32_i8 delivers, per
+// instruction, 32 of the 256 bit positions of 32 train x 32 query pairs, eight chained instructions the whole distance.
+// The accumulator starts at 2^20 + (row of the tile), so what comes out IS the tracking key of k_hamming_bf - distance
+// above the index, here (distance << 13 | row) - and the epilogue is v_med3 + v_min per pair, nothing else.
+//   * Tile t's rows are 32 t + row; instead of adding 32 t to 16 accumulators the two running keys of a lane are lowered by
+//     32 per tile (signed compares), which orders (distance, index) pairs exactly as the absolute keys would; 13 index bits
+//     = sweeps of 8192 train descriptors, decoded and merged into (distance << 16 | index) words after each sweep.
+//   * The position of a bit inside the K = 256 sum is free as long as both operands agree, so the expansion is chosen for
+//     the VALU: dword w of a descriptor feeds MFMA step w, and byte c of its q-th expanded dword is bit 8c + q of it:
+//     ((x << (7 - q)) & 0x80808080) | 0x40404040 (0xC0 = -64, 0x40 = +64), two operations per four operand bytes.
+//   * Query tiles (the B operand, the D columns) live in VGPRs for the whole scan: 64 queries per wave, 256 per workgroup.
+//     Train rows are expanded once per workgroup into LDS, 64 rows per stage, double buffered (one barrier per stage), rows
+//     272 B apart so that the 16-byte fragment reads of a wave spread over all banks; every fragment feeds two MFMAs.
+// D layout (gfx950, all 32 x 32 shapes): lane l holds column l & 31, register r row (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+// grid = (ceil(cap / 256), n_pairs), block = 256.  Same arguments and results as k_hamming_bf.
+constexpr int kBfQueriesPerBlock = 256;
+constexpr int kBfStageRows = 64;
+constexpr int kBfRowBytes = 272;
+constexpr int kBfSweep = 8192;
+constexpr int kBfIdle = 0x3fffffff;
+
+__device__ __forceinline__ v4i bf_expand4(uint32_t x, int q0) {
+  v4i r;
+  r[0] = (int)(((x << (7 - q0)) & 0x80808080u) | 0x40404040u);
+  r[1] = (int)(((x << (6 - q0)) & 0x80808080u) | 0x40404040u);
+  r[2] = (int)(((x << (5 - q0)) & 0x80808080u) | 0x40404040u);
+  r[3] = (int)(((x << (4 - q0)) & 0x80808080u) | 0x40404040u);
+  return r;
+}
+__device__ __forceinline__ void bf_track_rel(int& best, int& second, int cur) {
+#ifdef RGBL_EMU
+  const int hi = best > cur ? best : cur;
+  second = second < hi ? second : hi;
+#else
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(second) : "v"(best), "v"(cur), "v"(second));
+#endif
+  best = best < cur ? best : cur;
+}
+__device__ __forceinline__ void bf_merge(uint32_t& best, uint32_t& second, uint32_t ob, uint32_t os) {
+  const uint32_t hi = best > ob ? best : ob;
+  best = best < ob ? best : ob;
+  second = second < os ? second : os;
+  second = second < hi ? second : hi;
+}
+
+__global__ __launch_bounds__(256) void k_hamming_mfma(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_rows,
+                                                      int cap, const int32_t* __restrict__ pair_a,
+                                                      const int32_t* __restrict__ pair_b, int32_t* __restrict__ best_idx,
+                                                      int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_rows[2][kBfStageRows * kBfRowBytes];
+  const int p = blockIdx.y;
+  const int fa = pair_a ? pair_a[p] : 0, fb = pair_b ? pair_b[p] : 1;
+  const int na = n_rows[fa], nb = n_rows[fb];
+  const int q_base = blockIdx.x * kBfQueriesPerBlock;
+  if (q_base >= na) return;
+  const int tid = threadIdx.x, lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(wave_id());
+  const int col = lane & 31, half = lane >> 5;
+  const bool wave_has_queries = q_base + wave * 64 < na;
+
+  // query fragments: two 32-column tiles, eight K steps each
+  v4i bq[2][8];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int qi = q_base + wave * 64 + ct * 32 + col;
+    const uint4* src = reinterpret_cast<const uint4*>(desc + ((size_t)fa * cap + (qi < na ? qi : 0)) * 32);
+    const uint4 lo = src[0], hi = src[1];
+    const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bq[ct][s] = bf_expand4(~x[s], 4 * half);
+  }
+  v16i c_init;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c_init[r] = (1 << 20) + (r & 3) + 8 * (r >> 2) + 4 * half;
+
+  const uint32_t* __restrict__ train = reinterpret_cast<const uint32_t*>(desc + (size_t)fb * cap * 32);
+  const uint32_t kNone = (256u << 16) | 0xffffu;
+  uint32_t out_best[2] = {kNone, kNone}, out_second[2] = {kNone, kNone};
+
+  // stage s of the whole scan = train rows [64 s, 64 s + 64); work-item tid expands dwords tid and tid + 256 of it
+  const int n_stages = (nb + kBfStageRows - 1) / kBfStageRows;
+  auto load_stage = [&](int stage, uint32_t& x0, uint32_t& x1) {
+    const int d0 = stage * (kBfStageRows * 8) + tid, d1 = d0 + 256;
+    x0 = (d0 >> 3) < nb ? train[d0] : 0u;
+    x1 = (d1 >> 3) < nb ? train[d1] : 0u;
+  };
+  uint32_t nx0 = 0, nx1 = 0;
+  if (n_stages > 0) load_stage(0, nx0, nx1);
+  int best[2] = {kBfIdle, kBfIdle}, second[2] = {kBfIdle, kBfIdle};
+  int tiles_in_sweep = 0;
+  auto close_sweep = [&](int sweep_base) {
+    // relative keys -> (distance << 16 | absolute index), folded into the results of the earlier sweeps
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int off = 32 * (tiles_in_sweep - 1);
+      const int kb = best[ct] + off, ks = second[ct] + off;
+      const uint32_t wb = kb >= (257 << 13) ? kNone : ((uint32_t)(kb >> 13) << 16) | (uint32_t)(sweep_base + (kb & 8191));
+      const uint32_t ws = ks >= (257 << 13) ? kNone : ((uint32_t)(ks >> 13) << 16) | (uint32_t)(sweep_base + (ks & 8191));
+      bf_merge(out_best[ct], out_second[ct], wb, ws);
+      best[ct] = second[ct] = kBfIdle;
+    }
+    tiles_in_sweep = 0;
+  };
+  for (int stage = 0; stage < n_stages; ++stage) {
+    uint8_t* buf = s_rows[stage & 1];
+    const uint32_t x0 = nx0, x1 = nx1;
+    if (stage + 1 < n_stages) load_stage(stage + 1, nx0, nx1);
+    {
+      uint8_t* r0 = buf + (tid >> 3) * kBfRowBytes + (tid & 7) * 32;
+      uint8_t* r1 = r0 + 32 * kBfRowBytes;
+      *reinterpret_cast<v4i*>(r0) = bf_expand4(x0, 0);
+      *reinterpret_cast<v4i*>(r0 + 16) = bf_expand4(x0, 4);
+      *reinterpret_cast<v4i*>(r1) = bf_expand4(x1, 0);
+      *reinterpret_cast<v4i*>(r1 + 16) = bf_expand4(x1, 4);
+    }
+    __syncthreads();
+    if (!wave_has_queries) continue;
+#pragma unroll 1
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row0 = stage * kBfStageRows + rt * 32;  // first train row of the tile
+      if (row0 >= nb) break;
+      const uint8_t* frag = buf + (rt * 32 + col) * kBfRowBytes + half * 16;
+      v16i acc0 = c_init, acc1 = c_init;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const v4i a = *reinterpret_cast<const v4i*>(frag + s * 32);
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s], acc1, 0, 0, 0);
+      }
+      best[0] -= 32; second[0] -= 32; best[1] -= 32; second[1] -= 32;
+      ++tiles_in_sweep;
+      if (row0 + 32 <= nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { bf_track_rel(best[0], second[0], acc0[r]); bf_track_rel(best[1], second[1], acc1[r]); }
+      } else {  // the last tile of the train set: rows beyond it never win
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool live = row0 + (r & 3) + 8 * (r >> 2) + 4 * half < nb;
+          bf_track_rel(best[0], second[0], live ? acc0[r] : kBfIdle);
+          bf_track_rel(best[1], second[1], live ? acc1[r] : kBfIdle);
+        }
+      }
+      if (((row0 + 32) & (kBfSweep - 1)) == 0) close_sweep(row0 + 32 - kBfSweep);
+    }
+  }
+  if (!wave_has_queries) return;
+  if (tiles_in_sweep > 0) close_sweep(((nb - 1) / kBfSweep) * kBfSweep);
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    // the two halves of the wave hold the same columns, interleaved groups of four rows
+    const uint32_t ob = __shfl_xor(out_best[ct], 32), os = __shfl_xor(out_second[ct], 32);
+    bf_merge(out_best[ct], out_second[ct], ob, os);
+    const int qi = q_base + wave * 64 + ct * 32 + col;
+    if (half == 0 && qi < na) {
+      const size_t o = (size_t)p * cap + qi;
+      best_idx[o] = out_best[ct] == kNone ? -1 : (int32_t)(out_best[ct] & 0xffffu);
+      best_dist[o] = (int32_t)(out_best[ct] >> 16);
+      if (second_dist) second_dist[o] = (int32_t)(out_second[ct] >> 16);
+    }
   }
 }
 
@@ -904,6 +1070,11 @@ int ensure_arena(rgbl_matcher* m, size_t bytes) {
   m->buf_size = sz;
   return RGBL_OK;
 }
+// RGBL_BF_MFMA=0 selects the VALU popcount scan (k_hamming_bf) instead of the matrix-core one (A/B measurements)
+inline bool bf_on_matrix_cores() {
+  static const bool on = [] { const char* e = getenv("RGBL_BF_MFMA"); return !(e && e[0] == '0'); }();
+  return on;
+}
 struct Arena {
   uint8_t* base; size_t off = 0;
   template <class T> T* take(size_t count) {
@@ -1006,9 +1177,15 @@ int rgbl_hamming_bf_batch_device(rgbl_matcher* m, const uint8_t* d_desc, const i
   }
   if (n_pairs == 0) return RGBL_OK;
   RGBL_HIP(hipSetDevice(m->device));
-  m->timer.begin("k_hamming_bf", m->stream);
-  hipLaunchKernelGGL(k_hamming_bf, dim3((cap + 63) / 64, n_pairs), dim3(256), 0, m->stream, d_desc, d_n, cap, d_pair_a,
-                     d_pair_b, d_best_idx, d_best_dist, d_second_dist);
+  if (bf_on_matrix_cores()) {
+    m->timer.begin("k_hamming_mfma", m->stream);
+    hipLaunchKernelGGL(k_hamming_mfma, dim3((cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
+                       d_desc, d_n, cap, d_pair_a, d_pair_b, d_best_idx, d_best_dist, d_second_dist);
+  } else {
+    m->timer.begin("k_hamming_bf", m->stream);
+    hipLaunchKernelGGL(k_hamming_bf, dim3((cap + 63) / 64, n_pairs), dim3(256), 0, m->stream, d_desc, d_n, cap, d_pair_a,
+                       d_pair_b, d_best_idx, d_best_dist, d_second_dist);
+  }
   m->timer.end(m->stream);
   RGBL_HIP(hipGetLastError());
   return RGBL_OK;
@@ -1035,10 +1212,16 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   RGBL_HIP(hipMemcpyAsync(d_desc, desc_a, (size_t)na * 32, hipMemcpyHostToDevice, s));
   if (nb > 0) RGBL_HIP(hipMemcpyAsync(d_desc + (size_t)cap * 32, desc_b, (size_t)nb * 32, hipMemcpyHostToDevice, s));
   RGBL_HIP(hipMemcpyAsync(d_n, counts, sizeof(counts), hipMemcpyHostToDevice, s));
-  m->timer.begin("k_hamming_bf", s);
   // pair_a/pair_b == NULL selects the fixed pair (frame 0 -> frame 1)
-  hipLaunchKernelGGL(k_hamming_bf, dim3((na + 63) / 64, 1), dim3(256), 0, s, d_desc, d_n, cap, (const int32_t*)nullptr,
-                     (const int32_t*)nullptr, d_bi, d_bd, d_sd);
+  if (bf_on_matrix_cores()) {
+    m->timer.begin("k_hamming_mfma", s);
+    hipLaunchKernelGGL(k_hamming_mfma, dim3((na + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, 1), dim3(256), 0, s, d_desc, d_n, cap,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, d_bi, d_bd, d_sd);
+  } else {
+    m->timer.begin("k_hamming_bf", s);
+    hipLaunchKernelGGL(k_hamming_bf, dim3((na + 63) / 64, 1), dim3(256), 0, s, d_desc, d_n, cap, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, d_bi, d_bd, d_sd);
+  }
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
   RGBL_HIP(hipMemcpyAsync(best_idx, d_bi, sizeof(int32_t) * na, hipMemcpyDeviceToHost, s));

@@ -79,6 +79,7 @@ struct Block {
   Rendezvous bar;               // __syncthreads
   std::vector<Rendezvous> wbar; // per wave collectives
   std::vector<unsigned long long> slot;  // exchange slots, one per work-item
+  std::vector<unsigned char> wide;       // 32-byte exchange slots, one per work-item (matrix-core operands)
   unsigned phase = 0;
   std::function<void()> body;
   Fiber* cur = nullptr;
@@ -189,6 +190,33 @@ template <class T> inline T __shfl_down(T v, unsigned delta, int width = 64) {
   return emu_shfl_generic(v, src);
 }
 
+// v_mfma_i32_32x32x32_i8: D = A * B + C on a 32 x 32 tile with K = 32, one instruction per wave.  Operand layout as on
+// gfx950: lane l holds 16 consecutive k of row (A) / column (B) l & 31, the k-block chosen by l >> 5; lane l receives
+// column l & 31 of D, register r = row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
+typedef int emu_v4i __attribute__((vector_size(16)));
+typedef int emu_v16i __attribute__((vector_size(64)));
+inline emu_v16i __builtin_amdgcn_mfma_i32_32x32x32_i8(emu_v4i a, emu_v4i b, emu_v16i c, int, int, int) {
+  hipemu::Block* blk = hipemu::cur_block();
+  const int w = hipemu::wave_id(), lane = hipemu::lane_id();
+  unsigned char* base = &blk->wide[(size_t)w * 64 * 32];
+  std::memcpy(base + lane * 32, &a, 16);
+  std::memcpy(base + lane * 32 + 16, &b, 16);
+  hipemu::rendezvous(blk->wbar[2 * w], blk->wave_active[w]);
+  emu_v16i d = c;
+  const int col = lane & 31;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    int acc = 0;
+    for (int g = 0; g < 2; ++g) {
+      const signed char* pa = (const signed char*)(base + (row + 32 * g) * 32);
+      const signed char* pb = (const signed char*)(base + (col + 32 * g) * 32 + 16);
+      for (int k = 0; k < 16; ++k) acc += (int)pa[k] * (int)pb[k];
+    }
+    d[r] += acc;
+  }
+  hipemu::rendezvous(blk->wbar[2 * w + 1], blk->wave_active[w]);
+  return d;
+}
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // wave-uniform by construction where it is used
 inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline int __mul24(int a, int b) {  // signed 24-bit operands
@@ -342,6 +370,7 @@ void run_block(Block& b, const dim3& block) {
   b.wbar.assign(2 * nw, Rendezvous());
   b.bar = Rendezvous();
   b.slot.assign((size_t)nw * 64, 0);
+  b.wide.assign((size_t)nw * 64 * 32, 0);
   b.phase = 0;
   for (int t = 0; t < T; ++t) {
     Fiber& f = b.fibers[t];

@@ -216,6 +216,17 @@ def check_matcher_known_answers(lib):
         t[0, bit // 8] = 1 << (bit % 8)
         bi, bd, sd = m.BruteForce(t, np.concatenate([o, z]))
         assert (bi[0], bd[0], sd[0]) == (1, 1, 255)
+    # equal distances in different rows of one 32-row tile, in neighbouring tiles, stages and 8192-row sweeps of the
+    # matrix-core scan: the lowest index still wins and the second-best distance equals the best
+    one = z.copy(); one[0, 5] = 0x10
+    for first, other, n in ((3, 4, 9), (4, 3, 40), (31, 32, 70), (63, 64, 130), (40, 8200, 8300), (8191, 8192, 8200), (0, 8299, 8300)):
+        train = np.repeat(o, n, 0)
+        train[first] = one; train[other] = one
+        bi, bd, sd = m.BruteForce(z, train)
+        assert (bi[0], bd[0], sd[0]) == (min(first, other), 1, 1), (first, other, bi, bd, sd)
+        train[other] = o
+        bi, bd, sd = m.BruteForce(z, train)
+        assert (bi[0], bd[0], sd[0]) == (first, 1, 256), (first, other, bi, bd, sd)
     # empty train set: nothing found
     bi, bd, sd = m.BruteForce(z, np.zeros((0, 32), np.uint8))
     assert (bi[0], bd[0], sd[0]) == (-1, 256, 256)
