@@ -131,6 +131,54 @@ __device__ __forceinline__ uint32_t align_bytes(uint32_t hi, uint32_t lo, int sh
   return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)shift);
 #endif
 }
+// v_perm_b32: byte i of the result is byte sel[i] of the 8 bytes hi:lo (0-3 = lo, 4-7 = hi), 0x0c gives 0x00
+__device__ __forceinline__ uint32_t perm_bytes(uint32_t hi, uint32_t lo, uint32_t sel) {
+#ifdef RGBL_EMU
+  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t s = (sel >> (8 * i)) & 0xffu;
+    const uint32_t b = s < 8 ? (uint32_t)(v >> (8 * s)) & 0xffu : s == 0x0c ? 0u : s > 0x0c ? 0xffu : ((v >> (16 * (s - 8) + 15)) & 1 ? 0xffu : 0u);
+    r |= b << (8 * i);
+  }
+  return r;
+#else
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#endif
+}
+// packed 16-bit VALU operations on two unsigned halves of a word (v_pk_min_u16, v_pk_max_u16, v_pk_sub_u16 clamp)
+#ifdef RGBL_EMU
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  const uint32_t l = (a & 0xffffu) < (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu), h = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+  return l | (h << 16);
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  const uint32_t l = (a & 0xffffu) > (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu), h = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
+  return l | (h << 16);
+}
+__device__ __forceinline__ uint32_t pk_subs_u16(uint32_t a, uint32_t b) {  // saturating a - b per half
+  const uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16;
+  return (al > bl ? al - bl : 0u) | ((ah > bh ? ah - bh : 0u) << 16);
+}
+#else
+typedef unsigned short rgbl_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rgbl_us2 as_us2(uint32_t a) { rgbl_us2 x; __builtin_memcpy(&x, &a, 4); return x; }
+__device__ __forceinline__ uint32_t from_us2(rgbl_us2 x) { uint32_t a; __builtin_memcpy(&a, &x, 4); return a; }
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { return from_us2(__builtin_elementwise_min(as_us2(a), as_us2(b))); }
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) { return from_us2(__builtin_elementwise_max(as_us2(a), as_us2(b))); }
+__device__ __forceinline__ uint32_t pk_subs_u16(uint32_t a, uint32_t b) { return from_us2(__builtin_elementwise_sub_sat(as_us2(a), as_us2(b))); }
+#endif
+// dynamic LDS of a kernel (sized per launch); the emulator gives every workgroup thread a buffer of the hardware's size
+#ifdef RGBL_EMU
+#define RGBL_DYN_SHARED(T, name) static thread_local T name[(160 * 1024) / sizeof(T)]
+#else
+#define RGBL_DYN_SHARED(T, name) extern __shared__ T name[]
+#endif
+__device__ __forceinline__ uint32_t load_u32_any(const uint8_t* p) {  // global or LDS, no alignment needed on gfx950
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
