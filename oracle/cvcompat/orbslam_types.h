@@ -17,6 +17,7 @@
 
 #include <opencv2/core/core.hpp>
 
+#include "ORBextractor.h"  // the reference's own header (needs OpenCV types only)
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
 #include "sophus/sim3.hpp"
 
@@ -38,7 +39,10 @@ class GeometricCamera {
   // Pinhole::project(const Eigen::Vector3f&) (src/CameraModels/Pinhole.cpp:48-55)
   Eigen::Vector2f project(const Eigen::Vector3f& v) const { return Eigen::Vector2f(fx * v[0] / v[2] + cx, fy * v[1] / v[2] + cy); }
   float getParameter(int i) const { return i == 0 ? fx : i == 1 ? fy : i == 2 ? cx : cy; }
-  // Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:107-129): restated in oracle/match_oracle.cpp, reached through a hook
+  // Pinhole::toK_ (src/CameraModels/Pinhole.cpp:100-104)
+  Eigen::Matrix3f toK_() { Eigen::Matrix3f K; K(0, 0) = fx; K(0, 2) = cx; K(1, 1) = fy; K(1, 2) = cy; K(2, 2) = 1.f; return K; }
+  // Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:107-129): the reference's own lines, extracted at build time
+  // (oracle/Makefile: _ref/pinhole_epipolar.inc) and compiled as a member of this class in ref_matcher_glue.cpp
   bool epipolarConstrain(GeometricCamera* other, const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const Eigen::Matrix3f& R12,
                          const Eigen::Vector3f& t12, const float sigmaLevel, const float unc);
 };
@@ -100,6 +104,13 @@ class Frame {
   Sophus::SE3f mTcw, mTrl;
   FeatureGrid grid;
   static float mnMinX, mnMinY, mnMaxX, mnMaxY;  // static members in the reference as well (Frame.h)
+  // what Frame::ComputeStereoMatches (src/Frame.cc:901-1071) touches; its body is the reference's own lines, extracted at
+  // build time (oracle/Makefile: _ref/frame_stereo_matches.inc) and compiled in ref_frame_glue.cpp
+  std::vector<float> mvDepth, mvInvScaleFactors;
+  cv::Mat mDescriptorsRight;
+  ORBextractor* mpORBextractorLeft = nullptr;
+  ORBextractor* mpORBextractorRight = nullptr;
+  void ComputeStereoMatches();
 
   Sophus::SE3f GetPose() const { return mTcw; }
   Sophus::SE3f GetRelativePoseTrl() const { return mTrl; }

@@ -44,10 +44,29 @@ struct Matrix3f {
   Vector3f operator*(const Vector3f& p) const {
     return Vector3f(m[0] * p(0) + m[1] * p(1) + m[2] * p(2), m[3] * p(0) + m[4] * p(1) + m[5] * p(2), m[6] * p(0) + m[7] * p(1) + m[8] * p(2));
   }
+  // fixed-size lazy product: a coefficient is the redux of three products, which Eigen's unroller evaluates as p0 + (p1 + p2)
   Matrix3f operator*(const Matrix3f& o) const {
     Matrix3f r;
     for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) r.m[3 * i + j] = m[3 * i] * o.m[j] + m[3 * i + 1] * o.m[3 + j] + m[3 * i + 2] * o.m[6 + j];
+      for (int j = 0; j < 3; ++j) {
+        const float p0 = m[3 * i] * o.m[j], p1 = m[3 * i + 1] * o.m[3 + j], p2 = m[3 * i + 2] * o.m[6 + j];
+        r.m[3 * i + j] = p0 + (p1 + p2);
+      }
+    return r;
+  }
+  // internal::compute_inverse<Matrix3f, Matrix3f, 3>: cofactors, the determinant from the cofactors of column 0
+  Matrix3f inverse() const {
+    auto cof = [&](int i, int j) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      return m[3 * i1 + j1] * m[3 * i2 + j2] - m[3 * i1 + j2] * m[3 * i2 + j1];
+    };
+    const float c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+    const float det = c0 * m[0] + (c1 * m[3] + c2 * m[6]);
+    const float id = 1.0f / det;
+    Matrix3f r;
+    r.m[0] = c0 * id; r.m[1] = c1 * id; r.m[2] = c2 * id;
+    r.m[3] = cof(0, 1) * id; r.m[4] = cof(1, 1) * id; r.m[5] = cof(2, 1) * id;
+    r.m[6] = cof(0, 2) * id; r.m[7] = cof(1, 2) * id; r.m[8] = cof(2, 2) * id;
     return r;
   }
   Matrix3f transpose() const { Matrix3f r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[3 * i + j] = m[3 * j + i]; return r; }
@@ -112,6 +131,16 @@ struct Quaternionf {
 }  // namespace Eigen
 
 namespace Sophus {
+template <class T> struct SO3;
+template <> struct SO3<float> {
+  // SO3::hat: the skew-symmetric matrix of a 3-vector
+  static Eigen::Matrix3f hat(const Eigen::Vector3f& w) {
+    Eigen::Matrix3f r;
+    r(0, 1) = -w(2); r(0, 2) = w(1); r(1, 0) = w(2); r(1, 2) = -w(0); r(2, 0) = -w(1); r(2, 1) = w(0);
+    return r;
+  }
+};
+typedef SO3<float> SO3f;
 template <class T> class SE3;
 template <> class SE3<float> {
  public:

@@ -11,23 +11,12 @@ namespace ORB_SLAM3 {
 
 float Frame::mnMinX = 0, Frame::mnMinY = 0, Frame::mnMaxX = 0, Frame::mnMaxY = 0;
 
-// Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:107-129); the fundamental matrix through the oracle's
-// restatement of K1^-T [t12]x R12 K2^-1
-bool GeometricCamera::epipolarConstrain(GeometricCamera* other, const cv::KeyPoint& kp1, const cv::KeyPoint& kp2,
-                                        const Eigen::Matrix3f& R12, const Eigen::Vector3f& t12, const float sigmaLevel,
-                                        const float unc) {
-  const float K1[4] = {fx, fy, cx, cy}, K2[4] = {other->fx, other->fy, other->cx, other->cy};
-  float F12[9];
-  orc_fundamental(K1, K2, R12.m, t12.v, F12);
-  const float a = kp1.pt.x * F12[0] + kp1.pt.y * F12[3] + F12[6];
-  const float b = kp1.pt.x * F12[1] + kp1.pt.y * F12[4] + F12[7];
-  const float c = kp1.pt.x * F12[2] + kp1.pt.y * F12[5] + F12[8];
-  const float num = a * kp2.pt.x + b * kp2.pt.y + c;
-  const float den = a * a + b * b;
-  if (den == 0) return false;
-  const float dsqr = num * num / den;
-  return dsqr < 3.84 * unc;
-}
+// Pinhole::epipolarConstrain: lines 107-129 of /root/reference/src/CameraModels/Pinhole.cpp, unmodified, extracted by the
+// Makefile into _ref/pinhole_epipolar.inc; `Pinhole` is the stand-in camera class here (Eigen / Sophus come from
+// cvcompat/sophus/sim3.hpp, so Eigen's product / inverse arithmetic is restated, the function itself is the reference's)
+#define Pinhole GeometricCamera
+#include "_ref/pinhole_epipolar.inc"
+#undef Pinhole
 
 std::vector<std::pair<MapPoint*, MapPoint*>>* MapPoint::replace_log = nullptr;
 

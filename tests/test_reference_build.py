@@ -629,3 +629,54 @@ def test_reference_search_by_projection_sim3_agrees_with_oracle(refmatcher, seed
     om, onm = O.search_by_projection_sim3(search, matched2, float(th), 2 if with_kfs else 0, max_dist)
     assert nm == onm and np.array_equal(m, om)
     assert nm > 300 and not np.any((m >= 0) & (matched2 != 0))
+
+
+# ---- Frame::ComputeStereoMatches: the reference's own lines (src/Frame.cc:901-1071, extracted at build time) on the
+# reference's own ORBextractor / ORBmatcher, versus the oracle's restatement
+REF_FRAME_SO = os.path.join(ROOT, "oracle", "_ref", "libref_frame.so")
+
+
+@pytest.fixture(scope="module")
+def refframe(oracle):
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    if not os.path.exists(REF_FRAME_SO):
+        pytest.skip("oracle/_ref/libref_frame.so not built (needs /root/reference)")
+    lib = C.CDLL(REF_FRAME_SO)
+    lib.ref_stereo_matches.restype = C.c_int
+    lib.ref_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                       C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("w,h,nf,ini,mn,seq,mb,mbf,dscale", [
+    (1241, 376, 2000, 20, 7, 30, 0.54, 386.1448, 1.0),     # KITTI stereo settings (BASELINE cfg 3)
+    (1241, 376, 2000, 20, 7, 31, 0.54, 386.1448, 1.5),     # large disparities: more candidates per row band, border windows
+    (752, 480, 1200, 20, 7, 32, 0.11, 47.9, 0.6),          # EuRoC shape and baseline
+    (640, 480, 1000, 12, 7, 33, 0.08, 40.0, 0.25),         # tiny disparities: the disparity <= 0 clamp and the parabola gate
+])
+def test_reference_compute_stereo_matches_agrees_with_oracle(refframe, w, h, nf, ini, mn, seq, mb, mbf, dscale):
+    import parity_checks as pc
+    left, right = pc.stereo_pair(seq, w, h, disparity_scale=dscale)
+    cap = nf * 2 + 4096
+    kl, kr = np.zeros(cap, O.KP_DTYPE), np.zeros(cap, O.KP_DTYPE)
+    dl, dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+    ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    nl, nr = C.c_int(0), C.c_int(0)
+    rc = refframe.ref_stereo_matches(left.ctypes.data, right.ctypes.data, w, h, left.strides[0], nf, 1.2, 8, ini, mn, mb, mbf,
+                                     kl.ctypes.data, dl.ctypes.data, kr.ctypes.data, dr.ctypes.data, cap, C.byref(nl), C.byref(nr),
+                                     ur.ctypes.data, dp.ctypes.data)
+    assert rc == 0
+    nl, nr = nl.value, nr.value
+    ol, orr = O.Extractor(nf, 1.2, 8, ini, mn), O.Extractor(nf, 1.2, 8, ini, mn)
+    okl, odl, _ = ol(left)
+    okr, odr, _ = orr(right)
+    assert len(okl) == nl and len(okr) == nr
+    for f in ("x", "y", "octave"):
+        assert np.array_equal(kl[:nl][f], okl[f]) and np.array_equal(kr[:nr][f], okr[f])
+    assert np.array_equal(dl[:nl], odl) and np.array_equal(dr[:nr], odr)
+    our, odp = O.stereo_matches(ol, orr, okl, odl, okr, odr, mb, mbf)
+    assert np.array_equal(ur[:nl].view(np.uint32), our.view(np.uint32)), "mvuRight"
+    assert np.array_equal(dp[:nl].view(np.uint32), odp.view(np.uint32)), "mvDepth"
+    assert (our >= 0).sum() > 100  # the case must produce matches
