@@ -57,29 +57,30 @@ def algorithmic_bytes(kernel, w, h, n_points, k_per_frame):
         "k_inverse_dilate": 8 * w * h,                            # read raw + write processed
         "k_gather_depth": 12 * k_per_frame,
         "k_hamming_bf": 32 * 2 * k_per_frame + 8 * k_per_frame,
+        "k_hamming_mfma": 32 * 2 * k_per_frame + 8 * k_per_frame,
+        "k_level_fused": 5 * sp - px[0] - px[-1],                 # the three pixel passes together (SURVEY 8(d) B_ext without the 60 K)
     }
     return table.get(kernel)
 
 
-def pmc_traffic(kernel, frames_per_launch, profile_batch=512):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_*.csv:
-    FETCH_SIZE + WRITE_SIZE, KB -> bytes; separate --pmc runs of this same command at the default batch of 512).
-    Raw counter values: MI355X_MICROARCH.md notes FETCH_SIZE can under-report wide (16 B/lane) loads by 2x; these
-    kernels read 4 B/lane, for which the counter is uncalibrated.  None when the profiles are not present."""
-    total = 0.0
-    for name in ("r01_pmc_fetch_size.csv", "r01_pmc_write_size.csv"):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
+def pmc_traffic(kernel, frames_per_launch, launches_per_step):
+    """HBM-side bytes per LAUNCH of `kernel` from the committed rocprofv3 PMC passes of this same command (`--serial`, so
+    that dispatches per step are what this run launches): profiles/r02_pmc_traffic.json holds, per kernel, the FETCH_SIZE and
+    WRITE_SIZE totals of one step (sum over the step's dispatches, in bytes, multiplied by the calibration factors that
+    tools/micro/hbm_calib.hip measured for this access width - MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B
+    request for wide loads and is uncalibrated otherwise).  None when the file is absent or does not know the kernel."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path))
+        k = t["kernels"].get(kernel)
+        if not k:
             return None
-        found = False
-        for line in open(path).read().splitlines()[1:]:
-            cols = line.split(",")
-            if cols[0].endswith(kernel) or cols[0] == kernel:
-                total += float(cols[3]) * 1024.0
-                found = True
-        if not found:
-            return None
-    return total * frames_per_launch / profile_batch
+        per_step = (k["fetch_bytes_per_step"] + k["write_bytes_per_step"]) * frames_per_launch / t["frames_per_step"]
+        return per_step / max(launches_per_step, 1)
+    except (KeyError, ValueError):
+        return None
 
 
 def load_reference_build():
@@ -170,6 +171,203 @@ def cpu_baseline(seq_frames, scans, proj, w, h, nfeatures, budget_s=20.0, use_re
     return n / dt, n, [s / n * 1e3 for s in stage], ("reference" if ref else "port")
 
 
+def cpu_worker(spec):
+    """`python bench.py --cpu-worker CORE,WORKLOAD,BUDGET_S`: one process of the all-cores CPU baseline (leg (ii)): pins itself
+    to a core, synthesises its own frames + scans of the workload and loops the single-thread baseline over them for the
+    budget.  No torch, no HIP.  Prints one JSON line."""
+    core, workload, budget = spec.split(",")
+    core, budget = int(core), float(budget)
+    try:
+        os.sched_setaffinity(0, {core})
+    except (AttributeError, OSError):
+        pass
+    from orb_slam3_rgbl_amd import synth
+    from oracle import oracle_py as O
+    w, h, nfeatures, n_az, _ = WORKLOADS[workload]
+    K = synth.KITTI_K
+    if workload != "kitti":
+        K = synth.KITTI_K.copy()
+        K[0, 0] = K[1, 1] = 718.856 * w / synth.KITTI_W
+        K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    proj = O.projection_matrix(K, synth.KITTI_TR)
+    seq = synth.Sequence(1000 + core, w, h, n_frames=2)
+    frames = np.stack([seq.frame(i) for i in range(2)])
+    scans = [synth.lidar_scan(5000 + core, n_az=n_az)]
+    fps, n, stage_ms, kind = cpu_baseline(list(frames) * 4096, scans, proj, w, h, nfeatures, budget, use_reference=workload == "kitti")
+    print(json.dumps({"core": core, "frames": n, "fps": fps, "kind": kind}))
+
+
+def cpu_baseline_all_cores(workload, budget_s=12.0):
+    """SURVEY 8(d) CPU baseline leg (ii): every host core runs the single-thread baseline (leg (i)'s code) on its own
+    independent frames at the same time - one process per core, pinned, started from fresh interpreters so that nothing of
+    the GPU runtime is shared.  Returns (aggregate frames/s = sum of the per-core rates, cores used, frames done)."""
+    import subprocess
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = list(range(os.cpu_count() or 1))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "%d,%s,%g" % (c, workload, budget_s)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT) for c in cores]
+    fps = frames = used = 0
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=budget_s * 6 + 120)
+            d = json.loads(out.strip().splitlines()[-1])
+            fps += d["fps"]; frames += d["frames"]; used += 1
+        except Exception:
+            pr.kill()
+    return fps, used, frames
+
+
+def time_steps(step, sync, warmup, steps):
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def extra_workloads(lib, dev, torch):
+    """Driver-visible figures for the other GPU configurations of BASELINE.json, measured in the same run on the same
+    device (short runs; `value` stays the KITTI RGB-L configuration): configs[4] (4K frames + 262 144-point scans,
+    nFeatures 8000), configs[2] (KITTI stereo: two extractions + Frame::ComputeStereoMatches), and the latency of the
+    host-pointer (drop-in) entry points, one frame per call, PCIe and synchronisation included."""
+    from orb_slam3_rgbl_amd import _lib as L
+    from orb_slam3_rgbl_amd import frontend as F
+    from orb_slam3_rgbl_amd import synth
+    out = {}
+
+    def p(t):
+        return C.c_void_p(t.data_ptr())
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    # ---- configs[4]: 4K
+    try:
+        w, h, nf, n_az, B = WORKLOADS["4k"]
+        seq = synth.Sequence(7, w, h, n_frames=4)
+        distinct = [seq.frame(i) for i in range(4)]
+        frames = torch.from_numpy(np.stack([distinct[i % 4] for i in range(B)])).to(dev)
+        scan = synth.lidar_scan(7000, n_az=n_az)
+        n_points = scan.shape[1]
+        cloud = torch.from_numpy(np.stack([scan] * B)).to(dev)
+        K = synth.KITTI_K.copy()
+        K[0, 0] = K[1, 1] = 718.856 * w / synth.KITTI_W
+        K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+        proj = F.projection_matrix(K, synth.KITTI_TR, lib)
+        ex = F.ORBextractor(nf, SCALE, LEVELS, INI_TH, MIN_TH, w, h, max_batch=B, device=dev.index, lib=lib)
+        cap = ex.max_keypoints
+        dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=cap, max_batch=B, device=dev.index, lib=lib)
+        mt = F.ORBmatcher(0.6, False, device=dev.index, lib=lib)
+        one = C.c_void_p(lib.rgbl_extractor_stream(ex.h))
+        L.check(lib, lib.rgbl_matcher_set_stream(mt.h, one))
+        kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+        desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        n = torch.zeros(B, dtype=torch.int32, device=dev)
+        mono = torch.zeros(B, dtype=torch.int32, device=dev)
+        depth = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+        uright = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+        bi, bd, sd = (torch.zeros((B, cap), dtype=torch.int32, device=dev) for _ in range(3))
+        pa = torch.arange(B, dtype=torch.int32, device=dev)
+        pb = (pa + 1) % B
+        s_ex, s_dm = one, C.c_void_p(lib.rgbl_depth_stream(dm.h))
+
+        def step():
+            L.check(lib, lib.rgbl_stream_wait(s_ex, s_dm))   # the previous step's gather read this step's outputs
+            L.check(lib, lib.rgbl_extract_batch_device(ex.h, p(frames), B, w, h, w, w * h, 0, 0, p(kp), p(desc), cap, p(n), p(mono)))
+            L.check(lib, lib.rgbl_depth_project_batch_device(dm.h, p(cloud), B, n_points, n_points, 4 * n_points, w, h, None))
+            L.check(lib, lib.rgbl_stream_wait(s_dm, s_ex))
+            L.check(lib, lib.rgbl_depth_gather_batch_device(dm.h, B, w, h, p(kp), p(n), cap, None, p(depth), p(uright)))
+            L.check(lib, lib.rgbl_hamming_bf_batch_device(mt.h, p(desc), p(n), cap, p(pa), p(pb), B, p(bi), p(bd), p(sd)))
+        dt = time_steps(step, sync, 2, 6)
+        out["cfg5_4k"] = {"frames_per_s": B / dt, "ms_per_step": dt * 1e3, "frames_per_step": B, "image": [w, h], "nfeatures": nf,
+                          "lidar_points": n_points, "keypoints_per_frame": float(n.float().mean().item()),
+                          "what": "extract + depth + match, inputs resident in HBM, 1 GPU"}
+        ex.close(); dm.close(); mt.close()
+        del frames, cloud, kp, desc, depth, uright, bi, bd, sd
+    except Exception as e:  # never lose the main line over an extra figure
+        out["cfg5_4k"] = {"error": repr(e)}
+
+    # ---- configs[2]: KITTI stereo front end
+    try:
+        w, h, B = synth.KITTI_W, synth.KITTI_H, 64
+        sq = [synth.Sequence(40 + i, w + 128, h, n_frames=1).frame(0) for i in range(4)]
+        lefts, rights = [], []
+        for full in sq:  # rectified pair: the right view is the scene shifted by a row-dependent disparity of 4 .. 40 px
+            lefts.append(np.ascontiguousarray(full[:, 64:64 + w]))
+            r = np.empty((h, w), np.uint8)
+            for y in range(h):
+                d = int(round(4 + 36.0 * y / h))
+                r[y] = full[y, 64 + d:64 + d + w]
+            rights.append(r)
+        dl = torch.from_numpy(np.stack([lefts[i % 4] for i in range(B)])).to(dev)
+        dr = torch.from_numpy(np.stack([rights[i % 4] for i in range(B)])).to(dev)
+        exl = F.ORBextractor(2000, SCALE, LEVELS, 20, 7, w, h, max_batch=B, device=dev.index, lib=lib)
+        exr = F.ORBextractor(2000, SCALE, LEVELS, 20, 7, w, h, max_batch=B, device=dev.index, lib=lib)
+        cap = exl.max_keypoints
+
+        def outs():
+            return (torch.zeros((B, cap, 7), dtype=torch.float32, device=dev), torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
+                    torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev))
+        kl, ddl, nl, ml = outs()
+        kr, ddr, nr, mr = outs()
+        ur = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+        dp = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+
+        def step():
+            L.check(lib, lib.rgbl_extract_batch_device(exl.h, p(dl), B, w, h, w, w * h, 0, 0, p(kl), p(ddl), cap, p(nl), p(ml)))
+            L.check(lib, lib.rgbl_extract_batch_device(exr.h, p(dr), B, w, h, w, w * h, 0, 0, p(kr), p(ddr), cap, p(nr), p(mr)))
+            L.check(lib, lib.rgbl_stereo_matches_batch_device(exl.h, exr.h, B, p(kl), p(ddl), p(nl), p(kr), p(ddr), p(nr), cap,
+                                                              0.54, 386.1448, p(ur), p(dp)))
+        dt = time_steps(step, sync, 2, 8)
+        out["cfg3_stereo"] = {"stereo_frames_per_s": B / dt, "ms_per_step": dt * 1e3, "pairs_per_step": B, "image": [w, h],
+                              "nfeatures": 2000, "fast_thresholds": [20, 7], "stereo_matches_per_frame": float((dp > 0).float().sum().item() / B),
+                              "what": "left + right extraction + Frame::ComputeStereoMatches on the resident pyramids, 1 GPU"}
+        exl.close(); exr.close()
+    except Exception as e:
+        out["cfg3_stereo"] = {"error": repr(e)}
+
+    # ---- drop-in (host-pointer) entry points, one RGB-L frame per call
+    try:
+        w, h = synth.KITTI_W, synth.KITTI_H
+        seq = synth.Sequence(3, w, h, n_frames=4)
+        imgs = [seq.frame(i) for i in range(4)]
+        scan = synth.lidar_scan(3000)
+        ex = F.ORBextractor(2000, SCALE, LEVELS, INI_TH, MIN_TH, w, h, device=dev.index, lib=lib)
+        dm = F.DepthModule(F.projection_matrix(synth.KITTI_K, synth.KITTI_TR, lib), w, h, max_points=scan.shape[1],
+                           max_keypoints=ex.max_keypoints, device=dev.index, lib=lib)
+        mt = F.ORBmatcher(0.6, False, device=dev.index, lib=lib)
+        prev = None
+        best = None
+        for rep in range(4):
+            t = [0.0, 0.0, 0.0]
+            cnt = 0
+            for img in imgs * 3:
+                a = time.perf_counter(); kps, desc, _ = ex(img)
+                b = time.perf_counter(); dm.CalculateDepthFromPcd(kps, kps, scan, w, h, want_maps=False)
+                c = time.perf_counter()
+                if prev is not None:
+                    mt.BruteForce(prev, desc)
+                d = time.perf_counter()
+                prev = desc
+                t[0] += b - a; t[1] += c - b; t[2] += d - c; cnt += 1
+            cur = [v / cnt * 1e3 for v in t]
+            if best is None or sum(cur) < sum(best):
+                best = cur
+        out["host_api_single_frame"] = {"ms_per_frame": {"extract": best[0], "depth": best[1], "match": best[2], "total": sum(best)},
+                                        "frames_per_s": 1e3 / sum(best),
+                                        "what": "rgbl_extract + rgbl_depth_compute + rgbl_hamming_bf with host pointers: H2D, kernels, D2H, "
+                                                "synchronous return - what a drop-in System::TrackRGBL sees; never `value`"}
+        ex.close(); dm.close(); mt.close()
+    except Exception as e:
+        out["host_api_single_frame"] = {"error": repr(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,9 +376,16 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (default: workload specific)")
     ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 4K / stereo / single-frame figures (extra keys of the JSON line)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--serial", action="store_true", help="one stream for all handles (clean per-kernel timings)")
+    ap.add_argument("--gather", default="step", choices=["step", "final", "none"],
+                    help="N > 1: stream every step's records to rank 0 while the next step computes (default), exchange all of "
+                         "them once at the end, or not at all")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker)
 
     import torch
     import torch.distributed as dist
@@ -205,7 +410,7 @@ def main():
     lib = L.load()
 
     # ---- synthetic input, one independent sequence per rank (BASELINE configs[3]: sequences shard over GPUs)
-    seq = synth.Sequence(rank, w, h, n_frames=B)
+    seq = synth.Sequence(sharding.sequences_of_rank(world, world, rank)[0], w, h, n_frames=B)
     frames = np.stack([seq.frame(i) for i in range(B)])
     n_scans = min(B, 8)
     scans = [synth.lidar_scan(rank * 1000 + i, n_az=n_az) for i in range(n_scans)]
@@ -219,101 +424,17 @@ def main():
         K[0, 2], K[1, 2] = w / 2.0, h / 2.0
     proj = F.projection_matrix(K, synth.KITTI_TR, lib)
 
-    ex = F.ORBextractor(nfeatures, SCALE, LEVELS, INI_TH, MIN_TH, w, h, max_batch=B, device=local_rank, lib=lib)
-    cap = ex.max_keypoints
-    dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=cap, max_batch=B, device=local_rank, lib=lib)
-    mt = F.ORBmatcher(0.6, False, device=local_rank, lib=lib)
-
-    # HIP streams: the extractor's two (+ the matcher, below), one for the depth module: the LiDAR projection /
-    # up-sampling does not depend on the keypoints and overlaps with the extraction; ordering between the handles is expressed with HIP events (rgbl_stream_wait).
-    if args.serial:
-        one = C.c_void_p(lib.rgbl_extractor_stream(ex.h))
-        L.check(lib, lib.rgbl_depth_set_stream(dm.h, one))
-        L.check(lib, lib.rgbl_matcher_set_stream(mt.h, one))
-        # per-kernel HIP-event brackets on from the first step: the extractor then keeps its Gaussian on the main
-        # stream as well, so every launch of the run is serialised - the mode `rocprofv3 --kernel-trace --stats` is
-        # recorded in (profiles/), whose average durations are the ones the roofline leg below measures
-        ex.profile(True); dm.profile(True); mt.profile(True)
-    if not args.serial:
-        # the brute-force Hamming of step i is issue-bound like FAST: queued behind the extraction of step i + 1 on the
-        # extractor's stream it fills that stream's gaps instead of competing with it (83.2 k vs 77.5 - 82.7 k frames/s
-        # on its own stream, depending on how the runtime maps streams to hardware queues)
-        L.check(lib, lib.rgbl_matcher_set_stream(mt.h, C.c_void_p(lib.rgbl_extractor_stream(ex.h))))
-    s_ex = C.c_void_p(lib.rgbl_extractor_stream(ex.h))
-    s_dm = C.c_void_p(lib.rgbl_depth_stream(dm.h))
-    s_mt = C.c_void_p(lib.rgbl_matcher_stream(mt.h))
-    comm_stream = torch.cuda.Stream(dev) if world > 1 else None
-    s_comm = C.c_void_p(comm_stream.cuda_stream) if world > 1 else None
-
-    def wait(waiter, signaler):
-        L.check(lib, lib.rgbl_stream_wait(waiter, signaler))
-
+    from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline
+    # the step (extract -> depth -> match on resident inputs) and the gather of its records live in
+    # orb_slam3_rgbl_amd/pipeline.py - the same code tests/test_distributed.py drives with two gloo ranks
+    pipe = FrontEndPipeline(lib, torch, dev, w, h, nfeatures, proj, n_points, B, levels=LEVELS, scale=SCALE, ini_th=INI_TH,
+                            min_th=MIN_TH, world=world, rank=rank, gather=args.gather, serial=args.serial,
+                            log_steps=args.steps + args.warmup)
+    ex, dm, mt, cap = pipe.ex, pipe.dm, pipe.mt, pipe.cap
     d_imgs = torch.from_numpy(frames).to(dev)
     d_cloud = torch.from_numpy(cloud).to(dev)
-    # Two output sets (ping-pong): the matcher / depth gather of step k read set k%2 while the extractor of step k+1
-    # already fills the other one; HIP events mark "set free again" (rgbl_event_*).
-    class OutSet:
-        def __init__(self):
-            self.kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)   # rgbl_keypoint records (28 B)
-            self.desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-            self.n = torch.zeros(B, dtype=torch.int32, device=dev)
-            self.mono = torch.zeros(B, dtype=torch.int32, device=dev)
-            self.depth = torch.zeros((B, cap), dtype=torch.float32, device=dev)
-            self.uright = torch.zeros((B, cap), dtype=torch.float32, device=dev)
-            self.bi = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-            self.bd = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-            self.sd = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-            self.ev = {}
-            for name in ("extracted", "depth_done", "match_done", "comm_done"):
-                e = C.c_void_p()
-                L.check(lib, lib.rgbl_event_create(C.byref(e)))
-                self.ev[name] = e
-
-    sets = [OutSet(), OutSet()]
-    pair_a = torch.arange(B, dtype=torch.int32, device=dev)
-    pair_b = (pair_a + 1) % B
-    gather_buf = None
-    if world > 1:
-        send = [torch.zeros((B, sharding.record_bytes(cap)), dtype=torch.uint8, device=dev) for _ in range(2)]
-        gather_buf = [torch.zeros_like(send[0]) for _ in range(world)] if rank == 0 else None
-    step_no = [0]
-
-    def p(t):
-        return C.c_void_p(t.data_ptr())
-
-    def step():
-        o = sets[step_no[0] % 2]
-        # this set's readers of two steps ago must be done before the extractor overwrites it
-        L.check(lib, lib.rgbl_event_wait(s_ex, o.ev["depth_done"]))
-        L.check(lib, lib.rgbl_event_wait(s_ex, o.ev["match_done"]))
-        if world > 1:
-            L.check(lib, lib.rgbl_event_wait(s_ex, o.ev["comm_done"]))
-        L.check(lib, lib.rgbl_extract_batch_device(ex.h, p(d_imgs), B, w, h, w, w * h, 0, 0, p(o.kp), p(o.desc), cap,
-                                                   p(o.n), p(o.mono)))
-        L.check(lib, lib.rgbl_event_record(o.ev["extracted"], s_ex))
-        # LiDAR projection + up-sampling: independent of the keypoints, runs concurrently on the depth stream
-        L.check(lib, lib.rgbl_depth_project_batch_device(dm.h, p(d_cloud), B, n_points, n_points, 4 * n_points, w, h, None))
-        L.check(lib, lib.rgbl_event_wait(s_dm, o.ev["extracted"]))
-        L.check(lib, lib.rgbl_depth_gather_batch_device(dm.h, B, w, h, p(o.kp), p(o.n), cap, None, p(o.depth), p(o.uright)))
-        L.check(lib, lib.rgbl_event_record(o.ev["depth_done"], s_dm))
-        L.check(lib, lib.rgbl_event_wait(s_mt, o.ev["extracted"]))
-        L.check(lib, lib.rgbl_hamming_bf_batch_device(mt.h, p(o.desc), p(o.n), cap, p(pair_a), p(pair_b), B, p(o.bi),
-                                                      p(o.bd), p(o.sd)))
-        L.check(lib, lib.rgbl_event_record(o.ev["match_done"], s_mt))
-        if world > 1:
-            # the one exchange of the path: variable-length records to rank 0 (padded to cap, counts in front)
-            L.check(lib, lib.rgbl_event_wait(s_comm, o.ev["depth_done"]))
-            L.check(lib, lib.rgbl_event_wait(s_comm, o.ev["match_done"]))
-            with torch.cuda.stream(comm_stream):
-                sbuf = send[step_no[0] % 2]
-                sharding.pack_records(o.n, o.kp, o.desc, o.depth, o.uright, out=sbuf)
-                sharding.gather_records(sbuf, gather_buf, dst=0)
-            L.check(lib, lib.rgbl_event_record(o.ev["comm_done"], s_comm))
-        step_no[0] += 1
-
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        L.check(lib, lib.rgbl_extractor_sync(ex.h))  # also surfaces device-side overflow flags
+    pipe.set_inputs(d_imgs, d_cloud)
+    step, sync_all = pipe.step, pipe.sync
 
     for _ in range(args.warmup):
         step()
@@ -324,6 +445,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    pipe.finish()   # the records still on their way to rank 0 belong to the job
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -335,7 +457,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    last = sets[(step_no[0] - 1) % 2]
+    last = pipe.last()
     d_n, d_kp, d_desc, d_depth, d_uright, d_bi, d_bd, d_sd = (last.n, last.kp, last.desc, last.depth, last.uright, last.bi,
                                                                last.bd, last.sd)
     k_mean = float(d_n.float().mean().item())
@@ -373,10 +495,8 @@ def main():
     if rank == 0:
         # per-kernel timing leg: one stream for everything, so that the HIP-event brackets around each launch are not
         # stretched by other kernels running concurrently
-        one = C.c_void_p(lib.rgbl_extractor_stream(ex.h))
-        L.check(lib, lib.rgbl_depth_set_stream(dm.h, one))
-        L.check(lib, lib.rgbl_matcher_set_stream(mt.h, one))
-        s_dm.value = s_mt.value = one.value
+        pipe.serialise()
+        pipe.gather = "none"
         ex.profile(True); dm.profile(True); mt.profile(True)
         prof_steps = 3
         for _ in range(prof_steps):
@@ -393,7 +513,7 @@ def main():
         ab = algorithmic_bytes(dom, w, h, n_points, k_mean)
         achieved = (ab * B) / (per_step_ms * 1e-3) / 1e9 if ab else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(dom, B),
+                    "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(dom, B, launches / prof_steps),
                     "avg_launch_ms": per_launch_ms, "launches_per_step": launches / prof_steps,
                     "algorithmic_bytes_per_frame": ab, "frames_per_launch": B,
                     "kernel_share_of_gpu_time": ms_sum / total_ms if total_ms else None,
@@ -416,11 +536,22 @@ def main():
             what = ("oracle/_ref: the reference's own ORBextractor.cc and DepthModule.cc compiled unmodified against the OpenCV "
                     "stand-in (its cv:: primitives are scalar restatements, not OpenCV's SIMD code), matching = oracle all-pairs "
                     "Hamming" if kind == "reference" else "oracle/ (CPU restatement of the reference path)")
+            fps_all = cores_all = n_all = None
+            try:
+                fps_all, cores_all, n_all = cpu_baseline_all_cores(args.workload, min(args.cpu_budget, 12.0))
+            except Exception as e:  # the single-thread figure stands on its own
+                fps_all = None
+                sys.stderr.write("all-cores CPU baseline failed: %r\n" % (e,))
             cpu = {"value": fps, "unit": "frames/s", "cores": 1, "kind": kind,
                    "sample": "%d synthetic %dx%d frames + scans, extract+depth+match, %s, g++ -O2, 1 thread = the reference's "
                              "one-extractor-thread-per-image model" % (n_done, w, h, what),
                    "ms_per_frame": {"extract": stage_ms[0], "depth": stage_ms[1], "match": stage_ms[2]},
-                   "host_cores_available": os.cpu_count()}
+                   "host_cores_available": os.cpu_count(),
+                   # SURVEY 8(d) leg (ii): one independent frame per core on all host cores at once (same code per core)
+                   "all_cores": {"value": fps_all, "unit": "frames/s", "cores": cores_all, "frames": n_all,
+                                 "sample": "one pinned process per core, each looping leg (i)'s code over its own synthetic frames + scan for "
+                                           "~%d s at the same time; value = sum of the per-core rates" % min(args.cpu_budget, 12.0)}
+                                if fps_all else None}
 
     if rank == 0:
         total_frames = world * B * args.steps
@@ -441,11 +572,14 @@ def main():
                        else "4K synthetic cfg5", "image": [w, h], "nfeatures": nfeatures, "levels": LEVELS,
                        "lidar_points": n_points, "frames_per_gpu_per_step": B, "keypoints_per_frame": k_mean,
                        "match": "Hamming brute force, frame i vs i+1", "upsampling": "InverseDilation Diamond 5",
-                       "inputs": "resident in HBM", "parallelism": "frames/sequences sharded, %d rank(s)" % world},
+                       "inputs": "resident in HBM", "parallelism": "frames/sequences sharded, %d rank(s)" % world,
+                       "gather": (args.gather if world > 1 else "none")},
             "parity_spot_check": spot,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if world == 1 and not args.no_extras:
+            out["extra"] = extra_workloads(lib, dev, torch)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

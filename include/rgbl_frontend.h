@@ -170,6 +170,15 @@ void* rgbl_extractor_aux_stream(rgbl_extractor* h);
 /* Device-side ordering between handles without a host sync: work enqueued on `waiter_stream` after this call
  * starts only when everything enqueued on `signaler_stream` before this call has finished (HIP event). */
 int rgbl_stream_wait(void* waiter_stream, void* signaler_stream);
+/* Multi-GPU gather, SURVEY.md 8(e): compacts a batch's per-frame results (device arrays as the batch entry points produce
+ * them: counts, cap keypoints / descriptors / depths / uRights per frame) into variable-length records of 68 bytes per
+ * keypoint (28 B cv::KeyPoint | 32 B descriptor | f32 depth | f32 uRight), frames back to back starting at record
+ * `first_record` of d_out (which holds capacity_records records).  d_offsets[f] = first record of frame f,
+ * d_offsets[batch] = one past the last; *d_overflow is set to 1 (and the frame skipped) when the records do not fit.
+ * Enqueued on `hip_stream`, no host synchronisation.  There is no counterpart in the reference (it runs on one CPU). */
+int rgbl_pack_records_device(void* hip_stream, const int32_t* d_n, const rgbl_keypoint* d_kp, const uint8_t* d_desc,
+                             const float* d_depth, const float* d_uright, int batch, int cap, long long first_record,
+                             long long capacity_records, uint8_t* d_out, long long* d_offsets, int* d_overflow);
 /* The same with explicit, reusable HIP events: record marks a point on a stream, wait makes later work on another
  * stream start only after that point (a never-recorded event does not block). Enables software pipelining across
  * batches: e.g. the extractor may overwrite an output buffer as soon as the event recorded behind its last reader

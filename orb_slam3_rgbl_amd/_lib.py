@@ -150,6 +150,7 @@ SYMBOLS = {
     "rgbl_extractor_aux_stream": (_V, [_V]),
     "rgbl_matcher_stream": (_V, [_V]),
     "rgbl_stream_wait": (_I, [_V, _V]),
+    "rgbl_pack_records_device": (_I, [_V, _V, _V, _V, _V, _V, _I, _I, C.c_longlong, C.c_longlong, _V, _V, _V]),
     "rgbl_event_create": (_I, [C.POINTER(_V)]),
     "rgbl_event_destroy": (None, [_V]),
     "rgbl_event_record": (_I, [_V, _V]),

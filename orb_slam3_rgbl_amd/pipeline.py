@@ -1,0 +1,241 @@
+"""The batched front-end step (extract -> depth -> match) on device-resident inputs and the multi-GPU gather of its
+results — the code `bench.py` times and `tests/test_distributed.py` drives (there on the CPU: the SIMT-emulated library,
+CPU tensors and the gloo backend run the very same calls).
+
+One process per GPU; frames / sequences are sharded over the ranks and nothing in the per-frame path depends on another
+rank: the only exchange is the gather of the results to rank 0.  It is the two-phase variable-length
+gather of 8(e):
+  phase 1  the per-frame keypoint counts of every rank (all_gather of B int32 each),
+  phase 2  the compacted records (68 B per keypoint, `rgbl_pack_records_device`) by point-to-point send / recv, the root
+           posting one receive of the exact size per peer (on MI355X one xGMI link per peer, in parallel; a ring would be
+           per-link bound and is the wrong shape).
+`gather="step"` (default) streams every step's records to the root while the next step computes: the pack runs on a
+communication stream behind the step's last readers, and the exchange of step k is posted after step k + 1 has been
+enqueued, so the host never waits for the GPU it is feeding.  `gather="final"` keeps the compacted records of every step in
+HBM and exchanges them once at the end; `gather="none"` does no exchange.
+PyTorch is plumbing here: device memory, streams and torch.distributed.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from . import frontend as F
+
+RECORD_BYTES = 68
+
+
+def unpack_records(buf, counts):
+    """Compacted records (bytes) + per-frame counts -> list of per-frame dicts of numpy arrays."""
+    a = np.frombuffer(np.ascontiguousarray(buf), np.uint8)
+    out, o = [], 0
+    for n in counts:
+        n = int(n)
+        r = a[o * RECORD_BYTES:(o + n) * RECORD_BYTES].reshape(n, RECORD_BYTES)
+        out.append(dict(n=n, kp=r[:, :28].copy(), desc=r[:, 28:60].copy(), depth=r[:, 60:64].copy().view(np.float32).reshape(n),
+                        uright=r[:, 64:68].copy().view(np.float32).reshape(n)))
+        o += n
+    return out
+
+
+class OutSet:
+    """Outputs of one step (the pipeline ping-pongs between two sets) and the events that order their readers / writers."""
+
+    def __init__(self, lib, torch, dev, B, cap):
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self.kp = z((B, cap, 7), torch.float32)     # rgbl_keypoint records (28 B)
+        self.desc = z((B, cap, 32), torch.uint8)
+        self.n = z((B,), torch.int32)
+        self.mono = z((B,), torch.int32)
+        self.depth = z((B, cap), torch.float32)
+        self.uright = z((B, cap), torch.float32)
+        self.bi, self.bd, self.sd = (z((B, cap), torch.int32) for _ in range(3))
+        self.ev = {}
+        for name in ("extracted", "depth_done", "match_done", "comm_done"):
+            e = C.c_void_p()
+            L.check(lib, lib.rgbl_event_create(C.byref(e)))
+            self.ev[name] = e
+
+
+class FrontEndPipeline:
+    def __init__(self, lib, torch, dev, w, h, nfeatures, proj, n_points, batch, levels=8, scale=1.2, ini_th=12, min_th=7,
+                 world=1, rank=0, gather="step", serial=False, keep_steps=0, log_steps=1):
+        self.lib, self.torch, self.dev = lib, torch, dev
+        self.w, self.h, self.B, self.n_points = w, h, batch, n_points
+        self.world, self.rank, self.gather = world, rank, gather if world > 1 else "none"
+        index = dev.index if dev.type == "cuda" else 0
+        self.ex = F.ORBextractor(nfeatures, scale, levels, ini_th, min_th, w, h, max_batch=batch, device=index, lib=lib)
+        self.cap = self.ex.max_keypoints
+        self.dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=self.cap, max_batch=batch, device=index, lib=lib)
+        self.mt = F.ORBmatcher(0.6, False, device=index, lib=lib)
+        one = C.c_void_p(lib.rgbl_extractor_stream(self.ex.h))
+        if serial:
+            # one stream for all handles and per-kernel HIP-event brackets on: every launch of the run is serialised - the
+            # mode `rocprofv3 --kernel-trace --stats` is recorded in (profiles/)
+            L.check(lib, lib.rgbl_depth_set_stream(self.dm.h, one))
+            L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
+            self.profile(True)
+        else:
+            # the brute-force Hamming of step i is issue-bound like FAST: queued behind the extraction of step i + 1 on the
+            # extractor's stream it fills that stream's gaps instead of competing with it
+            L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
+        self._streams()
+        self.sets = [OutSet(lib, torch, dev, batch, self.cap) for _ in range(2)]
+        self.pair_a = torch.arange(batch, dtype=torch.int32, device=dev)
+        self.pair_b = (self.pair_a + 1) % batch
+        self.step_no = 0
+        # ---- gather state
+        self.comm_stream = torch.cuda.Stream(dev) if (self.gather != "none" and dev.type == "cuda") else None
+        self.s_comm = C.c_void_p(self.comm_stream.cuda_stream) if self.comm_stream is not None else C.c_void_p(None)
+        self.pending = None         # the step whose records are packed but not exchanged yet
+        self.received = []          # root: per exchanged step, per rank (counts [B] int32 on the host, records uint8 tensor)
+        self.keep = keep_steps      # root keeps the records of at most this many steps (0 = only the last)
+        if self.gather != "none":
+            slots = 2 if self.gather == "step" else max(log_steps, 1)   # 'final': one slot per step of the run
+            rec_cap = batch * self.cap
+            self.send = [torch.zeros(rec_cap * RECORD_BYTES, dtype=torch.uint8, device=dev) for _ in range(slots)]
+            self.offsets = [torch.zeros(batch + 1, dtype=torch.int64, device=dev) for _ in range(slots)]
+            self.counts = [torch.zeros(batch, dtype=torch.int32, device=dev) for _ in range(slots)]
+            self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.recv = None
+            if rank == 0:
+                self.recv = [[torch.zeros(rec_cap * RECORD_BYTES, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(2)]
+
+    def _streams(self):
+        lib = self.lib
+        self.s_ex = C.c_void_p(lib.rgbl_extractor_stream(self.ex.h))
+        self.s_dm = C.c_void_p(lib.rgbl_depth_stream(self.dm.h))
+        self.s_mt = C.c_void_p(lib.rgbl_matcher_stream(self.mt.h))
+
+    def profile(self, on):
+        self.ex.profile(on); self.dm.profile(on); self.mt.profile(on)
+
+    def serialise(self):
+        """All handles on the extractor's stream (the per-kernel timing leg of bench.py)."""
+        one = C.c_void_p(self.lib.rgbl_extractor_stream(self.ex.h))
+        L.check(self.lib, self.lib.rgbl_depth_set_stream(self.dm.h, one))
+        L.check(self.lib, self.lib.rgbl_matcher_set_stream(self.mt.h, one))
+        self._streams()
+
+    def profile_read(self):
+        k = {}
+        for src in (self.ex.profile_read(), self.dm.profile_read(), self.mt.profile_read()):
+            k.update(src)
+        return k
+
+    def set_inputs(self, d_imgs, d_cloud):
+        self.d_imgs, self.d_cloud = d_imgs, d_cloud
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    def step(self):
+        lib, p, B, w, h, cap = self.lib, self._p, self.B, self.w, self.h, self.cap
+        o = self.sets[self.step_no % 2]
+        # this set's readers of two steps ago must be done before the extractor overwrites it
+        L.check(lib, lib.rgbl_event_wait(self.s_ex, o.ev["depth_done"]))
+        L.check(lib, lib.rgbl_event_wait(self.s_ex, o.ev["match_done"]))
+        if self.gather != "none":
+            L.check(lib, lib.rgbl_event_wait(self.s_ex, o.ev["comm_done"]))
+        L.check(lib, lib.rgbl_extract_batch_device(self.ex.h, p(self.d_imgs), B, w, h, w, w * h, 0, 0, p(o.kp), p(o.desc), cap,
+                                                   p(o.n), p(o.mono)))
+        L.check(lib, lib.rgbl_event_record(o.ev["extracted"], self.s_ex))
+        # LiDAR projection + up-sampling: independent of the keypoints, runs concurrently on the depth stream
+        n_points = self.n_points
+        L.check(lib, lib.rgbl_depth_project_batch_device(self.dm.h, p(self.d_cloud), B, n_points, n_points, 4 * n_points, w, h, None))
+        L.check(lib, lib.rgbl_event_wait(self.s_dm, o.ev["extracted"]))
+        L.check(lib, lib.rgbl_depth_gather_batch_device(self.dm.h, B, w, h, p(o.kp), p(o.n), cap, None, p(o.depth), p(o.uright)))
+        L.check(lib, lib.rgbl_event_record(o.ev["depth_done"], self.s_dm))
+        L.check(lib, lib.rgbl_event_wait(self.s_mt, o.ev["extracted"]))
+        L.check(lib, lib.rgbl_hamming_bf_batch_device(self.mt.h, p(o.desc), p(o.n), cap, p(self.pair_a), p(self.pair_b), B, p(o.bi),
+                                                      p(o.bd), p(o.sd)))
+        L.check(lib, lib.rgbl_event_record(o.ev["match_done"], self.s_mt))
+        if self.gather != "none":
+            prev = self.pending
+            self._pack(o)
+            if self.gather == "step" and prev is not None:
+                self._exchange(prev)   # step k - 1's records travel while step k computes
+        self.step_no += 1
+
+    # ---- gather ------------------------------------------------------------------------------------------------
+    def _pack(self, o):
+        """Compaction of the step's results on the communication stream, behind the step's last writers."""
+        lib, p = self.lib, self._p
+        slot = self.step_no % len(self.send)
+        L.check(lib, lib.rgbl_event_wait(self.s_comm, o.ev["depth_done"]))
+        L.check(lib, lib.rgbl_event_wait(self.s_comm, o.ev["match_done"]))
+        L.check(lib, lib.rgbl_pack_records_device(self.s_comm, p(o.n), p(o.kp), p(o.desc), p(o.depth), p(o.uright), self.B, self.cap, 0,
+                                                  self.B * self.cap, p(self.send[slot]), p(self.offsets[slot]), p(self.overflow)))
+        ctx = self.torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else _Null()
+        with ctx:
+            self.counts[slot].copy_(o.n)  # the set is free again once the records and the counts are copied out
+        L.check(lib, lib.rgbl_event_record(o.ev["comm_done"], self.s_comm))
+        self.pending = slot
+
+    def _exchange(self, slot):
+        """Two-phase gather of one packed step to rank 0."""
+        import torch.distributed as dist
+        torch, world, rank, B = self.torch, self.world, self.rank, self.B
+        ctx = torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else _Null()
+        with ctx:
+            # phase 1: per-frame counts of every rank
+            all_counts = [torch.empty_like(self.counts[slot]) for _ in range(world)]
+            dist.all_gather(all_counts, self.counts[slot])
+            host_counts = [c.cpu().numpy() for c in all_counts]            # waits for the pack of THIS slot only
+            totals = [int(np.minimum(np.maximum(c, 0), self.cap).sum()) for c in host_counts]
+            # phase 2: exact-size point-to-point transfers, one per peer
+            ops = []
+            if rank == 0:
+                self.n_exchanged = getattr(self, "n_exchanged", 0) + 1
+                bank = self.recv[self.n_exchanged % 2]
+                for r in range(1, world):
+                    if totals[r] > 0:
+                        ops.append(dist.P2POp(dist.irecv, bank[r][:totals[r] * RECORD_BYTES], r))
+                bank[0][:totals[0] * RECORD_BYTES].copy_(self.send[slot][:totals[0] * RECORD_BYTES])
+            elif totals[rank] > 0:
+                ops.append(dist.P2POp(dist.isend, self.send[slot][:totals[rank] * RECORD_BYTES], 0))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            if rank == 0:
+                got = [(host_counts[r], bank[r][:totals[r] * RECORD_BYTES]) for r in range(world)]
+                if self.keep:
+                    got = [(c, t.clone()) for c, t in got]
+                    self.received = (self.received + [got])[-self.keep:]
+                else:
+                    self.received = [got]
+        if self.pending == slot:
+            self.pending = None
+
+    def finish(self):
+        """Flushes the gather: the last step's records (gather='step') or every kept step's (gather='final')."""
+        if self.gather == "step" and self.pending is not None:
+            self._exchange(self.pending)
+        elif self.gather == "final":
+            first = max(self.step_no - len(self.send), 0)
+            for k in range(first, self.step_no):
+                self._exchange(k % len(self.send))
+        if self.comm_stream is not None:
+            self.comm_stream.synchronize()
+
+    def sync(self):
+        if self.dev.type == "cuda":
+            self.torch.cuda.synchronize(self.dev)
+        L.check(self.lib, self.lib.rgbl_extractor_sync(self.ex.h))  # also surfaces device-side overflow flags
+        if self.gather != "none" and int(self.overflow.cpu()[0]) != 0:
+            raise RuntimeError("record buffer overflow in rgbl_pack_records_device")
+
+    def last(self):
+        return self.sets[(self.step_no - 1) % 2]
+
+    def close(self):
+        self.ex.close(); self.dm.close(); self.mt.close()
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -39,5 +39,50 @@ def pmc(db, out):
             wr.writerow([short(name), counter, n, "%.3f" % val, "%.1f" % (dur or 0)])
 
 
+def traffic(out_dir, steps, warmup, frames_per_step, out):
+    """FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial` (prof_bench_*) + of tools/micro/hbm_calib (prof_calib_*) ->
+    bytes per STEP per kernel (sum over the dispatches of the timed + profiled steps / their number), calibrated."""
+    import glob
+    import json
+    import os
+
+    def rows(tag):
+        db = glob.glob(os.path.join(out_dir, "prof_%s" % tag, "**", "*.db"), recursive=True)
+        if not db:
+            return []
+        cur = sqlite3.connect(db[0]).cursor()
+        return cur.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name").fetchall()
+
+    calib_bytes = float(1 << 30)
+    factors = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for name, counter, n, total in rows("calib_" + c):
+            k = short(name)
+            if k.startswith("calib_") and total:
+                factors["%s:%s" % (c, k)] = calib_bytes * n / total      # bytes per counter unit
+    # the bench kernels move 4-byte (pixel kernels) to 16-byte (descriptor / cloud) pieces per lane: use the 4-byte factors,
+    # and report both so that the choice can be checked
+    f_fetch = factors.get("FETCH_SIZE:calib_read_b32")
+    f_write = factors.get("WRITE_SIZE:calib_write_b32")
+    # bench.py runs `warmup` + `steps` timed steps and 3 more for its per-kernel timing leg, all serialised
+    n_steps = int(steps) + int(warmup) + 3
+    kernels = {}
+    for c, f, key in (("FETCH_SIZE", f_fetch, "fetch_bytes_per_step"), ("WRITE_SIZE", f_write, "write_bytes_per_step")):
+        for name, counter, n, total in rows("bench_" + c):
+            k = short(name)
+            if not k.startswith("k_"):
+                continue
+            d = kernels.setdefault(k, {"fetch_bytes_per_step": 0.0, "write_bytes_per_step": 0.0})
+            d[key] = (total or 0.0) * (f or 0.0) / n_steps
+            d["dispatches_per_step"] = n / n_steps
+    json.dump({"frames_per_step": int(frames_per_step), "steps_profiled": n_steps,
+               "bytes_per_counter_unit": factors, "factor_used": {"FETCH_SIZE": f_fetch, "WRITE_SIZE": f_write},
+               "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --serial --no-cpu-baseline --no-extras --steps %s --warmup %s" % (steps, warmup),
+               "kernels": kernels}, open(out, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    if sys.argv[1] == "traffic":
+        traffic(*sys.argv[2:7])
+    else:
+        {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])

@@ -1,10 +1,13 @@
-"""The N > 1 path on CPU: two processes (gloo), frames sharded by rank, records gathered to rank 0, and the
-gathered result must be byte-identical to what a single process produces for all frames (BASELINE configs[3])."""
+"""The N > 1 path on CPU: two processes (gloo) run the SAME pipeline code bench.py times (orb_slam3_rgbl_amd/pipeline.py:
+step = extract -> depth -> match, record packing, two-phase variable-length gather) with the SIMT-emulated library as the
+per-rank front end; what rank 0 gathers must be byte-identical to what a single process computes for every rank's input,
+and the records must decode to the oracle's keypoints / descriptors / depths (BASELINE configs[3])."""
 import os
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from orb_slam3_rgbl_amd import sharding
 
@@ -14,40 +17,69 @@ WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["RGBL_ROOT"])
 import numpy as np, torch, torch.distributed as dist
-from orb_slam3_rgbl_amd import sharding, synth
-from oracle import oracle_py as O   # stands in for the per-rank GPU front end: same record layout
+from orb_slam3_rgbl_amd import _lib, synth, sharding
+from orb_slam3_rgbl_amd import frontend as F
+from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline, unpack_records
 
-def records_for(seq_ids, frames_per_seq, w, h, cap):
-    ex = O.Extractor(300, 1.2, 4, 20, 7)
-    n, kp, desc, dep, ur = [], [], [], [], []
-    for s in seq_ids:
-        sq = synth.Sequence(s, w, h, n_frames=frames_per_seq)
-        for t in range(frames_per_seq):
-            k, d, _ = ex(sq.frame(t))
-            m = len(k)
-            kk = np.zeros((cap, 7), np.float32); kk.view(np.uint8).reshape(cap, 28)[:m] = k.view(np.uint8).reshape(m, 28)
-            dd = np.zeros((cap, 32), np.uint8); dd[:m] = d
-            de = np.full(cap, -1, np.float32); de[:m] = k["response"]          # any per-keypoint float payload
-            uu = np.full(cap, -1, np.float32); uu[:m] = k["x"] - 100.0 / np.maximum(k["response"], 1)
-            n.append(m); kp.append(kk); desc.append(dd); dep.append(de); ur.append(uu)
-    return (torch.tensor(n, dtype=torch.int32), torch.from_numpy(np.stack(kp)), torch.from_numpy(np.stack(desc)),
-            torch.from_numpy(np.stack(dep)), torch.from_numpy(np.stack(ur)))
+W, H, NF, LEVELS, B, STEPS, N_AZ = 200, 160, 300, 4, 3, 3, 240
+MODE = os.environ["RGBL_GATHER"]
+
+def inputs_of(rank):
+    sq = synth.Sequence(100 + rank, W, H, n_frames=B)
+    frames = np.stack([sq.frame(i) for i in range(B)])
+    cloud = np.stack([synth.lidar_scan(100 * rank + i, n_az=N_AZ) for i in range(B)])
+    return frames, cloud
+
+def make(lib, rank, world, gather, keep=0):
+    K = synth.KITTI_K.copy(); K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+    proj = F.projection_matrix(K, synth.KITTI_TR, lib)
+    frames, cloud = inputs_of(rank)
+    pipe = FrontEndPipeline(lib, torch, torch.device("cpu"), W, H, NF, proj, cloud.shape[2], B, levels=LEVELS, ini_th=20, min_th=7,
+                            world=world, rank=rank, gather=gather, keep_steps=keep, log_steps=STEPS)
+    pipe.set_inputs(torch.from_numpy(frames), torch.from_numpy(cloud))
+    return pipe, frames, cloud, proj
 
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    w, h, cap, n_seq, fps = 200, 160, 400, 4, 2
-    mine = sharding.sequences_of_rank(n_seq, world, rank)
-    send = sharding.pack_records(*records_for(mine, fps, w, h, cap))
-    got = sharding.gather_records(send, dst=0)
+    lib = _lib.bind(os.environ["RGBL_EMU_LIB"])
+    pipe, _, _, _ = make(lib, rank, world, MODE, keep=STEPS)
+    for _ in range(STEPS):
+        pipe.step()
+    pipe.finish()
+    pipe.sync()
+    ok = True
     if rank == 0:
-        # single-process result for every sequence, in (rank, local order) order
-        ok = True
+        from oracle import oracle_py as O   # the checker
+        ok &= len(pipe.received) == STEPS
         for r in range(world):
-            ref = sharding.pack_records(*records_for(sharding.sequences_of_rank(n_seq, world, r), fps, w, h, cap))
-            ok &= torch.equal(got[r], ref)
-            frames = sharding.unpack_records(got[r], cap)
-            ok &= all(f["n"] > 0 and f["desc"].shape == (f["n"], 32) for f in frames)
+            # what a single process produces for rank r's input
+            solo, frames, cloud, proj = make(lib, r, 1, "none")
+            solo.step(); solo.sync()
+            o = solo.last()
+            n = o.n.numpy()
+            for got in pipe.received:                      # every step processed the same resident batch
+                counts, rec = got[r]
+                ok &= np.array_equal(counts, n)
+                fr = unpack_records(rec.numpy(), counts)
+                for f in range(B):
+                    m = int(n[f])
+                    ok &= np.array_equal(fr[f]["kp"], o.kp[f, :m].numpy().view(np.uint8).reshape(m, 28))
+                    ok &= np.array_equal(fr[f]["desc"], o.desc[f, :m].numpy())
+                    ok &= np.array_equal(fr[f]["depth"].view(np.uint32), o.depth[f, :m].numpy().view(np.uint32))
+                    ok &= np.array_equal(fr[f]["uright"].view(np.uint32), o.uright[f, :m].numpy().view(np.uint32))
+            # and the records decode to the oracle's results
+            orc = O.Extractor(NF, 1.2, LEVELS, 20, 7)
+            P = O.make_depth_params(proj)
+            fr = unpack_records(pipe.received[-1][r][1].numpy(), pipe.received[-1][r][0])
+            for f in range(B):
+                okps, odesc, _ = orc(frames[f])
+                ok &= fr[f]["n"] == len(okps) and np.array_equal(fr[f]["kp"], okps.view(np.uint8).reshape(len(okps), 28))
+                ok &= np.array_equal(fr[f]["desc"], odesc)
+                od, our, _, _ = O.depth(P, cloud[f], W, H, np.stack([okps["x"], okps["y"]], 1), okps["x"], want_maps=False)
+                ok &= np.array_equal(fr[f]["depth"].view(np.uint32), od.view(np.uint32))
+                ok &= np.array_equal(fr[f]["uright"].view(np.uint32), our.view(np.uint32))
+            solo.close()
         print("GATHER_OK" if ok else "GATHER_MISMATCH")
     dist.barrier()
     dist.destroy_process_group()
@@ -67,31 +99,46 @@ def test_chunk_partition_covers_all_frames_with_halo():
     assert sharding.sequences_of_rank(11, 8, 2) == [2, 10]
 
 
-def test_pack_unpack_roundtrip():
+def test_pack_unpack_roundtrip(emu_lib):
+    import ctypes as C
+
     import torch
+
+    from orb_slam3_rgbl_amd import _lib as L
+    from orb_slam3_rgbl_amd.pipeline import RECORD_BYTES, unpack_records
     rng = np.random.default_rng(0)
-    B, cap = 3, 50
-    n = torch.tensor([50, 0, 17], dtype=torch.int32)
+    B, cap = 4, 50
+    n = torch.tensor([50, 0, 17, 3], dtype=torch.int32)
     kp = torch.from_numpy(rng.standard_normal((B, cap, 7)).astype(np.float32))
     desc = torch.from_numpy(rng.integers(0, 256, (B, cap, 32), dtype=np.uint8))
     dep = torch.from_numpy(rng.standard_normal((B, cap)).astype(np.float32))
     ur = torch.from_numpy(rng.standard_normal((B, cap)).astype(np.float32))
-    buf = sharding.pack_records(n, kp, desc, dep, ur)
-    assert buf.shape == (B, sharding.record_bytes(cap))
-    fr = sharding.unpack_records(buf, cap)
+    out = torch.zeros(B * cap * RECORD_BYTES, dtype=torch.uint8)
+    off = torch.zeros(B + 1, dtype=torch.int64)
+    ovf = torch.zeros(1, dtype=torch.int32)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    L.check(emu_lib, emu_lib.rgbl_pack_records_device(None, p(n), p(kp), p(desc), p(dep), p(ur), B, cap, 0, B * cap, p(out), p(off), p(ovf)))
+    assert off.tolist() == [0, 50, 50, 67, 70] and int(ovf[0]) == 0
+    fr = unpack_records(out.numpy(), n.numpy())
     for i in range(B):
         m = int(n[i])
         assert fr[i]["n"] == m
         assert np.array_equal(fr[i]["desc"], desc[i, :m].numpy())
         assert np.array_equal(fr[i]["kp"], kp[i, :m].numpy().view(np.uint8).reshape(m, 28))
         assert np.array_equal(fr[i]["depth"], dep[i, :m].numpy()) and np.array_equal(fr[i]["uright"], ur[i, :m].numpy())
+    # a buffer that is too small: the overflow flag is raised, nothing is written past the end
+    small = torch.zeros(60 * RECORD_BYTES, dtype=torch.uint8)
+    L.check(emu_lib, emu_lib.rgbl_pack_records_device(None, p(n), p(kp), p(desc), p(dep), p(ur), B, cap, 0, 60, p(small), p(off), p(ovf)))
+    assert int(ovf[0]) == 1
 
 
-def test_two_rank_gather_equals_single_process(tmp_path, oracle):
+@pytest.mark.parametrize("mode,port", [("step", 29517), ("final", 29519)])
+def test_two_rank_gather_equals_single_process(tmp_path, oracle, emu_lib, mode, port):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, RGBL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, RGBL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", RGBL_GATHER=mode, RGBL_EMU_THREADS="2",
+               RGBL_EMU_LIB=os.path.join(ROOT, "tests", "_build", "librgbl_frontend_emu.so"))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
-                         env=env, capture_output=True, text=True, timeout=300)
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
     assert "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

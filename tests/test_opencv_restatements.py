@@ -126,7 +126,8 @@ def fast_atan2_numpy(y, x):
     def poly(c):
         c2 = c * c
         return (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
-    a = np.where(ax >= ay, poly(c_lo), f(90.0) - poly(c_hi)).astype(np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):   # the branch that is not selected may overflow
+        a = np.where(ax >= ay, poly(c_lo), f(90.0) - poly(c_hi)).astype(np.float32)
     a = np.where(x < 0, f(180.0) - a, a).astype(np.float32)
     a = np.where(y < 0, f(360.0) - a, a).astype(np.float32)
     return a

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 for setting in "$@"; do
   tag=$(echo "$setting" | tr -c 'A-Za-z0-9_=\n' '_')
   if [ "$setting" = "-" ]; then envs=""; else envs="$setting"; fi
-  env $envs timeout 150 python bench.py --no-cpu-baseline > gpurun_out/ab_$tag.json 2> gpurun_out/ab_$tag.err
+  env $envs timeout 150 python bench.py --no-cpu-baseline --no-extras > gpurun_out/ab_$tag.json 2> gpurun_out/ab_$tag.err
   python - "$tag" <<'PY'
 import json, sys
 tag = sys.argv[1]
