@@ -278,6 +278,14 @@ int rgbl_depth_profile_read(rgbl_depth* h, const char** names, double* total_ms,
 typedef struct rgbl_matcher rgbl_matcher;
 int rgbl_matcher_create(int device, rgbl_matcher** out);
 void rgbl_matcher_destroy(rgbl_matcher* h);
+/* Pooled handles for callers that build their matcher per call, as the reference does: `ORBmatcher matcher(0.9, true);`
+ * is a function-local object in Tracking::TrackReferenceKeyFrame / TrackWithMotionModel / SearchLocalPoints / Relocalization
+ * (Tracking.cc:2525, 2761, 2890, 3424, 3662, 3701) and LocalMapping::CreateNewMapPoints (LocalMapping.cc:412).  acquire gives
+ * an idle handle of `device` (or creates the first ones), release parks it; the HIP stream and the device arena live on, so
+ * constructing / destroying the drop-in class costs no HIP object.  Handles held at the same time are distinct. */
+int rgbl_matcher_acquire(int device, rgbl_matcher** out);
+void rgbl_matcher_release(rgbl_matcher* h);
+int rgbl_matcher_pool_size(void);  /* idle handles (diagnostics / tests) */
 int rgbl_matcher_sync(rgbl_matcher* h);
 int rgbl_matcher_set_stream(rgbl_matcher* h, void* hip_stream);
 void* rgbl_matcher_stream(rgbl_matcher* h);
@@ -292,6 +300,15 @@ int rgbl_descriptor_distance(const uint8_t* a, const uint8_t* b);
  * Host pointers, synchronous.  second_dist may be NULL. */
 int rgbl_hamming_bf(rgbl_matcher* h, const uint8_t* desc_a, int na, const uint8_t* desc_b, int nb,
                     int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+/* Frame::ComputeStereoFishEyeMatches (/root/reference/src/Frame.cc:1256-1296) up to the triangulation:
+ * the lapping-area subsets of both images - rows [mono_left, n_left) and [mono_right, n_right), monoLeft / monoRight being
+ * what ORBextractor::operator() returned (Frame.cc:512-514) - matched by cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2) and
+ * Lowe's ratio test `size() >= 2 && best.distance < second.distance * 0.7`.  left_to_right[i] (n_left entries, indices into
+ * the FULL right arrays like mvLeftToRightMatch) = the right keypoint that passed, else -1; best_dist / second_dist
+ * (nullable, n_left entries, 256 = none) are the two knnMatch distances.  KannalaBrandt8::TriangulateMatches and the
+ * `depth > 0.0001f` gate (Frame.cc:1287-1294) stay with the caller, who owns the camera objects.  Host pointers, synchronous. */
+int rgbl_stereo_fisheye_matches(rgbl_matcher* h, const uint8_t* desc_left, int n_left, int mono_left, const uint8_t* desc_right,
+                                int n_right, int mono_right, int32_t* left_to_right, int32_t* best_dist, int32_t* second_dist);
 /* Device batch over frame pairs: descriptors of frame f live at d_desc + f*cap*32 with d_n[f] rows
  * (the layout rgbl_extract_batch_device() writes).  Pair p matches frame pair_a[p] (queries) against
  * frame pair_b[p] (train); outputs for pair p start at p*cap. */

@@ -86,6 +86,27 @@ void orc_hamming_bf(const uint8_t* a, int na, const uint8_t* b, int nb, int* bes
   }
 }
 
+void orc_stereo_fisheye_matches(const uint8_t* desc_left, int n_left, int mono_left, const uint8_t* desc_right, int n_right,
+                                int mono_right, int* left_to_right, int* best_dist, int* second_dist) {
+  // /root/reference/src/Frame.cc:1256-1296 up to the triangulation.  cv::BFMatcher::knnMatch(k = 2) with NORM_HAMMING and
+  // no cross check: per query the two smallest distances over the train rows in index order; a row displaces an entry of
+  // the pair only when its distance is strictly smaller (cv::batchDistance's K-nearest update), so the lower index wins ties.
+  for (int i = 0; i < n_left; ++i) { left_to_right[i] = -1; best_dist[i] = 256; second_dist[i] = 256; }
+  const int nt = n_right - mono_right;
+  for (int i = mono_left; i < n_left; ++i) {
+    int d0 = INT_MAX, d1 = INT_MAX, j0 = -1;
+    for (int j = mono_right; j < n_right; ++j) {
+      const int d = hamming256(desc_left + 32 * (size_t)i, desc_right + 32 * (size_t)j);
+      if (d < d0) { d1 = d0; d0 = d; j0 = j; }
+      else if (d < d1) d1 = d;
+    }
+    if (nt >= 1) best_dist[i] = d0;
+    if (nt >= 2) second_dist[i] = d1;
+    // Lowe's ratio: (*it).size() >= 2 && (*it)[0].distance < (*it)[1].distance * 0.7   (DMatch::distance is a float)
+    if (nt >= 2 && (double)(float)d0 < (double)(float)d1 * 0.7) left_to_right[i] = j0;
+  }
+}
+
 void orc_fundamental(const float K1[4], const float K2[4], const float R12[9], const float t12[3],
                      float F12[9]) {
   // Pinhole.cpp:109-112: F12 = K1^T^-1 * [t12]x * R12 * K2^-1, fp32, products left to right

@@ -129,6 +129,10 @@ int orc_structuring_element(int shape, int kw, int kh, uint8_t* out);
 /* ---- ORBmatcher ---- */
 int orc_descriptor_distance(const uint8_t* a, const uint8_t* b); /* ORBmatcher.cc:2058-2074 */
 /* brute force best / second-best (rule of ORBmatcher.cc:283-304: strict '<', first wins) */
+/* Frame::ComputeStereoFishEyeMatches (/root/reference/src/Frame.cc:1256-1296) up to the triangulation: knnMatch(k = 2) of
+ * the lapping-area subsets [mono, n) + Lowe's ratio 0.7; outputs have n_left entries (-1 / 256 = none). */
+void orc_stereo_fisheye_matches(const uint8_t* desc_left, int n_left, int mono_left, const uint8_t* desc_right, int n_right,
+                                int mono_right, int* left_to_right, int* best_dist, int* second_dist);
 void orc_hamming_bf(const uint8_t* a, int na, const uint8_t* b, int nb, int* best_idx, int* best_dist,
                     int* second_dist);
 

@@ -469,6 +469,17 @@ def stereo_matches(ex_left, ex_right, kpl, dl, kpr, dr, mb, mbf):
     return ur, dp
 
 
+def stereo_fisheye_matches(desc_left, mono_left, desc_right, mono_right):
+    a = np.ascontiguousarray(desc_left, np.uint8).reshape(-1, 32)
+    b = np.ascontiguousarray(desc_right, np.uint8).reshape(-1, 32)
+    l2r, bd, sd = (np.zeros(len(a), np.int32) for _ in range(3))
+    f = lib().orc_stereo_fisheye_matches
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    f(_p(a), len(a), int(mono_left), _p(b), len(b), int(mono_right), _p(l2r), _p(bd), _p(sd))
+    return l2r, bd, sd
+
+
 def resize_linear(src, dw, dh):
     src = np.ascontiguousarray(src, np.uint8)
     dst = np.zeros((dh, dw), np.uint8)

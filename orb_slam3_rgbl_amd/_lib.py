@@ -165,7 +165,11 @@ SYMBOLS = {
     "rgbl_matcher_profile": (_I, [_V, _I]),
     "rgbl_matcher_profile_read": (_I, [_V, _V, _V, _V, _I]),
     "rgbl_descriptor_distance": (_I, [_V, _V]),
+    "rgbl_matcher_acquire": (_I, [_I, C.POINTER(_V)]),
+    "rgbl_matcher_release": (None, [_V]),
+    "rgbl_matcher_pool_size": (_I, []),
     "rgbl_hamming_bf": (_I, [_V, _V, _I, _V, _I, _V, _V, _V]),
+    "rgbl_stereo_fisheye_matches": (_I, [_V, _V, _I, _I, _V, _I, _I, _V, _V, _V]),
     "rgbl_hamming_bf_batch_device": (_I, [_V, _V, _V, _I, _V, _V, _I, _V, _V, _V]),
     "rgbl_search_triangulation": (_I, [_V, C.POINTER(KeyframeView), C.POINTER(KeyframeView),
                                        C.POINTER(TriangulationParams), _V, C.POINTER(_I)]),

@@ -39,6 +39,16 @@ const char* last_error();
 
 constexpr int kWave = 64;  // gfx950 wavefront width; hard-coded on purpose
 
+// Host-pointer entry points queue uploads from caller / stack buffers; whichever way such a function is left - also through
+// an RGBL_HIP / RGBL_TRY error return - the stream is drained first, so nothing still reads memory the caller frees next.
+struct StreamDrain {
+  hipStream_t s;
+  explicit StreamDrain(hipStream_t stream) : s(stream) {}
+  ~StreamDrain() { (void)hipStreamSynchronize(s); }
+  StreamDrain(const StreamDrain&) = delete;
+  StreamDrain& operator=(const StreamDrain&) = delete;
+};
+
 // ---- per-kernel timing (HIP events on the launch stream), used by bench.py's roofline leg
 struct KernelTimer {
   struct Rec { int id; hipEvent_t a, b; };

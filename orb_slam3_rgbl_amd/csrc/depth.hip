@@ -590,6 +590,7 @@ static int depth_compute_host(rgbl_depth* e, const float* cloud, int n, int ld, 
   }
   RGBL_HIP(hipSetDevice(e->device));
   hipStream_t s = e->stream;
+  StreamDrain drain(s);  // error returns included: the uploads below read the caller's buffers
   if (n > 0) {
     if (xyzi) RGBL_HIP(hipMemcpyAsync(e->d_cloud, cloud, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, s));
     else RGBL_HIP(hipMemcpy2DAsync(e->d_cloud, sizeof(float) * n, cloud, sizeof(float) * ld, sizeof(float) * n, 4, hipMemcpyHostToDevice, s));

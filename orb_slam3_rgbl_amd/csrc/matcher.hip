@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -1122,6 +1123,54 @@ void rgbl_matcher_destroy(rgbl_matcher* m) {
   delete m;
 }
 
+// Pool of matcher handles.  The reference builds its ORBmatcher as a function-local object in every Tracking / LocalMapping /
+// LoopClosing call (Tracking.cc:2525, 2761, 2890, 3424, 3662, 3701; LocalMapping.cc:412): a drop-in class that created a HIP
+// stream (and later freed a device arena, which synchronises the whole device) per object would pay that several times per
+// frame.  acquire() hands out an idle handle of the device or creates one; release() parks it again - stream and arena stay
+// alive for the life of the process.  Handles in use at the same time are distinct, so concurrent callers keep overlapping.
+namespace {
+struct MatcherPool {
+  std::mutex mu;
+  std::vector<rgbl_matcher*> idle;
+};
+MatcherPool* matcher_pool_ptr() {
+  static MatcherPool* pool = new MatcherPool;  // never destroyed: no HIP calls from static destructors
+  return pool;
+}
+}  // namespace
+
+int rgbl_matcher_acquire(int device, rgbl_matcher** out) {
+  if (!out) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  {
+    MatcherPool& P = *matcher_pool_ptr();
+    std::lock_guard<std::mutex> lock(P.mu);
+    for (size_t i = 0; i < P.idle.size(); ++i)
+      if (P.idle[i]->device == device) {
+        *out = P.idle[i];
+        P.idle.erase(P.idle.begin() + (long)i);
+        return RGBL_OK;
+      }
+  }
+  return rgbl_matcher_create(device, out);
+}
+
+void rgbl_matcher_release(rgbl_matcher* m) {
+  if (!m) return;
+  if (m->stream != m->own_stream) {  // a borrowed stream must not outlive its owner's wishes
+    (void)hipStreamSynchronize(m->stream);
+    m->stream = m->own_stream;
+  }
+  MatcherPool& P = *matcher_pool_ptr();
+  std::lock_guard<std::mutex> lock(P.mu);
+  P.idle.push_back(m);
+}
+
+int rgbl_matcher_pool_size(void) {
+  MatcherPool& P = *matcher_pool_ptr();
+  std::lock_guard<std::mutex> lock(P.mu);
+  return (int)P.idle.size();
+}
+
 int rgbl_matcher_sync(rgbl_matcher* m) {
   if (!m) { set_error("null handle"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipSetDevice(m->device));
@@ -1199,6 +1248,7 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   }
   if (na == 0) return RGBL_OK;
   RGBL_HIP(hipSetDevice(m->device));
+  StreamDrain drain(m->stream);  // error returns included
   const int cap = std::max(std::max(na, nb), 1);
   RGBL_TRY(ensure_arena(m, pad256((size_t)2 * cap * 32) + pad256(8) + 3 * pad256((size_t)na * 4)));
   Arena A{m->d_buf};
@@ -1229,6 +1279,35 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   if (second_dist) RGBL_HIP(hipMemcpyAsync(second_dist, d_sd, sizeof(int32_t) * na, hipMemcpyDeviceToHost, s));
   RGBL_HIP(hipStreamSynchronize(s));
   m->timer.collect();
+  return RGBL_OK;
+}
+
+int rgbl_stereo_fisheye_matches(rgbl_matcher* m, const uint8_t* desc_left, int n_left, int mono_left, const uint8_t* desc_right,
+                                int n_right, int mono_right, int32_t* left_to_right, int32_t* best_dist, int32_t* second_dist) {
+  // Frame::ComputeStereoFishEyeMatches (/root/reference/src/Frame.cc:1256-1296) up to the triangulation: the lapping-area
+  // subsets [mono, n) of both descriptor sets, cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2) = best and second-best train
+  // row of every query (strict '<': the lower index stays in front on ties), then Lowe's ratio
+  // `matches.size() >= 2 && best < second * 0.7` (float times double, compared in double)
+  if (!m || n_left < 0 || n_right < 0 || mono_left < 0 || mono_right < 0 || mono_left > n_left || mono_right > n_right ||
+      (n_left > 0 && (!desc_left || !left_to_right)) || (n_right > 0 && !desc_right)) {
+    set_error("invalid argument");
+    return RGBL_ERR_INVALID;
+  }
+  for (int i = 0; i < n_left; ++i) {
+    left_to_right[i] = -1;
+    if (best_dist) best_dist[i] = 256;
+    if (second_dist) second_dist[i] = 256;
+  }
+  const int nq = n_left - mono_left, nt = n_right - mono_right;
+  if (nq == 0 || nt == 0) return RGBL_OK;
+  std::vector<int32_t> bi(nq), bd(nq), sd(nq);
+  RGBL_TRY(rgbl_hamming_bf(m, desc_left + (size_t)mono_left * 32, nq, desc_right + (size_t)mono_right * 32, nt, bi.data(), bd.data(),
+                           sd.data()));
+  for (int i = 0; i < nq; ++i) {
+    if (best_dist) best_dist[mono_left + i] = bd[i];
+    if (second_dist) second_dist[mono_left + i] = nt >= 2 ? sd[i] : 256;
+    if (nt >= 2 && (double)(float)bd[i] < (double)(float)sd[i] * 0.7) left_to_right[mono_left + i] = bi[i] + mono_right;
+  }
   return RGBL_OK;
 }
 
@@ -1284,6 +1363,7 @@ int rgbl_search_triangulation(rgbl_matcher* m, const rgbl_keyframe_view* k1, con
   const int npairs = (int)pa.size();
   if (npairs > 0 && n1 > 0 && n2 > 0) {
     RGBL_HIP(hipSetDevice(m->device));
+  StreamDrain drain(m->stream);  // error returns included
     const int nf1 = k1->node_off[k1->n_nodes], nf2 = k2->node_off[k2->n_nodes];
     size_t need = pad256((size_t)n1 * 32) + pad256((size_t)n2 * 32) + pad256((size_t)n1 * 8) + pad256((size_t)n2 * 8) +
                   pad256((size_t)n2 * 4) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 4) + pad256(n1) + pad256(n2) +
@@ -1396,6 +1476,7 @@ int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* o
   for (int i = 0; i < n1; ++i)
     if (in.valid1[i] && (in.oct1[i] < 0 || in.oct1[i] >= in.n_levels)) { set_error("octave out of range"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipSetDevice(m->device));
+  StreamDrain drain(m->stream);  // error returns included
   size_t need = pad256(n1) * 2 + pad256((size_t)n1 * 12) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 8) +
                 pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 3 + pad256(n2) +
                 pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 + pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) +
@@ -1547,6 +1628,7 @@ int rgbl_distinctive_descriptors(rgbl_matcher* m, const uint8_t* desc, const int
     if (off[p + 1] < off[p] || off[p + 1] - off[p] > 65535) { set_error("offsets must ascend, at most 65535 observations per point"); return RGBL_ERR_INVALID; }
   if (off[0] != 0 || (total > 0 && !desc)) { set_error("offsets start at 0; descriptors missing"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipSetDevice(m->device));
+  StreamDrain drain(m->stream);  // error returns included
   RGBL_TRY(ensure_arena(m, pad256((size_t)total * 32) + pad256((size_t)(n_points + 1) * 4) + pad256((size_t)n_points * 4)));
   Arena A{m->d_buf};
   hipStream_t s = m->stream;
@@ -1577,6 +1659,7 @@ static int fuse_core(rgbl_matcher* m, const rgbl_fuse_input* in, int cam_frame, 
   for (int i = 0; i < n1; ++i)
     if (in->valid1[i] && (in->level1[i] < 0 || in->level1[i] >= in->n_levels)) { set_error("predicted level out of range"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipSetDevice(m->device));
+  StreamDrain drain(m->stream);  // error returns included
   size_t need = pad256(n1) + pad256((size_t)n1 * 12) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 8) +
                 pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 2 +
                 pad256((size_t)n1 * 8) + pad256((size_t)(kGridCells + 1) * 4);
@@ -1694,6 +1777,7 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
   for (int i = 0; i < n1; ++i)
     if (in->valid1[i] && (in->level1[i] < 0 || in->level1[i] >= in->n_levels)) { set_error("predicted level out of range"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipSetDevice(m->device));
+  StreamDrain drain(m->stream);  // error returns included
   size_t need = pad256(n1) * 2 + pad256((size_t)n1 * 12) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) * 2 + pad256((size_t)n2 * 8) +
                 pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256(n2) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 2 +
                 pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 + pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) +
@@ -1763,6 +1847,7 @@ int rgbl_search_for_initialization(rgbl_matcher* m, const rgbl_initialization_in
   for (int i = 0; i < n1; ++i)
     if (in->kp1_octave[i] < 0) { set_error("negative octave"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipSetDevice(m->device));
+  StreamDrain drain(m->stream);  // error returns included
   size_t need = pad256((size_t)n1 * 8) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 8) + pad256((size_t)n2 * 4) +
                 pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 3 + pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 +
                 pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) + pad256((size_t)(kGridCells + 1) * 4);
@@ -2083,6 +2168,7 @@ static int bow_core(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_ke
       return RGBL_ERR_CAPACITY;
     }
   RGBL_HIP(hipSetDevice(m->device));
+  StreamDrain drain(m->stream);  // error returns included
   const int nf1 = kf->node_off[kf->n_nodes], nf2 = fr->node_off[fr->n_nodes];
   size_t need = pad256((size_t)n1 * 32) + pad256((size_t)n2 * 32) + pad256(n1) + pad256(n2) + pad256((size_t)(kf->n_nodes + 1) * 4) +
                 pad256((size_t)nf1 * 4) + pad256((size_t)(fr->n_nodes + 1) * 4) + pad256((size_t)nf2 * 4) +

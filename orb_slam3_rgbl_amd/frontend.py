@@ -312,6 +312,17 @@ class ORBmatcher:
         L.check(self.lib, self.lib.rgbl_hamming_bf(self.h, L.ptr(a), len(a), L.ptr(b), len(b), L.ptr(bi), L.ptr(bd), L.ptr(sd)))
         return bi, bd, sd
 
+    def StereoFishEyeMatches(self, desc_left, mono_left, desc_right, mono_right):
+        """Frame::ComputeStereoFishEyeMatches up to the triangulation: (mvLeftToRightMatch candidates, best, second distances)."""
+        a = np.ascontiguousarray(desc_left, np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(desc_right, np.uint8).reshape(-1, 32)
+        l2r = np.full(len(a), -1, np.int32)
+        bd = np.full(len(a), 256, np.int32)
+        sd = np.full(len(a), 256, np.int32)
+        L.check(self.lib, self.lib.rgbl_stereo_fisheye_matches(self.h, L.ptr(a), len(a), int(mono_left), L.ptr(b), len(b), int(mono_right),
+                                                               L.ptr(l2r), L.ptr(bd), L.ptr(sd)))
+        return l2r, bd, sd
+
     def fundamental(self, K1, K2, R12, t12):
         a = [np.ascontiguousarray(v, np.float32) for v in (K1, K2, R12, t12)]
         F = np.zeros(9, np.float32)

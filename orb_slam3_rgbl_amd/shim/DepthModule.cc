@@ -72,6 +72,24 @@ DepthModule::DepthModule(const std::string& strSettingPath, const int /*sensor*/
   b_parse_LiDARUpsampling = false;
   b_parse_LiDARUpsampling = ParseUpsamplingParameters(strSettingPath);
   if (!b_parse_LiDARUpsampling) std::cout << "*Error in the LiDAR upsampling parameters in the config file*" << std::endl;
+  // What the device path cannot do is reported ONCE, here, and switches the module off like a parse failure does - not
+  // once per frame from CalculateDepthFromPcd (the reference accepts any structuring-element size; the kernels hold 9 x 9).
+  if (b_parse_LiDARUpsampling && b_parse_LiDAR) {
+    const char* why = nullptr;
+    if (SelectedUpsamlingMethod == InverseDilation) {
+      const std::string& t = ParamUpsampling_InverseDilation_KernelType;
+      const int ku = ParamUpsampling_InverseDilation_KernelSize_u, kv = ParamUpsampling_InverseDilation_KernelSize_v;
+      if (t == "Diamond") { if (ku != 3 && ku != 5 && ku != 7 && ku != 9) why = "Diamond kernels exist for sizes 3, 5, 7 and 9 (DepthModule.h:138-161)"; }
+      else if ((t == "Rectangle" || t == "Cross" || t == "Ellipse") && (ku < 1 || kv < 1 || ku > 9 || kv > 9)) why = "structuring elements larger than 9 x 9 are not supported by the device kernels";
+    } else if (SelectedUpsamlingMethod == AverageFiltering &&
+               (ParamUpsampling_AverageFilter_KernelSize < 1 || ParamUpsampling_AverageFilter_KernelSize > 9)) {
+      why = "averaging kernels larger than 9 x 9 are not supported by the device kernels";
+    }
+    if (why) {
+      std::cout << "*LiDAR upsampling disabled: " << why << "*" << std::endl;
+      b_parse_LiDARUpsampling = false;
+    }
+  }
 }
 
 DepthModule::~DepthModule() { rgbl_depth_destroy(mpHandle); }
@@ -245,6 +263,10 @@ void DepthModule::Compute(const std::vector<cv::KeyPoint>& mvKeys, const std::ve
     return;
   }
   const int N = (int)mvKeys.size();
+  // every reachable method of the reference starts from N x -1 (DepthModule.cc:86-87, 163-164): Frame copies these vectors
+  // right after the call (Frame.cc:332-333), so they must have the right size even when the device path fails below
+  mvuRight = std::vector<float>(N, -1);
+  mvDepth = std::vector<float>(N, -1);
   EnsureHandle(imwidth, imheight, nPoints, N);
   if (!mpHandle) return;
   std::vector<float> kp_xy(2 * (size_t)N), kpun_x(N);
@@ -253,8 +275,6 @@ void DepthModule::Compute(const std::vector<cv::KeyPoint>& mvKeys, const std::ve
     kp_xy[2 * i + 1] = mvKeys[i].pt.y;
     kpun_x[i] = mvKeysUn[i].pt.x;
   }
-  mvuRight = std::vector<float>(N, -1);
-  mvDepth = std::vector<float>(N, -1);
   float *raw = nullptr, *proc = nullptr;
   if (downloadDenseMaps) {
     RawDepthMap.create(imheight, imwidth, CV_32F);

@@ -34,12 +34,14 @@ namespace ORB_SLAM3 {
 class ORBmatcher {
  public:
   ORBmatcher(float nnratio = 0.6, bool checkOri = true, int device = 0) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {
-    if (rgbl_matcher_create(device, &mpHandle) != RGBL_OK) {
+    // the reference constructs this class on the stack in every call (Tracking.cc:2890 ...): the device handle comes from
+    // the library's pool and goes back to it, no HIP stream / arena is created or freed per object
+    if (rgbl_matcher_acquire(device, &mpHandle) != RGBL_OK) {
       std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
       mpHandle = nullptr;
     }
   }
-  ~ORBmatcher() { rgbl_matcher_destroy(mpHandle); }
+  ~ORBmatcher() { rgbl_matcher_release(mpHandle); }
   ORBmatcher(const ORBmatcher&) = delete;
   ORBmatcher& operator=(const ORBmatcher&) = delete;
 

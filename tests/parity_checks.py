@@ -201,6 +201,47 @@ def check_matcher_bf(lib, na=777, nb=700, seed=3):
     m.close()
 
 
+def check_stereo_fisheye_matches(lib, n_left=900, n_right=850, mono_left=300, mono_right=260, seed=7):
+    """Frame::ComputeStereoFishEyeMatches up to the triangulation (SURVEY 8(f) row f4): knnMatch(k = 2) + Lowe 0.7 on the
+    lapping-area subsets."""
+    m = F.ORBmatcher(0.6, False, lib=lib)
+    a = synth.descriptors(n_left, seed)
+    src = np.resize(a[mono_left:], (max(n_right - mono_right, 1), 32)) if n_left > mono_left else synth.descriptors(max(n_right - mono_right, 1), seed + 9)
+    b_tail, _ = synth.perturbed_descriptors(src, seed=seed + 1)
+    b = np.concatenate([synth.descriptors(mono_right, seed + 2), b_tail[:n_right - mono_right]]) if n_right else np.zeros((0, 32), np.uint8)
+    got = m.StereoFishEyeMatches(a, mono_left, b, mono_right)
+    want = O.stereo_fisheye_matches(a, mono_left, b, mono_right)
+    for g, w_, name in zip(got, want, ("left_to_right", "best", "second")):
+        assert np.array_equal(g, w_), name
+    m.close()
+    return int((got[0] >= 0).sum())
+
+
+def check_stereo_fisheye_known_answers(lib):
+    m = F.ORBmatcher(0.6, False, lib=lib)
+    z = np.zeros((1, 32), np.uint8)
+    def flip(k):  # descriptor with k bits set
+        d = np.zeros(32, np.uint8)
+        for i in range(k):
+            d[i // 8] |= 1 << (i % 8)
+        return d[None]
+    # 7 < 10 * 0.7 is false in double arithmetic (10 * 0.7 == 7.0), 6 < 7.0 is true; indices are into the FULL right array
+    right = np.concatenate([flip(200), flip(7), flip(10)])
+    l2r, bd, sd = m.StereoFishEyeMatches(z, 0, right, 1)
+    assert (l2r[0], bd[0], sd[0]) == (-1, 7, 10)
+    right = np.concatenate([flip(200), flip(10), flip(6)])
+    l2r, bd, sd = m.StereoFishEyeMatches(z, 0, right, 1)
+    assert (l2r[0], bd[0], sd[0]) == (2, 6, 10)
+    # the rows before mono are not matched at all; a single train row gives no second neighbour -> never a match
+    l2r, bd, sd = m.StereoFishEyeMatches(np.concatenate([z, z]), 1, np.concatenate([z, z, flip(100)]), 0)
+    assert list(l2r) == [-1, -1] and list(bd) == [256, 0] and list(sd) == [256, 0]   # tie 0 / 0: 0 < 0 is false
+    l2r, bd, sd = m.StereoFishEyeMatches(z, 0, np.concatenate([flip(50), z]), 1)
+    assert (l2r[0], bd[0], sd[0]) == (-1, 0, 256)
+    l2r, bd, sd = m.StereoFishEyeMatches(z, 0, np.zeros((0, 32), np.uint8), 0)
+    assert (l2r[0], bd[0], sd[0]) == (-1, 256, 256)
+    m.close()
+
+
 def check_matcher_known_answers(lib):
     m = F.ORBmatcher(0.6, False, lib=lib)
     z = np.zeros((1, 32), np.uint8)

@@ -15,11 +15,22 @@ SHIM = os.path.join(ROOT, "orb_slam3_rgbl_amd", "shim")
 
 
 def build(libdir, libname, exe):
+    """Compiles the shim test program; safe under pytest-xdist (file lock, atomic replace, skipped when up to date)."""
+    import fcntl
+    import glob
     os.makedirs(os.path.dirname(exe), exist_ok=True)
-    cmd = ["g++", "-O1", "-std=c++17", "-DRGBL_FORCE_CV_COMPAT", "-I" + SHIM, os.path.join(ROOT, "tests", "shim_test.cpp"),
-           os.path.join(SHIM, "ORBextractor.cc"), os.path.join(SHIM, "DepthModule.cc"), "-o", exe, "-L" + libdir,
-           "-l" + libname, "-Wl,-rpath," + libdir, "-pthread"]
-    subprocess.check_call(cmd)
+    srcs = [os.path.join(ROOT, "tests", "shim_test.cpp"), os.path.join(SHIM, "ORBextractor.cc"), os.path.join(SHIM, "DepthModule.cc")]
+    deps = srcs + glob.glob(os.path.join(SHIM, "*.h")) + [os.path.join(ROOT, "include", "rgbl_frontend.h"),
+                                                           os.path.join(libdir, "lib%s.so" % libname)]
+    with open(exe + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
+            return
+        tmp = "%s.tmp.%d" % (exe, os.getpid())
+        cmd = ["g++", "-O1", "-std=c++17", "-DRGBL_FORCE_CV_COMPAT", "-I" + SHIM] + srcs + ["-o", tmp, "-L" + libdir,
+               "-l" + libname, "-Wl,-rpath," + libdir, "-pthread"]
+        subprocess.check_call(cmd)
+        os.replace(tmp, exe)
 
 
 def write_kf(f, kf, sf, s2, Tcw, Twc):

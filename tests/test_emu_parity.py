@@ -200,3 +200,31 @@ def test_extractor_fused_level_kernel(emu_lib, monkeypatch, cells):
     pc.check_extractor(emu_lib, 752, 480, 1200, frames=(1,), ini=20, mn=7, stages=True)
     pc.check_extractor_edge_cases(emu_lib)
     pc.check_extractor_batch(emu_lib, 400, 300, 500, 3)
+
+
+def test_stereo_fisheye_matches(emu_lib):
+    pc.check_stereo_fisheye_known_answers(emu_lib)
+    assert pc.check_stereo_fisheye_matches(emu_lib, 400, 380, 120, 100) > 50
+    pc.check_stereo_fisheye_matches(emu_lib, 70, 3, 0, 2)      # one train row: no second neighbour
+    pc.check_stereo_fisheye_matches(emu_lib, 50, 40, 50, 10)   # empty left subset
+
+
+def test_matcher_handle_pool(emu_lib):
+    # the drop-in ORBmatcher is a stack object per call in the reference (Tracking.cc:2890 ...): handles come from a pool
+    import ctypes as C
+    from orb_slam3_rgbl_amd import _lib as L
+    base = emu_lib.rgbl_matcher_pool_size()
+    h1, h2, h3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    L.check(emu_lib, emu_lib.rgbl_matcher_acquire(0, C.byref(h1)))
+    emu_lib.rgbl_matcher_release(h1)
+    assert emu_lib.rgbl_matcher_pool_size() == max(base, 1) if base == 0 else base
+    L.check(emu_lib, emu_lib.rgbl_matcher_acquire(0, C.byref(h2)))
+    L.check(emu_lib, emu_lib.rgbl_matcher_acquire(0, C.byref(h3)))   # two in use at once: distinct handles
+    assert h2.value != h3.value and h2.value is not None
+    emu_lib.rgbl_matcher_release(h2)
+    emu_lib.rgbl_matcher_release(h3)
+    n = emu_lib.rgbl_matcher_pool_size()
+    h4 = C.c_void_p()
+    L.check(emu_lib, emu_lib.rgbl_matcher_acquire(0, C.byref(h4)))   # a parked handle is handed out again, none is created
+    assert h4.value in (h2.value, h3.value, h1.value) and emu_lib.rgbl_matcher_pool_size() == n - 1
+    emu_lib.rgbl_matcher_release(h4)

@@ -219,3 +219,12 @@ def test_extractor_fused_level_kernel(gpu_lib, monkeypatch):
     pc.check_extractor(gpu_lib, 3840, 2160, 8000, stages=True)
     pc.check_extractor_edge_cases(gpu_lib)
     pc.check_extractor_batch(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000, 8)
+
+
+def test_stereo_fisheye_matches(gpu_lib):
+    # SURVEY 8(f) row f4, second half: Frame::ComputeStereoFishEyeMatches' knnMatch(k = 2) + Lowe ratio on the lapping areas
+    pc.check_stereo_fisheye_known_answers(gpu_lib)
+    assert pc.check_stereo_fisheye_matches(gpu_lib, 2400, 2300, 800, 700) > 500
+    pc.check_stereo_fisheye_matches(gpu_lib, 9000, 8800, 100, 300, seed=8)
+    pc.check_stereo_fisheye_matches(gpu_lib, 70, 3, 0, 2)
+    pc.check_stereo_fisheye_matches(gpu_lib, 50, 40, 50, 10)
