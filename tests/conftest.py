@@ -5,6 +5,15 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm ships its own libamdhip64 (ROCm 7.0 in this image) while librgbl_frontend.so links the system one
+# (/opt/rocm, 7.2).  Whichever HIP runtime is mapped first serves the whole process; if it is the system one, torch's
+# device initialisation later reports "No HIP GPUs are available".  The tests that hand torch device tensors to the
+# library therefore need torch loaded first - as bench.py does.
+try:
+    import torch  # noqa: F401
+except ImportError:  # the CPU-only parts of the suite do not need it
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
