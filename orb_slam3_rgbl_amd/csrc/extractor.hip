@@ -71,6 +71,7 @@ struct rgbl_extractor {
   std::vector<FusedXGroup> xgrp;
   std::vector<int32_t> xsrc;
   bool use_fused = false;
+  bool xcd_map = true;  // XCD-aware workgroup -> (item, frame) mapping of the pixel kernels (common.h: xcd_item_frame); RGBL_XCD_MAP=0 switches it off
   int fused_threads = 512;  // work-items per workgroup of k_level_fused (RGBL_FUSED_THREADS = 256 | 512 | 1024)
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> per_level;
@@ -439,6 +440,7 @@ int upload_tables(rgbl_extractor* e) {
   // RGBL_FUSED=1: the fused per-level kernel (fused_level.h) instead of k_resize_linear + k_fast_cells + k_gauss7.
   // Measured on these synthetic frames (a third of the upper levels' pixels are FAST corners) it is on a par with the
   // three kernels (2.9 vs 2.7 ms per 512 frames, both bound by VALU issue), so it is not the default yet.
+  if (const char* v = getenv("RGBL_XCD_MAP")) e->xcd_map = v[0] != '0';
   const char* fz = getenv("RGBL_FUSED");
   e->use_fused = (fz && fz[0] == '1') && build_fused(e, xt, yt);
   if (const char* v = getenv("RGBL_FUSED_THREADS")) { const int t = atoi(v); if (t == 256 || t == 512) e->fused_threads = t; }
@@ -499,7 +501,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   auto launch_fast = [&](hipStream_t st, int cell_begin, int cell_end) {
     if (cell_end <= cell_begin) return;
     e->timer.begin("k_fast_cells", st);
-    hipLaunchKernelGGL(fast, dim3(cell_end - cell_begin, batch), dim3(256), 0, st, e->d_geom, L, d_imgs, stride, frame_stride,
+    hipLaunchKernelGGL(fast, xcd_grid(e->xcd_map, cell_end - cell_begin, batch), dim3(256), 0, st, e->d_geom, L, d_imgs, stride, frame_stride,
                        e->d_pyr, e->pyr_frame, e->cfg.ini_th_fast, e->cfg.min_th_fast, e->d_cellcnt, (size_t)e->cells_frame,
                        e->d_slots, e->slots_frame, cell_begin);
     e->timer.end(st);
@@ -507,7 +509,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   auto launch_gauss = [&](hipStream_t st, int tile_begin, int tile_end) {
     if (tile_end <= tile_begin) return;
     e->timer.begin("k_gauss7", st);
-    hipLaunchKernelGGL(k_gauss7, dim3(tile_end - tile_begin, batch), dim3(256), 0, st, e->d_geom, L,
+    hipLaunchKernelGGL(k_gauss7, xcd_grid(e->xcd_map, tile_end - tile_begin, batch), dim3(256), 0, st, e->d_geom, L,
                        e->blur_tiles, d_imgs, stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame, tile_begin);
     e->timer.end(st);
   };
@@ -562,7 +564,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       e->timer.begin(getenv("RGBL_FUSED_PER_LEVEL") ? kLevelName[l] : "k_level_fused", s);
       {
         const dim3 grid(T.ntx * T.nty, batch);
-#define RGBL_LAUNCH_FUSED(NT, TP) hipLaunchKernelGGL((k_level_fused<NT, TP>), grid, dim3(NT), T.lds_bytes, s, A)
+#define RGBL_LAUNCH_FUSED(NT, TP) hipLaunchKernelGGL((k_level_fused<NT, TP>), xcd_grid(e->xcd_map, T.ntx * T.nty, batch), dim3(NT), T.lds_bytes, s, A)
         switch (T.tile_pitch) {
           case 96: RGBL_LAUNCH_FUSED(512, 96); break;
           case 128: RGBL_LAUNCH_FUSED(512, 128); break;
@@ -648,7 +650,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   int lap_cap = cap;
   if (lapping) lap_cap = std::min(cap, e->out_cap);
   e->timer.begin("k_orient_brief", s);
-  hipLaunchKernelGGL(k_orient_brief, dim3((e->kp_frame + 4 * kKpPerWave - 1) / (4 * kKpPerWave), batch), dim3(256), 0, s, e->d_geom, L, e->umax,
+  hipLaunchKernelGGL(k_orient_brief, xcd_grid(e->xcd_map, (e->kp_frame + 4 * kKpPerWave - 1) / (4 * kKpPerWave), batch), dim3(256), 0, s, e->d_geom, L, e->umax,
                      e->d_pattern, d_imgs, stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame,
                      e->d_kpkey, e->d_kpcount, (size_t)e->kp_frame, kp_dst, desc_dst, lapping ? e->out_cap : cap, d_n,
                      lapping ? (int32_t*)nullptr : d_mono, e->d_err);

@@ -197,7 +197,7 @@ __device__ __forceinline__ int fast_true_score(const uint8_t* c, int P) {
   return imax(dark, -bright) - 1;
 }
 
-// grid = (cells per frame over all levels, B), block = 256.  CM = compile-time bound of the scanned cell side: the
+// grid = xcd_grid(cells per frame over all levels, B) (common.h), block = 256.  CM = compile-time bound of the scanned cell side: the
 // LDS tiles are sized by it, and LDS is what limits the workgroups per CU (6 at CM = 72, 8 = the wave limit at CM = 48).
 template <int CM>
 __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict__ geom, int n_levels,
@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   __shared__ uint32_t s_keep[kBitWords], s_keep_ini[kBitWords];
 
   const int tid = threadIdx.x;
-  const int bx = blockIdx.x + cell_begin, f = blockIdx.y;  // the launch covers the cells cell_begin .. cell_begin + gridDim.x
+  const int f = xcd_frame();
+  const int bx = xcd_item() + cell_begin;  // the launch covers the cells cell_begin .. cell_begin + gridDim.x
   int l = 0;
   while (l + 1 < n_levels && bx >= geom[l + 1].cell_off) ++l;
   const LevelGeom& g = geom[l];
@@ -376,7 +377,8 @@ __global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ ge
                                                     uint8_t* __restrict__ blur, size_t blur_frame, int tile_begin) {
   constexpr int kPairs = (kBlurTH + 6) / 2;       // 19 row pairs
   __shared__ uint32_t s_p[kPairs * kBlurTW];      // [pair][column]: sum of row 2j | sum of row 2j + 1 << 16
-  const int tid = threadIdx.x, bx = blockIdx.x + tile_begin, f = blockIdx.y;
+  const int f = xcd_frame();
+  const int tid = threadIdx.x, bx = xcd_item() + tile_begin;
   int l = 0;
   while (l + 1 < n_levels && bx >= bt.tile_off[l + 1]) ++l;
   const LevelGeom& g = geom[l];
@@ -1360,7 +1362,7 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
   __shared__ uint32_t s_patch_w[4][37 * 10];  // blurred 37x37 neighbourhood, 40-byte rows
   __shared__ uint32_t s_raw_w[4][31 * 8];     // un-blurred 31x31 neighbourhood, 32-byte rows
   const int lane = lane_id(), wave = wave_id();
-  const int bx = blockIdx.x, f = blockIdx.y;
+  const int bx = xcd_item(), f = xcd_frame();  // grid = xcd_grid(keypoint groups, B): an XCD's L2 keeps its frames' levels
   const int* cnts = kp_count + (size_t)f * n_levels;
 
   // ---- lane k < kKpPerWave: which (level, index) is slot s0 + k?  slots are laid out level after level, kcap entries each

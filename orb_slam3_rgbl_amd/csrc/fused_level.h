@@ -216,10 +216,10 @@ __global__ __launch_bounds__(NT) void k_level_fused(FusedArgs A) {
   uint8_t* smem = reinterpret_cast<uint8_t*>(smem_w);
   const FusedTiles& T = *A.tiles;
   const LevelGeom& g = A.g;
-  const int tid = threadIdx.x, f = blockIdx.y;
+  const int tid = threadIdx.x, f = xcd_frame();  // grid = xcd_grid(tiles, B)
   const int rtid = NT - 1 - tid;  // second task loop of a phase: the work-items that idled last start first
   const int ntx = T.ntx;
-  const int tr = (int)blockIdx.x / ntx, tc = (int)blockIdx.x - tr * ntx;
+  const int tr = xcd_item() / ntx, tc = xcd_item() - tr * ntx;
   const FusedCol& C = T.col[tc];
   const FusedRow& R = T.row[tr];
   const int H = g.h;

@@ -228,3 +228,8 @@ def test_matcher_handle_pool(emu_lib):
     L.check(emu_lib, emu_lib.rgbl_matcher_acquire(0, C.byref(h4)))   # a parked handle is handed out again, none is created
     assert h4.value in (h2.value, h3.value, h1.value) and emu_lib.rgbl_matcher_pool_size() == n - 1
     emu_lib.rgbl_matcher_release(h4)
+
+
+def test_extractor_batch_of_eight_takes_the_xcd_aware_mapping(emu_lib):
+    # frames % 8 == 0: the pixel kernels remap workgroup -> (item, frame) so that an XCD covers whole frames
+    pc.check_extractor_batch(emu_lib, 400, 300, 500, 8)
