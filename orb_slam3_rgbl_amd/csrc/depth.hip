@@ -79,9 +79,9 @@ __global__ __launch_bounds__(256) void k_project_index(ProjParams P, const float
                                                        size_t map_stride, float* __restrict__ pt_depth, size_t pt_stride,
                                                        uint32_t tag) {
   // kProjectPts points per work-item, all of them requested before the first is used
-  const int f = blockIdx.y;
+  const int f = xcd_frame();
   const float* C = cloud + (size_t)f * cloud_stride;
-  const int i0 = blockIdx.x * (256 * kProjectPts) + threadIdx.x;
+  const int i0 = xcd_item() * (256 * kProjectPts) + threadIdx.x;
   CloudPoint c[kProjectPts];
 #pragma unroll
   for (int j = 0; j < kProjectPts; ++j) c[j] = load_point<kXyzi>(C, ld, imin(i0 + 256 * j, n - 1));
@@ -126,8 +126,11 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
   __shared__ float s_inv[(kTileH + 8) * 72];
   __shared__ int s_tap[81];
   __shared__ int s_ntap;
-  const int tid = threadIdx.x, f = blockIdx.z;
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * kTileH;
+  // grid = xcd_grid(tiles of a frame, B) (common.h): an XCD's L2 serves whole frames, tile halos are re-read from it
+  const int tid = threadIdx.x, f = xcd_frame();
+  const int tiles_x = (w + 63) >> 6;
+  const int tile_y = xcd_item() / tiles_x, tile_x = xcd_item() - tile_y * tiles_x;
+  const int x0 = tile_x * 64, y0 = tile_y * kTileH;
   const int ax = kRadius > 0 ? kRadius : K.kw / 2, ay = kRadius > 0 ? kRadius : K.kh / 2;
   const int tw = kRadius > 0 ? 64 + 2 * kRadius : 64 + K.kw - 1, th = kRadius > 0 ? kTileH + 2 * kRadius : kTileH + K.kh - 1;
   const float thr = S - 1;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void k_gather_depth(const float* __restrict__ 
                                                       const float* __restrict__ kpun, int un_stride, size_t un_frame,
                                                       const int32_t* __restrict__ n_per_frame, int n_fixed, float mbf,
                                                       float* __restrict__ depth, float* __restrict__ uright, size_t out_frame) {
-  const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+  const int i = xcd_item() * 256 + threadIdx.x, f = xcd_frame();  // grid = xcd_grid(keypoint groups, B)
   const int n = n_per_frame ? n_per_frame[f] : n_fixed;
   if (i >= n) return;
   const float u = kp[f * kp_frame + (size_t)i * kp_stride], v = kp[f * kp_frame + (size_t)i * kp_stride + 1];
@@ -339,6 +342,7 @@ struct rgbl_depth {
   size_t map_stride = 0;
   uint32_t* d_idx = nullptr;  // idx | raw contiguous so one memset clears both
   float* d_raw = nullptr;
+  bool xcd_map = true;          // XCD-aware launch geometry (common.h: xcd_grid); RGBL_XCD_MAP=0 switches it off
   uint32_t idx_gen = 0;        // generation of the index maps' newest entries; 0 = cleared / untagged content
   uint32_t max_gen = (1u << (32 - 20)) - 1u;  // RGBL_DEPTH_MAX_GEN lowers it (tests of the wrap-around)
   float* d_ptdepth = nullptr;  // depth of every projected point (max_batch x max_points), for the raw-map-free path
@@ -387,7 +391,7 @@ int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, 
   }
   if (n > 0) {
     e->timer.begin("k_project_index", s);
-    const dim3 pgrid((n + 255) / 256, batch), igrid((n + 256 * kProjectPts - 1) / (256 * kProjectPts), batch);
+    const dim3 pgrid((n + 255) / 256, batch), igrid = xcd_grid(e->xcd_map, (n + 256 * kProjectPts - 1) / (256 * kProjectPts), batch);
     if (xyzi) hipLaunchKernelGGL(k_project_index<true>, igrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms, pt_depth, pt_stride, tag);
     else hipLaunchKernelGGL(k_project_index<false>, igrid, dim3(256), 0, s, e->proj, d_cloud, cloud_stride, n, ld, w, h, e->d_idx, ms, pt_depth, pt_stride, tag);
     e->timer.end(s);
@@ -399,7 +403,7 @@ int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, 
     }
   }
   const dim3 tiles((w + 63) / 64, (h + 15) / 16, batch);
-  const dim3 dilate_tiles((w + 63) / 64, (h + 31) / 32, batch);  // k_inverse_dilate works on 64 x 32 tiles
+  const dim3 dilate_tiles = xcd_grid(e->xcd_map, ((w + 63) / 64) * ((h + 31) / 32), batch);  // k_inverse_dilate works on 64 x 32 tiles
   switch (e->cfg.method) {
     case RGBL_UPS_INVERSE_DILATION:
       e->timer.begin("k_inverse_dilate", s);
@@ -455,7 +459,7 @@ int enqueue_keypoints(rgbl_depth* e, int batch, int w, int h, const float* kp, i
     e->timer.end(s);
   } else {
     e->timer.begin("k_gather_depth", s);
-    hipLaunchKernelGGL(k_gather_depth, kgrid, dim3(256), 0, s, e->d_proc, ms, w, kp, kp_stride, kp_frame, kpun, un_stride,
+    hipLaunchKernelGGL(k_gather_depth, xcd_grid(e->xcd_map, (kmax + 255) / 256, batch), dim3(256), 0, s, e->d_proc, ms, w, kp, kp_stride, kp_frame, kpun, un_stride,
                        un_frame, d_n, n_fixed, e->cfg.mbf, d_depth, d_uright, out_frame);
     e->timer.end(s);
   }
@@ -560,6 +564,7 @@ int rgbl_depth_create(const rgbl_depth_cfg* cfg, int device, rgbl_depth** out) {
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_kpun, (size_t)cfg->max_keypoints);
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_depth, (size_t)cfg->max_keypoints);
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_uright, (size_t)cfg->max_keypoints);
+  if (const char* v = getenv("RGBL_XCD_MAP")) e->xcd_map = v[0] != '0';
   if (const char* v = getenv("RGBL_DEPTH_MAX_GEN")) e->max_gen = (uint32_t)std::min(std::max(atoi(v), 1), (int)e->max_gen);
   if (rc == RGBL_OK && hipStreamCreate(&e->own_stream) != hipSuccess) { set_error("hipStreamCreate failed"); rc = RGBL_ERR_HIP; }
   if (rc != RGBL_OK) { rgbl_depth_destroy(e); return rc; }

@@ -614,9 +614,9 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       const int spitch = (l == 1) ? stride : p.pitch;
       const size_t sframe = (l == 1) ? frame_stride : e->pyr_frame;
       e->timer.begin("k_resize_linear", s);
-      hipLaunchKernelGGL(k_resize_linear, dim3((g.w + 4 * kResizeLanes - 1) / (4 * kResizeLanes), (g.h + 4 * kResizeRows - 1) / (4 * kResizeRows), batch), dim3(kResizeWG),
-                         0, s, src, spitch, sframe, p.w, p.h, e->d_pyr + g.img_off, g.pitch, e->pyr_frame, g.w, g.h,
-                         e->d_xtab + g.xtab_off, e->d_ytab + g.ytab_off);
+      const int rtx = (g.w + 4 * kResizeLanes - 1) / (4 * kResizeLanes), rty = (g.h + 4 * kResizeRows - 1) / (4 * kResizeRows);
+      hipLaunchKernelGGL(k_resize_linear, xcd_grid(e->xcd_map, rtx * rty, batch), dim3(kResizeWG), 0, s, src, spitch, sframe, p.w, p.h, e->d_pyr + g.img_off, g.pitch, e->pyr_frame, g.w, g.h,
+                       e->d_xtab + g.xtab_off, e->d_ytab + g.ytab_off, rtx);
       e->timer.end(s);
     }
     // 4. Gaussian working images (ORBextractor.cc:1132-1133) of the upper levels, on the auxiliary stream next to 2. and 3.

@@ -78,13 +78,15 @@ __global__ __launch_bounds__(kResizeWG) void k_resize_linear(const uint8_t* __re
                                                        size_t sframe, int sw, int sh,
                                                        uint8_t* __restrict__ dst, int dpitch, size_t dframe,
                                                        int dw, int dh, const ResizeTab* __restrict__ xtab,
-                                                       const ResizeTab* __restrict__ ytab) {
+                                                       const ResizeTab* __restrict__ ytab, int tiles_x) {
+  // grid = xcd_grid(tiles_x * tiles_y, B) (common.h)
   const int tx = threadIdx.x % kResizeLanes, ty = threadIdx.x / kResizeLanes;
-  const int dx0 = (blockIdx.x * kResizeLanes + tx) * 4;
-  const int dy0 = (blockIdx.y * 4 + ty) * kResizeRows;
+  const int tile_y = xcd_item() / tiles_x, tile_x = xcd_item() - tile_y * tiles_x;
+  const int dx0 = (tile_x * kResizeLanes + tx) * 4;
+  const int dy0 = (tile_y * 4 + ty) * kResizeRows;
   if (dy0 >= dh || dx0 >= dw) return;
-  const uint8_t* S = src + (size_t)blockIdx.z * sframe;
-  uint8_t* D = dst + (size_t)blockIdx.z * dframe + (size_t)dy0 * dpitch;
+  const uint8_t* S = src + (size_t)xcd_frame() * sframe;
+  uint8_t* D = dst + (size_t)xcd_frame() * dframe + (size_t)dy0 * dpitch;
   // both coefficient tables are requested before either is used (one round trip, not two); the x table is padded to a
   // multiple of 4 entries per level with copies of the last entry
   const uint4* t4 = reinterpret_cast<const uint4*>(xtab + dx0);

@@ -166,10 +166,11 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(const uint8_t* __restrict_
                                                       const int32_t* __restrict__ pair_b, int32_t* __restrict__ best_idx,
                                                       int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist) {
   __shared__ __attribute__((aligned(16))) uint8_t s_rows[2][kBfStageRows * kBfRowBytes];
-  const int p = blockIdx.y;
+  // grid = xcd_grid(query blocks, pairs) (common.h): the query blocks of a pair share an XCD's L2 and with it the train set
+  const int p = xcd_frame();
   const int fa = pair_a ? pair_a[p] : 0, fb = pair_b ? pair_b[p] : 1;
   const int na = n_rows[fa], nb = n_rows[fb];
-  const int q_base = blockIdx.x * kBfQueriesPerBlock;
+  const int q_base = xcd_item() * kBfQueriesPerBlock;
   if (q_base >= na) return;
   const int tid = threadIdx.x, lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(wave_id());
@@ -1228,7 +1229,7 @@ int rgbl_hamming_bf_batch_device(rgbl_matcher* m, const uint8_t* d_desc, const i
   RGBL_HIP(hipSetDevice(m->device));
   if (bf_on_matrix_cores()) {
     m->timer.begin("k_hamming_mfma", m->stream);
-    hipLaunchKernelGGL(k_hamming_mfma, dim3((cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
+    hipLaunchKernelGGL(k_hamming_mfma, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
                        d_desc, d_n, cap, d_pair_a, d_pair_b, d_best_idx, d_best_dist, d_second_dist);
   } else {
     m->timer.begin("k_hamming_bf", m->stream);
@@ -1265,7 +1266,7 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   // pair_a/pair_b == NULL selects the fixed pair (frame 0 -> frame 1)
   if (bf_on_matrix_cores()) {
     m->timer.begin("k_hamming_mfma", s);
-    hipLaunchKernelGGL(k_hamming_mfma, dim3((na + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, 1), dim3(256), 0, s, d_desc, d_n, cap,
+    hipLaunchKernelGGL(k_hamming_mfma, xcd_grid(false, (na + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, 1), dim3(256), 0, s, d_desc, d_n, cap,
                        (const int32_t*)nullptr, (const int32_t*)nullptr, d_bi, d_bd, d_sd);
   } else {
     m->timer.begin("k_hamming_bf", s);
