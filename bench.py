@@ -379,6 +379,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the 4K / stereo / single-frame figures (extra keys of the JSON line)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--serial", action="store_true", help="one stream for all handles (clean per-kernel timings)")
+    ap.add_argument("--split", type=int, default=1, choices=[1, 2],
+                    help="2: two extractor handles with half the batch each, gated on one another's pixel phase (pipeline.py)")
     ap.add_argument("--gather", default="step", choices=["step", "final", "none"],
                     help="N > 1: stream every step's records to rank 0 while the next step computes (default), exchange all of "
                          "them once at the end, or not at all")
@@ -429,7 +431,7 @@ def main():
     # orb_slam3_rgbl_amd/pipeline.py - the same code tests/test_distributed.py drives with two gloo ranks
     pipe = FrontEndPipeline(lib, torch, dev, w, h, nfeatures, proj, n_points, B, levels=LEVELS, scale=SCALE, ini_th=INI_TH,
                             min_th=MIN_TH, world=world, rank=rank, gather=args.gather, serial=args.serial,
-                            log_steps=args.steps + args.warmup)
+                            log_steps=args.steps + args.warmup, split=args.split)
     ex, dm, mt, cap = pipe.ex, pipe.dm, pipe.mt, pipe.cap
     d_imgs = torch.from_numpy(frames).to(dev)
     d_cloud = torch.from_numpy(cloud).to(dev)
@@ -497,14 +499,13 @@ def main():
         # stretched by other kernels running concurrently
         pipe.serialise()
         pipe.gather = "none"
-        ex.profile(True); dm.profile(True); mt.profile(True)
+        pipe.profile(True)
         prof_steps = 3
         for _ in range(prof_steps):
             step()
         sync_all()
-        for src in (ex.profile_read(), dm.profile_read(), mt.profile_read()):
-            kernels.update(src)
-        ex.profile(False); dm.profile(False); mt.profile(False)
+        kernels.update(pipe.profile_read())
+        pipe.profile(False)
         total_ms = sum(v[0] for v in kernels.values())
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms_sum, launches = kernels[dom]

@@ -115,6 +115,8 @@ SYMBOLS = {
     "rgbl_device_count": (_I, []),
     "rgbl_extractor_create": (_I, [C.POINTER(ExtractorCfg), _I, C.POINTER(_V)]),
     "rgbl_extractor_destroy": (None, [_V]),
+    "rgbl_extractor_pixel_event": (_V, [_V]),
+    "rgbl_extractor_set_gate": (_I, [_V, _V]),
     "rgbl_extractor_tables": (_I, [_V, _V, _V, _V, _V, _V, _V]),
     "rgbl_extractor_max_keypoints": (_I, [_V]),
     "rgbl_extract": (_I, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _I, C.POINTER(_I), C.POINTER(_I)]),

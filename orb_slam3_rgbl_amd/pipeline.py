@@ -16,6 +16,7 @@ HBM and exchanges them once at the end; `gather="none"` does no exchange.
 PyTorch is plumbing here: device memory, streams and torch.distributed.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -59,25 +60,35 @@ class OutSet:
 
 class FrontEndPipeline:
     def __init__(self, lib, torch, dev, w, h, nfeatures, proj, n_points, batch, levels=8, scale=1.2, ini_th=12, min_th=7,
-                 world=1, rank=0, gather="step", serial=False, keep_steps=0, log_steps=1):
+                 world=1, rank=0, gather="step", serial=False, keep_steps=0, log_steps=1, split=1):
         self.lib, self.torch, self.dev = lib, torch, dev
         self.w, self.h, self.B, self.n_points = w, h, batch, n_points
         self.world, self.rank, self.gather = world, rank, gather if world > 1 else "none"
         index = dev.index if dev.type == "cuda" else 0
-        self.ex = F.ORBextractor(nfeatures, scale, levels, ini_th, min_th, w, h, max_batch=batch, device=index, lib=lib)
+        # split = 2: two extractor handles with half the batch each, gated on one another's pixel phase (rgbl_extractor_set_gate):
+        # while one half is in its quad-tree / descriptor phase (dependent chains and gathers, low utilisation) the other
+        # half's pyramid / FAST / Gaussian kernels fill the chip
+        self.split = split if (split > 1 and batch % split == 0 and not serial) else 1
+        self.exs = [F.ORBextractor(nfeatures, scale, levels, ini_th, min_th, w, h, max_batch=batch // self.split, device=index, lib=lib)
+                    for _ in range(self.split)]
+        self.ex = self.exs[0]
+        if self.split == 2:
+            for a, b in ((0, 1), (1, 0)):
+                L.check(lib, lib.rgbl_extractor_set_gate(self.exs[a].h, C.c_void_p(lib.rgbl_extractor_pixel_event(self.exs[b].h))))
         self.cap = self.ex.max_keypoints
         self.dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=self.cap, max_batch=batch, device=index, lib=lib)
         self.mt = F.ORBmatcher(0.6, False, device=index, lib=lib)
-        one = C.c_void_p(lib.rgbl_extractor_stream(self.ex.h))
+        one = C.c_void_p(lib.rgbl_extractor_stream(self.exs[-1].h))   # the last handle's stream sees the whole extraction done
         if serial:
             # one stream for all handles and per-kernel HIP-event brackets on: every launch of the run is serialised - the
             # mode `rocprofv3 --kernel-trace --stats` is recorded in (profiles/)
             L.check(lib, lib.rgbl_depth_set_stream(self.dm.h, one))
             L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
             self.profile(True)
-        else:
-            # the brute-force Hamming of step i is issue-bound like FAST: queued behind the extraction of step i + 1 on the
-            # extractor's stream it fills that stream's gaps instead of competing with it
+        elif os.environ.get("RGBL_MATCHER_STREAM", "shared") != "own":
+            # the matcher queued behind the extraction of step i + 1 on the extractor's stream (round 1: the VALU popcount
+            # scan was issue-bound like FAST and only competed with it on a stream of its own); RGBL_MATCHER_STREAM=own
+            # lets the matrix-core scan run next to the extraction instead
             L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
         self._streams()
         self.sets = [OutSet(lib, torch, dev, batch, self.cap) for _ in range(2)]
@@ -103,24 +114,33 @@ class FrontEndPipeline:
 
     def _streams(self):
         lib = self.lib
-        self.s_ex = C.c_void_p(lib.rgbl_extractor_stream(self.ex.h))
+        self.s_exs = [C.c_void_p(lib.rgbl_extractor_stream(e.h)) for e in self.exs]
+        self.s_ex = self.s_exs[-1]
         self.s_dm = C.c_void_p(lib.rgbl_depth_stream(self.dm.h))
         self.s_mt = C.c_void_p(lib.rgbl_matcher_stream(self.mt.h))
 
     def profile(self, on):
-        self.ex.profile(on); self.dm.profile(on); self.mt.profile(on)
+        for e in self.exs:
+            e.profile(on)
+        self.dm.profile(on); self.mt.profile(on)
 
     def serialise(self):
         """All handles on the extractor's stream (the per-kernel timing leg of bench.py)."""
-        one = C.c_void_p(self.lib.rgbl_extractor_stream(self.ex.h))
+        one = C.c_void_p(self.lib.rgbl_extractor_stream(self.exs[-1].h))
+        for e in self.exs[:-1]:
+            L.check(self.lib, self.lib.rgbl_extractor_set_stream(e.h, one))
+            L.check(self.lib, self.lib.rgbl_extractor_set_gate(e.h, None))
+        L.check(self.lib, self.lib.rgbl_extractor_set_gate(self.exs[-1].h, None))
         L.check(self.lib, self.lib.rgbl_depth_set_stream(self.dm.h, one))
         L.check(self.lib, self.lib.rgbl_matcher_set_stream(self.mt.h, one))
         self._streams()
 
     def profile_read(self):
         k = {}
-        for src in (self.ex.profile_read(), self.dm.profile_read(), self.mt.profile_read()):
-            k.update(src)
+        for src in [e.profile_read() for e in self.exs] + [self.dm.profile_read(), self.mt.profile_read()]:
+            for name, (ms, n) in src.items():
+                a = k.get(name, (0.0, 0))
+                k[name] = (a[0] + ms, a[1] + n)
         return k
 
     def set_inputs(self, d_imgs, d_cloud):
@@ -133,13 +153,18 @@ class FrontEndPipeline:
     def step(self):
         lib, p, B, w, h, cap = self.lib, self._p, self.B, self.w, self.h, self.cap
         o = self.sets[self.step_no % 2]
-        # this set's readers of two steps ago must be done before the extractor overwrites it
-        L.check(lib, lib.rgbl_event_wait(self.s_ex, o.ev["depth_done"]))
-        L.check(lib, lib.rgbl_event_wait(self.s_ex, o.ev["match_done"]))
-        if self.gather != "none":
-            L.check(lib, lib.rgbl_event_wait(self.s_ex, o.ev["comm_done"]))
-        L.check(lib, lib.rgbl_extract_batch_device(self.ex.h, p(self.d_imgs), B, w, h, w, w * h, 0, 0, p(o.kp), p(o.desc), cap,
-                                                   p(o.n), p(o.mono)))
+        # this set's readers of two steps ago must be done before the extractors overwrite it
+        half = B // self.split
+        for i, (e, s_e) in enumerate(zip(self.exs, self.s_exs)):
+            L.check(lib, lib.rgbl_event_wait(s_e, o.ev["depth_done"]))
+            L.check(lib, lib.rgbl_event_wait(s_e, o.ev["match_done"]))
+            if self.gather != "none":
+                L.check(lib, lib.rgbl_event_wait(s_e, o.ev["comm_done"]))
+            f0 = i * half
+            L.check(lib, lib.rgbl_extract_batch_device(e.h, p(self.d_imgs[f0:]), half, w, h, w, w * h, 0, 0, p(o.kp[f0:]), p(o.desc[f0:]), cap,
+                                                       p(o.n[f0:]), p(o.mono[f0:])))
+        for s_e in self.s_exs[:-1]:
+            L.check(lib, lib.rgbl_stream_wait(self.s_ex, s_e))   # "extracted" = every half
         L.check(lib, lib.rgbl_event_record(o.ev["extracted"], self.s_ex))
         # LiDAR projection + up-sampling: independent of the keypoints, runs concurrently on the depth stream
         n_points = self.n_points
@@ -222,7 +247,8 @@ class FrontEndPipeline:
     def sync(self):
         if self.dev.type == "cuda":
             self.torch.cuda.synchronize(self.dev)
-        L.check(self.lib, self.lib.rgbl_extractor_sync(self.ex.h))  # also surfaces device-side overflow flags
+        for e in self.exs:
+            L.check(self.lib, self.lib.rgbl_extractor_sync(e.h))  # also surfaces device-side overflow flags
         if self.gather != "none" and int(self.overflow.cpu()[0]) != 0:
             raise RuntimeError("record buffer overflow in rgbl_pack_records_device")
 
@@ -230,7 +256,9 @@ class FrontEndPipeline:
         return self.sets[(self.step_no - 1) % 2]
 
     def close(self):
-        self.ex.close(); self.dm.close(); self.mt.close()
+        for e in self.exs:
+            e.close()
+        self.dm.close(); self.mt.close()
 
 
 class _Null:
