@@ -298,17 +298,47 @@ bool build_fused(rgbl_extractor* e, const std::vector<ResizeTab>& xt, const std:
     for (int ncx = std::min(ncx_max, g.n_cols); ncx >= 1 && !fits; --ncx) {
     memset(&T, 0, sizeof(T));
     T.ncx = ncx;
-    T.ntx = (g.n_cols + ncx - 1) / ncx;
-    T.nty = g.n_rows;
+    // Tile boundaries.  Columns: [0, first cell) is a strip tile of its own (the 19-px border that only the Gaussian /
+    // resize need), then groups of ncx cells, then the rest up to the right border - a strip of its own unless it is
+    // narrower than 16 px, in which case the last cell tile owns it.  Rows alike.  Strips have no cells (nc = 0 / cell_row = -1).
+    std::vector<int> xb, xj0, xnc, yb, yrow;
+    {
+      const int first = (kMinBorder + 3) & ~3;
+      if (!(getenv("RGBL_FUSED_STRIPS") && getenv("RGBL_FUSED_STRIPS")[0] == '1')) {
+        // default: border columns / rows belong to the first and last cell tiles.  RGBL_FUSED_STRIPS=1 gives the 19-px border
+        // strip tiles of its own (LDS 45 -> 37 KB, 4 instead of 3 workgroups per CU) - measured SLOWER, 2.85 -> 3.30 ms per 512
+        // frames: 121 instead of 81 workgroups per level-0 frame, and a workgroup's fixed cost (argument / table loads,
+        // five barriers) outweighs the occupancy
+        for (int j0 = 0; j0 < g.n_cols; j0 += ncx) { xb.push_back(j0 == 0 ? 0 : ((kMinBorder + 3 + j0 * g.w_cell) & ~3)); xj0.push_back(j0); xnc.push_back(std::min(ncx, g.n_cols - j0)); }
+        xb.push_back(g.w);
+        for (int r = 0; r < g.n_rows; ++r) { yb.push_back(r == 0 ? 0 : kMinBorder + 3 + r * g.h_cell); yrow.push_back(r); }
+        yb.push_back(g.h);
+      } else {
+        xb.push_back(0); xj0.push_back(0); xnc.push_back(0);
+        for (int j0 = 0; j0 < g.n_cols; j0 += ncx) {
+          xb.push_back(j0 == 0 ? first : ((kMinBorder + 3 + j0 * g.w_cell) & ~3)); xj0.push_back(j0); xnc.push_back(std::min(ncx, g.n_cols - j0));
+        }
+        const int xr = std::min(g.w, (kMinBorder + 3 + g.n_cols * g.w_cell) & ~3);
+        if (g.w - xr >= 16) { xb.push_back(xr); xj0.push_back(g.n_cols); xnc.push_back(0); }
+        xb.push_back(g.w);
+        yb.push_back(0); yrow.push_back(-1);
+        for (int r = 0; r < g.n_rows; ++r) { yb.push_back(kMinBorder + 3 + r * g.h_cell); yrow.push_back(r); }
+        const int yr = std::min(g.h, kMinBorder + 3 + g.n_rows * g.h_cell);
+        if (g.h - yr >= 8) { yb.push_back(yr); yrow.push_back(-1); }
+        yb.push_back(g.h);
+      }
+    }
+    T.ntx = (int)xb.size() - 1;
+    T.nty = (int)yb.size() - 1;
     if (T.ntx > kFusedMaxTiles || T.nty > kFusedMaxTiles) return fused_no(1, l);
     int max_w = 0, max_h = 0;
     for (int c = 0; c < T.ntx; ++c) {
       FusedCol& C = T.col[c];
-      C.j0 = c * ncx;
-      C.nc = std::min(ncx, g.n_cols - C.j0);
-      C.xa = c == 0 ? 0 : ((kMinBorder + 3 + C.j0 * g.w_cell) & ~3);
-      C.xb = c == T.ntx - 1 ? g.w : ((kMinBorder + 3 + (C.j0 + ncx) * g.w_cell) & ~3);
-      if (C.xb <= C.xa || C.xb > g.w) return fused_no(2, l);
+      C.j0 = xj0[c];
+      C.nc = xnc[c];
+      C.xa = xb[c];
+      C.xb = xb[c + 1];
+      if (C.xb <= C.xa || C.xb > g.w || (C.xa & 3)) return fused_no(2, l);
       max_w = std::max(max_w, C.xb - C.xa);
       const int xorg = C.xa - 4, own_w = C.xb - C.xa;
       C.sw = 0; C.n_valid = 0;
@@ -321,6 +351,8 @@ bool build_fused(rgbl_extractor* e, const std::vector<ResizeTab>& xt, const std:
       C.gw4 = (own_w + 3) / 4;
       C.q16 = (own_w + 4 + kFusedHaloR + 15) / 16;
       if (C.q16 > 16) return fused_no(7, l);
+      // the scanned columns (+ 3) must lie inside what the tile stages
+      if (C.nc > 0 && (C.sx_t < 3 || C.sx_t + C.sw + 3 > 16 * C.q16)) return fused_no(8, l);
       C.q_lo = xorg < 0 ? 1 : 0;
       C.q_hi = std::min(C.q16, (g.w - xorg) >> 4);
       C.m_gpr = div_magic((uint32_t)std::max(C.gpr, 1));
@@ -329,13 +361,18 @@ bool build_fused(rgbl_extractor* e, const std::vector<ResizeTab>& xt, const std:
     }
     for (int r = 0; r < T.nty; ++r) {
       FusedRow& R = T.row[r];
-      R.ya = r == 0 ? 0 : kMinBorder + 3 + r * g.h_cell;
-      R.yb = r == T.nty - 1 ? g.h : kMinBorder + 3 + (r + 1) * g.h_cell;
+      R.ya = yb[r];
+      R.yb = yb[r + 1];
+      R.cell_row = yrow[r];
       if (R.yb <= R.ya || R.yb > g.h) return fused_no(3, l);
       max_h = std::max(max_h, R.yb - R.ya);
-      const int ini_y = kMinBorder + r * g.h_cell, max_y = std::min(ini_y + g.h_cell + 6, g.max_by);
-      R.sh = (ini_y < g.max_by - 3 && max_y - ini_y - 6 > 0) ? max_y - ini_y - 6 : 0;
-      R.sy_t = ini_y + 3 - (R.ya - 3);
+      R.sh = 0; R.sy_t = 3;
+      if (R.cell_row >= 0) {
+        const int ini_y = kMinBorder + R.cell_row * g.h_cell, max_y = std::min(ini_y + g.h_cell + 6, g.max_by);
+        R.sh = (ini_y < g.max_by - 3 && max_y - ini_y - 6 > 0) ? max_y - ini_y - 6 : 0;
+        R.sy_t = ini_y + 3 - (R.ya - 3);
+        if (R.sy_t < 3 || R.sy_t + R.sh + 3 > R.yb - R.ya + 6) return fused_no(9, l);
+      }
     }
     T.chunk_rows = (max_h + 1) / 2;  // two Gaussian chunks per tile (fused_level.h): the row-sum buffer holds half the tallest tile
     if (const char* v = getenv("RGBL_FUSED_CHUNK")) T.chunk_rows = std::min(std::max(atoi(v), T.chunk_rows), max_h);

@@ -5,7 +5,8 @@
 // k_fast_cells, k_gauss7 and k_resize_linear (extractor_kernels.h) each staged the same pixels on their own; here the
 // pixels cross HBM -> LDS once per level, and the whole is written for the VALU instruction count, which is what bounds it.
 //
-// Decomposition.  A tile = up to kFusedCells detection cells of one cell row.  Its cells' scanned areas
+// Decomposition.  A tile = up to kFusedCells detection cells of one cell row (optionally, RGBL_FUSED_STRIPS=1, with cell-less
+// strip tiles for the 19-px image border - fewer LDS bytes per workgroup, but measured slower, see extractor.hip).  Its cells' scanned areas
 // [19 + j wCell, 19 + (j + 1) wCell) x [19 + i hCell, 19 + (i + 1) hCell) tile the FAST region without overlap, so every
 // pixel's score is computed once; the Gaussian / resize "ownership" of a tile is the same rectangle with the left edge
 // rounded down to a multiple of 4 (aligned 32-bit stores) and extended to the image border in the first / last tile
@@ -54,6 +55,8 @@ struct FusedRow {
   int dya, dyb;      // rows of level l + 1 whose first tap lies in [ya, yb)
   int sh, sy_t;      // scanned rows of the cell row; tile row of the first scanned row
   int rows0, rows1;  // owned rows of the two Gaussian chunks
+  int cell_row;      // detection-cell row of the tile row, -1 for a border strip (no cells)
+  int pad0, pad1, pad2;
 };
 struct FusedTiles {
   int ntx, nty, ncx;
@@ -464,9 +467,9 @@ __global__ __launch_bounds__(NT) void k_level_fused(FusedArgs A) {
   // | Gaussian columns of chunk 1 next to (a)
   const int wave = wave_id(), lane = lane_id();
   uint32_t* s_prefix = s_keep + 2 * kFusedCells * BW;  // [cell][bit_words]
-  if (wave < C.nc) {
+  if (wave < C.nc && R.cell_row >= 0) {
     const int k = wave;
-    const int ci = tr * g.n_cols + C.j0 + k;
+    const int ci = R.cell_row * g.n_cols + C.j0 + k;
     uint32_t* my_cnt = A.cell_cnt + (size_t)f * A.cells_frame + g.cell_off + ci;
     if (k >= n_valid) {
       if (lane == 0) *my_cnt = 0;
@@ -507,9 +510,9 @@ __global__ __launch_bounds__(NT) void k_level_fused(FusedArgs A) {
     if (!((word >> (bit & 31)) & 1u)) continue;
     const uint32_t pos = s_prefix[k * BW + (bit >> 5)] + (uint32_t)__popc(word & ((1u << (bit & 31)) - 1u));
     if (pos < (uint32_t)g.cell_cap) {
-      const int ci = tr * g.n_cols + C.j0 + k;
+      const int ci = R.cell_row * g.n_cols + C.j0 + k;
       A.slots[(size_t)f * A.slots_frame + g.slot_off + (size_t)ci * g.cell_cap + pos] =
-          pack_key((C.j0 + k) * g.w_cell + 3 + xc, tr * g.h_cell + 3 + y, sc);
+          pack_key((C.j0 + k) * g.w_cell + 3 + xc, R.cell_row * g.h_cell + 3 + y, sc);
     }
   }
   RGBL_FUSED_STAMP(5)
