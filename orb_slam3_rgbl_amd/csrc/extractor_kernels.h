@@ -461,10 +461,12 @@ __global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ ge
   }
   const uint32_t kE0 = 18u | (34u << 16), kE1 = 48u | (56u << 16), kE2 = 48u | (34u << 16), kE3 = 18u;
   const uint32_t kO0 = 18u << 16, kO1 = 34u | (48u << 16), kO2 = 56u | (48u << 16), kO3 = 34u | (18u << 16);
+  // the row pitch is a multiple of 64 and x a multiple of 4: a full word always fits the row (what lands in the padding right
+  // of the last column is never read), so no byte-wise tail; acc < 2^24 and its byte 2 is the pixel: one v_perm_b32 per pixel
+  uint8_t* D = blur + (size_t)f * blur_frame + g.img_off + (__umul24((uint32_t)(y0 + 4 * rg), (uint32_t)g.pitch) + (uint32_t)x);
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
-    const int y = y0 + 4 * rg + o;
-    if (y >= H) break;
+    if (y0 + 4 * rg + o >= H) break;
     const int b = o >> 1;  // first row pair of the window
     uint32_t out = 0;
 #pragma unroll
@@ -477,14 +479,9 @@ __global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ ge
         acc = udot2(pv[b][i], kO0, acc); acc = udot2(pv[b + 1][i], kO1, acc);
         acc = udot2(pv[b + 2][i], kO2, acc); acc = udot2(pv[b + 3][i], kO3, acc);
       }
-      out |= (acc >> 16) << (8 * i);
+      out = i == 0 ? acc >> 16 : perm_bytes(acc, out, i == 1 ? 0x0c0c0600u : i == 2 ? 0x0c060100u : 0x06020100u);
     }
-    uint8_t* D = blur + (size_t)f * blur_frame + g.img_off + (__umul24((uint32_t)y, (uint32_t)g.pitch) + (uint32_t)x);
-    if (x + 3 < W) {
-      *reinterpret_cast<uint32_t*>(D) = out;
-    } else {
-      for (int i = 0; x + i < W; ++i) D[i] = (uint8_t)(out >> (8 * i));
-    }
+    *reinterpret_cast<uint32_t*>(D + __umul24((uint32_t)o, (uint32_t)g.pitch)) = out;
   }
 }
 
