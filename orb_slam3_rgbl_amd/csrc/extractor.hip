@@ -21,6 +21,7 @@
 
 #include "brief_pattern.h"
 #include "extractor_kernels.h"
+#include "octree_labels.h"
 #include "fused_level.h"
 
 namespace rgbl {
@@ -64,6 +65,7 @@ struct rgbl_extractor {
   hipStream_t graph_stream = nullptr;
   bool graph_ok = true;  // RGBL_GRAPH=0 or a failed capture switch the replay off
   int octree_wg = 0;  // 0 = choose per launch; RGBL_OCTREE_WG=256|512 pins the quad-tree workgroup width (tuning / tests)
+  int octree_ncap = 0;  // LDS node capacity of the label-based quad-tree kernel (512 / 2048); 0 = key-moving kernel on global lists
   int max_cell = 0;  // largest detection-cell side over the levels: selects the k_fast_cells instantiation
   // fused per-level kernel (fused_level.h): tile tables per level; use_fused = the geometry fits it and RGBL_FUSED != 0
   std::vector<FusedTiles> fused;
@@ -503,14 +505,16 @@ int alloc_scratch(rgbl_extractor* e) {
   RGBL_TRY(dev_alloc(e, &e->d_slots, B * e->slots_frame));
   RGBL_TRY(dev_alloc(e, &e->d_keys_a, B * e->keys_frame));
   RGBL_TRY(dev_alloc(e, &e->d_keys_b, B * e->keys_frame));
-  RGBL_TRY(dev_alloc(e, &e->d_list_a, B * e->nodes_frame));
-  RGBL_TRY(dev_alloc(e, &e->d_list_b, B * e->nodes_frame));
-  RGBL_TRY(dev_alloc(e, &e->d_div, B * e->nodes_frame));
-  RGBL_TRY(dev_alloc(e, &e->d_todo_a, B * e->nodes_frame));
-  RGBL_TRY(dev_alloc(e, &e->d_todo_b, B * e->nodes_frame));
-  RGBL_TRY(dev_alloc(e, &e->d_skey, B * e->nodes_frame));
-  RGBL_TRY(dev_alloc(e, &e->d_sval, B * e->nodes_frame));
-  RGBL_TRY(dev_alloc(e, &e->d_divided, B * e->nodes_frame));
+  if (e->octree_ncap == 0) {  // global node lists of the key-moving quad-tree kernel
+    RGBL_TRY(dev_alloc(e, &e->d_list_a, B * e->nodes_frame));
+    RGBL_TRY(dev_alloc(e, &e->d_list_b, B * e->nodes_frame));
+    RGBL_TRY(dev_alloc(e, &e->d_div, B * e->nodes_frame));
+    RGBL_TRY(dev_alloc(e, &e->d_todo_a, B * e->nodes_frame));
+    RGBL_TRY(dev_alloc(e, &e->d_todo_b, B * e->nodes_frame));
+    RGBL_TRY(dev_alloc(e, &e->d_skey, B * e->nodes_frame));
+    RGBL_TRY(dev_alloc(e, &e->d_sval, B * e->nodes_frame));
+    RGBL_TRY(dev_alloc(e, &e->d_divided, B * e->nodes_frame));
+  }
   RGBL_TRY(dev_alloc(e, &e->d_kpkey, B * (size_t)e->kp_frame));
   RGBL_TRY(dev_alloc(e, &e->d_kpcount, B * (size_t)e->L));
   RGBL_TRY(dev_alloc(e, &e->d_err, 1));
@@ -565,14 +569,24 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   ob.kp_key = e->d_kpkey; ob.kp_count = e->d_kpcount; ob.kp_frame = (size_t)e->kp_frame;
   ob.err = e->d_err;
   ob.dbg = getenv("RGBL_OCTREE_STAMPS") ? e->d_dbg : nullptr;
-  // 4 narrow workgroups fit a CU: once the (level, frame) problems can fill the chip that way, occupancy beats
-  // per-problem latency (KITTI, 256 frames: 0.57 -> 0.48 ms); small batches keep the wide group (4K, 16 frames: 2.8 vs 4.1 ms)
+  // narrow workgroups leave room for more (level, frame) problems per CU; small batches, which cannot fill the chip anyway,
+  // take the wide group (shorter passes over the keys).  Node lists of up to 512 / 2048 entries live in LDS
+  // (octree_labels.h); beyond that - more than ~9 000 features - the key-moving kernel on global lists takes over.
   const bool narrow = e->octree_wg ? e->octree_wg == kOctNarrow : (long)L * batch >= 1024;
   auto launch_octree = [&](hipStream_t st, int level_begin, int level_end) {
     if (level_end <= level_begin) return;
     e->timer.begin("k_octree", st);
-    if (narrow) hipLaunchKernelGGL(k_octree<kOctNarrow>, dim3(level_end - level_begin, batch), dim3(kOctNarrow), 0, st, e->d_geom, L, ob, level_begin);
-    else hipLaunchKernelGGL(k_octree<kOctWide>, dim3(level_end - level_begin, batch), dim3(kOctWide), 0, st, e->d_geom, L, ob, level_begin);
+    const dim3 grid(level_end - level_begin, batch);
+    if (e->octree_ncap == 0) {
+      if (narrow) hipLaunchKernelGGL(k_octree_moving<kOctNarrow>, grid, dim3(kOctNarrow), 0, st, e->d_geom, L, ob, level_begin);
+      else hipLaunchKernelGGL(k_octree_moving<kOctWide>, grid, dim3(kOctWide), 0, st, e->d_geom, L, ob, level_begin);
+    } else if (e->octree_ncap == 512) {
+      if (narrow) hipLaunchKernelGGL((k_octree<kOctNarrow, 512>), grid, dim3(kOctNarrow), 0, st, e->d_geom, L, ob, level_begin);
+      else hipLaunchKernelGGL((k_octree<kOctWide, 512>), grid, dim3(kOctWide), 0, st, e->d_geom, L, ob, level_begin);
+    } else {
+      if (narrow) hipLaunchKernelGGL((k_octree<kOctNarrow, 2048>), grid, dim3(kOctNarrow), 0, st, e->d_geom, L, ob, level_begin);
+      else hipLaunchKernelGGL((k_octree<kOctWide, 2048>), grid, dim3(kOctWide), 0, st, e->d_geom, L, ob, level_begin);
+    }
     e->timer.end(st);
   };
   if (e->use_fused) {
@@ -763,6 +777,18 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
   if (const char* v = getenv("RGBL_OCTREE_WG")) { const int wg = atoi(v); if (wg == kOctNarrow || wg == kOctWide) e->octree_wg = wg; }
   e->device = device;
   int rc = build_geometry(e);
+  if (rc == RGBL_OK) {
+    // quad-tree kernel: the smallest LDS node capacity that holds every level's list (RGBL_OCTREE_NCAP=0 forces the
+    // key-moving kernel on global lists, 2048 the large instantiation - tests)
+    uint32_t node_cap = 0, key_cap = 0;
+    for (int l = 0; l < e->L; ++l) { node_cap = std::max(node_cap, e->geom[l].node_cap); key_cap = std::max(key_cap, e->geom[l].key_cap); }
+    e->octree_ncap = node_cap <= 512 ? 512 : (node_cap <= 2048 ? 2048 : 0);
+    if (key_cap >= (1u << 24)) e->octree_ncap = 0;  // candidate indices travel in 24 bits of its best-key word
+    if (const char* v = getenv("RGBL_OCTREE_NCAP")) {
+      const int want = atoi(v);
+      if (want == 0 || (want == 2048 && node_cap <= 2048 && e->octree_ncap != 0)) e->octree_ncap = want;
+    }
+  }
   if (rc == RGBL_OK) rc = upload_tables(e);
   if (rc == RGBL_OK) rc = alloc_scratch(e);
   if (rc == RGBL_OK && (hipStreamCreate(&e->own_stream) != hipSuccess || hipStreamCreate(&e->aux_stream) != hipSuccess ||

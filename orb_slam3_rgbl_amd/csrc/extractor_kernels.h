@@ -815,7 +815,9 @@ constexpr int kOctWide = 512, kOctNarrow = 256;
 constexpr int kSortLds = 2048;     // largest expandable-node list sorted in LDS by the whole workgroup
 constexpr int kSortRanges = 160;   // > kSortLds / 17: pending ranges of more than 16 elements are disjoint
 
-struct SortRanges { int first[kSortRanges], last[kSortRanges], depth[kSortRanges]; };
+template <int R>
+struct SortRangesT { int first[R], last[R], depth[R]; };
+using SortRanges = SortRangesT<kSortRanges>;
 
 // Workgroup version of std_sort_restated().  libstdc++'s introsort partitions disjoint ranges independently, so
 // every pending range is partitioned by its own work-item (rounds = recursion depth), and the closing insertion
@@ -875,9 +877,9 @@ __device__ __forceinline__ void pk_heap_sort(uint64_t* w, int first, int last) {
 // of a serial scan; the four waves of the workgroup take different ranges of the same recursion depth.
 // seg_first / seg_last double as the L / R lists of the range being partitioned (a leaf is only labelled once
 // its range is final).
-template <int BS>
+template <int BS, int CAP = kSortLds, class Ranges = SortRanges>
 __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t* seg_first, uint16_t* seg_last,
-                                                    SortRanges* ra, SortRanges* rb, int* s_cnt) {
+                                                    Ranges* ra, Ranges* rb, int* s_cnt) {
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const int nw = (int)(blockDim.x >> 6);
   const unsigned long long lt = lanemask_lt();
@@ -893,8 +895,8 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t
   if (m <= 16)
     for (int i = tid; i < m; i += BS) { seg_first[i] = 0; seg_last[i] = (uint16_t)m; }
   __syncthreads();
-  SortRanges* cur = ra;
-  SortRanges* nxt = rb;
+  Ranges* cur = ra;
+  Ranges* nxt = rb;
   int ci = 0;
   for (;;) {
     const int nr = s_cnt[ci];
@@ -977,15 +979,16 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t
     }
     __syncthreads();
     if (tid == 0) s_cnt[ci] = 0;
-    { SortRanges* t = cur; cur = nxt; nxt = t; }
+    { Ranges* t = cur; cur = nxt; nxt = t; }
     ci ^= 1;
     __syncthreads();
   }
   // stable sort of every leaf (== __final_insertion_sort)
-  uint64_t mine[kSortLds / BS];
-  int dest[kSortLds / BS];
+  constexpr int kPer = (CAP + BS - 1) / BS;
+  uint64_t mine[kPer];
+  int dest[kPer];
 #pragma unroll
-  for (int k = 0; k < kSortLds / BS; ++k) {
+  for (int k = 0; k < kPer; ++k) {
     const int i = tid + BS * k;
     dest[k] = -1;
     if (i < m) {
@@ -1002,7 +1005,7 @@ __device__ __forceinline__ void block_sort_restated(uint64_t* w, int m, uint16_t
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kSortLds / BS; ++k)
+  for (int k = 0; k < kPer; ++k)
     if (dest[k] >= 0) w[dest[k]] = mine[k];
   __syncthreads();
 }
@@ -1079,7 +1082,7 @@ __device__ __forceinline__ void rebuild_list(const QNode* cur, QNode* nxt, int n
 }
 
 template <int BS>
-__global__ __launch_bounds__(BS, 4) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b, int level_begin) {
+__global__ __launch_bounds__(BS, 4) void k_octree_moving(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b, int level_begin) {
   __shared__ unsigned long long s_scan[32];
   __shared__ unsigned long long s_skey_pad[kSortLds + 8];  // 4 entries of read slack on both sides
   __shared__ uint32_t s_sval[kSortLds];

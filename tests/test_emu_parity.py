@@ -95,6 +95,23 @@ def test_extractor_both_quadtree_workgroup_widths(emu_lib, wg):
         os.environ.pop("RGBL_OCTREE_WG", None)
 
 
+@pytest.mark.parametrize("ncap", ["0", "2048"])
+def test_extractor_quadtree_kernel_variants(emu_lib, ncap):
+    # node lists of up to 512 entries take the small LDS instantiation of the label-based kernel; RGBL_OCTREE_NCAP pins the
+    # large one (2048) or the key-moving kernel on global lists (0), which configurations above ~9 000 features fall back to
+    os.environ["RGBL_OCTREE_NCAP"] = ncap
+    try:
+        pc.check_extractor(emu_lib, 520, 360, 1000, frames=(0, 1), seq=7, stages=True)
+        pc.check_extractor(emu_lib, 333, 217, 500, frames=(0,), nlevels=5, seq=4, stages=True)
+    finally:
+        os.environ.pop("RGBL_OCTREE_NCAP", None)
+
+
+def test_extractor_quadtree_gathers_cells_in_chunks(emu_lib):
+    # more detection cells (57 x 85) than the prefix array of the small instantiation holds (4096): chunked gather
+    pc.check_extractor(emu_lib, 3000, 2020, 300, frames=(0,), nlevels=1, seq=21)
+
+
 def test_ingest_cvtcolor_then_extract(emu_lib):
     assert pc.check_ingest_color(emu_lib, 402, 300) > 1000
 
