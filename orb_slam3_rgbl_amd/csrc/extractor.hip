@@ -463,9 +463,13 @@ int upload_tables(rgbl_extractor* e) {
     const int width = g.max_bx - kMinBorder;
     const float hX = (float)width / g.n_ini;
     rootx.resize(g.rootx_off + align_up((size_t)width + 1, 16), 0);
+    LevelGeom& gm = e->geom[l];
+    for (int k = 0; k <= kMaxRoots; ++k) gm.root_first[k] = 0x7fffffff;
     for (int x = 0; x <= width; ++x) {
       int r = (int)((float)x / hX);
-      rootx[g.rootx_off + x] = (uint8_t)std::min(r, g.n_ini - 1);
+      r = std::min(r, g.n_ini - 1);
+      rootx[g.rootx_off + x] = (uint8_t)r;
+      for (int k = 1; k <= r; ++k) gm.root_first[k] = std::min(gm.root_first[k], x);  // the table is monotone in x
     }
   }
   RGBL_TRY(dev_alloc(e, &e->d_geom, L));

@@ -37,6 +37,7 @@ struct LevelGeom {
   uint32_t node_off, node_cap;
   int n_ini;                  // number of root nodes
   int root_x[kMaxRoots + 1];  // root node x bounds
+  int root_first[kMaxRoots + 1];  // [k], k >= 1: first x whose keys go to root k or beyond (vpIniNodes[kp.pt.x / hX]: float division)
   uint32_t rootx_off;         // byte offset into the root lookup table (index by x relative to minBorder)
   uint32_t xtab_off, ytab_off;
   float scale;                // mvScaleFactor[level]

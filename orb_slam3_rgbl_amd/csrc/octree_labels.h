@@ -23,7 +23,10 @@ template <int NCAP>
 struct alignas(16) QtStore {
   uint2 geom[2][NCAP];        // x0 | x1 << 16, y0 | y1 << 16 (node rectangle, relative to minBorder)
   uint32_t cnt[2][NCAP][4];   // keys per child quadrant; the list that is not current doubles as the sort's scratch
-  uint32_t map[NCAP];         // old list position -> bit 31: split, bits 30..0: rank of its first child | new position
+  uint2 ctab[NCAP];           // old list position -> four 16-bit entries, one per quadrant: new list position of the keys
+                              // of that quadrant | 0x8000 when they are to be counted into their new node's quadrants
+                              // (a child with more than one key); a node that was not split: its new position, four times
+  uint32_t mid[2][NCAP];      // split point of a node's rectangle: x | y << 16
   uint16_t todo[2][NCAP];     // expandable nodes in creation order (vSizeAndPointerToNode); at the end: best key per node
   uint16_t sval[NCAP];        // sorted expandable nodes (list positions)
 };
@@ -32,8 +35,10 @@ __device__ __forceinline__ int qt_mid(uint32_t lohi) {  // lo + ceil((hi - lo) /
   const int lo = (int)(lohi & 0xffffu), hi = (int)(lohi >> 16);
   return lo + ((hi - lo + 1) >> 1);
 }
-__device__ __forceinline__ int qt_quadrant(uint32_t key, uint2 G) {  // n1 = 0 (UL), n2 = 1 (UR), n3 = 2 (BL), n4 = 3 (BR)
-  return (key_x(key) < qt_mid(G.x) ? 0 : 1) | (key_y(key) < qt_mid(G.y) ? 0 : 2);
+__device__ __forceinline__ uint32_t qt_mid2(uint2 G) { return (uint32_t)qt_mid(G.x) | ((uint32_t)qt_mid(G.y) << 16); }
+// n1 = 0 (UL), n2 = 1 (UR), n3 = 2 (BL), n4 = 3 (BR) of a node split at `mid`
+__device__ __forceinline__ int qt_quadrant(uint32_t key, uint32_t mid) {
+  return (key_x(key) < (int)(mid & 0xffffu) ? 0 : 1) | (key_y(key) < (int)(mid >> 16) ? 0 : 2);
 }
 __device__ __forceinline__ uint2 qt_child(uint2 G, int q) {
   const uint32_t mx = (uint32_t)qt_mid(G.x), my = (uint32_t)qt_mid(G.y);
@@ -42,37 +47,26 @@ __device__ __forceinline__ uint2 qt_child(uint2 G, int q) {
   c.y = (q & 2) ? (my | (G.y & 0xffff0000u)) : ((G.y & 0xffffu) | (my << 16));
   return c;
 }
+constexpr uint32_t kQtNotSplit = 0xffffffffu;  // ctab[].x of a node the current round has not split (yet)
 
-// +1 on counters[slot] (slot < 0: nothing).  `few`: the wave's keys fall into a handful of counters (early rounds:
-// 64 neighbouring candidates share one or two nodes) - one atomic per distinct counter instead of same-address
-// atomics that the LDS serialises.  `few` must be wave-uniform.
-__device__ __forceinline__ void qt_count(uint32_t* counters, int slot, bool few) {
-  if (few) {
-    unsigned long long left = __ballot(slot >= 0);
-    while (left) {
-      const int leader = __ffsll((long long)left) - 1;
-      const int v = __shfl(slot, leader);
-      const unsigned long long same = __ballot(slot == v);
-      if (lane_id() == leader) atomicAdd(&counters[v], (uint32_t)__popcll(same));
-      left &= ~same;
-    }
-  } else if (slot >= 0) {
-    atomicAdd(&counters[slot], 1u);
-  }
+// +1 on counters[slot] (slot < 0: nothing).  Plain LDS atomics: peeling the distinct counters of a wave (one atomic per
+// counter, ballot + readlane per distinct value) was measured slower in every round, 0.35 vs 0.27 ms per 512 frames.
+__device__ __forceinline__ void qt_count(uint32_t* counters, int slot) {
+  if (slot >= 0) atomicAdd(&counters[slot], 1u);
 }
 
 // New node list after the nodes of processing ranks 0 .. P-1 were offered for splitting (rank -> list position:
 // identity in the breadth-first rounds, the sorted order from the back near the quota), as std::list push_front /
 // erase leave it:
 //   [children of the LAST processed node (n4..n1), ..., children of the FIRST processed node] ++ [nodes not split, old order]
-// A node is split when it holds more than one key.  Writes list 1-p (rectangles; counters zeroed for children, copied
-// for survivors), todo[1-p] (children with more than one key, creation order) and map[]; *s_T = number of children.
+// A node is split when it holds more than one key.  Writes list 1-p (rectangles, split points; counters zeroed for
+// children, copied for survivors), todo[1-p] (children with more than one key, creation order) and ctab[].
 template <int BS, int NCAP>
 __device__ __forceinline__ void qt_rebuild(QtStore<NCAP>& S, int p, int n, int P, int m, bool identity, int cap,
-                                           unsigned long long* s_scan, int* s_newn, int* s_nexp, uint32_t* s_T) {
+                                           unsigned long long* s_scan, int* s_newn, int* s_nexp) {
   const int tid = threadIdx.x;
   if (!identity)
-    for (int pos = tid; pos < n; pos += BS) S.map[pos] = 0;
+    for (int pos = tid; pos < n; pos += BS) S.ctab[pos].x = kQtNotSplit;
   // children | expandable children << 32 of rank rho
   auto offer = [&](int rho, int& pos, uint32_t c[4]) -> unsigned long long {
     pos = identity ? rho : (int)S.sval[m - 1 - rho];
@@ -110,23 +104,31 @@ __device__ __forceinline__ void qt_rebuild(QtStore<NCAP>& S, int p, int n, int P
       if (v != 0) {
         const uint2 G = S.geom[p][pos];
         uint32_t child_rank = (uint32_t)(ex & 0xffffffffu), exp_rank = (uint32_t)(ex >> 32);
-        S.map[pos] = 0x80000000u | child_rank;
+        uint32_t e[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (c[q] > 0) {
             const uint32_t idx = T - child_rank - 1;
+            e[q] = idx;
             if (idx < (uint32_t)cap) {
-              S.geom[1 - p][idx] = qt_child(G, q);
+              const uint2 Gc = qt_child(G, q);
+              S.geom[1 - p][idx] = Gc;
+              S.mid[1 - p][idx] = qt_mid2(Gc);
               S.cnt[1 - p][idx][0] = 0; S.cnt[1 - p][idx][1] = 0; S.cnt[1 - p][idx][2] = 0; S.cnt[1 - p][idx][3] = 0;
             }
             if (c[q] > 1) {
+              e[q] |= 0x8000u;
               if (exp_rank < (uint32_t)cap) S.todo[1 - p][exp_rank] = (uint16_t)idx;
               ++exp_rank;
             }
             ++child_rank;
           }
+        uint2 t;
+        t.x = e[0] | (e[1] << 16);
+        t.y = e[2] | (e[3] << 16);
+        S.ctab[pos] = t;
       } else if (identity) {
-        S.map[pos] = 0;
+        S.ctab[pos].x = kQtNotSplit;
       }
     }
   }
@@ -134,7 +136,7 @@ __device__ __forceinline__ void qt_rebuild(QtStore<NCAP>& S, int p, int n, int P
   uint32_t kcarry = 0;
   for (int p0 = 0; p0 < n; p0 += BS) {
     const int pos = p0 + tid;
-    const uint32_t keep = (pos < n && (S.map[pos] >> 31) == 0) ? 1u : 0u;
+    const uint32_t keep = (pos < n && S.ctab[pos].x == kQtNotSplit) ? 1u : 0u;
     uint32_t tot;
     const uint32_t ex = kcarry + block_exclusive_scan<uint32_t>(keep, reinterpret_cast<uint32_t*>(s_scan), &tot);
     kcarry += tot;
@@ -142,29 +144,35 @@ __device__ __forceinline__ void qt_rebuild(QtStore<NCAP>& S, int p, int n, int P
       const uint32_t np = T + ex;
       if (np < (uint32_t)cap) {
         S.geom[1 - p][np] = S.geom[p][pos];
+        S.mid[1 - p][np] = S.mid[p][pos];
 #pragma unroll
         for (int q = 0; q < 4; ++q) S.cnt[1 - p][np][q] = S.cnt[p][pos][q];
       }
-      S.map[pos] = np;
+      uint2 t;
+      t.x = t.y = np | (np << 16);
+      S.ctab[pos] = t;
     }
   }
-  if (tid == 0) { *s_newn = (int)(T + kcarry); *s_nexp = (int)(T2 >> 32); *s_T = T; }
+  if (tid == 0) { *s_newn = (int)(T + kcarry); *s_nexp = (int)(T2 >> 32); }
   __syncthreads();
 }
+
+constexpr int kQtGather = 8;  // candidate-list positions per work-item and trip of the gather
+constexpr int kQtBatch = 4;   // keys per work-item and trip of the passes over the candidate list (independent loads in flight)
 
 template <int NCAP> struct QtRanges { static constexpr int value = NCAP / 16 + 16; };  // pending ranges hold > 16 elements and are disjoint
 
 template <int BS, int NCAP>
 __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b, int level_begin) {
+  static_assert(NCAP <= 0x4000, "list positions travel in 15 bits of the ctab entries");
   using Ranges = SortRangesT<QtRanges<NCAP>::value>;
   __shared__ QtStore<NCAP> S;
   __shared__ unsigned long long s_scan[32];
   __shared__ Ranges s_ra, s_rb;
   __shared__ int s_sort_cnt[2];
   __shared__ int s_newn, s_nexp, s_n, s_P;
-  __shared__ uint32_t s_T;
   __shared__ uint32_t s_rootcnt[kMaxRoots];
-  __shared__ int s_rootpos[kMaxRoots];
+  __shared__ int s_rootpos[kMaxRoots], s_rootfirst[kMaxRoots + 1];
 #define RGBL_STAMP(k) do { if (b.dbg && threadIdx.x == 0) b.dbg[((size_t)blockIdx.y * n_levels + blockIdx.x + level_begin) * 16 + (k)] = rgbl_clock(); } while (0)
   RGBL_STAMP(0);
 
@@ -173,21 +181,29 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   const LevelGeom& g = geom[l];
   uint32_t* keys = b.keys_a + (size_t)f * b.keys_frame + g.key_off;
   uint16_t* label = reinterpret_cast<uint16_t*>(b.keys_b + (size_t)f * b.keys_frame + g.key_off);
-  const int N = g.quota;
+  // scalars of the level up front: behind the stores below the compiler would have to re-read them from memory
+  const int N = g.quota, n_cells = g.n_cells, cell_cap = g.cell_cap, n_ini = g.n_ini, kcap = g.kcap;
   const int cap = (int)g.node_cap < NCAP ? (int)g.node_cap : NCAP;
+  if (tid <= kMaxRoots) s_rootfirst[tid] = g.root_first[tid];
+  if (tid < kMaxRoots) s_rootcnt[tid] = 0;
+  // root of a key (ORBextractor.cc:585, vpIniNodes[kp.pt.x / hX]): root_first[k] = first x that lands in root k or beyond
+  auto root_of = [&](uint32_t key) {
+    int r = 0;
+    for (int k = 1; k < n_ini; ++k) r += key_x(key) >= s_rootfirst[k] ? 1 : 0;
+    return r;
+  };
 
-  // ---- 0. the cells' candidates as one dense list in the reference's order (cell-major), each labelled with its root
-  //         node (ORBextractor.cc:582-586).  Output position j -> cell by bisection of the cells' prefix sums.
+  // ---- 0. the cells' candidates as one dense list in the reference's order (cell-major).  Output position j -> cell by
+  //         bisection of the cells' prefix sums; kQtGather independent positions per work-item, so that the chains
+  //         bisection -> slot read overlap.  Keys per root node on the way.
   uint32_t* s_pref = &S.cnt[0][0][0];
   constexpr int kPrefCap = 8 * NCAP;
   uint32_t C = 0;
   {
     const uint32_t* ccnt = b.cell_cnt + (size_t)f * b.cells_frame + g.cell_off;
     const uint32_t* slots = b.slots + (size_t)f * b.slots_frame + g.slot_off;
-    const uint8_t* rootx = b.rootx + g.rootx_off;
-    if (tid < kMaxRoots) s_rootcnt[tid] = 0;
-    for (int c_lo = 0; c_lo < g.n_cells; c_lo += kPrefCap) {
-      const int c_hi = c_lo + kPrefCap < g.n_cells ? c_lo + kPrefCap : g.n_cells;
+    for (int c_lo = 0; c_lo < n_cells; c_lo += kPrefCap) {
+      const int c_hi = c_lo + kPrefCap < n_cells ? c_lo + kPrefCap : n_cells;
       const int nc = c_hi - c_lo;
       __syncthreads();  // the previous chunk's bisections are done
       uint32_t run = 0;
@@ -200,23 +216,34 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
         run += tot;
       }
       __syncthreads();
-      for (uint32_t j0 = 0; j0 < run; j0 += BS) {
-        const uint32_t j = j0 + (uint32_t)tid;
-        int r = -1;
-        if (j < run) {
-          int lo = 0, hi = nc;  // s_pref[lo] <= j, and (hi == nc or s_pref[hi] > j): the last cell that starts at or before j
-          while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_pref[mid] <= j) lo = mid; else hi = mid;
+      for (uint32_t j0 = 0; j0 < run; j0 += BS * kQtGather) {
+        uint32_t j[kQtGather];
+        int lo[kQtGather], hi[kQtGather];
+#pragma unroll
+        for (int u = 0; u < kQtGather; ++u) { j[u] = j0 + (uint32_t)(u * BS + tid); lo[u] = 0; hi[u] = nc; }
+        // s_pref[lo] <= j and (hi == nc or s_pref[hi] > j): the last cell that starts at or before j.  No guard on
+        // hi - lo > 1: with hi = lo + 1 the probe is s_pref[lo] itself and nothing moves.
+        for (int span = nc; span > 1; span = (span + 1) >> 1) {
+#pragma unroll
+          for (int u = 0; u < kQtGather; ++u) {
+            const int mid = (lo[u] + hi[u]) >> 1;
+            const bool up = s_pref[mid] <= j[u];
+            lo[u] = up ? mid : lo[u];
+            hi[u] = up ? hi[u] : mid;
           }
-          const uint32_t key = slots[(size_t)(c_lo + lo) * g.cell_cap + (j - s_pref[lo])];
-          keys[C + j] = key;
-          r = rootx[key_x(key)];
-          label[C + j] = (uint16_t)r;
         }
-        for (int k = 0; k < g.n_ini; ++k) {
-          const int c = __popcll(__ballot(r == k));
-          if (lane == 0 && c) atomicAdd(&s_rootcnt[k], (uint32_t)c);
+        uint32_t key[kQtGather];
+#pragma unroll
+        for (int u = 0; u < kQtGather; ++u)
+          key[u] = j[u] < run ? slots[(size_t)(c_lo + lo[u]) * cell_cap + (j[u] - s_pref[lo[u]])] : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < kQtGather; ++u) {
+          if (j[u] < run) keys[C + j[u]] = key[u];
+          const int r = j[u] < run ? root_of(key[u]) : -1;
+          for (int k = 0; k < n_ini; ++k) {
+            const int c = __popcll(__ballot(r == k));
+            if (lane == 0 && c) atomicAdd(&s_rootcnt[k], (uint32_t)c);
+          }
         }
       }
       C += run;
@@ -225,16 +252,17 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   __syncthreads();
   RGBL_STAMP(1);
 
-  // ---- 1. root nodes; empty ones are erased (ORBextractor.cc:566-606)
+  // ---- 1. root nodes, empty ones erased (ORBextractor.cc:566-606); every key's label and its quadrant inside its root
   if (tid == 0) {
     int n0 = 0;
-    for (int r = 0; r < g.n_ini; ++r) {
+    for (int r = 0; r < n_ini; ++r) {
       s_rootpos[r] = n0;
       if (s_rootcnt[r] > 0) {
         uint2 G;
         G.x = (uint32_t)g.root_x[r] | ((uint32_t)g.root_x[r + 1] << 16);
         G.y = (uint32_t)(g.max_by - kMinBorder) << 16;
         S.geom[0][n0] = G;
+        S.mid[0][n0] = qt_mid2(G);
         S.cnt[0][n0][0] = 0; S.cnt[0][n0][1] = 0; S.cnt[0][n0][2] = 0; S.cnt[0][n0][3] = 0;
         ++n0;
       }
@@ -243,15 +271,23 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   }
   __syncthreads();
   int n = s_n;
-  for (uint32_t i0 = 0; i0 < C; i0 += BS) {
-    const uint32_t i = i0 + (uint32_t)tid;
-    int slot = -1;
-    if (i < C) {
-      const int pos = s_rootpos[label[i]];
-      label[i] = (uint16_t)pos;
-      slot = pos * 4 + qt_quadrant(keys[i], S.geom[0][pos]);
+  for (uint32_t i0 = 0; i0 < C; i0 += BS * kQtBatch) {
+    uint32_t key[kQtBatch];
+#pragma unroll
+    for (int u = 0; u < kQtBatch; ++u) {
+      const uint32_t i = i0 + (uint32_t)(u * BS + tid);
+      key[u] = i < C ? keys[i] : 0xffffffffu;
     }
-    qt_count(&S.cnt[0][0][0], slot, true);
+#pragma unroll
+    for (int u = 0; u < kQtBatch; ++u) {
+      int slot = -1;
+      if (key[u] != 0xffffffffu) {
+        const int pos = s_rootpos[root_of(key[u])];
+        label[i0 + (uint32_t)(u * BS + tid)] = (uint16_t)pos;
+        slot = pos * 4 + qt_quadrant(key[u], S.mid[0][pos]);
+      }
+      qt_count(&S.cnt[0][0][0], slot);
+    }
   }
   __syncthreads();
   RGBL_STAMP(2);
@@ -302,10 +338,9 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
       __syncthreads();
       P = s_P;
     }
-    qt_rebuild<BS, NCAP>(S, p, n, P, m, !careful, cap, s_scan, &s_newn, &s_nexp, &s_T);
+    qt_rebuild<BS, NCAP>(S, p, n, P, m, !careful, cap, s_scan, &s_newn, &s_nexp);
     n = s_newn;
     m = s_nexp;
-    const uint32_t T = s_T;
     if (n > cap - 8) { if (tid == 0) atomicOr(b.err, 1); finished = true; }
     else if (n >= N || n == prev) finished = true;
     else if (!careful && n + 3 * m > N) careful = true;
@@ -314,34 +349,41 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
       for (int pos = tid; pos < NCAP; pos += BS) best[pos] = 0;
       __syncthreads();
     }
-    // every key: the list position of its node in the new list; unless this was the last round, counted into its
-    // node's child quadrant (nodes that were not split keep their counters)
-    const bool few = n <= 64;
-    for (uint32_t i0 = 0; i0 < C; i0 += BS) {
-      const uint32_t i = i0 + (uint32_t)tid;
-      int slot = -1;
-      if (i < C) {
-        const uint32_t key = keys[i];
-        const uint32_t old = label[i];
-        const uint32_t mp = S.map[old];
-        uint32_t idx = mp;
-        if (mp >> 31) {
-          const uint2 G = S.geom[p][old];
-          const int q = qt_quadrant(key, G);
-          const uint32_t* c = S.cnt[p][old];
-          const uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-          const uint32_t before = (q > 0 && c0 > 0 ? 1u : 0u) + (q > 1 && c1 > 0 ? 1u : 0u) + (q > 2 && c2 > 0 ? 1u : 0u);
-          idx = T - 1u - ((mp & 0x7fffffffu) + before);
-          const uint32_t mine = q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3));
-          if (!finished && mine > 1 && idx < (uint32_t)cap) slot = (int)idx * 4 + qt_quadrant(key, qt_child(G, q));
-          label[i] = (uint16_t)idx;
-        } else if (idx != old) {
-          label[i] = (uint16_t)idx;
-        }
-        // ---- 3. the strongest key of every node, the first one of the candidate list on ties (ORBextractor.cc:757-776)
-        if (finished && idx < (uint32_t)cap) atomicMax(&best[idx], ((uint32_t)key_s(key) << 24) | (0xffffffu - i));
+    // every key: the list position of its node in the new list (one table entry per quadrant of its old node); keys
+    // of a fresh child with more than one key are counted into that child's quadrants - unless this was the last round
+    for (uint32_t i0 = 0; i0 < C; i0 += BS * kQtBatch) {
+      uint32_t keyv[kQtBatch], oldv[kQtBatch];
+#pragma unroll
+      for (int u = 0; u < kQtBatch; ++u) {
+        const uint32_t i = i0 + (uint32_t)(u * BS + tid);
+        keyv[u] = i < C ? keys[i] : 0u;
+        oldv[u] = i < C ? (uint32_t)label[i] : 0xffffffffu;
       }
-      if (!finished) qt_count(&S.cnt[1 - p][0][0], slot, few);
+      uint2 tabv[kQtBatch];
+      uint32_t midv[kQtBatch];
+#pragma unroll
+      for (int u = 0; u < kQtBatch; ++u) {
+        const uint32_t o = oldv[u] & (uint32_t)(NCAP - 1);
+        tabv[u] = S.ctab[o];
+        midv[u] = S.mid[p][o];
+      }
+#pragma unroll
+      for (int u = 0; u < kQtBatch; ++u) {
+        const uint32_t i = i0 + (uint32_t)(u * BS + tid);
+        const bool valid = oldv[u] != 0xffffffffu;
+        const int q = qt_quadrant(keyv[u], midv[u]);
+        const uint32_t e = (((q & 2) ? tabv[u].y : tabv[u].x) >> ((q & 1) * 16)) & 0xffffu;
+        const uint32_t idx = e & 0x7fffu;
+        if (valid && idx != oldv[u]) label[i] = (uint16_t)idx;
+        if (finished) {
+          // ---- 3. the strongest key of every node, the first one of the candidate list on ties (ORBextractor.cc:757-776)
+          if (valid && idx < (uint32_t)cap) atomicMax(&best[idx], ((uint32_t)key_s(keyv[u]) << 24) | (0xffffffu - i));
+        } else {
+          int slot = -1;
+          if (valid && (e & 0x8000u) && idx < (uint32_t)cap) slot = (int)idx * 4 + qt_quadrant(keyv[u], S.mid[1 - p][idx]);
+          qt_count(&S.cnt[1 - p][0][0], slot);
+        }
+      }
     }
     p ^= 1;
     __syncthreads();
@@ -350,7 +392,7 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   RGBL_STAMP(4);
 
   uint32_t* out = b.kp_key + (size_t)f * b.kp_frame + g.koff;
-  if (n > g.kcap) { if (tid == 0) atomicOr(b.err, 2); n = g.kcap; }
+  if (n > kcap) { if (tid == 0) atomicOr(b.err, 2); n = kcap; }
   if (n > cap) n = cap;
   for (int pos = tid; pos < n; pos += BS) {
     const uint32_t v = best[pos];

@@ -1,6 +1,6 @@
 import sys, os, ctypes as C
 os.environ["RGBL_OCTREE_STAMPS"]="1"
-sys.path.insert(0,'.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from orb_slam3_rgbl_amd import _lib as L, frontend as F, synth
 lib=L.load()
@@ -17,4 +17,6 @@ for l in range(8):
     d=st[:,l,:]
     seg=[(d[:,k+1].astype(np.int64)-d[:,k].astype(np.int64)).mean() for k in range(5)]
     sort=(d[:,9].astype(np.int64)-d[:,8].astype(np.int64)).mean()
+    rr=[(d[:,k].astype(np.int64)-d[:,0].astype(np.int64)).mean()/100.0 for k in range(10,16)]
+    print('   rounds (rebuild, pass) since roots:', ' '.join('%.0f'%v for v in rr))
     print('level',l,'C=%d n=%d'%(d[:,6].mean(), d[:,7].mean()), ' '.join('%s=%.0f'%(n,v/100.0) for n,v in zip(names,seg)), 'last_sort=%.0f'%(sort/100.0), 'total=%.0f (x100 ticks)'%((d[:,5].astype(np.int64)-d[:,0].astype(np.int64)).mean()/100.0))
