@@ -249,14 +249,35 @@ __device__ __forceinline__ int wave_sum_uniform(int v) {
 
 // Exclusive prefix sum over the 256 work-items of a workgroup (4 waves). `scratch` holds >= 8 values.
 // Returns the exclusive prefix of `v`; *total receives the workgroup sum. Contains two barriers.
+// Inclusive prefix sum over the 64 lanes.  32-bit values: Hillis-Steele inside the rows of 16 with four row_shr DPP adds,
+// then the two row broadcasts - register-file traffic only; __shfl_up is a ds_bpermute round trip per step.
 template <class T>
-__device__ __forceinline__ T block_exclusive_scan(T v, T* scratch, T* total) {
-  const int lane = lane_id(), w = wave_id();
+__device__ __forceinline__ T wave_inclusive_scan(T v) {
+#ifndef RGBL_EMU
+  if constexpr (sizeof(T) == 4) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1 (lanes without a source add 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return (T)x;
+  }
+#endif
+  const int lane = lane_id();
   T incl = v;
   for (int d = 1; d < 64; d <<= 1) {
     T up = __shfl_up(incl, d);
     if (lane >= d) incl += up;
   }
+  return incl;
+}
+
+template <class T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* scratch, T* total) {
+  const int lane = lane_id(), w = wave_id();
+  const T incl = wave_inclusive_scan(v);
   if (lane == 63) scratch[w] = incl;
   __syncthreads();
   const int nw = (int)((blockDim.x + 63) >> 6);

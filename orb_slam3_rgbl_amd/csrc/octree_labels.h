@@ -63,51 +63,51 @@ __device__ __forceinline__ void qt_count(uint32_t* counters, int slot) {
 // children, copied for survivors), todo[1-p] (children with more than one key, creation order) and ctab[].
 template <int BS, int NCAP>
 __device__ __forceinline__ void qt_rebuild(QtStore<NCAP>& S, int p, int n, int P, int m, bool identity, int cap,
-                                           unsigned long long* s_scan, int* s_newn, int* s_nexp) {
+                                           uint32_t* s_scan, int* s_newn, int* s_nexp) {
   const int tid = threadIdx.x;
+  constexpr int kPer = (NCAP + BS - 1) / BS;  // ranks per work-item: their counters stay in registers between the two steps
   if (!identity)
     for (int pos = tid; pos < n; pos += BS) S.ctab[pos].x = kQtNotSplit;
-  // children | expandable children << 32 of rank rho
-  auto offer = [&](int rho, int& pos, uint32_t c[4]) -> unsigned long long {
-    pos = identity ? rho : (int)S.sval[m - 1 - rho];
-    unsigned long long v = 0;
-    uint32_t total = 0;
+  // step 1: children | expandable children << 16 per rank, exclusive prefix (both fit 16 bits: at most 4 per node)
+  int pos_r[kPer];
+  uint32_t c_r[kPer][4], v_r[kPer], ex_r[kPer];
+  uint32_t carry = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      c[q] = S.cnt[p][pos][q];
-      total += c[q];
-      v += (c[q] > 0 ? 1ull : 0ull) + (c[q] > 1 ? (1ull << 32) : 0ull);
-    }
-    return total > 1 ? v : 0ull;
-  };
-  unsigned long long T2 = 0;
-  for (int r0 = 0; r0 < P; r0 += BS) {
-    const int rho = r0 + tid;
-    int pos;
-    uint32_t c[4];
-    const unsigned long long v = rho < P ? offer(rho, pos, c) : 0ull;
-    unsigned long long tot;
-    block_exclusive_scan<unsigned long long>(v, s_scan, &tot);
-    T2 += tot;
-  }
-  const uint32_t T = (uint32_t)(T2 & 0xffffffffu);
-  unsigned long long carry = 0;
-  for (int r0 = 0; r0 < P; r0 += BS) {
-    const int rho = r0 + tid;
-    int pos = 0;
-    uint32_t c[4] = {0, 0, 0, 0};
-    const unsigned long long v = rho < P ? offer(rho, pos, c) : 0ull;
-    unsigned long long tot;
-    const unsigned long long ex = carry + block_exclusive_scan<unsigned long long>(v, s_scan, &tot);
-    carry += tot;
+  for (int k = 0; k < kPer; ++k) {
+    if (k * BS >= P) break;  // uniform
+    const int rho = k * BS + tid;
+    pos_r[k] = 0; v_r[k] = 0;
+    c_r[k][0] = c_r[k][1] = c_r[k][2] = c_r[k][3] = 0;
     if (rho < P) {
-      if (v != 0) {
+      pos_r[k] = identity ? rho : (int)S.sval[m - 1 - rho];
+      uint32_t total = 0, v = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        c_r[k][q] = S.cnt[p][pos_r[k]][q];
+        total += c_r[k][q];
+        v += (c_r[k][q] > 0 ? 1u : 0u) + (c_r[k][q] > 1 ? 0x10000u : 0u);
+      }
+      v_r[k] = total > 1 ? v : 0u;
+    }
+    uint32_t tot;
+    ex_r[k] = carry + block_exclusive_scan<uint32_t>(v_r[k], s_scan, &tot);
+    carry += tot;
+  }
+  const uint32_t T = carry & 0xffffu, E = carry >> 16;
+  // step 2: the children, last processed node first
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    if (k * BS >= P) break;
+    const int rho = k * BS + tid;
+    if (rho < P) {
+      const int pos = pos_r[k];
+      if (v_r[k] != 0) {
         const uint2 G = S.geom[p][pos];
-        uint32_t child_rank = (uint32_t)(ex & 0xffffffffu), exp_rank = (uint32_t)(ex >> 32);
+        uint32_t child_rank = ex_r[k] & 0xffffu, exp_rank = ex_r[k] >> 16;
         uint32_t e[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (c[q] > 0) {
+          if (c_r[k][q] > 0) {
             const uint32_t idx = T - child_rank - 1;
             e[q] = idx;
             if (idx < (uint32_t)cap) {
@@ -116,7 +116,7 @@ __device__ __forceinline__ void qt_rebuild(QtStore<NCAP>& S, int p, int n, int P
               S.mid[1 - p][idx] = qt_mid2(Gc);
               S.cnt[1 - p][idx][0] = 0; S.cnt[1 - p][idx][1] = 0; S.cnt[1 - p][idx][2] = 0; S.cnt[1 - p][idx][3] = 0;
             }
-            if (c[q] > 1) {
+            if (c_r[k][q] > 1) {
               e[q] |= 0x8000u;
               if (exp_rank < (uint32_t)cap) S.todo[1 - p][exp_rank] = (uint16_t)idx;
               ++exp_rank;
@@ -133,12 +133,13 @@ __device__ __forceinline__ void qt_rebuild(QtStore<NCAP>& S, int p, int n, int P
     }
   }
   __syncthreads();
+  // step 3: the nodes that were not split keep their order behind the children
   uint32_t kcarry = 0;
   for (int p0 = 0; p0 < n; p0 += BS) {
     const int pos = p0 + tid;
     const uint32_t keep = (pos < n && S.ctab[pos].x == kQtNotSplit) ? 1u : 0u;
     uint32_t tot;
-    const uint32_t ex = kcarry + block_exclusive_scan<uint32_t>(keep, reinterpret_cast<uint32_t*>(s_scan), &tot);
+    const uint32_t ex = kcarry + block_exclusive_scan<uint32_t>(keep, s_scan, &tot);
     kcarry += tot;
     if (keep) {
       const uint32_t np = T + ex;
@@ -153,7 +154,7 @@ __device__ __forceinline__ void qt_rebuild(QtStore<NCAP>& S, int p, int n, int P
       S.ctab[pos] = t;
     }
   }
-  if (tid == 0) { *s_newn = (int)(T + kcarry); *s_nexp = (int)(T2 >> 32); }
+  if (tid == 0) { *s_newn = (int)(T + kcarry); *s_nexp = (int)E; }
   __syncthreads();
 }
 
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   static_assert(NCAP <= 0x4000, "list positions travel in 15 bits of the ctab entries");
   using Ranges = SortRangesT<QtRanges<NCAP>::value>;
   __shared__ QtStore<NCAP> S;
-  __shared__ unsigned long long s_scan[32];
+  __shared__ uint32_t s_scan[32];
   __shared__ Ranges s_ra, s_rb;
   __shared__ int s_sort_cnt[2];
   __shared__ int s_newn, s_nexp, s_n, s_P;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
         const int c = c0 + tid;
         const uint32_t cnt = c < c_hi ? ccnt[c] : 0u;
         uint32_t tot;
-        const uint32_t ex = run + block_exclusive_scan<uint32_t>(cnt, reinterpret_cast<uint32_t*>(s_scan), &tot);
+        const uint32_t ex = run + block_exclusive_scan<uint32_t>(cnt, s_scan, &tot);
         if (c < c_hi) s_pref[c - c_lo] = ex;
         run += tot;
       }
@@ -321,19 +322,19 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
       __syncthreads();
       // first rank (from the back of the sorted array) after which the list has reached the quota: the reference
       // breaks out of its loop there
-      long long carry = 0;
+      int carry = 0;
       for (int r0 = 0; r0 < m; r0 += BS) {
         const int rho = r0 + tid;
-        long long v = 0;
+        int v = 0;
         if (rho < m) {
           const uint32_t* c = S.cnt[p][S.sval[m - 1 - rho]];
-          v = (long long)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) - 1;
+          v = (int)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) - 1;
         }
-        unsigned long long tot;
-        const unsigned long long ex = block_exclusive_scan<unsigned long long>((unsigned long long)v, s_scan, &tot);
-        const long long size_after = (long long)n + carry + (long long)ex + v;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)v, s_scan, &tot);  // modulo 2^32: the partial sums are small ints
+        const int size_after = n + carry + (int)ex + v;
         if (rho < m && size_after >= N) atomicMin(&s_P, rho + 1);
-        carry += (long long)tot;
+        carry += (int)tot;
       }
       __syncthreads();
       P = s_P;
