@@ -201,9 +201,9 @@ __device__ __forceinline__ int fast_true_score(const uint8_t* c, int P) {
 }
 
 // grid = xcd_grid(cells per frame over all levels, B) (common.h), block = 256.  CM = compile-time bound of the scanned cell side: the
-// LDS tiles are sized by it, and LDS is what limits the workgroups per CU (6 at CM = 72, 8 = the wave limit at CM = 48).
-template <int CM>
-__global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict__ geom, int n_levels,
+// LDS tiles are sized by it, and LDS is what limits the workgroups per CU (6 at CM = 72; 17 at CM = 48, where 16 workgroups of 128 fill the 32 wave slots).
+template <int CM, int BS>
+__global__ __launch_bounds__(BS) void k_fast_cells(const LevelGeom* __restrict__ geom, int n_levels,
                                                     const uint8_t* __restrict__ img0, int pitch0,
                                                     size_t frame0, const uint8_t* __restrict__ pyr,
                                                     size_t pyr_frame, int ini_th, int min_th,
@@ -213,12 +213,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   constexpr int kScoreP = CM + 4;  // score tile pitch (cell + 1-px zero frame), multiple of 4
   constexpr int kBitWords = (CM * CM + 63) / 64 * 2;  // bitmap words, an even number: the compaction reads them in pairs
   constexpr int kCornerCap = 512;                     // pixels with a score kept as a list for the NMS (all survivors are scanned beyond that)
-  static_assert(kBitWords <= 256, "one bitmap word per work-item");
+  static_assert(kBitWords <= BS, "one bitmap word per work-item");
   __shared__ uint32_t s_tile_w[(CM + 6) * kTileP / 4];
   uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile_w);
   __shared__ uint32_t s_score_w[(CM + 2) * kScoreP / 4];
   uint8_t* s_score = reinterpret_cast<uint8_t*>(s_score_w);
-  __shared__ uint16_t s_surv[CM * CM];
+  // survivors of the pre-screen as a list; cells with more of them than the list holds (noise, checkerboards) are scored pixel by pixel
+  constexpr int kSurvCap = CM <= kCellSmall ? 1024 : CM * CM;
+  __shared__ uint16_t s_surv[kSurvCap];
   __shared__ uint16_t s_corner[kCornerCap];
   __shared__ int s_nsurv, s_ncorner, s_any_ini;
   __shared__ uint32_t s_keep[kBitWords], s_keep_ini[kBitWords];
@@ -258,19 +260,19 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   {
     const int nwords = (tw + 3) >> 2;  // reads at most 3 bytes past the tile, still >= 13 px inside the row
     const uint32_t wmagic = (0x100000u + (uint32_t)nwords - 1u) / (uint32_t)nwords;
-    for (int i = tid; i < nwords * th; i += 256) {
+    for (int i = tid; i < nwords * th; i += BS) {
       const int y = (int)(__umul24((uint32_t)i, wmagic) >> 20), k = i - (int)__umul24((uint32_t)y, (uint32_t)nwords);
       // row and pitch are far below 2^24 and a level far below 4 GB: one full-rate 24-bit multiply instead of a 64-bit one
       s_tile_w[(y * kTileP >> 2) + k] = load_u32_unaligned(img + (__umul24((uint32_t)(ini_y + y), (uint32_t)pitch) + (uint32_t)(ini_x + 4 * k)));
     }
   }
-  for (int i = tid; i < (sh + 2) * (kScoreP / 4); i += 256) s_score_w[i] = 0;
+  for (int i = tid; i < (sh + 2) * (kScoreP / 4); i += BS) s_score_w[i] = 0;
   if (tid == 0) { s_nsurv = 0; s_ncorner = 0; s_any_ini = 0; }
   if (tid < kBitWords) { s_keep[tid] = 0; s_keep_ini[tid] = 0; }
   __syncthreads();
 
   // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are compacted
-  for (int p = tid; p < npix; p += 256) {
+  for (int p = tid; p < npix; p += BS) {
     const int y = RGBL_DIV_SW(p);
     const uint8_t* c = &s_tile[RGBL_TILE_AT(p, y)];
     const int v = c[0], lo = v - min_th, hi = v + min_th;
@@ -283,15 +285,16 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
     }
     if (dark || bright) {
       const int pos = atomicAdd(&s_nsurv, 1);
-      s_surv[pos] = (uint16_t)p;
+      if (pos < kSurvCap) s_surv[pos] = (uint16_t)p;
     }
   }
   __syncthreads();
 
   // ---- phase B: exact score of the survivors; the few that are corners (score >= min threshold) are listed
-  const int nsurv = s_nsurv;
-  for (int i = tid; i < nsurv; i += 256) {
-    const int p = s_surv[i];
+  const bool all = s_nsurv > kSurvCap;  // the pre-screen is a necessary condition only: scoring every pixel gives the same corners
+  const int nsurv = all ? npix : s_nsurv;
+  for (int i = tid; i < nsurv; i += BS) {
+    const int p = all ? i : (int)s_surv[i];
     const int y = RGBL_DIV_SW(p);
     const int sc = fast_true_score(&s_tile[RGBL_TILE_AT(p, y)], kTileP);
     if (sc >= min_th) {
@@ -306,8 +309,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelGeom* __restrict_
   //      set a bit in a row-major bitmap (one for the min threshold, one for the ini threshold)
   const bool listed = s_ncorner <= kCornerCap;
   const int ncheck = listed ? s_ncorner : nsurv;
-  for (int i = tid; i < ncheck; i += 256) {
-    const int p = listed ? s_corner[i] : s_surv[i];
+  for (int i = tid; i < ncheck; i += BS) {
+    const int p = listed ? (int)s_corner[i] : (all ? i : (int)s_surv[i]);
     const int y = RGBL_DIV_SW(p);
     const uint8_t* s = &s_score[RGBL_SCORE_AT(p, y)];
     const int v = s[0];
