@@ -377,7 +377,8 @@ struct BlurTiles { int tile_off[kMaxLevels + 1]; int tiles_x[kMaxLevels]; };
 // 2j + 1), so the vertical pass is four v_dot2_u32_u16 per output over five such words, the rounding constant being the
 // initial accumulator: even output rows take the weights (18,34)(48,56)(48,34)(18,0), odd ones (0,18)(34,48)(56,48)(34,18).
 // About 10 VALU instructions per pixel (shifts, masks and multiply-adds on unpacked bytes took 25).
-__global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ geom, int n_levels, BlurTiles bt,
+template <int BS>
+__global__ __launch_bounds__(BS) void k_gauss7(const LevelGeom* __restrict__ geom, int n_levels, BlurTiles bt,
                                                     const uint8_t* __restrict__ img0, int pitch0, size_t frame0,
                                                     const uint8_t* __restrict__ pyr, size_t pyr_frame,
                                                     uint8_t* __restrict__ blur, size_t blur_frame, int tile_begin) {
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ ge
   // interior column groups: all six words requested before the first use.  The groups that touch the left or right border
   // of the level are left to a second, compacted pass - inside this loop two lanes per wave would drag the other 62 through
   // the byte-wise path in every iteration of every tile in the first and last tile column.
-  for (int task = tid; task < kPairs * 32; task += 256) {
+  for (int task = tid; task < kPairs * 32; task += BS) {
     const int j = task >> 5, cg = task & 31;
     const int x = x0 + 4 * cg;
     if (x < 4 || x + 8 > W) continue;
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ ge
     const int n_right = (x0 + 4 * cg_r0 + 8 > W) ? cg_last - cg_r0 + 1 : 0;
     const int n_left = (x0 == 0 && cg_r0 > 0) ? 1 : 0;                  // x = 0 < 4 (when it is not a right-border group too)
     const int n_edge = n_left + n_right;
-    for (int task = tid; task < kPairs * n_edge; task += 256) {
+    for (int task = tid; task < kPairs * n_edge; task += BS) {
       const int j = task / n_edge, e = task - j * n_edge;
       const int cg = e < n_left ? 0 : cg_r0 + (e - n_left);
       const int x = x0 + 4 * cg;
@@ -454,9 +455,10 @@ __global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ ge
     }
   }
   __syncthreads();
-  const int cg = tid & 31, rg = tid >> 5;
+  for (int item = tid; item < 256; item += BS) {  // 32 column groups x 8 row groups
+  const int cg = item & 31, rg = item >> 5;
   const int x = x0 + 4 * cg;
-  if (x >= W) return;
+  if (x >= W) continue;
   uint32_t pv[5][4];  // row pairs 2 rg .. 2 rg + 4 = the tile rows 4 rg .. 4 rg + 9
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
@@ -486,6 +488,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const LevelGeom* __restrict__ ge
       out = i == 0 ? acc >> 16 : perm_bytes(acc, out, i == 1 ? 0x0c0c0600u : i == 2 ? 0x0c060100u : 0x06020100u);
     }
     *reinterpret_cast<uint32_t*>(D + __umul24((uint32_t)o, (uint32_t)g.pitch)) = out;
+  }
   }
 }
 
