@@ -200,9 +200,81 @@ __device__ __forceinline__ int fast_true_score(const uint8_t* c, int P) {
   return imax(dark, -bright) - 1;
 }
 
+// ring pixel k of cv::FAST's 16-ring as a byte offset in a tile of pitch P
+__device__ __forceinline__ int ring_off(int k, int P) {
+  switch (k) {
+    case 0: return 3 * P; case 1: return 3 * P + 1; case 2: return 2 * P + 2; case 3: return P + 3;
+    case 4: return 3; case 5: return -P + 3; case 6: return -2 * P + 2; case 7: return -3 * P + 1;
+    case 8: return -3 * P; case 9: return -3 * P - 1; case 10: return -2 * P - 2; case 11: return -P - 3;
+    case 12: return -3; case 13: return P - 3; case 14: return 2 * P - 2; default: return 3 * P - 1;
+  }
+}
+
+// packed signed 16-bit helpers of the score (v_pk_sub_i16, v_pk_min_i16, v_pk_max_i16; half swaps fold into op_sel)
+#ifdef RGBL_EMU
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) { return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16); }
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
+  const int16_t al = (int16_t)a, bl = (int16_t)b, ah = (int16_t)(a >> 16), bh = (int16_t)(b >> 16);
+  return (uint16_t)(al < bl ? al : bl) | ((uint32_t)(uint16_t)(ah < bh ? ah : bh) << 16);
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+  const int16_t al = (int16_t)a, bl = (int16_t)b, ah = (int16_t)(a >> 16), bh = (int16_t)(b >> 16);
+  return (uint16_t)(al > bl ? al : bl) | ((uint32_t)(uint16_t)(ah > bh ? ah : bh) << 16);
+}
+__device__ __forceinline__ uint32_t pk_swap(uint32_t a) { return (a >> 16) | (a << 16); }
+#else
+typedef short rgbl_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rgbl_s2 as_s2(uint32_t a) { rgbl_s2 x; __builtin_memcpy(&x, &a, 4); return x; }
+__device__ __forceinline__ uint32_t from_s2(rgbl_s2 x) { uint32_t a; __builtin_memcpy(&a, &x, 4); return a; }
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) { return from_s2(as_s2(a) - as_s2(b)); }
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) { return from_s2(__builtin_elementwise_min(as_s2(a), as_s2(b))); }
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { return from_s2(__builtin_elementwise_max(as_s2(a), as_s2(b))); }
+__device__ __forceinline__ uint32_t pk_swap(uint32_t a) { return from_s2(as_s2(a).yx); }
+#endif
+
+// fast_true_score (extractor_kernels.h) on pairs: register k holds the differences d_k and d_{k+8} as two signed halves,
+// so ring position k + 8 is register k with its halves swapped and every sliding minimum / maximum is computed for two ring
+// positions at once.  Same value: the largest t for which the pixel is still a FAST-9/16 corner, < 0 if there is none.
+__device__ __forceinline__ int fast_true_score_pk(const uint8_t* c, int P) {
+  const uint32_t v = c[0];
+  const uint32_t vv = v | (v << 16);
+  uint32_t D[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t a = c[ring_off(k, P)], b = c[ring_off(k + 8, P)];
+    D[k] = pk_sub_i16(vv, a | (b << 16));
+  }
+  // index k + 8 of any of the arrays below = entry k with swapped halves
+#define RGBL_AT(A, k) ((k) < 8 ? (A)[(k) & 7] : pk_swap((A)[((k) - 8) & 7]))
+  uint32_t mn2[8], mx2[8], mn4[8], mx4[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { mn2[k] = pk_min_i16(D[k], RGBL_AT(D, k + 1)); mx2[k] = pk_max_i16(D[k], RGBL_AT(D, k + 1)); }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { mn4[k] = pk_min_i16(mn2[k], RGBL_AT(mn2, k + 2)); mx4[k] = pk_max_i16(mx2[k], RGBL_AT(mx2, k + 2)); }
+  uint32_t dark = 0x80008000u, bright = 0x7fff7fffu;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t far = pk_swap(D[k]);  // d_{k+8} for position k, d_k for position k + 8
+    const uint32_t mn9 = pk_min_i16(pk_min_i16(mn4[k], RGBL_AT(mn4, k + 4)), far);
+    const uint32_t mx9 = pk_max_i16(pk_max_i16(mx4[k], RGBL_AT(mx4, k + 4)), far);
+    dark = pk_max_i16(dark, mn9);
+    bright = pk_min_i16(bright, mx9);
+  }
+#undef RGBL_AT
+  const int dk = imax((int)(int16_t)(dark & 0xffffu), (int)(int16_t)(dark >> 16));
+  const int br = imin((int)(int16_t)(bright & 0xffffu), (int)(int16_t)(bright >> 16));
+  return imax(dk, -br) - 1;
+}
+
+// Two adjacent aligned words of the LDS tile (one ds_read2_b32).  Unaligned LDS reads are legal on gfx950 but cost ~15 LDS
+// cycles per instruction (SQ_LDS_UNALIGNED_STALL; measured: 68 % of the kernel's time went there), so the tile is only ever
+// read through aligned words and the byte shifts happen in v_perm_b32 / v_alignbyte_b32.
+struct alignas(4) LdsPair { uint32_t lo, hi; };
+__device__ __forceinline__ LdsPair lds_pair(const uint8_t* p) { return *reinterpret_cast<const LdsPair*>(p); }
+
 // grid = xcd_grid(cells per frame over all levels, B) (common.h), block = 256.  CM = compile-time bound of the scanned cell side: the
 // LDS tiles are sized by it, and LDS is what limits the workgroups per CU (6 at CM = 72; 17 at CM = 48, where 16 workgroups of 128 fill the 32 wave slots).
-template <int CM, int BS>
+template <int CM, int BS, bool kPk = false>
 __global__ __launch_bounds__(BS) void k_fast_cells(const LevelGeom* __restrict__ geom, int n_levels,
                                                     const uint8_t* __restrict__ img0, int pitch0,
                                                     size_t frame0, const uint8_t* __restrict__ pyr,
@@ -271,7 +343,8 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const LevelGeom* __restrict__
   if (tid < kBitWords) { s_keep[tid] = 0; s_keep_ini[tid] = 0; }
   __syncthreads();
 
-  // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are compacted
+  // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are listed.  (Four pixels per
+  //      task on packed 16-bit halves of aligned word pairs, as in fused_level.h, was measured slower here: 1.24 -> 1.39 ms.)
   for (int p = tid; p < npix; p += BS) {
     const int y = RGBL_DIV_SW(p);
     const uint8_t* c = &s_tile[RGBL_TILE_AT(p, y)];
@@ -296,7 +369,7 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const LevelGeom* __restrict__
   for (int i = tid; i < nsurv; i += BS) {
     const int p = all ? i : (int)s_surv[i];
     const int y = RGBL_DIV_SW(p);
-    const int sc = fast_true_score(&s_tile[RGBL_TILE_AT(p, y)], kTileP);
+    const int sc = kPk ? fast_true_score_pk(&s_tile[RGBL_TILE_AT(p, y)], kTileP) : fast_true_score(&s_tile[RGBL_TILE_AT(p, y)], kTileP);
     if (sc >= min_th) {
       s_score[RGBL_SCORE_AT(p, y)] = (uint8_t)sc;
       const int pos = atomicAdd(&s_ncorner, 1);

@@ -88,82 +88,10 @@ struct FusedArgs {
   unsigned long long* dbg;  // phase stamps (cycles summed over the workgroups of a launch), null unless RGBL_FUSED_STAMPS is set
 };
 
-// ring pixel k of cv::FAST's 16-ring as a byte offset in a tile of pitch P
-__device__ __forceinline__ int ring_off(int k, int P) {
-  switch (k) {
-    case 0: return 3 * P; case 1: return 3 * P + 1; case 2: return 2 * P + 2; case 3: return P + 3;
-    case 4: return 3; case 5: return -P + 3; case 6: return -2 * P + 2; case 7: return -3 * P + 1;
-    case 8: return -3 * P; case 9: return -3 * P - 1; case 10: return -2 * P - 2; case 11: return -P - 3;
-    case 12: return -3; case 13: return P - 3; case 14: return 2 * P - 2; default: return 3 * P - 1;
-  }
-}
-
 // exact quotient x / d by a multiplication: floor(x * ceil(2^22 / d) / 2^22) == x / d while x * d < 2^22, and the 32-bit
 // product does not overflow while x / d < 1000 (both checked on the host for every divisor a level uses)
 __host__ __device__ inline uint32_t div_magic(uint32_t d) { return (0x400000u + d - 1u) / d; }
 __device__ __forceinline__ int div_by(uint32_t x, uint32_t magic) { return (int)(__umul24(x, magic) >> 22); }
-
-// packed signed 16-bit helpers of the score (v_pk_sub_i16, v_pk_min_i16, v_pk_max_i16; half swaps fold into op_sel)
-#ifdef RGBL_EMU
-__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) { return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16); }
-__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
-  const int16_t al = (int16_t)a, bl = (int16_t)b, ah = (int16_t)(a >> 16), bh = (int16_t)(b >> 16);
-  return (uint16_t)(al < bl ? al : bl) | ((uint32_t)(uint16_t)(ah < bh ? ah : bh) << 16);
-}
-__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
-  const int16_t al = (int16_t)a, bl = (int16_t)b, ah = (int16_t)(a >> 16), bh = (int16_t)(b >> 16);
-  return (uint16_t)(al > bl ? al : bl) | ((uint32_t)(uint16_t)(ah > bh ? ah : bh) << 16);
-}
-__device__ __forceinline__ uint32_t pk_swap(uint32_t a) { return (a >> 16) | (a << 16); }
-#else
-typedef short rgbl_s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ rgbl_s2 as_s2(uint32_t a) { rgbl_s2 x; __builtin_memcpy(&x, &a, 4); return x; }
-__device__ __forceinline__ uint32_t from_s2(rgbl_s2 x) { uint32_t a; __builtin_memcpy(&a, &x, 4); return a; }
-__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) { return from_s2(as_s2(a) - as_s2(b)); }
-__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) { return from_s2(__builtin_elementwise_min(as_s2(a), as_s2(b))); }
-__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { return from_s2(__builtin_elementwise_max(as_s2(a), as_s2(b))); }
-__device__ __forceinline__ uint32_t pk_swap(uint32_t a) { return from_s2(as_s2(a).yx); }
-#endif
-
-// fast_true_score (extractor_kernels.h) on pairs: register k holds the differences d_k and d_{k+8} as two signed halves,
-// so ring position k + 8 is register k with its halves swapped and every sliding minimum / maximum is computed for two ring
-// positions at once.  Same value: the largest t for which the pixel is still a FAST-9/16 corner, < 0 if there is none.
-__device__ __forceinline__ int fast_true_score_pk(const uint8_t* c, int P) {
-  const uint32_t v = c[0];
-  const uint32_t vv = v | (v << 16);
-  uint32_t D[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const uint32_t a = c[ring_off(k, P)], b = c[ring_off(k + 8, P)];
-    D[k] = pk_sub_i16(vv, a | (b << 16));
-  }
-  // index k + 8 of any of the arrays below = entry k with swapped halves
-#define RGBL_AT(A, k) ((k) < 8 ? (A)[(k) & 7] : pk_swap((A)[((k) - 8) & 7]))
-  uint32_t mn2[8], mx2[8], mn4[8], mx4[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { mn2[k] = pk_min_i16(D[k], RGBL_AT(D, k + 1)); mx2[k] = pk_max_i16(D[k], RGBL_AT(D, k + 1)); }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { mn4[k] = pk_min_i16(mn2[k], RGBL_AT(mn2, k + 2)); mx4[k] = pk_max_i16(mx2[k], RGBL_AT(mx2, k + 2)); }
-  uint32_t dark = 0x80008000u, bright = 0x7fff7fffu;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const uint32_t far = pk_swap(D[k]);  // d_{k+8} for position k, d_k for position k + 8
-    const uint32_t mn9 = pk_min_i16(pk_min_i16(mn4[k], RGBL_AT(mn4, k + 4)), far);
-    const uint32_t mx9 = pk_max_i16(pk_max_i16(mx4[k], RGBL_AT(mx4, k + 4)), far);
-    dark = pk_max_i16(dark, mn9);
-    bright = pk_min_i16(bright, mx9);
-  }
-#undef RGBL_AT
-  const int dk = imax((int)(int16_t)(dark & 0xffffu), (int)(int16_t)(dark >> 16));
-  const int br = imin((int)(int16_t)(bright & 0xffffu), (int)(int16_t)(bright >> 16));
-  return imax(dk, -br) - 1;
-}
-
-// Two adjacent aligned words of the LDS tile (one ds_read2_b32).  Unaligned LDS reads are legal on gfx950 but cost ~15 LDS
-// cycles per instruction (SQ_LDS_UNALIGNED_STALL; measured: 68 % of the kernel's time went there), so the tile is only ever
-// read through aligned words and the byte shifts happen in v_perm_b32 / v_alignbyte_b32.
-struct alignas(4) LdsPair { uint32_t lo, hi; };
-__device__ __forceinline__ LdsPair lds_pair(const uint8_t* p) { return *reinterpret_cast<const LdsPair*>(p); }
 
 // FAST pre-screen of 4 horizontally adjacent pixels per task.  S = (tile column of the first scanned pixel) & 3, a
 // compile-time constant per instantiation: the 4 bytes of ring sample (dx, dy) start S + dx bytes from an aligned word,
