@@ -87,6 +87,7 @@ struct rgbl_extractor {
   int img_pitch = 0;
   // device memory
   LevelGeom* d_geom = nullptr;
+  FastCell* d_cells = nullptr;  // one record per detection cell of a frame (k_fast_cells)
   ResizeTab *d_xtab = nullptr, *d_ytab = nullptr;
   uint8_t* d_rootx = nullptr;
   int8_t* d_pattern = nullptr;
@@ -472,6 +473,35 @@ int upload_tables(rgbl_extractor* e) {
       for (int k = 1; k <= r; ++k) gm.root_first[k] = std::min(gm.root_first[k], x);  // the table is monotone in x
     }
   }
+  // detection cells (ORBextractor.cc:789-822), level after level
+  std::vector<FastCell> cells((size_t)e->cells_frame);
+  for (int l = 0; l < L; ++l) {
+    const LevelGeom& g = e->geom[l];
+    for (int ci = 0; ci < g.n_cells; ++ci) {
+      FastCell c;
+      memset(&c, 0, sizeof(c));
+      const int row = ci / g.n_cols, col = ci - row * g.n_cols;
+      const int ini_x = kMinBorder + col * g.w_cell, ini_y = kMinBorder + row * g.h_cell;
+      const int max_x = std::min(ini_x + g.w_cell + 6, g.max_bx), max_y = std::min(ini_y + g.h_cell + 6, g.max_by);
+      const int tw = max_x - ini_x, th = max_y - ini_y, sw = tw - 6, sh = th - 6;
+      c.ini_x = (uint16_t)ini_x; c.ini_y = (uint16_t)ini_y;
+      c.kx0 = (uint16_t)(col * g.w_cell + 3); c.ky0 = (uint16_t)(row * g.h_cell + 3);
+      c.l = (uint8_t)l;
+      c.skip = (ini_x >= g.max_bx - 6 || ini_y >= g.max_by - 3 || sw <= 0 || sh <= 0) ? 1 : 0;
+      c.pitch = (uint16_t)g.pitch; c.cell_cap = (uint16_t)g.cell_cap;
+      c.img_off = g.img_off;
+      c.slot_base = g.slot_off + (uint32_t)ci * (uint32_t)g.cell_cap;
+      if (!c.skip) {
+        const uint32_t nwords = (uint32_t)(tw + 3) >> 2;
+        c.tw = (uint8_t)tw; c.th = (uint8_t)th;
+        c.magic = (0x100000u + (uint32_t)sw - 1u) / (uint32_t)sw;
+        c.wmagic = (0x100000u + nwords - 1u) / nwords;
+      }
+      cells[(size_t)g.cell_off + ci] = c;
+    }
+  }
+  RGBL_TRY(dev_alloc(e, &e->d_cells, cells.size()));
+  RGBL_HIP(hipMemcpy(e->d_cells, cells.data(), sizeof(FastCell) * cells.size(), hipMemcpyHostToDevice));
   RGBL_TRY(dev_alloc(e, &e->d_geom, L));
   RGBL_TRY(dev_alloc(e, &e->d_xtab, xt.size() + 8));
   RGBL_TRY(dev_alloc(e, &e->d_ytab, yt.size()));
@@ -551,7 +581,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   auto launch_fast = [&](hipStream_t st, int cell_begin, int cell_end) {
     if (cell_end <= cell_begin) return;
     e->timer.begin("k_fast_cells", st);
-    hipLaunchKernelGGL(fast, xcd_grid(e->xcd_map, cell_end - cell_begin, batch), dim3(fast_bs == 128 ? 128 : 256), 0, st, e->d_geom, L, d_imgs, stride, frame_stride,
+    hipLaunchKernelGGL(fast, xcd_grid(e->xcd_map, cell_end - cell_begin, batch), dim3(fast_bs == 128 ? 128 : 256), 0, st, e->d_cells, d_imgs, stride, frame_stride,
                        e->d_pyr, e->pyr_frame, e->cfg.ini_th_fast, e->cfg.min_th_fast, e->d_cellcnt, (size_t)e->cells_frame,
                        e->d_slots, e->slots_frame, cell_begin);
     e->timer.end(st);

@@ -274,8 +274,18 @@ __device__ __forceinline__ LdsPair lds_pair(const uint8_t* p) { return *reinterp
 
 // grid = xcd_grid(cells per frame over all levels, B) (common.h), block = 256.  CM = compile-time bound of the scanned cell side: the
 // LDS tiles are sized by it, and LDS is what limits the workgroups per CU (6 at CM = 72; 17 at CM = 48, where 16 workgroups of 128 fill the 32 wave slots).
+struct FastCell {  // one detection cell of a frame, prepared by the host (upload_tables)
+  uint16_t ini_x, ini_y;     // first pixel of its tile (cell + 3-px ring margin) in the level
+  uint16_t kx0, ky0;         // key coordinates (relative to minBorder) of its first scanned pixel
+  uint8_t tw, th, l, skip;   // tile size, level; skip: the cell starts too close to the border (ORBextractor.cc:810-822)
+  uint16_t pitch, cell_cap;
+  uint32_t magic, wmagic;    // ceil(2^20 / scanned width), ceil(2^20 / tile words per row)
+  uint32_t img_off, slot_base;
+};
+static_assert(sizeof(FastCell) == 32, "one s_load_dwordx8 per cell");
+
 template <int CM, int BS, bool kPk = false>
-__global__ __launch_bounds__(BS) void k_fast_cells(const LevelGeom* __restrict__ geom, int n_levels,
+__global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ cells,
                                                     const uint8_t* __restrict__ img0, int pitch0,
                                                     size_t frame0, const uint8_t* __restrict__ pyr,
                                                     size_t pyr_frame, int ini_th, int min_th,
@@ -300,30 +310,24 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const LevelGeom* __restrict__
   const int tid = threadIdx.x;
   const int f = xcd_frame();
   const int bx = xcd_item() + cell_begin;  // the launch covers the cells cell_begin .. cell_begin + gridDim.x
-  int l = 0;
-  while (l + 1 < n_levels && bx >= geom[l + 1].cell_off) ++l;
-  const LevelGeom& g = geom[l];
-  const int ci = bx - g.cell_off;
-  const int ci_row = ci / g.n_cols, ci_col = ci - ci_row * g.n_cols;
+  // everything a cell needs in one 32-byte scalar load (the level search, two divisions and the LevelGeom look-ups of a
+  // one-cell workgroup were a chain of dependent scalar loads in front of its first pixel request)
+  const FastCell C = cells[bx];
   uint32_t* my_cnt = cell_cnt + (size_t)f * cells_frame + bx;
-
-  const int ini_x = kMinBorder + ci_col * g.w_cell, ini_y = kMinBorder + ci_row * g.h_cell;
-  const int max_x = imin(ini_x + g.w_cell + 6, g.max_bx), max_y = imin(ini_y + g.h_cell + 6, g.max_by);
-  // ORBextractor.cc:810-822: cells starting too close to the border are skipped
-  const int tw = max_x - ini_x, th = max_y - ini_y;
-  const int sw = tw - 6, sh = th - 6;  // scanned (candidate) area of cv::FAST on the sub-image
-  if (ini_x >= g.max_bx - 6 || ini_y >= g.max_by - 3 || sw <= 0 || sh <= 0) {
+  if (C.skip) {  // ORBextractor.cc:810-822: cells starting too close to the border are skipped
     if (tid == 0) *my_cnt = 0;
     return;
   }
-  const uint8_t* img = (l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
-  const int pitch = (l == 0) ? pitch0 : g.pitch;
+  const int ini_x = C.ini_x, ini_y = C.ini_y, tw = C.tw, th = C.th;
+  const int sw = tw - 6, sh = th - 6;  // scanned (candidate) area of cv::FAST on the sub-image
+  const uint8_t* img = (C.l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + C.img_off;
+  const int pitch = (C.l == 0) ? pitch0 : (int)C.pitch;
 
   // ---- stage the (sw+6) x (sh+6) pixel tile and clear the score tile
   const int npix = sw * sh;
   // p / sw == (p * ceil(2^20 / sw)) >> 20 while p * sw < 2^20 (p < 72 * 72, sw <= 72); the product stays below 2^27.
   // 24-bit multiplies: v_mul_u32_u24 issues at the full VALU rate, v_mul_hi_u32 / v_mul_lo_u32 at a quarter of it.
-  const uint32_t magic = (0x100000u + (uint32_t)sw - 1u) / (uint32_t)sw;
+  const uint32_t magic = C.magic;
 #define RGBL_DIV_SW(p) ((int)(__umul24((uint32_t)(p), magic) >> 20))
 #define RGBL_MUL_SW(y) ((int)__umul24((uint32_t)(y), (uint32_t)sw))
   // pixel p = y * sw + x of the scanned area inside the two LDS tiles
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const LevelGeom* __restrict__
 #define RGBL_SCORE_AT(p, y) ((p) + (int)__umul24((uint32_t)(y), (uint32_t)(kScoreP - sw)) + kScoreP + 1)
   {
     const int nwords = (tw + 3) >> 2;  // reads at most 3 bytes past the tile, still >= 13 px inside the row
-    const uint32_t wmagic = (0x100000u + (uint32_t)nwords - 1u) / (uint32_t)nwords;
+    const uint32_t wmagic = C.wmagic;
     for (int i = tid; i < nwords * th; i += BS) {
       const int y = (int)(__umul24((uint32_t)i, wmagic) >> 20), k = i - (int)__umul24((uint32_t)y, (uint32_t)nwords);
       // row and pitch are far below 2^24 and a level far below 4 GB: one full-rate 24-bit multiply instead of a 64-bit one
@@ -424,12 +428,12 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const LevelGeom* __restrict__
       total += __shfl(incl, 63);
     }
     wave_sync();
-    const uint32_t n_out = total < (uint32_t)g.cell_cap ? total : (uint32_t)g.cell_cap;  // cap is a proven bound
-    uint32_t* out = slots + (size_t)f * slots_frame + g.slot_off + (size_t)ci * g.cell_cap;
+    const uint32_t n_out = total < (uint32_t)C.cell_cap ? total : (uint32_t)C.cell_cap;  // cap is a proven bound
+    uint32_t* out = slots + (size_t)f * slots_frame + C.slot_base;
     for (uint32_t i = lane; i < n_out; i += 64) {
       const int p = s_list[i];
       const int y = RGBL_DIV_SW(p), x = p - RGBL_MUL_SW(y);
-      out[i] = pack_key(ci_col * g.w_cell + 3 + x, ci_row * g.h_cell + 3 + y, s_score[RGBL_SCORE_AT(p, y)]);
+      out[i] = pack_key(C.kx0 + x, C.ky0 + y, s_score[RGBL_SCORE_AT(p, y)]);
     }
     if (lane == 0) *my_cnt = n_out;
   }
