@@ -454,8 +454,11 @@ struct BlurTiles { int tile_off[kMaxLevels + 1]; int tiles_x[kMaxLevels]; };
 // 2j + 1), so the vertical pass is four v_dot2_u32_u16 per output over five such words, the rounding constant being the
 // initial accumulator: even output rows take the weights (18,34)(48,56)(48,34)(18,0), odd ones (0,18)(34,48)(56,48)(34,18).
 // About 10 VALU instructions per pixel (shifts, masks and multiply-adds on unpacked bytes took 25).
+struct GaussTile { uint16_t x0, y0, w, h, pitch; uint8_t l, pad; uint32_t img_off; };  // one output tile, prepared by the host
+static_assert(sizeof(GaussTile) == 16, "one s_load_dwordx4 per tile");
+
 template <int BS>
-__global__ __launch_bounds__(BS) void k_gauss7(const LevelGeom* __restrict__ geom, int n_levels, BlurTiles bt,
+__global__ __launch_bounds__(BS) void k_gauss7(const GaussTile* __restrict__ tiles,
                                                     const uint8_t* __restrict__ img0, int pitch0, size_t frame0,
                                                     const uint8_t* __restrict__ pyr, size_t pyr_frame,
                                                     uint8_t* __restrict__ blur, size_t blur_frame, int tile_begin) {
@@ -463,15 +466,11 @@ __global__ __launch_bounds__(BS) void k_gauss7(const LevelGeom* __restrict__ geo
   __shared__ uint32_t s_p[kPairs * kBlurTW];      // [pair][column]: sum of row 2j | sum of row 2j + 1 << 16
   const int f = xcd_frame();
   const int tid = threadIdx.x, bx = xcd_item() + tile_begin;
-  int l = 0;
-  while (l + 1 < n_levels && bx >= bt.tile_off[l + 1]) ++l;
-  const LevelGeom& g = geom[l];
-  const int t = bx - bt.tile_off[l];
-  const int ty = t / bt.tiles_x[l], tx = t - ty * bt.tiles_x[l];
-  const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
-  const uint8_t* img = (l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
-  const int pitch = (l == 0) ? pitch0 : g.pitch;
-  const int W = g.w, H = g.h;
+  const GaussTile T = tiles[bx];  // level, origin and geometry in one scalar load (no level search, no division)
+  const int x0 = T.x0, y0 = T.y0;
+  const uint8_t* img = (T.l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + T.img_off;
+  const int pitch = (T.l == 0) ? pitch0 : (int)T.pitch;
+  const int W = T.w, H = T.h;
   const uint32_t kWA = 18u | (34u << 8) | (48u << 16) | (56u << 24), kWB = 48u | (34u << 8) | (18u << 16);
 
   // one row pair x four columns: seven-tap sums of both rows from their three words each, stored as one 128-bit LDS write
@@ -546,7 +545,7 @@ __global__ __launch_bounds__(BS) void k_gauss7(const LevelGeom* __restrict__ geo
   const uint32_t kO0 = 18u << 16, kO1 = 34u | (48u << 16), kO2 = 56u | (48u << 16), kO3 = 34u | (18u << 16);
   // the row pitch is a multiple of 64 and x a multiple of 4: a full word always fits the row (what lands in the padding right
   // of the last column is never read), so no byte-wise tail; acc < 2^24 and its byte 2 is the pixel: one v_perm_b32 per pixel
-  uint8_t* D = blur + (size_t)f * blur_frame + g.img_off + (__umul24((uint32_t)(y0 + 4 * rg), (uint32_t)g.pitch) + (uint32_t)x);
+  uint8_t* D = blur + (size_t)f * blur_frame + T.img_off + (__umul24((uint32_t)(y0 + 4 * rg), (uint32_t)T.pitch) + (uint32_t)x);
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
     if (y0 + 4 * rg + o >= H) break;
@@ -564,7 +563,7 @@ __global__ __launch_bounds__(BS) void k_gauss7(const LevelGeom* __restrict__ geo
       }
       out = i == 0 ? acc >> 16 : perm_bytes(acc, out, i == 1 ? 0x0c0c0600u : i == 2 ? 0x0c060100u : 0x06020100u);
     }
-    *reinterpret_cast<uint32_t*>(D + __umul24((uint32_t)o, (uint32_t)g.pitch)) = out;
+    *reinterpret_cast<uint32_t*>(D + __umul24((uint32_t)o, (uint32_t)T.pitch)) = out;
   }
   }
 }
@@ -1434,7 +1433,8 @@ __device__ __forceinline__ int bcast_i(int v, int k) {  // value of lane k, wave
 }
 __device__ __forceinline__ float bcast_f(float v, int k) { return __int_as_float(bcast_i(__float_as_int(v), k)); }
 
-__global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restrict__ geom, int n_levels, UMax umax,
+template <int BS>
+__global__ __launch_bounds__(BS) void k_orient_brief(const LevelGeom* __restrict__ geom, int n_levels, UMax umax,
                                                       const int8_t* __restrict__ pattern,
                                                       const uint8_t* __restrict__ img0, int pitch0, size_t frame0,
                                                       const uint8_t* __restrict__ pyr, size_t pyr_frame,
@@ -1445,14 +1445,14 @@ __global__ __launch_bounds__(256) void k_orient_brief(const LevelGeom* __restric
                                                       uint8_t* __restrict__ out_desc, int cap,
                                                       int32_t* __restrict__ out_n, int32_t* __restrict__ out_mono,
                                                       int* __restrict__ err) {
-  __shared__ uint32_t s_patch_w[4][37 * 10];  // blurred 37x37 neighbourhood, 40-byte rows
-  __shared__ uint32_t s_raw_w[4][31 * 8];     // un-blurred 31x31 neighbourhood, 32-byte rows
+  __shared__ uint32_t s_patch_w[BS / 64][37 * 10];  // blurred 37x37 neighbourhood, 40-byte rows
+  __shared__ uint32_t s_raw_w[BS / 64][31 * 8];     // un-blurred 31x31 neighbourhood, 32-byte rows
   const int lane = lane_id(), wave = wave_id();
   const int bx = xcd_item(), f = xcd_frame();  // grid = xcd_grid(keypoint groups, B): an XCD's L2 keeps its frames' levels
   const int* cnts = kp_count + (size_t)f * n_levels;
 
   // ---- lane k < kKpPerWave: which (level, index) is slot s0 + k?  slots are laid out level after level, kcap entries each
-  const int s0 = (bx * 4 + wave) * kKpPerWave;
+  const int s0 = (bx * (BS / 64) + wave) * kKpPerWave;
   const int slot = s0 + (lane < kKpPerWave ? lane : 0);
   int l = 0;
   for (int j = 1; j < n_levels; ++j) l += (slot >= geom[j].koff) ? 1 : 0;  // koff ascends with the level
