@@ -1445,8 +1445,7 @@ __global__ __launch_bounds__(BS) void k_orient_brief(const LevelGeom* __restrict
                                                       uint8_t* __restrict__ out_desc, int cap,
                                                       int32_t* __restrict__ out_n, int32_t* __restrict__ out_mono,
                                                       int* __restrict__ err) {
-  __shared__ uint32_t s_patch_w[BS / 64][37 * 10];  // blurred 37x37 neighbourhood, 40-byte rows
-  __shared__ uint32_t s_raw_w[BS / 64][31 * 8];     // un-blurred 31x31 neighbourhood, 32-byte rows
+  __shared__ unsigned long long s_patch_q[BS / 64][37 * 5];  // blurred 37x37 neighbourhood, 40-byte rows
   const int lane = lane_id(), wave = wave_id();
   const int bx = xcd_item(), f = xcd_frame();  // grid = xcd_grid(keypoint groups, B): an XCD's L2 keeps its frames' levels
   const int* cnts = kp_count + (size_t)f * n_levels;
@@ -1485,7 +1484,11 @@ __global__ __launch_bounds__(BS) void k_orient_brief(const LevelGeom* __restrict
   // ---- all patch words of all keypoints are requested first (one exposed memory latency per wave instead of one per
   //      keypoint and pass): 4 + 6 registers per keypoint.  Keypoints sit >= 19 px inside the level, so x-15..x+16 and
   //      x-18..x+21 stay inside the row pitch.
-  uint32_t rawreg[kKpPerWave][4], blreg[kKpPerWave][6];
+  // Wide loads: a patch row of 32 bytes is two lanes x 16 bytes (one global_load_dwordx4 per keypoint instead of four dword
+  // loads), a blurred row of 40 bytes five lanes x 8 bytes (three dwordx2 loads instead of six dword loads) - the kernel is
+  // bound by the number of vector-memory instructions its patches take, not by their bytes.
+  uint32_t rawreg[kKpPerWave][4];
+  unsigned long long blreg[kKpPerWave][3];
 #pragma unroll
   for (int k = 0; k < kKpPerWave; ++k) {
     if (!((vmask >> k) & 1)) continue;  // wave-uniform
@@ -1494,11 +1497,10 @@ __global__ __launch_bounds__(BS) void k_orient_brief(const LevelGeom* __restrict
     const uint8_t* img = (lk == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + g.img_off;
     const int pitch = (lk == 0) ? pitch0 : g.pitch;
     const uint8_t* src = img + (size_t)(y - 15) * pitch + (x - 15);  // wave-uniform
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = lane + 64 * j;  // row offsets as full-rate 24-bit multiplies (a 64-bit multiply-add costs four issue slots)
-      rawreg[k][j] = i < 31 * 8 ? load_u32_unaligned(src + (__umul24((uint32_t)(i >> 3), (uint32_t)pitch) + (uint32_t)(4 * (i & 7)))) : 0u;
-    }
+    uint4 q;
+    q.x = q.y = q.z = q.w = 0u;
+    if (lane < 62) __builtin_memcpy(&q, src + (__umul24((uint32_t)(lane >> 1), (uint32_t)pitch) + (uint32_t)(16 * (lane & 1))), 16);
+    rawreg[k][0] = q.x; rawreg[k][1] = q.y; rawreg[k][2] = q.z; rawreg[k][3] = q.w;
   }
 #pragma unroll
   for (int k = 0; k < kKpPerWave; ++k) {
@@ -1507,10 +1509,12 @@ __global__ __launch_bounds__(BS) void k_orient_brief(const LevelGeom* __restrict
     const LevelGeom& g = geom[lk];
     const uint8_t* bl = blur + (size_t)f * blur_frame + g.img_off + (size_t)(y - 18) * g.pitch + (x - 18);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < 3; ++j) {
       const int i = lane + 64 * j;
-      const int r = i / 10, c = i - r * 10;
-      blreg[k][j] = i < 37 * 10 ? load_u32_unaligned(bl + (__umul24((uint32_t)r, (uint32_t)g.pitch) + (uint32_t)(4 * c))) : 0u;
+      const int r = i / 5, c = i - r * 5;
+      unsigned long long v = 0ull;
+      if (i < 37 * 5) __builtin_memcpy(&v, bl + (__umul24((uint32_t)r, (uint32_t)g.pitch) + (uint32_t)(8 * c)), 8);
+      blreg[k][j] = v;
     }
   }
 
@@ -1523,38 +1527,28 @@ __global__ __launch_bounds__(BS) void k_orient_brief(const LevelGeom* __restrict
     const int d = umax.v[lane < 62 ? (v < 0 ? -v : v) : 0];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const bool in = half ? (q + 1 <= d) : (15 - q <= d);
+      const bool in = lane < 62 && (half ? (q + 1 <= d) : (15 - q <= d));
       ic_mask[q >> 2] |= in ? (0xffu << (8 * (q & 3))) : 0u;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) ic_coef[j] = 0x03020100u + 0x04040404u * (uint32_t)j + (half ? 0x01010101u : 0u);
     ic_off = half ? 0 : 15;
   }
-  // ---- pass 1, keypoint after keypoint: IC_Angle moments (ORBextractor.cc:76-101) over the rows v = -15..15
+  // ---- pass 1, keypoint after keypoint: IC_Angle moments (ORBextractor.cc:76-101) straight from the registers the patch
+  //      was loaded into: two lanes per row, both sums are integer dot products (v_dot4_u32_u8) of the masked words
   int my_m10 = 0, my_m01 = 0;
 #pragma unroll
   for (int k = 0; k < kKpPerWave; ++k) {
     if (!((vmask >> k) & 1)) continue;  // wave-uniform
-    wave_sync();  // the previous keypoint's readers are done with the buffer
+    uint32_t sum0 = 0, sum1 = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (lane + 64 * j < 31 * 8) s_raw_w[wave][lane + 64 * j] = rawreg[k][j];
-    wave_sync();
-    int m10 = 0, m01 = 0;
-    if (lane < 62) {
-      // two lanes per row; the half row is read as four 32-bit LDS words (all in flight together), the bytes outside the
-      // circle are masked and both sums are integer dot products (v_dot4_u32_u8) of the masked words
-      const uint32_t* roww = s_raw_w[wave] + (lane >> 1) * 8 + (lane & 1) * 4;  // bytes u = -15..0 (half 0) or 1..16 (half 1)
-      uint32_t sum0 = 0, sum1 = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t wm = roww[j] & ic_mask[j];
-        sum0 = udot4(wm, 0x01010101u, sum0);
-        sum1 = udot4(wm, ic_coef[j], sum1);
-      }
-      m10 = (int)sum1 - ic_off * (int)sum0;   // sum of u p with u = q - 15 (half 0) or q + 1 (half 1)
-      m01 = ((lane >> 1) - 15) * (int)sum0;
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t wm = rawreg[k][j] & ic_mask[j];
+      sum0 = udot4(wm, 0x01010101u, sum0);
+      sum1 = udot4(wm, ic_coef[j], sum1);
     }
+    int m10 = (int)sum1 - ic_off * (int)sum0;   // sum of u p with u = q - 15 (half 0) or q + 1 (half 1)
+    int m01 = ((lane >> 1) - 15) * (int)sum0;
     m10 = wave_sum_uniform(m10);
     m01 = wave_sum_uniform(m01);
     if (lane == k) { my_m10 = m10; my_m01 = m01; }
@@ -1567,7 +1561,7 @@ __global__ __launch_bounds__(BS) void k_orient_brief(const LevelGeom* __restrict
   const float ca = glibc_cosf(ang), sb = glibc_sinf(ang);
 
   // ---- pass 2, keypoint after keypoint: steered BRIEF-256 on the blurred level through a 37x37 LDS patch
-  const uint8_t* patch = reinterpret_cast<const uint8_t*>(s_patch_w[wave]);
+  const uint8_t* patch = reinterpret_cast<const uint8_t*>(s_patch_q[wave]);
 #pragma unroll
   for (int k = 0; k < kKpPerWave; ++k) {
     if (!((vmask >> k) & 1)) continue;  // wave-uniform
@@ -1575,8 +1569,8 @@ __global__ __launch_bounds__(BS) void k_orient_brief(const LevelGeom* __restrict
     const float a = bcast_f(ca, k), b = bcast_f(sb, k);
     wave_sync();
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
-      if (lane + 64 * j < 37 * 10) s_patch_w[wave][lane + 64 * j] = blreg[k][j];
+    for (int j = 0; j < 3; ++j)
+      if (lane + 64 * j < 37 * 5) s_patch_q[wave][lane + 64 * j] = blreg[k][j];
     wave_sync();
     // Two points of a pair side by side in packed fp32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per instruction,
     // no contraction): x a - y b and x b + y a as in computeOrbDescriptor (ORBextractor.cc:118-119).  cvRound = adding
