@@ -47,12 +47,12 @@ __device__ __forceinline__ int project_loaded(const ProjParams& P, const CloudPo
   float p[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    // OpenCV's generic GEMM accumulates every dot product in double, k = 0..3, and rounds once
-    double acc = 0.0;
-    acc += (double)P.m[4 * r + 0] * x;
-    acc += (double)P.m[4 * r + 1] * y;
-    acc += (double)P.m[4 * r + 2] * z;
-    acc += (double)P.m[4 * r + 3] * o;
+    // OpenCV's generic GEMM accumulates every dot product in double, k = 0..3, and rounds once.  A product of two floats
+    // is exact in double, so fma(m, v, acc) rounds exactly what acc + m * v rounds: same bits, half the fp64 instructions.
+    double acc = fma((double)P.m[4 * r + 0], x, 0.0);  // 0.0 + product as the reference forms it (the sign of a zero sum included)
+    acc = fma((double)P.m[4 * r + 1], y, acc);
+    acc = fma((double)P.m[4 * r + 2], z, acc);
+    acc = fma((double)P.m[4 * r + 3], o, acc);
     p[r] = (float)acc;
   }
   const float recip = __fdiv_rn(1.0f, p[2]);
