@@ -90,6 +90,8 @@ struct rgbl_extractor {
   FastCell* d_cells = nullptr;  // one record per detection cell of a frame (k_fast_cells)
   GaussTile* d_gtiles = nullptr;  // one record per Gaussian output tile of a frame (k_gauss7)
   ResizeTab *d_xtab = nullptr, *d_ytab = nullptr;
+  ResizeGroup* d_xgroups = nullptr;  // k_resize_linear: one record per 4 output columns (index xtab_off / 4 + group)
+  int32_t* d_xsxa = nullptr;         // first source byte of the group's 8-byte window, -1 = byte path
   uint8_t* d_rootx = nullptr;
   int8_t* d_pattern = nullptr;
   uint8_t *d_img = nullptr, *d_pyr = nullptr, *d_blur = nullptr;
@@ -520,6 +522,32 @@ int upload_tables(rgbl_extractor* e) {
   RGBL_TRY(dev_alloc(e, &e->d_geom, L));
   RGBL_TRY(dev_alloc(e, &e->d_xtab, xt.size() + 8));
   RGBL_TRY(dev_alloc(e, &e->d_ytab, yt.size()));
+  {
+    std::vector<ResizeGroup> groups(xt.size() / 4 + 1);
+    std::vector<int32_t> sxas(xt.size() / 4 + 1, -1);
+    memset(groups.data(), 0, sizeof(ResizeGroup) * groups.size());
+    for (int l = 1; l < L; ++l) {
+      const int sw = e->geom[l - 1].w;
+      const size_t g0 = e->geom[l].xtab_off / 4, g1 = (l + 1 < L ? e->geom[l + 1].xtab_off : xt.size()) / 4;
+      for (size_t G = g0; G < g1; ++G) {
+        const ResizeTab* X = xt.data() + 4 * G;
+        ResizeGroup& R = groups[G];
+        const int sxa = std::min((int)X[0].sofs, sw - 8);
+        bool ok = sw >= 8 && sxa >= 0;
+        for (int i = 0; i < 4; ++i) {
+          ok = ok && X[i].sofs >= sxa && X[i].sofs + 1 - sxa <= 7;
+          const uint32_t o = (uint32_t)std::min(std::max(X[i].sofs - sxa, 0), 6);
+          R.sel[i] = o | (0x0cu << 8) | ((o + 1) << 16) | (0x0cu << 24);
+          R.w[i] = (uint32_t)(uint16_t)X[i].a0 | ((uint32_t)(uint16_t)X[i].a1 << 16);
+        }
+        sxas[G] = ok ? sxa : -1;
+      }
+    }
+    RGBL_TRY(dev_alloc(e, &e->d_xgroups, groups.size()));
+    RGBL_TRY(dev_alloc(e, &e->d_xsxa, sxas.size()));
+    RGBL_HIP(hipMemcpy(e->d_xgroups, groups.data(), sizeof(ResizeGroup) * groups.size(), hipMemcpyHostToDevice));
+    RGBL_HIP(hipMemcpy(e->d_xsxa, sxas.data(), sizeof(int32_t) * sxas.size(), hipMemcpyHostToDevice));
+  }
   RGBL_TRY(dev_alloc(e, &e->d_rootx, rootx.size()));
   RGBL_TRY(dev_alloc(e, &e->d_pattern, 1024));
   RGBL_HIP(hipMemcpy(e->d_geom, e->geom.data(), sizeof(LevelGeom) * L, hipMemcpyHostToDevice));
@@ -724,7 +752,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       e->timer.begin("k_resize_linear", s);
       const int rtx = (g.w + 4 * kResizeLanes - 1) / (4 * kResizeLanes), rty = (g.h + 4 * kResizeRows - 1) / (4 * kResizeRows);
       hipLaunchKernelGGL(k_resize_linear, xcd_grid(e->xcd_map, rtx * rty, batch), dim3(kResizeWG), 0, s, src, spitch, sframe, p.w, p.h, e->d_pyr + g.img_off, g.pitch, e->pyr_frame, g.w, g.h,
-                       e->d_xtab + g.xtab_off, e->d_ytab + g.ytab_off, rtx);
+                       e->d_xtab + g.xtab_off, e->d_xgroups + g.xtab_off / 4, e->d_xsxa + g.xtab_off / 4, e->d_ytab + g.ytab_off, rtx);
       e->timer.end(s);
     }
     // 4. Gaussian working images (ORBextractor.cc:1132-1133) of the upper levels, on the auxiliary stream next to 2. and 3.

@@ -75,10 +75,18 @@ constexpr int kResizeRows = 4;  // output rows per work-item (1 / 2 / 4 measured
 // column of a level is mostly empty (1034 columns = 4.04 workgroups: 83 % of the launched lanes work over the 7 levels);
 // 32 lanes per row leave 92 % (0.595 -> 0.575 ms; 16 lanes per row: 0.58).
 constexpr int kResizeLanes = 32, kResizeWG = kResizeLanes * 4;
+// One group of 4 output columns, prepared by the host: the 8-byte source window (pulled back at the end of a row so that it
+// stays inside it), per column the v_perm_b32 selector that pulls its two taps out of the window as two 16-bit halves and
+// the two 11-bit weights packed the same way (one v_dot2_u32_u16 per source row and column).  sxa < 0: the taps of the
+// group do not fit 8 bytes (scale factors above ~1.7) or the source is narrower than 8 px - byte path.
+struct ResizeGroup { uint32_t sel[4], w[4]; };
+static_assert(sizeof(ResizeGroup) == 32, "two 16-byte loads per group");
+
 __global__ __launch_bounds__(kResizeWG) void k_resize_linear(const uint8_t* __restrict__ src, int spitch,
                                                        size_t sframe, int sw, int sh,
                                                        uint8_t* __restrict__ dst, int dpitch, size_t dframe,
                                                        int dw, int dh, const ResizeTab* __restrict__ xtab,
+                                                       const ResizeGroup* __restrict__ xgroups, const int32_t* __restrict__ xsxa,
                                                        const ResizeTab* __restrict__ ytab, int tiles_x) {
   // grid = xcd_grid(tiles_x * tiles_y, B) (common.h)
   const int tx = threadIdx.x % kResizeLanes, ty = threadIdx.x / kResizeLanes;
@@ -88,52 +96,52 @@ __global__ __launch_bounds__(kResizeWG) void k_resize_linear(const uint8_t* __re
   if (dy0 >= dh || dx0 >= dw) return;
   const uint8_t* S = src + (size_t)xcd_frame() * sframe;
   uint8_t* D = dst + (size_t)xcd_frame() * dframe + (size_t)dy0 * dpitch;
-  // both coefficient tables are requested before either is used (one round trip, not two); the x table is padded to a
-  // multiple of 4 entries per level with copies of the last entry
-  const uint4* t4 = reinterpret_cast<const uint4*>(xtab + dx0);
-  const uint4 q0 = t4[0], q1 = t4[1];
+  // the group's record and the row table are requested before either is used (one round trip, not two); the x table is
+  // padded to a multiple of 4 entries per level with copies of the last entry
+  const int sxa = xsxa[dx0 >> 2];
+  const uint4* g4 = reinterpret_cast<const uint4*>(xgroups + (dx0 >> 2));
+  const uint4 gs = g4[0], gw = g4[1];
   // the kResizeRows rows' vertical taps; rows past the image repeat the last one (computed, not stored)
   ResizeTab ry[kResizeRows];
 #pragma unroll
   for (int r = 0; r < kResizeRows; ++r) ry[r] = ytab[imin(dy0 + r, dh - 1)];
-  ResizeTab rx[4];
-  rx[0].sofs = (int)q0.x; rx[0].a0 = (int16_t)(q0.y & 0xffff); rx[0].a1 = (int16_t)(q0.y >> 16);
-  rx[1].sofs = (int)q0.z; rx[1].a0 = (int16_t)(q0.w & 0xffff); rx[1].a1 = (int16_t)(q0.w >> 16);
-  rx[2].sofs = (int)q1.x; rx[2].a0 = (int16_t)(q1.y & 0xffff); rx[2].a1 = (int16_t)(q1.y >> 16);
-  rx[3].sofs = (int)q1.z; rx[3].a0 = (int16_t)(q1.w & 0xffff); rx[3].a1 = (int16_t)(q1.w >> 16);
-  // the 8-byte source window starts at the first column's source pixel, pulled back at the end of the row so that it stays
-  // inside it; the x table is padded with copies of its last entry and the level's row pitch with 64-byte alignment, so the
-  // last (partial) group of a row takes this path too and stores a full word
-  const int sxa = imin(rx[0].sofs, sw - 8);
-  if (sw >= 8 && rx[3].sofs + 1 - sxa <= 7) {
-    // all 4 kResizeRows source words are requested before the first one is used: a wave keeps 4 KB in flight, the
-    // kernel is bound by the round trips per byte otherwise (one row per work-item ran at 1.2 TB/s)
-    unsigned long long r0[kResizeRows], r1[kResizeRows];
+  if (sxa >= 0) {
+    // all 4 kResizeRows source windows are requested before the first one is used: a wave keeps 4 KB in flight, the
+    // kernel is bound by the round trips per byte otherwise (one row per work-item ran at 1.2 TB/s).  The last (partial)
+    // group of a row takes this path too and stores a full word (the level's row pitch is 64-byte aligned).
+    uint32_t r0l[kResizeRows], r0h[kResizeRows], r1l[kResizeRows], r1h[kResizeRows];
 #pragma unroll
     for (int r = 0; r < kResizeRows; ++r) {
       const int sy0 = imin(imax(ry[r].sofs, 0), sh - 1), sy1 = imin(imax(ry[r].sofs + 1, 0), sh - 1);
       const uint8_t* S0 = S + (size_t)sy0 * spitch + sxa;
       const uint8_t* S1 = S + (size_t)sy1 * spitch + sxa;
-      r0[r] = (unsigned long long)load_u32_unaligned(S0) | ((unsigned long long)load_u32_unaligned(S0 + 4) << 32);
-      r1[r] = (unsigned long long)load_u32_unaligned(S1) | ((unsigned long long)load_u32_unaligned(S1 + 4) << 32);
+      r0l[r] = load_u32_unaligned(S0); r0h[r] = load_u32_unaligned(S0 + 4);
+      r1l[r] = load_u32_unaligned(S1); r1h[r] = load_u32_unaligned(S1 + 4);
     }
+    const uint32_t sel[4] = {gs.x, gs.y, gs.z, gs.w}, wt[4] = {gw.x, gw.y, gw.z, gw.w};
 #pragma unroll
     for (int r = 0; r < kResizeRows; ++r) {
       const int b0 = ry[r].a0, b1 = ry[r].a1;
       uint32_t out = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int sh8 = 8 * (rx[i].sofs - sxa);
-        const int p00 = (int)((r0[r] >> sh8) & 0xff), p01 = (int)((r0[r] >> (sh8 + 8)) & 0xff);
-        const int p10 = (int)((r1[r] >> sh8) & 0xff), p11 = (int)((r1[r] >> (sh8 + 8)) & 0xff);
-        const int h0 = p00 * rx[i].a0 + p01 * rx[i].a1;
-        const int h1 = p10 * rx[i].a0 + p11 * rx[i].a1;
+        const int h0 = (int)udot2(perm_bytes(r0h[r], r0l[r], sel[i]), wt[i], 0u);  // p00 a0 + p01 a1
+        const int h1 = (int)udot2(perm_bytes(r1h[r], r1l[r], sel[i]), wt[i], 0u);
         const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
         out |= (uint32_t)(v & 0xff) << (8 * i);
       }
       if (dy0 + r < dh) *reinterpret_cast<uint32_t*>(D + (size_t)r * dpitch + dx0) = out;  // dpitch and dx0 are multiples of 4
     }
     return;
+  }
+  ResizeTab rx[4];
+  {
+    const uint4* t4 = reinterpret_cast<const uint4*>(xtab + dx0);
+    const uint4 q0 = t4[0], q1 = t4[1];
+    rx[0].sofs = (int)q0.x; rx[0].a0 = (int16_t)(q0.y & 0xffff); rx[0].a1 = (int16_t)(q0.y >> 16);
+    rx[1].sofs = (int)q0.z; rx[1].a0 = (int16_t)(q0.w & 0xffff); rx[1].a1 = (int16_t)(q0.w >> 16);
+    rx[2].sofs = (int)q1.x; rx[2].a0 = (int16_t)(q1.y & 0xffff); rx[2].a1 = (int16_t)(q1.y >> 16);
+    rx[3].sofs = (int)q1.z; rx[3].a0 = (int16_t)(q1.w & 0xffff); rx[3].a1 = (int16_t)(q1.w >> 16);
   }
   // large scale factors / sources narrower than 8 px: byte path (unrolled with compile-time r: a run-time index into ry[]
   // makes the compiler park the array in LDS, 16 KB per workgroup, for the common path as well)
