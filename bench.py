@@ -412,7 +412,8 @@ def main():
     lib = L.load()
 
     # ---- synthetic input, one independent sequence per rank (BASELINE configs[3]: sequences shard over GPUs)
-    seq = synth.Sequence(sharding.sequences_of_rank(world, world, rank)[0], w, h, n_frames=B)
+    # constant_density: 1200 shapes per frame area whatever the batch (the scene grows with the sequence length)
+    seq = synth.Sequence(sharding.sequences_of_rank(world, world, rank)[0], w, h, n_frames=B, constant_density=not os.environ.get("RGBL_BENCH_SPARSE"))
     frames = np.stack([seq.frame(i) for i in range(B)])
     n_scans = min(B, 8)
     scans = [synth.lidar_scan(rank * 1000 + i, n_az=n_az) for i in range(n_scans)]

@@ -54,6 +54,17 @@ constexpr uint32_t kQtNotSplit = 0xffffffffu;  // ctab[].x of a node the current
 __device__ __forceinline__ void qt_count(uint32_t* counters, int slot) {
   if (slot >= 0) atomicAdd(&counters[slot], 1u);
 }
+// While the list is short, thousands of keys meet in a few dozen counters and the LDS serialises same-address atomics (a
+// dense KITTI level 0: 8 600 keys into 12 counters took 160 k cycles with four workgroups sharing the CU's LDS).  Those
+// rounds count into 2^rlog copies of every counter, the copy chosen by the lane, and sum the copies afterwards.
+__device__ __forceinline__ void qt_count_rep(uint32_t* copies, int slot, int rlog) {
+  if (slot >= 0) atomicAdd(&copies[(slot << rlog) + (lane_id() & ((1 << rlog) - 1))], 1u);
+}
+__device__ __forceinline__ int qt_rep_log(int counters, int words) {  // copies per counter that fit `words`, at most 32
+  int rlog = 0;
+  while (rlog < 5 && (counters << (rlog + 1)) <= words) ++rlog;
+  return rlog;
+}
 
 // New node list after the nodes of processing ranks 0 .. P-1 were offered for splitting (rank -> list position:
 // identity in the breadth-first rounds, the sorted order from the back near the quota), as std::list push_front /
@@ -158,7 +169,6 @@ __device__ __forceinline__ void qt_rebuild(QtStore<NCAP>& S, int p, int n, int P
   __syncthreads();
 }
 
-constexpr int kQtGather = 8;  // candidate-list positions per work-item and trip of the gather
 constexpr int kQtBatch = 4;   // keys per work-item and trip of the passes over the candidate list (independent loads in flight)
 
 template <int NCAP> struct QtRanges { static constexpr int value = NCAP / 16 + 16; };  // pending ranges hold > 16 elements and are disjoint
@@ -172,12 +182,11 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   __shared__ Ranges s_ra, s_rb;
   __shared__ int s_sort_cnt[2];
   __shared__ int s_newn, s_nexp, s_n, s_P;
-  __shared__ uint32_t s_rootcnt[kMaxRoots];
   __shared__ int s_rootpos[kMaxRoots], s_rootfirst[kMaxRoots + 1];
 #define RGBL_STAMP(k) do { if (b.dbg && threadIdx.x == 0) b.dbg[((size_t)blockIdx.y * n_levels + blockIdx.x + level_begin) * 16 + (k)] = rgbl_clock(); } while (0)
   RGBL_STAMP(0);
 
-  const int tid = threadIdx.x, lane = lane_id();
+  const int tid = threadIdx.x;
   const int l = blockIdx.x + level_begin, f = blockIdx.y;  // the launch covers the levels level_begin .. level_begin + gridDim.x
   const LevelGeom& g = geom[l];
   uint32_t* keys = b.keys_a + (size_t)f * b.keys_frame + g.key_off;
@@ -186,7 +195,6 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   const int N = g.quota, n_cells = g.n_cells, cell_cap = g.cell_cap, n_ini = g.n_ini, kcap = g.kcap;
   const int cap = (int)g.node_cap < NCAP ? (int)g.node_cap : NCAP;
   if (tid <= kMaxRoots) s_rootfirst[tid] = g.root_first[tid];
-  if (tid < kMaxRoots) s_rootcnt[tid] = 0;
   // root of a key (ORBextractor.cc:585, vpIniNodes[kp.pt.x / hX]): root_first[k] = first x that lands in root k or beyond
   auto root_of = [&](uint32_t key) {
     int r = 0;
@@ -194,19 +202,34 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
     return r;
   };
 
-  // ---- 0. the cells' candidates as one dense list in the reference's order (cell-major).  Output position j -> cell by
-  //         bisection of the cells' prefix sums; kQtGather independent positions per work-item, so that the chains
-  //         bisection -> slot read overlap.  Keys per root node on the way.
-  uint32_t* s_pref = &S.cnt[0][0][0];
-  constexpr int kPrefCap = 8 * NCAP;
+  // ---- 0. + 1.  The cells' candidates as one dense list in the reference's order (cell-major), each labelled with its
+  //         root node and counted into its root's quadrants on the way (ORBextractor.cc:566-606).  Half a wave
+  //         copies one cell at a time (its slots are contiguous: whole cache lines in, whole lines out - with four
+  //         2 048 workgroups at once, 8-lane groups cost 2.5 x the time); four cells per trip, 8 requests per lane in flight.
+  //         Roots are numbered as if none were empty; the rare frame with an empty root is fixed up afterwards.
+  uint32_t* s_pref = &S.cnt[0][kMaxRoots][0];  // behind the root nodes' counters
+  constexpr int kPrefCap = 8 * NCAP - 4 * kMaxRoots - 1;
+  constexpr int kGrp = 32, kGroups = BS / kGrp, kPre = 2, kTrip = 4;
+  if (tid < n_ini) {
+    uint2 G;
+    G.x = (uint32_t)g.root_x[tid] | ((uint32_t)g.root_x[tid + 1] << 16);
+    G.y = (uint32_t)(g.max_by - kMinBorder) << 16;
+    S.geom[0][tid] = G;
+    S.mid[0][tid] = qt_mid2(G);
+    S.cnt[0][tid][0] = 0; S.cnt[0][tid][1] = 0; S.cnt[0][tid][2] = 0; S.cnt[0][tid][3] = 0;
+  }
+  uint32_t* s_rep0 = reinterpret_cast<uint32_t*>(&S.ctab[0]);  // 2 NCAP words, idle until the first rebuild
+  const int rlog0 = qt_rep_log(4 * n_ini, 2 * NCAP);
+  for (int i = tid; i < ((4 * n_ini) << rlog0); i += BS) s_rep0[i] = 0;
   uint32_t C = 0;
   {
     const uint32_t* ccnt = b.cell_cnt + (size_t)f * b.cells_frame + g.cell_off;
     const uint32_t* slots = b.slots + (size_t)f * b.slots_frame + g.slot_off;
+    const int grp = tid / kGrp, gl = tid % kGrp;
     for (int c_lo = 0; c_lo < n_cells; c_lo += kPrefCap) {
       const int c_hi = c_lo + kPrefCap < n_cells ? c_lo + kPrefCap : n_cells;
       const int nc = c_hi - c_lo;
-      __syncthreads();  // the previous chunk's bisections are done
+      __syncthreads();  // the previous chunk's readers are done (and the root nodes are set)
       uint32_t run = 0;
       for (int c0 = c_lo; c0 < c_hi; c0 += BS) {
         const int c = c0 + tid;
@@ -216,55 +239,65 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
         if (c < c_hi) s_pref[c - c_lo] = ex;
         run += tot;
       }
+      if (tid == 0) s_pref[nc] = run;
       __syncthreads();
-      for (uint32_t j0 = 0; j0 < run; j0 += BS * kQtGather) {
-        uint32_t j[kQtGather];
-        int lo[kQtGather], hi[kQtGather];
+      auto take = [&](uint32_t key, uint32_t at) {
+        const int r = root_of(key);
+        keys[at] = key;
+        label[at] = (uint16_t)r;
+        qt_count_rep(s_rep0, r * 4 + qt_quadrant(key, S.mid[0][r]), rlog0);
+      };
+      for (int c0 = grp; c0 < nc; c0 += kTrip * kGroups) {
+        // the first kPre * kGrp candidates of kTrip cells are requested before any is used (a cell holds ~30, rarely more
+        // than 64): the slots come from HBM, a trip that waited for them piece by piece cost microseconds
+        uint32_t bq[kTrip], nq[kTrip], kq[kTrip][kPre];
+        const uint32_t* sq[kTrip];
 #pragma unroll
-        for (int u = 0; u < kQtGather; ++u) { j[u] = j0 + (uint32_t)(u * BS + tid); lo[u] = 0; hi[u] = nc; }
-        // s_pref[lo] <= j and (hi == nc or s_pref[hi] > j): the last cell that starts at or before j.  No guard on
-        // hi - lo > 1: with hi = lo + 1 the probe is s_pref[lo] itself and nothing moves.
-        for (int span = nc; span > 1; span = (span + 1) >> 1) {
-#pragma unroll
-          for (int u = 0; u < kQtGather; ++u) {
-            const int mid = (lo[u] + hi[u]) >> 1;
-            const bool up = s_pref[mid] <= j[u];
-            lo[u] = up ? mid : lo[u];
-            hi[u] = up ? hi[u] : mid;
-          }
+        for (int t = 0; t < kTrip; ++t) {
+          const int c = c0 + t * kGroups;
+          const bool on = c < nc;
+          bq[t] = on ? s_pref[c] : 0u;
+          nq[t] = on ? s_pref[c + 1] - bq[t] : 0u;
+          sq[t] = slots + (size_t)(c_lo + (on ? c : c0)) * cell_cap;
         }
-        uint32_t key[kQtGather];
 #pragma unroll
-        for (int u = 0; u < kQtGather; ++u)
-          key[u] = j[u] < run ? slots[(size_t)(c_lo + lo[u]) * cell_cap + (j[u] - s_pref[lo[u]])] : 0xffffffffu;
+        for (int t = 0; t < kTrip; ++t)
 #pragma unroll
-        for (int u = 0; u < kQtGather; ++u) {
-          if (j[u] < run) keys[C + j[u]] = key[u];
-          const int r = j[u] < run ? root_of(key[u]) : -1;
-          for (int k = 0; k < n_ini; ++k) {
-            const int c = __popcll(__ballot(r == k));
-            if (lane == 0 && c) atomicAdd(&s_rootcnt[k], (uint32_t)c);
+          for (int j = 0; j < kPre; ++j) {
+            const uint32_t k = (uint32_t)(gl + kGrp * j);
+            kq[t][j] = k < nq[t] ? sq[t][k] : 0u;
           }
+#pragma unroll
+        for (int t = 0; t < kTrip; ++t) {
+#pragma unroll
+          for (int j = 0; j < kPre; ++j) {
+            const uint32_t k = (uint32_t)(gl + kGrp * j);
+            if (k < nq[t]) take(kq[t][j], C + bq[t] + k);
+          }
+          for (uint32_t k = (uint32_t)(gl + kGrp * kPre); k < nq[t]; k += kGrp) take(sq[t][k], C + bq[t] + k);
         }
       }
       C += run;
     }
   }
   __syncthreads();
+  if (tid < 4 * n_ini) {
+    uint32_t v = 0;
+    for (int j = 0; j < (1 << rlog0); ++j) v += s_rep0[(tid << rlog0) + j];
+    S.cnt[0][tid >> 2][tid & 3] = v;
+  }
+  __syncthreads();
   RGBL_STAMP(1);
-
-  // ---- 1. root nodes, empty ones erased (ORBextractor.cc:566-606); every key's label and its quadrant inside its root
-  if (tid == 0) {
+  if (tid == 0) {  // empty roots are erased (ORBextractor.cc:597-606)
     int n0 = 0;
     for (int r = 0; r < n_ini; ++r) {
       s_rootpos[r] = n0;
-      if (s_rootcnt[r] > 0) {
-        uint2 G;
-        G.x = (uint32_t)g.root_x[r] | ((uint32_t)g.root_x[r + 1] << 16);
-        G.y = (uint32_t)(g.max_by - kMinBorder) << 16;
-        S.geom[0][n0] = G;
-        S.mid[0][n0] = qt_mid2(G);
-        S.cnt[0][n0][0] = 0; S.cnt[0][n0][1] = 0; S.cnt[0][n0][2] = 0; S.cnt[0][n0][3] = 0;
+      if (S.cnt[0][r][0] + S.cnt[0][r][1] + S.cnt[0][r][2] + S.cnt[0][r][3] > 0) {
+        if (n0 != r) {
+          S.geom[0][n0] = S.geom[0][r];
+          S.mid[0][n0] = S.mid[0][r];
+          S.cnt[0][n0][0] = S.cnt[0][r][0]; S.cnt[0][n0][1] = S.cnt[0][r][1]; S.cnt[0][n0][2] = S.cnt[0][r][2]; S.cnt[0][n0][3] = S.cnt[0][r][3];
+        }
         ++n0;
       }
     }
@@ -272,23 +305,8 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   }
   __syncthreads();
   int n = s_n;
-  for (uint32_t i0 = 0; i0 < C; i0 += BS * kQtBatch) {
-    uint32_t key[kQtBatch];
-#pragma unroll
-    for (int u = 0; u < kQtBatch; ++u) {
-      const uint32_t i = i0 + (uint32_t)(u * BS + tid);
-      key[u] = i < C ? keys[i] : 0xffffffffu;
-    }
-#pragma unroll
-    for (int u = 0; u < kQtBatch; ++u) {
-      int slot = -1;
-      if (key[u] != 0xffffffffu) {
-        const int pos = s_rootpos[root_of(key[u])];
-        label[i0 + (uint32_t)(u * BS + tid)] = (uint16_t)pos;
-        slot = pos * 4 + qt_quadrant(key[u], S.mid[0][pos]);
-      }
-      qt_count(&S.cnt[0][0][0], slot);
-    }
+  if (n != n_ini) {  // wave-uniform, rare: the labels of the roots behind an empty one move up
+    for (uint32_t i = (uint32_t)tid; i < C; i += BS) label[i] = (uint16_t)s_rootpos[label[i]];
   }
   __syncthreads();
   RGBL_STAMP(2);
@@ -346,8 +364,14 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
     else if (n >= N || n == prev) finished = true;
     else if (!careful && n + 3 * m > N) careful = true;
     if (!stamped && (careful || finished)) { RGBL_STAMP(3); stamped = true; }
+    // copies of the new list's counters (in the old list's counters, which nobody reads any more) while it is short
+    uint32_t* s_rep = &S.cnt[p][0][0];
+    const int rlog = (finished || 4 * n > NCAP) ? 0 : qt_rep_log(4 * n, 4 * NCAP);
     if (finished) {
       for (int pos = tid; pos < NCAP; pos += BS) best[pos] = 0;
+      __syncthreads();
+    } else if (rlog > 0) {
+      for (int i = tid; i < ((4 * n) << rlog); i += BS) s_rep[i] = 0;
       __syncthreads();
     }
     // every key: the list position of its node in the new list (one table entry per quadrant of its old node); keys
@@ -382,8 +406,17 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
         } else {
           int slot = -1;
           if (valid && (e & 0x8000u) && idx < (uint32_t)cap) slot = (int)idx * 4 + qt_quadrant(keyv[u], S.mid[1 - p][idx]);
-          qt_count(&S.cnt[1 - p][0][0], slot);
+          if (rlog > 0) qt_count_rep(s_rep, slot, rlog);
+          else qt_count(&S.cnt[1 - p][0][0], slot);
         }
+      }
+    }
+    if (rlog > 0) {  // wave-uniform
+      __syncthreads();
+      for (int i = tid; i < 4 * n; i += BS) {
+        uint32_t v = 0;
+        for (int j = 0; j < (1 << rlog); ++j) v += s_rep[(i << rlog) + j];
+        if (v) S.cnt[1 - p][i >> 2][i & 3] += v;  // fresh children start at zero, nodes that were not split receive nothing
       }
     }
     p ^= 1;

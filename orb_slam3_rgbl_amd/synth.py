@@ -44,13 +44,17 @@ def _scene(rng, w, h, n_shapes):
 class Sequence:
     """A synthetic camera sequence: frame t is the scene shifted by (3t, t) px plus fresh sensor noise."""
 
-    def __init__(self, seq_id=0, w=KITTI_W, h=KITTI_H, n_frames=64, n_shapes=None):
+    def __init__(self, seq_id=0, w=KITTI_W, h=KITTI_H, n_frames=64, n_shapes=None, constant_density=False):
         self.w, self.h, self.seq_id = w, h, seq_id
         self.margin_x, self.margin_y = 3 * n_frames + 8, n_frames + 8
         rng = np.random.default_rng(0xC0FFEE + 7919 * seq_id)
         if n_shapes is None:
-            # ~1200 shapes at KITTI size give 8-10k FAST candidates on level 0, the density SURVEY.md 8(d) targets
-            n_shapes = int(round(1200 * (w * h) / float(KITTI_W * KITTI_H)))
+            # ~1200 shapes per KITTI-size FRAME give 8-10k FAST candidates on level 0, the density SURVEY.md 8(d) targets.
+            # constant_density: the count follows the area of the scene the frames are cut from (a long sequence needs a
+            # scene several frames wide); without it the count follows the frame, i.e. long sequences get sparser frames
+            # (what the fixtures of the parity tests were generated with).
+            area = (w + self.margin_x) * (h + self.margin_y) if constant_density else w * h
+            n_shapes = int(round(1200 * area / float(KITTI_W * KITTI_H)))
         self.scene = _scene(rng, w + self.margin_x, h + self.margin_y, n_shapes)
 
     def frame(self, t):

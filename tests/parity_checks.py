@@ -54,6 +54,28 @@ def check_extractor(lib, w, h, nfeatures, frames=(0,), ini=12, mn=7, nlevels=8, 
     return total
 
 
+def check_extractor_empty_root(lib, w=600, h=160, nfeatures=400):
+    """A wide image (round(w / h) = 4 quad-tree roots) whose middle has no corners at all: the reference erases the empty root
+    nodes (ORBextractor.cc:597-606), the nodes behind them move up in the list."""
+    ex = F.ORBextractor(nfeatures, 1.2, 4, 20, 7, w, h, lib=lib)
+    orc = O.Extractor(nfeatures, 1.2, 4, 20, 7)
+    img = synth.Sequence(31, w, h, n_frames=1).frame(0).copy()
+    img[:, int(0.28 * w):int(0.72 * w)] = 90   # roots 1 and 2 of 4 see a constant image
+    kps, desc, mono = ex(img)
+    okps, odesc, omono = orc(img)
+    assert len(okps) > 50
+    assert_keypoints_equal(kps, okps, "empty root")
+    assert np.array_equal(desc, odesc) and mono == omono
+    left = img.copy()
+    left[:, :int(0.55 * w)] = 90               # the first roots empty, the last ones not
+    kps, desc, mono = ex(left)
+    okps, odesc, omono = orc(left)
+    assert len(okps) > 20
+    assert_keypoints_equal(kps, okps, "empty leading roots")
+    assert np.array_equal(desc, odesc) and mono == omono
+    ex.close()
+
+
 def check_extractor_batch(lib, w, h, nfeatures, batch, ini=12, mn=7, seq=1):
     """The batched entry point must give, frame by frame, what the single-frame entry point gives."""
     ex = F.ORBextractor(nfeatures, 1.2, 8, ini, mn, w, h, max_batch=batch, lib=lib)

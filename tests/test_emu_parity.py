@@ -107,6 +107,10 @@ def test_extractor_quadtree_kernel_variants(emu_lib, ncap):
         os.environ.pop("RGBL_OCTREE_NCAP", None)
 
 
+def test_extractor_quadtree_empty_root_nodes(emu_lib):
+    pc.check_extractor_empty_root(emu_lib)
+
+
 def test_extractor_quadtree_gathers_cells_in_chunks(emu_lib):
     # more detection cells (57 x 85) than the prefix array of the small instantiation holds (4096): chunked gather
     pc.check_extractor(emu_lib, 3000, 2020, 300, frames=(0,), nlevels=1, seq=21)

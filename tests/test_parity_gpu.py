@@ -51,6 +51,7 @@ def test_extractor_other_shapes(gpu_lib):
 
 def test_extractor_edge_cases(gpu_lib):
     pc.check_extractor_edge_cases(gpu_lib)
+    pc.check_extractor_empty_root(gpu_lib)
 
 
 def test_extractor_4k_cfg5(gpu_lib):

@@ -12,6 +12,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c -d $OUT/prof_bench_$c -o p -- python $REPO/bench.py --serial --no-cpu-baseline --no-extras --steps $STEPS --warmup $WARM > $OUT/prof_bench_$c.log 2>&1
 done
 cd $REPO
-python profiles/summarize_rocprof.py traffic $OUT $STEPS $WARM 512 $OUT/r02_pmc_traffic.json
+BATCH=$(python -c "import bench; print(bench.WORKLOADS['kitti'][4])")
+python profiles/summarize_rocprof.py traffic $OUT $STEPS $WARM $BATCH $OUT/r02_pmc_traffic.json
 for c in FETCH_SIZE WRITE_SIZE; do rm -rf $OUT/prof_calib_$c $OUT/prof_bench_$c; done
 cat $OUT/r02_pmc_traffic.json | head -60

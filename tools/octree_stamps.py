@@ -6,7 +6,7 @@ from orb_slam3_rgbl_amd import _lib as L, frontend as F, synth
 lib=L.load()
 W,H,NF,B=(int(v) for v in (sys.argv[1:5] if len(sys.argv)>4 else (1241,376,2000,16)))
 ex=F.ORBextractor(NF,1.2,8,12,7,W,H,max_batch=B,lib=lib)
-s=synth.Sequence(0,W,H,n_frames=B)
+s=synth.Sequence(0,W,H,n_frames=B,constant_density=True)
 imgs=np.stack([s.frame(i) for i in range(B)])
 for it in range(2): res=ex.extract_batch(imgs)
 st=np.zeros(B*8*16,np.uint64)
