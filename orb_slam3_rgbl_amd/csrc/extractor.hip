@@ -619,12 +619,13 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
 
   // cells of at most kCellSmall px (every level of the usual image sizes) take the small-LDS instantiation
   // a cell is a chain of five short phases: 16 workgroups of two waves per CU overlap better than 8 of four (1.46 -> 1.3x ms per 512 frames)
-  const int fast_bs = e->max_cell <= kCellSmall ? ((getenv("RGBL_FAST_BS") && atoi(getenv("RGBL_FAST_BS")) == 256) ? 256 : 128) : 256;
-  auto fast = e->max_cell <= kCellSmall ? (fast_bs == 128 ? k_fast_cells<kCellSmall, 128, true> : k_fast_cells<kCellSmall, 256>) : k_fast_cells<kCellMax, 256>;
+  int fast_bs = e->max_cell <= kCellSmall ? (getenv("RGBL_FAST_BS") ? atoi(getenv("RGBL_FAST_BS")) : 128) : 256;  // dense input: 64 / 128 / 256 work-items 2.22 / 1.85 / 2.25 ms
+  if (fast_bs != 64 && fast_bs != 128 && fast_bs != 256) fast_bs = 128;
+  auto fast = e->max_cell <= kCellSmall ? (fast_bs == 128 ? k_fast_cells<kCellSmall, 128, true> : (fast_bs == 64 ? k_fast_cells<kCellSmall, 64, true> : k_fast_cells<kCellSmall, 256>)) : k_fast_cells<kCellMax, 256>;
   auto launch_fast = [&](hipStream_t st, int cell_begin, int cell_end) {
     if (cell_end <= cell_begin) return;
     e->timer.begin("k_fast_cells", st);
-    hipLaunchKernelGGL(fast, xcd_grid(e->xcd_map, cell_end - cell_begin, batch), dim3(fast_bs == 128 ? 128 : 256), 0, st, e->d_cells, d_imgs, stride, frame_stride,
+    hipLaunchKernelGGL(fast, xcd_grid(e->xcd_map, cell_end - cell_begin, batch), dim3(fast_bs), 0, st, e->d_cells, d_imgs, stride, frame_stride,
                        e->d_pyr, e->pyr_frame, e->cfg.ini_th_fast, e->cfg.min_th_fast, e->d_cellcnt, (size_t)e->cells_frame,
                        e->d_slots, e->slots_frame, cell_begin);
     e->timer.end(st);

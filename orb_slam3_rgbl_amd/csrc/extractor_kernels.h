@@ -303,7 +303,6 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
   constexpr int kScoreP = CM + 4;  // score tile pitch (cell + 1-px zero frame), multiple of 4
   constexpr int kBitWords = (CM * CM + 63) / 64 * 2;  // bitmap words, an even number: the compaction reads them in pairs
   constexpr int kCornerCap = 512;                     // pixels with a score kept as a list for the NMS (all survivors are scanned beyond that)
-  static_assert(kBitWords <= BS, "one bitmap word per work-item");
   __shared__ uint32_t s_tile_w[(CM + 6) * kTileP / 4];
   uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile_w);
   __shared__ uint32_t s_score_w[(CM + 2) * kScoreP / 4];
@@ -352,7 +351,7 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
   }
   for (int i = tid; i < (sh + 2) * (kScoreP / 4); i += BS) s_score_w[i] = 0;
   if (tid == 0) { s_nsurv = 0; s_ncorner = 0; s_any_ini = 0; }
-  if (tid < kBitWords) { s_keep[tid] = 0; s_keep_ini[tid] = 0; }
+  for (int i = tid; i < kBitWords; i += BS) { s_keep[i] = 0; s_keep_ini[i] = 0; }
   __syncthreads();
 
   // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are listed.  (Four pixels per
