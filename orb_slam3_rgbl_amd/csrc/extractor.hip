@@ -103,6 +103,8 @@ struct rgbl_extractor {
   uint8_t* d_divided = nullptr;
   uint32_t* d_kpkey = nullptr;
   int* d_kpcount = nullptr;
+  uint32_t* d_levelcnt = nullptr;  // [B][L] candidates per level, counted by k_fast_cells' cells (dense candidate lists)
+  bool dense = false;              // k_fast_cells writes a level's candidates as one list (label-based quad-tree kernel, separate pixel kernels)
   int* d_err = nullptr;
   int32_t* d_stereo_sad = nullptr;  // ComputeStereoMatches scratch (grow-only)
   size_t stereo_sad_count = 0;
@@ -225,6 +227,8 @@ int build_geometry(rgbl_extractor* e) {
     }
     e->max_cell = std::max(e->max_cell, std::max(g.w_cell, g.h_cell));
     g.n_cells = g.n_cols * g.n_rows;
+    g.m_wcell = (0x100000u + (uint32_t)g.w_cell - 1u) / (uint32_t)g.w_cell;
+    g.m_hcell = (0x100000u + (uint32_t)g.h_cell - 1u) / (uint32_t)g.h_cell;
     g.cell_off = cell_off;
     cell_off += g.n_cells;
     g.cell_cap = ((g.w_cell + 1) / 2) * ((g.h_cell + 1) / 2);  // strict 3x3 NMS keeps at most one pixel per 2x2
@@ -594,6 +598,7 @@ int alloc_scratch(rgbl_extractor* e) {
   }
   RGBL_TRY(dev_alloc(e, &e->d_kpkey, B * (size_t)e->kp_frame));
   RGBL_TRY(dev_alloc(e, &e->d_kpcount, B * (size_t)e->L));
+  RGBL_TRY(dev_alloc(e, &e->d_levelcnt, B * (size_t)e->L));
   RGBL_TRY(dev_alloc(e, &e->d_err, 1));
   RGBL_TRY(dev_alloc(e, &e->d_dbg, B * (size_t)e->L * 16));
   RGBL_HIP(hipMemset(e->d_dbg, 0, B * (size_t)e->L * 16 * sizeof(unsigned long long)));
@@ -616,6 +621,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   hipStream_t s = e->stream;
   e->last_img0 = d_imgs; e->last_pitch0 = stride; e->last_frame0 = frame_stride; e->last_batch = batch;
   if (e->gate) RGBL_HIP(hipStreamWaitEvent(s, e->gate, 0));  // software pipelining across handles (rgbl_extractor_set_gate)
+  if (e->dense) RGBL_HIP(hipMemsetAsync(e->d_levelcnt, 0, sizeof(uint32_t) * (size_t)batch * L, s));  // before ev_start: both streams see it
 
   // cells of at most kCellSmall px (every level of the usual image sizes) take the small-LDS instantiation
   // a cell is a chain of five short phases: 16 workgroups of two waves per CU overlap better than 8 of four (1.46 -> 1.3x ms per 512 frames)
@@ -627,7 +633,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
     e->timer.begin("k_fast_cells", st);
     hipLaunchKernelGGL(fast, xcd_grid(e->xcd_map, cell_end - cell_begin, batch), dim3(fast_bs), 0, st, e->d_cells, d_imgs, stride, frame_stride,
                        e->d_pyr, e->pyr_frame, e->cfg.ini_th_fast, e->cfg.min_th_fast, e->d_cellcnt, (size_t)e->cells_frame,
-                       e->d_slots, e->slots_frame, cell_begin);
+                       e->d_slots, e->slots_frame, cell_begin, e->d_geom, L, e->d_keys_a, e->keys_frame, e->dense ? e->d_levelcnt : nullptr);
     e->timer.end(st);
   };
   auto launch_gauss = [&](hipStream_t st, int tile_begin, int tile_end) {
@@ -649,6 +655,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   ob.divided = e->d_divided; ob.nodes_frame = e->nodes_frame;
   ob.rootx = e->d_rootx;
   ob.kp_key = e->d_kpkey; ob.kp_count = e->d_kpcount; ob.kp_frame = (size_t)e->kp_frame;
+  ob.level_cnt = e->dense ? e->d_levelcnt : nullptr;
   ob.err = e->d_err;
   ob.dbg = getenv("RGBL_OCTREE_STAMPS") ? e->d_dbg : nullptr;
   // narrow workgroups leave room for more (level, frame) problems per CU; small batches, which cannot fill the chip anyway,
@@ -873,6 +880,8 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
     }
   }
   if (rc == RGBL_OK) rc = upload_tables(e);
+  // dense candidate lists need the label-based quad-tree kernel (order-free) and the per-cell FAST kernel (RGBL_DENSE=0: cell slots)
+  if (rc == RGBL_OK) e->dense = e->octree_ncap != 0 && !e->use_fused && !(getenv("RGBL_DENSE") && getenv("RGBL_DENSE")[0] == '0');
   if (rc == RGBL_OK) rc = alloc_scratch(e);
   if (rc == RGBL_OK && (hipStreamCreate(&e->own_stream) != hipSuccess || hipStreamCreate(&e->aux_stream) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming) != hipSuccess ||
@@ -1210,23 +1219,39 @@ int rgbl_extractor_get_candidates(rgbl_extractor* e, int frame, int level, rgbl_
   RGBL_HIP(hipSetDevice(e->device));
   RGBL_HIP(hipStreamSynchronize(e->stream));
   const LevelGeom& g = e->geom[level];
+  auto emit = [&](uint32_t key, int n) {
+    if (out && n < cap) {
+      rgbl_keypoint kp;
+      kp.x = (float)(key & 0xfff); kp.y = (float)((key >> 12) & 0xfff); kp.size = 7.f; kp.angle = -1.f;
+      kp.response = (float)(key >> 24); kp.octave = 0; kp.class_id = -1;
+      out[n] = kp;
+    }
+  };
+  int n = 0;
+  if (e->dense) {
+    // the level's list in the order the cells finished: back into the reference's order (cell after cell, row-major inside)
+    uint32_t C = 0;
+    RGBL_HIP(hipMemcpy(&C, e->d_levelcnt + (size_t)frame * e->L + level, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    C = std::min(C, g.key_cap);
+    std::vector<uint32_t> keys(C);
+    if (C) RGBL_HIP(hipMemcpy(keys.data(), e->d_keys_a + (size_t)frame * e->keys_frame + g.key_off, sizeof(uint32_t) * C, hipMemcpyDeviceToHost));
+    auto order = [&](uint32_t key) {
+      const uint32_t x = (key & 0xfff) - 3u, y = ((key >> 12) & 0xfff) - 3u;
+      const uint32_t col = x / (uint32_t)g.w_cell, row = y / (uint32_t)g.h_cell;
+      return ((unsigned long long)(row * (uint32_t)g.n_cols + col) << 14) | ((y - row * g.h_cell) << 7) | (x - col * g.w_cell);
+    };
+    std::sort(keys.begin(), keys.end(), [&](uint32_t a, uint32_t b) { return order(a) < order(b); });
+    for (uint32_t key : keys) emit(key, n++);
+  } else {
   std::vector<uint32_t> cnt(g.n_cells);
   RGBL_HIP(hipMemcpy(cnt.data(), e->d_cellcnt + (size_t)frame * e->cells_frame + g.cell_off, sizeof(uint32_t) * g.n_cells,
                      hipMemcpyDeviceToHost));
   std::vector<uint32_t> slots((size_t)g.n_cells * g.cell_cap);
   RGBL_HIP(hipMemcpy(slots.data(), e->d_slots + (size_t)frame * e->slots_frame + g.slot_off, sizeof(uint32_t) * slots.size(),
                      hipMemcpyDeviceToHost));
-  int n = 0;
   for (int c = 0; c < g.n_cells; ++c)
-    for (uint32_t k = 0; k < cnt[c]; ++k, ++n) {
-      if (out && n < cap) {
-        const uint32_t key = slots[(size_t)c * g.cell_cap + k];
-        rgbl_keypoint kp;
-        kp.x = (float)(key & 0xfff); kp.y = (float)((key >> 12) & 0xfff); kp.size = 7.f; kp.angle = -1.f;
-        kp.response = (float)(key >> 24); kp.octave = 0; kp.class_id = -1;
-        out[n] = kp;
-      }
-    }
+    for (uint32_t k = 0; k < cnt[c]; ++k, ++n) emit(slots[(size_t)c * g.cell_cap + k], n);
+  }
   *out_n = n;
   return RGBL_OK;
 }

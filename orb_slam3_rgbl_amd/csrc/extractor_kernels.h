@@ -38,6 +38,7 @@ struct LevelGeom {
   int n_ini;                  // number of root nodes
   int root_x[kMaxRoots + 1];  // root node x bounds
   int root_first[kMaxRoots + 1];  // [k], k >= 1: first x whose keys go to root k or beyond (vpIniNodes[kp.pt.x / hX]: float division)
+  uint32_t m_wcell, m_hcell;  // ceil(2^20 / w_cell), ceil(2^20 / h_cell): cell of a candidate from its coordinates
   uint32_t rootx_off;         // byte offset into the root lookup table (index by x relative to minBorder)
   uint32_t xtab_off, ytab_off;
   float scale;                // mvScaleFactor[level]
@@ -282,6 +283,15 @@ __device__ __forceinline__ LdsPair lds_pair(const uint8_t* p) { return *reinterp
 
 // grid = xcd_grid(cells per frame over all levels, B) (common.h), block = 256.  CM = compile-time bound of the scanned cell side: the
 // LDS tiles are sized by it, and LDS is what limits the workgroups per CU (6 at CM = 72; 17 at CM = 48, where 16 workgroups of 128 fill the 32 wave slots).
+// value of the wave's first lane, wave-uniform
+__device__ __forceinline__ int wave_first(int v) {
+#ifdef RGBL_EMU
+  return __shfl(v, 0);
+#else
+  return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
 struct FastCell {  // one detection cell of a frame, prepared by the host (upload_tables)
   uint16_t ini_x, ini_y;     // first pixel of its tile (cell + 3-px ring margin) in the level
   uint16_t kx0, ky0;         // key coordinates (relative to minBorder) of its first scanned pixel
@@ -298,7 +308,9 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
                                                     size_t frame0, const uint8_t* __restrict__ pyr,
                                                     size_t pyr_frame, int ini_th, int min_th,
                                                     uint32_t* __restrict__ cell_cnt, size_t cells_frame,
-                                                    uint32_t* __restrict__ slots, size_t slots_frame, int cell_begin) {
+                                                    uint32_t* __restrict__ slots, size_t slots_frame, int cell_begin,
+                                                    const LevelGeom* __restrict__ geom, int n_levels, uint32_t* __restrict__ dense_keys,
+                                                    size_t keys_frame, uint32_t* __restrict__ level_cnt) {
   constexpr int kTileP = CM + 8;   // LDS tile pitch (cell + 6 ring margin, padded)
   constexpr int kScoreP = CM + 4;  // score tile pitch (cell + 1-px zero frame), multiple of 4
   constexpr int kBitWords = (CM * CM + 63) / 64 * 2;  // bitmap words, an even number: the compaction reads them in pairs
@@ -436,7 +448,16 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
     }
     wave_sync();
     const uint32_t n_out = total < (uint32_t)C.cell_cap ? total : (uint32_t)C.cell_cap;  // cap is a proven bound
+    // Dense output (level_cnt != null): the cell reserves its range of the level's candidate list with one atomic; the
+    // list is then in whatever order the cells finish, which the quad-tree kernel does not care about (octree_labels.h:
+    // the reference's candidate order is a function of the coordinates).  Otherwise: the cell's own slots.
     uint32_t* out = slots + (size_t)f * slots_frame + C.slot_base;
+    if (level_cnt) {
+      uint32_t base = 0;
+      if (lane == 0 && n_out) base = atomicAdd(&level_cnt[(size_t)f * n_levels + C.l], n_out);
+      base = (uint32_t)wave_first((int)base);
+      out = dense_keys + (size_t)f * keys_frame + geom[C.l].key_off + base;
+    }
     for (uint32_t i = lane; i < n_out; i += 64) {
       const int p = s_list[i];
       const int y = RGBL_DIV_SW(p), x = p - RGBL_MUL_SW(y);
@@ -710,6 +731,7 @@ struct OctreeBufs {
   const uint8_t* rootx;
   uint32_t* kp_key; int* kp_count; size_t kp_frame;  // outputs: selected keys per level, counts [B][L]
   int* err;
+  const uint32_t* level_cnt;  // [B][L] candidates per level when k_fast_cells wrote them densely (keys_a, any cell order); null: cell slots
   unsigned long long* dbg;  // optional: 16 cycle-counter stamps per (frame, level) workgroup (diagnostics)
 };
 

@@ -14,6 +14,10 @@
 // counters, the label maps and the sort of the quota phase live in LDS (NCAP nodes); (c) is an atomic maximum over
 // (response, -candidate index).
 //
+// Input: normally one list per (level, frame) that k_fast_cells' cells appended to in whatever order they finished (the
+// reference's candidate order - cell after cell, row-major inside a cell - is a function of a key's coordinates and only
+// matters for (c)); with the fused per-level kernel or RGBL_DENSE=0 the cells' own slots, gathered here in that order.
+//
 // Launch: one workgroup of BS work-items per (level, frame), grid (levels, frames).
 #pragma once
 
@@ -27,7 +31,7 @@ struct alignas(16) QtStore {
                               // of that quadrant | 0x8000 when they are to be counted into their new node's quadrants
                               // (a child with more than one key); a node that was not split: its new position, four times
   uint32_t mid[2][NCAP];      // split point of a node's rectangle: x | y << 16
-  uint16_t todo[2][NCAP];     // expandable nodes in creation order (vSizeAndPointerToNode); at the end: best key per node
+  uint16_t todo[2][NCAP];     // expandable nodes in creation order (vSizeAndPointerToNode)
   uint16_t sval[NCAP];        // sorted expandable nodes (list positions)
 };
 
@@ -222,7 +226,8 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   const int rlog0 = qt_rep_log(4 * n_ini, 2 * NCAP);
   for (int i = tid; i < ((4 * n_ini) << rlog0); i += BS) s_rep0[i] = 0;
   uint32_t C = 0;
-  {
+  const bool dense = b.level_cnt != nullptr;  // k_fast_cells left the level's candidates as one list (any cell order)
+  if (!dense) {
     const uint32_t* ccnt = b.cell_cnt + (size_t)f * b.cells_frame + g.cell_off;
     const uint32_t* slots = b.slots + (size_t)f * b.slots_frame + g.slot_off;
     const int grp = tid / kGrp, gl = tid % kGrp;
@@ -279,6 +284,25 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
       }
       C += run;
     }
+  } else {
+    C = b.level_cnt[(size_t)f * n_levels + l];
+    if (C > g.key_cap) C = g.key_cap;
+    __syncthreads();  // the root nodes and the counter copies are set
+    for (uint32_t i0 = 0; i0 < C; i0 += BS * kQtBatch) {
+      uint32_t key[kQtBatch];
+#pragma unroll
+      for (int u = 0; u < kQtBatch; ++u) {
+        const uint32_t i = i0 + (uint32_t)(u * BS + tid);
+        key[u] = i < C ? keys[i] : 0xffffffffu;
+      }
+#pragma unroll
+      for (int u = 0; u < kQtBatch; ++u)
+        if (key[u] != 0xffffffffu) {
+          const int r = root_of(key[u]);
+          label[i0 + (uint32_t)(u * BS + tid)] = (uint16_t)r;
+          qt_count_rep(s_rep0, r * 4 + qt_quadrant(key[u], S.mid[0][r]), rlog0);
+        }
+    }
   }
   __syncthreads();
   if (tid < 4 * n_ini) {
@@ -314,9 +338,11 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   // ---- 2. rounds of splits: breadth-first (ORBextractor.cc:608-686), then - once another full round would overshoot
   //         the quota - the most populated nodes first, one at a time in the reference, up to the node that reaches
   //         the quota (ORBextractor.cc:689-753)
-  uint32_t* best = reinterpret_cast<uint32_t*>(&S.todo[0][0]);
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(&S.cnt[1][0][0]);
   int p = 0, m = 0;
   bool finished = (n == 0), careful = false, stamped = false;
+  const int w_cell = g.w_cell, h_cell = g.h_cell, n_cols = g.n_cols;
+  const uint32_t m_wcell = g.m_wcell, m_hcell = g.m_hcell;
   while (!finished) {
     const int prev = n;
     int P = n;
@@ -367,8 +393,12 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
     // copies of the new list's counters (in the old list's counters, which nobody reads any more) while it is short
     uint32_t* s_rep = &S.cnt[p][0][0];
     const int rlog = (finished || 4 * n > NCAP) ? 0 : qt_rep_log(4 * n, 4 * NCAP);
+    // the last round: per node the strongest key, on ties the first one of the reference's candidate list (cell after
+    // cell, row-major inside a cell): response << 56 | (2^28 - 1 - order) << 24 | coordinates, one LDS maximum per key
+    best = reinterpret_cast<unsigned long long*>(&S.cnt[1 - p][0][0]);
     if (finished) {
-      for (int pos = tid; pos < NCAP; pos += BS) best[pos] = 0;
+      __syncthreads();  // qt_rebuild's last writes into that buffer are done
+      for (int pos = tid; pos < NCAP; pos += BS) best[pos] = 0ull;
       __syncthreads();
     } else if (rlog > 0) {
       for (int i = tid; i < ((4 * n) << rlog); i += BS) s_rep[i] = 0;
@@ -402,7 +432,17 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
         if (valid && idx != oldv[u]) label[i] = (uint16_t)idx;
         if (finished) {
           // ---- 3. the strongest key of every node, the first one of the candidate list on ties (ORBextractor.cc:757-776)
-          if (valid && idx < (uint32_t)cap) atomicMax(&best[idx], ((uint32_t)key_s(keyv[u]) << 24) | (0xffffffu - i));
+          if (valid && idx < (uint32_t)cap) {
+            uint32_t order = i;  // cell slots gathered in the reference's order
+            if (dense) {
+              // FAST scans a cell from its pixel 3: cell = (coordinate - 3) / cell size (the scanned width never exceeds it)
+              const uint32_t x = (uint32_t)key_x(keyv[u]) - 3u, y = (uint32_t)key_y(keyv[u]) - 3u;
+              const uint32_t col = __umul24(x, m_wcell) >> 20, row = __umul24(y, m_hcell) >> 20;
+              order = ((row * (uint32_t)n_cols + col) << 14) | ((y - row * (uint32_t)h_cell) << 7) | (x - col * (uint32_t)w_cell);
+            }
+            atomicMax(&best[idx], ((unsigned long long)key_s(keyv[u]) << 56) | ((unsigned long long)(0xfffffffu - order) << 24) |
+                                      (unsigned long long)(keyv[u] & 0xffffffu));
+          }
         } else {
           int slot = -1;
           if (valid && (e & 0x8000u) && idx < (uint32_t)cap) slot = (int)idx * 4 + qt_quadrant(keyv[u], S.mid[1 - p][idx]);
@@ -429,8 +469,8 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   if (n > kcap) { if (tid == 0) atomicOr(b.err, 2); n = kcap; }
   if (n > cap) n = cap;
   for (int pos = tid; pos < n; pos += BS) {
-    const uint32_t v = best[pos];
-    out[pos] = v ? keys[0xffffffu - (v & 0xffffffu)] : 0u;
+    const unsigned long long v = best[pos];
+    out[pos] = (uint32_t)(v >> 56) << 24 | (uint32_t)(v & 0xffffffull);
   }
   if (tid == 0) b.kp_count[(size_t)f * n_levels + l] = n;
   RGBL_STAMP(5);

@@ -111,6 +111,17 @@ def test_extractor_quadtree_empty_root_nodes(emu_lib):
     pc.check_extractor_empty_root(emu_lib)
 
 
+def test_extractor_cell_slot_candidates(emu_lib):
+    # RGBL_DENSE=0: the FAST kernel keeps every cell's candidates in the cell's own slots and the quad-tree kernel gathers
+    # them (the layout of the fused per-level kernel and of configurations beyond 2048 quad-tree nodes)
+    os.environ["RGBL_DENSE"] = "0"
+    try:
+        pc.check_extractor(emu_lib, 520, 360, 1000, frames=(0, 1), seq=7, stages=True)
+        pc.check_extractor_empty_root(emu_lib)
+    finally:
+        os.environ.pop("RGBL_DENSE", None)
+
+
 def test_extractor_quadtree_gathers_cells_in_chunks(emu_lib):
     # more detection cells (57 x 85) than the prefix array of the small instantiation holds (4096): chunked gather
     pc.check_extractor(emu_lib, 3000, 2020, 300, frames=(0,), nlevels=1, seq=21)

@@ -1,3 +1,4 @@
+import os
 """Parity tests proper: the HIP path on a real MI355X, called through the C ABI, against the CPU oracle."""
 import numpy as np
 import pytest
@@ -52,6 +53,15 @@ def test_extractor_other_shapes(gpu_lib):
 def test_extractor_edge_cases(gpu_lib):
     pc.check_extractor_edge_cases(gpu_lib)
     pc.check_extractor_empty_root(gpu_lib)
+
+
+def test_extractor_cell_slot_candidates(gpu_lib):
+    os.environ["RGBL_DENSE"] = "0"
+    try:
+        pc.check_extractor(gpu_lib, 1241, 376, 2000, frames=(0,), seq=2, stages=True)
+        pc.check_extractor_empty_root(gpu_lib)
+    finally:
+        os.environ.pop("RGBL_DENSE", None)
 
 
 def test_extractor_4k_cfg5(gpu_lib):
