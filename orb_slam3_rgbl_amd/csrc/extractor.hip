@@ -598,7 +598,8 @@ int alloc_scratch(rgbl_extractor* e) {
   }
   RGBL_TRY(dev_alloc(e, &e->d_kpkey, B * (size_t)e->kp_frame));
   RGBL_TRY(dev_alloc(e, &e->d_kpcount, B * (size_t)e->L));
-  RGBL_TRY(dev_alloc(e, &e->d_levelcnt, B * (size_t)e->L));
+  RGBL_TRY(dev_alloc(e, &e->d_levelcnt, 2 * B * (size_t)e->L));  // counters | the last extraction's counts
+  RGBL_HIP(hipMemset(e->d_levelcnt, 0, 2 * B * (size_t)e->L * sizeof(uint32_t)));
   RGBL_TRY(dev_alloc(e, &e->d_err, 1));
   RGBL_TRY(dev_alloc(e, &e->d_dbg, B * (size_t)e->L * 16));
   RGBL_HIP(hipMemset(e->d_dbg, 0, B * (size_t)e->L * 16 * sizeof(unsigned long long)));
@@ -621,7 +622,6 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   hipStream_t s = e->stream;
   e->last_img0 = d_imgs; e->last_pitch0 = stride; e->last_frame0 = frame_stride; e->last_batch = batch;
   if (e->gate) RGBL_HIP(hipStreamWaitEvent(s, e->gate, 0));  // software pipelining across handles (rgbl_extractor_set_gate)
-  if (e->dense) RGBL_HIP(hipMemsetAsync(e->d_levelcnt, 0, sizeof(uint32_t) * (size_t)batch * L, s));  // before ev_start: both streams see it
 
   // cells of at most kCellSmall px (every level of the usual image sizes) take the small-LDS instantiation
   // a cell is a chain of five short phases: 16 workgroups of two waves per CU overlap better than 8 of four (1.46 -> 1.3x ms per 512 frames)
@@ -656,6 +656,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   ob.rootx = e->d_rootx;
   ob.kp_key = e->d_kpkey; ob.kp_count = e->d_kpcount; ob.kp_frame = (size_t)e->kp_frame;
   ob.level_cnt = e->dense ? e->d_levelcnt : nullptr;
+  ob.level_cnt_last = e->d_levelcnt + (size_t)e->cfg.max_batch * L;
   ob.err = e->d_err;
   ob.dbg = getenv("RGBL_OCTREE_STAMPS") ? e->d_dbg : nullptr;
   // narrow workgroups leave room for more (level, frame) problems per CU; small batches, which cannot fill the chip anyway,
@@ -822,6 +823,7 @@ int check_device_flags(rgbl_extractor* e) {
   RGBL_HIP(hipMemcpy(&flags, e->d_err, sizeof(int), hipMemcpyDeviceToHost));
   if (flags) {
     RGBL_HIP(hipMemset(e->d_err, 0, sizeof(int)));
+    RGBL_HIP(hipMemset(e->d_levelcnt, 0, sizeof(uint32_t) * (size_t)e->cfg.max_batch * e->L));  // whatever a failed extraction left behind
     if (flags & 3) { set_error("quad-tree scratch overflow (flags=%d)", flags); return RGBL_ERR_OVERFLOW; }
     set_error("more keypoints than the caller's capacity");
     return RGBL_ERR_CAPACITY;
@@ -1231,7 +1233,7 @@ int rgbl_extractor_get_candidates(rgbl_extractor* e, int frame, int level, rgbl_
   if (e->dense) {
     // the level's list in the order the cells finished: back into the reference's order (cell after cell, row-major inside)
     uint32_t C = 0;
-    RGBL_HIP(hipMemcpy(&C, e->d_levelcnt + (size_t)frame * e->L + level, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    RGBL_HIP(hipMemcpy(&C, e->d_levelcnt + ((size_t)e->cfg.max_batch + frame) * e->L + level, sizeof(uint32_t), hipMemcpyDeviceToHost));
     C = std::min(C, g.key_cap);
     std::vector<uint32_t> keys(C);
     if (C) RGBL_HIP(hipMemcpy(keys.data(), e->d_keys_a + (size_t)frame * e->keys_frame + g.key_off, sizeof(uint32_t) * C, hipMemcpyDeviceToHost));

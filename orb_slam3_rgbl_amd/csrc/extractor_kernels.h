@@ -731,7 +731,10 @@ struct OctreeBufs {
   const uint8_t* rootx;
   uint32_t* kp_key; int* kp_count; size_t kp_frame;  // outputs: selected keys per level, counts [B][L]
   int* err;
-  const uint32_t* level_cnt;  // [B][L] candidates per level when k_fast_cells wrote them densely (keys_a, any cell order); null: cell slots
+  uint32_t* level_cnt;        // [B][L] candidates per level when k_fast_cells wrote them densely (keys_a, any cell order); null: cell slots.
+                              // The quad-tree workgroup of a (frame, level) reads its counter, leaves it at zero for the next
+                              // extraction and keeps a copy in level_cnt_last (rgbl_extractor_get_candidates)
+  uint32_t* level_cnt_last;
   unsigned long long* dbg;  // optional: 16 cycle-counter stamps per (frame, level) workgroup (diagnostics)
 };
 

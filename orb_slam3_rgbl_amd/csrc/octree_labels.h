@@ -287,7 +287,8 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   } else {
     C = b.level_cnt[(size_t)f * n_levels + l];
     if (C > g.key_cap) C = g.key_cap;
-    __syncthreads();  // the root nodes and the counter copies are set
+    __syncthreads();  // the root nodes and the counter copies are set; everybody has read the counter
+    if (tid == 0) { b.level_cnt_last[(size_t)f * n_levels + l] = C; b.level_cnt[(size_t)f * n_levels + l] = 0; }
     for (uint32_t i0 = 0; i0 < C; i0 += BS * kQtBatch) {
       uint32_t key[kQtBatch];
 #pragma unroll
