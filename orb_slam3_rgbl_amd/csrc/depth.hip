@@ -348,7 +348,8 @@ struct rgbl_depth {
   float* d_ptdepth = nullptr;  // depth of every projected point (max_batch x max_points), for the raw-map-free path
   float* d_proc = nullptr;
   float* d_cloud = nullptr;
-  float *d_kp = nullptr, *d_kpun = nullptr, *d_depth = nullptr, *d_uright = nullptr;
+  float *d_kp = nullptr, *d_kpun = nullptr, *d_depth = nullptr, *d_uright = nullptr;  // one block: kp (2 K) | kpun (K) | depth (K) | uright (K)
+  float* h_kio = nullptr;      // page-locked mirror of that block: the keypoint arrays of the host entry points travel in one request each way
   std::vector<void*> allocs;
 };
 
@@ -560,10 +561,16 @@ int rgbl_depth_create(const rgbl_depth_cfg* cfg, int device, rgbl_depth** out) {
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_proc, B * e->map_stride);
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_cloud, (size_t)4 * cfg->max_points);
   if (rc == RGBL_OK) rc = dalloc(e, &e->d_ptdepth, B * (size_t)cfg->max_points);
-  if (rc == RGBL_OK) rc = dalloc(e, &e->d_kp, (size_t)2 * cfg->max_keypoints);
-  if (rc == RGBL_OK) rc = dalloc(e, &e->d_kpun, (size_t)cfg->max_keypoints);
-  if (rc == RGBL_OK) rc = dalloc(e, &e->d_depth, (size_t)cfg->max_keypoints);
-  if (rc == RGBL_OK) rc = dalloc(e, &e->d_uright, (size_t)cfg->max_keypoints);
+  if (rc == RGBL_OK) rc = dalloc(e, &e->d_kp, (size_t)5 * cfg->max_keypoints);
+  if (rc == RGBL_OK) {
+    e->d_kpun = e->d_kp + (size_t)2 * cfg->max_keypoints;
+    e->d_depth = e->d_kpun + cfg->max_keypoints;
+    e->d_uright = e->d_depth + cfg->max_keypoints;
+    if (hipHostMalloc(reinterpret_cast<void**>(&e->h_kio), sizeof(float) * 5 * (size_t)std::max(cfg->max_keypoints, 1), hipHostMallocDefault) != hipSuccess) {
+      e->h_kio = nullptr;
+      (void)hipGetLastError();
+    }
+  }
   if (const char* v = getenv("RGBL_XCD_MAP")) e->xcd_map = v[0] != '0';
   if (const char* v = getenv("RGBL_DEPTH_MAX_GEN")) e->max_gen = (uint32_t)std::min(std::max(atoi(v), 1), (int)e->max_gen);
   if (rc == RGBL_OK && hipStreamCreate(&e->own_stream) != hipSuccess) { set_error("hipStreamCreate failed"); rc = RGBL_ERR_HIP; }
@@ -579,6 +586,7 @@ void rgbl_depth_destroy(rgbl_depth* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   e->timer.collect();
   for (void* p : e->allocs) (void)hipFree(p);
+  if (e->h_kio) (void)hipHostFree(e->h_kio);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -600,13 +608,20 @@ static int depth_compute_host(rgbl_depth* e, const float* cloud, int n, int ld, 
     if (xyzi) RGBL_HIP(hipMemcpyAsync(e->d_cloud, cloud, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, s));
     else RGBL_HIP(hipMemcpy2DAsync(e->d_cloud, sizeof(float) * n, cloud, sizeof(float) * ld, sizeof(float) * n, 4, hipMemcpyHostToDevice, s));
   }
-  if (k > 0) {
+  const size_t K = (size_t)e->cfg.max_keypoints;
+  if (k > 0 && e->h_kio) {
+    memcpy(e->h_kio, kp_xy, sizeof(float) * 2 * k);
+    memcpy(e->h_kio + 2 * K, kpun_x, sizeof(float) * k);
+    RGBL_HIP(hipMemcpyAsync(e->d_kp, e->h_kio, sizeof(float) * (2 * K + k), hipMemcpyHostToDevice, s));
+  } else if (k > 0) {
     RGBL_HIP(hipMemcpyAsync(e->d_kp, kp_xy, sizeof(float) * 2 * k, hipMemcpyHostToDevice, s));
     RGBL_HIP(hipMemcpyAsync(e->d_kpun, kpun_x, sizeof(float) * k, hipMemcpyHostToDevice, s));
   }
   RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi, out_raw != nullptr));
   RGBL_TRY(enqueue_keypoints(e, 1, w, h, e->d_kp, 2, 0, e->d_kpun, 1, 0, nullptr, k, k, e->d_depth, e->d_uright, 0));
-  if (k > 0) {
+  if (k > 0 && e->h_kio) {
+    RGBL_HIP(hipMemcpyAsync(e->h_kio + 3 * K, e->d_depth, sizeof(float) * (K + k), hipMemcpyDeviceToHost, s));
+  } else if (k > 0) {
     RGBL_HIP(hipMemcpyAsync(out_depth, e->d_depth, sizeof(float) * k, hipMemcpyDeviceToHost, s));
     RGBL_HIP(hipMemcpyAsync(out_uright, e->d_uright, sizeof(float) * k, hipMemcpyDeviceToHost, s));
   }
@@ -614,6 +629,10 @@ static int depth_compute_host(rgbl_depth* e, const float* cloud, int n, int ld, 
   if (out_processed && e->cfg.method != RGBL_UPS_NEAREST_NEIGHBOR_PIXEL)
     RGBL_HIP(hipMemcpyAsync(out_processed, e->d_proc, sizeof(float) * e->map_stride, hipMemcpyDeviceToHost, s));
   RGBL_HIP(hipStreamSynchronize(s));
+  if (k > 0 && e->h_kio) {
+    memcpy(out_depth, e->h_kio + 3 * K, sizeof(float) * k);
+    memcpy(out_uright, e->h_kio + 4 * K, sizeof(float) * k);
+  }
   e->timer.collect();
   return RGBL_OK;
 }

@@ -103,6 +103,8 @@ struct rgbl_extractor {
   uint8_t* d_divided = nullptr;
   uint32_t* d_kpkey = nullptr;
   int* d_kpcount = nullptr;
+  uint8_t* h_pinned = nullptr;      // page-locked result block of the host-pointer path: counts, flags, keypoints, descriptors of small batches
+  size_t h_pinned_bytes = 0;
   uint32_t* d_levelcnt = nullptr;  // [B][L] candidates per level, counted by k_fast_cells' cells (dense candidate lists)
   bool dense = false;              // k_fast_cells writes a level's candidates as one list (label-based quad-tree kernel, separate pixel kernels)
   int* d_err = nullptr;
@@ -611,6 +613,9 @@ int alloc_scratch(rgbl_extractor* e) {
   RGBL_TRY(dev_alloc(e, &e->d_tmp_desc, B * (size_t)e->out_cap * 32));
   RGBL_TRY(dev_alloc(e, &e->d_out_n, B));
   RGBL_TRY(dev_alloc(e, &e->d_out_mono, B));
+  // results of up to 4 frames per call come back through one page-locked block (run_staged)
+  e->h_pinned_bytes = 256 + 2 * sizeof(int32_t) * B + std::min<size_t>(B, 4) * (size_t)e->out_cap * (sizeof(rgbl_keypoint) + 32);
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->h_pinned), e->h_pinned_bytes, hipHostMallocDefault) != hipSuccess) { e->h_pinned = nullptr; e->h_pinned_bytes = 0; (void)hipGetLastError(); }
   return RGBL_OK;
 }
 
@@ -915,6 +920,7 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
   if (e->ev_pyr) (void)hipEventDestroy(e->ev_pyr);
   if (e->ev_blur) (void)hipEventDestroy(e->ev_blur);
+  if (e->h_pinned) (void)hipHostFree(e->h_pinned);
   if (e->ev_start) (void)hipEventDestroy(e->ev_start);
   if (e->ev_fast0) (void)hipEventDestroy(e->ev_fast0);
   if (e->ev_pixels) (void)hipEventDestroy(e->ev_pixels);
@@ -1000,11 +1006,43 @@ static int enqueue_extract_staged(rgbl_extractor* e, int batch, int dev_stride, 
                          e->d_out_mono);
 }
 
-// the frames already sit in e->d_img (row stride dev_stride): extraction, then the results back to the host
+// the frames already sit in e->d_img (row stride dev_stride): extraction, then the results back to the host.
+// Small batches (one frame per call above all): counts, error flags, keypoints and descriptors travel into ONE page-locked
+// block behind the kernels and the call synchronises ONCE - three blocking round trips (counts, the error flag, the
+// arrays) and copies into pageable memory were a third of a single frame's extraction latency.
 static int run_staged(rgbl_extractor* e, int batch, int dev_stride, int lap0, int lap1, rgbl_keypoint* out_kp,
                       uint8_t* out_desc, int cap, int* out_n, int* out_mono) {
   hipStream_t s = e->stream;
   RGBL_TRY(enqueue_extract_staged(e, batch, dev_stride, lap0, lap1));
+  const size_t kp_bytes = (size_t)batch * e->out_cap * sizeof(rgbl_keypoint), desc_bytes = (size_t)batch * e->out_cap * 32;
+  const size_t head = 256 + 2 * sizeof(int32_t) * (size_t)e->cfg.max_batch;
+  const bool one_trip = e->h_pinned && head + kp_bytes + desc_bytes <= e->h_pinned_bytes;
+  if (one_trip) {
+    int32_t* p_err = reinterpret_cast<int32_t*>(e->h_pinned);
+    int32_t* p_n = reinterpret_cast<int32_t*>(e->h_pinned + 256);
+    int32_t* p_mono = p_n + e->cfg.max_batch;
+    uint8_t* p_kp = e->h_pinned + head;
+    uint8_t* p_desc = p_kp + kp_bytes;
+    RGBL_HIP(hipMemcpyAsync(p_err, e->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipMemcpyAsync(p_n, e->d_out_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipMemcpyAsync(p_mono, e->d_out_mono, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipMemcpyAsync(p_kp, e->d_out_kp, kp_bytes, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipMemcpyAsync(p_desc, e->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipStreamSynchronize(s));
+    e->timer.collect();
+    if (*p_err) RGBL_TRY(check_device_flags(e));  // resets the flag and names the error
+    int rc = RGBL_OK;
+    for (int b = 0; b < batch; ++b) {
+      const int n = p_n[b];
+      out_n[b] = n; out_mono[b] = p_mono[b];
+      const int ncopy = std::min(n, cap);
+      if (n > cap) { set_error("frame %d has %d keypoints, capacity %d", b, n, cap); rc = RGBL_ERR_CAPACITY; }
+      if (n > cap && lap1 >= 19) continue;  // a truncated lapping layout would be meaningless
+      memcpy(out_kp + (size_t)b * cap, p_kp + (size_t)b * e->out_cap * sizeof(rgbl_keypoint), sizeof(rgbl_keypoint) * ncopy);
+      memcpy(out_desc + (size_t)b * cap * 32, p_desc + (size_t)b * e->out_cap * 32, (size_t)ncopy * 32);
+    }
+    return rc;
+  }
   RGBL_HIP(hipMemcpyAsync(out_n, e->d_out_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
   RGBL_HIP(hipMemcpyAsync(out_mono, e->d_out_mono, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
   RGBL_HIP(hipStreamSynchronize(s));

@@ -1061,6 +1061,8 @@ struct rgbl_matcher {
   KernelTimer timer;
   uint8_t* d_buf = nullptr;  // grow-only staging arena for the host entry points
   size_t buf_size = 0;
+  uint8_t* h_pin = nullptr;  // grow-only page-locked mirror of the brute-force scan's inputs / outputs (rgbl_hamming_bf)
+  size_t pin_size = 0;
 };
 
 namespace {
@@ -1120,6 +1122,7 @@ void rgbl_matcher_destroy(rgbl_matcher* m) {
   (void)hipStreamSynchronize(m->stream);
   m->timer.collect();
   if (m->d_buf) (void)hipFree(m->d_buf);
+  if (m->h_pin) (void)hipHostFree(m->h_pin);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   delete m;
 }
@@ -1260,9 +1263,27 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   int32_t* d_sd = A.take<int32_t>(na);
   hipStream_t s = m->stream;
   const int32_t counts[2] = {na, nb};
-  RGBL_HIP(hipMemcpyAsync(d_desc, desc_a, (size_t)na * 32, hipMemcpyHostToDevice, s));
-  if (nb > 0) RGBL_HIP(hipMemcpyAsync(d_desc + (size_t)cap * 32, desc_b, (size_t)nb * 32, hipMemcpyHostToDevice, s));
-  RGBL_HIP(hipMemcpyAsync(d_n, counts, sizeof(counts), hipMemcpyHostToDevice, s));
+  // Both descriptor sets and the counts are mirrored in one page-locked block laid out like the arena, so that they go up
+  // with ONE request and the three result arrays come back with one (small scans - a frame against a frame - are all
+  // latency: seven requests from / to pageable memory around a 40 us kernel).  Sets above 1 MB keep the direct copies.
+  const size_t in_bytes = (size_t)(reinterpret_cast<uint8_t*>(d_n) - d_desc) + sizeof(counts);
+  const size_t out_bytes = (size_t)(reinterpret_cast<uint8_t*>(d_sd + na) - reinterpret_cast<uint8_t*>(d_bi));
+  bool pinned = in_bytes + out_bytes <= ((size_t)1 << 20);
+  if (pinned && m->pin_size < in_bytes + out_bytes) {
+    if (m->h_pin) { (void)hipHostFree(m->h_pin); m->h_pin = nullptr; m->pin_size = 0; }
+    if (hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), (size_t)1 << 20, hipHostMallocDefault) == hipSuccess) m->pin_size = (size_t)1 << 20;
+    else { (void)hipGetLastError(); pinned = false; }
+  }
+  if (pinned) {
+    memcpy(m->h_pin, desc_a, (size_t)na * 32);
+    if (nb > 0) memcpy(m->h_pin + (size_t)cap * 32, desc_b, (size_t)nb * 32);
+    memcpy(m->h_pin + (reinterpret_cast<uint8_t*>(d_n) - d_desc), counts, sizeof(counts));
+    RGBL_HIP(hipMemcpyAsync(d_desc, m->h_pin, in_bytes, hipMemcpyHostToDevice, s));
+  } else {
+    RGBL_HIP(hipMemcpyAsync(d_desc, desc_a, (size_t)na * 32, hipMemcpyHostToDevice, s));
+    if (nb > 0) RGBL_HIP(hipMemcpyAsync(d_desc + (size_t)cap * 32, desc_b, (size_t)nb * 32, hipMemcpyHostToDevice, s));
+    RGBL_HIP(hipMemcpyAsync(d_n, counts, sizeof(counts), hipMemcpyHostToDevice, s));
+  }
   // pair_a/pair_b == NULL selects the fixed pair (frame 0 -> frame 1)
   if (bf_on_matrix_cores()) {
     m->timer.begin("k_hamming_mfma", s);
@@ -1275,10 +1296,19 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   }
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
-  RGBL_HIP(hipMemcpyAsync(best_idx, d_bi, sizeof(int32_t) * na, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipMemcpyAsync(best_dist, d_bd, sizeof(int32_t) * na, hipMemcpyDeviceToHost, s));
-  if (second_dist) RGBL_HIP(hipMemcpyAsync(second_dist, d_sd, sizeof(int32_t) * na, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipStreamSynchronize(s));
+  if (pinned) {
+    uint8_t* h_out = m->h_pin + in_bytes;
+    RGBL_HIP(hipMemcpyAsync(h_out, d_bi, out_bytes, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipStreamSynchronize(s));
+    memcpy(best_idx, h_out, sizeof(int32_t) * na);
+    memcpy(best_dist, h_out + (reinterpret_cast<uint8_t*>(d_bd) - reinterpret_cast<uint8_t*>(d_bi)), sizeof(int32_t) * na);
+    if (second_dist) memcpy(second_dist, h_out + (reinterpret_cast<uint8_t*>(d_sd) - reinterpret_cast<uint8_t*>(d_bi)), sizeof(int32_t) * na);
+  } else {
+    RGBL_HIP(hipMemcpyAsync(best_idx, d_bi, sizeof(int32_t) * na, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipMemcpyAsync(best_dist, d_bd, sizeof(int32_t) * na, hipMemcpyDeviceToHost, s));
+    if (second_dist) RGBL_HIP(hipMemcpyAsync(second_dist, d_sd, sizeof(int32_t) * na, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipStreamSynchronize(s));
+  }
   m->timer.collect();
   return RGBL_OK;
 }
