@@ -107,6 +107,7 @@ struct rgbl_extractor {
   size_t h_pinned_bytes = 0;
   uint32_t* d_levelcnt = nullptr;  // [B][L] candidates per level, counted by k_fast_cells' cells (dense candidate lists)
   bool dense = false;              // k_fast_cells writes a level's candidates as one list (label-based quad-tree kernel, separate pixel kernels)
+  bool dense_dirty = false;        // an enqueue failed between the FAST and the quad-tree launches: the counters may hold leftovers
   int* d_err = nullptr;
   int32_t* d_stereo_sad = nullptr;  // ComputeStereoMatches scratch (grow-only)
   size_t stereo_sad_count = 0;
@@ -627,6 +628,8 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   hipStream_t s = e->stream;
   e->last_img0 = d_imgs; e->last_pitch0 = stride; e->last_frame0 = frame_stride; e->last_batch = batch;
   if (e->gate) RGBL_HIP(hipStreamWaitEvent(s, e->gate, 0));  // software pipelining across handles (rgbl_extractor_set_gate)
+  if (e->dense && e->dense_dirty) RGBL_HIP(hipMemsetAsync(e->d_levelcnt, 0, sizeof(uint32_t) * (size_t)e->cfg.max_batch * L, s));
+  e->dense_dirty = e->dense;  // cleared at the end of a complete enqueue: the quad-tree workgroups leave the counters at zero
 
   // cells of at most kCellSmall px (every level of the usual image sizes) take the small-LDS instantiation
   // a cell is a chain of five short phases: 16 workgroups of two waves per CU overlap better than 8 of four (1.46 -> 1.3x ms per 512 frames)
@@ -820,6 +823,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
     e->timer.end(s);
   }
   RGBL_HIP(hipGetLastError());
+  e->dense_dirty = false;
   return RGBL_OK;
 }
 
