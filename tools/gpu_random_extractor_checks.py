@@ -1,0 +1,27 @@
+"""Randomised GPU-vs-oracle extractor checks over image sizes / feature counts / level counts (bit-exact keypoints and
+descriptors, candidate lists per level).  Usage (on an MI355X): python tools/gpu_random_extractor_checks.py [seed] [cases]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch  # noqa: F401  (HIP runtime order)
+import parity_checks as pc
+from orb_slam3_rgbl_amd import _lib as L
+
+lib = L.load()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+done = 0
+while done < n_cases:
+    w, h = int(rng.integers(200, 1400)), int(rng.integers(120, 700))
+    if round((w - 32) / max(h - 32, 1)) < 1 or round((w - 32) / max(h - 32, 1)) > 16:
+        continue
+    nlevels = int(rng.integers(1, 9))
+    if min(w, h) / 1.2 ** (nlevels - 1) < 80:
+        continue
+    nf = int(rng.choice([50, 300, 1000, 2000, 3500, 6000]))
+    ini = int(rng.choice([12, 20]))
+    total = pc.check_extractor(lib, w, h, nf, frames=(0,), ini=ini, mn=7, nlevels=nlevels, seq=int(rng.integers(0, 1000)), stages=True)
+    print("ok %4dx%-4d levels %d nfeatures %5d ini %2d -> %d keypoints" % (w, h, nlevels, nf, ini, total), flush=True)
+    done += 1
+print("all", done, "cases bit-exact")
