@@ -109,9 +109,13 @@ __device__ __forceinline__ unsigned long long rgbl_clock() {
 #ifdef RGBL_EMU
 typedef emu_v4i v4i;    // matrix-core operand: 16 signed bytes per lane
 typedef emu_v16i v16i;  // matrix-core accumulator of a 32 x 32 tile: 16 x i32 per lane
+typedef emu_v8i v8i;    // operand of the block-scaled f8f6f4 matrix-core instructions (FP4: the first four dwords)
+typedef emu_v16f v16f;
 #else
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 #endif
 typedef float f32x2 __attribute__((vector_size(8)));  // two fp32 lanes of one packed VALU operation
 // integer dot products and byte shuffles of the VALU (v_dot4_u32_u8, v_dot2_u32_u16, v_alignbyte_b32, v_perm_b32)

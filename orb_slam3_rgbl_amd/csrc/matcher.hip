@@ -280,6 +280,167 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(const uint8_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same scan once more, on gfx950's block-scaled FP4 matrix-core instruction (v_mfma_scale_f32_32x32x64_f8f6f4 with
+// E2M1 operands: 64 bit positions per instruction, twice the i8 rate, half the operand bytes).  A descriptor bit becomes the
+// four-bit float +-4 (0x6 / 0xE): train bit a -> 4 (1 - 2a), query bit b -> -4 (1 - 2b); both operands carry the block scale
+// 2^4 (E8M0 byte 131), so a product is +-4096 and the 256-long sum is 8192 * hamming - 2^20 - the numbers of the i8 form,
+// exact in the f32 accumulator (all values are integers below 2^22).  The accumulator starts at 2^20 + row, the tracking
+// key comes out as a float and is tracked with v_med3_f32 / v_min_f32.  Dword w of a descriptor is the 32 values one lane
+// group feeds to step w / 2 (group w & 1); which bit lands in which nibble of the group does not matter as long as train
+// and query agree.  Everything else - query tiles in VGPRs, 64 train rows per double-buffered LDS stage, relative keys,
+// sweeps - as in k_hamming_mfma.  grid = (ceil(cap / 256), n_pairs), block = 256.
+constexpr int kBfRowBytesF4 = 144;  // 128 bytes of nibbles + 16: the 16-byte fragment reads of a wave spread over the banks
+constexpr float kBfIdleF = 1073741824.f;
+
+__device__ __forceinline__ v4i bf_expand_fp4(uint32_t x) {  // bit j of x -> nibble j: 0x6 (+4) or 0xE (-4)
+  v4i r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t t = (x >> (8 * i)) & 0xffu;
+    t = (t | (t << 12)) & 0x000f000fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    r[i] = (int)(0x66666666u | (t << 3));
+  }
+  return r;
+}
+__device__ __forceinline__ void bf_track_rel_f(float& best, float& second, float cur) {
+#ifdef RGBL_EMU
+  const float hi = best > cur ? best : cur;
+  second = second < hi ? second : hi;
+#else
+  asm("v_med3_f32 %0, %1, %2, %3" : "=v"(second) : "v"(best), "v"(cur), "v"(second));
+#endif
+  best = best < cur ? best : cur;
+}
+
+__global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_rows,
+                                                     int cap, const int32_t* __restrict__ pair_a,
+                                                     const int32_t* __restrict__ pair_b, int32_t* __restrict__ best_idx,
+                                                     int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_rows[2][kBfStageRows * kBfRowBytesF4];
+  __shared__ uint32_t s_lut[256];  // byte -> its eight nibbles: the train rows are expanded with four table reads per dword
+  const int p = xcd_frame();
+  const int fa = pair_a ? pair_a[p] : 0, fb = pair_b ? pair_b[p] : 1;
+  const int na = n_rows[fa], nb = n_rows[fb];
+  const int q_base = xcd_item() * kBfQueriesPerBlock;
+  if (q_base >= na) return;
+  const int tid = threadIdx.x, lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(wave_id());
+  const int col = lane & 31, half = lane >> 5;
+  const bool wave_has_queries = q_base + wave * 64 < na;
+  constexpr int kScale = 131;  // E8M0: 2^(131 - 127) = 16 per operand
+  s_lut[tid] = (uint32_t)bf_expand_fp4((uint32_t)tid)[0];  // the first barrier of the stage loop publishes it
+
+  // query fragments: two 32-column tiles, four K steps each
+  v8i bq[2][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int qi = q_base + wave * 64 + ct * 32 + col;
+    const uint4* src = reinterpret_cast<const uint4*>(desc + ((size_t)fa * cap + (qi < na ? qi : 0)) * 32);
+    const uint4 lo = src[0], hi = src[1];
+    const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const v4i e = bf_expand_fp4(~(half ? x[2 * s + 1] : x[2 * s]));
+      bq[ct][s] = v8i{e[0], e[1], e[2], e[3], 0, 0, 0, 0};
+    }
+  }
+  v16f c_init;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c_init[r] = (float)((1 << 20) + (r & 3) + 8 * (r >> 2) + 4 * half);
+
+  const uint32_t* __restrict__ train = reinterpret_cast<const uint32_t*>(desc + (size_t)fb * cap * 32);
+  const uint32_t kNone = (256u << 16) | 0xffffu;
+  uint32_t out_best[2] = {kNone, kNone}, out_second[2] = {kNone, kNone};
+
+  // stage s of the whole scan = train rows [64 s, 64 s + 64); work-item tid expands dwords tid and tid + 256 of it
+  const int n_stages = (nb + kBfStageRows - 1) / kBfStageRows;
+  auto load_stage = [&](int stage, uint32_t& x0, uint32_t& x1) {
+    const int d0 = stage * (kBfStageRows * 8) + tid, d1 = d0 + 256;
+    x0 = (d0 >> 3) < nb ? train[d0] : 0u;
+    x1 = (d1 >> 3) < nb ? train[d1] : 0u;
+  };
+  uint32_t nx0 = 0, nx1 = 0;
+  if (n_stages > 0) load_stage(0, nx0, nx1);
+  float best[2] = {kBfIdleF, kBfIdleF}, second[2] = {kBfIdleF, kBfIdleF};
+  int tiles_in_sweep = 0;
+  auto close_sweep = [&](int sweep_base) {
+    // relative keys -> (distance << 16 | absolute index), folded into the results of the earlier sweeps
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float off = (float)(32 * (tiles_in_sweep - 1));
+      const int kb = (int)(best[ct] + off), ks = (int)(second[ct] + off);  // exact: integers below 2^31 / idle 2^30 + small
+      const uint32_t wb = kb >= (257 << 13) ? kNone : ((uint32_t)(kb >> 13) << 16) | (uint32_t)(sweep_base + (kb & 8191));
+      const uint32_t ws = ks >= (257 << 13) ? kNone : ((uint32_t)(ks >> 13) << 16) | (uint32_t)(sweep_base + (ks & 8191));
+      bf_merge(out_best[ct], out_second[ct], wb, ws);
+      best[ct] = second[ct] = kBfIdleF;
+    }
+    tiles_in_sweep = 0;
+  };
+  for (int stage = 0; stage < n_stages; ++stage) {
+    uint8_t* buf = s_rows[stage & 1];
+    const uint32_t x0 = nx0, x1 = nx1;
+    if (stage + 1 < n_stages) load_stage(stage + 1, nx0, nx1);
+    {
+      uint8_t* r0 = buf + (tid >> 3) * kBfRowBytesF4 + (tid & 7) * 16;
+      if (stage == 0) {  // the table is not published yet
+        *reinterpret_cast<v4i*>(r0) = bf_expand_fp4(x0);
+        *reinterpret_cast<v4i*>(r0 + 32 * kBfRowBytesF4) = bf_expand_fp4(x1);
+      } else {
+        *reinterpret_cast<v4i*>(r0) = v4i{(int)s_lut[x0 & 0xff], (int)s_lut[(x0 >> 8) & 0xff], (int)s_lut[(x0 >> 16) & 0xff], (int)s_lut[x0 >> 24]};
+        *reinterpret_cast<v4i*>(r0 + 32 * kBfRowBytesF4) = v4i{(int)s_lut[x1 & 0xff], (int)s_lut[(x1 >> 8) & 0xff], (int)s_lut[(x1 >> 16) & 0xff], (int)s_lut[x1 >> 24]};
+      }
+    }
+    __syncthreads();
+    if (!wave_has_queries) continue;
+#pragma unroll 1
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row0 = stage * kBfStageRows + rt * 32;  // first train row of the tile
+      if (row0 >= nb) break;
+      const uint8_t* frag = buf + (rt * 32 + col) * kBfRowBytesF4 + half * 16;
+      v16f acc0 = c_init, acc1 = c_init;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const v4i a4 = *reinterpret_cast<const v4i*>(frag + s * 32);
+        const v8i a = v8i{a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};
+        acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[0][s], acc0, 4, 4, 0, kScale, 0, kScale);
+        acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[1][s], acc1, 4, 4, 0, kScale, 0, kScale);
+      }
+      best[0] -= 32.f; second[0] -= 32.f; best[1] -= 32.f; second[1] -= 32.f;
+      ++tiles_in_sweep;
+      if (row0 + 32 <= nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { bf_track_rel_f(best[0], second[0], acc0[r]); bf_track_rel_f(best[1], second[1], acc1[r]); }
+      } else {  // the last tile of the train set: rows beyond it never win
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool live = row0 + (r & 3) + 8 * (r >> 2) + 4 * half < nb;
+          bf_track_rel_f(best[0], second[0], live ? acc0[r] : kBfIdleF);
+          bf_track_rel_f(best[1], second[1], live ? acc1[r] : kBfIdleF);
+        }
+      }
+      if (((row0 + 32) & (kBfSweep - 1)) == 0) close_sweep(row0 + 32 - kBfSweep);
+    }
+  }
+  if (!wave_has_queries) return;
+  if (tiles_in_sweep > 0) close_sweep(((nb - 1) / kBfSweep) * kBfSweep);
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    // the two halves of the wave hold the same columns, interleaved groups of four rows
+    const uint32_t ob = __shfl_xor(out_best[ct], 32), os = __shfl_xor(out_second[ct], 32);
+    bf_merge(out_best[ct], out_second[ct], ob, os);
+    const int qi = q_base + wave * 64 + ct * 32 + col;
+    if (half == 0 && qi < na) {
+      const size_t o = (size_t)p * cap + qi;
+      best_idx[o] = out_best[ct] == kNone ? -1 : (int32_t)(out_best[ct] & 0xffffu);
+      best_dist[o] = (int32_t)(out_best[ct] >> 16);
+      if (second_dist) second_dist[o] = (int32_t)(out_second[ct] >> 16);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:329-403) for a batch of map points: among the
 // N descriptors that observe a point, the one with the least median Hamming distance to all N (its own 0 included; median =
 // sorted row[(size_t)(0.5 * (N - 1))]; strict '<' over the rows, so the first minimum wins).
@@ -1079,6 +1240,11 @@ inline bool bf_on_matrix_cores() {
   static const bool on = [] { const char* e = getenv("RGBL_BF_MFMA"); return !(e && e[0] == '0'); }();
   return on;
 }
+// RGBL_BF_MFMA=i8 keeps the i8 instruction (k_hamming_mfma); default: the block-scaled FP4 one (k_hamming_fp4)
+inline bool bf_on_fp4() {
+  static const bool on = [] { const char* e = getenv("RGBL_BF_MFMA"); return !(e && e[0] == 'i'); }();
+  return on;
+}
 struct Arena {
   uint8_t* base; size_t off = 0;
   template <class T> T* take(size_t count) {
@@ -1232,7 +1398,7 @@ int rgbl_hamming_bf_batch_device(rgbl_matcher* m, const uint8_t* d_desc, const i
   RGBL_HIP(hipSetDevice(m->device));
   if (bf_on_matrix_cores()) {
     m->timer.begin("k_hamming_mfma", m->stream);
-    hipLaunchKernelGGL(k_hamming_mfma, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
+    hipLaunchKernelGGL(bf_on_fp4() ? k_hamming_fp4 : k_hamming_mfma, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
                        d_desc, d_n, cap, d_pair_a, d_pair_b, d_best_idx, d_best_dist, d_second_dist);
   } else {
     m->timer.begin("k_hamming_bf", m->stream);
@@ -1287,7 +1453,7 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   // pair_a/pair_b == NULL selects the fixed pair (frame 0 -> frame 1)
   if (bf_on_matrix_cores()) {
     m->timer.begin("k_hamming_mfma", s);
-    hipLaunchKernelGGL(k_hamming_mfma, xcd_grid(false, (na + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, 1), dim3(256), 0, s, d_desc, d_n, cap,
+    hipLaunchKernelGGL(bf_on_fp4() ? k_hamming_fp4 : k_hamming_mfma, xcd_grid(false, (na + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, 1), dim3(256), 0, s, d_desc, d_n, cap,
                        (const int32_t*)nullptr, (const int32_t*)nullptr, d_bi, d_bd, d_sd);
   } else {
     m->timer.begin("k_hamming_bf", s);

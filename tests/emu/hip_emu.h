@@ -217,6 +217,42 @@ inline emu_v16i __builtin_amdgcn_mfma_i32_32x32x32_i8(emu_v4i a, emu_v4i b, emu_
   hipemu::rendezvous(blk->wbar[2 * w + 1], blk->wave_active[w]);
   return d;
 }
+// v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 (E2M1) operands (cbsz = blgp = 4): D = (A * 2^(scale_a - 127)) * (B * 2^(scale_b - 127)) + C on a
+// 32 x 32 tile with K = 64.  Lane l holds 32 four-bit values (16 bytes, the first four dwords of the operand) of row (A) /
+// column (B) l & 31, the K half chosen by l >> 5; the scale is byte 0 of the lane's scale operand (an E8M0 exponent, one
+// per 32-value block).  D as for the other 32 x 32 shapes.  Which k a nibble stands for inside its half is the same for A
+// and B, hence irrelevant for the sum.
+typedef int emu_v8i __attribute__((vector_size(32)));
+typedef float emu_v16f __attribute__((vector_size(64)));
+inline emu_v16f __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(emu_v8i a, emu_v8i b, emu_v16f c, int cbsz, int blgp, int, int scale_a, int, int scale_b) {
+  static const float kE2M1[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+  (void)cbsz; (void)blgp;  // FP4 only
+  hipemu::Block* blk = hipemu::cur_block();
+  const int w = hipemu::wave_id(), lane = hipemu::lane_id();
+  unsigned char* base = &blk->wide[(size_t)w * 64 * 32];
+  std::memcpy(base + lane * 32, &a, 16);
+  std::memcpy(base + lane * 32 + 16, &b, 16);
+  hipemu::rendezvous(blk->wbar[2 * w], blk->wave_active[w]);
+  const double sc = std::ldexp(1.0, (scale_a & 0xff) - 127) * std::ldexp(1.0, (scale_b & 0xff) - 127);
+  emu_v16f d = c;
+  const int col = lane & 31;
+  auto val = [&](const unsigned char* p, int j) {
+    const int code = (p[j >> 1] >> (4 * (j & 1))) & 0xf;
+    return (code & 8) ? -kE2M1[code & 7] : kE2M1[code & 7];
+  };
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    double acc = 0.0;
+    for (int g = 0; g < 2; ++g) {
+      const unsigned char* pa = base + (row + 32 * g) * 32;
+      const unsigned char* pb = base + (col + 32 * g) * 32 + 16;
+      for (int k = 0; k < 32; ++k) acc += (double)val(pa, k) * (double)val(pb, k);
+    }
+    d[r] = (float)((double)d[r] + acc * sc);  // exact here: small integers times powers of two
+  }
+  hipemu::rendezvous(blk->wbar[2 * w + 1], blk->wave_active[w]);
+  return d;
+}
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // wave-uniform by construction where it is used
 inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline int __mul24(int a, int b) {  // signed 24-bit operands
