@@ -311,7 +311,7 @@ __device__ __forceinline__ void bf_track_rel_f(float& best, float& second, float
 #else
   asm("v_med3_f32 %0, %1, %2, %3" : "=v"(second) : "v"(best), "v"(cur), "v"(second));
 #endif
-  best = best < cur ? best : cur;
+  best = fminf(best, cur);  // one v_min_f32 (a compare + select under strict floating-point rules otherwise); no NaNs here
 }
 
 __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_rows,
@@ -1397,7 +1397,7 @@ int rgbl_hamming_bf_batch_device(rgbl_matcher* m, const uint8_t* d_desc, const i
   if (n_pairs == 0) return RGBL_OK;
   RGBL_HIP(hipSetDevice(m->device));
   if (bf_on_matrix_cores()) {
-    m->timer.begin("k_hamming_mfma", m->stream);
+    m->timer.begin(bf_on_fp4() ? "k_hamming_fp4" : "k_hamming_mfma", m->stream);
     hipLaunchKernelGGL(bf_on_fp4() ? k_hamming_fp4 : k_hamming_mfma, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
                        d_desc, d_n, cap, d_pair_a, d_pair_b, d_best_idx, d_best_dist, d_second_dist);
   } else {
@@ -1452,7 +1452,7 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   }
   // pair_a/pair_b == NULL selects the fixed pair (frame 0 -> frame 1)
   if (bf_on_matrix_cores()) {
-    m->timer.begin("k_hamming_mfma", s);
+    m->timer.begin(bf_on_fp4() ? "k_hamming_fp4" : "k_hamming_mfma", s);
     hipLaunchKernelGGL(bf_on_fp4() ? k_hamming_fp4 : k_hamming_mfma, xcd_grid(false, (na + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, 1), dim3(256), 0, s, d_desc, d_n, cap,
                        (const int32_t*)nullptr, (const int32_t*)nullptr, d_bi, d_bd, d_sd);
   } else {
