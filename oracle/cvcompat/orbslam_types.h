@@ -104,6 +104,7 @@ class Frame {
   Sophus::SE3f mTcw, mTrl;
   FeatureGrid grid;
   static float mnMinX, mnMinY, mnMaxX, mnMaxY;  // static members in the reference as well (Frame.h)
+  static float mfGridElementWidthInv, mfGridElementHeightInv;
   // what Frame::ComputeStereoMatches (src/Frame.cc:901-1071) touches; its body is the reference's own lines, extracted at
   // build time (oracle/Makefile: _ref/frame_stereo_matches.inc) and compiled in ref_frame_glue.cpp
   std::vector<float> mvDepth, mvInvScaleFactors;
@@ -134,6 +135,8 @@ class KeyFrame {
   DBoW2::FeatureVector mFeatVec;
   Sophus::SE3f mTcw, mTwc;
   FeatureGrid grid;
+  int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;  // const members of the reference's KeyFrame (copies of the Frame statics)
+  float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
 
   Sophus::SE3f GetPose() { return mTcw; }
   Sophus::SE3f GetPoseInverse() { return mTwc; }

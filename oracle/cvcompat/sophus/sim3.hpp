@@ -73,30 +73,33 @@ struct Matrix3f {
 };
 
 struct Quaternionf {
-  float x, y, z, w;
-  Quaternionf() : x(0), y(0), z(0), w(1) {}
-  Quaternionf(float w_, float x_, float y_, float z_) : x(x_), y(y_), z(z_), w(w_) {}
-  Vector3f vec() const { return Vector3f(x, y, z); }
+  // coefficients behind accessor functions, as in Eigen (the shims read unit_quaternion().x() etc.)
+  float qx, qy, qz, qw;
+  Quaternionf() : qx(0), qy(0), qz(0), qw(1) {}
+  Quaternionf(float w_, float x_, float y_, float z_) : qx(x_), qy(y_), qz(z_), qw(w_) {}
+  float& x() { return qx; } float& y() { return qy; } float& z() { return qz; } float& w() { return qw; }
+  float x() const { return qx; } float y() const { return qy; } float z() const { return qz; } float w() const { return qw; }
+  Vector3f vec() const { return Vector3f(qx, qy, qz); }
   // QuaternionBase::_transformVector
   Vector3f operator*(const Vector3f& p) const {
     Vector3f uv = vec().cross(p);
     uv = uv + uv;
-    return p + w * uv + vec().cross(uv);
+    return p + qw * uv + vec().cross(uv);
   }
   // quaternion product (Eigen's internal::quat_product, scalar path)
   Quaternionf operator*(const Quaternionf& b) const {
-    return Quaternionf(w * b.w - x * b.x - y * b.y - z * b.z, w * b.x + x * b.w + y * b.z - z * b.y,
-                       w * b.y + y * b.w + z * b.x - x * b.z, w * b.z + z * b.w + x * b.y - y * b.x);
+    return Quaternionf(qw * b.qw - qx * b.qx - qy * b.qy - qz * b.qz, qw * b.qx + qx * b.qw + qy * b.qz - qz * b.qy,
+                       qw * b.qy + qy * b.qw + qz * b.qx - qx * b.qz, qw * b.qz + qz * b.qw + qx * b.qy - qy * b.qx);
   }
-  Quaternionf conjugate() const { return Quaternionf(w, -x, -y, -z); }
-  float squaredNorm() const { return x * x + y * y + z * z + w * w; }
-  void normalize() { const float n = sqrtf(squaredNorm()); x /= n; y /= n; z /= n; w /= n; }
+  Quaternionf conjugate() const { return Quaternionf(qw, -qx, -qy, -qz); }
+  float squaredNorm() const { return qx * qx + qy * qy + qz * qz + qw * qw; }
+  void normalize() { const float n = sqrtf(squaredNorm()); qx /= n; qy /= n; qz /= n; qw /= n; }
   // QuaternionBase::toRotationMatrix
   Matrix3f toRotationMatrix() const {
     Matrix3f r;
-    const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
-    const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
-                tzz = tz * z;
+    const float tx = 2.f * qx, ty = 2.f * qy, tz = 2.f * qz;
+    const float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy,
+                tzz = tz * qz;
     r(0, 0) = 1.f - (tyy + tzz); r(0, 1) = txy - twz; r(0, 2) = txz + twy;
     r(1, 0) = txy + twz; r(1, 1) = 1.f - (txx + tzz); r(1, 2) = tyz - twx;
     r(2, 0) = txz - twy; r(2, 1) = tyz + twx; r(2, 2) = 1.f - (txx + tyy);
@@ -108,9 +111,9 @@ struct Quaternionf {
     float t = a(0, 0) + a(1, 1) + a(2, 2);
     if (t > 0.f) {
       t = sqrtf(t + 1.f);
-      q.w = 0.5f * t;
+      q.qw = 0.5f * t;
       t = 0.5f / t;
-      q.x = (a(2, 1) - a(1, 2)) * t; q.y = (a(0, 2) - a(2, 0)) * t; q.z = (a(1, 0) - a(0, 1)) * t;
+      q.qx = (a(2, 1) - a(1, 2)) * t; q.qy = (a(0, 2) - a(2, 0)) * t; q.qz = (a(1, 0) - a(0, 1)) * t;
     } else {
       int i = 0;
       if (a(1, 1) > a(0, 0)) i = 1;
@@ -120,10 +123,10 @@ struct Quaternionf {
       float c[3];
       c[i] = 0.5f * t;
       t = 0.5f / t;
-      q.w = (a(k, j) - a(j, k)) * t;
+      q.qw = (a(k, j) - a(j, k)) * t;
       c[j] = (a(j, i) + a(i, j)) * t;
       c[k] = (a(k, i) + a(i, k)) * t;
-      q.x = c[0]; q.y = c[1]; q.z = c[2];
+      q.qx = c[0]; q.qy = c[1]; q.qz = c[2];
     }
     return q;
   }
@@ -156,7 +159,7 @@ template <> class SE3<float> {
     r.q_ = q_ * o.q_;
     // SO3 product: renormalise only when the squared norm drifted (Sophus so3.hpp operator*)
     const float sn = r.q_.squaredNorm();
-    if (sn != 1.f) { const float s = 2.f / (1.f + sn); r.q_.x *= s; r.q_.y *= s; r.q_.z *= s; r.q_.w *= s; }
+    if (sn != 1.f) { const float s = 2.f / (1.f + sn); r.q_.qx *= s; r.q_.qy *= s; r.q_.qz *= s; r.q_.qw *= s; }
     r.t_ = q_ * o.t_ + t_;
     return r;
   }

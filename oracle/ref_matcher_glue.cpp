@@ -10,6 +10,7 @@
 namespace ORB_SLAM3 {
 
 float Frame::mnMinX = 0, Frame::mnMinY = 0, Frame::mnMaxX = 0, Frame::mnMaxY = 0;
+float Frame::mfGridElementWidthInv = 0, Frame::mfGridElementHeightInv = 0;
 
 // Pinhole::epipolarConstrain: lines 107-129 of /root/reference/src/CameraModels/Pinhole.cpp, unmodified, extracted by the
 // Makefile into _ref/pinhole_epipolar.inc; `Pinhole` is the stand-in camera class here (Eigen / Sophus come from
