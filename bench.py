@@ -575,7 +575,9 @@ def main():
                        else "4K synthetic cfg5", "image": [w, h], "nfeatures": nfeatures, "levels": LEVELS,
                        "lidar_points": n_points, "frames_per_gpu_per_step": B, "keypoints_per_frame": k_mean,
                        "match": "Hamming brute force, frame i vs i+1", "upsampling": "InverseDilation Diamond 5",
-                       "inputs": "resident in HBM", "parallelism": "frames/sequences sharded, %d rank(s)" % world,
+                       "inputs": "resident in HBM",
+                       "frames": "synth.Sequence, %s" % ("shape count of ONE frame for the whole scene (RGBL_BENCH_SPARSE: the pre-correction input)" if os.environ.get("RGBL_BENCH_SPARSE") else "constant corner density: 1200 shapes per frame area, ~8.6 k FAST candidates on level 0"),
+                       "parallelism": "frames/sequences sharded, %d rank(s)" % world,
                        "gather": (args.gather if world > 1 else "none")},
             "parity_spot_check": spot,
             "roofline": roofline,
