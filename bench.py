@@ -59,7 +59,6 @@ def algorithmic_bytes(kernel, w, h, n_points, k_per_frame):
         "k_hamming_bf": 32 * 2 * k_per_frame + 8 * k_per_frame,
         "k_hamming_mfma": 32 * 2 * k_per_frame + 8 * k_per_frame,
         "k_hamming_fp4": 32 * 2 * k_per_frame + 8 * k_per_frame,
-        "k_level_fused": 5 * sp - px[0] - px[-1],                 # the three pixel passes together (SURVEY 8(d) B_ext without the 60 K)
     }
     return table.get(kernel)
 

@@ -22,7 +22,6 @@
 #include "brief_pattern.h"
 #include "extractor_kernels.h"
 #include "octree_labels.h"
-#include "fused_level.h"
 
 namespace rgbl {
 
@@ -53,7 +52,7 @@ struct rgbl_extractor {
   hipStream_t stream = nullptr, own_stream = nullptr;
   hipStream_t aux_stream = nullptr;  // the Gaussian working images only depend on the pyramid: they overlap FAST + quad-tree
   hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_fast0 = nullptr;
-  hipEvent_t ev_pixels = nullptr;  // recorded behind the last pixel kernel (FAST / fused level) of an extraction
+  hipEvent_t ev_pixels = nullptr;  // recorded behind the last pixel kernel (FAST) of an extraction
   hipEvent_t gate = nullptr;       // not owned: the extraction starts only after this event (another handle's ev_pixels)
   KernelTimer timer;
   // hipGraph of the host-pointer path (all device pointers of that path are the handle's own buffers, so one captured
@@ -67,16 +66,7 @@ struct rgbl_extractor {
   int octree_wg = 0;  // 0 = choose per launch; RGBL_OCTREE_WG=256|512 pins the quad-tree workgroup width (tuning / tests)
   int octree_ncap = 0;  // LDS node capacity of the label-based quad-tree kernel (512 / 2048); 0 = key-moving kernel on global lists
   int max_cell = 0;  // largest detection-cell side over the levels: selects the k_fast_cells instantiation
-  // fused per-level kernel (fused_level.h): tile tables per level; use_fused = the geometry fits it and RGBL_FUSED != 0
-  std::vector<FusedTiles> fused;
-  FusedTiles* d_fused = nullptr;
-  FusedXGroup* d_xgrp = nullptr;  // per group of 4 output columns of every level >= 1 (index xtab_off / 4 + group)
-  int32_t* d_xsrc = nullptr;
-  std::vector<FusedXGroup> xgrp;
-  std::vector<int32_t> xsrc;
-  bool use_fused = false;
   bool xcd_map = true;  // XCD-aware workgroup -> (item, frame) mapping of the pixel kernels (common.h: xcd_item_frame); RGBL_XCD_MAP=0 switches it off
-  int fused_threads = 512;  // work-items per workgroup of k_level_fused (RGBL_FUSED_THREADS = 256 | 512 | 1024)
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> per_level;
   UMax umax;
@@ -276,188 +266,6 @@ int build_geometry(rgbl_extractor* e) {
   return RGBL_OK;
 }
 
-// Tile tables of the fused per-level kernel.  Returns false when a level does not fit it (the three separate kernels
-// are used then): more than kFusedMaxTiles tile columns / rows, a resize window wider than 8 source pixels (scale factors
-// above ~1.7), an LDS footprint above 64 KB, or quotients outside the range of its multiply-shift divisions.
-static bool fused_no(int why, int level) {
-  if (getenv("RGBL_DEBUG")) fprintf(stderr, "rgbl: fused level kernel not used (reason %d at level %d)\n", why, level);
-  return false;
-}
-bool build_fused(rgbl_extractor* e, const std::vector<ResizeTab>& xt, const std::vector<ResizeTab>& yt) {
-  const int L = e->L;
-  int ncx_max = kFusedCells;
-  if (const char* v = getenv("RGBL_FUSED_CELLS")) ncx_max = std::min(std::max(atoi(v), 1), kFusedCells);
-  int lds_max = 64 * 1024;  // per workgroup; a level takes the most cells per tile that fit
-  if (const char* v = getenv("RGBL_FUSED_LDS")) lds_max = std::min(std::max(atoi(v), 8 * 1024), 64 * 1024);
-  e->fused.assign(L, FusedTiles());
-  // cv::resize column tables in the form the fused kernel consumes (fused_level.h: FusedXGroup)
-  e->xgrp.assign(xt.size() / 4 + 1, FusedXGroup());
-  e->xsrc.assign(xt.size() / 4 + 1, 0);
-  for (size_t G = 0; G + 1 <= xt.size() / 4; ++G) {
-    const ResizeTab* X = xt.data() + 4 * G;
-    e->xsrc[G] = X[0].sofs;
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t o = (uint32_t)std::min(std::max(X[i].sofs - X[0].sofs, 0), 6);
-      e->xgrp[G].sel[i] = o | (0x0cu << 8) | ((o + 1) << 16) | (0x0cu << 24);
-      e->xgrp[G].w[i] = (uint32_t)(uint16_t)X[i].a0 | ((uint32_t)(uint16_t)X[i].a1 << 16);
-    }
-  }
-  auto a4 = [](int v) { return (v + 3) & ~3; };
-  auto a16 = [](int v) { return (v + 15) & ~15; };
-  for (int l = 0; l < L; ++l) {
-    const LevelGeom& g = e->geom[l];
-    FusedTiles& T = e->fused[l];
-    bool fits = false;
-    for (int ncx = std::min(ncx_max, g.n_cols); ncx >= 1 && !fits; --ncx) {
-    memset(&T, 0, sizeof(T));
-    T.ncx = ncx;
-    // Tile boundaries.  Columns: [0, first cell) is a strip tile of its own (the 19-px border that only the Gaussian /
-    // resize need), then groups of ncx cells, then the rest up to the right border - a strip of its own unless it is
-    // narrower than 16 px, in which case the last cell tile owns it.  Rows alike.  Strips have no cells (nc = 0 / cell_row = -1).
-    std::vector<int> xb, xj0, xnc, yb, yrow;
-    {
-      const int first = (kMinBorder + 3) & ~3;
-      if (!(getenv("RGBL_FUSED_STRIPS") && getenv("RGBL_FUSED_STRIPS")[0] == '1')) {
-        // default: border columns / rows belong to the first and last cell tiles.  RGBL_FUSED_STRIPS=1 gives the 19-px border
-        // strip tiles of its own (LDS 45 -> 37 KB, 4 instead of 3 workgroups per CU) - measured SLOWER, 2.85 -> 3.30 ms per 512
-        // frames: 121 instead of 81 workgroups per level-0 frame, and a workgroup's fixed cost (argument / table loads,
-        // five barriers) outweighs the occupancy
-        for (int j0 = 0; j0 < g.n_cols; j0 += ncx) { xb.push_back(j0 == 0 ? 0 : ((kMinBorder + 3 + j0 * g.w_cell) & ~3)); xj0.push_back(j0); xnc.push_back(std::min(ncx, g.n_cols - j0)); }
-        xb.push_back(g.w);
-        for (int r = 0; r < g.n_rows; ++r) { yb.push_back(r == 0 ? 0 : kMinBorder + 3 + r * g.h_cell); yrow.push_back(r); }
-        yb.push_back(g.h);
-      } else {
-        xb.push_back(0); xj0.push_back(0); xnc.push_back(0);
-        for (int j0 = 0; j0 < g.n_cols; j0 += ncx) {
-          xb.push_back(j0 == 0 ? first : ((kMinBorder + 3 + j0 * g.w_cell) & ~3)); xj0.push_back(j0); xnc.push_back(std::min(ncx, g.n_cols - j0));
-        }
-        const int xr = std::min(g.w, (kMinBorder + 3 + g.n_cols * g.w_cell) & ~3);
-        if (g.w - xr >= 16) { xb.push_back(xr); xj0.push_back(g.n_cols); xnc.push_back(0); }
-        xb.push_back(g.w);
-        yb.push_back(0); yrow.push_back(-1);
-        for (int r = 0; r < g.n_rows; ++r) { yb.push_back(kMinBorder + 3 + r * g.h_cell); yrow.push_back(r); }
-        const int yr = std::min(g.h, kMinBorder + 3 + g.n_rows * g.h_cell);
-        if (g.h - yr >= 8) { yb.push_back(yr); yrow.push_back(-1); }
-        yb.push_back(g.h);
-      }
-    }
-    T.ntx = (int)xb.size() - 1;
-    T.nty = (int)yb.size() - 1;
-    if (T.ntx > kFusedMaxTiles || T.nty > kFusedMaxTiles) return fused_no(1, l);
-    int max_w = 0, max_h = 0;
-    for (int c = 0; c < T.ntx; ++c) {
-      FusedCol& C = T.col[c];
-      C.j0 = xj0[c];
-      C.nc = xnc[c];
-      C.xa = xb[c];
-      C.xb = xb[c + 1];
-      if (C.xb <= C.xa || C.xb > g.w || (C.xa & 3)) return fused_no(2, l);
-      max_w = std::max(max_w, C.xb - C.xa);
-      const int xorg = C.xa - 4, own_w = C.xb - C.xa;
-      C.sw = 0; C.n_valid = 0;
-      for (int k = 0; k < C.nc; ++k) {  // ORBextractor.cc:810-822: cells that start too close to the border are skipped
-        const int ini_x = kMinBorder + (C.j0 + k) * g.w_cell;
-        if (ini_x < g.max_bx - 6) { C.sw = k * g.w_cell + std::min(g.w_cell, g.max_bx - ini_x - 6); C.n_valid = k + 1; }
-      }
-      C.sx_t = kMinBorder + 3 + C.j0 * g.w_cell - xorg;
-      C.gpr = (C.sw + 3) / 4;
-      C.gw4 = (own_w + 3) / 4;
-      C.q16 = (own_w + 4 + kFusedHaloR + 15) / 16;
-      if (C.q16 > 16) return fused_no(7, l);
-      // the scanned columns (+ 3) must lie inside what the tile stages
-      if (C.nc > 0 && (C.sx_t < 3 || C.sx_t + C.sw + 3 > 16 * C.q16)) return fused_no(8, l);
-      C.q_lo = xorg < 0 ? 1 : 0;
-      C.q_hi = std::min(C.q16, (g.w - xorg) >> 4);
-      C.m_gpr = div_magic((uint32_t)std::max(C.gpr, 1));
-      C.m_sw = div_magic((uint32_t)std::max(C.sw, 1));
-      C.m_gw4 = div_magic((uint32_t)C.gw4);
-    }
-    for (int r = 0; r < T.nty; ++r) {
-      FusedRow& R = T.row[r];
-      R.ya = yb[r];
-      R.yb = yb[r + 1];
-      R.cell_row = yrow[r];
-      if (R.yb <= R.ya || R.yb > g.h) return fused_no(3, l);
-      max_h = std::max(max_h, R.yb - R.ya);
-      R.sh = 0; R.sy_t = 3;
-      if (R.cell_row >= 0) {
-        const int ini_y = kMinBorder + R.cell_row * g.h_cell, max_y = std::min(ini_y + g.h_cell + 6, g.max_by);
-        R.sh = (ini_y < g.max_by - 3 && max_y - ini_y - 6 > 0) ? max_y - ini_y - 6 : 0;
-        R.sy_t = ini_y + 3 - (R.ya - 3);
-        if (R.sy_t < 3 || R.sy_t + R.sh + 3 > R.yb - R.ya + 6) return fused_no(9, l);
-      }
-    }
-    T.chunk_rows = (max_h + 1) / 2;  // two Gaussian chunks per tile (fused_level.h): the row-sum buffer holds half the tallest tile
-    if (const char* v = getenv("RGBL_FUSED_CHUNK")) T.chunk_rows = std::min(std::max(atoi(v), T.chunk_rows), max_h);
-    for (int r = 0; r < T.nty; ++r) {
-      T.row[r].rows0 = std::min(T.row[r].yb - T.row[r].ya, T.chunk_rows);
-      T.row[r].rows1 = T.row[r].yb - T.row[r].ya - T.row[r].rows0;
-    }
-    int max_g = 0, max_r = 0;
-    if (l + 1 < L) {
-      const LevelGeom& n = e->geom[l + 1];
-      const ResizeTab* X = xt.data() + n.xtab_off;
-      const ResizeTab* Y = yt.data() + n.ytab_off;
-      const int ngroups = (n.w + 3) / 4;
-      for (int G = 0; G < ngroups; ++G)
-        if (X[4 * G + 3].sofs + 1 - X[4 * G].sofs > 7) return fused_no(4, l);
-      int G = 0;
-      for (int c = 0; c < T.ntx; ++c) {
-        while (G < ngroups && X[4 * G].sofs < T.col[c].xa) ++G;
-        T.col[c].ga = G;
-        if (c > 0) T.col[c - 1].gb = G;
-      }
-      T.col[T.ntx - 1].gb = ngroups;
-      T.col[0].ga = 0;
-      auto src_row = [&](int dy) { return std::min(std::max(Y[dy].sofs, 0), g.h - 1); };
-      int dy = 0;
-      for (int r = 0; r < T.nty; ++r) {
-        while (dy < n.h && src_row(dy) < T.row[r].ya) ++dy;
-        T.row[r].dya = dy;
-        if (r > 0) T.row[r - 1].dyb = dy;
-      }
-      T.row[T.nty - 1].dyb = n.h;
-      T.row[0].dya = 0;
-      for (int c = 0; c < T.ntx; ++c) max_g = std::max(max_g, T.col[c].gb - T.col[c].ga);
-      for (int r = 0; r < T.nty; ++r) max_r = std::max(max_r, T.row[r].dyb - T.row[r].dya);
-    }
-    for (int c = 0; c < T.ntx; ++c) T.col[c].m_ng = div_magic((uint32_t)std::max(T.col[c].gb - T.col[c].ga, 1));
-    T.m_wcell = div_magic((uint32_t)g.w_cell);
-    // LDS layout
-    T.tile_pitch = 16 * ((max_w + 4 + kFusedHaloR + 15) / 16);
-    for (int tp : {96, 128, 160, 176, 192, 224, 256})  // the instantiated pitches of k_level_fused
-      if (T.tile_pitch <= tp) { T.tile_pitch = tp; break; }
-    T.tile_rows = max_h + 7;
-    T.hs_pitch = a4(max_w);
-    T.hs_pairs = std::max((T.chunk_rows + 7) / 2, 2 * ((T.chunk_rows + 3) / 4) + 3);
-    T.score_pitch = a4(ncx * g.w_cell + 2);
-    T.bit_words = 2 * ((g.w_cell * g.h_cell + 63) / 64);
-    int off = 16;
-    T.off_tile = off; off = a16(off + T.tile_pitch * T.tile_rows + 16);
-    T.off_hs = off; off = a16(off + 4 * T.hs_pitch * T.hs_pairs);
-    T.off_surv = off; off = a16(off + 2 * ncx * g.w_cell * g.h_cell);
-    T.off_score = off; off = a16(off + T.score_pitch * (g.h_cell + 2));
-    T.off_keep = off; off = a16(off + 4 * kFusedCells * 3 * T.bit_words);  // two bitmaps per cell + the prefix words of the chosen one
-    T.off_misc = off; off = a16(off + 32);
-    T.off_xt = off; off = a16(off + 32 * max_g);
-    T.off_xs = off; off = a16(off + 4 * max_g);
-    T.off_yt = off; off = a16(off + 8 * max_r);
-    T.lds_bytes = off;
-    if (const char* v = getenv("RGBL_FUSED_LDS_PAD")) T.lds_bytes += atoi(v);  // occupancy experiments
-    if (T.lds_bytes > lds_max) continue;
-    // ranges of the multiply-shift divisions (fused_level.h: x * d < 2^22, x / d < 1000)
-    const long sw = (long)ncx * g.w_cell, sh = g.h_cell;
-    if (sw * sh * sw >= (1 << 22) || sh >= 1000 || (long)T.hs_pitch / 4 * T.hs_pairs * (T.hs_pitch / 4) >= (1 << 22) ||
-        (long)std::max(max_g, 1) * std::max(max_r, 1) * std::max(max_g, 1) >= (1 << 22))
-      return fused_no(6, l);
-    fits = true;
-    if (getenv("RGBL_DEBUG")) fprintf(stderr, "rgbl: fused level %d: %d x %d tiles of %d cells, pitch %d, rows %d, chunk %d, LDS %d B\n", l, T.ntx, T.nty, ncx, T.tile_pitch, T.tile_rows, T.chunk_rows, T.lds_bytes);
-    }
-    if (!fits) return fused_no(5, l);
-  }
-  return true;
-}
-
 int upload_tables(rgbl_extractor* e) {
   const int L = e->L;
   std::vector<ResizeTab> xt, yt;
@@ -562,21 +370,7 @@ int upload_tables(rgbl_extractor* e) {
   if (!yt.empty()) RGBL_HIP(hipMemcpy(e->d_ytab, yt.data(), sizeof(ResizeTab) * yt.size(), hipMemcpyHostToDevice));
   RGBL_HIP(hipMemcpy(e->d_rootx, rootx.data(), rootx.size(), hipMemcpyHostToDevice));
   RGBL_HIP(hipMemcpy(e->d_pattern, kBriefPattern, 1024, hipMemcpyHostToDevice));
-  // RGBL_FUSED=1: the fused per-level kernel (fused_level.h) instead of k_resize_linear + k_fast_cells + k_gauss7.
-  // Measured on these synthetic frames (a third of the upper levels' pixels are FAST corners) it is on a par with the
-  // three kernels (2.9 vs 2.7 ms per 512 frames, both bound by VALU issue), so it is not the default yet.
   if (const char* v = getenv("RGBL_XCD_MAP")) e->xcd_map = v[0] != '0';
-  const char* fz = getenv("RGBL_FUSED");
-  e->use_fused = (fz && fz[0] == '1') && build_fused(e, xt, yt);
-  if (const char* v = getenv("RGBL_FUSED_THREADS")) { const int t = atoi(v); if (t == 256 || t == 512) e->fused_threads = t; }
-  if (e->use_fused) {
-    RGBL_TRY(dev_alloc(e, &e->d_fused, L));
-    RGBL_HIP(hipMemcpy(e->d_fused, e->fused.data(), sizeof(FusedTiles) * L, hipMemcpyHostToDevice));
-    RGBL_TRY(dev_alloc(e, &e->d_xgrp, e->xgrp.size()));
-    RGBL_TRY(dev_alloc(e, &e->d_xsrc, e->xsrc.size()));
-    RGBL_HIP(hipMemcpy(e->d_xgrp, e->xgrp.data(), sizeof(FusedXGroup) * e->xgrp.size(), hipMemcpyHostToDevice));
-    RGBL_HIP(hipMemcpy(e->d_xsrc, e->xsrc.data(), sizeof(int32_t) * e->xsrc.size(), hipMemcpyHostToDevice));
-  }
   return RGBL_OK;
 }
 
@@ -687,63 +481,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
     }
     e->timer.end(st);
   };
-  if (e->use_fused) {
-    // One launch per level: FAST cells + Gaussian tile + the next level's pixels from one staged tile (fused_level.h).
-    // Level l + 1 needs level l complete, so the launches form a chain on the handle's stream; the quad-tree of level 0 -
-    // the longest dependent chains - starts on the auxiliary stream as soon as level 0's candidates exist.
-    const bool overlap = !e->timer.enabled;
-    for (int l = 0; l < L; ++l) {
-      const FusedTiles& T = e->fused[l];
-      FusedArgs A;
-      memset(&A, 0, sizeof(A));
-      A.g = e->geom[l];
-      if (l + 1 < L) {
-        const LevelGeom& n = e->geom[l + 1];
-        A.next_w = n.w; A.next_h = n.h; A.next_pitch = n.pitch;
-        A.xgrp = e->d_xgrp + n.xtab_off / 4; A.xsrc = e->d_xsrc + n.xtab_off / 4; A.ytab = e->d_ytab + n.ytab_off;
-        A.next = e->d_pyr + n.img_off; A.next_frame = e->pyr_frame;
-      }
-      A.src = l == 0 ? d_imgs : e->d_pyr + A.g.img_off;
-      A.spitch = l == 0 ? stride : A.g.pitch;
-      A.sframe = l == 0 ? frame_stride : e->pyr_frame;
-      A.blur = e->d_blur + A.g.img_off; A.blur_frame = e->pyr_frame;
-      A.cell_cnt = e->d_cellcnt; A.cells_frame = (size_t)e->cells_frame;
-      A.slots = e->d_slots; A.slots_frame = e->slots_frame;
-      A.ini_th = e->cfg.ini_th_fast; A.min_th = e->cfg.min_th_fast;
-      A.tiles = e->d_fused + l;
-      A.dbg = getenv("RGBL_FUSED_STAMPS") ? e->d_dbg + 8 * l : nullptr;
-      static const char* kLevelName[kMaxLevels] = {"k_level_fused_0", "k_level_fused_1", "k_level_fused_2", "k_level_fused_3", "k_level_fused_4", "k_level_fused_5", "k_level_fused_6", "k_level_fused_7", "k_level_fused_8", "k_level_fused_9", "k_level_fused_10", "k_level_fused_11", "k_level_fused_12", "k_level_fused_13", "k_level_fused_14", "k_level_fused_15"};
-      e->timer.begin(getenv("RGBL_FUSED_PER_LEVEL") ? kLevelName[l] : "k_level_fused", s);
-      {
-        const dim3 grid(T.ntx * T.nty, batch);
-#define RGBL_LAUNCH_FUSED(NT, TP) hipLaunchKernelGGL((k_level_fused<NT, TP>), xcd_grid(e->xcd_map, T.ntx * T.nty, batch), dim3(NT), T.lds_bytes, s, A)
-        switch (T.tile_pitch) {
-          case 96: RGBL_LAUNCH_FUSED(512, 96); break;
-          case 128: RGBL_LAUNCH_FUSED(512, 128); break;
-          case 160: RGBL_LAUNCH_FUSED(512, 160); break;
-          case 176: RGBL_LAUNCH_FUSED(512, 176); break;
-          case 192: RGBL_LAUNCH_FUSED(512, 192); break;
-          case 224: RGBL_LAUNCH_FUSED(512, 224); break;
-          default: RGBL_LAUNCH_FUSED(512, 256); break;
-        }
-#undef RGBL_LAUNCH_FUSED
-      }
-      e->timer.end(s);
-      if (l == 0 && overlap && L > 1) {
-        RGBL_HIP(hipEventRecord(e->ev_fast0, s));
-        RGBL_HIP(hipStreamWaitEvent(e->aux_stream, e->ev_fast0, 0));
-        launch_octree(e->aux_stream, 0, 1);
-        RGBL_HIP(hipEventRecord(e->ev_blur, e->aux_stream));
-      }
-    }
-    RGBL_HIP(hipEventRecord(e->ev_pixels, s));
-    if (overlap && L > 1) {
-      launch_octree(s, 1, L);
-      RGBL_HIP(hipStreamWaitEvent(s, e->ev_blur, 0));
-    } else {
-      launch_octree(s, 0, L);
-    }
-  } else {
+  {
     // Level 0 of the pyramid is the input image itself: its FAST cells (a third of all pixels) and its Gaussian do not
     // wait for the resize chain - seven short dependent launches that leave most of the chip idle - but run next to it
     // on the auxiliary stream.  (While per-kernel timing is on, everything stays on one stream so that the event
@@ -892,7 +630,7 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
   }
   if (rc == RGBL_OK) rc = upload_tables(e);
   // dense candidate lists need the label-based quad-tree kernel (order-free) and the per-cell FAST kernel (RGBL_DENSE=0: cell slots)
-  if (rc == RGBL_OK) e->dense = e->octree_ncap != 0 && !e->use_fused && !(getenv("RGBL_DENSE") && getenv("RGBL_DENSE")[0] == '0');
+  if (rc == RGBL_OK) e->dense = e->octree_ncap != 0 && !(getenv("RGBL_DENSE") && getenv("RGBL_DENSE")[0] == '0');
   if (rc == RGBL_OK) rc = alloc_scratch(e);
   if (rc == RGBL_OK && (hipStreamCreate(&e->own_stream) != hipSuccess || hipStreamCreate(&e->aux_stream) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming) != hipSuccess ||

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
   __syncthreads();
 
   // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are listed.  (Four pixels per
-  //      task on packed 16-bit halves of aligned word pairs, as in fused_level.h, was measured slower here: 1.24 -> 1.39 ms.)
+  //      task on packed 16-bit halves of aligned word pairs, as the fused per-level kernel of round 2 had it, was measured slower here: 1.24 -> 1.39 ms.)
   for (int p = tid; p < npix; p += BS) {
     const int y = RGBL_DIV_SW(p);
     const uint8_t* c = &s_tile[RGBL_TILE_AT(p, y)];

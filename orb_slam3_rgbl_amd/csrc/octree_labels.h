@@ -16,7 +16,7 @@
 //
 // Input: normally one list per (level, frame) that k_fast_cells' cells appended to in whatever order they finished (the
 // reference's candidate order - cell after cell, row-major inside a cell - is a function of a key's coordinates and only
-// matters for (c)); with the fused per-level kernel or RGBL_DENSE=0 the cells' own slots, gathered here in that order.
+// matters for (c)); with RGBL_DENSE=0 the cells' own slots, gathered here in that order.
 //
 // Launch: one workgroup of BS work-items per (level, frame), grid (levels, frames).
 #pragma once

@@ -113,7 +113,7 @@ def test_extractor_quadtree_empty_root_nodes(emu_lib):
 
 def test_extractor_cell_slot_candidates(emu_lib):
     # RGBL_DENSE=0: the FAST kernel keeps every cell's candidates in the cell's own slots and the quad-tree kernel gathers
-    # them (the layout of the fused per-level kernel and of configurations beyond 2048 quad-tree nodes)
+    # them (the layout of configurations beyond 2048 quad-tree nodes)
     os.environ["RGBL_DENSE"] = "0"
     try:
         pc.check_extractor(emu_lib, 520, 360, 1000, frames=(0, 1), seq=7, stages=True)
@@ -220,18 +220,6 @@ def test_search_by_sim3(emu_lib, seed, th):
 @pytest.mark.parametrize("seed,th,form,ratio", [(151, 8, 0, 1.5), (152, 30, 2, 1.0), (153, 3, 0, 2.5)])
 def test_search_by_projection_sim3(emu_lib, seed, th, form, ratio):
     assert pc.check_search_by_projection_sim3(emu_lib, seed, th, form, ratio, n1=1200, n2=1000) > 80
-
-
-@pytest.mark.parametrize("cells", ["4", "2"])
-def test_extractor_fused_level_kernel(emu_lib, monkeypatch, cells):
-    # k_level_fused (FAST cells + Gaussian + next level's pixels from one staged tile) instead of the three separate kernels
-    monkeypatch.setenv("RGBL_FUSED", "1")
-    monkeypatch.setenv("RGBL_FUSED_CELLS", cells)
-    pc.check_extractor(emu_lib, 400, 300, 500, stages=True)
-    pc.check_extractor(emu_lib, 1241, 376, 2000, stages=True)
-    pc.check_extractor(emu_lib, 752, 480, 1200, frames=(1,), ini=20, mn=7, stages=True)
-    pc.check_extractor_edge_cases(emu_lib)
-    pc.check_extractor_batch(emu_lib, 400, 300, 500, 3)
 
 
 def test_stereo_fisheye_matches(emu_lib):

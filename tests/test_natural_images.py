@@ -56,15 +56,7 @@ def test_emulated_kernels_on_natural_images(emu_lib, name):
     check_device(emu_lib, name)
 
 
-@pytest.mark.parametrize("name", sorted(GOLDEN))
-def test_fused_level_kernel_on_natural_images(emu_lib, monkeypatch, name):
-    monkeypatch.setenv("RGBL_FUSED", "1")
-    check_device(emu_lib, name)
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", ["0", "1"])
 @pytest.mark.parametrize("name", sorted(GOLDEN))
-def test_gpu_on_natural_images(gpu_lib, monkeypatch, name, fused):
-    monkeypatch.setenv("RGBL_FUSED", fused)
+def test_gpu_on_natural_images(gpu_lib, name):
     check_device(gpu_lib, name)

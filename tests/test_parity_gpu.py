@@ -1,5 +1,6 @@
-import os
 """Parity tests proper: the HIP path on a real MI355X, called through the C ABI, against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -220,16 +221,6 @@ def test_search_by_sim3(gpu_lib, seed, th):
 @pytest.mark.parametrize("seed,th,form,ratio", [(151, 8, 0, 1.5), (152, 30, 2, 1.0), (153, 3, 0, 2.5)])
 def test_search_by_projection_sim3(gpu_lib, seed, th, form, ratio):
     assert pc.check_search_by_projection_sim3(gpu_lib, seed, th, form, ratio) > 80
-
-
-def test_extractor_fused_level_kernel(gpu_lib, monkeypatch):
-    # the fused per-level kernel (RGBL_FUSED=1) must produce the same pyramid, blurred levels, candidates and keypoints
-    monkeypatch.setenv("RGBL_FUSED", "1")
-    pc.check_extractor(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000, frames=(0, 3), stages=True)
-    pc.check_extractor(gpu_lib, 752, 480, 1200, stages=True)
-    pc.check_extractor(gpu_lib, 3840, 2160, 8000, stages=True)
-    pc.check_extractor_edge_cases(gpu_lib)
-    pc.check_extractor_batch(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000, 8)
 
 
 def test_stereo_fisheye_matches(gpu_lib):
