@@ -63,24 +63,80 @@ def algorithmic_bytes(kernel, w, h, n_points, k_per_frame):
     return table.get(kernel)
 
 
-def pmc_traffic(kernel, frames_per_launch, launches_per_step):
-    """HBM-side bytes per LAUNCH of `kernel` from the committed rocprofv3 PMC passes of this same command (`--serial`, so
-    that dispatches per step are what this run launches): profiles/r02_pmc_traffic.json holds, per kernel, the FETCH_SIZE and
-    WRITE_SIZE totals of one step (sum over the step's dispatches, in bytes, multiplied by the calibration factors that
-    tools/micro/hbm_calib.hip measured for this access width - MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B
-    request for wide loads and is uncalibrated otherwise).  None when the file is absent or does not know the kernel."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
+TRAFFIC_FILES = {"kitti": ("r03_pmc_traffic.json", "r02_pmc_traffic.json"), "4k": ("r03_pmc_traffic_4k.json",)}
+CLOCK_HZ, SIMDS = 2.4e9, 1024     # MI355X: 256 CUs x 4 SIMDs, one VALU instruction of a wave64 per 4 cycles and SIMD
+
+
+def pmc_profile(workload):
+    """The committed counter passes of this same command (`--serial`, so that dispatches per step are what this run launches):
+    profiles/rNN_pmc_traffic*.json holds, per kernel, the FETCH_SIZE and WRITE_SIZE totals of one step in bytes (converted with
+    the factors tools/micro/hbm_calib.hip measured on this GPU) and, from round 3 on, the SQ_INSTS_VALU total.  Returns
+    (dict, file name) or (None, None)."""
+    for name in TRAFFIC_FILES.get(workload, ()):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                return json.load(open(path)), "profiles/" + name
+            except ValueError:
+                pass
+    return None, None
+
+
+def pmc_traffic(prof, kernel, frames_per_launch, launches_per_step):
+    """HBM-side bytes per LAUNCH of `kernel` from the committed passes; None when they do not know the kernel."""
     try:
-        t = json.load(open(path))
-        k = t["kernels"].get(kernel)
-        if not k:
-            return None
-        per_step = (k["fetch_bytes_per_step"] + k["write_bytes_per_step"]) * frames_per_launch / t["frames_per_step"]
+        k = prof["kernels"][kernel]
+        per_step = (k["fetch_bytes_per_step"] + k["write_bytes_per_step"]) * frames_per_launch / prof["frames_per_step"]
         return per_step / max(launches_per_step, 1)
-    except (KeyError, ValueError):
+    except (KeyError, TypeError, ValueError):
         return None
+
+
+def roofline_of(kernels, prof_steps, workload, w, h, n_points, k_mean, B, step_s=None):
+    """The roofline object of the dominant kernel (largest share of the serialised GPU time) from per-kernel HIP-event times
+    {name: (ms summed over prof_steps steps, launches)}: algorithmic bytes over its own time against the 8 TB/s
+    of HBM3E - for every kernel of the step as well (`per_kernel_hbm`) -, the HBM-side traffic of the committed counter passes,
+    and, where those passes hold SQ_INSTS_VALU, the share of the VALU issue slots the kernel used: the pixel kernels of this
+    path are bound by vector issue, not by bytes, and `bound` says which of the two is closer to its ceiling."""
+    total_ms = sum(v[0] for v in kernels.values())
+    dom = max(kernels, key=lambda k: kernels[k][0])
+    ms_sum, launches = kernels[dom]
+    per_step_ms = ms_sum / prof_steps                      # all launches of that kernel in one step
+    per_launch_ms = ms_sum / max(launches, 1)
+    ab = algorithmic_bytes(dom, w, h, n_points, k_mean)
+    achieved = (ab * B) / (per_step_ms * 1e-3) / 1e9 if ab else None
+    prof, source = pmc_profile(workload)
+    traffic = pmc_traffic(prof, dom, B, launches / prof_steps)
+    r = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+         "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
+         "traffic_source": (source + " (counter passes of this command, replayed; not counted in this run)") if traffic else None,
+         "traffic_over_algorithmic": (traffic / (ab * B * prof_steps / max(launches, 1))) if (traffic and ab) else None,
+         "avg_launch_ms": per_launch_ms, "launches_per_step": launches / prof_steps,
+         "algorithmic_bytes_per_frame": ab, "frames_per_launch": B,
+         "kernel_share_of_gpu_time": ms_sum / total_ms if total_ms else None,
+         "kernels_ms_per_step": {k: v[0] / prof_steps for k, v in sorted(kernels.items())}}
+    try:
+        valu = prof["kernels"][dom]["valu_insts_per_step"] * B / prof["frames_per_step"]
+        issue = valu * 4.0 / (per_step_ms * 1e-3 * CLOCK_HZ * SIMDS)
+        r["valu_issue_frac"] = issue
+        r["valu_insts_per_pixel"] = valu * 64.0 / (ab * B) if dom == "k_fast_cells" else None
+        r["valu_source"] = source + " (SQ_INSTS_VALU of this command, replayed) over this run's kernel time"
+        if r["frac"] is not None and issue > r["frac"]:
+            r["bound"] = "valu"
+    except (KeyError, TypeError):
+        pass
+    per_kernel = {}
+    step_bytes = 0.0
+    for k, v in sorted(kernels.items()):
+        kb = algorithmic_bytes(k, w, h, n_points, k_mean)
+        if kb and v[0] > 0:
+            gbs = kb * B / (v[0] / prof_steps * 1e-3) / 1e9
+            per_kernel[k] = {"GB/s": round(gbs, 1), "frac": round(gbs / 8000.0, 4)}
+            step_bytes += kb * B
+    r["per_kernel_hbm"] = per_kernel
+    if step_s:
+        r["step_algorithmic_GB/s"] = round(step_bytes / step_s / 1e9, 1)
+    return r
 
 
 def load_reference_build():
@@ -246,8 +302,9 @@ def extra_workloads(lib, dev, torch):
     def sync():
         torch.cuda.synchronize(dev)
 
-    # ---- configs[4]: 4K
+    # ---- configs[4]: 4K (the step of pipeline.py on 4K frames; then its serialised per-kernel leg for the roofline object)
     try:
+        from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline
         w, h, nf, n_az, B = WORKLOADS["4k"]
         seq = synth.Sequence(7, w, h, n_frames=4)
         distinct = [seq.frame(i) for i in range(4)]
@@ -259,36 +316,24 @@ def extra_workloads(lib, dev, torch):
         K[0, 0] = K[1, 1] = 718.856 * w / synth.KITTI_W
         K[0, 2], K[1, 2] = w / 2.0, h / 2.0
         proj = F.projection_matrix(K, synth.KITTI_TR, lib)
-        ex = F.ORBextractor(nf, SCALE, LEVELS, INI_TH, MIN_TH, w, h, max_batch=B, device=dev.index, lib=lib)
-        cap = ex.max_keypoints
-        dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=cap, max_batch=B, device=dev.index, lib=lib)
-        mt = F.ORBmatcher(0.6, False, device=dev.index, lib=lib)
-        one = C.c_void_p(lib.rgbl_extractor_stream(ex.h))
-        L.check(lib, lib.rgbl_matcher_set_stream(mt.h, one))
-        kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
-        desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-        n = torch.zeros(B, dtype=torch.int32, device=dev)
-        mono = torch.zeros(B, dtype=torch.int32, device=dev)
-        depth = torch.zeros((B, cap), dtype=torch.float32, device=dev)
-        uright = torch.zeros((B, cap), dtype=torch.float32, device=dev)
-        bi, bd, sd = (torch.zeros((B, cap), dtype=torch.int32, device=dev) for _ in range(3))
-        pa = torch.arange(B, dtype=torch.int32, device=dev)
-        pb = (pa + 1) % B
-        s_ex, s_dm = one, C.c_void_p(lib.rgbl_depth_stream(dm.h))
-
-        def step():
-            L.check(lib, lib.rgbl_stream_wait(s_ex, s_dm))   # the previous step's gather read this step's outputs
-            L.check(lib, lib.rgbl_extract_batch_device(ex.h, p(frames), B, w, h, w, w * h, 0, 0, p(kp), p(desc), cap, p(n), p(mono)))
-            L.check(lib, lib.rgbl_depth_project_batch_device(dm.h, p(cloud), B, n_points, n_points, 4 * n_points, w, h, None))
-            L.check(lib, lib.rgbl_stream_wait(s_dm, s_ex))
-            L.check(lib, lib.rgbl_depth_gather_batch_device(dm.h, B, w, h, p(kp), p(n), cap, None, p(depth), p(uright)))
-            L.check(lib, lib.rgbl_hamming_bf_batch_device(mt.h, p(desc), p(n), cap, p(pa), p(pb), B, p(bi), p(bd), p(sd)))
-        dt = time_steps(step, sync, 2, 6)
+        pipe = FrontEndPipeline(lib, torch, dev, w, h, nf, proj, n_points, B, levels=LEVELS, scale=SCALE, ini_th=INI_TH, min_th=MIN_TH,
+                                gather="none")
+        pipe.set_inputs(frames, cloud)
+        dt = time_steps(pipe.step, pipe.sync, 2, 6)
+        k_mean = float(pipe.last().n.float().mean().item())
+        pipe.serialise()
+        pipe.profile(True)
+        for _ in range(2):
+            pipe.step()
+        pipe.sync()
+        kernels = pipe.profile_read()
+        pipe.profile(False)
         out["cfg5_4k"] = {"frames_per_s": B / dt, "ms_per_step": dt * 1e3, "frames_per_step": B, "image": [w, h], "nfeatures": nf,
-                          "lidar_points": n_points, "keypoints_per_frame": float(n.float().mean().item()),
-                          "what": "extract + depth + match, inputs resident in HBM, 1 GPU"}
-        ex.close(); dm.close(); mt.close()
-        del frames, cloud, kp, desc, depth, uright, bi, bd, sd
+                          "lidar_points": n_points, "keypoints_per_frame": k_mean,
+                          "what": "extract + depth + match, inputs resident in HBM, 1 GPU",
+                          "roofline": roofline_of(kernels, 2, "4k", w, h, n_points, k_mean, B, dt)}
+        pipe.close()
+        del frames, cloud, pipe
     except Exception as e:  # never lose the main line over an extra figure
         out["cfg5_4k"] = {"error": repr(e)}
 
@@ -379,11 +424,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the 4K / stereo / single-frame figures (extra keys of the JSON line)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--serial", action="store_true", help="one stream for all handles (clean per-kernel timings)")
-    ap.add_argument("--split", type=int, default=1, choices=[1, 2],
-                    help="2: two extractor handles with half the batch each, gated on one another's pixel phase (pipeline.py)")
-    ap.add_argument("--gather", default="step", choices=["step", "final", "none"],
-                    help="N > 1: stream every step's records to rank 0 while the next step computes (default), exchange all of "
-                         "them once at the end, or not at all")
+    ap.add_argument("--gather", default=None, choices=["step", "final", "none"],
+                    help="gather of the keypoint / descriptor / depth records to rank 0: stream every step's records while the "
+                         "next step computes (default for N > 1), exchange all of them once at the end, or not at all (default "
+                         "for N = 1; step / final then run the same choreography without a peer)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -410,6 +454,7 @@ def main():
     w, h, nfeatures, n_az, default_batch = WORKLOADS[args.workload]
     B = args.batch or default_batch
     lib = L.load()
+    gather = args.gather or ("step" if world > 1 else "none")
 
     # ---- synthetic input, one independent sequence per rank (BASELINE configs[3]: sequences shard over GPUs)
     # constant_density: 1200 shapes per frame area whatever the batch (the scene grows with the sequence length)
@@ -431,8 +476,8 @@ def main():
     # the step (extract -> depth -> match on resident inputs) and the gather of its records live in
     # orb_slam3_rgbl_amd/pipeline.py - the same code tests/test_distributed.py drives with two gloo ranks
     pipe = FrontEndPipeline(lib, torch, dev, w, h, nfeatures, proj, n_points, B, levels=LEVELS, scale=SCALE, ini_th=INI_TH,
-                            min_th=MIN_TH, world=world, rank=rank, gather=args.gather, serial=args.serial,
-                            log_steps=args.steps + args.warmup, split=args.split)
+                            min_th=MIN_TH, world=world, rank=rank, gather=gather, serial=args.serial,
+                            log_steps=args.steps + args.warmup)
     ex, dm, mt, cap = pipe.ex, pipe.dm, pipe.mt, pipe.cap
     d_imgs = torch.from_numpy(frames).to(dev)
     d_cloud = torch.from_numpy(cloud).to(dev)
@@ -507,30 +552,7 @@ def main():
         sync_all()
         kernels.update(pipe.profile_read())
         pipe.profile(False)
-        total_ms = sum(v[0] for v in kernels.values())
-        dom = max(kernels, key=lambda k: kernels[k][0])
-        ms_sum, launches = kernels[dom]
-        per_step_ms = ms_sum / prof_steps                      # all launches of that kernel in one step
-        per_launch_ms = ms_sum / max(launches, 1)
-        ab = algorithmic_bytes(dom, w, h, n_points, k_mean)
-        achieved = (ab * B) / (per_step_ms * 1e-3) / 1e9 if ab else None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(dom, B, launches / prof_steps),
-                    "avg_launch_ms": per_launch_ms, "launches_per_step": launches / prof_steps,
-                    "algorithmic_bytes_per_frame": ab, "frames_per_launch": B,
-                    "kernel_share_of_gpu_time": ms_sum / total_ms if total_ms else None,
-                    "kernels_ms_per_step": {k: v[0] / prof_steps for k, v in sorted(kernels.items())}}
-        # achieved-HBM fraction of every kernel of the step (algorithmic bytes / its own time), north_star's per-kernel report
-        per_kernel = {}
-        step_bytes = 0.0
-        for k, v in sorted(kernels.items()):
-            kb = algorithmic_bytes(k, w, h, n_points, k_mean)
-            if kb and v[0] > 0:
-                gbs = kb * B / (v[0] / prof_steps * 1e-3) / 1e9
-                per_kernel[k] = {"GB/s": round(gbs, 1), "frac": round(gbs / 8000.0, 4)}
-                step_bytes += kb * B
-        roofline["per_kernel_hbm"] = per_kernel
-        roofline["step_algorithmic_GB/s"] = round(step_bytes / (elapsed / args.steps) / 1e9, 1)
+        roofline = roofline_of(kernels, prof_steps, args.workload, w, h, n_points, k_mean, B, elapsed / args.steps)
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = min(B, 256)
             fps, n_done, stage_ms, kind = cpu_baseline(frames[:n_cpu], scans, proj, w, h, nfeatures, args.cpu_budget,
@@ -577,7 +599,12 @@ def main():
                        "inputs": "resident in HBM",
                        "frames": "synth.Sequence, %s" % ("shape count of ONE frame for the whole scene (RGBL_BENCH_SPARSE: the pre-correction input)" if os.environ.get("RGBL_BENCH_SPARSE") else "constant corner density: 1200 shapes per frame area, ~8.6 k FAST candidates on level 0"),
                        "parallelism": "frames/sequences sharded, %d rank(s)" % world,
-                       "gather": (args.gather if world > 1 else "none")},
+                       "gather": {"none": "none",
+                                  "step": "step: every step's records (68 B per keypoint, packed on the device) go to rank 0 while the "
+                                          "next step computes - counts by all-gather, records by exact-size send / recv, one xGMI link "
+                                          "per peer; the volume (~70 MB per rank and step) is a tenth of what the links carry, exchanged "
+                                          "once at the end (--gather final) it would be a serial tail of about a third of the compute time",
+                                  "final": "final: the records of all steps stay packed in HBM and are exchanged once, inside the timed region"}[gather]},
             "parity_spot_check": spot,
             "roofline": roofline,
             "cpu_baseline": cpu,

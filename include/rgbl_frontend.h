@@ -167,14 +167,6 @@ void* rgbl_extractor_stream(rgbl_extractor* h); /* hipStream_t currently used by
 /* the handle's second, internal stream (level-0 FAST / quad-tree and the Gaussian run there next to the resize chain);
  * other handles may queue work behind it with rgbl_*_set_stream */
 void* rgbl_extractor_aux_stream(rgbl_extractor* h);
-/* Software pipelining across extractor handles.  An extraction is a pixel phase (pyramid, FAST, Gaussian: bound by vector
- * issue) followed by a phase of dependent chains and gathers (quad-tree, orientation / descriptors: low utilisation).  The
- * event returned by rgbl_extractor_pixel_event is recorded behind the last pixel kernel of every extraction of the handle;
- * a handle whose gate is set to another handle's event starts its next extraction only when that event has fired (a
- * never-recorded event does not block).  Two handles with half a batch each, gated on one another, keep one pixel phase
- * and one chain phase in flight at any time (pipeline.py: split=2).  The gate event is borrowed, not owned. */
-void* rgbl_extractor_pixel_event(rgbl_extractor* h);
-int rgbl_extractor_set_gate(rgbl_extractor* h, void* event);
 /* Device-side ordering between handles without a host sync: work enqueued on `waiter_stream` after this call
  * starts only when everything enqueued on `signaler_stream` before this call has finished (HIP event). */
 int rgbl_stream_wait(void* waiter_stream, void* signaler_stream);
@@ -294,6 +286,7 @@ void rgbl_matcher_destroy(rgbl_matcher* h);
 int rgbl_matcher_acquire(int device, rgbl_matcher** out);
 void rgbl_matcher_release(rgbl_matcher* h);
 int rgbl_matcher_pool_size(void);  /* idle handles (diagnostics / tests) */
+int rgbl_matcher_pool_clear(void); /* destroys the idle handles (streams, device arenas, page-locked blocks): orderly shutdown; returns how many */
 int rgbl_matcher_sync(rgbl_matcher* h);
 int rgbl_matcher_set_stream(rgbl_matcher* h, void* hip_stream);
 void* rgbl_matcher_stream(rgbl_matcher* h);

@@ -115,8 +115,6 @@ SYMBOLS = {
     "rgbl_device_count": (_I, []),
     "rgbl_extractor_create": (_I, [C.POINTER(ExtractorCfg), _I, C.POINTER(_V)]),
     "rgbl_extractor_destroy": (None, [_V]),
-    "rgbl_extractor_pixel_event": (_V, [_V]),
-    "rgbl_extractor_set_gate": (_I, [_V, _V]),
     "rgbl_extractor_tables": (_I, [_V, _V, _V, _V, _V, _V, _V]),
     "rgbl_extractor_max_keypoints": (_I, [_V]),
     "rgbl_extract": (_I, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _I, C.POINTER(_I), C.POINTER(_I)]),
@@ -170,6 +168,7 @@ SYMBOLS = {
     "rgbl_matcher_acquire": (_I, [_I, C.POINTER(_V)]),
     "rgbl_matcher_release": (None, [_V]),
     "rgbl_matcher_pool_size": (_I, []),
+    "rgbl_matcher_pool_clear": (_I, []),
     "rgbl_hamming_bf": (_I, [_V, _V, _I, _V, _I, _V, _V, _V]),
     "rgbl_stereo_fisheye_matches": (_I, [_V, _V, _I, _I, _V, _I, _I, _V, _V, _V]),
     "rgbl_hamming_bf_batch_device": (_I, [_V, _V, _V, _I, _V, _V, _I, _V, _V, _V]),

@@ -198,12 +198,15 @@ __device__ __forceinline__ uint32_t load_u32_any(const uint8_t* p) {  // global 
 // halo pixels / cache lines of one frame sit on 8 different L2s and every line leaves the fabric up to 8 times.  With the
 // grid (8, items, frames / 8) blockIdx.x IS the XCD, and XCD x works on the frames z * 8 + x: the neighbours of a frame
 // share an L2 (FETCH_SIZE of k_fast_cells: 4.3 x the image bytes before, 0.9 x after).  Frame counts that are not a
-// multiple of 8 (or RGBL_XCD_MAP=0) take the grid (1, items, frames).
+// multiple of 8 (or RGBL_XCD_MAP=0) take the grid (1, items, frames).  grid.y is limited to 65535: more items per frame than
+// that (a 4096 x 4096 image at scale 1.1 with 16 levels has more detection cells) take the plain grid (items, 1, frames),
+// which the kernels recognise by gridDim.x > 8.
 inline dim3 xcd_grid(bool enabled, unsigned items, unsigned frames) {
+  if (items > 65535u) return dim3(items, 1, frames);
   return (enabled && frames % 8u == 0u) ? dim3(8, items, frames / 8u) : dim3(1, items, frames);
 }
-__device__ __forceinline__ int xcd_frame() { return (int)(blockIdx.z * gridDim.x + blockIdx.x); }
-__device__ __forceinline__ int xcd_item() { return (int)blockIdx.y; }
+__device__ __forceinline__ int xcd_frame() { return gridDim.x > 8u ? (int)blockIdx.z : (int)(blockIdx.z * gridDim.x + blockIdx.x); }
+__device__ __forceinline__ int xcd_item() { return gridDim.x > 8u ? (int)blockIdx.x : (int)blockIdx.y; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

@@ -52,8 +52,6 @@ struct rgbl_extractor {
   hipStream_t stream = nullptr, own_stream = nullptr;
   hipStream_t aux_stream = nullptr;  // the Gaussian working images only depend on the pyramid: they overlap FAST + quad-tree
   hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_fast0 = nullptr;
-  hipEvent_t ev_pixels = nullptr;  // recorded behind the last pixel kernel (FAST) of an extraction
-  hipEvent_t gate = nullptr;       // not owned: the extraction starts only after this event (another handle's ev_pixels)
   KernelTimer timer;
   // hipGraph of the host-pointer path (all device pointers of that path are the handle's own buffers, so one captured
   // launch sequence can be replayed): key = (batch, row stride, lapping area, stream)
@@ -421,7 +419,6 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   const int L = e->L;
   hipStream_t s = e->stream;
   e->last_img0 = d_imgs; e->last_pitch0 = stride; e->last_frame0 = frame_stride; e->last_batch = batch;
-  if (e->gate) RGBL_HIP(hipStreamWaitEvent(s, e->gate, 0));  // software pipelining across handles (rgbl_extractor_set_gate)
   if (e->dense && e->dense_dirty) RGBL_HIP(hipMemsetAsync(e->d_levelcnt, 0, sizeof(uint32_t) * (size_t)e->cfg.max_batch * L, s));
   e->dense_dirty = e->dense;  // cleared at the end of a complete enqueue: the quad-tree workgroups leave the counters at zero
 
@@ -525,7 +522,6 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
     } else {
       launch_fast(s, 0, e->cells_frame);
     }
-    RGBL_HIP(hipEventRecord(e->ev_pixels, s));
     // 3. quad-tree distribution (ORBextractor.cc:555-779) of the remaining levels (level 0 went with its FAST cells above)
     if (overlap) {
       launch_octree(s, 1, L);
@@ -636,8 +632,7 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
                         hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&e->ev_fast0, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&e->ev_pixels, hipEventDisableTiming) != hipSuccess)) {
+                        hipEventCreateWithFlags(&e->ev_fast0, hipEventDisableTiming) != hipSuccess)) {
     set_error("hipStreamCreate failed");
     rc = RGBL_ERR_HIP;
   }
@@ -665,7 +660,6 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   if (e->h_pinned) (void)hipHostFree(e->h_pinned);
   if (e->ev_start) (void)hipEventDestroy(e->ev_start);
   if (e->ev_fast0) (void)hipEventDestroy(e->ev_fast0);
-  if (e->ev_pixels) (void)hipEventDestroy(e->ev_pixels);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -1055,12 +1049,6 @@ int rgbl_extractor_set_stream(rgbl_extractor* e, void* hip_stream) {
 
 void* rgbl_extractor_stream(rgbl_extractor* e) { return e ? (void*)e->stream : nullptr; }
 void* rgbl_extractor_aux_stream(rgbl_extractor* e) { return e ? (void*)e->aux_stream : nullptr; }
-void* rgbl_extractor_pixel_event(rgbl_extractor* e) { return e ? (void*)e->ev_pixels : nullptr; }
-int rgbl_extractor_set_gate(rgbl_extractor* e, void* event) {
-  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
-  e->gate = (hipEvent_t)event;
-  return RGBL_OK;
-}
 
 int rgbl_stream_wait(void* waiter, void* signaler) {
   // everything enqueued on `signaler` so far must finish before work enqueued on `waiter` after this call starts

@@ -1236,14 +1236,15 @@ int ensure_arena(rgbl_matcher* m, size_t bytes) {
   return RGBL_OK;
 }
 // RGBL_BF_MFMA=0 selects the VALU popcount scan (k_hamming_bf) instead of the matrix-core one (A/B measurements)
+// (read per call: a getenv is nothing next to a launch, and the tests switch variants inside one process)
 inline bool bf_on_matrix_cores() {
-  static const bool on = [] { const char* e = getenv("RGBL_BF_MFMA"); return !(e && e[0] == '0'); }();
-  return on;
+  const char* e = getenv("RGBL_BF_MFMA");
+  return !(e && e[0] == '0');
 }
 // RGBL_BF_MFMA=i8 keeps the i8 instruction (k_hamming_mfma); default: the block-scaled FP4 one (k_hamming_fp4)
 inline bool bf_on_fp4() {
-  static const bool on = [] { const char* e = getenv("RGBL_BF_MFMA"); return !(e && e[0] == 'i'); }();
-  return on;
+  const char* e = getenv("RGBL_BF_MFMA");
+  return !(e && e[0] == 'i');
 }
 struct Arena {
   uint8_t* base; size_t off = 0;
@@ -1330,9 +1331,26 @@ void rgbl_matcher_release(rgbl_matcher* m) {
     (void)hipStreamSynchronize(m->stream);
     m->stream = m->own_stream;
   }
+  if (m->timer.enabled || !m->timer.recs.empty()) {  // the next owner must not inherit profiling brackets
+    (void)hipStreamSynchronize(m->stream);
+    m->timer.collect();
+    m->timer.enabled = false;
+  }
+  m->timer.reset();
   MatcherPool& P = *matcher_pool_ptr();
   std::lock_guard<std::mutex> lock(P.mu);
   P.idle.push_back(m);
+}
+
+int rgbl_matcher_pool_clear(void) {
+  std::vector<rgbl_matcher*> idle;
+  {
+    MatcherPool& P = *matcher_pool_ptr();
+    std::lock_guard<std::mutex> lock(P.mu);
+    idle.swap(P.idle);
+  }
+  for (rgbl_matcher* m : idle) rgbl_matcher_destroy(m);
+  return (int)idle.size();
 }
 
 int rgbl_matcher_pool_size(void) {

@@ -45,6 +45,9 @@ __global__ __launch_bounds__(256) void k_pack_records(const int32_t* __restrict_
   }
 }
 
+// an empty batch still leaves its one offset behind (the header promises d_offsets[batch])
+__global__ void k_pack_records_empty(long long first_record, long long* __restrict__ offsets) { offsets[0] = first_record; }
+
 }  // namespace rgbl
 
 extern "C" int rgbl_pack_records_device(void* hip_stream, const int32_t* d_n, const rgbl_keypoint* d_kp, const uint8_t* d_desc,
@@ -56,7 +59,11 @@ extern "C" int rgbl_pack_records_device(void* hip_stream, const int32_t* d_n, co
     set_error("invalid argument");
     return RGBL_ERR_INVALID;
   }
-  if (batch == 0) return RGBL_OK;
+  if (batch == 0) {
+    hipLaunchKernelGGL(k_pack_records_empty, dim3(1), dim3(1), 0, (hipStream_t)hip_stream, first_record, d_offsets);
+    RGBL_HIP(hipGetLastError());
+    return RGBL_OK;
+  }
   hipLaunchKernelGGL(k_pack_records, dim3(batch), dim3(256), 0, (hipStream_t)hip_stream, d_n,
                      reinterpret_cast<const uint32_t*>(d_kp), reinterpret_cast<const uint32_t*>(d_desc),
                      reinterpret_cast<const uint32_t*>(d_depth), reinterpret_cast<const uint32_t*>(d_uright), cap, first_record,

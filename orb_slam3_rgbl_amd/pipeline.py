@@ -9,10 +9,14 @@ gather of 8(e):
   phase 2  the compacted records (68 B per keypoint, `rgbl_pack_records_device`) by point-to-point send / recv, the root
            posting one receive of the exact size per peer (on MI355X one xGMI link per peer, in parallel; a ring would be
            per-link bound and is the wrong shape).
-`gather="step"` (default) streams every step's records to the root while the next step computes: the pack runs on a
-communication stream behind the step's last readers, and the exchange of step k is posted after step k + 1 has been
-enqueued, so the host never waits for the GPU it is feeding.  `gather="final"` keeps the compacted records of every step in
-HBM and exchanges them once at the end; `gather="none"` does no exchange.
+`gather="step"` streams every step's records to the root while the next step computes.  Per step k, on the communication
+stream and in this order: the pack of step k behind the step's last writers, the all-gather of its counts and their copy
+into page-locked host memory (asynchronous, an event marks them).  The host touches those counts only one step later, after
+step k + 1 has been enqueued, posts the exact-size transfers of step k and goes on: it never waits for the step it has just
+queued, only for the one before, so the GPU always has a full step of work ahead of the host.  `gather="final"` keeps the
+compacted records of every step in HBM and exchanges them once at the end (no host synchronisation inside the run);
+`gather="none"` does no exchange.  With one rank the same choreography runs (pack on the communication stream, counts through
+the page-locked block, the root's device copy, the events) without a peer - and through RCCL when a process group exists.
 PyTorch is plumbing here: device memory, streams and torch.distributed.
 """
 import ctypes as C
@@ -60,21 +64,13 @@ class OutSet:
 
 class FrontEndPipeline:
     def __init__(self, lib, torch, dev, w, h, nfeatures, proj, n_points, batch, levels=8, scale=1.2, ini_th=12, min_th=7,
-                 world=1, rank=0, gather="step", serial=False, keep_steps=0, log_steps=1, split=1):
+                 world=1, rank=0, gather="step", serial=False, keep_steps=0, log_steps=1):
         self.lib, self.torch, self.dev = lib, torch, dev
         self.w, self.h, self.B, self.n_points = w, h, batch, n_points
-        self.world, self.rank, self.gather = world, rank, gather if world > 1 else "none"
+        self.world, self.rank, self.gather = world, rank, gather
         index = dev.index if dev.type == "cuda" else 0
-        # split = 2: two extractor handles with half the batch each, gated on one another's pixel phase (rgbl_extractor_set_gate):
-        # while one half is in its quad-tree / descriptor phase (dependent chains and gathers, low utilisation) the other
-        # half's pyramid / FAST / Gaussian kernels fill the chip
-        self.split = split if (split > 1 and batch % split == 0 and not serial) else 1
-        self.exs = [F.ORBextractor(nfeatures, scale, levels, ini_th, min_th, w, h, max_batch=batch // self.split, device=index, lib=lib)
-                    for _ in range(self.split)]
+        self.exs = [F.ORBextractor(nfeatures, scale, levels, ini_th, min_th, w, h, max_batch=batch, device=index, lib=lib)]
         self.ex = self.exs[0]
-        if self.split == 2:
-            for a, b in ((0, 1), (1, 0)):
-                L.check(lib, lib.rgbl_extractor_set_gate(self.exs[a].h, C.c_void_p(lib.rgbl_extractor_pixel_event(self.exs[b].h))))
         self.cap = self.ex.max_keypoints
         self.dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=self.cap, max_batch=batch, device=index, lib=lib)
         self.mt = F.ORBmatcher(0.6, False, device=index, lib=lib)
@@ -96,17 +92,27 @@ class FrontEndPipeline:
         self.pair_b = (self.pair_a + 1) % batch
         self.step_no = 0
         # ---- gather state
-        self.comm_stream = torch.cuda.Stream(dev) if (self.gather != "none" and dev.type == "cuda") else None
+        self.cuda = dev.type == "cuda"
+        self.comm_stream = torch.cuda.Stream(dev) if (self.gather != "none" and self.cuda) else None
         self.s_comm = C.c_void_p(self.comm_stream.cuda_stream) if self.comm_stream is not None else C.c_void_p(None)
         self.pending = None         # the step whose records are packed but not exchanged yet
         self.received = []          # root: per exchanged step, per rank (counts [B] int32 on the host, records uint8 tensor)
         self.keep = keep_steps      # root keeps the records of at most this many steps (0 = only the last)
+        self.n_exchanged = 0
+        self.dist = None
         if self.gather != "none":
+            import torch.distributed as dist
+            if world > 1 or dist.is_initialized():
+                self.dist = dist    # one rank with a process group: the collectives still go through the backend
             slots = 2 if self.gather == "step" else max(log_steps, 1)   # 'final': one slot per step of the run
             rec_cap = batch * self.cap
             self.send = [torch.zeros(rec_cap * RECORD_BYTES, dtype=torch.uint8, device=dev) for _ in range(slots)]
             self.offsets = [torch.zeros(batch + 1, dtype=torch.int64, device=dev) for _ in range(slots)]
             self.counts = [torch.zeros(batch, dtype=torch.int32, device=dev) for _ in range(slots)]
+            # counts of every rank: gathered on the device, read by the host from a page-locked copy behind an event
+            self.all_counts = [[torch.zeros(batch, dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(slots)]
+            self.host_counts = [torch.zeros((world, batch), dtype=torch.int32, pin_memory=self.cuda) for _ in range(slots)]
+            self.counts_ready = [torch.cuda.Event() if self.cuda else None for _ in range(slots)]
             self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
             self.recv = None
             if rank == 0:
@@ -127,10 +133,6 @@ class FrontEndPipeline:
     def serialise(self):
         """All handles on the extractor's stream (the per-kernel timing leg of bench.py)."""
         one = C.c_void_p(self.lib.rgbl_extractor_stream(self.exs[-1].h))
-        for e in self.exs[:-1]:
-            L.check(self.lib, self.lib.rgbl_extractor_set_stream(e.h, one))
-            L.check(self.lib, self.lib.rgbl_extractor_set_gate(e.h, None))
-        L.check(self.lib, self.lib.rgbl_extractor_set_gate(self.exs[-1].h, None))
         L.check(self.lib, self.lib.rgbl_depth_set_stream(self.dm.h, one))
         L.check(self.lib, self.lib.rgbl_matcher_set_stream(self.mt.h, one))
         self._streams()
@@ -154,7 +156,7 @@ class FrontEndPipeline:
         lib, p, B, w, h, cap = self.lib, self._p, self.B, self.w, self.h, self.cap
         o = self.sets[self.step_no % 2]
         # this set's readers of two steps ago must be done before the extractors overwrite it
-        half = B // self.split
+        half = B
         for i, (e, s_e) in enumerate(zip(self.exs, self.s_exs)):
             L.check(lib, lib.rgbl_event_wait(s_e, o.ev["depth_done"]))
             L.check(lib, lib.rgbl_event_wait(s_e, o.ev["match_done"]))
@@ -178,51 +180,68 @@ class FrontEndPipeline:
         L.check(lib, lib.rgbl_event_record(o.ev["match_done"], self.s_mt))
         if self.gather != "none":
             prev = self.pending
-            self._pack(o)
             if self.gather == "step" and prev is not None:
-                self._exchange(prev)   # step k - 1's records travel while step k computes
+                # step k - 1's records travel while step k (queued above) computes.  Posted BEFORE the pack of step k: the
+                # communication stream is in order, and behind that pack the exchange would wait for the step just queued.
+                self._exchange(prev)
+            self._pack(o)
         self.step_no += 1
 
     # ---- gather ------------------------------------------------------------------------------------------------
+    def _comm(self):
+        return self.torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else _Null()
+
     def _pack(self, o):
-        """Compaction of the step's results on the communication stream, behind the step's last writers."""
+        """Compaction of the step's results on the communication stream, behind the step's last writers; phase 1 of the
+        gather (the counts of every rank) follows it on the same stream and ends in page-locked host memory."""
         lib, p = self.lib, self._p
         slot = self.step_no % len(self.send)
         L.check(lib, lib.rgbl_event_wait(self.s_comm, o.ev["depth_done"]))
         L.check(lib, lib.rgbl_event_wait(self.s_comm, o.ev["match_done"]))
         L.check(lib, lib.rgbl_pack_records_device(self.s_comm, p(o.n), p(o.kp), p(o.desc), p(o.depth), p(o.uright), self.B, self.cap, 0,
                                                   self.B * self.cap, p(self.send[slot]), p(self.offsets[slot]), p(self.overflow)))
-        ctx = self.torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else _Null()
-        with ctx:
+        with self._comm():
             self.counts[slot].copy_(o.n)  # the set is free again once the records and the counts are copied out
         L.check(lib, lib.rgbl_event_record(o.ev["comm_done"], self.s_comm))
+        if self.gather == "step":
+            self._gather_counts([slot])
         self.pending = slot
 
+    def _gather_counts(self, slots):
+        """Phase 1: per-frame counts of every rank for the given slots -> host_counts[slot] (asynchronous on a GPU)."""
+        with self._comm():
+            for slot in slots:
+                if self.dist is not None:
+                    self.dist.all_gather(self.all_counts[slot], self.counts[slot])
+                else:
+                    self.all_counts[slot][0].copy_(self.counts[slot])
+                for r in range(self.world):
+                    self.host_counts[slot][r].copy_(self.all_counts[slot][r], non_blocking=True)
+                if self.cuda:
+                    self.counts_ready[slot].record(self.comm_stream)
+
     def _exchange(self, slot):
-        """Two-phase gather of one packed step to rank 0."""
-        import torch.distributed as dist
-        torch, world, rank, B = self.torch, self.world, self.rank, self.B
-        ctx = torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else _Null()
-        with ctx:
-            # phase 1: per-frame counts of every rank
-            all_counts = [torch.empty_like(self.counts[slot]) for _ in range(world)]
-            dist.all_gather(all_counts, self.counts[slot])
-            host_counts = [c.cpu().numpy() for c in all_counts]            # waits for the pack of THIS slot only
-            totals = [int(np.minimum(np.maximum(c, 0), self.cap).sum()) for c in host_counts]
-            # phase 2: exact-size point-to-point transfers, one per peer
+        """Phase 2 of the gather of one packed step to rank 0: exact-size point-to-point transfers, one per
+        peer, sized by the counts phase 1 left in page-locked memory."""
+        torch, world, rank = self.torch, self.world, self.rank
+        if self.cuda:
+            self.counts_ready[slot].synchronize()   # an event of an EARLIER step in gather='step': already signalled or about to be
+        host_counts = [self.host_counts[slot][r].numpy().copy() for r in range(world)]
+        totals = [int(np.minimum(np.maximum(c, 0), self.cap).sum()) for c in host_counts]
+        with self._comm():
             ops = []
             if rank == 0:
-                self.n_exchanged = getattr(self, "n_exchanged", 0) + 1
+                self.n_exchanged += 1
                 bank = self.recv[self.n_exchanged % 2]
                 for r in range(1, world):
                     if totals[r] > 0:
-                        ops.append(dist.P2POp(dist.irecv, bank[r][:totals[r] * RECORD_BYTES], r))
+                        ops.append(self.dist.P2POp(self.dist.irecv, bank[r][:totals[r] * RECORD_BYTES], r))
                 bank[0][:totals[0] * RECORD_BYTES].copy_(self.send[slot][:totals[0] * RECORD_BYTES])
             elif totals[rank] > 0:
-                ops.append(dist.P2POp(dist.isend, self.send[slot][:totals[rank] * RECORD_BYTES], 0))
+                ops.append(self.dist.P2POp(self.dist.isend, self.send[slot][:totals[rank] * RECORD_BYTES], 0))
             if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
+                for req in self.dist.batch_isend_irecv(ops):
+                    req.wait()   # nccl: orders the communication stream behind the transfer, the host goes on
             if rank == 0:
                 got = [(host_counts[r], bank[r][:totals[r] * RECORD_BYTES]) for r in range(world)]
                 if self.keep:
@@ -239,8 +258,10 @@ class FrontEndPipeline:
             self._exchange(self.pending)
         elif self.gather == "final":
             first = max(self.step_no - len(self.send), 0)
-            for k in range(first, self.step_no):
-                self._exchange(k % len(self.send))
+            slots = [k % len(self.send) for k in range(first, self.step_no)]
+            self._gather_counts(slots)
+            for slot in slots:
+                self._exchange(slot)
         if self.comm_stream is not None:
             self.comm_stream.synchronize()
 

@@ -1256,3 +1256,49 @@ def check_search_by_projection_sim3(lib, seed=151, th=8, proj_form=0, ratio=1.5,
     assert not np.array_equal(free, om)
     mt.close()
     return on
+
+
+def check_pipeline_gather(lib, mode, dev=None, w=620, h=188, nfeatures=800, batch=16, steps=4, n_az=600, levels=8):
+    """The batched step + the gather of its records (orb_slam3_rgbl_amd/pipeline.py) with ONE rank: what the root holds after
+    every step must decode to that step's own outputs, and those to the oracle's."""
+    import torch
+
+    from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline, unpack_records
+    dev = dev or torch.device("cuda", 0)
+    K = synth.KITTI_K.copy()
+    K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    proj = F.projection_matrix(K, synth.KITTI_TR, lib)
+    sq = synth.Sequence(70, w, h, n_frames=batch)
+    frames = np.stack([sq.frame(i) for i in range(batch)])
+    cloud = np.stack([synth.lidar_scan(700 + i, n_az=n_az) for i in range(batch)])
+    pipe = FrontEndPipeline(lib, torch, dev, w, h, nfeatures, proj, cloud.shape[2], batch, levels=levels, ini_th=20, min_th=7, world=1, rank=0,
+                            gather=mode, keep_steps=steps, log_steps=steps)
+    pipe.set_inputs(torch.from_numpy(frames).to(dev), torch.from_numpy(cloud).to(dev))
+    for _ in range(steps):
+        pipe.step()
+    pipe.finish()
+    pipe.sync()
+    assert len(pipe.received) == steps
+    o = pipe.last()
+    n = o.n.cpu().numpy()
+    assert n.min() > 50
+    kp, desc, depth, uright = (t.cpu().numpy() for t in (o.kp, o.desc, o.depth, o.uright))
+    for got in pipe.received:             # every step processed the same resident batch
+        counts, rec = got[0]
+        assert np.array_equal(counts, n)
+        fr = unpack_records(rec.cpu().numpy(), counts)
+        for f in range(batch):
+            m = int(n[f])
+            assert np.array_equal(fr[f]["kp"], kp[f, :m].view(np.uint8).reshape(m, 28))
+            assert np.array_equal(fr[f]["desc"], desc[f, :m])
+            assert np.array_equal(bits(fr[f]["depth"]), bits(depth[f, :m])) and np.array_equal(bits(fr[f]["uright"]), bits(uright[f, :m]))
+    orc = O.Extractor(nfeatures, 1.2, levels, 20, 7)
+    P = O.make_depth_params(proj)
+    fr = unpack_records(pipe.received[-1][0][1].cpu().numpy(), pipe.received[-1][0][0])
+    for f in (0, batch // 2, batch - 1):
+        okps, odesc, _ = orc(frames[f])
+        assert fr[f]["n"] == len(okps) and np.array_equal(fr[f]["kp"], okps.view(np.uint8).reshape(len(okps), 28))
+        assert np.array_equal(fr[f]["desc"], odesc)
+        od, our, _, _ = O.depth(P, cloud[f], w, h, np.stack([okps["x"], okps["y"]], 1), okps["x"], want_maps=False)
+        assert np.array_equal(bits(fr[f]["depth"]), bits(od)) and np.array_equal(bits(fr[f]["uright"]), bits(our))
+    pipe.close()

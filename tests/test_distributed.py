@@ -23,6 +23,11 @@ from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline, unpack_records
 
 W, H, NF, LEVELS, B, STEPS, N_AZ = 200, 160, 300, 4, 3, 3, 240
 MODE = os.environ["RGBL_GATHER"]
+CUDA = os.environ.get("RGBL_DEVICE", "cpu") == "cuda"     # the same worker on real GPUs: backend nccl (= RCCL), product library
+if CUDA:
+    W, H, NF, LEVELS, B, STEPS, N_AZ = 620, 188, 800, 8, 16, 4, 600
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+DEV = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if CUDA else torch.device("cpu")
 
 def inputs_of(rank):
     sq = synth.Sequence(100 + rank, W, H, n_frames=B)
@@ -34,15 +39,27 @@ def make(lib, rank, world, gather, keep=0):
     K = synth.KITTI_K.copy(); K[0, 2], K[1, 2] = W / 2.0, H / 2.0
     proj = F.projection_matrix(K, synth.KITTI_TR, lib)
     frames, cloud = inputs_of(rank)
-    pipe = FrontEndPipeline(lib, torch, torch.device("cpu"), W, H, NF, proj, cloud.shape[2], B, levels=LEVELS, ini_th=20, min_th=7,
+    pipe = FrontEndPipeline(lib, torch, DEV, W, H, NF, proj, cloud.shape[2], B, levels=LEVELS, ini_th=20, min_th=7,
                             world=world, rank=rank, gather=gather, keep_steps=keep, log_steps=STEPS)
-    pipe.set_inputs(torch.from_numpy(frames), torch.from_numpy(cloud))
+    pipe.set_inputs(torch.from_numpy(frames).to(DEV), torch.from_numpy(cloud).to(DEV))
     return pipe, frames, cloud, proj
 
 def main():
-    dist.init_process_group("gloo")
+    if CUDA:
+        dist.init_process_group("nccl", device_id=DEV)
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    lib = _lib.bind(os.environ["RGBL_EMU_LIB"])
+    lib = _lib.load() if CUDA else _lib.bind(os.environ["RGBL_EMU_LIB"])
+    if CUDA and os.environ.get("RGBL_SELF_P2P") == "1":
+        # one rank: a grouped send / receive to itself is the only way its point-to-point path can run through RCCL
+        a = torch.arange(1 << 20, dtype=torch.int32, device=DEV)
+        b = torch.zeros_like(a)
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, a, rank), dist.P2POp(dist.irecv, b, rank)]):
+            req.wait()
+        torch.cuda.synchronize(DEV)
+        assert torch.equal(a, b)
+        print("SELF_P2P_OK")
     pipe, _, _, _ = make(lib, rank, world, MODE, keep=STEPS)
     for _ in range(STEPS):
         pipe.step()
@@ -57,21 +74,22 @@ def main():
             solo, frames, cloud, proj = make(lib, r, 1, "none")
             solo.step(); solo.sync()
             o = solo.last()
-            n = o.n.numpy()
+            n = o.n.cpu().numpy()
+            s_kp, s_desc, s_depth, s_uright = (t.cpu().numpy() for t in (o.kp, o.desc, o.depth, o.uright))
             for got in pipe.received:                      # every step processed the same resident batch
                 counts, rec = got[r]
                 ok &= np.array_equal(counts, n)
-                fr = unpack_records(rec.numpy(), counts)
+                fr = unpack_records(rec.cpu().numpy(), counts)
                 for f in range(B):
                     m = int(n[f])
-                    ok &= np.array_equal(fr[f]["kp"], o.kp[f, :m].numpy().view(np.uint8).reshape(m, 28))
-                    ok &= np.array_equal(fr[f]["desc"], o.desc[f, :m].numpy())
-                    ok &= np.array_equal(fr[f]["depth"].view(np.uint32), o.depth[f, :m].numpy().view(np.uint32))
-                    ok &= np.array_equal(fr[f]["uright"].view(np.uint32), o.uright[f, :m].numpy().view(np.uint32))
+                    ok &= np.array_equal(fr[f]["kp"], s_kp[f, :m].view(np.uint8).reshape(m, 28))
+                    ok &= np.array_equal(fr[f]["desc"], s_desc[f, :m])
+                    ok &= np.array_equal(fr[f]["depth"].view(np.uint32), s_depth[f, :m].view(np.uint32))
+                    ok &= np.array_equal(fr[f]["uright"].view(np.uint32), s_uright[f, :m].view(np.uint32))
             # and the records decode to the oracle's results
             orc = O.Extractor(NF, 1.2, LEVELS, 20, 7)
             P = O.make_depth_params(proj)
-            fr = unpack_records(pipe.received[-1][r][1].numpy(), pipe.received[-1][r][0])
+            fr = unpack_records(pipe.received[-1][r][1].cpu().numpy(), pipe.received[-1][r][0])
             for f in range(B):
                 okps, odesc, _ = orc(frames[f])
                 ok &= fr[f]["n"] == len(okps) and np.array_equal(fr[f]["kp"], okps.view(np.uint8).reshape(len(okps), 28))
@@ -141,4 +159,37 @@ def test_two_rank_gather_equals_single_process(tmp_path, oracle, emu_lib, mode, 
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=600)
+    assert "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def _run_on_gpus(tmp_path, nproc, mode, port, self_p2p=False):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, RGBL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", RGBL_GATHER=mode, RGBL_DEVICE="cuda",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", RGBL_SELF_P2P="1" if self_p2p else "0")
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                          env=env, capture_output=True, text=True, timeout=420)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,port", [("step", 29531), ("final", 29533)])
+def test_rccl_gather_with_one_rank(tmp_path, oracle, gpu_lib, mode, port):
+    """ONE rank, backend nccl: process-group initialisation, the all-gather of the counts and (a grouped send / receive of the
+    rank to itself) the point-to-point path run through RCCL on the hardware, around the same pipeline the N > 1 bench runs.
+    What the root holds must equal a plain single-process run and decode to the oracle's results."""
+    out = _run_on_gpus(tmp_path, 1, mode, port, self_p2p=(mode == "step"))
+    assert "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    if mode == "step":
+        assert "SELF_P2P_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,port", [("step", 29535), ("final", 29537)])
+def test_rccl_gather_two_ranks(tmp_path, oracle, gpu_lib, mode, port):
+    """Two ranks on two GPUs over RCCL / xGMI (skipped on the one-GPU boxes of the pool)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    out = _run_on_gpus(tmp_path, 2, mode, port)
     assert "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -247,9 +247,36 @@ def test_matcher_handle_pool(emu_lib):
     h4 = C.c_void_p()
     L.check(emu_lib, emu_lib.rgbl_matcher_acquire(0, C.byref(h4)))   # a parked handle is handed out again, none is created
     assert h4.value in (h2.value, h3.value, h1.value) and emu_lib.rgbl_matcher_pool_size() == n - 1
+    # profiling brackets of one owner are not inherited by the next one
+    L.check(emu_lib, emu_lib.rgbl_matcher_profile(h4, 1))
+    import numpy as np
+    rng = np.random.default_rng(1)
+    a, b = (rng.integers(0, 256, (40, 32), dtype=np.uint8) for _ in range(2))
+    bi, bd, sd = (np.zeros(40, np.int32) for _ in range(3))
+    L.check(emu_lib, emu_lib.rgbl_hamming_bf(h4, a.ctypes.data, 40, b.ctypes.data, 40, bi.ctypes.data, bd.ctypes.data, sd.ctypes.data))
     emu_lib.rgbl_matcher_release(h4)
+    h5 = C.c_void_p()
+    L.check(emu_lib, emu_lib.rgbl_matcher_acquire(0, C.byref(h5)))
+    names = (C.c_char_p * 8)()
+    ms = (C.c_double * 8)()
+    launches = (C.c_long * 8)()
+    k = emu_lib.rgbl_matcher_profile_read(h5, names, ms, launches, 8)
+    assert all(launches[i] == 0 for i in range(min(k, 8)))
+    L.check(emu_lib, emu_lib.rgbl_hamming_bf(h5, a.ctypes.data, 40, b.ctypes.data, 40, bi.ctypes.data, bd.ctypes.data, sd.ctypes.data))
+    k = emu_lib.rgbl_matcher_profile_read(h5, names, ms, launches, 8)
+    assert all(launches[i] == 0 for i in range(min(k, 8)))     # profiling is off again
+    emu_lib.rgbl_matcher_release(h5)
+    # orderly shutdown: the idle handles are destroyed
+    n = emu_lib.rgbl_matcher_pool_size()
+    assert n >= 1 and emu_lib.rgbl_matcher_pool_clear() == n and emu_lib.rgbl_matcher_pool_size() == 0
 
 
 def test_extractor_batch_of_eight_takes_the_xcd_aware_mapping(emu_lib):
     # frames % 8 == 0: the pixel kernels remap workgroup -> (item, frame) so that an XCD covers whole frames
     pc.check_extractor_batch(emu_lib, 400, 300, 500, 8)
+
+
+@pytest.mark.parametrize("mode", ["step", "final"])
+def test_gather_choreography_with_one_rank(emu_lib, mode):
+    import torch
+    pc.check_pipeline_gather(emu_lib, mode, dev=torch.device("cpu"), w=240, h=160, nfeatures=300, batch=3, steps=3, n_az=240, levels=4)

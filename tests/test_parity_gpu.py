@@ -230,3 +230,103 @@ def test_stereo_fisheye_matches(gpu_lib):
     pc.check_stereo_fisheye_matches(gpu_lib, 9000, 8800, 100, 300, seed=8)
     pc.check_stereo_fisheye_matches(gpu_lib, 70, 3, 0, 2)
     pc.check_stereo_fisheye_matches(gpu_lib, 50, 40, 50, 10)
+
+
+# ---- kernels that can be dispatched but are not on the default path ("missing" 1 and 2) -------------------------
+
+def test_extractor_initialisation_extractor_uses_the_key_moving_quadtree(gpu_lib):
+    # Tracking.cc:601 builds the monocular initialisation extractor with 5 * nFeatures: 10 000 features on KITTI need more than
+    # 2048 quad-tree nodes on level 0, i.e. k_octree_moving (node lists in global memory) instead of the label-based kernel
+    n = pc.check_extractor(gpu_lib, synth.KITTI_W, synth.KITTI_H, 10000, frames=(0, 1), seq=12)
+    assert n > 2 * 8000
+    pc.check_extractor_batch(gpu_lib, synth.KITTI_W, synth.KITTI_H, 10000, batch=8, seq=13)   # XCD grid + narrow / wide workgroups
+
+
+def test_extractor_key_moving_quadtree_forced(gpu_lib, monkeypatch):
+    # RGBL_OCTREE_NCAP=0: the same kernel on the usual configurations (2000 features), stage by stage
+    monkeypatch.setenv("RGBL_OCTREE_NCAP", "0")
+    pc.check_extractor(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000, frames=(0, 2), seq=2, stages=True)
+    pc.check_extractor(gpu_lib, 752, 480, 1200, frames=(0,), seq=6)
+    pc.check_extractor_empty_root(gpu_lib)
+    pc.check_extractor_edge_cases(gpu_lib)
+    pc.check_extractor_batch(gpu_lib, 480, 320, 700, batch=160, seq=9)        # >= 1024 problems: the 256-wide workgroups
+    monkeypatch.setenv("RGBL_OCTREE_NCAP", "2048")
+    pc.check_extractor(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000, frames=(0,), seq=2)   # label-based kernel, 2048-node LDS lists
+
+
+@pytest.mark.parametrize("variant", ["i8", "0"])
+def test_matcher_bf_other_hamming_kernels(gpu_lib, monkeypatch, variant):
+    # RGBL_BF_MFMA=i8: k_hamming_mfma (v_mfma_i32_32x32x32_i8); =0: k_hamming_bf (VALU popcount).  Default: k_hamming_fp4.
+    monkeypatch.setenv("RGBL_BF_MFMA", variant)
+    pc.check_matcher_known_answers(gpu_lib)
+    pc.check_matcher_bf(gpu_lib, 2000, 2000)
+    pc.check_matcher_bf(gpu_lib, 8000, 8000, seed=5)
+    pc.check_matcher_bf(gpu_lib, 1, 333)
+    pc.check_matcher_bf(gpu_lib, 257, 1)
+    pc.check_matcher_bf(gpu_lib, 9000, 8800, seed=6)    # more than one sweep of 8192 train rows
+    pc.check_stereo_fisheye_known_answers(gpu_lib)
+    assert pc.check_stereo_fisheye_matches(gpu_lib, 2400, 2300, 800, 700) > 500
+
+
+def test_pack_records_on_the_device(gpu_lib):
+    # k_pack_records (records.hip) against a numpy pack: 68-byte records, frames back to back, offsets, overflow flag
+    import ctypes as C
+
+    import torch
+
+    from orb_slam3_rgbl_amd import _lib as L
+    from orb_slam3_rgbl_amd.pipeline import RECORD_BYTES, unpack_records
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for B, cap, first in ((4, 50, 0), (512, 2411, 0), (37, 300, 123), (1, 7, 0)):
+        n_h = rng.integers(-3, cap + 20, B).astype(np.int32)          # counts outside [0, cap] are clamped like the readers do
+        n_h[0] = cap
+        if B > 2:
+            n_h[1] = 0
+        kp_h = rng.integers(0, 2 ** 32, (B, cap, 7), dtype=np.uint32)
+        desc_h = rng.integers(0, 256, (B, cap, 32), dtype=np.uint8)
+        dep_h = rng.integers(0, 2 ** 32, (B, cap), dtype=np.uint32)
+        ur_h = rng.integers(0, 2 ** 32, (B, cap), dtype=np.uint32)
+        n, kp, desc, dep, ur = (torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(dev) for a in (n_h, kp_h, desc_h, dep_h, ur_h))
+        cl = np.clip(n_h, 0, cap)
+        total = int(cl.sum())
+        out = torch.full(((first + total) * RECORD_BYTES + 64,), 0xEE, dtype=torch.uint8, device=dev)
+        off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        L.check(gpu_lib, gpu_lib.rgbl_pack_records_device(C.c_void_p(s.cuda_stream), p(n), p(kp), p(desc), p(dep), p(ur), B, cap, first,
+                                                          first + total, p(out), p(off), p(ovf)))
+        s.synchronize()
+        assert int(ovf.cpu()[0]) == 0
+        assert np.array_equal(off.cpu().numpy(), first + np.concatenate([[0], np.cumsum(cl)]))
+        o = out.cpu().numpy()
+        assert (o[:first * RECORD_BYTES] == 0xEE).all() and (o[(first + total) * RECORD_BYTES:] == 0xEE).all()   # nothing outside its range
+        want = np.concatenate([np.concatenate([kp_h[f, :m].view(np.uint8).reshape(m, 28), desc_h[f, :m],
+                                               dep_h[f, :m, None].view(np.uint8).reshape(m, 4),
+                                               ur_h[f, :m, None].view(np.uint8).reshape(m, 4)], 1) for f, m in enumerate(cl)])
+        assert np.array_equal(o[first * RECORD_BYTES:(first + total) * RECORD_BYTES].reshape(total, RECORD_BYTES), want)
+        fr = unpack_records(o[first * RECORD_BYTES:], cl)
+        assert all(fr[f]["n"] == cl[f] for f in range(B))
+        # one record short: the overflow flag goes up and nothing lands behind the buffer's end
+        if total > 0:
+            small = torch.full(((first + total) * RECORD_BYTES,), 0xEE, dtype=torch.uint8, device=dev)
+            L.check(gpu_lib, gpu_lib.rgbl_pack_records_device(C.c_void_p(s.cuda_stream), p(n), p(kp), p(desc), p(dep), p(ur), B, cap, first,
+                                                              first + total - 1, p(small), p(off), p(ovf)))
+            s.synchronize()
+            assert int(ovf.cpu()[0]) == 1
+            assert (small.cpu().numpy()[(first + total - 1) * RECORD_BYTES:] == 0xEE).all()
+    # an empty batch leaves its one offset
+    off = torch.full((1,), -1, dtype=torch.int64, device=dev)
+    L.check(gpu_lib, gpu_lib.rgbl_pack_records_device(None, p(n), p(kp), p(desc), p(dep), p(ur), 0, cap, 5, 5, p(out), p(off), p(ovf)))
+    torch.cuda.synchronize(dev)
+    assert int(off.cpu()[0]) == 5
+
+
+@pytest.mark.parametrize("mode", ["step", "final"])
+def test_gather_choreography_with_one_rank(gpu_lib, mode):
+    # FrontEndPipeline with gather = step | final at world == 1: the pack on the communication stream, the counts through
+    # page-locked memory behind an event, the root's device copy and the comm_done / depth_done / match_done events all
+    # execute on the hardware (no peer, so no RCCL transfer); the records must decode to the step's own outputs
+    pc.check_pipeline_gather(gpu_lib, mode)
