@@ -1258,7 +1258,7 @@ def check_search_by_projection_sim3(lib, seed=151, th=8, proj_form=0, ratio=1.5,
     return on
 
 
-def check_pipeline_gather(lib, mode, dev=None, w=620, h=188, nfeatures=800, batch=16, steps=4, n_az=600, levels=8):
+def check_pipeline_gather(lib, mode, dev=None, w=640, h=360, nfeatures=800, batch=16, steps=4, n_az=600, levels=8):
     """The batched step + the gather of its records (orb_slam3_rgbl_amd/pipeline.py) with ONE rank: what the root holds after
     every step must decode to that step's own outputs, and those to the oracle's."""
     import torch

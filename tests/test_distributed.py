@@ -25,7 +25,7 @@ W, H, NF, LEVELS, B, STEPS, N_AZ = 200, 160, 300, 4, 3, 3, 240
 MODE = os.environ["RGBL_GATHER"]
 CUDA = os.environ.get("RGBL_DEVICE", "cpu") == "cuda"     # the same worker on real GPUs: backend nccl (= RCCL), product library
 if CUDA:
-    W, H, NF, LEVELS, B, STEPS, N_AZ = 620, 188, 800, 8, 16, 4, 600
+    W, H, NF, LEVELS, B, STEPS, N_AZ = 640, 360, 800, 8, 16, 4, 600
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
 DEV = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if CUDA else torch.device("cpu")
 
@@ -169,7 +169,7 @@ def _run_on_gpus(tmp_path, nproc, mode, port, self_p2p=False):
                HSA_ENABLE_IPC_MODE_LEGACY="0", RGBL_SELF_P2P="1" if self_p2p else "0")
     return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
                            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-                          env=env, capture_output=True, text=True, timeout=420)
+                          env=env, capture_output=True, text=True, timeout=240)
 
 
 @pytest.mark.gpu
