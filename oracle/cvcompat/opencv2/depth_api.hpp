@@ -341,3 +341,5 @@ class FileStorage {
 };
 
 }  // namespace cv
+
+#pragma GCC pop_options  // pushed in opencv.hpp

@@ -21,6 +21,12 @@
 
 #include "../../oracle.h"
 
+// The stand-ins below stand for OpenCV's separately compiled library: their arithmetic must not follow the flags of the
+// translation unit that includes them (oracle/Makefile builds the reference's files a second time with the reference's own
+// -O3 -march=native, where GCC contracts a * b + c into FMAs).  Popped at the end of depth_api.hpp.
+#pragma GCC push_options
+#pragma GCC optimize("fp-contract=off")
+
 #define CV_PI 3.1415926535897932384626433832795
 #define CV_8U 0
 #define CV_8UC1 0

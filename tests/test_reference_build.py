@@ -16,15 +16,31 @@ from yaml_cases import PARSE_CASES, yaml_with
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_orbextractor.so")
+BUILDS = ["portable", "native"]   # -O2 -ffp-contract=off | the reference's own -O3 -march=native (CMakeLists.txt:10-13)
 
 
-@pytest.fixture(scope="module")
-def ref(oracle):
+def ref_build(path, build):
+    """Path of the portable or the native build of a reference library; skips when it is not there or (native) was built on
+    another CPU (-march=native code must not run elsewhere)."""
     if os.path.isdir("/root/reference/src"):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
-    if not os.path.exists(REF_SO):
+    if build == "native":
+        path = path.replace(".so", "_native.so")
+        stamp = os.path.join(ROOT, "oracle", "_ref", "native_host.txt")
+        if not (os.path.exists(path) and os.path.exists(stamp)):
+            pytest.skip("oracle/_ref native build not there (needs /root/reference)")
+        here = subprocess.run("g++ -march=native -Q --help=target | grep -E -- '-march=|-mtune=' | tr -s ' \\t' ' '", shell=True,
+                              capture_output=True, text=True).stdout
+        if here != open(stamp).read():
+            pytest.skip("oracle/_ref native build was made on another CPU")
+    if not os.path.exists(path):
         pytest.skip("oracle/_ref not built (needs /root/reference)")
-    lib = C.CDLL(REF_SO)
+    return path
+
+
+@pytest.fixture(scope="module", params=BUILDS)
+def ref(oracle, request):
+    lib = C.CDLL(ref_build(REF_SO, request.param))
     lib.ref_extract.restype = C.c_int
     lib.ref_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
@@ -77,13 +93,9 @@ REF_DEPTH_SO = os.path.join(ROOT, "oracle", "_ref", "libref_depthmodule.so")
 _F = C.c_float
 
 
-@pytest.fixture(scope="module")
-def refdepth(oracle):
-    if os.path.isdir("/root/reference/src"):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
-    if not os.path.exists(REF_DEPTH_SO):
-        pytest.skip("oracle/_ref not built (needs /root/reference)")
-    lib = C.CDLL(REF_DEPTH_SO)
+@pytest.fixture(scope="module", params=BUILDS)
+def refdepth(oracle, request):
+    lib = C.CDLL(ref_build(REF_DEPTH_SO, request.param))
     lib.ref_depth_create.restype = C.c_void_p
     lib.ref_depth_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
     lib.ref_depth_destroy.argtypes = [C.c_void_p]
@@ -680,3 +692,36 @@ def test_reference_compute_stereo_matches_agrees_with_oracle(refframe, w, h, nf,
     assert np.array_equal(ur[:nl].view(np.uint32), our.view(np.uint32)), "mvuRight"
     assert np.array_equal(dp[:nl].view(np.uint32), odp.view(np.uint32)), "mvDepth"
     assert (our >= 0).sum() > 100  # the case must produce matches
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The two other RGB-L settings files the reference ships (Examples/RGB-L/KITTI04-12.yaml, KITTIxx-03.yaml: KITTI sequences
+# 03 - 12) still carry the stale key LiDAR.MethodInverseDilation.KernelSize; DepthModule.cc:566-582 asks for KernelSize_u /
+# KernelSize_v, so ParseUpsamplingParameters fails, CalculateDepthFromPcd returns at once (:52-55) and every keypoint of those
+# sequences keeps mvDepth = -1: as shipped, the reference runs them as monocular frames.  Read in place, not copied.
+SHIPPED = "/root/reference/Examples/RGB-L"
+
+
+@pytest.mark.parametrize("name,fx", [("KITTI04-12.yaml", 707.0912), ("KITTIxx-03.yaml", 721.5377)])
+def test_reference_disables_upsampling_on_its_other_shipped_settings(refdepth, name, fx):
+    path = os.path.join(SHIPPED, name)
+    if not os.path.exists(path):
+        pytest.skip("the reference's Examples/RGB-L is not on this host")
+    R = RefDepth(refdepth, path)
+    assert R.parsed == (True, False)
+    # K * Tr is still built, with this file's intrinsics, as the restated oracle builds it
+    K = synth.KITTI_K.copy()
+    cx, cy = {"KITTI04-12.yaml": (601.8873, 183.1104), "KITTIxx-03.yaml": (609.5593, 172.854)}[name]
+    K[0, 0] = K[1, 1] = fx
+    K[0, 2], K[1, 2] = cx, cy
+    assert np.array_equal(bits(R.proj), bits(O.projection_matrix(K, synth.KITTI_TR)))
+    # and a frame comes back untouched: rc != 0, no depth
+    w, h = 1226, 370
+    xy, un = keypoints_for(w, h, 200, 1)
+    rc, d, ur, raw, proc = R(synth.lidar_scan(2), w, h, xy, un)
+    assert rc != 0 and not d.any() and not raw.any()
+    R.close()
+    # the settings file the golden fixture was taken from parses
+    R = RefDepth(refdepth, os.path.join(SHIPPED, "KITTI00-02.yaml"))
+    assert R.parsed == (True, True)
+    R.close()

@@ -38,3 +38,19 @@ def test_shim_depthmodule_parse_outcomes(emu_lib, tmp_path):
             assert bool(flags & 2) == expect[1], (edits, drop, res.stdout)
         else:
             assert not (flags & 1)
+
+
+@pytest.mark.parametrize("name,expect", [("KITTI00-02.yaml", 3), ("KITTI04-12.yaml", 1), ("KITTIxx-03.yaml", 1)])
+def test_shim_depthmodule_on_the_references_shipped_settings(emu_lib, name, expect):
+    """The three settings files of Examples/RGB-L, read in place: the drop-in parser must end where the reference's own parser
+    ends (tests/test_reference_build.py::test_reference_disables_upsampling_on_its_other_shipped_settings) - the files for
+    sequences 03 - 12 carry a stale key, up-sampling stays disabled (DepthModule.cc:566-582)."""
+    import subprocess
+    path = os.path.join("/root/reference/Examples/RGB-L", name)
+    if not os.path.exists(path):
+        pytest.skip("the reference's Examples/RGB-L is not on this host")
+    exe = os.path.join(ROOT, "tests", "_build", "shim_test_emu")
+    shim_driver.build(os.path.join(ROOT, "tests", "_build"), "rgbl_frontend_emu", exe)
+    res = subprocess.run([exe, "--parse", path], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert int(res.stdout.strip().splitlines()[-1].split()[1]) == expect, res.stdout
