@@ -302,6 +302,24 @@ struct FastCell {  // one detection cell of a frame, prepared by the host (uploa
 };
 static_assert(sizeof(FastCell) == 32, "one s_load_dwordx8 per cell");
 
+// 16 bytes per lane from global memory straight into LDS (gfx950 LDS-DMA, global_load_lds_dwordx4): no VGPR round trip, no
+// ds_write.  The destination is NOT per lane: the wave's 64 pieces land back to back from `lds_wave_base` (wave-uniform) in
+// lane order, inactive lanes leave their 16 bytes untouched.  The data is ordered for LDS reads by vmcnt(0) + a barrier
+// (__syncthreads() emits both while such a load is in flight).
+__device__ __forceinline__ void lds_dma16(const uint8_t* gsrc, uint8_t* lds_wave_base) {
+#ifdef RGBL_EMU
+  __builtin_memcpy(lds_wave_base + 16 * lane_id(), gsrc, 16);
+#else
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+// One detection cell per workgroup; the reference's own control flow (ORBextractor.cc:826-846): cv::FAST at iniThFAST on the
+// cell, and only if that finds nothing cv::FAST at minThFAST.  (Rounds 1 - 2 made one pass at minThFAST and derived the
+// iniThFAST set from the same score map: on frames where most pre-screen survivors at the low threshold are not corners at
+// the high one, the exact score - the expensive phase - was computed for pixels whose result the reference never looks at.)
 template <int CM, int BS, bool kPk = false>
 __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ cells,
                                                     const uint8_t* __restrict__ img0, int pitch0,
@@ -311,20 +329,22 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
                                                     uint32_t* __restrict__ slots, size_t slots_frame, int cell_begin,
                                                     const LevelGeom* __restrict__ geom, int n_levels, uint32_t* __restrict__ dense_keys,
                                                     size_t keys_frame, uint32_t* __restrict__ level_cnt) {
-  constexpr int kTileP = CM + 8;   // LDS tile pitch (cell + 6 ring margin, padded)
+  constexpr int kTileP = (CM + 6 + 15) / 16 * 16;  // LDS tile pitch: whole 16-byte pieces (64 for cells up to 48 px, 80 beyond)
+  constexpr int kPieces = kTileP / 16;
   constexpr int kScoreP = CM + 4;  // score tile pitch (cell + 1-px zero frame), multiple of 4
+  constexpr int kScoreQuads = ((CM + 2) * kScoreP / 4 + 3) / 4;  // the score tile in 16-byte pieces
   constexpr int kBitWords = (CM * CM + 63) / 64 * 2;  // bitmap words, an even number: the compaction reads them in pairs
   constexpr int kCornerCap = 512;                     // pixels with a score kept as a list for the NMS (all survivors are scanned beyond that)
-  __shared__ uint32_t s_tile_w[(CM + 6) * kTileP / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tile_w[(CM + 6) * kTileP / 4];
   uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile_w);
-  __shared__ uint32_t s_score_w[(CM + 2) * kScoreP / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t s_score_w[kScoreQuads * 4];
   uint8_t* s_score = reinterpret_cast<uint8_t*>(s_score_w);
   // survivors of the pre-screen as a list; cells with more of them than the list holds (noise, checkerboards) are scored pixel by pixel
   constexpr int kSurvCap = CM <= kCellSmall ? 1024 : CM * CM;
   __shared__ uint16_t s_surv[kSurvCap];
   __shared__ uint16_t s_corner[kCornerCap];
-  __shared__ int s_nsurv, s_ncorner, s_any_ini;
-  __shared__ uint32_t s_keep[kBitWords], s_keep_ini[kBitWords];
+  __shared__ int s_nsurv, s_ncorner, s_any;
+  __shared__ uint32_t s_keep[kBitWords];
 
   const int tid = threadIdx.x;
   const int f = xcd_frame();
@@ -342,7 +362,9 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
   const uint8_t* img = (C.l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + C.img_off;
   const int pitch = (C.l == 0) ? pitch0 : (int)C.pitch;
 
-  // ---- stage the (sw+6) x (sh+6) pixel tile and clear the score tile
+  // ---- stage the (sw+6) x (sh+6) pixel tile: a lane moves 16 bytes, four (five) lanes a tile row, the wave's pieces land in
+  //      LDS back to back = rows of pitch kTileP.  The last piece of a row reads up to 15 bytes past the tile: still inside the
+  //      image (the tile ends >= 13 px left of the row's end, and never on the last row).
   const int npix = sw * sh;
   // p / sw == (p * ceil(2^20 / sw)) >> 20 while p * sw < 2^20 (p < 72 * 72, sw <= 72); the product stays below 2^27.
   // 24-bit multiplies: v_mul_u32_u24 issues at the full VALU rate, v_mul_hi_u32 / v_mul_lo_u32 at a quarter of it.
@@ -353,78 +375,87 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
 #define RGBL_TILE_AT(p, y) ((p) + (int)__umul24((uint32_t)(y), (uint32_t)(kTileP - sw)) + 3 * kTileP + 3)
 #define RGBL_SCORE_AT(p, y) ((p) + (int)__umul24((uint32_t)(y), (uint32_t)(kScoreP - sw)) + kScoreP + 1)
   {
-    const int nwords = (tw + 3) >> 2;  // reads at most 3 bytes past the tile, still >= 13 px inside the row
-    const uint32_t wmagic = C.wmagic;
-    for (int i = tid; i < nwords * th; i += BS) {
-      const int y = (int)(__umul24((uint32_t)i, wmagic) >> 20), k = i - (int)__umul24((uint32_t)y, (uint32_t)nwords);
-      // row and pitch are far below 2^24 and a level far below 4 GB: one full-rate 24-bit multiply instead of a 64-bit one
-      s_tile_w[(y * kTileP >> 2) + k] = load_u32_unaligned(img + (__umul24((uint32_t)(ini_y + y), (uint32_t)pitch) + (uint32_t)(ini_x + 4 * k)));
+    const int used = (tw + 15) >> 4;  // pieces of a row that hold tile bytes
+    for (int j0 = 0; j0 < th * kPieces; j0 += BS) {
+      const int j = j0 + tid;
+      const int y = kPieces == 4 ? j >> 2 : (int)(__umul24((uint32_t)j, 0x3334u) >> 16), k = j - y * kPieces;  // j / 5 for j < 2^14
+      if (y < th && k < used)
+        lds_dma16(img + (__umul24((uint32_t)(ini_y + y), (uint32_t)pitch) + (uint32_t)(ini_x + 16 * k)), s_tile + (j0 + (tid & ~63)) * 16);
     }
   }
-  for (int i = tid; i < (sh + 2) * (kScoreP / 4); i += BS) s_score_w[i] = 0;
-  if (tid == 0) { s_nsurv = 0; s_ncorner = 0; s_any_ini = 0; }
-  for (int i = tid; i < kBitWords; i += BS) { s_keep[i] = 0; s_keep_ini[i] = 0; }
-  __syncthreads();
+  const int n_passes = ini_th > min_th ? 2 : 1;
+  for (int pass = 0; pass < n_passes; ++pass) {
+    const int thr = (pass == 0 && n_passes == 2) ? ini_th : min_th;   // this pass = cv::FAST(cell, thr, nonmax suppression)
+    // ---- clear the score tile, the counters and the bitmap
+    {
+      uint4* q = reinterpret_cast<uint4*>(s_score_w);
+      for (int i = tid; i < kScoreQuads; i += BS) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (tid == 0) { s_nsurv = 0; s_ncorner = 0; s_any = 0; }
+    for (int i = tid; i < kBitWords; i += BS) s_keep[i] = 0;
+    __syncthreads();
 
-  // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are listed.  (Four pixels per
-  //      task on packed 16-bit halves of aligned word pairs, as the fused per-level kernel of round 2 had it, was measured slower here: 1.24 -> 1.39 ms.)
-  for (int p = tid; p < npix; p += BS) {
-    const int y = RGBL_DIV_SW(p);
-    const uint8_t* c = &s_tile[RGBL_TILE_AT(p, y)];
-    const int v = c[0], lo = v - min_th, hi = v + min_th;
-    bool dark = true, bright = true;
+    // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are listed.  (Four pixels per
+    //      task on packed 16-bit halves of aligned word pairs, as the fused per-level kernel of round 2 had it, was measured slower here: 1.24 -> 1.39 ms.)
+    for (int p = tid; p < npix; p += BS) {
+      const int y = RGBL_DIV_SW(p);
+      const uint8_t* c = &s_tile[RGBL_TILE_AT(p, y)];
+      const int v = c[0], lo = v - thr, hi = v + thr;
+      bool dark = true, bright = true;
 #pragma unroll
-    for (int k = 0; k < 8; k += 2) {
-      const int a = RGBL_RING(c, kTileP, k), b = RGBL_RING(c, kTileP, k + 8);
-      dark = dark && (a < lo || b < lo);
-      bright = bright && (a > hi || b > hi);
+      for (int k = 0; k < 8; k += 2) {
+        const int a = RGBL_RING(c, kTileP, k), b = RGBL_RING(c, kTileP, k + 8);
+        dark = dark && (a < lo || b < lo);
+        bright = bright && (a > hi || b > hi);
+      }
+      if (dark || bright) {
+        const int pos = atomicAdd(&s_nsurv, 1);
+        if (pos < kSurvCap) s_surv[pos] = (uint16_t)p;
+      }
     }
-    if (dark || bright) {
-      const int pos = atomicAdd(&s_nsurv, 1);
-      if (pos < kSurvCap) s_surv[pos] = (uint16_t)p;
-    }
-  }
-  __syncthreads();
+    __syncthreads();
 
-  // ---- phase B: exact score of the survivors; the few that are corners (score >= min threshold) are listed
-  const bool all = s_nsurv > kSurvCap;  // the pre-screen is a necessary condition only: scoring every pixel gives the same corners
-  const int nsurv = all ? npix : s_nsurv;
-  for (int i = tid; i < nsurv; i += BS) {
-    const int p = all ? i : (int)s_surv[i];
-    const int y = RGBL_DIV_SW(p);
-    const int sc = kPk ? fast_true_score_pk(&s_tile[RGBL_TILE_AT(p, y)], kTileP) : fast_true_score(&s_tile[RGBL_TILE_AT(p, y)], kTileP);
-    if (sc >= min_th) {
-      s_score[RGBL_SCORE_AT(p, y)] = (uint8_t)sc;
-      const int pos = atomicAdd(&s_ncorner, 1);
-      if (pos < kCornerCap) s_corner[pos] = (uint16_t)p;
+    // ---- phase B: exact score of the survivors; the ones that are corners at this threshold are listed
+    const bool all = s_nsurv > kSurvCap;  // the pre-screen is a necessary condition only: scoring every pixel gives the same corners
+    const int nsurv = all ? npix : s_nsurv;
+    for (int i = tid; i < nsurv; i += BS) {
+      const int p = all ? i : (int)s_surv[i];
+      const int y = RGBL_DIV_SW(p);
+      const int sc = kPk ? fast_true_score_pk(&s_tile[RGBL_TILE_AT(p, y)], kTileP) : fast_true_score(&s_tile[RGBL_TILE_AT(p, y)], kTileP);
+      if (sc >= thr) {
+        s_score[RGBL_SCORE_AT(p, y)] = (uint8_t)sc;
+        const int pos = atomicAdd(&s_ncorner, 1);
+        if (pos < kCornerCap) s_corner[pos] = (uint16_t)p;
+      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 
-  // ---- phase C: 3x3 strict NMS inside the cell over the pixels that have a score; survivors of the NMS
-  //      set a bit in a row-major bitmap (one for the min threshold, one for the ini threshold)
-  const bool listed = s_ncorner <= kCornerCap;
-  const int ncheck = listed ? s_ncorner : nsurv;
-  for (int i = tid; i < ncheck; i += BS) {
-    const int p = listed ? (int)s_corner[i] : (all ? i : (int)s_surv[i]);
-    const int y = RGBL_DIV_SW(p);
-    const uint8_t* s = &s_score[RGBL_SCORE_AT(p, y)];
-    const int v = s[0];
-    if (v != 0 && v > s[-1] && v > s[1] && v > s[-kScoreP - 1] && v > s[-kScoreP] && v > s[-kScoreP + 1] &&
-        v > s[kScoreP - 1] && v > s[kScoreP] && v > s[kScoreP + 1]) {
-      atomicOr(&s_keep[p >> 5], 1u << (p & 31));
-      if (v >= ini_th) { atomicOr(&s_keep_ini[p >> 5], 1u << (p & 31)); s_any_ini = 1; }
+    // ---- phase C: 3x3 strict NMS inside the cell over the pixels that have a score; its survivors set a bit in a
+    //      row-major bitmap
+    const bool listed = s_ncorner <= kCornerCap;
+    const int ncheck = listed ? s_ncorner : nsurv;
+    for (int i = tid; i < ncheck; i += BS) {
+      const int p = listed ? (int)s_corner[i] : (all ? i : (int)s_surv[i]);
+      const int y = RGBL_DIV_SW(p);
+      const uint8_t* s = &s_score[RGBL_SCORE_AT(p, y)];
+      const int v = s[0];
+      if (v != 0 && v > s[-1] && v > s[1] && v > s[-kScoreP - 1] && v > s[-kScoreP] && v > s[-kScoreP + 1] &&
+          v > s[kScoreP - 1] && v > s[kScoreP] && v > s[kScoreP + 1]) {
+        atomicOr(&s_keep[p >> 5], 1u << (p & 31));
+        s_any = 1;
+      }
     }
+    __syncthreads();
+    if (s_any) break;  // ORBextractor.cc:832: the second cv::FAST runs only when the first found nothing
+    if (pass + 1 < n_passes) __syncthreads();  // everyone has read s_any before the next pass clears it
   }
-  __syncthreads();
-  // two-threshold rule of ORBextractor.cc:826-846: the ini-threshold set if it is non-empty, else the min set.
   // Ordered compaction by the first wave alone (no further barrier; the other waves are done): a lane owns 64 bitmap
   // bits, ascending bits = cv::FAST's row-major emission order.  The ordered pixel list goes through LDS (the survivor
   // list's space) so that the keys leave with one coalesced store per 64 keypoints.
   if (wave_id() != 0) return;
   {
     const int lane = lane_id();
-    const uint32_t* keep = s_any_ini ? s_keep_ini : s_keep;
+    const uint32_t* keep = s_keep;
     const int npairs = (npix + 63) >> 6;  // <= 81
     uint16_t* s_list = s_surv;
     uint32_t total = 0;
