@@ -63,7 +63,7 @@ struct rgbl_extractor {
   bool graph_ok = true;  // RGBL_GRAPH=0 or a failed capture switch the replay off
   int octree_wg = 0;  // 0 = choose per launch; RGBL_OCTREE_WG=256|512 pins the quad-tree workgroup width (tuning / tests)
   int octree_ncap = 0;  // LDS node capacity of the label-based quad-tree kernel (512 / 2048); 0 = key-moving kernel on global lists
-  int max_cell = 0;  // largest detection-cell side over the levels: selects the k_fast_cells instantiation
+  int max_cell = 0, max_cell_w = 0;  // largest detection-cell side / width over the levels: select the k_fast_cells instantiation
   bool xcd_map = true;  // XCD-aware workgroup -> (item, frame) mapping of the pixel kernels (common.h: xcd_item_frame); RGBL_XCD_MAP=0 switches it off
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> per_level;
@@ -217,6 +217,7 @@ int build_geometry(rgbl_extractor* e) {
       return RGBL_ERR_INVALID;
     }
     e->max_cell = std::max(e->max_cell, std::max(g.w_cell, g.h_cell));
+    e->max_cell_w = std::max(e->max_cell_w, g.w_cell);
     g.n_cells = g.n_cols * g.n_rows;
     g.m_wcell = (0x100000u + (uint32_t)g.w_cell - 1u) / (uint32_t)g.w_cell;
     g.m_hcell = (0x100000u + (uint32_t)g.h_cell - 1u) / (uint32_t)g.h_cell;
@@ -422,11 +423,11 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   if (e->dense && e->dense_dirty) RGBL_HIP(hipMemsetAsync(e->d_levelcnt, 0, sizeof(uint32_t) * (size_t)e->cfg.max_batch * L, s));
   e->dense_dirty = e->dense;  // cleared at the end of a complete enqueue: the quad-tree workgroups leave the counters at zero
 
-  // cells of at most kCellSmall px (every level of the usual image sizes) take the small-LDS instantiation
-  // a cell is a chain of five short phases: 16 workgroups of two waves per CU overlap better than 8 of four (1.46 -> 1.3x ms per 512 frames)
-  int fast_bs = e->max_cell <= kCellSmall ? (getenv("RGBL_FAST_BS") ? atoi(getenv("RGBL_FAST_BS")) : 128) : 256;  // dense input: 64 / 128 / 256 work-items 2.22 / 1.85 / 2.25 ms
-  if (fast_bs != 64 && fast_bs != 128 && fast_bs != 256) fast_bs = 128;
-  auto fast = e->max_cell <= kCellSmall ? (fast_bs == 128 ? k_fast_cells<kCellSmall, 128, true> : (fast_bs == 64 ? k_fast_cells<kCellSmall, 64, true> : k_fast_cells<kCellSmall, 256>)) : k_fast_cells<kCellMax, 256>;
+  // cells of at most kCellSmall px (every level of the usual image sizes) take the small-LDS instantiation: two waves per
+  // cell (a cell is a chain of short phases; 16 workgroups of two waves per CU overlap better than 8 of four), tile pitch 48
+  // bytes when no level's cells are wider than 42 px, else 64; bigger cells: four waves, pitch 80
+  const int fast_bs = e->max_cell <= kCellSmall ? 128 : 256;
+  auto fast = e->max_cell <= kCellSmall ? (e->max_cell_w <= 42 ? k_fast_cells<kCellSmall, 128, 48> : k_fast_cells<kCellSmall, 128, 64>) : k_fast_cells<kCellMax, 256, 80>;
   auto launch_fast = [&](hipStream_t st, int cell_begin, int cell_end) {
     if (cell_end <= cell_begin) return;
     e->timer.begin("k_fast_cells", st);

@@ -186,29 +186,6 @@ constexpr int kCellSmall = 48;      // the common case (cells of 35..48 px): 11 
    : (k) == 10 ? (c)[-2 * (P) - 2] : (k) == 11 ? (c)[-(P) - 3] : (k) == 12 ? (c)[-3]                  \
    : (k) == 13 ? (c)[(P) - 3] : (k) == 14 ? (c)[2 * (P) - 2] : (c)[3 * (P) - 1])
 
-// largest t for which the pixel is still a FAST-9/16 corner (== cv cornerScore<16> for corners); <0 if none
-__device__ __forceinline__ int fast_true_score(const uint8_t* c, int P) {
-  const int v = c[0];
-  int d[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) d[k] = v - (int)RGBL_RING(c, P, k);
-  int mn2[16], mx2[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { mn2[k] = imin(d[k], d[(k + 1) & 15]); mx2[k] = imax(d[k], d[(k + 1) & 15]); }
-  int mn4[16], mx4[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { mn4[k] = imin(mn2[k], mn2[(k + 2) & 15]); mx4[k] = imax(mx2[k], mx2[(k + 2) & 15]); }
-  int dark = -256, bright = 256;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int mn9 = imin(imin(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);  // min over ring k..k+8
-    const int mx9 = imax(imax(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-    dark = imax(dark, mn9);
-    bright = imin(bright, mx9);
-  }
-  return imax(dark, -bright) - 1;
-}
-
 // ring pixel k of cv::FAST's 16-ring as a byte offset in a tile of pitch P
 __device__ __forceinline__ int ring_off(int k, int P) {
   switch (k) {
@@ -241,38 +218,42 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { return 
 __device__ __forceinline__ uint32_t pk_swap(uint32_t a) { return from_s2(as_s2(a).yx); }
 #endif
 
-// fast_true_score (extractor_kernels.h) on pairs: register k holds the differences d_k and d_{k+8} as two signed halves,
-// so ring position k + 8 is register k with its halves swapped and every sliding minimum / maximum is computed for two ring
-// positions at once.  Same value: the largest t for which the pixel is still a FAST-9/16 corner, < 0 if there is none.
-__device__ __forceinline__ int fast_true_score_pk(const uint8_t* c, int P) {
+// The FAST score of ONE polarity: the largest threshold t at which the pixel still has a 9-arc of that polarity (< 0: none) =
+// cv cornerScore<16> for a corner of that polarity.  A 9-arc of darker pixels and a 9-arc of brighter ones exclude each other
+// (9 + 9 > 16), and the pre-screen says which of the two a pixel can have - well below 5 % of its survivors pass for both.
+// sgn = 0xffffffff: the dark arc, differences d_k = v - ring_k; sgn = 0x00010001: the bright arc, d_k = ring_k - v; either
+// way the result is max_k min(d_k .. d_k+8) - 1.  Packed 16-bit arithmetic: register k holds d_k and d_{k+8} as two signed
+// halves (one v_pk_mad_i16 per ring pair forms them), so ring position k + 8 is register k with its halves swapped (op_sel) and
+// every sliding minimum is computed for two ring positions at once; log-step windows 2, 4, 8, + 1.
+#ifdef RGBL_EMU
+__device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t lo = (uint32_t)((int)(int16_t)a * (int)(int16_t)b + (int)(int16_t)c) & 0xffffu;
+  const uint32_t hi = (uint32_t)((int)(int16_t)(a >> 16) * (int)(int16_t)(b >> 16) + (int)(int16_t)(c >> 16)) & 0xffffu;
+  return lo | (hi << 16);
+}
+#else
+__device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) { return from_s2(as_s2(a) * as_s2(b) + as_s2(c)); }
+#endif
+__device__ __forceinline__ int fast_score_one(const uint8_t* c, int P, uint32_t sgn) {
   const uint32_t v = c[0];
-  const uint32_t vv = v | (v << 16);
+  const uint32_t vs = pk_mad_i16(v | (v << 16), sgn ^ 0xfffefffeu, 0u);  // -sgn * v in both halves (sgn = -1 -> * 1, sgn = 1 -> * -1)
   uint32_t D[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const uint32_t a = c[ring_off(k, P)], b = c[ring_off(k + 8, P)];
-    D[k] = pk_sub_i16(vv, a | (b << 16));
+    D[k] = pk_mad_i16(a | (b << 16), sgn, vs);  // sgn * ring - sgn * v
   }
-  // index k + 8 of any of the arrays below = entry k with swapped halves
 #define RGBL_AT(A, k) ((k) < 8 ? (A)[(k) & 7] : pk_swap((A)[((k) - 8) & 7]))
-  uint32_t mn2[8], mx2[8], mn4[8], mx4[8];
+  uint32_t mn2[8], mn4[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { mn2[k] = pk_min_i16(D[k], RGBL_AT(D, k + 1)); mx2[k] = pk_max_i16(D[k], RGBL_AT(D, k + 1)); }
+  for (int k = 0; k < 8; ++k) mn2[k] = pk_min_i16(D[k], RGBL_AT(D, k + 1));
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { mn4[k] = pk_min_i16(mn2[k], RGBL_AT(mn2, k + 2)); mx4[k] = pk_max_i16(mx2[k], RGBL_AT(mx2, k + 2)); }
-  uint32_t dark = 0x80008000u, bright = 0x7fff7fffu;
+  for (int k = 0; k < 8; ++k) mn4[k] = pk_min_i16(mn2[k], RGBL_AT(mn2, k + 2));
+  uint32_t best = 0x80008000u;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const uint32_t far = pk_swap(D[k]);  // d_{k+8} for position k, d_k for position k + 8
-    const uint32_t mn9 = pk_min_i16(pk_min_i16(mn4[k], RGBL_AT(mn4, k + 4)), far);
-    const uint32_t mx9 = pk_max_i16(pk_max_i16(mx4[k], RGBL_AT(mx4, k + 4)), far);
-    dark = pk_max_i16(dark, mn9);
-    bright = pk_min_i16(bright, mx9);
-  }
+  for (int k = 0; k < 8; ++k) best = pk_max_i16(best, pk_min_i16(pk_min_i16(mn4[k], RGBL_AT(mn4, k + 4)), pk_swap(D[k])));
 #undef RGBL_AT
-  const int dk = imax((int)(int16_t)(dark & 0xffffu), (int)(int16_t)(dark >> 16));
-  const int br = imin((int)(int16_t)(bright & 0xffffu), (int)(int16_t)(bright >> 16));
-  return imax(dk, -br) - 1;
+  return imax((int)(int16_t)(best & 0xffffu), (int)(int16_t)(best >> 16)) - 1;
 }
 
 // Two adjacent aligned words of the LDS tile (one ds_read2_b32).  Unaligned LDS reads are legal on gfx950 but cost ~15 LDS
@@ -302,6 +283,31 @@ struct FastCell {  // one detection cell of a frame, prepared by the host (uploa
 };
 static_assert(sizeof(FastCell) == 32, "one s_load_dwordx8 per cell");
 
+// lanes of the wave for which `pred` holds, as a wave-uniform mask (the condition's own scalar mask: __ballot(int) would
+// first turn the predicate into a register and compare that again)
+__device__ __forceinline__ unsigned long long wave_ballot(bool pred) {
+#ifdef RGBL_EMU
+  return __ballot(pred ? 1 : 0);
+#else
+  return __builtin_amdgcn_ballot_w64(pred);
+#endif
+}
+// number of set bits of a wave mask below the calling lane (v_mbcnt_lo / v_mbcnt_hi)
+__device__ __forceinline__ int wave_rank(unsigned long long mask) {
+#ifdef RGBL_EMU
+  return (int)__popcll(mask & lanemask_lt());
+#else
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+#endif
+}
+__device__ __forceinline__ int wave_last(int v) {  // value of lane 63, wave-uniform
+#ifdef RGBL_EMU
+  return __shfl(v, 63);
+#else
+  return __builtin_amdgcn_readlane(v, 63);
+#endif
+}
+
 // 16 bytes per lane from global memory straight into LDS (gfx950 LDS-DMA, global_load_lds_dwordx4): no VGPR round trip, no
 // ds_write.  The destination is NOT per lane: the wave's 64 pieces land back to back from `lds_wave_base` (wave-uniform) in
 // lane order, inactive lanes leave their 16 bytes untouched.  The data is ordered for LDS reads by vmcnt(0) + a barrier
@@ -320,7 +326,7 @@ __device__ __forceinline__ void lds_dma16(const uint8_t* gsrc, uint8_t* lds_wave
 // cell, and only if that finds nothing cv::FAST at minThFAST.  (Rounds 1 - 2 made one pass at minThFAST and derived the
 // iniThFAST set from the same score map: on frames where most pre-screen survivors at the low threshold are not corners at
 // the high one, the exact score - the expensive phase - was computed for pixels whose result the reference never looks at.)
-template <int CM, int BS, bool kPk = false>
+template <int CM, int BS, int P>
 __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ cells,
                                                     const uint8_t* __restrict__ img0, int pitch0,
                                                     size_t frame0, const uint8_t* __restrict__ pyr,
@@ -329,22 +335,42 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
                                                     uint32_t* __restrict__ slots, size_t slots_frame, int cell_begin,
                                                     const LevelGeom* __restrict__ geom, int n_levels, uint32_t* __restrict__ dense_keys,
                                                     size_t keys_frame, uint32_t* __restrict__ level_cnt) {
-  constexpr int kTileP = (CM + 6 + 15) / 16 * 16;  // LDS tile pitch: whole 16-byte pieces (64 for cells up to 48 px, 80 beyond)
-  constexpr int kPieces = kTileP / 16;
-  constexpr int kScoreP = CM + 4;  // score tile pitch (cell + 1-px zero frame), multiple of 4
-  constexpr int kScoreQuads = ((CM + 2) * kScoreP / 4 + 3) / 4;  // the score tile in 16-byte pieces
-  constexpr int kBitWords = (CM * CM + 63) / 64 * 2;  // bitmap words, an even number: the compaction reads them in pairs
+  // P = pitch of BOTH LDS tiles in bytes: whole 16-byte pieces (the LDS-DMA's granule) and at least the widest tile row
+  // (cell width + 6).  48 for cells up to 42 px wide - every level of KITTI, EuRoC, VGA or 4K frames -: 12 banks per row, so
+  // the rows of a cell rotate through all 32 LDS banks and the scattered reads of phases B and C (a wave's survivors lie in
+  // a handful of neighbouring rows) spread out; with 64 (16 banks) every other row started on the same bank and the cell's 10
+  // word columns used 20 of the 32 banks: LDS bank-conflict cycles 1.45e8 -> see DESIGN 9.  64 / 80 for wider cells.
+  static_assert(P % 16 == 0 && P >= 48 && P <= 80, "tile pitch");
+  constexpr int kPieces = P / 16;
+  // A pixel is named by its byte offset t = ty * P + tx in the pixel tile (tile coordinates: scanned pixel (x, y) sits at
+  // (x + 3, y + 3)); its score sits at t - kScoreOff in the score tile (same pitch, 1-px zero frame), its bit in the bitmap at
+  // b = t - kBitOff = y * P + x.  Only phase A, which walks the scanned area linearly, needs a division.
+  constexpr int kScoreOff = 2 * P + 2, kBitOff = 3 * P + 3;
+  constexpr int kScoreQuads = (CM + 2) * P / 16;      // the score tile in 16-byte pieces
+  constexpr int kBitWords = (CM * P + 63) / 64 * 2;   // bitmap words, an even number: the compaction reads them in pairs
   constexpr int kCornerCap = 512;                     // pixels with a score kept as a list for the NMS (all survivors are scanned beyond that)
-  __shared__ __attribute__((aligned(16))) uint32_t s_tile_w[(CM + 6) * kTileP / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tile_w[(CM + 6) * P / 4];
   uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile_w);
   __shared__ __attribute__((aligned(16))) uint32_t s_score_w[kScoreQuads * 4];
   uint8_t* s_score = reinterpret_cast<uint8_t*>(s_score_w);
-  // survivors of the pre-screen as a list; cells with more of them than the list holds (noise, checkerboards) are scored pixel by pixel
-  constexpr int kSurvCap = CM <= kCellSmall ? 1024 : CM * CM;
+  // survivors of the pre-screen as lists of (t | polarity << 15), one list per wave: a wave ranks its survivors with a ballot
+  // and keeps its count in a scalar register - no LDS atomic and no round trip per trip of the loop.  Cells with more survivors
+  // than a list holds (noise, checkerboards) are scored pixel by pixel, both polarities.  The corners found by phase B alike.
+  constexpr int kWaves = BS / 64;
+  constexpr int kSurvCap = CM <= kCellSmall ? 1024 : CM * CM, kSurvPerWave = kSurvCap / kWaves;
+  constexpr int kCornerPerWave = kCornerCap / kWaves;
   __shared__ uint16_t s_surv[kSurvCap];
   __shared__ uint16_t s_corner[kCornerCap];
-  __shared__ int s_nsurv, s_ncorner, s_any;
+  __shared__ int s_nsurv[kWaves], s_ncorner[kWaves], s_any;
   __shared__ uint32_t s_keep[kBitWords];
+  // entry i of the concatenation of the waves' lists (counts c[w], capacity cap per wave)
+#define RGBL_LIST_AT(list, c, cap, i, out)                                                             \
+  do {                                                                                                 \
+    int seg_ = 0, j_ = (i);                                                                            \
+    _Pragma("unroll") for (int w_ = 0; w_ + 1 < kWaves; ++w_)                                          \
+      if (seg_ == w_ && j_ >= (c)[w_]) { j_ -= (c)[w_]; seg_ = w_ + 1; }                               \
+    (out) = (list)[seg_ * (cap) + j_];                                                                 \
+  } while (0)
 
   const int tid = threadIdx.x;
   const int f = xcd_frame();
@@ -363,85 +389,145 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
   const int pitch = (C.l == 0) ? pitch0 : (int)C.pitch;
 
   // ---- stage the (sw+6) x (sh+6) pixel tile: a lane moves 16 bytes, four (five) lanes a tile row, the wave's pieces land in
-  //      LDS back to back = rows of pitch kTileP.  The last piece of a row reads up to 15 bytes past the tile: still inside the
+  //      LDS back to back = rows of pitch P.  The last piece of a row reads up to 15 bytes past the tile: still inside the
   //      image (the tile ends >= 13 px left of the row's end, and never on the last row).
   const int npix = sw * sh;
   // p / sw == (p * ceil(2^20 / sw)) >> 20 while p * sw < 2^20 (p < 72 * 72, sw <= 72); the product stays below 2^27.
   // 24-bit multiplies: v_mul_u32_u24 issues at the full VALU rate, v_mul_hi_u32 / v_mul_lo_u32 at a quarter of it.
   const uint32_t magic = C.magic;
-#define RGBL_DIV_SW(p) ((int)(__umul24((uint32_t)(p), magic) >> 20))
-#define RGBL_MUL_SW(y) ((int)__umul24((uint32_t)(y), (uint32_t)sw))
-  // pixel p = y * sw + x of the scanned area inside the two LDS tiles
-#define RGBL_TILE_AT(p, y) ((p) + (int)__umul24((uint32_t)(y), (uint32_t)(kTileP - sw)) + 3 * kTileP + 3)
-#define RGBL_SCORE_AT(p, y) ((p) + (int)__umul24((uint32_t)(y), (uint32_t)(kScoreP - sw)) + kScoreP + 1)
+  // pixel p = y * sw + x of the scanned area -> its tile offset t
+#define RGBL_T_OF(p) ((p) + (int)__umul24(__umul24((uint32_t)(p), magic) >> 20, (uint32_t)(P - sw)) + kBitOff)
   {
     const int used = (tw + 15) >> 4;  // pieces of a row that hold tile bytes
     for (int j0 = 0; j0 < th * kPieces; j0 += BS) {
       const int j = j0 + tid;
-      const int y = kPieces == 4 ? j >> 2 : (int)(__umul24((uint32_t)j, 0x3334u) >> 16), k = j - y * kPieces;  // j / 5 for j < 2^14
+      const int y = kPieces == 4 ? j >> 2 : (int)(__umul24((uint32_t)j, kPieces == 3 ? 0x5556u : 0x3334u) >> 16), k = j - y * kPieces;  // j / 3, j / 5 for j < 2^14
       if (y < th && k < used)
         lds_dma16(img + (__umul24((uint32_t)(ini_y + y), (uint32_t)pitch) + (uint32_t)(ini_x + 16 * k)), s_tile + (j0 + (tid & ~63)) * 16);
     }
   }
+#ifdef RGBL_FAST_SKIP
+  const int n_passes = 1;  // timing experiments: one pass at min_th whatever it finds
+#else
   const int n_passes = ini_th > min_th ? 2 : 1;
+#endif
   for (int pass = 0; pass < n_passes; ++pass) {
     const int thr = (pass == 0 && n_passes == 2) ? ini_th : min_th;   // this pass = cv::FAST(cell, thr, nonmax suppression)
-    // ---- clear the score tile, the counters and the bitmap
+    // ---- clear the score tile (the rows in use), the counters and the bitmap
     {
       uint4* q = reinterpret_cast<uint4*>(s_score_w);
-      for (int i = tid; i < kScoreQuads; i += BS) q[i] = make_uint4(0u, 0u, 0u, 0u);
+      for (int i = tid; i < (sh + 2) * kPieces; i += BS) q[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    if (tid == 0) { s_nsurv = 0; s_ncorner = 0; s_any = 0; }
+    if (tid == 0) s_any = 0;
     for (int i = tid; i < kBitWords; i += BS) s_keep[i] = 0;
     __syncthreads();
 
-    // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs; survivors are listed.  (Four pixels per
-    //      task on packed 16-bit halves of aligned word pairs, as the fused per-level kernel of round 2 had it, was measured slower here: 1.24 -> 1.39 ms.)
-    for (int p = tid; p < npix; p += BS) {
-      const int y = RGBL_DIV_SW(p);
-      const uint8_t* c = &s_tile[RGBL_TILE_AT(p, y)];
-      const int v = c[0], lo = v - thr, hi = v + thr;
-      bool dark = true, bright = true;
+    // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs, per polarity; survivors are listed with the
+    //      polarity they can have (dark if both - the rare pixel that passes for both gets a second entry for the bright arc).
+    //      (Four pixels per task on packed 16-bit halves of aligned word pairs, as the fused per-level kernel of round 2 had
+    //      it, was measured slower here: 1.24 -> 1.39 ms.)
+    const int wv = wave_id();
+    {
+      uint16_t* mine = s_surv + wv * kSurvPerWave;
+      int n_mine = 0;  // wave-uniform
+      uint32_t pm = __umul24((uint32_t)tid, magic);
+#if defined(RGBL_FAST_SKIP) && RGBL_FAST_SKIP >= 2
+      for (int p0 = 0; p0 < 0; p0 += BS) {
+#else
+      for (int p0 = 0; p0 < npix; p0 += BS) {
+#endif
+        const int p = p0 + tid;
+        bool dark = false, bright = false;
+        int t = 0;
+        if (p < npix) {
+          t = p + (int)__umul24(pm >> 20, (uint32_t)(P - sw)) + kBitOff;  // RGBL_T_OF(p) with p * magic carried along
+          pm += (uint32_t)BS * magic;
+          const uint8_t* c = &s_tile[t];
+          const int v = c[0], lo = v - thr, hi = v + thr;
+          dark = true; bright = true;
 #pragma unroll
-      for (int k = 0; k < 8; k += 2) {
-        const int a = RGBL_RING(c, kTileP, k), b = RGBL_RING(c, kTileP, k + 8);
-        dark = dark && (a < lo || b < lo);
-        bright = bright && (a > hi || b > hi);
+          for (int k = 0; k < 8; k += 2) {
+            const int a = RGBL_RING(c, P, k), b = RGBL_RING(c, P, k + 8);
+            dark = dark && (a < lo || b < lo);
+            bright = bright && (a > hi || b > hi);
+          }
+        }
+        const unsigned long long m_any = wave_ballot(dark || bright);
+        if (dark || bright) {
+          const int pos = n_mine + wave_rank(m_any);
+          if (pos < kSurvPerWave) mine[pos] = (uint16_t)(dark ? t : (t | 0x8000));
+        }
+        n_mine += (int)__popcll(m_any);
+        const unsigned long long m_both = wave_ballot(dark && bright);
+        if (m_both) {
+          if (dark && bright) {
+            const int pos = n_mine + wave_rank(m_both);
+            if (pos < kSurvPerWave) mine[pos] = (uint16_t)(t | 0x8000);
+          }
+          n_mine += (int)__popcll(m_both);
+        }
       }
-      if (dark || bright) {
-        const int pos = atomicAdd(&s_nsurv, 1);
-        if (pos < kSurvCap) s_surv[pos] = (uint16_t)p;
-      }
+      if (lane_id() == 0) s_nsurv[wv] = n_mine;
     }
     __syncthreads();
 
-    // ---- phase B: exact score of the survivors; the ones that are corners at this threshold are listed
-    const bool all = s_nsurv > kSurvCap;  // the pre-screen is a necessary condition only: scoring every pixel gives the same corners
-    const int nsurv = all ? npix : s_nsurv;
-    for (int i = tid; i < nsurv; i += BS) {
-      const int p = all ? i : (int)s_surv[i];
-      const int y = RGBL_DIV_SW(p);
-      const int sc = kPk ? fast_true_score_pk(&s_tile[RGBL_TILE_AT(p, y)], kTileP) : fast_true_score(&s_tile[RGBL_TILE_AT(p, y)], kTileP);
-      if (sc >= thr) {
-        s_score[RGBL_SCORE_AT(p, y)] = (uint8_t)sc;
-        const int pos = atomicAdd(&s_ncorner, 1);
-        if (pos < kCornerCap) s_corner[pos] = (uint16_t)p;
+    // ---- phase B: exact score of the listed arcs; the ones that exist at this threshold are corners and are listed
+    int cs[kWaves];
+    bool all = false;  // the pre-screen is a necessary condition only: scoring every pixel, both arcs, gives the same corners
+    int nsurv = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) { cs[w] = s_nsurv[w]; all = all || cs[w] > kSurvPerWave; nsurv += cs[w]; }
+    if (all) nsurv = 2 * npix;
+#if defined(RGBL_FAST_SKIP) && RGBL_FAST_SKIP >= 1
+    nsurv = 0;
+#endif
+    {
+      uint16_t* mine = s_corner + wv * kCornerPerWave;
+      int n_mine = 0;
+      for (int i0 = 0; i0 < nsurv; i0 += BS) {
+        const int i = i0 + tid;
+        bool corner = false;
+        int t = 0;
+        if (i < nsurv) {
+          int e;
+          if (all) e = RGBL_T_OF(i >> 1) | ((i & 1) << 15);
+          else RGBL_LIST_AT(s_surv, cs, kSurvPerWave, i, e);
+          t = e & 0x7fff;
+          const int sc = fast_score_one(&s_tile[t], P, (e & 0x8000) ? 0x00010001u : 0xffffffffu);
+          if (sc >= thr) {  // at most one of a pixel's two arcs can exist
+            s_score[t - kScoreOff] = (uint8_t)sc;
+            corner = true;
+          }
+        }
+        const unsigned long long m = wave_ballot(corner);
+        if (corner) {
+          const int pos = n_mine + wave_rank(m);
+          if (pos < kCornerPerWave) mine[pos] = (uint16_t)t;
+        }
+        n_mine += (int)__popcll(m);
       }
+      if (lane_id() == 0) s_ncorner[wv] = n_mine;
     }
     __syncthreads();
 
     // ---- phase C: 3x3 strict NMS inside the cell over the pixels that have a score; its survivors set a bit in a
     //      row-major bitmap
-    const bool listed = s_ncorner <= kCornerCap;
-    const int ncheck = listed ? s_ncorner : nsurv;
+    int cc[kWaves];
+    bool listed = true;
+    int ncheck = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) { cc[w] = s_ncorner[w]; listed = listed && cc[w] <= kCornerPerWave; ncheck += cc[w]; }
+    if (!listed) ncheck = nsurv;
     for (int i = tid; i < ncheck; i += BS) {
-      const int p = listed ? (int)s_corner[i] : (all ? i : (int)s_surv[i]);
-      const int y = RGBL_DIV_SW(p);
-      const uint8_t* s = &s_score[RGBL_SCORE_AT(p, y)];
+      int t;
+      if (listed) RGBL_LIST_AT(s_corner, cc, kCornerPerWave, i, t);
+      else if (all) t = RGBL_T_OF(i >> 1);
+      else { RGBL_LIST_AT(s_surv, cs, kSurvPerWave, i, t); t &= 0x7fff; }
+      const uint8_t* s = &s_score[t - kScoreOff];
       const int v = s[0];
-      if (v != 0 && v > s[-1] && v > s[1] && v > s[-kScoreP - 1] && v > s[-kScoreP] && v > s[-kScoreP + 1] &&
-          v > s[kScoreP - 1] && v > s[kScoreP] && v > s[kScoreP + 1]) {
-        atomicOr(&s_keep[p >> 5], 1u << (p & 31));
+      if (v != 0 && v > s[-1] && v > s[1] && v > s[-P - 1] && v > s[-P] && v > s[-P + 1] && v > s[P - 1] && v > s[P] && v > s[P + 1]) {
+        const int b = t - kBitOff;
+        atomicOr(&s_keep[b >> 5], 1u << (b & 31));  // (a pixel listed twice sets its bit twice)
         s_any = 1;
       }
     }
@@ -449,6 +535,8 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
     if (s_any) break;  // ORBextractor.cc:832: the second cv::FAST runs only when the first found nothing
     if (pass + 1 < n_passes) __syncthreads();  // everyone has read s_any before the next pass clears it
   }
+#undef RGBL_T_OF
+#undef RGBL_LIST_AT
   // Ordered compaction by the first wave alone (no further barrier; the other waves are done): a lane owns 64 bitmap
   // bits, ascending bits = cv::FAST's row-major emission order.  The ordered pixel list goes through LDS (the survivor
   // list's space) so that the keys leave with one coalesced store per 64 keypoints.
@@ -456,7 +544,7 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
   {
     const int lane = lane_id();
     const uint32_t* keep = s_keep;
-    const int npairs = (npix + 63) >> 6;  // <= 81
+    const int npairs = (sh * P + 63) >> 6;  // <= 90
     uint16_t* s_list = s_surv;
     uint32_t total = 0;
     for (int w0 = 0; w0 < npairs; w0 += 64) {
@@ -464,18 +552,14 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
       unsigned long long word = 0;
       if (t < npairs) word = (unsigned long long)keep[2 * t] | ((unsigned long long)keep[2 * t + 1] << 32);
       const uint32_t cnt = (uint32_t)__popcll(word);
-      uint32_t incl = cnt;
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d);
-        if (lane >= d) incl += up;
-      }
+      const uint32_t incl = wave_inclusive_scan(cnt);  // DPP adds, no LDS round trips
       uint32_t pos = total + incl - cnt;
       while (word) {
         const int bit = __ffsll((long long)word) - 1;
         word &= word - 1;
         s_list[pos++] = (uint16_t)(t * 64 + bit);
       }
-      total += __shfl(incl, 63);
+      total += (uint32_t)wave_last((int)incl);
     }
     wave_sync();
     const uint32_t n_out = total < (uint32_t)C.cell_cap ? total : (uint32_t)C.cell_cap;  // cap is a proven bound
@@ -490,9 +574,9 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
       out = dense_keys + (size_t)f * keys_frame + geom[C.l].key_off + base;
     }
     for (uint32_t i = lane; i < n_out; i += 64) {
-      const int p = s_list[i];
-      const int y = RGBL_DIV_SW(p), x = p - RGBL_MUL_SW(y);
-      out[i] = pack_key(C.kx0 + x, C.ky0 + y, s_score[RGBL_SCORE_AT(p, y)]);
+      const int b = s_list[i];
+      const int y = b / P, x = b - y * P;
+      out[i] = pack_key(C.kx0 + x, C.ky0 + y, s_score[b + P + 1]);
     }
     if (lane == 0) *my_cnt = n_out;
   }
