@@ -153,35 +153,44 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
     return inside ? (t > thr ? 0.f : t) : -FLT_MAX;  // THRESH_TOZERO_INV
   };
   if (kRadius > 0) {
-    // compile-time tile: every load of a work-item's 5-6 elements is requested before the first is used, the indexed
-    // variant then requests all its depth look-ups together (the kernel is bound by round trips, not by bytes)
-    constexpr int kTw = 64 + 2 * kRadius, kTh = kTileH + 2 * kRadius, kIter = (kTw * kTh + 255) / 256;
+    // compile-time tile (64 + 2 r) x (32 + 2 r): a work-item fetches column (tid & 63) of every fourth row, the first
+    // 2 r (32 + 2 r) work-items also one element of the 2 r columns to the right of those - no divisions by the tile width, one 32-bit index per element, every load of a
+    // work-item requested before the first is used; the indexed variant then requests all its depth look-ups together
+    constexpr int kTw = 64 + 2 * kRadius, kTh = kTileH + 2 * kRadius;
+    static_assert(kTw <= 72 && kTh <= kTileH + 8, "tile inside s_inv");
+    constexpr int kMain = (kTh + 3) / 4;                       // rows per work-item in the 64 main columns
+    constexpr int kSideElems = 2 * kRadius * kTh;              // the columns 64 .. kTw - 1
+    constexpr int kSide = (kSideElems + 255) / 256, kIter = kMain + kSide;
+    // tiles that lie inside the image with their halo (three quarters of a KITTI frame's) skip the per-element bounds tests
+    const bool interior = x0 >= kRadius && y0 >= kRadius && x0 + 64 + kRadius <= w && y0 + kTileH + kRadius <= h;
+    const int r0 = tid >> 6, c0 = tid & 63;
     bool inside[kIter];
-    size_t at[kIter];
+    int at[kIter], lds[kIter];
     float raw_v[kIter];
     uint32_t id[kIter];
 #pragma unroll
     for (int j = 0; j < kIter; ++j) {
-      const int i = tid + 256 * j;
-      const int r = i / kTw, c = i - r * kTw;
+      const int si = tid + 256 * (j - kMain), sr = si / (2 * kRadius);   // element si of the side columns (rows of 2 r)
+      const int r = j < kMain ? r0 + 4 * j : sr, c = j < kMain ? c0 : 64 + (si - sr * (2 * kRadius));
+      const bool live = j < kMain ? (4 * j + 3 < kTh || r < kTh) : si < kSideElems;
       const int yy = y0 + r - kRadius, xx = x0 + c - kRadius;
-      inside[j] = i < kTw * kTh && yy >= 0 && yy < h && xx >= 0 && xx < w;
-      at[j] = inside[j] ? (size_t)yy * w + xx : 0;
+      inside[j] = live && (interior || (yy >= 0 && yy < h && xx >= 0 && xx < w));
+      at[j] = inside[j] ? yy * w + xx : 0;
+      lds[j] = live ? r * 72 + c : -1;
       if (kIndexed) id[j] = inside[j] ? I[at[j]] : 0u;
       else raw_v[j] = inside[j] ? R[at[j]] : 0.f;
     }
     if (kIndexed) {
 #pragma unroll
       for (int j = 0; j < kIter; ++j) {
-        const bool hit = (id[j] & ~kIdxMask) == tag && (id[j] & kIdxMask);  // entries of earlier generations are empty pixels
-        raw_v[j] = hit ? D[(id[j] & kIdxMask) - 1] : 0.f;
+        const uint32_t pt = id[j] & kIdxMask;
+        const bool hit = (id[j] ^ tag) == pt && pt;  // tag | index: entries of earlier generations (another tag) are empty pixels
+        raw_v[j] = hit ? D[pt - 1] : 0.f;
       }
     }
 #pragma unroll
-    for (int j = 0; j < kIter; ++j) {
-      const int i = tid + 256 * j;
-      if (i < kTw * kTh) s_inv[(i / kTw) * 72 + (i % kTw)] = inverted(inside[j], raw_v[j]);
-    }
+    for (int j = 0; j < kIter; ++j)
+      if (lds[j] >= 0) s_inv[lds[j]] = inverted(inside[j], raw_v[j]);
   } else {
     for (int i = tid; i < tw * th; i += 256) {
       const int r = i / tw, c = i - r * tw;
@@ -201,24 +210,47 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
   }
   __syncthreads();
   const int x = tid & 63;
-  for (int k = 0; k < kTileH / 4; ++k) {
-    const int y = (tid >> 6) + 4 * k;
-    if (x0 + x >= w || y0 + y >= h) continue;
-    float m = -FLT_MAX;
-    if (kRadius > 0) {
+  if (kRadius > 0) {
+    // Diamond |dx| + |dy| <= r: a work-item owns 8 consecutive rows of one column.  Per tile row it reads the 2 r + 1 values
+    // around its column once and nests their maxima, H[k] = max over |dx| <= k; an output is then the maximum of
+    // H[r - |dy|] over the rows dy = -r .. r.  (13 LDS reads and 13 maxima per output at r = 2 before, 7.5 reads and 5
+    // three-input maxima now; the maximum is exact whatever the order.)
+    constexpr int kRows = 8, R = kRadius;
+    const int yb = (tid >> 6) * kRows;            // first output row of this work-item inside the tile
+    float H[kRows + 2 * R][R + 1];
 #pragma unroll
-      for (int dy = -kRadius; dy <= kRadius; ++dy) {
-        const int span = kRadius - (dy < 0 ? -dy : dy);
+    for (int r = 0; r < kRows + 2 * R; ++r) {
+      const float* row = &s_inv[(yb + r) * 72 + x];   // tile columns x .. x + 2 r, the output's own column at x + r
+      float v[2 * R + 1];
 #pragma unroll
-        for (int dx = -span; dx <= span; ++dx) m = fmaxf(m, s_inv[(y + kRadius + dy) * 72 + x + kRadius + dx]);
+      for (int c = 0; c <= 2 * R; ++c) v[c] = row[c];
+      H[r][0] = v[R];
+#pragma unroll
+      for (int k = 1; k <= R; ++k) H[r][k] = fmaxf(fmaxf(H[r][k - 1], v[R - k]), v[R + k]);
+    }
+    if (x0 + x < w) {
+#pragma unroll
+      for (int j = 0; j < kRows; ++j) {
+        const int y = yb + j;
+        if (y0 + y >= h) break;
+        float m = H[j + R][R];
+#pragma unroll
+        for (int d = 1; d <= R; ++d) m = fmaxf(fmaxf(m, H[j + R - d][R - d]), H[j + R + d][R - d]);
+        const float t = S - m;
+        out[(size_t)f * map_stride + (size_t)(y0 + y) * w + x0 + x] = t > thr ? 0.f : t;
       }
-    } else {
-      const int nt = s_ntap;
+    }
+  } else {
+    const int nt = s_ntap;
+    for (int k = 0; k < kTileH / 4; ++k) {
+      const int y = (tid >> 6) + 4 * k;
+      if (x0 + x >= w || y0 + y >= h) continue;
+      float m = -FLT_MAX;
       const float* base = &s_inv[y * 72 + x];
       for (int t = 0; t < nt; ++t) m = fmaxf(m, base[s_tap[t]]);
+      const float t = S - m;
+      out[(size_t)f * map_stride + (size_t)(y0 + y) * w + x0 + x] = t > thr ? 0.f : t;
     }
-    const float t = S - m;
-    out[(size_t)f * map_stride + (size_t)(y0 + y) * w + x0 + x] = t > thr ? 0.f : t;
   }
 }
 
