@@ -511,16 +511,14 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
     __syncthreads();
 
     // ---- phase C: 3x3 strict NMS inside the cell over the pixels that have a score; its survivors set a bit in a
-    //      row-major bitmap
-    int cc[kWaves];
+    //      row-major bitmap.  A wave checks the corners it listed itself; if a wave's list overflowed, everybody scans all survivors.
     bool listed = true;
-    int ncheck = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) { cc[w] = s_ncorner[w]; listed = listed && cc[w] <= kCornerPerWave; ncheck += cc[w]; }
-    if (!listed) ncheck = nsurv;
-    for (int i = tid; i < ncheck; i += BS) {
+    for (int w = 0; w < kWaves; ++w) listed = listed && s_ncorner[w] <= kCornerPerWave;
+    const int ncheck = listed ? s_ncorner[wv] : nsurv;
+    for (int i = listed ? lane_id() : tid; i < ncheck; i += listed ? 64 : BS) {
       int t;
-      if (listed) RGBL_LIST_AT(s_corner, cc, kCornerPerWave, i, t);
+      if (listed) t = s_corner[wv * kCornerPerWave + i];
       else if (all) t = RGBL_T_OF(i >> 1);
       else { RGBL_LIST_AT(s_surv, cs, kSurvPerWave, i, t); t &= 0x7fff; }
       const uint8_t* s = &s_score[t - kScoreOff];

@@ -317,10 +317,15 @@ __device__ __forceinline__ void bf_track_rel_f(float& best, float& second, float
 __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__ desc, const int32_t* __restrict__ n_rows,
                                                      int cap, const int32_t* __restrict__ pair_a,
                                                      const int32_t* __restrict__ pair_b, int32_t* __restrict__ best_idx,
-                                                     int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist) {
+                                                     int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist,
+                                                     int splits, uint32_t* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) uint8_t s_rows[2][kBfStageRows * kBfRowBytesF4];
   __shared__ uint32_t s_lut[256];  // byte -> its eight nibbles: the train rows are expanded with four table reads per dword
-  const int p = xcd_frame();
+  // splits > 1 (one pair per call, rgbl_hamming_bf): the launch's frame index is a slice of the train set instead of a pair;
+  // every slice leaves its packed best / second per query in `partial`, k_hamming_merge folds them (a frame against a frame is
+  // 8 query blocks: alone they occupy 8 of 256 CUs for 43 us)
+  const int split = splits > 1 ? xcd_frame() : 0;
+  const int p = splits > 1 ? 0 : xcd_frame();
   const int fa = pair_a ? pair_a[p] : 0, fb = pair_b ? pair_b[p] : 1;
   const int na = n_rows[fa], nb = n_rows[fb];
   const int q_base = xcd_item() * kBfQueriesPerBlock;
@@ -355,16 +360,19 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
   uint32_t out_best[2] = {kNone, kNone}, out_second[2] = {kNone, kNone};
 
   // stage s of the whole scan = train rows [64 s, 64 s + 64); work-item tid expands dwords tid and tid + 256 of it
-  const int n_stages = (nb + kBfStageRows - 1) / kBfStageRows;
+  const int all_stages = (nb + kBfStageRows - 1) / kBfStageRows;
+  const int stages_per = (all_stages + splits - 1) / (splits > 1 ? splits : 1);
+  const int s_begin = split * stages_per, n_stages = imin(all_stages, s_begin + stages_per);  // this launch slice: stages [s_begin, n_stages)
   auto load_stage = [&](int stage, uint32_t& x0, uint32_t& x1) {
     const int d0 = stage * (kBfStageRows * 8) + tid, d1 = d0 + 256;
     x0 = (d0 >> 3) < nb ? train[d0] : 0u;
     x1 = (d1 >> 3) < nb ? train[d1] : 0u;
   };
   uint32_t nx0 = 0, nx1 = 0;
-  if (n_stages > 0) load_stage(0, nx0, nx1);
+  if (n_stages > s_begin) load_stage(s_begin, nx0, nx1);
   float best[2] = {kBfIdleF, kBfIdleF}, second[2] = {kBfIdleF, kBfIdleF};
   int tiles_in_sweep = 0;
+  int sweep_start = s_begin * kBfStageRows;  // first train row of the sweep in progress
   auto close_sweep = [&](int sweep_base) {
     // relative keys -> (distance << 16 | absolute index), folded into the results of the earlier sweeps
 #pragma unroll
@@ -378,13 +386,13 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
     }
     tiles_in_sweep = 0;
   };
-  for (int stage = 0; stage < n_stages; ++stage) {
+  for (int stage = s_begin; stage < n_stages; ++stage) {
     uint8_t* buf = s_rows[stage & 1];
     const uint32_t x0 = nx0, x1 = nx1;
     if (stage + 1 < n_stages) load_stage(stage + 1, nx0, nx1);
     {
       uint8_t* r0 = buf + (tid >> 3) * kBfRowBytesF4 + (tid & 7) * 16;
-      if (stage == 0) {  // the table is not published yet
+      if (stage == s_begin) {  // the table is not published yet
         *reinterpret_cast<v4i*>(r0) = bf_expand_fp4(x0);
         *reinterpret_cast<v4i*>(r0 + 32 * kBfRowBytesF4) = bf_expand_fp4(x1);
       } else {
@@ -420,11 +428,11 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
           bf_track_rel_f(best[1], second[1], live ? acc1[r] : kBfIdleF);
         }
       }
-      if (((row0 + 32) & (kBfSweep - 1)) == 0) close_sweep(row0 + 32 - kBfSweep);
+      if (row0 + 32 - sweep_start == kBfSweep) { close_sweep(sweep_start); sweep_start = row0 + 32; }
     }
   }
   if (!wave_has_queries) return;
-  if (tiles_in_sweep > 0) close_sweep(((nb - 1) / kBfSweep) * kBfSweep);
+  if (tiles_in_sweep > 0) close_sweep(sweep_start);
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     // the two halves of the wave hold the same columns, interleaved groups of four rows
@@ -432,13 +440,35 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
     bf_merge(out_best[ct], out_second[ct], ob, os);
     const int qi = q_base + wave * 64 + ct * 32 + col;
     if (half == 0 && qi < na) {
-      const size_t o = (size_t)p * cap + qi;
-      best_idx[o] = out_best[ct] == kNone ? -1 : (int32_t)(out_best[ct] & 0xffffu);
-      best_dist[o] = (int32_t)(out_best[ct] >> 16);
-      if (second_dist) second_dist[o] = (int32_t)(out_second[ct] >> 16);
+      if (splits > 1) {
+        uint32_t* o = partial + ((size_t)split * na + qi) * 2;
+        o[0] = out_best[ct]; o[1] = out_second[ct];
+      } else {
+        const size_t o = (size_t)p * cap + qi;
+        best_idx[o] = out_best[ct] == kNone ? -1 : (int32_t)(out_best[ct] & 0xffffu);
+        best_dist[o] = (int32_t)(out_best[ct] >> 16);
+        if (second_dist) second_dist[o] = (int32_t)(out_second[ct] >> 16);
+      }
     }
   }
 }
+
+// folds the slices' packed (distance << 16 | index) best / second of every query (k_hamming_fp4 with splits > 1)
+__global__ __launch_bounds__(256) void k_hamming_merge(const uint32_t* __restrict__ partial, int na, int splits, int32_t* __restrict__ best_idx,
+                                                       int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist) {
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  if (qi >= na) return;
+  const uint32_t kNone = (256u << 16) | 0xffffu;
+  uint32_t b = kNone, s2 = kNone;
+  for (int sp = 0; sp < splits; ++sp) {
+    const uint32_t* o = partial + ((size_t)sp * na + qi) * 2;
+    bf_merge(b, s2, o[0], o[1]);
+  }
+  best_idx[qi] = b == kNone ? -1 : (int32_t)(b & 0xffffu);
+  best_dist[qi] = (int32_t)(b >> 16);
+  if (second_dist) second_dist[qi] = (int32_t)(s2 >> 16);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:329-403) for a batch of map points: among the
@@ -1416,7 +1446,9 @@ int rgbl_hamming_bf_batch_device(rgbl_matcher* m, const uint8_t* d_desc, const i
   RGBL_HIP(hipSetDevice(m->device));
   if (bf_on_matrix_cores()) {
     m->timer.begin(bf_on_fp4() ? "k_hamming_fp4" : "k_hamming_mfma", m->stream);
-    hipLaunchKernelGGL(bf_on_fp4() ? k_hamming_fp4 : k_hamming_mfma, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
+    if (bf_on_fp4()) hipLaunchKernelGGL(k_hamming_fp4, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
+                       d_desc, d_n, cap, d_pair_a, d_pair_b, d_best_idx, d_best_dist, d_second_dist, 1, (uint32_t*)nullptr);
+    else hipLaunchKernelGGL(k_hamming_mfma, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
                        d_desc, d_n, cap, d_pair_a, d_pair_b, d_best_idx, d_best_dist, d_second_dist);
   } else {
     m->timer.begin("k_hamming_bf", m->stream);
@@ -1438,13 +1470,20 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   RGBL_HIP(hipSetDevice(m->device));
   StreamDrain drain(m->stream);  // error returns included
   const int cap = std::max(std::max(na, nb), 1);
-  RGBL_TRY(ensure_arena(m, pad256((size_t)2 * cap * 32) + pad256(8) + 3 * pad256((size_t)na * 4)));
+  // One pair per call: the query blocks alone (8 for 2000 descriptors) would leave most of the chip idle, so the train set is
+  // cut into slices of whole 64-row stages, one launch slice each, folded by k_hamming_merge (FP4 kernel only).
+  const int qblocks = (na + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, stages = (nb + kBfStageRows - 1) / kBfStageRows;
+  int splits = 1;
+  if (bf_on_matrix_cores() && bf_on_fp4() && !(getenv("RGBL_BF_SPLIT") && getenv("RGBL_BF_SPLIT")[0] == '0'))
+    splits = std::max(1, std::min(std::min(16, stages / 4), 128 / std::max(qblocks, 1)));
+  RGBL_TRY(ensure_arena(m, pad256((size_t)2 * cap * 32) + pad256(8) + 3 * pad256((size_t)na * 4) + pad256((size_t)splits * na * 8)));
   Arena A{m->d_buf};
   uint8_t* d_desc = A.take<uint8_t>((size_t)2 * cap * 32);
   int32_t* d_n = A.take<int32_t>(2);
   int32_t* d_bi = A.take<int32_t>(na);
   int32_t* d_bd = A.take<int32_t>(na);
   int32_t* d_sd = A.take<int32_t>(na);
+  uint32_t* d_partial = A.take<uint32_t>((size_t)splits * na * 2);
   hipStream_t s = m->stream;
   const int32_t counts[2] = {na, nb};
   // Both descriptor sets and the counts are mirrored in one page-locked block laid out like the arena, so that they go up
@@ -1471,8 +1510,14 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   // pair_a/pair_b == NULL selects the fixed pair (frame 0 -> frame 1)
   if (bf_on_matrix_cores()) {
     m->timer.begin(bf_on_fp4() ? "k_hamming_fp4" : "k_hamming_mfma", s);
-    hipLaunchKernelGGL(bf_on_fp4() ? k_hamming_fp4 : k_hamming_mfma, xcd_grid(false, (na + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, 1), dim3(256), 0, s, d_desc, d_n, cap,
-                       (const int32_t*)nullptr, (const int32_t*)nullptr, d_bi, d_bd, d_sd);
+    if (bf_on_fp4()) {
+      hipLaunchKernelGGL(k_hamming_fp4, xcd_grid(false, qblocks, splits), dim3(256), 0, s, d_desc, d_n, cap, (const int32_t*)nullptr,
+                         (const int32_t*)nullptr, d_bi, d_bd, d_sd, splits, d_partial);
+      if (splits > 1) hipLaunchKernelGGL(k_hamming_merge, dim3((na + 255) / 256), dim3(256), 0, s, d_partial, na, splits, d_bi, d_bd, d_sd);
+    } else {
+      hipLaunchKernelGGL(k_hamming_mfma, xcd_grid(false, qblocks, 1), dim3(256), 0, s, d_desc, d_n, cap, (const int32_t*)nullptr,
+                         (const int32_t*)nullptr, d_bi, d_bd, d_sd);
+    }
   } else {
     m->timer.begin("k_hamming_bf", s);
     hipLaunchKernelGGL(k_hamming_bf, dim3((na + 63) / 64, 1), dim3(256), 0, s, d_desc, d_n, cap, (const int32_t*)nullptr,

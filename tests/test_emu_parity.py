@@ -60,8 +60,10 @@ def test_depth_edge_cases(emu_lib):
 
 def test_matcher(emu_lib):
     pc.check_matcher_known_answers(emu_lib)
-    pc.check_matcher_bf(emu_lib, 300, 280)
+    pc.check_matcher_bf(emu_lib, 300, 280)     # 5 stages of 64 train rows: one launch slice
     pc.check_matcher_bf(emu_lib, 1, 33)
+    pc.check_matcher_bf(emu_lib, 130, 700, seed=8)   # 11 stages: the train set goes in two slices, folded by k_hamming_merge
+    pc.check_matcher_bf(emu_lib, 70, 9000, seed=9)   # 16 slices, a sweep boundary (8192 rows) inside one of them
 
 
 def test_search_for_triangulation(emu_lib):

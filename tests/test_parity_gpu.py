@@ -92,6 +92,8 @@ def test_matcher_bf(gpu_lib):
     pc.check_matcher_bf(gpu_lib, 8000, 8000, seed=5)   # cfg 5
     pc.check_matcher_bf(gpu_lib, 1, 333)
     pc.check_matcher_bf(gpu_lib, 257, 1)
+    pc.check_matcher_bf(gpu_lib, 9000, 8800, seed=6)   # three launch slices, a sweep boundary (8192 train rows) inside the third
+    pc.check_matcher_bf(gpu_lib, 300, 20000, seed=7)   # 16 slices of 20 stages
 
 
 def test_search_for_triangulation(gpu_lib):

@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp; OUT=$PWD/gpurun_out; REPO=$PWD
 tag=$1; counters=$2; shift 2
 cd /tmp
-env "$@" timeout 250 rocprofv3 --pmc $counters -d $OUT/prof_$tag -o p -- python $REPO/bench.py --serial --no-cpu-baseline --no-extras --steps 3 --warmup 1 > $OUT/prof_$tag.log 2>&1
+env "$@" timeout 120 rocprofv3 --pmc $counters -d $OUT/prof_$tag -o p -- python $REPO/bench.py --serial --no-cpu-baseline --no-extras --steps 3 --warmup 1 > $OUT/prof_$tag.log 2>&1
 cd $REPO
 db=$(find $OUT/prof_$tag -name "*.db" | head -1)
 [ -n "$db" ] && python profiles/summarize_rocprof.py pmc $db $OUT/pmc_$tag.csv
