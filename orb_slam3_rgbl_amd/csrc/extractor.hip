@@ -425,9 +425,9 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
 
   // cells of at most kCellSmall px (every level of the usual image sizes) take the small-LDS instantiation: two waves per
   // cell (a cell is a chain of short phases; 16 workgroups of two waves per CU overlap better than 8 of four), tile pitch 48
-  // bytes when no level's cells are wider than 42 px, else 64; bigger cells: four waves, pitch 80
+  // bytes when no level's cells are wider than 41 px (cell + 7 bytes per tile row), else 64; bigger cells: four waves, pitch 80
   const int fast_bs = e->max_cell <= kCellSmall ? 128 : 256;
-  auto fast = e->max_cell <= kCellSmall ? (e->max_cell_w <= 42 ? k_fast_cells<kCellSmall, 128, 48> : k_fast_cells<kCellSmall, 128, 64>) : k_fast_cells<kCellMax, 256, 80>;
+  auto fast = e->max_cell <= kCellSmall ? (e->max_cell_w <= 41 ? k_fast_cells<kCellSmall, 128, 48> : k_fast_cells<kCellSmall, 128, 64>) : k_fast_cells<kCellMax, 256, 80>;
   auto launch_fast = [&](hipStream_t st, int cell_begin, int cell_end) {
     if (cell_end <= cell_begin) return;
     e->timer.begin("k_fast_cells", st);

@@ -336,20 +336,20 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
                                                     const LevelGeom* __restrict__ geom, int n_levels, uint32_t* __restrict__ dense_keys,
                                                     size_t keys_frame, uint32_t* __restrict__ level_cnt) {
   // P = pitch of BOTH LDS tiles in bytes: whole 16-byte pieces (the LDS-DMA's granule) and at least the widest tile row
-  // (cell width + 6).  48 for cells up to 42 px wide - every level of KITTI, EuRoC, VGA or 4K frames -: 12 banks per row, so
+  // (cell width + 7).  48 for cells up to 41 px wide - every level of KITTI, EuRoC, VGA or 4K frames -: 12 banks per row, so
   // the rows of a cell rotate through all 32 LDS banks and the scattered reads of phases B and C (a wave's survivors lie in
   // a handful of neighbouring rows) spread out; with 64 (16 banks) every other row started on the same bank and the cell's 10
   // word columns used 20 of the 32 banks: LDS bank-conflict cycles 1.45e8 -> see DESIGN 9.  64 / 80 for wider cells.
   static_assert(P % 16 == 0 && P >= 48 && P <= 80, "tile pitch");
   constexpr int kPieces = P / 16;
   // A pixel is named by its byte offset t = ty * P + tx in the pixel tile (tile coordinates: scanned pixel (x, y) sits at
-  // (x + 3, y + 3)); its score sits at t - kScoreOff in the score tile (same pitch, 1-px zero frame), its bit in the bitmap at
+  // (x + 4, y + 3): the scanned area starts on a 4-byte boundary of the tile rows); its score sits at t - kScoreOff in the score tile (same pitch, 1-px zero frame), its bit in the bitmap at
   // b = t - kBitOff = y * P + x.  Only phase A, which walks the scanned area linearly, needs a division.
-  constexpr int kScoreOff = 2 * P + 2, kBitOff = 3 * P + 3;
+  constexpr int kScoreOff = 2 * P + 3, kBitOff = 3 * P + 4;
   constexpr int kScoreQuads = (CM + 2) * P / 16;      // the score tile in 16-byte pieces
   constexpr int kBitWords = (CM * P + 63) / 64 * 2;   // bitmap words, an even number: the compaction reads them in pairs
   constexpr int kCornerCap = 512;                     // pixels with a score kept as a list for the NMS (all survivors are scanned beyond that)
-  __shared__ __attribute__((aligned(16))) uint32_t s_tile_w[(CM + 6) * P / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tile_w[(CM + 6) * P / 4 + 4];  // + slack: the last group of the last row reads one word on
   uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile_w);
   __shared__ __attribute__((aligned(16))) uint32_t s_score_w[kScoreQuads * 4];
   uint8_t* s_score = reinterpret_cast<uint8_t*>(s_score_w);
@@ -389,8 +389,9 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
   const int pitch = (C.l == 0) ? pitch0 : (int)C.pitch;
 
   // ---- stage the (sw+6) x (sh+6) pixel tile: a lane moves 16 bytes, four (five) lanes a tile row, the wave's pieces land in
-  //      LDS back to back = rows of pitch P.  The last piece of a row reads up to 15 bytes past the tile: still inside the
-  //      image (the tile ends >= 13 px left of the row's end, and never on the last row).
+  //      LDS back to back = rows of pitch P.  Tile column 0 is the pixel LEFT of the cell's sub-image (ini_x >= 13), so that the
+  //      scanned area starts at column 4.  The last piece of a row reads up to 14 bytes past the tile: still inside the image
+  //      (the tile ends >= 13 px left of the row's end, and never on the last row).
   const int npix = sw * sh;
   // p / sw == (p * ceil(2^20 / sw)) >> 20 while p * sw < 2^20 (p < 72 * 72, sw <= 72); the product stays below 2^27.
   // 24-bit multiplies: v_mul_u32_u24 issues at the full VALU rate, v_mul_hi_u32 / v_mul_lo_u32 at a quarter of it.
@@ -398,12 +399,12 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
   // pixel p = y * sw + x of the scanned area -> its tile offset t
 #define RGBL_T_OF(p) ((p) + (int)__umul24(__umul24((uint32_t)(p), magic) >> 20, (uint32_t)(P - sw)) + kBitOff)
   {
-    const int used = (tw + 15) >> 4;  // pieces of a row that hold tile bytes
+    const int used = (tw + 1 + 15) >> 4;  // pieces of a row that hold tile bytes (the tile starts one pixel left of the cell's sub-image)
     for (int j0 = 0; j0 < th * kPieces; j0 += BS) {
       const int j = j0 + tid;
       const int y = kPieces == 4 ? j >> 2 : (int)(__umul24((uint32_t)j, kPieces == 3 ? 0x5556u : 0x3334u) >> 16), k = j - y * kPieces;  // j / 3, j / 5 for j < 2^14
       if (y < th && k < used)
-        lds_dma16(img + (__umul24((uint32_t)(ini_y + y), (uint32_t)pitch) + (uint32_t)(ini_x + 16 * k)), s_tile + (j0 + (tid & ~63)) * 16);
+        lds_dma16(img + (__umul24((uint32_t)(ini_y + y), (uint32_t)pitch) + (uint32_t)(ini_x - 1 + 16 * k)), s_tile + (j0 + (tid & ~63)) * 16);
     }
   }
 #ifdef RGBL_FAST_SKIP
@@ -424,48 +425,63 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
 
     // ---- phase A: cheap necessary condition on the 4 axis/diagonal ring pairs, per polarity; survivors are listed with the
     //      polarity they can have (dark if both - the rare pixel that passes for both gets a second entry for the bright arc).
-    //      (Four pixels per task on packed 16-bit halves of aligned word pairs, as the fused per-level kernel of round 2 had
-    //      it, was measured slower here: 1.24 -> 1.39 ms.)
+    //      A work-item tests FOUR pixels of a row: the scanned area starts on a word boundary of the tile, so the 4 centres are
+    //      one aligned word and every ring byte has a fixed place in one of 11 aligned words (3 of the row, 3 each of the rows
+    //      +-2, 1 each of the rows +-3) - the byte selects fold into the min / max instructions (SDWA).  11 word reads instead
+    //      of 36 byte reads per 4 pixels, index arithmetic once per 4.
     const int wv = wave_id();
     {
       uint16_t* mine = s_surv + wv * kSurvPerWave;
       int n_mine = 0;  // wave-uniform
-      uint32_t pm = __umul24((uint32_t)tid, magic);
+      const int gpr = (sw + 3) >> 2, ngroups = gpr * sh;   // groups of 4 pixels per row / per cell
+      const uint32_t gmagic = (0x10000u + (uint32_t)gpr - 1u) / (uint32_t)gpr;  // g / gpr == (g * gmagic) >> 16 for g < 72 * 18, gpr <= 18
 #if defined(RGBL_FAST_SKIP) && RGBL_FAST_SKIP >= 2
-      for (int p0 = 0; p0 < 0; p0 += BS) {
+      for (int g0 = 0; g0 < 0; g0 += BS) {
 #else
-      for (int p0 = 0; p0 < npix; p0 += BS) {
+      for (int g0 = 0; g0 < ngroups; g0 += BS) {
 #endif
-        const int p = p0 + tid;
-        bool dark = false, bright = false;
-        int t = 0;
-        if (p < npix) {
-          t = p + (int)__umul24(pm >> 20, (uint32_t)(P - sw)) + kBitOff;  // RGBL_T_OF(p) with p * magic carried along
-          pm += (uint32_t)BS * magic;
-          const uint8_t* c = &s_tile[t];
-          const int v = c[0], lo = v - thr, hi = v + thr;
-          dark = true; bright = true;
+        // no divergent region around the tests: a lane past the last group works on that group again with all four pixels
+        // masked out (nvalid = 0), so that the flags stay scalar masks - the ballots below cost nothing
+        const int gl = g0 + tid, g = imin(gl, ngroups - 1);
+        const int gy = (int)(__umul24((uint32_t)g, gmagic) >> 16), gx = g - gy * gpr;
+        const int wi = (gy + 3) * (P / 4) + 1 + gx;   // word of the group's 4 centres
+        const int t0 = 4 * wi;
+        const uint32_t* W = s_tile_w + wi;
+        const uint32_t c0 = W[-1], c1 = W[0], c2 = W[1];
+        const uint32_t u0 = W[2 * (P / 4) - 1], u1 = W[2 * (P / 4)], u2 = W[2 * (P / 4) + 1];      // row + 2
+        const uint32_t d0 = W[-2 * (P / 4) - 1], d1 = W[-2 * (P / 4)], d2 = W[-2 * (P / 4) + 1];   // row - 2
+        const uint32_t u3 = W[3 * (P / 4)], d3 = W[-3 * (P / 4)];                                  // rows +- 3
+        const int nvalid = gl < ngroups ? sw - 4 * gx : 0;  // pixels of the group inside the scanned area (the last group of a row may hold fewer than 4)
+        // byte k (-4 .. 7, relative to the group's first pixel) of a row given as three words
+#define RGBL_B(w0, w1, w2, k) ((int)(((k) < 0 ? (w0) >> (8 * ((k) + 4)) : (k) < 4 ? (w1) >> (8 * ((k) & 3)) : (w2) >> (8 * ((k) - 4))) & 0xffu))
 #pragma unroll
-          for (int k = 0; k < 8; k += 2) {
-            const int a = RGBL_RING(c, P, k), b = RGBL_RING(c, P, k + 8);
-            dark = dark && (a < lo || b < lo);
-            bright = bright && (a > hi || b > hi);
+        for (int j = 0; j < 4; ++j) {
+          const int v = RGBL_B(c0, c1, c2, j), lo = v - thr, hi = v + thr;
+          const int a0 = RGBL_B(u3, u3, u3, j), b0 = RGBL_B(d3, d3, d3, j);                  // ring 0 / 8: (0, +3), (0, -3)
+          const int a1 = RGBL_B(c0, c1, c2, j + 3), b1 = RGBL_B(c0, c1, c2, j - 3);          // ring 4 / 12: (+3, 0), (-3, 0)
+          const int a2 = RGBL_B(u0, u1, u2, j + 2), b2 = RGBL_B(d0, d1, d2, j - 2);          // ring 2 / 10: (+2, +2), (-2, -2)
+          const int a3 = RGBL_B(d0, d1, d2, j + 2), b3 = RGBL_B(u0, u1, u2, j - 2);          // ring 6 / 14: (+2, -2), (-2, +2)
+          const int M = imax(imax(imin(a0, b0), imin(a1, b1)), imax(imin(a2, b2), imin(a3, b3)));   // every pair has a member below lo
+          const int m = imin(imin(imax(a0, b0), imax(a1, b1)), imin(imax(a2, b2), imax(a3, b3)));   // every pair has a member above hi
+          // ballots of the comparisons themselves (their scalar masks), combined in scalar registers: a ballot of a combined
+          // flag would turn it into a register and compare that again
+          const bool vj = j < nvalid, dk = M < lo, br = m > hi;
+          const unsigned long long mv = wave_ballot(vj), md = wave_ballot(dk) & mv, mb = wave_ballot(br) & mv;
+          const unsigned long long m_any = md | mb, m_both = md & mb;
+          if (vj && (dk || br)) {  // (a list that overflows only counts on: the cell is then scored pixel by pixel)
+            const int pos = n_mine + wave_rank(m_any);
+            if (pos < kSurvPerWave) mine[pos] = (uint16_t)(dk ? (t0 + j) : ((t0 + j) | 0x8000));
+          }
+          n_mine += (int)__popcll(m_any);
+          if (m_both) {
+            if (vj && dk && br) {
+              const int pos = n_mine + wave_rank(m_both);
+              if (pos < kSurvPerWave) mine[pos] = (uint16_t)((t0 + j) | 0x8000);
+            }
+            n_mine += (int)__popcll(m_both);
           }
         }
-        const unsigned long long m_any = wave_ballot(dark || bright);
-        if (dark || bright) {
-          const int pos = n_mine + wave_rank(m_any);
-          if (pos < kSurvPerWave) mine[pos] = (uint16_t)(dark ? t : (t | 0x8000));
-        }
-        n_mine += (int)__popcll(m_any);
-        const unsigned long long m_both = wave_ballot(dark && bright);
-        if (m_both) {
-          if (dark && bright) {
-            const int pos = n_mine + wave_rank(m_both);
-            if (pos < kSurvPerWave) mine[pos] = (uint16_t)(t | 0x8000);
-          }
-          n_mine += (int)__popcll(m_both);
-        }
+#undef RGBL_B
       }
       if (lane_id() == 0) s_nsurv[wv] = n_mine;
     }
@@ -485,21 +501,16 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
       uint16_t* mine = s_corner + wv * kCornerPerWave;
       int n_mine = 0;
       for (int i0 = 0; i0 < nsurv; i0 += BS) {
-        const int i = i0 + tid;
-        bool corner = false;
-        int t = 0;
-        if (i < nsurv) {
-          int e;
-          if (all) e = RGBL_T_OF(i >> 1) | ((i & 1) << 15);
-          else RGBL_LIST_AT(s_surv, cs, kSurvPerWave, i, e);
-          t = e & 0x7fff;
-          const int sc = fast_score_one(&s_tile[t], P, (e & 0x8000) ? 0x00010001u : 0xffffffffu);
-          if (sc >= thr) {  // at most one of a pixel's two arcs can exist
-            s_score[t - kScoreOff] = (uint8_t)sc;
-            corner = true;
-          }
-        }
-        const unsigned long long m = wave_ballot(corner);
+        // (a lane past the end scores the last entry again and is masked out: no divergent region, the flag stays a scalar mask)
+        const int il = i0 + tid, i = imin(il, nsurv - 1);
+        int e;
+        if (all) e = RGBL_T_OF(i >> 1) | ((i & 1) << 15);
+        else RGBL_LIST_AT(s_surv, cs, kSurvPerWave, i, e);
+        const int t = e & 0x7fff;
+        const int sc = fast_score_one(&s_tile[t], P, (e & 0x8000) ? 0x00010001u : 0xffffffffu);
+        const bool live = il < nsurv, hit = sc >= thr, corner = live && hit;  // at most one of a pixel's two arcs can exist
+        if (corner) s_score[t - kScoreOff] = (uint8_t)sc;
+        const unsigned long long m = wave_ballot(live) & wave_ballot(hit);
         if (corner) {
           const int pos = n_mine + wave_rank(m);
           if (pos < kCornerPerWave) mine[pos] = (uint16_t)t;
