@@ -39,9 +39,10 @@ def pmc(db, out):
             wr.writerow([short(name), counter, n, "%.3f" % val, "%.1f" % (dur or 0)])
 
 
-def traffic(out_dir, steps, warmup, frames_per_step, out):
-    """FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial` (prof_bench_*) + of tools/micro/hbm_calib (prof_calib_*) ->
-    bytes per STEP per kernel (sum over the dispatches of the timed + profiled steps / their number), calibrated."""
+def traffic(out_dir, steps, warmup, frames_per_step, out, tag="bench", extra_args=""):
+    """FETCH_SIZE / WRITE_SIZE (and SQ_INSTS_VALU) passes of `bench.py --serial` (prof_<tag>_*) + of tools/micro/hbm_calib
+    (prof_calib_*) -> bytes (vector instructions) per STEP per kernel (sum over the dispatches of the timed + profiled steps /
+    their number), the bytes calibrated."""
     import glob
     import json
     import os
@@ -67,8 +68,9 @@ def traffic(out_dir, steps, warmup, frames_per_step, out):
     # bench.py runs `warmup` + `steps` timed steps and 3 more for its per-kernel timing leg, all serialised
     n_steps = int(steps) + int(warmup) + 3
     kernels = {}
-    for c, f, key in (("FETCH_SIZE", f_fetch, "fetch_bytes_per_step"), ("WRITE_SIZE", f_write, "write_bytes_per_step")):
-        for name, counter, n, total in rows("bench_" + c):
+    for c, f, key in (("FETCH_SIZE", f_fetch, "fetch_bytes_per_step"), ("WRITE_SIZE", f_write, "write_bytes_per_step"),
+                      ("SQ_INSTS_VALU", 1.0, "valu_insts_per_step")):
+        for name, counter, n, total in rows(tag + "_" + c):
             k = short(name)
             if not k.startswith("k_"):
                 continue
@@ -77,12 +79,12 @@ def traffic(out_dir, steps, warmup, frames_per_step, out):
             d["dispatches_per_step"] = n / n_steps
     json.dump({"frames_per_step": int(frames_per_step), "steps_profiled": n_steps,
                "bytes_per_counter_unit": factors, "factor_used": {"FETCH_SIZE": f_fetch, "WRITE_SIZE": f_write},
-               "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --serial --no-cpu-baseline --no-extras --steps %s --warmup %s" % (steps, warmup),
+               "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU -- python bench.py --serial --no-cpu-baseline --no-extras --steps %s --warmup %s %s" % (steps, warmup, extra_args),
                "kernels": kernels}, open(out, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "traffic":
-        traffic(*sys.argv[2:7])
+        traffic(*sys.argv[2:9])
     else:
         {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
