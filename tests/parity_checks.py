@@ -116,6 +116,16 @@ def check_extractor_edge_cases(lib, w=160, h=120):
     okps, odesc, omono = orc(chk)
     assert_keypoints_equal(kps, okps, "checkerboard")
     assert np.array_equal(desc, odesc)
+    # white noise: more pre-screen survivors than the FAST kernel's per-wave lists hold (every pixel is then scored, both
+    # polarities) and more corners than its corner lists hold (the NMS then scans all survivors); two-level noise: plateaus
+    noise = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    salt = (rng.random((h, w)) > 0.5).astype(np.uint8) * 200 + 20
+    for name, im in (("white noise", noise), ("two-level noise", salt)):
+        kps, desc, mono = ex(im)
+        okps, odesc, omono = orc(im)
+        assert len(okps) > 100
+        assert_keypoints_equal(kps, okps, name)
+        assert np.array_equal(desc, odesc)
     # non-contiguous rows (stride > width)
     big = np.zeros((h, w + 37), np.uint8)
     img = synth.Sequence(9, w, h, 1).frame(0)
