@@ -424,6 +424,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the 4K / stereo / single-frame figures (extra keys of the JSON line)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--serial", action="store_true", help="one stream for all handles (clean per-kernel timings)")
+    ap.add_argument("--lanes", type=int, default=1, choices=[1, 2],
+                    help="2: two sets of handles used alternately - two steps in flight (pipeline.py)")
     ap.add_argument("--gather", default=None, choices=["step", "final", "none"],
                     help="gather of the keypoint / descriptor / depth records to rank 0: stream every step's records while the "
                          "next step computes (default for N > 1), exchange all of them once at the end, or not at all (default "
@@ -477,7 +479,7 @@ def main():
     # orb_slam3_rgbl_amd/pipeline.py - the same code tests/test_distributed.py drives with two gloo ranks
     pipe = FrontEndPipeline(lib, torch, dev, w, h, nfeatures, proj, n_points, B, levels=LEVELS, scale=SCALE, ini_th=INI_TH,
                             min_th=MIN_TH, world=world, rank=rank, gather=gather, serial=args.serial,
-                            log_steps=args.steps + args.warmup)
+                            log_steps=args.steps + args.warmup, lanes=args.lanes)
     ex, dm, mt, cap = pipe.ex, pipe.dm, pipe.mt, pipe.cap
     d_imgs = torch.from_numpy(frames).to(dev)
     d_cloud = torch.from_numpy(cloud).to(dev)

@@ -454,6 +454,8 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
         const int nvalid = gl < ngroups ? sw - 4 * gx : 0;  // pixels of the group inside the scanned area (the last group of a row may hold fewer than 4)
         // byte k (-4 .. 7, relative to the group's first pixel) of a row given as three words
 #define RGBL_B(w0, w1, w2, k) ((int)(((k) < 0 ? (w0) >> (8 * ((k) + 4)) : (k) < 4 ? (w1) >> (8 * ((k) & 3)) : (w2) >> (8 * ((k) - 4))) & 0xffu))
+        bool dk[4], br[4], vj[4];
+        int cnt = 0;  // list entries of this work-item: one per surviving pixel, two where both polarities pass
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int v = RGBL_B(c0, c1, c2, j), lo = v - thr, hi = v + thr;
@@ -463,24 +465,23 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
           const int a3 = RGBL_B(d0, d1, d2, j + 2), b3 = RGBL_B(u0, u1, u2, j - 2);          // ring 6 / 14: (+2, -2), (-2, +2)
           const int M = imax(imax(imin(a0, b0), imin(a1, b1)), imax(imin(a2, b2), imin(a3, b3)));   // every pair has a member below lo
           const int m = imin(imin(imax(a0, b0), imax(a1, b1)), imin(imax(a2, b2), imax(a3, b3)));   // every pair has a member above hi
-          // ballots of the comparisons themselves (their scalar masks), combined in scalar registers: a ballot of a combined
-          // flag would turn it into a register and compare that again
-          const bool vj = j < nvalid, dk = M < lo, br = m > hi;
-          const unsigned long long mv = wave_ballot(vj), md = wave_ballot(dk) & mv, mb = wave_ballot(br) & mv;
-          const unsigned long long m_any = md | mb, m_both = md & mb;
-          if (vj && (dk || br)) {  // (a list that overflows only counts on: the cell is then scored pixel by pixel)
-            const int pos = n_mine + wave_rank(m_any);
-            if (pos < kSurvPerWave) mine[pos] = (uint16_t)(dk ? (t0 + j) : ((t0 + j) | 0x8000));
-          }
-          n_mine += (int)__popcll(m_any);
-          if (m_both) {
-            if (vj && dk && br) {
-              const int pos = n_mine + wave_rank(m_both);
-              if (pos < kSurvPerWave) mine[pos] = (uint16_t)((t0 + j) | 0x8000);
-            }
-            n_mine += (int)__popcll(m_both);
+          vj[j] = j < nvalid; dk[j] = M < lo; br[j] = m > hi;
+          cnt += (vj[j] && (dk[j] || br[j])) ? 1 : 0;
+          cnt += (vj[j] && dk[j] && br[j]) ? 1 : 0;
+        }
+        // One reservation per work-item and trip instead of one per pixel: the work-items' entry counts are scanned over the
+        // wave (DPP adds), a work-item then writes its entries one after the other.  A trip that does not fit the list as a
+        // whole writes nothing (uniform) and only counts on: the cell is then scored pixel by pixel.
+        const int incl = wave_inclusive_scan(cnt), total = wave_last(incl);
+        if (n_mine + total <= kSurvPerWave) {
+          uint16_t* dst = mine + (n_mine + incl - cnt);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (vj[j] && (dk[j] || br[j])) *dst++ = (uint16_t)(dk[j] ? (t0 + j) : ((t0 + j) | 0x8000));
+            if (vj[j] && dk[j] && br[j]) *dst++ = (uint16_t)((t0 + j) | 0x8000);
           }
         }
+        n_mine += total;
 #undef RGBL_B
       }
       if (lane_id() == 0) s_nsurv[wv] = n_mine;

@@ -62,31 +62,47 @@ class OutSet:
             self.ev[name] = e
 
 
+class _Lane:
+    """One set of handles (extractor, depth module, matcher) with their streams: the work of one step."""
+
+    def __init__(self, lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial):
+        self.ex = F.ORBextractor(nfeatures, scale, levels, ini_th, min_th, w, h, max_batch=batch, device=index, lib=lib)
+        self.dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=self.ex.max_keypoints, max_batch=batch, device=index, lib=lib)
+        self.mt = F.ORBmatcher(0.6, False, device=index, lib=lib)
+        one = C.c_void_p(lib.rgbl_extractor_stream(self.ex.h))
+        if serial:
+            L.check(lib, lib.rgbl_depth_set_stream(self.dm.h, one))
+            L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
+        elif os.environ.get("RGBL_MATCHER_STREAM", "shared") != "own":
+            # the matcher queued on the extractor's stream (round 1: the VALU popcount scan was issue-bound like FAST and only
+            # competed with it on a stream of its own); RGBL_MATCHER_STREAM=own lets the matrix-core scan run next to it
+            L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
+        self.streams(lib)
+
+    def streams(self, lib):
+        self.s_ex = C.c_void_p(lib.rgbl_extractor_stream(self.ex.h))
+        self.s_dm = C.c_void_p(lib.rgbl_depth_stream(self.dm.h))
+        self.s_mt = C.c_void_p(lib.rgbl_matcher_stream(self.mt.h))
+
+
 class FrontEndPipeline:
     def __init__(self, lib, torch, dev, w, h, nfeatures, proj, n_points, batch, levels=8, scale=1.2, ini_th=12, min_th=7,
-                 world=1, rank=0, gather="step", serial=False, keep_steps=0, log_steps=1):
+                 world=1, rank=0, gather="step", serial=False, keep_steps=0, log_steps=1, lanes=1):
         self.lib, self.torch, self.dev = lib, torch, dev
         self.w, self.h, self.B, self.n_points = w, h, batch, n_points
         self.world, self.rank, self.gather = world, rank, gather
         index = dev.index if dev.type == "cuda" else 0
-        self.exs = [F.ORBextractor(nfeatures, scale, levels, ini_th, min_th, w, h, max_batch=batch, device=index, lib=lib)]
-        self.ex = self.exs[0]
+        # lanes = 2: two sets of handles used alternately, step k on lane k mod 2 with the output set k mod 2 - two steps in
+        # flight: the tail of step k (quad-trees of the upper levels, descriptors, matching: dependent chains and gathers that
+        # leave most vector-issue slots idle) runs next to the head of step k + 1 (pyramid, FAST, Gaussian: issue-bound)
+        self.lanes = [_Lane(lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial)
+                      for _ in range(1 if serial else max(1, min(lanes, 2)))]
+        self.ex, self.dm, self.mt = self.lanes[0].ex, self.lanes[0].dm, self.lanes[0].mt
         self.cap = self.ex.max_keypoints
-        self.dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=self.cap, max_batch=batch, device=index, lib=lib)
-        self.mt = F.ORBmatcher(0.6, False, device=index, lib=lib)
-        one = C.c_void_p(lib.rgbl_extractor_stream(self.exs[-1].h))   # the last handle's stream sees the whole extraction done
         if serial:
             # one stream for all handles and per-kernel HIP-event brackets on: every launch of the run is serialised - the
             # mode `rocprofv3 --kernel-trace --stats` is recorded in (profiles/)
-            L.check(lib, lib.rgbl_depth_set_stream(self.dm.h, one))
-            L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
             self.profile(True)
-        elif os.environ.get("RGBL_MATCHER_STREAM", "shared") != "own":
-            # the matcher queued behind the extraction of step i + 1 on the extractor's stream (round 1: the VALU popcount
-            # scan was issue-bound like FAST and only competed with it on a stream of its own); RGBL_MATCHER_STREAM=own
-            # lets the matrix-core scan run next to the extraction instead
-            L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
-        self._streams()
         self.sets = [OutSet(lib, torch, dev, batch, self.cap) for _ in range(2)]
         self.pair_a = torch.arange(batch, dtype=torch.int32, device=dev)
         self.pair_b = (self.pair_a + 1) % batch
@@ -118,31 +134,28 @@ class FrontEndPipeline:
             if rank == 0:
                 self.recv = [[torch.zeros(rec_cap * RECORD_BYTES, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(2)]
 
-    def _streams(self):
-        lib = self.lib
-        self.s_exs = [C.c_void_p(lib.rgbl_extractor_stream(e.h)) for e in self.exs]
-        self.s_ex = self.s_exs[-1]
-        self.s_dm = C.c_void_p(lib.rgbl_depth_stream(self.dm.h))
-        self.s_mt = C.c_void_p(lib.rgbl_matcher_stream(self.mt.h))
-
     def profile(self, on):
-        for e in self.exs:
-            e.profile(on)
-        self.dm.profile(on); self.mt.profile(on)
+        for ln in self.lanes:
+            ln.ex.profile(on); ln.dm.profile(on); ln.mt.profile(on)
 
     def serialise(self):
-        """All handles on the extractor's stream (the per-kernel timing leg of bench.py)."""
-        one = C.c_void_p(self.lib.rgbl_extractor_stream(self.exs[-1].h))
-        L.check(self.lib, self.lib.rgbl_depth_set_stream(self.dm.h, one))
-        L.check(self.lib, self.lib.rgbl_matcher_set_stream(self.mt.h, one))
-        self._streams()
+        """One lane, all its handles on the extractor's stream (the per-kernel timing leg of bench.py)."""
+        self.sync()
+        ln = self.lanes[0]
+        self.all_lanes = list(self.lanes)
+        self.lanes = [ln]
+        one = C.c_void_p(self.lib.rgbl_extractor_stream(ln.ex.h))
+        L.check(self.lib, self.lib.rgbl_depth_set_stream(ln.dm.h, one))
+        L.check(self.lib, self.lib.rgbl_matcher_set_stream(ln.mt.h, one))
+        ln.streams(self.lib)
 
     def profile_read(self):
         k = {}
-        for src in [e.profile_read() for e in self.exs] + [self.dm.profile_read(), self.mt.profile_read()]:
-            for name, (ms, n) in src.items():
-                a = k.get(name, (0.0, 0))
-                k[name] = (a[0] + ms, a[1] + n)
+        for ln in self.lanes:
+            for src in (ln.ex.profile_read(), ln.dm.profile_read(), ln.mt.profile_read()):
+                for name, (ms, n) in src.items():
+                    a = k.get(name, (0.0, 0))
+                    k[name] = (a[0] + ms, a[1] + n)
         return k
 
     def set_inputs(self, d_imgs, d_cloud):
@@ -155,29 +168,24 @@ class FrontEndPipeline:
     def step(self):
         lib, p, B, w, h, cap = self.lib, self._p, self.B, self.w, self.h, self.cap
         o = self.sets[self.step_no % 2]
-        # this set's readers of two steps ago must be done before the extractors overwrite it
-        half = B
-        for i, (e, s_e) in enumerate(zip(self.exs, self.s_exs)):
-            L.check(lib, lib.rgbl_event_wait(s_e, o.ev["depth_done"]))
-            L.check(lib, lib.rgbl_event_wait(s_e, o.ev["match_done"]))
-            if self.gather != "none":
-                L.check(lib, lib.rgbl_event_wait(s_e, o.ev["comm_done"]))
-            f0 = i * half
-            L.check(lib, lib.rgbl_extract_batch_device(e.h, p(self.d_imgs[f0:]), half, w, h, w, w * h, 0, 0, p(o.kp[f0:]), p(o.desc[f0:]), cap,
-                                                       p(o.n[f0:]), p(o.mono[f0:])))
-        for s_e in self.s_exs[:-1]:
-            L.check(lib, lib.rgbl_stream_wait(self.s_ex, s_e))   # "extracted" = every half
-        L.check(lib, lib.rgbl_event_record(o.ev["extracted"], self.s_ex))
+        ln = self.lanes[self.step_no % len(self.lanes)]
+        # this set's readers of two steps ago must be done before the extractor overwrites it
+        L.check(lib, lib.rgbl_event_wait(ln.s_ex, o.ev["depth_done"]))
+        L.check(lib, lib.rgbl_event_wait(ln.s_ex, o.ev["match_done"]))
+        if self.gather != "none":
+            L.check(lib, lib.rgbl_event_wait(ln.s_ex, o.ev["comm_done"]))
+        L.check(lib, lib.rgbl_extract_batch_device(ln.ex.h, p(self.d_imgs), B, w, h, w, w * h, 0, 0, p(o.kp), p(o.desc), cap, p(o.n), p(o.mono)))
+        L.check(lib, lib.rgbl_event_record(o.ev["extracted"], ln.s_ex))
         # LiDAR projection + up-sampling: independent of the keypoints, runs concurrently on the depth stream
         n_points = self.n_points
-        L.check(lib, lib.rgbl_depth_project_batch_device(self.dm.h, p(self.d_cloud), B, n_points, n_points, 4 * n_points, w, h, None))
-        L.check(lib, lib.rgbl_event_wait(self.s_dm, o.ev["extracted"]))
-        L.check(lib, lib.rgbl_depth_gather_batch_device(self.dm.h, B, w, h, p(o.kp), p(o.n), cap, None, p(o.depth), p(o.uright)))
-        L.check(lib, lib.rgbl_event_record(o.ev["depth_done"], self.s_dm))
-        L.check(lib, lib.rgbl_event_wait(self.s_mt, o.ev["extracted"]))
-        L.check(lib, lib.rgbl_hamming_bf_batch_device(self.mt.h, p(o.desc), p(o.n), cap, p(self.pair_a), p(self.pair_b), B, p(o.bi),
+        L.check(lib, lib.rgbl_depth_project_batch_device(ln.dm.h, p(self.d_cloud), B, n_points, n_points, 4 * n_points, w, h, None))
+        L.check(lib, lib.rgbl_event_wait(ln.s_dm, o.ev["extracted"]))
+        L.check(lib, lib.rgbl_depth_gather_batch_device(ln.dm.h, B, w, h, p(o.kp), p(o.n), cap, None, p(o.depth), p(o.uright)))
+        L.check(lib, lib.rgbl_event_record(o.ev["depth_done"], ln.s_dm))
+        L.check(lib, lib.rgbl_event_wait(ln.s_mt, o.ev["extracted"]))
+        L.check(lib, lib.rgbl_hamming_bf_batch_device(ln.mt.h, p(o.desc), p(o.n), cap, p(self.pair_a), p(self.pair_b), B, p(o.bi),
                                                       p(o.bd), p(o.sd)))
-        L.check(lib, lib.rgbl_event_record(o.ev["match_done"], self.s_mt))
+        L.check(lib, lib.rgbl_event_record(o.ev["match_done"], ln.s_mt))
         if self.gather != "none":
             prev = self.pending
             if self.gather == "step" and prev is not None:
@@ -268,8 +276,8 @@ class FrontEndPipeline:
     def sync(self):
         if self.dev.type == "cuda":
             self.torch.cuda.synchronize(self.dev)
-        for e in self.exs:
-            L.check(self.lib, self.lib.rgbl_extractor_sync(e.h))  # also surfaces device-side overflow flags
+        for ln in self.lanes:
+            L.check(self.lib, self.lib.rgbl_extractor_sync(ln.ex.h))  # also surfaces device-side overflow flags
         if self.gather != "none" and int(self.overflow.cpu()[0]) != 0:
             raise RuntimeError("record buffer overflow in rgbl_pack_records_device")
 
@@ -277,9 +285,8 @@ class FrontEndPipeline:
         return self.sets[(self.step_no - 1) % 2]
 
     def close(self):
-        for e in self.exs:
-            e.close()
-        self.dm.close(); self.mt.close()
+        for ln in getattr(self, "all_lanes", self.lanes):
+            ln.ex.close(); ln.dm.close(); ln.mt.close()
 
 
 class _Null:
