@@ -326,9 +326,10 @@ def test_pack_records_on_the_device(gpu_lib):
     assert int(off.cpu()[0]) == 5
 
 
-@pytest.mark.parametrize("mode", ["step", "final"])
-def test_gather_choreography_with_one_rank(gpu_lib, mode):
+@pytest.mark.parametrize("mode,lanes", [("step", 1), ("final", 1), ("step", 2), ("final", 2)])
+def test_gather_choreography_with_one_rank(gpu_lib, mode, lanes):
     # FrontEndPipeline with gather = step | final at world == 1: the pack on the communication stream, the counts through
     # page-locked memory behind an event, the root's device copy and the comm_done / depth_done / match_done events all
     # execute on the hardware (no peer, so no RCCL transfer); the records must decode to the step's own outputs
-    pc.check_pipeline_gather(gpu_lib, mode)
+    # lanes = 2: two steps in flight on two sets of handles (pipeline.py)
+    pc.check_pipeline_gather(gpu_lib, mode, lanes=lanes)
