@@ -218,6 +218,15 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { return 
 __device__ __forceinline__ uint32_t pk_swap(uint32_t a) { return from_s2(as_s2(a).yx); }
 #endif
 
+// Hides where an LDS index came from: the compiler otherwise folds "index - constant" back into the accesses' offsets, and
+// every NEGATIVE offset then costs an address addition (DS instructions take unsigned immediate offsets only).
+__device__ __forceinline__ int opaque(int v) {
+#ifndef RGBL_EMU
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+
 // The FAST score of ONE polarity: the largest threshold t at which the pixel still has a 9-arc of that polarity (< 0: none) =
 // cv cornerScore<16> for a corner of that polarity.  A 9-arc of darker pixels and a 9-arc of brighter ones exclude each other
 // (9 + 9 > 16), and the pre-screen says which of the two a pixel can have - well below 5 % of its survivors pass for both.
@@ -234,13 +243,16 @@ __device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t 
 #else
 __device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) { return from_s2(as_s2(a) * as_s2(b) + as_s2(c)); }
 #endif
-__device__ __forceinline__ int fast_score_one(const uint8_t* c, int P, uint32_t sgn) {
-  const uint32_t v = c[0];
+__device__ __forceinline__ int fast_score_one(const uint8_t* tile, int t, int P, uint32_t sgn) {
+  // the pixel at tile[t]; every read as a non-negative offset from the ring's first byte (row - 3, column - 3)
+  const uint8_t* const o = tile + opaque(t - (3 * P + 3));
+#define RGBL_O(k) o[ring_off((k), P) + 3 * P + 3]
+  const uint32_t v = o[3 * P + 3];
   const uint32_t vs = pk_mad_i16(v | (v << 16), sgn ^ 0xfffefffeu, 0u);  // -sgn * v in both halves (sgn = -1 -> * 1, sgn = 1 -> * -1)
   uint32_t D[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const uint32_t a = c[ring_off(k, P)], b = c[ring_off(k + 8, P)];
+    const uint32_t a = RGBL_O(k), b = RGBL_O(k + 8);
     D[k] = pk_mad_i16(a | (b << 16), sgn, vs);  // sgn * ring - sgn * v
   }
 #define RGBL_AT(A, k) ((k) < 8 ? (A)[(k) & 7] : pk_swap((A)[((k) - 8) & 7]))
@@ -253,6 +265,7 @@ __device__ __forceinline__ int fast_score_one(const uint8_t* c, int P, uint32_t 
 #pragma unroll
   for (int k = 0; k < 8; ++k) best = pk_max_i16(best, pk_min_i16(pk_min_i16(mn4[k], RGBL_AT(mn4, k + 4)), pk_swap(D[k])));
 #undef RGBL_AT
+#undef RGBL_O
   return imax((int)(int16_t)(best & 0xffffu), (int)(int16_t)(best >> 16)) - 1;
 }
 
@@ -446,11 +459,12 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
         const int gy = (int)(__umul24((uint32_t)g, gmagic) >> 16), gx = g - gy * gpr;
         const int wi = (gy + 3) * (P / 4) + 1 + gx;   // word of the group's 4 centres
         const int t0 = 4 * wi;
-        const uint32_t* W = s_tile_w + wi;
-        const uint32_t c0 = W[-1], c1 = W[0], c2 = W[1];
-        const uint32_t u0 = W[2 * (P / 4) - 1], u1 = W[2 * (P / 4)], u2 = W[2 * (P / 4) + 1];      // row + 2
-        const uint32_t d0 = W[-2 * (P / 4) - 1], d1 = W[-2 * (P / 4)], d2 = W[-2 * (P / 4) + 1];   // row - 2
-        const uint32_t u3 = W[3 * (P / 4)], d3 = W[-3 * (P / 4)];                                  // rows +- 3
+        const uint32_t* W = s_tile_w + (wi - 3 * (P / 4));   // row - 3
+        constexpr int R = P / 4;
+        const uint32_t c0 = W[3 * R - 1], c1 = W[3 * R], c2 = W[3 * R + 1];
+        const uint32_t u0 = W[5 * R - 1], u1 = W[5 * R], u2 = W[5 * R + 1];   // row + 2
+        const uint32_t d0 = W[R - 1], d1 = W[R], d2 = W[R + 1];               // row - 2
+        const uint32_t u3 = W[6 * R], d3 = W[0];                              // rows +- 3
         const int nvalid = gl < ngroups ? sw - 4 * gx : 0;  // pixels of the group inside the scanned area (the last group of a row may hold fewer than 4)
         // byte k (-4 .. 7, relative to the group's first pixel) of a row given as three words
 #define RGBL_B(w0, w1, w2, k) ((int)(((k) < 0 ? (w0) >> (8 * ((k) + 4)) : (k) < 4 ? (w1) >> (8 * ((k) & 3)) : (w2) >> (8 * ((k) - 4))) & 0xffu))
@@ -508,7 +522,7 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
         if (all) e = RGBL_T_OF(i >> 1) | ((i & 1) << 15);
         else RGBL_LIST_AT(s_surv, cs, kSurvPerWave, i, e);
         const int t = e & 0x7fff;
-        const int sc = fast_score_one(&s_tile[t], P, (e & 0x8000) ? 0x00010001u : 0xffffffffu);
+        const int sc = fast_score_one(s_tile, t, P, (e & 0x8000) ? 0x00010001u : 0xffffffffu);
         const bool live = il < nsurv, hit = sc >= thr, corner = live && hit;  // at most one of a pixel's two arcs can exist
         if (corner) s_score[t - kScoreOff] = (uint8_t)sc;
         const unsigned long long m = wave_ballot(live) & wave_ballot(hit);
@@ -533,9 +547,9 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
       if (listed) t = s_corner[wv * kCornerPerWave + i];
       else if (all) t = RGBL_T_OF(i >> 1);
       else { RGBL_LIST_AT(s_surv, cs, kSurvPerWave, i, t); t &= 0x7fff; }
-      const uint8_t* s = &s_score[t - kScoreOff];
-      const int v = s[0];
-      if (v != 0 && v > s[-1] && v > s[1] && v > s[-P - 1] && v > s[-P] && v > s[-P + 1] && v > s[P - 1] && v > s[P] && v > s[P + 1]) {
+      const uint8_t* s = &s_score[t - kScoreOff - (P + 1)];  // the 3x3 neighbourhood's first byte
+      const int v = s[P + 1];
+      if (v != 0 && v > s[P] && v > s[P + 2] && v > s[0] && v > s[1] && v > s[2] && v > s[2 * P] && v > s[2 * P + 1] && v > s[2 * P + 2]) {
         const int b = t - kBitOff;
         atomicOr(&s_keep[b >> 5], 1u << (b & 31));  // (a pixel listed twice sets its bit twice)
         s_any = 1;

@@ -109,6 +109,13 @@ def test_extractor_quadtree_kernel_variants(emu_lib, ncap):
         os.environ.pop("RGBL_OCTREE_NCAP", None)
 
 
+def test_extractor_fast_kernel_instantiations(emu_lib):
+    # k_fast_cells<48, 128, 48> is what the usual frames take; 43-px-wide cells take the 64-byte tile pitch, cells above 48 px
+    # (the last level of a VGA frame: 51 px high) the four-wave kernel with the 80-byte pitch
+    pc.check_extractor(emu_lib, 159, 152, 200, frames=(0, 1), nlevels=1, seq=3, stages=True)
+    pc.check_extractor(emu_lib, 640, 480, 600, frames=(0,), seq=4, stages=True)
+
+
 def test_extractor_quadtree_empty_root_nodes(emu_lib):
     pc.check_extractor_empty_root(emu_lib)
 

@@ -51,6 +51,12 @@ def test_extractor_other_shapes(gpu_lib):
     pc.check_extractor(gpu_lib, 1226, 370, 2000, frames=(0,), seq=8)                  # KITTI 04-12
 
 
+def test_extractor_fast_kernel_instantiations(gpu_lib):
+    # 43-px-wide cells: k_fast_cells<48, 128, 64>; 51-px cells on the last level: k_fast_cells<72, 256, 80>
+    pc.check_extractor(gpu_lib, 159, 152, 200, frames=(0, 1), nlevels=1, seq=3, stages=True)
+    pc.check_extractor(gpu_lib, 640, 480, 600, frames=(0,), seq=4, stages=True)
+
+
 def test_extractor_edge_cases(gpu_lib):
     pc.check_extractor_edge_cases(gpu_lib)
     pc.check_extractor_empty_root(gpu_lib)

@@ -10,6 +10,8 @@ which = sys.argv[1]
 if which == "extract":
     pc.check_extractor(lib, 400, 300, 600, frames=(0,), stages=True)
     pc.check_extractor_partial_batches(lib, 360, 280, 400)
+    pc.check_extractor(lib, 159, 152, 200, frames=(0,), nlevels=1, seq=3)   # 43-px cells: the 64-byte tile pitch
+    pc.check_extractor(lib, 640, 480, 600, frames=(0,), seq=4)                # 51-px cells on the last level: four waves, 80-byte pitch
 elif which == "depth":
     for m in (F.UPS_INVERSE_DILATION, F.UPS_AVERAGE_FILTERING, F.UPS_NEAREST_NEIGHBOR_PIXEL):
         pc.check_depth(lib, m, w=620, h=188, n_az=900, n_kp=400)
@@ -18,6 +20,7 @@ elif which == "depth":
     pc.check_ingest_kitti_bin(lib)
 elif which == "match":
     pc.check_matcher_bf(lib, 300, 280)
+    pc.check_matcher_bf(lib, 130, 700, seed=8)   # two launch slices + merge
     pc.check_triangulation(lib, 600, seed=11)
     pc.check_search_by_projection(lib, 21, "forward", 7.0, False, True, n1=700, n2=800)
     pc.check_search_by_projection_edge_cases(lib)
