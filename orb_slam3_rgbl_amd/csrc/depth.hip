@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -161,36 +162,44 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
     constexpr int kMain = (kTh + 3) / 4;                       // rows per work-item in the 64 main columns
     constexpr int kSideElems = 2 * kRadius * kTh;              // the columns 64 .. kTw - 1
     constexpr int kSide = (kSideElems + 255) / 256, kIter = kMain + kSide;
-    // tiles that lie inside the image with their halo (three quarters of a KITTI frame's) skip the per-element bounds tests
-    const bool interior = x0 >= kRadius && y0 >= kRadius && x0 + 64 + kRadius <= w && y0 + kTileH + kRadius <= h;
     const int r0 = tid >> 6, c0 = tid & 63;
-    bool inside[kIter];
-    int at[kIter], lds[kIter];
-    float raw_v[kIter];
-    uint32_t id[kIter];
-#pragma unroll
-    for (int j = 0; j < kIter; ++j) {
-      const int si = tid + 256 * (j - kMain), sr = si / (2 * kRadius);   // element si of the side columns (rows of 2 r)
-      const int r = j < kMain ? r0 + 4 * j : sr, c = j < kMain ? c0 : 64 + (si - sr * (2 * kRadius));
-      const bool live = j < kMain ? (4 * j + 3 < kTh || r < kTh) : si < kSideElems;
-      const int yy = y0 + r - kRadius, xx = x0 + c - kRadius;
-      inside[j] = live && (interior || (yy >= 0 && yy < h && xx >= 0 && xx < w));
-      at[j] = inside[j] ? yy * w + xx : 0;
-      lds[j] = live ? r * 72 + c : -1;
-      if (kIndexed) id[j] = inside[j] ? I[at[j]] : 0u;
-      else raw_v[j] = inside[j] ? R[at[j]] : 0.f;
-    }
-    if (kIndexed) {
+    // Two instantiations of the staging: tiles that lie inside the image with their halo (three quarters of a KITTI frame's)
+    // know every element to be inside - no bounds tests, one base index plus scalar row offsets.
+    auto stage = [&](auto interior_c) {
+      constexpr bool kInterior = decltype(interior_c)::value;
+      bool inside[kIter];
+      int at[kIter], lds[kIter];
+      float raw_v[kIter];
+      uint32_t id[kIter];
+      const int at0 = (int)__umul24((uint32_t)(kInterior ? y0 - kRadius + r0 : 0), (uint32_t)w) + x0 - kRadius + c0;
 #pragma unroll
       for (int j = 0; j < kIter; ++j) {
-        const uint32_t pt = id[j] & kIdxMask;
-        const bool hit = (id[j] ^ tag) == pt && pt;  // tag | index: entries of earlier generations (another tag) are empty pixels
-        raw_v[j] = hit ? D[pt - 1] : 0.f;
+        constexpr int kSideW = kRadius > 0 ? 2 * kRadius : 1;  // (this block is not reached with kRadius == 0)
+        const int si = tid + 256 * (j - kMain), sr = si / kSideW;   // element si of the side columns (rows of 2 r)
+        const int r = j < kMain ? r0 + 4 * j : sr, c = j < kMain ? c0 : 64 + (si - sr * kSideW);
+        const bool live = j < kMain ? (4 * j + 3 < kTh || r < kTh) : si < kSideElems;
+        const int yy = y0 + r - kRadius, xx = x0 + c - kRadius;
+        inside[j] = live && (kInterior || (yy >= 0 && yy < h && xx >= 0 && xx < w));
+        // rows and widths far below 2^24: full-rate multiplies; interior main columns: base + (scalar) 4 j w
+        at[j] = !inside[j] ? 0 : (kInterior && j < kMain) ? at0 + 4 * j * w : (int)__umul24((uint32_t)yy, (uint32_t)w) + xx;
+        lds[j] = live ? r * 72 + c : -1;
+        if (kIndexed) id[j] = inside[j] ? I[at[j]] : 0u;
+        else raw_v[j] = inside[j] ? R[at[j]] : 0.f;
       }
-    }
+      if (kIndexed) {
 #pragma unroll
-    for (int j = 0; j < kIter; ++j)
-      if (lds[j] >= 0) s_inv[lds[j]] = inverted(inside[j], raw_v[j]);
+        for (int j = 0; j < kIter; ++j) {
+          const uint32_t pt = id[j] & kIdxMask;
+          const bool hit = (id[j] ^ tag) == pt && pt;  // tag | index: entries of earlier generations (another tag) are empty pixels
+          raw_v[j] = hit ? D[pt - 1] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kIter; ++j)
+        if (lds[j] >= 0) s_inv[lds[j]] = inverted(inside[j], raw_v[j]);
+    };
+    if (x0 >= kRadius && y0 >= kRadius && x0 + 64 + kRadius <= w && y0 + kTileH + kRadius <= h) stage(std::true_type{});
+    else stage(std::false_type{});
   } else {
     for (int i = tid; i < tw * th; i += 256) {
       const int r = i / tw, c = i - r * tw;
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
       for (int k = 1; k <= R; ++k) H[r][k] = fmaxf(fmaxf(H[r][k - 1], v[R - k]), v[R + k]);
     }
     if (x0 + x < w) {
+      float* O = out + (size_t)f * map_stride + (__umul24((uint32_t)(y0 + yb), (uint32_t)w) + (uint32_t)(x0 + x));
 #pragma unroll
       for (int j = 0; j < kRows; ++j) {
         const int y = yb + j;
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256) void k_inverse_dilate(DilateMask K, float S, c
 #pragma unroll
         for (int d = 1; d <= R; ++d) m = fmaxf(fmaxf(m, H[j + R - d][R - d]), H[j + R + d][R - d]);
         const float t = S - m;
-        out[(size_t)f * map_stride + (size_t)(y0 + y) * w + x0 + x] = t > thr ? 0.f : t;
+        O[(uint32_t)(j * w)] = t > thr ? 0.f : t;   // j * w: scalar
       }
     }
   } else {
