@@ -660,12 +660,16 @@ __global__ __launch_bounds__(BS) void k_gauss7(const GaussTile* __restrict__ til
   // interior column groups: all six words requested before the first use.  The groups that touch the left or right border
   // of the level are left to a second, compacted pass - inside this loop two lanes per wave would drag the other 62 through
   // the byte-wise path in every iteration of every tile in the first and last tile column.
+  const bool rows_inside = y0 >= 3 && y0 + kBlurTH + 3 <= H;
   for (int task = tid; task < kPairs * 32; task += BS) {
     const int j = task >> 5, cg = task & 31;
     const int x = x0 + 4 * cg;
     if (x < 4 || x + 8 > W) continue;
-    const uint8_t* row0 = img + __umul24((uint32_t)reflect101(y0 + 2 * j - 3, H), (uint32_t)pitch) + x;
-    const uint8_t* row1 = img + __umul24((uint32_t)reflect101(y0 + 2 * j - 2, H), (uint32_t)pitch) + x;
+    // tiles whose rows y0 - 3 .. y0 + 34 all exist (every tile but the first and last tile row of a level) skip the reflection
+    int ya = y0 + 2 * j - 3, yb = ya + 1;
+    if (!rows_inside) { ya = reflect101(ya, H); yb = reflect101(yb, H); }   // uniform
+    const uint8_t* row0 = img + __umul24((uint32_t)ya, (uint32_t)pitch) + x;
+    const uint8_t* row1 = img + __umul24((uint32_t)yb, (uint32_t)pitch) + x;
     uint32_t w[2][3];
     w[0][0] = load_u32_unaligned(row0 - 4); w[0][1] = load_u32_unaligned(row0); w[0][2] = load_u32_unaligned(row0 + 4);
     w[1][0] = load_u32_unaligned(row1 - 4); w[1][1] = load_u32_unaligned(row1); w[1][2] = load_u32_unaligned(row1 + 4);
