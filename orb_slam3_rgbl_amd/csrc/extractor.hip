@@ -629,24 +629,7 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
   // dense candidate lists need the label-based quad-tree kernel (order-free) and the per-cell FAST kernel (RGBL_DENSE=0: cell slots)
   if (rc == RGBL_OK) e->dense = e->octree_ncap != 0 && !(getenv("RGBL_DENSE") && getenv("RGBL_DENSE")[0] == '0');
   if (rc == RGBL_OK) rc = alloc_scratch(e);
-  // The auxiliary stream carries level 0's FAST cells and quad-tree problems - the longest dependent chain of an extraction -
-  // and gets the higher priority, the main stream stays at the default one.  (A main stream at the LOWEST priority gave the
-  // batched step the same gain but made single launches slow - the resize chain of a one-frame extraction 4 -> 21 us per
-  // launch.)  RGBL_PRIO=0: both streams at the default priority, RGBL_PRIO=m: the main stream above the auxiliary one.
-  auto make_stream = [](hipStream_t* s, int prio_rel) {
-#ifdef RGBL_EMU
-    (void)prio_rel;
-    return hipStreamCreate(s);
-#else
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least priority (largest number)
-    return prio_rel == 0 ? hipStreamCreate(s) : hipStreamCreateWithPriority(s, hipStreamDefault, prio_rel > 0 ? hi : lo);
-#endif
-  };
-  const char* pr = getenv("RGBL_PRIO");
-  const int p_main = pr && pr[0] == 'm' ? 1 : (pr && pr[0] == 'L' ? -1 : 0);
-  const int p_aux = pr && (pr[0] == 'm' || pr[0] == '0') ? 0 : 1;
-  if (rc == RGBL_OK && (make_stream(&e->own_stream, p_main) != hipSuccess || make_stream(&e->aux_stream, p_aux) != hipSuccess ||
+  if (rc == RGBL_OK && (hipStreamCreate(&e->own_stream) != hipSuccess || hipStreamCreate(&e->aux_stream) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming) != hipSuccess ||
