@@ -83,6 +83,12 @@ int rgbl_extractor_max_keypoints(const rgbl_extractor* h);
  * *out_mono = the reference's return value (monoIndex).  Empty image -> RGBL_ERR_EMPTY, *out_mono=-1. */
 int rgbl_extract(rgbl_extractor* h, const uint8_t* img, int w, int h_, int stride, int lap0, int lap1,
                  rgbl_keypoint* out_kp, uint8_t* out_desc, int cap, int* out_n, int* out_mono);
+/* Latency of one frame (optional): the upload of the image, the whole extraction and the copies of its results into the
+ * handle's page-locked block are queued and NOT waited for.  The rgbl_extract call that follows with the same image pointer,
+ * size, stride and lapping area collects the results (any other extraction call waits for the begun one and drops it).  Work
+ * queued on other handles in between - rgbl_depth_prefetch above all - runs next to the extraction, and so does the host.
+ * The image must stay unchanged until it is collected. */
+int rgbl_extract_begin(rgbl_extractor* h, const uint8_t* img, int w, int h_, int stride, int lap0, int lap1);
 
 /* Batched host variant: `batch` images of identical size, image b at imgs + b*frame_stride bytes.
  * Outputs for frame b start at out_kp + b*cap and out_desc + b*cap*32; out_n/out_mono hold batch ints. */
@@ -238,6 +244,14 @@ int rgbl_structuring_element(int shape, int kw, int kh, uint8_t* out);
 int rgbl_depth_compute(rgbl_depth* h, const float* cloud, int n, int ld, int w, int h_,
                        const float* kp_xy, const float* kpun_x, int k, float* out_depth,
                        float* out_uright, float* out_raw, float* out_processed);
+
+/* Latency of one frame (optional): the part of CalculateDepthFromPcd that does not depend on the keypoints - upload of the scan,
+ * ProjectPointcloudToImage, the up-sampling (DepthModule.cc:57-76 without GetFeatureDepthFromDepthMap) - queued on the handle's
+ * stream, not waited for.  Called between rgbl_extract_begin and rgbl_extract it runs next to the extraction; the
+ * rgbl_depth_compute / _xyzi call that follows with the same cloud pointer, n and ld then only gathers the keypoints' depths
+ * (with out_raw != NULL, or another cloud, it computes everything as usual).  The scan must stay unchanged in between. */
+int rgbl_depth_prefetch(rgbl_depth* h, const float* cloud, int n, int ld, int w, int h_);
+int rgbl_depth_prefetch_xyzi(rgbl_depth* h, const float* xyzi, int n, int w, int h_);
 
 /* The same on a scan as it lies in a KITTI velodyne .bin file: n records (x, y, z, reflectance).  Replaces
  * LoadPointcloudBinaryMat's repack to 4 x n (Examples/RGB-L/rgbl_kitti.cc:151-185: reflectance dropped, homogeneous

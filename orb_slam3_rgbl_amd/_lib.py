@@ -118,6 +118,7 @@ SYMBOLS = {
     "rgbl_extractor_tables": (_I, [_V, _V, _V, _V, _V, _V, _V]),
     "rgbl_extractor_max_keypoints": (_I, [_V]),
     "rgbl_extract": (_I, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "rgbl_extract_begin": (_I, [_V, _V, _I, _I, _I, _I, _I]),
     "rgbl_extract_batch": (_I, [_V, _V, _I, _I, _I, _I, _Z, _I, _I, _V, _V, _I, _V, _V]),
     "rgbl_extract_batch_device": (_I, [_V, _V, _I, _I, _I, _I, _Z, _I, _I, _V, _V, _I, _V, _V]),
     "rgbl_extractor_sync": (_I, [_V]),
@@ -139,6 +140,8 @@ SYMBOLS = {
     "rgbl_depth_compute_xyzi": (_I, [_V, _V, _I, _I, _I, _V, _V, _I, _V, _V, _V, _V]),
     "rgbl_depth_project_xyzi_batch_device": (_I, [_V, _V, _I, _I, _Z, _I, _I, _V]),
     "rgbl_depth_compute": (_I, [_V, _V, _I, _I, _I, _I, _V, _V, _I, _V, _V, _V, _V]),
+    "rgbl_depth_prefetch": (_I, [_V, _V, _I, _I, _I, _I]),
+    "rgbl_depth_prefetch_xyzi": (_I, [_V, _V, _I, _I, _I]),
     "rgbl_depth_batch_device": (_I, [_V, _V, _I, _I, _I, _Z, _I, _I, _V, _V, _I, _V, _V, _V, _V]),
     "rgbl_depth_project_batch_device": (_I, [_V, _V, _I, _I, _I, _Z, _I, _I, _V]),
     "rgbl_depth_gather_batch_device": (_I, [_V, _I, _I, _I, _V, _V, _I, _V, _V, _V]),

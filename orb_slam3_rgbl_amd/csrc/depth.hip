@@ -393,6 +393,8 @@ struct rgbl_depth {
   float *d_kp = nullptr, *d_kpun = nullptr, *d_depth = nullptr, *d_uright = nullptr;  // one block: kp (2 K) | kpun (K) | depth (K) | uright (K)
   float* h_kio = nullptr;      // page-locked mirror of that block: the keypoint arrays of the host entry points travel in one request each way
   std::vector<void*> allocs;
+  // rgbl_depth_prefetch: the maps of this cloud are queued (or done) on the handle's stream
+  struct { bool active = false; const float* cloud = nullptr; int n = 0, ld = 0; bool xyzi = false; } prefetched;
 };
 
 namespace {
@@ -633,6 +635,31 @@ void rgbl_depth_destroy(rgbl_depth* e) {
   delete e;
 }
 
+static int upload_cloud(rgbl_depth* e, const float* cloud, int n, int ld, bool xyzi) {
+  hipStream_t s = e->stream;
+  if (xyzi) RGBL_HIP(hipMemcpyAsync(e->d_cloud, cloud, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, s));
+  else RGBL_HIP(hipMemcpy2DAsync(e->d_cloud, sizeof(float) * n, cloud, sizeof(float) * ld, sizeof(float) * n, 4, hipMemcpyHostToDevice, s));
+  return RGBL_OK;
+}
+
+// The part of CalculateDepthFromPcd that does not need the keypoints - upload of the scan, projection, up-sampling - queued
+// on the handle's stream and NOT waited for: issued between rgbl_extract_begin and rgbl_extract it runs next to the extraction
+// (the host stages the 1.9 MB of a KITTI scan while the GPU extracts).  The rgbl_depth_compute* call that follows with the same
+// cloud pointer, point count and layout only gathers the keypoints' depths.  The caller must not change the scan in between.
+static int depth_prefetch_host(rgbl_depth* e, const float* cloud, int n, int ld, bool xyzi, int w, int h) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  if (w != e->cfg.width || h != e->cfg.height || n < 0 || n > e->cfg.max_points || (n > 0 && (!cloud || (!xyzi && ld < n)))) {
+    set_error("depth arguments do not match the handle (%dx%d, %d points)", e->cfg.width, e->cfg.height, e->cfg.max_points);
+    return RGBL_ERR_INVALID;
+  }
+  RGBL_HIP(hipSetDevice(e->device));
+  e->prefetched.active = false;
+  if (n > 0) RGBL_TRY(upload_cloud(e, cloud, n, ld, xyzi));
+  RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi, false));
+  e->prefetched.active = true; e->prefetched.cloud = cloud; e->prefetched.n = n; e->prefetched.ld = ld; e->prefetched.xyzi = xyzi;
+  return RGBL_OK;
+}
+
 static int depth_compute_host(rgbl_depth* e, const float* cloud, int n, int ld, bool xyzi, int w, int h, const float* kp_xy,
                               const float* kpun_x, int k, float* out_depth, float* out_uright, float* out_raw,
                               float* out_processed) {
@@ -646,10 +673,11 @@ static int depth_compute_host(rgbl_depth* e, const float* cloud, int n, int ld, 
   RGBL_HIP(hipSetDevice(e->device));
   hipStream_t s = e->stream;
   StreamDrain drain(s);  // error returns included: the uploads below read the caller's buffers
-  if (n > 0) {
-    if (xyzi) RGBL_HIP(hipMemcpyAsync(e->d_cloud, cloud, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, s));
-    else RGBL_HIP(hipMemcpy2DAsync(e->d_cloud, sizeof(float) * n, cloud, sizeof(float) * ld, sizeof(float) * n, 4, hipMemcpyHostToDevice, s));
-  }
+  // rgbl_depth_prefetch was given this very cloud: its upload, projection and up-sampling are queued (or done)
+  const bool have_maps = e->prefetched.active && e->prefetched.cloud == cloud && e->prefetched.n == n && e->prefetched.ld == ld &&
+                         e->prefetched.xyzi == xyzi && !out_raw;
+  e->prefetched.active = false;
+  if (n > 0 && !have_maps) RGBL_TRY(upload_cloud(e, cloud, n, ld, xyzi));
   const size_t K = (size_t)e->cfg.max_keypoints;
   if (k > 0 && e->h_kio) {
     memcpy(e->h_kio, kp_xy, sizeof(float) * 2 * k);
@@ -659,7 +687,7 @@ static int depth_compute_host(rgbl_depth* e, const float* cloud, int n, int ld, 
     RGBL_HIP(hipMemcpyAsync(e->d_kp, kp_xy, sizeof(float) * 2 * k, hipMemcpyHostToDevice, s));
     RGBL_HIP(hipMemcpyAsync(e->d_kpun, kpun_x, sizeof(float) * k, hipMemcpyHostToDevice, s));
   }
-  RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi, out_raw != nullptr));
+  if (!have_maps) RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi, out_raw != nullptr));
   RGBL_TRY(enqueue_keypoints(e, 1, w, h, e->d_kp, 2, 0, e->d_kpun, 1, 0, nullptr, k, k, e->d_depth, e->d_uright, 0));
   if (k > 0 && e->h_kio) {
     RGBL_HIP(hipMemcpyAsync(e->h_kio + 3 * K, e->d_depth, sizeof(float) * (K + k), hipMemcpyDeviceToHost, s));
@@ -684,6 +712,9 @@ int rgbl_depth_compute(rgbl_depth* e, const float* cloud, int n, int ld, int w, 
                        float* out_processed) {
   return depth_compute_host(e, cloud, n, ld, false, w, h, kp_xy, kpun_x, k, out_depth, out_uright, out_raw, out_processed);
 }
+
+int rgbl_depth_prefetch(rgbl_depth* e, const float* cloud, int n, int ld, int w, int h) { return depth_prefetch_host(e, cloud, n, ld, false, w, h); }
+int rgbl_depth_prefetch_xyzi(rgbl_depth* e, const float* xyzi, int n, int w, int h) { return depth_prefetch_host(e, xyzi, n, n, true, w, h); }
 
 // the scan as it lies in a KITTI velodyne .bin file (LoadPointcloudBinaryMat, rgbl_kitti.cc:151-185)
 int rgbl_depth_compute_xyzi(rgbl_depth* e, const float* xyzi, int n, int w, int h, const float* kp_xy, const float* kpun_x,

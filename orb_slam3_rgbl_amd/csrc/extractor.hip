@@ -109,6 +109,8 @@ struct rgbl_extractor {
   uint8_t *d_out_desc = nullptr, *d_tmp_desc = nullptr;
   int32_t *d_out_n = nullptr, *d_out_mono = nullptr;
   int out_cap = 0;
+  // rgbl_extract_begin: an extraction of one frame whose results are on their way into the page-locked block
+  struct { bool active = false; const uint8_t* img = nullptr; int w = 0, h = 0, stride = 0, lap0 = 0, lap1 = 0; } pending;
   // last call (for get_level / get_candidates)
   const uint8_t* last_img0 = nullptr;
   int last_pitch0 = 0;
@@ -692,6 +694,7 @@ int rgbl_extract_batch_device(rgbl_extractor* e, const uint8_t* d_imgs, int batc
     return RGBL_ERR_INVALID;
   }
   RGBL_HIP(hipSetDevice(e->device));
+  if (e->pending.active) { e->pending.active = false; RGBL_HIP(hipStreamSynchronize(e->stream)); }  // a begun extraction is overtaken
   return enqueue_extract(e, d_imgs, batch, stride, frame_stride, lap0, lap1, d_kp, d_desc, cap, d_n, d_mono);
 }
 
@@ -747,24 +750,54 @@ static int enqueue_extract_staged(rgbl_extractor* e, int batch, int dev_stride, 
 // Small batches (one frame per call above all): counts, error flags, keypoints and descriptors travel into ONE page-locked
 // block behind the kernels and the call synchronises ONCE - three blocking round trips (counts, the error flag, the
 // arrays) and copies into pageable memory were a third of a single frame's extraction latency.
-static int run_staged(rgbl_extractor* e, int batch, int dev_stride, int lap0, int lap1, rgbl_keypoint* out_kp,
-                      uint8_t* out_desc, int cap, int* out_n, int* out_mono) {
-  hipStream_t s = e->stream;
-  RGBL_TRY(enqueue_extract_staged(e, batch, dev_stride, lap0, lap1));
+// an extraction begun with rgbl_extract_begin that another entry point now overtakes: wait for it, forget it
+static int drop_pending(rgbl_extractor* e) {
+  if (e->pending.active) { e->pending.active = false; RGBL_HIP(hipStreamSynchronize(e->stream)); }
+  return RGBL_OK;
+}
+
+static bool staged_one_trip(const rgbl_extractor* e, int batch) {
   const size_t kp_bytes = (size_t)batch * e->out_cap * sizeof(rgbl_keypoint), desc_bytes = (size_t)batch * e->out_cap * 32;
   const size_t head = 256 + 2 * sizeof(int32_t) * (size_t)e->cfg.max_batch;
-  const bool one_trip = e->h_pinned && head + kp_bytes + desc_bytes <= e->h_pinned_bytes;
-  if (one_trip) {
+  return e->h_pinned && head + kp_bytes + desc_bytes <= e->h_pinned_bytes;
+}
+
+// first half: the kernels and - for small batches - the copies of counts, error flag, keypoints and descriptors into the
+// page-locked block, all queued, nothing waited for
+static int staged_enqueue(rgbl_extractor* e, int batch, int dev_stride, int lap0, int lap1) {
+  hipStream_t s = e->stream;
+  RGBL_TRY(enqueue_extract_staged(e, batch, dev_stride, lap0, lap1));
+  if (!staged_one_trip(e, batch)) return RGBL_OK;
+  const size_t kp_bytes = (size_t)batch * e->out_cap * sizeof(rgbl_keypoint), desc_bytes = (size_t)batch * e->out_cap * 32;
+  const size_t head = 256 + 2 * sizeof(int32_t) * (size_t)e->cfg.max_batch;
+  int32_t* p_err = reinterpret_cast<int32_t*>(e->h_pinned);
+  int32_t* p_n = reinterpret_cast<int32_t*>(e->h_pinned + 256);
+  int32_t* p_mono = p_n + e->cfg.max_batch;
+  uint8_t* p_kp = e->h_pinned + head;
+  uint8_t* p_desc = p_kp + kp_bytes;
+  RGBL_HIP(hipMemcpyAsync(p_err, e->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipMemcpyAsync(p_n, e->d_out_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipMemcpyAsync(p_mono, e->d_out_mono, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipMemcpyAsync(p_kp, e->d_out_kp, kp_bytes, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipMemcpyAsync(p_desc, e->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, s));
+  return RGBL_OK;
+}
+
+// second half: wait, then the results from the page-locked block (or, for big batches, straight from the device) to the caller.
+// Small batches (one frame per call above all): counts, error flags, keypoints and descriptors travel into ONE page-locked
+// block behind the kernels and the call synchronises ONCE - three blocking round trips (counts, the error flag, the
+// arrays) and copies into pageable memory were a third of a single frame's extraction latency.
+static int staged_finish(rgbl_extractor* e, int batch, int lap1, rgbl_keypoint* out_kp, uint8_t* out_desc, int cap, int* out_n,
+                         int* out_mono) {
+  hipStream_t s = e->stream;
+  if (staged_one_trip(e, batch)) {
+    const size_t kp_bytes = (size_t)batch * e->out_cap * sizeof(rgbl_keypoint);
+    const size_t head = 256 + 2 * sizeof(int32_t) * (size_t)e->cfg.max_batch;
     int32_t* p_err = reinterpret_cast<int32_t*>(e->h_pinned);
     int32_t* p_n = reinterpret_cast<int32_t*>(e->h_pinned + 256);
     int32_t* p_mono = p_n + e->cfg.max_batch;
     uint8_t* p_kp = e->h_pinned + head;
     uint8_t* p_desc = p_kp + kp_bytes;
-    RGBL_HIP(hipMemcpyAsync(p_err, e->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
-    RGBL_HIP(hipMemcpyAsync(p_n, e->d_out_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-    RGBL_HIP(hipMemcpyAsync(p_mono, e->d_out_mono, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-    RGBL_HIP(hipMemcpyAsync(p_kp, e->d_out_kp, kp_bytes, hipMemcpyDeviceToHost, s));
-    RGBL_HIP(hipMemcpyAsync(p_desc, e->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, s));
     RGBL_HIP(hipStreamSynchronize(s));
     e->timer.collect();
     if (*p_err) RGBL_TRY(check_device_flags(e));  // resets the flag and names the error
@@ -800,6 +833,50 @@ static int run_staged(rgbl_extractor* e, int batch, int dev_stride, int lap0, in
   return rc;
 }
 
+// the frames already sit in e->d_img (row stride dev_stride): extraction, then the results back to the host
+static int run_staged(rgbl_extractor* e, int batch, int dev_stride, int lap0, int lap1, rgbl_keypoint* out_kp,
+                      uint8_t* out_desc, int cap, int* out_n, int* out_mono) {
+  RGBL_TRY(staged_enqueue(e, batch, dev_stride, lap0, lap1));
+  return staged_finish(e, batch, lap1, out_kp, out_desc, cap, out_n, out_mono);
+}
+
+// host -> device staging of `batch` frames; returns the row stride the kernels read them with
+static int upload_frames(rgbl_extractor* e, const uint8_t* imgs, int batch, int w, int h, int stride, size_t frame_stride, int* dev_stride) {
+  hipStream_t s = e->stream;
+  // The kernels accept any row stride, so a frame whose rows are at most img_pitch apart is moved with ONE linear copy and
+  // read with the caller's stride (a 2-D copy from pageable memory degenerates into one transfer per row: 376 transfers
+  // per KITTI frame).
+  *dev_stride = e->img_pitch;
+  if (stride <= e->img_pitch) {
+    *dev_stride = stride;
+    const size_t bytes = (size_t)(h - 1) * stride + w;  // never read past the caller's last row
+    for (int b = 0; b < batch; ++b)
+      RGBL_HIP(hipMemcpyAsync(e->d_img + (size_t)b * e->img_frame, imgs + (size_t)b * frame_stride, bytes, hipMemcpyHostToDevice, s));
+  } else {
+    for (int b = 0; b < batch; ++b)
+      RGBL_HIP(hipMemcpy2DAsync(e->d_img + (size_t)b * e->img_frame, e->img_pitch, imgs + (size_t)b * frame_stride, stride,
+                                w, h, hipMemcpyHostToDevice, s));
+  }
+  return RGBL_OK;
+}
+
+int rgbl_extract_begin(rgbl_extractor* e, const uint8_t* img, int w, int h, int stride, int lap0, int lap1) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  if (!img || w <= 0 || h <= 0) { set_error("empty image"); return RGBL_ERR_EMPTY; }
+  if (w != e->cfg.width || h != e->cfg.height || stride < w || !staged_one_trip(e, 1)) {
+    set_error("image %dx%d does not match the handle (%dx%d)", w, h, e->cfg.width, e->cfg.height);
+    return RGBL_ERR_INVALID;
+  }
+  RGBL_HIP(hipSetDevice(e->device));
+  if (e->pending.active) { RGBL_HIP(hipStreamSynchronize(e->stream)); e->pending.active = false; }  // an extraction nobody collected
+  int dev_stride = 0;
+  RGBL_TRY(upload_frames(e, img, 1, w, h, stride, 0, &dev_stride));
+  RGBL_TRY(staged_enqueue(e, 1, dev_stride, lap0, lap1));
+  e->pending.active = true; e->pending.img = img; e->pending.w = w; e->pending.h = h; e->pending.stride = stride;
+  e->pending.lap0 = lap0; e->pending.lap1 = lap1;
+  return RGBL_OK;
+}
+
 int rgbl_extract_batch(rgbl_extractor* e, const uint8_t* imgs, int batch, int w, int h, int stride, size_t frame_stride,
                        int lap0, int lap1, rgbl_keypoint* out_kp, uint8_t* out_desc, int cap, int* out_n,
                        int* out_mono) {
@@ -814,21 +891,16 @@ int rgbl_extract_batch(rgbl_extractor* e, const uint8_t* imgs, int batch, int w,
     return RGBL_ERR_INVALID;
   }
   RGBL_HIP(hipSetDevice(e->device));
-  hipStream_t s = e->stream;
-  // Host -> device staging.  The kernels accept any row stride, so a frame whose rows are at most img_pitch apart
-  // is moved with ONE linear copy and read with the caller's stride (a 2-D copy from pageable memory degenerates
-  // into one transfer per row: 376 transfers per KITTI frame).
-  int dev_stride = e->img_pitch;
-  if (stride <= e->img_pitch) {
-    dev_stride = stride;
-    const size_t bytes = (size_t)(h - 1) * stride + w;  // never read past the caller's last row
-    for (int b = 0; b < batch; ++b)
-      RGBL_HIP(hipMemcpyAsync(e->d_img + (size_t)b * e->img_frame, imgs + (size_t)b * frame_stride, bytes, hipMemcpyHostToDevice, s));
-  } else {
-    for (int b = 0; b < batch; ++b)
-      RGBL_HIP(hipMemcpy2DAsync(e->d_img + (size_t)b * e->img_frame, e->img_pitch, imgs + (size_t)b * frame_stride, stride,
-                                w, h, hipMemcpyHostToDevice, s));
+  if (e->pending.active) {
+    // rgbl_extract_begin was given this very frame: its kernels and result copies are queued (or done) - collect them
+    const bool same = batch == 1 && e->pending.img == imgs && e->pending.w == w && e->pending.h == h && e->pending.stride == stride &&
+                      e->pending.lap0 == lap0 && e->pending.lap1 == lap1;
+    e->pending.active = false;
+    if (same) return staged_finish(e, 1, lap1, out_kp, out_desc, cap, out_n, out_mono);
+    RGBL_HIP(hipStreamSynchronize(e->stream));  // another frame: the begun extraction is dropped
   }
+  int dev_stride = 0;
+  RGBL_TRY(upload_frames(e, imgs, batch, w, h, stride, frame_stride, &dev_stride));
   return run_staged(e, batch, dev_stride, lap0, lap1, out_kp, out_desc, cap, out_n, out_mono);
 }
 
@@ -926,6 +998,7 @@ int rgbl_extract_color(rgbl_extractor* e, const uint8_t* img, int channels, int 
     return RGBL_ERR_INVALID;
   }
   RGBL_HIP(hipSetDevice(e->device));
+  RGBL_TRY(drop_pending(e));
   hipStream_t s = e->stream;
   const size_t need = (size_t)stride * h + 16;
   if (need > e->color_bytes) {  // first colour frame (or a wider stride): grown once, kept

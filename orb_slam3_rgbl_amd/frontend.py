@@ -90,6 +90,15 @@ class ORBextractor:
                                                 C.byref(mono)))
         return kps[:n.value].copy(), desc[:n.value].copy(), mono.value
 
+    def Begin(self, image, vLappingArea=(0, 0)):
+        """Optional latency hook (rgbl_extract_begin): upload + extraction of `image` are queued and not waited for; the next
+        operator() call on the SAME array collects the results.  Work issued in between (DepthModule.PrefetchPointcloud) runs
+        next to the extraction.  The array must be contiguous in x and unchanged until then."""
+        if image.dtype != np.uint8 or image.ndim != 2 or image.strides[1] != 1:
+            raise TypeError("image must be CV_8UC1 with contiguous rows")
+        h, w = image.shape
+        L.check(self.lib, self.lib.rgbl_extract_begin(self.h, L.ptr(image), w, h, image.strides[0], int(vLappingArea[0]), int(vLappingArea[1])))
+
     def extract_color(self, image, mbRGB, vLappingArea=(0, 0)):
         """Tracking::GrabImageRGBL's cvtColor (Tracking.cc:1567-1580) + operator() on an H x W x {3,4} 8-bit image.
         mbRGB (settings `Camera.RGB`) selects COLOR_RGB(A)2GRAY, otherwise COLOR_BGR(A)2GRAY.
@@ -228,6 +237,14 @@ class DepthModule:
             self.close()
         except Exception:
             pass
+
+    def PrefetchPointcloud(self, PointCloud, imwidth, imheight):
+        """Optional latency hook (rgbl_depth_prefetch): upload, projection and up-sampling of the scan are queued and not
+        waited for; CalculateDepthFromPcd(..., want_maps=False) on the SAME array then only gathers the keypoints' depths."""
+        cloud = PointCloud
+        if cloud.dtype != np.float32 or cloud.ndim != 2 or cloud.shape[0] != 4 or cloud.strides[1] != 4:
+            raise TypeError("PointCloud must be a 4 x N float32 array with contiguous rows")
+        L.check(self.lib, self.lib.rgbl_depth_prefetch(self.h, L.ptr(cloud), cloud.shape[1], cloud.strides[0] // 4, imwidth, imheight))
 
     def CalculateDepthFromPcd(self, mvKeys, mvKeysUn, PointCloud, imwidth, imheight, want_maps=True):
         """mvKeys / mvKeysUn: KP_DTYPE arrays (or [k,2] float arrays); PointCloud: 4 x N float32."""

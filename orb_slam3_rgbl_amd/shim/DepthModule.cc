@@ -241,6 +241,13 @@ void DepthModule::CalculateDepthFromPcd(std::vector<cv::KeyPoint> mvKeys, std::v
   Compute(mvKeys, mvKeysUn, PointCloud.ptr<float>(), PointCloud.cols, (int)(PointCloud.step / sizeof(float)), false, imwidth, imheight);
 }
 
+void DepthModule::PrefetchPointcloud(const cv::Mat& PointCloud, const int imwidth, const int imheight) {
+  if (!b_parse_LiDARUpsampling || !b_parse_LiDAR || SelectedUpsamlingMethod == None || SelectedUpsamlingMethod == IPBasic) return;
+  EnsureHandle(imwidth, imheight, PointCloud.cols, std::max(mHandleKeys / 2, 4096));
+  if (!mpHandle) return;
+  (void)rgbl_depth_prefetch(mpHandle, PointCloud.ptr<float>(), PointCloud.cols, (int)(PointCloud.step / sizeof(float)), imwidth, imheight);
+}
+
 // The scan exactly as read from a KITTI velodyne .bin file (nPoints records x, y, z, reflectance): what the example's
 // LoadPointcloudBinaryMat (Examples/RGB-L/rgbl_kitti.cc:151-185) repacks into the 4 x N matrix, without the repack.
 void DepthModule::CalculateDepthFromKittiBin(const std::vector<cv::KeyPoint>& mvKeys, const std::vector<cv::KeyPoint>& mvKeysUn,

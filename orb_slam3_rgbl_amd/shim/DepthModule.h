@@ -26,6 +26,11 @@ class DepthModule {
   // Depth value handler, manages the depth calculation for each frame (DepthModule.cc:50-79).
   void CalculateDepthFromPcd(std::vector<cv::KeyPoint> mvKeys, std::vector<cv::KeyPoint> mvKeysUn,
                              const cv::Mat& PointCloud, const int imwidth, const int imheight);
+  // Optional latency hook (rgbl_depth_prefetch): the part of CalculateDepthFromPcd that does not need the keypoints - upload of
+  // the scan, projection, up-sampling - queued on the device and not waited for.  Called right after ORBextractor::Begin it runs
+  // next to the extraction; CalculateDepthFromPcd on the SAME cv::Mat data then only gathers the keypoints' depths (with
+  // downloadDenseMaps set the maps are computed again with the raw map).  The scan must stay unchanged in between.
+  void PrefetchPointcloud(const cv::Mat& PointCloud, const int imwidth, const int imheight);
   // Same, on the raw contents of a KITTI velodyne .bin file (nPoints x {x, y, z, reflectance}): replaces the example's
   // LoadPointcloudBinaryMat repack (Examples/RGB-L/rgbl_kitti.cc:151-185) + CalculateDepthFromPcd.
   void CalculateDepthFromKittiBin(const std::vector<cv::KeyPoint>& mvKeys, const std::vector<cv::KeyPoint>& mvKeysUn,

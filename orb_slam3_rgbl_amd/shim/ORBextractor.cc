@@ -103,6 +103,21 @@ int ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, st
   return mono;
 }
 
+bool ORBextractor::Begin(cv::InputArray _image, std::vector<int>& vLappingArea) {
+#ifdef RGBL_HAVE_OPENCV
+  if (_image.empty()) return false;
+  cv::Mat image = _image.getMat();
+#else
+  if (_image.empty()) return false;
+  const cv::Mat& image = _image;
+#endif
+  if (image.type() != CV_8UC1) return false;
+  EnsureHandle(image.cols, image.rows);
+  if (!mpHandle) return false;
+  const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+  return rgbl_extract_begin(mpHandle, image.data, image.cols, image.rows, (int)image.step, lap0, lap1) == RGBL_OK;
+}
+
 int ORBextractor::ExtractColor(const unsigned char* data, int channels, int step, int width, int height, bool bRGB,
                                cv::Mat& imGray, std::vector<cv::KeyPoint>& _keypoints, cv::Mat& _descriptors,
                                std::vector<int>& vLappingArea) {

@@ -25,6 +25,11 @@ class ORBextractor {
   int operator()(cv::InputArray _image, cv::InputArray _mask, std::vector<cv::KeyPoint>& _keypoints,
                  cv::OutputArray _descriptors, std::vector<int>& vLappingArea);
 
+  // Optional latency hook (rgbl_extract_begin): upload and extraction of `image` are queued and not waited for; the operator()
+  // call that follows on the SAME cv::Mat data collects the results.  What is issued in between - above all
+  // DepthModule::PrefetchPointcloud - runs next to the extraction.  Returns false when nothing was begun.
+  bool Begin(cv::InputArray _image, std::vector<int>& vLappingArea);
+
   // cvtColor + operator() in one device round trip (Tracking::GrabImageRGBL, Tracking.cc:1567-1580): `data` is an
   // 8-bit image with 3 or 4 interleaved channels (1 = already gray), bRGB = Tracking::mbRGB.  imGray receives mImGray.
   int ExtractColor(const unsigned char* data, int channels, int step, int width, int height, bool bRGB, cv::Mat& imGray,

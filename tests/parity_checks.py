@@ -1312,3 +1312,46 @@ def check_pipeline_gather(lib, mode, dev=None, w=640, h=360, nfeatures=800, batc
         od, our, _, _ = O.depth(P, cloud[f], w, h, np.stack([okps["x"], okps["y"]], 1), okps["x"], want_maps=False)
         assert np.array_equal(bits(fr[f]["depth"]), bits(od)) and np.array_equal(bits(fr[f]["uright"]), bits(our))
     pipe.close()
+
+
+def check_overlapped_frame(lib, w=synth.KITTI_W, h=synth.KITTI_H, nfeatures=2000, frames=3):
+    """The optional latency hooks: rgbl_extract_begin + rgbl_depth_prefetch, then the ordinary calls on the same buffers, must
+    give what the ordinary calls alone give (= the oracle's results), whatever is interleaved."""
+    ex = F.ORBextractor(nfeatures, 1.2, 8, 12, 7, w, h, lib=lib)
+    orc = O.Extractor(nfeatures, 1.2, 8, 12, 7)
+    K = synth.KITTI_K.copy()
+    K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    proj = F.projection_matrix(K, synth.KITTI_TR, lib)
+    P = O.make_depth_params(proj)
+    dm = F.DepthModule(proj, w, h, max_keypoints=ex.max_keypoints, lib=lib)
+    sq = synth.Sequence(17, w, h, n_frames=frames)
+    for i in range(frames):
+        img = np.ascontiguousarray(sq.frame(i))
+        cloud = np.ascontiguousarray(synth.lidar_scan(170 + i, n_az=600 if w < 1000 else 1900), np.float32)
+        ex.Begin(img)
+        dm.PrefetchPointcloud(cloud, w, h)
+        kps, desc, mono = ex(img)                                   # collects the begun extraction
+        dm.CalculateDepthFromPcd(kps, kps, cloud, w, h, want_maps=False)   # gathers on the prefetched maps
+        okps, odesc, omono = orc(img)
+        assert_keypoints_equal(kps, okps, "overlapped frame %d" % i)
+        assert np.array_equal(desc, odesc) and mono == omono
+        od, our, _, oproc = O.depth(P, cloud, w, h, np.stack([okps["x"], okps["y"]], 1), okps["x"])
+        assert np.array_equal(bits(dm.mvDepth), bits(od)) and np.array_equal(bits(dm.mvuRight), bits(our))
+        assert (od > 0).sum() > 20
+    # a begun extraction that is overtaken by another image is dropped, a prefetched scan that is not the one computed is ignored
+    img0, img1 = np.ascontiguousarray(sq.frame(0)), np.ascontiguousarray(sq.frame(1))
+    c0 = np.ascontiguousarray(synth.lidar_scan(170, n_az=600 if w < 1000 else 1900), np.float32)
+    c1 = np.ascontiguousarray(synth.lidar_scan(171, n_az=600 if w < 1000 else 1900), np.float32)
+    ex.Begin(img0)
+    dm.PrefetchPointcloud(c0, w, h)
+    kps, desc, mono = ex(img1)
+    okps, odesc, _ = orc(img1)
+    assert_keypoints_equal(kps, okps, "overtaken")
+    assert np.array_equal(desc, odesc)
+    dm.CalculateDepthFromPcd(kps, kps, c1, w, h, want_maps=True)     # maps wanted: everything is computed
+    od, our, oraw, oproc = O.depth(P, c1, w, h, np.stack([okps["x"], okps["y"]], 1), okps["x"])
+    assert np.array_equal(bits(dm.mvDepth), bits(od)) and np.array_equal(bits(dm.ProcessedDepthMap), bits(oproc))
+    dm.PrefetchPointcloud(c0, w, h)
+    dm.CalculateDepthFromPcd(kps, kps, c1, w, h, want_maps=False)    # another scan than the prefetched one
+    assert np.array_equal(bits(dm.mvDepth), bits(od))
+    ex.close(); dm.close()

@@ -201,7 +201,9 @@ def run_and_check(exe, tmp):
     ninit, n1i = take(np.int32, 2)
     init_match = take(np.int32, n1i)
     init_prev = take(np.float32, 2 * n1i).reshape(n1i, 2)
+    hooks_same = take(np.int32, 1)[0]
     assert pos == len(buf)
+    assert hooks_same == 1, "ORBextractor::Begin / DepthModule::PrefetchPointcloud changed the results"
     oim, oiprev, oin = O.search_for_initialization(icase, 100, 0.9, True)
     assert ninit == oin and np.array_equal(init_match, oim) and np.array_equal(pc.bits(init_prev), pc.bits(oiprev)) and ninit > 300
     osm, osn = pc.search_by_sim3(scase, 7.5, O.project_search)

@@ -697,6 +697,27 @@ int main(int argc, char** argv) {
     wr(out, vnMatches12.data(), n1);
     for (int i = 0; i < n1; ++i) { wr(out, &vbPrevMatched[i].x, 1); wr(out, &vbPrevMatched[i].y, 1); }
   }
+  // --- the optional latency hooks: Begin + PrefetchPointcloud right before the ordinary calls of
+  //     Frame's RGB-L constructor must change nothing in what those calls return
+  {
+    ORB_SLAM3::ORBextractor ex2(2000, 1.2f, 8, 12, 7);
+    ORB_SLAM3::DepthModule depth2(argv[1], 6);
+    depth2.downloadDenseMaps = false;
+    std::vector<cv::KeyPoint> keys2;
+    cv::Mat desc2;
+    int same = 1;
+    for (int rep = 0; rep < 2; ++rep) {   // the second time round every handle exists already
+      same &= ex2.Begin(im, vLapping) ? 1 : 0;
+      depth2.PrefetchPointcloud(pcd, w, h);
+      const int mono2 = ex2(im, cv::Mat(), keys2, desc2, vLapping);
+      depth2.CalculateDepthFromPcd(keys2, keys2, pcd, w, h);
+      same &= mono2 == mono && keys2.size() == keys.size() && memcmp(keys2.data(), keys.data(), sizeof(cv::KeyPoint) * keys.size()) == 0;
+      same &= desc2.rows == desc.rows && memcmp(desc2.data, desc.data, (size_t)desc.rows * 32) == 0;
+      same &= depth2.mvDepth.size() == depth.mvDepth.size() && memcmp(depth2.mvDepth.data(), depth.mvDepth.data(), sizeof(float) * depth.mvDepth.size()) == 0;
+      same &= memcmp(depth2.mvuRight.data(), depth.mvuRight.data(), sizeof(float) * depth.mvuRight.size()) == 0;
+    }
+    wr(out, &same, 1);
+  }
   fclose(out);
   printf("shim_test ok: %d keypoints, %d depths, %d triangulation matches\n", nk, nd, nm);
   return 0;

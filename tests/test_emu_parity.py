@@ -289,3 +289,7 @@ def test_extractor_batch_of_eight_takes_the_xcd_aware_mapping(emu_lib):
 def test_gather_choreography_with_one_rank(emu_lib, mode, lanes):
     import torch
     pc.check_pipeline_gather(emu_lib, mode, dev=torch.device("cpu"), w=240, h=160, nfeatures=300, batch=3, steps=3, n_az=240, levels=4, lanes=lanes)
+
+
+def test_overlapped_frame_hooks(emu_lib):
+    pc.check_overlapped_frame(emu_lib, w=400, h=300, nfeatures=500, frames=2)

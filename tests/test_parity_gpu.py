@@ -339,3 +339,8 @@ def test_gather_choreography_with_one_rank(gpu_lib, mode, lanes):
     # execute on the hardware (no peer, so no RCCL transfer); the records must decode to the step's own outputs
     # lanes = 2: two steps in flight on two sets of handles (pipeline.py)
     pc.check_pipeline_gather(gpu_lib, mode, lanes=lanes)
+
+
+def test_overlapped_frame_hooks(gpu_lib):
+    # rgbl_extract_begin + rgbl_depth_prefetch: upload and maps of the scan run next to the extraction of the frame
+    pc.check_overlapped_frame(gpu_lib)

@@ -25,6 +25,17 @@ for it in range(3):
             t[0] += b - a; t[1] += c - b; t[2] += d - c; n += 1
 print("host API, 1 frame per call (H2D + kernels + D2H, synchronous): extract %.3f ms, depth %.3f ms, match %.3f ms -> %.0f frames/s"
       % (t[0] / n * 1e3, t[1] / n * 1e3, t[2] / n * 1e3, n / sum(t)))
+cloud32 = np.ascontiguousarray(cloud, np.float32)
+for it in range(3):
+    a = time.perf_counter(); n = 0
+    for rep in range(5):
+        for img in imgs:
+            ex.Begin(img); dm.PrefetchPointcloud(cloud32, w, h)
+            kps, desc, _ = ex(img)
+            dm.CalculateDepthFromPcd(kps, kps, cloud32, w, h, want_maps=False)
+            mt.BruteForce(prev, desc); prev = desc; n += 1
+    tot = (time.perf_counter() - a) / n * 1e3
+print("host API, 1 frame per call behind rgbl_extract_begin + rgbl_depth_prefetch: %.3f ms per frame -> %.0f frames/s" % (tot, 1e3 / tot))
 res = None
 exb = F.ORBextractor(2000, 1.2, 8, 12, 7, w, h, max_batch=64, lib=lib)
 big = np.stack([imgs[i % 8] for i in range(64)])
