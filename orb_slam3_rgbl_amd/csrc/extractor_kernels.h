@@ -1644,8 +1644,7 @@ __global__ __launch_bounds__(BS) void k_orient_brief(const LevelGeom* __restrict
   if (valid && dense >= cap) valid = false;
   const uint32_t key = valid ? kp_key[(size_t)f * kp_frame + slot] : 0u;
   const int kx = key_x(key) + kMinBorder, ky = key_y(key) + kMinBorder;
-  const unsigned long long vmask = __ballot(valid);
-  if (vmask == 0) return;  // wave-uniform
+  const unsigned long long vmask = __ballot(valid);  // (no early exit of a wave without keypoints: workgroup barriers below)
 
   // the lane's four pattern pairs (x0, y0, x1, y1 as signed bytes), the same for every keypoint
   f32x2 px[4], py[4];  // (x0, x1) and (y0, y1) of the lane's pairs
@@ -1729,11 +1728,22 @@ __global__ __launch_bounds__(BS) void k_orient_brief(const LevelGeom* __restrict
     if (lane == k) { my_m10 = m10; my_m01 = m01; }
   }
 
-  // ---- once per keypoint, lane k for keypoint k: orientation and the steering coefficients
-  const float angle = fast_atan2_deg((float)my_m01, (float)my_m10);
-  const float factor_pi = (float)(3.14159265358979323846 / 180.f);
-  const float ang = angle * factor_pi;
-  const float ca = glibc_cosf(ang), sb = glibc_sinf(ang);
+  // ---- once per keypoint: orientation and the steering coefficients (fastAtan2, glibc's sinf / cosf in double precision:
+  //      ~150 vector instructions that only need one lane per keypoint).  The first wave does it for the keypoints of ALL the
+  //      workgroup's waves (lane j for the workgroup's j-th keypoint) instead of every wave for its own four.
+  __shared__ int s_mom[BS / 64 * kKpPerWave][2];
+  __shared__ float s_angle[BS / 64 * kKpPerWave], s_cos[BS / 64 * kKpPerWave], s_sin[BS / 64 * kKpPerWave];
+  if (lane < kKpPerWave) { s_mom[wave * kKpPerWave + lane][0] = my_m10; s_mom[wave * kKpPerWave + lane][1] = my_m01; }
+  __syncthreads();
+  if (wave == 0 && lane < BS / 64 * kKpPerWave) {
+    const float an = fast_atan2_deg((float)s_mom[lane][1], (float)s_mom[lane][0]);
+    const float factor_pi = (float)(3.14159265358979323846 / 180.f);
+    const float rad = an * factor_pi;
+    s_angle[lane] = an; s_cos[lane] = glibc_cosf(rad); s_sin[lane] = glibc_sinf(rad);
+  }
+  __syncthreads();
+  const int mine = wave * kKpPerWave + (lane < kKpPerWave ? lane : 0);
+  const float angle = s_angle[mine], ca = s_cos[mine], sb = s_sin[mine];
 
   // ---- pass 2, keypoint after keypoint: steered BRIEF-256 on the blurred level through a 37x37 LDS patch
   const uint8_t* patch = reinterpret_cast<const uint8_t*>(s_patch_q[wave]);
