@@ -421,12 +421,16 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
     }
   }
 #ifdef RGBL_FAST_SKIP
-  const int n_passes = 1;  // timing experiments: one pass at min_th whatever it finds
+  const int n_passes = 1;  // timing experiments: one pass (at ini_th) whatever it finds
 #else
   const int n_passes = ini_th > min_th ? 2 : 1;
 #endif
   for (int pass = 0; pass < n_passes; ++pass) {
+#ifdef RGBL_FAST_SKIP
+    const int thr = ini_th;   // timing experiments: the first pass only
+#else
     const int thr = (pass == 0 && n_passes == 2) ? ini_th : min_th;   // this pass = cv::FAST(cell, thr, nonmax suppression)
+#endif
     // ---- clear the score tile (the rows in use), the counters and the bitmap
     {
       uint4* q = reinterpret_cast<uint4*>(s_score_w);
