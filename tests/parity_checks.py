@@ -1355,3 +1355,23 @@ def check_overlapped_frame(lib, w=synth.KITTI_W, h=synth.KITTI_H, nfeatures=2000
     dm.CalculateDepthFromPcd(kps, kps, c1, w, h, want_maps=False)    # another scan than the prefetched one
     assert np.array_equal(bits(dm.mvDepth), bits(od))
     ex.close(); dm.close()
+
+
+def check_extractor_low_contrast(lib, w=614, h=343, ini=20, mn=7, contrast=0.15, seq=77, nfeatures=1500, nlevels=6):
+    """Frames whose contrast is scaled down: most detection cells find nothing at iniThFAST and run cv::FAST a second time at
+    minThFAST (ORBextractor.cc:832-846) - the second pass of k_fast_cells."""
+    img = synth.Sequence(seq, w, h, n_frames=1).frame(0)
+    img = np.clip(img.astype(np.float32) * contrast + 90, 0, 255).astype(np.uint8)
+    ex = F.ORBextractor(nfeatures, 1.2, nlevels, ini, mn, w, h, lib=lib)
+    orc = O.Extractor(nfeatures, 1.2, nlevels, ini, mn)
+    kps, desc, mono = ex(img)
+    okps, odesc, omono = orc(img)
+    assert_keypoints_equal(kps, okps, "low contrast")
+    assert np.array_equal(desc, odesc) and mono == omono
+    for l in range(nlevels):
+        c, oc = ex.level_candidates(l), orc.level_candidates(l)
+        assert len(c) == len(oc), "level %d: %d candidates vs %d" % (l, len(c), len(oc))
+        for f in ("x", "y", "response"):
+            assert np.array_equal(c[f], oc[f]), "level %d candidate %s" % (l, f)
+    ex.close()
+    return len(kps)

@@ -293,3 +293,8 @@ def test_gather_choreography_with_one_rank(emu_lib, mode, lanes):
 
 def test_overlapped_frame_hooks(emu_lib):
     pc.check_overlapped_frame(emu_lib, w=400, h=300, nfeatures=500, frames=2)
+
+
+def test_extractor_second_fast_pass(emu_lib):
+    assert pc.check_extractor_low_contrast(emu_lib, 400, 300, 20, 7, 0.15, nfeatures=600, nlevels=4) > 100
+    pc.check_extractor_low_contrast(emu_lib, 300, 220, 30, 10, 0.08, nfeatures=300, nlevels=3)   # hardly any corner at either threshold

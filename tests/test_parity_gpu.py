@@ -344,3 +344,10 @@ def test_gather_choreography_with_one_rank(gpu_lib, mode, lanes):
 def test_overlapped_frame_hooks(gpu_lib):
     # rgbl_extract_begin + rgbl_depth_prefetch: upload and maps of the scan run next to the extraction of the frame
     pc.check_overlapped_frame(gpu_lib)
+
+
+def test_extractor_second_fast_pass(gpu_lib):
+    # low-contrast frames: the cells that find nothing at iniThFAST run the pre-screen / score / NMS again at minThFAST
+    assert pc.check_extractor_low_contrast(gpu_lib, 1241, 376, 20, 7, 0.15, nfeatures=2000, nlevels=8) > 1000
+    pc.check_extractor_low_contrast(gpu_lib, 793, 286, 30, 10, 0.08)
+    pc.check_extractor_low_contrast(gpu_lib, 1145, 290, 30, 3, 0.15)

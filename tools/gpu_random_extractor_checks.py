@@ -25,3 +25,25 @@ while done < n_cases:
     print("ok %4dx%-4d levels %d nfeatures %5d ini %2d -> %d keypoints" % (w, h, nlevels, nf, ini, total), flush=True)
     done += 1
 print("all", done, "cases bit-exact")
+
+# low-contrast frames: most detection cells find nothing at iniThFAST and take the second cv::FAST pass at minThFAST
+from orb_slam3_rgbl_amd import frontend as F, synth
+from oracle import oracle_py as O
+for case in range(max(n_cases // 3, 4)):
+    w, h = int(rng.integers(300, 1300)), int(rng.integers(200, 500))
+    ini, mn = int(rng.choice([12, 20, 30])), int(rng.choice([3, 7, 10]))
+    contrast = float(rng.choice([0.08, 0.15, 0.3]))
+    img = synth.Sequence(int(rng.integers(0, 1000)), w, h, n_frames=1).frame(0)
+    img = np.clip(img.astype(np.float32) * contrast + 90, 0, 255).astype(np.uint8)
+    ex = F.ORBextractor(1500, 1.2, 6, ini, mn, w, h, lib=lib)
+    orc = O.Extractor(1500, 1.2, 6, ini, mn)
+    kps, desc, mono = ex(img)
+    okps, odesc, omono = orc(img)
+    pc.assert_keypoints_equal(kps, okps, "low contrast %dx%d" % (w, h))
+    assert np.array_equal(desc, odesc) and mono == omono
+    for l in range(6):
+        c, oc = ex.level_candidates(l), orc.level_candidates(l)
+        assert len(c) == len(oc) and all(np.array_equal(c[f], oc[f]) for f in ("x", "y", "response")), (w, h, l)
+    print("ok low contrast %4dx%-4d FAST %2d/%2d x%.2f -> %d keypoints" % (w, h, ini, mn, contrast, len(kps)), flush=True)
+    ex.close()
+print("low-contrast cases bit-exact")
