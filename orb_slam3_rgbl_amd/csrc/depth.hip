@@ -391,6 +391,7 @@ struct rgbl_depth {
   float* d_proc = nullptr;
   float* d_cloud = nullptr;
   float *d_kp = nullptr, *d_kpun = nullptr, *d_depth = nullptr, *d_uright = nullptr;  // one block: kp (2 K) | kpun (K) | depth (K) | uright (K)
+  float* h_cloud = nullptr;    // page-locked staging of one scan (rgbl_depth_prefetch), allocated on first use
   float* h_kio = nullptr;      // page-locked mirror of that block: the keypoint arrays of the host entry points travel in one request each way
   std::vector<void*> allocs;
   // rgbl_depth_prefetch: the maps of this cloud are queued (or done) on the handle's stream
@@ -631,6 +632,7 @@ void rgbl_depth_destroy(rgbl_depth* e) {
   e->timer.collect();
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->h_kio) (void)hipHostFree(e->h_kio);
+  if (e->h_cloud) (void)hipHostFree(e->h_cloud);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -654,7 +656,23 @@ static int depth_prefetch_host(rgbl_depth* e, const float* cloud, int n, int ld,
   }
   RGBL_HIP(hipSetDevice(e->device));
   e->prefetched.active = false;
-  if (n > 0) RGBL_TRY(upload_cloud(e, cloud, n, ld, xyzi));
+  if (n > 0) {
+    // The scan goes through a page-locked block of the handle: the host copies it there (while the GPU extracts), the DMA
+    // from there is asynchronous under every HIP runtime - an asynchronous copy straight from pageable memory is staged by
+    // the runtime, and the one PyTorch ships (ROCm 7.0) holds it back behind the work of other streams: no overlap at all.
+    if (!e->h_cloud && hipHostMalloc(reinterpret_cast<void**>(&e->h_cloud), sizeof(float) * 4 * (size_t)e->cfg.max_points, hipHostMallocDefault) != hipSuccess) {
+      e->h_cloud = nullptr;
+      (void)hipGetLastError();
+    }
+    if (e->h_cloud) {
+      RGBL_HIP(hipStreamSynchronize(e->stream));  // the block's previous transfer (long done in a frame loop)
+      if (xyzi) memcpy(e->h_cloud, cloud, sizeof(float) * 4 * (size_t)n);
+      else for (int r = 0; r < 4; ++r) memcpy(e->h_cloud + (size_t)r * n, cloud + (size_t)r * ld, sizeof(float) * n);
+      RGBL_HIP(hipMemcpyAsync(e->d_cloud, e->h_cloud, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, e->stream));
+    } else {
+      RGBL_TRY(upload_cloud(e, cloud, n, ld, xyzi));
+    }
+  }
   RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi, false));
   e->prefetched.active = true; e->prefetched.cloud = cloud; e->prefetched.n = n; e->prefetched.ld = ld; e->prefetched.xyzi = xyzi;
   return RGBL_OK;
