@@ -493,9 +493,12 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       RGBL_HIP(hipEventRecord(e->ev_start, s));
       RGBL_HIP(hipStreamWaitEvent(bs, e->ev_start, 0));
       launch_fast(bs, 0, cells0);
-      launch_octree(bs, 0, 1);  // the longest dependent chains of the quad-tree start as early as they can
-      RGBL_HIP(hipEventRecord(e->ev_fast0, bs));
+      // level 0's Gaussian in front of its quad-tree launch: the quad-tree workgroups (37 KB of LDS each) only get placed as the
+      // FAST cells of the upper levels drain anyway, the Gaussian fills the time until then (125.7 -> 126.8 k frames/s; the
+      // quad-tree launch on the main stream in front of the upper levels' FAST cells instead: 122.3 k)
       launch_gauss(bs, 0, tiles0);
+      launch_octree(bs, 0, 1);
+      RGBL_HIP(hipEventRecord(e->ev_fast0, bs));
     }
     // 1. pyramid: level l from level l-1 (ORBextractor.cc:1170-1195)
     for (int l = 1; l < L; ++l) {
