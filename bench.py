@@ -427,6 +427,20 @@ def extra_workloads(lib, dev, torch):
                                                 "calls behind rgbl_extract_begin + rgbl_depth_prefetch (two extra lines in Frame's RGB-L constructor, "
                                                 "INTEGRATION.md): scan upload, projection and up-sampling run next to the extraction"}
         ex.close(); dm.close(); mt.close()
+        # the same frame loop from C++, through the drop-in classes (tools/shim_latency.cpp, built and run as a child process):
+        # what ORB_SLAM3 itself would see - the figures above carry ~40 us of ctypes / numpy per frame
+        try:
+            import re
+            import subprocess
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shim_latency.py")], capture_output=True, text=True, timeout=180)
+            m = re.findall(r"(C\+\+ drop-in classes[^:]*): ([0-9.]+) ms per frame \(extract ([0-9.]+), depth ([0-9.]+), match ([0-9.]+)\)", res.stdout)
+            if len(m) == 2:
+                out["host_api_single_frame"]["cpp_drop_in_classes"] = {
+                    "ms_per_frame": {"extract": float(m[0][2]), "depth": float(m[0][3]), "match": float(m[0][4]), "total": float(m[0][1]),
+                                     "total_with_begin_prefetch": float(m[1][1])},
+                    "what": "tools/shim_latency.cpp: ORB_SLAM3::ORBextractor / DepthModule (shim/) + rgbl_hamming_bf from C++, one frame per call"}
+        except Exception as e:
+            out["host_api_single_frame"]["cpp_drop_in_classes"] = {"error": repr(e)}
     except Exception as e:
         out["host_api_single_frame"] = {"error": repr(e)}
     return out
