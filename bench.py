@@ -571,6 +571,28 @@ def main():
         spot = "bit-exact vs CPU oracle on frames %s (keypoints, descriptors, depth, uRight, matches)" % \
             ", ".join(str(v) for v in spot_frames) if ok else "MISMATCH vs CPU oracle"
 
+    # ---- opt-in variant, reported beside the headline only: no dense ProcessedDepthMap (rgbl_depth_set_sparse), the keypoints'
+    # depths come out of the index maps directly.  Same inputs, same lanes; depth / uRight must not change by a bit.
+    sparse_leg = None
+    if world == 1 and not args.no_extras and not args.serial:
+        ref_depth, ref_ur = d_depth.clone(), d_uright.clone()
+        for ln in pipe.lanes:
+            ln.dm.SetSparseUpsampling(True)
+        n_sparse = max(10, args.steps // 2)
+        dt = time_steps(step, lambda: (pipe.finish(), torch.cuda.synchronize(dev)), 3, n_sparse)
+        sl = pipe.last()
+        same = bool(torch.equal(sl.depth.view(torch.int32), ref_depth.view(torch.int32)) and
+                    torch.equal(sl.uright.view(torch.int32), ref_ur.view(torch.int32)))
+        for ln in pipe.lanes:
+            ln.dm.SetSparseUpsampling(False)
+        step()
+        sync_all()
+        sparse_leg = {"value": B / dt, "unit": "frames/s", "steps": n_sparse, "depth_uright_equal_to_dense_run": same,
+                      "what": "the headline step with rgbl_depth_set_sparse(1): k_inverse_dilate is not launched, the gather evaluates "
+                              "the dilation at the keypoints' pixels (the dense map has no reader in RGB-L tracking: Tracking.cc:1584 "
+                              "copies it for FrameDrawer.cc:375, which is commented out). Not the headline: SURVEY 8(d) counts the "
+                              "dense map's bytes"}
+
     # ---- rank 0 at N == 1: roofline of the dominant kernel (HIP events on the launch stream) + CPU baseline
     roofline = None
     cpu = None
@@ -646,6 +668,7 @@ def main():
         }
         if world == 1 and not args.no_extras:
             out["extra"] = extra_workloads(lib, dev, torch)
+            out["extra"]["sparse_upsampling"] = sparse_leg
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

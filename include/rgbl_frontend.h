@@ -283,6 +283,12 @@ int rgbl_depth_gather_batch_device(rgbl_depth* h, int batch, int w, int h_, cons
 int rgbl_depth_sync(rgbl_depth* h);
 void* rgbl_depth_stream(rgbl_depth* h); /* hipStream_t currently used by the handle */
 int rgbl_depth_set_stream(rgbl_depth* h, void* hip_stream);
+/* Sparse up-sampling (off by default).  The reference fills ProcessedDepthMap for every frame (DepthModule.cc:203-251) and
+ * then reads it at the keypoints only (DepthModule.cc:82-104); in RGB-L tracking nothing else reads it - its one consumer,
+ * FrameDrawer.cc:375, is commented out.  With the switch on, an InverseDilation handle writes the dense map only for calls
+ * that ask for it (out_processed / d_processed non-NULL); otherwise the keypoint gather evaluates the dilation at the
+ * keypoints' pixels from the projected index map.  mvDepth / mvuRight are bit-identical either way. */
+int rgbl_depth_set_sparse(rgbl_depth* h, int enable);
 int rgbl_depth_profile(rgbl_depth* h, int enable);
 int rgbl_depth_profile_read(rgbl_depth* h, const char** names, double* total_ms, long* launches, int cap);
 

@@ -159,6 +159,7 @@ SYMBOLS = {
     "rgbl_event_record": (_I, [_V, _V]),
     "rgbl_event_wait": (_I, [_V, _V]),
     "rgbl_depth_set_stream": (_I, [_V, _V]),
+    "rgbl_depth_set_sparse": (_I, [_V, _I]),
     "rgbl_depth_profile": (_I, [_V, _I]),
     "rgbl_depth_profile_read": (_I, [_V, _V, _V, _V, _I]),
     "rgbl_matcher_create": (_I, [_I, C.POINTER(_V)]),

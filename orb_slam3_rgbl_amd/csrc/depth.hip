@@ -314,6 +314,48 @@ __global__ __launch_bounds__(256) void k_gather_depth(const float* __restrict__ 
   uright[f * out_frame + i] = our;
 }
 
+// DepthModule.cc:203-251 evaluated at the keypoints only (rgbl_depth_set_sparse): the value k_inverse_dilate would write at the
+// keypoint's pixel - same taps, same THRESH_TOZERO_INV arithmetic, the maximum is exact in any order - read through the index
+// map, then DepthModule.cc:82-104 as k_gather_depth.  One work-item per keypoint, <= 81 taps (13 for the shipped Diamond 5).
+__global__ __launch_bounds__(256) void k_gather_depth_sparse(DilateMask K, float S, const uint32_t* __restrict__ idx_map,
+                                                             const float* __restrict__ pt_depth, size_t pt_stride, uint32_t tag,
+                                                             size_t map_stride, int w, int h,
+                                                             const float* __restrict__ kp, int kp_stride, size_t kp_frame,
+                                                             const float* __restrict__ kpun, int un_stride, size_t un_frame,
+                                                             const int32_t* __restrict__ n_per_frame, int n_fixed, float mbf,
+                                                             float* __restrict__ depth, float* __restrict__ uright, size_t out_frame) {
+  const int i = xcd_item() * 256 + threadIdx.x, f = xcd_frame();  // grid = xcd_grid(keypoint groups, B)
+  const int n = n_per_frame ? n_per_frame[f] : n_fixed;
+  if (i >= n) return;
+  const float u = kp[f * kp_frame + (size_t)i * kp_stride], v = kp[f * kp_frame + (size_t)i * kp_stride + 1];
+  const uint32_t* I = idx_map + (size_t)f * map_stride;
+  const float* D = pt_depth + (size_t)f * pt_stride;
+  const int px = (int)u - K.kw / 2, py = (int)v - K.kh / 2;
+  const float thr = S - 1;
+  float m = -FLT_MAX;  // taps outside the image never win (cv::dilate's default border)
+  for (int ky = 0; ky < K.kh; ++ky) {
+    const int yy = py + ky;
+    if (yy < 0 || yy >= h) continue;
+    for (int kx = 0; kx < K.kw; ++kx) {
+      const int xx = px + kx;
+      if (!K.m[ky * K.kw + kx] || xx < 0 || xx >= w) continue;
+      const uint32_t e = I[(size_t)yy * w + xx], pt = e & kIdxMask;
+      const float r = ((e ^ tag) == pt && pt) ? D[pt - 1] : 0.f;
+      const float t = S - r;
+      m = fmaxf(m, t > thr ? 0.f : t);
+    }
+  }
+  const float t = S - m;
+  const float d = t > thr ? 0.f : t;
+  float od = -1.f, our = -1.f;
+  if (d > 0) {
+    od = d;
+    our = kpun[f * un_frame + (size_t)i * un_stride] - __fdiv_rn(mbf, d);
+  }
+  depth[f * out_frame + i] = od;
+  uright[f * out_frame + i] = our;
+}
+
 // DepthModule.cc:145-198.  The reference runs cv::distanceTransform(DIST_L2, 5x5) over the whole map and then
 // looks at one value per keypoint; the 5x5 chamfer metric has a closed form per displacement, so the distance
 // at a keypoint is the minimum of that form over the hits inside a small window (16.16 fixed point, exact).
@@ -396,6 +438,10 @@ struct rgbl_depth {
   std::vector<void*> allocs;
   // rgbl_depth_prefetch: the maps of this cloud are queued (or done) on the handle's stream
   struct { bool active = false; const float* cloud = nullptr; int n = 0, ld = 0; bool xyzi = false; } prefetched;
+  // rgbl_depth_set_sparse: the dense ProcessedDepthMap is written only when a caller asks for it; `maps` describes what the
+  // last projection left behind (dense == false: index maps of generation `tag`, the gather evaluates the dilation per keypoint)
+  bool sparse = false;
+  struct { bool dense = true; bool indexed = false; uint32_t tag = 0; int batch = 0; } maps;
 };
 
 namespace {
@@ -406,9 +452,56 @@ int dalloc(rgbl_depth* e, T** p, size_t count) {
   return RGBL_OK;
 }
 
+// DepthModule.cc:203-251 / 253-300: the dense ProcessedDepthMap of the maps the last projection wrote.
+int enqueue_upsample(rgbl_depth* e, int batch, int w, int h) {
+  hipStream_t s = e->stream;
+  const size_t ms = e->map_stride, pt_stride = (size_t)e->cfg.max_points;
+  const bool indexed = e->maps.indexed;
+  const uint32_t tag = e->maps.tag;
+  const dim3 tiles((w + 63) / 64, (h + 15) / 16, batch);
+  const dim3 dilate_tiles = xcd_grid(e->xcd_map, ((w + 63) / 64) * ((h + 31) / 32), batch);  // k_inverse_dilate works on 64 x 32 tiles
+  switch (e->cfg.method) {
+    case RGBL_UPS_INVERSE_DILATION:
+      e->timer.begin("k_inverse_dilate", s);
+      // opt_max_dist * ParamUpsampling_InverseDilation_ScaleFactor; the scale factor is never parsed (1.0)
+#define RGBL_DILATE(R, I) hipLaunchKernelGGL((k_inverse_dilate<R, I>), dilate_tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, \
+                                            e->d_idx, e->d_ptdepth, pt_stride, tag, e->d_proc, ms, w, h)
+      if (indexed) {
+        switch (e->diamond_radius) {
+          case 1: RGBL_DILATE(1, true); break;
+          case 2: RGBL_DILATE(2, true); break;
+          case 3: RGBL_DILATE(3, true); break;
+          case 4: RGBL_DILATE(4, true); break;
+          default: RGBL_DILATE(0, true); break;
+        }
+      } else {
+        switch (e->diamond_radius) {
+          case 1: RGBL_DILATE(1, false); break;
+          case 2: RGBL_DILATE(2, false); break;
+          case 3: RGBL_DILATE(3, false); break;
+          case 4: RGBL_DILATE(4, false); break;
+          default: RGBL_DILATE(0, false); break;
+        }
+      }
+#undef RGBL_DILATE
+      e->timer.end(s);
+      break;
+    case RGBL_UPS_AVERAGE_FILTERING:
+      e->timer.begin("k_average_filter", s);
+      hipLaunchKernelGGL(k_average_filter, tiles, dim3(256), 0, s, e->cfg.avg_kernel_size, e->d_raw, e->d_proc, ms, w, h);
+      e->timer.end(s);
+      break;
+    default:
+      break;
+  }
+  e->maps.dense = true;
+  RGBL_HIP(hipGetLastError());
+  return RGBL_OK;
+}
+
 // Part 1 (independent of the keypoints): projection + ordered scatter + dense up-sampling.
 int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w, int h,
-                 float* d_processed_out, bool xyzi = false, bool need_raw = true) {
+                 float* d_processed_out, bool xyzi = false, bool need_raw = true, bool want_dense = true) {
   hipStream_t s = e->stream;
   const size_t ms = e->map_stride;
   // the inverse dilation can read the points' depths through the index map: no raw map unless the caller wants it
@@ -448,42 +541,10 @@ int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, 
       e->timer.end(s);
     }
   }
-  const dim3 tiles((w + 63) / 64, (h + 15) / 16, batch);
-  const dim3 dilate_tiles = xcd_grid(e->xcd_map, ((w + 63) / 64) * ((h + 31) / 32), batch);  // k_inverse_dilate works on 64 x 32 tiles
-  switch (e->cfg.method) {
-    case RGBL_UPS_INVERSE_DILATION:
-      e->timer.begin("k_inverse_dilate", s);
-      // opt_max_dist * ParamUpsampling_InverseDilation_ScaleFactor; the scale factor is never parsed (1.0)
-#define RGBL_DILATE(R, I) hipLaunchKernelGGL((k_inverse_dilate<R, I>), dilate_tiles, dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f, e->d_raw, \
-                                            e->d_idx, e->d_ptdepth, pt_stride, tag, e->d_proc, ms, w, h)
-      if (indexed) {
-        switch (e->diamond_radius) {
-          case 1: RGBL_DILATE(1, true); break;
-          case 2: RGBL_DILATE(2, true); break;
-          case 3: RGBL_DILATE(3, true); break;
-          case 4: RGBL_DILATE(4, true); break;
-          default: RGBL_DILATE(0, true); break;
-        }
-      } else {
-        switch (e->diamond_radius) {
-          case 1: RGBL_DILATE(1, false); break;
-          case 2: RGBL_DILATE(2, false); break;
-          case 3: RGBL_DILATE(3, false); break;
-          case 4: RGBL_DILATE(4, false); break;
-          default: RGBL_DILATE(0, false); break;
-        }
-      }
-#undef RGBL_DILATE
-      e->timer.end(s);
-      break;
-    case RGBL_UPS_AVERAGE_FILTERING:
-      e->timer.begin("k_average_filter", s);
-      hipLaunchKernelGGL(k_average_filter, tiles, dim3(256), 0, s, e->cfg.avg_kernel_size, e->d_raw, e->d_proc, ms, w, h);
-      e->timer.end(s);
-      break;
-    default:
-      break;
-  }
+  e->maps.indexed = indexed; e->maps.tag = tag; e->maps.batch = batch;
+  // sparse handles keep the index maps and leave the dilation to the gather, unless the dense map is asked for here
+  e->maps.dense = !(e->sparse && indexed && !want_dense);
+  if (e->maps.dense) RGBL_TRY(enqueue_upsample(e, batch, w, h));
   if (d_processed_out && e->cfg.method != RGBL_UPS_NEAREST_NEIGHBOR_PIXEL)
     RGBL_HIP(hipMemcpyAsync(d_processed_out, e->d_proc, (size_t)batch * ms * sizeof(float), hipMemcpyDeviceToDevice, s));
   RGBL_HIP(hipGetLastError());
@@ -502,6 +563,12 @@ int enqueue_keypoints(rgbl_depth* e, int batch, int w, int h, const float* kp, i
     e->timer.begin("k_nn_depth", s);
     hipLaunchKernelGGL(k_nn_depth, kgrid, dim3(256), 0, s, e->d_raw, ms, w, h, kp, kp_stride, kp_frame, kpun, un_stride,
                        un_frame, d_n, n_fixed, e->cfg.mbf, e->cfg.nn_search_radius, d_depth, d_uright, out_frame);
+    e->timer.end(s);
+  } else if (!e->maps.dense) {
+    e->timer.begin("k_gather_depth_sparse", s);
+    hipLaunchKernelGGL(k_gather_depth_sparse, xcd_grid(e->xcd_map, (kmax + 255) / 256, batch), dim3(256), 0, s, e->mask, e->cfg.max_dist * 1.0f,
+                       e->d_idx, e->d_ptdepth, (size_t)e->cfg.max_points, e->maps.tag, ms, w, h, kp, kp_stride, kp_frame, kpun,
+                       un_stride, un_frame, d_n, n_fixed, e->cfg.mbf, d_depth, d_uright, out_frame);
     e->timer.end(s);
   } else {
     e->timer.begin("k_gather_depth", s);
@@ -673,7 +740,7 @@ static int depth_prefetch_host(rgbl_depth* e, const float* cloud, int n, int ld,
       RGBL_TRY(upload_cloud(e, cloud, n, ld, xyzi));
     }
   }
-  RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi, false));
+  RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi, false, false));
   e->prefetched.active = true; e->prefetched.cloud = cloud; e->prefetched.n = n; e->prefetched.ld = ld; e->prefetched.xyzi = xyzi;
   return RGBL_OK;
 }
@@ -705,7 +772,8 @@ static int depth_compute_host(rgbl_depth* e, const float* cloud, int n, int ld, 
     RGBL_HIP(hipMemcpyAsync(e->d_kp, kp_xy, sizeof(float) * 2 * k, hipMemcpyHostToDevice, s));
     RGBL_HIP(hipMemcpyAsync(e->d_kpun, kpun_x, sizeof(float) * k, hipMemcpyHostToDevice, s));
   }
-  if (!have_maps) RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi, out_raw != nullptr));
+  if (!have_maps) RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi, out_raw != nullptr, out_processed != nullptr));
+  else if (out_processed && !e->maps.dense) RGBL_TRY(enqueue_upsample(e, 1, w, h));  // a sparse prefetch, and the map is wanted after all
   RGBL_TRY(enqueue_keypoints(e, 1, w, h, e->d_kp, 2, 0, e->d_kpun, 1, 0, nullptr, k, k, e->d_depth, e->d_uright, 0));
   if (k > 0 && e->h_kio) {
     RGBL_HIP(hipMemcpyAsync(e->h_kio + 3 * K, e->d_depth, sizeof(float) * (K + k), hipMemcpyDeviceToHost, s));
@@ -749,7 +817,7 @@ int rgbl_depth_project_xyzi_batch_device(rgbl_depth* e, const float* d_xyzi, int
     return RGBL_ERR_INVALID;
   }
   RGBL_HIP(hipSetDevice(e->device));
-  return enqueue_maps(e, d_xyzi, batch, n, n, scan_stride, w, h, d_processed, true, false);
+  return enqueue_maps(e, d_xyzi, batch, n, n, scan_stride, w, h, d_processed, true, false, d_processed != nullptr);
 }
 
 int rgbl_depth_project_batch_device(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, size_t cloud_stride, int w,
@@ -761,7 +829,7 @@ int rgbl_depth_project_batch_device(rgbl_depth* e, const float* d_cloud, int bat
     return RGBL_ERR_INVALID;
   }
   RGBL_HIP(hipSetDevice(e->device));
-  return enqueue_maps(e, d_cloud, batch, n, ld, cloud_stride, w, h, d_processed, false, false);
+  return enqueue_maps(e, d_cloud, batch, n, ld, cloud_stride, w, h, d_processed, false, false, d_processed != nullptr);
 }
 
 int rgbl_depth_gather_batch_device(rgbl_depth* e, int batch, int w, int h, const rgbl_keypoint* d_kp, const int32_t* d_n,
@@ -800,6 +868,11 @@ int rgbl_depth_set_stream(rgbl_depth* e, void* hip_stream) {
   if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipStreamSynchronize(e->stream));
   e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  return RGBL_OK;
+}
+int rgbl_depth_set_sparse(rgbl_depth* e, int enable) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  e->sparse = enable != 0;
   return RGBL_OK;
 }
 int rgbl_depth_profile(rgbl_depth* e, int enable) {

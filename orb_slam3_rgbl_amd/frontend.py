@@ -287,6 +287,11 @@ class DepthModule:
                                                            L.ptr(self.mvDepth), L.ptr(self.mvuRight), L.ptr(self.RawDepthMap),
                                                            L.ptr(self.ProcessedDepthMap)))
 
+    def SetSparseUpsampling(self, enable):
+        """rgbl_depth_set_sparse: an InverseDilation module writes ProcessedDepthMap only for calls that ask for the maps;
+        otherwise the dilation is evaluated at the keypoints' pixels.  mvDepth / mvuRight do not change."""
+        L.check(self.lib, self.lib.rgbl_depth_set_sparse(self.h, int(bool(enable))))
+
     def profile(self, enable):
         L.check(self.lib, self.lib.rgbl_depth_profile(self.h, int(enable)))
 

@@ -87,7 +87,8 @@ class _Lane:
 
 class FrontEndPipeline:
     def __init__(self, lib, torch, dev, w, h, nfeatures, proj, n_points, batch, levels=8, scale=1.2, ini_th=12, min_th=7,
-                 world=1, rank=0, gather="step", serial=False, keep_steps=0, log_steps=1, lanes=1):
+                 world=1, rank=0, gather="step", serial=False, keep_steps=0, log_steps=1, lanes=1,
+                 sparse_depth=False):
         self.lib, self.torch, self.dev = lib, torch, dev
         self.w, self.h, self.B, self.n_points = w, h, batch, n_points
         self.world, self.rank, self.gather = world, rank, gather
@@ -98,6 +99,9 @@ class FrontEndPipeline:
         self.lanes = [_Lane(lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial)
                       for _ in range(1 if serial else max(1, min(lanes, 2)))]
         self.ex, self.dm, self.mt = self.lanes[0].ex, self.lanes[0].dm, self.lanes[0].mt
+        # sparse_depth: no dense ProcessedDepthMap (rgbl_depth_set_sparse) - the step never hands it out anyway
+        for ln in self.lanes:
+            ln.dm.SetSparseUpsampling(sparse_depth)
         self.cap = self.ex.max_keypoints
         if serial:
             # one stream for all handles and per-kernel HIP-event brackets on: every launch of the run is serialised - the

@@ -185,6 +185,12 @@ def test_depth_generation_wrap(emu_lib, max_gen):
     pc.check_depth_partial_batches(emu_lib, max_gen=max_gen)
 
 
+@pytest.mark.parametrize("kernel", [(F.KERNEL_DIAMOND, 5, 7), (F.KERNEL_DIAMOND, 3, 3), (F.KERNEL_RECT, 5, 7), (F.KERNEL_ELLIPSE, 7, 5),
+                                    (F.KERNEL_CROSS, 3, 9)])
+def test_depth_sparse_upsampling(emu_lib, kernel):
+    pc.check_depth_sparse(emu_lib, kernel=kernel)
+
+
 def test_extractor_partial_batches(emu_lib):
     pc.check_extractor_partial_batches(emu_lib, 360, 280, 400)
 
@@ -289,6 +295,12 @@ def test_extractor_batch_of_eight_takes_the_xcd_aware_mapping(emu_lib):
 def test_gather_choreography_with_one_rank(emu_lib, mode, lanes):
     import torch
     pc.check_pipeline_gather(emu_lib, mode, dev=torch.device("cpu"), w=240, h=160, nfeatures=300, batch=3, steps=3, n_az=240, levels=4, lanes=lanes)
+
+
+def test_pipeline_with_sparse_upsampling(emu_lib):
+    import torch
+    pc.check_pipeline_gather(emu_lib, "step", dev=torch.device("cpu"), w=240, h=160, nfeatures=300, batch=3, steps=3, n_az=240, levels=4, lanes=2,
+                             sparse_depth=True)
 
 
 def test_overlapped_frame_hooks(emu_lib):

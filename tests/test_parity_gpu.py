@@ -180,6 +180,14 @@ def test_depth_generation_wrap(gpu_lib, max_gen):
     pc.check_depth_partial_batches(gpu_lib, torch.device("cuda", 0), w=620, h=188, max_gen=max_gen)
 
 
+@pytest.mark.parametrize("kernel", [(F.KERNEL_DIAMOND, 5, 7), (F.KERNEL_DIAMOND, 9, 9), (F.KERNEL_RECT, 5, 7), (F.KERNEL_ELLIPSE, 7, 5),
+                                    (F.KERNEL_CROSS, 3, 9)])
+def test_depth_sparse_upsampling(gpu_lib, kernel):
+    """k_gather_depth_sparse against the oracle's dense map sampled at the keypoints (and the dense path through the same handle)"""
+    import torch
+    pc.check_depth_sparse(gpu_lib, torch.device("cuda", 0), w=620, h=188, kernel=kernel, batch=4, cap=512)
+
+
 def test_extractor_partial_batches(gpu_lib):
     pc.check_extractor_partial_batches(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000)
 
@@ -339,6 +347,11 @@ def test_gather_choreography_with_one_rank(gpu_lib, mode, lanes):
     # execute on the hardware (no peer, so no RCCL transfer); the records must decode to the step's own outputs
     # lanes = 2: two steps in flight on two sets of handles (pipeline.py)
     pc.check_pipeline_gather(gpu_lib, mode, lanes=lanes)
+
+
+def test_pipeline_with_sparse_upsampling(gpu_lib):
+    # the batched step without the dense ProcessedDepthMap (rgbl_depth_set_sparse): records equal to the oracle's
+    pc.check_pipeline_gather(gpu_lib, "step", lanes=2, sparse_depth=True)
 
 
 def test_overlapped_frame_hooks(gpu_lib):
