@@ -174,6 +174,10 @@ __device__ __forceinline__ uint32_t pk_subs_u16(uint32_t a, uint32_t b) {  // sa
   const uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16;
   return (al > bl ? al - bl : 0u) | ((ah > bh ? ah - bh : 0u) << 16);
 }
+__device__ __forceinline__ uint32_t pk_adds_u16(uint32_t a, uint32_t b) {  // saturating a + b per half
+  const uint32_t l = (a & 0xffffu) + (b & 0xffffu), h = (a >> 16) + (b >> 16);
+  return (l > 0xffffu ? 0xffffu : l) | ((h > 0xffffu ? 0xffffu : h) << 16);
+}
 #else
 typedef unsigned short rgbl_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ rgbl_us2 as_us2(uint32_t a) { rgbl_us2 x; __builtin_memcpy(&x, &a, 4); return x; }
@@ -181,6 +185,7 @@ __device__ __forceinline__ uint32_t from_us2(rgbl_us2 x) { uint32_t a; __builtin
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { return from_us2(__builtin_elementwise_min(as_us2(a), as_us2(b))); }
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) { return from_us2(__builtin_elementwise_max(as_us2(a), as_us2(b))); }
 __device__ __forceinline__ uint32_t pk_subs_u16(uint32_t a, uint32_t b) { return from_us2(__builtin_elementwise_sub_sat(as_us2(a), as_us2(b))); }
+__device__ __forceinline__ uint32_t pk_adds_u16(uint32_t a, uint32_t b) { return from_us2(__builtin_elementwise_add_sat(as_us2(a), as_us2(b))); }
 #endif
 // dynamic LDS of a kernel (sized per launch); the emulator gives every workgroup thread a buffer of the hardware's size
 #ifdef RGBL_EMU

@@ -218,6 +218,29 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { return 
 __device__ __forceinline__ uint32_t pk_swap(uint32_t a) { return from_s2(as_s2(a).yx); }
 #endif
 
+// v_mul_u32_u24 spelled out: the compiler turns __umul24 of operands it cannot bound into a mask + v_mul_lo_u32, which issues at
+// a quarter of the rate.  Both operands must be below 2^24, the second one wave-uniform.
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
+#ifdef RGBL_EMU
+  return (a & 0xffffffu) * (b & 0xffffffu);
+#else
+  uint32_t r;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));   // b: wave-uniform
+  return r;
+#endif
+}
+
+// v + (pred ? 1 : 0) as ONE vector instruction: the predicate is a comparison's scalar mask already, v_addc_co takes it as
+// the carry (the compiler's own choice was v_cndmask 0 / 1 + add).
+__device__ __forceinline__ int add_flag(int v, unsigned long long mask) {  // mask: wave_ballot of bare comparisons, combined with & |
+#ifdef RGBL_EMU
+  return v + (int)((mask >> lane_id()) & 1ull);
+#else
+  int r;
+  asm("v_addc_co_u32_e64 %0, vcc, 0, %1, %2" : "=v"(r) : "v"(v), "s"(mask) : "vcc");
+  return r;
+#endif
+}
 // Hides where an LDS index came from: the compiler otherwise folds "index - constant" back into the accesses' offsets, and
 // every NEGATIVE offset then costs an address addition (DS instructions take unsigned immediate offsets only).
 __device__ __forceinline__ int opaque(int v) {
@@ -256,14 +279,22 @@ __device__ __forceinline__ int fast_score_one(const uint8_t* tile, int t, int P,
     D[k] = pk_mad_i16(a | (b << 16), sgn, vs);  // sgn * ring - sgn * v
   }
 #define RGBL_AT(A, k) ((k) < 8 ? (A)[(k) & 7] : pk_swap((A)[((k) - 8) & 7]))
-  uint32_t mn2[8], mn4[8];
+  // A 9-window starts at an even position s - 1 or at the odd position s behind it; both contain the 8-window s .. s + 7, the
+  // first adds d[s-1], the second d[s+8], and max(min(a, x), min(a, y)) = min(a, max(x, y)).  So only the 8-windows at the ODD
+  // positions are needed: 4 registers (position s and s + 8 share one) instead of 8 at every log step - 23 packed
+  // operations instead of 40.  (cv's cornerScore<16> walks k = 0, 2, .. 14 the same way.)
+  uint32_t mn2[4], mn4[4], mn8[4];
+#define RGBL_ODD(A, s) ((s) < 8 ? (A)[((s) >> 1) & 3] : pk_swap((A)[(((s) - 8) >> 1) & 3]))   /* register of the odd position s */
 #pragma unroll
-  for (int k = 0; k < 8; ++k) mn2[k] = pk_min_i16(D[k], RGBL_AT(D, k + 1));
+  for (int i = 0; i < 4; ++i) mn2[i] = pk_min_i16(D[2 * i + 1], RGBL_AT(D, 2 * i + 2));
 #pragma unroll
-  for (int k = 0; k < 8; ++k) mn4[k] = pk_min_i16(mn2[k], RGBL_AT(mn2, k + 2));
+  for (int i = 0; i < 4; ++i) mn4[i] = pk_min_i16(mn2[i], RGBL_ODD(mn2, 2 * i + 3));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) mn8[i] = pk_min_i16(mn4[i], RGBL_ODD(mn4, 2 * i + 5));
   uint32_t best = 0x80008000u;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) best = pk_max_i16(best, pk_min_i16(pk_min_i16(mn4[k], RGBL_AT(mn4, k + 4)), pk_swap(D[k])));
+  for (int i = 0; i < 4; ++i) best = pk_max_i16(best, pk_min_i16(mn8[i], pk_max_i16(D[2 * i], pk_swap(D[2 * i + 1]))));
+#undef RGBL_ODD
 #undef RGBL_AT
 #undef RGBL_O
   return imax((int)(int16_t)(best & 0xffffu), (int)(int16_t)(best >> 16)) - 1;
@@ -333,6 +364,18 @@ __device__ __forceinline__ void lds_dma16(const uint8_t* gsrc, uint8_t* lds_wave
   typedef __attribute__((address_space(3))) void* lptr_t;
   __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)lds_wave_base, 16, 0, 0);
 #endif
+}
+
+// Bytes K and K + 2 of the 12 bytes w0 | w1 | w2 (numbered -4 .. 7) as the HIGH bytes of a register's two 16-bit halves.
+// kClean: the low bytes are zero; otherwise they hold whatever is cheapest (nothing at all when K = 1 mod 4).
+template <int K, bool kClean = false>
+__device__ __forceinline__ uint32_t hi_pair(uint32_t w0, uint32_t w1, uint32_t w2) {
+  constexpr int q = (K + 4) >> 2, r = (K + 4) & 3;
+  static_assert(K >= -4 && K + 2 <= 7, "inside the three words");
+  const uint32_t lo = q == 0 ? w0 : q == 1 ? w1 : w2, hi = q == 0 ? w1 : w2;
+  if (!kClean && r == 1) return lo;
+  if (!kClean && r == 0) return lo << 8;
+  return perm_bytes(hi, lo, 0x000c000cu | ((uint32_t)r << 8) | ((uint32_t)(r + 2) << 24));
 }
 
 // One detection cell per workgroup; the reference's own control flow (ORBextractor.cc:826-846): cv::FAST at iniThFAST on the
@@ -460,7 +503,7 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
         // no divergent region around the tests: a lane past the last group works on that group again with all four pixels
         // masked out (nvalid = 0), so that the flags stay scalar masks - the ballots below cost nothing
         const int gl = g0 + tid, g = imin(gl, ngroups - 1);
-        const int gy = (int)(__umul24((uint32_t)g, gmagic) >> 16), gx = g - gy * gpr;
+        const int gy = (int)(mul24((uint32_t)g, gmagic) >> 16), gx = g - gy * gpr;
         const int wi = (gy + 3) * (P / 4) + 1 + gx;   // word of the group's 4 centres
         const int t0 = 4 * wi;
         const uint32_t* W = s_tile_w + (wi - 3 * (P / 4));   // row - 3
@@ -469,38 +512,68 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
         const uint32_t u0 = W[5 * R - 1], u1 = W[5 * R], u2 = W[5 * R + 1];   // row + 2
         const uint32_t d0 = W[R - 1], d1 = W[R], d2 = W[R + 1];               // row - 2
         const uint32_t u3 = W[6 * R], d3 = W[0];                              // rows +- 3
-        const int nvalid = gl < ngroups ? sw - 4 * gx : 0;  // pixels of the group inside the scanned area (the last group of a row may hold fewer than 4)
-        // byte k (-4 .. 7, relative to the group's first pixel) of a row given as three words
-#define RGBL_B(w0, w1, w2, k) ((int)(((k) < 0 ? (w0) >> (8 * ((k) + 4)) : (k) < 4 ? (w1) >> (8 * ((k) & 3)) : (w2) >> (8 * ((k) - 4))) & 0xffu))
-        bool dk[4], br[4], vj[4];
-        int cnt = 0;  // list entries of this work-item: one per surviving pixel, two where both polarities pass
+        const int nvalid = sw - 4 * gx;  // pixels of the group inside the scanned area (the last group of a row may hold fewer than 4)
+        const bool live = gl < ngroups;
+        const unsigned long long mlive = wave_ballot(gl < ngroups);
+        // Two pixels per instruction: the ring values of the pixels (1, 3) resp. (0, 2) of the group sit in the HIGH bytes of the
+        // two 16-bit halves of a register, whatever is in the low bytes (a minimum / maximum of such halves has the minimum /
+        // maximum of the high bytes in its high byte) - pixels 1 and 3 of an aligned word ARE such a register, the others
+        // cost one shift or v_perm_b32 for two pixels.  The bounds are clean: lo = (v - thr) << 8 saturated at 0, hi =
+        // (v + thr) << 8 | 0xff saturated at 0xffff, so that "M < lo" and "m > hi" on the halves compare the high bytes
+        // strictly (equal high bytes never pass, whatever the low ones hold).
+        bool dk[4], br[4];
+        unsigned long long mdk[4], mbr[4];   // the same conditions as wave masks (the comparisons' own scalar results)
+        const uint32_t th2 = ((uint32_t)thr << 8) | ((uint32_t)thr << 24);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {  // o = 1: pixels 1 (low half) and 3 (high half); o = 0: pixels 0 and 2
+          uint32_t c, a0, b0, a1, b1, a2, b2, a3, b3;
+          if (o == 1) {
+            c = hi_pair<1, true>(c0, c1, c2);
+            a0 = hi_pair<1>(0u, u3, 0u); b0 = hi_pair<1>(0u, d3, 0u);                       // ring 0 / 8: (0, +3), (0, -3)
+            a1 = hi_pair<4>(c0, c1, c2); b1 = hi_pair<-2>(c0, c1, c2);                      // ring 4 / 12: (+3, 0), (-3, 0)
+            a2 = hi_pair<3>(u0, u1, u2); b2 = hi_pair<-1>(d0, d1, d2);                      // ring 2 / 10: (+2, +2), (-2, -2)
+            a3 = hi_pair<3>(d0, d1, d2); b3 = hi_pair<-1>(u0, u1, u2);                      // ring 6 / 14: (+2, -2), (-2, +2)
+          } else {
+            c = hi_pair<0, true>(c0, c1, c2);
+            a0 = hi_pair<0>(0u, u3, 0u); b0 = hi_pair<0>(0u, d3, 0u);
+            a1 = hi_pair<3>(c0, c1, c2); b1 = hi_pair<-3>(c0, c1, c2);
+            a2 = hi_pair<2>(u0, u1, u2); b2 = hi_pair<-2>(d0, d1, d2);
+            a3 = hi_pair<2>(d0, d1, d2); b3 = hi_pair<-2>(u0, u1, u2);
+          }
+          const uint32_t M = pk_max_u16(pk_max_u16(pk_min_u16(a0, b0), pk_min_u16(a1, b1)), pk_max_u16(pk_min_u16(a2, b2), pk_min_u16(a3, b3)));   // every pair has a member below lo
+          const uint32_t m = pk_min_u16(pk_min_u16(pk_max_u16(a0, b0), pk_max_u16(a1, b1)), pk_min_u16(pk_max_u16(a2, b2), pk_max_u16(a3, b3)));   // every pair has a member above hi
+          const uint32_t lo = pk_subs_u16(c, th2), hi = pk_adds_u16(c, th2 | 0x00ff00ffu);
+          dk[o] = (uint16_t)M < (uint16_t)lo; dk[o + 2] = (uint16_t)(M >> 16) < (uint16_t)(lo >> 16);
+          br[o] = (uint16_t)m > (uint16_t)hi; br[o + 2] = (uint16_t)(m >> 16) > (uint16_t)(hi >> 16);
+          mdk[o] = wave_ballot((uint16_t)M < (uint16_t)lo); mdk[o + 2] = wave_ballot((uint16_t)(M >> 16) < (uint16_t)(lo >> 16));
+          mbr[o] = wave_ballot((uint16_t)m > (uint16_t)hi); mbr[o + 2] = wave_ballot((uint16_t)(m >> 16) > (uint16_t)(hi >> 16));
+        }
+        // A work-item has up to 8 list entries: per pixel one for the dark arc (t) and one for the bright arc (t | 0x8000),
+        // for whichever passes.  c[k] = entries among its first k candidates: eight adds of a condition's scalar mask as carry.
+        // One reservation per work-item and trip: the counts are scanned over the wave (DPP adds), entry k then goes to
+        // (first slot of the work-item) + c[k] - one address and one value operation per entry, the condition is the write's
+        // execution mask.  A trip that does not fit the list as a whole writes nothing (uniform) and only counts on: the
+        // cell is then scored pixel by pixel.
+        bool on[8];
+        int c[9];
+        c[0] = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int v = RGBL_B(c0, c1, c2, j), lo = v - thr, hi = v + thr;
-          const int a0 = RGBL_B(u3, u3, u3, j), b0 = RGBL_B(d3, d3, d3, j);                  // ring 0 / 8: (0, +3), (0, -3)
-          const int a1 = RGBL_B(c0, c1, c2, j + 3), b1 = RGBL_B(c0, c1, c2, j - 3);          // ring 4 / 12: (+3, 0), (-3, 0)
-          const int a2 = RGBL_B(u0, u1, u2, j + 2), b2 = RGBL_B(d0, d1, d2, j - 2);          // ring 2 / 10: (+2, +2), (-2, -2)
-          const int a3 = RGBL_B(d0, d1, d2, j + 2), b3 = RGBL_B(u0, u1, u2, j - 2);          // ring 6 / 14: (+2, -2), (-2, +2)
-          const int M = imax(imax(imin(a0, b0), imin(a1, b1)), imax(imin(a2, b2), imin(a3, b3)));   // every pair has a member below lo
-          const int m = imin(imin(imax(a0, b0), imax(a1, b1)), imin(imax(a2, b2), imax(a3, b3)));   // every pair has a member above hi
-          vj[j] = j < nvalid; dk[j] = M < lo; br[j] = m > hi;
-          cnt += (vj[j] && (dk[j] || br[j])) ? 1 : 0;
-          cnt += (vj[j] && dk[j] && br[j]) ? 1 : 0;
+          const bool v = live && j < nvalid;
+          const unsigned long long mv = mlive & wave_ballot(j < nvalid);
+          on[2 * j] = v && dk[j]; on[2 * j + 1] = v && br[j];
+          c[2 * j + 1] = add_flag(c[2 * j], mv & mdk[j]);
+          c[2 * j + 2] = add_flag(c[2 * j + 1], mv & mbr[j]);
         }
-        // One reservation per work-item and trip instead of one per pixel: the work-items' entry counts are scanned over the
-        // wave (DPP adds), a work-item then writes its entries one after the other.  A trip that does not fit the list as a
-        // whole writes nothing (uniform) and only counts on: the cell is then scored pixel by pixel.
+        const int cnt = c[8];
         const int incl = wave_inclusive_scan(cnt), total = wave_last(incl);
         if (n_mine + total <= kSurvPerWave) {
           uint16_t* dst = mine + (n_mine + incl - cnt);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (vj[j] && (dk[j] || br[j])) *dst++ = (uint16_t)(dk[j] ? (t0 + j) : ((t0 + j) | 0x8000));
-            if (vj[j] && dk[j] && br[j]) *dst++ = (uint16_t)((t0 + j) | 0x8000);
-          }
+          for (int k = 0; k < 8; ++k)
+            if (on[k]) dst[c[k]] = (uint16_t)(t0 + (k >> 1) + ((k & 1) << 15));   // t0 + j < 2^15
         }
         n_mine += total;
-#undef RGBL_B
       }
       if (lane_id() == 0) s_nsurv[wv] = n_mine;
     }
