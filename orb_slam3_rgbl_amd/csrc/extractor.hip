@@ -64,6 +64,7 @@ struct rgbl_extractor {
   int octree_wg = 0;  // 0 = choose per launch; RGBL_OCTREE_WG=256|512 pins the quad-tree workgroup width (tuning / tests)
   int octree_ncap = 0;  // LDS node capacity of the label-based quad-tree kernel (512 / 2048); 0 = key-moving kernel on global lists
   int max_cell = 0, max_cell_w = 0;  // largest detection-cell side / width over the levels: select the k_fast_cells instantiation
+  int fast_waves = 0;  // waves per detection cell of k_fast_cells: 0 = by batch size, RGBL_FAST_BS=64 / 128 force 1 / 2
   bool xcd_map = true;  // XCD-aware workgroup -> (item, frame) mapping of the pixel kernels (common.h: xcd_item_frame); RGBL_XCD_MAP=0 switches it off
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> per_level;
@@ -372,6 +373,7 @@ int upload_tables(rgbl_extractor* e) {
   RGBL_HIP(hipMemcpy(e->d_rootx, rootx.data(), rootx.size(), hipMemcpyHostToDevice));
   RGBL_HIP(hipMemcpy(e->d_pattern, kBriefPattern, 1024, hipMemcpyHostToDevice));
   if (const char* v = getenv("RGBL_XCD_MAP")) e->xcd_map = v[0] != '0';
+  if (const char* v = getenv("RGBL_FAST_BS")) e->fast_waves = atoi(v) == 64 ? 1 : atoi(v) == 128 ? 2 : 0;
   return RGBL_OK;
 }
 
@@ -428,8 +430,13 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   // cells of at most kCellSmall px (every level of the usual image sizes) take the small-LDS instantiation: two waves per
   // cell (a cell is a chain of short phases; 16 workgroups of two waves per CU overlap better than 8 of four), tile pitch 48
   // bytes when no level's cells are wider than 41 px (cell + 7 bytes per tile row), else 64; bigger cells: four waves, pitch 80
-  const int fast_bs = e->max_cell <= kCellSmall ? 128 : 256;
+  int fast_bs = e->max_cell <= kCellSmall ? 128 : 256;
   auto fast = e->max_cell <= kCellSmall ? (e->max_cell_w <= 41 ? k_fast_cells<kCellSmall, 128, 48> : k_fast_cells<kCellSmall, 128, 64>) : k_fast_cells<kCellMax, 256, 80>;
+  // Batches: ONE wave per cell - no second wave's fixed work (6.0e8 instead of 6.7e8 vector instructions per 512-frame step),
+  // the kernel's own time is the same (fewer waves to hide the LDS round trips) but what runs beside it gains; a single
+  // frame is latency-bound and keeps two waves per cell (half the trips per wave).  RGBL_FAST_BS=64 / 128 overrides.
+  const bool one_wave = e->fast_waves ? e->fast_waves == 1 : batch >= 8;
+  if (one_wave && e->max_cell <= kCellSmall && e->max_cell_w <= 41) { fast = k_fast_cells<kCellSmall, 64, 48>; fast_bs = 64; }
   auto launch_fast = [&](hipStream_t st, int cell_begin, int cell_end) {
     if (cell_end <= cell_begin) return;
     e->timer.begin("k_fast_cells", st);

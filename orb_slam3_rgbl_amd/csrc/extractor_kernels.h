@@ -498,11 +498,13 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
 #if defined(RGBL_FAST_SKIP) && RGBL_FAST_SKIP >= 2
       for (int g0 = 0; g0 < 0; g0 += BS) {
 #else
-      for (int g0 = 0; g0 < ngroups; g0 += BS) {
+      // wave w takes the groups 64 w + 64 k BS/64 ..: its loop ends with ITS last group (the 315 groups of a 35 x 35 cell are
+      // 5 wave trips, 3 + 2, not 2 x 3)
+      for (int g0 = 64 * wv; g0 < ngroups; g0 += BS) {
 #endif
         // no divergent region around the tests: a lane past the last group works on that group again with all four pixels
         // masked out (nvalid = 0), so that the flags stay scalar masks - the ballots below cost nothing
-        const int gl = g0 + tid, g = imin(gl, ngroups - 1);
+        const int gl = g0 + lane_id(), g = imin(gl, ngroups - 1);
         const int gy = (int)(mul24((uint32_t)g, gmagic) >> 16), gx = g - gy * gpr;
         const int wi = (gy + 3) * (P / 4) + 1 + gx;   // word of the group's 4 centres
         const int t0 = 4 * wi;
@@ -585,25 +587,32 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
     int nsurv = 0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) { cs[w] = s_nsurv[w]; all = all || cs[w] > kSurvPerWave; nsurv += cs[w]; }
+    int cs_mine = s_nsurv[wv];
     if (all) nsurv = 2 * npix;
 #if defined(RGBL_FAST_SKIP) && RGBL_FAST_SKIP >= 1
     nsurv = 0;
+    cs_mine = 0;
 #endif
     {
       uint16_t* mine = s_corner + wv * kCornerPerWave;
       int n_mine = 0;
-      for (int i0 = 0; i0 < nsurv; i0 += BS) {
+      // A wave scores the entries of its OWN list (as many wave trips in all as over the concatenated lists, and no search for
+      // the list an index falls into); `all`: everybody takes its share of all pixels, both arcs each.
+      const int n_loop = all ? nsurv : cs_mine, step = all ? BS : 64;
+      const uint16_t* my_surv = s_surv + wv * kSurvPerWave;
+      for (int i0 = 0; i0 < n_loop; i0 += step) {
         // (a lane past the end scores the last entry again and is masked out: no divergent region, the flag stays a scalar mask)
-        const int il = i0 + tid, i = imin(il, nsurv - 1);
+        const int il = i0 + (all ? tid : lane_id()), i = imin(il, n_loop - 1);
         int e;
         if (all) e = RGBL_T_OF(i >> 1) | ((i & 1) << 15);
-        else RGBL_LIST_AT(s_surv, cs, kSurvPerWave, i, e);
+        else e = my_surv[i];
         const int t = e & 0x7fff;
-        const int sc = fast_score_one(s_tile, t, P, (e & 0x8000) ? 0x00010001u : 0xffffffffu);
-        const bool live = il < nsurv, hit = sc >= thr, corner = live && hit;  // at most one of a pixel's two arcs can exist
-        if (corner) s_score[t - kScoreOff] = (uint8_t)sc;
-        const unsigned long long m = wave_ballot(live) & wave_ballot(hit);
+        const int sc = fast_score_one(s_tile, t, P, e < 0x8000 ? 0xffffffffu : 0x00010001u);
+        const bool live = il < n_loop, hit = sc >= thr, corner = live && hit;  // at most one of a pixel's two arcs can exist
+        // (the ballots in the block of their comparisons: across a branch the compiler rebuilds a mask from a 0 / 1 register)
+        const unsigned long long m = wave_ballot(il < n_loop) & wave_ballot(sc >= thr);
         if (corner) {
+          s_score[t - kScoreOff] = (uint8_t)sc;
           const int pos = n_mine + wave_rank(m);
           if (pos < kCornerPerWave) mine[pos] = (uint16_t)t;
         }

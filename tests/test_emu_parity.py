@@ -116,6 +116,18 @@ def test_extractor_fast_kernel_instantiations(emu_lib):
     pc.check_extractor(emu_lib, 640, 480, 600, frames=(0,), seq=4, stages=True)
 
 
+@pytest.mark.parametrize("bs", ["64", "128"])
+def test_extractor_fast_kernel_waves_per_cell(emu_lib, bs):
+    # one wave per detection cell (what batches of 8 and more frames take) and two (single frames), each forced on both
+    os.environ["RGBL_FAST_BS"] = bs
+    try:
+        pc.check_extractor(emu_lib, 1241, 376, 2000, frames=(0,), seq=5, stages=True)
+        pc.check_extractor_batch(emu_lib, 400, 300, 500, 8)
+        pc.check_extractor_low_contrast(emu_lib)
+    finally:
+        os.environ.pop("RGBL_FAST_BS", None)
+
+
 def test_extractor_quadtree_empty_root_nodes(emu_lib):
     pc.check_extractor_empty_root(emu_lib)
 

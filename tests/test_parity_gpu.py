@@ -57,6 +57,18 @@ def test_extractor_fast_kernel_instantiations(gpu_lib):
     pc.check_extractor(gpu_lib, 640, 480, 600, frames=(0,), seq=4, stages=True)
 
 
+@pytest.mark.parametrize("bs", ["64", "128"])
+def test_extractor_fast_kernel_waves_per_cell(gpu_lib, bs):
+    # one wave per detection cell (what batches of 8 and more frames take) and two (single frames), each forced on both
+    os.environ["RGBL_FAST_BS"] = bs
+    try:
+        pc.check_extractor(gpu_lib, 1241, 376, 2000, frames=(0,), seq=5, stages=True)
+        pc.check_extractor_batch(gpu_lib, 400, 300, 500, 8)
+        pc.check_extractor_low_contrast(gpu_lib)
+    finally:
+        os.environ.pop("RGBL_FAST_BS", None)
+
+
 def test_extractor_edge_cases(gpu_lib):
     pc.check_extractor_edge_cases(gpu_lib)
     pc.check_extractor_empty_root(gpu_lib)
