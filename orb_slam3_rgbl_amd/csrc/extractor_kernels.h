@@ -404,29 +404,19 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
   constexpr int kScoreOff = 2 * P + 3, kBitOff = 3 * P + 4;
   constexpr int kScoreQuads = (CM + 2) * P / 16;      // the score tile in 16-byte pieces
   constexpr int kBitWords = (CM * P + 63) / 64 * 2;   // bitmap words, an even number: the compaction reads them in pairs
-  constexpr int kCornerCap = 512;                     // pixels with a score kept as a list for the NMS (all survivors are scanned beyond that)
   __shared__ __attribute__((aligned(16))) uint32_t s_tile_w[(CM + 6) * P / 4 + 4];  // + slack: the last group of the last row reads one word on
   uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile_w);
   __shared__ __attribute__((aligned(16))) uint32_t s_score_w[kScoreQuads * 4];
   uint8_t* s_score = reinterpret_cast<uint8_t*>(s_score_w);
   // survivors of the pre-screen as lists of (t | polarity << 15), one list per wave: a wave ranks its survivors with a ballot
   // and keeps its count in a scalar register - no LDS atomic and no round trip per trip of the loop.  Cells with more survivors
-  // than a list holds (noise, checkerboards) are scored pixel by pixel, both polarities.  The corners found by phase B alike.
+  // than a list holds (noise, checkerboards) are scored pixel by pixel, both polarities.  The corners phase B finds go to the
+  // front of the same list: a wave compacts its own entries in place (a corner's slot is never behind the entry it came from).
   constexpr int kWaves = BS / 64;
   constexpr int kSurvCap = CM <= kCellSmall ? 1024 : CM * CM, kSurvPerWave = kSurvCap / kWaves;
-  constexpr int kCornerPerWave = kCornerCap / kWaves;
   __shared__ uint16_t s_surv[kSurvCap];
-  __shared__ uint16_t s_corner[kCornerCap];
   __shared__ int s_nsurv[kWaves], s_ncorner[kWaves], s_any;
   __shared__ uint32_t s_keep[kBitWords];
-  // entry i of the concatenation of the waves' lists (counts c[w], capacity cap per wave)
-#define RGBL_LIST_AT(list, c, cap, i, out)                                                             \
-  do {                                                                                                 \
-    int seg_ = 0, j_ = (i);                                                                            \
-    _Pragma("unroll") for (int w_ = 0; w_ + 1 < kWaves; ++w_)                                          \
-      if (seg_ == w_ && j_ >= (c)[w_]) { j_ -= (c)[w_]; seg_ = w_ + 1; }                               \
-    (out) = (list)[seg_ * (cap) + j_];                                                                 \
-  } while (0)
 
   const int tid = threadIdx.x;
   const int f = xcd_frame();
@@ -582,24 +572,21 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
     __syncthreads();
 
     // ---- phase B: exact score of the listed arcs; the ones that exist at this threshold are corners and are listed
-    int cs[kWaves];
     bool all = false;  // the pre-screen is a necessary condition only: scoring every pixel, both arcs, gives the same corners
-    int nsurv = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) { cs[w] = s_nsurv[w]; all = all || cs[w] > kSurvPerWave; nsurv += cs[w]; }
+    for (int w = 0; w < kWaves; ++w) all = all || s_nsurv[w] > kSurvPerWave;
     int cs_mine = s_nsurv[wv];
-    if (all) nsurv = 2 * npix;
+    int nsurv = all ? 2 * npix : 0;   // all: the pixels' arcs, everybody takes a share
 #if defined(RGBL_FAST_SKIP) && RGBL_FAST_SKIP >= 1
     nsurv = 0;
     cs_mine = 0;
 #endif
+    uint16_t* const my_surv = s_surv + wv * kSurvPerWave;
     {
-      uint16_t* mine = s_corner + wv * kCornerPerWave;
       int n_mine = 0;
       // A wave scores the entries of its OWN list (as many wave trips in all as over the concatenated lists, and no search for
       // the list an index falls into); `all`: everybody takes its share of all pixels, both arcs each.
       const int n_loop = all ? nsurv : cs_mine, step = all ? BS : 64;
-      const uint16_t* my_surv = s_surv + wv * kSurvPerWave;
       for (int i0 = 0; i0 < n_loop; i0 += step) {
         // (a lane past the end scores the last entry again and is masked out: no divergent region, the flag stays a scalar mask)
         const int il = i0 + (all ? tid : lane_id()), i = imin(il, n_loop - 1);
@@ -614,7 +601,7 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
         if (corner) {
           s_score[t - kScoreOff] = (uint8_t)sc;
           const int pos = n_mine + wave_rank(m);
-          if (pos < kCornerPerWave) mine[pos] = (uint16_t)t;
+          if (pos < kSurvPerWave) my_surv[pos] = (uint16_t)t;   // pos <= the entry's own index (entries of the list), or the list is not read (all)
         }
         n_mine += (int)__popcll(m);
       }
@@ -623,16 +610,16 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
     __syncthreads();
 
     // ---- phase C: 3x3 strict NMS inside the cell over the pixels that have a score; its survivors set a bit in a
-    //      row-major bitmap.  A wave checks the corners it listed itself; if a wave's list overflowed, everybody scans all survivors.
+    //      row-major bitmap.  A wave checks the corners it listed itself; a list can only overflow when every pixel was scored
+    //      (`all`: more corners than list slots) - everybody then looks at its share of all pixels.
     bool listed = true;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) listed = listed && s_ncorner[w] <= kCornerPerWave;
+    for (int w = 0; w < kWaves; ++w) listed = listed && s_ncorner[w] <= kSurvPerWave;
     const int ncheck = listed ? s_ncorner[wv] : nsurv;
     for (int i = listed ? lane_id() : tid; i < ncheck; i += listed ? 64 : BS) {
       int t;
-      if (listed) t = s_corner[wv * kCornerPerWave + i];
-      else if (all) t = RGBL_T_OF(i >> 1);
-      else { RGBL_LIST_AT(s_surv, cs, kSurvPerWave, i, t); t &= 0x7fff; }
+      if (listed) t = my_surv[i];
+      else t = RGBL_T_OF(i >> 1);
       const uint8_t* s = &s_score[t - kScoreOff - (P + 1)];  // the 3x3 neighbourhood's first byte
       const int v = s[P + 1];
       if (v != 0 && v > s[P] && v > s[P + 2] && v > s[0] && v > s[1] && v > s[2] && v > s[2 * P] && v > s[2 * P + 1] && v > s[2 * P + 2]) {
@@ -646,7 +633,6 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
     if (pass + 1 < n_passes) __syncthreads();  // everyone has read s_any before the next pass clears it
   }
 #undef RGBL_T_OF
-#undef RGBL_LIST_AT
   // Ordered compaction by the first wave alone (no further barrier; the other waves are done): a lane owns 64 bitmap
   // bits, ascending bits = cv::FAST's row-major emission order.  The ordered pixel list goes through LDS (the survivor
   // list's space) so that the keys leave with one coalesced store per 64 keypoints.
