@@ -51,7 +51,7 @@ struct rgbl_extractor {
   int L = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
   hipStream_t aux_stream = nullptr;  // the Gaussian working images only depend on the pyramid: they overlap FAST + quad-tree
-  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_fast0 = nullptr;
+  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_fast0 = nullptr, ev_desc0 = nullptr;
   KernelTimer timer;
   // hipGraph of the host-pointer path (all device pointers of that path are the handle's own buffers, so one captured
   // launch sequence can be replayed): key = (batch, row stride, lapping area, stream)
@@ -550,13 +550,27 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   uint8_t* desc_dst = lapping ? e->d_tmp_desc : d_desc;
   int lap_cap = cap;
   if (lapping) lap_cap = std::min(cap, e->out_cap);
-  e->timer.begin("k_orient_brief", s);
-  // one-wave or two-wave workgroups were measured behind four-wave ones here (0.72 - 0.73 vs 0.70 ms): the waves are independent anyway
-  hipLaunchKernelGGL(k_orient_brief<256>, xcd_grid(e->xcd_map, (e->kp_frame + 4 * kKpPerWave - 1) / (4 * kKpPerWave), batch), dim3(256), 0, s, e->d_geom, L, e->umax,
-                     e->d_pattern, d_imgs, stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame,
-                     e->d_kpkey, e->d_kpcount, (size_t)e->kp_frame, kp_dst, desc_dst, lapping ? e->out_cap : cap, d_n,
-                     lapping ? (int32_t*)nullptr : d_mono, e->d_err);
-  e->timer.end(s);
+  // Batches: level 0's keypoints (its quad-tree and its Gaussian are done long before the upper levels' quad-trees) are
+  // described on the auxiliary stream next to those quad-trees; the main stream takes the other levels and the frame totals.
+  const bool split_desc = !e->timer.enabled && batch >= 8 && L > 1 && e->geom[1].koff > 0;
+  const int slot_split = split_desc ? e->geom[1].koff : 0;
+  auto launch_desc = [&](hipStream_t st, int slot_begin, int slot_end, int write_total) {
+    if (slot_end <= slot_begin) return;
+    e->timer.begin("k_orient_brief", st);
+    // one-wave or two-wave workgroups were measured behind four-wave ones here (0.72 - 0.73 vs 0.70 ms): the waves are independent anyway
+    hipLaunchKernelGGL(k_orient_brief<256>, xcd_grid(e->xcd_map, (slot_end - slot_begin + 4 * kKpPerWave - 1) / (4 * kKpPerWave), batch), dim3(256), 0, st, e->d_geom, L, e->umax,
+                       e->d_pattern, d_imgs, stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame,
+                       e->d_kpkey, e->d_kpcount, (size_t)e->kp_frame, kp_dst, desc_dst, lapping ? e->out_cap : cap, d_n,
+                       lapping ? (int32_t*)nullptr : d_mono, e->d_err, slot_begin, slot_end, write_total);
+    e->timer.end(st);
+  };
+  if (split_desc) {
+    // (the auxiliary stream has level 0's quad-tree and every level's Gaussian behind it at this point)
+    launch_desc(e->aux_stream, 0, slot_split, 0);
+    RGBL_HIP(hipEventRecord(e->ev_desc0, e->aux_stream));
+  }
+  launch_desc(s, slot_split, e->kp_frame, 1);
+  if (split_desc) RGBL_HIP(hipStreamWaitEvent(s, e->ev_desc0, 0));
   if (lapping) {
     (void)lap_cap;
     if (cap < e->out_cap) {
@@ -645,7 +659,8 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
                         hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&e->ev_fast0, hipEventDisableTiming) != hipSuccess)) {
+                        hipEventCreateWithFlags(&e->ev_fast0, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&e->ev_desc0, hipEventDisableTiming) != hipSuccess)) {
     set_error("hipStreamCreate failed");
     rc = RGBL_ERR_HIP;
   }
@@ -673,6 +688,7 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   if (e->h_pinned) (void)hipHostFree(e->h_pinned);
   if (e->ev_start) (void)hipEventDestroy(e->ev_start);
   if (e->ev_fast0) (void)hipEventDestroy(e->ev_fast0);
+  if (e->ev_desc0) (void)hipEventDestroy(e->ev_desc0);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }

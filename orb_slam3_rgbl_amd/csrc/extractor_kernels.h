@@ -1691,22 +1691,25 @@ __global__ __launch_bounds__(BS) void k_orient_brief(const LevelGeom* __restrict
                                                       rgbl_keypoint* __restrict__ out_kp,
                                                       uint8_t* __restrict__ out_desc, int cap,
                                                       int32_t* __restrict__ out_n, int32_t* __restrict__ out_mono,
-                                                      int* __restrict__ err) {
+                                                      int* __restrict__ err, int slot_begin, int slot_end, int write_total) {
+  // The launch covers the keypoint slots slot_begin .. slot_end - 1 (slots are laid out level after level): level 0's
+  // keypoints can be described while the quad-trees of the upper levels still run; write_total: this launch sees the final
+  // counts of ALL levels and writes the frame's keypoint count.
   __shared__ unsigned long long s_patch_q[BS / 64][37 * 5];  // blurred 37x37 neighbourhood, 40-byte rows
   const int lane = lane_id(), wave = wave_id();
   const int bx = xcd_item(), f = xcd_frame();  // grid = xcd_grid(keypoint groups, B): an XCD's L2 keeps its frames' levels
   const int* cnts = kp_count + (size_t)f * n_levels;
 
   // ---- lane k < kKpPerWave: which (level, index) is slot s0 + k?  slots are laid out level after level, kcap entries each
-  const int s0 = (bx * (BS / 64) + wave) * kKpPerWave;
+  const int s0 = slot_begin + (bx * (BS / 64) + wave) * kKpPerWave;
   const int slot = s0 + (lane < kKpPerWave ? lane : 0);
   int l = 0;
   for (int j = 1; j < n_levels; ++j) l += (slot >= geom[j].koff) ? 1 : 0;  // koff ascends with the level
   const int idx = slot - geom[l].koff;
-  bool valid = lane < kKpPerWave && slot < (int)kp_frame && idx < cnts[l];
+  bool valid = lane < kKpPerWave && slot < slot_end && idx < cnts[l];
   int dense = idx;  // position in the level-major output order
   for (int j = 0; j < n_levels; ++j) dense += (j < l) ? cnts[j] : 0;
-  if (s0 == 0 && lane == 0) {
+  if (write_total && bx == 0 && wave == 0 && lane == 0) {
     int total = 0;
     for (int j = 0; j < n_levels; ++j) total += cnts[j];
     out_n[f] = total < cap ? total : cap;
