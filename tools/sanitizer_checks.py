@@ -12,11 +12,15 @@ if which == "extract":
     pc.check_extractor_partial_batches(lib, 360, 280, 400)
     pc.check_extractor(lib, 159, 152, 200, frames=(0,), nlevels=1, seq=3)   # 43-px cells: the 64-byte tile pitch
     pc.check_extractor(lib, 640, 480, 600, frames=(0,), seq=4)                # 51-px cells on the last level: four waves, 80-byte pitch
+    pc.check_extractor_batch(lib, 400, 300, 500, 8)                            # batches: one wave per cell
+    pc.check_extractor_low_contrast(lib)                                       # the second FAST pass
 elif which == "depth":
     for m in (F.UPS_INVERSE_DILATION, F.UPS_AVERAGE_FILTERING, F.UPS_NEAREST_NEIGHBOR_PIXEL):
         pc.check_depth(lib, m, w=620, h=188, n_az=900, n_kp=400)
     pc.check_depth_edge_cases(lib)
     pc.check_depth_partial_batches(lib)
+    pc.check_depth_sparse(lib)
+    pc.check_depth_sparse(lib, kernel=(F.KERNEL_RECT, 5, 7))
     pc.check_ingest_kitti_bin(lib)
 elif which == "match":
     pc.check_matcher_bf(lib, 300, 280)
