@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kResizeWG) void k_resize_linear(const uint8_t* __re
 // ------------------------------------------------------------------------------------------------
 // FAST-9/16 on one detection cell per workgroup.
 constexpr int kCellMax = 72;        // max scanned cell side handled (wCell/hCell <= 72: levels at least 35 px wide)
-constexpr int kCellSmall = 48;      // the common case (cells of 35..48 px): 11 KB of LDS instead of 24 KB per workgroup
+constexpr int kCellSmall = 48;      // the common case (cells of 35..48 px): 7.4 KB of LDS instead of 24 KB per workgroup
 
 // Bresenham ring of radius 3, OpenCV order (modules/features2d/src/fast_score.cpp makeOffsets)
 #define RGBL_RING(c, P, k)                                                                            \
@@ -408,8 +408,8 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
   uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile_w);
   __shared__ __attribute__((aligned(16))) uint32_t s_score_w[kScoreQuads * 4];
   uint8_t* s_score = reinterpret_cast<uint8_t*>(s_score_w);
-  // survivors of the pre-screen as lists of (t | polarity << 15), one list per wave: a wave ranks its survivors with a ballot
-  // and keeps its count in a scalar register - no LDS atomic and no round trip per trip of the loop.  Cells with more survivors
+  // survivors of the pre-screen as lists of (t | polarity << 15), one list per wave: a wave reserves the slots of a trip with one
+  // scan over its work-items' entry counts and keeps its count in a scalar register - no LDS atomic and no round trip per trip.  Cells with more survivors
   // than a list holds (noise, checkerboards) are scored pixel by pixel, both polarities.  The corners phase B finds go to the
   // front of the same list: a wave compacts its own entries in place (a corner's slot is never behind the entry it came from).
   constexpr int kWaves = BS / 64;
