@@ -1452,3 +1452,23 @@ def check_depth_sparse(lib, dev=None, w=310, h=94, kernel=(F.KERNEL_DIAMOND, 5, 
                                         L.ptr(dep), L.ptr(ur), None, None))
     assert np.array_equal(bits(dep), bits(od)) and np.array_equal(bits(ur), bits(our)), "prefetch, sparse gather"
     dm.close()
+
+
+def check_extractor_dense_corners(lib, w=114, h=80):
+    """Four out of five pixels are FAST corners at threshold 1 (a sum of two cosines): in the 41 x 48 px cells of this frame
+    more corners than k_fast_cells' per-wave lists hold - every pixel is scored, both arcs, and the NMS walks all pixels
+    instead of a corner list (the path no natural image takes)."""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    rng = np.random.default_rng(3)
+    for period, th in ((12, 1), (10, 2)):   # ~1 590 resp. ~1 470 corners in each of the two cells; +-2 of noise against score plateaus
+        img = (127 + 60 * (np.cos(2 * np.pi * xx / period) + np.cos(2 * np.pi * yy / period)) + rng.integers(-2, 3, (h, w))).clip(0, 255).astype(np.uint8)
+        ex = F.ORBextractor(500, 1.2, 1, th, th, w, h, lib=lib)
+        orc = O.Extractor(500, 1.2, 1, th, th)
+        kps, desc, mono = ex(img)
+        okps, odesc, omono = orc(img)
+        assert len(okps) > 50
+        assert_keypoints_equal(kps, okps, "dense corners, period %d" % period)
+        assert np.array_equal(desc, odesc)
+        c, oc = ex.level_candidates(0), orc.level_candidates(0)
+        assert len(c) == len(oc) and all(np.array_equal(c[f], oc[f]) for f in ("x", "y", "response"))
+        ex.close()

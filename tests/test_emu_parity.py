@@ -124,6 +124,7 @@ def test_extractor_fast_kernel_waves_per_cell(emu_lib, bs):
         pc.check_extractor(emu_lib, 1241, 376, 2000, frames=(0,), seq=5, stages=True)
         pc.check_extractor_batch(emu_lib, 400, 300, 500, 8)
         pc.check_extractor_low_contrast(emu_lib)
+        pc.check_extractor_dense_corners(emu_lib)
     finally:
         os.environ.pop("RGBL_FAST_BS", None)
 
