@@ -82,13 +82,13 @@ class ORBextractor:
             image = np.ascontiguousarray(image)
         h, w = image.shape
         cap = self.max_keypoints
-        kps = np.zeros(cap, KP_DTYPE)
-        desc = np.zeros((cap, 32), np.uint8)
+        kps = np.empty(cap, KP_DTYPE)          # fresh arrays per call: the library fills the first n entries, the caller gets views
+        desc = np.empty((cap, 32), np.uint8)
         n, mono = C.c_int(0), C.c_int(-1)
         L.check(self.lib, self.lib.rgbl_extract(self.h, L.ptr(image), w, h, image.strides[0], int(vLappingArea[0]),
                                                 int(vLappingArea[1]), L.ptr(kps), L.ptr(desc), cap, C.byref(n),
                                                 C.byref(mono)))
-        return kps[:n.value].copy(), desc[:n.value].copy(), mono.value
+        return kps[:n.value], desc[:n.value], mono.value
 
     def Begin(self, image, vLappingArea=(0, 0)):
         """Optional latency hook (rgbl_extract_begin): upload + extraction of `image` are queued and not waited for; the next
@@ -200,6 +200,16 @@ def projection_matrix(K3x4, Tr4x4, lib=None):
     return out
 
 
+def _keys_xy(a):
+    """[k, 2] float32, contiguous: the coordinates of KP_DTYPE records or of a [k, 2] array."""
+    if a.dtype == KP_DTYPE:
+        out = np.empty((len(a), 2), np.float32)
+        out[:, 0] = a["x"]
+        out[:, 1] = a["y"]
+        return out
+    return np.ascontiguousarray(a, np.float32).reshape(-1, 2)
+
+
 class DepthModule:
     """Mirror of ORB_SLAM3::DepthModule. The YAML keys of Examples/RGB-L/*.yaml arrive as keyword arguments."""
 
@@ -248,19 +258,15 @@ class DepthModule:
 
     def CalculateDepthFromPcd(self, mvKeys, mvKeysUn, PointCloud, imwidth, imheight, want_maps=True):
         """mvKeys / mvKeysUn: KP_DTYPE arrays (or [k,2] float arrays); PointCloud: 4 x N float32."""
-        def xy(a):
-            if a.dtype == KP_DTYPE:
-                return np.stack([a["x"], a["y"]], 1).astype(np.float32)
-            return np.ascontiguousarray(a, np.float32).reshape(-1, 2)
-        kp = np.ascontiguousarray(xy(mvKeys))
-        un = np.ascontiguousarray(xy(mvKeysUn)[:, 0])
+        kp = _keys_xy(mvKeys)
+        un = np.ascontiguousarray(_keys_xy(mvKeysUn)[:, 0])
         cloud = np.asarray(PointCloud, np.float32)
         if cloud.ndim != 2 or cloud.shape[0] != 4:
             raise ValueError("PointCloud must be 4 x N (rows x, y, z, 1)")
         if cloud.strides[1] != 4:
             cloud = np.ascontiguousarray(cloud)
         n, k = cloud.shape[1], kp.shape[0]
-        self.mvDepth, self.mvuRight = np.zeros(k, np.float32), np.zeros(k, np.float32)
+        self.mvDepth, self.mvuRight = np.empty(k, np.float32), np.empty(k, np.float32)   # written for every keypoint
         self.RawDepthMap = np.zeros((imheight, imwidth), np.float32) if want_maps else None
         proc_ok = want_maps and self.cfg.method != UPS_NEAREST_NEIGHBOR_PIXEL
         self.ProcessedDepthMap = np.zeros((imheight, imwidth), np.float32) if proc_ok else None
@@ -271,15 +277,11 @@ class DepthModule:
     def CalculateDepthFromKittiBin(self, mvKeys, mvKeysUn, xyzi, imwidth, imheight, want_maps=True):
         """The scan as read from a KITTI velodyne .bin file: N x 4 float32 (x, y, z, reflectance) - what
         LoadPointcloudBinaryMat (Examples/RGB-L/rgbl_kitti.cc:151-185) turns into the 4 x N matrix, without the repack."""
-        def xy(a):
-            if a.dtype == KP_DTYPE:
-                return np.stack([a["x"], a["y"]], 1).astype(np.float32)
-            return np.ascontiguousarray(a, np.float32).reshape(-1, 2)
-        kp = np.ascontiguousarray(xy(mvKeys))
-        un = np.ascontiguousarray(xy(mvKeysUn)[:, 0])
+        kp = _keys_xy(mvKeys)
+        un = np.ascontiguousarray(_keys_xy(mvKeysUn)[:, 0])
         pts = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
         n, k = pts.shape[0], kp.shape[0]
-        self.mvDepth, self.mvuRight = np.zeros(k, np.float32), np.zeros(k, np.float32)
+        self.mvDepth, self.mvuRight = np.empty(k, np.float32), np.empty(k, np.float32)
         self.RawDepthMap = np.zeros((imheight, imwidth), np.float32) if want_maps else None
         proc_ok = want_maps and self.cfg.method != UPS_NEAREST_NEIGHBOR_PIXEL
         self.ProcessedDepthMap = np.zeros((imheight, imwidth), np.float32) if proc_ok else None
