@@ -193,6 +193,12 @@ int rgbl_event_create(void** out_event);
 void rgbl_event_destroy(void* event);
 int rgbl_event_record(void* event, void* stream);
 int rgbl_event_wait(void* stream, void* event);
+/* A stream of the library's device with the lowest (priority < 0), the default (0) or the highest (> 0) scheduling priority,
+ * to be handed to the rgbl_*_set_stream calls.  Work that is not on a batch pipeline's critical chain (the Hamming scan of
+ * step k next to the extraction of step k + 1) belongs on a low-priority stream: its workgroups fill the slots the chain
+ * leaves instead of competing for them (bench.py: +4 %). */
+int rgbl_stream_create(void** out_stream, int priority);
+void rgbl_stream_destroy(void* stream);
 int rgbl_extractor_profile(rgbl_extractor* h, int enable);
 /* Returns the number of distinct kernels; fills up to cap entries. names[i] points to static storage. */
 int rgbl_extractor_profile_read(rgbl_extractor* h, const char** names, double* total_ms, long* launches,

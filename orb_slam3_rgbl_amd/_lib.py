@@ -158,6 +158,8 @@ SYMBOLS = {
     "rgbl_event_destroy": (None, [_V]),
     "rgbl_event_record": (_I, [_V, _V]),
     "rgbl_event_wait": (_I, [_V, _V]),
+    "rgbl_stream_create": (_I, [C.POINTER(_V), _I]),
+    "rgbl_stream_destroy": (None, [_V]),
     "rgbl_depth_set_stream": (_I, [_V, _V]),
     "rgbl_depth_set_sparse": (_I, [_V, _I]),
     "rgbl_depth_profile": (_I, [_V, _I]),

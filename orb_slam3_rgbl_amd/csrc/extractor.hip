@@ -1169,6 +1169,23 @@ int rgbl_event_create(void** ev) {
   return RGBL_OK;
 }
 void rgbl_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int rgbl_stream_create(void** out, int priority) {
+  if (!out) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  hipStream_t st = nullptr;
+#ifdef RGBL_EMU
+  (void)priority;
+  RGBL_HIP(hipStreamCreate(&st));
+#else
+  int least = 0, greatest = 0;
+  RGBL_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  RGBL_HIP(hipStreamCreateWithPriority(&st, hipStreamDefault, priority < 0 ? least : priority > 0 ? greatest : 0));   // 0 = the default priority
+#endif
+  *out = (void*)st;
+  return RGBL_OK;
+}
+void rgbl_stream_destroy(void* st) {
+  if (st) { (void)hipStreamSynchronize((hipStream_t)st); (void)hipStreamDestroy((hipStream_t)st); }
+}
 int rgbl_event_record(void* ev, void* stream) {
   if (!ev) { set_error("null event"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));

@@ -66,6 +66,7 @@ class _Lane:
     """One set of handles (extractor, depth module, matcher) with their streams: the work of one step."""
 
     def __init__(self, lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial):
+        self.own_stream = None
         self.ex = F.ORBextractor(nfeatures, scale, levels, ini_th, min_th, w, h, max_batch=batch, device=index, lib=lib)
         self.dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=self.ex.max_keypoints, max_batch=batch, device=index, lib=lib)
         self.mt = F.ORBmatcher(0.6, False, device=index, lib=lib)
@@ -73,10 +74,18 @@ class _Lane:
         if serial:
             L.check(lib, lib.rgbl_depth_set_stream(self.dm.h, one))
             L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
-        elif os.environ.get("RGBL_MATCHER_STREAM", "shared") != "own":
-            # the matcher queued on the extractor's stream (round 1: the VALU popcount scan was issue-bound like FAST and only
-            # competed with it on a stream of its own); RGBL_MATCHER_STREAM=own lets the matrix-core scan run next to it
-            L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
+        else:
+            # The Hamming scan of step k is not on the chain resize -> FAST -> quad-tree -> descriptors that paces the steps: on
+            # a LOW-PRIORITY stream of its own it runs next to the extraction of step k + 1 and only takes what that leaves
+            # (142 - 144 k frames/s).  On the extractor's stream (RGBL_MATCHER_STREAM=shared, the rounds 1 - 3 default) it is a
+            # link of the chain (136 - 138 k); on a stream of the default priority it competes with FAST for issue slots (130 - 132 k).
+            mode = os.environ.get("RGBL_MATCHER_STREAM", "low")
+            if mode == "shared":
+                L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
+            elif mode == "low":
+                self.own_stream = C.c_void_p()
+                L.check(lib, lib.rgbl_stream_create(C.byref(self.own_stream), -1))
+                L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, self.own_stream))
         self.streams(lib)
 
     def streams(self, lib):
@@ -291,6 +300,9 @@ class FrontEndPipeline:
     def close(self):
         for ln in getattr(self, "all_lanes", self.lanes):
             ln.ex.close(); ln.dm.close(); ln.mt.close()
+            if ln.own_stream is not None:
+                self.lib.rgbl_stream_destroy(ln.own_stream)
+                ln.own_stream = None
 
 
 class _Null:
