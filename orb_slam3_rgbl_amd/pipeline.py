@@ -65,7 +65,7 @@ class OutSet:
 class _Lane:
     """One set of handles (extractor, depth module, matcher) with their streams: the work of one step."""
 
-    def __init__(self, lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial):
+    def __init__(self, lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial, gather="none"):
         self.own_stream = None
         self.ex = F.ORBextractor(nfeatures, scale, levels, ini_th, min_th, w, h, max_batch=batch, device=index, lib=lib)
         self.dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=self.ex.max_keypoints, max_batch=batch, device=index, lib=lib)
@@ -79,7 +79,10 @@ class _Lane:
             # a LOW-PRIORITY stream of its own it runs next to the extraction of step k + 1 and only takes what that leaves
             # (142 - 144 k frames/s).  On the extractor's stream (RGBL_MATCHER_STREAM=shared, the rounds 1 - 3 default) it is a
             # link of the chain (136 - 138 k); on a stream of the default priority it competes with FAST for issue slots (130 - 132 k).
-            mode = os.environ.get("RGBL_MATCHER_STREAM", "low")
+            # With the gather on there is a communication stream as well: five streams on the runtime's four hardware queues
+            # cost more than the priority gains (123 k against 134 k at one rank with gather='step'), so the scan stays on the
+            # extractor's stream there.
+            mode = os.environ.get("RGBL_MATCHER_STREAM", "low" if gather == "none" else "shared")
             if mode == "shared":
                 L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
             elif mode == "low":
@@ -105,7 +108,7 @@ class FrontEndPipeline:
         # lanes = 2: two sets of handles used alternately, step k on lane k mod 2 with the output set k mod 2 - two steps in
         # flight: the tail of step k (quad-trees of the upper levels, descriptors, matching: dependent chains and gathers that
         # leave most vector-issue slots idle) runs next to the head of step k + 1 (pyramid, FAST, Gaussian: issue-bound)
-        self.lanes = [_Lane(lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial)
+        self.lanes = [_Lane(lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial, gather)
                       for _ in range(1 if serial else max(1, min(lanes, 2)))]
         self.ex, self.dm, self.mt = self.lanes[0].ex, self.lanes[0].dm, self.lanes[0].mt
         # sparse_depth: no dense ProcessedDepthMap (rgbl_depth_set_sparse) - the step never hands it out anyway
