@@ -79,10 +79,11 @@ class _Lane:
             # a LOW-PRIORITY stream of its own it runs next to the extraction of step k + 1 and only takes what that leaves
             # (142 - 144 k frames/s).  On the extractor's stream (RGBL_MATCHER_STREAM=shared, the rounds 1 - 3 default) it is a
             # link of the chain (136 - 138 k); on a stream of the default priority it competes with FAST for issue slots (130 - 132 k).
-            # With the gather on there is a communication stream as well: five streams on the runtime's four hardware queues
-            # cost more than the priority gains (123 k against 134 k at one rank with gather='step'), so the scan stays on the
-            # extractor's stream there.
-            mode = os.environ.get("RGBL_MATCHER_STREAM", "low" if gather == "none" else "shared")
+            # With the gather on, a communication stream of its own would be the FIFTH stream on the runtime's four hardware
+            # queues, which costs more than the priority gains (123 k against 134 k at one rank with gather='step'): the
+            # pipeline then uses this low-priority stream for the communication as well (one lane), or leaves the scan on the
+            # extractor's stream (two lanes).
+            mode = os.environ.get("RGBL_MATCHER_STREAM", "low" if gather != "two-lanes" else "shared")
             if mode == "shared":
                 L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
             elif mode == "low":
@@ -108,8 +109,10 @@ class FrontEndPipeline:
         # lanes = 2: two sets of handles used alternately, step k on lane k mod 2 with the output set k mod 2 - two steps in
         # flight: the tail of step k (quad-trees of the upper levels, descriptors, matching: dependent chains and gathers that
         # leave most vector-issue slots idle) runs next to the head of step k + 1 (pyramid, FAST, Gaussian: issue-bound)
-        self.lanes = [_Lane(lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial, gather)
-                      for _ in range(1 if serial else max(1, min(lanes, 2)))]
+        n_lanes = 1 if serial else max(1, min(lanes, 2))
+        self.lanes = [_Lane(lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial,
+                            "two-lanes" if (gather != "none" and n_lanes > 1) else gather)
+                      for _ in range(n_lanes)]
         self.ex, self.dm, self.mt = self.lanes[0].ex, self.lanes[0].dm, self.lanes[0].mt
         # sparse_depth: no dense ProcessedDepthMap (rgbl_depth_set_sparse) - the step never hands it out anyway
         for ln in self.lanes:
@@ -125,7 +128,13 @@ class FrontEndPipeline:
         self.step_no = 0
         # ---- gather state
         self.cuda = dev.type == "cuda"
-        self.comm_stream = torch.cuda.Stream(dev) if (self.gather != "none" and self.cuda) else None
+        self.comm_stream = None
+        self.comm_wraps_low = False
+        if self.gather != "none" and self.cuda:
+            low = self.lanes[0].own_stream if len(self.lanes) == 1 else None
+            # pack, counts and the exchange of step k - 1 behind the Hamming scan of step k on ONE low-priority stream (see _Lane)
+            self.comm_stream = torch.cuda.ExternalStream(low.value, device=dev) if low is not None else torch.cuda.Stream(dev)
+            self.comm_wraps_low = low is not None
         self.s_comm = C.c_void_p(self.comm_stream.cuda_stream) if self.comm_stream is not None else C.c_void_p(None)
         self.pending = None         # the step whose records are packed but not exchanged yet
         self.received = []          # root: per exchanged step, per rank (counts [B] int32 on the host, records uint8 tensor)
@@ -304,7 +313,10 @@ class FrontEndPipeline:
         for ln in getattr(self, "all_lanes", self.lanes):
             ln.ex.close(); ln.dm.close(); ln.mt.close()
             if ln.own_stream is not None:
-                self.lib.rgbl_stream_destroy(ln.own_stream)
+                # a stream PyTorch has seen (the communication stream wraps it) stays alive: the caching allocator keeps
+                # blocks that were used on it and touches the stream again when they are released
+                if not self.comm_wraps_low:
+                    self.lib.rgbl_stream_destroy(ln.own_stream)
                 ln.own_stream = None
 
 
