@@ -17,6 +17,9 @@ queued, only for the one before, so the GPU always has a full step of work ahead
 compacted records of every step in HBM and exchanges them once at the end (no host synchronisation inside the run);
 `gather="none"` does no exchange.  With one rank the same choreography runs (pack on the communication stream, counts through
 the page-locked block, the root's device copy, the events) without a peer - and through RCCL when a process group exists.
+The communication stream is the low-priority stream of the Hamming scan (`rgbl_stream_create`, one lane): what is off the
+chain resize -> FAST -> quad-tree -> descriptors that paces the steps only takes the slots the chain leaves, and a fifth stream
+would not find a hardware queue of its own.  The exchange of step k - 1 therefore starts behind the scan of step k.
 PyTorch is plumbing here: device memory, streams and torch.distributed.
 """
 import ctypes as C
@@ -214,8 +217,8 @@ class FrontEndPipeline:
         if self.gather != "none":
             prev = self.pending
             if self.gather == "step" and prev is not None:
-                # step k - 1's records travel while step k (queued above) computes.  Posted BEFORE the pack of step k: the
-                # communication stream is in order, and behind that pack the exchange would wait for the step just queued.
+                # step k - 1's records travel while step k (queued above) and step k + 1 compute.  Posted BEFORE the pack of step k:
+                # the communication stream is in order, and behind that pack the exchange would wait for the step just queued.
                 self._exchange(prev)
             self._pack(o)
         self.step_no += 1
