@@ -2,6 +2,7 @@
 under the SIMT emulator of tests/emu (small sizes).  This checks kernel logic, not the MI355X."""
 import os
 
+import numpy as np
 import pytest
 
 import parity_checks as pc
@@ -323,3 +324,21 @@ def test_overlapped_frame_hooks(emu_lib):
 def test_extractor_second_fast_pass(emu_lib):
     assert pc.check_extractor_low_contrast(emu_lib, 400, 300, 20, 7, 0.15, nfeatures=600, nlevels=4) > 100
     pc.check_extractor_low_contrast(emu_lib, 300, 220, 30, 10, 0.08, nfeatures=300, nlevels=3)   # hardly any corner at either threshold
+
+
+def test_prioritised_streams_carry_work(emu_lib):
+    # rgbl_stream_create: a handle works on a lowest- / highest-priority stream exactly as on its own
+    import ctypes as C
+    from orb_slam3_rgbl_amd import _lib as L
+    for prio in (-1, 0, 1):
+        st = C.c_void_p()
+        L.check(emu_lib, emu_lib.rgbl_stream_create(C.byref(st), prio))
+        m = F.ORBmatcher(0.6, False, lib=emu_lib)
+        L.check(emu_lib, emu_lib.rgbl_matcher_set_stream(m.h, st))
+        rng = np.random.default_rng(prio + 5)
+        a, b = rng.integers(0, 256, (300, 32), dtype=np.uint8), rng.integers(0, 256, (280, 32), dtype=np.uint8)
+        bi, bd, sd = m.BruteForce(a, b)
+        d = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+        assert np.array_equal(bd, d.min(1)) and np.array_equal(bi, np.where(d == d.min(1)[:, None], np.arange(280)[None, :], 1 << 30).min(1))
+        m.close()
+        emu_lib.rgbl_stream_destroy(st)

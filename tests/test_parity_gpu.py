@@ -377,3 +377,21 @@ def test_extractor_second_fast_pass(gpu_lib):
     assert pc.check_extractor_low_contrast(gpu_lib, 1241, 376, 20, 7, 0.15, nfeatures=2000, nlevels=8) > 1000
     pc.check_extractor_low_contrast(gpu_lib, 793, 286, 30, 10, 0.08)
     pc.check_extractor_low_contrast(gpu_lib, 1145, 290, 30, 3, 0.15)
+
+
+def test_prioritised_streams_carry_work(gpu_lib):
+    # rgbl_stream_create: a handle works on a lowest- / highest-priority stream exactly as on its own
+    import ctypes as C
+    from orb_slam3_rgbl_amd import _lib as L
+    for prio in (-1, 0, 1):
+        st = C.c_void_p()
+        L.check(gpu_lib, gpu_lib.rgbl_stream_create(C.byref(st), prio))
+        m = F.ORBmatcher(0.6, False, lib=gpu_lib)
+        L.check(gpu_lib, gpu_lib.rgbl_matcher_set_stream(m.h, st))
+        rng = np.random.default_rng(prio + 5)
+        a, b = rng.integers(0, 256, (300, 32), dtype=np.uint8), rng.integers(0, 256, (280, 32), dtype=np.uint8)
+        bi, bd, sd = m.BruteForce(a, b)
+        d = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+        assert np.array_equal(bd, d.min(1)) and np.array_equal(bi, np.where(d == d.min(1)[:, None], np.arange(280)[None, :], 1 << 30).min(1))
+        m.close()
+        gpu_lib.rgbl_stream_destroy(st)
