@@ -51,7 +51,8 @@ struct rgbl_extractor {
   int L = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
   hipStream_t aux_stream = nullptr;  // the Gaussian working images only depend on the pyramid: they overlap FAST + quad-tree
-  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_fast0 = nullptr, ev_desc0 = nullptr;
+  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_fast0 = nullptr, ev_desc0 = nullptr, ev_r = nullptr, ev_fb = nullptr;
+  int split_pyr = 0;  // RGBL_SPLIT_PYR=k (opt-in, batches): the pyramid levels k .. L - 1 and their FAST cells leave the main chain
   KernelTimer timer;
   // hipGraph of the host-pointer path (all device pointers of that path are the handle's own buffers, so one captured
   // launch sequence can be replayed): key = (batch, row stride, lapping area, stream)
@@ -373,6 +374,7 @@ int upload_tables(rgbl_extractor* e) {
   RGBL_HIP(hipMemcpy(e->d_rootx, rootx.data(), rootx.size(), hipMemcpyHostToDevice));
   RGBL_HIP(hipMemcpy(e->d_pattern, kBriefPattern, 1024, hipMemcpyHostToDevice));
   if (const char* v = getenv("RGBL_XCD_MAP")) e->xcd_map = v[0] != '0';
+  if (const char* v = getenv("RGBL_SPLIT_PYR")) e->split_pyr = atoi(v);
   if (const char* v = getenv("RGBL_FAST_BS")) e->fast_waves = atoi(v) == 64 ? 1 : atoi(v) == 128 ? 2 : 0;
   return RGBL_OK;
 }
@@ -496,6 +498,46 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
     const bool overlap = !e->timer.enabled;
     hipStream_t bs = overlap ? e->aux_stream : s;
     const int cells0 = L > 1 ? e->geom[1].cell_off : e->cells_frame, tiles0 = e->blur_tiles.tile_off[1];
+    // 1. pyramid: level l from level l-1 (ORBextractor.cc:1170-1195)
+    auto launch_resize = [&](hipStream_t st, int l) {
+      const LevelGeom& g = e->geom[l];
+      const LevelGeom& p = e->geom[l - 1];
+      const uint8_t* src = (l == 1) ? d_imgs : e->d_pyr + p.img_off;
+      const int spitch = (l == 1) ? stride : p.pitch;
+      const size_t sframe = (l == 1) ? frame_stride : e->pyr_frame;
+      e->timer.begin("k_resize_linear", st);
+      const int rtx = (g.w + 4 * kResizeLanes - 1) / (4 * kResizeLanes), rty = (g.h + 4 * kResizeRows - 1) / (4 * kResizeRows);
+      hipLaunchKernelGGL(k_resize_linear, xcd_grid(e->xcd_map, rtx * rty, batch), dim3(kResizeWG), 0, st, src, spitch, sframe, p.w, p.h, e->d_pyr + g.img_off, g.pitch, e->pyr_frame, g.w, g.h,
+                       e->d_xtab + g.xtab_off, e->d_xgroups + g.xtab_off / 4, e->d_xsxa + g.xtab_off / 4, e->d_ytab + g.ytab_off, rtx);
+      e->timer.end(st);
+    };
+    const int sp = (overlap && batch >= 8 && e->split_pyr >= 2 && e->split_pyr < L) ? e->split_pyr : 0;
+    if (sp) {
+      // Opt-in (RGBL_SPLIT_PYR=k, batches): the small levels k .. L - 1 - their resizes are the tail of a chain of dependent
+      // launches, their FAST cells a sixth of the upper levels' - are produced on the auxiliary stream behind level 0's FAST
+      // cells, so that the main stream's FAST launch (levels 1 .. k - 1) starts after k - 1 resizes instead of L - 1.
+      // Measured at the end of round 3: k = 4 144.7 k, k = 3 144.3 k, k = 5 143.0 k against 142.9 - 143.3 k frames/s - one
+      // per cent, left off by default.
+      RGBL_HIP(hipEventRecord(e->ev_start, s));
+      RGBL_HIP(hipStreamWaitEvent(bs, e->ev_start, 0));
+      launch_fast(bs, 0, cells0);
+      for (int l = 1; l < sp; ++l) launch_resize(s, l);
+      RGBL_HIP(hipEventRecord(e->ev_r, s));
+      RGBL_HIP(hipStreamWaitEvent(bs, e->ev_r, 0));
+      for (int l = sp; l < L; ++l) launch_resize(bs, l);
+      launch_fast(bs, e->geom[sp].cell_off, e->cells_frame);
+      RGBL_HIP(hipEventRecord(e->ev_fb, bs));
+      launch_gauss(bs, 0, tiles0);
+      launch_octree(bs, 0, 1);
+      RGBL_HIP(hipEventRecord(e->ev_fast0, bs));
+      launch_gauss(bs, tiles0, e->blur_tiles.tile_off[L]);
+      RGBL_HIP(hipEventRecord(e->ev_blur, bs));
+      launch_fast(s, cells0, e->geom[sp].cell_off);
+      RGBL_HIP(hipStreamWaitEvent(s, e->ev_fb, 0));
+      launch_octree(s, 1, L);
+      RGBL_HIP(hipStreamWaitEvent(s, e->ev_fast0, 0));
+      RGBL_HIP(hipStreamWaitEvent(s, e->ev_blur, 0));
+    } else {
     if (overlap) {
       RGBL_HIP(hipEventRecord(e->ev_start, s));
       RGBL_HIP(hipStreamWaitEvent(bs, e->ev_start, 0));
@@ -507,19 +549,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       launch_octree(bs, 0, 1);
       RGBL_HIP(hipEventRecord(e->ev_fast0, bs));
     }
-    // 1. pyramid: level l from level l-1 (ORBextractor.cc:1170-1195)
-    for (int l = 1; l < L; ++l) {
-      const LevelGeom& g = e->geom[l];
-      const LevelGeom& p = e->geom[l - 1];
-      const uint8_t* src = (l == 1) ? d_imgs : e->d_pyr + p.img_off;
-      const int spitch = (l == 1) ? stride : p.pitch;
-      const size_t sframe = (l == 1) ? frame_stride : e->pyr_frame;
-      e->timer.begin("k_resize_linear", s);
-      const int rtx = (g.w + 4 * kResizeLanes - 1) / (4 * kResizeLanes), rty = (g.h + 4 * kResizeRows - 1) / (4 * kResizeRows);
-      hipLaunchKernelGGL(k_resize_linear, xcd_grid(e->xcd_map, rtx * rty, batch), dim3(kResizeWG), 0, s, src, spitch, sframe, p.w, p.h, e->d_pyr + g.img_off, g.pitch, e->pyr_frame, g.w, g.h,
-                       e->d_xtab + g.xtab_off, e->d_xgroups + g.xtab_off / 4, e->d_xsxa + g.xtab_off / 4, e->d_ytab + g.ytab_off, rtx);
-      e->timer.end(s);
-    }
+    for (int l = 1; l < L; ++l) launch_resize(s, l);
     // 4. Gaussian working images (ORBextractor.cc:1132-1133) of the upper levels, on the auxiliary stream next to 2. and 3.
     if (overlap) {
       RGBL_HIP(hipEventRecord(e->ev_pyr, s));
@@ -544,6 +574,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
     }
     // 5. orientation + descriptors + packing (ORBextractor.cc:894-895, 1136-1165); needs the blurred levels
     if (overlap) RGBL_HIP(hipStreamWaitEvent(s, e->ev_blur, 0));
+    }
   }
   const bool lapping = lap1 >= 19 && lap1 >= lap0;  // keypoint x is always >= 19: nothing can fall into [lap0, lap1] otherwise
   rgbl_keypoint* kp_dst = lapping ? e->d_tmp_kp : d_kp;
@@ -660,7 +691,9 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
                         hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_fast0, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&e->ev_desc0, hipEventDisableTiming) != hipSuccess)) {
+                        hipEventCreateWithFlags(&e->ev_desc0, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&e->ev_r, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&e->ev_fb, hipEventDisableTiming) != hipSuccess)) {
     set_error("hipStreamCreate failed");
     rc = RGBL_ERR_HIP;
   }
@@ -689,6 +722,8 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   if (e->ev_start) (void)hipEventDestroy(e->ev_start);
   if (e->ev_fast0) (void)hipEventDestroy(e->ev_fast0);
   if (e->ev_desc0) (void)hipEventDestroy(e->ev_desc0);
+  if (e->ev_r) (void)hipEventDestroy(e->ev_r);
+  if (e->ev_fb) (void)hipEventDestroy(e->ev_fb);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
