@@ -1472,3 +1472,26 @@ def check_extractor_dense_corners(lib, w=114, h=80):
         c, oc = ex.level_candidates(0), orc.level_candidates(0)
         assert len(c) == len(oc) and all(np.array_equal(c[f], oc[f]) for f in ("x", "y", "response"))
         ex.close()
+
+
+def check_extractor_threshold_extremes(lib, w=200, h=150):
+    """FAST thresholds at the ends of the range on saturated images: the pre-screen's bounds v - t / v + t leave 0 .. 255 (they
+    are saturated 16-bit halves in k_fast_cells) and scores reach 254."""
+    rng = np.random.default_rng(11)
+    blocks = (rng.integers(0, 2, (h // 5 + 1, w // 5 + 1)) * 255).astype(np.uint8).repeat(5, 0).repeat(5, 1)[:h, :w]
+    salt = np.where(rng.random((h, w)) > 0.93, 255, 0).astype(np.uint8)
+    ramp = (np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8)
+    ramp[rng.random((h, w)) > 0.97] = 255
+    ramp[rng.random((h, w)) > 0.97] = 0
+    for ini, mn in ((255, 255), (255, 1), (254, 200), (128, 127), (1, 1)):
+        ex = F.ORBextractor(400, 1.2, 3, ini, mn, w, h, lib=lib)
+        orc = O.Extractor(400, 1.2, 3, ini, mn)
+        for name, img in (("blocks", blocks), ("salt", salt), ("ramp", ramp)):
+            kps, desc, mono = ex(img)
+            okps, odesc, omono = orc(img)
+            assert_keypoints_equal(kps, okps, "%s at FAST %d / %d" % (name, ini, mn))
+            assert np.array_equal(desc, odesc)
+            for l in range(3):
+                c, oc = ex.level_candidates(l), orc.level_candidates(l)
+                assert len(c) == len(oc) and all(np.array_equal(c[f], oc[f]) for f in ("x", "y", "response")), (name, ini, mn, l)
+        ex.close()

@@ -126,6 +126,7 @@ def test_extractor_fast_kernel_waves_per_cell(emu_lib, bs):
         pc.check_extractor_batch(emu_lib, 400, 300, 500, 8)
         pc.check_extractor_low_contrast(emu_lib)
         pc.check_extractor_dense_corners(emu_lib)
+        pc.check_extractor_threshold_extremes(emu_lib)
     finally:
         os.environ.pop("RGBL_FAST_BS", None)
 

@@ -66,6 +66,7 @@ def test_extractor_fast_kernel_waves_per_cell(gpu_lib, bs):
         pc.check_extractor_batch(gpu_lib, 400, 300, 500, 8)
         pc.check_extractor_low_contrast(gpu_lib)
         pc.check_extractor_dense_corners(gpu_lib)
+        pc.check_extractor_threshold_extremes(gpu_lib)
     finally:
         os.environ.pop("RGBL_FAST_BS", None)
 
