@@ -36,5 +36,6 @@ elif which == "misc":
     pc.check_stereo_matches(lib, w=640, h=300, nfeatures=1200)
     pc.check_ingest_color(lib, 402, 300)
     pc.check_extractor_edge_cases(lib)
+    pc.check_extractor_threshold_extremes(lib)
     pc.check_extractor_dense_corners(lib)                                      # corner lists overflow: every pixel scored, NMS over all pixels
 print("asan run", which, "done")
