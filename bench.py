@@ -8,10 +8,12 @@ of every frame against its successor.  Workload = BASELINE.json configs[1] (KITT
 1241x376, 8 levels, FAST 12/7, InverseDilation Diamond-5); `--workload 4k` selects configs[4].
 
 Launch contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver starts it under
-torch.distributed.run with one rank per GPU (backend nccl == RCCL).  Frames / sequences shard over the
-ranks with no data-path collective; the only communication is the gather of the variable-length
-keypoint/descriptor/depth records to rank 0 at the end of every step (weak scaling).
-Rank 0 prints ONE JSON line.
+torch.distributed.run with one rank per GPU (backend nccl == RCCL) - and a bare `python bench.py --gpus N` (no WORLD_SIZE in
+the environment) re-executes itself that way, or exits non-zero when the node has fewer than N GPUs: `n_gpus` of the JSON
+line is always what ran (`launch_plan`).  Frames / sequences shard over the ranks with no data-path collective; the only
+communication is the gather of the variable-length keypoint/descriptor/depth records to rank 0 (weak scaling), by default
+through the library's own C-ABI entry points over RCCL (`--transport abi`: rgbl_gather_*, csrc/gather.hip), or through
+torch.distributed (`--transport torch`).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -40,6 +42,44 @@ def level_sizes(w, h):
         sc = np.float32(sc * np.float32(SCALE))
         inv.append(np.float32(1.0) / sc)
     return [(int(np.rint(np.float32(w) * s)), int(np.rint(np.float32(h) * s))) for s in inv]
+
+
+def launch_plan(gpus, environ, device_count, argv, port=None):
+    """What a `bench.py --gpus N` invocation has to do, as data (unit-tested in tests/test_bench_launch.py):
+      ("run", world)        - go on in this process as one rank of `world`;
+      ("exec", [argv ...])  - N > 1 asked for on a bare command line: re-execute under torch.distributed.run, one rank per GPU;
+      ("error", message)    - the request cannot be honoured (fewer GPUs than ranks, or a launcher that started another
+                              number of ranks than --gpus says): exit non-zero rather than print a line whose n_gpus is not N."""
+    world_env = environ.get("WORLD_SIZE")
+    if world_env is not None:
+        world = int(world_env)
+        if gpus != world:
+            return ("error", "--gpus %d but the launcher started WORLD_SIZE=%d ranks: n_gpus must be what runs" % (gpus, world))
+        if device_count is not None and int(environ.get("LOCAL_RANK", "0")) >= device_count:
+            return ("error", "LOCAL_RANK %s has no GPU (%d visible)" % (environ.get("LOCAL_RANK"), device_count))
+        return ("run", world)
+    if gpus <= 1:
+        return ("run", 1)
+    if device_count is not None and device_count < gpus:
+        return ("error", "--gpus %d asked for, %d HIP device(s) visible on this node: not launching (one rank per GPU, no oversubscription)" % (gpus, device_count))
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return ("exec", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+                     "--master-addr", "127.0.0.1", "--master-port", str(port)] + list(argv))
+
+
+def step_bytes_8d(w, h, n_points, k_per_frame):
+    """ALGORITHMIC bytes of one frame through the whole step, B_ext + B_dep + B_m (zero fill and scatter of
+    the depth maps included, as the contract counts them)."""
+    px = [a * b for a, b in level_sizes(w, h)]
+    sp = sum(px)
+    b_ext = 5 * sp - px[0] - px[-1] + 60 * k_per_frame
+    b_dep = 20 * n_points + 12 * w * h + 12 * k_per_frame
+    b_m = 32 * 2 * k_per_frame + 8 * k_per_frame
+    return b_ext + b_dep + b_m
 
 
 def algorithmic_bytes(kernel, w, h, n_points, k_per_frame):
@@ -135,7 +175,12 @@ def roofline_of(kernels, prof_steps, workload, w, h, n_points, k_mean, B, step_s
             step_bytes += kb * B
     r["per_kernel_hbm"] = per_kernel
     if step_s:
-        r["step_algorithmic_GB/s"] = round(step_bytes / step_s / 1e9, 1)
+        # the contract's figure: SURVEY 8(d) B_ext + B_dep + B_m per frame (the depth maps' zero fill and scatter included)
+        r["step_algorithmic_GB/s"] = round(step_bytes_8d(w, h, n_points, k_mean) * B / step_s / 1e9, 1)
+        r["step_algorithmic_bytes_per_frame"] = step_bytes_8d(w, h, n_points, k_mean)
+        # the same over what the step's kernels actually have to move in this implementation (no zero fill: generation-tagged
+        # index maps; no raw map): the sum of the per-kernel figures above
+        r["step_kernel_sum_GB/s"] = round(step_bytes / step_s / 1e9, 1)
     return r
 
 
@@ -284,6 +329,62 @@ def time_steps(step, sync, warmup, steps):
         step()
     sync()
     return (time.perf_counter() - t0) / steps
+
+
+def gather_legs_one_rank(lib, torch, dist, dev, d_imgs, d_cloud, w, h, nfeatures, proj, n_points, B, steps):
+    """the gather inside timed steps on the hardware with ONE rank - every leg a fresh pipeline on the
+    headline's resident inputs, same number of steps, one after the other in this process:
+      none            no gather (the headline's configuration at N = 1)
+      abi_step/final  the library's rgbl_gather_* with a one-rank RCCL communicator, loopback on: ncclAllGather of the counts
+                      and a grouped ncclSend / ncclRecv of the rank's own records, queued on the low-priority stream of the scan
+      torch_step/final  torch.distributed with a one-rank nccl process group: all_gather + (no peer: device copy); the
+                      collectives run on ProcessGroupNCCL's internal stream - the 'fifth stream' of DESIGN 9
+    No scaling claim follows from any of this: one rank has no peer, the bytes never leave the GPU."""
+    import socket
+
+    from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline, make_comm
+    made_pg = False
+    if not dist.is_initialized():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        made_pg = True
+    comm = make_comm(lib, dist, dev.index)
+    ver = C.c_int(0)
+    lib.rgbl_comm_info(comm, None, None, None, C.byref(ver))
+    out = {"steps": steps, "frames_per_step": B, "rccl_version": ver.value, "unit": "frames/s"}
+    try:
+        for name, gather, transport, cm in (("none", "none", "abi", None), ("abi_step", "step", "abi", comm), ("abi_final", "final", "abi", comm),
+                                            ("torch_step", "step", "torch", None), ("torch_final", "final", "torch", None)):
+            pipe = FrontEndPipeline(lib, torch, dev, w, h, nfeatures, proj, n_points, B, levels=LEVELS, scale=SCALE, ini_th=INI_TH,
+                                    min_th=MIN_TH, world=1, rank=0, gather=gather, log_steps=steps + 3, transport=transport, comm=cm,
+                                    loopback=cm is not None)
+            pipe.set_inputs(d_imgs, d_cloud)
+            for _ in range(3):
+                pipe.step()
+            pipe.finish()
+            pipe.sync()
+            if gather == "final":   # the slots are per step of the run: start the timed run from slot 0 again
+                pipe.step_no = 0
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                pipe.step()
+            pipe.finish()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / steps
+            pipe.sync()
+            out[name] = round(B / dt, 1)
+            pipe.close()
+        out["cost_of_abi_step"] = round(1.0 - out["abi_step"] / out["none"], 4)
+        out["cost_of_torch_step"] = round(1.0 - out["torch_step"] / out["none"], 4)
+        out["what"] = ("one rank, collectives inside the timed steps: rgbl_gather_* over RCCL on the scan's low-priority stream (abi) "
+                       "against torch.distributed / ProcessGroupNCCL on its internal stream (torch); no peer, no scaling claim")
+    finally:
+        lib.rgbl_comm_destroy(comm)
+        if made_pg:
+            dist.destroy_process_group()
+    return out
 
 
 def extra_workloads(lib, dev, torch):
@@ -463,6 +564,13 @@ def main():
                     help="gather of the keypoint / descriptor / depth records to rank 0: stream every step's records while the "
                          "next step computes (default for N > 1), exchange all of them once at the end, or not at all (default "
                          "for N = 1; step / final then run the same choreography without a peer)")
+    ap.add_argument("--transport", default="abi", choices=["abi", "torch"],
+                    help="what carries the gather: the library's own C-ABI entry points over RCCL (rgbl_gather_*, csrc/gather.hip: "
+                         "ncclAllGather + grouped ncclSend / ncclRecv on the pipeline's low-priority stream; default) or "
+                         "torch.distributed (ProcessGroupNCCL, which runs its collectives on an internal stream of its own)")
+    ap.add_argument("--pg", action="store_true",
+                    help="N = 1: create the one-rank process group / RCCL communicator anyway and gather (default --gather step), so "
+                         "that the collectives - and with --transport torch ProcessGroupNCCL's internal stream - are inside the timed steps")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -471,25 +579,43 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # ---- who runs: this process as one rank, or N ranks under torch.distributed.run (a bare `--gpus N` launches itself)
+    plan = launch_plan(args.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0, sys.argv)
+    if plan[0] == "error":
+        raise SystemExit("bench.py: " + plan[1])
+    if plan[0] == "exec":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+        sys.stdout.flush()
+        os.execv(plan[1][0], plan[1])
+    world = plan[1]
+
     from orb_slam3_rgbl_amd import _lib as L
     from orb_slam3_rgbl_amd import frontend as F
     from orb_slam3_rgbl_amd import sharding, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     w, h, nfeatures, n_az, default_batch = WORKLOADS[args.workload]
     B = args.batch or default_batch
     lib = L.load()
-    gather = args.gather or ("step" if world > 1 else "none")
+    gather = args.gather or ("step" if (world > 1 or args.pg) else "none")
+    comm = None
+    if gather != "none" and args.transport == "abi" and dist.is_initialized():
+        from orb_slam3_rgbl_amd.pipeline import make_comm
+        comm = make_comm(lib, dist, local_rank)   # rgbl_comm_create: the framework only hands the unique id around
 
     # ---- synthetic input, one independent sequence per rank (BASELINE configs[3]: sequences shard over GPUs)
     # constant_density: 1200 shapes per frame area whatever the batch (the scene grows with the sequence length)
@@ -512,7 +638,8 @@ def main():
     # orb_slam3_rgbl_amd/pipeline.py - the same code tests/test_distributed.py drives with two gloo ranks
     pipe = FrontEndPipeline(lib, torch, dev, w, h, nfeatures, proj, n_points, B, levels=LEVELS, scale=SCALE, ini_th=INI_TH,
                             min_th=MIN_TH, world=world, rank=rank, gather=gather, serial=args.serial,
-                            log_steps=args.steps + args.warmup, lanes=args.lanes)
+                            log_steps=args.steps + args.warmup, lanes=args.lanes, transport=args.transport, comm=comm,
+                            loopback=(comm is not None and world == 1))
     ex, dm, mt, cap = pipe.ex, pipe.dm, pipe.mt, pipe.cap
     d_imgs = torch.from_numpy(frames).to(dev)
     d_cloud = torch.from_numpy(cloud).to(dev)
@@ -656,6 +783,11 @@ def main():
                        "inputs": "resident in HBM",
                        "frames": "synth.Sequence, %s" % ("shape count of ONE frame for the whole scene (RGBL_BENCH_SPARSE: the pre-correction input)" if os.environ.get("RGBL_BENCH_SPARSE") else "constant corner density: 1200 shapes per frame area, ~8.6 k FAST candidates on level 0"),
                        "parallelism": "frames/sequences sharded, %d rank(s)" % world,
+                       "gather_transport": None if gather == "none" else
+                                           ("C ABI rgbl_gather_* over RCCL (ncclAllGather + grouped ncclSend/ncclRecv) on the pipeline's low-priority stream"
+                                            if pipe.transport == "abi" and comm is not None else
+                                            "C ABI rgbl_gather_* without a communicator (one rank: device copies)" if pipe.transport == "abi" else
+                                            "torch.distributed (ProcessGroupNCCL)" if dist.is_initialized() else "no backend (one rank: device copies)"),
                        "gather": {"none": "none",
                                   "step": "step: every step's records (68 B per keypoint, packed on the device) go to rank 0 while the "
                                           "next step computes - counts by all-gather, records by exact-size send / recv, one xGMI link "
@@ -669,8 +801,16 @@ def main():
         if world == 1 and not args.no_extras:
             out["extra"] = extra_workloads(lib, dev, torch)
             out["extra"]["sparse_upsampling"] = sparse_leg
+            try:
+                out["extra"]["gather_rccl_1rank"] = gather_legs_one_rank(lib, torch, dist, dev, d_imgs, d_cloud, w, h, nfeatures, proj, n_points, B,
+                                                                         max(10, args.steps // 2))
+            except Exception as e:   # the headline stands on its own
+                out["extra"]["gather_rccl_1rank"] = {"error": repr(e)}
         print(json.dumps(out))
-    if world > 1:
+    if comm is not None:
+        pipe.close()
+        lib.rgbl_comm_destroy(comm)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

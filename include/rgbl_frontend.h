@@ -35,7 +35,8 @@ enum {
   RGBL_ERR_HIP = -3,       /* a HIP runtime call failed */
   RGBL_ERR_CAPACITY = -4,  /* caller buffer too small; counts are still reported */
   RGBL_ERR_OVERFLOW = -5,  /* an internal scratch bound was exceeded (never silently truncated) */
-  RGBL_ERR_EMPTY = -6      /* empty image: mirrors ORBextractor::operator() returning -1 */
+  RGBL_ERR_EMPTY = -6,     /* empty image: mirrors ORBextractor::operator() returning -1 */
+  RGBL_ERR_COMM = -7       /* RCCL could not be loaded, or one of its calls failed (rgbl_comm_*, rgbl_gather_*) */
 };
 
 const char* rgbl_last_error(void);
@@ -89,6 +90,10 @@ int rgbl_extract(rgbl_extractor* h, const uint8_t* img, int w, int h_, int strid
  * queued on other handles in between - rgbl_depth_prefetch above all - runs next to the extraction, and so does the host.
  * The image must stay unchanged until it is collected. */
 int rgbl_extract_begin(rgbl_extractor* h, const uint8_t* img, int w, int h_, int stride, int lap0, int lap1);
+/* Drops a begun extraction that will not be collected (waits for it, forgets it).  A begun frame is recognised by its host
+ * pointer, size, stride and lapping area alone: call this before freeing a buffer that was begun but never handed to
+ * rgbl_extract - an allocator may give the address to the next frame, which would then collect the old frame's results. */
+int rgbl_extract_cancel(rgbl_extractor* h);
 
 /* Batched host variant: `batch` images of identical size, image b at imgs + b*frame_stride bytes.
  * Outputs for frame b start at out_kp + b*cap and out_desc + b*cap*32; out_n/out_mono hold batch ints. */
@@ -185,6 +190,54 @@ int rgbl_stream_wait(void* waiter_stream, void* signaler_stream);
 int rgbl_pack_records_device(void* hip_stream, const int32_t* d_n, const rgbl_keypoint* d_kp, const uint8_t* d_desc,
                              const float* d_depth, const float* d_uright, int batch, int cap, long long first_record,
                              long long capacity_records, uint8_t* d_out, long long* d_offsets, int* d_overflow);
+/* ---- The gather itself, over RCCL (round 4).  `north_star`: "host stays C++ calling through a thin C-ABI ... RCCL over xGMI
+ * only for the final keypoint/descriptor gather".  The reference has no counterpart (one process, one CPU); a multi-GPU host
+ * loop in the style of Examples/RGB-L/rgbl_kitti.cc:87-125 (one process per GPU, each tracking its own sequences) calls:
+ *
+ *   rank 0:  rgbl_comm_unique_id(id);  -> id reaches the other ranks out of band (file, socket, MPI_Bcast, a torch store)
+ *   all:     rgbl_comm_create(id, world, rank, device, &comm);            ncclCommInitRank
+ *            rgbl_gather_create(comm, batch, cap, slots, stream, &g);
+ *   per step k (slot = k % slots), behind the step's kernels, nothing waits on the host:
+ *            rgbl_gather_pack(g, slot, d_n, d_kp, d_desc, d_depth, d_uright, wait_events, n, done_event);
+ *                 pack (rgbl_pack_records_device) + phase 1: ncclAllGather of the per-frame counts of every rank, their copy into
+ *                 page-locked host memory, an event behind it
+ *   one step later (or all slots at the end: "final" gather):
+ *            rgbl_gather_exchange(g, slot);
+ *                 phase 2: the host waits for THAT slot's counts only and posts one exact-size ncclSend (non-root) resp. one
+ *                 ncclRecv per peer (root) inside one ncclGroup - on MI355X one xGMI link per peer, in parallel
+ *   root:    rgbl_gather_sync(g); rgbl_gather_result(g, r, &counts, &d_records, &n) for r = 0 .. world - 1
+ *
+ * Everything is queued on ONE stream the library controls (default: a low-priority stream of its own; or the caller's, e.g. the
+ * low-priority stream of the Hamming scan): the collectives do not get a stream of their own the way a framework's process group
+ * gives them one.  librccl is loaded lazily (dlopen; an RCCL already mapped into the process - PyTorch's - is reused): a
+ * single-GPU process never touches it; rgbl_comm_unique_id / rgbl_comm_create return RGBL_ERR_COMM if it cannot be loaded.
+ * comm == NULL in rgbl_gather_create: one rank without RCCL (device copies), the same choreography. */
+#define RGBL_COMM_ID_BYTES 128
+typedef struct rgbl_comm rgbl_comm;
+typedef struct rgbl_gather rgbl_gather;
+int rgbl_comm_available(void);                                  /* 1 when an RCCL library can be loaded (loads it) */
+int rgbl_comm_unique_id(uint8_t id[RGBL_COMM_ID_BYTES]);        /* ncclGetUniqueId */
+int rgbl_comm_create(const uint8_t id[RGBL_COMM_ID_BYTES], int world, int rank, int device, rgbl_comm** out);
+void rgbl_comm_destroy(rgbl_comm* c);
+int rgbl_comm_info(const rgbl_comm* c, int* world, int* rank, int* device, int* rccl_version);
+/* batch frames per step, cap keypoints per frame (the layout of the batch entry points' outputs), slots packed steps that
+ * may wait for their exchange (2 = streaming, one step of slack; the number of steps for a gather at the end). */
+int rgbl_gather_create(rgbl_comm* comm, int device, int batch, int cap, int slots, void* hip_stream, rgbl_gather** out);
+void rgbl_gather_destroy(rgbl_gather* g);
+void* rgbl_gather_stream(rgbl_gather* g);
+/* one rank only: the root's own records travel through ncclSend / ncclRecv to itself instead of a device copy, so that a
+ * one-GPU box exercises the point-to-point path (needs a comm) */
+int rgbl_gather_set_loopback(rgbl_gather* g, int enable);
+int rgbl_gather_pack(rgbl_gather* g, int slot, const int32_t* d_n, const rgbl_keypoint* d_kp, const uint8_t* d_desc,
+                     const float* d_depth, const float* d_uright, void* const* wait_events, int n_wait, void* done_event);
+int rgbl_gather_exchange(rgbl_gather* g, int slot);
+int rgbl_gather_sync(rgbl_gather* g);   /* waits for the stream; RGBL_ERR_OVERFLOW if a pack did not fit its slot */
+/* root, after rgbl_gather_exchange: the records of `rank` of the most recent exchange (valid until the exchange after the
+ * next one: two receive banks) and their per-frame counts (host memory, `batch` ints).  The device pointer may be used by
+ * work queued on rgbl_gather_stream, or after rgbl_gather_sync. */
+int rgbl_gather_result(rgbl_gather* g, int rank, const int32_t** h_counts, const uint8_t** d_records, long long* n_records);
+/* convenience: queues a copy of those records into dst (device or host memory, >= n_records * 68 bytes) on the gather's stream */
+int rgbl_gather_copy_result(rgbl_gather* g, int rank, void* dst, long long capacity_bytes);
 /* The same with explicit, reusable HIP events: record marks a point on a stream, wait makes later work on another
  * stream start only after that point (a never-recorded event does not block). Enables software pipelining across
  * batches: e.g. the extractor may overwrite an output buffer as soon as the event recorded behind its last reader
@@ -197,7 +250,8 @@ int rgbl_event_wait(void* stream, void* event);
  * to be handed to the rgbl_*_set_stream calls.  Work that is not on a batch pipeline's critical chain (the Hamming scan of
  * step k next to the extraction of step k + 1) belongs on a low-priority stream: its workgroups fill the slots the chain
  * leaves instead of competing for them (bench.py: +4 %). */
-int rgbl_stream_create(void** out_stream, int priority);
+int rgbl_stream_create(void** out_stream, int priority);        /* on the calling thread's current device */
+int rgbl_stream_create_on(int device, void** out_stream, int priority); /* on `device` (hipSetDevice first): what multi-GPU hosts call */
 void rgbl_stream_destroy(void* stream);
 int rgbl_extractor_profile(rgbl_extractor* h, int enable);
 /* Returns the number of distinct kernels; fills up to cap entries. names[i] points to static storage. */
@@ -258,6 +312,10 @@ int rgbl_depth_compute(rgbl_depth* h, const float* cloud, int n, int ld, int w, 
  * (with out_raw != NULL, or another cloud, it computes everything as usual).  The scan must stay unchanged in between. */
 int rgbl_depth_prefetch(rgbl_depth* h, const float* cloud, int n, int ld, int w, int h_);
 int rgbl_depth_prefetch_xyzi(rgbl_depth* h, const float* xyzi, int n, int w, int h_);
+/* Forgets a prefetched scan that will not be followed by rgbl_depth_compute* (same reason as rgbl_extract_cancel: the scan is
+ * recognised by pointer, n and ld).  Every other projecting entry point of the handle (the batch-device ones included)
+ * invalidates a prefetch by itself. */
+int rgbl_depth_prefetch_cancel(rgbl_depth* h);
 
 /* The same on a scan as it lies in a KITTI velodyne .bin file: n records (x, y, z, reflectance).  Replaces
  * LoadPointcloudBinaryMat's repack to 4 x n (Examples/RGB-L/rgbl_kitti.cc:151-185: reflectance dropped, homogeneous

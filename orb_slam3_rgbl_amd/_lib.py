@@ -16,7 +16,8 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
 
 RGBL_OK = 0
-ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_OVERFLOW, ERR_EMPTY = -1, -2, -3, -4, -5, -6
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_OVERFLOW, ERR_EMPTY, ERR_COMM = -1, -2, -3, -4, -5, -6, -7
+COMM_ID_BYTES = 128
 
 
 class RgblError(RuntimeError):
@@ -119,6 +120,7 @@ SYMBOLS = {
     "rgbl_extractor_max_keypoints": (_I, [_V]),
     "rgbl_extract": (_I, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _I, C.POINTER(_I), C.POINTER(_I)]),
     "rgbl_extract_begin": (_I, [_V, _V, _I, _I, _I, _I, _I]),
+    "rgbl_extract_cancel": (_I, [_V]),
     "rgbl_extract_batch": (_I, [_V, _V, _I, _I, _I, _I, _Z, _I, _I, _V, _V, _I, _V, _V]),
     "rgbl_extract_batch_device": (_I, [_V, _V, _I, _I, _I, _I, _Z, _I, _I, _V, _V, _I, _V, _V]),
     "rgbl_extractor_sync": (_I, [_V]),
@@ -142,6 +144,7 @@ SYMBOLS = {
     "rgbl_depth_compute": (_I, [_V, _V, _I, _I, _I, _I, _V, _V, _I, _V, _V, _V, _V]),
     "rgbl_depth_prefetch": (_I, [_V, _V, _I, _I, _I, _I]),
     "rgbl_depth_prefetch_xyzi": (_I, [_V, _V, _I, _I, _I]),
+    "rgbl_depth_prefetch_cancel": (_I, [_V]),
     "rgbl_depth_batch_device": (_I, [_V, _V, _I, _I, _I, _Z, _I, _I, _V, _V, _I, _V, _V, _V, _V]),
     "rgbl_depth_project_batch_device": (_I, [_V, _V, _I, _I, _I, _Z, _I, _I, _V]),
     "rgbl_depth_gather_batch_device": (_I, [_V, _I, _I, _I, _V, _V, _I, _V, _V, _V]),
@@ -154,11 +157,26 @@ SYMBOLS = {
     "rgbl_matcher_stream": (_V, [_V]),
     "rgbl_stream_wait": (_I, [_V, _V]),
     "rgbl_pack_records_device": (_I, [_V, _V, _V, _V, _V, _V, _I, _I, C.c_longlong, C.c_longlong, _V, _V, _V]),
+    "rgbl_comm_available": (_I, []),
+    "rgbl_comm_unique_id": (_I, [_V]),
+    "rgbl_comm_create": (_I, [_V, _I, _I, _I, C.POINTER(_V)]),
+    "rgbl_comm_destroy": (None, [_V]),
+    "rgbl_comm_info": (_I, [_V, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "rgbl_gather_create": (_I, [_V, _I, _I, _I, _I, _V, C.POINTER(_V)]),
+    "rgbl_gather_destroy": (None, [_V]),
+    "rgbl_gather_stream": (_V, [_V]),
+    "rgbl_gather_set_loopback": (_I, [_V, _I]),
+    "rgbl_gather_pack": (_I, [_V, _I, _V, _V, _V, _V, _V, _V, _I, _V]),
+    "rgbl_gather_exchange": (_I, [_V, _I]),
+    "rgbl_gather_sync": (_I, [_V]),
+    "rgbl_gather_result": (_I, [_V, _I, C.POINTER(_V), C.POINTER(_V), C.POINTER(C.c_longlong)]),
+    "rgbl_gather_copy_result": (_I, [_V, _I, _V, C.c_longlong]),
     "rgbl_event_create": (_I, [C.POINTER(_V)]),
     "rgbl_event_destroy": (None, [_V]),
     "rgbl_event_record": (_I, [_V, _V]),
     "rgbl_event_wait": (_I, [_V, _V]),
     "rgbl_stream_create": (_I, [C.POINTER(_V), _I]),
+    "rgbl_stream_create_on": (_I, [_I, C.POINTER(_V), _I]),
     "rgbl_stream_destroy": (None, [_V]),
     "rgbl_depth_set_stream": (_I, [_V, _V]),
     "rgbl_depth_set_sparse": (_I, [_V, _I]),

@@ -504,6 +504,10 @@ int enqueue_maps(rgbl_depth* e, const float* d_cloud, int batch, int n, int ld, 
                  float* d_processed_out, bool xyzi = false, bool need_raw = true, bool want_dense = true) {
   hipStream_t s = e->stream;
   const size_t ms = e->map_stride;
+  // Whatever a prefetch left in the maps is overwritten from here on: EVERY entry point that projects - the host ones, the
+  // batch-device ones - comes through this function, so a later rgbl_depth_compute with the prefetched cloud's pointer
+  // projects again instead of gathering from another scan's maps.  depth_prefetch_host re-arms it behind its own call.
+  e->prefetched.active = false;
   // the inverse dilation can read the points' depths through the index map: no raw map unless the caller wants it
   // (device batches may bring more points per scan than the host staging size the per-point buffer was sized for)
   const bool indexed = e->cfg.method == RGBL_UPS_INVERSE_DILATION && !need_raw && n <= e->cfg.max_points && (uint32_t)n < kIdxMask;
@@ -801,6 +805,17 @@ int rgbl_depth_compute(rgbl_depth* e, const float* cloud, int n, int ld, int w, 
 
 int rgbl_depth_prefetch(rgbl_depth* e, const float* cloud, int n, int ld, int w, int h) { return depth_prefetch_host(e, cloud, n, ld, false, w, h); }
 int rgbl_depth_prefetch_xyzi(rgbl_depth* e, const float* xyzi, int n, int w, int h) { return depth_prefetch_host(e, xyzi, n, n, true, w, h); }
+// A prefetched scan is recognised by its host pointer, point count and layout only.  A caller that frees (or rewrites) the
+// buffer without having called rgbl_depth_compute* on it says so here: the allocator may hand the same address to the next scan.
+int rgbl_depth_prefetch_cancel(rgbl_depth* e) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  if (e->prefetched.active) {
+    e->prefetched.active = false;
+    RGBL_HIP(hipSetDevice(e->device));
+    RGBL_HIP(hipStreamSynchronize(e->stream));  // the staged copy of the scan has left the page-locked block
+  }
+  return RGBL_OK;
+}
 
 // the scan as it lies in a KITTI velodyne .bin file (LoadPointcloudBinaryMat, rgbl_kitti.cc:151-185)
 int rgbl_depth_compute_xyzi(rgbl_depth* e, const float* xyzi, int n, int w, int h, const float* kp_xy, const float* kpun_x,

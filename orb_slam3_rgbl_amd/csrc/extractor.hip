@@ -924,9 +924,14 @@ static int upload_frames(rgbl_extractor* e, const uint8_t* imgs, int batch, int 
 int rgbl_extract_begin(rgbl_extractor* e, const uint8_t* img, int w, int h, int stride, int lap0, int lap1) {
   if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
   if (!img || w <= 0 || h <= 0) { set_error("empty image"); return RGBL_ERR_EMPTY; }
-  if (w != e->cfg.width || h != e->cfg.height || stride < w || !staged_one_trip(e, 1)) {
+  if (w != e->cfg.width || h != e->cfg.height || stride < w) {
     set_error("image %dx%d does not match the handle (%dx%d)", w, h, e->cfg.width, e->cfg.height);
     return RGBL_ERR_INVALID;
+  }
+  if (!staged_one_trip(e, 1)) {
+    set_error("rgbl_extract_begin needs the handle's page-locked result block (%zu bytes; one frame's results do not fit or the block could not be allocated): call rgbl_extract instead",
+              e->h_pinned ? e->h_pinned_bytes : (size_t)0);
+    return RGBL_ERR_CAPACITY;
   }
   RGBL_HIP(hipSetDevice(e->device));
   if (e->pending.active) { RGBL_HIP(hipStreamSynchronize(e->stream)); e->pending.active = false; }  // an extraction nobody collected
@@ -936,6 +941,14 @@ int rgbl_extract_begin(rgbl_extractor* e, const uint8_t* img, int w, int h, int 
   e->pending.active = true; e->pending.img = img; e->pending.w = w; e->pending.h = h; e->pending.stride = stride;
   e->pending.lap0 = lap0; e->pending.lap1 = lap1;
   return RGBL_OK;
+}
+
+// A begun frame is recognised by its host pointer and geometry only.  A caller that drops the frame without collecting it
+// (rgbl_extract on the same buffer) says so here before the buffer is freed: the allocator may hand the address to the next frame.
+int rgbl_extract_cancel(rgbl_extractor* e) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(e->device));
+  return drop_pending(e);
 }
 
 int rgbl_extract_batch(rgbl_extractor* e, const uint8_t* imgs, int batch, int w, int h, int stride, size_t frame_stride,
@@ -1204,6 +1217,13 @@ int rgbl_event_create(void** ev) {
   return RGBL_OK;
 }
 void rgbl_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int rgbl_stream_create_on(int device, void** out, int priority) {
+  if (!out) { set_error("null argument"); return RGBL_ERR_INVALID; }
+  *out = nullptr;
+  if (device < 0 || device >= rgbl_device_count()) { set_error("no usable HIP device %d", device); return RGBL_ERR_NO_DEVICE; }
+  RGBL_HIP(hipSetDevice(device));
+  return rgbl_stream_create(out, priority);
+}
 int rgbl_stream_create(void** out, int priority) {
   if (!out) { set_error("null argument"); return RGBL_ERR_INVALID; }
   hipStream_t st = nullptr;

@@ -88,6 +88,7 @@ class ORBextractor:
         L.check(self.lib, self.lib.rgbl_extract(self.h, L.ptr(image), w, h, image.strides[0], int(vLappingArea[0]),
                                                 int(vLappingArea[1]), L.ptr(kps), L.ptr(desc), cap, C.byref(n),
                                                 C.byref(mono)))
+        self._begun = None
         return kps[:n.value], desc[:n.value], mono.value
 
     def Begin(self, image, vLappingArea=(0, 0)):
@@ -98,6 +99,13 @@ class ORBextractor:
             raise TypeError("image must be CV_8UC1 with contiguous rows")
         h, w = image.shape
         L.check(self.lib, self.lib.rgbl_extract_begin(self.h, L.ptr(image), w, h, image.strides[0], int(vLappingArea[0]), int(vLappingArea[1])))
+        # the library recognises the begun frame by its address: holding the array keeps that address from being reused
+        self._begun = image
+
+    def CancelBegin(self):
+        """Drops a begun frame that will not be collected (rgbl_extract_cancel)."""
+        L.check(self.lib, self.lib.rgbl_extract_cancel(self.h))
+        self._begun = None
 
     def extract_color(self, image, mbRGB, vLappingArea=(0, 0)):
         """Tracking::GrabImageRGBL's cvtColor (Tracking.cc:1567-1580) + operator() on an H x W x {3,4} 8-bit image.
@@ -255,6 +263,12 @@ class DepthModule:
         if cloud.dtype != np.float32 or cloud.ndim != 2 or cloud.shape[0] != 4 or cloud.strides[1] != 4:
             raise TypeError("PointCloud must be a 4 x N float32 array with contiguous rows")
         L.check(self.lib, self.lib.rgbl_depth_prefetch(self.h, L.ptr(cloud), cloud.shape[1], cloud.strides[0] // 4, imwidth, imheight))
+        self._prefetched = cloud  # the scan is recognised by its address: keep it from being reused until it is consumed
+
+    def CancelPrefetch(self):
+        """Forgets a prefetched scan that will not be followed by CalculateDepthFromPcd (rgbl_depth_prefetch_cancel)."""
+        L.check(self.lib, self.lib.rgbl_depth_prefetch_cancel(self.h))
+        self._prefetched = None
 
     def CalculateDepthFromPcd(self, mvKeys, mvKeysUn, PointCloud, imwidth, imheight, want_maps=True):
         """mvKeys / mvKeysUn: KP_DTYPE arrays (or [k,2] float arrays); PointCloud: 4 x N float32."""
@@ -273,6 +287,7 @@ class DepthModule:
         L.check(self.lib, self.lib.rgbl_depth_compute(self.h, L.ptr(cloud), n, cloud.strides[0] // 4, imwidth, imheight,
                                                       L.ptr(kp), L.ptr(un), k, L.ptr(self.mvDepth), L.ptr(self.mvuRight),
                                                       L.ptr(self.RawDepthMap), L.ptr(self.ProcessedDepthMap)))
+        self._prefetched = None
 
     def CalculateDepthFromKittiBin(self, mvKeys, mvKeysUn, xyzi, imwidth, imheight, want_maps=True):
         """The scan as read from a KITTI velodyne .bin file: N x 4 float32 (x, y, z, reflectance) - what

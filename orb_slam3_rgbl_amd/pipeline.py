@@ -20,6 +20,14 @@ the page-locked block, the root's device copy, the events) without a peer - and 
 The communication stream is the low-priority stream of the Hamming scan (`rgbl_stream_create`, one lane): what is off the
 chain resize -> FAST -> quad-tree -> descriptors that paces the steps only takes the slots the chain leaves, and a fifth stream
 would not find a hardware queue of its own.  The exchange of step k - 1 therefore starts behind the scan of step k.
+
+Two transports carry the same choreography:
+  transport="abi"    (round 4, the default whenever a `comm` is given or there is one rank) - the library's own entry points
+                     `rgbl_gather_pack` / `rgbl_gather_exchange` (csrc/gather.hip): ncclAllGather + grouped ncclSend / ncclRecv
+                     straight on RCCL, queued on the stream handed to `rgbl_gather_create` - the low-priority stream above.  This
+                     is what a C++ host calls; no framework process group and none of its internal streams.
+  transport="torch"  torch.distributed (`all_gather`, `batch_isend_irecv`): the gloo backend of the CPU tests, and on GPUs
+                     ProcessGroupNCCL, which runs its collectives on an internal stream of its own.
 PyTorch is plumbing here: device memory, streams and torch.distributed.
 """
 import ctypes as C
@@ -65,11 +73,34 @@ class OutSet:
             self.ev[name] = e
 
 
+# A stream that PyTorch has wrapped (torch.cuda.ExternalStream, transport="torch") must outlive every tensor the caching
+# allocator has seen on it, i.e. in practice the process: ONE such low-priority stream per device is created and shared by
+# all pipelines of the process instead of leaking one per pipeline.
+_WRAPPED_LOW_STREAMS = {}
+
+
+def make_comm(lib, dist, device_index):
+    """An RCCL communicator of the library (rgbl_comm_create) for the ranks of an initialised torch.distributed group:
+    rank 0 draws the unique id, the group's object broadcast carries it - the only thing the framework is used for."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ident = (C.c_uint8 * L.COMM_ID_BYTES)()
+    if rank == 0:
+        L.check(lib, lib.rgbl_comm_unique_id(ident))
+    box = [bytes(ident)]
+    dist.broadcast_object_list(box, src=0)
+    ident = (C.c_uint8 * L.COMM_ID_BYTES).from_buffer_copy(box[0])
+    comm = C.c_void_p()
+    L.check(lib, lib.rgbl_comm_create(ident, world, rank, device_index, C.byref(comm)))
+    return comm
+
+
 class _Lane:
     """One set of handles (extractor, depth module, matcher) with their streams: the work of one step."""
 
-    def __init__(self, lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial, gather="none"):
+    def __init__(self, lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial, gather="none",
+                 shared_low=False):
         self.own_stream = None
+        self.owns_stream = True
         self.ex = F.ORBextractor(nfeatures, scale, levels, ini_th, min_th, w, h, max_batch=batch, device=index, lib=lib)
         self.dm = F.DepthModule(proj, w, h, max_points=n_points, max_keypoints=self.ex.max_keypoints, max_batch=batch, device=index, lib=lib)
         self.mt = F.ORBmatcher(0.6, False, device=index, lib=lib)
@@ -90,8 +121,14 @@ class _Lane:
             if mode == "shared":
                 L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
             elif mode == "low":
-                self.own_stream = C.c_void_p()
-                L.check(lib, lib.rgbl_stream_create(C.byref(self.own_stream), -1))
+                if shared_low and index in _WRAPPED_LOW_STREAMS:
+                    self.own_stream = _WRAPPED_LOW_STREAMS[index]
+                else:
+                    self.own_stream = C.c_void_p()
+                    L.check(lib, lib.rgbl_stream_create_on(index, C.byref(self.own_stream), -1))
+                    if shared_low:
+                        _WRAPPED_LOW_STREAMS[index] = self.own_stream
+                self.owns_stream = not shared_low
                 L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, self.own_stream))
         self.streams(lib)
 
@@ -103,18 +140,27 @@ class _Lane:
 
 class FrontEndPipeline:
     def __init__(self, lib, torch, dev, w, h, nfeatures, proj, n_points, batch, levels=8, scale=1.2, ini_th=12, min_th=7,
-                 world=1, rank=0, gather="step", serial=False, keep_steps=0, log_steps=1, lanes=1,
-                 sparse_depth=False):
+                 world=1, rank=0, gather=None, serial=False, keep_steps=0, log_steps=1, lanes=1,
+                 sparse_depth=False, transport=None, comm=None, loopback=False):
         self.lib, self.torch, self.dev = lib, torch, dev
         self.w, self.h, self.B, self.n_points = w, h, batch, n_points
+        # one rank and nobody asked for a gather: none (no buffers, no pack, no host event per step - ADVICE r3)
+        gather = gather or ("step" if world > 1 else "none")
         self.world, self.rank, self.gather = world, rank, gather
-        index = dev.index if dev.type == "cuda" else 0
+        if transport is None:
+            transport = "abi" if (comm is not None or world == 1) else "torch"
+        if transport == "abi" and world > 1 and comm is None:
+            raise ValueError("transport='abi' with more than one rank needs an rgbl_comm (pipeline.make_comm)")
+        self.transport, self.comm, self.g = transport, comm, None
+        index = dev.index if (dev.type == "cuda" and dev.index is not None) else 0
+        self.index = index
         # lanes = 2: two sets of handles used alternately, step k on lane k mod 2 with the output set k mod 2 - two steps in
         # flight: the tail of step k (quad-trees of the upper levels, descriptors, matching: dependent chains and gathers that
         # leave most vector-issue slots idle) runs next to the head of step k + 1 (pyramid, FAST, Gaussian: issue-bound)
         n_lanes = 1 if serial else max(1, min(lanes, 2))
+        wrap_low = gather != "none" and n_lanes == 1 and transport == "torch" and dev.type == "cuda"
         self.lanes = [_Lane(lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial,
-                            "two-lanes" if (gather != "none" and n_lanes > 1) else gather)
+                            "two-lanes" if (gather != "none" and n_lanes > 1) else gather, shared_low=wrap_low)
                       for _ in range(n_lanes)]
         self.ex, self.dm, self.mt = self.lanes[0].ex, self.lanes[0].dm, self.lanes[0].mt
         # sparse_depth: no dense ProcessedDepthMap (rgbl_depth_set_sparse) - the step never hands it out anyway
@@ -132,23 +178,30 @@ class FrontEndPipeline:
         # ---- gather state
         self.cuda = dev.type == "cuda"
         self.comm_stream = None
-        self.comm_wraps_low = False
-        if self.gather != "none" and self.cuda:
-            low = self.lanes[0].own_stream if len(self.lanes) == 1 else None
-            # pack, counts and the exchange of step k - 1 behind the Hamming scan of step k on ONE low-priority stream (see _Lane)
-            self.comm_stream = torch.cuda.ExternalStream(low.value, device=dev) if low is not None else torch.cuda.Stream(dev)
-            self.comm_wraps_low = low is not None
-        self.s_comm = C.c_void_p(self.comm_stream.cuda_stream) if self.comm_stream is not None else C.c_void_p(None)
         self.pending = None         # the step whose records are packed but not exchanged yet
         self.received = []          # root: per exchanged step, per rank (counts [B] int32 on the host, records uint8 tensor)
         self.keep = keep_steps      # root keeps the records of at most this many steps (0 = only the last)
         self.n_exchanged = 0
         self.dist = None
-        if self.gather != "none":
+        self.n_slots = 2 if self.gather == "step" else max(log_steps, 1)   # 'final': one slot per step of the run
+        low = self.lanes[0].own_stream if (len(self.lanes) == 1 and not serial) else None
+        if self.gather != "none" and transport == "abi":
+            # the library's gather on the Hamming scan's low-priority stream (its own low-priority stream with two lanes)
+            self.g = C.c_void_p()
+            L.check(lib, lib.rgbl_gather_create(comm, index, batch, self.cap, self.n_slots, low, C.byref(self.g)))
+            if loopback:
+                L.check(lib, lib.rgbl_gather_set_loopback(self.g, 1))
+            self.s_comm = C.c_void_p(lib.rgbl_gather_stream(self.g))
+        elif self.gather != "none" and self.cuda:
+            # pack, counts and the exchange of step k - 1 behind the Hamming scan of step k on ONE low-priority stream (see _Lane)
+            self.comm_stream = torch.cuda.ExternalStream(low.value, device=dev) if low is not None else torch.cuda.Stream(dev)
+        if self.g is None:
+            self.s_comm = C.c_void_p(self.comm_stream.cuda_stream) if self.comm_stream is not None else C.c_void_p(None)
+        if self.gather != "none" and transport == "torch":
             import torch.distributed as dist
             if world > 1 or dist.is_initialized():
                 self.dist = dist    # one rank with a process group: the collectives still go through the backend
-            slots = 2 if self.gather == "step" else max(log_steps, 1)   # 'final': one slot per step of the run
+            slots = self.n_slots
             rec_cap = batch * self.cap
             self.send = [torch.zeros(rec_cap * RECORD_BYTES, dtype=torch.uint8, device=dev) for _ in range(slots)]
             self.offsets = [torch.zeros(batch + 1, dtype=torch.int64, device=dev) for _ in range(slots)]
@@ -231,7 +284,13 @@ class FrontEndPipeline:
         """Compaction of the step's results on the communication stream, behind the step's last writers; phase 1 of the
         gather (the counts of every rank) follows it on the same stream and ends in page-locked host memory."""
         lib, p = self.lib, self._p
-        slot = self.step_no % len(self.send)
+        slot = self.step_no % self.n_slots
+        if self.g is not None:
+            # pack + phase 1 (ncclAllGather of the counts, their copy into page-locked memory) in one call of the C ABI
+            waits = (C.c_void_p * 2)(o.ev["depth_done"], o.ev["match_done"])
+            L.check(lib, lib.rgbl_gather_pack(self.g, slot, p(o.n), p(o.kp), p(o.desc), p(o.depth), p(o.uright), waits, 2, o.ev["comm_done"]))
+            self.pending = slot
+            return
         L.check(lib, lib.rgbl_event_wait(self.s_comm, o.ev["depth_done"]))
         L.check(lib, lib.rgbl_event_wait(self.s_comm, o.ev["match_done"]))
         L.check(lib, lib.rgbl_pack_records_device(self.s_comm, p(o.n), p(o.kp), p(o.desc), p(o.depth), p(o.uright), self.B, self.cap, 0,
@@ -260,6 +319,8 @@ class FrontEndPipeline:
         """Phase 2 of the gather of one packed step to rank 0: exact-size point-to-point transfers, one per
         peer, sized by the counts phase 1 left in page-locked memory."""
         torch, world, rank = self.torch, self.world, self.rank
+        if self.g is not None:
+            return self._exchange_abi(slot)
         if self.cuda:
             self.counts_ready[slot].synchronize()   # an event of an EARLIER step in gather='step': already signalled or about to be
         host_counts = [self.host_counts[slot][r].numpy().copy() for r in range(world)]
@@ -288,17 +349,40 @@ class FrontEndPipeline:
         if self.pending == slot:
             self.pending = None
 
+    def _exchange_abi(self, slot):
+        """Phase 2 through the C ABI: rgbl_gather_exchange waits for the slot's counts and posts the grouped ncclSend / ncclRecv."""
+        lib, torch = self.lib, self.torch
+        L.check(lib, lib.rgbl_gather_exchange(self.g, slot))
+        if self.rank == 0:
+            self.n_exchanged += 1
+            got = []
+            for r in range(self.world):
+                h_counts, d_rec, n_rec = C.c_void_p(), C.c_void_p(), C.c_longlong()
+                L.check(lib, lib.rgbl_gather_result(self.g, r, C.byref(h_counts), C.byref(d_rec), C.byref(n_rec)))
+                counts = np.ctypeslib.as_array(C.cast(h_counts, C.POINTER(C.c_int32)), (self.B,)).copy()
+                rec = None
+                if self.keep:   # tests: a copy of the root's bank (the bank itself is reused two exchanges later)
+                    rec = torch.zeros(n_rec.value * RECORD_BYTES, dtype=torch.uint8, device=self.dev)
+                    L.check(lib, lib.rgbl_gather_copy_result(self.g, r, C.c_void_p(rec.data_ptr()), rec.numel()))
+                got.append((counts, rec))
+            self.received = (self.received + [got])[-self.keep:] if self.keep else [got]
+        if self.pending == slot:
+            self.pending = None
+
     def finish(self):
         """Flushes the gather: the last step's records (gather='step') or every kept step's (gather='final')."""
         if self.gather == "step" and self.pending is not None:
             self._exchange(self.pending)
         elif self.gather == "final":
-            first = max(self.step_no - len(self.send), 0)
-            slots = [k % len(self.send) for k in range(first, self.step_no)]
-            self._gather_counts(slots)
+            first = max(self.step_no - self.n_slots, 0)
+            slots = [k % self.n_slots for k in range(first, self.step_no)]
+            if self.g is None:
+                self._gather_counts(slots)   # (the ABI's pack has already queued every step's all-gather)
             for slot in slots:
                 self._exchange(slot)
-        if self.comm_stream is not None:
+        if self.g is not None:
+            L.check(self.lib, self.lib.rgbl_gather_sync(self.g))
+        elif self.comm_stream is not None:
             self.comm_stream.synchronize()
 
     def sync(self):
@@ -306,19 +390,23 @@ class FrontEndPipeline:
             self.torch.cuda.synchronize(self.dev)
         for ln in self.lanes:
             L.check(self.lib, self.lib.rgbl_extractor_sync(ln.ex.h))  # also surfaces device-side overflow flags
-        if self.gather != "none" and int(self.overflow.cpu()[0]) != 0:
+        if self.g is not None:
+            L.check(self.lib, self.lib.rgbl_gather_sync(self.g))   # RGBL_ERR_OVERFLOW if a pack did not fit
+        elif self.gather != "none" and int(self.overflow.cpu()[0]) != 0:
             raise RuntimeError("record buffer overflow in rgbl_pack_records_device")
 
     def last(self):
         return self.sets[(self.step_no - 1) % 2]
 
     def close(self):
+        if self.g is not None:
+            self.lib.rgbl_gather_destroy(self.g)
+            self.g = None
         for ln in getattr(self, "all_lanes", self.lanes):
             ln.ex.close(); ln.dm.close(); ln.mt.close()
             if ln.own_stream is not None:
-                # a stream PyTorch has seen (the communication stream wraps it) stays alive: the caching allocator keeps
-                # blocks that were used on it and touches the stream again when they are released
-                if not self.comm_wraps_low:
+                # a stream PyTorch has wrapped is the process-wide one of _WRAPPED_LOW_STREAMS and stays; the others go
+                if ln.owns_stream:
                     self.lib.rgbl_stream_destroy(ln.own_stream)
                 ln.own_stream = None
 

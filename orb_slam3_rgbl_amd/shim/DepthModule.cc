@@ -248,6 +248,10 @@ void DepthModule::PrefetchPointcloud(const cv::Mat& PointCloud, const int imwidt
   (void)rgbl_depth_prefetch(mpHandle, PointCloud.ptr<float>(), PointCloud.cols, (int)(PointCloud.step / sizeof(float)), imwidth, imheight);
 }
 
+void DepthModule::CancelPrefetch() {
+  if (mpHandle) (void)rgbl_depth_prefetch_cancel(mpHandle);
+}
+
 // The scan exactly as read from a KITTI velodyne .bin file (nPoints records x, y, z, reflectance): what the example's
 // LoadPointcloudBinaryMat (Examples/RGB-L/rgbl_kitti.cc:151-185) repacks into the 4 x N matrix, without the repack.
 void DepthModule::CalculateDepthFromKittiBin(const std::vector<cv::KeyPoint>& mvKeys, const std::vector<cv::KeyPoint>& mvKeysUn,

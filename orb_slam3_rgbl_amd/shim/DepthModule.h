@@ -31,6 +31,8 @@ class DepthModule {
   // next to the extraction; CalculateDepthFromPcd on the SAME cv::Mat data then only gathers the keypoints' depths (with
   // downloadDenseMaps set the maps are computed again with the raw map).  The scan must stay unchanged in between.
   void PrefetchPointcloud(const cv::Mat& PointCloud, const int imwidth, const int imheight);
+  // Forgets a prefetched scan that will not reach CalculateDepthFromPcd (rgbl_depth_prefetch_cancel): call before its cv::Mat is released.
+  void CancelPrefetch();
   // Same, on the raw contents of a KITTI velodyne .bin file (nPoints x {x, y, z, reflectance}): replaces the example's
   // LoadPointcloudBinaryMat repack (Examples/RGB-L/rgbl_kitti.cc:151-185) + CalculateDepthFromPcd.
   void CalculateDepthFromKittiBin(const std::vector<cv::KeyPoint>& mvKeys, const std::vector<cv::KeyPoint>& mvKeysUn,

@@ -118,6 +118,10 @@ bool ORBextractor::Begin(cv::InputArray _image, std::vector<int>& vLappingArea) 
   return rgbl_extract_begin(mpHandle, image.data, image.cols, image.rows, (int)image.step, lap0, lap1) == RGBL_OK;
 }
 
+void ORBextractor::CancelBegin() {
+  if (mpHandle) (void)rgbl_extract_cancel(mpHandle);
+}
+
 int ORBextractor::ExtractColor(const unsigned char* data, int channels, int step, int width, int height, bool bRGB,
                                cv::Mat& imGray, std::vector<cv::KeyPoint>& _keypoints, cv::Mat& _descriptors,
                                std::vector<int>& vLappingArea) {

@@ -29,6 +29,8 @@ class ORBextractor {
   // call that follows on the SAME cv::Mat data collects the results.  What is issued in between - above all
   // DepthModule::PrefetchPointcloud - runs next to the extraction.  Returns false when nothing was begun.
   bool Begin(cv::InputArray _image, std::vector<int>& vLappingArea);
+  // Drops a begun frame that will not reach operator() (rgbl_extract_cancel): call before its cv::Mat is released.
+  void CancelBegin();
 
   // cvtColor + operator() in one device round trip (Tracking::GrabImageRGBL, Tracking.cc:1567-1580): `data` is an
   // 8-bit image with 3 or 4 interleaved channels (1 = already gray), bRGB = Tracking::mbRGB.  imGray receives mImGray.

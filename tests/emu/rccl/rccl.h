@@ -1,0 +1,24 @@
+// rccl/rccl.h of the CPU SIMT-emulation build (TEST INFRASTRUCTURE ONLY, never part of the product): the subset of RCCL's
+// API that orb_slam3_rgbl_amd/csrc/gather.hip calls, with RCCL's signatures, implemented in tests/emu/nccl_emu.cpp as a
+// mailbox in the file system so that two processes on a GPU-less machine run the very same gather code.
+#pragma once
+#include <stddef.h>
+
+#include "../hip_emu.h"
+
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4, ncclInvalidUsage = 5 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2 } ncclDataType_t;
+
+ncclResult_t ncclGetVersion(int* version);
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+const char* ncclGetErrorString(ncclResult_t result);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();

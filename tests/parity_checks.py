@@ -925,6 +925,23 @@ def check_depth_partial_batches(lib, dev=None, w=310, h=94, max_gen=None):
             od, our, oraw, oproc = O.depth(P, cloud[b], w, h, np.stack([kps["x"][b], kps["y"][b]], 1), kps["x"][b])
             assert np.array_equal(bits(down(d_proc)[b]), bits(oproc)), "processed map, batch %d frame %d" % (batch, b)
             assert np.array_equal(bits(down(d_depth)[b]), bits(od)) and np.array_equal(bits(down(d_ur)[b]), bits(our))
+    # prefetch(A), a batch-device projection of B through the same handle, then compute(A) - the prefetched maps
+    # are gone and compute(A) must project A again instead of gathering from B's maps; and a cancelled prefetch is forgotten
+    hk = np.stack([rng.uniform(0, w - 1, cap), rng.uniform(0, h - 1, cap)], 1).astype(np.float32)
+    A, Bc = np.ascontiguousarray(scans[0]), np.ascontiguousarray(scans[1])
+    odA = O.depth(P, A, w, h, hk, hk[:, 0])[0]
+    odB = O.depth(P, Bc, w, h, hk, hk[:, 0])[0]
+    assert not np.array_equal(bits(odA), bits(odB))
+    d_B = up(Bc[None])
+    dm.PrefetchPointcloud(A, w, h)
+    L.check(lib, lib.rgbl_depth_project_batch_device(dm.h, ptr(d_B), 1, n, n, 4 * n, w, h, None))
+    dm.CalculateDepthFromPcd(hk, hk, A, w, h, want_maps=False)
+    assert np.array_equal(bits(dm.mvDepth), bits(odA)), "compute(A) after prefetch(A) + project_batch_device(B) gathered from B's maps"
+    dm.PrefetchPointcloud(A, w, h)
+    dm.CancelPrefetch()
+    A[:] = Bc                                   # the same address now holds another scan
+    dm.CalculateDepthFromPcd(hk, hk, A, w, h, want_maps=False)
+    assert np.array_equal(bits(dm.mvDepth), bits(odB)), "a cancelled prefetch was still used"
     dm.close()
 
 
@@ -1355,6 +1372,14 @@ def check_overlapped_frame(lib, w=synth.KITTI_W, h=synth.KITTI_H, nfeatures=2000
     dm.PrefetchPointcloud(c0, w, h)
     dm.CalculateDepthFromPcd(kps, kps, c1, w, h, want_maps=False)    # another scan than the prefetched one
     assert np.array_equal(bits(dm.mvDepth), bits(od))
+    # a cancelled begin is forgotten: the same buffer with new contents is extracted afresh
+    buf = img0.copy()
+    ex.Begin(buf)
+    ex.CancelBegin()
+    buf[:] = img1
+    kps2, desc2, _ = ex(buf)
+    assert_keypoints_equal(kps2, okps, "cancelled begin")
+    assert np.array_equal(desc2, odesc)
     ex.close(); dm.close()
 
 

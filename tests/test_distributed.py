@@ -19,10 +19,11 @@ sys.path.insert(0, os.environ["RGBL_ROOT"])
 import numpy as np, torch, torch.distributed as dist
 from orb_slam3_rgbl_amd import _lib, synth, sharding
 from orb_slam3_rgbl_amd import frontend as F
-from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline, unpack_records
+from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline, unpack_records, make_comm
 
 W, H, NF, LEVELS, B, STEPS, N_AZ = 200, 160, 300, 4, 3, 3, 240
 MODE = os.environ["RGBL_GATHER"]
+TRANSPORT = os.environ.get("RGBL_TRANSPORT", "torch")   # abi: the library's rgbl_gather_* over RCCL (nccl_emu on the CPU)
 CUDA = os.environ.get("RGBL_DEVICE", "cpu") == "cuda"     # the same worker on real GPUs: backend nccl (= RCCL), product library
 if CUDA:
     W, H, NF, LEVELS, B, STEPS, N_AZ = 640, 360, 800, 8, 16, 4, 600
@@ -35,12 +36,13 @@ def inputs_of(rank):
     cloud = np.stack([synth.lidar_scan(100 * rank + i, n_az=N_AZ) for i in range(B)])
     return frames, cloud
 
-def make(lib, rank, world, gather, keep=0):
+def make(lib, rank, world, gather, keep=0, transport=None, comm=None):
     K = synth.KITTI_K.copy(); K[0, 2], K[1, 2] = W / 2.0, H / 2.0
     proj = F.projection_matrix(K, synth.KITTI_TR, lib)
     frames, cloud = inputs_of(rank)
     pipe = FrontEndPipeline(lib, torch, DEV, W, H, NF, proj, cloud.shape[2], B, levels=LEVELS, ini_th=20, min_th=7,
-                            world=world, rank=rank, gather=gather, keep_steps=keep, log_steps=STEPS)
+                            world=world, rank=rank, gather=gather, keep_steps=keep, log_steps=STEPS, transport=transport, comm=comm,
+                            loopback=(transport == "abi" and world == 1 and comm is not None))
     pipe.set_inputs(torch.from_numpy(frames).to(DEV), torch.from_numpy(cloud).to(DEV))
     return pipe, frames, cloud, proj
 
@@ -60,7 +62,8 @@ def main():
         torch.cuda.synchronize(DEV)
         assert torch.equal(a, b)
         print("SELF_P2P_OK")
-    pipe, _, _, _ = make(lib, rank, world, MODE, keep=STEPS)
+    comm = make_comm(lib, dist, DEV.index if CUDA else 0) if TRANSPORT == "abi" else None
+    pipe, _, _, _ = make(lib, rank, world, MODE, keep=STEPS, transport=TRANSPORT, comm=comm)
     for _ in range(STEPS):
         pipe.step()
     pipe.finish()
@@ -99,6 +102,9 @@ def main():
                 ok &= np.array_equal(fr[f]["uright"].view(np.uint32), our.view(np.uint32))
             solo.close()
         print("GATHER_OK" if ok else "GATHER_MISMATCH")
+    pipe.close()
+    if comm is not None:
+        lib.rgbl_comm_destroy(comm)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -150,11 +156,15 @@ def test_pack_unpack_roundtrip(emu_lib):
     assert int(ovf[0]) == 1
 
 
-@pytest.mark.parametrize("mode,port", [("step", 29517), ("final", 29519)])
-def test_two_rank_gather_equals_single_process(tmp_path, oracle, emu_lib, mode, port):
+@pytest.mark.parametrize("mode,port,transport", [("step", 29517, "torch"), ("final", 29519, "torch"),
+                                                 ("step", 29521, "abi"), ("final", 29523, "abi")])
+def test_two_rank_gather_equals_single_process(tmp_path, oracle, emu_lib, mode, port, transport):
+    """transport torch: torch.distributed over gloo.  transport abi: the library's own rgbl_gather_* entry points
+    (csrc/gather.hip) with tests/emu/nccl_emu.cpp standing in for RCCL - gloo only carries the unique id."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, RGBL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", RGBL_GATHER=mode, RGBL_EMU_THREADS="2",
+               RGBL_TRANSPORT=transport, TMPDIR=str(tmp_path),
                RGBL_EMU_LIB=os.path.join(ROOT, "tests", "_build", "librgbl_frontend_emu.so"))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
@@ -162,11 +172,11 @@ def test_two_rank_gather_equals_single_process(tmp_path, oracle, emu_lib, mode, 
     assert "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-def _run_on_gpus(tmp_path, nproc, mode, port, self_p2p=False):
+def _run_on_gpus(tmp_path, nproc, mode, port, self_p2p=False, transport="torch"):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, RGBL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", RGBL_GATHER=mode, RGBL_DEVICE="cuda",
-               HSA_ENABLE_IPC_MODE_LEGACY="0", RGBL_SELF_P2P="1" if self_p2p else "0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", RGBL_SELF_P2P="1" if self_p2p else "0", RGBL_TRANSPORT=transport)
     return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
                            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                           env=env, capture_output=True, text=True, timeout=240)
@@ -185,11 +195,21 @@ def test_rccl_gather_with_one_rank(tmp_path, oracle, gpu_lib, mode, port):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,port", [("step", 29535), ("final", 29537)])
-def test_rccl_gather_two_ranks(tmp_path, oracle, gpu_lib, mode, port):
+@pytest.mark.parametrize("mode,port", [("step", 29541), ("final", 29543)])
+def test_rccl_gather_through_the_c_abi_with_one_rank(tmp_path, oracle, gpu_lib, mode, port):
+    """ONE rank, the library's own gather (rgbl_comm_create / rgbl_gather_pack / rgbl_gather_exchange): ncclCommInitRank, the
+    ncclAllGather of the counts and - loopback - a grouped ncclSend / ncclRecv of the rank's records to itself run through RCCL
+    on the hardware, on the pipeline's low-priority stream; torch.distributed only hands the unique id around."""
+    out = _run_on_gpus(tmp_path, 1, mode, port, transport="abi")
+    assert "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,port,transport", [("step", 29535, "torch"), ("final", 29537, "torch"), ("step", 29545, "abi"), ("final", 29547, "abi")])
+def test_rccl_gather_two_ranks(tmp_path, oracle, gpu_lib, mode, port, transport):
     """Two ranks on two GPUs over RCCL / xGMI (skipped on the one-GPU boxes of the pool)."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
-    out = _run_on_gpus(tmp_path, 2, mode, port)
+    out = _run_on_gpus(tmp_path, 2, mode, port, transport=transport)
     assert "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
