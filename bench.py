@@ -376,6 +376,8 @@ def gather_legs_one_rank(lib, torch, dist, dev, d_imgs, d_cloud, w, h, nfeatures
             pipe.sync()
             out[name] = round(B / dt, 1)
             pipe.close()
+            if os.environ.get("RGBL_BENCH_VERBOSE"):
+                sys.stderr.write("gather leg %s: %.1f frames/s\n" % (name, out[name]))
         out["cost_of_abi_step"] = round(1.0 - out["abi_step"] / out["none"], 4)
         out["cost_of_torch_step"] = round(1.0 - out["torch_step"] / out["none"], 4)
         out["what"] = ("one rank, collectives inside the timed steps: rgbl_gather_* over RCCL on the scan's low-priority stream (abi) "
@@ -806,7 +808,19 @@ def main():
                                                                          max(10, args.steps // 2))
             except Exception as e:   # the headline stands on its own
                 out["extra"]["gather_rccl_1rank"] = {"error": repr(e)}
-        print(json.dumps(out))
+        line = json.dumps(out)
+    # The JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio when the first communicator
+    # is created, which a pipe only sees when the buffer is flushed - at exit, behind the line, unless it is flushed here.
+    # Every rank flushes, then a barrier, then rank 0 prints.
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
     if comm is not None:
         pipe.close()
         lib.rgbl_comm_destroy(comm)
