@@ -78,6 +78,10 @@ struct rgbl_extractor {
   // device memory
   LevelGeom* d_geom = nullptr;
   FastCell* d_cells = nullptr;  // one record per detection cell of a frame (k_fast_cells)
+  CellGroup* d_groups = nullptr;          // groups of up to 256 consecutive cells of one level (k_compact_cells)
+  std::vector<int> group_off;             // [L + 1] first group of every level
+  int compact_min_batch = 8;              // batches of at least this many frames: FAST cells write their own slots, k_compact_cells
+                                          // builds the dense lists (RGBL_COMPACT=0: never, =1: always)
   GaussTile* d_gtiles = nullptr;  // one record per Gaussian output tile of a frame (k_gauss7)
   ResizeTab *d_xtab = nullptr, *d_ytab = nullptr;
   ResizeGroup* d_xgroups = nullptr;  // k_resize_linear: one record per 4 output columns (index xtab_off / 4 + group)
@@ -337,6 +341,22 @@ int upload_tables(rgbl_extractor* e) {
   RGBL_HIP(hipMemcpy(e->d_gtiles, gtiles.data(), sizeof(GaussTile) * gtiles.size(), hipMemcpyHostToDevice));
   RGBL_TRY(dev_alloc(e, &e->d_cells, cells.size()));
   RGBL_HIP(hipMemcpy(e->d_cells, cells.data(), sizeof(FastCell) * cells.size(), hipMemcpyHostToDevice));
+  {
+    // groups of consecutive cells for k_compact_cells: never across a level (one counter, one list per level) - the launch
+    // ranges of the FAST kernel are whole levels, so they are whole groups as well
+    std::vector<CellGroup> groups;
+    e->group_off.assign(L + 1, 0);
+    for (int l = 0; l < L; ++l) {
+      const LevelGeom& g = e->geom[l];
+      e->group_off[l] = (int)groups.size();
+      for (int ci = 0; ci < g.n_cells; ci += kCompactCells)
+        groups.push_back(CellGroup{(uint32_t)(g.cell_off + ci), (uint32_t)std::min(kCompactCells, g.n_cells - ci)});
+    }
+    e->group_off[L] = (int)groups.size();
+    RGBL_TRY(dev_alloc(e, &e->d_groups, groups.size()));
+    RGBL_HIP(hipMemcpy(e->d_groups, groups.data(), sizeof(CellGroup) * groups.size(), hipMemcpyHostToDevice));
+    if (const char* v = getenv("RGBL_COMPACT")) e->compact_min_batch = atoi(v) ? 1 : 0x7fffffff;
+  }
   RGBL_TRY(dev_alloc(e, &e->d_geom, L));
   RGBL_TRY(dev_alloc(e, &e->d_xtab, xt.size() + 8));
   RGBL_TRY(dev_alloc(e, &e->d_ytab, yt.size()));
@@ -439,13 +459,25 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   // frame is latency-bound and keeps two waves per cell (half the trips per wave).  RGBL_FAST_BS=64 / 128 overrides.
   const bool one_wave = e->fast_waves ? e->fast_waves == 1 : batch >= 8;
   if (one_wave && e->max_cell <= kCellSmall && e->max_cell_w <= 41) { fast = k_fast_cells<kCellSmall, 64, 48>; fast_bs = 64; }
+  // Batches: the cells write their own slots (no reservation on the level's counter: on a 4K frame all resident cells of a
+  // XCD hammered ONE address) and k_compact_cells builds the dense lists behind them, one atomic per 256 cells.  A single
+  // frame keeps the reservation inside the FAST kernel: no contention to speak of, and one launch less on its critical path.
+  const bool compact = e->dense && batch >= e->compact_min_batch;
+  auto level_at = [&](int cell) { for (int l = 0; l < L; ++l) if ((int)e->geom[l].cell_off == cell) return l; return L; };
   auto launch_fast = [&](hipStream_t st, int cell_begin, int cell_end) {
     if (cell_end <= cell_begin) return;
     e->timer.begin("k_fast_cells", st);
     hipLaunchKernelGGL(fast, xcd_grid(e->xcd_map, cell_end - cell_begin, batch), dim3(fast_bs), 0, st, e->d_cells, d_imgs, stride, frame_stride,
                        e->d_pyr, e->pyr_frame, e->cfg.ini_th_fast, e->cfg.min_th_fast, e->d_cellcnt, (size_t)e->cells_frame,
-                       e->d_slots, e->slots_frame, cell_begin, e->d_geom, L, e->d_keys_a, e->keys_frame, e->dense ? e->d_levelcnt : nullptr);
+                       e->d_slots, e->slots_frame, cell_begin, e->d_geom, L, e->d_keys_a, e->keys_frame, (e->dense && !compact) ? e->d_levelcnt : nullptr);
     e->timer.end(st);
+    if (compact) {
+      const int g0 = e->group_off[level_at(cell_begin)], g1 = e->group_off[level_at(cell_end)];   // the ranges are whole levels
+      e->timer.begin("k_compact_cells", st);
+      hipLaunchKernelGGL(k_compact_cells, xcd_grid(e->xcd_map, g1 - g0, batch), dim3(256), 0, st, e->d_groups, e->d_cells, e->d_cellcnt,
+                         (size_t)e->cells_frame, e->d_slots, e->slots_frame, e->d_geom, L, e->d_keys_a, e->keys_frame, e->d_levelcnt, g0);
+      e->timer.end(st);
+    }
   };
   auto launch_gauss = [&](hipStream_t st, int tile_begin, int tile_end) {
     if (tile_end <= tile_begin) return;

@@ -131,6 +131,24 @@ def test_extractor_fast_kernel_waves_per_cell(emu_lib, bs):
         os.environ.pop("RGBL_FAST_BS", None)
 
 
+@pytest.mark.parametrize("compact", ["1", "0"])
+def test_extractor_cell_compaction_kernel(emu_lib, compact):
+    # batches: the FAST cells write their own slots, k_compact_cells builds the level's dense candidate list (one reservation
+    # per 256 cells); RGBL_COMPACT=1 forces it for single frames too, =0 keeps the per-cell reservation inside k_fast_cells
+    os.environ["RGBL_COMPACT"] = compact
+    try:
+        pc.check_extractor(emu_lib, 1241, 376, 2000, frames=(0,), seq=5, stages=True)
+        pc.check_extractor_batch(emu_lib, 400, 300, 500, 8)
+        # 106 cell columns of 36 px (the last two of every row are skipped, ORBextractor.cc:810-822), 424 cells on level 0: two groups
+        pc.check_extractor(emu_lib, 3840, 280, 1500, frames=(0,), nlevels=2, seq=12, stages=True)
+        pc.check_extractor_low_contrast(emu_lib)
+        pc.check_extractor_dense_corners(emu_lib)
+        pc.check_extractor_empty_root(emu_lib)
+        pc.check_extractor_edge_cases(emu_lib)
+    finally:
+        os.environ.pop("RGBL_COMPACT", None)
+
+
 def test_extractor_quadtree_empty_root_nodes(emu_lib):
     pc.check_extractor_empty_root(emu_lib)
 

@@ -71,6 +71,24 @@ def test_extractor_fast_kernel_waves_per_cell(gpu_lib, bs):
         os.environ.pop("RGBL_FAST_BS", None)
 
 
+@pytest.mark.parametrize("compact", ["1", "0"])
+def test_extractor_cell_compaction_kernel(gpu_lib, compact):
+    # batches: the FAST cells write their own slots, k_compact_cells builds the level's dense candidate list (one reservation
+    # per 256 cells); RGBL_COMPACT=1 forces it for single frames too, =0 keeps the per-cell reservation inside k_fast_cells
+    os.environ["RGBL_COMPACT"] = compact
+    try:
+        pc.check_extractor(gpu_lib, 1241, 376, 2000, frames=(0,), seq=5, stages=True)
+        pc.check_extractor_batch(gpu_lib, 400, 300, 500, 8)
+        # 106 cell columns of 36 px (the last two of every row are skipped, ORBextractor.cc:810-822), 424 cells on level 0: two groups
+        pc.check_extractor(gpu_lib, 3840, 280, 1500, frames=(0,), nlevels=2, seq=12, stages=True)
+        pc.check_extractor_low_contrast(gpu_lib)
+        pc.check_extractor_dense_corners(gpu_lib)
+        pc.check_extractor_empty_root(gpu_lib)
+        pc.check_extractor_edge_cases(gpu_lib)
+    finally:
+        os.environ.pop("RGBL_COMPACT", None)
+
+
 def test_extractor_edge_cases(gpu_lib):
     pc.check_extractor_edge_cases(gpu_lib)
     pc.check_extractor_empty_root(gpu_lib)
