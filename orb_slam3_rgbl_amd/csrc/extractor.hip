@@ -517,8 +517,11 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       if (narrow) hipLaunchKernelGGL((k_octree<kOctNarrow, 512>), grid, dim3(kOctNarrow), 0, st, e->d_geom, L, ob, level_begin);
       else hipLaunchKernelGGL((k_octree<kOctWide, 512>), grid, dim3(kOctWide), 0, st, e->d_geom, L, ob, level_begin);
     } else {
-      if (narrow) hipLaunchKernelGGL((k_octree<kOctNarrow, 2048>), grid, dim3(kOctNarrow), 0, st, e->d_geom, L, ob, level_begin);
-      else hipLaunchKernelGGL((k_octree<kOctWide, 2048>), grid, dim3(kOctWide), 0, st, e->d_geom, L, ob, level_begin);
+      // 2048 nodes = 147 KB of LDS: ONE workgroup per CU whatever its width, so it takes all 16 wave slots of the CU - a 4K
+      // level-0 problem is ~160 k candidates per pass (round 4: 512 -> 1024 work-items; RGBL_OCTREE_WG=256 / 512 still pin the others)
+      if (e->octree_wg == kOctNarrow) hipLaunchKernelGGL((k_octree<kOctNarrow, 2048>), grid, dim3(kOctNarrow), 0, st, e->d_geom, L, ob, level_begin);
+      else if (e->octree_wg == kOctWide) hipLaunchKernelGGL((k_octree<kOctWide, 2048>), grid, dim3(kOctWide), 0, st, e->d_geom, L, ob, level_begin);
+      else hipLaunchKernelGGL((k_octree<1024, 2048>), grid, dim3(1024), 0, st, e->d_geom, L, ob, level_begin);
     }
     e->timer.end(st);
   };
