@@ -694,6 +694,42 @@ def test_reference_compute_stereo_matches_agrees_with_oracle(refframe, w, h, nf,
     assert (our >= 0).sum() > 100  # the case must produce matches
 
 
+def test_reference_compute_stereo_matches_on_a_real_stereo_pair(refframe):
+    """Row f1 on real imagery: the rectified Middlebury 'Motorcycle' pair that ships with scikit-image, read
+    in place - the reference's own Frame::ComputeStereoMatches lines on the reference's own extractor against the oracle, bit
+    for bit, and both against the pair's ground-truth disparity (the function does what it is meant to do on a photograph)."""
+    import real_images as R
+    lrgb, rrgb, gt = R.stereo_pair()
+    left, right = O.cvt_gray(lrgb, True), O.cvt_gray(rrgb, True)
+    h, w = left.shape
+    nf, ini, mn, mb, mbf = 1500, 20, 7, R.MOTORCYCLE_MB, R.MOTORCYCLE_MBF
+    cap = nf * 2 + 4096
+    kl, kr = np.zeros(cap, O.KP_DTYPE), np.zeros(cap, O.KP_DTYPE)
+    dl, dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+    ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    nl, nr = C.c_int(0), C.c_int(0)
+    rc = refframe.ref_stereo_matches(left.ctypes.data, right.ctypes.data, w, h, left.strides[0], nf, 1.2, 8, ini, mn, mb, mbf,
+                                     kl.ctypes.data, dl.ctypes.data, kr.ctypes.data, dr.ctypes.data, cap, C.byref(nl), C.byref(nr),
+                                     ur.ctypes.data, dp.ctypes.data)
+    assert rc == 0
+    nl, nr = nl.value, nr.value
+    ol, orr = O.Extractor(nf, 1.2, 8, ini, mn), O.Extractor(nf, 1.2, 8, ini, mn)
+    okl, odl, _ = ol(left)
+    okr, odr, _ = orr(right)
+    assert len(okl) == nl and len(okr) == nr
+    assert np.array_equal(dl[:nl], odl) and np.array_equal(dr[:nr], odr)
+    our, odp = O.stereo_matches(ol, orr, okl, odl, okr, odr, mb, mbf)
+    assert np.array_equal(ur[:nl].view(np.uint32), our.view(np.uint32)), "mvuRight"
+    assert np.array_equal(dp[:nl].view(np.uint32), odp.view(np.uint32)), "mvDepth"
+    m = our >= 0
+    assert m.sum() > 400
+    if gt is not None:
+        truth = gt[np.round(okl["y"][m]).astype(int), np.round(okl["x"][m]).astype(int)]
+        known = np.isfinite(truth)
+        err = np.abs((okl["x"][m] - our[m])[known] - truth[known])
+        assert np.median(err) < 0.5 and (err < 2.0).mean() > 0.9     # sub-pixel on a photograph: 0.27 px median here
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # The two other RGB-L settings files the reference ships (Examples/RGB-L/KITTI04-12.yaml, KITTIxx-03.yaml: KITTI sequences
 # 03 - 12) still carry the stale key LiDAR.MethodInverseDilation.KernelSize; DepthModule.cc:566-582 asks for KernelSize_u /
