@@ -573,6 +573,11 @@ def main():
     ap.add_argument("--pg", action="store_true",
                     help="N = 1: create the one-rank process group / RCCL communicator anyway and gather (default --gather step), so "
                          "that the collectives - and with --transport torch ProcessGroupNCCL's internal stream - are inside the timed steps")
+    ap.add_argument("--shard", default="sequences", choices=["sequences", "chunks"],
+                    help="sequences: one independent sequence per rank (BASELINE configs[3], the default).  chunks: ONE long sequence "
+                         "of world x batch frames cut into contiguous chunks (sharding.frame_chunk), every rank also extracts the "
+                         "frame behind its chunk (a one-frame halo, recomputed, never communicated) so that its last frame is "
+                         "matched against its true successor - SURVEY 8(e) 'single long sequence'")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -621,12 +626,22 @@ def main():
 
     # ---- synthetic input, one independent sequence per rank (BASELINE configs[3]: sequences shard over GPUs)
     # constant_density: 1200 shapes per frame area whatever the batch (the scene grows with the sequence length)
-    seq = synth.Sequence(sharding.sequences_of_rank(world, world, rank)[0], w, h, n_frames=B, constant_density=not os.environ.get("RGBL_BENCH_SPARSE"))
-    frames = np.stack([seq.frame(i) for i in range(B)])
+    halo = 1 if args.shard == "chunks" else 0
+    if halo:
+        # one sequence for all ranks; rank r owns the frames [r B, (r + 1) B) and recomputes the first frame of the next chunk
+        # (the last rank wraps around to frame 0, so that every rank does the same amount of work)
+        total = world * B
+        seq = synth.Sequence(0, w, h, n_frames=total, constant_density=not os.environ.get("RGBL_BENCH_SPARSE"))
+        first, last, _ = sharding.frame_chunk(total, world, rank)
+        assert last - first == B
+        frames = np.stack([seq.frame((first + i) % total) for i in range(B + 1)])
+    else:
+        seq = synth.Sequence(sharding.sequences_of_rank(world, world, rank)[0], w, h, n_frames=B, constant_density=not os.environ.get("RGBL_BENCH_SPARSE"))
+        frames = np.stack([seq.frame(i) for i in range(B)])
     n_scans = min(B, 8)
     scans = [synth.lidar_scan(rank * 1000 + i, n_az=n_az) for i in range(n_scans)]
     n_points = scans[0].shape[1]
-    cloud = np.stack([scans[i % n_scans] for i in range(B)])  # [B, 4, N]
+    cloud = np.stack([scans[i % n_scans] for i in range(B + halo)])  # [B (+ halo), 4, N]
     if args.workload == "kitti":
         K = synth.KITTI_K
     else:
@@ -641,7 +656,7 @@ def main():
     pipe = FrontEndPipeline(lib, torch, dev, w, h, nfeatures, proj, n_points, B, levels=LEVELS, scale=SCALE, ini_th=INI_TH,
                             min_th=MIN_TH, world=world, rank=rank, gather=gather, serial=args.serial,
                             log_steps=args.steps + args.warmup, lanes=args.lanes, transport=args.transport, comm=comm,
-                            loopback=(comm is not None and world == 1))
+                            loopback=(comm is not None and world == 1), halo=halo)
     ex, dm, mt, cap = pipe.ex, pipe.dm, pipe.mt, pipe.cap
     d_imgs = torch.from_numpy(frames).to(dev)
     d_cloud = torch.from_numpy(cloud).to(dev)
@@ -692,7 +707,7 @@ def main():
             od, our, _, _ = O.depth(P, cloud[fi], w, h, np.stack([okps["x"], okps["y"]], 1), okps["x"], want_maps=False)
             ok &= np.array_equal(d_depth[fi, :n].cpu().numpy().view(np.uint32), od.view(np.uint32))
             ok &= np.array_equal(d_uright[fi, :n].cpu().numpy().view(np.uint32), our.view(np.uint32))
-            nxt = (fi + 1) % B
+            nxt = (fi + 1) % len(frames)     # chunks: the last owned frame meets the halo frame
             ndesc = orc(frames[nxt])[1]
             obi, obd, osd = O.hamming_bf(odesc, ndesc)
             ok &= np.array_equal(d_bi[fi, :n].cpu().numpy(), obi) and np.array_equal(d_bd[fi, :n].cpu().numpy(), obd)
@@ -784,7 +799,8 @@ def main():
                        "match": "Hamming brute force, frame i vs i+1", "upsampling": "InverseDilation Diamond 5",
                        "inputs": "resident in HBM",
                        "frames": "synth.Sequence, %s" % ("shape count of ONE frame for the whole scene (RGBL_BENCH_SPARSE: the pre-correction input)" if os.environ.get("RGBL_BENCH_SPARSE") else "constant corner density: 1200 shapes per frame area, ~8.6 k FAST candidates on level 0"),
-                       "parallelism": "frames/sequences sharded, %d rank(s)" % world,
+                       "parallelism": ("one sequence of %d frames in contiguous chunks + one-frame halo, %d rank(s)" % (world * B, world)) if halo
+                                      else "frames/sequences sharded, %d rank(s)" % world,
                        "gather_transport": None if gather == "none" else
                                            ("C ABI rgbl_gather_* over RCCL (ncclAllGather + grouped ncclSend/ncclRecv) on the pipeline's low-priority stream"
                                             if pipe.transport == "abi" and comm is not None else

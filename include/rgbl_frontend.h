@@ -172,6 +172,11 @@ int rgbl_stereo_matches_batch_device(rgbl_extractor* left, rgbl_extractor* right
  * per (frame, level) workgroup; this copies them out. */
 int rgbl_extractor_debug_stamps(rgbl_extractor* h, unsigned long long* out, int count);
 
+/* Self-test on the device: the hand-written instruction wrappers of the kernels (v_mul_u32_u24 with a scalar operand,
+ * v_addc_co_u32 with an SGPR mask, global_load_lds_dwordx4 from unaligned sources) against their plain expressions on n
+ * random inputs in partially active waves.  RGBL_OK, or RGBL_ERR_HIP with the first mismatch in rgbl_last_error(). */
+int rgbl_selftest_wrappers(int device, int n, unsigned seed);
+
 /* Stream control + per-kernel timing (HIP events on the launch stream) for bench.py. */
 int rgbl_extractor_set_stream(rgbl_extractor* h, void* hip_stream /* hipStream_t, NULL = own */);
 void* rgbl_extractor_stream(rgbl_extractor* h); /* hipStream_t currently used by the handle */

@@ -132,6 +132,7 @@ SYMBOLS = {
     "rgbl_stereo_matches": (_I, [_V, _V, _V, _V, _I, _V, _V, _I, _F, _F, _V, _V]),
     "rgbl_stereo_matches_batch_device": (_I, [_V, _V, _I, _V, _V, _V, _V, _V, _V, _I, _F, _F, _V, _V]),
     "rgbl_extractor_debug_stamps": (_I, [_V, _V, _I]),
+    "rgbl_selftest_wrappers": (_I, [_I, _I, C.c_uint]),
     "rgbl_extractor_set_stream": (_I, [_V, _V]),
     "rgbl_extractor_profile": (_I, [_V, _I]),
     "rgbl_extractor_profile_read": (_I, [_V, _V, _V, _V, _I]),

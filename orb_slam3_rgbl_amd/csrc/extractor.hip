@@ -51,6 +51,8 @@ struct rgbl_extractor {
   int L = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
   hipStream_t aux_stream = nullptr;  // the Gaussian working images only depend on the pyramid: they overlap FAST + quad-tree
+  hipStream_t lvl_stream = nullptr;  // single frames: FAST + quad-tree of the levels 1 - 2 start behind their own resizes (RGBL_LEVEL_SPLIT=0: off)
+  int level_split = 3;               // ... the main stream keeps the levels from this one on
   hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_fast0 = nullptr, ev_desc0 = nullptr, ev_r = nullptr, ev_fb = nullptr;
   int split_pyr = 0;  // RGBL_SPLIT_PYR=k (opt-in, batches): the pyramid levels k .. L - 1 and their FAST cells leave the main chain
   KernelTimer timer;
@@ -63,6 +65,7 @@ struct rgbl_extractor {
   hipStream_t graph_stream = nullptr;
   bool graph_ok = true;  // RGBL_GRAPH=0 or a failed capture switch the replay off
   int octree_wg = 0;  // 0 = choose per launch; RGBL_OCTREE_WG=256|512 pins the quad-tree workgroup width (tuning / tests)
+  bool octree_ldskeys = true;  // single frames: k_octree keeps the candidate lists in LDS (RGBL_OCTREE_LDSKEYS=0 switches it off)
   int octree_ncap = 0;  // LDS node capacity of the label-based quad-tree kernel (512 / 2048); 0 = key-moving kernel on global lists
   int max_cell = 0, max_cell_w = 0;  // largest detection-cell side / width over the levels: select the k_fast_cells instantiation
   int fast_waves = 0;  // waves per detection cell of k_fast_cells: 0 = by batch size, RGBL_FAST_BS=64 / 128 force 1 / 2
@@ -514,7 +517,10 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       if (narrow) hipLaunchKernelGGL(k_octree_moving<kOctNarrow>, grid, dim3(kOctNarrow), 0, st, e->d_geom, L, ob, level_begin);
       else hipLaunchKernelGGL(k_octree_moving<kOctWide>, grid, dim3(kOctWide), 0, st, e->d_geom, L, ob, level_begin);
     } else if (e->octree_ncap == 512) {
-      if (narrow) hipLaunchKernelGGL((k_octree<kOctNarrow, 512>), grid, dim3(kOctNarrow), 0, st, e->d_geom, L, ob, level_begin);
+      // a handful of problems (a single frame): candidate lists in LDS, 1024 work-items each (octree_labels.h: KEYCAP)
+      if (e->octree_ldskeys && !e->octree_wg && (long)(level_end - level_begin) * batch <= 64)
+        hipLaunchKernelGGL((k_octree<1024, 512, kOctKeysLds>), grid, dim3(1024), 0, st, e->d_geom, L, ob, level_begin);
+      else if (narrow) hipLaunchKernelGGL((k_octree<kOctNarrow, 512>), grid, dim3(kOctNarrow), 0, st, e->d_geom, L, ob, level_begin);
       else hipLaunchKernelGGL((k_octree<kOctWide, 512>), grid, dim3(kOctWide), 0, st, e->d_geom, L, ob, level_begin);
     } else {
       // 2048 nodes = 147 KB of LDS: ONE workgroup per CU whatever its width, so it takes all 16 wave slots of the CU - a 4K
@@ -570,6 +576,36 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       launch_fast(s, cells0, e->geom[sp].cell_off);
       RGBL_HIP(hipStreamWaitEvent(s, e->ev_fb, 0));
       launch_octree(s, 1, L);
+      RGBL_HIP(hipStreamWaitEvent(s, e->ev_fast0, 0));
+      RGBL_HIP(hipStreamWaitEvent(s, e->ev_blur, 0));
+    } else if (overlap && batch < 8 && e->level_split >= 2 && e->level_split < L) {
+      // A single frame is a race of dependent chains, and the longest one sets its latency.  Until round 4: main stream =
+      // 7 resizes -> FAST of ALL upper levels -> their quad-trees (the level-1 problem: 53 us) -> descriptors.  Level 1 exists
+      // after ONE resize: the levels 1 .. k - 1 (k = 3) now take a third stream - FAST and quad-tree behind their own resizes -
+      // while the main stream finishes the pyramid and handles the small levels k .. L - 1; level 0 stays on the auxiliary
+      // stream.  Critical path 29 + 14 + 55 us -> max(level 0: 14 + quad-tree, levels 1 - 2: 8 + 12 + quad-tree, rest: 29 + 8 + 32).
+      const int k = e->level_split;
+      hipStream_t ls = e->lvl_stream;
+      RGBL_HIP(hipEventRecord(e->ev_start, s));
+      RGBL_HIP(hipStreamWaitEvent(bs, e->ev_start, 0));
+      launch_fast(bs, 0, cells0);
+      launch_gauss(bs, 0, tiles0);
+      launch_octree(bs, 0, 1);
+      RGBL_HIP(hipEventRecord(e->ev_fast0, bs));
+      for (int l = 1; l < k; ++l) launch_resize(s, l);
+      RGBL_HIP(hipEventRecord(e->ev_r, s));
+      RGBL_HIP(hipStreamWaitEvent(ls, e->ev_r, 0));
+      launch_fast(ls, cells0, e->geom[k].cell_off);
+      launch_octree(ls, 1, k);
+      RGBL_HIP(hipEventRecord(e->ev_fb, ls));
+      for (int l = k; l < L; ++l) launch_resize(s, l);
+      RGBL_HIP(hipEventRecord(e->ev_pyr, s));
+      RGBL_HIP(hipStreamWaitEvent(bs, e->ev_pyr, 0));
+      launch_gauss(bs, tiles0, e->blur_tiles.tile_off[L]);
+      RGBL_HIP(hipEventRecord(e->ev_blur, bs));
+      launch_fast(s, e->geom[k].cell_off, e->cells_frame);
+      launch_octree(s, k, L);
+      RGBL_HIP(hipStreamWaitEvent(s, e->ev_fb, 0));
       RGBL_HIP(hipStreamWaitEvent(s, e->ev_fast0, 0));
       RGBL_HIP(hipStreamWaitEvent(s, e->ev_blur, 0));
     } else {
@@ -702,6 +738,8 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
   rgbl_extractor* e = new rgbl_extractor;
   e->cfg = *cfg;
   if (const char* v = getenv("RGBL_GRAPH")) e->graph_ok = atoi(v) != 0;
+  if (const char* v = getenv("RGBL_OCTREE_LDSKEYS")) e->octree_ldskeys = atoi(v) != 0;
+  if (const char* v = getenv("RGBL_LEVEL_SPLIT")) e->level_split = atoi(v);
   if (const char* v = getenv("RGBL_OCTREE_WG")) { const int wg = atoi(v); if (wg == kOctNarrow || wg == kOctWide) e->octree_wg = wg; }
   e->device = device;
   int rc = build_geometry(e);
@@ -721,7 +759,7 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
   // dense candidate lists need the label-based quad-tree kernel (order-free) and the per-cell FAST kernel (RGBL_DENSE=0: cell slots)
   if (rc == RGBL_OK) e->dense = e->octree_ncap != 0 && !(getenv("RGBL_DENSE") && getenv("RGBL_DENSE")[0] == '0');
   if (rc == RGBL_OK) rc = alloc_scratch(e);
-  if (rc == RGBL_OK && (hipStreamCreate(&e->own_stream) != hipSuccess || hipStreamCreate(&e->aux_stream) != hipSuccess ||
+  if (rc == RGBL_OK && (hipStreamCreate(&e->own_stream) != hipSuccess || hipStreamCreate(&e->aux_stream) != hipSuccess || hipStreamCreate(&e->lvl_stream) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming) != hipSuccess ||
@@ -751,6 +789,7 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
 #endif
   if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
+  if (e->lvl_stream) { (void)hipStreamSynchronize(e->lvl_stream); (void)hipStreamDestroy(e->lvl_stream); }
   if (e->ev_pyr) (void)hipEventDestroy(e->ev_pyr);
   if (e->ev_blur) (void)hipEventDestroy(e->ev_blur);
   if (e->h_pinned) (void)hipHostFree(e->h_pinned);
@@ -1404,6 +1443,61 @@ int rgbl_extractor_profile_read(rgbl_extractor* e, const char** names, double* t
     if (launches) launches[i] = e->timer.count[i];
   }
   return n;
+}
+
+// Self-test of the hand-written instruction wrappers on the device (see k_selftest_wrappers): n random inputs, every result
+// compared with its plain expression on the host.  RGBL_OK, or RGBL_ERR_HIP with the first mismatch in rgbl_last_error().
+int rgbl_selftest_wrappers(int device, int n, unsigned seed) {
+  using namespace rgbl;
+  if (n < 1 || n > (1 << 20)) { set_error("selftest: 1 <= n <= 2^20"); return RGBL_ERR_INVALID; }
+  if (rgbl_device_count() <= device || device < 0) { set_error("no usable HIP device %d (this library has no CPU fallback)", device); return RGBL_ERR_NO_DEVICE; }
+  RGBL_HIP(hipSetDevice(device));
+  std::vector<uint32_t> a(n), fl(n);
+  std::vector<uint8_t> src((size_t)16 * n + 32);
+  uint32_t st = seed * 2654435761u + 12345u;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return st ^ (st >> 15); };
+  for (int i = 0; i < n; ++i) { a[i] = rnd(); fl[i] = rnd(); }
+  for (auto& v : src) v = (uint8_t)(rnd() >> 9);
+  const uint32_t b = rnd() & 0xffffffu;
+  uint32_t *d_a = nullptr, *d_fl = nullptr, *d_mul = nullptr;
+  int* d_add = nullptr;
+  uint8_t *d_src = nullptr, *d_dma = nullptr;
+  std::vector<uint32_t> mul(n, 0xdeadbeefu);
+  std::vector<int> add(n, 0x5a5a5a5a);
+  std::vector<uint8_t> dma((size_t)16 * n, 0);
+  int rc = RGBL_OK;
+  auto run = [&]() -> int {
+    RGBL_HIP(hipMalloc(&d_a, sizeof(uint32_t) * n)); RGBL_HIP(hipMalloc(&d_fl, sizeof(uint32_t) * n));
+    RGBL_HIP(hipMalloc(&d_mul, sizeof(uint32_t) * n)); RGBL_HIP(hipMalloc(&d_add, sizeof(int) * n));
+    RGBL_HIP(hipMalloc(&d_src, src.size())); RGBL_HIP(hipMalloc(&d_dma, dma.size()));
+    RGBL_HIP(hipMemcpy(d_a, a.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    RGBL_HIP(hipMemcpy(d_fl, fl.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    RGBL_HIP(hipMemcpy(d_src, src.data(), src.size(), hipMemcpyHostToDevice));
+    RGBL_HIP(hipMemcpy(d_mul, mul.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    RGBL_HIP(hipMemcpy(d_add, add.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest_wrappers, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) nullptr, d_a, b, d_fl, d_src, d_mul, d_add, d_dma, n);
+    RGBL_HIP(hipGetLastError());
+    RGBL_HIP(hipMemcpy(mul.data(), d_mul, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    RGBL_HIP(hipMemcpy(add.data(), d_add, sizeof(int) * n, hipMemcpyDeviceToHost));
+    RGBL_HIP(hipMemcpy(dma.data(), d_dma, dma.size(), hipMemcpyDeviceToHost));
+    return RGBL_OK;
+  };
+  rc = run();
+  for (void* p : {(void*)d_a, (void*)d_fl, (void*)d_mul, (void*)d_add, (void*)d_src, (void*)d_dma}) if (p) (void)hipFree(p);
+  if (rc != RGBL_OK) return rc;
+  for (int i = 0; i < n; ++i) {
+    const bool active = (a[i] & 3u) != 0u;
+    const uint32_t want_mul = active ? (a[i] & 0xffffffu) * b : 0xdeadbeefu;
+    const int want_add = active ? (int)a[i] + (int)(fl[i] & 1u) : 0x5a5a5a5a;
+    if (mul[i] != want_mul) { set_error("selftest: mul24(%#x, %#x) = %#x, expected %#x (lane %d)", a[i] & 0xffffffu, b, mul[i], want_mul, i); return RGBL_ERR_HIP; }
+    if (add[i] != want_add) { set_error("selftest: add_flag(%d, %u) = %d, expected %d (lane %d)", (int)a[i], fl[i] & 1u, add[i], want_add, i); return RGBL_ERR_HIP; }
+    const bool moved = (i % 64) % 5 != 4;
+    for (int k = 0; k < 16; ++k) {
+      const uint8_t want = moved ? src[(size_t)16 * i + (i & 3) + k] : (uint8_t)0xee;
+      if (dma[(size_t)16 * i + k] != want) { set_error("selftest: lds_dma16 lane %d byte %d = %#x, expected %#x", i, k, dma[(size_t)16 * i + k], want); return RGBL_ERR_HIP; }
+    }
+  }
+  return RGBL_OK;
 }
 
 #ifdef RGBL_EMU

@@ -679,6 +679,31 @@ __global__ __launch_bounds__(BS) void k_fast_cells(const FastCell* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_selftest_wrappers: the hand-written instruction wrappers of this file against their plain expressions (the CPU
+// emulation replaces them by plain C, so only a run on the hardware says anything about the code that ships): mul24
+// (v_mul_u32_u24 with a scalar second operand), add_flag (v_addc_co_u32 with a 64-bit SGPR mask as carry-in), lds_dma16
+// (global_load_lds_dwordx4 from unaligned sources), each in waves with some lanes switched off.
+__global__ __launch_bounds__(256) void k_selftest_wrappers(const uint32_t* __restrict__ a, uint32_t b, const uint32_t* __restrict__ flags,
+                                                            const uint8_t* __restrict__ src, uint32_t* __restrict__ out_mul,
+                                                            int* __restrict__ out_add, uint8_t* __restrict__ out_dma, int n) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_buf[256 * 16];
+  const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+  const uint32_t av = i < n ? a[i] : 0u;
+  const bool active = i < n && (av & 3u) != 0u;    // a quarter of the lanes sits out
+  for (int k = tid; k < 256 * 16 / 4; k += 256) reinterpret_cast<uint32_t*>(s_buf)[k] = 0xeeeeeeeeu;
+  __syncthreads();
+  const unsigned long long m = wave_ballot(i < n && (flags[i < n ? i : 0] & 1u) != 0u);   // computed by the whole wave
+  if (active) {
+    out_mul[i] = mul24(av & 0xffffffu, b);
+    out_add[i] = add_flag((int)av, m);
+  }
+  if (i < n && (lane_id() % 5) != 4) lds_dma16(src + (size_t)16 * i + (i & 3), s_buf + wave_id() * 1024);   // sources 0 - 3 bytes off alignment
+  __syncthreads();
+  if (i < n)
+    for (int k = 0; k < 16; ++k) out_dma[(size_t)16 * i + k] = s_buf[16 * tid + k];
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_compact_cells (round 4): the cells' own candidate slots -> the level's dense candidate list, for batches.
 // k_fast_cells used to reserve every cell's range of that list with one returning atomicAdd on the (frame, level) counter.
 // With the XCD-aware launch a XCD's ~670 resident cells belong to ONE frame, on a 4K frame to one LEVEL: all their atomics
@@ -1191,6 +1216,7 @@ __device__ __forceinline__ void block_split(const QNode& nd, uint32_t* keys_a, u
 // chain (fewer strides per pass) while a narrower one lets more problems share a CU (VGPRs allow 4 waves per SIMD):
 // kOctWide when the batch cannot fill the chip anyway, kOctNarrow when there are plenty of (level, frame) problems.
 constexpr int kOctWide = 512, kOctNarrow = 256;
+constexpr int kOctKeysLds = 12288;   // single-frame quad-tree: candidate lists up to this long live in LDS (48 + 24 KB next to the 37 KB of nodes)
 constexpr int kSortLds = 2048;     // largest expandable-node list sorted in LDS by the whole workgroup
 constexpr int kSortRanges = 160;   // > kSortLds / 17: pending ranges of more than 16 elements are disjoint
 

@@ -177,9 +177,16 @@ constexpr int kQtBatch = 4;   // keys per work-item and trip of the passes over 
 
 template <int NCAP> struct QtRanges { static constexpr int value = NCAP / 16 + 16; };  // pending ranges hold > 16 elements and are disjoint
 
-template <int BS, int NCAP>
+// KEYCAP > 0 (round 4, single frames): candidate lists of up to KEYCAP keys are copied into LDS by the first pass, together
+// with their labels, and every later pass reads them there.  ONE (level, frame) problem is a chain of ~8 passes over its keys,
+// and with only 8 problems on the GPU nothing hides a pass's global-memory round trips (~17 keys per work-item in batches of
+// 4: five dependent L2 latencies per pass, 24 of the 62 us of a KITTI level-0 problem).  Occupancy does not matter there, so
+// the workgroup also takes 1024 work-items.  Batches keep the global lists (37 KB of LDS, four problems per CU).
+template <int BS, int NCAP, int KEYCAP = 0>
 __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geom, int n_levels, OctreeBufs b, int level_begin) {
   static_assert(NCAP <= 0x4000, "list positions travel in 15 bits of the ctab entries");
+  __shared__ uint32_t s_keys[KEYCAP > 0 ? KEYCAP : 1];
+  __shared__ uint16_t s_label[KEYCAP > 0 ? KEYCAP : 2];
   using Ranges = SortRangesT<QtRanges<NCAP>::value>;
   __shared__ QtStore<NCAP> S;
   __shared__ uint32_t s_scan[32];
@@ -289,17 +296,21 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
     if (C > g.key_cap) C = g.key_cap;
     __syncthreads();  // the root nodes and the counter copies are set; everybody has read the counter
     if (tid == 0) { b.level_cnt_last[(size_t)f * n_levels + l] = C; b.level_cnt[(size_t)f * n_levels + l] = 0; }
+    const uint32_t* kin = keys;   // the list k_fast_cells left in global memory
+    const bool in_lds = KEYCAP > 0 && C <= (uint32_t)KEYCAP;   // workgroup-uniform
+    if (in_lds) { keys = s_keys; label = s_label; }            // every later pass works on the LDS copy
     for (uint32_t i0 = 0; i0 < C; i0 += BS * kQtBatch) {
       uint32_t key[kQtBatch];
 #pragma unroll
       for (int u = 0; u < kQtBatch; ++u) {
         const uint32_t i = i0 + (uint32_t)(u * BS + tid);
-        key[u] = i < C ? keys[i] : 0xffffffffu;
+        key[u] = i < C ? kin[i] : 0xffffffffu;
       }
 #pragma unroll
       for (int u = 0; u < kQtBatch; ++u)
         if (key[u] != 0xffffffffu) {
           const int r = root_of(key[u]);
+          if (in_lds) keys[i0 + (uint32_t)(u * BS + tid)] = key[u];
           label[i0 + (uint32_t)(u * BS + tid)] = (uint16_t)r;
           qt_count_rep(s_rep0, r * 4 + qt_quadrant(key[u], S.mid[0][r]), rlog0);
         }

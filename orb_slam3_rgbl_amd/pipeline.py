@@ -141,9 +141,14 @@ class _Lane:
 class FrontEndPipeline:
     def __init__(self, lib, torch, dev, w, h, nfeatures, proj, n_points, batch, levels=8, scale=1.2, ini_th=12, min_th=7,
                  world=1, rank=0, gather=None, serial=False, keep_steps=0, log_steps=1, lanes=1,
-                 sparse_depth=False, transport=None, comm=None, loopback=False):
+                 sparse_depth=False, transport=None, comm=None, loopback=False, halo=0):
         self.lib, self.torch, self.dev = lib, torch, dev
         self.w, self.h, self.B, self.n_points = w, h, batch, n_points
+        # halo = 1: ONE long sequence cut into contiguous chunks (sharding.frame_chunk): the rank owns `batch` frames per step and
+        # also extracts the frame behind them - the first one of the next rank's chunk - so that its last frame can be matched
+        # against its successor without any communication.  The halo frame is computed twice, gathered never (the next rank owns it).
+        self.halo = int(halo)
+        self.Bh = batch + self.halo
         # one rank and nobody asked for a gather: none (no buffers, no pack, no host event per step - ADVICE r3)
         gather = gather or ("step" if world > 1 else "none")
         self.world, self.rank, self.gather = world, rank, gather
@@ -159,7 +164,7 @@ class FrontEndPipeline:
         # leave most vector-issue slots idle) runs next to the head of step k + 1 (pyramid, FAST, Gaussian: issue-bound)
         n_lanes = 1 if serial else max(1, min(lanes, 2))
         wrap_low = gather != "none" and n_lanes == 1 and transport == "torch" and dev.type == "cuda"
-        self.lanes = [_Lane(lib, index, w, h, nfeatures, proj, n_points, batch, levels, scale, ini_th, min_th, serial,
+        self.lanes = [_Lane(lib, index, w, h, nfeatures, proj, n_points, self.Bh, levels, scale, ini_th, min_th, serial,
                             "two-lanes" if (gather != "none" and n_lanes > 1) else gather, shared_low=wrap_low)
                       for _ in range(n_lanes)]
         self.ex, self.dm, self.mt = self.lanes[0].ex, self.lanes[0].dm, self.lanes[0].mt
@@ -171,9 +176,9 @@ class FrontEndPipeline:
             # one stream for all handles and per-kernel HIP-event brackets on: every launch of the run is serialised - the
             # mode `rocprofv3 --kernel-trace --stats` is recorded in (profiles/)
             self.profile(True)
-        self.sets = [OutSet(lib, torch, dev, batch, self.cap) for _ in range(2)]
+        self.sets = [OutSet(lib, torch, dev, self.Bh, self.cap) for _ in range(2)]
         self.pair_a = torch.arange(batch, dtype=torch.int32, device=dev)
-        self.pair_b = (self.pair_a + 1) % batch
+        self.pair_b = (self.pair_a + 1) % self.Bh    # with a halo frame the last owned frame meets its true successor
         self.step_no = 0
         # ---- gather state
         self.cuda = dev.type == "cuda"
@@ -247,7 +252,7 @@ class FrontEndPipeline:
         return C.c_void_p(t.data_ptr())
 
     def step(self):
-        lib, p, B, w, h, cap = self.lib, self._p, self.B, self.w, self.h, self.cap
+        lib, p, B, w, h, cap = self.lib, self._p, self.Bh, self.w, self.h, self.cap   # extraction and depth include the halo frame
         o = self.sets[self.step_no % 2]
         ln = self.lanes[self.step_no % len(self.lanes)]
         # this set's readers of two steps ago must be done before the extractor overwrites it
@@ -264,7 +269,7 @@ class FrontEndPipeline:
         L.check(lib, lib.rgbl_depth_gather_batch_device(ln.dm.h, B, w, h, p(o.kp), p(o.n), cap, None, p(o.depth), p(o.uright)))
         L.check(lib, lib.rgbl_event_record(o.ev["depth_done"], ln.s_dm))
         L.check(lib, lib.rgbl_event_wait(ln.s_mt, o.ev["extracted"]))
-        L.check(lib, lib.rgbl_hamming_bf_batch_device(ln.mt.h, p(o.desc), p(o.n), cap, p(self.pair_a), p(self.pair_b), B, p(o.bi),
+        L.check(lib, lib.rgbl_hamming_bf_batch_device(ln.mt.h, p(o.desc), p(o.n), cap, p(self.pair_a), p(self.pair_b), self.B, p(o.bi),
                                                       p(o.bd), p(o.sd)))
         L.check(lib, lib.rgbl_event_record(o.ev["match_done"], ln.s_mt))
         if self.gather != "none":
@@ -296,7 +301,7 @@ class FrontEndPipeline:
         L.check(lib, lib.rgbl_pack_records_device(self.s_comm, p(o.n), p(o.kp), p(o.desc), p(o.depth), p(o.uright), self.B, self.cap, 0,
                                                   self.B * self.cap, p(self.send[slot]), p(self.offsets[slot]), p(self.overflow)))
         with self._comm():
-            self.counts[slot].copy_(o.n)  # the set is free again once the records and the counts are copied out
+            self.counts[slot].copy_(o.n[:self.B])  # the set is free again once the records and the counts are copied out
         L.check(lib, lib.rgbl_event_record(o.ev["comm_done"], self.s_comm))
         if self.gather == "step":
             self._gather_counts([slot])

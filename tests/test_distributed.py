@@ -112,6 +112,75 @@ main()
 '''
 
 
+CHUNK_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["RGBL_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from orb_slam3_rgbl_amd import _lib, synth, sharding
+from orb_slam3_rgbl_amd import frontend as F
+from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline, unpack_records, make_comm
+
+W, H, NF, LEVELS, N_AZ, N_FRAMES = 200, 160, 300, 4, 240, 7      # 7 frames over 2 ranks: chunks of 4 and 3
+DEV = torch.device("cpu")
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lib = _lib.bind(os.environ["RGBL_EMU_LIB"])
+    K = synth.KITTI_K.copy(); K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+    proj = F.projection_matrix(K, synth.KITTI_TR, lib)
+    sq = synth.Sequence(300, W, H, n_frames=N_FRAMES)            # ONE long sequence, the same on every rank
+    frames = np.stack([sq.frame(i) for i in range(N_FRAMES)])
+    cloud = np.stack([synth.lidar_scan(300 + i, n_az=N_AZ) for i in range(N_FRAMES)])
+    b, e, e_halo = sharding.frame_chunk(N_FRAMES, world, rank)
+    own = e - b
+    # the gather's step shape is the same on every rank: the largest chunk (ranks with a shorter one pad with an empty frame count)
+    comm = make_comm(lib, dist, 0)
+    pipe = FrontEndPipeline(lib, torch, DEV, W, H, NF, proj, cloud.shape[2], own, levels=LEVELS, ini_th=20, min_th=7, world=1, rank=0,
+                            gather="none", halo=e_halo - e)
+    pipe.set_inputs(torch.from_numpy(frames[b:e_halo].copy()), torch.from_numpy(cloud[b:e_halo].copy()))
+    pipe.step(); pipe.sync()
+    o = pipe.last()
+    # what ONE process computes for the whole sequence
+    solo = FrontEndPipeline(lib, torch, DEV, W, H, NF, proj, cloud.shape[2], N_FRAMES, levels=LEVELS, ini_th=20, min_th=7, world=1, rank=0, gather="none")
+    solo.set_inputs(torch.from_numpy(frames), torch.from_numpy(cloud))
+    solo.step(); solo.sync()
+    s = solo.last()
+    ok = True
+    for t in range(b, e):
+        n = int(s.n[t])
+        ok &= int(o.n[t - b]) == n
+        ok &= torch.equal(o.kp[t - b, :n].view(torch.int32), s.kp[t, :n].view(torch.int32)) and torch.equal(o.desc[t - b, :n], s.desc[t, :n])   # (class_id -1 reads as NaN in a float view)
+        ok &= torch.equal(o.depth[t - b, :n].view(torch.int32), s.depth[t, :n].view(torch.int32))
+        if t + 1 < N_FRAMES:   # every owned frame meets its TRUE successor - across the chunk boundary through the halo frame
+            ok &= torch.equal(o.bi[t - b, :n], s.bi[t, :n]) and torch.equal(o.bd[t - b, :n], s.bd[t, :n]) and torch.equal(o.sd[t - b, :n], s.sd[t, :n])
+    if e < N_FRAMES:
+        ok &= e_halo == e + 1 and int(o.n[own]) == int(s.n[e])      # the halo frame is the next rank's first frame, recomputed here
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok))
+    if rank == 0:
+        print("CHUNKS_OK" if all(flags) else "CHUNKS_MISMATCH %s" % flags)
+    pipe.close(); solo.close(); lib.rgbl_comm_destroy(comm)
+    dist.barrier(); dist.destroy_process_group()
+
+main()
+'''
+
+
+def test_chunked_sequence_matches_across_the_chunk_boundary(tmp_path, oracle, emu_lib):
+    """SURVEY 8(e) 'single long sequence': contiguous chunks per rank with a one-frame halo (sharding.frame_chunk,
+    FrontEndPipeline(halo=1)).  Two gloo ranks; every owned frame's keypoints, depths and (t, t + 1) matches - the pair across
+    the chunk boundary included - equal what one process computes for the whole sequence."""
+    script = tmp_path / "chunk_worker.py"
+    script.write_text(CHUNK_WORKER)
+    env = dict(os.environ, RGBL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", RGBL_EMU_THREADS="2", TMPDIR=str(tmp_path),
+               RGBL_EMU_LIB=os.path.join(ROOT, "tests", "_build", "librgbl_frontend_emu.so"))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29525", str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert "CHUNKS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_chunk_partition_covers_all_frames_with_halo():
     for n, world in ((4541, 8), (10, 3), (7, 8), (64, 1)):
         seen = []

@@ -149,6 +149,13 @@ def test_extractor_cell_compaction_kernel(emu_lib, compact):
         os.environ.pop("RGBL_COMPACT", None)
 
 
+def test_instruction_wrapper_selftest_runs(emu_lib):
+    # the emulation's plain-C stand-ins trivially agree; what this checks is the self-test's own host-side expectations
+    from orb_slam3_rgbl_amd import _lib as L
+    for n, seed in ((1, 1), (64, 3), (1000, 4)):
+        L.check(emu_lib, emu_lib.rgbl_selftest_wrappers(0, n, seed))
+
+
 def test_extractor_quadtree_empty_root_nodes(emu_lib):
     pc.check_extractor_empty_root(emu_lib)
 

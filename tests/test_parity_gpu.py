@@ -89,6 +89,13 @@ def test_extractor_cell_compaction_kernel(gpu_lib, compact):
         os.environ.pop("RGBL_COMPACT", None)
 
 
+def test_instruction_wrappers_on_the_hardware(gpu_lib):
+    # mul24 / add_flag / lds_dma16: inline asm and builtins that the CPU emulation replaces by plain C
+    from orb_slam3_rgbl_amd import _lib as L
+    for n, seed in ((1, 1), (63, 2), (64, 3), (1000, 4), (65536 + 17, 5)):
+        L.check(gpu_lib, gpu_lib.rgbl_selftest_wrappers(0, n, seed))
+
+
 def test_extractor_edge_cases(gpu_lib):
     pc.check_extractor_edge_cases(gpu_lib)
     pc.check_extractor_empty_root(gpu_lib)
