@@ -103,7 +103,7 @@ def algorithmic_bytes(kernel, w, h, n_points, k_per_frame):
     return table.get(kernel)
 
 
-TRAFFIC_FILES = {"kitti": ("r03_pmc_traffic.json", "r02_pmc_traffic.json"), "4k": ("r03_pmc_traffic_4k.json",)}
+TRAFFIC_FILES = {"kitti": ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"), "4k": ("r04_pmc_traffic_4k.json", "r03_pmc_traffic_4k.json")}
 CLOCK_HZ, SIMDS = 2.4e9, 1024     # MI355X: 256 CUs x 4 SIMDs, one VALU instruction of a wave64 per 4 cycles and SIMD
 
 
