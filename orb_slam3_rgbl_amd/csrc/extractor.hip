@@ -86,10 +86,6 @@ struct rgbl_extractor {
   int compact_min_batch = 8;              // batches of at least this many frames: FAST cells write their own slots, k_compact_cells
                                           // builds the dense lists (RGBL_COMPACT=0: never, =1: always)
   GaussTile* d_gtiles = nullptr;  // one record per Gaussian output tile of a frame (k_gauss7)
-  GaussTile* d_gtiles_m = nullptr;        // the 128 x 128 tiles of the matrix-core Gaussian (k_gauss7_mfma)
-  std::vector<int> mtile_off;             // [L + 1] first such tile of every level
-  v4i* d_gauss_tab = nullptr;             // its four band matrices as B operands, [4][64] x 16 bytes
-  bool gauss_mfma = false;                // RGBL_GAUSS_MFMA=1
   ResizeTab *d_xtab = nullptr, *d_ytab = nullptr;
   ResizeGroup* d_xgroups = nullptr;  // k_resize_linear: one record per 4 output columns (index xtab_off / 4 + group)
   int32_t* d_xsxa = nullptr;         // first source byte of the group's 8-byte window, -1 = byte path
@@ -346,48 +342,6 @@ int upload_tables(rgbl_extractor* e) {
   }
   RGBL_TRY(dev_alloc(e, &e->d_gtiles, gtiles.size()));
   RGBL_HIP(hipMemcpy(e->d_gtiles, gtiles.data(), sizeof(GaussTile) * gtiles.size(), hipMemcpyHostToDevice));
-  {
-    // k_gauss7_mfma: 128 x 128 tiles and the band matrices of the 7-tap kernel in the B-operand layout of
-    // v_mfma_i32_32x32x32_i8 (lane l: column l & 31 of B, K half l >> 5, 16 consecutive K indices as bytes)
-    std::vector<GaussTile> mt;
-    e->mtile_off.assign(L + 1, 0);
-    for (int l = 0; l < L; ++l) {
-      const LevelGeom& g = e->geom[l];
-      e->mtile_off[l] = (int)mt.size();
-      for (int y = 0; y < g.h; y += kMBlurTH)
-        for (int x = 0; x < g.w; x += kMBlurTW) {
-          GaussTile gt;
-          memset(&gt, 0, sizeof(gt));
-          gt.x0 = (uint16_t)x; gt.y0 = (uint16_t)y; gt.w = (uint16_t)g.w; gt.h = (uint16_t)g.h; gt.pitch = (uint16_t)g.pitch;
-          gt.l = (uint8_t)l; gt.img_off = g.img_off;
-          mt.push_back(gt);
-        }
-    }
-    e->mtile_off[L] = (int)mt.size();
-    RGBL_TRY(dev_alloc(e, &e->d_gtiles_m, mt.size()));
-    RGBL_HIP(hipMemcpy(e->d_gtiles_m, mt.data(), sizeof(GaussTile) * mt.size(), hipMemcpyHostToDevice));
-    static const int8_t kW7[7] = {18, 34, 48, 56, 48, 34, 18};   // OpenCV's 8.8 fixed-point kernel of GaussianBlur(7 x 7, sigma 2)
-    std::vector<int8_t> tab((size_t)4 * 64 * 16, 0);
-    for (int lane = 0; lane < 64; ++lane) {
-      const int n = lane & 31, g = lane >> 5;
-      for (int q = 0; q < 16; ++q) {
-        // horizontal, K blocks 0 / 1: K index k = 32 kb + 16 g + q is input column c0 - 3 + k, output column c0 + n: tap k - n
-        for (int kb = 0; kb < 2; ++kb) {
-          const int t = 32 * kb + 16 * g + q - n;
-          if (t >= 0 && t <= 6) tab[((size_t)(kb * 64 + lane)) * 16 + q] = kW7[t];
-        }
-        // vertical: K index (g, q) is sum row m = (q & 3) + 8 (q >> 2) + 4 g of a block (the D layout of the first product);
-        // block j - 1 (rows 32 (j - 1) - 3 + m) against output row 32 (j - 1) + n: tap m - n; block j: tap 32 + m - n
-        const int m = (q & 3) + 8 * (q >> 2) + 4 * g;
-        const int ta = m - n, tb = 32 + m - n;
-        if (ta >= 0 && ta <= 6) tab[((size_t)(2 * 64 + lane)) * 16 + q] = kW7[ta];
-        if (tb >= 0 && tb <= 6) tab[((size_t)(3 * 64 + lane)) * 16 + q] = kW7[tb];
-      }
-    }
-    RGBL_TRY(dev_alloc(e, &e->d_gauss_tab, (size_t)4 * 64));
-    RGBL_HIP(hipMemcpy(e->d_gauss_tab, tab.data(), tab.size(), hipMemcpyHostToDevice));
-    if (const char* v = getenv("RGBL_GAUSS_MFMA")) e->gauss_mfma = atoi(v) != 0;
-  }
   RGBL_TRY(dev_alloc(e, &e->d_cells, cells.size()));
   RGBL_HIP(hipMemcpy(e->d_cells, cells.data(), sizeof(FastCell) * cells.size(), hipMemcpyHostToDevice));
   {
@@ -530,16 +484,6 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   };
   auto launch_gauss = [&](hipStream_t st, int tile_begin, int tile_end) {
     if (tile_end <= tile_begin) return;
-    if (e->gauss_mfma) {
-      // the ranges are whole levels: the same levels in the 128 x 128 tiling of the matrix-core kernel
-      auto lvl = [&](int t) { for (int l = 0; l < L; ++l) if (e->blur_tiles.tile_off[l] == t) return l; return L; };
-      const int m0 = e->mtile_off[lvl(tile_begin)], m1 = e->mtile_off[lvl(tile_end)];
-      e->timer.begin("k_gauss7_mfma", st);
-      hipLaunchKernelGGL(k_gauss7_mfma, xcd_grid(e->xcd_map, m1 - m0, batch), dim3(256), 0, st, e->d_gtiles_m, d_imgs, stride, frame_stride,
-                         e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame, m0, e->d_gauss_tab);
-      e->timer.end(st);
-      return;
-    }
     e->timer.begin("k_gauss7", st);
     // two passes with a barrier in between: 16 workgroups of two waves per CU interleave better than 8 of four (0.63 -> 0.54 ms)
     const bool g128 = !(getenv("RGBL_GAUSS_BS") && atoi(getenv("RGBL_GAUSS_BS")) == 256);

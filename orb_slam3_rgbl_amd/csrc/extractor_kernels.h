@@ -886,102 +886,6 @@ __global__ __launch_bounds__(BS) void k_gauss7(const GaussTile* __restrict__ til
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_gauss7_mfma (round 4): the same 7x7 Gaussian on the matrix cores, as two banded-Toeplitz products.
-// The step is paced by vector issue and the matrix pipe idles outside the Hamming scan; a separable 7-tap filter IS a small
-// integer matrix product:   horizontal  S[r][c] = sum_k (P[r][c - 3 + k] - 128) Wh[k][c],   Wh[k][c] = w[k - c] (0 <= k - c <= 6)
-//                           vertical    V[c][R] = sum_m  S'[m][c] Wv[m][R]                  (the same band over rows)
-// on v_mfma_i32_32x32x32_i8 (exact: |operands| <= 128, |sums| < 2^23).  Pixels go in as p - 128 (one v_xor per 4 pixels; the
-// constant 128 * 256 = 2^15 that leaves is put back for free, see below); the horizontal sums have 16 bits, so the vertical
-// product runs on their low and high BYTE planes (two products, V = 256 Vhi + Vlo).  No LDS and no transposition: the D layout
-// of the first product - a lane holds ONE column and 16 rows - is, byte plane by byte plane, exactly the A-operand layout of
-// the second one with K = those rows (which row a K index stands for only has to agree between A and the constant B).
-//   D1 raw = S - 2^15:  its byte 0 is S's low byte; its byte 1 is S's high byte xor 0x80, i.e. ALREADY (high byte - 128)
-//   -> low plane = byte0 xor 0x80, high plane = byte1: 16 v_perm_b32 + 4 v_xor per 16 x 64 sums
-//   out = (256 (Vhi + 2^15) + (Vlo + 2^15) + 2^15) >> 16: the constants ride in the low plane's accumulator input
-// One wave owns a strip of 32 columns and walks down the rows in blocks of 32: block j's 32 sum rows are image rows
-// 32 j - 3 .. 32 j + 28, output block j - 1 (rows 32 (j - 1) .. + 31) needs the sums of block j - 1 and the first six of block j:
-// per 32 x 32 outputs 2 + 4 matrix instructions and ~90 vector instructions (k_gauss7: ~290).
-// grid = xcd_grid(128 x 128 tiles over all levels, frames), block = 256 (one 32-column strip per wave).
-constexpr int kMBlurTW = 128, kMBlurTH = 128;
-
-__device__ __forceinline__ v16i mfma_i8(v4i a, v4i b, v16i c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
-
-// 16 bytes of an image row from column c on, BORDER_REFLECT_101 applied where the window leaves [0, W)
-__device__ __forceinline__ v4i gauss_load16(const uint8_t* row, int c, int W) {
-  v4i v;
-  if (c >= 0 && c + 16 <= W) {
-    __builtin_memcpy(&v, row + c, 16);
-  } else {
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int k = 0; k < 16; ++k) w[k >> 2] |= (uint32_t)row[reflect101(c + k, W)] << (8 * (k & 3));
-    v[0] = (int)w[0]; v[1] = (int)w[1]; v[2] = (int)w[2]; v[3] = (int)w[3];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] ^= (int)0x80808080u;   // p - 128
-  return v;
-}
-
-__global__ __launch_bounds__(256) void k_gauss7_mfma(const GaussTile* __restrict__ tiles, const uint8_t* __restrict__ img0, int pitch0,
-                                                      size_t frame0, const uint8_t* __restrict__ pyr, size_t pyr_frame,
-                                                      uint8_t* __restrict__ blur, size_t blur_frame, int tile_begin,
-                                                      const v4i* __restrict__ tab) {
-  const int f = xcd_frame(), lane = lane_id();
-  const GaussTile T = tiles[xcd_item() + tile_begin];
-  const int W = T.w, H = T.h, y0 = T.y0;
-  const int c0 = T.x0 + 32 * wave_id();
-  if (c0 >= W) return;   // (whole waves; no barrier in this kernel)
-  const uint8_t* img = (T.l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + T.img_off;
-  const int pitch = (T.l == 0) ? pitch0 : (int)T.pitch;
-  uint8_t* dst = blur + (size_t)f * blur_frame + T.img_off;
-  // the band matrices as B operands, one 16-byte piece per lane each (host table, upload_tables)
-  const v4i bh0 = tab[lane], bh1 = tab[64 + lane], bva = tab[128 + lane], bvb = tab[192 + lane];
-  const int m = lane & 31, g = lane >> 5;
-  const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const int kC = 0x810000;   // 256 * 2^15 + 2^15 + 2^15
-  const v16i ck = {kC, kC, kC, kC, kC, kC, kC, kC, kC, kC, kC, kC, kC, kC, kC, kC};
-  const int nblk = imin(kMBlurTH / 32, (H - y0 + 31) >> 5);   // output blocks of this tile
-  v4i plo_prev = {0, 0, 0, 0}, phi_prev = {0, 0, 0, 0};
-  for (int j = 0; j <= nblk; ++j) {
-    // ---- horizontal sums of the image rows y0 + 32 j - 3 + (0 .. 31): this lane feeds row m, columns c0 - 3 + 16 g (+ 32) ..
-    const int r = reflect101(y0 + 32 * j - 3 + m, H);
-    const uint8_t* row = img + __umul24((uint32_t)r, (uint32_t)pitch);
-    const v4i a0 = gauss_load16(row, c0 - 3 + 16 * g, W), a1 = gauss_load16(row, c0 + 29 + 16 * g, W);
-    const v16i d1 = mfma_i8(a1, bh1, mfma_i8(a0, bh0, zero));   // lane: column c0 + m; register q: sum row (q & 3) + 8 (q >> 2) + 4 g
-    // ---- the two byte planes, register q -> byte q (the K order of the vertical product)
-    v4i plo, phi;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t q0 = (uint32_t)d1[4 * i], q1 = (uint32_t)d1[4 * i + 1], q2 = (uint32_t)d1[4 * i + 2], q3 = (uint32_t)d1[4 * i + 3];
-      const uint32_t t01 = perm_bytes(q1, q0, 0x05010400u), t23 = perm_bytes(q3, q2, 0x05010400u);   // low bytes | high bytes of a pair
-      plo[i] = (int)(perm_bytes(t23, t01, 0x05040100u) ^ 0x80808080u);
-      phi[i] = (int)perm_bytes(t23, t01, 0x07060302u);
-    }
-    if (j > 0) {
-      // ---- vertical: output rows y0 + 32 (j - 1) + (0 .. 31) from the sums of block j - 1 and the first six of block j
-      const v16i vlo = mfma_i8(plo, bvb, mfma_i8(plo_prev, bva, ck));
-      const v16i vhi = mfma_i8(phi, bvb, mfma_i8(phi_prev, bva, zero));
-      // lane: output row y0 + 32 (j - 1) + m; register q: column c0 + (q & 3) + 8 (q >> 2) + 4 g - four consecutive columns a word
-      const int R = y0 + 32 * (j - 1) + m;
-      if (R < H) {
-        uint8_t* D = dst + (__umul24((uint32_t)R, (uint32_t)T.pitch) + (uint32_t)(c0 + 4 * g));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (c0 + 8 * i + 4 * g >= W) break;
-          uint32_t o[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = ((uint32_t)vhi[4 * i + k] << 8) + (uint32_t)vlo[4 * i + k];   // byte 2 = the pixel
-          const uint32_t out = perm_bytes(perm_bytes(o[3], o[2], 0x0c0c0602u), perm_bytes(o[1], o[0], 0x0c0c0602u), 0x05040100u);
-          // the row pitch is a multiple of 64 and the column one of 4: a full word always fits the row
-          *reinterpret_cast<uint32_t*>(D + 8 * i) = out;
-        }
-      }
-    }
-    plo_prev = plo; phi_prev = phi;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // libstdc++ std::sort (GCC 11 introsort) re-stated on two parallel arrays, ordering = ascending key.
 // The reference sorts its expandable quad-tree nodes with std::sort + compareNodes (ORBextractor.cc:538-553,
 // :700); nodes with equal (size, UL.x) end up in an order that only the algorithm's exact sequence of
