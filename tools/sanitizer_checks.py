@@ -14,6 +14,10 @@ if which == "extract":
     pc.check_extractor(lib, 640, 480, 600, frames=(0,), seq=4)                # 51-px cells on the last level: four waves, 80-byte pitch
     pc.check_extractor_batch(lib, 400, 300, 500, 8)                            # batches: one wave per cell
     pc.check_extractor_low_contrast(lib)                                       # the second FAST pass
+    os.environ["RGBL_COMPACT"] = "1"                                           # k_compact_cells for single frames too (round 4)
+    pc.check_extractor(lib, 3840, 280, 1500, frames=(0,), nlevels=2, seq=12)   # 424 cells on level 0: two groups, skipped border cells
+    pc.check_extractor_empty_root(lib)
+    os.environ.pop("RGBL_COMPACT")
 elif which == "depth":
     for m in (F.UPS_INVERSE_DILATION, F.UPS_AVERAGE_FILTERING, F.UPS_NEAREST_NEIGHBOR_PIXEL):
         pc.check_depth(lib, m, w=620, h=188, n_az=900, n_kp=400)
@@ -38,4 +42,10 @@ elif which == "misc":
     pc.check_extractor_edge_cases(lib)
     pc.check_extractor_threshold_extremes(lib)
     pc.check_extractor_dense_corners(lib)                                      # corner lists overflow: every pixel scored, NMS over all pixels
+elif which == "gather":
+    # the library's gather (csrc/gather.hip) without a communicator (one rank, device copies) inside the pipeline, both modes,
+    # the chunk halo, and the on-device self-test's host side
+    pc.check_pipeline_gather(lib, "step", dev=__import__("torch").device("cpu"), w=320, h=200, nfeatures=400, batch=4, steps=3, n_az=300, levels=4)
+    pc.check_pipeline_gather(lib, "final", dev=__import__("torch").device("cpu"), w=320, h=200, nfeatures=400, batch=4, steps=3, n_az=300, levels=4)
+    L.check(lib, lib.rgbl_selftest_wrappers(0, 1000, 7))
 print("asan run", which, "done")
