@@ -17,8 +17,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <array>
-#include <map>
 #include <vector>
 
 #include "brief_pattern.h"
@@ -88,12 +86,6 @@ struct rgbl_extractor {
   int compact_min_batch = 8;              // batches of at least this many frames: FAST cells write their own slots, k_compact_cells
                                           // builds the dense lists (RGBL_COMPACT=0: never, =1: always)
   GaussTile* d_gtiles = nullptr;  // one record per Gaussian output tile of a frame (k_gauss7)
-  GaussTile* d_gtiles_m = nullptr;        // the 128 x 128 tiles of the matrix-core Gaussian (k_gauss7_mfma)
-  std::vector<int> mtile_off;             // [L + 1] first such tile of every level
-  v4i* d_gauss_tab = nullptr;             // its four band matrices as B operands, [4][64] x 16 bytes
-  GaussStrip* d_gauss_strips = nullptr;   // per (level, 32-column strip): its windows and band table
-  int* d_gauss_strip_off = nullptr;
-  bool gauss_mfma = false, gauss_mfma_ok = true;   // RGBL_GAUSS_MFMA=1
   ResizeTab *d_xtab = nullptr, *d_ytab = nullptr;
   ResizeGroup* d_xgroups = nullptr;  // k_resize_linear: one record per 4 output columns (index xtab_off / 4 + group)
   int32_t* d_xsxa = nullptr;         // first source byte of the group's 8-byte window, -1 = byte path
@@ -350,91 +342,6 @@ int upload_tables(rgbl_extractor* e) {
   }
   RGBL_TRY(dev_alloc(e, &e->d_gtiles, gtiles.size()));
   RGBL_HIP(hipMemcpy(e->d_gtiles, gtiles.data(), sizeof(GaussTile) * gtiles.size(), hipMemcpyHostToDevice));
-  {
-    // k_gauss7_mfma: 128 x 128 tiles and the band matrices of the 7-tap kernel in the B-operand layout of
-    // v_mfma_i32_32x32x32_i8 (lane l: column l & 31 of B, K half l >> 5, 16 consecutive K indices as bytes)
-    std::vector<GaussTile> mt;
-    e->mtile_off.assign(L + 1, 0);
-    for (int l = 0; l < L; ++l) {
-      const LevelGeom& g = e->geom[l];
-      e->mtile_off[l] = (int)mt.size();
-      for (int y = 0; y < g.h; y += kMBlurTH)
-        for (int x = 0; x < g.w; x += kMBlurTW) {
-          GaussTile gt;
-          memset(&gt, 0, sizeof(gt));
-          gt.x0 = (uint16_t)x; gt.y0 = (uint16_t)y; gt.w = (uint16_t)g.w; gt.h = (uint16_t)g.h; gt.pitch = (uint16_t)g.pitch;
-          gt.l = (uint8_t)l; gt.img_off = g.img_off;
-          mt.push_back(gt);
-        }
-    }
-    e->mtile_off[L] = (int)mt.size();
-    RGBL_TRY(dev_alloc(e, &e->d_gtiles_m, mt.size()));
-    RGBL_HIP(hipMemcpy(e->d_gtiles_m, mt.data(), sizeof(GaussTile) * mt.size(), hipMemcpyHostToDevice));
-    static const int8_t kW7[7] = {18, 34, 48, 56, 48, 34, 18};   // OpenCV's 8.8 fixed-point kernel of GaussianBlur(7 x 7, sigma 2)
-    // band tables: [0], [1] the vertical bands; [2 + 2 c], [3 + 2 c] the horizontal band of border geometry c (K blocks 0 / 1)
-    std::vector<std::array<int8_t, 64 * 16>> tabs(2);
-    for (auto& t : tabs) t.fill(0);
-    for (int lane = 0; lane < 64; ++lane) {
-      const int n = lane & 31, g = lane >> 5;
-      for (int q = 0; q < 16; ++q) {
-        // K index (g, q) is sum row m = (q & 3) + 8 (q >> 2) + 4 g of a block (the D layout of the first product); block j - 1
-        // (rows 32 (j - 1) - 3 + m) against output row 32 (j - 1) + n: tap m - n; block j: tap 32 + m - n
-        const int m = (q & 3) + 8 * (q >> 2) + 4 * g;
-        const int ta = m - n, tb = 32 + m - n;
-        if (ta >= 0 && ta <= 6) tabs[0][(size_t)lane * 16 + q] = kW7[ta];
-        if (tb >= 0 && tb <= 6) tabs[1][(size_t)lane * 16 + q] = kW7[tb];
-      }
-    }
-    // horizontal: per (level, strip) the three 16-byte windows, pulled inside the row, and the band over them with
-    // BORDER_REFLECT_101 folded in: the weight of tap t of output column c0 + n goes to the window byte that holds column
-    // reflect101(c0 + n - 3 + t).  Strips with the same (window offsets relative to c0, distance to the right border) share a table.
-    std::vector<GaussStrip> strips;
-    std::vector<int> strip_off(L + 1, 0);
-    std::map<std::array<int, 5>, int> classes;
-    for (int l = 0; l < L; ++l) {
-      const int W = e->geom[l].w;
-      strip_off[l] = (int)strips.size();
-      if (W < 16) { set_error("level %d is %d px wide: the matrix-core Gaussian needs 16", l, W); e->gauss_mfma_ok = false; }
-      for (int c0 = 0; c0 < W; c0 += 32) {
-        GaussStrip st;
-        int base[3];
-        for (int j = 0; j < 3; ++j) { base[j] = std::min(std::max(c0 - 3 + 16 * j, 0), std::max(W - 16, 0)); st.base[j] = (uint16_t)base[j]; }
-        const int n_out = std::min(32, W - c0);
-        const std::array<int, 5> key = {base[0] - c0, base[1] - c0, base[2] - c0, std::min(W - c0, 64), c0 == 0 ? 1 : 0};
-        auto it = classes.find(key);
-        if (it == classes.end()) {
-          const int cls = (int)classes.size();
-          it = classes.emplace(key, cls).first;
-          tabs.emplace_back(); tabs.emplace_back();
-          auto& t0 = tabs[2 + 2 * cls]; auto& t1 = tabs[3 + 2 * cls];
-          t0.fill(0); t1.fill(0);
-          for (int n = 0; n < n_out; ++n)
-            for (int t = 0; t < 7; ++t) {
-              int col = c0 + n - 3 + t;
-              if (col < 0) col = -col;
-              if (col >= W) col = 2 * (W - 1) - col;
-              int j = 0;
-              while (j < 3 && !(col >= base[j] && col < base[j] + 16)) ++j;
-              if (j == 3) { set_error("matrix-core Gaussian: column %d of a %d px row is in no window", col, W); e->gauss_mfma_ok = false; continue; }
-              // window 0 = K block 0, half 0; window 1 = K block 0, half 1; window 2 = K block 1, half 0; B lane = 32 * half + n
-              auto& tt = j == 2 ? t1 : t0;
-              tt[(size_t)(32 * (j == 1 ? 1 : 0) + n) * 16 + (col - base[j])] += kW7[t];
-            }
-        }
-        st.cls = (uint16_t)it->second;
-        strips.push_back(st);
-      }
-    }
-    strip_off[L] = (int)strips.size();
-    RGBL_TRY(dev_alloc(e, &e->d_gauss_tab, tabs.size() * 64));
-    for (size_t i = 0; i < tabs.size(); ++i)
-      RGBL_HIP(hipMemcpy(reinterpret_cast<int8_t*>(e->d_gauss_tab) + i * 1024, tabs[i].data(), 1024, hipMemcpyHostToDevice));
-    RGBL_TRY(dev_alloc(e, &e->d_gauss_strips, strips.size()));
-    RGBL_HIP(hipMemcpy(e->d_gauss_strips, strips.data(), sizeof(GaussStrip) * strips.size(), hipMemcpyHostToDevice));
-    RGBL_TRY(dev_alloc(e, &e->d_gauss_strip_off, strip_off.size()));
-    RGBL_HIP(hipMemcpy(e->d_gauss_strip_off, strip_off.data(), sizeof(int) * strip_off.size(), hipMemcpyHostToDevice));
-    if (const char* v = getenv("RGBL_GAUSS_MFMA")) e->gauss_mfma = atoi(v) != 0 && e->gauss_mfma_ok;
-  }
   RGBL_TRY(dev_alloc(e, &e->d_cells, cells.size()));
   RGBL_HIP(hipMemcpy(e->d_cells, cells.data(), sizeof(FastCell) * cells.size(), hipMemcpyHostToDevice));
   {
@@ -577,16 +484,6 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   };
   auto launch_gauss = [&](hipStream_t st, int tile_begin, int tile_end) {
     if (tile_end <= tile_begin) return;
-    if (e->gauss_mfma) {
-      // the ranges are whole levels: the same levels in the 128 x 128 tiling of the matrix-core kernel
-      auto lvl = [&](int t) { for (int l = 0; l < L; ++l) if (e->blur_tiles.tile_off[l] == t) return l; return L; };
-      const int m0 = e->mtile_off[lvl(tile_begin)], m1 = e->mtile_off[lvl(tile_end)];
-      e->timer.begin("k_gauss7_mfma", st);
-      hipLaunchKernelGGL(k_gauss7_mfma, xcd_grid(e->xcd_map, m1 - m0, batch), dim3(256), 0, st, e->d_gtiles_m, d_imgs, stride, frame_stride,
-                         e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame, m0, e->d_gauss_tab, e->d_gauss_strips, e->d_gauss_strip_off);
-      e->timer.end(st);
-      return;
-    }
     e->timer.begin("k_gauss7", st);
     // two passes with a barrier in between: 16 workgroups of two waves per CU interleave better than 8 of four (0.63 -> 0.54 ms)
     const bool g128 = !(getenv("RGBL_GAUSS_BS") && atoi(getenv("RGBL_GAUSS_BS")) == 256);

@@ -366,15 +366,6 @@ __device__ __forceinline__ void lds_dma16(const uint8_t* gsrc, uint8_t* lds_wave
 #endif
 }
 
-// All outstanding LDS-DMA of this wave has landed and is visible to its LDS reads (the compiler does not track the LDS side of
-// global_load_lds: without a workgroup barrier - which waits for vmcnt(0) by itself - the wait has to be spelled out).
-__device__ __forceinline__ void wait_lds_dma() {
-#ifndef RGBL_EMU
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-  wave_sync();
-}
-
 // Bytes K and K + 2 of the 12 bytes w0 | w1 | w2 (numbered -4 .. 7) as the HIGH bytes of a register's two 16-bit halves.
 // kClean: the low bytes are zero; otherwise they hold whatever is cheapest (nothing at all when K = 1 mod 4).
 template <int K, bool kClean = false>
@@ -892,137 +883,6 @@ __global__ __launch_bounds__(BS) void k_gauss7(const GaussTile* __restrict__ til
     *reinterpret_cast<uint32_t*>(D + __umul24((uint32_t)o, (uint32_t)T.pitch)) = out;
   }
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_gauss7_mfma (round 4): the same 7x7 Gaussian on the matrix cores, as two banded-Toeplitz products.
-// The step is paced by vector issue and the matrix pipe idles outside the Hamming scan; a separable 7-tap filter IS a small
-// integer matrix product:   horizontal  S[r][c] = sum_k (P[r][c - 3 + k] - 128) Wh[k][c],   Wh[k][c] = w[k - c] (0 <= k - c <= 6)
-//                           vertical    V[c][R] = sum_m  S'[m][c] Wv[m][R]                  (the same band over rows)
-// on v_mfma_i32_32x32x32_i8 (exact: |operands| <= 128, |sums| < 2^23).  Pixels go in as p - 128 (one v_xor per 4 pixels; the
-// constant 128 * 256 = 2^15 that leaves is put back for free, see below); the horizontal sums have 16 bits, so the vertical
-// product runs on their low and high BYTE planes (two products, V = 256 Vhi + Vlo).  No LDS and no transposition: the D layout
-// of the first product - a lane holds ONE column and 16 rows - is, byte plane by byte plane, exactly the A-operand layout of
-// the second one with K = those rows (which row a K index stands for only has to agree between A and the constant B).
-//   D1 raw = S - 2^15:  its byte 0 is S's low byte; its byte 1 is S's high byte xor 0x80, i.e. ALREADY (high byte - 128)
-//   -> low plane = byte0 xor 0x80, high plane = byte1: 16 v_perm_b32 + 4 v_xor per 16 x 64 sums
-//   out = (256 (Vhi + 2^15) + (Vlo + 2^15) + 2^15) >> 16: the constants ride in the low plane's accumulator input
-// One wave owns a strip of 32 columns and walks down the rows in blocks of 32: block j's 32 sum rows are image rows
-// 32 j - 3 .. 32 j + 28, output block j - 1 (rows 32 (j - 1) .. + 31) needs the sums of block j - 1 and the first six of block j:
-// per 32 x 32 outputs 2 + 4 matrix instructions and ~90 vector instructions (k_gauss7: ~290).
-// grid = xcd_grid(128 x 256 tiles over all levels, frames), block = 256 (one 32-column strip per wave; the rows leave together).
-constexpr int kMBlurTW = 128, kMBlurTH = 256;   // a wave walks down 8 blocks: its prologue (tile, strip and band-table loads) is paid once
-
-__device__ __forceinline__ v16i mfma_i8(v4i a, v4i b, v16i c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
-
-// A strip of 32 output columns reads three 16-byte windows of every image row (columns c0 - 3 .. c0 + 44; the K indices
-// 0 - 15, 16 - 31, 32 - 47 of the horizontal product, the fourth window's band is empty).  At the left and right border the
-// windows are pulled inside the row (clamped to [0, W - 16]: never a byte outside the image) and BORDER_REFLECT_101 becomes
-// part of the CONSTANT operand: the host adds the weight of every reflected tap to the entry of the column it reflects onto
-// (upload_tables: one band table per distinct border geometry).  No byte-wise path, no divergence: a border strip costs what
-// an interior one does.
-struct GaussStrip { uint16_t base[3]; uint16_t cls; };   // clamped first column of the three windows, index of the band table
-
-__global__ __launch_bounds__(256) void k_gauss7_mfma(const GaussTile* __restrict__ tiles, const uint8_t* __restrict__ img0, int pitch0,
-                                                      size_t frame0, const uint8_t* __restrict__ pyr, size_t pyr_frame,
-                                                      uint8_t* __restrict__ blur, size_t blur_frame, int tile_begin,
-                                                      const v4i* __restrict__ tab, const GaussStrip* __restrict__ strips,
-                                                      const int* __restrict__ strip_off) {
-  const int f = xcd_frame(), lane = lane_id();
-  const GaussTile T = tiles[xcd_item() + tile_begin];
-  const int W = T.w, H = T.h, y0 = T.y0;
-  const int wv = wave_first(wave_id());
-  const int c0 = T.x0 + 32 * wv;   // wave-uniform, and said so: the strip record below comes through scalar loads
-  const bool active = c0 < W;      // a strip beyond the level's width: the wave only keeps the workgroup's barriers and row stores company
-  const uint8_t* img = (T.l == 0) ? img0 + (size_t)f * frame0 : pyr + (size_t)f * pyr_frame + T.img_off;
-  const int pitch = (T.l == 0) ? pitch0 : (int)T.pitch;
-  uint8_t* dst = blur + (size_t)f * blur_frame + T.img_off;
-  const int m = lane & 31, g = lane >> 5;
-  const GaussStrip S = strips[strip_off[T.l] + (active ? (c0 >> 5) : 0)];
-  // B operands: [0] the vertical bands (block j - 1, block j), shared; [1 + cls] the strip's horizontal band, K blocks 0 and 1
-  const v4i bva = tab[lane], bvb = tab[64 + lane];
-  const v4i bh0 = tab[(2 + 2 * S.cls) * 64 + lane], bh1 = tab[(3 + 2 * S.cls) * 64 + lane];
-  const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const int kC = 0x810000;   // 256 * 2^15 + 2^15 + 2^15
-  const v16i ck = {kC, kC, kC, kC, kC, kC, kC, kC, kC, kC, kC, kC, kC, kC, kC, kC};
-  const int nblk = imin(kMBlurTH / 32, (H - y0 + 31) >> 5);   // output blocks of this tile
-  // The 32 rows x 3 windows of a block travel as 96 16-byte pieces: piece p = 3 * row + window, lane p (and p - 64) of two
-  // LDS-DMA instructions - three neighbouring lanes read one row's 48 bytes, 22 rows an instruction (a lane per ROW, straight
-  // into the A layout, made every instruction touch 64 cache lines: 1.03 ms per 512 frames, bound by the address path).  The
-  // pieces land in the wave's own LDS block in lane order, two blocks taking turns: block j + 1 travels while block j is
-  // multiplied; the A operand of lane (m, g) is piece 3 m + g (and 3 m + 2 for the second instruction's half 0).
-  __shared__ __attribute__((aligned(16))) uint8_t s_rows[4][2][96 * 16];
-  uint8_t* my_rows = &s_rows[wave_id()][0][0];
-  auto request_rows = [&](int j) {   // image rows y0 + 32 j - 3 + (0 .. 31) -> buffer j & 1
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int p = lane + 64 * i, rr = (int)(__umul24((uint32_t)p, 0x5556u) >> 16), w = p - 3 * rr;   // p / 3, p % 3
-      if (p < 96) {
-        const uint8_t* row = img + __umul24((uint32_t)reflect101(y0 + 32 * j - 3 + rr, H), (uint32_t)pitch);
-        lds_dma16(row + (w == 0 ? S.base[0] : w == 1 ? S.base[1] : S.base[2]), my_rows + (j & 1) * (96 * 16) + 64 * 16 * i);
-      }
-    }
-  };
-  v4i plo_prev = {0, 0, 0, 0}, phi_prev = {0, 0, 0, 0};
-  // The D layout gives a lane one ROW of its strip's 32 x 32 output block: stored from there, each of a block's four store
-  // instructions writes 8 bytes into 32 different cache lines, and the address path of the CU set the kernel's time (0.92 ms per
-  // 512 frames).  The four strips of the workgroup therefore meet in LDS - 32 rows x 128 bytes, two buffers taking turns - and
-  // leave as ROWS: a store instruction is two full 128-byte rows.  The words of block j - 1 are staged at the end of iteration
-  // j and stored at the top of iteration j + 1, behind that iteration's wait for its rows: no wait ever meets a fresh store.
-  constexpr int kOutPitch = 132;   // bytes: rows rotate through the banks
-  __shared__ __attribute__((aligned(4))) uint8_t s_out[2][32 * kOutPitch];
-  const int tid = threadIdx.x;
-  auto store_rows = [&](int jb) {   // output block jb (rows y0 + 32 jb ..) from s_out[jb & 1]
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int rr = 8 * k + (tid >> 5), R = y0 + 32 * jb + rr, x = T.x0 + 4 * (tid & 31);
-      if (R < H && x < W)   // the row pitch is a multiple of 64 and the column one of 4: a full word always fits the row
-        *reinterpret_cast<uint32_t*>(dst + (__umul24((uint32_t)R, (uint32_t)T.pitch) + (uint32_t)x)) =
-            *reinterpret_cast<const uint32_t*>(&s_out[jb & 1][rr * kOutPitch + 4 * (tid & 31)]);
-    }
-  };
-  if (active) request_rows(0);
-  for (int j = 0; j <= nblk; ++j) {
-    // ---- horizontal sums (as p - 128: one xor per four pixels); the next block's rows are requested first and travel meanwhile
-    wait_lds_dma();   // block j's pieces have landed (requested an iteration ago, behind the previous block's stores)
-    if (j >= 2) store_rows(j - 2);   // staged at the end of the previous iteration (a barrier ago)
-    if (!active) { __syncthreads(); continue; }
-    const uint8_t* buf = my_rows + (j & 1) * (96 * 16);
-    v4i x0 = *reinterpret_cast<const v4i*>(buf + (3 * m + g) * 16);
-    v4i x1 = *reinterpret_cast<const v4i*>(buf + (3 * m + 2) * 16);
-    if (g) x1 = v4i{0, 0, 0, 0};   // K indices 48 - 63 meet an empty band
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { x0[i] ^= (int)0x80808080u; x1[i] ^= (int)0x80808080u; }
-    wave_sync();
-    if (j < nblk) request_rows(j + 1);
-    const v16i d1 = mfma_i8(x1, bh1, mfma_i8(x0, bh0, zero));   // lane: column c0 + m; register q: sum row (q & 3) + 8 (q >> 2) + 4 g
-    // ---- the two byte planes, register q -> byte q (the K order of the vertical product)
-    v4i plo, phi;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t q0 = (uint32_t)d1[4 * i], q1 = (uint32_t)d1[4 * i + 1], q2 = (uint32_t)d1[4 * i + 2], q3 = (uint32_t)d1[4 * i + 3];
-      const uint32_t t01 = perm_bytes(q1, q0, 0x05010400u), t23 = perm_bytes(q3, q2, 0x05010400u);   // low bytes | high bytes of a pair
-      plo[i] = (int)(perm_bytes(t23, t01, 0x05040100u) ^ 0x80808080u);
-      phi[i] = (int)perm_bytes(t23, t01, 0x07060302u);
-    }
-    if (j > 0) {
-      // ---- vertical: output rows y0 + 32 (j - 1) + (0 .. 31) from the sums of block j - 1 and the first six of block j
-      const v16i vlo = mfma_i8(plo, bvb, mfma_i8(plo_prev, bva, ck));
-      const v16i vhi = mfma_i8(phi, bvb, mfma_i8(phi_prev, bva, zero));
-      // lane: output row y0 + 32 (j - 1) + m; register q: column c0 + (q & 3) + 8 (q >> 2) + 4 g - four consecutive columns a word
-      uint8_t* O = &s_out[(j - 1) & 1][m * kOutPitch + 32 * wv + 4 * g];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint32_t o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = ((uint32_t)vhi[4 * i + k] << 8) + (uint32_t)vlo[4 * i + k];   // byte 2 = the pixel
-        *reinterpret_cast<uint32_t*>(O + 8 * i) = perm_bytes(perm_bytes(o[3], o[2], 0x0c0c0602u), perm_bytes(o[1], o[0], 0x0c0c0602u), 0x05040100u);
-      }
-    }
-    plo_prev = plo; phi_prev = phi;
-    __syncthreads();   // the block's words of all four strips are staged (and the other buffer's readers are a barrier behind)
-  }
-  if (nblk >= 1) store_rows(nblk - 1);
 }
 
 // ------------------------------------------------------------------------------------------------

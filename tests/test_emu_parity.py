@@ -131,20 +131,6 @@ def test_extractor_fast_kernel_waves_per_cell(emu_lib, bs):
         os.environ.pop("RGBL_FAST_BS", None)
 
 
-def test_extractor_gaussian_on_the_matrix_cores(emu_lib):
-    # RGBL_GAUSS_MFMA=1: k_gauss7_mfma (two banded-Toeplitz i8 products per 32 x 32 block) instead of k_gauss7; the blurred
-    # levels are compared byte for byte (stages=True) - narrow levels, widths that are no multiple of 32 / 128, one-tile levels
-    os.environ["RGBL_GAUSS_MFMA"] = "1"
-    try:
-        pc.check_extractor(emu_lib, 1241, 376, 2000, frames=(0,), seq=5, stages=True)
-        pc.check_extractor(emu_lib, 333, 217, 500, frames=(0,), nlevels=5, seq=4, stages=True)
-        pc.check_extractor(emu_lib, 640, 480, 600, frames=(0,), seq=4, stages=True)
-        pc.check_extractor_batch(emu_lib, 400, 300, 500, 8)
-        pc.check_extractor_edge_cases(emu_lib)
-    finally:
-        os.environ.pop("RGBL_GAUSS_MFMA", None)
-
-
 @pytest.mark.parametrize("compact", ["1", "0"])
 def test_extractor_cell_compaction_kernel(emu_lib, compact):
     # batches: the FAST cells write their own slots, k_compact_cells builds the level's dense candidate list (one reservation
