@@ -505,6 +505,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   ob.level_cnt_last = e->d_levelcnt + (size_t)e->cfg.max_batch * L;
   ob.err = e->d_err;
   ob.dbg = getenv("RGBL_OCTREE_STAMPS") ? e->d_dbg : nullptr;
+  ob.no_hist = (getenv("RGBL_OCTREE_HIST") && getenv("RGBL_OCTREE_HIST")[0] == '0') ? 1 : 0;
   // narrow workgroups leave room for more (level, frame) problems per CU; small batches, which cannot fill the chip anyway,
   // take the wide group (shorter passes over the keys).  Node lists of up to 512 / 2048 entries live in LDS
   // (octree_labels.h); beyond that - more than ~9 000 features - the key-moving kernel on global lists takes over.

@@ -1025,6 +1025,7 @@ struct OctreeBufs {
                               // extraction and keeps a copy in level_cnt_last (rgbl_extractor_get_candidates)
   uint32_t* level_cnt_last;
   unsigned long long* dbg;  // optional: 16 cycle-counter stamps per (frame, level) workgroup (diagnostics)
+  int no_hist;              // RGBL_OCTREE_HIST=0: the breadth-first phase round by round over the keys (rounds 1 - 3) instead of on the cell pyramid
 };
 
 __device__ __forceinline__ int quadrant_of(uint32_t key, int mx, int my) {

@@ -41,9 +41,12 @@ __device__ __forceinline__ int qt_mid(uint32_t lohi) {  // lo + ceil((hi - lo) /
 }
 __device__ __forceinline__ uint32_t qt_mid2(uint2 G) { return (uint32_t)qt_mid(G.x) | ((uint32_t)qt_mid(G.y) << 16); }
 // n1 = 0 (UL), n2 = 1 (UR), n3 = 2 (BL), n4 = 3 (BR) of a node split at `mid`
+// (bits 12 .. 15 of a stored split point carry the node's depth below its root, qt_mid_depth: coordinates stay below 4096)
 __device__ __forceinline__ int qt_quadrant(uint32_t key, uint32_t mid) {
-  return (key_x(key) < (int)(mid & 0xffffu) ? 0 : 1) | (key_y(key) < (int)(mid >> 16) ? 0 : 2);
+  return (key_x(key) < (int)(mid & 0xfffu) ? 0 : 1) | (key_y(key) < (int)(mid >> 16) ? 0 : 2);
 }
+__device__ __forceinline__ uint32_t qt_mid_depth(uint2 G, int depth) { return qt_mid2(G) | ((uint32_t)(depth < 15 ? depth : 15) << 12); }
+__device__ __forceinline__ int qt_depth_of(uint32_t mid) { return (int)((mid >> 12) & 0xfu); }
 __device__ __forceinline__ uint2 qt_child(uint2 G, int q) {
   const uint32_t mx = (uint32_t)qt_mid(G.x), my = (uint32_t)qt_mid(G.y);
   uint2 c;
@@ -78,7 +81,7 @@ __device__ __forceinline__ int qt_rep_log(int counters, int words) {  // copies 
 // children, copied for survivors), todo[1-p] (children with more than one key, creation order) and ctab[].
 template <int BS, int NCAP>
 __device__ __forceinline__ void qt_rebuild(QtStore<NCAP>& S, int p, int n, int P, int m, bool identity, int cap,
-                                           uint32_t* s_scan, int* s_newn, int* s_nexp) {
+                                           uint32_t* s_scan, int* s_newn, int* s_nexp, int* s_nchild = nullptr) {
   const int tid = threadIdx.x;
   constexpr int kPer = (NCAP + BS - 1) / BS;  // ranks per work-item: their counters stay in registers between the two steps
   if (!identity)
@@ -128,7 +131,7 @@ __device__ __forceinline__ void qt_rebuild(QtStore<NCAP>& S, int p, int n, int P
             if (idx < (uint32_t)cap) {
               const uint2 Gc = qt_child(G, q);
               S.geom[1 - p][idx] = Gc;
-              S.mid[1 - p][idx] = qt_mid2(Gc);
+              S.mid[1 - p][idx] = qt_mid_depth(Gc, qt_depth_of(S.mid[p][pos]) + 1);
               S.cnt[1 - p][idx][0] = 0; S.cnt[1 - p][idx][1] = 0; S.cnt[1 - p][idx][2] = 0; S.cnt[1 - p][idx][3] = 0;
             }
             if (c_r[k][q] > 1) {
@@ -169,8 +172,47 @@ __device__ __forceinline__ void qt_rebuild(QtStore<NCAP>& S, int p, int n, int P
       S.ctab[pos] = t;
     }
   }
-  if (tid == 0) { *s_newn = (int)(T + kcarry); *s_nexp = (int)E; }
+  if (tid == 0) { *s_newn = (int)(T + kcarry); *s_nexp = (int)E; if (s_nchild) *s_nchild = (int)T; }
   __syncthreads();
+}
+
+// ---- The breadth-first phase without passes over the keys (round 4) ---------------------------------------------------
+// A node's rectangle is a function of its root and of the path of quadrants that leads to it - the split points (qt_mid) do
+// not depend on the keys, and x and y split independently.  So ONE pass can give every key the path it would take through
+// HD rounds of splits (root | x path | y path = its cell of the 2^HD x 2^HD subdivision of its root) and count the keys per
+// cell; the counts of every shallower node are sums of 2 x 2 blocks (a pyramid of HD levels).  While the reference is in
+// its breadth-first phase (every node with more than one key splits, ORBextractor.cc:608-686) a round then only rebuilds
+// the node list - the children's per-quadrant counts come out of the pyramid - and no key is touched.  The keys meet their
+// nodes again through a table cell -> list position when the first round needs more than the pyramid holds (depth > HD - 2),
+// when the quota phase starts (its rounds split only some nodes) or at the very end.
+// level d (1 .. D) of the pyramid: entry (root << 2 d) | (x path << d) | y path, behind the entries of the levels above it
+__device__ __forceinline__ int qt_hist_off(int n_ini, int d) { return n_ini * (((1 << (2 * d)) - 4) / 3); }
+// the path of a coordinate through `depth` splits of [lo, hi]: bit = 1 where it lies right of (at) the split point
+__device__ __forceinline__ int qt_path(int v, int lo, int hi, int depth) {
+  int path = 0;
+  for (int d = 0; d < depth; ++d) {
+    const int mid = lo + ((hi - lo + 1) >> 1);
+    const int bit = v >= mid ? 1 : 0;
+    lo = bit ? mid : lo;
+    hi = bit ? hi : mid;
+    path = (path << 1) | bit;
+  }
+  return path;
+}
+// depth and paths of a NODE rectangle (x0 | x1 << 16, y0 | y1 << 16) below its root's: descends until the interval is met
+__device__ __forceinline__ int qt_node_path(uint2 G, int rx0, int rx1, int ry1, int max_depth, int* xp, int* yp) {
+  int xlo = rx0, xhi = rx1, ylo = 0, yhi = ry1, px = 0, py = 0, d = 0;
+  const int x0 = (int)(G.x & 0xffffu), x1 = (int)(G.x >> 16), y0 = (int)(G.y & 0xffffu), y1 = (int)(G.y >> 16);
+  while (d < max_depth && !(xlo == x0 && xhi == x1 && ylo == y0 && yhi == y1)) {
+    const int mx = xlo + ((xhi - xlo + 1) >> 1), my = ylo + ((yhi - ylo + 1) >> 1);
+    const int bx = x0 >= mx ? 1 : 0, by = y0 >= my ? 1 : 0;
+    xlo = bx ? mx : xlo; xhi = bx ? xhi : mx;
+    ylo = by ? my : ylo; yhi = by ? yhi : my;
+    px = (px << 1) | bx; py = (py << 1) | by;
+    ++d;
+  }
+  *xp = px; *yp = py;
+  return d;
 }
 
 constexpr int kQtBatch = 4;   // keys per work-item and trip of the passes over the candidate list (independent loads in flight)
@@ -187,6 +229,12 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   static_assert(NCAP <= 0x4000, "list positions travel in 15 bits of the ctab entries");
   __shared__ uint32_t s_keys[KEYCAP > 0 ? KEYCAP : 1];
   __shared__ uint16_t s_label[KEYCAP > 0 ? KEYCAP : 2];
+  // the pyramid of per-cell key counts (see above): as deep as its space allows - 4 roots x 3 levels next to the 37 KB of a
+  // batch workgroup (four of them still share a CU), 5 levels where LDS is not what limits the workgroups per CU
+  constexpr int kHistEntries = KEYCAP > 0 ? 1 : (NCAP > 512 ? 2 * 1364 : 4 * 84);   // (the single-frame instantiation does without, see below)
+  __shared__ uint32_t s_hist[kHistEntries];
+  __shared__ int s_rootx[kMaxRoots + 1];
+  __shared__ int s_nchild;
   using Ranges = SortRangesT<QtRanges<NCAP>::value>;
   __shared__ QtStore<NCAP> S;
   __shared__ uint32_t s_scan[32];
@@ -205,7 +253,7 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   // scalars of the level up front: behind the stores below the compiler would have to re-read them from memory
   const int N = g.quota, n_cells = g.n_cells, cell_cap = g.cell_cap, n_ini = g.n_ini, kcap = g.kcap;
   const int cap = (int)g.node_cap < NCAP ? (int)g.node_cap : NCAP;
-  if (tid <= kMaxRoots) s_rootfirst[tid] = g.root_first[tid];
+  if (tid <= kMaxRoots) { s_rootfirst[tid] = g.root_first[tid]; s_rootx[tid] = g.root_x[tid]; }
   // root of a key (ORBextractor.cc:585, vpIniNodes[kp.pt.x / hX]): root_first[k] = first x that lands in root k or beyond
   auto root_of = [&](uint32_t key) {
     int r = 0;
@@ -226,7 +274,7 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
     G.x = (uint32_t)g.root_x[tid] | ((uint32_t)g.root_x[tid + 1] << 16);
     G.y = (uint32_t)(g.max_by - kMinBorder) << 16;
     S.geom[0][tid] = G;
-    S.mid[0][tid] = qt_mid2(G);
+    S.mid[0][tid] = qt_mid_depth(G, 0);
     S.cnt[0][tid][0] = 0; S.cnt[0][tid][1] = 0; S.cnt[0][tid][2] = 0; S.cnt[0][tid][3] = 0;
   }
   uint32_t* s_rep0 = reinterpret_cast<uint32_t*>(&S.ctab[0]);  // 2 NCAP words, idle until the first rebuild
@@ -234,6 +282,20 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   for (int i = tid; i < ((4 * n_ini) << rlog0); i += BS) s_rep0[i] = 0;
   uint32_t C = 0;
   const bool dense = b.level_cnt != nullptr;  // k_fast_cells left the level's candidates as one list (any cell order)
+  // depth of the pyramid: what fits its space for this level's number of roots (0 = the round-by-round passes of rounds 1 - 3)
+  int hist_depth = 0;
+  // Not for the handful-of-problems instantiation (KEYCAP > 0): with the keys in LDS a pass over them is cheap, and what the
+  // pyramid adds - the paths of 8 600 keys in the first pass, the cell table in front of the quota phase - cost a KITTI level-0
+  // problem more (+42 k cycles) than the four passes it saves (-26 k); measured, round 4.  Batches and 4K frames gain.
+  if (dense && !b.no_hist && KEYCAP == 0) {
+    // (cells of at least 2 x 2 px at the deepest level: no interval of a node that the tables meet has shrunk to a point, so
+    // a node's left edge names its root and its path)
+    int min_w = g.max_by - kMinBorder;
+    for (int r = 0; r < n_ini; ++r) min_w = imin(min_w, g.root_x[r + 1] - g.root_x[r]);
+    for (int d = 2; d <= 5; ++d)
+      if (qt_hist_off(n_ini, d + 1) <= kHistEntries && (n_ini << (2 * d)) <= 0x10000 && (min_w >> d) >= 2) hist_depth = d;
+  }
+  bool from_codes = false;   // the keys' labels are cell codes (the breadth-first phase runs on the pyramid), not list positions
   if (!dense) {
     const uint32_t* ccnt = b.cell_cnt + (size_t)f * b.cells_frame + g.cell_off;
     const uint32_t* slots = b.slots + (size_t)f * b.slots_frame + g.slot_off;
@@ -299,6 +361,43 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
     const uint32_t* kin = keys;   // the list k_fast_cells left in global memory
     const bool in_lds = KEYCAP > 0 && C <= (uint32_t)KEYCAP;   // workgroup-uniform
     if (in_lds) { keys = s_keys; label = s_label; }            // every later pass works on the LDS copy
+    if (hist_depth >= 2) {
+      // every key's cell at depth D = hist_depth as its label, counted into the pyramid's deepest level
+      for (int i = tid; i < qt_hist_off(n_ini, hist_depth + 1); i += BS) s_hist[i] = 0;
+      __syncthreads();
+      const int offD = qt_hist_off(n_ini, hist_depth), ry1 = g.max_by - kMinBorder;
+      for (uint32_t i0 = 0; i0 < C; i0 += BS * kQtBatch) {
+        uint32_t key[kQtBatch];
+#pragma unroll
+        for (int u = 0; u < kQtBatch; ++u) {
+          const uint32_t i = i0 + (uint32_t)(u * BS + tid);
+          key[u] = i < C ? kin[i] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < kQtBatch; ++u)
+          if (key[u] != 0xffffffffu) {
+            const int r = root_of(key[u]);
+            const int code = (r << (2 * hist_depth)) | (qt_path(key_x(key[u]), s_rootx[r], s_rootx[r + 1], hist_depth) << hist_depth) |
+                             qt_path(key_y(key[u]), 0, ry1, hist_depth);
+            if (in_lds) keys[i0 + (uint32_t)(u * BS + tid)] = key[u];
+            label[i0 + (uint32_t)(u * BS + tid)] = (uint16_t)code;
+            atomicAdd(&s_hist[offD + code], 1u);
+          }
+      }
+      __syncthreads();
+      // the shallower levels: sums of 2 x 2 cells
+      for (int d = hist_depth - 1; d >= 1; --d) {
+        const int off = qt_hist_off(n_ini, d), offc = qt_hist_off(n_ini, d + 1), cells = n_ini << (2 * d);
+        for (int e = tid; e < cells; e += BS) {
+          const int r = e >> (2 * d), xp = (e >> d) & ((1 << d) - 1), yp = e & ((1 << d) - 1);
+          const int c = offc + (r << (2 * d + 2)) + ((2 * xp) << (d + 1)) + 2 * yp;
+          s_hist[off + e] = s_hist[c] + s_hist[c + 1] + s_hist[c + (1 << (d + 1))] + s_hist[c + (1 << (d + 1)) + 1];
+        }
+        __syncthreads();
+      }
+      if (tid < 4 * n_ini) S.cnt[0][tid >> 2][tid & 3] = s_hist[((tid >> 2) << 2) + ((tid & 1) << 1) + ((tid >> 1) & 1)];   // level 1: (root << 2) | (x bit << 1) | y bit
+      from_codes = true;
+    } else
     for (uint32_t i0 = 0; i0 < C; i0 += BS * kQtBatch) {
       uint32_t key[kQtBatch];
 #pragma unroll
@@ -317,7 +416,7 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
     }
   }
   __syncthreads();
-  if (tid < 4 * n_ini) {
+  if (!from_codes && tid < 4 * n_ini) {
     uint32_t v = 0;
     for (int j = 0; j < (1 << rlog0); ++j) v += s_rep0[(tid << rlog0) + j];
     S.cnt[0][tid >> 2][tid & 3] = v;
@@ -341,7 +440,7 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   }
   __syncthreads();
   int n = s_n;
-  if (n != n_ini) {  // wave-uniform, rare: the labels of the roots behind an empty one move up
+  if (n != n_ini && !from_codes) {  // wave-uniform, rare: the labels of the roots behind an empty one move up (cell codes name the root itself)
     for (uint32_t i = (uint32_t)tid; i < C; i += BS) label[i] = (uint16_t)s_rootpos[label[i]];
   }
   __syncthreads();
@@ -352,6 +451,7 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
   //         the quota (ORBextractor.cc:689-753)
   unsigned long long* best = reinterpret_cast<unsigned long long*>(&S.cnt[1][0][0]);
   int p = 0, m = 0;
+  int bfs_depth = 0;   // depth of the expandable nodes while the rounds run on the pyramid
   bool finished = (n == 0), careful = false, stamped = false;
   const int w_cell = g.w_cell, h_cell = g.h_cell, n_cols = g.n_cols;
   const uint32_t m_wcell = g.m_wcell, m_hcell = g.m_hcell;
@@ -395,13 +495,54 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
       __syncthreads();
       P = s_P;
     }
-    qt_rebuild<BS, NCAP>(S, p, n, P, m, !careful, cap, s_scan, &s_newn, &s_nexp);
+    // A round on the pyramid alone: breadth-first (every expandable node splits, all of them at depth `bfs_depth`) and the
+    // children's quadrant counts - level bfs_depth + 2 - still inside it.  Otherwise, if the labels are still cell codes, the
+    // keys meet their nodes of the CURRENT list through the table first (its space: the pyramid's deepest level, read for the
+    // last time by the previous round's children).
+    const bool node_round = from_codes && !careful && bfs_depth + 2 <= hist_depth;
+    const int offD = qt_hist_off(n_ini, hist_depth);
+    auto cells_to_positions = [&](int list, int count) {   // every depth-D cell -> the list position of the node that covers it
+      const int ry1 = g.max_by - kMinBorder, nw = BS / 64;
+      for (int pos = wave_id(); pos < count; pos += nw) {
+        const uint2 G = S.geom[list][pos];
+        const int dn = qt_depth_of(S.mid[list][pos]), x0 = (int)(G.x & 0xffffu), y0 = (int)(G.y & 0xffffu);
+        int r = 0;
+        for (int k = 1; k < n_ini; ++k) r += x0 >= s_rootx[k] ? 1 : 0;
+        const int sh = hist_depth - dn;   // the node covers 2^sh x 2^sh cells (dn <= hist_depth while the labels are codes)
+        const int base = offD + (r << (2 * hist_depth)) + ((qt_path(x0, s_rootx[r], s_rootx[r + 1], dn) << sh) << hist_depth) + (qt_path(y0, 0, ry1, dn) << sh);
+        for (int c = lane_id(); c < (1 << (2 * sh)); c += 64) s_hist[base + ((c >> sh) << hist_depth) + (c & ((1 << sh) - 1))] = (uint32_t)pos;
+      }
+      __syncthreads();
+    };
+    if (from_codes && !node_round) cells_to_positions(p, n);
+    qt_rebuild<BS, NCAP>(S, p, n, P, m, !careful, cap, s_scan, &s_newn, &s_nexp, &s_nchild);
     n = s_newn;
     m = s_nexp;
     if (n > cap - 8) { if (tid == 0) atomicOr(b.err, 1); finished = true; }
     else if (n >= N || n == prev) finished = true;
     else if (!careful && n + 3 * m > N) careful = true;
     if (!stamped && (careful || finished)) { RGBL_STAMP(3); stamped = true; }
+    if (node_round && !finished) {
+      // the children of this round (the front of the new list) take their quadrant counts from the pyramid; no key is touched
+      const int T = s_nchild, ry1 = g.max_by - kMinBorder, dc = bfs_depth + 1, offq = qt_hist_off(n_ini, dc + 1);
+      for (int idx = tid; idx < T && idx < cap; idx += BS) {
+        const uint2 G = S.geom[1 - p][idx];
+        const int x0 = (int)(G.x & 0xffffu), y0 = (int)(G.y & 0xffffu);
+        int r = 0;
+        for (int k = 1; k < n_ini; ++k) r += x0 >= s_rootx[k] ? 1 : 0;
+        const int xp = qt_path(x0, s_rootx[r], s_rootx[r + 1], dc), yp = qt_path(y0, 0, ry1, dc);
+        const int c = offq + (r << (2 * dc + 2)) + ((2 * xp) << (dc + 1)) + 2 * yp;
+        S.cnt[1 - p][idx][0] = s_hist[c]; S.cnt[1 - p][idx][2] = s_hist[c + 1];
+        S.cnt[1 - p][idx][1] = s_hist[c + (1 << (dc + 1))]; S.cnt[1 - p][idx][3] = s_hist[c + (1 << (dc + 1)) + 1];
+      }
+      ++bfs_depth;
+      p ^= 1;
+      __syncthreads();
+      continue;
+    }
+    // a pyramid round that ended the distribution: the keys meet the nodes of the NEW list directly
+    const bool via_new_list = node_round;   // (finished)
+    if (via_new_list) cells_to_positions(1 - p, n < cap ? n : cap);
     // copies of the new list's counters (in the old list's counters, which nobody reads any more) while it is short
     uint32_t* s_rep = &S.cnt[p][0][0];
     const int rlog = (finished || 4 * n > NCAP) ? 0 : qt_rep_log(4 * n, 4 * NCAP);
@@ -428,6 +569,11 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
       }
       uint2 tabv[kQtBatch];
       uint32_t midv[kQtBatch];
+      if (from_codes) {   // workgroup-uniform: the labels are cell codes, the table names the node (of the old list, or - via_new_list - of the new one)
+#pragma unroll
+        for (int u = 0; u < kQtBatch; ++u)
+          if (oldv[u] != 0xffffffffu) oldv[u] = s_hist[offD + (int)oldv[u]];
+      }
 #pragma unroll
       for (int u = 0; u < kQtBatch; ++u) {
         const uint32_t o = oldv[u] & (uint32_t)(NCAP - 1);
@@ -439,9 +585,9 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
         const uint32_t i = i0 + (uint32_t)(u * BS + tid);
         const bool valid = oldv[u] != 0xffffffffu;
         const int q = qt_quadrant(keyv[u], midv[u]);
-        const uint32_t e = (((q & 2) ? tabv[u].y : tabv[u].x) >> ((q & 1) * 16)) & 0xffffu;
+        const uint32_t e = via_new_list ? oldv[u] : (((q & 2) ? tabv[u].y : tabv[u].x) >> ((q & 1) * 16)) & 0xffffu;
         const uint32_t idx = e & 0x7fffu;
-        if (valid && idx != oldv[u]) label[i] = (uint16_t)idx;
+        if (valid && (from_codes || idx != oldv[u])) label[i] = (uint16_t)idx;
         if (finished) {
           // ---- 3. the strongest key of every node, the first one of the candidate list on ties (ORBextractor.cc:757-776)
           if (valid && idx < (uint32_t)cap) {
@@ -471,6 +617,7 @@ __global__ __launch_bounds__(BS) void k_octree(const LevelGeom* __restrict__ geo
         if (v) S.cnt[1 - p][i >> 2][i & 3] += v;  // fresh children start at zero, nodes that were not split receive nothing
       }
     }
+    from_codes = false;   // the labels are list positions from here on
     p ^= 1;
     __syncthreads();
   }

@@ -71,6 +71,24 @@ def test_extractor_fast_kernel_waves_per_cell(gpu_lib, bs):
         os.environ.pop("RGBL_FAST_BS", None)
 
 
+def test_extractor_quadtree_round_by_round(gpu_lib):
+    # RGBL_OCTREE_HIST=0: the breadth-first phase of the quad-tree kernel as passes over the keys (rounds 1 - 3) instead of on
+    # the pyramid of per-cell counts (the default for batches and for 2 048-node problems); RGBL_OCTREE_LDSKEYS=0 makes single
+    # frames take the batch instantiation, i.e. the pyramid: both ways of every shape
+    for env in ({"RGBL_OCTREE_HIST": "0"}, {"RGBL_OCTREE_LDSKEYS": "0"}, {"RGBL_OCTREE_LDSKEYS": "0", "RGBL_OCTREE_NCAP": "2048"}):
+        os.environ.update(env)
+        try:
+            pc.check_extractor(gpu_lib, 1241, 376, 2000, frames=(0,), seq=5, stages=True)
+            pc.check_extractor(gpu_lib, 333, 217, 500, frames=(0,), nlevels=5, seq=4, stages=True)
+            pc.check_extractor_batch(gpu_lib, 400, 300, 500, 8)
+            pc.check_extractor_empty_root(gpu_lib)
+            pc.check_extractor_edge_cases(gpu_lib)
+            pc.check_extractor_dense_corners(gpu_lib)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+
+
 @pytest.mark.parametrize("compact", ["1", "0"])
 def test_extractor_cell_compaction_kernel(gpu_lib, compact):
     # batches: the FAST cells write their own slots, k_compact_cells builds the level's dense candidate list (one reservation
