@@ -309,13 +309,20 @@ int rgbl_gather_exchange(rgbl_gather* g, int slot) {
     for (int r = 1; r < W; ++r) any = any || total[r] > 0;
     const bool self = g->loopback && total[0] > 0;
     if (any || self) {
+      // one group: the transfers are posted together and progress in parallel (an error return inside it still closes the group)
+      struct Group {
+        bool open = false;
+        ~Group() { if (open) (void)nccl().GroupEnd(); }
+      } grp;
       RGBL_NCCL(nccl().GroupStart());
+      grp.open = true;
       if (self) {
         RGBL_NCCL(nccl().Send(g->d_send[slot], (size_t)total[0] * kRecordBytes, ncclUint8, 0, g->comm->comm, s));
         RGBL_NCCL(nccl().Recv(base, (size_t)total[0] * kRecordBytes, ncclUint8, 0, g->comm->comm, s));
       }
       for (int r = 1; r < W; ++r)
         if (total[r] > 0) RGBL_NCCL(nccl().Recv(base + (size_t)r * g->slot_bytes, (size_t)total[r] * kRecordBytes, ncclUint8, r, g->comm->comm, s));
+      grp.open = false;
       RGBL_NCCL(nccl().GroupEnd());
     }
     if (!self && total[0] > 0)
