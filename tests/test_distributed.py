@@ -282,3 +282,45 @@ def test_rccl_gather_two_ranks(tmp_path, oracle, gpu_lib, mode, port, transport)
         pytest.skip("needs two GPUs")
     out = _run_on_gpus(tmp_path, 2, mode, port, transport=transport)
     assert "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_gather_entry_points_reject_misuse(emu_lib):
+    """Error behaviour of the C-ABI gather (csrc/gather.hip): status codes, never a hang or a crash."""
+    import ctypes as C
+
+    import numpy as np
+
+    from orb_slam3_rgbl_amd import _lib as L
+    lib = emu_lib
+    g = C.c_void_p()
+    assert lib.rgbl_gather_create(None, 0, 0, 10, 2, None, C.byref(g)) == L.ERR_INVALID          # batch 0
+    assert lib.rgbl_gather_create(None, 99, 4, 10, 2, None, C.byref(g)) == L.ERR_NO_DEVICE       # no such device
+    ident = (C.c_uint8 * L.COMM_ID_BYTES)()
+    comm = C.c_void_p()
+    assert lib.rgbl_comm_create(ident, 2, 2, 0, C.byref(comm)) == L.ERR_INVALID                   # rank >= world
+    assert lib.rgbl_comm_create(None, 1, 0, 0, C.byref(comm)) == L.ERR_INVALID
+    L.check(lib, lib.rgbl_gather_create(None, 0, 3, 8, 2, None, C.byref(g)))                      # one rank, no communicator
+    assert lib.rgbl_gather_set_loopback(g, 1) == L.ERR_INVALID                                    # loopback needs a communicator
+    assert lib.rgbl_gather_exchange(g, 0) == L.ERR_INVALID                                        # nothing packed
+    assert lib.rgbl_gather_exchange(g, 5) == L.ERR_INVALID
+    assert lib.rgbl_gather_result(g, 0, None, None, None) == L.ERR_INVALID                        # no exchange yet
+    n = np.array([8, 0, 3], np.int32)
+    kp = np.zeros((3, 8, 7), np.float32); desc = np.arange(3 * 8 * 32, dtype=np.uint8).reshape(3, 8, 32)
+    dep = np.ones((3, 8), np.float32); ur = np.full((3, 8), 2.0, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.rgbl_gather_pack(g, 2, p(n), p(kp), p(desc), p(dep), p(ur), None, 0, None) == L.ERR_INVALID   # slot out of range
+    L.check(lib, lib.rgbl_gather_pack(g, 1, p(n), p(kp), p(desc), p(dep), p(ur), None, 0, None))
+    L.check(lib, lib.rgbl_gather_exchange(g, 1))
+    L.check(lib, lib.rgbl_gather_sync(g))
+    assert lib.rgbl_gather_result(g, 1, None, None, None) == L.ERR_INVALID                        # rank out of range
+    counts, rec, cnt = C.c_void_p(), C.c_void_p(), C.c_longlong()
+    L.check(lib, lib.rgbl_gather_result(g, 0, C.byref(counts), C.byref(rec), C.byref(cnt)))
+    assert cnt.value == 11 and list(np.ctypeslib.as_array(C.cast(counts, C.POINTER(C.c_int32)), (3,))) == [8, 0, 3]
+    small = np.zeros(10 * 68, np.uint8)
+    assert lib.rgbl_gather_copy_result(g, 0, p(small), small.size) == L.ERR_CAPACITY
+    full = np.zeros(11 * 68, np.uint8)
+    L.check(lib, lib.rgbl_gather_copy_result(g, 0, p(full), full.size))
+    L.check(lib, lib.rgbl_gather_sync(g))
+    assert np.array_equal(full.reshape(11, 68)[:, 28:60], np.concatenate([desc[0, :8], desc[2, :3]]))
+    assert lib.rgbl_gather_exchange(g, 1) == L.ERR_INVALID                                        # already exchanged
+    lib.rgbl_gather_destroy(g)
