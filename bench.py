@@ -22,7 +22,12 @@ import os
 import sys
 import time
 
-import numpy as np
+# dmabuf IPC: on this driver RCCL between processes (and any sharing of device memory across processes) needs it, and it has to
+# be in the environment BEFORE the HIP runtime is initialised - i.e. before `import torch` - on every path: the self-launch,
+# ranks started by the driver's own torchrun, a single process.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -389,6 +394,55 @@ def gather_legs_one_rank(lib, torch, dist, dev, d_imgs, d_cloud, w, h, nfeatures
     return out
 
 
+def spot_check(O, orc, P, frames, cloud, out_set, spot_frames, w, h, n_next=None):
+    """Parity spot check of what a timed pipeline produced: the given frames of the step's output set (keypoints, descriptors,
+    depth, uRight, matches against the following frame) against the CPU oracle, bit for bit.  Returns the JSON line's string."""
+    h_n = out_set.n.cpu().numpy()
+    ok = True
+    n_next = n_next or len(frames)
+    for fi in spot_frames:
+        n = int(h_n[fi])
+        kps = out_set.kp[fi, :n].cpu().numpy().view(np.uint32)
+        okps, odesc, _ = orc(frames[fi])
+        ok &= n == len(okps) and np.array_equal(kps, okps.view(np.uint32).reshape(n, 7))
+        ok &= np.array_equal(out_set.desc[fi, :n].cpu().numpy(), odesc)
+        od, our, _, _ = O.depth(P, cloud[fi], w, h, np.stack([okps["x"], okps["y"]], 1), okps["x"], want_maps=False)
+        ok &= np.array_equal(out_set.depth[fi, :n].cpu().numpy().view(np.uint32), od.view(np.uint32))
+        ok &= np.array_equal(out_set.uright[fi, :n].cpu().numpy().view(np.uint32), our.view(np.uint32))
+        nxt = (fi + 1) % n_next     # chunks: the last owned frame meets the halo frame
+        ndesc = orc(frames[nxt])[1]
+        obi, obd, osd = O.hamming_bf(odesc, ndesc)
+        ok &= np.array_equal(out_set.bi[fi, :n].cpu().numpy(), obi) and np.array_equal(out_set.bd[fi, :n].cpu().numpy(), obd)
+        ok &= np.array_equal(out_set.sd[fi, :n].cpu().numpy(), osd)
+    return ("bit-exact vs CPU oracle on frames %s (keypoints, descriptors, depth, uRight, matches)" %
+            ", ".join(str(v) for v in spot_frames)) if ok else "MISMATCH vs CPU oracle"
+
+
+def serial_kernel_leg(pipe, n_steps):
+    """The per-kernel timing leg: `n_steps` serialised steps (one stream for everything, HIP-event brackets around every
+    launch), read back step by step.  Returns ({kernel: (ms summed over the steps, launches)} with the sum built from the
+    per-step MEDIAN - one slow step does not move it -, {kernel: {"median", "min", "max"} ms per step})."""
+    pipe.serialise()
+    pipe.gather = "none"
+    pipe.profile(True)
+    per_step, prev = [], {}
+    for _ in range(n_steps):
+        pipe.step()
+        pipe.sync()
+        cur = pipe.profile_read()
+        per_step.append({k: (v[0] - prev.get(k, (0.0, 0))[0], v[1] - prev.get(k, (0.0, 0))[1]) for k, v in cur.items()})
+        prev = cur
+    pipe.profile(False)
+    kernels, stats = {}, {}
+    for k in sorted(prev):
+        ms = sorted(st[k][0] for st in per_step if k in st)
+        launches = per_step[-1][k][1]
+        med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
+        kernels[k] = (med * n_steps, launches * n_steps)
+        stats[k] = {"median": round(med, 4), "min": round(ms[0], 4), "max": round(ms[-1], 4)}
+    return kernels, stats
+
+
 def extra_workloads(lib, dev, torch):
     """Driver-visible figures for the other GPU configurations of BASELINE.json, measured in the same run on the same
     device (short runs; `value` stays the KITTI RGB-L configuration): configs[4] (4K frames + 262 144-point scans,
@@ -591,7 +645,6 @@ def main():
     if plan[0] == "error":
         raise SystemExit("bench.py: " + plan[1])
     if plan[0] == "exec":
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
         sys.stdout.flush()
         os.execv(plan[1][0], plan[1])
     world = plan[1]
@@ -689,31 +742,12 @@ def main():
                                                                last.bd, last.sd)
     k_mean = float(d_n.float().mean().item())
 
-    # ---- parity spot check of what the timed pipeline produced (two frames against the CPU oracle)
+    # ---- parity spot check of what the timed pipeline produced (four frames against the CPU oracle)
     spot = None
     if rank == 0:
         from oracle import oracle_py as O
         orc = O.Extractor(nfeatures, SCALE, LEVELS, INI_TH, MIN_TH)
-        P = O.make_depth_params(proj)
-        h_n = d_n.cpu().numpy()
-        ok = True
-        spot_frames = sorted({0, B // 3, 2 * B // 3, B - 1})
-        for fi in spot_frames:
-            n = int(h_n[fi])
-            kps = d_kp[fi, :n].cpu().numpy().view(np.uint32)
-            okps, odesc, _ = orc(frames[fi])
-            ok &= n == len(okps) and np.array_equal(kps, okps.view(np.uint32).reshape(n, 7))
-            ok &= np.array_equal(d_desc[fi, :n].cpu().numpy(), odesc)
-            od, our, _, _ = O.depth(P, cloud[fi], w, h, np.stack([okps["x"], okps["y"]], 1), okps["x"], want_maps=False)
-            ok &= np.array_equal(d_depth[fi, :n].cpu().numpy().view(np.uint32), od.view(np.uint32))
-            ok &= np.array_equal(d_uright[fi, :n].cpu().numpy().view(np.uint32), our.view(np.uint32))
-            nxt = (fi + 1) % len(frames)     # chunks: the last owned frame meets the halo frame
-            ndesc = orc(frames[nxt])[1]
-            obi, obd, osd = O.hamming_bf(odesc, ndesc)
-            ok &= np.array_equal(d_bi[fi, :n].cpu().numpy(), obi) and np.array_equal(d_bd[fi, :n].cpu().numpy(), obd)
-            ok &= np.array_equal(d_sd[fi, :n].cpu().numpy(), osd)
-        spot = "bit-exact vs CPU oracle on frames %s (keypoints, descriptors, depth, uRight, matches)" % \
-            ", ".join(str(v) for v in spot_frames) if ok else "MISMATCH vs CPU oracle"
+        spot = spot_check(O, orc, O.make_depth_params(proj), frames, cloud, last, sorted({0, B // 3, 2 * B // 3, B - 1}), w, h)
 
     # ---- opt-in variant, reported beside the headline only: no dense ProcessedDepthMap (rgbl_depth_set_sparse), the keypoints'
     # depths come out of the index maps directly.  Same inputs, same lanes; depth / uRight must not change by a bit.
@@ -744,16 +778,12 @@ def main():
     if rank == 0:
         # per-kernel timing leg: one stream for everything, so that the HIP-event brackets around each launch are not
         # stretched by other kernels running concurrently
-        pipe.serialise()
-        pipe.gather = "none"
-        pipe.profile(True)
-        prof_steps = 3
-        for _ in range(prof_steps):
-            step()
-        sync_all()
-        kernels.update(pipe.profile_read())
-        pipe.profile(False)
+        prof_steps = 12
+        kernels, kernel_stats = serial_kernel_leg(pipe, prof_steps)
         roofline = roofline_of(kernels, prof_steps, args.workload, w, h, n_points, k_mean, B, elapsed / args.steps)
+        roofline["kernels_ms_per_step_stats"] = kernel_stats
+        roofline["kernels_ms_per_step_what"] = ("median over %d serialised steps (HIP events on the launch stream, every step read back "
+                                                "on its own), min / max beside it" % prof_steps)
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = min(B, 256)
             fps, n_done, stage_ms, kind = cpu_baseline(frames[:n_cpu], scans, proj, w, h, nfeatures, args.cpu_budget,

@@ -180,6 +180,7 @@ int rgbl_selftest_wrappers(int device, int n, unsigned seed);
 /* Stream control + per-kernel timing (HIP events on the launch stream) for bench.py. */
 int rgbl_extractor_set_stream(rgbl_extractor* h, void* hip_stream /* hipStream_t, NULL = own */);
 void* rgbl_extractor_stream(rgbl_extractor* h); /* hipStream_t currently used by the handle */
+int rgbl_extractor_set_phase_stream(rgbl_extractor* h, void* hip_stream /* hipStream_t, NULL = off */);
 /* the handle's second, internal stream (level-0 FAST / quad-tree and the Gaussian run there next to the resize chain);
  * other handles may queue work behind it with rgbl_*_set_stream */
 void* rgbl_extractor_aux_stream(rgbl_extractor* h);

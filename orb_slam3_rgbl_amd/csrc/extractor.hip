@@ -54,7 +54,13 @@ struct rgbl_extractor {
   hipStream_t lvl_stream = nullptr;  // single frames: FAST + quad-tree of the levels 1 - 2 start behind their own resizes (RGBL_LEVEL_SPLIT=0: off)
   int level_split = 3;               // ... the main stream keeps the levels from this one on
   hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_fast0 = nullptr, ev_desc0 = nullptr, ev_r = nullptr, ev_fb = nullptr;
-  int split_pyr = 0;  // RGBL_SPLIT_PYR=k (opt-in, batches): the pyramid levels k .. L - 1 and their FAST cells leave the main chain
+  hipStream_t phase_stream = nullptr;  // two-phase schedule (rgbl_extractor_set_phase_stream): the pixel phase's stream
+  hipEvent_t ev_done = nullptr;        // ... end of the handle's previous descriptor phase (its scratch is free again)
+  bool ev_done_valid = false;
+  int split_pyr = 0;  // batches: the pyramid levels k .. L - 1 and their FAST cells leave the main chain (default L / 2 from 6 levels on; RGBL_SPLIT_PYR=k, 0 = off)
+  bool gauss_wg256 = false;     // RGBL_GAUSS_BS=256: four-wave workgroups for k_gauss7 (two waves measured faster)
+  bool octree_stamps = false;   // RGBL_OCTREE_STAMPS: the quad-tree kernel leaves phase time stamps (tools/octree_stamps.py)
+  bool octree_no_hist = false;  // RGBL_OCTREE_HIST=0: breadth-first rounds as passes over the keys instead of on the count pyramid
   KernelTimer timer;
   // hipGraph of the host-pointer path (all device pointers of that path are the handle's own buffers, so one captured
   // launch sequence can be replayed): key = (batch, row stride, lapping area, stream)
@@ -397,6 +403,7 @@ int upload_tables(rgbl_extractor* e) {
   RGBL_HIP(hipMemcpy(e->d_rootx, rootx.data(), rootx.size(), hipMemcpyHostToDevice));
   RGBL_HIP(hipMemcpy(e->d_pattern, kBriefPattern, 1024, hipMemcpyHostToDevice));
   if (const char* v = getenv("RGBL_XCD_MAP")) e->xcd_map = v[0] != '0';
+  e->split_pyr = L >= 6 ? L / 2 : 0;   // 8 levels: the levels 4 - 7 (a fifth of the pixels) leave the main chain (round 5: the default)
   if (const char* v = getenv("RGBL_SPLIT_PYR")) e->split_pyr = atoi(v);
   if (const char* v = getenv("RGBL_FAST_BS")) e->fast_waves = atoi(v) == 64 ? 1 : atoi(v) == 128 ? 2 : 0;
   return RGBL_OK;
@@ -486,7 +493,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
     if (tile_end <= tile_begin) return;
     e->timer.begin("k_gauss7", st);
     // two passes with a barrier in between: 16 workgroups of two waves per CU interleave better than 8 of four (0.63 -> 0.54 ms)
-    const bool g128 = !(getenv("RGBL_GAUSS_BS") && atoi(getenv("RGBL_GAUSS_BS")) == 256);
+    const bool g128 = !e->gauss_wg256;
     hipLaunchKernelGGL(g128 ? k_gauss7<128> : k_gauss7<256>, xcd_grid(e->xcd_map, tile_end - tile_begin, batch), dim3(g128 ? 128 : 256), 0, st, e->d_gtiles,
                        d_imgs, stride, frame_stride, e->d_pyr, e->pyr_frame, e->d_blur, e->pyr_frame, tile_begin);
     e->timer.end(st);
@@ -504,8 +511,8 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   ob.level_cnt = e->dense ? e->d_levelcnt : nullptr;
   ob.level_cnt_last = e->d_levelcnt + (size_t)e->cfg.max_batch * L;
   ob.err = e->d_err;
-  ob.dbg = getenv("RGBL_OCTREE_STAMPS") ? e->d_dbg : nullptr;
-  ob.no_hist = (getenv("RGBL_OCTREE_HIST") && getenv("RGBL_OCTREE_HIST")[0] == '0') ? 1 : 0;
+  ob.dbg = e->octree_stamps ? e->d_dbg : nullptr;
+  ob.no_hist = e->octree_no_hist ? 1 : 0;
   // narrow workgroups leave room for more (level, frame) problems per CU; small batches, which cannot fill the chip anyway,
   // take the wide group (shorter passes over the keys).  Node lists of up to 512 / 2048 entries live in LDS
   // (octree_labels.h); beyond that - more than ~9 000 features - the key-moving kernel on global lists takes over.
@@ -554,12 +561,27 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       e->timer.end(st);
     };
     const int sp = (overlap && batch >= 8 && e->split_pyr >= 2 && e->split_pyr < L) ? e->split_pyr : 0;
-    if (sp) {
-      // Opt-in (RGBL_SPLIT_PYR=k, batches): the small levels k .. L - 1 - their resizes are the tail of a chain of dependent
-      // launches, their FAST cells a sixth of the upper levels' - are produced on the auxiliary stream behind level 0's FAST
+    if (overlap && batch >= 8 && e->phase_stream) {
+      // Two-phase schedule: the pixel phase (FAST of level 0, pyramid, FAST of the other levels, compaction - issue-bound,
+      // touches cells / candidate lists / pyramid) on the phase stream, the keypoint phase (quad-trees, Gaussian, descriptors -
+      // latency-bound) on the handle's stream behind it.  Two handles that share both streams and are called alternately run
+      // the pixel phase of call k + 1 next to the keypoint phase of call k (each handle has its own scratch).
+      hipStream_t P = e->phase_stream;
+      if (e->ev_done_valid) RGBL_HIP(hipStreamWaitEvent(P, e->ev_done, 0));
+      launch_fast(P, 0, cells0);
+      for (int l = 1; l < L; ++l) launch_resize(P, l);
+      launch_fast(P, cells0, e->cells_frame);
+      RGBL_HIP(hipEventRecord(e->ev_pyr, P));
+      RGBL_HIP(hipStreamWaitEvent(s, e->ev_pyr, 0));
+      launch_octree(s, 0, L);
+      launch_gauss(s, 0, e->blur_tiles.tile_off[L]);
+    } else if (sp) {
+      // Batches (RGBL_SPLIT_PYR=k; default k = L / 2): the small levels k .. L - 1 - their resizes are the tail of a chain of
+      // dependent launches, their FAST cells a fifth of the pixels - are produced on the auxiliary stream behind level 0's FAST
       // cells, so that the main stream's FAST launch (levels 1 .. k - 1) starts after k - 1 resizes instead of L - 1.
-      // Measured at the end of round 3: k = 4 144.7 k, k = 3 144.3 k, k = 5 143.0 k against 142.9 - 143.3 k frames/s - one
-      // per cent, left off by default.
+      // Round 3: k = 4 144.7 k, k = 3 144.3 k, k = 5 143.0 k against 142.9 - 143.3 k frames/s, left off.  Round 5, three A/B
+      // calls on the KITTI step: k = 4 +1.8 ... +2.7 % (145.4 / 146.3 / 144.4 k against 142.8 / 142.9 / 140.6 k), k = 3 and 5
+      // nothing; the small levels' quad-trees on the auxiliary stream as well: -2 %.  The default since.
       RGBL_HIP(hipEventRecord(e->ev_start, s));
       RGBL_HIP(hipStreamWaitEvent(bs, e->ev_start, 0));
       launch_fast(bs, 0, cells0);
@@ -659,7 +681,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   if (lapping) lap_cap = std::min(cap, e->out_cap);
   // Batches: level 0's keypoints (its quad-tree and its Gaussian are done long before the upper levels' quad-trees) are
   // described on the auxiliary stream next to those quad-trees; the main stream takes the other levels and the frame totals.
-  const bool split_desc = !e->timer.enabled && batch >= 8 && L > 1 && e->geom[1].koff > 0;
+  const bool split_desc = !e->timer.enabled && batch >= 8 && L > 1 && e->geom[1].koff > 0 && !e->phase_stream;
   const int slot_split = split_desc ? e->geom[1].koff : 0;
   auto launch_desc = [&](hipStream_t st, int slot_begin, int slot_end, int write_total) {
     if (slot_end <= slot_begin) return;
@@ -678,6 +700,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   }
   launch_desc(s, slot_split, e->kp_frame, 1);
   if (split_desc) RGBL_HIP(hipStreamWaitEvent(s, e->ev_desc0, 0));
+  if (e->phase_stream) { RGBL_HIP(hipEventRecord(e->ev_done, s)); e->ev_done_valid = true; }
   if (lapping) {
     (void)lap_cap;
     if (cap < e->out_cap) {
@@ -742,7 +765,11 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
   RGBL_HIP(hipSetDevice(device));
   rgbl_extractor* e = new rgbl_extractor;
   e->cfg = *cfg;
+  // Tuning switches are read here, once per handle (include/rgbl_frontend.h lists them) - never on a launch path.
   if (const char* v = getenv("RGBL_GRAPH")) e->graph_ok = atoi(v) != 0;
+  if (const char* v = getenv("RGBL_GAUSS_BS")) e->gauss_wg256 = atoi(v) == 256;
+  if (getenv("RGBL_OCTREE_STAMPS")) e->octree_stamps = true;
+  if (const char* v = getenv("RGBL_OCTREE_HIST")) e->octree_no_hist = v[0] == '0';
   if (const char* v = getenv("RGBL_OCTREE_LDSKEYS")) e->octree_ldskeys = atoi(v) != 0;
   if (const char* v = getenv("RGBL_LEVEL_SPLIT")) e->level_split = atoi(v);
   if (const char* v = getenv("RGBL_OCTREE_WG")) { const int wg = atoi(v); if (wg == kOctNarrow || wg == kOctWide) e->octree_wg = wg; }
@@ -771,6 +798,7 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
                         hipEventCreateWithFlags(&e->ev_fast0, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_desc0, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_r, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_fb, hipEventDisableTiming) != hipSuccess)) {
     set_error("hipStreamCreate failed");
     rc = RGBL_ERR_HIP;
@@ -803,6 +831,7 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   if (e->ev_desc0) (void)hipEventDestroy(e->ev_desc0);
   if (e->ev_r) (void)hipEventDestroy(e->ev_r);
   if (e->ev_fb) (void)hipEventDestroy(e->ev_fb);
+  if (e->ev_done) (void)hipEventDestroy(e->ev_done);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -1271,6 +1300,15 @@ int rgbl_extractor_set_stream(rgbl_extractor* e, void* hip_stream) {
   if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipStreamSynchronize(e->stream));
   e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  return RGBL_OK;
+}
+
+int rgbl_extractor_set_phase_stream(rgbl_extractor* e, void* hip_stream) {
+  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipStreamSynchronize(e->stream));
+  if (e->phase_stream) RGBL_HIP(hipStreamSynchronize(e->phase_stream));
+  e->phase_stream = (hipStream_t)hip_stream;
+  e->ev_done_valid = false;
   return RGBL_OK;
 }
 

@@ -1254,6 +1254,11 @@ struct rgbl_matcher {
   size_t buf_size = 0;
   uint8_t* h_pin = nullptr;  // grow-only page-locked mirror of the brute-force scan's inputs / outputs (rgbl_hamming_bf)
   size_t pin_size = 0;
+  // tuning switches, read ONCE at rgbl_matcher_create (include/rgbl_frontend.h lists them): never on a launch path
+  bool bf_matrix = true;   // RGBL_BF_MFMA=0: the VALU popcount scan (k_hamming_bf)
+  bool bf_fp4 = true;      // RGBL_BF_MFMA=i8: v_mfma_i32_32x32x32_i8 (k_hamming_mfma) instead of the block-scaled FP4 instruction
+  bool bf_split = true;    // RGBL_BF_SPLIT=0: one pair per call without train-set slices
+  int bf_lds_pad = 0;      // EXPERIMENT
 };
 
 namespace {
@@ -1265,17 +1270,10 @@ int ensure_arena(rgbl_matcher* m, size_t bytes) {
   m->buf_size = sz;
   return RGBL_OK;
 }
-// RGBL_BF_MFMA=0 selects the VALU popcount scan (k_hamming_bf) instead of the matrix-core one (A/B measurements)
-// (read per call: a getenv is nothing next to a launch, and the tests switch variants inside one process)
-inline bool bf_on_matrix_cores() {
-  const char* e = getenv("RGBL_BF_MFMA");
-  return !(e && e[0] == '0');
-}
-// RGBL_BF_MFMA=i8 keeps the i8 instruction (k_hamming_mfma); default: the block-scaled FP4 one (k_hamming_fp4)
-inline bool bf_on_fp4() {
-  const char* e = getenv("RGBL_BF_MFMA");
-  return !(e && e[0] == 'i');
-}
+// RGBL_BF_MFMA=0 selects the VALU popcount scan (k_hamming_bf) instead of the matrix-core one, =i8 the i8 instruction
+// (k_hamming_mfma) instead of the block-scaled FP4 one (k_hamming_fp4, the default): read when the handle is created.
+inline bool bf_on_matrix_cores(const rgbl_matcher* m) { return m->bf_matrix; }
+inline bool bf_on_fp4(const rgbl_matcher* m) { return m->bf_fp4; }
 struct Arena {
   uint8_t* base; size_t off = 0;
   template <class T> T* take(size_t count) {
@@ -1307,6 +1305,9 @@ int rgbl_matcher_create(int device, rgbl_matcher** out) {
   RGBL_HIP(hipSetDevice(device));
   rgbl_matcher* m = new rgbl_matcher;
   m->device = device;
+  if (const char* v = getenv("RGBL_BF_MFMA")) { m->bf_matrix = v[0] != '0'; m->bf_fp4 = v[0] != 'i'; }
+  if (const char* v = getenv("RGBL_BF_SPLIT")) m->bf_split = v[0] != '0';
+  if (const char* v = getenv("RGBL_BF_LDS_PAD")) m->bf_lds_pad = atoi(v);
   if (hipStreamCreate(&m->own_stream) != hipSuccess) { delete m; set_error("hipStreamCreate failed"); return RGBL_ERR_HIP; }
   m->stream = m->own_stream;
   *out = m;
@@ -1444,9 +1445,9 @@ int rgbl_hamming_bf_batch_device(rgbl_matcher* m, const uint8_t* d_desc, const i
   }
   if (n_pairs == 0) return RGBL_OK;
   RGBL_HIP(hipSetDevice(m->device));
-  if (bf_on_matrix_cores()) {
-    m->timer.begin(bf_on_fp4() ? "k_hamming_fp4" : "k_hamming_mfma", m->stream);
-    if (bf_on_fp4()) hipLaunchKernelGGL(k_hamming_fp4, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
+  if (bf_on_matrix_cores(m)) {
+    m->timer.begin(bf_on_fp4(m) ? "k_hamming_fp4" : "k_hamming_mfma", m->stream);
+    if (bf_on_fp4(m)) hipLaunchKernelGGL(k_hamming_fp4, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), m->bf_lds_pad, m->stream,
                        d_desc, d_n, cap, d_pair_a, d_pair_b, d_best_idx, d_best_dist, d_second_dist, 1, (uint32_t*)nullptr);
     else hipLaunchKernelGGL(k_hamming_mfma, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
                        d_desc, d_n, cap, d_pair_a, d_pair_b, d_best_idx, d_best_dist, d_second_dist);
@@ -1474,7 +1475,7 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   // cut into slices of whole 64-row stages, one launch slice each, folded by k_hamming_merge (FP4 kernel only).
   const int qblocks = (na + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, stages = (nb + kBfStageRows - 1) / kBfStageRows;
   int splits = 1;
-  if (bf_on_matrix_cores() && bf_on_fp4() && !(getenv("RGBL_BF_SPLIT") && getenv("RGBL_BF_SPLIT")[0] == '0'))
+  if (bf_on_matrix_cores(m) && bf_on_fp4(m) && m->bf_split)
     splits = std::max(1, std::min(std::min(16, stages / 4), 128 / std::max(qblocks, 1)));
   RGBL_TRY(ensure_arena(m, pad256((size_t)2 * cap * 32) + pad256(8) + 3 * pad256((size_t)na * 4) + pad256((size_t)splits * na * 8)));
   Arena A{m->d_buf};
@@ -1508,9 +1509,9 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
     RGBL_HIP(hipMemcpyAsync(d_n, counts, sizeof(counts), hipMemcpyHostToDevice, s));
   }
   // pair_a/pair_b == NULL selects the fixed pair (frame 0 -> frame 1)
-  if (bf_on_matrix_cores()) {
-    m->timer.begin(bf_on_fp4() ? "k_hamming_fp4" : "k_hamming_mfma", s);
-    if (bf_on_fp4()) {
+  if (bf_on_matrix_cores(m)) {
+    m->timer.begin(bf_on_fp4(m) ? "k_hamming_fp4" : "k_hamming_mfma", s);
+    if (bf_on_fp4(m)) {
       hipLaunchKernelGGL(k_hamming_fp4, xcd_grid(false, qblocks, splits), dim3(256), 0, s, d_desc, d_n, cap, (const int32_t*)nullptr,
                          (const int32_t*)nullptr, d_bi, d_bd, d_sd, splits, d_partial);
       if (splits > 1) hipLaunchKernelGGL(k_hamming_merge, dim3((na + 255) / 256), dim3(256), 0, s, d_partial, na, splits, d_bi, d_bd, d_sd);

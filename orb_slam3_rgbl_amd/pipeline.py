@@ -168,6 +168,25 @@ class FrontEndPipeline:
                             "two-lanes" if (gather != "none" and n_lanes > 1) else gather, shared_low=wrap_low)
                       for _ in range(n_lanes)]
         self.ex, self.dm, self.mt = self.lanes[0].ex, self.lanes[0].dm, self.lanes[0].mt
+        self.two_phase = False
+        if n_lanes == 2 and os.environ.get("RGBL_TWO_PHASE"):
+            # EXPERIMENT: two extractor handles (= two sets of scratch) called alternately on ONE pair of streams: the pixel phase
+            # of step k + 1 next to the keypoint phase of step k; one depth module, one matcher
+            self.two_phase = True
+            self.s_q = C.c_void_p(); self.s_p = C.c_void_p()
+            L.check(lib, lib.rgbl_stream_create_on(index, C.byref(self.s_q), 0))
+            L.check(lib, lib.rgbl_stream_create_on(index, C.byref(self.s_p), 0))
+            for ln in self.lanes:
+                L.check(lib, lib.rgbl_extractor_set_stream(ln.ex.h, self.s_q))
+                L.check(lib, lib.rgbl_extractor_set_phase_stream(ln.ex.h, self.s_p))
+            l0, l1 = self.lanes
+            l1.dm.close(); l1.mt.close()
+            if l1.own_stream is not None and l1.owns_stream:
+                lib.rgbl_stream_destroy(l1.own_stream)
+            l1.own_stream = None
+            l1.dm, l1.mt = l0.dm, l0.mt
+            for ln in self.lanes:
+                ln.streams(lib)
         # sparse_depth: no dense ProcessedDepthMap (rgbl_depth_set_sparse) - the step never hands it out anyway
         for ln in self.lanes:
             ln.dm.SetSparseUpsampling(sparse_depth)
@@ -264,12 +283,15 @@ class FrontEndPipeline:
         L.check(lib, lib.rgbl_event_record(o.ev["extracted"], ln.s_ex))
         # LiDAR projection + up-sampling: independent of the keypoints, runs concurrently on the depth stream
         n_points = self.n_points
-        L.check(lib, lib.rgbl_depth_project_batch_device(ln.dm.h, p(self.d_cloud), B, n_points, n_points, 4 * n_points, w, h, None))
+        if not os.environ.get("RGBL_EXP_NO_DEPTH"):
+          L.check(lib, lib.rgbl_depth_project_batch_device(ln.dm.h, p(self.d_cloud), B, n_points, n_points, 4 * n_points, w, h, None))
         L.check(lib, lib.rgbl_event_wait(ln.s_dm, o.ev["extracted"]))
-        L.check(lib, lib.rgbl_depth_gather_batch_device(ln.dm.h, B, w, h, p(o.kp), p(o.n), cap, None, p(o.depth), p(o.uright)))
+        if not os.environ.get("RGBL_EXP_NO_DEPTH"):
+          L.check(lib, lib.rgbl_depth_gather_batch_device(ln.dm.h, B, w, h, p(o.kp), p(o.n), cap, None, p(o.depth), p(o.uright)))
         L.check(lib, lib.rgbl_event_record(o.ev["depth_done"], ln.s_dm))
         L.check(lib, lib.rgbl_event_wait(ln.s_mt, o.ev["extracted"]))
-        L.check(lib, lib.rgbl_hamming_bf_batch_device(ln.mt.h, p(o.desc), p(o.n), cap, p(self.pair_a), p(self.pair_b), self.B, p(o.bi),
+        if not os.environ.get("RGBL_EXP_NO_MATCH"):
+          L.check(lib, lib.rgbl_hamming_bf_batch_device(ln.mt.h, p(o.desc), p(o.n), cap, p(self.pair_a), p(self.pair_b), self.B, p(o.bi),
                                                       p(o.bd), p(o.sd)))
         L.check(lib, lib.rgbl_event_record(o.ev["match_done"], ln.s_mt))
         if self.gather != "none":
@@ -407,8 +429,10 @@ class FrontEndPipeline:
         if self.g is not None:
             self.lib.rgbl_gather_destroy(self.g)
             self.g = None
-        for ln in getattr(self, "all_lanes", self.lanes):
-            ln.ex.close(); ln.dm.close(); ln.mt.close()
+        for i, ln in enumerate(getattr(self, "all_lanes", self.lanes)):
+            ln.ex.close()
+            if not (self.two_phase and i > 0):
+                ln.dm.close(); ln.mt.close()
             if ln.own_stream is not None:
                 # a stream PyTorch has wrapped is the process-wide one of _WRAPPED_LOW_STREAMS and stays; the others go
                 if ln.owns_stream:

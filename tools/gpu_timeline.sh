@@ -20,16 +20,17 @@ ix = {c: i for i, c in enumerate(cols)}
 name_c = "name" if "name" in ix else [c for c in cols if "name" in c][0]
 st = "start" if "start" in ix else [c for c in cols if "start" in c][0]
 en = "end" if "end" in ix else [c for c in cols if c.startswith("end")][0]
-q = [c for c in cols if "queue" in c or "stream" in c]
+q = [c for c in ("stream_id", "queue_id") if c in ix]   # the HIP stream AND the HSA queue it was mapped to (streams can share one)
 rows = [r for r in rows if "k_" in str(r[ix[name_c]])]
 rows.sort(key=lambda r: r[ix[st]])
 t0 = rows[0][ix[st]]
 with open("gpurun_out/timeline.csv", "w", newline="") as f:
     w = csv.writer(f)
-    w.writerow(["kernel", "queue", "start_us", "end_us"])
+    w.writerow(["kernel", "stream", "queue", "start_us", "end_us"])
     for r in rows:
         n = str(r[ix[name_c]]).split("(")[0].replace("rgbl::", "").replace("void ", "").split("<")[0]
-        w.writerow([n, r[ix[q[0]]] if q else "", "%.1f" % ((r[ix[st]] - t0) / 1e3), "%.1f" % ((r[ix[en]] - t0) / 1e3)])
+        w.writerow([n, r[ix["stream_id"]] if "stream_id" in ix else "", r[ix["queue_id"]] if "queue_id" in ix else "",
+                    "%.1f" % ((r[ix[st]] - t0) / 1e3), "%.1f" % ((r[ix[en]] - t0) / 1e3)])
 print(len(rows), "dispatches")
 PY
 rm -rf $OUT/prof_tl
