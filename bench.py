@@ -463,12 +463,13 @@ def extra_workloads(lib, dev, torch):
     try:
         from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline
         w, h, nf, n_az, B = WORKLOADS["4k"]
-        seq = synth.Sequence(7, w, h, n_frames=4)
-        distinct = [seq.frame(i) for i in range(4)]
-        frames = torch.from_numpy(np.stack([distinct[i % 4] for i in range(B)])).to(dev)
-        scan = synth.lidar_scan(7000, n_az=n_az)
-        n_points = scan.shape[1]
-        cloud = torch.from_numpy(np.stack([scan] * B)).to(dev)
+        # 64 DISTINCT frames and scans (round 4 repeated 4 frames and one scan 16 x / 64 x)
+        seq = synth.Sequence(7, w, h, n_frames=B)
+        frames_np = np.stack([seq.frame(i) for i in range(B)])
+        frames = torch.from_numpy(frames_np).to(dev)
+        cloud_np = np.stack([synth.lidar_scan(7000 + i, n_az=n_az) for i in range(B)])
+        n_points = cloud_np.shape[2]
+        cloud = torch.from_numpy(cloud_np).to(dev)
         K = synth.KITTI_K.copy()
         K[0, 0] = K[1, 1] = 718.856 * w / synth.KITTI_W
         K[0, 2], K[1, 2] = w / 2.0, h / 2.0
@@ -478,36 +479,38 @@ def extra_workloads(lib, dev, torch):
         pipe.set_inputs(frames, cloud)
         dt = time_steps(pipe.step, pipe.sync, 2, 6)
         k_mean = float(pipe.last().n.float().mean().item())
-        pipe.serialise()
-        pipe.profile(True)
-        for _ in range(2):
-            pipe.step()
-        pipe.sync()
-        kernels = pipe.profile_read()
-        pipe.profile(False)
+        # parity of exactly what was timed: the batched path (k_compact_cells, XCD grid, k_octree<1024, 2048> on the count pyramid)
+        # on the first and the last frame of the last timed step, against the CPU oracle - the headline's check, same wording
+        from oracle import oracle_py as O
+        spot = spot_check(O, O.Extractor(nf, SCALE, LEVELS, INI_TH, MIN_TH), O.make_depth_params(proj), frames_np, cloud_np, pipe.last(),
+                          [0, B - 1], w, h)
+        kernels, kstats = serial_kernel_leg(pipe, 4)
         out["cfg5_4k"] = {"frames_per_s": B / dt, "ms_per_step": dt * 1e3, "frames_per_step": B, "image": [w, h], "nfeatures": nf,
-                          "lidar_points": n_points, "keypoints_per_frame": k_mean,
+                          "lidar_points": n_points, "keypoints_per_frame": k_mean, "distinct_frames_and_scans": B,
+                          "parity_spot_check": spot,
                           "what": "extract + depth + match, inputs resident in HBM, 1 GPU",
-                          "roofline": roofline_of(kernels, 2, "4k", w, h, n_points, k_mean, B, dt)}
+                          "roofline": roofline_of(kernels, 4, "4k", w, h, n_points, k_mean, B, dt)}
+        out["cfg5_4k"]["roofline"]["kernels_ms_per_step_stats"] = kstats
         pipe.close()
-        del frames, cloud, pipe
+        del frames, cloud, pipe, frames_np, cloud_np
     except Exception as e:  # never lose the main line over an extra figure
         out["cfg5_4k"] = {"error": repr(e)}
 
     # ---- configs[2]: KITTI stereo front end
     try:
         w, h, B = synth.KITTI_W, synth.KITTI_H, 64
-        sq = [synth.Sequence(40 + i, w + 128, h, n_frames=1).frame(0) for i in range(4)]
+        sseq = synth.Sequence(40, w + 128, h, n_frames=B)
         lefts, rights = [], []
-        for full in sq:  # rectified pair: the right view is the scene shifted by a row-dependent disparity of 4 .. 40 px
+        for i in range(B):  # 64 distinct rectified pairs: the right view is the scene shifted by a row-dependent disparity of 4 .. 40 px
+            full = sseq.frame(i)
             lefts.append(np.ascontiguousarray(full[:, 64:64 + w]))
             r = np.empty((h, w), np.uint8)
             for y in range(h):
                 d = int(round(4 + 36.0 * y / h))
                 r[y] = full[y, 64 + d:64 + d + w]
             rights.append(r)
-        dl = torch.from_numpy(np.stack([lefts[i % 4] for i in range(B)])).to(dev)
-        dr = torch.from_numpy(np.stack([rights[i % 4] for i in range(B)])).to(dev)
+        dl = torch.from_numpy(np.stack(lefts)).to(dev)
+        dr = torch.from_numpy(np.stack(rights)).to(dev)
         exl = F.ORBextractor(2000, SCALE, LEVELS, 20, 7, w, h, max_batch=B, device=dev.index, lib=lib)
         exr = F.ORBextractor(2000, SCALE, LEVELS, 20, 7, w, h, max_batch=B, device=dev.index, lib=lib)
         cap = exl.max_keypoints
@@ -526,7 +529,25 @@ def extra_workloads(lib, dev, torch):
             L.check(lib, lib.rgbl_stereo_matches_batch_device(exl.h, exr.h, B, p(kl), p(ddl), p(nl), p(kr), p(ddr), p(nr), cap,
                                                               0.54, 386.1448, p(ur), p(dp)))
         dt = time_steps(step, sync, 2, 8)
+        # parity of what was timed: both extractions and Frame::ComputeStereoMatches of the first and the last pair vs the CPU oracle
+        from oracle import oracle_py as O
+        ok = True
+        for fi in (0, B - 1):
+            ol, orr = O.Extractor(2000, SCALE, LEVELS, 20, 7), O.Extractor(2000, SCALE, LEVELS, 20, 7)
+            kL, dL, _ = ol(lefts[fi])
+            kR, dR, _ = orr(rights[fi])
+            n_l, n_r = int(nl[fi].item()), int(nr[fi].item())
+            ok &= n_l == len(kL) and n_r == len(kR)
+            ok &= np.array_equal(kl[fi, :n_l].cpu().numpy().view(np.uint32), kL.view(np.uint32).reshape(len(kL), 7))
+            ok &= np.array_equal(kr[fi, :n_r].cpu().numpy().view(np.uint32), kR.view(np.uint32).reshape(len(kR), 7))
+            ok &= np.array_equal(ddl[fi, :n_l].cpu().numpy(), dL) and np.array_equal(ddr[fi, :n_r].cpu().numpy(), dR)
+            our, odp = O.stereo_matches(ol, orr, kL, dL, kR, dR, 0.54, 386.1448)
+            ok &= np.array_equal(ur[fi, :n_l].cpu().numpy().view(np.uint32), np.asarray(our, np.float32).view(np.uint32))
+            ok &= np.array_equal(dp[fi, :n_l].cpu().numpy().view(np.uint32), np.asarray(odp, np.float32).view(np.uint32))
         out["cfg3_stereo"] = {"stereo_frames_per_s": B / dt, "ms_per_step": dt * 1e3, "pairs_per_step": B, "image": [w, h],
+                              "distinct_pairs": B,
+                              "parity_spot_check": ("bit-exact vs CPU oracle on pairs 0, %d (keypoints and descriptors of both views, uRight, depth)" % (B - 1))
+                                                   if ok else "MISMATCH vs CPU oracle",
                               "nfeatures": 2000, "fast_thresholds": [20, 7], "stereo_matches_per_frame": float((dp > 0).float().sum().item() / B),
                               "what": "left + right extraction + Frame::ComputeStereoMatches on the resident pyramids, 1 GPU"}
         exl.close(); exr.close()
@@ -732,10 +753,32 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     sync_all()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    multi = None
+    if world > 1 or dist.is_initialized():
+        # what an N > 1 line needs so that "RCCL saw N ranks" is on record, not taken on trust: the communicator's own view of the
+        # world, every rank's own rate (its clock around the same barriers), and what the root actually received per step
+        own = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(every, own)
+        per_rank = [float(v.item()) for v in every]
+        elapsed = max(per_rank)
+        multi = {"per_rank_frames_per_s": [round(B * args.steps / v, 1) for v in per_rank]}
+        cw, cr, cv = C.c_int(0), C.c_int(0), C.c_int(0)
+        if comm is not None:
+            lib.rgbl_comm_info(comm, C.byref(cw), C.byref(cr), None, C.byref(cv))
+            multi["rccl"] = {"world": cw.value, "rank_of_this_process": cr.value, "version": cv.value,
+                             "source": "rgbl_comm_info of the communicator the gather ran on (ncclCommInitRank through the C ABI)"}
+        else:
+            multi["rccl"] = {"world": dist.get_world_size(), "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                             "source": "torch.distributed process group (backend nccl = RCCL)"}
+        if rank == 0 and gather != "none" and pipe.received:
+            got = pipe.received[-1]     # the last exchange: per rank (counts [B], records)
+            per_rank_bytes = [int(np.minimum(np.maximum(c, 0), cap).sum()) * 68 for c, _ in got]
+            multi["gathered_bytes_per_step"] = int(sum(per_rank_bytes))
+            multi["gathered_bytes_per_step_per_rank"] = per_rank_bytes
+            multi["root_ingest_GB/s"] = round(sum(per_rank_bytes[1:]) / (elapsed / args.steps) / 1e9, 2)
+            multi["root_ingest_what"] = ("bytes of the ranks 1 .. N - 1 arriving at rank 0 per step over the step time (one xGMI link per "
+                                         "peer, exact-size ncclRecv each); the root's own records are a device copy")
 
     last = pipe.last()
     d_n, d_kp, d_desc, d_depth, d_uright, d_bi, d_bd, d_sd = (last.n, last.kp, last.desc, last.depth, last.uright, last.bi,
@@ -843,6 +886,7 @@ def main():
                                           "once at the end (--gather final) it would be a serial tail of about a third of the compute time",
                                   "final": "final: the records of all steps stay packed in HBM and are exchanged once, inside the timed region"}[gather]},
             "parity_spot_check": spot,
+            "multi_gpu": multi,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -180,7 +180,6 @@ int rgbl_selftest_wrappers(int device, int n, unsigned seed);
 /* Stream control + per-kernel timing (HIP events on the launch stream) for bench.py. */
 int rgbl_extractor_set_stream(rgbl_extractor* h, void* hip_stream /* hipStream_t, NULL = own */);
 void* rgbl_extractor_stream(rgbl_extractor* h); /* hipStream_t currently used by the handle */
-int rgbl_extractor_set_phase_stream(rgbl_extractor* h, void* hip_stream /* hipStream_t, NULL = off */);
 /* the handle's second, internal stream (level-0 FAST / quad-tree and the Gaussian run there next to the resize chain);
  * other handles may queue work behind it with rgbl_*_set_stream */
 void* rgbl_extractor_aux_stream(rgbl_extractor* h);
@@ -202,7 +201,7 @@ int rgbl_pack_records_device(void* hip_stream, const int32_t* d_n, const rgbl_ke
  *
  *   rank 0:  rgbl_comm_unique_id(id);  -> id reaches the other ranks out of band (file, socket, MPI_Bcast, a torch store)
  *   all:     rgbl_comm_create(id, world, rank, device, &comm);            ncclCommInitRank
- *            rgbl_gather_create(comm, batch, cap, slots, stream, &g);
+ *            rgbl_gather_create(comm, device, batch, cap, slots, stream, &g);
  *   per step k (slot = k % slots), behind the step's kernels, nothing waits on the host:
  *            rgbl_gather_pack(g, slot, d_n, d_kp, d_desc, d_depth, d_uright, wait_events, n, done_event);
  *                 pack (rgbl_pack_records_device) + phase 1: ncclAllGather of the per-frame counts of every rank, their copy into
@@ -212,6 +211,14 @@ int rgbl_pack_records_device(void* hip_stream, const int32_t* d_n, const rgbl_ke
  *                 phase 2: the host waits for THAT slot's counts only and posts one exact-size ncclSend (non-root) resp. one
  *                 ncclRecv per peer (root) inside one ncclGroup - on MI355X one xGMI link per peer, in parallel
  *   root:    rgbl_gather_sync(g); rgbl_gather_result(g, r, &counts, &d_records, &n) for r = 0 .. world - 1
+ *            The root owns TWO receive banks, used alternately: what rgbl_gather_result hands out is overwritten by the SECOND
+ *            following rgbl_gather_exchange.  A gather at the end that exchanges several slots in a row must copy every
+ *            exchange's records out (rgbl_gather_copy_result, queued on the gather's stream) before the exchange after next.
+ *   Errors:  a slot is packed once and exchanged once, in that order (RGBL_ERR_INVALID otherwise - a rank that packed over a
+ *            step it never exchanged would be one all-gather ahead of its peers).  An exchange that fails after some transfers
+ *            were posted aborts the communicator (ncclCommAbort: the peers' matching calls return with an error instead of
+ *            hanging) and the gather handle answers RGBL_ERR_COMM from then on.  rgbl_comm_destroy while gather handles still
+ *            use the communicator is deferred to the last rgbl_gather_destroy.
  *
  * Everything is queued on ONE stream the library controls (default: a low-priority stream of its own; or the caller's, e.g. the
  * low-priority stream of the Hamming scan): the collectives do not get a stream of their own the way a framework's process group

@@ -134,7 +134,6 @@ SYMBOLS = {
     "rgbl_extractor_debug_stamps": (_I, [_V, _V, _I]),
     "rgbl_selftest_wrappers": (_I, [_I, _I, C.c_uint]),
     "rgbl_extractor_set_stream": (_I, [_V, _V]),
-    "rgbl_extractor_set_phase_stream": (_I, [_V, _V]),
     "rgbl_extractor_profile": (_I, [_V, _I]),
     "rgbl_extractor_profile_read": (_I, [_V, _V, _V, _V, _I]),
     "rgbl_depth_create": (_I, [C.POINTER(DepthCfg), _I, C.POINTER(_V)]),

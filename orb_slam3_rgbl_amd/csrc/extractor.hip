@@ -54,9 +54,6 @@ struct rgbl_extractor {
   hipStream_t lvl_stream = nullptr;  // single frames: FAST + quad-tree of the levels 1 - 2 start behind their own resizes (RGBL_LEVEL_SPLIT=0: off)
   int level_split = 3;               // ... the main stream keeps the levels from this one on
   hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_start = nullptr, ev_fast0 = nullptr, ev_desc0 = nullptr, ev_r = nullptr, ev_fb = nullptr;
-  hipStream_t phase_stream = nullptr;  // two-phase schedule (rgbl_extractor_set_phase_stream): the pixel phase's stream
-  hipEvent_t ev_done = nullptr;        // ... end of the handle's previous descriptor phase (its scratch is free again)
-  bool ev_done_valid = false;
   int split_pyr = 0;  // batches: the pyramid levels k .. L - 1 and their FAST cells leave the main chain (default L / 2 from 6 levels on; RGBL_SPLIT_PYR=k, 0 = off)
   bool gauss_wg256 = false;     // RGBL_GAUSS_BS=256: four-wave workgroups for k_gauss7 (two waves measured faster)
   bool octree_stamps = false;   // RGBL_OCTREE_STAMPS: the quad-tree kernel leaves phase time stamps (tools/octree_stamps.py)
@@ -561,21 +558,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       e->timer.end(st);
     };
     const int sp = (overlap && batch >= 8 && e->split_pyr >= 2 && e->split_pyr < L) ? e->split_pyr : 0;
-    if (overlap && batch >= 8 && e->phase_stream) {
-      // Two-phase schedule: the pixel phase (FAST of level 0, pyramid, FAST of the other levels, compaction - issue-bound,
-      // touches cells / candidate lists / pyramid) on the phase stream, the keypoint phase (quad-trees, Gaussian, descriptors -
-      // latency-bound) on the handle's stream behind it.  Two handles that share both streams and are called alternately run
-      // the pixel phase of call k + 1 next to the keypoint phase of call k (each handle has its own scratch).
-      hipStream_t P = e->phase_stream;
-      if (e->ev_done_valid) RGBL_HIP(hipStreamWaitEvent(P, e->ev_done, 0));
-      launch_fast(P, 0, cells0);
-      for (int l = 1; l < L; ++l) launch_resize(P, l);
-      launch_fast(P, cells0, e->cells_frame);
-      RGBL_HIP(hipEventRecord(e->ev_pyr, P));
-      RGBL_HIP(hipStreamWaitEvent(s, e->ev_pyr, 0));
-      launch_octree(s, 0, L);
-      launch_gauss(s, 0, e->blur_tiles.tile_off[L]);
-    } else if (sp) {
+    if (sp) {
       // Batches (RGBL_SPLIT_PYR=k; default k = L / 2): the small levels k .. L - 1 - their resizes are the tail of a chain of
       // dependent launches, their FAST cells a fifth of the pixels - are produced on the auxiliary stream behind level 0's FAST
       // cells, so that the main stream's FAST launch (levels 1 .. k - 1) starts after k - 1 resizes instead of L - 1.
@@ -681,7 +664,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   if (lapping) lap_cap = std::min(cap, e->out_cap);
   // Batches: level 0's keypoints (its quad-tree and its Gaussian are done long before the upper levels' quad-trees) are
   // described on the auxiliary stream next to those quad-trees; the main stream takes the other levels and the frame totals.
-  const bool split_desc = !e->timer.enabled && batch >= 8 && L > 1 && e->geom[1].koff > 0 && !e->phase_stream;
+  const bool split_desc = !e->timer.enabled && batch >= 8 && L > 1 && e->geom[1].koff > 0;
   const int slot_split = split_desc ? e->geom[1].koff : 0;
   auto launch_desc = [&](hipStream_t st, int slot_begin, int slot_end, int write_total) {
     if (slot_end <= slot_begin) return;
@@ -700,7 +683,6 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   }
   launch_desc(s, slot_split, e->kp_frame, 1);
   if (split_desc) RGBL_HIP(hipStreamWaitEvent(s, e->ev_desc0, 0));
-  if (e->phase_stream) { RGBL_HIP(hipEventRecord(e->ev_done, s)); e->ev_done_valid = true; }
   if (lapping) {
     (void)lap_cap;
     if (cap < e->out_cap) {
@@ -798,7 +780,6 @@ int rgbl_extractor_create(const rgbl_extractor_cfg* cfg, int device, rgbl_extrac
                         hipEventCreateWithFlags(&e->ev_fast0, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_desc0, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_r, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_fb, hipEventDisableTiming) != hipSuccess)) {
     set_error("hipStreamCreate failed");
     rc = RGBL_ERR_HIP;
@@ -831,7 +812,6 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   if (e->ev_desc0) (void)hipEventDestroy(e->ev_desc0);
   if (e->ev_r) (void)hipEventDestroy(e->ev_r);
   if (e->ev_fb) (void)hipEventDestroy(e->ev_fb);
-  if (e->ev_done) (void)hipEventDestroy(e->ev_done);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -1300,15 +1280,6 @@ int rgbl_extractor_set_stream(rgbl_extractor* e, void* hip_stream) {
   if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipStreamSynchronize(e->stream));
   e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
-  return RGBL_OK;
-}
-
-int rgbl_extractor_set_phase_stream(rgbl_extractor* e, void* hip_stream) {
-  if (!e) { set_error("null handle"); return RGBL_ERR_INVALID; }
-  RGBL_HIP(hipStreamSynchronize(e->stream));
-  if (e->phase_stream) RGBL_HIP(hipStreamSynchronize(e->phase_stream));
-  e->phase_stream = (hipStream_t)hip_stream;
-  e->ev_done_valid = false;
   return RGBL_OK;
 }
 

@@ -37,6 +37,7 @@ struct NcclApi {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommDestroy) CommAbort = nullptr;   // ncclCommAbort has ncclCommDestroy's signature; optional (null: no abort on errors)
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclSend) Send = nullptr;
@@ -62,6 +63,7 @@ NcclApi& nccl() {
     api.GetVersion = &ncclGetVersion; api.GetUniqueId = &ncclGetUniqueId; api.CommInitRank = &ncclCommInitRank;
     api.CommDestroy = &ncclCommDestroy; api.GetErrorString = &ncclGetErrorString; api.AllGather = &ncclAllGather;
     api.Send = &ncclSend; api.Recv = &ncclRecv; api.GroupStart = &ncclGroupStart; api.GroupEnd = &ncclGroupEnd;
+    api.CommAbort = &ncclCommAbort;
     api.ok = true; api.where = "tests/emu/nccl_emu.cpp";
 #else
     void* h = nullptr;
@@ -85,6 +87,7 @@ NcclApi& nccl() {
     RGBL_SYM(CommDestroy, "ncclCommDestroy"); RGBL_SYM(GetErrorString, "ncclGetErrorString"); RGBL_SYM(AllGather, "ncclAllGather");
     RGBL_SYM(Send, "ncclSend"); RGBL_SYM(Recv, "ncclRecv"); RGBL_SYM(GroupStart, "ncclGroupStart"); RGBL_SYM(GroupEnd, "ncclGroupEnd");
 #undef RGBL_SYM
+    api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(h, "ncclCommAbort"));
     api.ok = all;
 #endif
   });
@@ -114,6 +117,11 @@ using namespace rgbl;
 struct rgbl_comm {
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0, device = 0, version = 0;
+  // Lifetime: gather handles hold a reference.  rgbl_comm_destroy with gathers still alive only marks the handle;
+  // the communicator goes with the last rgbl_gather_destroy - a gather never sees a dangling pointer.
+  int users = 0;
+  bool released = false;   // rgbl_comm_destroy was called
+  bool aborted = false;    // a failed exchange aborted the communicator (ncclCommAbort): every later call returns RGBL_ERR_COMM
 };
 
 struct rgbl_gather {
@@ -121,6 +129,7 @@ struct rgbl_gather {
   int world = 1, rank = 0, device = 0;
   int batch = 0, cap = 0, slots = 0;
   bool loopback = false;
+  bool failed = false;         // an exchange failed half-way (peers may be blocked): the handle refuses further collectives
   hipStream_t stream = nullptr, own_stream = nullptr;
   size_t slot_bytes = 0;       // batch * cap * 68
   // per slot
@@ -190,11 +199,18 @@ int rgbl_comm_create(const uint8_t id[RGBL_COMM_ID_BYTES], int world, int rank, 
   return RGBL_OK;
 }
 
-void rgbl_comm_destroy(rgbl_comm* c) {
-  if (!c) return;
+namespace {
+void comm_free(rgbl_comm* c) {
   (void)hipSetDevice(c->device);
-  if (c->comm) (void)nccl().CommDestroy(c->comm);
+  if (c->comm && !c->aborted) (void)nccl().CommDestroy(c->comm);
   delete c;
+}
+}  // namespace
+
+void rgbl_comm_destroy(rgbl_comm* c) {
+  if (!c || c->released) return;
+  c->released = true;
+  if (c->users == 0) comm_free(c);   // otherwise the last rgbl_gather_destroy frees it
 }
 
 int rgbl_comm_info(const rgbl_comm* c, int* world, int* rank, int* device, int* rccl_version) {
@@ -210,11 +226,12 @@ int rgbl_gather_create(rgbl_comm* comm, int device, int batch, int cap, int slot
   if (!out || batch < 1 || cap < 1 || slots < 1) { set_error("rgbl_gather_create: batch, cap, slots >= 1"); return RGBL_ERR_INVALID; }
   *out = nullptr;
   if (comm && comm->device != device) { set_error("the communicator lives on device %d, not %d", comm->device, device); return RGBL_ERR_INVALID; }
+  if (comm && (comm->released || comm->aborted)) { set_error("the communicator was destroyed or aborted"); return RGBL_ERR_COMM; }
   if (device < 0 || device >= rgbl_device_count()) { set_error("no usable HIP device %d (this library has no CPU fallback)", device); return RGBL_ERR_NO_DEVICE; }
   RGBL_HIP(hipSetDevice(device));
   rgbl_gather* g = new rgbl_gather;
   g->comm = comm; g->device = device; g->batch = batch; g->cap = cap; g->slots = slots;
-  if (comm) { g->world = comm->world; g->rank = comm->rank; }
+  if (comm) { g->world = comm->world; g->rank = comm->rank; ++comm->users; }
   g->slot_bytes = (size_t)batch * cap * kRecordBytes;
   const int W = g->world;
   int rc = RGBL_OK;
@@ -255,6 +272,7 @@ void rgbl_gather_destroy(rgbl_gather* g) {
   for (void* p : g->dev_allocs) (void)hipFree(p);
   for (void* p : g->host_allocs) (void)hipHostFree(p);
   if (g->own_stream) rgbl_stream_destroy((void*)g->own_stream);
+  if (g->comm && --g->comm->users == 0 && g->comm->released) comm_free(g->comm);
   delete g;
 }
 
@@ -273,6 +291,10 @@ int rgbl_gather_pack(rgbl_gather* g, int slot, const int32_t* d_n, const rgbl_ke
     set_error("rgbl_gather_pack: invalid argument");
     return RGBL_ERR_INVALID;
   }
+  if (g->failed || (g->comm && g->comm->aborted)) { set_error("rgbl_gather_pack: an earlier exchange failed, the handle is unusable"); return RGBL_ERR_COMM; }
+  // a slot is free again once it has been exchanged: packing over a step that never left would lose its records silently and
+  // leave this rank one all-gather ahead of the others
+  if (g->packed[slot]) { set_error("rgbl_gather_pack: slot %d still holds a packed step (rgbl_gather_exchange it first)", slot); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipSetDevice(g->device));
   hipStream_t s = g->stream;
   for (int i = 0; i < n_wait; ++i)
@@ -291,19 +313,12 @@ int rgbl_gather_pack(rgbl_gather* g, int slot, const int32_t* d_n, const rgbl_ke
   return RGBL_OK;
 }
 
-int rgbl_gather_exchange(rgbl_gather* g, int slot) {
-  if (!g || slot < 0 || slot >= g->slots) { set_error("rgbl_gather_exchange: invalid slot"); return RGBL_ERR_INVALID; }
-  if (!g->packed[slot]) { set_error("rgbl_gather_exchange: slot %d holds no packed step", slot); return RGBL_ERR_INVALID; }
-  RGBL_HIP(hipSetDevice(g->device));
+namespace {
+// phase 2 proper; any error return leaves transfers half posted - rgbl_gather_exchange turns that into a failed handle
+int exchange_posted(rgbl_gather* g, int slot, const std::vector<long long>& total, int bank) {
   hipStream_t s = g->stream;
-  // the only host wait of the gather: the counts of THIS slot - in a streaming run an event of the step before the one just queued
-  RGBL_HIP(hipEventSynchronize(g->ev_counts[slot]));
-  const int W = g->world, B = g->batch;
-  std::vector<long long> total(W, 0);
-  for (int r = 0; r < W; ++r)
-    for (int f = 0; f < B; ++f) total[r] += std::min(std::max(g->h_counts[slot][(size_t)r * B + f], 0), g->cap);
+  const int W = g->world;
   if (g->rank == 0) {
-    const int bank = (int)(++g->n_exchanged & 1);
     uint8_t* base = g->d_recv[bank];
     bool any = false;
     for (int r = 1; r < W; ++r) any = any || total[r] > 0;
@@ -327,11 +342,39 @@ int rgbl_gather_exchange(rgbl_gather* g, int slot) {
     }
     if (!self && total[0] > 0)
       RGBL_HIP(hipMemcpyAsync(base, g->d_send[slot], (size_t)total[0] * kRecordBytes, hipMemcpyDeviceToDevice, s));
+  } else if (total[g->rank] > 0) {
+    RGBL_NCCL(nccl().Send(g->d_send[slot], (size_t)total[g->rank] * kRecordBytes, ncclUint8, 0, g->comm->comm, s));
+  }
+  return RGBL_OK;
+}
+}  // namespace
+
+int rgbl_gather_exchange(rgbl_gather* g, int slot) {
+  if (!g || slot < 0 || slot >= g->slots) { set_error("rgbl_gather_exchange: invalid slot"); return RGBL_ERR_INVALID; }
+  if (g->failed || (g->comm && g->comm->aborted)) { set_error("rgbl_gather_exchange: an earlier exchange failed, the handle is unusable"); return RGBL_ERR_COMM; }
+  if (!g->packed[slot]) { set_error("rgbl_gather_exchange: slot %d holds no packed step", slot); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(g->device));
+  // the only host wait of the gather: the counts of THIS slot - in a streaming run an event of the step before the one just queued
+  RGBL_HIP(hipEventSynchronize(g->ev_counts[slot]));
+  const int W = g->world, B = g->batch;
+  std::vector<long long> total(W, 0);
+  for (int r = 0; r < W; ++r)
+    for (int f = 0; f < B; ++f) total[r] += std::min(std::max(g->h_counts[slot][(size_t)r * B + f], 0), g->cap);
+  const int bank = (int)((g->n_exchanged + 1) & 1);
+  const int rc = exchange_posted(g, slot, total, bank);
+  if (rc != RGBL_OK) {
+    // Some transfers may be posted and the peers sit in their matching calls: nothing this rank could still do would match
+    // them.  Abort the communicator (it unblocks the peers with an error instead of a hang) and refuse further collectives.
+    g->failed = true;
+    if (g->comm && !g->comm->aborted && nccl().CommAbort) { (void)nccl().CommAbort(g->comm->comm); g->comm->aborted = true; }
+    return rc;
+  }
+  // book-keeping only once the whole group is posted: a failed exchange flips no bank and publishes no counts
+  if (g->rank == 0) {
+    ++g->n_exchanged;
     g->last_bank = bank;
     g->last_total = total;
     memcpy(g->last_counts.data(), g->h_counts[slot], sizeof(int32_t) * (size_t)W * B);
-  } else if (total[g->rank] > 0) {
-    RGBL_NCCL(nccl().Send(g->d_send[slot], (size_t)total[g->rank] * kRecordBytes, ncclUint8, 0, g->comm->comm, s));
   }
   g->packed[slot] = 0;
   return RGBL_OK;

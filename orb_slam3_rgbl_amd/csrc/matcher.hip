@@ -1258,7 +1258,6 @@ struct rgbl_matcher {
   bool bf_matrix = true;   // RGBL_BF_MFMA=0: the VALU popcount scan (k_hamming_bf)
   bool bf_fp4 = true;      // RGBL_BF_MFMA=i8: v_mfma_i32_32x32x32_i8 (k_hamming_mfma) instead of the block-scaled FP4 instruction
   bool bf_split = true;    // RGBL_BF_SPLIT=0: one pair per call without train-set slices
-  int bf_lds_pad = 0;      // EXPERIMENT
 };
 
 namespace {
@@ -1307,7 +1306,6 @@ int rgbl_matcher_create(int device, rgbl_matcher** out) {
   m->device = device;
   if (const char* v = getenv("RGBL_BF_MFMA")) { m->bf_matrix = v[0] != '0'; m->bf_fp4 = v[0] != 'i'; }
   if (const char* v = getenv("RGBL_BF_SPLIT")) m->bf_split = v[0] != '0';
-  if (const char* v = getenv("RGBL_BF_LDS_PAD")) m->bf_lds_pad = atoi(v);
   if (hipStreamCreate(&m->own_stream) != hipSuccess) { delete m; set_error("hipStreamCreate failed"); return RGBL_ERR_HIP; }
   m->stream = m->own_stream;
   *out = m;
@@ -1447,7 +1445,7 @@ int rgbl_hamming_bf_batch_device(rgbl_matcher* m, const uint8_t* d_desc, const i
   RGBL_HIP(hipSetDevice(m->device));
   if (bf_on_matrix_cores(m)) {
     m->timer.begin(bf_on_fp4(m) ? "k_hamming_fp4" : "k_hamming_mfma", m->stream);
-    if (bf_on_fp4(m)) hipLaunchKernelGGL(k_hamming_fp4, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), m->bf_lds_pad, m->stream,
+    if (bf_on_fp4(m)) hipLaunchKernelGGL(k_hamming_fp4, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
                        d_desc, d_n, cap, d_pair_a, d_pair_b, d_best_idx, d_best_dist, d_second_dist, 1, (uint32_t*)nullptr);
     else hipLaunchKernelGGL(k_hamming_mfma, xcd_grid(true, (cap + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock, n_pairs), dim3(256), 0, m->stream,
                        d_desc, d_n, cap, d_pair_a, d_pair_b, d_best_idx, d_best_dist, d_second_dist);

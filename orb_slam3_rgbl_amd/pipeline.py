@@ -154,7 +154,8 @@ class FrontEndPipeline:
         self.world, self.rank, self.gather = world, rank, gather
         if transport is None:
             transport = "abi" if (comm is not None or world == 1) else "torch"
-        if transport == "abi" and world > 1 and comm is None:
+        if transport == "abi" and world > 1 and comm is None and gather != "none":
+            # (no gather, no communicator needed: `--gather none` is the compute-only weak-scaling baseline - ADVICE r4)
             raise ValueError("transport='abi' with more than one rank needs an rgbl_comm (pipeline.make_comm)")
         self.transport, self.comm, self.g = transport, comm, None
         index = dev.index if (dev.type == "cuda" and dev.index is not None) else 0
@@ -168,25 +169,6 @@ class FrontEndPipeline:
                             "two-lanes" if (gather != "none" and n_lanes > 1) else gather, shared_low=wrap_low)
                       for _ in range(n_lanes)]
         self.ex, self.dm, self.mt = self.lanes[0].ex, self.lanes[0].dm, self.lanes[0].mt
-        self.two_phase = False
-        if n_lanes == 2 and os.environ.get("RGBL_TWO_PHASE"):
-            # EXPERIMENT: two extractor handles (= two sets of scratch) called alternately on ONE pair of streams: the pixel phase
-            # of step k + 1 next to the keypoint phase of step k; one depth module, one matcher
-            self.two_phase = True
-            self.s_q = C.c_void_p(); self.s_p = C.c_void_p()
-            L.check(lib, lib.rgbl_stream_create_on(index, C.byref(self.s_q), 0))
-            L.check(lib, lib.rgbl_stream_create_on(index, C.byref(self.s_p), 0))
-            for ln in self.lanes:
-                L.check(lib, lib.rgbl_extractor_set_stream(ln.ex.h, self.s_q))
-                L.check(lib, lib.rgbl_extractor_set_phase_stream(ln.ex.h, self.s_p))
-            l0, l1 = self.lanes
-            l1.dm.close(); l1.mt.close()
-            if l1.own_stream is not None and l1.owns_stream:
-                lib.rgbl_stream_destroy(l1.own_stream)
-            l1.own_stream = None
-            l1.dm, l1.mt = l0.dm, l0.mt
-            for ln in self.lanes:
-                ln.streams(lib)
         # sparse_depth: no dense ProcessedDepthMap (rgbl_depth_set_sparse) - the step never hands it out anyway
         for ln in self.lanes:
             ln.dm.SetSparseUpsampling(sparse_depth)
@@ -270,7 +252,9 @@ class FrontEndPipeline:
     def _p(t):
         return C.c_void_p(t.data_ptr())
 
-    def step(self):
+    def step(self, active=True):
+        """One step.  active=False: this rank has no frames for the step (BASELINE configs[3]: 11 sequences on 8 ranks - the
+        ranks 3 .. 7 idle in the second round) but still takes part in the step's collectives with all-zero counts."""
         lib, p, B, w, h, cap = self.lib, self._p, self.Bh, self.w, self.h, self.cap   # extraction and depth include the halo frame
         o = self.sets[self.step_no % 2]
         ln = self.lanes[self.step_no % len(self.lanes)]
@@ -279,19 +263,32 @@ class FrontEndPipeline:
         L.check(lib, lib.rgbl_event_wait(ln.s_ex, o.ev["match_done"]))
         if self.gather != "none":
             L.check(lib, lib.rgbl_event_wait(ln.s_ex, o.ev["comm_done"]))
+        if not active:
+            ts = C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream) if self.cuda else None
+            if ts is not None:
+                L.check(lib, lib.rgbl_stream_wait(ts, ln.s_ex))
+            o.n.zero_()
+            if ts is not None:
+                L.check(lib, lib.rgbl_stream_wait(ln.s_ex, ts))
+            for name in ("extracted", "depth_done", "match_done"):
+                L.check(lib, lib.rgbl_event_record(o.ev[name], ln.s_ex))
+            if self.gather != "none":
+                prev = self.pending
+                if self.gather == "step" and prev is not None:
+                    self._exchange(prev)
+                self._pack(o)
+            self.step_no += 1
+            return
         L.check(lib, lib.rgbl_extract_batch_device(ln.ex.h, p(self.d_imgs), B, w, h, w, w * h, 0, 0, p(o.kp), p(o.desc), cap, p(o.n), p(o.mono)))
         L.check(lib, lib.rgbl_event_record(o.ev["extracted"], ln.s_ex))
         # LiDAR projection + up-sampling: independent of the keypoints, runs concurrently on the depth stream
         n_points = self.n_points
-        if not os.environ.get("RGBL_EXP_NO_DEPTH"):
-          L.check(lib, lib.rgbl_depth_project_batch_device(ln.dm.h, p(self.d_cloud), B, n_points, n_points, 4 * n_points, w, h, None))
+        L.check(lib, lib.rgbl_depth_project_batch_device(ln.dm.h, p(self.d_cloud), B, n_points, n_points, 4 * n_points, w, h, None))
         L.check(lib, lib.rgbl_event_wait(ln.s_dm, o.ev["extracted"]))
-        if not os.environ.get("RGBL_EXP_NO_DEPTH"):
-          L.check(lib, lib.rgbl_depth_gather_batch_device(ln.dm.h, B, w, h, p(o.kp), p(o.n), cap, None, p(o.depth), p(o.uright)))
+        L.check(lib, lib.rgbl_depth_gather_batch_device(ln.dm.h, B, w, h, p(o.kp), p(o.n), cap, None, p(o.depth), p(o.uright)))
         L.check(lib, lib.rgbl_event_record(o.ev["depth_done"], ln.s_dm))
         L.check(lib, lib.rgbl_event_wait(ln.s_mt, o.ev["extracted"]))
-        if not os.environ.get("RGBL_EXP_NO_MATCH"):
-          L.check(lib, lib.rgbl_hamming_bf_batch_device(ln.mt.h, p(o.desc), p(o.n), cap, p(self.pair_a), p(self.pair_b), self.B, p(o.bi),
+        L.check(lib, lib.rgbl_hamming_bf_batch_device(ln.mt.h, p(o.desc), p(o.n), cap, p(self.pair_a), p(self.pair_b), self.B, p(o.bi),
                                                       p(o.bd), p(o.sd)))
         L.check(lib, lib.rgbl_event_record(o.ev["match_done"], ln.s_mt))
         if self.gather != "none":
@@ -389,8 +386,16 @@ class FrontEndPipeline:
                 counts = np.ctypeslib.as_array(C.cast(h_counts, C.POINTER(C.c_int32)), (self.B,)).copy()
                 rec = None
                 if self.keep:   # tests: a copy of the root's bank (the bank itself is reused two exchanges later)
-                    rec = torch.zeros(n_rec.value * RECORD_BYTES, dtype=torch.uint8, device=self.dev)
+                    # no fill kernel on torch's stream that could land behind the copy on the gather's stream, and both
+                    # directions ordered by events: the block the caching allocator hands out may still be in use on torch's
+                    # current stream, and the tensor's later readers run there
+                    rec = torch.empty(n_rec.value * RECORD_BYTES, dtype=torch.uint8, device=self.dev)
+                    ts = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream) if self.cuda else None
+                    if ts is not None:
+                        L.check(lib, lib.rgbl_stream_wait(self.s_comm, ts))
                     L.check(lib, lib.rgbl_gather_copy_result(self.g, r, C.c_void_p(rec.data_ptr()), rec.numel()))
+                    if ts is not None:
+                        L.check(lib, lib.rgbl_stream_wait(ts, self.s_comm))
                 got.append((counts, rec))
             self.received = (self.received + [got])[-self.keep:] if self.keep else [got]
         if self.pending == slot:
@@ -429,10 +434,8 @@ class FrontEndPipeline:
         if self.g is not None:
             self.lib.rgbl_gather_destroy(self.g)
             self.g = None
-        for i, ln in enumerate(getattr(self, "all_lanes", self.lanes)):
-            ln.ex.close()
-            if not (self.two_phase and i > 0):
-                ln.dm.close(); ln.mt.close()
+        for ln in getattr(self, "all_lanes", self.lanes):
+            ln.ex.close(); ln.dm.close(); ln.mt.close()
             if ln.own_stream is not None:
                 # a stream PyTorch has wrapped is the process-wide one of _WRAPPED_LOW_STREAMS and stays; the others go
                 if ln.owns_stream:

@@ -111,6 +111,8 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
   return ncclSuccess;
 }
 
+ncclResult_t ncclCommAbort(ncclComm_t c) { return ncclCommDestroy(c); }
+
 const char* ncclGetErrorString(ncclResult_t r) {
   switch (r) {
     case ncclSuccess: return "no error";

@@ -1332,6 +1332,47 @@ def check_pipeline_gather(lib, mode, dev=None, w=640, h=360, nfeatures=800, batc
     pipe.close()
 
 
+def check_pipeline_step(lib, w, h, nfeatures, batch, n_az, dev=None, steps=2, seq=90, levels=8, ini=12, mn=7):
+    """The batched step exactly as bench.py times it (FrontEndPipeline: extract -> depth -> match on resident inputs, no gather):
+    EVERY frame of the last step against the oracle - keypoints, descriptors, depth, uRight and the matches against the
+    following frame.  BASELINE configs[4] runs through here at its own size (3840x2160, 8000 features, 262 144 points)."""
+    import torch
+
+    from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline
+    dev = dev or torch.device("cuda", 0)
+    K = synth.KITTI_K.copy()
+    K[0, 0] = K[1, 1] = 718.856 * w / synth.KITTI_W
+    K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    proj = F.projection_matrix(K, synth.KITTI_TR, lib)
+    sq = synth.Sequence(seq, w, h, n_frames=batch)
+    frames = np.stack([sq.frame(i) for i in range(batch)])
+    cloud = np.stack([synth.lidar_scan(10 * seq + i, n_az=n_az) for i in range(batch)])
+    pipe = FrontEndPipeline(lib, torch, dev, w, h, nfeatures, proj, cloud.shape[2], batch, levels=levels, ini_th=ini, min_th=mn, gather="none")
+    pipe.set_inputs(torch.from_numpy(frames).to(dev), torch.from_numpy(cloud).to(dev))
+    for _ in range(steps):
+        pipe.step()
+    pipe.finish()
+    pipe.sync()
+    o = pipe.last()
+    n = o.n.cpu().numpy()
+    kp, desc, depth, uright, bi, bd, sd = (t.cpu().numpy() for t in (o.kp, o.desc, o.depth, o.uright, o.bi, o.bd, o.sd))
+    orc = O.Extractor(nfeatures, 1.2, levels, ini, mn)
+    P = O.make_depth_params(proj)
+    ref = [orc(frames[f])[:2] for f in range(batch)]
+    for f in range(batch):
+        okps, odesc = ref[f]
+        m = int(n[f])
+        assert m == len(okps), "frame %d: %d keypoints, oracle %d" % (f, m, len(okps))
+        assert np.array_equal(kp[f, :m].view(np.uint32), okps.view(np.uint32).reshape(m, 7)), "keypoints of frame %d" % f
+        assert np.array_equal(desc[f, :m], odesc), "descriptors of frame %d" % f
+        od, our, _, _ = O.depth(P, cloud[f], w, h, np.stack([okps["x"], okps["y"]], 1), okps["x"], want_maps=False)
+        assert np.array_equal(bits(depth[f, :m]), bits(od)) and np.array_equal(bits(uright[f, :m]), bits(our)), "depth of frame %d" % f
+        obi, obd, osd = O.hamming_bf(odesc, ref[(f + 1) % batch][1])
+        assert np.array_equal(bi[f, :m], obi) and np.array_equal(bd[f, :m], obd) and np.array_equal(sd[f, :m], osd), "matches of frame %d" % f
+    pipe.close()
+    return int(n.min())
+
+
 def check_overlapped_frame(lib, w=synth.KITTI_W, h=synth.KITTI_H, nfeatures=2000, frames=3):
     """The optional latency hooks: rgbl_extract_begin + rgbl_depth_prefetch, then the ordinary calls on the same buffers, must
     give what the ordinary calls alone give (= the oracle's results), whatever is interleaved."""

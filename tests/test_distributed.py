@@ -181,6 +181,107 @@ def test_chunked_sequence_matches_across_the_chunk_boundary(tmp_path, oracle, em
     assert "CHUNKS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+ROUND_ROBIN_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["RGBL_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from orb_slam3_rgbl_amd import _lib, synth, sharding
+from orb_slam3_rgbl_amd import frontend as F
+from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline, unpack_records, make_comm
+
+# BASELINE configs[3]: the 11 KITTI sequences 00-10 on the 8 GPUs of a node, sequence s -> rank s mod 8 (sharding.sequences_of_rank):
+# the ranks 0 - 2 own two sequences, the others one and idle in the second round (all-zero counts, same collectives)
+W, H, NF, LEVELS, B, N_AZ, N_SEQ = 160, 128, 200, 3, 2, 200, 11
+DEV = torch.device("cpu")
+
+def inputs_of(seq):
+    sq = synth.Sequence(500 + seq, W, H, n_frames=B)
+    frames = np.stack([sq.frame(i) for i in range(B)])
+    cloud = np.stack([synth.lidar_scan(500 + 10 * seq + i, n_az=N_AZ) for i in range(B)])
+    return frames, cloud
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lib = _lib.bind(os.environ["RGBL_EMU_LIB"])
+    K = synth.KITTI_K.copy(); K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+    proj = F.projection_matrix(K, synth.KITTI_TR, lib)
+    mine = sharding.sequences_of_rank(N_SEQ, world, rank)
+    rounds = max(len(sharding.sequences_of_rank(N_SEQ, world, r)) for r in range(world))
+    transport = os.environ.get("RGBL_TRANSPORT", "abi")
+    comm = make_comm(lib, dist, 0) if transport == "abi" else None
+    if comm is not None:
+        cw = __import__("ctypes").c_int(0)
+        lib.rgbl_comm_info(comm, __import__("ctypes").byref(cw), None, None, None)
+        assert cw.value == world
+    n_points = inputs_of(0)[1].shape[2]
+    pipe = FrontEndPipeline(lib, torch, DEV, W, H, NF, proj, n_points, B, levels=LEVELS, ini_th=20, min_th=7, world=world, rank=rank,
+                            gather=os.environ["RGBL_GATHER"], keep_steps=rounds, log_steps=rounds, transport=transport, comm=comm)
+    for j in range(rounds):
+        if j < len(mine):
+            frames, cloud = inputs_of(mine[j])
+            pipe.set_inputs(torch.from_numpy(frames), torch.from_numpy(cloud))
+            pipe.step()
+        else:
+            pipe.step(active=False)
+        pipe.sync()   # (the inputs of the next round replace this round's)
+    pipe.finish()
+    pipe.sync()
+    ok = True
+    if rank == 0:
+        ok &= len(pipe.received) == rounds
+        solo = FrontEndPipeline(lib, torch, DEV, W, H, NF, proj, n_points, B, levels=LEVELS, ini_th=20, min_th=7, world=1, rank=0, gather="none")
+        seen = 0
+        for j in range(rounds):
+            for r in range(world):
+                counts, rec = pipe.received[j][r]
+                s = r + world * j
+                if s >= N_SEQ:
+                    ok &= int(np.abs(counts).sum()) == 0 and rec.numel() == 0      # an idle rank sends nothing
+                    continue
+                frames, cloud = inputs_of(s)
+                solo.set_inputs(torch.from_numpy(frames), torch.from_numpy(cloud))
+                solo.step(); solo.sync()
+                o = solo.last()
+                n = o.n.numpy()
+                ok &= np.array_equal(counts, n) and int(n.min()) > 10
+                fr = unpack_records(rec.numpy(), counts)
+                for f in range(B):
+                    m = int(n[f])
+                    ok &= np.array_equal(fr[f]["kp"], o.kp[f, :m].numpy().view(np.uint8).reshape(m, 28))
+                    ok &= np.array_equal(fr[f]["desc"], o.desc[f, :m].numpy())
+                    ok &= np.array_equal(fr[f]["depth"].view(np.uint32), o.depth[f, :m].numpy().view(np.uint32))
+                    ok &= np.array_equal(fr[f]["uright"].view(np.uint32), o.uright[f, :m].numpy().view(np.uint32))
+                seen += 1
+        ok &= seen == N_SEQ
+        solo.close()
+        print("ROUND_ROBIN_OK %d sequences on %d ranks" % (seen, world) if ok else "ROUND_ROBIN_MISMATCH")
+    pipe.close()
+    if comm is not None:
+        lib.rgbl_comm_destroy(comm)
+    dist.barrier()
+    dist.destroy_process_group()
+
+main()
+'''
+
+
+@pytest.mark.parametrize("mode,port,transport", [("step", 29551, "abi"), ("final", 29553, "abi")])
+def test_eight_ranks_eleven_sequences_round_robin(tmp_path, oracle, emu_lib, mode, port, transport):
+    """BASELINE configs[3] at the node's real width: 8 ranks (gloo bootstrap; the library's gather over the emulated RCCL, or
+    torch.distributed), 11 sequences round-robin - two rounds, five ranks idle in the second one with all-zero counts.  What rank 0
+    holds for every (round, rank) is byte-identical with a single-process run of that sequence."""
+    script = tmp_path / "rr_worker.py"
+    script.write_text(ROUND_ROBIN_WORKER)
+    env = dict(os.environ, RGBL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", RGBL_GATHER=mode, RGBL_EMU_THREADS="1",
+               RGBL_TRANSPORT=transport, TMPDIR=str(tmp_path),
+               RGBL_EMU_LIB=os.path.join(ROOT, "tests", "_build", "librgbl_frontend_emu.so"))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert "ROUND_ROBIN_OK 11 sequences on 8 ranks" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_chunk_partition_covers_all_frames_with_halo():
     for n, world in ((4541, 8), (10, 3), (7, 8), (64, 1)):
         seen = []
@@ -310,6 +411,9 @@ def test_gather_entry_points_reject_misuse(emu_lib):
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     assert lib.rgbl_gather_pack(g, 2, p(n), p(kp), p(desc), p(dep), p(ur), None, 0, None) == L.ERR_INVALID   # slot out of range
     L.check(lib, lib.rgbl_gather_pack(g, 1, p(n), p(kp), p(desc), p(dep), p(ur), None, 0, None))
+    # packing over a step that was never exchanged would lose its records silently
+    assert lib.rgbl_gather_pack(g, 1, p(n), p(kp), p(desc), p(dep), p(ur), None, 0, None) == L.ERR_INVALID
+    assert b"still holds a packed step" in lib.rgbl_last_error()
     L.check(lib, lib.rgbl_gather_exchange(g, 1))
     L.check(lib, lib.rgbl_gather_sync(g))
     assert lib.rgbl_gather_result(g, 1, None, None, None) == L.ERR_INVALID                        # rank out of range
@@ -324,3 +428,20 @@ def test_gather_entry_points_reject_misuse(emu_lib):
     assert np.array_equal(full.reshape(11, 68)[:, 28:60], np.concatenate([desc[0, :8], desc[2, :3]]))
     assert lib.rgbl_gather_exchange(g, 1) == L.ERR_INVALID                                        # already exchanged
     lib.rgbl_gather_destroy(g)
+    # the communicator's lifetime - destroyed by the caller while a gather handle still uses it: deferred to the
+    # last rgbl_gather_destroy, the handle keeps working in between (one emulated rank, loopback transfers through the "RCCL")
+    os.environ.setdefault("TMPDIR", "/tmp")
+    L.check(lib, lib.rgbl_comm_unique_id(ident))
+    L.check(lib, lib.rgbl_comm_create(ident, 1, 0, 0, C.byref(comm)))
+    L.check(lib, lib.rgbl_gather_create(comm, 0, 3, 8, 2, None, C.byref(g)))
+    L.check(lib, lib.rgbl_gather_set_loopback(g, 1))
+    lib.rgbl_comm_destroy(comm)                       # too early: the gather still holds it
+    lib.rgbl_comm_destroy(comm)                       # and twice
+    L.check(lib, lib.rgbl_gather_pack(g, 0, p(n), p(kp), p(desc), p(dep), p(ur), None, 0, None))
+    L.check(lib, lib.rgbl_gather_exchange(g, 0))
+    L.check(lib, lib.rgbl_gather_sync(g))
+    L.check(lib, lib.rgbl_gather_result(g, 0, C.byref(counts), C.byref(rec), C.byref(cnt)))
+    assert cnt.value == 11
+    g2 = C.c_void_p()
+    assert lib.rgbl_gather_create(comm, 0, 3, 8, 2, None, C.byref(g2)) == L.ERR_COMM              # no new users of a released communicator
+    lib.rgbl_gather_destroy(g)                        # frees the communicator as well

@@ -41,7 +41,7 @@ def run_ranks(exe, world, mode, steps, tmp_path, devices=None, env=None):
     return outs[0][0]
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])     # 8: one rank per GPU of an MI355X node
 @pytest.mark.parametrize("mode", ["step", "final"])
 def test_gather_from_cpp_under_emulation(emu_lib, tmp_path, world, mode):
     exe = os.path.join(ROOT, "tests", "_build", "gather_test_emu")

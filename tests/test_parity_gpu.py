@@ -307,6 +307,22 @@ def test_stereo_fisheye_matches(gpu_lib):
 
 # ---- kernels that can be dispatched but are not on the default path ("missing" 1 and 2) -------------------------
 
+def test_extractor_4k_cfg5_batched(gpu_lib):
+    # configs[4] in the form bench.py TIMES it (VERDICT r4 missing 1): a batch of 8 4K frames = k_fast_cells (one wave per cell,
+    # own slots) -> k_compact_cells -> k_octree<1024, 2048> on the count pyramid, XCD-aware grids, the split pyramid chain
+    pc.check_extractor_batch(gpu_lib, 3840, 2160, 8000, batch=8, seq=9)
+
+
+def test_pipeline_step_4k_cfg5(gpu_lib):
+    # ... and the whole timed step at that size: extract + depth on 262 144-point scans + match, every frame vs the oracle
+    assert pc.check_pipeline_step(gpu_lib, 3840, 2160, 8000, batch=8, n_az=4096) > 4000
+
+
+def test_pipeline_step_kitti_cfg2(gpu_lib):
+    # the headline's step (KITTI size, 2000 features, 121 600-point scans) on 16 distinct frames, every one checked
+    assert pc.check_pipeline_step(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000, batch=16, n_az=1900, seq=91) > 1500
+
+
 def test_extractor_initialisation_extractor_uses_the_key_moving_quadtree(gpu_lib):
     # Tracking.cc:601 builds the monocular initialisation extractor with 5 * nFeatures: 10 000 features on KITTI need more than
     # 2048 quad-tree nodes on level 0, i.e. k_octree_moving (node lists in global memory) instead of the label-based kernel
