@@ -420,26 +420,29 @@ def spot_check(O, orc, P, frames, cloud, out_set, spot_frames, w, h, n_next=None
 
 def serial_kernel_leg(pipe, n_steps):
     """The per-kernel timing leg: `n_steps` serialised steps (one stream for everything, HIP-event brackets around every
-    launch), read back step by step.  Returns ({kernel: (ms summed over the steps, launches)} with the sum built from the
-    per-step MEDIAN - one slow step does not move it -, {kernel: {"median", "min", "max"} ms per step})."""
+    launch) queued back to back - no host synchronisation between them: a GPU that runs dry makes the brackets of a step's
+    first launches measure the host's launch latency - and every launch's own duration read back afterwards
+    (rgbl_*_profile_samples).  Returns ({kernel: (ms summed over the steps, launches)} built from the per-step MEDIAN, so that
+    one slow step does not move it, and {kernel: {"median", "min", "max"} in ms per step})."""
     pipe.serialise()
     pipe.gather = "none"
     pipe.profile(True)
-    per_step, prev = [], {}
     for _ in range(n_steps):
         pipe.step()
-        pipe.sync()
-        cur = pipe.profile_read()
-        per_step.append({k: (v[0] - prev.get(k, (0.0, 0))[0], v[1] - prev.get(k, (0.0, 0))[1]) for k, v in cur.items()})
-        prev = cur
+    pipe.sync()
+    samples = pipe.profile_samples()
     pipe.profile(False)
     kernels, stats = {}, {}
-    for k in sorted(prev):
-        ms = sorted(st[k][0] for st in per_step if k in st)
-        launches = per_step[-1][k][1]
+    for k in sorted(samples):
+        v = samples[k]
+        per = len(v) // n_steps               # launches per step (7 for the resize, 1 otherwise)
+        if per == 0:
+            continue
+        by_step = [sum(v[i * per:(i + 1) * per]) for i in range(n_steps)]
+        ms = sorted(by_step)
         med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
-        kernels[k] = (med * n_steps, launches * n_steps)
-        stats[k] = {"median": round(med, 4), "min": round(ms[0], 4), "max": round(ms[-1], 4)}
+        kernels[k] = (med * n_steps, per * n_steps)
+        stats[k] = {"median": round(med, 4), "min": round(ms[0], 4), "max": round(ms[-1], 4), "max_at_step": by_step.index(ms[-1])}
     return kernels, stats
 
 

@@ -270,6 +270,11 @@ int rgbl_extractor_profile(rgbl_extractor* h, int enable);
 /* Returns the number of distinct kernels; fills up to cap entries. names[i] points to static storage. */
 int rgbl_extractor_profile_read(rgbl_extractor* h, const char** names, double* total_ms, long* launches,
                                 int cap);
+/* Every launch's own duration (ms, launch order) of kernel number `kernel` (its index in rgbl_*_profile_read's arrays) since
+ * profiling was switched on: returns how many there are, copies the first `cap`.  bench.py builds its per-step median /
+ * min / max table from these without synchronising between steps (a host sync per step lets the GPU run dry, and the
+ * event bracket of the first launches then measures the host's launch latency). */
+int rgbl_extractor_profile_samples(rgbl_extractor* h, int kernel, float* ms, int cap);
 
 /* ------------------------------------------------------------------------------------------------
  * DepthModule             replaces include/DepthModule.h:45-99, src/DepthModule.cc:50-274
@@ -368,6 +373,7 @@ int rgbl_depth_set_stream(rgbl_depth* h, void* hip_stream);
 int rgbl_depth_set_sparse(rgbl_depth* h, int enable);
 int rgbl_depth_profile(rgbl_depth* h, int enable);
 int rgbl_depth_profile_read(rgbl_depth* h, const char** names, double* total_ms, long* launches, int cap);
+int rgbl_depth_profile_samples(rgbl_depth* h, int kernel, float* ms, int cap);
 
 /* ------------------------------------------------------------------------------------------------
  * ORBmatcher              replaces include/ORBmatcher.h:43,75-76, src/ORBmatcher.cc:907-1146,2058-2074
@@ -389,6 +395,7 @@ int rgbl_matcher_set_stream(rgbl_matcher* h, void* hip_stream);
 void* rgbl_matcher_stream(rgbl_matcher* h);
 int rgbl_matcher_profile(rgbl_matcher* h, int enable);
 int rgbl_matcher_profile_read(rgbl_matcher* h, const char** names, double* total_ms, long* launches, int cap);
+int rgbl_matcher_profile_samples(rgbl_matcher* h, int kernel, float* ms, int cap);
 
 /* static int ORBmatcher::DescriptorDistance(a, b) (ORBmatcher.cc:2058-2074) on two 32-byte rows. Host. */
 int rgbl_descriptor_distance(const uint8_t* a, const uint8_t* b);
@@ -692,6 +699,35 @@ int rgbl_bow_descend_batch_device(rgbl_vocabulary* v, void* hip_stream, const ui
 /* F12 with the reference's fp32 evaluation order (Pinhole.cpp:109-112); K = {fx, fy, cx, cy}. Host. */
 void rgbl_fundamental(const float K1[4], const float K2[4], const float R12[9], const float t12[3],
                       float F12[9]);
+
+/* ------------------------------------------------------------------------------------------------
+ * Environment switches.  Every one of them is read ONCE, when the handle it concerns is created (never on a launch path:
+ * the entry points are called from the three SLAM threads), and is a tuning / test aid - the defaults are what is measured
+ * and shipped.  Results are bit-identical under all of them (tests/test_parity_gpu.py runs every variant against the oracle).
+ *
+ *   rgbl_extractor_create
+ *     RGBL_SPLIT_PYR=k      batches: the pyramid levels k .. L-1 and their FAST cells leave the main launch chain for the auxiliary
+ *                           stream (default L / 2 from 6 levels on; 0 = off)
+ *     RGBL_LEVEL_SPLIT=k    single frames: the levels 1 .. k-1 get a stream of their own (default 3; 0 = off)
+ *     RGBL_FAST_BS=64|128   waves per FAST detection cell (default: 64 for batches of >= 8 frames, 128 for single frames)
+ *     RGBL_COMPACT=0|1      k_compact_cells never / always (default: batches of >= 8 frames)
+ *     RGBL_DENSE=0          quad-tree reads the cells' own slots instead of a dense per-level candidate list
+ *     RGBL_OCTREE_NCAP=0|512|2048   quad-tree node capacity in LDS (0 = the key-moving kernel on global lists; default by nFeatures)
+ *     RGBL_OCTREE_WG=256|512        quad-tree workgroup width (default by batch size)
+ *     RGBL_OCTREE_LDSKEYS=0         single frames: candidate lists stay in global memory
+ *     RGBL_OCTREE_HIST=0            breadth-first rounds as passes over the keys instead of on the per-cell count pyramid
+ *     RGBL_OCTREE_STAMPS=1          the quad-tree kernel leaves phase time stamps (rgbl_extractor_debug_stamps)
+ *     RGBL_GAUSS_BS=256     four-wave workgroups for the Gaussian (default two waves)
+ *     RGBL_XCD_MAP=0        plain (items, frames) grids instead of the XCD-aware (8, items, frames / 8) mapping (also rgbl_depth_create)
+ *     RGBL_GRAPH=0          host-pointer extraction without hipGraph replay
+ *   rgbl_depth_create
+ *     RGBL_DEPTH_MAX_GEN=n  generations of the index map before it is cleared (tests of the wrap-around)
+ *   rgbl_matcher_create
+ *     RGBL_BF_MFMA=0|i8     Hamming scan on the VALU (popcount) / on v_mfma_i32_32x32x32_i8 (default: block-scaled FP4 instruction)
+ *     RGBL_BF_SPLIT=0       one pair per call without train-set slices
+ *   first rgbl_comm_* call
+ *     RGBL_RCCL_LIB=path    librccl to dlopen when none is mapped into the process yet
+ * ---------------------------------------------------------------------------------------------- */
 
 #ifdef __cplusplus
 }

@@ -136,6 +136,7 @@ SYMBOLS = {
     "rgbl_extractor_set_stream": (_I, [_V, _V]),
     "rgbl_extractor_profile": (_I, [_V, _I]),
     "rgbl_extractor_profile_read": (_I, [_V, _V, _V, _V, _I]),
+    "rgbl_extractor_profile_samples": (_I, [_V, _I, _V, _I]),
     "rgbl_depth_create": (_I, [C.POINTER(DepthCfg), _I, C.POINTER(_V)]),
     "rgbl_depth_destroy": (None, [_V]),
     "rgbl_projection_matrix": (None, [_V, _V, _V]),
@@ -183,12 +184,14 @@ SYMBOLS = {
     "rgbl_depth_set_sparse": (_I, [_V, _I]),
     "rgbl_depth_profile": (_I, [_V, _I]),
     "rgbl_depth_profile_read": (_I, [_V, _V, _V, _V, _I]),
+    "rgbl_depth_profile_samples": (_I, [_V, _I, _V, _I]),
     "rgbl_matcher_create": (_I, [_I, C.POINTER(_V)]),
     "rgbl_matcher_destroy": (None, [_V]),
     "rgbl_matcher_sync": (_I, [_V]),
     "rgbl_matcher_set_stream": (_I, [_V, _V]),
     "rgbl_matcher_profile": (_I, [_V, _I]),
     "rgbl_matcher_profile_read": (_I, [_V, _V, _V, _V, _I]),
+    "rgbl_matcher_profile_samples": (_I, [_V, _I, _V, _I]),
     "rgbl_descriptor_distance": (_I, [_V, _V]),
     "rgbl_matcher_acquire": (_I, [_I, C.POINTER(_V)]),
     "rgbl_matcher_release": (None, [_V]),
@@ -259,3 +262,16 @@ def read_profile(lib, fn, handle):
     cnt = (C.c_long * 32)()
     n = fn(handle, C.cast(names, C.c_void_p), C.cast(ms, C.c_void_p), C.cast(cnt, C.c_void_p), 32)
     return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n, 32))}
+
+
+def read_profile_samples(lib, fn_read, fn_samples, handle):
+    """{kernel: [every launch's duration in ms, launch order]} since profiling was switched on."""
+    names = (C.c_char_p * 32)()
+    n = fn_read(handle, C.cast(names, C.c_void_p), None, None, 32)
+    out = {}
+    for i in range(min(n, 32)):
+        k = fn_samples(handle, i, None, 0)
+        buf = (C.c_float * max(k, 1))()
+        k = fn_samples(handle, i, C.cast(buf, C.c_void_p), k)
+        out[names[i].decode()] = [float(buf[j]) for j in range(k)]
+    return out

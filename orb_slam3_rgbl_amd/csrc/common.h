@@ -56,6 +56,7 @@ struct KernelTimer {
   std::vector<Rec> recs;
   std::vector<double> total_ms;
   std::vector<long> count;
+  std::vector<std::vector<float>> samples;   // every launch's duration, in launch order (rgbl_*_profile_samples)
   std::vector<std::string> names;
   int id_of(const char* name) {
     for (size_t i = 0; i < names.size(); ++i)
@@ -63,6 +64,7 @@ struct KernelTimer {
     names.push_back(name);
     total_ms.push_back(0);
     count.push_back(0);
+    samples.emplace_back();
     return (int)names.size() - 1;
   }
   void begin(const char* name, hipStream_t s) {
@@ -86,6 +88,7 @@ struct KernelTimer {
       (void)hipEventElapsedTime(&ms, r.a, r.b);
       total_ms[r.id] += ms;
       count[r.id] += 1;
+      samples[r.id].push_back(ms);
       (void)hipEventDestroy(r.a);
       (void)hipEventDestroy(r.b);
     }
@@ -93,7 +96,14 @@ struct KernelTimer {
   }
   void reset() {
     collect();
-    for (size_t i = 0; i < total_ms.size(); ++i) { total_ms[i] = 0; count[i] = 0; }
+    for (size_t i = 0; i < total_ms.size(); ++i) { total_ms[i] = 0; count[i] = 0; samples[i].clear(); }
+  }
+  // the durations of kernel `id`'s launches since the last reset (call collect() first); returns how many there are
+  int read_samples(int id, float* out, int cap) const {
+    if (id < 0 || id >= (int)samples.size()) return 0;
+    const int n = (int)samples[id].size();
+    for (int i = 0; i < n && i < cap; ++i) out[i] = samples[id][i];
+    return n;
   }
 };
 

@@ -909,5 +909,11 @@ int rgbl_depth_profile_read(rgbl_depth* e, const char** names, double* total_ms,
   }
   return n;
 }
+int rgbl_depth_profile_samples(rgbl_depth* e, int kernel, float* ms, int cap) {
+  if (!e || (cap > 0 && !ms)) return 0;
+  (void)hipStreamSynchronize(e->stream);
+  e->timer.collect();
+  return e->timer.read_samples(kernel, ms, cap);
+}
 
 }  // extern "C"

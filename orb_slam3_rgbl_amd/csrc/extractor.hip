@@ -1458,6 +1458,12 @@ int rgbl_extractor_profile_read(rgbl_extractor* e, const char** names, double* t
   }
   return n;
 }
+int rgbl_extractor_profile_samples(rgbl_extractor* e, int kernel, float* ms, int cap) {
+  if (!e || (cap > 0 && !ms)) return 0;
+  (void)hipStreamSynchronize(e->stream);
+  e->timer.collect();
+  return e->timer.read_samples(kernel, ms, cap);
+}
 
 // Self-test of the hand-written instruction wrappers on the device (see k_selftest_wrappers): n random inputs, every result
 // compared with its plain expression on the host.  RGBL_OK, or RGBL_ERR_HIP with the first mismatch in rgbl_last_error().

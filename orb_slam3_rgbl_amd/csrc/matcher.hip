@@ -1421,6 +1421,12 @@ int rgbl_matcher_profile_read(rgbl_matcher* m, const char** names, double* total
   }
   return n;
 }
+int rgbl_matcher_profile_samples(rgbl_matcher* m, int kernel, float* ms, int cap) {
+  if (!m || (cap > 0 && !ms)) return 0;
+  (void)hipStreamSynchronize(m->stream);
+  m->timer.collect();
+  return m->timer.read_samples(kernel, ms, cap);
+}
 
 int rgbl_descriptor_distance(const uint8_t* a, const uint8_t* b) {
   // host helper with the reference's word-wise semantics (8 x 32-bit little-endian words)

@@ -176,6 +176,9 @@ class ORBextractor:
     def profile_read(self):
         return L.read_profile(self.lib, self.lib.rgbl_extractor_profile_read, self.h)
 
+    def profile_samples(self):
+        return L.read_profile_samples(self.lib, self.lib.rgbl_extractor_profile_read, self.lib.rgbl_extractor_profile_samples, self.h)
+
 
 def ComputeStereoMatches(extractorLeft, extractorRight, mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mb, mbf):
     """Frame::ComputeStereoMatches (src/Frame.cc:901-1071). Both extractors must just have processed the left / right
@@ -314,6 +317,9 @@ class DepthModule:
 
     def profile_read(self):
         return L.read_profile(self.lib, self.lib.rgbl_depth_profile_read, self.h)
+
+    def profile_samples(self):
+        return L.read_profile_samples(self.lib, self.lib.rgbl_depth_profile_read, self.lib.rgbl_depth_profile_samples, self.h)
 
 
 class ORBmatcher:
@@ -683,6 +689,9 @@ class ORBmatcher:
 
     def profile_read(self):
         return L.read_profile(self.lib, self.lib.rgbl_matcher_profile_read, self.h)
+
+    def profile_samples(self):
+        return L.read_profile_samples(self.lib, self.lib.rgbl_matcher_profile_read, self.lib.rgbl_matcher_profile_samples, self.h)
 
 
 class ORBVocabulary:

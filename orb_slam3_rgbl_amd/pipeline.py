@@ -245,6 +245,14 @@ class FrontEndPipeline:
                     k[name] = (a[0] + ms, a[1] + n)
         return k
 
+    def profile_samples(self):
+        """{kernel: [every launch's duration, ms]} of the (single) lane since profile(True)."""
+        k = {}
+        ln = self.lanes[0]
+        for src in (ln.ex.profile_samples(), ln.dm.profile_samples(), ln.mt.profile_samples()):
+            k.update(src)
+        return k
+
     def set_inputs(self, d_imgs, d_cloud):
         self.d_imgs, self.d_cloud = d_imgs, d_cloud
 
