@@ -108,7 +108,8 @@ struct rgbl_extractor {
   uint32_t* d_levelcnt = nullptr;  // [B][L] candidates per level, counted by k_fast_cells' cells (dense candidate lists)
   bool dense = false;              // k_fast_cells writes a level's candidates as one list (label-based quad-tree kernel, separate pixel kernels)
   bool dense_dirty = false;        // an enqueue failed between the FAST and the quad-tree launches: the counters may hold leftovers
-  int* d_err = nullptr;
+  int* d_err = nullptr;            // (the first word of d_stage)
+  uint8_t* d_stage = nullptr;      // error flags | d_out_n | d_out_mono | d_out_kp | d_out_desc, the layout of h_pinned
   int32_t* d_stereo_sad = nullptr;  // ComputeStereoMatches scratch (grow-only)
   size_t stereo_sad_count = 0;
   void* d_stereo_stage = nullptr;
@@ -429,17 +430,28 @@ int alloc_scratch(rgbl_extractor* e) {
   RGBL_TRY(dev_alloc(e, &e->d_kpcount, B * (size_t)e->L));
   RGBL_TRY(dev_alloc(e, &e->d_levelcnt, 2 * B * (size_t)e->L));  // counters | the last extraction's counts
   RGBL_HIP(hipMemset(e->d_levelcnt, 0, 2 * B * (size_t)e->L * sizeof(uint32_t)));
-  RGBL_TRY(dev_alloc(e, &e->d_err, 1));
   RGBL_TRY(dev_alloc(e, &e->d_dbg, B * (size_t)e->L * 16));
   RGBL_HIP(hipMemset(e->d_dbg, 0, B * (size_t)e->L * 16 * sizeof(unsigned long long)));
-  RGBL_HIP(hipMemset(e->d_err, 0, sizeof(int)));
   e->out_cap = e->kp_frame;
-  RGBL_TRY(dev_alloc(e, &e->d_out_kp, B * (size_t)e->out_cap));
+  // The host-pointer path's results live in ONE device block laid out like the page-locked block they are copied into:
+  //   error flags (256 B) | counts [B] | monoIndex [B] | keypoints [B x out_cap] | descriptors [B x out_cap x 32]
+  // so that a call that fills the whole handle (one frame per call above all) brings everything back with ONE copy - round 4
+  // queued five (flag, counts, monoIndex, keypoints, descriptors: three copy kernels and two DMA transfers of ~5 us each at
+  // the very end of a frame's critical path).
+  {
+    const size_t head = 256 + 2 * sizeof(int32_t) * B, kp_bytes = B * (size_t)e->out_cap * sizeof(rgbl_keypoint);
+    uint8_t* blk = nullptr;
+    RGBL_TRY(dev_alloc(e, &blk, head + kp_bytes + B * (size_t)e->out_cap * 32));
+    e->d_stage = blk;
+    e->d_err = reinterpret_cast<int*>(blk);
+    e->d_out_n = reinterpret_cast<int32_t*>(blk + 256);
+    e->d_out_mono = e->d_out_n + B;
+    e->d_out_kp = reinterpret_cast<rgbl_keypoint*>(blk + head);
+    e->d_out_desc = blk + head + kp_bytes;
+    RGBL_HIP(hipMemset(blk, 0, head));
+  }
   RGBL_TRY(dev_alloc(e, &e->d_tmp_kp, B * (size_t)e->out_cap));
-  RGBL_TRY(dev_alloc(e, &e->d_out_desc, B * (size_t)e->out_cap * 32));
   RGBL_TRY(dev_alloc(e, &e->d_tmp_desc, B * (size_t)e->out_cap * 32));
-  RGBL_TRY(dev_alloc(e, &e->d_out_n, B));
-  RGBL_TRY(dev_alloc(e, &e->d_out_mono, B));
   // results of up to 4 frames per call come back through one page-locked block (run_staged)
   e->h_pinned_bytes = 256 + 2 * sizeof(int32_t) * B + std::min<size_t>(B, 4) * (size_t)e->out_cap * (sizeof(rgbl_keypoint) + 32);
   if (hipHostMalloc(reinterpret_cast<void**>(&e->h_pinned), e->h_pinned_bytes, hipHostMallocDefault) != hipSuccess) { e->h_pinned = nullptr; e->h_pinned_bytes = 0; (void)hipGetLastError(); }
@@ -924,11 +936,16 @@ static int staged_enqueue(rgbl_extractor* e, int batch, int dev_stride, int lap0
   int32_t* p_mono = p_n + e->cfg.max_batch;
   uint8_t* p_kp = e->h_pinned + head;
   uint8_t* p_desc = p_kp + kp_bytes;
-  RGBL_HIP(hipMemcpyAsync(p_err, e->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipMemcpyAsync(p_n, e->d_out_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipMemcpyAsync(p_mono, e->d_out_mono, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipMemcpyAsync(p_kp, e->d_out_kp, kp_bytes, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipMemcpyAsync(p_desc, e->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, s));
+  (void)p_err; (void)p_n; (void)p_mono;
+  // device block and page-locked block share their layout up to the keypoints of `batch` frames; the descriptors follow the
+  // keypoints of ALL max_batch frames on the device, of `batch` frames on the host: one copy when the call fills the handle
+  if (batch == e->cfg.max_batch) {
+    RGBL_HIP(hipMemcpyAsync(e->h_pinned, e->d_stage, head + kp_bytes + desc_bytes, hipMemcpyDeviceToHost, s));
+  } else {
+    RGBL_HIP(hipMemcpyAsync(e->h_pinned, e->d_stage, head + kp_bytes, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipMemcpyAsync(p_desc, e->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, s));
+  }
+  (void)p_kp;
   return RGBL_OK;
 }
 

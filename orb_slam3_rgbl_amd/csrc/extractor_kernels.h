@@ -1756,6 +1756,9 @@ __device__ __forceinline__ int bcast_i(int v, int k) {  // value of lane k, wave
 }
 __device__ __forceinline__ float bcast_f(float v, int k) { return __int_as_float(bcast_i(__float_as_int(v), k)); }
 
+// (Round 5: more resident waves do not help here - amdgpu_waves_per_eu(6) gives 71 VGPRs / 7 waves per SIMD instead of 82 / 5 and
+// the kernel takes 0.65 instead of 0.63 ms per 512 frames, (8) spills: 0.81 ms.  What paces it is the number of cache lines its
+// patch gathers touch - ~90 per keypoint, one L1 tag look-up each - not the latency those waves could hide.)
 template <int BS>
 __global__ __launch_bounds__(BS) void k_orient_brief(const LevelGeom* __restrict__ geom, int n_levels, UMax umax,
                                                       const int8_t* __restrict__ pattern,
