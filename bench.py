@@ -38,6 +38,7 @@ WORKLOADS = {
     "4k": (3840, 2160, 8000, 4096, 64),
 }
 LEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 12, 7
+PROF_STEPS = 12    # serialised steps of the per-kernel timing leg (profiles/summarize_rocprof.py divides its counter totals by them)
 
 
 def level_sizes(w, h):
@@ -108,7 +109,7 @@ def algorithmic_bytes(kernel, w, h, n_points, k_per_frame):
     return table.get(kernel)
 
 
-TRAFFIC_FILES = {"kitti": ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"), "4k": ("r04_pmc_traffic_4k.json", "r03_pmc_traffic_4k.json")}
+TRAFFIC_FILES = {"kitti": ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"), "4k": ("r05_pmc_traffic_4k.json", "r04_pmc_traffic_4k.json", "r03_pmc_traffic_4k.json")}
 CLOCK_HZ, SIMDS = 2.4e9, 1024     # MI355X: 256 CUs x 4 SIMDs, one VALU instruction of a wave64 per 4 cycles and SIMD
 
 
@@ -824,7 +825,7 @@ def main():
     if rank == 0:
         # per-kernel timing leg: one stream for everything, so that the HIP-event brackets around each launch are not
         # stretched by other kernels running concurrently
-        prof_steps = 12
+        prof_steps = PROF_STEPS
         kernels, kernel_stats = serial_kernel_leg(pipe, prof_steps)
         roofline = roofline_of(kernels, prof_steps, args.workload, w, h, n_points, k_mean, B, elapsed / args.steps)
         roofline["kernels_ms_per_step_stats"] = kernel_stats

@@ -65,8 +65,11 @@ def traffic(out_dir, steps, warmup, frames_per_step, out, tag="bench", extra_arg
     # and report both so that the choice can be checked
     f_fetch = factors.get("FETCH_SIZE:calib_read_b32")
     f_write = factors.get("WRITE_SIZE:calib_write_b32")
-    # bench.py runs `warmup` + `steps` timed steps and 3 more for its per-kernel timing leg, all serialised
-    n_steps = int(steps) + int(warmup) + 3
+    # bench.py runs `warmup` + `steps` timed steps and bench.PROF_STEPS more for its per-kernel timing leg, all serialised
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n_steps = int(steps) + int(warmup) + bench.PROF_STEPS
     kernels = {}
     for c, f, key in (("FETCH_SIZE", f_fetch, "fetch_bytes_per_step"), ("WRITE_SIZE", f_write, "write_bytes_per_step"),
                       ("SQ_INSTS_VALU", 1.0, "valu_insts_per_step")):
