@@ -53,7 +53,9 @@ def test_introsort_restatement_reproduces_std_sort_tie_order(emu_lib, oracle):
 
 def test_introsort_heapsort_fallback_path(emu_lib, oracle):
     # median-of-three killer sequence (Musser): drives introsort into its depth limit -> heap sort branch
-    for n in (512, 2048):
+    # (40 .. 200: the depth limit is reached INSIDE a range of at most 64 elements - the wave-register finisher of round 5 hands
+    # what is left back to the heap sort)
+    for n in (40, 64, 66, 70, 72, 80, 90, 100, 128, 200, 512, 2048):
         k = n // 2
         a = np.zeros(n, np.uint64)
         for i in range(1, k + 1):
