@@ -1332,6 +1332,44 @@ def check_pipeline_gather(lib, mode, dev=None, w=640, h=360, nfeatures=800, batc
     pipe.close()
 
 
+def check_pipeline_idle_steps(lib, mode, dev=None, w=640, h=360, nfeatures=800, batch=8, n_az=600, levels=8):
+    """FrontEndPipeline.step(active=False): a rank without frames for a step (BASELINE configs[3]: 11 sequences on 8 ranks) still takes
+    part in the step's gather with all-zero counts.  One rank: active, idle, active, idle - the root's records of the active steps equal
+    a plain run's, the idle steps arrive empty, and nothing of an idle step leaks into the next active one."""
+    import torch
+
+    from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline, unpack_records
+    dev = dev or torch.device("cuda", 0)
+    K = synth.KITTI_K.copy()
+    K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    proj = F.projection_matrix(K, synth.KITTI_TR, lib)
+    sq = synth.Sequence(71, w, h, n_frames=batch)
+    frames = np.stack([sq.frame(i) for i in range(batch)])
+    cloud = np.stack([synth.lidar_scan(710 + i, n_az=n_az) for i in range(batch)])
+    pattern = (True, False, True, False, False, True)
+    pipe = FrontEndPipeline(lib, torch, dev, w, h, nfeatures, proj, cloud.shape[2], batch, levels=levels, ini_th=20, min_th=7, world=1, rank=0,
+                            gather=mode, keep_steps=len(pattern), log_steps=len(pattern))
+    pipe.set_inputs(torch.from_numpy(frames).to(dev), torch.from_numpy(cloud).to(dev))
+    for a in pattern:
+        pipe.step(active=a)
+    pipe.finish()
+    pipe.sync()
+    assert len(pipe.received) == len(pattern)
+    orc = O.Extractor(nfeatures, 1.2, levels, 20, 7)
+    ref = [orc(frames[f])[:2] for f in range(batch)]
+    for a, got in zip(pattern, pipe.received):
+        counts, rec = got[0]
+        if not a:
+            assert int(np.abs(counts).sum()) == 0 and rec.numel() == 0
+            continue
+        fr = unpack_records(rec.cpu().numpy(), counts)
+        for f in range(batch):
+            okps, odesc = ref[f]
+            assert fr[f]["n"] == len(okps) and np.array_equal(fr[f]["kp"], okps.view(np.uint8).reshape(len(okps), 28))
+            assert np.array_equal(fr[f]["desc"], odesc)
+    pipe.close()
+
+
 def check_pipeline_step(lib, w, h, nfeatures, batch, n_az, dev=None, steps=2, seq=90, levels=8, ini=12, mn=7):
     """The batched step exactly as bench.py times it (FrontEndPipeline: extract -> depth -> match on resident inputs, no gather):
     EVERY frame of the last step against the oracle - keypoints, descriptors, depth, uRight and the matches against the

@@ -181,6 +181,12 @@ def test_extractor_4k_geometry_through_the_batch_kernels(emu_lib):
         os.environ.pop("RGBL_FAST_BS", None)
 
 
+@pytest.mark.parametrize("mode", ["step", "final"])
+def test_pipeline_idle_steps_take_part_in_the_gather(emu_lib, mode):
+    import torch
+    pc.check_pipeline_idle_steps(emu_lib, mode, dev=torch.device("cpu"), w=240, h=160, nfeatures=300, batch=2, n_az=240, levels=4)
+
+
 def test_instruction_wrapper_selftest_runs(emu_lib):
     # the emulation's plain-C stand-ins trivially agree; what this checks is the self-test's own host-side expectations
     from orb_slam3_rgbl_amd import _lib as L

@@ -318,6 +318,11 @@ def test_pipeline_step_4k_cfg5(gpu_lib):
     assert pc.check_pipeline_step(gpu_lib, 3840, 2160, 8000, batch=8, n_az=4096) > 4000
 
 
+@pytest.mark.parametrize("mode", ["step", "final"])
+def test_pipeline_idle_steps_take_part_in_the_gather(gpu_lib, mode):
+    pc.check_pipeline_idle_steps(gpu_lib, mode)
+
+
 def test_pipeline_step_kitti_cfg2(gpu_lib):
     # the headline's step (KITTI size, 2000 features, 121 600-point scans) on 16 distinct frames, every one checked
     assert pc.check_pipeline_step(gpu_lib, synth.KITTI_W, synth.KITTI_H, 2000, batch=16, n_az=1900, seq=91) > 1500
