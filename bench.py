@@ -897,6 +897,14 @@ def main():
         if world == 1 and not args.no_extras:
             out["extra"] = extra_workloads(lib, dev, torch)
             out["extra"]["sparse_upsampling"] = sparse_leg
+            # BASELINE configs[2] (SearchForTriangulation) and the matcher calls of one tracked frame: per-call latency through the
+            # host-pointer C ABI with the reference's own ORBmatcher.cc / DBoW2 / ComputeStereoMatches timed beside each (bench_calls.py)
+            import bench_calls
+            for name, leg in (("cfg3_triangulation", bench_calls.triangulation_leg), ("tracking_calls", bench_calls.tracking_leg)):
+                try:
+                    out["extra"][name] = leg(lib)
+                except Exception as e:   # the headline stands on its own
+                    out["extra"][name] = {"error": repr(e)}
             try:
                 out["extra"]["gather_rccl_1rank"] = gather_legs_one_rank(lib, torch, dist, dev, d_imgs, d_cloud, w, h, nfeatures, proj, n_points, B,
                                                                          max(10, args.steps // 2))

@@ -3,6 +3,7 @@
 // TEST INFRASTRUCTURE (oracle/Makefile target `ref`).
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 
 #include "Thirdparty/DBoW2/DBoW2/FORB.h"
@@ -10,7 +11,11 @@
 
 typedef DBoW2::TemplatedVocabulary<DBoW2::FORB::TDescriptor, DBoW2::FORB> ORBVocabulary;  // include/ORBVocabulary.h
 
+static double g_transform_seconds = 0.0;  // wall time of the last transform() call itself (bench.py)
+
 extern "C" {
+
+double ref_voc_last_call_seconds() { return g_transform_seconds; }
 
 void* ref_voc_load_text(const char* path) {
   ORBVocabulary* v = new ORBVocabulary();
@@ -31,7 +36,11 @@ int ref_voc_transform(void* h, const uint8_t* desc, int n, int levelsup, int cap
   }
   DBoW2::BowVector bow;
   DBoW2::FeatureVector fv;
-  v->transform(features, bow, fv, levelsup);
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    v->transform(features, bow, fv, levelsup);
+    g_transform_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
   *n_words = (int)bow.size();
   *n_nodes = (int)fv.size();
   if ((int)bow.size() > cap_words || (int)fv.size() > cap_nodes) return -1;

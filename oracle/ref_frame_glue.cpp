@@ -8,9 +8,14 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include "ORBmatcher.h"  // /root/reference/include
 #include "oracle.h"
+
+// wall time of the last Frame::ComputeStereoMatches() call itself (bench.py: the CPU side of the stereo matcher)
+static double g_stereo_call_seconds = 0.0;
+extern "C" double ref_frame_last_call_seconds() { return g_stereo_call_seconds; }
 
 namespace cv {
 enum { NORM_L1 = 2 };
@@ -56,7 +61,11 @@ extern "C" int ref_stereo_matches(const uint8_t* left, const uint8_t* right, int
   F.mpORBextractorRight = &exr;
   *n_left = F.N; *n_right = (int)F.mvKeysRight.size();
   if (F.N > cap || *n_right > cap) return -1;
-  F.ComputeStereoMatches();
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    F.ComputeStereoMatches();
+    g_stereo_call_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
   copy_keys(F.mvKeys, F.mDescriptors, kp_left, desc_left, cap);
   copy_keys(F.mvKeysRight, F.mDescriptorsRight, kp_right, desc_right, cap);
   for (int i = 0; i < F.N; ++i) { out_uright[i] = F.mvuRight[i]; out_depth[i] = F.mvDepth[i]; }

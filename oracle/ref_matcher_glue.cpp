@@ -4,8 +4,21 @@
 #include <math.h>
 #include <string.h>
 
+#include <chrono>
+
 #include "ORBmatcher.h"  // /root/reference/include (orbslam_types.h is force-included in front of it)
 #include "oracle.h"
+
+// Wall time of the last call INTO the reference's own function (not of the stand-in objects built around it): what
+// bench.py reports as the CPU side of a matcher call (`cpu_baseline`, kind "reference").
+namespace {
+double g_last_call_seconds = 0.0;
+struct CallTimer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  ~CallTimer() { g_last_call_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+extern "C" double ref_last_call_seconds() { return g_last_call_seconds; }
 
 namespace ORB_SLAM3 {
 
@@ -150,7 +163,8 @@ int ref_search_triangulation(const KfArrays* a1, const KfArrays* a2, const float
   fill_keyframe(kf2, *a2, &cam, &some, scale_factors, level_sigma2, n_levels, q2, t2);
   ORBmatcher matcher(0.6f, check_orientation != 0);
   std::vector<std::pair<size_t, size_t> > pairs;
-  const int nm = matcher.SearchForTriangulation(&kf1, &kf2, pairs, only_stereo != 0, coarse != 0);
+  int nm;
+  { CallTimer timed; nm = matcher.SearchForTriangulation(&kf1, &kf2, pairs, only_stereo != 0, coarse != 0); }
   for (int i = 0; i < a1->n; ++i) matches12[i] = -1;
   for (const auto& pr : pairs) matches12[pr.first] = (int)pr.second;
   // the same expressions as ORBmatcher.cc:914-931
@@ -210,7 +224,8 @@ extern "C" int ref_search_by_projection(const orc_projection_input* in, int* mat
   cur.grid.mfGridElementWidthInv = in->grid[4]; cur.grid.mfGridElementHeightInv = in->grid[5];
   cur.grid.Build(cur.mvKeysUn);
   ORBmatcher matcher(0.9f, in->check_orientation != 0);
-  const int nm = matcher.SearchByProjection(cur, last, in->th, in->mono != 0);
+  int nm;
+  { CallTimer timed; nm = matcher.SearchByProjection(cur, last, in->th, in->mono != 0); }
   for (int i = 0; i < in->n2; ++i) match2[i] = cur.mvpMapPoints[i] ? (int)(cur.mvpMapPoints[i] - points.data()) : -1;
   return nm;
 }
@@ -266,7 +281,8 @@ extern "C" int ref_search_by_projection_kf(const orc_kf_projection_input* in, in
   cur.grid.mfGridElementWidthInv = in->grid[4]; cur.grid.mfGridElementHeightInv = in->grid[5];
   cur.grid.Build(cur.mvKeysUn);
   ORBmatcher matcher(0.9f, in->check_orientation != 0);
-  const int nm = matcher.SearchByProjection(cur, &kf, found, in->th, in->orb_dist);
+  int nm;
+  { CallTimer timed; nm = matcher.SearchByProjection(cur, &kf, found, in->th, in->orb_dist); }
   for (int i = 0; i < in->n2; ++i) {
     MapPoint* p = cur.mvpMapPoints[i];
     match2[i] = (p && p != &before) ? (int)(p - points.data()) : -1;
@@ -315,7 +331,8 @@ extern "C" int ref_search_local_points(const orc_local_points_input* in, int* ma
   F.grid.mfGridElementWidthInv = in->grid[4]; F.grid.mfGridElementHeightInv = in->grid[5];
   F.grid.Build(F.mvKeysUn);
   ORBmatcher matcher(in->nnratio, true);
-  const int nm = matcher.SearchByProjection(F, vp, in->th, false, 50.0f);
+  int nm;
+  { CallTimer timed; nm = matcher.SearchByProjection(F, vp, in->th, false, 50.0f); }
   for (int i = 0; i < in->n2; ++i) {
     MapPoint* p = F.mvpMapPoints[i];
     match2[i] = (p && p != &old_point) ? (int)(p - points.data()) : -1;
@@ -353,7 +370,8 @@ extern "C" int ref_search_by_bow(const KfArrays* kfa, const KfArrays* fra, float
     F.mFeatVec[(unsigned)fra->node_id[k]] = std::vector<unsigned>(fra->node_feat + fra->node_off[k], fra->node_feat + fra->node_off[k + 1]);
   ORBmatcher matcher(nnratio, check_orientation != 0);
   std::vector<MapPoint*> vpMapPointMatches;
-  const int nm = matcher.SearchByBoW(&kf, F, vpMapPointMatches);
+  int nm;
+  { CallTimer timed; nm = matcher.SearchByBoW(&kf, F, vpMapPointMatches); }
   for (int i = 0; i < fra->n; ++i) match2[i] = vpMapPointMatches[i] ? (int)(vpMapPointMatches[i] - pts.data()) : -1;
   return nm;
 }
@@ -383,7 +401,8 @@ extern "C" int ref_search_by_bow_kf(const KfArrays* a1, const KfArrays* a2, floa
   }
   ORBmatcher matcher(nnratio, check_orientation != 0);
   std::vector<MapPoint*> vpMatches12;
-  const int nm = matcher.SearchByBoW(&kf[0], &kf[1], vpMatches12);
+  int nm;
+  { CallTimer timed; nm = matcher.SearchByBoW(&kf[0], &kf[1], vpMatches12); }
   for (int i = 0; i < a1->n; ++i) match12[i] = vpMatches12[i] ? (int)(vpMatches12[i] - pts2.data()) : -1;
   return nm;
 }
@@ -443,7 +462,8 @@ extern "C" int ref_fuse(const orc_fuse_input* in, const uint8_t* kf_state2, int*
   std::vector<std::pair<MapPoint*, MapPoint*>> log;
   MapPoint::replace_log = &log;
   ORBmatcher matcher(0.6f, true);
-  const int nFused = matcher.Fuse(&kf, vp, in->th);
+  int nFused;
+  { CallTimer timed; nFused = matcher.Fuse(&kf, vp, in->th); }
   MapPoint::replace_log = nullptr;
   for (int i = 0; i < in->n1; ++i) {
     best_idx[i] = -1;
@@ -534,7 +554,8 @@ extern "C" int ref_search_by_sim3(const Sim3Side* a1, const Sim3Side* a2, const 
     if (prior12[i] >= 0) vpMatches12[i] = &p2[prior12[i]];
   Sophus::Sim3f S12(1.f, Eigen::Quaternionf(1.f, 0.f, 0.f, 0.f), Eigen::Vector3f(0.f, 0.f, 0.f));
   ORBmatcher matcher(0.75f, true);
-  const int nFound = matcher.SearchBySim3(&kf1, &kf2, vpMatches12, S12, th);
+  int nFound;
+  { CallTimer timed; nFound = matcher.SearchBySim3(&kf1, &kf2, vpMatches12, S12, th); }
   for (int i = 0; i < a1->n; ++i) match12[i] = vpMatches12[i] ? (int)(vpMatches12[i] - p2.data()) : -1;
   return nFound;
 }
@@ -568,7 +589,8 @@ extern "C" int ref_fuse_sim3(const Sim3Side* cand, const uint8_t* in_kf1, const 
   }
   Sophus::Sim3f Scw(1.f, Eigen::Quaternionf(1.f, 0.f, 0.f, 0.f), Eigen::Vector3f(0.f, 0.f, 0.f));
   ORBmatcher matcher(0.8f, true);
-  const int nFused = matcher.Fuse(&kf, Scw, vp, th, vpReplacePoint);
+  int nFused;
+  { CallTimer timed; nFused = matcher.Fuse(&kf, Scw, vp, th, vpReplacePoint); }
   for (int i = 0; i < cand->n; ++i) {
     fused[i] = -1;
     if (vpReplacePoint[i]) {
@@ -649,7 +671,8 @@ extern "C" int ref_search_for_initialization(const orc_initialization_input* in,
   for (int i = 0; i < in->n1; ++i) { prev[i].x = prev_matched[2 * i]; prev[i].y = prev_matched[2 * i + 1]; }
   std::vector<int> m12;
   ORBmatcher matcher(in->nnratio, in->check_orientation != 0);
-  const int nm = matcher.SearchForInitialization(F1, F2, prev, m12, in->window_size);
+  int nm;
+  { CallTimer timed; nm = matcher.SearchForInitialization(F1, F2, prev, m12, in->window_size); }
   for (int i = 0; i < in->n1; ++i) { matches12[i] = m12[i]; prev_matched[2 * i] = prev[i].x; prev_matched[2 * i + 1] = prev[i].y; }
   return nm;
 }

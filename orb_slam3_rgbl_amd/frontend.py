@@ -181,6 +181,10 @@ class ORBextractor:
 
 
 def ComputeStereoMatches(extractorLeft, extractorRight, mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mb, mbf):
+    return prepare_ComputeStereoMatches(extractorLeft, extractorRight, mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mb, mbf)()
+
+
+def prepare_ComputeStereoMatches(extractorLeft, extractorRight, mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mb, mbf):
     """Frame::ComputeStereoMatches (src/Frame.cc:901-1071). Both extractors must just have processed the left / right
     image (their device-resident pyramids are read). Returns (mvuRight, mvDepth)."""
     lib = extractorLeft.lib
@@ -190,9 +194,13 @@ def ComputeStereoMatches(extractorLeft, extractorRight, mvKeys, mDescriptors, mv
     dr = np.ascontiguousarray(mDescriptorsRight, np.uint8).reshape(-1, 32)
     ur = np.full(len(kl), -1, np.float32)
     dp = np.full(len(kl), -1, np.float32)
-    L.check(lib, lib.rgbl_stereo_matches(extractorLeft.h, extractorRight.h, L.ptr(kl), L.ptr(dl), len(kl), L.ptr(kr), L.ptr(dr),
-                                         len(kr), float(mb), float(mbf), L.ptr(ur), L.ptr(dp)))
-    return ur, dp
+    args = (extractorLeft.h, extractorRight.h, L.ptr(kl), L.ptr(dl), len(kl), L.ptr(kr), L.ptr(dr), len(kr), float(mb), float(mbf),
+            L.ptr(ur), L.ptr(dp))
+
+    def call():
+        L.check(lib, lib.rgbl_stereo_matches(*args))
+        return ur, dp
+    return call
 
 
 def structuring_element(shape, kw, kh, lib=None):
@@ -375,7 +383,11 @@ class ORBmatcher:
         return F
 
     def SearchByProjection(self, frames, th, bMono):
+        return self.prepare_SearchByProjection(frames, th, bMono)()
+
+    def prepare_SearchByProjection(self, frames, th, bMono):
         """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1676-1887).
+        (prepare_*: the input block is built once, the returned closure is the C call alone - what bench.py times.)
         frames: dict with the LastFrame arrays valid1, world_pos1, mp_desc1, mp_observed1, octave1, angle1, the CurrentFrame
         arrays kp2_xy, kp2_octave, kp2_angle, uright2, desc2, and grid[6], Tcw_q/Tcw_t, Tlw_q/Tlw_t, K[4], mb, mbf,
         scale_factors.  Returns (match2: LastFrame feature index per CurrentFrame feature or -1, nmatches)."""
@@ -403,8 +415,12 @@ class ORBmatcher:
         P.th, P.mono, P.check_orientation = float(th), int(bMono), int(self.mbCheckOrientation)
         match2 = np.zeros(P.n2, np.int32)
         n = C.c_int(0)
-        L.check(self.lib, self.lib.rgbl_search_by_projection(self.h, C.byref(P), L.ptr(match2), C.byref(n)))
-        return match2, n.value
+        fn, h, pP, pm, pn = self.lib.rgbl_search_by_projection, self.h, C.byref(P), L.ptr(match2), C.byref(n)
+
+        def call(_keep=keep):   # the closure owns the input arrays
+            L.check(self.lib, fn(h, pP, pm, pn))
+            return match2, n.value
+        return call
 
     @staticmethod
     def PredictScale(dist3D, mfMaxDistance, mfLogScaleFactor, mnScaleLevels):
@@ -554,6 +570,9 @@ class ORBmatcher:
         return match, n.value
 
     def SearchLocalPoints(self, pts, th):
+        return self.prepare_SearchLocalPoints(pts, th)()
+
+    def prepare_SearchLocalPoints(self, pts, th):
         """ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) (ORBmatcher.cc:43-213), the call of
         Tracking::SearchLocalPoints.  pts: dict with the map point arrays valid1, proj1 [n,3] (mTrackProjX, mTrackProjY,
         mTrackProjXR), level1, view_cos1, mp_desc1, mp_observed1, the frame arrays kp2_xy, kp2_octave, uright2, desc2,
@@ -579,8 +598,12 @@ class ORBmatcher:
         P.th, P.nnratio = float(th), float(self.mfNNratio)
         match2 = np.zeros(P.n2, np.int32)
         n = C.c_int(0)
-        L.check(self.lib, self.lib.rgbl_search_local_points(self.h, C.byref(P), L.ptr(match2), C.byref(n)))
-        return match2, n.value
+        fn, h, pP, pm, pn = self.lib.rgbl_search_local_points, self.h, C.byref(P), L.ptr(match2), C.byref(n)
+
+        def call(_keep=keep):   # the closure owns the input arrays
+            L.check(self.lib, fn(h, pP, pm, pn))
+            return match2, n.value
+        return call
 
     def SearchForInitialization(self, case, windowSize=100):
         """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:648-763).
@@ -624,6 +647,9 @@ class ORBmatcher:
         return v
 
     def SearchByBoW(self, kf, frame):
+        return self.prepare_SearchByBoW(kf, frame)()
+
+    def prepare_SearchByBoW(self, kf, frame):
         """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (ORBmatcher.cc:223-425).  kf / frame: dicts as for
         SearchForTriangulation; kf["has_mp"] = map point present and not bad.  Returns (per frame feature the key-frame
         feature whose map point it gets, or -1; nmatches)."""
@@ -631,9 +657,13 @@ class ORBmatcher:
         v1, v2 = self._view(kf, keep), self._view(frame, keep)
         m = np.full(v2.n, -1, np.int32)
         nm = C.c_int(0)
-        L.check(self.lib, self.lib.rgbl_search_by_bow(self.h, C.byref(v1), C.byref(v2), float(self.mfNNratio),
-                                                      int(self.mbCheckOrientation), L.ptr(m), C.byref(nm)))
-        return m, nm.value
+        fn, h, p1, p2, r, o, pm, pn = (self.lib.rgbl_search_by_bow, self.h, C.byref(v1), C.byref(v2), float(self.mfNNratio),
+                                       int(self.mbCheckOrientation), L.ptr(m), C.byref(nm))
+
+        def call(_keep=keep):   # the closure owns the input arrays
+            L.check(self.lib, fn(h, p1, p2, r, o, pm, pn))
+            return m, nm.value
+        return call
 
     def SearchByBoWKeyFrames(self, kf1, kf2):
         """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (ORBmatcher.cc:765-905).  kf1 / kf2: dicts as for
@@ -649,6 +679,10 @@ class ORBmatcher:
 
     def SearchForTriangulation(self, kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, bOnlyStereo=False,
                                bCoarse=False):
+        return self.prepare_SearchForTriangulation(kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, bOnlyStereo, bCoarse)()
+
+    def prepare_SearchForTriangulation(self, kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, bOnlyStereo=False,
+                                       bCoarse=False):
         """kf = dict(desc, xy, octave, angle, uright, has_mp, node_id, node_off, node_feat).
         Returns (vMatchedPairs as [m,2] int array in ascending idx1, nmatches)."""
         keep = []
@@ -678,11 +712,15 @@ class ORBmatcher:
         P.only_stereo, P.coarse, P.check_orientation = int(bOnlyStereo), int(bCoarse), int(self.mbCheckOrientation)
         m12 = np.full(v1.n, -1, np.int32)
         nm = C.c_int(0)
-        L.check(self.lib, self.lib.rgbl_search_triangulation(self.h, C.byref(v1), C.byref(v2), C.byref(P), L.ptr(m12),
-                                                             C.byref(nm)))
-        idx1 = np.nonzero(m12 >= 0)[0]
-        pairs = np.stack([idx1, m12[idx1]], 1) if len(idx1) else np.zeros((0, 2), np.int64)
-        return pairs, nm.value, m12
+        keep += [sf, s2]
+        fn, h, p1, p2, pP, pm, pn = self.lib.rgbl_search_triangulation, self.h, C.byref(v1), C.byref(v2), C.byref(P), L.ptr(m12), C.byref(nm)
+
+        def call(_keep=keep):   # the closure owns the input arrays
+            L.check(self.lib, fn(h, p1, p2, pP, pm, pn))
+            idx1 = np.nonzero(m12 >= 0)[0]
+            pairs = np.stack([idx1, m12[idx1]], 1) if len(idx1) else np.zeros((0, 2), np.int64)
+            return pairs, nm.value, m12
+        return call
 
     def profile(self, enable):
         L.check(self.lib, self.lib.rgbl_matcher_profile(self.h, int(enable)))
@@ -725,6 +763,9 @@ class ORBVocabulary:
         return dict(k=k.value, L=lv.value, n_nodes=nn.value, n_words=nw.value)
 
     def transform(self, features, levelsup=4):
+        return self.prepare_transform(features, levelsup)()
+
+    def prepare_transform(self, features, levelsup=4):
         """features: [n, 32] u8.  Returns (BowVector word ids, BowVector values, FeatureVector node ids, node offsets,
         feature indices)."""
         desc = np.ascontiguousarray(features, np.uint8).reshape(-1, 32)
@@ -732,9 +773,13 @@ class ORBVocabulary:
         wid, wval = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.float64)
         nid, noff, nfeat = np.zeros(max(n, 1), np.uint32), np.zeros(n + 1, np.int32), np.zeros(max(n, 1), np.uint32)
         nw, nn = C.c_int(0), C.c_int(0)
-        L.check(self.lib, self.lib.rgbl_bow_transform(self.h, L.ptr(desc), n, levelsup, L.ptr(wid), L.ptr(wval), n, C.byref(nw),
-                                                      L.ptr(nid), L.ptr(noff), L.ptr(nfeat), n, C.byref(nn)))
-        return wid[:nw.value].copy(), wval[:nw.value].copy(), nid[:nn.value].copy(), noff[:nn.value + 1].copy(), nfeat[:noff[nn.value]].copy()
+        args = (self.h, L.ptr(desc), n, levelsup, L.ptr(wid), L.ptr(wval), n, C.byref(nw), L.ptr(nid), L.ptr(noff), L.ptr(nfeat), n,
+                C.byref(nn))
+
+        def call():
+            L.check(self.lib, self.lib.rgbl_bow_transform(*args))
+            return wid[:nw.value].copy(), wval[:nw.value].copy(), nid[:nn.value].copy(), noff[:nn.value + 1].copy(), nfeat[:noff[nn.value]].copy()
+        return call
 
     def close(self):
         if self.h:

@@ -8,6 +8,7 @@ from oracle import oracle_py as O
 from orb_slam3_rgbl_amd import _lib as L
 from orb_slam3_rgbl_amd import frontend as F
 from orb_slam3_rgbl_amd import synth
+from orb_slam3_rgbl_amd.cases import make_triangulation_case, make_projection_case, make_local_points_case, _quat, _rot  # noqa: F401
 
 KP_FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
 
@@ -306,64 +307,6 @@ def check_matcher_known_answers(lib):
     m.close()
 
 
-def make_triangulation_case(n=1500, seed=11, n_nodes=100):
-    rng = np.random.default_rng(seed)
-    a = synth.descriptors(n, seed)
-    b, perm = synth.perturbed_descriptors(a, flip_p=0.04, seed=seed + 1)
-    # a few exact duplicates in image 2 to exercise "ties -> later candidate wins"
-    dup = rng.integers(0, n, 40)
-    b[dup] = b[(dup + 1) % n]
-    key1 = (a[:, 0].astype(np.int64) * 131 + a[:, 1] * 31 + a[:, 2]) % n_nodes
-    key2 = key1[perm]  # a feature of image 2 falls into the node of the feature it was derived from
-    key2[dup] = key2[(dup + 1) % n]
-
-    def csr(key):
-        order = np.argsort(key, kind="stable").astype(np.int32)
-        ids, cnt = np.unique(key, return_counts=True)
-        off = np.zeros(len(ids) + 1, np.int32)
-        off[1:] = np.cumsum(cnt)
-        return ids.astype(np.int32), off, order
-
-    xy1 = np.stack([rng.uniform(20, 1200, n), rng.uniform(20, 350, n)], 1).astype(np.float32)
-    disp = rng.uniform(2, 60, n).astype(np.float32)
-    xy2 = xy1[perm].copy()
-    xy2[:, 0] -= disp[perm]
-    xy2[:, 1] += rng.normal(0, 1.2, n).astype(np.float32)  # some pairs violate the epipolar bound
-    oct1 = rng.integers(0, 8, n).astype(np.int32)
-    oct2 = rng.integers(0, 8, n).astype(np.int32)
-    ang1 = rng.uniform(0, 360, n).astype(np.float32)
-    ang2 = (ang1[perm] + rng.normal(0, 25, n)).astype(np.float32) % 360
-    ur1 = np.where(rng.random(n) < 0.5, xy1[:, 0] - 5, -1).astype(np.float32)
-    ur2 = np.where(rng.random(n) < 0.5, xy2[:, 0] - 5, -1).astype(np.float32)
-    mp1 = (rng.random(n) < 0.3).astype(np.uint8)
-    mp2 = (rng.random(n) < 0.3).astype(np.uint8)
-    id1, off1, f1 = csr(key1)
-    id2, off2, f2 = csr(key2)
-    # drop a few nodes from each side so the merge walk has to skip
-    keep1 = rng.random(len(id1)) < 0.9
-    keep2 = rng.random(len(id2)) < 0.9
-
-    def drop(ids, off, feat, keep):
-        nid, noff, nfeat = [], [0], []
-        for i, k in enumerate(keep):
-            if k:
-                nid.append(ids[i])
-                nfeat.extend(feat[off[i]:off[i + 1]])
-                noff.append(len(nfeat))
-        return np.array(nid, np.int32), np.array(noff, np.int32), np.array(nfeat, np.int32)
-
-    id1, off1, f1 = drop(id1, off1, f1, keep1)
-    id2, off2, f2 = drop(id2, off2, f2, keep2)
-    kf1 = dict(desc=a, xy=xy1, octave=oct1, angle=ang1, uright=ur1, has_mp=mp1, node_id=id1, node_off=off1, node_feat=f1)
-    kf2 = dict(desc=b, xy=xy2, octave=oct2, angle=ang2, uright=ur2, has_mp=mp2, node_id=id2, node_off=off2, node_feat=f2)
-    K = np.array([718.856, 718.856, 607.1928, 185.2157], np.float32)
-    R = np.eye(3, dtype=np.float32).reshape(9)
-    t = np.array([-0.54, 0.002, 0.001], np.float32)
-    ep = np.array([900.0, 185.0], np.float32)  # inside the image so the epipole guard rejects some pairs
-    sf = (1.2 ** np.arange(8)).astype(np.float32)
-    return kf1, kf2, K, R, t, ep, sf, (sf * sf).astype(np.float32)
-
-
 def check_triangulation(lib, n=1500, seed=11):
     kf1, kf2, K, R, t, ep, sf, s2 = make_triangulation_case(n, seed)
     total = 0
@@ -511,76 +454,6 @@ def check_ingest_kitti_bin(lib, method=F.UPS_INVERSE_DILATION, w=620, h=188, n_a
 
 
 # ---- ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) -------------------------
-def _quat(axis, angle):
-    axis = np.asarray(axis, np.float64)
-    axis = axis / np.linalg.norm(axis)
-    return np.concatenate([axis * np.sin(angle / 2), [np.cos(angle / 2)]]).astype(np.float32)
-
-
-def _rot(q):
-    x, y, z, w = [float(v) for v in q]
-    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
-                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
-                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
-
-
-def make_projection_case(n1=1800, n2=2000, seed=21, motion="forward", w=synth.KITTI_W, h=synth.KITTI_H):
-    """A LastFrame with map points and a CurrentFrame whose features they should re-find.  Clusters of near-identical
-    current features and several map points aiming at the same feature exercise the 'feature already holds an observed
-    map point' rule (later points fall back to their second choice); unobserved (temporal) points get overwritten."""
-    rng = np.random.default_rng(seed)
-    K = np.array([718.856, 718.856, 607.1928, 185.2157], np.float32)
-    xy2 = np.stack([rng.uniform(5, w - 5, n2), rng.uniform(5, h - 5, n2)], 1).astype(np.float32)
-    desc2 = synth.descriptors(n2, seed)
-    # clusters: copies of a feature a few pixels away with almost the same descriptor
-    ncl = n2 // 10
-    src = rng.integers(0, n2, ncl)
-    dst = rng.permutation(n2)[:ncl]
-    xy2[dst] = xy2[src] + rng.uniform(-4, 4, (ncl, 2)).astype(np.float32)
-    flips = rng.random((ncl, 256)) < 0.02
-    desc2[dst] = desc2[src] ^ np.packbits(flips, axis=1, bitorder="little")
-    xy2[:, 0] = np.clip(xy2[:, 0], 1, w - 2)
-    xy2[:, 1] = np.clip(xy2[:, 1], 1, h - 2)
-    oct2 = rng.integers(0, 8, n2).astype(np.int32)
-    oct2[dst] = oct2[src]
-    ang2 = rng.uniform(0, 360, n2).astype(np.float32)
-    depth2 = rng.uniform(4, 70, n2)
-    mbf = 386.1448
-    uright2 = np.where(rng.random(n2) < 0.6, xy2[:, 0] - mbf / depth2 + rng.normal(0, 1.0, n2), -1).astype(np.float32)
-    # poses
-    qc = _quat([0.1, 1.0, 0.05], 0.02)
-    tc = np.array([0.05, -0.02, 0.3], np.float32)
-    dz = {"forward": 0.9, "backward": -0.9, "none": 0.05}[motion]
-    ql = _quat([0.0, 1.0, 0.0], 0.01)
-    Rc, Rl = _rot(qc), _rot(ql)
-    Cc = -Rc.T @ tc.astype(np.float64)                       # current camera centre in the world
-    # last camera: dz metres behind (forward motion) along its own optical axis
-    tl = (-Rl @ Cc + np.array([0.02, 0.0, dz])).astype(np.float32)
-    # map points: most aim at a current feature (several at the same one), the rest are elsewhere
-    target = rng.integers(0, n2, n1)
-    target[: n1 // 6] = target[n1 // 6: 2 * (n1 // 6)]        # duplicates
-    aimed = rng.random(n1) < 0.8
-    z = depth2[target] * rng.uniform(0.97, 1.03, n1)
-    uv = xy2[target] + rng.normal(0, 1.5, (n1, 2))
-    uv[~aimed] = np.stack([rng.uniform(-50, w + 50, (~aimed).sum()), rng.uniform(-50, h + 50, (~aimed).sum())], 1)
-    z[rng.random(n1) < 0.03] *= -1                            # behind the camera
-    xc = np.stack([(uv[:, 0] - K[2]) / K[0] * z, (uv[:, 1] - K[3]) / K[1] * z, z], 1)
-    world = ((xc - tc.astype(np.float64)) @ Rc).astype(np.float32)   # Rc^T (xc - tc)
-    flips = rng.random((n1, 256)) < 0.03
-    mp_desc = desc2[target] ^ np.packbits(flips, axis=1, bitorder="little")
-    mp_desc[~aimed] = synth.descriptors(int((~aimed).sum()), seed + 1)
-    oct1 = np.clip(oct2[target] + rng.integers(-1, 2, n1), 0, 7).astype(np.int32)
-    ang1 = ((ang2[target] + rng.normal(0, 20, n1)) % 360).astype(np.float32)
-    ang1[rng.random(n1) < 0.1] = rng.uniform(0, 360, 1).astype(np.float32)[0]
-    gw, gh = np.float32(w), np.float32(h)
-    grid = np.array([0, 0, gw, gh, np.float32(64) / (gw - np.float32(0)), np.float32(48) / (gh - np.float32(0))], np.float32)
-    return dict(valid1=(rng.random(n1) < 0.9).astype(np.uint8), world_pos1=world, mp_desc1=mp_desc,
-                mp_observed1=(rng.random(n1) < 0.75).astype(np.uint8), octave1=oct1, angle1=ang1,
-                kp2_xy=xy2, kp2_octave=oct2, kp2_angle=ang2, uright2=uright2, desc2=desc2, grid=grid,
-                Tcw_q=qc, Tcw_t=tc, Tlw_q=ql, Tlw_t=tl, K=K, mb=0.54, mbf=mbf,
-                scale_factors=(1.2 ** np.arange(8)).astype(np.float32))
-
-
 def check_search_by_projection(lib, seed=21, motion="forward", th=7.0, mono=False, check_ori=True, n1=1800, n2=2000):
     case = make_projection_case(n1, n2, seed, motion)
     mt = F.ORBmatcher(0.9, check_ori, lib=lib)
@@ -691,46 +564,6 @@ def check_search_by_projection_edge_cases(lib):
 
 
 # ---- ORBmatcher::SearchByProjection(F, vpMapPoints, th, ...) = Tracking::SearchLocalPoints -------------------------------
-def make_local_points_case(n1=3000, n2=2000, seed=41, w=synth.KITTI_W, h=synth.KITTI_H):
-    """Local map points with predicted projections (what Frame::isInFrustum leaves in the MapPoint) against a frame in which
-    a part of the features already holds tracked points.  Clusters of look-alike features make the ratio test bite,
-    several map points aim at the same feature (the later one is blocked and falls back or fails its ratio test)."""
-    rng = np.random.default_rng(seed)
-    xy2 = np.stack([rng.uniform(5, w - 5, n2), rng.uniform(5, h - 5, n2)], 1).astype(np.float32)
-    desc2 = synth.descriptors(n2, seed)
-    ncl = n2 // 6
-    src = rng.integers(0, n2, ncl)
-    dst = rng.permutation(n2)[:ncl]
-    xy2[dst] = xy2[src] + rng.uniform(-3, 3, (ncl, 2)).astype(np.float32)
-    flips = rng.random((ncl, 256)) < rng.choice([0.01, 0.05, 0.15], ncl)[:, None]
-    desc2[dst] = desc2[src] ^ np.packbits(flips, axis=1, bitorder="little")
-    xy2[:, 0] = np.clip(xy2[:, 0], 1, w - 2)
-    xy2[:, 1] = np.clip(xy2[:, 1], 1, h - 2)
-    oct2 = rng.integers(0, 8, n2).astype(np.int32)
-    oct2[dst] = np.where(rng.random(ncl) < 0.7, oct2[src], np.clip(oct2[src] - 1, 0, 7))
-    depth2 = rng.uniform(4, 70, n2)
-    mbf = 386.1448
-    uright2 = np.where(rng.random(n2) < 0.6, xy2[:, 0] - mbf / depth2, -1).astype(np.float32)
-    blocked2 = (rng.random(n2) < 0.3).astype(np.uint8)          # already tracked by the motion model
-    target = rng.integers(0, n2, n1)
-    target[: n1 // 5] = target[n1 // 5: 2 * (n1 // 5)]
-    aimed = rng.random(n1) < 0.8
-    uv = xy2[target] + rng.normal(0, 1.0, (n1, 2)).astype(np.float32)
-    uv[~aimed] = np.stack([rng.uniform(0, w, (~aimed).sum()), rng.uniform(0, h, (~aimed).sum())], 1)
-    xr = (uv[:, 0] - mbf / depth2[target] + rng.normal(0, 1.5, n1)).astype(np.float32)
-    proj = np.concatenate([uv, xr[:, None]], 1).astype(np.float32)
-    level = np.clip(oct2[target] + rng.integers(0, 2, n1), 0, 7).astype(np.int32)   # window accepts level-1 .. level
-    flips = rng.random((n1, 256)) < 0.04
-    mp_desc = desc2[target] ^ np.packbits(flips, axis=1, bitorder="little")
-    mp_desc[~aimed] = synth.descriptors(int((~aimed).sum()), seed + 1)
-    gw, gh = np.float32(w), np.float32(h)
-    grid = np.array([0, 0, gw, gh, np.float32(64) / gw, np.float32(48) / gh], np.float32)
-    return dict(valid1=(rng.random(n1) < 0.85).astype(np.uint8), proj1=proj, level1=level,
-                view_cos1=np.where(rng.random(n1) < 0.5, 0.9995, 0.9).astype(np.float32), mp_desc1=mp_desc,
-                mp_observed1=(rng.random(n1) < 0.9).astype(np.uint8), kp2_xy=xy2, kp2_octave=oct2, uright2=uright2, desc2=desc2,
-                blocked2=blocked2, grid=grid, scale_factors=(1.2 ** np.arange(8)).astype(np.float32))
-
-
 def check_search_local_points(lib, seed=41, th=1.0, nnratio=0.8, n1=3000, n2=2000):
     case = make_local_points_case(n1, n2, seed)
     mt = F.ORBmatcher(nnratio, True, lib=lib)
