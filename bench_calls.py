@@ -58,11 +58,16 @@ def _ref_stats(fn, n=REF_CALLS):
     return out, {"median_us": s["median_us"], "min_us": s["min_us"], "calls": n}
 
 
-def _entry(gpu, kern, kern_total, ref, parity, **more):
+def _entry(gpu, kern, kern_total, ref, parity, resident=None, **more):
     e = {"gpu_call": gpu, "kernels_us": kern, "kernels_total_us": kern_total, "parity": parity}
+    if resident is not None:
+        # the same call with the frame(s) resident on the device (rgbl_device_frame): their descriptors / keypoints are not uploaded
+        e["gpu_call_resident"] = resident
     if ref is not None:
         e["cpu_reference"] = ref
         e["gpu_over_cpu_time"] = round(gpu["median_us"] / ref["median_us"], 3) if ref["median_us"] else None
+        if resident is not None and ref["median_us"]:
+            e["gpu_resident_over_cpu_time"] = round(resident["median_us"] / ref["median_us"], 3)
     e.update(more)
     return e
 
@@ -80,8 +85,10 @@ def real_frames(lib, n=2, seq=7, nfeatures=2000, ini=12, mn=7, w=None, h=None):
     for i in range(n):
         kps, desc, _ = ex(sq.frame(i))
         dm.CalculateDepthFromPcd(kps, kps, synth.lidar_scan(seq + i), w, h)
+        # the frame's resident copy: straight from the extractor's and the depth module's device results (no PCIe)
+        dev = F.DeviceFrame(len(kps) + 64, lib=lib).capture(ex, len(kps), dm)
         out.append(dict(xy=np.stack([kps["x"], kps["y"]], 1).astype(np.float32), desc=desc.copy(), octave=kps["octave"].astype(np.int32),
-                        angle=kps["angle"].astype(np.float32), uright=dm.mvuRight.copy()))
+                        angle=kps["angle"].astype(np.float32), uright=dm.mvuRight.copy(), resident=dev))
     dm.close()
     ex.close()
     return out
@@ -114,8 +121,17 @@ def triangulation_leg(lib, sizes=(2000, 8000)):
         ok = bool(nm == onm and np.array_equal(m12, om) and (ref is None or (rnm == nm and np.array_equal(rm, m12))))
         gpu = _time_call(call)
         kern, ktot = _kernel_us(m, call)
+        # both key frames resident (descriptors, keypoints, uRight, FeatureVector): only the map-point masks and the node pairs go up
+        d1 = F.DeviceFrame(n, lib=lib).upload(kf1["desc"], kf1["xy"], kf1["octave"], kf1["uright"]).set_feature_vector(kf1["node_off"], kf1["node_feat"])
+        d2 = F.DeviceFrame(n, lib=lib).upload(kf2["desc"], kf2["xy"], kf2["octave"], kf2["uright"]).set_feature_vector(kf2["node_off"], kf2["node_feat"])
+        rcall = m.prepare_SearchForTriangulation(dict(kf1, device=d1), dict(kf2, device=d2), Fm, ep, sf, s2, False, False)
+        _, rnm2, rm12 = rcall()
+        ok = ok and rnm2 == nm and np.array_equal(rm12, om)
+        resident = _time_call(rcall)
+        d1.close()
+        d2.close()
         res["n%d" % n] = _entry(gpu, kern, ktot, ref_stat, "bit-exact vs oracle%s" % (" and the reference's own ORBmatcher.cc" if ref is not None else "") if ok else "MISMATCH",
-                                n1=n, n2=n, pairs=int(nm), shared_nodes=int(len(np.intersect1d(kf1["node_id"], kf2["node_id"]))))
+                                resident=resident, n1=n, n2=n, pairs=int(nm), shared_nodes=int(len(np.intersect1d(kf1["node_id"], kf2["node_id"]))))
     m.close()
     return res
 
@@ -147,7 +163,11 @@ def tracking_leg(lib):
         ok = ok and rnm == nm and np.array_equal(rm, m2)
     gpu = _time_call(call)
     kern, ktot = _kernel_us(mt, call)
-    res["search_by_projection"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", n1=int(len(case["valid1"])),
+    rcall = mt.prepare_SearchByProjection(dict(case, device2=cur["resident"]), 15.0, False)
+    rm2, rnm2 = rcall()
+    ok = ok and rnm2 == nm and np.array_equal(rm2, om)
+    resident = _time_call(rcall)
+    res["search_by_projection"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", resident=resident, n1=int(len(case["valid1"])),
                                          n2=int(len(cur["xy"])), matches=int(nm), ref_lines="ORBmatcher.cc:1676-1887, Tracking.cc:2917-2934")
     mt.close()
     # -- SearchByProjection(F, vpMapPoints, th): Tracking::SearchLocalPoints, ORBmatcher(0.8), th = 1
@@ -165,7 +185,11 @@ def tracking_leg(lib):
         ok = ok and rnm == nm and np.array_equal(rm, m2)
     gpu = _time_call(call)
     kern, ktot = _kernel_us(mt, call)
-    res["search_local_points"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", n1=3000, n2=int(len(cur["xy"])),
+    rcall = mt.prepare_SearchLocalPoints(dict(case, device2=cur["resident"]), 1.0)
+    rm2, rnm2 = rcall()
+    ok = ok and rnm2 == nm and np.array_equal(rm2, om)
+    resident = _time_call(rcall)
+    res["search_local_points"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", resident=resident, n1=3000, n2=int(len(cur["xy"])),
                                         matches=int(nm), ref_lines="ORBmatcher.cc:43-213, Tracking.cc:3370-3450")
     mt.close()
     # -- ORBVocabulary::transform (Frame::ComputeBoW): synthetic ORBvoc-shaped tree, k = 10, L = 5 (ORBvoc.txt: L = 6, absent)
@@ -191,7 +215,11 @@ def tracking_leg(lib):
                                            np.asarray(w).view(np.uint64) if w.dtype == np.float64 else w) for g, w in zip(rgot, got))
             rd.ref_voc_destroy(hv)
     gpu = _time_call(tcall)
-    res["bow_transform"] = _entry(gpu, None, None, ref_stat, "bit-exact" if ok else "MISMATCH", features=int(len(cur["desc"])),
+    rcall = V.prepare_transform_frame(cur["resident"], levelsup)
+    ok = ok and all(np.array_equal(g.view(np.uint64) if g.dtype == np.float64 else g, w.view(np.uint64) if w.dtype == np.float64 else w)
+                    for g, w in zip(rcall(), want))
+    resident = _time_call(rcall)
+    res["bow_transform"] = _entry(gpu, None, None, ref_stat, "bit-exact" if ok else "MISMATCH", resident=resident, features=int(len(cur["desc"])),
                                   vocabulary="synthetic k=10 L=5 (%d nodes), levelsup 3; ORBvoc.txt (k=10 L=6) is not in the image" % varr["n_nodes"],
                                   ref_lines="Frame.cc:828-835, TemplatedVocabulary.h:1127-1255")
     # -- SearchByBoW(pKF, F, vpMapPointMatches): Tracking::TrackReferenceKeyFrame, ORBmatcher(0.7, true)
@@ -199,6 +227,7 @@ def tracking_leg(lib):
 
     def with_fv(f, has_mp):
         _, _, nid, noff, nfeat = V.transform(f["desc"], levelsup)
+        f = {k: v for k, v in f.items() if k != "resident"}
         return dict(f, has_mp=has_mp, node_id=nid.astype(np.int32), node_off=noff.astype(np.int32), node_feat=nfeat.astype(np.int32))
     kf = with_fv(prev, (rng.random(len(prev["xy"])) < 0.7).astype(np.uint8))
     frm = with_fv(cur, np.zeros(len(cur["xy"]), np.uint8))
@@ -213,7 +242,13 @@ def tracking_leg(lib):
         ok = ok and rnm == nm and np.array_equal(rm, m2)
     gpu = _time_call(call)
     kern, ktot = _kernel_us(mt, call)
-    res["search_by_bow"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", n1=int(len(prev["xy"])), n2=int(len(cur["xy"])),
+    prev["resident"].set_feature_vector(kf["node_off"], kf["node_feat"])
+    cur["resident"].set_feature_vector(frm["node_off"], frm["node_feat"])
+    rcall = mt.prepare_SearchByBoW(dict(kf, device=prev["resident"]), dict(frm, device=cur["resident"]))
+    rm2, rnm2 = rcall()
+    ok = ok and rnm2 == nm and np.array_equal(rm2, om)
+    resident = _time_call(rcall)
+    res["search_by_bow"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", resident=resident, n1=int(len(prev["xy"])), n2=int(len(cur["xy"])),
                                   matches=int(nm), nodes=int(len(kf["node_id"])), ref_lines="ORBmatcher.cc:223-425, Tracking.cc:2798-2810")
     mt.close()
     V.close()
@@ -243,6 +278,8 @@ def tracking_leg(lib):
                                    ref_lines="Frame.cc:901-1071")
     exl.close()
     exr.close()
+    for f in fr:
+        f["resident"].close()
     return res
 
 

@@ -421,6 +421,33 @@ int rgbl_hamming_bf_batch_device(rgbl_matcher* h, const uint8_t* d_desc, const i
                                  const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs,
                                  int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist);
 
+/* ---- Frames resident on the device ----------------------------------------------------------------------------------
+ * A Frame / KeyFrame is matched many times (Tracking: SearchByProjection, SearchLocalPoints, SearchByBoW on the same
+ * CurrentFrame; LocalMapping: SearchForTriangulation / Fuse of one key frame against ~10-20 neighbours), and its per-feature
+ * arrays - mDescriptors, mvKeysUn[].pt / .octave, mvuRight (src/Frame.cc:110-125, 302-340; KeyFrame.cc:41-76) - never change
+ * after construction.  An rgbl_device_frame holds them in HBM: filled ONCE, either from host arrays (one page-locked block,
+ * one copy) or straight from the extractor / depth handles that produced them (device to device - the descriptors and
+ * keypoints never cross PCIe a second time), and named by the `device` member of the views below, whose host pointers for
+ * these four arrays are then not read.  Optionally the FeatureVector's CSR arrays as well.  A frame object is filled by one
+ * thread at a time; once filled it may be read by any number of concurrent matcher calls. */
+typedef struct rgbl_device_frame rgbl_device_frame;
+int rgbl_device_frame_create(int device, int capacity /* features */, rgbl_device_frame** out);
+void rgbl_device_frame_destroy(rgbl_device_frame* f);
+/* n <= capacity features from host arrays; uright may be NULL (monocular: all -1).  Synchronous. */
+int rgbl_device_frame_upload(rgbl_device_frame* f, int n, const uint8_t* desc, const float* kp_xy, const int32_t* kp_octave,
+                             const float* uright);
+/* The n keypoints / descriptors frame `frame` of the extractor's LAST rgbl_extract* call left on the device (n = the count
+ * that call returned) and, with a depth handle, the mvuRight of ITS last rgbl_depth_compute* call (else -1).  K / dist
+ * (nullable) = Frame::UndistortKeyPoints (Frame.cc:837-870): mvKeysUn from mvKeys; nothing is computed when dist is NULL or
+ * dist[0] == 0, as upstream.  Enqueued on the extractor's stream behind that extraction; returns without waiting. */
+int rgbl_device_frame_capture(rgbl_device_frame* f, rgbl_extractor* ex, int frame, int n, rgbl_depth* depth, const float K[4],
+                              const float* dist, int n_dist);
+/* mFeatVec as CSR (the node ids stay with the caller: the merge walk of two FeatureVectors is host work).  Synchronous. */
+int rgbl_device_frame_set_feature_vector(rgbl_device_frame* f, int n_nodes, const int32_t* node_off, const int32_t* node_feat);
+int rgbl_device_frame_size(const rgbl_device_frame* f);
+/* test / debug: the resident arrays back to the host (any pointer may be NULL) */
+int rgbl_device_frame_download(rgbl_device_frame* f, uint8_t* desc, float* kp_xy, int32_t* kp_octave, float* uright);
+
 /* int ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse)
  * (ORBmatcher.h:75-76, ORBmatcher.cc:907-1146) on flattened key-frames (mono / stereo pinhole,
  * mpCamera2 == nullptr).  The shim flattens KeyFrame under its mutexes, computes F12 and the epipole
@@ -438,6 +465,9 @@ typedef struct {
   const int32_t* node_id;
   const int32_t* node_off;  /* n_nodes + 1 */
   const int32_t* node_feat; /* feature indices, ascending inside a node */
+  /* nullable: the frame's resident copy - desc, kp_xy, kp_octave, uright above are then not read (and node_off / node_feat
+   * only by the host-side passes, when the frame holds its FeatureVector: n_nodes must equal what was set) */
+  const rgbl_device_frame* device;
 } rgbl_keyframe_view;
 
 typedef struct {
@@ -502,6 +532,7 @@ typedef struct {
   float th;
   int mono;                    /* bMono */
   int check_orientation;       /* mbCheckOrientation */
+  const rgbl_device_frame* device2; /* nullable: CurrentFrame resident on the device - kp2_xy, kp2_octave, uright2, desc2 are then not read */
 } rgbl_projection_input;
 /* Host pointers, synchronous.  match2 has n2 entries: the index of the LastFrame feature whose map point the call leaves
  * in CurrentFrame.mvpMapPoints[i2], or -1.  *out_nmatches = return value of the reference function. */
@@ -539,6 +570,7 @@ typedef struct {
   float th;
   int orb_dist;                /* ORBdist, 0..255 */
   int check_orientation;       /* mbCheckOrientation */
+  const rgbl_device_frame* device2; /* nullable: CurrentFrame resident on the device - kp2_xy, kp2_octave, uright2, desc2 are then not read */
 } rgbl_keyframe_projection_input;
 /* Host pointers, synchronous.  match2 (n2 entries): index of the key-frame feature whose map point the call stores in
  * CurrentFrame.mvpMapPoints[i2], or -1 (entry left as it was).  *out_nmatches = return value of the reference function. */
@@ -569,6 +601,7 @@ typedef struct {
   int proj_form;               /* 0: Pinhole::project (fx x / z + cx) as in Fuse; 1: invz = 1.0 / z (double), fx (x invz) + cx as in
                                   SearchBySim3; 2 (rgbl_search_by_projection_sim3 only): invz = 1 / z in float */
   int max_dist;                /* TH_LOW (Fuse) / TH_HIGH (SearchBySim3) */
+  const rgbl_device_frame* device2; /* nullable: pKF resident on the device - kp2_xy, kp2_octave, uright2, desc2 are then not read */
 } rgbl_project_search_input;
 /* Host pointers, synchronous.  best_idx[i] = key-frame feature with the smallest distance (<= max_dist) or -1; best_dist nullable. */
 int rgbl_project_search(rgbl_matcher* h, const rgbl_project_search_input* in, int32_t* best_idx, int32_t* best_dist);
@@ -615,6 +648,7 @@ typedef struct {
   const float* inv_level_sigma2;  /* pKF->mvInvLevelSigma2 */
   int n_levels;
   float th;
+  const rgbl_device_frame* device2; /* nullable: pKF resident on the device - kp2_xy, kp2_octave, uright2, desc2 are then not read */
 } rgbl_fuse_input;
 /* Host pointers, synchronous.  best_idx[i] = the key-frame feature point i would be fused with (bestDist <= TH_LOW), or -1;
  * best_dist (nullable) = bestDist, 256 when the point had no candidate. */
@@ -639,6 +673,7 @@ typedef struct {
   int n_levels;
   float th;
   float nnratio;               /* mfNNratio */
+  const rgbl_device_frame* device2; /* nullable: F resident on the device - kp2_xy, kp2_octave, uright2, desc2 are then not read */
 } rgbl_local_points_input;
 /* Host pointers, synchronous.  match2 (n2 entries): index of the map point the call stores in F.mvpMapPoints[i2], or -1
  * (entry left as it was).  *out_nmatches = return value of the reference function. */
@@ -691,6 +726,10 @@ int rgbl_vocabulary_info(const rgbl_vocabulary* v, int* k, int* L, int* n_nodes,
 int rgbl_bow_transform(rgbl_vocabulary* v, const uint8_t* desc, int n, int levelsup, uint32_t* word_id, double* word_val,
                        int cap_words, int* n_words, uint32_t* node_id, int32_t* node_off, uint32_t* node_feat, int cap_nodes,
                        int* n_nodes);
+/* The same on a frame whose descriptors are resident (rgbl_device_frame): nothing is uploaded. */
+int rgbl_bow_transform_frame(rgbl_vocabulary* v, const rgbl_device_frame* frame, int levelsup, uint32_t* word_id, double* word_val,
+                             int cap_words, int* n_words, uint32_t* node_id, int32_t* node_off, uint32_t* node_feat, int cap_nodes,
+                             int* n_nodes);
 /* Device-resident batch, descent only: the descriptors of rgbl_extract_batch_device() (frame b at d_desc + b*cap*32, d_n
  * counts) -> per feature word id, word weight, node id at level L - levelsup.  Enqueued on hip_stream (NULL: own stream). */
 int rgbl_bow_descend_batch_device(rgbl_vocabulary* v, void* hip_stream, const uint8_t* d_desc, const int32_t* d_n, int batch,

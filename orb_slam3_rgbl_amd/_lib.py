@@ -44,7 +44,7 @@ class KeyframeView(C.Structure):
     _fields_ = [("n", C.c_int), ("desc", C.c_void_p), ("kp_xy", C.c_void_p), ("kp_octave", C.c_void_p),
                 ("kp_angle", C.c_void_p), ("uright", C.c_void_p), ("has_mappoint", C.c_void_p),
                 ("n_nodes", C.c_int), ("node_id", C.c_void_p), ("node_off", C.c_void_p),
-                ("node_feat", C.c_void_p)]
+                ("node_feat", C.c_void_p), ("device", C.c_void_p)]
 
 
 class TriangulationParams(C.Structure):
@@ -61,7 +61,8 @@ class ProjectionInput(C.Structure):
                 ("uright2", C.c_void_p), ("desc2", C.c_void_p), ("grid", C.c_float * 6),
                 ("Tcw_q", C.c_float * 4), ("Tcw_t", C.c_float * 3), ("Tlw_q", C.c_float * 4), ("Tlw_t", C.c_float * 3),
                 ("K", C.c_float * 4), ("mb", C.c_float), ("mbf", C.c_float), ("scale_factors", C.c_void_p),
-                ("n_levels", C.c_int), ("th", C.c_float), ("mono", C.c_int), ("check_orientation", C.c_int)]
+                ("n_levels", C.c_int), ("th", C.c_float), ("mono", C.c_int), ("check_orientation", C.c_int),
+                ("device2", C.c_void_p)]
 
 
 class KeyFrameProjectionInput(C.Structure):
@@ -71,7 +72,8 @@ class KeyFrameProjectionInput(C.Structure):
                 ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p), ("kp2_angle", C.c_void_p),
                 ("desc2", C.c_void_p), ("occupied2", C.c_void_p), ("grid", C.c_float * 6),
                 ("Tcw_q", C.c_float * 4), ("Tcw_t", C.c_float * 3), ("K", C.c_float * 4), ("scale_factors", C.c_void_p),
-                ("n_levels", C.c_int), ("th", C.c_float), ("orb_dist", C.c_int), ("check_orientation", C.c_int)]
+                ("n_levels", C.c_int), ("th", C.c_float), ("orb_dist", C.c_int), ("check_orientation", C.c_int),
+                ("device2", C.c_void_p)]
 
 
 class FuseInput(C.Structure):
@@ -80,7 +82,7 @@ class FuseInput(C.Structure):
                 ("level1", C.c_void_p), ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p),
                 ("uright2", C.c_void_p), ("desc2", C.c_void_p), ("grid", C.c_float * 6), ("Tcw_q", C.c_float * 4),
                 ("Tcw_t", C.c_float * 3), ("K", C.c_float * 4), ("bf", C.c_float), ("scale_factors", C.c_void_p),
-                ("inv_level_sigma2", C.c_void_p), ("n_levels", C.c_int), ("th", C.c_float)]
+                ("inv_level_sigma2", C.c_void_p), ("n_levels", C.c_int), ("th", C.c_float), ("device2", C.c_void_p)]
 
 
 class ProjectSearchInput(C.Structure):
@@ -88,7 +90,8 @@ class ProjectSearchInput(C.Structure):
     _fields_ = [("n1", C.c_int), ("valid1", C.c_void_p), ("cam_pos1", C.c_void_p), ("mp_desc1", C.c_void_p),
                 ("level1", C.c_void_p), ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p),
                 ("desc2", C.c_void_p), ("grid", C.c_float * 6), ("K", C.c_float * 4), ("scale_factors", C.c_void_p),
-                ("n_levels", C.c_int), ("th", C.c_float), ("proj_form", C.c_int), ("max_dist", C.c_int)]
+                ("n_levels", C.c_int), ("th", C.c_float), ("proj_form", C.c_int), ("max_dist", C.c_int),
+                ("device2", C.c_void_p)]
 
 
 class LocalPointsInput(C.Structure):
@@ -97,7 +100,7 @@ class LocalPointsInput(C.Structure):
                 ("view_cos1", C.c_void_p), ("mp_desc1", C.c_void_p), ("mp_observed1", C.c_void_p),
                 ("n2", C.c_int), ("kp2_xy", C.c_void_p), ("kp2_octave", C.c_void_p), ("uright2", C.c_void_p),
                 ("desc2", C.c_void_p), ("blocked2", C.c_void_p), ("grid", C.c_float * 6), ("scale_factors", C.c_void_p),
-                ("n_levels", C.c_int), ("th", C.c_float), ("nnratio", C.c_float)]
+                ("n_levels", C.c_int), ("th", C.c_float), ("nnratio", C.c_float), ("device2", C.c_void_p)]
 
 
 class InitializationInput(C.Structure):
@@ -219,6 +222,14 @@ SYMBOLS = {
     "rgbl_bow_transform": (_I, [_V, _V, _I, _I, _V, _V, _I, C.POINTER(_I), _V, _V, _V, _I, C.POINTER(_I)]),
     "rgbl_bow_descend_batch_device": (_I, [_V, _V, _V, _V, _I, _I, _I, _V, _V, _V]),
     "rgbl_fundamental": (None, [_V, _V, _V, _V, _V]),
+    "rgbl_device_frame_create": (_I, [_I, _I, C.POINTER(_V)]),
+    "rgbl_device_frame_destroy": (None, [_V]),
+    "rgbl_device_frame_upload": (_I, [_V, _I, _V, _V, _V, _V]),
+    "rgbl_device_frame_capture": (_I, [_V, _V, _I, _I, _V, _V, _V, _I]),
+    "rgbl_device_frame_set_feature_vector": (_I, [_V, _I, _V, _V]),
+    "rgbl_device_frame_size": (_I, [_V]),
+    "rgbl_device_frame_download": (_I, [_V, _V, _V, _V, _V]),
+    "rgbl_bow_transform_frame": (_I, [_V, _V, _I, _V, _V, _I, C.POINTER(_I), _V, _V, _V, _I, C.POINTER(_I)]),
 }
 
 

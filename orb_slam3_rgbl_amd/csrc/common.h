@@ -107,6 +107,31 @@ struct KernelTimer {
   }
 };
 
+}  // namespace rgbl
+
+// ---- a frame / key frame resident on the device (include/rgbl_frontend.h: rgbl_device_frame_*) -------------------
+// One allocation: descriptors [cap x 32] | xy [cap x 2] | octave [cap] | uright [cap]; the FeatureVector's CSR arrays in a
+// second, grow-only one.  `ready` is recorded behind whatever filled the arrays last (an upload on the frame's own stream, a
+// capture on the extractor's); a matcher call makes its stream wait for it.
+struct rgbl_device_frame {
+  int device = 0, cap = 0, n = 0;
+  uint8_t* block = nullptr;
+  uint8_t* d_desc = nullptr;
+  float* d_xy = nullptr;
+  int32_t* d_oct = nullptr;
+  float* d_ur = nullptr;
+  int32_t* d_fv = nullptr;      // node_off [n_nodes + 1] | node_feat [nf]
+  int fv_cap = 0, n_nodes = -1, nf = 0;
+  uint8_t* h_pin = nullptr;     // page-locked mirror of one upload
+  size_t pin_size = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ready = nullptr;
+};
+// where the last host-pointer call of a handle left its results on the device (extractor.hip / depth.hip; not exported C ABI)
+int rgbl_internal_depth_uright(rgbl_depth* d, const float** d_uright, int* k, hipStream_t* stream);
+
+namespace rgbl {
+
 // ---- device helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }  // round-half-even
 __device__ __forceinline__ unsigned long long rgbl_clock() {

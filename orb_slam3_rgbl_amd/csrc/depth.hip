@@ -433,6 +433,7 @@ struct rgbl_depth {
   float* d_proc = nullptr;
   float* d_cloud = nullptr;
   float *d_kp = nullptr, *d_kpun = nullptr, *d_depth = nullptr, *d_uright = nullptr;  // one block: kp (2 K) | kpun (K) | depth (K) | uright (K)
+  int last_k = 0;              // keypoints of the last host-pointer call: their mvuRight is still in d_uright (rgbl_device_frame_capture)
   float* h_cloud = nullptr;    // page-locked staging of one scan (rgbl_depth_prefetch), allocated on first use
   float* h_kio = nullptr;      // page-locked mirror of that block: the keypoint arrays of the host entry points travel in one request each way
   std::vector<void*> allocs;
@@ -779,6 +780,7 @@ static int depth_compute_host(rgbl_depth* e, const float* cloud, int n, int ld, 
   if (!have_maps) RGBL_TRY(enqueue_maps(e, e->d_cloud, 1, n, n, 0, w, h, nullptr, xyzi, out_raw != nullptr, out_processed != nullptr));
   else if (out_processed && !e->maps.dense) RGBL_TRY(enqueue_upsample(e, 1, w, h));  // a sparse prefetch, and the map is wanted after all
   RGBL_TRY(enqueue_keypoints(e, 1, w, h, e->d_kp, 2, 0, e->d_kpun, 1, 0, nullptr, k, k, e->d_depth, e->d_uright, 0));
+  e->last_k = k;
   if (k > 0 && e->h_kio) {
     RGBL_HIP(hipMemcpyAsync(e->h_kio + 3 * K, e->d_depth, sizeof(float) * (K + k), hipMemcpyDeviceToHost, s));
   } else if (k > 0) {
@@ -917,3 +919,10 @@ int rgbl_depth_profile_samples(rgbl_depth* e, int kernel, float* ms, int cap) {
 }
 
 }  // extern "C"
+
+// not part of the C ABI: where the last host-pointer call left mvuRight (common.h)
+int rgbl_internal_depth_uright(rgbl_depth* d, const float** d_uright, int* k, hipStream_t* stream) {
+  if (!d) { set_error("null depth handle"); return RGBL_ERR_INVALID; }
+  *d_uright = d->d_uright; *k = d->last_k; *stream = d->stream;
+  return RGBL_OK;
+}

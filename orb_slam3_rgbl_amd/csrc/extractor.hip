@@ -407,6 +407,10 @@ int upload_tables(rgbl_extractor* e) {
   return RGBL_OK;
 }
 
+// layout of the host-pointer path's result block (device and page-locked): head | keypoints | descriptors, every part 256-byte aligned
+static inline size_t stage_head(const rgbl_extractor* e) { return (256 + 2 * sizeof(int32_t) * (size_t)e->cfg.max_batch + 255) / 256 * 256; }
+static inline size_t stage_kp_bytes(const rgbl_extractor* e, int batch) { return ((size_t)batch * e->out_cap * sizeof(rgbl_keypoint) + 255) / 256 * 256; }
+
 int alloc_scratch(rgbl_extractor* e) {
   const size_t B = (size_t)e->cfg.max_batch;
   RGBL_TRY(dev_alloc(e, &e->d_img, B * e->img_frame + 256));
@@ -439,7 +443,9 @@ int alloc_scratch(rgbl_extractor* e) {
   // queued five (flag, counts, monoIndex, keypoints, descriptors: three copy kernels and two DMA transfers of ~5 us each at
   // the very end of a frame's critical path).
   {
-    const size_t head = 256 + 2 * sizeof(int32_t) * B, kp_bytes = B * (size_t)e->out_cap * sizeof(rgbl_keypoint);
+    // head and keypoint ranges are rounded up to 256 bytes (in this block and in the page-locked one alike), so that the
+    // descriptors - written with 16-byte and 8-byte stores by k_lapping_permute / k_orient_brief - start 256-byte aligned
+    const size_t head = stage_head(e), kp_bytes = stage_kp_bytes(e, (int)B);
     uint8_t* blk = nullptr;
     RGBL_TRY(dev_alloc(e, &blk, head + kp_bytes + B * (size_t)e->out_cap * 32));
     e->d_stage = blk;
@@ -453,7 +459,7 @@ int alloc_scratch(rgbl_extractor* e) {
   RGBL_TRY(dev_alloc(e, &e->d_tmp_kp, B * (size_t)e->out_cap));
   RGBL_TRY(dev_alloc(e, &e->d_tmp_desc, B * (size_t)e->out_cap * 32));
   // results of up to 4 frames per call come back through one page-locked block (run_staged)
-  e->h_pinned_bytes = 256 + 2 * sizeof(int32_t) * B + std::min<size_t>(B, 4) * (size_t)e->out_cap * (sizeof(rgbl_keypoint) + 32);
+  e->h_pinned_bytes = stage_head(e) + stage_kp_bytes(e, (int)std::min<size_t>(B, 4)) + std::min<size_t>(B, 4) * (size_t)e->out_cap * 32;
   if (hipHostMalloc(reinterpret_cast<void**>(&e->h_pinned), e->h_pinned_bytes, hipHostMallocDefault) != hipSuccess) { e->h_pinned = nullptr; e->h_pinned_bytes = 0; (void)hipGetLastError(); }
   return RGBL_OK;
 }
@@ -918,8 +924,8 @@ static int drop_pending(rgbl_extractor* e) {
 }
 
 static bool staged_one_trip(const rgbl_extractor* e, int batch) {
-  const size_t kp_bytes = (size_t)batch * e->out_cap * sizeof(rgbl_keypoint), desc_bytes = (size_t)batch * e->out_cap * 32;
-  const size_t head = 256 + 2 * sizeof(int32_t) * (size_t)e->cfg.max_batch;
+  const size_t kp_bytes = stage_kp_bytes(e, batch), desc_bytes = (size_t)batch * e->out_cap * 32;
+  const size_t head = stage_head(e);
   return e->h_pinned && head + kp_bytes + desc_bytes <= e->h_pinned_bytes;
 }
 
@@ -929,8 +935,8 @@ static int staged_enqueue(rgbl_extractor* e, int batch, int dev_stride, int lap0
   hipStream_t s = e->stream;
   RGBL_TRY(enqueue_extract_staged(e, batch, dev_stride, lap0, lap1));
   if (!staged_one_trip(e, batch)) return RGBL_OK;
-  const size_t kp_bytes = (size_t)batch * e->out_cap * sizeof(rgbl_keypoint), desc_bytes = (size_t)batch * e->out_cap * 32;
-  const size_t head = 256 + 2 * sizeof(int32_t) * (size_t)e->cfg.max_batch;
+  const size_t kp_bytes = stage_kp_bytes(e, batch), desc_bytes = (size_t)batch * e->out_cap * 32;
+  const size_t head = stage_head(e);
   int32_t* p_err = reinterpret_cast<int32_t*>(e->h_pinned);
   int32_t* p_n = reinterpret_cast<int32_t*>(e->h_pinned + 256);
   int32_t* p_mono = p_n + e->cfg.max_batch;
@@ -957,8 +963,8 @@ static int staged_finish(rgbl_extractor* e, int batch, int lap1, rgbl_keypoint* 
                          int* out_mono) {
   hipStream_t s = e->stream;
   if (staged_one_trip(e, batch)) {
-    const size_t kp_bytes = (size_t)batch * e->out_cap * sizeof(rgbl_keypoint);
-    const size_t head = 256 + 2 * sizeof(int32_t) * (size_t)e->cfg.max_batch;
+    const size_t kp_bytes = stage_kp_bytes(e, batch);
+    const size_t head = stage_head(e);
     int32_t* p_err = reinterpret_cast<int32_t*>(e->h_pinned);
     int32_t* p_n = reinterpret_cast<int32_t*>(e->h_pinned + 256);
     int32_t* p_mono = p_n + e->cfg.max_batch;
@@ -1140,17 +1146,56 @@ int rgbl_undistort_keypoints_batch_device(rgbl_extractor* e, const rgbl_keypoint
   return RGBL_OK;
 }
 
+// Frame / KeyFrame arrays straight from the handles that produced them (include/rgbl_frontend.h: rgbl_device_frame_capture):
+// mvKeysUn[].pt (= mvKeys[].pt, or cv::undistortPoints of it), .octave, mDescriptors, mvuRight - device to device.
+int rgbl_device_frame_capture(rgbl_device_frame* f, rgbl_extractor* e, int frame, int n, rgbl_depth* depth, const float K[4],
+                              const float* dist, int n_dist) {
+  if (!f || !e || frame < 0 || frame >= e->cfg.max_batch || n < 0 || n > f->cap || n > e->out_cap) {
+    set_error("device frame capture: invalid argument / more keypoints than the frame holds");
+    return RGBL_ERR_INVALID;
+  }
+  if (f->device != e->device) { set_error("device frame and extractor live on different devices"); return RGBL_ERR_INVALID; }
+  const float* d_ur = nullptr;
+  hipStream_t ds = nullptr;
+  if (depth) {
+    int k = 0;
+    RGBL_TRY(rgbl_internal_depth_uright(depth, &d_ur, &k, &ds));
+    if (k != n) { set_error("device frame capture: the depth handle's last call had %d keypoints, the frame %d", k, n); return RGBL_ERR_INVALID; }
+  }
+  const bool undist = K && dist && n_dist > 0 && dist[0] != 0.0f;   // Frame.cc:839: nothing to do without distortion
+  UndistortParams U;
+  if (undist) RGBL_TRY(undistort_params(K, dist, n_dist, &U));
+  RGBL_HIP(hipSetDevice(e->device));
+  hipStream_t s = e->stream;
+  RGBL_HIP(hipStreamWaitEvent(s, f->ready, 0));          // an upload of the frame's own still in flight
+  if (ds && ds != s) RGBL_TRY(rgbl_stream_wait(s, ds));  // mvuRight is written on the depth handle's stream
+  f->n = n;
+  if (n > 0) {
+    const rgbl_keypoint* kp = e->d_out_kp + (size_t)frame * e->out_cap;
+    hipLaunchKernelGGL(k_frame_capture, dim3((n + 255) / 256), dim3(256), 0, s, kp, e->d_out_desc + (size_t)frame * e->out_cap * 32, n, d_ur,
+                       undist ? 0 : 1, f->d_xy, f->d_oct, f->d_ur, f->d_desc);
+    if (undist)
+      hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256, 1), dim3(256), 0, s, U, reinterpret_cast<const float*>(kp), 7, (size_t)0,
+                         (const int32_t*)nullptr, n, f->d_xy, 2, (size_t)0);
+    RGBL_HIP(hipGetLastError());
+  }
+  RGBL_HIP(hipEventRecord(f->ready, s));
+  return RGBL_OK;
+}
+
 int rgbl_undistort_points(rgbl_extractor* e, const float* xy, int n, const float K[4], const float* dist, int n_dist, float* out_xy) {
   if (!e || n < 0 || (n > 0 && (!xy || !out_xy))) { set_error("null argument"); return RGBL_ERR_INVALID; }
   UndistortParams U;
   RGBL_TRY(undistort_params(K, dist, n_dist, &U));
   if (n == 0) return RGBL_OK;
-  const size_t room = (size_t)e->cfg.max_batch * e->out_cap * sizeof(rgbl_keypoint);  // staging: the two keypoint buffers
+  // staging: the two scratch buffers of the lapping-area pass (the result buffers stay what the last extraction left in them -
+  // rgbl_device_frame_capture reads them)
+  const size_t room = (size_t)e->cfg.max_batch * e->out_cap * sizeof(rgbl_keypoint);
   if ((size_t)n * 2 * sizeof(float) > room) { set_error("undistort: at most %zu points per call with this handle", room / 8); return RGBL_ERR_CAPACITY; }
   RGBL_HIP(hipSetDevice(e->device));
   hipStream_t s = e->stream;
   float* d_in = reinterpret_cast<float*>(e->d_tmp_kp);
-  float* d_out = reinterpret_cast<float*>(e->d_out_kp);
+  float* d_out = reinterpret_cast<float*>(e->d_tmp_desc);
   RGBL_HIP(hipMemcpyAsync(d_in, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256, 1), dim3(256), 0, s, U, d_in, 2, (size_t)0, (const int32_t*)nullptr, n, d_out, 2, (size_t)0);
   RGBL_HIP(hipGetLastError());

@@ -2227,6 +2227,23 @@ __host__ __device__ __forceinline__ void undistort_point(const UndistortParams& 
   *oy = (float)(yy * ww);
 }
 
+// rgbl_device_frame_capture: a frame's cv::KeyPoint records + descriptors + mvuRight as the structure-of-arrays the matcher
+// kernels read (xy, octave, uright, descriptors).  One work-item per keypoint, the descriptor as two 16-byte words.
+__global__ __launch_bounds__(256) void k_frame_capture(const rgbl_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc, int n,
+                                                       const float* __restrict__ uright, int write_xy, float* __restrict__ xy,
+                                                       int32_t* __restrict__ oct, float* __restrict__ ur, uint8_t* __restrict__ out_desc) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  const rgbl_keypoint k = kp[i];
+  if (write_xy) { xy[2 * i] = k.x; xy[2 * i + 1] = k.y; }
+  oct[i] = k.octave;
+  ur[i] = uright ? uright[i] : -1.f;
+  const uint4* src = reinterpret_cast<const uint4*>(desc + (size_t)i * 32);
+  uint4* dst = reinterpret_cast<uint4*>(out_desc + (size_t)i * 32);
+  dst[0] = src[0];
+  dst[1] = src[1];
+}
+
 // in / out: strided (x, y) float pairs (stride in floats: 2 for plain arrays, 7 for rgbl_keypoint records); grid = (ceil(cap/256), B)
 __global__ __launch_bounds__(256) void k_undistort(UndistortParams U, const float* __restrict__ in, int in_stride, size_t in_frame,
                                                    const int32_t* __restrict__ n_per_frame, int n_fixed, float* __restrict__ out,

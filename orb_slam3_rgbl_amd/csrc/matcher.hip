@@ -1283,13 +1283,70 @@ struct Arena {
   }
 };
 inline size_t pad256(size_t b) { return (b + 255) / 256 * 256 + 256; }
-template <class E>
-int upload(Arena& A, hipStream_t s, const E** dst, const E* src, size_t count) {
-  E* p = A.take<E>(count);
-  *dst = p;
-  RGBL_HIP(hipMemcpyAsync(p, src, count * sizeof(E), hipMemcpyHostToDevice, s));
+int ensure_pin(rgbl_matcher* m, size_t bytes) {
+  if (bytes <= m->pin_size) return RGBL_OK;
+  if (m->h_pin) { (void)hipHostFree(m->h_pin); m->h_pin = nullptr; m->pin_size = 0; }
+  const size_t sz = std::max(bytes, (size_t)1 << 20);
+  RGBL_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), sz, hipHostMallocDefault));
+  m->pin_size = sz;
   return RGBL_OK;
 }
+// One call of a host-pointer entry point.  The device arena and its page-locked mirror share ONE layout: what the call
+// uploads is copied into the mirror at the offsets its device copies have and goes up with ONE hipMemcpyAsync (round 5
+// queued one per array, 8 - 17 per call, from pageable memory); the result arrays are taken back to back and come back
+// with one.  Arrays of a frame that is resident on the device (rgbl_device_frame) are not staged at all.
+struct HostCall {
+  rgbl_matcher* m = nullptr;
+  hipStream_t s = nullptr;
+  Arena A{nullptr};
+  size_t up_end = 0, res_begin = ~(size_t)0, res_end = 0;
+  int begin(rgbl_matcher* mm, size_t need) {
+    m = mm; s = mm->stream;
+    RGBL_TRY(ensure_arena(m, need));
+    RGBL_TRY(ensure_pin(m, need));
+    A = Arena{m->d_buf};
+    return RGBL_OK;
+  }
+  size_t off_of(const void* d) const { return (size_t)(reinterpret_cast<const uint8_t*>(d) - m->d_buf); }
+  template <class E> int put(const E** dst, const E* src, size_t count) {
+    E* p = A.take<E>(count);
+    *dst = p;
+    if (count) memcpy(m->h_pin + off_of(p), src, count * sizeof(E));
+    up_end = A.off;
+    return RGBL_OK;
+  }
+  template <class E> E* put_fill(size_t count, int byte) {   // an array the device starts from (e.g. all -1) travels with the upload
+    E* p = A.take<E>(count);
+    if (count) memset(m->h_pin + off_of(p), byte, count * sizeof(E));
+    up_end = A.off;
+    return p;
+  }
+  int upload() {
+    if (up_end) RGBL_HIP(hipMemcpyAsync(m->d_buf, m->h_pin, up_end, hipMemcpyHostToDevice, s));
+    return RGBL_OK;
+  }
+  template <class E> E* stage(size_t count) { E* p = A.take<E>(count); up_end = A.off; return p; }   // the caller fills mirror(p)
+  template <class E> E* mirror(E* d) { return reinterpret_cast<E*>(m->h_pin + off_of(d)); }
+  template <class E> E* scratch(size_t count) { return A.take<E>(count); }
+  template <class E> void mark_result(E* p, size_t count) {
+    res_begin = std::min(res_begin, off_of(p));
+    res_end = std::max(res_end, off_of(p) + count * sizeof(E));
+  }
+  template <class E> E* result(size_t count) { E* p = A.take<E>(count); mark_result(p, count); return p; }
+  int fetch() {   // the call's only wait
+    if (res_end > res_begin) RGBL_HIP(hipMemcpyAsync(m->h_pin + res_begin, m->d_buf + res_begin, res_end - res_begin, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipStreamSynchronize(s));
+    m->timer.collect();
+    return RGBL_OK;
+  }
+  template <class E> const E* host(const E* d) const { return reinterpret_cast<const E*>(m->h_pin + off_of(d)); }
+  // a frame's resident arrays: the stream waits for whatever filled them last
+  int use(const rgbl_device_frame* f, int n) {
+    if (f->device != m->device || f->n != n) { set_error("device frame: %d features on device %d, the call says %d on device %d", f->n, f->device, n, m->device); return RGBL_ERR_INVALID; }
+    RGBL_HIP(hipStreamWaitEvent(s, f->ready, 0));
+    return RGBL_OK;
+  }
+};
 }  // namespace
 
 extern "C" {
@@ -1388,6 +1445,113 @@ int rgbl_matcher_pool_size(void) {
   return (int)P.idle.size();
 }
 
+// ---- frames resident on the device (include/rgbl_frontend.h) -----------------------------------------------------------
+int rgbl_device_frame_create(int device, int capacity, rgbl_device_frame** out) {
+  if (!out || capacity < 1 || capacity > 65535) { set_error("device frame: capacity 1 .. 65535"); return RGBL_ERR_INVALID; }
+  *out = nullptr;
+  if (rgbl_device_count() <= device || device < 0) {
+    set_error("no usable HIP device %d (this library has no CPU fallback)", device);
+    return RGBL_ERR_NO_DEVICE;
+  }
+  RGBL_HIP(hipSetDevice(device));
+  rgbl_device_frame* f = new rgbl_device_frame;
+  f->device = device;
+  f->cap = (capacity + 63) / 64 * 64;   // every array starts 256-byte aligned
+  const size_t cap = (size_t)f->cap;
+  if (hipMalloc(&f->block, cap * 48) != hipSuccess || hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&f->ready, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    rgbl_device_frame_destroy(f);
+    set_error("device frame: allocation failed");
+    return RGBL_ERR_HIP;
+  }
+  f->d_desc = f->block;
+  f->d_xy = reinterpret_cast<float*>(f->block + cap * 32);
+  f->d_oct = reinterpret_cast<int32_t*>(f->block + cap * 40);
+  f->d_ur = reinterpret_cast<float*>(f->block + cap * 44);
+  RGBL_HIP(hipEventRecord(f->ready, f->stream));
+  *out = f;
+  return RGBL_OK;
+}
+
+void rgbl_device_frame_destroy(rgbl_device_frame* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->device);
+  if (f->ready) { (void)hipEventSynchronize(f->ready); (void)hipEventDestroy(f->ready); }
+  if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
+  if (f->block) (void)hipFree(f->block);
+  if (f->d_fv) (void)hipFree(f->d_fv);
+  if (f->h_pin) (void)hipHostFree(f->h_pin);
+  delete f;
+}
+
+static int frame_pin(rgbl_device_frame* f, size_t bytes) {
+  if (bytes <= f->pin_size) return RGBL_OK;
+  if (f->h_pin) { (void)hipHostFree(f->h_pin); f->h_pin = nullptr; f->pin_size = 0; }
+  RGBL_HIP(hipHostMalloc(reinterpret_cast<void**>(&f->h_pin), bytes, hipHostMallocDefault));
+  f->pin_size = bytes;
+  return RGBL_OK;
+}
+
+int rgbl_device_frame_upload(rgbl_device_frame* f, int n, const uint8_t* desc, const float* kp_xy, const int32_t* kp_octave,
+                             const float* uright) {
+  if (!f || n < 0 || n > f->cap || (n > 0 && (!desc || !kp_xy || !kp_octave))) { set_error("device frame upload: invalid argument / more features than the capacity"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(f->device));
+  const size_t cap = (size_t)f->cap;
+  RGBL_TRY(frame_pin(f, cap * 48));
+  (void)hipEventSynchronize(f->ready);   // nothing still fills the arrays from elsewhere
+  memcpy(f->h_pin, desc, (size_t)n * 32);
+  memcpy(f->h_pin + cap * 32, kp_xy, (size_t)n * 8);
+  memcpy(f->h_pin + cap * 40, kp_octave, (size_t)n * 4);
+  float* ur = reinterpret_cast<float*>(f->h_pin + cap * 44);
+  if (uright) memcpy(ur, uright, (size_t)n * 4);
+  else for (int i = 0; i < n; ++i) ur[i] = -1.f;
+  // the mirror has the block's layout: one request for all four arrays
+  RGBL_HIP(hipMemcpyAsync(f->block, f->h_pin, cap * 44 + (size_t)n * 4, hipMemcpyHostToDevice, f->stream));
+  RGBL_HIP(hipEventRecord(f->ready, f->stream));
+  RGBL_HIP(hipStreamSynchronize(f->stream));   // the mirror is reused by the next upload; the caller's arrays are free at once anyway
+  f->n = n;
+  return RGBL_OK;
+}
+
+int rgbl_device_frame_set_feature_vector(rgbl_device_frame* f, int n_nodes, const int32_t* node_off, const int32_t* node_feat) {
+  if (!f || n_nodes < 0 || !node_off || node_off[0] != 0) { set_error("device frame: invalid FeatureVector"); return RGBL_ERR_INVALID; }
+  const int nf = node_off[n_nodes];
+  if (nf < 0 || nf > f->cap || (nf > 0 && !node_feat)) { set_error("device frame: FeatureVector with %d entries, capacity %d", nf, f->cap); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(f->device));
+  const int words = n_nodes + 1 + nf;
+  if (words > f->fv_cap) {
+    if (f->d_fv) { RGBL_HIP(hipStreamSynchronize(f->stream)); (void)hipFree(f->d_fv); f->d_fv = nullptr; f->fv_cap = 0; }
+    const int cap = std::max(words, 2 * f->cap + 2);
+    RGBL_HIP(hipMalloc(&f->d_fv, sizeof(int32_t) * (size_t)cap));
+    f->fv_cap = cap;
+  }
+  RGBL_TRY(frame_pin(f, std::max((size_t)f->cap * 48, sizeof(int32_t) * (size_t)words)));
+  (void)hipEventSynchronize(f->ready);
+  int32_t* h = reinterpret_cast<int32_t*>(f->h_pin);
+  memcpy(h, node_off, sizeof(int32_t) * ((size_t)n_nodes + 1));
+  if (nf) memcpy(h + n_nodes + 1, node_feat, sizeof(int32_t) * (size_t)nf);
+  RGBL_HIP(hipMemcpyAsync(f->d_fv, h, sizeof(int32_t) * (size_t)words, hipMemcpyHostToDevice, f->stream));
+  RGBL_HIP(hipEventRecord(f->ready, f->stream));
+  RGBL_HIP(hipStreamSynchronize(f->stream));
+  f->n_nodes = n_nodes; f->nf = nf;
+  return RGBL_OK;
+}
+
+int rgbl_device_frame_size(const rgbl_device_frame* f) { return f ? f->n : 0; }
+
+int rgbl_device_frame_download(rgbl_device_frame* f, uint8_t* desc, float* kp_xy, int32_t* kp_octave, float* uright) {
+  if (!f) { set_error("null frame"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(f->device));
+  RGBL_HIP(hipEventSynchronize(f->ready));
+  const size_t n = (size_t)f->n;
+  if (desc && n) RGBL_HIP(hipMemcpy(desc, f->d_desc, n * 32, hipMemcpyDeviceToHost));
+  if (kp_xy && n) RGBL_HIP(hipMemcpy(kp_xy, f->d_xy, n * 8, hipMemcpyDeviceToHost));
+  if (kp_octave && n) RGBL_HIP(hipMemcpy(kp_octave, f->d_oct, n * 4, hipMemcpyDeviceToHost));
+  if (uright && n) RGBL_HIP(hipMemcpy(uright, f->d_ur, n * 4, hipMemcpyDeviceToHost));
+  return RGBL_OK;
+}
+
 int rgbl_matcher_sync(rgbl_matcher* m) {
   if (!m) { set_error("null handle"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipSetDevice(m->device));
@@ -1481,37 +1645,21 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   int splits = 1;
   if (bf_on_matrix_cores(m) && bf_on_fp4(m) && m->bf_split)
     splits = std::max(1, std::min(std::min(16, stages / 4), 128 / std::max(qblocks, 1)));
-  RGBL_TRY(ensure_arena(m, pad256((size_t)2 * cap * 32) + pad256(8) + 3 * pad256((size_t)na * 4) + pad256((size_t)splits * na * 8)));
-  Arena A{m->d_buf};
-  uint8_t* d_desc = A.take<uint8_t>((size_t)2 * cap * 32);
-  int32_t* d_n = A.take<int32_t>(2);
-  int32_t* d_bi = A.take<int32_t>(na);
-  int32_t* d_bd = A.take<int32_t>(na);
-  int32_t* d_sd = A.take<int32_t>(na);
-  uint32_t* d_partial = A.take<uint32_t>((size_t)splits * na * 2);
-  hipStream_t s = m->stream;
+  HostCall hc;
+  RGBL_TRY(hc.begin(m, pad256((size_t)2 * cap * 32) + pad256(8) + 3 * pad256((size_t)na * 4) + pad256((size_t)splits * na * 8)));
+  hipStream_t s = hc.s;
+  // both descriptor sets and the counts in one block, ONE request up; the three result arrays come back with one
+  uint8_t* d_desc = hc.stage<uint8_t>((size_t)2 * cap * 32);
+  memcpy(hc.mirror(d_desc), desc_a, (size_t)na * 32);
+  if (nb > 0) memcpy(hc.mirror(d_desc) + (size_t)cap * 32, desc_b, (size_t)nb * 32);
   const int32_t counts[2] = {na, nb};
-  // Both descriptor sets and the counts are mirrored in one page-locked block laid out like the arena, so that they go up
-  // with ONE request and the three result arrays come back with one (small scans - a frame against a frame - are all
-  // latency: seven requests from / to pageable memory around a 40 us kernel).  Sets above 1 MB keep the direct copies.
-  const size_t in_bytes = (size_t)(reinterpret_cast<uint8_t*>(d_n) - d_desc) + sizeof(counts);
-  const size_t out_bytes = (size_t)(reinterpret_cast<uint8_t*>(d_sd + na) - reinterpret_cast<uint8_t*>(d_bi));
-  bool pinned = in_bytes + out_bytes <= ((size_t)1 << 20);
-  if (pinned && m->pin_size < in_bytes + out_bytes) {
-    if (m->h_pin) { (void)hipHostFree(m->h_pin); m->h_pin = nullptr; m->pin_size = 0; }
-    if (hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), (size_t)1 << 20, hipHostMallocDefault) == hipSuccess) m->pin_size = (size_t)1 << 20;
-    else { (void)hipGetLastError(); pinned = false; }
-  }
-  if (pinned) {
-    memcpy(m->h_pin, desc_a, (size_t)na * 32);
-    if (nb > 0) memcpy(m->h_pin + (size_t)cap * 32, desc_b, (size_t)nb * 32);
-    memcpy(m->h_pin + (reinterpret_cast<uint8_t*>(d_n) - d_desc), counts, sizeof(counts));
-    RGBL_HIP(hipMemcpyAsync(d_desc, m->h_pin, in_bytes, hipMemcpyHostToDevice, s));
-  } else {
-    RGBL_HIP(hipMemcpyAsync(d_desc, desc_a, (size_t)na * 32, hipMemcpyHostToDevice, s));
-    if (nb > 0) RGBL_HIP(hipMemcpyAsync(d_desc + (size_t)cap * 32, desc_b, (size_t)nb * 32, hipMemcpyHostToDevice, s));
-    RGBL_HIP(hipMemcpyAsync(d_n, counts, sizeof(counts), hipMemcpyHostToDevice, s));
-  }
+  const int32_t* d_n = nullptr;
+  RGBL_TRY(hc.put(&d_n, counts, 2));
+  RGBL_TRY(hc.upload());
+  int32_t* d_bi = hc.result<int32_t>(na);
+  int32_t* d_bd = hc.result<int32_t>(na);
+  int32_t* d_sd = hc.result<int32_t>(na);
+  uint32_t* d_partial = hc.scratch<uint32_t>((size_t)splits * na * 2);
   // pair_a/pair_b == NULL selects the fixed pair (frame 0 -> frame 1)
   if (bf_on_matrix_cores(m)) {
     m->timer.begin(bf_on_fp4(m) ? "k_hamming_fp4" : "k_hamming_mfma", s);
@@ -1530,20 +1678,10 @@ int rgbl_hamming_bf(rgbl_matcher* m, const uint8_t* desc_a, int na, const uint8_
   }
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
-  if (pinned) {
-    uint8_t* h_out = m->h_pin + in_bytes;
-    RGBL_HIP(hipMemcpyAsync(h_out, d_bi, out_bytes, hipMemcpyDeviceToHost, s));
-    RGBL_HIP(hipStreamSynchronize(s));
-    memcpy(best_idx, h_out, sizeof(int32_t) * na);
-    memcpy(best_dist, h_out + (reinterpret_cast<uint8_t*>(d_bd) - reinterpret_cast<uint8_t*>(d_bi)), sizeof(int32_t) * na);
-    if (second_dist) memcpy(second_dist, h_out + (reinterpret_cast<uint8_t*>(d_sd) - reinterpret_cast<uint8_t*>(d_bi)), sizeof(int32_t) * na);
-  } else {
-    RGBL_HIP(hipMemcpyAsync(best_idx, d_bi, sizeof(int32_t) * na, hipMemcpyDeviceToHost, s));
-    RGBL_HIP(hipMemcpyAsync(best_dist, d_bd, sizeof(int32_t) * na, hipMemcpyDeviceToHost, s));
-    if (second_dist) RGBL_HIP(hipMemcpyAsync(second_dist, d_sd, sizeof(int32_t) * na, hipMemcpyDeviceToHost, s));
-    RGBL_HIP(hipStreamSynchronize(s));
-  }
-  m->timer.collect();
+  RGBL_TRY(hc.fetch());
+  memcpy(best_idx, hc.host(d_bi), sizeof(int32_t) * na);
+  memcpy(best_dist, hc.host(d_bd), sizeof(int32_t) * na);
+  if (second_dist) memcpy(second_dist, hc.host(d_sd), sizeof(int32_t) * na);
   return RGBL_OK;
 }
 
@@ -1635,29 +1773,45 @@ int rgbl_search_triangulation(rgbl_matcher* m, const rgbl_keyframe_view* k1, con
                   pad256((size_t)(k1->n_nodes + 1) * 4) + pad256((size_t)nf1 * 4) + pad256((size_t)(k2->n_nodes + 1) * 4) +
                   pad256((size_t)nf2 * 4) + 2 * pad256((size_t)npairs * 4) + 2 * pad256((size_t)prm->n_levels * 4) +
                   pad256((size_t)n1 * 4);
-    RGBL_TRY(ensure_arena(m, need));
-    Arena A{m->d_buf};
-    hipStream_t s = m->stream;
+    HostCall hc;
+    RGBL_TRY(hc.begin(m, need));
+    hipStream_t s = hc.s;
     TriDev T;
-    RGBL_TRY(upload(A, s, &T.desc1, k1->desc, (size_t)n1 * 32));
-    RGBL_TRY(upload(A, s, &T.desc2, k2->desc, (size_t)n2 * 32));
-    RGBL_TRY(upload(A, s, &T.xy1, k1->kp_xy, (size_t)n1 * 2));
-    RGBL_TRY(upload(A, s, &T.xy2, k2->kp_xy, (size_t)n2 * 2));
-    RGBL_TRY(upload(A, s, &T.oct2, k2->kp_octave, (size_t)n2));
-    RGBL_TRY(upload(A, s, &T.ur1, k1->uright, (size_t)n1));
-    RGBL_TRY(upload(A, s, &T.ur2, k2->uright, (size_t)n2));
-    RGBL_TRY(upload(A, s, &T.mp1, k1->has_mappoint, (size_t)n1));
-    RGBL_TRY(upload(A, s, &T.mp2, k2->has_mappoint, (size_t)n2));
-    RGBL_TRY(upload(A, s, &T.off1, k1->node_off, (size_t)k1->n_nodes + 1));
-    RGBL_TRY(upload(A, s, &T.feat1, k1->node_feat, (size_t)nf1));
-    RGBL_TRY(upload(A, s, &T.off2, k2->node_off, (size_t)k2->n_nodes + 1));
-    RGBL_TRY(upload(A, s, &T.feat2, k2->node_feat, (size_t)nf2));
-    RGBL_TRY(upload(A, s, &T.pair_n1, pa.data(), (size_t)npairs));
-    RGBL_TRY(upload(A, s, &T.pair_n2, pb.data(), (size_t)npairs));
-    RGBL_TRY(upload(A, s, &T.scale2, prm->scale_factors2, (size_t)prm->n_levels));
-    RGBL_TRY(upload(A, s, &T.sigma2, prm->level_sigma2_2, (size_t)prm->n_levels));
-    T.matches12 = A.take<int32_t>(n1);
-    RGBL_HIP(hipMemsetAsync(T.matches12, 0xff, sizeof(int32_t) * n1, s));
+    const rgbl_keyframe_view* kv[2] = {k1, k2};
+    const uint8_t** desc[2] = {&T.desc1, &T.desc2};
+    const float** xy[2] = {&T.xy1, &T.xy2};
+    const float** ur[2] = {&T.ur1, &T.ur2};
+    const int32_t **off[2] = {&T.off1, &T.off2}, **feat[2] = {&T.feat1, &T.feat2};
+    const int32_t* oct1_unused = nullptr;
+    const int32_t** oct[2] = {&oct1_unused, &T.oct2};
+    for (int k = 0; k < 2; ++k) {
+      const rgbl_keyframe_view* v = kv[k];
+      const int nf = v->node_off[v->n_nodes];
+      if (const rgbl_device_frame* f = v->device) {
+        RGBL_TRY(hc.use(f, v->n));
+        *desc[k] = f->d_desc; *xy[k] = f->d_xy; *oct[k] = f->d_oct; *ur[k] = f->d_ur;
+      } else {
+        RGBL_TRY(hc.put(desc[k], v->desc, (size_t)v->n * 32));
+        RGBL_TRY(hc.put(xy[k], v->kp_xy, (size_t)v->n * 2));
+        if (k == 1) RGBL_TRY(hc.put(oct[k], v->kp_octave, (size_t)v->n));
+        RGBL_TRY(hc.put(ur[k], v->uright, (size_t)v->n));
+      }
+      if (v->device && v->device->n_nodes == v->n_nodes && v->device->nf == nf) {
+        *off[k] = v->device->d_fv; *feat[k] = v->device->d_fv + v->n_nodes + 1;
+      } else {
+        RGBL_TRY(hc.put(off[k], v->node_off, (size_t)v->n_nodes + 1));
+        RGBL_TRY(hc.put(feat[k], v->node_feat, (size_t)nf));
+      }
+    }
+    RGBL_TRY(hc.put(&T.mp1, k1->has_mappoint, (size_t)n1));
+    RGBL_TRY(hc.put(&T.mp2, k2->has_mappoint, (size_t)n2));
+    RGBL_TRY(hc.put(&T.pair_n1, pa.data(), (size_t)npairs));
+    RGBL_TRY(hc.put(&T.pair_n2, pb.data(), (size_t)npairs));
+    RGBL_TRY(hc.put(&T.scale2, prm->scale_factors2, (size_t)prm->n_levels));
+    RGBL_TRY(hc.put(&T.sigma2, prm->level_sigma2_2, (size_t)prm->n_levels));
+    T.matches12 = hc.put_fill<int32_t>(n1, 0xff);   // all -1: travels with the upload
+    hc.mark_result(T.matches12, n1);
+    RGBL_TRY(hc.upload());
     memcpy(T.F, prm->F12, sizeof(T.F));
     T.ep[0] = prm->epipole[0];
     T.ep[1] = prm->epipole[1];
@@ -1667,9 +1821,8 @@ int rgbl_search_triangulation(rgbl_matcher* m, const rgbl_keyframe_view* k1, con
     hipLaunchKernelGGL(k_search_triangulation, dim3(npairs), dim3(256), 0, s, T);
     m->timer.end(s);
     RGBL_HIP(hipGetLastError());
-    RGBL_HIP(hipMemcpyAsync(matches12, T.matches12, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
-    RGBL_HIP(hipStreamSynchronize(s));
-    m->timer.collect();
+    RGBL_TRY(hc.fetch());
+    memcpy(matches12, hc.host(T.matches12), sizeof(int32_t) * n1);
   }
   int nmatches = 0;
   for (int i = 0; i < n1; ++i) nmatches += matches12[i] >= 0;
@@ -1730,8 +1883,26 @@ struct ProjHost {
   const float *grid, *Tcw_q, *Tcw_t, *K;
   float mbf, th;
   int forward, backward, skip_behind, max_dist, check_orientation;
+  int want_ur2;   // with dev2: the overload tests the stereo coordinate (ur2 is then the resident array)
   int sim3_mode;  // 0, or 1 / 2 = the projection form of the SearchByProjection(pKF, Scw, ...) overloads (wpos1 = camera-frame points)
+  const rgbl_device_frame* dev2;  // nullable: the second frame's xy / octave / uright / descriptors resident on the device
 };
+
+// the second frame's per-feature arrays: from the resident copy, or staged with the rest of the call's upload
+int put_frame2(HostCall& hc, ProjDev& P, const rgbl_device_frame* dev2, int n2, const float* xy2, const int32_t* oct2, const float* ur2,
+               bool want_ur, const uint8_t* desc2) {
+  if (dev2) {
+    RGBL_TRY(hc.use(dev2, n2));
+    P.xy2 = dev2->d_xy; P.oct2 = dev2->d_oct; P.desc2 = dev2->d_desc;
+    if (want_ur) P.ur2 = dev2->d_ur;
+    return RGBL_OK;
+  }
+  RGBL_TRY(hc.put(&P.xy2, xy2, (size_t)n2 * 2));
+  RGBL_TRY(hc.put(&P.oct2, oct2, (size_t)n2));
+  if (want_ur) RGBL_TRY(hc.put(&P.ur2, ur2, (size_t)n2));
+  RGBL_TRY(hc.put(&P.desc2, desc2, (size_t)n2 * 32));
+  return RGBL_OK;
+}
 
 int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* out_nmatches) {
   *out_nmatches = 0;
@@ -1746,35 +1917,31 @@ int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* o
                 pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 3 + pad256(n2) +
                 pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 + pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) +
                 pad256((size_t)(kGridCells + 1) * 4);
-  RGBL_TRY(ensure_arena(m, need));
-  Arena A{m->d_buf};
-  hipStream_t s = m->stream;
+  HostCall hc;
+  RGBL_TRY(hc.begin(m, need));
+  hipStream_t s = hc.s;
   ProjDev P;
   P.n1 = n1; P.n2 = n2;
   P.proj1 = nullptr; P.level1 = nullptr; P.viewcos1 = nullptr; P.blocked2 = nullptr; P.ur2 = nullptr; P.nnratio = 0.f;
-  std::vector<uint8_t> all_block;
-  const uint8_t* obs1 = in.obs1;
-  if (!obs1) { all_block.assign(n1, 1); obs1 = all_block.data(); }
-  RGBL_TRY(upload(A, s, &P.valid1, in.valid1, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.obs1, obs1, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.wpos1, in.wpos1, (size_t)n1 * 3));
-  RGBL_TRY(upload(A, s, &P.mpdesc1, in.mpdesc1, (size_t)n1 * 32));
-  RGBL_TRY(upload(A, s, &P.oct1, in.oct1, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.xy2, in.xy2, (size_t)n2 * 2));
-  RGBL_TRY(upload(A, s, &P.oct2, in.oct2, (size_t)n2));
-  if (in.ur2) RGBL_TRY(upload(A, s, &P.ur2, in.ur2, (size_t)n2));
-  if (in.blocked2) RGBL_TRY(upload(A, s, &P.blocked2, in.blocked2, (size_t)n2));
-  RGBL_TRY(upload(A, s, &P.desc2, in.desc2, (size_t)n2 * 32));
-  P.cell_start = A.take<uint32_t>(kGridCells + 1);
-  P.cell_items = A.take<uint16_t>(n2);
-  P.taken_by = A.take<int32_t>(n2);
-  P.min_unres = A.take<int32_t>(n2);
-  P.win = A.take<float4>(n1);
-  P.rng = A.take<int4>(n1);
-  P.cand = A.take<unsigned long long>((size_t)n1 * kProjCand);
-  P.ncand = A.take<uint8_t>(n1);
-  P.state = A.take<uint8_t>(n1);
-  P.choice = A.take<int32_t>(n1);
+  RGBL_TRY(hc.put(&P.valid1, in.valid1, (size_t)n1));
+  if (in.obs1) RGBL_TRY(hc.put(&P.obs1, in.obs1, (size_t)n1));
+  else P.obs1 = hc.put_fill<uint8_t>(n1, 1);   // every point blocks
+  RGBL_TRY(hc.put(&P.wpos1, in.wpos1, (size_t)n1 * 3));
+  RGBL_TRY(hc.put(&P.mpdesc1, in.mpdesc1, (size_t)n1 * 32));
+  RGBL_TRY(hc.put(&P.oct1, in.oct1, (size_t)n1));
+  RGBL_TRY(put_frame2(hc, P, in.dev2, n2, in.xy2, in.oct2, in.ur2, in.ur2 != nullptr || (in.dev2 && in.want_ur2), in.desc2));
+  if (in.blocked2) RGBL_TRY(hc.put(&P.blocked2, in.blocked2, (size_t)n2));
+  RGBL_TRY(hc.upload());
+  P.choice = hc.result<int32_t>(n1);
+  P.cell_start = hc.scratch<uint32_t>(kGridCells + 1);
+  P.cell_items = hc.scratch<uint16_t>(n2);
+  P.taken_by = hc.scratch<int32_t>(n2);
+  P.min_unres = hc.scratch<int32_t>(n2);
+  P.win = hc.scratch<float4>(n1);
+  P.rng = hc.scratch<int4>(n1);
+  P.cand = hc.scratch<unsigned long long>((size_t)n1 * kProjCand);
+  P.ncand = hc.scratch<uint8_t>(n1);
+  P.state = hc.scratch<uint8_t>(n1);
   memcpy(P.grid, in.grid, sizeof(P.grid));
   memcpy(P.q, in.Tcw_q, sizeof(P.q));
   memcpy(P.t, in.Tcw_t, sizeof(P.t));
@@ -1795,10 +1962,8 @@ int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* o
   hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(kProjBS), 0, s, P);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
-  std::vector<int32_t> choice(n1);
-  RGBL_HIP(hipMemcpyAsync(choice.data(), P.choice, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipStreamSynchronize(s));
-  m->timer.collect();
+  RGBL_TRY(hc.fetch());
+  const int32_t* choice = hc.host(P.choice);
   // what the loop leaves in CurrentFrame.mvpMapPoints (a later point overwrites an unobserved earlier one), the match
   // count, and the rotation-consistency pass (ORBmatcher.cc:1768-1790, 1860-1884 / 1961-2006)
   int nmatches = 0;
@@ -1857,6 +2022,7 @@ int rgbl_search_by_projection(rgbl_matcher* m, const rgbl_projection_input* in, 
   h.skip_behind = 1;
   h.max_dist = 100;  // TH_HIGH
   h.check_orientation = in->check_orientation;
+  h.dev2 = in->device2; h.want_ur2 = 1;
   return projection_core(m, h, match2, out_nmatches);
 }
 
@@ -1882,6 +2048,7 @@ int rgbl_search_by_projection_keyframe(rgbl_matcher* m, const rgbl_keyframe_proj
   h.skip_behind = 0;
   h.max_dist = in->orb_dist;
   h.check_orientation = in->check_orientation;
+  h.dev2 = in->device2; h.want_ur2 = 0;
   return projection_core(m, h, match2, out_nmatches);
 }
 
@@ -1894,26 +2061,26 @@ int rgbl_distinctive_descriptors(rgbl_matcher* m, const uint8_t* desc, const int
   if (off[0] != 0 || (total > 0 && !desc)) { set_error("offsets start at 0; descriptors missing"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipSetDevice(m->device));
   StreamDrain drain(m->stream);  // error returns included
-  RGBL_TRY(ensure_arena(m, pad256((size_t)total * 32) + pad256((size_t)(n_points + 1) * 4) + pad256((size_t)n_points * 4)));
-  Arena A{m->d_buf};
-  hipStream_t s = m->stream;
+  HostCall hc;
+  RGBL_TRY(hc.begin(m, pad256((size_t)total * 32) + pad256((size_t)(n_points + 1) * 4) + pad256((size_t)n_points * 4)));
+  hipStream_t s = hc.s;
   const uint8_t* d_desc = nullptr;
   const int32_t* d_off = nullptr;
-  if (total > 0) RGBL_TRY(upload(A, s, &d_desc, desc, (size_t)total * 32));
-  RGBL_TRY(upload(A, s, &d_off, off, (size_t)n_points + 1));
-  int32_t* d_best = A.take<int32_t>(n_points);
+  if (total > 0) RGBL_TRY(hc.put(&d_desc, desc, (size_t)total * 32));
+  RGBL_TRY(hc.put(&d_off, off, (size_t)n_points + 1));
+  RGBL_TRY(hc.upload());
+  int32_t* d_best = hc.result<int32_t>(n_points);
   m->timer.begin("k_distinctive", s);
   hipLaunchKernelGGL(k_distinctive, dim3(n_points), dim3(64), 0, s, d_desc, d_off, d_best);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
-  RGBL_HIP(hipMemcpyAsync(best, d_best, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipStreamSynchronize(s));
-  m->timer.collect();
+  RGBL_TRY(hc.fetch());
+  memcpy(best, hc.host(d_best), sizeof(int32_t) * n_points);
   return RGBL_OK;
 }
 
 static int fuse_core(rgbl_matcher* m, const rgbl_fuse_input* in, int cam_frame, int proj_form, int chi2_gate, int max_dist,
-                     int32_t* best_idx, int32_t* best_dist) {
+                     int want_ur2, int32_t* best_idx, int32_t* best_dist) {
   if (!m || !in || !best_idx || in->n1 < 0 || in->n2 < 0 || in->n2 > 65535 || in->n_levels < 1 || in->n_levels > kProjMaxLevels) {
     set_error("invalid argument (the key frame may hold at most 65535 features, %d pyramid levels)", kProjMaxLevels);
     return RGBL_ERR_INVALID;
@@ -1928,23 +2095,21 @@ static int fuse_core(rgbl_matcher* m, const rgbl_fuse_input* in, int cam_frame, 
   size_t need = pad256(n1) + pad256((size_t)n1 * 12) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 8) +
                 pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 2 +
                 pad256((size_t)n1 * 8) + pad256((size_t)(kGridCells + 1) * 4);
-  RGBL_TRY(ensure_arena(m, need));
-  Arena A{m->d_buf};
-  hipStream_t s = m->stream;
+  HostCall hc;
+  RGBL_TRY(hc.begin(m, need));
+  hipStream_t s = hc.s;
   ProjDev P{};
   P.n1 = n1; P.n2 = n2;
-  RGBL_TRY(upload(A, s, &P.valid1, in->valid1, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.wpos1, in->world_pos1, (size_t)n1 * 3));
-  RGBL_TRY(upload(A, s, &P.mpdesc1, in->mp_desc1, (size_t)n1 * 32));
-  RGBL_TRY(upload(A, s, &P.oct1, in->level1, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.xy2, in->kp2_xy, (size_t)n2 * 2));
-  RGBL_TRY(upload(A, s, &P.oct2, in->kp2_octave, (size_t)n2));
-  if (in->uright2) RGBL_TRY(upload(A, s, &P.ur2, in->uright2, (size_t)n2));
-  RGBL_TRY(upload(A, s, &P.desc2, in->desc2, (size_t)n2 * 32));
-  P.cell_start = A.take<uint32_t>(kGridCells + 1);
-  P.cell_items = A.take<uint16_t>(n2);
-  P.taken_by = A.take<int32_t>(n2);  // written by k_proj_grid, not used by the fuse search
-  P.cand = A.take<unsigned long long>(n1);
+  RGBL_TRY(hc.put(&P.valid1, in->valid1, (size_t)n1));
+  RGBL_TRY(hc.put(&P.wpos1, in->world_pos1, (size_t)n1 * 3));
+  RGBL_TRY(hc.put(&P.mpdesc1, in->mp_desc1, (size_t)n1 * 32));
+  RGBL_TRY(hc.put(&P.oct1, in->level1, (size_t)n1));
+  RGBL_TRY(put_frame2(hc, P, in->device2, n2, in->kp2_xy, in->kp2_octave, in->uright2, want_ur2 != 0, in->desc2));
+  RGBL_TRY(hc.upload());
+  P.cand = hc.result<unsigned long long>(n1);
+  P.cell_start = hc.scratch<uint32_t>(kGridCells + 1);
+  P.cell_items = hc.scratch<uint16_t>(n2);
+  P.taken_by = hc.scratch<int32_t>(n2);  // written by k_proj_grid, not used by the fuse search
   memcpy(P.grid, in->grid, sizeof(P.grid));
   memcpy(P.q, in->Tcw_q, sizeof(P.q));
   memcpy(P.t, in->Tcw_t, sizeof(P.t));
@@ -1964,10 +2129,8 @@ static int fuse_core(rgbl_matcher* m, const rgbl_fuse_input* in, int cam_frame, 
   hipLaunchKernelGGL(k_fuse_search, dim3((n1 + 63) / 64), dim3(64), 0, s, P, Fz);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
-  std::vector<unsigned long long> keys(n1);
-  RGBL_HIP(hipMemcpyAsync(keys.data(), P.cand, sizeof(unsigned long long) * n1, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipStreamSynchronize(s));
-  m->timer.collect();
+  RGBL_TRY(hc.fetch());
+  const unsigned long long* keys = hc.host(P.cand);
   for (int i = 0; i < n1; ++i) {
     if (keys[i] == ~0ull) continue;
     const int dist = (int)(keys[i] >> 32);
@@ -2000,11 +2163,12 @@ int rgbl_search_by_projection_sim3(rgbl_matcher* m, const rgbl_project_search_in
   h.max_dist = in->max_dist;
   h.check_orientation = 0;
   h.sim3_mode = in->proj_form == 0 ? 1 : 2;
+  h.dev2 = in->device2; h.want_ur2 = 0;
   return projection_core(m, h, match2, out_nmatches);
 }
 
 int rgbl_fuse_search(rgbl_matcher* m, const rgbl_fuse_input* in, int32_t* best_idx, int32_t* best_dist) {
-  return fuse_core(m, in, 0, 0, 1, 50 /* TH_LOW */, best_idx, best_dist);
+  return fuse_core(m, in, 0, 0, 1, 50 /* TH_LOW */, (in && (in->uright2 || in->device2)) ? 1 : 0, best_idx, best_dist);
 }
 
 // The per-point search shared by ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:1340-1455:
@@ -2026,7 +2190,8 @@ int rgbl_project_search(rgbl_matcher* m, const rgbl_project_search_input* in, in
   f.inv_level_sigma2 = in->scale_factors;  // not read without the chi-square gate
   f.n_levels = in->n_levels;
   f.th = in->th;
-  return fuse_core(m, &f, 1, in->proj_form, 0, in->max_dist, best_idx, best_dist);
+  f.device2 = in->device2;
+  return fuse_core(m, &f, 1, in->proj_form, 0, in->max_dist, 0, best_idx, best_dist);
 }
 
 int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in, int32_t* match2, int* out_nmatches) {
@@ -2047,33 +2212,31 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
                 pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256(n2) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 2 +
                 pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 + pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) +
                 pad256((size_t)(kGridCells + 1) * 4);
-  RGBL_TRY(ensure_arena(m, need));
-  Arena A{m->d_buf};
-  hipStream_t s = m->stream;
+  HostCall hc;
+  RGBL_TRY(hc.begin(m, need));
+  hipStream_t s = hc.s;
   ProjDev P;
   memset(&P, 0, sizeof(P));
   P.n1 = n1; P.n2 = n2;
-  RGBL_TRY(upload(A, s, &P.valid1, in->valid1, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.obs1, in->mp_observed1, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.proj1, in->proj1, (size_t)n1 * 3));
-  RGBL_TRY(upload(A, s, &P.mpdesc1, in->mp_desc1, (size_t)n1 * 32));
-  RGBL_TRY(upload(A, s, &P.level1, in->level1, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.viewcos1, in->view_cos1, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.xy2, in->kp2_xy, (size_t)n2 * 2));
-  RGBL_TRY(upload(A, s, &P.oct2, in->kp2_octave, (size_t)n2));
-  RGBL_TRY(upload(A, s, &P.ur2, in->uright2, (size_t)n2));
-  RGBL_TRY(upload(A, s, &P.desc2, in->desc2, (size_t)n2 * 32));
-  if (in->blocked2) RGBL_TRY(upload(A, s, &P.blocked2, in->blocked2, (size_t)n2));
-  P.cell_start = A.take<uint32_t>(kGridCells + 1);
-  P.cell_items = A.take<uint16_t>(n2);
-  P.taken_by = A.take<int32_t>(n2);
-  P.min_unres = A.take<int32_t>(n2);
-  P.win = A.take<float4>(n1);
-  P.rng = A.take<int4>(n1);
-  P.cand = A.take<unsigned long long>((size_t)n1 * kProjCand);
-  P.ncand = A.take<uint8_t>(n1);
-  P.state = A.take<uint8_t>(n1);
-  P.choice = A.take<int32_t>(n1);
+  RGBL_TRY(hc.put(&P.valid1, in->valid1, (size_t)n1));
+  RGBL_TRY(hc.put(&P.obs1, in->mp_observed1, (size_t)n1));
+  RGBL_TRY(hc.put(&P.proj1, in->proj1, (size_t)n1 * 3));
+  RGBL_TRY(hc.put(&P.mpdesc1, in->mp_desc1, (size_t)n1 * 32));
+  RGBL_TRY(hc.put(&P.level1, in->level1, (size_t)n1));
+  RGBL_TRY(hc.put(&P.viewcos1, in->view_cos1, (size_t)n1));
+  RGBL_TRY(put_frame2(hc, P, in->device2, n2, in->kp2_xy, in->kp2_octave, in->uright2, true, in->desc2));
+  if (in->blocked2) RGBL_TRY(hc.put(&P.blocked2, in->blocked2, (size_t)n2));
+  RGBL_TRY(hc.upload());
+  P.choice = hc.result<int32_t>(n1);
+  P.cell_start = hc.scratch<uint32_t>(kGridCells + 1);
+  P.cell_items = hc.scratch<uint16_t>(n2);
+  P.taken_by = hc.scratch<int32_t>(n2);
+  P.min_unres = hc.scratch<int32_t>(n2);
+  P.win = hc.scratch<float4>(n1);
+  P.rng = hc.scratch<int4>(n1);
+  P.cand = hc.scratch<unsigned long long>((size_t)n1 * kProjCand);
+  P.ncand = hc.scratch<uint8_t>(n1);
+  P.state = hc.scratch<uint8_t>(n1);
   memcpy(P.grid, in->grid, sizeof(P.grid));
   P.th = in->th;
   P.nnratio = in->nnratio;
@@ -2088,10 +2251,8 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
   hipLaunchKernelGGL(k_local_resolve, dim3(1), dim3(kProjBS), 0, s, P);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
-  std::vector<int32_t> choice(n1);
-  RGBL_HIP(hipMemcpyAsync(choice.data(), P.choice, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipStreamSynchronize(s));
-  m->timer.collect();
+  RGBL_TRY(hc.fetch());
+  const int32_t* choice = hc.host(P.choice);
   int nmatches = 0;
   for (int i = 0; i < n1; ++i)
     if (choice[i] >= 0) { match2[choice[i]] = i; ++nmatches; }  // a later point overwrites an unobserved earlier one
@@ -2116,29 +2277,28 @@ int rgbl_search_for_initialization(rgbl_matcher* m, const rgbl_initialization_in
   size_t need = pad256((size_t)n1 * 8) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 8) + pad256((size_t)n2 * 4) +
                 pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 3 + pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 +
                 pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) + pad256((size_t)(kGridCells + 1) * 4);
-  RGBL_TRY(ensure_arena(m, need));
-  Arena A{m->d_buf};
-  hipStream_t s = m->stream;
+  HostCall hc;
+  RGBL_TRY(hc.begin(m, need));
+  hipStream_t s = hc.s;
   ProjDev P;
   memset(&P, 0, sizeof(P));
   P.n1 = n1; P.n2 = n2;
-  RGBL_TRY(upload(A, s, &P.proj1, prev_matched, (size_t)n1 * 2));
-  RGBL_TRY(upload(A, s, &P.mpdesc1, in->desc1, (size_t)n1 * 32));
-  RGBL_TRY(upload(A, s, &P.oct1, in->kp1_octave, (size_t)n1));
-  RGBL_TRY(upload(A, s, &P.xy2, in->kp2_xy, (size_t)n2 * 2));
-  RGBL_TRY(upload(A, s, &P.oct2, in->kp2_octave, (size_t)n2));
-  RGBL_TRY(upload(A, s, &P.desc2, in->desc2, (size_t)n2 * 32));
-  P.cell_start = A.take<uint32_t>(kGridCells + 1);
-  P.cell_items = A.take<uint16_t>(n2);
-  P.taken_by = A.take<int32_t>(n2);
-  P.min_unres = A.take<int32_t>(n2);
-  P.owner = A.take<int32_t>(n2);
-  P.win = A.take<float4>(n1);
-  P.rng = A.take<int4>(n1);
-  P.cand = A.take<unsigned long long>((size_t)n1 * kProjCand);
-  P.ncand = A.take<uint8_t>(n1);
-  P.state = A.take<uint8_t>(n1);
-  P.choice = A.take<int32_t>(n1);
+  RGBL_TRY(hc.put(&P.proj1, (const float*)prev_matched, (size_t)n1 * 2));
+  RGBL_TRY(hc.put(&P.mpdesc1, in->desc1, (size_t)n1 * 32));
+  RGBL_TRY(hc.put(&P.oct1, in->kp1_octave, (size_t)n1));
+  RGBL_TRY(put_frame2(hc, P, nullptr, n2, in->kp2_xy, in->kp2_octave, nullptr, false, in->desc2));
+  RGBL_TRY(hc.upload());
+  P.choice = hc.result<int32_t>(n1);
+  P.owner = hc.result<int32_t>(n2);
+  P.cell_start = hc.scratch<uint32_t>(kGridCells + 1);
+  P.cell_items = hc.scratch<uint16_t>(n2);
+  P.taken_by = hc.scratch<int32_t>(n2);
+  P.min_unres = hc.scratch<int32_t>(n2);
+  P.win = hc.scratch<float4>(n1);
+  P.rng = hc.scratch<int4>(n1);
+  P.cand = hc.scratch<unsigned long long>((size_t)n1 * kProjCand);
+  P.ncand = hc.scratch<uint8_t>(n1);
+  P.state = hc.scratch<uint8_t>(n1);
   memcpy(P.grid, in->grid, sizeof(P.grid));
   P.th = (float)in->window_size;  // GetFeaturesInArea takes r as const float&
   P.nnratio = in->nnratio;
@@ -2157,11 +2317,8 @@ int rgbl_search_for_initialization(rgbl_matcher* m, const rgbl_initialization_in
   hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(kProjBS), 0, s, P);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
-  std::vector<int32_t> choice(n1), owner(n2);
-  RGBL_HIP(hipMemcpyAsync(choice.data(), P.choice, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipMemcpyAsync(owner.data(), P.owner, sizeof(int32_t) * n2, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipStreamSynchronize(s));
-  m->timer.collect();
+  RGBL_TRY(hc.fetch());
+  const int32_t *choice = hc.host(P.choice), *owner = hc.host(P.owner);
   // a feature whose match was taken over later stays in the rotation histogram (pushed at match time, :720-730) but
   // holds no match any more (:708-712); nmatches always equals the number of entries >= 0
   std::vector<int> hist[30];
@@ -2203,8 +2360,9 @@ struct rgbl_vocabulary {
   VocDev dev{};
   std::vector<void*> allocs;
   hipStream_t stream = nullptr;
-  // staging for the host entry point (grown on demand)
-  uint8_t* d_desc = nullptr; int32_t* d_word = nullptr; double* d_weight = nullptr; int32_t* d_node = nullptr; int stage_cap = 0;
+  // staging for the host entry point (grown on demand): ONE device block desc [cap x 32] | weight [cap] | word [cap] | node [cap]
+  // and its page-locked mirror - one request up, one back
+  uint8_t* d_stage = nullptr; uint8_t* h_stage = nullptr; int stage_cap = 0;
 };
 
 static int voc_upload(rgbl_vocabulary* v, int n_nodes, int L, const int32_t* child_off, const int32_t* child, const uint8_t* desc,
@@ -2244,10 +2402,8 @@ void rgbl_vocabulary_destroy(rgbl_vocabulary* v) {
   if (!v) return;
   (void)hipSetDevice(v->device);
   for (void* p : v->allocs) (void)hipFree(p);
-  if (v->d_desc) (void)hipFree(v->d_desc);
-  if (v->d_word) (void)hipFree(v->d_word);
-  if (v->d_weight) (void)hipFree(v->d_weight);
-  if (v->d_node) (void)hipFree(v->d_node);
+  if (v->d_stage) (void)hipFree(v->d_stage);
+  if (v->h_stage) (void)hipHostFree(v->h_stage);
   if (v->stream) (void)hipStreamDestroy(v->stream);
   delete v;
 }
@@ -2345,34 +2501,44 @@ int rgbl_bow_descend_batch_device(rgbl_vocabulary* v, void* hip_stream, const ui
 // void TemplatedVocabulary::transform(const std::vector<TDescriptor>& features, BowVector& v, FeatureVector& fv, int levelsup)
 // (TemplatedVocabulary.h:1127-1192) for TF_IDF / L1_NORM: BowVector::addWeight in feature order, L1 normalisation summed in
 // ascending word order, FeatureVector::addFeature with ascending feature indices; stopped words (weight 0) are dropped.
-int rgbl_bow_transform(rgbl_vocabulary* v, const uint8_t* desc, int n, int levelsup, uint32_t* word_id, double* word_val,
-                       int cap_words, int* n_words, uint32_t* node_id, int32_t* node_off, uint32_t* node_feat, int cap_nodes,
-                       int* n_nodes) {
-  if (!v || !n_words || !n_nodes || n < 0 || (n > 0 && !desc)) { set_error("invalid argument"); return RGBL_ERR_INVALID; }
+static int bow_transform_core(rgbl_vocabulary* v, const rgbl_device_frame* frame, const uint8_t* desc, int n, int levelsup,
+                              uint32_t* word_id, double* word_val, int cap_words, int* n_words, uint32_t* node_id, int32_t* node_off,
+                              uint32_t* node_feat, int cap_nodes, int* n_nodes) {
+  if (!v || !n_words || !n_nodes || n < 0 || (n > 0 && !desc && !frame)) { set_error("invalid argument"); return RGBL_ERR_INVALID; }
+  if (frame && frame->device != v->device) { set_error("device frame and vocabulary live on different devices"); return RGBL_ERR_INVALID; }
   *n_words = 0; *n_nodes = 0;
   if (n == 0) { if (node_off && cap_nodes >= 0) node_off[0] = 0; return RGBL_OK; }
   RGBL_HIP(hipSetDevice(v->device));
   if (n > v->stage_cap) {
-    if (v->d_desc) { (void)hipFree(v->d_desc); (void)hipFree(v->d_word); (void)hipFree(v->d_weight); (void)hipFree(v->d_node); }
-    v->d_desc = nullptr; v->stage_cap = 0;
+    if (v->d_stage) { (void)hipFree(v->d_stage); (void)hipHostFree(v->h_stage); }
+    v->d_stage = nullptr; v->h_stage = nullptr; v->stage_cap = 0;
     const int cap = std::max(n, 4096);
-    RGBL_HIP(hipMalloc(&v->d_desc, (size_t)cap * 32));
-    RGBL_HIP(hipMalloc(&v->d_word, sizeof(int32_t) * (size_t)cap));
-    RGBL_HIP(hipMalloc(&v->d_weight, sizeof(double) * (size_t)cap));
-    RGBL_HIP(hipMalloc(&v->d_node, sizeof(int32_t) * (size_t)cap));
+    RGBL_HIP(hipMalloc(&v->d_stage, (size_t)cap * 48));
+    RGBL_HIP(hipHostMalloc(reinterpret_cast<void**>(&v->h_stage), (size_t)cap * 48, hipHostMallocDefault));
     v->stage_cap = cap;
   }
+  const size_t cap = (size_t)v->stage_cap;   // results back to back: weight [n] | word [n] | node [n]
+  const uint8_t* d_desc = v->d_stage;
+  double* d_weight = reinterpret_cast<double*>(v->d_stage + cap * 32);
+  int32_t* d_word = reinterpret_cast<int32_t*>(d_weight + n);
+  int32_t* d_node = d_word + n;
   hipStream_t s = v->stream;
-  RGBL_HIP(hipMemcpyAsync(v->d_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_bow_descend, dim3((n + 255) / 256, 1), dim3(256), 0, s, v->dev, v->d_desc, (const int32_t*)nullptr, n, levelsup,
-                     v->d_word, v->d_weight, v->d_node);
+  StreamDrain drain(s);  // error returns included
+  if (frame) {   // the frame's descriptors are resident: nothing goes up
+    RGBL_HIP(hipStreamWaitEvent(s, frame->ready, 0));
+    d_desc = frame->d_desc;
+  } else {
+    memcpy(v->h_stage, desc, (size_t)n * 32);
+    RGBL_HIP(hipMemcpyAsync(v->d_stage, v->h_stage, (size_t)n * 32, hipMemcpyHostToDevice, s));
+  }
+  hipLaunchKernelGGL(k_bow_descend, dim3((n + 255) / 256, 1), dim3(256), 0, s, v->dev, d_desc, (const int32_t*)nullptr, n, levelsup,
+                     d_word, d_weight, d_node);
   RGBL_HIP(hipGetLastError());
-  std::vector<int32_t> word(n), node(n);
-  std::vector<double> weight(n);
-  RGBL_HIP(hipMemcpyAsync(word.data(), v->d_word, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipMemcpyAsync(weight.data(), v->d_weight, sizeof(double) * n, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipMemcpyAsync(node.data(), v->d_node, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+  RGBL_HIP(hipMemcpyAsync(v->h_stage + cap * 32, v->d_stage + cap * 32, (size_t)n * 16, hipMemcpyDeviceToHost, s));
   RGBL_HIP(hipStreamSynchronize(s));
+  const double* weight = reinterpret_cast<const double*>(v->h_stage + cap * 32);
+  const int32_t* word = reinterpret_cast<const int32_t*>(weight + n);
+  const int32_t* node = word + n;
   // the two std::map containers of the reference, as sorted (key, payload) runs
   std::vector<std::pair<uint32_t, int> > wf, nf;  // (word | node, feature)
   for (int i = 0; i < n; ++i)
@@ -2410,6 +2576,21 @@ int rgbl_bow_transform(rgbl_vocabulary* v, const uint8_t* desc, int n, int level
   return RGBL_OK;
 }
 
+int rgbl_bow_transform(rgbl_vocabulary* v, const uint8_t* desc, int n, int levelsup, uint32_t* word_id, double* word_val,
+                       int cap_words, int* n_words, uint32_t* node_id, int32_t* node_off, uint32_t* node_feat, int cap_nodes,
+                       int* n_nodes) {
+  return bow_transform_core(v, nullptr, desc, n, levelsup, word_id, word_val, cap_words, n_words, node_id, node_off, node_feat, cap_nodes,
+                            n_nodes);
+}
+
+int rgbl_bow_transform_frame(rgbl_vocabulary* v, const rgbl_device_frame* frame, int levelsup, uint32_t* word_id, double* word_val,
+                             int cap_words, int* n_words, uint32_t* node_id, int32_t* node_off, uint32_t* node_feat, int cap_nodes,
+                             int* n_nodes) {
+  if (!frame) { set_error("null frame"); return RGBL_ERR_INVALID; }
+  return bow_transform_core(v, frame, nullptr, frame->n, levelsup, word_id, word_val, cap_words, n_words, node_id, node_off, node_feat,
+                            cap_nodes, n_nodes);
+}
+
 // device part of both SearchByBoW overloads: match1[idx1] = feature of `fr` taken by key-frame feature idx1 (or -1), match2 the
 // inverse; pa / pb = the shared vocabulary nodes in merge order
 static int bow_core(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_keyframe_view* fr, float nnratio, bool second_needs_mp,
@@ -2438,35 +2619,48 @@ static int bow_core(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_ke
   size_t need = pad256((size_t)n1 * 32) + pad256((size_t)n2 * 32) + pad256(n1) + pad256(n2) + pad256((size_t)(kf->n_nodes + 1) * 4) +
                 pad256((size_t)nf1 * 4) + pad256((size_t)(fr->n_nodes + 1) * 4) + pad256((size_t)nf2 * 4) +
                 2 * pad256((size_t)npairs * 4) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 4);
-  RGBL_TRY(ensure_arena(m, need));
-  Arena A{m->d_buf};
-  hipStream_t s = m->stream;
+  HostCall hc;
+  RGBL_TRY(hc.begin(m, need));
+  hipStream_t s = hc.s;
   BowDev T;
   T.valid2 = nullptr;
-  RGBL_TRY(upload(A, s, &T.desc1, kf->desc, (size_t)n1 * 32));
-  RGBL_TRY(upload(A, s, &T.desc2, fr->desc, (size_t)n2 * 32));
-  RGBL_TRY(upload(A, s, &T.valid1, kf->has_mappoint, (size_t)n1));
-  if (second_needs_mp) RGBL_TRY(upload(A, s, &T.valid2, fr->has_mappoint, (size_t)n2));
-  RGBL_TRY(upload(A, s, &T.off1, kf->node_off, (size_t)kf->n_nodes + 1));
-  RGBL_TRY(upload(A, s, &T.feat1, kf->node_feat, (size_t)nf1));
-  RGBL_TRY(upload(A, s, &T.off2, fr->node_off, (size_t)fr->n_nodes + 1));
-  RGBL_TRY(upload(A, s, &T.feat2, fr->node_feat, (size_t)nf2));
-  RGBL_TRY(upload(A, s, &T.pair_n1, pa.data(), (size_t)npairs));
-  RGBL_TRY(upload(A, s, &T.pair_n2, pb.data(), (size_t)npairs));
-  T.match1 = A.take<int32_t>(n1);
-  T.match2 = A.take<int32_t>(n2);
+  const rgbl_keyframe_view* kv[2] = {kf, fr};
+  const uint8_t** desc[2] = {&T.desc1, &T.desc2};
+  const int32_t **off[2] = {&T.off1, &T.off2}, **feat[2] = {&T.feat1, &T.feat2};
+  for (int k = 0; k < 2; ++k) {
+    const rgbl_keyframe_view* v = kv[k];
+    const int nf = v->node_off[v->n_nodes];
+    if (const rgbl_device_frame* f = v->device) {
+      RGBL_TRY(hc.use(f, v->n));
+      *desc[k] = f->d_desc;
+    } else {
+      RGBL_TRY(hc.put(desc[k], v->desc, (size_t)v->n * 32));
+    }
+    if (v->device && v->device->n_nodes == v->n_nodes && v->device->nf == nf) {
+      *off[k] = v->device->d_fv; *feat[k] = v->device->d_fv + v->n_nodes + 1;
+    } else {
+      RGBL_TRY(hc.put(off[k], v->node_off, (size_t)v->n_nodes + 1));
+      RGBL_TRY(hc.put(feat[k], v->node_feat, (size_t)nf));
+    }
+  }
+  RGBL_TRY(hc.put(&T.valid1, kf->has_mappoint, (size_t)n1));
+  if (second_needs_mp) RGBL_TRY(hc.put(&T.valid2, fr->has_mappoint, (size_t)n2));
+  RGBL_TRY(hc.put(&T.pair_n1, pa.data(), (size_t)npairs));
+  RGBL_TRY(hc.put(&T.pair_n2, pb.data(), (size_t)npairs));
+  T.match1 = hc.put_fill<int32_t>(n1, 0xff);   // all -1: travel with the upload
+  T.match2 = hc.put_fill<int32_t>(n2, 0xff);
+  hc.mark_result(T.match1, n1);
+  hc.mark_result(T.match2, n2);
+  RGBL_TRY(hc.upload());
   T.nnratio = nnratio;
   T.max_best = max_best;
-  RGBL_HIP(hipMemsetAsync(T.match1, 0xff, sizeof(int32_t) * n1, s));
-  RGBL_HIP(hipMemsetAsync(T.match2, 0xff, sizeof(int32_t) * n2, s));
   m->timer.begin("k_search_by_bow", s);
   hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(64), 0, s, T);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
-  RGBL_HIP(hipMemcpyAsync(match1.data(), T.match1, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipMemcpyAsync(match2.data(), T.match2, sizeof(int32_t) * n2, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipStreamSynchronize(s));
-  m->timer.collect();
+  RGBL_TRY(hc.fetch());
+  memcpy(match1.data(), hc.host(T.match1), sizeof(int32_t) * n1);
+  memcpy(match2.data(), hc.host(T.match2), sizeof(int32_t) * n2);
   return RGBL_OK;
 }
 

@@ -330,6 +330,65 @@ class DepthModule:
         return L.read_profile_samples(self.lib, self.lib.rgbl_depth_profile_read, self.lib.rgbl_depth_profile_samples, self.h)
 
 
+class DeviceFrame:
+    """A Frame / KeyFrame whose per-feature arrays (mDescriptors, mvKeysUn[].pt / .octave, mvuRight) are resident in HBM
+    (rgbl_device_frame): filled once - from host arrays or straight from the extractor / depth handles - and named by the
+    `device` / `device2` member of the matcher inputs, which then upload nothing for it."""
+
+    def __init__(self, capacity, device=0, lib=None):
+        self.lib = lib or L.load()
+        self.h = C.c_void_p()
+        L.check(self.lib, self.lib.rgbl_device_frame_create(device, int(capacity), C.byref(self.h)))
+
+    def upload(self, desc, xy, octave, uright=None):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        a = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        o = np.ascontiguousarray(octave, np.int32)
+        u = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        L.check(self.lib, self.lib.rgbl_device_frame_upload(self.h, len(d), L.ptr(d), L.ptr(a), L.ptr(o), L.ptr(u)))
+        return self
+
+    def capture(self, extractor, n, depth=None, frame=0, K=None, dist=None):
+        """The n keypoints / descriptors of the extractor's last call (and the depth module's mvuRight): device to device."""
+        k = None if K is None else np.ascontiguousarray(K, np.float32)
+        dc = None if dist is None else np.ascontiguousarray(dist, np.float32).reshape(-1)
+        L.check(self.lib, self.lib.rgbl_device_frame_capture(self.h, extractor.h, int(frame), int(n), depth.h if depth is not None else None,
+                                                             L.ptr(k), L.ptr(dc), 0 if dc is None else len(dc)))
+        return self
+
+    def set_feature_vector(self, node_off, node_feat):
+        off = np.ascontiguousarray(node_off, np.int32)
+        ft = np.ascontiguousarray(node_feat, np.int32)
+        L.check(self.lib, self.lib.rgbl_device_frame_set_feature_vector(self.h, len(off) - 1, L.ptr(off), L.ptr(ft) if len(ft) else None))
+        return self
+
+    def __len__(self):
+        return self.lib.rgbl_device_frame_size(self.h)
+
+    def download(self):
+        n = len(self)
+        desc, xy = np.zeros((n, 32), np.uint8), np.zeros((n, 2), np.float32)
+        octave, ur = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        L.check(self.lib, self.lib.rgbl_device_frame_download(self.h, L.ptr(desc), L.ptr(xy), L.ptr(octave), L.ptr(ur)))
+        return dict(desc=desc, xy=xy, octave=octave, uright=ur)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.rgbl_device_frame_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _dev(d, key):
+    f = d.get(key) if hasattr(d, "get") else None
+    return f.h if f is not None else None
+
+
 class ORBmatcher:
     TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30  # src/ORBmatcher.cc:35-37
 
@@ -413,6 +472,7 @@ class ORBmatcher:
         P.scale_factors = arr(frames["scale_factors"], np.float32)
         P.n_levels = len(frames["scale_factors"])
         P.th, P.mono, P.check_orientation = float(th), int(bMono), int(self.mbCheckOrientation)
+        P.device2 = _dev(frames, "device2")
         match2 = np.zeros(P.n2, np.int32)
         n = C.c_int(0)
         fn, h, pP, pm, pn = self.lib.rgbl_search_by_projection, self.h, C.byref(P), L.ptr(match2), C.byref(n)
@@ -464,6 +524,7 @@ class ORBmatcher:
         P.scale_factors = arr(kf["scale_factors"], np.float32)
         P.n_levels = len(kf["scale_factors"])
         P.th, P.orb_dist, P.check_orientation = float(th), int(ORBdist), int(self.mbCheckOrientation)
+        P.device2 = _dev(kf, "device2")
         match2 = np.zeros(P.n2, np.int32)
         n = C.c_int(0)
         L.check(self.lib, self.lib.rgbl_search_by_projection_keyframe(self.h, C.byref(P), L.ptr(match2), C.byref(n)))
@@ -495,6 +556,7 @@ class ORBmatcher:
         P.scale_factors, P.inv_level_sigma2 = arr(case["scale_factors"], np.float32), arr(case["inv_level_sigma2"], np.float32)
         P.n_levels = len(case["scale_factors"])
         P.th = float(th)
+        P.device2 = _dev(case, "device2")
         best = np.zeros(P.n1, np.int32)
         dist = np.zeros(P.n1, np.int32)
         L.check(self.lib, self.lib.rgbl_fuse_search(self.h, C.byref(P), L.ptr(best), L.ptr(dist)))
@@ -536,6 +598,7 @@ class ORBmatcher:
         P.scale_factors = arr(case["scale_factors"], np.float32)
         P.n_levels = len(case["scale_factors"])
         P.th, P.proj_form, P.max_dist = float(th), int(proj_form), int(max_dist)
+        P.device2 = _dev(case, "device2")
         best = np.zeros(P.n1, np.int32)
         dist = np.zeros(P.n1, np.int32)
         L.check(self.lib, self.lib.rgbl_project_search(self.h, C.byref(P), L.ptr(best), L.ptr(dist)))
@@ -563,6 +626,7 @@ class ORBmatcher:
         P.scale_factors = arr(case["scale_factors"], np.float32)
         P.n_levels = len(case["scale_factors"])
         P.th, P.proj_form, P.max_dist = float(th), int(proj_form), int(max_dist)
+        P.device2 = _dev(case, "device2")
         m2 = np.ascontiguousarray(matched2, np.uint8)
         match = np.zeros(P.n2, np.int32)
         n = C.c_int(0)
@@ -596,6 +660,7 @@ class ORBmatcher:
         P.scale_factors = arr(pts["scale_factors"], np.float32)
         P.n_levels = len(pts["scale_factors"])
         P.th, P.nnratio = float(th), float(self.mfNNratio)
+        P.device2 = _dev(pts, "device2")
         match2 = np.zeros(P.n2, np.int32)
         n = C.c_int(0)
         fn, h, pP, pm, pn = self.lib.rgbl_search_local_points, self.h, C.byref(P), L.ptr(match2), C.byref(n)
@@ -644,6 +709,7 @@ class ORBmatcher:
             keep.append(a)
             setattr(v, field, a.ctypes.data)
         v.n_nodes = len(kf["node_id"])
+        v.device = _dev(kf, "device")
         return v
 
     def SearchByBoW(self, kf, frame):
@@ -699,6 +765,7 @@ class ORBmatcher:
                 keep.append(a)
                 setattr(v, field, a.ctypes.data)
             v.n_nodes = len(kf["node_id"])
+            v.device = _dev(kf, "device")
             return v
 
         v1, v2 = view(kf1), view(kf2)
@@ -778,6 +845,19 @@ class ORBVocabulary:
 
         def call():
             L.check(self.lib, self.lib.rgbl_bow_transform(*args))
+            return wid[:nw.value].copy(), wval[:nw.value].copy(), nid[:nn.value].copy(), noff[:nn.value + 1].copy(), nfeat[:noff[nn.value]].copy()
+        return call
+
+    def prepare_transform_frame(self, frame, levelsup=4):
+        """transform() of a DeviceFrame's resident descriptors: nothing is uploaded."""
+        n = len(frame)
+        wid, wval = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.float64)
+        nid, noff, nfeat = np.zeros(max(n, 1), np.uint32), np.zeros(n + 1, np.int32), np.zeros(max(n, 1), np.uint32)
+        nw, nn = C.c_int(0), C.c_int(0)
+        args = (self.h, frame.h, levelsup, L.ptr(wid), L.ptr(wval), n, C.byref(nw), L.ptr(nid), L.ptr(noff), L.ptr(nfeat), n, C.byref(nn))
+
+        def call():
+            L.check(self.lib, self.lib.rgbl_bow_transform_frame(*args))
             return wid[:nw.value].copy(), wval[:nw.value].copy(), nid[:nn.value].copy(), noff[:nn.value + 1].copy(), nfeat[:noff[nn.value]].copy()
         return call
 

@@ -232,7 +232,7 @@ class ORBmatcher {
       oct2[i] = CurrentFrame.mvKeysUn[i].octave;
       angle2[i] = CurrentFrame.mvKeysUn[i].angle;
     }
-    rgbl_projection_input in;
+    rgbl_projection_input in{};
     in.n1 = n1; in.valid1 = valid.data(); in.world_pos1 = pos.data(); in.mp_desc1 = desc1.data();
     in.mp_observed1 = observed.data(); in.octave1 = oct1.data(); in.angle1 = angle1.data();
     in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.kp2_angle = angle2.data();
@@ -302,7 +302,7 @@ class ORBmatcher {
       angle2[i] = CurrentFrame.mvKeysUn[i].angle;
       occupied[i] = CurrentFrame.mvpMapPoints[i] ? 1 : 0;
     }
-    rgbl_keyframe_projection_input in;
+    rgbl_keyframe_projection_input in{};
     in.n1 = n1; in.valid1 = valid.data(); in.world_pos1 = pos.data(); in.mp_desc1 = desc1.data();
     in.level1 = level1.data(); in.angle1 = angle1.data();
     in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.kp2_angle = angle2.data();
@@ -366,7 +366,7 @@ class ORBmatcher {
       xy2[2 * (size_t)i + 1] = pKF->mvKeysUn[i].pt.y;
       oct2[i] = pKF->mvKeysUn[i].octave;
     }
-    rgbl_fuse_input in;
+    rgbl_fuse_input in{};
     in.n1 = n1; in.valid1 = valid.data(); in.world_pos1 = pos.data(); in.mp_desc1 = desc1.data(); in.level1 = level1.data();
     in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.uright2 = pKF->mvuRight.data();
     in.desc2 = pKF->mDescriptors.template ptr<uint8_t>();
@@ -590,7 +590,7 @@ class ORBmatcher {
       oct2[i] = F.mvKeysUn[i].octave;
       blocked[i] = (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;
     }
-    rgbl_local_points_input in;
+    rgbl_local_points_input in{};
     in.n1 = n1; in.valid1 = valid.data(); in.proj1 = proj.data(); in.level1 = level.data(); in.view_cos1 = vcos.data();
     in.mp_desc1 = desc1.data(); in.mp_observed1 = observed.data();
     in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.uright2 = F.mvuRight.data();
@@ -634,7 +634,7 @@ class ORBmatcher {
       xy2[2 * (size_t)i] = F2.mvKeysUn[i].pt.x; xy2[2 * (size_t)i + 1] = F2.mvKeysUn[i].pt.y;
       oct2[i] = F2.mvKeysUn[i].octave; ang2[i] = F2.mvKeysUn[i].angle;
     }
-    rgbl_initialization_input in;
+    rgbl_initialization_input in{};
     in.n1 = n1; in.kp1_octave = oct1.data(); in.kp1_angle = ang1.data(); in.desc1 = F1.mDescriptors.template ptr<uint8_t>();
     in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.kp2_angle = ang2.data();
     in.desc2 = F2.mDescriptors.template ptr<uint8_t>();
@@ -663,7 +663,7 @@ class ORBmatcher {
     std::vector<float> xy, angle;
     std::vector<int32_t> octave, node_id, node_off, node_feat;
     std::vector<uint8_t> has_mp;
-    rgbl_keyframe_view view;
+    rgbl_keyframe_view view{};
   };
   // Snapshot of the key-frame state the kernel needs; GetMapPoint() takes the key-frame's own mutex per call,
   // exactly as the reference's inner loops do (KeyFrame.cc:373-377).
@@ -735,7 +735,7 @@ class ORBmatcher {
       oct2[i] = pKF->mvKeysUn[i].octave;
       matched[i] = vpMatched[i] ? 1 : 0;
     }
-    rgbl_project_search_input in;
+    rgbl_project_search_input in{};
     in.n1 = n1; in.valid1 = valid.data(); in.cam_pos1 = pos.data(); in.mp_desc1 = desc1.data(); in.level1 = level1.data();
     in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.desc2 = pKF->mDescriptors.template ptr<uint8_t>();
     in.grid[0] = pKF->mnMinX; in.grid[1] = pKF->mnMinY; in.grid[2] = pKF->mnMaxX; in.grid[3] = pKF->mnMaxY;
@@ -769,7 +769,7 @@ class ORBmatcher {
       xy2[2 * (size_t)i + 1] = pKF->mvKeysUn[i].pt.y;
       oct2[i] = pKF->mvKeysUn[i].octave;
     }
-    rgbl_project_search_input in;
+    rgbl_project_search_input in{};
     in.n1 = n1; in.valid1 = valid.data(); in.cam_pos1 = pos.data(); in.mp_desc1 = desc.data(); in.level1 = level.data();
     in.n2 = n2; in.kp2_xy = xy2.data(); in.kp2_octave = oct2.data(); in.desc2 = pKF->mDescriptors.template ptr<uint8_t>();
     in.grid[0] = pKF->mnMinX; in.grid[1] = pKF->mnMinY; in.grid[2] = pKF->mnMaxX; in.grid[3] = pKF->mnMaxY;

@@ -1432,3 +1432,153 @@ def check_extractor_threshold_extremes(lib, w=200, h=150):
                 c, oc = ex.level_candidates(l), orc.level_candidates(l)
                 assert len(c) == len(oc) and all(np.array_equal(c[f], oc[f]) for f in ("x", "y", "response")), (name, ini, mn, l)
         ex.close()
+
+
+# ---- frames resident on the device (rgbl_device_frame): every matcher must give the host-array result ---------------------
+def check_device_frames(lib, n=900, seed=17, w=640, h=360, nfeatures=700):
+    """(i) upload / download round trip; (ii) capture straight from the extractor + depth handles == the arrays the host API
+    returned (incl. Frame::UndistortKeyPoints on the device); (iii) SearchForTriangulation, both SearchByBoW overloads, the three
+    greedy projection searches, the Fuse / Sim3 per-point searches and ORBVocabulary::transform with resident frames == the
+    same calls on host arrays == the oracle."""
+    rng = np.random.default_rng(seed)
+    # (i)
+    kf1, kf2, K, R, t, ep, sf, s2 = make_triangulation_case(n, seed, n_nodes=60)
+    d1 = F.DeviceFrame(n, lib=lib).upload(kf1["desc"], kf1["xy"], kf1["octave"], kf1["uright"])
+    d2 = F.DeviceFrame(n + 100, lib=lib).upload(kf2["desc"], kf2["xy"], kf2["octave"], kf2["uright"])
+    back = d2.download()
+    assert len(d2) == n and np.array_equal(back["desc"], kf2["desc"]) and np.array_equal(bits(back["xy"]), bits(kf2["xy"]))
+    assert np.array_equal(back["octave"], kf2["octave"]) and np.array_equal(bits(back["uright"]), bits(kf2["uright"]))
+    mono = F.DeviceFrame(8, lib=lib).upload(kf1["desc"][:5], kf1["xy"][:5], kf1["octave"][:5], None)
+    assert (mono.download()["uright"] == -1).all()
+    mono.close()
+    try:
+        F.DeviceFrame(4, lib=lib).upload(kf1["desc"][:70], kf1["xy"][:70], kf1["octave"][:70])
+        raise AssertionError("more features than the capacity must be refused")
+    except L.RgblError as e:
+        assert e.code == L.ERR_INVALID
+    # (iii) key-frame views: triangulation with and without the resident FeatureVector, SearchByBoW x 2
+    hollow = lambda kf: dict(kf, desc=np.zeros_like(kf["desc"]), xy=np.zeros_like(kf["xy"]), octave=np.zeros_like(kf["octave"]),
+                             uright=np.zeros_like(kf["uright"]))   # host arrays that must NOT be read
+    for with_fv in (False, True):
+        if with_fv:
+            d1.set_feature_vector(kf1["node_off"], kf1["node_feat"])
+            d2.set_feature_vector(kf2["node_off"], kf2["node_feat"])
+        for check_ori in (False, True):
+            m = F.ORBmatcher(0.6, check_ori, lib=lib)
+            Fm = m.fundamental(K, K, R, t)
+            for only_stereo, coarse in ((False, False), (True, False), (False, True)):
+                want = O.search_triangulation(kf1, kf2, Fm, ep, sf, s2, only_stereo, coarse, check_ori)
+                for a, b in ((dict(hollow(kf1), device=d1), dict(hollow(kf2), device=d2)), (dict(hollow(kf1), device=d1), kf2), (kf1, dict(hollow(kf2), device=d2))):
+                    _, nm, m12 = m.SearchForTriangulation(a, b, Fm, ep, sf, s2, only_stereo, coarse)
+                    assert nm == want[1] and np.array_equal(m12, want[0]), "triangulation on resident frames"
+            m.close()
+    a = dict(kf1, has_mp=(rng.random(n) < 0.7).astype(np.uint8))
+    b = dict(kf2, has_mp=(rng.random(n) < 0.8).astype(np.uint8))
+    for ori in (False, True):
+        mt = F.ORBmatcher(0.7, ori, lib=lib)
+        want = O.search_by_bow(a, b, 0.7, ori)
+        got = mt.SearchByBoW(dict(hollow(a), device=d1), dict(hollow(b), device=d2))
+        assert got[1] == want[1] and np.array_equal(got[0], want[0]), "SearchByBoW on resident frames"
+        want = O.search_by_bow_kf(a, b, 0.7, ori)
+        got = mt.SearchByBoWKeyFrames(dict(hollow(a), device=d1), dict(hollow(b), device=d2))
+        assert got[1] == want[1] and np.array_equal(got[0], want[0]), "SearchByBoW(KF, KF) on resident frames"
+        mt.close()
+    d1.close()
+    d2.close()
+    # the projection searches: the CurrentFrame / key frame resident, the map points from the host
+    def frame2(c, ur=True):
+        f = F.DeviceFrame(len(c["kp2_xy"]), lib=lib)
+        return f.upload(c["desc2"], c["kp2_xy"], c["kp2_octave"], c["uright2"] if ur and "uright2" in c else None)
+
+    def hollow2(c):
+        z = {k: np.zeros_like(c[k]) for k in ("kp2_xy", "kp2_octave", "desc2") if k in c}
+        if "uright2" in c:
+            z["uright2"] = np.zeros_like(c["uright2"])
+        return dict(c, **z)
+    case = make_projection_case(n, n + 50, seed + 1, "forward")
+    f2 = frame2(case)
+    mt = F.ORBmatcher(0.9, True, lib=lib)
+    for th in (7.0, 15.0):
+        want = O.search_by_projection(case, th, False, True)
+        got = mt.SearchByProjection(dict(hollow2(case), device2=f2), th, False)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0]), "SearchByProjection on a resident CurrentFrame"
+    f2.close()
+    case = make_relocalization_case(n, n + 50, seed + 2)
+    valid, level = relocalization_prepass(case)
+    f2 = frame2(case, ur=False)
+    want = O.search_by_projection_kf(case, 10.0, 100, True)
+    got = mt.SearchByProjectionKeyFrame(dict(hollow2(case), valid1=valid, level1=level, device2=f2), 10.0, 100)
+    assert got[1] == want[1] and np.array_equal(got[0], want[0]), "SearchByProjection(F, KF) on a resident frame"
+    f2.close()
+    mt.close()
+    case = make_local_points_case(n + 300, n, seed + 3)
+    f2 = frame2(case)
+    mt = F.ORBmatcher(0.8, True, lib=lib)
+    want = O.search_local_points(case, 1.0, 0.8)
+    got = mt.SearchLocalPoints(dict(hollow2(case), device2=f2), 1.0)
+    assert got[1] == want[1] and np.array_equal(got[0], want[0]), "SearchLocalPoints on a resident frame"
+    f2.close()
+    mt.close()
+    case = make_fuse_case(n + 200, n, seed + 4)
+    valid, level = fuse_prepass(case)
+    c = dict(case, valid1=valid, level1=level)
+    f2 = frame2(c)
+    mt = F.ORBmatcher(0.6, True, lib=lib)
+    want = mt.FuseSearch(c, 3.0)
+    got = mt.FuseSearch(dict(hollow2(c), device2=f2), 3.0)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and (want[0] >= 0).sum() > 30, "Fuse search on a resident key frame"
+    f2.close()
+    c = make_project_search_case(n + 200, n, seed + 5)
+    f2 = frame2(c, ur=False)
+    for form, maxd in ((0, 50), (1, 100)):
+        want = mt.ProjectSearch(c, 4.0, form, maxd)
+        got = mt.ProjectSearch(dict(hollow2(c), device2=f2), 4.0, form, maxd)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), "project search on a resident key frame"
+    matched2 = (rng.random(n) < 0.1).astype(np.uint8)
+    want = mt.SearchByProjectionSim3(c, matched2, 8, 0, 75)
+    got = mt.SearchByProjectionSim3(dict(hollow2(c), device2=f2), matched2, 8, 0, 75)
+    assert got[1] == want[1] and np.array_equal(got[0], want[0]), "SearchByProjection(KF, Sim3) on a resident key frame"
+    f2.close()
+    mt.close()
+    # (ii) capture: extractor (+ depth module) -> resident frame, no host arrays in between
+    sq = synth.Sequence(seed, w, h, n_frames=2)
+    ex = F.ORBextractor(nfeatures, 1.2, 8, 12, 7, w, h, lib=lib)
+    Kc = synth.KITTI_K.copy()
+    Kc[0, 2], Kc[1, 2] = w / 2.0, h / 2.0
+    dm = F.DepthModule(F.projection_matrix(Kc, synth.KITTI_TR, lib), w, h, max_keypoints=ex.max_keypoints, lib=lib)
+    cap = F.DeviceFrame(ex.max_keypoints, lib=lib)
+    for i in range(2):
+        kps, desc, _ = ex(sq.frame(i))
+        dm.CalculateDepthFromPcd(kps, kps, synth.lidar_scan(seed + i, n_az=600), w, h, want_maps=False)
+        cap.capture(ex, len(kps), dm)
+        got = cap.download()
+        assert len(cap) == len(kps) and np.array_equal(got["desc"], desc)
+        assert np.array_equal(bits(got["xy"]), bits(np.stack([kps["x"], kps["y"]], 1))) and np.array_equal(got["octave"], kps["octave"])
+        assert np.array_equal(bits(got["uright"]), bits(dm.mvuRight)) and (dm.mvuRight > 0).sum() > 10
+    cap.capture(ex, len(kps), None)          # monocular: no depth handle
+    assert (cap.download()["uright"] == -1).all()
+    k4 = np.array([Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2]], np.float32)
+    dist = np.array([-0.28, 0.07, 1e-4, -2e-4, 0.0], np.float32)
+    cap.capture(ex, len(kps), None, K=k4, dist=dist)    # Frame::UndistortKeyPoints on the way
+    want_xy = ex.UndistortKeyPoints(np.stack([kps["x"], kps["y"]], 1), k4, dist)
+    assert np.array_equal(bits(cap.download()["xy"]), bits(want_xy)) and not np.array_equal(want_xy, np.stack([kps["x"], kps["y"]], 1))
+    # a captured frame in a matcher call + ORBVocabulary::transform of its resident descriptors
+    cap.capture(ex, len(kps), dm)
+    frame = dict(xy=np.stack([kps["x"], kps["y"]], 1), desc=desc, octave=kps["octave"], angle=kps["angle"], uright=dm.mvuRight)
+    case = make_local_points_case(1200, seed=seed + 6, w=w, h=h, frame2=frame)
+    mt = F.ORBmatcher(0.8, True, lib=lib)
+    want = O.search_local_points(case, 3.0, 0.8)
+    got = mt.SearchLocalPoints(dict(hollow2(case), device2=cap), 3.0)
+    assert got[1] == want[1] and np.array_equal(got[0], want[0]) and want[1] > 50, "SearchLocalPoints on a captured frame"
+    mt.close()
+    voc = synth.make_vocabulary(8, 3, seed)
+    V = F.ORBVocabulary(lib=lib).from_arrays(synth.vocabulary_arrays(voc))
+    want = V.transform(desc, 2)
+    got = V.prepare_transform_frame(cap, 2)()
+    for g, x in zip(got, want):
+        assert np.array_equal(g.view(np.uint64) if g.dtype == np.float64 else g, x.view(np.uint64) if x.dtype == np.float64 else x)
+    V.close()
+    cap.close()
+    dm.close()
+    ex.close()
+    return True

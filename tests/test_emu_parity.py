@@ -406,3 +406,8 @@ def test_prioritised_streams_carry_work(emu_lib):
         assert np.array_equal(bd, d.min(1)) and np.array_equal(bi, np.where(d == d.min(1)[:, None], np.arange(280)[None, :], 1 << 30).min(1))
         m.close()
         emu_lib.rgbl_stream_destroy(st)
+
+
+def test_device_resident_frames(emu_lib):
+    """rgbl_device_frame: upload / capture / FeatureVector, and every matcher entry point that takes one."""
+    assert pc.check_device_frames(emu_lib, n=500, nfeatures=400, w=400, h=300)

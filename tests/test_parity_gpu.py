@@ -460,3 +460,11 @@ def test_prioritised_streams_carry_work(gpu_lib):
         assert np.array_equal(bd, d.min(1)) and np.array_equal(bi, np.where(d == d.min(1)[:, None], np.arange(280)[None, :], 1 << 30).min(1))
         m.close()
         gpu_lib.rgbl_stream_destroy(st)
+
+
+@pytest.mark.gpu
+def test_device_resident_frames(gpu_lib):
+    """rgbl_device_frame on the MI355X: upload / capture (extractor + depth handles -> frame, device to device, with and without
+    Frame::UndistortKeyPoints) / FeatureVector, and every matcher entry point that takes a resident frame == the host-array
+    call == the oracle."""
+    assert pc.check_device_frames(gpu_lib, n=2000, nfeatures=2000, w=1241, h=376)
