@@ -20,7 +20,7 @@ def build(libdir, libname, exe):
     import glob
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     srcs = [os.path.join(ROOT, "tests", "shim_test.cpp"), os.path.join(SHIM, "ORBextractor.cc"), os.path.join(SHIM, "DepthModule.cc")]
-    deps = srcs + glob.glob(os.path.join(SHIM, "*.h")) + [os.path.join(ROOT, "include", "rgbl_frontend.h"),
+    deps = srcs + glob.glob(os.path.join(SHIM, "*.h")) + [os.path.join(ROOT, "include", "rgbl_frontend.h"), os.path.join(ROOT, "tests", "shim_standins.h"),
                                                            os.path.join(libdir, "lib%s.so" % libname)]
     with open(exe + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
