@@ -1432,7 +1432,9 @@ static int stereo_enqueue(rgbl_extractor* L, rgbl_extractor* R, int batch, const
   PyrView pr{R->last_img0, R->last_pitch0, R->last_frame0, R->d_pyr, R->pyr_frame};
   hipStream_t s = L->stream;
   L->timer.begin("k_stereo_match", s);
-  hipLaunchKernelGGL(k_stereo_match, dim3((cap + 255) / 256, batch), dim3(256), 0, s, L->d_geom, st, pl, pr, d_kpl, d_dl, d_nl,
+  // one wave per workgroup for a handful of pairs (a KITTI pair: 32 workgroups on 32 CUs instead of 8), four for batches
+  const int bs = batch < 8 ? 64 : 256;
+  hipLaunchKernelGGL(k_stereo_match, dim3((cap + bs - 1) / bs, batch), dim3(bs), 0, s, L->d_geom, st, pl, pr, d_kpl, d_dl, d_nl,
                      d_kpr, d_dr, d_nr, cap, mb, mbf, L->cfg.height, d_uright, d_depth, L->d_stereo_sad);
   L->timer.end(s);
   L->timer.begin("k_stereo_filter", s);

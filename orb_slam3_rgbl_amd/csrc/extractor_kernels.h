@@ -2006,6 +2006,8 @@ __global__ __launch_bounds__(kOctWide) void k_test_block_sort(uint64_t* key, uin
 //   k_stereo_filter  one workgroup per frame: median of the accepted SADs by a two-level histogram, outlier cut.
 struct ScaleTables { float scale[kMaxLevels], inv_scale[kMaxLevels]; };
 struct PyrView { const uint8_t* img0; int pitch0; size_t frame0; const uint8_t* pyr; size_t pyr_frame; };
+constexpr int kStereoTile = 2048;      // right keypoints staged in LDS per pass of k_stereo_match (18 KB)
+constexpr int kStereoRowBias = 4096;   // row bands are kept as two biased 16-bit halves of one word
 
 __device__ __forceinline__ int pyr_px(const uint8_t* base, int pitch, int w, int h, int x, int y) {
   return base[(size_t)reflect101(y, h) * pitch + reflect101(x, w)];  // the reference reads a reflect-101 bordered buffer
@@ -2017,11 +2019,18 @@ __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restric
                                                       const uint8_t* __restrict__ dr, const int32_t* __restrict__ nr, int cap,
                                                       float mb, float mbf, int n_rows, float* __restrict__ uright,
                                                       float* __restrict__ depth, int32_t* __restrict__ sad_out) {
+  // The right keypoints' row band [floor(y - 2 s), ceil(y + 2 s)], octave and u - what the reference's vRowIndices table and
+  // the candidate tests read - are staged in LDS in tiles of kStereoTile, once per workgroup (round 6: every work-item had
+  // fetched all Nr 28-byte records from global memory itself, one dependent load per candidate: 560 us for one KITTI pair).
+  __shared__ float s_u[kStereoTile];
+  __shared__ int s_band[kStereoTile];       // minr (low half, biased) | maxr (high half, biased)
+  __shared__ uint8_t s_oct[kStereoTile];
   const int f = blockIdx.y;
-  const int iL = blockIdx.x * 256 + threadIdx.x;
+  const int iL = blockIdx.x * blockDim.x + threadIdx.x;
   const int N = nl[f], Nr = nr[f];
-  if (iL >= N) return;
-  const size_t o = (size_t)f * cap + iL;
+  if ((int)(blockIdx.x * blockDim.x) >= N) return;   // the whole workgroup is beyond the frame's keypoints (uniform: no barrier is skipped by a part of it)
+  const bool live = iL < N;
+  const size_t o = (size_t)f * cap + (live ? iL : 0);
   const rgbl_keypoint kL = kpl[o];
   float out_u = -1.0f, out_d = -1.0f;
   int out_sad = -1;
@@ -2030,24 +2039,41 @@ __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restric
   const int levelL = kL.octave;
   const int row = (int)vL;
   const float minU = uL - maxD, maxU = uL - minD;
-  if (!(maxU < 0) && row >= 0 && row < n_rows) {
-    const unsigned long long* D = reinterpret_cast<const unsigned long long*>(dl + o * 32);
-    const unsigned long long q0 = D[0], q1 = D[1], q2 = D[2], q3 = D[3];
-    int bestDist = 100 /* TH_HIGH */, bestIdxR = 0;
-    const rgbl_keypoint* KR = kpr + (size_t)f * cap;
-    const unsigned long long* DR = reinterpret_cast<const unsigned long long*>(dr + (size_t)f * cap * 32);
-    for (int iR = 0; iR < Nr; ++iR) {
-      const float kpY = KR[iR].y, uR = KR[iR].x;
-      const int octR = KR[iR].octave;
-      const float r = 2.0f * st.scale[octR];
-      const int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
-      if (row < minr || row > maxr) continue;
-      if (octR < levelL - 1 || octR > levelL + 1) continue;
-      if (!(uR >= minU && uR <= maxU)) continue;
-      const unsigned long long* t = DR + 4 * (size_t)iR;
-      const int dist = __popcll(q0 ^ t[0]) + __popcll(q1 ^ t[1]) + __popcll(q2 ^ t[2]) + __popcll(q3 ^ t[3]);
-      if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+  const bool searching = live && !(maxU < 0) && row >= 0 && row < n_rows;
+  const unsigned long long* D = reinterpret_cast<const unsigned long long*>(dl + o * 32);
+  const unsigned long long q0 = D[0], q1 = D[1], q2 = D[2], q3 = D[3];
+  int bestDist = 100 /* TH_HIGH */, bestIdxR = 0;
+  const rgbl_keypoint* KR = kpr + (size_t)f * cap;
+  const unsigned long long* DR = reinterpret_cast<const unsigned long long*>(dr + (size_t)f * cap * 32);
+  const int rowb = row + kStereoRowBias;
+  for (int t0 = 0; t0 < Nr; t0 += kStereoTile) {
+    const int nt = imin(kStereoTile, Nr - t0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < nt; j += blockDim.x) {
+      const rgbl_keypoint k = KR[t0 + j];
+      const float r = 2.0f * st.scale[k.octave];
+      const int maxr = imin(imax((int)ceilf(k.y + r), -kStereoRowBias), 0x7fff - kStereoRowBias);
+      const int minr = imin(imax((int)floorf(k.y - r), -kStereoRowBias), 0x7fff - kStereoRowBias);
+      s_u[j] = k.x;
+      s_band[j] = (minr + kStereoRowBias) | ((maxr + kStereoRowBias) << 16);
+      s_oct[j] = (uint8_t)k.octave;
     }
+    __syncthreads();
+    if (searching)
+      for (int j = 0; j < nt; ++j) {
+        const int band = s_band[j];
+        if (rowb < (band & 0xffff) || rowb > (band >> 16)) continue;
+        const int octR = s_oct[j];
+        if (octR < levelL - 1 || octR > levelL + 1) continue;
+        const float uR = s_u[j];
+        if (!(uR >= minU && uR <= maxU)) continue;
+        const unsigned long long* t = DR + 4 * (size_t)(t0 + j);
+        const int dist = __popcll(q0 ^ t[0]) + __popcll(q1 ^ t[1]) + __popcll(q2 ^ t[2]) + __popcll(q3 ^ t[3]);
+        if (dist < bestDist) { bestDist = dist; bestIdxR = t0 + j; }
+      }
+  }
+  if (!live) return;
+  if (searching) {
     if (bestDist < 75 /* (TH_HIGH + TH_LOW) / 2 */) {
       const float uR0 = KR[bestIdxR].x;
       const float scaleFactor = st.inv_scale[levelL];

@@ -629,7 +629,20 @@ __host__ __device__ __forceinline__ void quat_rotate(const float q[4], float px,
   *rx = px + q[3] * ux + cx; *ry = py + q[3] * uy + cy; *rz = pz + q[3] * uz + cz;
 }
 
-// visits the candidates of a point that pass the static tests of GetFeaturesInArea + the stereo check (ORBmatcher.cc:1749-1755)
+// the static tests of GetFeaturesInArea + the stereo check (ORBmatcher.cc:1749-1755) for feature c of a point's window
+__device__ __forceinline__ bool window_accepts(const ProjDev& P, const float4& w, const int4& r, bool check_levels, int c) {
+  if (check_levels) {
+    const int o = P.oct2[c];
+    if (o < r.z) return false;
+    if (r.w >= 0 && o > r.w) return false;
+  }
+  const float dx = P.xy2[2 * c] - w.x, dy = P.xy2[2 * c + 1] - w.y;
+  if (!(fabsf(dx) < w.z && fabsf(dy) < w.z)) return false;
+  const float ur = P.ur2 ? P.ur2[c] : -1.f;  // no stereo coordinate test in the key-frame overload
+  if (ur > 0 && fabsf(w.w - ur) > w.z) return false;
+  return true;
+}
+// visits the candidates of a point that pass those tests, in the reference's traversal order (one work-item walks the window)
 template <class F>
 __device__ __forceinline__ void for_candidates(const ProjDev& P, const float4& w, const int4& r, F&& f) {
   const int x0 = r.x & 0xff, x1 = r.x >> 8, y0 = r.y & 0xff, y1 = r.y >> 8;
@@ -640,18 +653,46 @@ __device__ __forceinline__ void for_candidates(const ProjDev& P, const float4& w
       const uint32_t kb = P.cell_start[cell], ke = P.cell_start[cell + 1];
       for (uint32_t k = kb; k < ke; ++k) {
         const int c = P.cell_items[k];
-        if (check_levels) {
-          const int o = P.oct2[c];
-          if (o < r.z) continue;
-          if (r.w >= 0 && o > r.w) continue;
-        }
-        const float dx = P.xy2[2 * c] - w.x, dy = P.xy2[2 * c + 1] - w.y;
-        if (!(fabsf(dx) < w.z && fabsf(dy) < w.z)) continue;
-        const float ur = P.ur2 ? P.ur2[c] : -1.f;  // no stereo coordinate test in the key-frame overload
-        if (ur > 0 && fabsf(w.w - ur) > w.z) continue;
-        f(c, cell);
+        if (window_accepts(P, w, r, check_levels, c)) f(c, cell);
       }
     }
+}
+// The same walk by a whole WAVE (round 6: a work-item per point ran ~100 dependent gathers one after the other - 200 us for a
+// frame's 2000 points): the window's cells go to the lanes in traversal order (cell t of the walk: ix = x0 + t / ny,
+// iy = y0 + t % ny), 64 at a time, a lane takes its cell's features.  pred(c) says whether the feature is a candidate, the
+// candidates' ranks in traversal order come from one DPP prefix sum per 64 cells, key_of(c, cell) is evaluated for the first
+// kProjCand of them and stored at its rank: the list a single work-item would have written.  Returns the number of
+// candidates (wave-uniform).  All 64 lanes must call it.
+template <class Pred, class KeyOf>
+__device__ __forceinline__ int wave_candidates(const ProjDev& P, const float4& w, const int4& r, unsigned long long* list, Pred&& pred,
+                                               KeyOf&& key_of) {
+  const int lane = lane_id();
+  const int x0 = r.x & 0xff, x1 = r.x >> 8, y0 = r.y & 0xff, y1 = r.y >> 8, ny = y1 - y0 + 1, ncells = (x1 - x0 + 1) * ny;
+  const bool check_levels = (r.z > 0) || (r.w >= 0);
+  int base = 0;
+  for (int t0 = 0; t0 < ncells; t0 += 64) {
+    const int t = t0 + lane;
+    uint32_t kb = 0, ke = 0;
+    int cell = 0;
+    if (t < ncells) {
+      cell = (x0 + t / ny) * kGridRows + y0 + t % ny;
+      kb = P.cell_start[cell]; ke = P.cell_start[cell + 1];
+    }
+    int cnt = 0;
+    for (uint32_t k = kb; k < ke; ++k) {
+      const int c = P.cell_items[k];
+      cnt += (window_accepts(P, w, r, check_levels, c) && pred(c)) ? 1 : 0;
+    }
+    const int incl = wave_inclusive_scan(cnt);
+    int pos = base + incl - cnt;
+    base += __shfl(incl, 63);
+    if (cnt > 0 && pos < kProjCand)
+      for (uint32_t k = kb; k < ke && pos < kProjCand; ++k) {
+        const int c = P.cell_items[k];
+        if (window_accepts(P, w, r, check_levels, c) && pred(c)) list[pos++] = key_of(c, cell);
+      }
+  }
+  return base;
 }
 __device__ __forceinline__ unsigned long long proj_key(int dist, int cell, int c) {
   // strict '<' over the traversal (cells x-major, feature index inside a cell) == minimum of this key
@@ -700,14 +741,15 @@ __global__ __launch_bounds__(kProjBS) void k_proj_grid(ProjDev P) {
   }
 }
 
-// grid = ceil(n1 / 64), block = 64: projection and search window of every LastFrame map point (ORBmatcher.cc:1696-1735),
-// then its viable candidates
-__global__ __launch_bounds__(64) void k_proj_candidates(ProjDev P) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
+// grid = ceil(n1 / 4), block = 256 = one wave per LastFrame map point: projection and search window (ORBmatcher.cc:1696-1735,
+// computed by every lane alike), then its viable candidates by wave_candidates
+constexpr int kPointsPerBlock = 4;
+__global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P) {
+  const int i = blockIdx.x * kPointsPerBlock + wave_id();
   if (i >= P.n1) return;
+  const int lane = lane_id();
   uint8_t st = 1;
   int n = 0;
-  P.choice[i] = -1;
   if (P.valid1[i]) {
     float x, y, z;
     if (P.sim3_mode) {
@@ -743,24 +785,18 @@ __global__ __launch_bounds__(64) void k_proj_candidates(ProjDev P) {
       if (x0 < kGridCols && x1 >= 0 && y0 < kGridRows && y1 >= 0) {
         const float4 w = make_float4(u, v, radius, u - P.mbf * invzc);
         const int4 r = make_int4(x0 | (x1 << 8), y0 | (y1 << 8), min_level, max_level);
-        P.win[i] = w;
-        P.rng[i] = r;
         const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
         const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
-        int total = 0;
-        for_candidates(P, w, r, [&](int c, int cell) {
-          const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
-          if (dist > P.max_dist) return;
-          if (total < kProjCand) P.cand[(size_t)i * kProjCand + total] = proj_key(dist, cell, c);
-          ++total;
-        });
+        auto dist_of = [&](int c) { return hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)); };
+        const int total = wave_candidates(P, w, r, P.cand + (size_t)i * kProjCand, [&](int c) { return dist_of(c) <= P.max_dist; },
+                                          [&](int c, int cell) { return proj_key(dist_of(c), cell, c); });
+        if (lane == 0) { P.win[i] = w; P.rng[i] = r; }
         n = total <= kProjCand ? total : (kProjCand | kProjOverflow);
         st = total > 0 ? 0 : 1;  // no viable candidate: bestDist > TH_HIGH whatever the others do
       }
     }
   }
-  P.ncand[i] = (uint8_t)n;
-  P.state[i] = st;
+  if (lane == 0) { P.choice[i] = -1; P.ncand[i] = (uint8_t)n; P.state[i] = st; }
 }
 
 // smallest key of point i among the features not held by a lower-index blocker (~0 = none)
@@ -930,13 +966,13 @@ struct LocalScan {
   }
 };
 
-// grid = ceil(n1 / 64), block = 64
-__global__ __launch_bounds__(64) void k_local_candidates(ProjDev P) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
+// grid = ceil(n1 / 4), block = 256 = one wave per map point
+__global__ __launch_bounds__(256) void k_local_candidates(ProjDev P) {
+  const int i = blockIdx.x * kPointsPerBlock + wave_id();
   if (i >= P.n1) return;
+  const int lane = lane_id();
   uint8_t st = 1;
   int n = 0;
-  P.choice[i] = -1;
   if (P.valid1[i]) {
     const int level = P.level1[i];
     float r = (double)P.viewcos1[i] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos: the literal is a double in the reference
@@ -951,25 +987,19 @@ __global__ __launch_bounds__(64) void k_local_candidates(ProjDev P) {
       if (x0 < kGridCols && x1 >= 0 && y0 < kGridRows && y1 >= 0) {
         const float4 w = make_float4(x, y, radius, P.proj1[3 * i + 2]);
         const int4 rg = make_int4(x0 | (x1 << 8), y0 | (y1 << 8), level - 1, level);
-        P.win[i] = w;
-        P.rng[i] = rg;
         const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
         const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
-        int total = 0;
-        for_candidates(P, w, rg, [&](int c, int) {
-          if (total < kProjCand) {
-            const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
-            P.cand[(size_t)i * kProjCand + total] = ((unsigned long long)dist << 32) | ((unsigned long long)P.oct2[c] << 16) | (unsigned)c;
-          }
-          ++total;
+        const int total = wave_candidates(P, w, rg, P.cand + (size_t)i * kProjCand, [](int) { return true; }, [&](int c, int) {
+          const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
+          return ((unsigned long long)dist << 32) | ((unsigned long long)P.oct2[c] << 16) | (unsigned)c;
         });
+        if (lane == 0) { P.win[i] = w; P.rng[i] = rg; }
         n = total <= kProjCand ? total : (kProjCand | kProjOverflow);
         st = total > 0 ? 0 : 1;
       }
     }
   }
-  P.ncand[i] = (uint8_t)n;
-  P.state[i] = st;
+  if (lane == 0) { P.choice[i] = -1; P.ncand[i] = (uint8_t)n; P.state[i] = st; }
 }
 
 // visits the candidates of point i that no lower-index blocker holds, in traversal order: f(dist, level, c)
@@ -1956,7 +1986,7 @@ int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* o
   hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
   m->timer.end(s);
   m->timer.begin("k_proj_candidates", s);
-  hipLaunchKernelGGL(k_proj_candidates, dim3((n1 + 63) / 64), dim3(64), 0, s, P);
+  hipLaunchKernelGGL(k_proj_candidates, dim3((n1 + kPointsPerBlock - 1) / kPointsPerBlock), dim3(256), 0, s, P);
   m->timer.end(s);
   m->timer.begin("k_proj_resolve", s);
   hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(kProjBS), 0, s, P);
@@ -2245,7 +2275,7 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
   hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
   m->timer.end(s);
   m->timer.begin("k_local_candidates", s);
-  hipLaunchKernelGGL(k_local_candidates, dim3((n1 + 63) / 64), dim3(64), 0, s, P);
+  hipLaunchKernelGGL(k_local_candidates, dim3((n1 + kPointsPerBlock - 1) / kPointsPerBlock), dim3(256), 0, s, P);
   m->timer.end(s);
   m->timer.begin("k_local_resolve", s);
   hipLaunchKernelGGL(k_local_resolve, dim3(1), dim3(kProjBS), 0, s, P);

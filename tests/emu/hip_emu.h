@@ -68,6 +68,7 @@ struct Fiber {
   bool done = false;
   emu_uint3 tidx{0, 0, 0};
   char* stack = nullptr;
+  void* tsan = nullptr;   // ThreadSanitizer's view of this fiber (-fsanitize=thread builds only)
 };
 
 struct Block {
@@ -83,6 +84,7 @@ struct Block {
   unsigned phase = 0;
   std::function<void()> body;
   Fiber* cur = nullptr;
+  void* tsan_sched = nullptr;
 };
 
 extern thread_local Block* g_blk;
@@ -353,6 +355,19 @@ inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t /*shmem*/
 }
 
 #ifdef HIP_EMU_IMPLEMENTATION
+// ThreadSanitizer does not follow swapcontext by itself: every switch is announced (tests/test_shim_threads.py builds the
+// emulator with -fsanitize=thread to check the library's host code under the reference's concurrent callers)
+#if defined(__SANITIZE_THREAD__)
+extern "C" {
+void* __tsan_get_current_fiber(void);
+void* __tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void* fiber);
+void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+}
+#define HIPEMU_TSAN_SWITCH(f) __tsan_switch_to_fiber((f), 0)
+#else
+#define HIPEMU_TSAN_SWITCH(f) ((void)0)
+#endif
 thread_local emu_uint3 threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
 namespace hipemu {
@@ -361,6 +376,7 @@ thread_local Block* g_blk = nullptr;
 void yield_to_scheduler() {
   Block* b = cur_block();
   Fiber* f = b->cur;
+  HIPEMU_TSAN_SWITCH(b->tsan_sched);
   swapcontext(&f->ctx, &b->sched);
 }
 
@@ -379,15 +395,15 @@ static void fiber_entry() {
   release(b->bar, b->active);
   release(b->wbar[2 * w], b->wave_active[w]);
   release(b->wbar[2 * w + 1], b->wave_active[w]);
+  HIPEMU_TSAN_SWITCH(b->tsan_sched);
   swapcontext(&f->ctx, &b->sched);
 }
 
 static int order_mode() {
-  static int m = -1;
-  if (m < 0) {
+  static const int m = [] {   // initialised once, thread-safely: kernels of several host threads get here concurrently
     const char* e = getenv("RGBL_EMU_ORDER");
-    m = !e ? 0 : !strcmp(e, "asc") ? 1 : !strcmp(e, "desc") ? 2 : !strcmp(e, "shuffle") ? 3 : 0;
-  }
+    return !e ? 0 : !strcmp(e, "asc") ? 1 : !strcmp(e, "desc") ? 2 : !strcmp(e, "shuffle") ? 3 : 0;
+  }();
   return m;
 }
 
@@ -422,7 +438,14 @@ void run_block(Block& b, const dim3& block) {
     f.ctx.uc_stack.ss_size = STACK;
     f.ctx.uc_link = nullptr;
     makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+#if defined(__SANITIZE_THREAD__)
+    if (f.tsan) __tsan_destroy_fiber(f.tsan);   // a fresh context is a fresh fiber for the sanitizer
+    f.tsan = __tsan_create_fiber(0);
+#endif
   }
+#if defined(__SANITIZE_THREAD__)
+  b.tsan_sched = __tsan_get_current_fiber();
+#endif
   cur_block() = &b;
   std::vector<int> order(T);
   unsigned rng = 12345u + blockIdx.x * 977u;
@@ -438,6 +461,7 @@ void run_block(Block& b, const dim3& block) {
       if (f.done) continue;
       b.cur = &f;
       threadIdx = f.tidx;
+      HIPEMU_TSAN_SWITCH(f.tsan);
       swapcontext(&b.sched, &f.ctx);
       if (mode == 0 && b.phase != phase0) break;  // a rendezvous completed: flip the order
     }
