@@ -9,7 +9,7 @@
 //        extracting; every thread also provokes an error now and then and must read ITS OWN message from rgbl_last_error().
 // Every concurrent result must equal the sequential run of the same call; the sequential results are written to <out.bin>
 // for the Python side to hold against the oracle.  Exit code 0 = all equal.
-//   shim_threads_test <w> <h> <left.raw> <right.raw> <tri.bin> <proj.bin> <iters> <out.bin>
+//   shim_threads_test <w> <h> <left.raw> <right.raw> <tri.bin> <proj.bin> <iters> <out.bin> [<nfeatures> <nlevels>]
 #include <stdlib.h>
 #include <string.h>
 
@@ -116,10 +116,10 @@ int main(int argc, char** argv) {
   fclose(f);
   ProjCase pc;
   if (!pc.load(argv[6])) return 5;
-  const int nfeat = w >= 1000 ? 2000 : 500;
+  const int nfeat = argc > 9 ? atoi(argv[9]) : (w >= 1000 ? 2000 : 500), nlevels = argc > 10 ? atoi(argv[10]) : 8;
 
   // ---- sequential reference results of this very library
-  ORB_SLAM3::ORBextractor exL(nfeat, 1.2f, 8, 20, 7), exR(nfeat, 1.2f, 8, 20, 7);  // Tracking.cc:1281-1287 (stereo thresholds)
+  ORB_SLAM3::ORBextractor exL(nfeat, 1.2f, nlevels, 20, 7), exR(nfeat, 1.2f, nlevels, 20, 7);  // Tracking.cc:1281-1287 (stereo thresholds)
   Extraction seqL, seqR;
   extract(&exL, &left, &seqL);
   extract(&exR, &right, &seqR);

@@ -75,11 +75,14 @@ def test_serialised_kernel_table_is_stable(gpu_lib):
         _, stats = bench.serial_kernel_leg(pipe, 12)
         pipe.close()
         return stats
-    a = table(False)
-    b = table(True)
-    for k in a:
-        if a[k]["median"] > 0.1 * B / 512:
-            assert abs(a[k]["median"] - b[k]["median"]) <= 0.15 * a[k]["median"], (k, a[k], b[k])
+    # the GPU is shared with the other pytest-xdist workers of a `-n 4` run: a comparison of two timings gets up to three tries
+    for attempt in range(3):
+        a = table(False)
+        b = table(True)
+        off = [(k, a[k], b[k]) for k in a if a[k]["median"] > 0.1 * B / 512 and abs(a[k]["median"] - b[k]["median"]) > 0.15 * a[k]["median"]]
+        if not off:
+            break
+    assert not off, off
     # the outlier itself is real and stays visible as `max` / `max_at_step` (one step in twelve took 2.4 x when this test was
     # written); what the table reports - the median - sits within 15 % of the fastest step
     print("k_hamming_fp4 per-step stats: fresh", a["k_hamming_fp4"], "after load", b["k_hamming_fp4"])

@@ -89,11 +89,12 @@ def write_inputs(tmp, w, h, n_tri, n1, n2):
     return left, right, (kf1, kf2, Fm, ep, sf, s2), case
 
 
-def run_and_check(exe, tmp, w, h, iters, n_tri=1200, n1=1500, n2=1700, env=None):
+def run_and_check(exe, tmp, w, h, iters, n_tri=1200, n1=1500, n2=1700, env=None, nfeat=None, nlevels=8, small=False):
     left, right, tri, case = write_inputs(tmp, w, h, n_tri, n1, n2)
     out = os.path.join(tmp, "threads_out.bin")
     res = subprocess.run([exe, str(w), str(h), os.path.join(tmp, "left.raw"), os.path.join(tmp, "right.raw"), os.path.join(tmp, "tri.bin"),
-                          os.path.join(tmp, "proj.bin"), str(iters), out], capture_output=True, text=True, timeout=1500, env=env)
+                          os.path.join(tmp, "proj.bin"), str(iters), out, str(nfeat or (2000 if w >= 1000 else 500)), str(nlevels)],
+                         capture_output=True, text=True, timeout=1500, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-6000:]
     assert "threads ok" in res.stdout and " 0 mismatches" in res.stdout
     # the sequential results the threads were held to, against the oracle
@@ -105,12 +106,12 @@ def run_and_check(exe, tmp, w, h, iters, n_tri=1200, n1=1500, n2=1700, env=None)
         a = np.frombuffer(buf, dtype, count, pos)
         pos += a.nbytes
         return a
-    nfeat = 2000 if w >= 1000 else 500
+    nfeat = nfeat or (2000 if w >= 1000 else 500)
     descs = []
     for img in (left, right):
         mono, nk = take(np.int32, 2)
         kps, desc = take(O.KP_DTYPE, nk), take(np.uint8, nk * 32).reshape(nk, 32)
-        okps, odesc, omono = O.Extractor(nfeat, 1.2, 8, 20, 7)(img)
+        okps, odesc, omono = O.Extractor(nfeat, 1.2, nlevels, 20, 7)(img)
         pc.assert_keypoints_equal(kps, okps, "threaded extractor")
         assert np.array_equal(desc, odesc) and mono == omono
         descs.append(desc)
@@ -119,11 +120,11 @@ def run_and_check(exe, tmp, w, h, iters, n_tri=1200, n1=1500, n2=1700, env=None)
     kf1, kf2, Fm, ep, sf, s2 = tri
     om12, onm = O.search_triangulation(kf1, kf2, Fm, ep, sf, s2, False, False, False)
     idx1 = np.nonzero(om12 >= 0)[0]
-    assert nm == onm == npairs and np.array_equal(pairs[:, 0], idx1) and np.array_equal(pairs[:, 1], om12[idx1]) and nm > 20
+    assert nm == onm == npairs and np.array_equal(pairs[:, 0], idx1) and np.array_equal(pairs[:, 1], om12[idx1]) and nm > (2 if small else 20)
     pn, n2_ = take(np.int32, 2)
     m2 = take(np.int32, n2_)
     om, on = O.search_by_projection(case, 15.0, False, True)
-    assert pn == on and np.array_equal(m2, om) and on > 100
+    assert pn == on and np.array_equal(m2, om) and on > (5 if small else 100)
     nbf = take(np.int32, 1)[0]
     bi, bd, sd = take(np.int32, nbf), take(np.int32, nbf), take(np.int32, nbf)
     obi, obd, osd = O.hamming_bf(descs[0], descs[1])
@@ -142,8 +143,10 @@ def test_threads_under_thread_sanitizer(oracle, tmp_path):
     lib = build_tsan_emulator()
     exe = os.path.join(BUILD, "shim_threads_test_tsan")
     build_exe(BUILD, "rgbl_frontend_emu_thread", exe, extra=("-fsanitize=thread",))
-    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66 second_deadlock_stack=1", RGBL_EMU_THREADS="4")
-    res = run_and_check(exe, str(tmp_path), 400, 250, 2, n_tri=300, n1=300, n2=400, env=env)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66 second_deadlock_stack=1")
+    # the emulator's fibers are slow under TSan (every work-item switch is announced): a 96 x 80 image, one pyramid level, one
+    # round - five extractions and two calls of every matcher, ~2 minutes
+    res = run_and_check(exe, str(tmp_path), 96, 80, 1, n_tri=60, n1=60, n2=80, env=env, nfeat=60, nlevels=1, small=True)
     assert "ThreadSanitizer" not in res.stderr, res.stderr[-6000:]
     assert os.path.exists(lib)
 
