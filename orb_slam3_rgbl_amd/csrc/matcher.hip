@@ -800,20 +800,20 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P) {
 }
 
 // smallest key of point i among the features not held by a lower-index blocker (~0 = none)
-__device__ __forceinline__ unsigned long long proj_best(const ProjDev& P, int i) {
+__device__ __forceinline__ unsigned long long proj_best(const ProjDev& P, const int32_t* taken_by, int i) {
   unsigned long long best = ~0ull;
   const int n = P.ncand[i];
   if (!(n & kProjOverflow)) {
     for (int k = 0; k < n; ++k) {
       const unsigned long long key = P.cand[(size_t)i * kProjCand + k];
-      if (P.taken_by[(int)(key & 0xffffu)] >= i && key < best) best = key;
+      if (taken_by[(int)(key & 0xffffu)] >= i && key < best) best = key;
     }
     return best;
   }
   const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
   const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
   for_candidates(P, P.win[i], P.rng[i], [&](int c, int cell) {
-    if (P.taken_by[c] < i) return;
+    if (taken_by[c] < i) return;
     const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
     if (dist > P.max_dist) return;
     const unsigned long long key = proj_key(dist, cell, c);
@@ -822,47 +822,62 @@ __device__ __forceinline__ unsigned long long proj_best(const ProjDev& P, int i)
   return best;
 }
 
-// grid = 1, block = kProjBS
+// grid = 1, block = kProjBS.  LDS = true (frames of up to kResolveLdsN2 features, kResolveLdsN1 points: every KITTI-size call):
+// who holds a feature, the lowest unresolved blocker per feature and the points' states live in LDS for the whole kernel - a
+// round is three passes over them, and with the arrays in global memory every pass was a chain of dependent ~1 us loads
+// (round 6: 8 rounds of 17 us for a frame's 2000 points).
+constexpr int kResolveLdsN2 = 6144, kResolveLdsN1 = 12288;
+template <bool LDS>
 __global__ __launch_bounds__(kProjBS) void k_proj_resolve(ProjDev P) {
   __shared__ int s_unres;
+  __shared__ int32_t s_taken[LDS ? kResolveLdsN2 : 1], s_min[LDS ? kResolveLdsN2 : 1];
+  __shared__ uint8_t s_state[LDS ? kResolveLdsN1 : 1];
+  int32_t* taken_by = LDS ? s_taken : P.taken_by;
+  int32_t* min_unres = LDS ? s_min : P.min_unres;
+  uint8_t* state = LDS ? s_state : P.state;
   const int tid = threadIdx.x;
+  if (LDS) {
+    for (int c = tid; c < P.n2; c += kProjBS) s_taken[c] = P.taken_by[c];
+    for (int i = tid; i < P.n1; i += kProjBS) s_state[i] = P.state[i];
+    __syncthreads();
+  }
   for (int round = 0; round <= P.n1; ++round) {
-    for (int c = tid; c < P.n2; c += kProjBS) P.min_unres[c] = INT_MAX;
+    for (int c = tid; c < P.n2; c += kProjBS) min_unres[c] = INT_MAX;
     if (tid == 0) s_unres = 0;
     __syncthreads();
     // every unresolved blocker announces itself on the features it may still take
     for (int i = tid; i < P.n1; i += kProjBS) {
-      if (P.state[i] != 0 || !P.obs1[i]) continue;
+      if (state[i] != 0 || !P.obs1[i]) continue;
       const int n = P.ncand[i];
       if (!(n & kProjOverflow)) {
         for (int k = 0; k < n; ++k) {
           const int c = (int)(P.cand[(size_t)i * kProjCand + k] & 0xffffu);
-          if (P.taken_by[c] >= i) atomicMin(&P.min_unres[c], i);
+          if (taken_by[c] >= i) atomicMin(&min_unres[c], i);
         }
       } else {
         const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
         const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
         for_candidates(P, P.win[i], P.rng[i], [&](int c, int) {
-          if (P.taken_by[c] < i) return;
-          if (hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)) <= P.max_dist) atomicMin(&P.min_unres[c], i);
+          if (taken_by[c] < i) return;
+          if (hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)) <= P.max_dist) atomicMin(&min_unres[c], i);
         });
       }
     }
     __syncthreads();
     for (int i = tid; i < P.n1; i += kProjBS) {
-      if (P.state[i] != 0) continue;
-      const unsigned long long best = proj_best(P, i);
+      if (state[i] != 0) continue;
+      const unsigned long long best = proj_best(P, taken_by, i);
       const int c = (int)(best & 0xffffu);
-      if (best == ~0ull) { P.state[i] = 2; P.choice[i] = -1; }           // everything viable is taken: no match
-      else if (P.min_unres[c] >= i) { P.state[i] = 2; P.choice[i] = c; }  // nobody in front of i can still take c
+      if (best == ~0ull) { state[i] = 2; P.choice[i] = -1; }           // everything viable is taken: no match
+      else if (min_unres[c] >= i) { state[i] = 2; P.choice[i] = c; }  // nobody in front of i can still take c
       else atomicAdd(&s_unres, 1);
     }
     __syncthreads();
     for (int i = tid; i < P.n1; i += kProjBS) {
-      if (P.state[i] != 2) continue;
-      P.state[i] = 1;
+      if (state[i] != 2) continue;
+      state[i] = 1;
       const int c = P.choice[i];
-      if (c >= 0 && P.obs1[i]) P.taken_by[c] = i;  // two blockers can never become final on one feature in the same round
+      if (c >= 0 && P.obs1[i]) taken_by[c] = i;  // two blockers can never become final on one feature in the same round
     }
     __syncthreads();
     if (s_unres == 0) break;
@@ -1004,54 +1019,65 @@ __global__ __launch_bounds__(256) void k_local_candidates(ProjDev P) {
 
 // visits the candidates of point i that no lower-index blocker holds, in traversal order: f(dist, level, c)
 template <class F>
-__device__ __forceinline__ void local_available(const ProjDev& P, int i, F&& f) {
+__device__ __forceinline__ void local_available(const ProjDev& P, const int32_t* taken_by, int i, F&& f) {
   const int n = P.ncand[i];
   if (!(n & kProjOverflow)) {
     for (int k = 0; k < n; ++k) {
       const unsigned long long key = P.cand[(size_t)i * kProjCand + k];
       const int c = (int)(key & 0xffffu);
-      if (P.taken_by[c] >= i) f((int)(key >> 32), (int)((key >> 16) & 0xffffu), c);
+      if (taken_by[c] >= i) f((int)(key >> 32), (int)((key >> 16) & 0xffffu), c);
     }
     return;
   }
   const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
   const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
   for_candidates(P, P.win[i], P.rng[i], [&](int c, int) {
-    if (P.taken_by[c] < i) return;
+    if (taken_by[c] < i) return;
     f(hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)), P.oct2[c], c);
   });
 }
 
-// grid = 1, block = kProjBS
+// grid = 1, block = kProjBS; LDS as for k_proj_resolve
+template <bool LDS>
 __global__ __launch_bounds__(kProjBS) void k_local_resolve(ProjDev P) {
   __shared__ int s_unres;
+  __shared__ int32_t s_taken[LDS ? kResolveLdsN2 : 1], s_min[LDS ? kResolveLdsN2 : 1];
+  __shared__ uint8_t s_state[LDS ? kResolveLdsN1 : 1];
+  int32_t* taken_by = LDS ? s_taken : P.taken_by;
+  int32_t* min_unres = LDS ? s_min : P.min_unres;
+  uint8_t* state = LDS ? s_state : P.state;
   const int tid = threadIdx.x;
+  if (LDS) {
+    for (int c = tid; c < P.n2; c += kProjBS) s_taken[c] = P.taken_by[c];
+    for (int i = tid; i < P.n1; i += kProjBS) s_state[i] = P.state[i];
+    __syncthreads();
+  }
   for (int round = 0; round <= P.n1; ++round) {
-    for (int c = tid; c < P.n2; c += kProjBS) P.min_unres[c] = INT_MAX;
+    for (int c = tid; c < P.n2; c += kProjBS) min_unres[c] = INT_MAX;
     if (tid == 0) s_unres = 0;
     __syncthreads();
     for (int i = tid; i < P.n1; i += kProjBS) {
-      if (P.state[i] != 0 || !P.obs1[i]) continue;
-      local_available(P, i, [&](int dist, int, int c) { if (dist <= 100) atomicMin(&P.min_unres[c], i); });
+      if (state[i] != 0 || !P.obs1[i]) continue;
+      local_available(P, taken_by, i, [&](int dist, int, int c) { if (dist <= 100) atomicMin(&min_unres[c], i); });
     }
     __syncthreads();
     for (int i = tid; i < P.n1; i += kProjBS) {
-      if (P.state[i] != 0) continue;
+      if (state[i] != 0) continue;
       LocalScan sc;
       bool settled = true;
-      local_available(P, i, [&](int dist, int level, int c) {
+      local_available(P, taken_by, i, [&](int dist, int level, int c) {
         sc.visit(dist, level, c);
-        if (P.min_unres[c] < i) settled = false;  // somebody in front of i may still take this feature
+        if (min_unres[c] < i) settled = false;  // somebody in front of i may still take this feature
       });
-      if (settled) { P.state[i] = 2; P.choice[i] = sc.accept(P.nnratio); }
+      if (settled) { state[i] = 2; P.choice[i] = sc.accept(P.nnratio); }
       else atomicAdd(&s_unres, 1);
     }
     __syncthreads();
     for (int i = tid; i < P.n1; i += kProjBS) {
-      if (P.state[i] != 2) continue;
-      P.state[i] = 1;
+      if (state[i] != 2) continue;
+      state[i] = 1;
       const int c = P.choice[i];
-      if (c >= 0 && P.obs1[i]) P.taken_by[c] = i;
+      if (c >= 0 && P.obs1[i]) taken_by[c] = i;
     }
     __syncthreads();
     if (s_unres == 0) break;
@@ -1989,7 +2015,8 @@ int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* o
   hipLaunchKernelGGL(k_proj_candidates, dim3((n1 + kPointsPerBlock - 1) / kPointsPerBlock), dim3(256), 0, s, P);
   m->timer.end(s);
   m->timer.begin("k_proj_resolve", s);
-  hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(kProjBS), 0, s, P);
+  if (n2 <= kResolveLdsN2 && n1 <= kResolveLdsN1) hipLaunchKernelGGL(k_proj_resolve<true>, dim3(1), dim3(kProjBS), 0, s, P);
+  else hipLaunchKernelGGL(k_proj_resolve<false>, dim3(1), dim3(kProjBS), 0, s, P);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
   RGBL_TRY(hc.fetch());
@@ -2278,7 +2305,8 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
   hipLaunchKernelGGL(k_local_candidates, dim3((n1 + kPointsPerBlock - 1) / kPointsPerBlock), dim3(256), 0, s, P);
   m->timer.end(s);
   m->timer.begin("k_local_resolve", s);
-  hipLaunchKernelGGL(k_local_resolve, dim3(1), dim3(kProjBS), 0, s, P);
+  if (n2 <= kResolveLdsN2 && n1 <= kResolveLdsN1) hipLaunchKernelGGL(k_local_resolve<true>, dim3(1), dim3(kProjBS), 0, s, P);
+  else hipLaunchKernelGGL(k_local_resolve<false>, dim3(1), dim3(kProjBS), 0, s, P);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
   RGBL_TRY(hc.fetch());

@@ -411,3 +411,9 @@ def test_prioritised_streams_carry_work(emu_lib):
 def test_device_resident_frames(emu_lib):
     """rgbl_device_frame: upload / capture / FeatureVector, and every matcher entry point that takes one."""
     assert pc.check_device_frames(emu_lib, n=500, nfeatures=400, w=400, h=300)
+
+
+def test_projection_searches_beyond_the_lds_resolve(emu_lib):
+    """Frames / point sets above kResolveLdsN2 / kResolveLdsN1 take the resolve kernels' global-memory form."""
+    assert pc.check_search_by_projection(emu_lib, 27, "forward", 15.0, False, True, n1=900, n2=6500) > 100
+    assert pc.check_search_local_points(emu_lib, 48, 3.0, 0.8, n1=12400, n2=1500) > 100

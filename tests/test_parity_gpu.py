@@ -468,3 +468,9 @@ def test_device_resident_frames(gpu_lib):
     Frame::UndistortKeyPoints) / FeatureVector, and every matcher entry point that takes a resident frame == the host-array
     call == the oracle."""
     assert pc.check_device_frames(gpu_lib, n=2000, nfeatures=2000, w=1241, h=376)
+
+
+def test_projection_searches_beyond_the_lds_resolve(gpu_lib):
+    """Frames / point sets above kResolveLdsN2 / kResolveLdsN1 take the resolve kernels' global-memory form."""
+    assert pc.check_search_by_projection(gpu_lib, 27, "forward", 15.0, False, True, n1=2500, n2=8000) > 300
+    assert pc.check_search_local_points(gpu_lib, 48, 3.0, 0.8, n1=13000, n2=3000) > 300
