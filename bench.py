@@ -109,7 +109,7 @@ def algorithmic_bytes(kernel, w, h, n_points, k_per_frame):
     return table.get(kernel)
 
 
-TRAFFIC_FILES = {"kitti": ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"), "4k": ("r05_pmc_traffic_4k.json", "r04_pmc_traffic_4k.json", "r03_pmc_traffic_4k.json")}
+TRAFFIC_FILES = {"kitti": ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"), "4k": ("r06_pmc_traffic_4k.json", "r05_pmc_traffic_4k.json", "r04_pmc_traffic_4k.json", "r03_pmc_traffic_4k.json")}
 CLOCK_HZ, SIMDS = 2.4e9, 1024     # MI355X: 256 CUs x 4 SIMDs, one VALU instruction of a wave64 per 4 cycles and SIMD
 
 
@@ -138,7 +138,29 @@ def pmc_traffic(prof, kernel, frames_per_launch, launches_per_step):
         return None
 
 
-def roofline_of(kernels, prof_steps, workload, w, h, n_points, k_mean, B, step_s=None):
+def measured_copy_ceiling(torch, dev, gib=1, reps=6):
+    """SURVEY 8(d) "% of a measured device-copy ceiling": a device-to-device copy of `gib` GiB timed in THIS run (HIP events on
+    the current stream), bytes read + bytes written per second.  /opt/skills/guides/MI355X_MICROARCH.md measured 6.29 TB/s."""
+    n = gib << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev)
+    dst = torch.empty(n, dtype=torch.uint8, device=dev)
+    src.fill_(1)
+    dst.copy_(src)
+    torch.cuda.synchronize(dev)
+    best = None
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        dst.copy_(src)
+        b.record()
+        b.synchronize()
+        ms = a.elapsed_time(b)
+        best = ms if best is None else min(best, ms)
+    del src, dst
+    return 2.0 * n / (best * 1e-3) / 1e9
+
+
+def roofline_of(kernels, prof_steps, workload, w, h, n_points, k_mean, B, step_s=None, copy_ceiling=None):
     """The roofline object of the dominant kernel (largest share of the serialised GPU time) from per-kernel HIP-event times
     {name: (ms summed over prof_steps steps, launches)}: algorithmic bytes over its own time against the 8 TB/s
     of HBM3E - for every kernel of the step as well (`per_kernel_hbm`) -, the HBM-side traffic of the committed counter passes,
@@ -161,13 +183,29 @@ def roofline_of(kernels, prof_steps, workload, w, h, n_points, k_mean, B, step_s
          "algorithmic_bytes_per_frame": ab, "frames_per_launch": B,
          "kernel_share_of_gpu_time": ms_sum / total_ms if total_ms else None,
          "kernels_ms_per_step": {k: v[0] / prof_steps for k, v in sorted(kernels.items())}}
+    if copy_ceiling:
+        r["peak_measured"] = round(copy_ceiling, 1)
+        r["peak_measured_what"] = "device-to-device copy of 1 GiB timed in this run (read + written bytes per second); the guide's figure is 6290 GB/s"
+        r["frac_of_measured"] = (achieved / copy_ceiling) if achieved else None
     try:
         valu = prof["kernels"][dom]["valu_insts_per_step"] * B / prof["frames_per_step"]
         issue = valu * 4.0 / (per_step_ms * 1e-3 * CLOCK_HZ * SIMDS)
         r["valu_issue_frac"] = issue
+        r["valu_issue_frac_what"] = ("SQ_INSTS_VALU x 4 cycles / (kernel time x 2.4 GHz x 1024 SIMDs): the 4 cycles are what tools/micro/valu_rates "
+                                     "measures for the integer instructions these kernels are made of (0.20 - 0.25 wave-instructions per cycle and SIMD; "
+                                     "v_add 0.34), not the guide's 2-cycle issue of a wave64 operation - an upper bound for a mixed stream")
         r["valu_insts_per_pixel"] = valu * 64.0 / (ab * B) if dom == "k_fast_cells" else None
         r["valu_source"] = source + " (SQ_INSTS_VALU of this command, replayed) over this run's kernel time"
         if r["frac"] is not None and issue > r["frac"]:
+            r["bound"] = "valu"
+    except (KeyError, TypeError):
+        pass
+    try:
+        # the counter's own view: SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD issues vector work
+        quad = prof["kernels"][dom]["valu_active_quadcycles_per_step"] * B / prof["frames_per_step"]
+        r["valu_busy"] = quad * 4.0 / (per_step_ms * 1e-3 * CLOCK_HZ * SIMDS)
+        r["valu_busy_source"] = source + " (SQ_ACTIVE_INST_VALU x 4 cycles of this command, replayed) / (this run's kernel time x 2.4 GHz x 1024 SIMDs)"
+        if r["frac"] is not None and r["valu_busy"] > r["frac"]:
             r["bound"] = "valu"
     except (KeyError, TypeError):
         pass
@@ -178,6 +216,8 @@ def roofline_of(kernels, prof_steps, workload, w, h, n_points, k_mean, B, step_s
         if kb and v[0] > 0:
             gbs = kb * B / (v[0] / prof_steps * 1e-3) / 1e9
             per_kernel[k] = {"GB/s": round(gbs, 1), "frac": round(gbs / 8000.0, 4)}
+            if copy_ceiling:
+                per_kernel[k]["frac_of_measured"] = round(gbs / copy_ceiling, 4)
             step_bytes += kb * B
     r["per_kernel_hbm"] = per_kernel
     if step_s:
@@ -187,6 +227,9 @@ def roofline_of(kernels, prof_steps, workload, w, h, n_points, k_mean, B, step_s
         # the same over what the step's kernels actually have to move in this implementation (no zero fill: generation-tagged
         # index maps; no raw map): the sum of the per-kernel figures above
         r["step_kernel_sum_GB/s"] = round(step_bytes / step_s / 1e9, 1)
+        r["step_algorithmic_frac"] = round(r["step_algorithmic_GB/s"] / 8000.0, 4)
+        if copy_ceiling:
+            r["step_algorithmic_frac_of_measured"] = round(r["step_algorithmic_GB/s"] / copy_ceiling, 4)
     return r
 
 
@@ -447,7 +490,95 @@ def serial_kernel_leg(pipe, n_steps):
     return kernels, stats
 
 
-def extra_workloads(lib, dev, torch):
+def natural_frames(n, w, h):
+    """KITTI-size frames cut from a canvas tiled with the two committed photographs (tests/golden/natural_camera.png and
+    natural_brick.png, 512 x 512 grey, CC0 scikit-image samples; alternate tiles mirrored so that no seam adds an edge),
+    frame t = the window shifted by (3 t, t) px - the motion of synth.Sequence.  None when PIL or the files are missing."""
+    try:
+        from PIL import Image
+        imgs = [np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "natural_%s.png" % k)).convert("L"), np.uint8) for k in ("camera", "brick")]
+    except Exception:
+        return None
+    cw, ch = w + 3 * n + 8, h + n + 8
+    rows = []
+    for ty in range((ch + 511) // 512):
+        row = []
+        for tx in range((cw + 511) // 512):
+            t = imgs[(tx // 2 + ty // 2) % 2]
+            t = t[:, ::-1] if tx % 2 else t
+            t = t[::-1] if ty % 2 else t
+            row.append(t)
+        rows.append(np.concatenate(row, 1))
+    canvas = np.concatenate(rows, 0)[:ch, :cw]
+    return np.stack([np.ascontiguousarray(canvas[t:t + h, 3 * t:3 * t + w]) for t in range(n)])
+
+
+def prescreen_stats(img, t=INI_TH):
+    """Share of a level-0 image's pixels that pass k_fast_cells' necessary-condition test (each of the 4 opposite pairs at the
+    even ring positions has a darker / brighter member) and that really carry a 9-arc (numpy; one threshold)."""
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    hh, ww = img.shape
+    I = img.astype(np.int16)
+    c = I[3:hh - 3, 3:ww - 3]
+    R = [I[3 + dy:hh - 3 + dy, 3 + dx:ww - 3 + dx] for dx, dy in ring]
+    out = []
+    for F in ([r < c - t for r in R], [r > c + t for r in R]):
+        p4 = np.ones_like(F[0])
+        for k in (0, 2, 4, 6):
+            p4 &= F[k] | F[k + 8]
+        arc = np.zeros_like(F[0])
+        for s0 in range(16):
+            a = np.ones_like(F[0])
+            for j in range(9):
+                a &= F[(s0 + j) % 16]
+            arc |= a
+        out.append((p4, arc))
+    return {"prescreen_survivors": round(float((out[0][0] | out[1][0]).mean()), 4), "pixels_with_a_9_arc": round(float((out[0][1] | out[1][1]).mean()), 4)}
+
+
+def natural_texture_leg(lib, dev, torch, synth_frames, cloud_np, proj, n_points, synth_rate):
+    """extra.natural_texture: the headline step on frames tiled from photographs instead of the SURVEY 8(d) generator - how
+    far the synthetic corner density is from natural imagery, and what it does to the rate.  Never `value`."""
+    from orb_slam3_rgbl_amd import frontend as F
+    from orb_slam3_rgbl_amd.pipeline import FrontEndPipeline
+    from oracle import oracle_py as O
+    w, h, nf, _, _ = WORKLOADS["kitti"]
+    B = 256
+    frames_np = natural_frames(B, w, h)
+    if frames_np is None:
+        return {"skipped": "PIL or tests/golden/natural_*.png not available"}
+    cl = np.ascontiguousarray(cloud_np[:B]) if len(cloud_np) >= B else np.stack([cloud_np[i % len(cloud_np)] for i in range(B)])
+    pipe = FrontEndPipeline(lib, torch, dev, w, h, nf, proj, n_points, B, levels=LEVELS, scale=SCALE, ini_th=INI_TH, min_th=MIN_TH, gather="none")
+    d_f, d_c = torch.from_numpy(frames_np).to(dev), torch.from_numpy(cl).to(dev)
+    pipe.set_inputs(d_f, d_c)
+    dt = time_steps(pipe.step, pipe.sync, 3, 20)
+    k_mean = float(pipe.last().n.float().mean().item())
+    spot = spot_check(O, O.Extractor(nf, SCALE, LEVELS, INI_TH, MIN_TH), O.make_depth_params(proj), frames_np, cl, pipe.last(), [0, B - 1], w, h)
+    # the same B on the synthetic frames, same call, for the ratio
+    pipe.set_inputs(torch.from_numpy(np.ascontiguousarray(synth_frames[:B])).to(dev), d_c)
+    dt_s = time_steps(pipe.step, pipe.sync, 3, 20)
+    pipe.close()
+    # FAST candidates of level 0 (what cv::FAST returns over all cells, before the quad-tree) on a few frames, single-frame handle
+    ex = F.ORBextractor(nf, SCALE, LEVELS, INI_TH, MIN_TH, w, h, device=dev.index, lib=lib)
+    cand = {}
+    for name, fr in (("natural", frames_np), ("synthetic", synth_frames)):
+        c = []
+        for fi in (0, B // 2, B - 1):
+            ex(np.ascontiguousarray(fr[fi]))
+            c.append(len(ex.level_candidates(0)))
+        cand[name] = float(np.mean(c))
+    ex.close()
+    return {"frames_per_s": B / dt, "ms_per_step": dt * 1e3, "frames_per_step": B, "keypoints_per_frame": k_mean,
+            "synthetic_frames_per_s_same_call": B / dt_s, "natural_over_synthetic_rate": round(dt_s / dt, 4),
+            "level0_fast_candidates_per_frame": cand,
+            "level0_pixel_shares_at_iniThFAST": {"natural": prescreen_stats(frames_np[B // 2]), "synthetic": prescreen_stats(synth_frames[min(B // 2, len(synth_frames) - 1)])},
+            "parity_spot_check": spot, "headline_frames_per_s": synth_rate,
+            "what": "extract + depth + match of 256 KITTI-size frames cut from a canvas tiled with tests/golden/natural_camera.png / natural_brick.png "
+                    "(mirrored tiles, window shifted by (3 t, t) px), the synthetic scans; beside it the same 256-frame step on the first 256 "
+                    "synthetic frames of the headline.  The headline stays configs[1] on the SURVEY 8(d) generator"}
+
+
+def extra_workloads(lib, dev, torch, copy_ceiling=None):
     """Driver-visible figures for the other GPU configurations of BASELINE.json, measured in the same run on the same
     device (short runs; `value` stays the KITTI RGB-L configuration): configs[4] (4K frames + 262 144-point scans,
     nFeatures 8000), configs[2] (KITTI stereo: two extractions + Frame::ComputeStereoMatches), and the latency of the
@@ -493,7 +624,7 @@ def extra_workloads(lib, dev, torch):
                           "lidar_points": n_points, "keypoints_per_frame": k_mean, "distinct_frames_and_scans": B,
                           "parity_spot_check": spot,
                           "what": "extract + depth + match, inputs resident in HBM, 1 GPU",
-                          "roofline": roofline_of(kernels, 4, "4k", w, h, n_points, k_mean, B, dt)}
+                          "roofline": roofline_of(kernels, 4, "4k", w, h, n_points, k_mean, B, dt, copy_ceiling)}
         out["cfg5_4k"]["roofline"]["kernels_ms_per_step_stats"] = kstats
         pipe.close()
         del frames, cloud, pipe, frames_np, cloud_np
@@ -639,8 +770,6 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the 4K / stereo / single-frame figures (extra keys of the JSON line)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--serial", action="store_true", help="one stream for all handles (clean per-kernel timings)")
-    ap.add_argument("--lanes", type=int, default=1, choices=[1, 2],
-                    help="2: two sets of handles used alternately - two steps in flight (pipeline.py)")
     ap.add_argument("--gather", default=None, choices=["step", "final", "none"],
                     help="gather of the keypoint / descriptor / depth records to rank 0: stream every step's records while the "
                          "next step computes (default for N > 1), exchange all of them once at the end, or not at all (default "
@@ -733,7 +862,7 @@ def main():
     # orb_slam3_rgbl_amd/pipeline.py - the same code tests/test_distributed.py drives with two gloo ranks
     pipe = FrontEndPipeline(lib, torch, dev, w, h, nfeatures, proj, n_points, B, levels=LEVELS, scale=SCALE, ini_th=INI_TH,
                             min_th=MIN_TH, world=world, rank=rank, gather=gather, serial=args.serial,
-                            log_steps=args.steps + args.warmup, lanes=args.lanes, transport=args.transport, comm=comm,
+                            log_steps=args.steps + args.warmup, transport=args.transport, comm=comm,
                             loopback=(comm is not None and world == 1), halo=halo)
     ex, dm, mt, cap = pipe.ex, pipe.dm, pipe.mt, pipe.cap
     d_imgs = torch.from_numpy(frames).to(dev)
@@ -797,7 +926,7 @@ def main():
         spot = spot_check(O, orc, O.make_depth_params(proj), frames, cloud, last, sorted({0, B // 3, 2 * B // 3, B - 1}), w, h)
 
     # ---- opt-in variant, reported beside the headline only: no dense ProcessedDepthMap (rgbl_depth_set_sparse), the keypoints'
-    # depths come out of the index maps directly.  Same inputs, same lanes; depth / uRight must not change by a bit.
+    # depths come out of the index maps directly.  Same inputs; depth / uRight must not change by a bit.
     sparse_leg = None
     if world == 1 and not args.no_extras and not args.serial:
         ref_depth, ref_ur = d_depth.clone(), d_uright.clone()
@@ -822,12 +951,18 @@ def main():
     roofline = None
     cpu = None
     kernels = {}
+    copy_ceiling = None
     if rank == 0:
         # per-kernel timing leg: one stream for everything, so that the HIP-event brackets around each launch are not
         # stretched by other kernels running concurrently
         prof_steps = PROF_STEPS
         kernels, kernel_stats = serial_kernel_leg(pipe, prof_steps)
-        roofline = roofline_of(kernels, prof_steps, args.workload, w, h, n_points, k_mean, B, elapsed / args.steps)
+        try:
+            copy_ceiling = measured_copy_ceiling(torch, dev)
+        except Exception as e:   # the line stands without it
+            copy_ceiling = None
+            sys.stderr.write("copy ceiling not measured: %r\n" % (e,))
+        roofline = roofline_of(kernels, prof_steps, args.workload, w, h, n_points, k_mean, B, elapsed / args.steps, copy_ceiling)
         roofline["kernels_ms_per_step_stats"] = kernel_stats
         roofline["kernels_ms_per_step_what"] = ("median over %d serialised steps (HIP events on the launch stream, every step read back "
                                                 "on its own), min / max beside it" % prof_steps)
@@ -895,10 +1030,14 @@ def main():
             "cpu_baseline": cpu,
         }
         if world == 1 and not args.no_extras:
-            out["extra"] = extra_workloads(lib, dev, torch)
+            out["extra"] = extra_workloads(lib, dev, torch, copy_ceiling)
             out["extra"]["sparse_upsampling"] = sparse_leg
             # BASELINE configs[2] (SearchForTriangulation) and the matcher calls of one tracked frame: per-call latency through the
             # host-pointer C ABI with the reference's own ORBmatcher.cc / DBoW2 / ComputeStereoMatches timed beside each (bench_calls.py)
+            try:
+                out["extra"]["natural_texture"] = natural_texture_leg(lib, dev, torch, frames, cloud, proj, n_points, total_frames / elapsed)
+            except Exception as e:
+                out["extra"]["natural_texture"] = {"error": repr(e)}
             import bench_calls
             for name, leg in (("cfg3_triangulation", bench_calls.triangulation_leg), ("tracking_calls", bench_calls.tracking_leg)):
                 try:

@@ -115,9 +115,8 @@ class _Lane:
             # link of the chain (136 - 138 k); on a stream of the default priority it competes with FAST for issue slots (130 - 132 k).
             # With the gather on, a communication stream of its own would be the FIFTH stream on the runtime's four hardware
             # queues, which costs more than the priority gains (123 k against 134 k at one rank with gather='step'): the
-            # pipeline then uses this low-priority stream for the communication as well (one lane), or leaves the scan on the
-            # extractor's stream (two lanes).
-            mode = os.environ.get("RGBL_MATCHER_STREAM", "low" if gather != "two-lanes" else "shared")
+            # pipeline then uses this low-priority stream for the communication as well.
+            mode = os.environ.get("RGBL_MATCHER_STREAM", "low")
             if mode == "shared":
                 L.check(lib, lib.rgbl_matcher_set_stream(self.mt.h, one))
             elif mode == "low":
@@ -140,7 +139,7 @@ class _Lane:
 
 class FrontEndPipeline:
     def __init__(self, lib, torch, dev, w, h, nfeatures, proj, n_points, batch, levels=8, scale=1.2, ini_th=12, min_th=7,
-                 world=1, rank=0, gather=None, serial=False, keep_steps=0, log_steps=1, lanes=1,
+                 world=1, rank=0, gather=None, serial=False, keep_steps=0, log_steps=1,
                  sparse_depth=False, transport=None, comm=None, loopback=False, halo=0):
         self.lib, self.torch, self.dev = lib, torch, dev
         self.w, self.h, self.B, self.n_points = w, h, batch, n_points
@@ -160,14 +159,11 @@ class FrontEndPipeline:
         self.transport, self.comm, self.g = transport, comm, None
         index = dev.index if (dev.type == "cuda" and dev.index is not None) else 0
         self.index = index
-        # lanes = 2: two sets of handles used alternately, step k on lane k mod 2 with the output set k mod 2 - two steps in
-        # flight: the tail of step k (quad-trees of the upper levels, descriptors, matching: dependent chains and gathers that
-        # leave most vector-issue slots idle) runs next to the head of step k + 1 (pyramid, FAST, Gaussian: issue-bound)
-        n_lanes = 1 if serial else max(1, min(lanes, 2))
-        wrap_low = gather != "none" and n_lanes == 1 and transport == "torch" and dev.type == "cuda"
-        self.lanes = [_Lane(lib, index, w, h, nfeatures, proj, n_points, self.Bh, levels, scale, ini_th, min_th, serial,
-                            "two-lanes" if (gather != "none" and n_lanes > 1) else gather, shared_low=wrap_low)
-                      for _ in range(n_lanes)]
+        # ONE set of handles (the "two steps in flight on two sets of handles" schedule of rounds 3 - 5 lost every measurement,
+        # docs/history/, and is gone; the list stays a list for the callers that walk it)
+        wrap_low = gather != "none" and transport == "torch" and dev.type == "cuda"
+        self.lanes = [_Lane(lib, index, w, h, nfeatures, proj, n_points, self.Bh, levels, scale, ini_th, min_th, serial, gather,
+                            shared_low=wrap_low)]
         self.ex, self.dm, self.mt = self.lanes[0].ex, self.lanes[0].dm, self.lanes[0].mt
         # sparse_depth: no dense ProcessedDepthMap (rgbl_depth_set_sparse) - the step never hands it out anyway
         for ln in self.lanes:
@@ -190,9 +186,9 @@ class FrontEndPipeline:
         self.n_exchanged = 0
         self.dist = None
         self.n_slots = 2 if self.gather == "step" else max(log_steps, 1)   # 'final': one slot per step of the run
-        low = self.lanes[0].own_stream if (len(self.lanes) == 1 and not serial) else None
+        low = self.lanes[0].own_stream if not serial else None
         if self.gather != "none" and transport == "abi":
-            # the library's gather on the Hamming scan's low-priority stream (its own low-priority stream with two lanes)
+            # the library's gather on the Hamming scan's low-priority stream
             self.g = C.c_void_p()
             L.check(lib, lib.rgbl_gather_create(comm, index, batch, self.cap, self.n_slots, low, C.byref(self.g)))
             if loopback:

@@ -72,7 +72,7 @@ def traffic(out_dir, steps, warmup, frames_per_step, out, tag="bench", extra_arg
     n_steps = int(steps) + int(warmup) + bench.PROF_STEPS
     kernels = {}
     for c, f, key in (("FETCH_SIZE", f_fetch, "fetch_bytes_per_step"), ("WRITE_SIZE", f_write, "write_bytes_per_step"),
-                      ("SQ_INSTS_VALU", 1.0, "valu_insts_per_step")):
+                      ("SQ_INSTS_VALU", 1.0, "valu_insts_per_step"), ("SQ_ACTIVE_INST_VALU", 1.0, "valu_active_quadcycles_per_step")):
         for name, counter, n, total in rows(tag + "_" + c):
             k = short(name)
             if not k.startswith("k_"):

@@ -1118,7 +1118,7 @@ def check_search_by_projection_sim3(lib, seed=151, th=8, proj_form=0, ratio=1.5,
     return on
 
 
-def check_pipeline_gather(lib, mode, dev=None, w=640, h=360, nfeatures=800, batch=16, steps=4, n_az=600, levels=8, lanes=1,
+def check_pipeline_gather(lib, mode, dev=None, w=640, h=360, nfeatures=800, batch=16, steps=4, n_az=600, levels=8,
                           sparse_depth=False):
     """The batched step + the gather of its records (orb_slam3_rgbl_amd/pipeline.py) with ONE rank: what the root holds after
     every step must decode to that step's own outputs, and those to the oracle's."""
@@ -1133,7 +1133,7 @@ def check_pipeline_gather(lib, mode, dev=None, w=640, h=360, nfeatures=800, batc
     frames = np.stack([sq.frame(i) for i in range(batch)])
     cloud = np.stack([synth.lidar_scan(700 + i, n_az=n_az) for i in range(batch)])
     pipe = FrontEndPipeline(lib, torch, dev, w, h, nfeatures, proj, cloud.shape[2], batch, levels=levels, ini_th=20, min_th=7, world=1, rank=0,
-                            gather=mode, keep_steps=steps, log_steps=steps, lanes=lanes, sparse_depth=sparse_depth)
+                            gather=mode, keep_steps=steps, log_steps=steps, sparse_depth=sparse_depth)
     pipe.set_inputs(torch.from_numpy(frames).to(dev), torch.from_numpy(cloud).to(dev))
     for _ in range(steps):
         pipe.step()

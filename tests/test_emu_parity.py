@@ -369,15 +369,15 @@ def test_extractor_batch_of_eight_takes_the_xcd_aware_mapping(emu_lib):
     pc.check_extractor_batch(emu_lib, 400, 300, 500, 8)
 
 
-@pytest.mark.parametrize("mode,lanes", [("step", 1), ("final", 1), ("step", 2)])
-def test_gather_choreography_with_one_rank(emu_lib, mode, lanes):
+@pytest.mark.parametrize("mode", ["step", "final"])
+def test_gather_choreography_with_one_rank(emu_lib, mode):
     import torch
-    pc.check_pipeline_gather(emu_lib, mode, dev=torch.device("cpu"), w=240, h=160, nfeatures=300, batch=3, steps=3, n_az=240, levels=4, lanes=lanes)
+    pc.check_pipeline_gather(emu_lib, mode, dev=torch.device("cpu"), w=240, h=160, nfeatures=300, batch=3, steps=3, n_az=240, levels=4)
 
 
 def test_pipeline_with_sparse_upsampling(emu_lib):
     import torch
-    pc.check_pipeline_gather(emu_lib, "step", dev=torch.device("cpu"), w=240, h=160, nfeatures=300, batch=3, steps=3, n_az=240, levels=4, lanes=2,
+    pc.check_pipeline_gather(emu_lib, "step", dev=torch.device("cpu"), w=240, h=160, nfeatures=300, batch=3, steps=3, n_az=240, levels=4,
                              sparse_depth=True)
 
 

@@ -418,18 +418,17 @@ def test_pack_records_on_the_device(gpu_lib):
     assert int(off.cpu()[0]) == 5
 
 
-@pytest.mark.parametrize("mode,lanes", [("step", 1), ("final", 1), ("step", 2), ("final", 2)])
-def test_gather_choreography_with_one_rank(gpu_lib, mode, lanes):
+@pytest.mark.parametrize("mode", ["step", "final"])
+def test_gather_choreography_with_one_rank(gpu_lib, mode):
     # FrontEndPipeline with gather = step | final at world == 1: the pack on the communication stream, the counts through
     # page-locked memory behind an event, the root's device copy and the comm_done / depth_done / match_done events all
     # execute on the hardware (no peer, so no RCCL transfer); the records must decode to the step's own outputs
-    # lanes = 2: two steps in flight on two sets of handles (pipeline.py)
-    pc.check_pipeline_gather(gpu_lib, mode, lanes=lanes)
+    pc.check_pipeline_gather(gpu_lib, mode)
 
 
 def test_pipeline_with_sparse_upsampling(gpu_lib):
     # the batched step without the dense ProcessedDepthMap (rgbl_depth_set_sparse): records equal to the oracle's
-    pc.check_pipeline_gather(gpu_lib, "step", lanes=2, sparse_depth=True)
+    pc.check_pipeline_gather(gpu_lib, "step", sparse_depth=True)
 
 
 def test_overlapped_frame_hooks(gpu_lib):
