@@ -108,11 +108,6 @@ struct rgbl_extractor {
   uint32_t* d_levelcnt = nullptr;  // [B][L] candidates per level, counted by k_fast_cells' cells (dense candidate lists)
   bool dense = false;              // k_fast_cells writes a level's candidates as one list (label-based quad-tree kernel, separate pixel kernels)
   bool dense_dirty = false;        // an enqueue failed between the FAST and the quad-tree launches: the counters may hold leftovers
-  // k_pyramid_cone: cone[0] = the levels 1 .. split - 1 from the image, cone[1] = the levels split .. L - 1 from level split - 1
-  struct Cone { bool ok = false; int l0 = 0, nl = 0, ntiles = 0; ConeTile* d_tiles = nullptr; ConeArgs args; } cone[2];
-  unsigned cone_mask = 3;          // RGBL_CONE=0|1|2|3: which of the two cones replace their k_resize_linear launches (batches)
-  unsigned exp_skip = 0;           // EXPERIMENT (RGBL_EXP_SKIP): kernels left out from the 4th enqueue on - "what if it were free"
-  long n_enqueued = 0;
   int* d_err = nullptr;            // (the first word of d_stage)
   uint8_t* d_stage = nullptr;      // error flags | d_out_n | d_out_mono | d_out_kp | d_out_desc, the layout of h_pinned
   int32_t* d_stereo_sad = nullptr;  // ComputeStereoMatches scratch (grow-only)
@@ -397,77 +392,6 @@ int upload_tables(rgbl_extractor* e) {
     RGBL_TRY(dev_alloc(e, &e->d_xsxa, sxas.size()));
     RGBL_HIP(hipMemcpy(e->d_xgroups, groups.data(), sizeof(ResizeGroup) * groups.size(), hipMemcpyHostToDevice));
     RGBL_HIP(hipMemcpy(e->d_xsxa, sxas.data(), sizeof(int32_t) * sxas.size(), hipMemcpyHostToDevice));
-    // ---- plans of k_pyramid_cone (extractor_kernels.h): per tile of a cone's last level the rectangles it computes (r) and
-    //      stores (o) on every level and the source rectangle it stages, derived from the very tables the kernel reads
-    if (const char* v = getenv("RGBL_CONE")) e->cone_mask = (unsigned)atoi(v);
-    const int sp0 = L >= 6 ? L / 2 : 0;
-    const int split = getenv("RGBL_SPLIT_PYR") ? atoi(getenv("RGBL_SPLIT_PYR")) : sp0;
-    for (int ci = 0; ci < 2; ++ci) {
-      rgbl_extractor::Cone& C = e->cone[ci];
-      C.ok = false;
-      if (split < 2 || split >= L) break;
-      C.l0 = ci == 0 ? 0 : split - 1;
-      C.nl = ci == 0 ? split - 1 : L - split;
-      if (C.nl < 1 || C.nl > kConeMaxLevels) continue;
-      const LevelGeom& last = e->geom[C.l0 + C.nl];
-      const int ntx = (last.w + kConeTW - 1) / kConeTW, nty = (last.h + kConeTH - 1) / kConeTH;
-      auto pad4 = [](int v) { return (v + 3) / 4 * 4; };
-      std::vector<ConeTile> tiles((size_t)ntx * nty);
-      bool ok = true;
-      for (int ty = 0; ty < nty && ok; ++ty)
-        for (int tx = 0; tx < ntx && ok; ++tx) {
-          ConeTile& T = tiles[(size_t)ty * ntx + tx];
-          memset(&T, 0, sizeof(T));
-          int rx0 = 0, rx1 = 0, ry0 = 0, ry1 = 0;
-          for (int k = C.nl; k >= 1; --k) {
-            const LevelGeom& g = e->geom[C.l0 + k];
-            auto ox = [&](int t) { return t >= ntx ? pad4(g.w) : std::min(pad4(g.w), (int)((long)t * kConeTW * g.w / last.w) / 4 * 4); };
-            auto oy = [&](int t) { return t >= nty ? g.h : std::min(g.h, (int)((long)t * kConeTH * g.h / last.h)); };
-            const int ox0 = ox(tx), ox1 = ox(tx + 1), oy0 = oy(ty), oy1 = oy(ty + 1);
-            if (k == C.nl) { rx0 = ox0; rx1 = ox1; ry0 = oy0; ry1 = oy1; }
-            else {
-              // the footprint of level k + 1's rectangle on this level: 8-byte windows of its column groups, two rows per row
-              const LevelGeom& up = e->geom[C.l0 + k + 1];
-              const size_t G0 = up.xtab_off / 4 + (size_t)rx0 / 4, G1 = up.xtab_off / 4 + (size_t)rx1 / 4 - 1;
-              for (size_t G = G0; G <= G1; ++G) ok = ok && sxas[G] >= 0;
-              if (!ok) break;
-              int fx0 = sxas[G0] / 4 * 4, fx1 = pad4(sxas[G1] + 8);
-              const ResizeTab* Y = yt.data() + up.ytab_off;
-              int fy0 = std::min(std::max((int)Y[ry0].sofs, 0), g.h - 1), fy1 = std::min(std::max((int)Y[ry1 - 1].sofs + 1, 0), g.h - 1) + 1;
-              if (ox1 > ox0 && oy1 > oy0) { fx0 = std::min(fx0, ox0); fx1 = std::max(fx1, ox1); fy0 = std::min(fy0, oy0); fy1 = std::max(fy1, oy1); }
-              rx0 = fx0; rx1 = fx1; ry0 = fy0; ry1 = fy1;
-            }
-            if (rx1 <= rx0 || ry1 <= ry0) { ok = false; break; }   // (an empty tile cannot occur: the last level is tiled by its own size)
-            T.r[k - 1] = ConeRect{(int16_t)rx0, (int16_t)rx1, (int16_t)ry0, (int16_t)ry1};
-            T.o[k - 1] = ConeRect{(int16_t)ox0, (int16_t)ox1, (int16_t)oy0, (int16_t)oy1};
-            if (k < C.nl && (rx1 - rx0) / 4 * (ry1 - ry0) > kConeWords) ok = false;
-          }
-          if (!ok) break;
-          {
-            const LevelGeom& g1 = e->geom[C.l0 + 1];
-            const LevelGeom& g0 = e->geom[C.l0];
-            const size_t G0 = g1.xtab_off / 4 + (size_t)rx0 / 4, G1 = g1.xtab_off / 4 + (size_t)rx1 / 4 - 1;
-            for (size_t G = G0; G <= G1; ++G) ok = ok && sxas[G] >= 0;
-            if (!ok) break;
-            const ResizeTab* Y = yt.data() + g1.ytab_off;
-            const int sx0 = sxas[G0] / 4 * 4, sx1 = pad4(sxas[G1] + 8);
-            const int sy0 = std::min(std::max((int)Y[ry0].sofs, 0), g0.h - 1), sy1 = std::min(std::max((int)Y[ry1 - 1].sofs + 1, 0), g0.h - 1) + 1;
-            T.src = ConeRect{(int16_t)sx0, (int16_t)sx1, (int16_t)sy0, (int16_t)sy1};
-            if ((sx1 - sx0) / 4 * (sy1 - sy0) > kConeWords) ok = false;
-          }
-        }
-      if (!ok) continue;
-      C.ntiles = ntx * nty;
-      memset(&C.args, 0, sizeof(C.args));
-      C.args.nl = C.nl; C.args.sw = e->geom[C.l0].w; C.args.sh = e->geom[C.l0].h;
-      for (int k = 1; k <= C.nl; ++k) {
-        const LevelGeom& g = e->geom[C.l0 + k];
-        C.args.lv[k - 1] = ConeLevel{g.w, g.h, g.pitch, g.img_off, g.xtab_off / 4, g.ytab_off};
-      }
-      RGBL_TRY(dev_alloc(e, &C.d_tiles, tiles.size()));
-      RGBL_HIP(hipMemcpy(C.d_tiles, tiles.data(), sizeof(ConeTile) * tiles.size(), hipMemcpyHostToDevice));
-      C.ok = true;
-    }
   }
   RGBL_TRY(dev_alloc(e, &e->d_rootx, rootx.size()));
   RGBL_TRY(dev_alloc(e, &e->d_pattern, 1024));
@@ -480,14 +404,6 @@ int upload_tables(rgbl_extractor* e) {
   e->split_pyr = L >= 6 ? L / 2 : 0;   // 8 levels: the levels 4 - 7 (a fifth of the pixels) leave the main chain (round 5: the default)
   if (const char* v = getenv("RGBL_SPLIT_PYR")) e->split_pyr = atoi(v);
   if (const char* v = getenv("RGBL_FAST_BS")) e->fast_waves = atoi(v) == 64 ? 1 : atoi(v) == 128 ? 2 : 0;
-  if (const char* v = getenv("RGBL_EXP_SKIP")) {   // timing experiments on repeated identical inputs only: results go stale
-    if (strstr(v, "resize13")) e->exp_skip |= 1u;
-    if (strstr(v, "resize47")) e->exp_skip |= 2u;
-    if (strstr(v, "gauss")) e->exp_skip |= 4u;
-    if (strstr(v, "orient")) e->exp_skip |= 8u;
-    if (strstr(v, "fast0")) e->exp_skip |= 16u;
-    if (strstr(v, "fastup")) e->exp_skip |= 32u;
-  }
   return RGBL_OK;
 }
 
@@ -554,7 +470,6 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
                     int32_t* d_mono) {
   const int L = e->L;
   hipStream_t s = e->stream;
-  const unsigned skip = (++e->n_enqueued > 3) ? e->exp_skip : 0u;
   e->last_img0 = d_imgs; e->last_pitch0 = stride; e->last_frame0 = frame_stride; e->last_batch = batch;
   if (e->dense && e->dense_dirty) RGBL_HIP(hipMemsetAsync(e->d_levelcnt, 0, sizeof(uint32_t) * (size_t)e->cfg.max_batch * L, s));
   e->dense_dirty = e->dense;  // cleared at the end of a complete enqueue: the quad-tree workgroups leave the counters at zero
@@ -576,8 +491,6 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   auto level_at = [&](int cell) { for (int l = 0; l < L; ++l) if ((int)e->geom[l].cell_off == cell) return l; return L; };
   auto launch_fast = [&](hipStream_t st, int cell_begin, int cell_end) {
     if (cell_end <= cell_begin) return;
-    if ((skip & 16u) && cell_begin == 0) return;
-    if ((skip & 32u) && cell_begin != 0) return;
     e->timer.begin("k_fast_cells", st);
     hipLaunchKernelGGL(fast, xcd_grid(e->xcd_map, cell_end - cell_begin, batch), dim3(fast_bs), 0, st, e->d_cells, d_imgs, stride, frame_stride,
                        e->d_pyr, e->pyr_frame, e->cfg.ini_th_fast, e->cfg.min_th_fast, e->d_cellcnt, (size_t)e->cells_frame,
@@ -593,7 +506,6 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   };
   auto launch_gauss = [&](hipStream_t st, int tile_begin, int tile_end) {
     if (tile_end <= tile_begin) return;
-    if (skip & 4u) return;
     e->timer.begin("k_gauss7", st);
     // two passes with a barrier in between: 16 workgroups of two waves per CU interleave better than 8 of four (0.63 -> 0.54 ms)
     const bool g128 = !e->gauss_wg256;
@@ -652,8 +564,6 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
     const int cells0 = L > 1 ? e->geom[1].cell_off : e->cells_frame, tiles0 = e->blur_tiles.tile_off[1];
     // 1. pyramid: level l from level l-1 (ORBextractor.cc:1170-1195)
     auto launch_resize = [&](hipStream_t st, int l) {
-      if ((skip & 1u) && l < 4) return;
-      if ((skip & 2u) && l >= 4) return;
       const LevelGeom& g = e->geom[l];
       const LevelGeom& p = e->geom[l - 1];
       const uint8_t* src = (l == 1) ? d_imgs : e->d_pyr + p.img_off;
@@ -664,24 +574,6 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       hipLaunchKernelGGL(k_resize_linear, xcd_grid(e->xcd_map, rtx * rty, batch), dim3(kResizeWG), 0, st, src, spitch, sframe, p.w, p.h, e->d_pyr + g.img_off, g.pitch, e->pyr_frame, g.w, g.h,
                        e->d_xtab + g.xtab_off, e->d_xgroups + g.xtab_off / 4, e->d_xsxa + g.xtab_off / 4, e->d_ytab + g.ytab_off, rtx);
       e->timer.end(st);
-    };
-    // levels first .. last by one k_pyramid_cone launch where a plan exists (batches), else level after level
-    auto launch_levels = [&](hipStream_t st, int first, int last) {
-      for (int ci = 0; ci < 2; ++ci) {
-        const rgbl_extractor::Cone& C = e->cone[ci];
-        if (batch >= 8 && C.ok && ((e->cone_mask >> ci) & 1u) && C.l0 + 1 == first && C.l0 + C.nl == last) {
-          if ((skip & 1u) && first < 4) return;
-          if ((skip & 2u) && first >= 4) return;
-          const LevelGeom& p = e->geom[C.l0];
-          e->timer.begin("k_pyramid_cone", st);
-          hipLaunchKernelGGL(k_pyramid_cone, xcd_grid(e->xcd_map, C.ntiles, batch), dim3(256), 0, st, C.l0 == 0 ? d_imgs : e->d_pyr + p.img_off,
-                             C.l0 == 0 ? stride : p.pitch, C.l0 == 0 ? frame_stride : e->pyr_frame, e->d_pyr, e->pyr_frame, C.args, C.d_tiles,
-                             e->d_xgroups, e->d_xsxa, e->d_ytab);
-          e->timer.end(st);
-          return;
-        }
-      }
-      for (int l = first; l <= last; ++l) launch_resize(st, l);
     };
     const int sp = (overlap && batch >= 8 && e->split_pyr >= 2 && e->split_pyr < L) ? e->split_pyr : 0;
     if (sp) {
@@ -694,10 +586,10 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       RGBL_HIP(hipEventRecord(e->ev_start, s));
       RGBL_HIP(hipStreamWaitEvent(bs, e->ev_start, 0));
       launch_fast(bs, 0, cells0);
-      launch_levels(s, 1, sp - 1);
+      for (int l = 1; l < sp; ++l) launch_resize(s, l);
       RGBL_HIP(hipEventRecord(e->ev_r, s));
       RGBL_HIP(hipStreamWaitEvent(bs, e->ev_r, 0));
-      launch_levels(bs, sp, L - 1);
+      for (int l = sp; l < L; ++l) launch_resize(bs, l);
       launch_fast(bs, e->geom[sp].cell_off, e->cells_frame);
       RGBL_HIP(hipEventRecord(e->ev_fb, bs));
       launch_gauss(bs, 0, tiles0);
@@ -756,8 +648,7 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
       launch_octree(bs, 0, 1);
       RGBL_HIP(hipEventRecord(e->ev_fast0, bs));
     }
-    if (batch >= 8 && e->split_pyr >= 2 && e->split_pyr < L) { launch_levels(s, 1, e->split_pyr - 1); launch_levels(s, e->split_pyr, L - 1); }
-    else for (int l = 1; l < L; ++l) launch_resize(s, l);
+    for (int l = 1; l < L; ++l) launch_resize(s, l);
     // 4. Gaussian working images (ORBextractor.cc:1132-1133) of the upper levels, on the auxiliary stream next to 2. and 3.
     if (overlap) {
       RGBL_HIP(hipEventRecord(e->ev_pyr, s));
@@ -795,7 +686,6 @@ int enqueue_extract(rgbl_extractor* e, const uint8_t* d_imgs, int batch, int str
   const int slot_split = split_desc ? e->geom[1].koff : 0;
   auto launch_desc = [&](hipStream_t st, int slot_begin, int slot_end, int write_total) {
     if (slot_end <= slot_begin) return;
-    if (skip & 8u) return;
     e->timer.begin("k_orient_brief", st);
     // one-wave or two-wave workgroups were measured behind four-wave ones here (0.72 - 0.73 vs 0.70 ms): the waves are independent anyway
     hipLaunchKernelGGL(k_orient_brief<256>, xcd_grid(e->xcd_map, (slot_end - slot_begin + 4 * kKpPerWave - 1) / (4 * kKpPerWave), batch), dim3(256), 0, st, e->d_geom, L, e->umax,

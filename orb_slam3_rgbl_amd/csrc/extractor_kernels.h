@@ -174,97 +174,6 @@ __global__ __launch_bounds__(kResizeWG) void k_resize_linear(const uint8_t* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Several pyramid levels in ONE launch (round 6).  ORBextractor::ComputePyramid resizes level l from level l - 1
-// (ORBextractor.cc:1183), so the batch path ran seven dependent launches, every level written to HBM and read back by the
-// next one.  A workgroup of k_pyramid_cone owns a kConeTW x kConeTH tile of the LAST level of its cone, stages the source
-// region that tile depends on (through all the levels in between) in LDS once, and computes its regions of the levels
-// l0 + 1 .. l0 + nl from one another there - the same fixed-point arithmetic on the same host tables as k_resize_linear
-// (column groups of 4 with their 8-byte source window, byte selectors and packed weights; row table).  Every level's pixels
-// are STORED by exactly one workgroup (its part of a partition of the level into column-group-aligned rectangles); what a
-// workgroup needs beyond its part is recomputed (~10 % of the pixels at three levels).  All rectangles are precomputed on
-// the host (ConeTile), in pixels, x ranges multiples of 4.
-constexpr int kConeMaxLevels = 4, kConeTW = 64, kConeTH = 16, kConeWords = 1600;
-struct ConeRect { int16_t x0, x1, y0, y1; };
-struct ConeTile { ConeRect src, r[kConeMaxLevels], o[kConeMaxLevels]; };
-struct ConeLevel { int w, h, pitch; uint32_t img_off, xg_off, ytab_off; };
-struct ConeArgs { int nl, sw, sh; ConeLevel lv[kConeMaxLevels]; };
-
-__global__ __launch_bounds__(256) void k_pyramid_cone(const uint8_t* __restrict__ src, int spitch, size_t sframe,
-                                                      uint8_t* __restrict__ pyr, size_t pyr_frame, ConeArgs A,
-                                                      const ConeTile* __restrict__ tiles, const ResizeGroup* __restrict__ xgroups,
-                                                      const int32_t* __restrict__ xsxa, const ResizeTab* __restrict__ ytab) {
-  __shared__ uint32_t s_buf[2][kConeWords + 4];
-  const int tid = threadIdx.x, f = xcd_frame();
-  const ConeTile& T = tiles[xcd_item()];
-  // a work-item keeps ONE column (word / column group) and walks the rows, 8 rows of 32 columns per pass of the workgroup:
-  // no division, the group's record is read once per level, a row's table entry is one broadcast load per half wave
-  const int cx = tid & 31, cy = tid >> 5;
-  {
-    const uint8_t* S = src + (size_t)f * sframe;
-    const int x0 = T.src.x0, nw = (T.src.x1 - x0) >> 2, ny = T.src.y1 - T.src.y0;
-    for (int c = cx; c < nw; c += 32) {
-      const int x = x0 + 4 * c;
-      const bool whole = x + 4 <= A.sw;
-      for (int r = cy; r < ny; r += 8) {
-        const uint8_t* row = S + (size_t)(T.src.y0 + r) * spitch;
-        uint32_t v;
-        if (whole) v = load_u32_unaligned(row + x);
-        else {  // the last, partial word of a source row: nothing behind the row's last pixel is touched
-          v = 0;
-          for (int k = 0; k < 4; ++k) v |= (uint32_t)row[imin(x + k, A.sw - 1)] << (8 * k);
-        }
-        s_buf[0][r * nw + c] = v;
-      }
-    }
-  }
-  __syncthreads();
-  ConeRect prev = T.src;
-  for (int k = 0; k < A.nl; ++k) {
-    const ConeLevel& Lv = A.lv[k];
-    const ConeRect R = T.r[k], O = T.o[k];
-    const uint32_t* in = s_buf[k & 1];
-    uint32_t* out = s_buf[(k + 1) & 1];
-    const int pw = (prev.x1 - prev.x0) >> 2, nw = (R.x1 - R.x0) >> 2, ny = R.y1 - R.y0;
-    const int sh = k == 0 ? A.sh : A.lv[k - 1].h;
-    const bool keep = k + 1 < A.nl;
-    uint8_t* D = pyr + (size_t)f * pyr_frame + Lv.img_off;
-    const ResizeTab* Y = ytab + Lv.ytab_off;
-    for (int c = cx; c < nw; c += 32) {
-      const int xg = (R.x0 >> 2) + c, x = 4 * xg;
-      const int sxa = xsxa[Lv.xg_off + xg] - prev.x0;
-      const uint4* g4 = reinterpret_cast<const uint4*>(xgroups + Lv.xg_off + xg);
-      const uint4 gs = g4[0], gw = g4[1];
-      const uint32_t sel[4] = {gs.x, gs.y, gs.z, gs.w}, wt[4] = {gw.x, gw.y, gw.z, gw.w};
-      const int sft = sxa & 3;
-      const uint32_t* col = in + (sxa >> 2);
-      const bool own_x = x >= O.x0 && x < O.x1;
-      for (int r = cy; r < ny; r += 8) {
-        const int y = R.y0 + r;
-        const ResizeTab ry = Y[y];
-        const uint32_t* p0 = col + (imin(imax(ry.sofs, 0), sh - 1) - prev.y0) * pw;
-        const uint32_t* p1 = col + (imin(imax(ry.sofs + 1, 0), sh - 1) - prev.y0) * pw;
-        const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2], c0 = p1[0], c1 = p1[1], c2 = p1[2];
-        const uint32_t r0l = align_bytes(a1, a0, sft), r0h = align_bytes(a2, a1, sft);
-        const uint32_t r1l = align_bytes(c1, c0, sft), r1h = align_bytes(c2, c1, sft);
-        const int b0 = ry.a0, b1 = ry.a1;
-        uint32_t o4 = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int h0 = (int)udot2(perm_bytes(r0h, r0l, sel[j]), wt[j], 0u);
-          const int h1 = (int)udot2(perm_bytes(r1h, r1l, sel[j]), wt[j], 0u);
-          const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-          o4 |= (uint32_t)(v & 0xff) << (8 * j);
-        }
-        if (keep) out[r * nw + c] = o4;
-        if (own_x && y >= O.y0 && y < O.y1) *reinterpret_cast<uint32_t*>(D + (size_t)y * Lv.pitch + x) = o4;
-      }
-    }
-    __syncthreads();
-    prev = R;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // FAST-9/16 on one detection cell per workgroup.
 constexpr int kCellMax = 72;        // max scanned cell side handled (wCell/hCell <= 72: levels at least 35 px wide)
 constexpr int kCellSmall = 48;      // the common case (cells of 35..48 px): 7.4 KB of LDS instead of 24 KB per workgroup
