@@ -231,7 +231,8 @@ typedef struct rgbl_gather rgbl_gather;
 int rgbl_comm_available(void);                                  /* 1 when an RCCL library can be loaded (loads it) */
 int rgbl_comm_unique_id(uint8_t id[RGBL_COMM_ID_BYTES]);        /* ncclGetUniqueId */
 int rgbl_comm_create(const uint8_t id[RGBL_COMM_ID_BYTES], int world, int rank, int device, rgbl_comm** out);
-void rgbl_comm_destroy(rgbl_comm* c);
+void rgbl_comm_destroy(rgbl_comm* c);   /* while gather handles use the communicator it lives on until the last of them is
+                                            destroyed; a second call is valid only during that time (afterwards the object is gone) */
 int rgbl_comm_info(const rgbl_comm* c, int* world, int* rank, int* device, int* rccl_version);
 /* batch frames per step, cap keypoints per frame (the layout of the batch entry points' outputs), slots packed steps that
  * may wait for their exchange (2 = streaming, one step of slack; the number of steps for a gather at the end). */
@@ -742,7 +743,8 @@ void rgbl_fundamental(const float K1[4], const float K2[4], const float R12[9], 
 /* ------------------------------------------------------------------------------------------------
  * Environment switches.  Every one of them is read ONCE, when the handle it concerns is created (never on a launch path:
  * the entry points are called from the three SLAM threads), and is a tuning / test aid - the defaults are what is measured
- * and shipped.  Results are bit-identical under all of them (tests/test_parity_gpu.py runs every variant against the oracle).
+ * and shipped.  Results are bit-identical under all of them (parity_checks.check_switches: the batch and the single-frame
+ * extraction and the Hamming scan under every switch that changes a launch path, on the emulator and on the MI355X).
  *
  *   rgbl_extractor_create
  *     RGBL_SPLIT_PYR=k      batches: the pyramid levels k .. L-1 and their FAST cells leave the main launch chain for the auxiliary

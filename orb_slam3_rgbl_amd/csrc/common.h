@@ -56,7 +56,8 @@ struct KernelTimer {
   std::vector<Rec> recs;
   std::vector<double> total_ms;
   std::vector<long> count;
-  std::vector<std::vector<float>> samples;   // every launch's duration, in launch order (rgbl_*_profile_samples)
+  static constexpr size_t kMaxSamples = 1 << 16;
+  std::vector<std::vector<float>> samples;   // every launch's duration, in launch order (rgbl_*_profile_samples), the first kMaxSamples of them
   std::vector<std::string> names;
   int id_of(const char* name) {
     for (size_t i = 0; i < names.size(); ++i)
@@ -88,7 +89,7 @@ struct KernelTimer {
       (void)hipEventElapsedTime(&ms, r.a, r.b);
       total_ms[r.id] += ms;
       count[r.id] += 1;
-      samples[r.id].push_back(ms);
+      if (samples[r.id].size() < kMaxSamples) samples[r.id].push_back(ms);   // profiling left on for hours must not grow without bound
       (void)hipEventDestroy(r.a);
       (void)hipEventDestroy(r.b);
     }

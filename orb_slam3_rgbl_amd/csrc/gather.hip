@@ -119,6 +119,9 @@ struct rgbl_comm {
   int world = 1, rank = 0, device = 0, version = 0;
   // Lifetime: gather handles hold a reference.  rgbl_comm_destroy with gathers still alive only marks the handle;
   // the communicator goes with the last rgbl_gather_destroy - a gather never sees a dangling pointer.
+  // lifetime: gather handles hold the communicator (users); rgbl_comm_destroy marks it released, the last one out frees it.
+  // One mutex for both fields: gather_create / gather_destroy / comm_destroy may come from different threads.
+  std::mutex mu;
   int users = 0;
   bool released = false;   // rgbl_comm_destroy was called
   bool aborted = false;    // a failed exchange aborted the communicator (ncclCommAbort): every later call returns RGBL_ERR_COMM
@@ -208,9 +211,15 @@ void comm_free(rgbl_comm* c) {
 }  // namespace
 
 void rgbl_comm_destroy(rgbl_comm* c) {
-  if (!c || c->released) return;
-  c->released = true;
-  if (c->users == 0) comm_free(c);   // otherwise the last rgbl_gather_destroy frees it
+  if (!c) return;
+  bool free_now = false;
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->released) return;          // a second call is valid only while gather handles keep the communicator alive (header)
+    c->released = true;
+    free_now = c->users == 0;         // otherwise the last rgbl_gather_destroy frees it
+  }
+  if (free_now) comm_free(c);
 }
 
 int rgbl_comm_info(const rgbl_comm* c, int* world, int* rank, int* device, int* rccl_version) {
@@ -231,7 +240,11 @@ int rgbl_gather_create(rgbl_comm* comm, int device, int batch, int cap, int slot
   RGBL_HIP(hipSetDevice(device));
   rgbl_gather* g = new rgbl_gather;
   g->comm = comm; g->device = device; g->batch = batch; g->cap = cap; g->slots = slots;
-  if (comm) { g->world = comm->world; g->rank = comm->rank; ++comm->users; }
+  if (comm) {
+    std::lock_guard<std::mutex> lock(comm->mu);
+    if (comm->released) { delete g; set_error("the communicator was destroyed"); return RGBL_ERR_COMM; }
+    g->world = comm->world; g->rank = comm->rank; ++comm->users;
+  }
   g->slot_bytes = (size_t)batch * cap * kRecordBytes;
   const int W = g->world;
   int rc = RGBL_OK;
@@ -272,7 +285,14 @@ void rgbl_gather_destroy(rgbl_gather* g) {
   for (void* p : g->dev_allocs) (void)hipFree(p);
   for (void* p : g->host_allocs) (void)hipHostFree(p);
   if (g->own_stream) rgbl_stream_destroy((void*)g->own_stream);
-  if (g->comm && --g->comm->users == 0 && g->comm->released) comm_free(g->comm);
+  if (g->comm) {
+    bool free_now = false;
+    {
+      std::lock_guard<std::mutex> lock(g->comm->mu);
+      free_now = --g->comm->users == 0 && g->comm->released;
+    }
+    if (free_now) comm_free(g->comm);
+  }
   delete g;
 }
 
@@ -284,6 +304,14 @@ int rgbl_gather_set_loopback(rgbl_gather* g, int enable) {
   g->loopback = enable != 0;
   return RGBL_OK;
 }
+
+namespace {
+// a collective of this handle may be half posted: nothing this rank could still do would match what the peers wait for
+void fail_and_abort(rgbl_gather* g) {
+  g->failed = true;
+  if (g->comm && !g->comm->aborted && nccl().CommAbort) { (void)nccl().CommAbort(g->comm->comm); g->comm->aborted = true; }
+}
+}  // namespace
 
 int rgbl_gather_pack(rgbl_gather* g, int slot, const int32_t* d_n, const rgbl_keypoint* d_kp, const uint8_t* d_desc,
                      const float* d_depth, const float* d_uright, void* const* wait_events, int n_wait, void* done_event) {
@@ -304,11 +332,17 @@ int rgbl_gather_pack(rgbl_gather* g, int slot, const int32_t* d_n, const rgbl_ke
   RGBL_HIP(hipMemcpyAsync(g->d_counts[slot], d_n, sizeof(int32_t) * g->batch, hipMemcpyDeviceToDevice, s));
   // the step's output set is free again once its records and counts are copied out
   if (done_event) RGBL_HIP(hipEventRecord((hipEvent_t)done_event, s));
-  // phase 1
-  if (g->comm) RGBL_NCCL(nccl().AllGather(g->d_counts[slot], g->d_all_counts[slot], (size_t)g->batch, ncclInt32, g->comm->comm, s));
-  else RGBL_HIP(hipMemcpyAsync(g->d_all_counts[slot], g->d_counts[slot], sizeof(int32_t) * g->batch, hipMemcpyDeviceToDevice, s));
-  RGBL_HIP(hipMemcpyAsync(g->h_counts[slot], g->d_all_counts[slot], sizeof(int32_t) * (size_t)g->world * g->batch, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipEventRecord(g->ev_counts[slot], s));
+  // phase 1.  From the all-gather on a failure cannot be retried: the collective may be posted and the peers sit in it, a
+  // second pack of this slot would put this rank one all-gather ahead.  Same treatment as a failed exchange:
+  // the handle fails, the communicator is aborted (the peers return with an error instead of hanging).
+  const int rc = [&]() -> int {
+    if (g->comm) RGBL_NCCL(nccl().AllGather(g->d_counts[slot], g->d_all_counts[slot], (size_t)g->batch, ncclInt32, g->comm->comm, s));
+    else RGBL_HIP(hipMemcpyAsync(g->d_all_counts[slot], g->d_counts[slot], sizeof(int32_t) * g->batch, hipMemcpyDeviceToDevice, s));
+    RGBL_HIP(hipMemcpyAsync(g->h_counts[slot], g->d_all_counts[slot], sizeof(int32_t) * (size_t)g->world * g->batch, hipMemcpyDeviceToHost, s));
+    RGBL_HIP(hipEventRecord(g->ev_counts[slot], s));
+    return RGBL_OK;
+  }();
+  if (rc != RGBL_OK) { fail_and_abort(g); return g->comm ? RGBL_ERR_COMM : rc; }
   g->packed[slot] = 1;
   return RGBL_OK;
 }
@@ -355,7 +389,12 @@ int rgbl_gather_exchange(rgbl_gather* g, int slot) {
   if (!g->packed[slot]) { set_error("rgbl_gather_exchange: slot %d holds no packed step", slot); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipSetDevice(g->device));
   // the only host wait of the gather: the counts of THIS slot - in a streaming run an event of the step before the one just queued
-  RGBL_HIP(hipEventSynchronize(g->ev_counts[slot]));
+  if (hipEventSynchronize(g->ev_counts[slot]) != hipSuccess) {   // the counts never arrived: the all-gather of this slot is lost
+    (void)hipGetLastError();
+    set_error("rgbl_gather_exchange: waiting for the counts of slot %d failed", slot);
+    fail_and_abort(g);
+    return RGBL_ERR_COMM;
+  }
   const int W = g->world, B = g->batch;
   std::vector<long long> total(W, 0);
   for (int r = 0; r < W; ++r)
@@ -365,8 +404,7 @@ int rgbl_gather_exchange(rgbl_gather* g, int slot) {
   if (rc != RGBL_OK) {
     // Some transfers may be posted and the peers sit in their matching calls: nothing this rank could still do would match
     // them.  Abort the communicator (it unblocks the peers with an error instead of a hang) and refuse further collectives.
-    g->failed = true;
-    if (g->comm && !g->comm->aborted && nccl().CommAbort) { (void)nccl().CommAbort(g->comm->comm); g->comm->aborted = true; }
+    fail_and_abort(g);
     return rc;
   }
   // book-keeping only once the whole group is posted: a failed exchange flips no bank and publishes no counts

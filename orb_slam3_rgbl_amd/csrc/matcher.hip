@@ -1256,44 +1256,69 @@ struct BowDev {
 };
 constexpr int kBowBucket = 16384;  // frame features of one node tracked in LDS (one byte each)
 
-// grid = shared nodes, block = 64
+// grid = shared nodes, block = 64.  The node's key-frame features are taken one after the other (a frame feature taken by an
+// earlier one is gone for the later ones: ORBmatcher.cc:296-299), so what sits inside that serial loop decides the kernel's
+// time.  Round 6: the key-frame features' descriptors are staged in LDS 64 at a time and a lane keeps the descriptor of ITS
+// frame feature (bucket position = lane, every bucket of a KITTI frame's ~100 nodes fits) in registers - the loop body is LDS
+// reads and register work instead of three dependent global loads per key-frame feature (100 -> ~15 us for a frame pair).
 __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
   __shared__ uint8_t s_taken[kBowBucket];
+  __shared__ unsigned long long s_q[64][4];
+  __shared__ int s_idx1[64];
   const int np = blockIdx.x, lane = threadIdx.x;
   const int a = T.pair_n1[np], b = T.pair_n2[np];
   const int b1 = T.off1[a], e1 = T.off1[a + 1], b2 = T.off2[b], n2 = T.off2[b + 1] - b2;
   for (int j = lane; j < n2; j += 64) s_taken[j] = (T.valid2 && !T.valid2[T.feat2[b2 + j]]) ? 1 : 0;
-  wave_sync();
-  for (int p = b1; p < e1; ++p) {
-    const int idx1 = T.feat1[p];
-    if (!T.valid1[idx1]) continue;  // wave-uniform
-    const unsigned long long* D1 = reinterpret_cast<const unsigned long long*>(T.desc1 + (size_t)idx1 * 32);
-    const unsigned long long q[4] = {D1[0], D1[1], D1[2], D1[3]};
-    uint32_t best = 0xffffffffu;  // dist << 16 | bucket position
-    int second = 256;
-    for (int j = lane; j < n2; j += 64) {
-      if (s_taken[j]) continue;
-      const int idx2 = T.feat2[b2 + j];
-      const int dist = hamming256(q, reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)idx2 * 32));
-      const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)j;
-      if (key < best) { if (best != 0xffffffffu) second = (int)(best >> 16); best = key; }
-      else if (dist < second) second = dist;
-    }
-    // wave-wide: the smallest key, and the smallest distance among everything else
-    uint32_t wbest = best;
-    for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)wbest, m); wbest = o < wbest ? o : wbest; }
-    int other = best == wbest ? second : (best == 0xffffffffu ? 256 : (int)(best >> 16));
-    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(other, m); other = o < other ? o : other; }
-    if (wbest == 0xffffffffu) continue;
-    const int best_dist = (int)(wbest >> 16), pos = (int)(wbest & 0xffffu);
-    if (best_dist <= T.max_best && (float)best_dist < T.nnratio * (float)other) {
-      if (lane == 0) {
-        const int idx2 = T.feat2[b2 + pos];
-        s_taken[pos] = 1;
-        T.match1[idx1] = idx2;
-        T.match2[idx2] = idx1;
+  unsigned long long t0[4] = {0ull, 0ull, 0ull, 0ull};
+  if (lane < n2) {
+    const unsigned long long* D2 = reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)T.feat2[b2 + lane] * 32);
+    t0[0] = D2[0]; t0[1] = D2[1]; t0[2] = D2[2]; t0[3] = D2[3];
+  }
+  for (int p0 = b1; p0 < e1; p0 += 64) {
+    wave_sync();
+    {
+      const int p = p0 + lane;
+      int idx1 = -1;
+      if (p < e1) { idx1 = T.feat1[p]; if (!T.valid1[idx1]) idx1 = -1; }
+      s_idx1[lane] = idx1;
+      if (idx1 >= 0) {
+        const unsigned long long* D1 = reinterpret_cast<const unsigned long long*>(T.desc1 + (size_t)idx1 * 32);
+        s_q[lane][0] = D1[0]; s_q[lane][1] = D1[1]; s_q[lane][2] = D1[2]; s_q[lane][3] = D1[3];
       }
-      wave_sync();
+    }
+    wave_sync();
+    const int cnt = imin(64, e1 - p0);
+    for (int k = 0; k < cnt; ++k) {
+      const int idx1 = s_idx1[k];
+      if (idx1 < 0) continue;  // wave-uniform
+      const unsigned long long q[4] = {s_q[k][0], s_q[k][1], s_q[k][2], s_q[k][3]};
+      uint32_t best = 0xffffffffu;  // dist << 16 | bucket position
+      int second = 256;
+      if (lane < n2 && !s_taken[lane]) best = ((uint32_t)hamming256(q, t0) << 16) | (uint32_t)lane;
+      for (int j = lane + 64; j < n2; j += 64) {
+        if (s_taken[j]) continue;
+        const int idx2 = T.feat2[b2 + j];
+        const int dist = hamming256(q, reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)idx2 * 32));
+        const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)j;
+        if (key < best) { if (best != 0xffffffffu) second = (int)(best >> 16); best = key; }
+        else if (dist < second) second = dist;
+      }
+      // wave-wide: the smallest key, and the smallest distance among everything else
+      uint32_t wbest = best;
+      for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)wbest, m); wbest = o < wbest ? o : wbest; }
+      int other = best == wbest ? second : (best == 0xffffffffu ? 256 : (int)(best >> 16));
+      for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(other, m); other = o < other ? o : other; }
+      if (wbest == 0xffffffffu) continue;
+      const int best_dist = (int)(wbest >> 16), pos = (int)(wbest & 0xffffu);
+      if (best_dist <= T.max_best && (float)best_dist < T.nnratio * (float)other) {
+        if (lane == 0) {
+          const int idx2 = T.feat2[b2 + pos];
+          s_taken[pos] = 1;
+          T.match1[idx1] = idx2;
+          T.match2[idx2] = idx1;
+        }
+        wave_sync();
+      }
     }
   }
 }

@@ -48,6 +48,9 @@ class DepthModule {
   bool downloadDenseMaps = true;
   int device = 0;
 
+  // the C-ABI handle (mvuRight of the last CalculateDepthFromPcd stays resident in it: ORBextractor::CaptureDeviceFrame)
+  rgbl_depth* Handle() const { return mpHandle; }
+
  protected:
   bool ParseRGBLParameters(const std::string& strSettingPath);
   bool ParseUpsamplingParameters(const std::string& strSettingPath);

@@ -172,6 +172,27 @@ void ORBextractor::UndistortKeyPoints(const std::vector<cv::KeyPoint>& mvKeys, c
   for (int i = 0; i < n; ++i) { mvKeysUn[i].pt.x = xy[2 * i]; mvKeysUn[i].pt.y = xy[2 * i + 1]; }
 }
 
+bool ORBextractor::CaptureDeviceFrame(rgbl_device_frame*& frame, int n, rgbl_depth* depth, const cv::Mat& K, const cv::Mat& mDistCoef) {
+  if (!mpHandle) { std::cerr << "[ORBextractor] CaptureDeviceFrame needs an extractor that has processed an image" << std::endl; return false; }
+  if (frame && rgbl_device_frame_size(frame) < 0) return false;
+  if (!frame && rgbl_device_frame_create(device, std::max(rgbl_extractor_max_keypoints(mpHandle), 1), &frame) != RGBL_OK) {
+    std::cerr << "[ORBextractor] " << rgbl_last_error() << std::endl;
+    return false;
+  }
+  float k[4] = {0, 0, 0, 0}, dist[5] = {0, 0, 0, 0, 0};
+  const int nd = (int)mDistCoef.total();
+  const bool und = !K.empty() && (nd == 4 || nd == 5);
+  if (und) {
+    k[0] = K.at<float>(0, 0); k[1] = K.at<float>(1, 1); k[2] = K.at<float>(0, 2); k[3] = K.at<float>(1, 2);
+    for (int i = 0; i < nd; ++i) dist[i] = mDistCoef.at<float>(i);
+  }
+  if (rgbl_device_frame_capture(frame, mpHandle, 0, n, depth, und ? k : nullptr, und ? dist : nullptr, und ? nd : 0) != RGBL_OK) {
+    std::cerr << "[ORBextractor] " << rgbl_last_error() << std::endl;
+    return false;
+  }
+  return true;
+}
+
 void ORBextractor::FillPyramid() {
   if (keepPyramid) {
     mvPyramidStorage.resize(nlevels);

@@ -8,6 +8,8 @@
 #include "cv_compat.h"
 
 struct rgbl_extractor;
+struct rgbl_device_frame;
+struct rgbl_depth;
 
 namespace ORB_SLAM3 {
 
@@ -42,6 +44,14 @@ class ORBextractor {
   // K: 3x3 CV_32F (Pinhole::toK()), mDistCoef: 4x1 or 5x1 CV_32F.  Call after operator() (the handle exists by then).
   void UndistortKeyPoints(const std::vector<cv::KeyPoint>& mvKeys, const cv::Mat& K, const cv::Mat& mDistCoef,
                           std::vector<cv::KeyPoint>& mvKeysUn);
+
+  // The frame this extractor has just produced, resident on the device for the matchers (rgbl_device_frame; INTEGRATION.md
+  // "Frames resident on the device"): n = mvKeys.size() of the operator() call just made; depth = the DepthModule's handle
+  // after CalculateDepthFromPcd (mvuRight), or NULL; K / mDistCoef as for UndistortKeyPoints (empty: mvKeysUn = mvKeys).
+  // Device to device - nothing crosses PCIe.  `frame` is created on first use and reused (capacity grows as needed);
+  // the owner (Frame / KeyFrame) destroys it with rgbl_device_frame_destroy.  Returns false (and says why) on failure.
+  bool CaptureDeviceFrame(rgbl_device_frame*& frame, int n, rgbl_depth* depth = nullptr, const cv::Mat& K = cv::Mat(),
+                          const cv::Mat& mDistCoef = cv::Mat());
 
   int inline GetLevels() { return nlevels; }
   float inline GetScaleFactor() { return scaleFactor; }

@@ -29,6 +29,14 @@
 #include "../../include/rgbl_frontend.h"
 #include "cv_compat.h"
 
+namespace rgbl_shim {
+// A Frame / KeyFrame class with a member `rgbl_device_frame* mpDeviceFrame` (one line in Frame.h / KeyFrame.h,
+// filled by ORBextractor::CaptureDeviceFrame in the Frame constructor) is matched from its resident copy: descriptors,
+// mvKeysUn and mvuRight are not uploaded again.  Classes without the member behave as before.
+template <class T> auto device_frame_of(const T& f, int) -> decltype(static_cast<const rgbl_device_frame*>(f.mpDeviceFrame)) { return f.mpDeviceFrame; }
+template <class T> const rgbl_device_frame* device_frame_of(const T&, long) { return nullptr; }
+}  // namespace rgbl_shim
+
 namespace ORB_SLAM3 {
 
 class ORBmatcher {
@@ -251,6 +259,7 @@ class ORBmatcher {
     in.scale_factors = CurrentFrame.mvScaleFactors.data();
     in.n_levels = (int)CurrentFrame.mvScaleFactors.size();
     in.th = th; in.mono = bMono; in.check_orientation = mbCheckOrientation;
+    in.device2 = rgbl_shim::device_frame_of(CurrentFrame, 0);
     std::vector<int32_t> match2(n2, -1);
     int nmatches = 0;
     if (rgbl_search_by_projection(mpHandle, &in, match2.data(), &nmatches) != RGBL_OK) {
@@ -600,6 +609,7 @@ class ORBmatcher {
     in.scale_factors = F.mvScaleFactors.data();
     in.n_levels = (int)F.mvScaleFactors.size();
     in.th = th; in.nnratio = mfNNratio;
+    in.device2 = rgbl_shim::device_frame_of(F, 0);
     std::vector<int32_t> match2(n2, -1);
     int nmatches = 0;
     if (rgbl_search_local_points(mpHandle, &in, match2.data(), &nmatches) != RGBL_OK) {
@@ -695,6 +705,7 @@ class ORBmatcher {
     f.view.node_id = f.node_id.data();
     f.view.node_off = f.node_off.data();
     f.view.node_feat = f.node_feat.data();
+    f.view.device = rgbl_shim::device_frame_of(*kf, 0);
   }
 
   // the part the two SearchByProjection(pKF, Scw, ...) overloads share: the reference's tests on the MapPoint objects, then the

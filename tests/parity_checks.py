@@ -1582,3 +1582,40 @@ def check_device_frames(lib, n=900, seed=17, w=640, h=360, nfeatures=700):
     dm.close()
     ex.close()
     return True
+
+
+def check_switches(lib, w=400, h=300, nfeatures=500, batch=8):
+    """Every RGBL_* tuning switch of include/rgbl_frontend.h that changes a launch path (they are read when a handle is
+    created): the batch extraction, the host-pointer extraction and the Hamming scan must stay bit-identical under each
+    (the header says so, so it is checked)."""
+    import os
+    settings = [{"RGBL_SPLIT_PYR": "0"}, {"RGBL_SPLIT_PYR": "3"}, {"RGBL_GAUSS_BS": "256"}, {"RGBL_XCD_MAP": "0"}, {"RGBL_DENSE": "0"},
+                {"RGBL_COMPACT": "0"}, {"RGBL_FAST_BS": "128"}, {"RGBL_OCTREE_HIST": "0"}, {"RGBL_OCTREE_WG": "512"}, {"RGBL_GRAPH": "0"},
+                {"RGBL_LEVEL_SPLIT": "0"}, {"RGBL_BF_SPLIT": "0"}, {"RGBL_BF_MFMA": "0"}, {"RGBL_BF_MFMA": "i8"}]
+    for env in settings:
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            if any(k.startswith("RGBL_BF") for k in env):
+                check_matcher_bf(lib, 500, 450, seed=9)
+            else:
+                check_extractor_batch(lib, w, h, nfeatures, batch)
+                check_extractor(lib, w, h, nfeatures, frames=(0,))
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    # the batch path with per-kernel profiling on (one stream, no pyramid split)
+    ex = F.ORBextractor(nfeatures, 1.2, 8, 12, 7, w, h, max_batch=batch, lib=lib)
+    ex.profile(True)
+    s = synth.Sequence(2, w, h, n_frames=batch)
+    imgs = np.stack([s.frame(i) for i in range(batch)])
+    orc = O.Extractor(nfeatures, 1.2, 8, 12, 7)
+    for i, (kps, desc, mono) in enumerate(ex.extract_batch(imgs)):
+        okps, odesc, omono = orc(imgs[i])
+        assert_keypoints_equal(kps, okps, "profiled batch frame %d" % i)
+        assert np.array_equal(desc, odesc) and mono == omono
+    ex.close()
+    return len(settings)

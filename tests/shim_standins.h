@@ -49,6 +49,7 @@ struct KeyFrame {
   std::vector<MapPoint*> mvpMapPoints;
   cv::Mat mDescriptors;
   SE3 Tcw, Twc;
+  const rgbl_device_frame* mpDeviceFrame = nullptr;   // the optional resident copy the drop-in ORBmatcher looks for
   MapPoint* GetMapPoint(size_t i) { return mvpMapPoints[i]; }
   SE3 GetPose() { return Tcw; }
   SE3 GetPoseInverse() { return Twc; }

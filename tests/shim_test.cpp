@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <map>
 #include <set>
@@ -299,6 +300,45 @@ int main(int argc, char** argv) {
   for (auto& pr : pairs) { int a = (int)pr.first, b = (int)pr.second; wr(out, &a, 1); wr(out, &b, 1); }
   const int dd = ORB_SLAM3::ORBmatcher::DescriptorDistance(kf1.mDescriptors.row(0), kf2.mDescriptors.row(0));
   wr(out, &dd, 1);
+  {
+    // --- the same call with both key frames resident on the device (KeyFrame::mpDeviceFrame): same pairs
+    rgbl_device_frame* d[2] = {nullptr, nullptr};
+    KeyFrame* kfs[2] = {&kf1, &kf2};
+    for (int k = 0; k < 2; ++k) {
+      KeyFrame& kf = *kfs[k];
+      std::vector<float> xy(2 * (size_t)kf.N);
+      std::vector<int32_t> oct(kf.N);
+      for (int i = 0; i < kf.N; ++i) { xy[2 * i] = kf.mvKeysUn[i].pt.x; xy[2 * i + 1] = kf.mvKeysUn[i].pt.y; oct[i] = kf.mvKeysUn[i].octave; }
+      if (rgbl_device_frame_create(0, std::max(kf.N, 1), &d[k]) != RGBL_OK ||
+          rgbl_device_frame_upload(d[k], kf.N, kf.mDescriptors.data, xy.data(), oct.data(), kf.mvuRight.data()) != RGBL_OK) {
+        fprintf(stderr, "device frame: %s\n", rgbl_last_error());
+        return 20;
+      }
+      kf.mpDeviceFrame = d[k];
+    }
+    std::vector<std::pair<size_t, size_t> > pairs_res;
+    const int nm_res = matcher.SearchForTriangulation(&kf1, &kf2, pairs_res, false, false);
+    if (nm_res != nm || pairs_res != pairs) { fprintf(stderr, "SearchForTriangulation on resident key frames differs\n"); return 21; }
+    kf1.mpDeviceFrame = kf2.mpDeviceFrame = nullptr;
+    rgbl_device_frame_destroy(d[0]); rgbl_device_frame_destroy(d[1]);
+    // --- and the frame the extractor + depth module have just produced, captured device to device
+    std::vector<cv::KeyPoint> kc; cv::Mat dc;
+    extractor(im, cv::Mat(), kc, dc, vLapping);
+    depth.CalculateDepthFromPcd(kc, kc, pcd, w, h);
+    rgbl_device_frame* cap = nullptr;
+    if (!extractor.CaptureDeviceFrame(cap, (int)kc.size(), depth.Handle())) return 22;
+    const int nc2 = rgbl_device_frame_size(cap);
+    std::vector<uint8_t> gd((size_t)nc2 * 32);
+    std::vector<float> gxy(2 * (size_t)nc2), gur(nc2);
+    std::vector<int32_t> goct(nc2);
+    if (nc2 != (int)kc.size() || rgbl_device_frame_download(cap, gd.data(), gxy.data(), goct.data(), gur.data()) != RGBL_OK) return 23;
+    bool same = memcmp(gd.data(), dc.data, gd.size()) == 0;
+    for (int i = 0; i < nc2; ++i)
+      same = same && gxy[2 * i] == kc[i].pt.x && gxy[2 * i + 1] == kc[i].pt.y && goct[i] == kc[i].octave &&
+             memcmp(&gur[i], &depth.mvuRight[i], 4) == 0;
+    rgbl_device_frame_destroy(cap);
+    if (!same) { fprintf(stderr, "captured device frame differs from what the drop-in classes returned\n"); return 24; }
+  }
   {
     // --- as Tracking::TrackReferenceKeyFrame (Tracking.cc:2798-2810): matcher(0.7, true).SearchByBoW(mpReferenceKF, mCurrentFrame, vpMapPointMatches)
     kf2.mvKeys = kf2.mvKeysUn;

@@ -417,3 +417,7 @@ def test_projection_searches_beyond_the_lds_resolve(emu_lib):
     """Frames / point sets above kResolveLdsN2 / kResolveLdsN1 take the resolve kernels' global-memory form."""
     assert pc.check_search_by_projection(emu_lib, 27, "forward", 15.0, False, True, n1=900, n2=6500) > 100
     assert pc.check_search_local_points(emu_lib, 48, 3.0, 0.8, n1=12400, n2=1500) > 100
+
+
+def test_every_tuning_switch_is_bit_identical(emu_lib):
+    assert pc.check_switches(emu_lib, w=320, h=280, nfeatures=300) == 14

@@ -473,3 +473,9 @@ def test_projection_searches_beyond_the_lds_resolve(gpu_lib):
     """Frames / point sets above kResolveLdsN2 / kResolveLdsN1 take the resolve kernels' global-memory form."""
     assert pc.check_search_by_projection(gpu_lib, 27, "forward", 15.0, False, True, n1=2500, n2=8000) > 300
     assert pc.check_search_local_points(gpu_lib, 48, 3.0, 0.8, n1=13000, n2=3000) > 300
+
+
+def test_every_tuning_switch_is_bit_identical(gpu_lib):
+    """include/rgbl_frontend.h: 'results are bit-identical under all of them' - batch + single-frame extraction and the Hamming
+    scan under every switch that changes a launch path, and the batch path with profiling on."""
+    assert pc.check_switches(gpu_lib, w=1241, h=376, nfeatures=2000, batch=8) == 14

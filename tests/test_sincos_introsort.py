@@ -53,8 +53,8 @@ def test_introsort_restatement_reproduces_std_sort_tie_order(emu_lib, oracle):
 
 def test_introsort_heapsort_fallback_path(emu_lib, oracle):
     # median-of-three killer sequence (Musser): drives introsort into its depth limit -> heap sort branch
-    # (40 .. 200: the depth limit is reached INSIDE a range of at most 64 elements - the wave-register finisher of round 5 hands
-    # what is left back to the heap sort)
+    # (40 .. 200: small sizes at which the depth limit 2 floor(log2 n) is exhausted inside short ranges, so that the heap-sort
+    # branch starts from ranges of a few dozen elements as well as from long ones)
     for n in (40, 64, 66, 70, 72, 80, 90, 100, 128, 200, 512, 2048):
         k = n // 2
         a = np.zeros(n, np.uint64)

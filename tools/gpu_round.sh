@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call for the round's evidence: GPU parity tests, the default bench line, rocprofv3 kernel stats of the
 # serialised bench and of the single-frame host path, the calibrated FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes
-# (tools/gpu_traffic.sh) and the SQ counter passes.  Everything lands in gpurun_out/ (copy the r05_* files to profiles/).
+# (tools/gpu_traffic.sh) and the SQ counter passes.  Everything lands in gpurun_out/ (copy the r06_* files to profiles/).
 #   Usage: gpurun --timeout 1700 -- 'bash tools/gpu_round.sh'
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
@@ -20,18 +20,18 @@ try:
 except Exception as e:
     print("bench failed", e, open("gpurun_out/bench.err").read()[-800:])
 PY
-cp $OUT/bench.json $OUT/r05_bench_line.json
+cp $OUT/bench.json $OUT/r06_bench_line.json
 cd /tmp
-timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o r05 -- python $REPO/bench.py --serial --no-cpu-baseline --no-extras --steps 10 --warmup 3 > $OUT/prof_stats.log 2>&1
-timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/prof_single -o r05 -- python $REPO/tools/host_api_latency.py > $OUT/prof_single.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o r06 -- python $REPO/bench.py --serial --no-cpu-baseline --no-extras --steps 10 --warmup 3 > $OUT/prof_stats.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/prof_single -o r06 -- python $REPO/tools/host_api_latency.py > $OUT/prof_single.log 2>&1
 cd $REPO
-db=$(find $OUT/prof_stats -name "*.db" | head -1); [ -n "$db" ] && python profiles/summarize_rocprof.py stats $db $OUT/r05_kernel_stats.csv
-db=$(find $OUT/prof_single -name "*.db" | head -1); [ -n "$db" ] && python profiles/summarize_rocprof.py stats $db $OUT/r05_single_frame_kernel_stats.csv
+db=$(find $OUT/prof_stats -name "*.db" | head -1); [ -n "$db" ] && python profiles/summarize_rocprof.py stats $db $OUT/r06_kernel_stats.csv
+db=$(find $OUT/prof_single -name "*.db" | head -1); [ -n "$db" ] && python profiles/summarize_rocprof.py stats $db $OUT/r06_single_frame_kernel_stats.csv
 rm -rf $OUT/prof_stats $OUT/prof_single
 bash tools/gpu_traffic.sh > $OUT/traffic.log 2>&1; tail -3 $OUT/traffic.log
 bash tools/gpu_pmc.sh sqA "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" > $OUT/sqA.log 2>&1
 bash tools/gpu_pmc.sh sqB "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" > $OUT/sqB.log 2>&1
-cp $OUT/pmc_sqA.csv $OUT/r05_pmc_sq_cycles.csv; cp $OUT/pmc_sqB.csv $OUT/r05_pmc_sq_insts.csv
-bash tools/gpu_timeline.sh > $OUT/timeline.log 2>&1; cp $OUT/timeline.csv $OUT/r05_step_timeline.csv
-( cd tools/micro && ./valu_rates ) > $OUT/r05_valu_rates.txt 2>&1
-cat $OUT/r05_kernel_stats.csv | head -14; cat $OUT/r05_single_frame_kernel_stats.csv | head -14; cat $OUT/r05_valu_rates.txt
+cp $OUT/pmc_sqA.csv $OUT/r06_pmc_sq_cycles.csv; cp $OUT/pmc_sqB.csv $OUT/r06_pmc_sq_insts.csv
+bash tools/gpu_timeline.sh > $OUT/timeline.log 2>&1; cp $OUT/timeline.csv $OUT/r06_step_timeline.csv
+( cd tools/micro && ./valu_rates ) > $OUT/r06_valu_rates.txt 2>&1
+cat $OUT/r06_kernel_stats.csv | head -14; cat $OUT/r06_single_frame_kernel_stats.csv | head -14; cat $OUT/r06_valu_rates.txt
