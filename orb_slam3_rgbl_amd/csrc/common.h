@@ -174,6 +174,14 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) { 
   return __builtin_amdgcn_udot2(x, y, c, false);
 #endif
 }
+__device__ __forceinline__ uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) {  // c + sum of |a.byte - b.byte| over the four bytes (v_sad_u8)
+#ifdef RGBL_EMU
+  for (int k = 0; k < 4; ++k) { const int d = (int)((a >> (8 * k)) & 0xffu) - (int)((b >> (8 * k)) & 0xffu); c += (uint32_t)(d < 0 ? -d : d); }
+  return c;
+#else
+  return __builtin_amdgcn_sad_u8(a, b, c);
+#endif
+}
 __device__ __forceinline__ uint32_t align_bytes(uint32_t hi, uint32_t lo, int shift) {  // bytes shift .. shift + 3 of hi:lo
 #ifdef RGBL_EMU
   return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * (shift & 3)));

@@ -2007,6 +2007,7 @@ __global__ __launch_bounds__(kOctWide) void k_test_block_sort(uint64_t* key, uin
 struct ScaleTables { float scale[kMaxLevels], inv_scale[kMaxLevels]; };
 struct PyrView { const uint8_t* img0; int pitch0; size_t frame0; const uint8_t* pyr; size_t pyr_frame; };
 constexpr int kStereoTile = 2048;      // right keypoints staged in LDS per pass of k_stereo_match (18 KB)
+constexpr int kStereoBatch = 16;        // candidates whose descriptors are fetched together
 constexpr int kStereoRowBias = 4096;   // row bands are kept as two biased 16-bit halves of one word
 
 __device__ __forceinline__ int pyr_px(const uint8_t* base, int pitch, int w, int h, int x, int y) {
@@ -2046,6 +2047,28 @@ __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restric
   const rgbl_keypoint* KR = kpr + (size_t)f * cap;
   const unsigned long long* DR = reinterpret_cast<const unsigned long long*>(dr + (size_t)f * cap * 32);
   const int rowb = row + kStereoRowBias;
+  // candidates of the current tile that passed the cheap tests, per work-item, in index order: their descriptors are fetched
+  // afterwards, kStereoBatch independent 32-byte gathers at a time (inside the scan every candidate's gather had to return
+  // before the next band could be looked at)
+  __shared__ uint16_t s_cand[kStereoBatch][64 * 4];   // [slot][work-item]: conflict-free columns
+  const int me = threadIdx.x;
+  auto flush = [&](int n, int t0) {
+    for (int c0 = 0; c0 < n; c0 += 4) {   // four gathers in flight, then their distances in index order
+      int iR[4];
+      unsigned long long w[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        iR[u] = t0 + s_cand[imin(c0 + u, n - 1)][me];
+        const unsigned long long* t = DR + 4 * (size_t)iR[u];
+        w[u][0] = t[0]; w[u][1] = t[1]; w[u][2] = t[2]; w[u][3] = t[3];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int dist = __popcll(q0 ^ w[u][0]) + __popcll(q1 ^ w[u][1]) + __popcll(q2 ^ w[u][2]) + __popcll(q3 ^ w[u][3]);
+        if (c0 + u < n && dist < bestDist) { bestDist = dist; bestIdxR = iR[u]; }
+      }
+    }
+  };
   for (int t0 = 0; t0 < Nr; t0 += kStereoTile) {
     const int nt = imin(kStereoTile, Nr - t0);
     __syncthreads();
@@ -2059,7 +2082,8 @@ __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restric
       s_oct[j] = (uint8_t)k.octave;
     }
     __syncthreads();
-    if (searching)
+    if (searching) {
+      int nc = 0;
       for (int j = 0; j < nt; ++j) {
         const int band = s_band[j];
         if (rowb < (band & 0xffff) || rowb > (band >> 16)) continue;
@@ -2067,10 +2091,11 @@ __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restric
         if (octR < levelL - 1 || octR > levelL + 1) continue;
         const float uR = s_u[j];
         if (!(uR >= minU && uR <= maxU)) continue;
-        const unsigned long long* t = DR + 4 * (size_t)(t0 + j);
-        const int dist = __popcll(q0 ^ t[0]) + __popcll(q1 ^ t[1]) + __popcll(q2 ^ t[2]) + __popcll(q3 ^ t[3]);
-        if (dist < bestDist) { bestDist = dist; bestIdxR = t0 + j; }
+        s_cand[nc][me] = (uint16_t)j;
+        if (++nc == kStereoBatch) { flush(nc, t0); nc = 0; }
       }
+      flush(nc, t0);
+    }
   }
   if (!live) return;
   if (searching) {
@@ -2090,6 +2115,28 @@ __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restric
         int sad[11];
 #pragma unroll
         for (int k = 0; k < 11; ++k) sad[k] = 0;
+        // windows that lie inside the level (nearly all): a row of the left window is three unaligned words, of the right one six;
+        // the 11 shifted comparisons are byte-aligned word triples (v_alignbyte_b32) and three v_sad_u8 each, the twelfth byte
+        // masked on both sides (round 6; 32 byte loads and 121 subtract / absolute / add triples per row before)
+        const bool inside = xl0 >= 0 && xl0 + 12 <= g.w && xr0 >= 0 && xr0 + 24 <= g.w && yl0 >= 0 && yl0 + 11 <= g.h;
+        if (inside) {
+          for (int yy = 0; yy < 11; ++yy) {
+            const uint8_t* rl = IL + (size_t)(yl0 + yy) * pl + xl0;
+            const uint8_t* rr = IR + (size_t)(yl0 + yy) * pr + xr0;
+            const uint32_t a0 = load_u32_unaligned(rl), a1 = load_u32_unaligned(rl + 4), a2 = load_u32_unaligned(rl + 8) & 0x00ffffffu;
+            uint32_t b[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) b[j] = load_u32_unaligned(rr + 4 * j);
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+              const int w0 = k >> 2, sh = k & 3;
+              const uint32_t c0 = sh ? align_bytes(b[w0 + 1], b[w0], sh) : b[w0];
+              const uint32_t c1 = sh ? align_bytes(b[w0 + 2], b[w0 + 1], sh) : b[w0 + 1];
+              const uint32_t c2 = (sh ? align_bytes(b[w0 + 3], b[w0 + 2], sh) : b[w0 + 2]) & 0x00ffffffu;
+              sad[k] = (int)sad_u8(a2, c2, sad_u8(a1, c1, sad_u8(a0, c0, (uint32_t)sad[k])));
+            }
+          }
+        } else
         for (int yy = 0; yy < 11; ++yy) {
           int a[11], b[21];
 #pragma unroll
