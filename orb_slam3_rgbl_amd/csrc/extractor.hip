@@ -1432,9 +1432,9 @@ static int stereo_enqueue(rgbl_extractor* L, rgbl_extractor* R, int batch, const
   PyrView pr{R->last_img0, R->last_pitch0, R->last_frame0, R->d_pyr, R->pyr_frame};
   hipStream_t s = L->stream;
   L->timer.begin("k_stereo_match", s);
-  // one wave per workgroup for a handful of pairs (a KITTI pair: 32 workgroups on 32 CUs instead of 8), four for batches
-  const int bs = batch < 8 ? 64 : 256;
-  hipLaunchKernelGGL(k_stereo_match, dim3((cap + bs - 1) / bs, batch), dim3(bs), 0, s, L->d_geom, st, pl, pr, d_kpl, d_dl, d_nl,
+  // four waves per workgroup: the right keypoints are staged per workgroup (kStereoTile at a time), a wide group shares that
+  const int bs = 256;
+  hipLaunchKernelGGL(k_stereo_match, dim3((cap * kStereoLanes + bs - 1) / bs, batch), dim3(bs), 0, s, L->d_geom, st, pl, pr, d_kpl, d_dl, d_nl,
                      d_kpr, d_dr, d_nr, cap, mb, mbf, L->cfg.height, d_uright, d_depth, L->d_stereo_sad);
   L->timer.end(s);
   L->timer.begin("k_stereo_filter", s);

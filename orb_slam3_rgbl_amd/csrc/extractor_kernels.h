@@ -2007,6 +2007,7 @@ __global__ __launch_bounds__(kOctWide) void k_test_block_sort(uint64_t* key, uin
 struct ScaleTables { float scale[kMaxLevels], inv_scale[kMaxLevels]; };
 struct PyrView { const uint8_t* img0; int pitch0; size_t frame0; const uint8_t* pyr; size_t pyr_frame; };
 constexpr int kStereoTile = 2048;      // right keypoints staged in LDS per pass of k_stereo_match (18 KB)
+constexpr int kStereoLanes = 4;         // work-items per left keypoint in the candidate search
 constexpr int kStereoBatch = 16;        // candidates whose descriptors are fetched together
 constexpr int kStereoRowBias = 4096;   // row bands are kept as two biased 16-bit halves of one word
 
@@ -2023,13 +2024,16 @@ __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restric
   // The right keypoints' row band [floor(y - 2 s), ceil(y + 2 s)], octave and u - what the reference's vRowIndices table and
   // the candidate tests read - are staged in LDS in tiles of kStereoTile, once per workgroup (round 6: every work-item had
   // fetched all Nr 28-byte records from global memory itself, one dependent load per candidate: 560 us for one KITTI pair).
-  __shared__ float s_u[kStereoTile];
-  __shared__ int s_band[kStereoTile];       // minr (low half, biased) | maxr (high half, biased)
-  __shared__ uint8_t s_oct[kStereoTile];
+  __shared__ __attribute__((aligned(16))) float s_u[kStereoTile];
+  __shared__ __attribute__((aligned(16))) int s_band[kStereoTile];   // minr (low half, biased) | maxr (high half, biased)
+  __shared__ __attribute__((aligned(16))) uint8_t s_oct[kStereoTile];
+  // kStereoLanes work-items per left keypoint: each scans every kStereoLanes-th group of 32 right keypoints (the scan is
+  // N_left x N_right cheap tests - ALU-bound at ~100 us per KITTI pair with one work-item per left keypoint, and a pair's 2000
+  // left keypoints are 32 waves on 256 CUs), the best (distance, index) keys meet in a two-step lane exchange
   const int f = blockIdx.y;
-  const int iL = blockIdx.x * blockDim.x + threadIdx.x;
+  const int iL = (int)(blockIdx.x * blockDim.x + threadIdx.x) / kStereoLanes, part = threadIdx.x & (kStereoLanes - 1);
   const int N = nl[f], Nr = nr[f];
-  if ((int)(blockIdx.x * blockDim.x) >= N) return;   // the whole workgroup is beyond the frame's keypoints (uniform: no barrier is skipped by a part of it)
+  if ((int)(blockIdx.x * blockDim.x) / kStereoLanes >= N) return;   // the whole workgroup is beyond the frame's keypoints (uniform: no barrier is skipped by a part of it)
   const bool live = iL < N;
   const size_t o = (size_t)f * cap + (live ? iL : 0);
   const rgbl_keypoint kL = kpl[o];
@@ -2081,23 +2085,53 @@ __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restric
       s_band[j] = (minr + kStereoRowBias) | ((maxr + kStereoRowBias) << 16);
       s_oct[j] = (uint8_t)k.octave;
     }
+    if (threadIdx.x < 4 && (nt & 3) && (nt & ~3) + (int)threadIdx.x >= nt) s_band[(nt & ~3) + threadIdx.x] = 0xffff;   // no row is below 0xffff
     __syncthreads();
     if (searching) {
+      // Four right keypoints per trip, everything about them read up front (three wide LDS reads, one latency) and tested
+      // without a branch.  The left keypoints of a wave lie on arbitrary rows, so SOME lane has a candidate in nearly every
+      // group of four: an early exit per band never leaves the wave, and the three dependent LDS reads behind it - band,
+      // octave, u - ran one after the other for every right keypoint (~1300 cycles per group of four, 270 us per frame).
       int nc = 0;
-      for (int j = 0; j < nt; ++j) {
-        const int band = s_band[j];
-        if (rowb < (band & 0xffff) || rowb > (band >> 16)) continue;
-        const int octR = s_oct[j];
-        if (octR < levelL - 1 || octR > levelL + 1) continue;
-        const float uR = s_u[j];
-        if (!(uR >= minU && uR <= maxU)) continue;
-        s_cand[nc][me] = (uint16_t)j;
-        if (++nc == kStereoBatch) { flush(nc, t0); nc = 0; }
+      for (int j32 = 32 * part; j32 < nt; j32 += 32 * kStereoLanes) {
+        // 32 right keypoints -> one bit each (pure ALU behind three wide LDS reads per four), then only the set bits are
+        // walked: the append with its rare flush stays out of the per-keypoint path
+        uint32_t mask = 0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          const int j4 = j32 + 4 * g;   // (entries behind nt up to the next multiple of 4 are padding, behind that stale: masked below)
+          const int4 b4 = *reinterpret_cast<const int4*>(&s_band[j4]);
+          const float4 u4 = *reinterpret_cast<const float4*>(&s_u[j4]);
+          const uint32_t o4 = *reinterpret_cast<const uint32_t*>(&s_oct[j4]);
+          const int bb[4] = {b4.x, b4.y, b4.z, b4.w};
+          const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int octR = (int)((o4 >> (8 * u)) & 0xffu);
+            const bool pass = !(rowb < (bb[u] & 0xffff) || rowb > (int)((uint32_t)bb[u] >> 16)) && !(octR < levelL - 1 || octR > levelL + 1) &&
+                              (uu[u] >= minU && uu[u] <= maxU);
+            mask |= pass ? (1u << (4 * g + u)) : 0u;
+          }
+        }
+        if (nt - j32 < 32) mask &= (1u << (nt - j32)) - 1u;
+        while (mask) {
+          const int u = __ffs((int)mask) - 1;
+          mask &= mask - 1u;
+          s_cand[nc][me] = (uint16_t)(j32 + u);
+          if (++nc == kStereoBatch) { flush(nc, t0); nc = 0; }
+        }
       }
       flush(nc, t0);
     }
   }
-  if (!live) return;
+  {
+    // strict '<' in index order == the smallest (distance, index) key: the lanes of a keypoint merge theirs
+    uint32_t key = ((uint32_t)bestDist << 16) | (uint32_t)bestIdxR;
+#pragma unroll
+    for (int m = 1; m < kStereoLanes; m <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)key, m); key = o < key ? o : key; }
+    bestDist = (int)(key >> 16); bestIdxR = (int)(key & 0xffffu);
+  }
+  if (!live || part != 0) return;
   if (searching) {
     if (bestDist < 75 /* (TH_HIGH + TH_LOW) / 2 */) {
       const float uR0 = KR[bestIdxR].x;
