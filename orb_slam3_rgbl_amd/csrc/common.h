@@ -303,6 +303,24 @@ __device__ __forceinline__ int wave_sum_uniform(int v) {
 #endif
 }
 
+// Minimum of an unsigned value over the 64 lanes as a wave-uniform value, the same DPP ladder as wave_sum_uniform (lanes a
+// step has no source for keep their own value: the identity 0xffffffff comes in as `old`).
+__device__ __forceinline__ uint32_t wave_min_uniform(uint32_t v) {
+#ifdef RGBL_EMU
+  for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, m); v = o < v ? o : v; }
+  return v;
+#else
+  auto mn = [](uint32_t a, int b) { return (uint32_t)b < a ? (uint32_t)b : a; };
+  v = mn(v, __builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v = mn(v, __builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v = mn(v, __builtin_amdgcn_update_dpp(-1, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v = mn(v, __builtin_amdgcn_update_dpp(-1, (int)v, 0x140, 0xF, 0xF, false));  // row_mirror: every lane holds its row's minimum
+  v = mn(v, __builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3
+  v = mn(v, __builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+#endif
+}
+
 // Exclusive prefix sum over the 256 work-items of a workgroup (4 waves). `scratch` holds >= 8 values.
 // Returns the exclusive prefix of `v`; *total receives the workgroup sum. Contains two barriers.
 // Inclusive prefix sum over the 64 lanes.  32-bit values: Hillis-Steele inside the rows of 16 with four row_shr DPP adds,

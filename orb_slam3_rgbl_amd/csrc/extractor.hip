@@ -116,6 +116,7 @@ struct rgbl_extractor {
   void* d_color = nullptr;  // staging of one host colour frame (rgbl_extract_color), allocated on first use
   size_t color_bytes = 0;
   size_t stereo_stage_bytes = 0;
+  uint8_t* h_stereo_stage = nullptr;   // page-locked mirror of d_stereo_stage (rgbl_stereo_matches: one request per direction)
   unsigned long long* d_dbg = nullptr;
   // staging for the host entry points and for the lapping permutation
   rgbl_keypoint *d_out_kp = nullptr, *d_tmp_kp = nullptr;
@@ -816,6 +817,7 @@ void rgbl_extractor_destroy(rgbl_extractor* e) {
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->d_stereo_sad) (void)hipFree(e->d_stereo_sad);
   if (e->d_stereo_stage) (void)hipFree(e->d_stereo_stage);
+  if (e->h_stereo_stage) (void)hipHostFree(e->h_stereo_stage);
   if (e->d_color) (void)hipFree(e->d_color);
 #ifndef RGBL_EMU
   if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
@@ -1473,8 +1475,10 @@ int rgbl_stereo_matches(rgbl_extractor* left, rgbl_extractor* right, const rgbl_
   if (bytes > left->stereo_stage_bytes) {
     RGBL_HIP(hipStreamSynchronize(left->stream));
     if (left->d_stereo_stage) RGBL_HIP(hipFree(left->d_stereo_stage));
-    left->d_stereo_stage = nullptr;
+    if (left->h_stereo_stage) RGBL_HIP(hipHostFree(left->h_stereo_stage));
+    left->d_stereo_stage = nullptr; left->h_stereo_stage = nullptr; left->stereo_stage_bytes = 0;
     RGBL_HIP(hipMalloc(&left->d_stereo_stage, bytes));
+    RGBL_HIP(hipHostMalloc(reinterpret_cast<void**>(&left->h_stereo_stage), bytes, hipHostMallocDefault));
     left->stereo_stage_bytes = bytes;
   }
   uint8_t* base = (uint8_t*)left->d_stereo_stage;
@@ -1486,18 +1490,24 @@ int rgbl_stereo_matches(rgbl_extractor* left, rgbl_extractor* right, const rgbl_
   float* d_u = (float*)((uint8_t*)d_n + 256);
   float* d_d = d_u + cap;
   hipStream_t s = left->stream;
+  // the page-locked mirror has the device block's layout: keypoints and descriptors of both views and the counts go up with
+  // ONE request, uRight and depth come back with one (round 5: five uploads and two read-backs from / to pageable memory)
+  uint8_t* hb = left->h_stereo_stage;
   const int32_t counts[2] = {n_left, n_right};
-  RGBL_HIP(hipMemcpyAsync(d_kpl, kp_left, sizeof(rgbl_keypoint) * n_left, hipMemcpyHostToDevice, s));
-  RGBL_HIP(hipMemcpyAsync(d_dl, desc_left, (size_t)32 * n_left, hipMemcpyHostToDevice, s));
+  memcpy(hb, kp_left, sizeof(rgbl_keypoint) * n_left);
+  memcpy(hb + ((uint8_t*)d_dl - base), desc_left, (size_t)32 * n_left);
   if (n_right > 0) {
-    RGBL_HIP(hipMemcpyAsync(d_kpr, kp_right, sizeof(rgbl_keypoint) * n_right, hipMemcpyHostToDevice, s));
-    RGBL_HIP(hipMemcpyAsync(d_dr, desc_right, (size_t)32 * n_right, hipMemcpyHostToDevice, s));
+    memcpy(hb + ((uint8_t*)d_kpr - base), kp_right, sizeof(rgbl_keypoint) * n_right);
+    memcpy(hb + ((uint8_t*)d_dr - base), desc_right, (size_t)32 * n_right);
   }
-  RGBL_HIP(hipMemcpyAsync(d_n, counts, sizeof(counts), hipMemcpyHostToDevice, s));
+  memcpy(hb + ((uint8_t*)d_n - base), counts, sizeof(counts));
+  RGBL_HIP(hipMemcpyAsync(base, hb, (size_t)((uint8_t*)d_n - base) + sizeof(counts), hipMemcpyHostToDevice, s));
   RGBL_TRY(stereo_enqueue(left, right, 1, d_kpl, d_dl, d_n, d_kpr, d_dr, d_n + 1, cap, mb, mbf, d_u, d_d));
-  RGBL_HIP(hipMemcpyAsync(out_uright, d_u, sizeof(float) * n_left, hipMemcpyDeviceToHost, s));
-  RGBL_HIP(hipMemcpyAsync(out_depth, d_d, sizeof(float) * n_left, hipMemcpyDeviceToHost, s));
+  float* h_u = reinterpret_cast<float*>(hb + ((uint8_t*)d_u - base));
+  RGBL_HIP(hipMemcpyAsync(h_u, d_u, sizeof(float) * ((size_t)cap + n_left), hipMemcpyDeviceToHost, s));
   RGBL_HIP(hipStreamSynchronize(s));
+  memcpy(out_uright, h_u, sizeof(float) * n_left);
+  memcpy(out_depth, h_u + cap, sizeof(float) * n_left);
   left->timer.collect();
   return RGBL_OK;
 }

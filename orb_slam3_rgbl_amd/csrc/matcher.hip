@@ -1304,10 +1304,8 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
         else if (dist < second) second = dist;
       }
       // wave-wide: the smallest key, and the smallest distance among everything else
-      uint32_t wbest = best;
-      for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)wbest, m); wbest = o < wbest ? o : wbest; }
-      int other = best == wbest ? second : (best == 0xffffffffu ? 256 : (int)(best >> 16));
-      for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(other, m); other = o < other ? o : other; }
+      const uint32_t wbest = wave_min_uniform(best);   // register-file DPP steps: the two reductions sit in the node's serial loop
+      const int other = (int)wave_min_uniform((uint32_t)(best == wbest ? second : (best == 0xffffffffu ? 256 : (int)(best >> 16))));
       if (wbest == 0xffffffffu) continue;
       const int best_dist = (int)(wbest >> 16), pos = (int)(wbest & 0xffffu);
       if (best_dist <= T.max_best && (float)best_dist < T.nnratio * (float)other) {
