@@ -35,3 +35,4 @@ cp $OUT/pmc_sqA.csv $OUT/r06_pmc_sq_cycles.csv; cp $OUT/pmc_sqB.csv $OUT/r06_pmc
 bash tools/gpu_timeline.sh > $OUT/timeline.log 2>&1; cp $OUT/timeline.csv $OUT/r06_step_timeline.csv
 ( cd tools/micro && ./valu_rates ) > $OUT/r06_valu_rates.txt 2>&1
 cat $OUT/r06_kernel_stats.csv | head -14; cat $OUT/r06_single_frame_kernel_stats.csv | head -14; cat $OUT/r06_valu_rates.txt
+bash tools/gpu_calls.sh r06 > $OUT/calls.log 2>&1; grep -E "^cfg3|^tracking" $OUT/calls.log
