@@ -1584,7 +1584,7 @@ def check_device_frames(lib, n=900, seed=17, w=640, h=360, nfeatures=700):
     return True
 
 
-def check_switches(lib, w=400, h=300, nfeatures=500, batch=8):
+def check_switches(lib, w=400, h=300, nfeatures=500, batch=8, subset=None):
     """Every RGBL_* tuning switch of include/rgbl_frontend.h that changes a launch path (they are read when a handle is
     created): the batch extraction, the host-pointer extraction and the Hamming scan must stay bit-identical under each
     (the header says so, so it is checked)."""
@@ -1592,6 +1592,8 @@ def check_switches(lib, w=400, h=300, nfeatures=500, batch=8):
     settings = [{"RGBL_SPLIT_PYR": "0"}, {"RGBL_SPLIT_PYR": "3"}, {"RGBL_GAUSS_BS": "256"}, {"RGBL_XCD_MAP": "0"}, {"RGBL_DENSE": "0"},
                 {"RGBL_COMPACT": "0"}, {"RGBL_FAST_BS": "128"}, {"RGBL_OCTREE_HIST": "0"}, {"RGBL_OCTREE_WG": "512"}, {"RGBL_GRAPH": "0"},
                 {"RGBL_LEVEL_SPLIT": "0"}, {"RGBL_BF_SPLIT": "0"}, {"RGBL_BF_MFMA": "0"}, {"RGBL_BF_MFMA": "i8"}]
+    if subset is not None:   # the emulator runs a representative half (the CPU suite's time), the MI355X all of them
+        settings = [e for e in settings if list(e.items())[0] in subset]
     for env in settings:
         saved = {k: os.environ.get(k) for k in env}
         os.environ.update(env)

@@ -420,4 +420,6 @@ def test_projection_searches_beyond_the_lds_resolve(emu_lib):
 
 
 def test_every_tuning_switch_is_bit_identical(emu_lib):
-    assert pc.check_switches(emu_lib, w=320, h=280, nfeatures=300) == 14
+    subset = {("RGBL_SPLIT_PYR", "0"), ("RGBL_XCD_MAP", "0"), ("RGBL_DENSE", "0"), ("RGBL_COMPACT", "0"), ("RGBL_GRAPH", "0"), ("RGBL_BF_MFMA", "0"),
+              ("RGBL_BF_MFMA", "i8")}
+    assert pc.check_switches(emu_lib, w=320, h=280, nfeatures=300, subset=subset) == 7

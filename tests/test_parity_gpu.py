@@ -479,3 +479,29 @@ def test_every_tuning_switch_is_bit_identical(gpu_lib):
     """include/rgbl_frontend.h: 'results are bit-identical under all of them' - batch + single-frame extraction and the Hamming
     scan under every switch that changes a launch path, and the batch path with profiling on."""
     assert pc.check_switches(gpu_lib, w=1241, h=376, nfeatures=2000, batch=8) == 14
+
+
+def test_bow_transform_on_a_vocabulary_of_orbvoc_size(gpu_lib):
+    """Row f4 at the size of the real ORBvoc.txt (k = 10, L = 6: ~10^6 nodes, 30 MB of node descriptors resident in HBM; the file
+    itself is not in the image): transform(features, BowVector, FeatureVector, levelsup = 4) of 2000 descriptors from host arrays
+    and from a resident frame against the oracle's descent."""
+    import time
+    t0 = time.time()
+    voc = synth.make_vocabulary(10, 6, 11)
+    varr = synth.vocabulary_arrays(voc)
+    assert varr["n_nodes"] > 800000, varr["n_nodes"]
+    rng = np.random.default_rng(3)
+    leaves = voc["desc"][voc["is_leaf"] > 0]
+    pick = leaves[rng.integers(0, len(leaves), 1500)]
+    desc = np.ascontiguousarray(np.concatenate([pick ^ np.packbits(rng.random((len(pick), 256)) < 0.03, axis=1, bitorder="little"),
+                                                synth.descriptors(500, 5)]))
+    want = O.bow_transform(varr, desc, 4)
+    V = F.ORBVocabulary(lib=gpu_lib).from_arrays(varr)
+    fr = F.DeviceFrame(len(desc), lib=gpu_lib).upload(desc, np.zeros((len(desc), 2), np.float32), np.zeros(len(desc), np.int32))
+    for got in (V.transform(desc, 4), V.prepare_transform_frame(fr, 4)()):
+        for g, w, name in zip(got, want, ("word ids", "word values", "node ids", "node offsets", "feature indices")):
+            assert np.array_equal(g.view(np.uint64) if g.dtype == np.float64 else g, w.view(np.uint64) if w.dtype == np.float64 else w), name
+    assert len(want[2]) <= 100 and len(want[0]) > 1000   # levelsup = 4 of 6 levels: FeatureVector nodes of tree level 2
+    fr.close()
+    V.close()
+    print("ORBvoc-size vocabulary: %d nodes, %.1f s" % (varr["n_nodes"], time.time() - t0))

@@ -16,3 +16,6 @@ for san in address undefined; do
     LD_PRELOAD=$rt ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 RGBL_SANITIZED_LIB=$lib python "$ROOT/tools/sanitizer_checks.py" $part 2>&1 | tail -1
   done
 done
+# ThreadSanitizer: the reference's concurrent callers (two extractor threads, three matcher threads) on the emulator built with
+# -fsanitize=thread (tests/test_shim_threads.py builds it; the emulator's fibers are announced to TSan)
+cd "$ROOT" && RGBL_TSAN=1 python -m pytest tests/test_shim_threads.py -q -k thread_sanitizer 2>&1 | tail -1
