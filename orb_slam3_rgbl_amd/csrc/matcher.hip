@@ -827,9 +827,14 @@ __device__ __forceinline__ unsigned long long proj_best(const ProjDev& P, const 
 // round is three passes over them, and with the arrays in global memory every pass was a chain of dependent ~1 us loads
 // (round 6: 8 rounds of 17 us for a frame's 2000 points).
 constexpr int kResolveLdsN2 = 6144, kResolveLdsN1 = 12288;
+// min_unres[c] = (stamp << 20 | lowest unresolved blocker that may still take c), stamp = kStampMax - round: a round's entries are
+// smaller than everything older rounds left behind, so the array is not cleared between rounds (one pass and one barrier per
+// round less); it is refilled with INT_MAX every kStampMax rounds (the worst case - a chain of n1 blockers - takes n1 rounds).
+constexpr int kStampMax = 2047;
+__device__ __forceinline__ bool lower_unresolved(int m, int stamp, int i) { return (m >> 20) == stamp && (m & 0xfffff) < i; }
 template <bool LDS>
 __global__ __launch_bounds__(kProjBS) void k_proj_resolve(ProjDev P) {
-  __shared__ int s_unres;
+  __shared__ int s_unres[2];
   __shared__ int32_t s_taken[LDS ? kResolveLdsN2 : 1], s_min[LDS ? kResolveLdsN2 : 1];
   __shared__ uint8_t s_state[LDS ? kResolveLdsN1 : 1];
   int32_t* taken_by = LDS ? s_taken : P.taken_by;
@@ -839,49 +844,52 @@ __global__ __launch_bounds__(kProjBS) void k_proj_resolve(ProjDev P) {
   if (LDS) {
     for (int c = tid; c < P.n2; c += kProjBS) s_taken[c] = P.taken_by[c];
     for (int i = tid; i < P.n1; i += kProjBS) s_state[i] = P.state[i];
-    __syncthreads();
   }
+  if (tid < 2) s_unres[tid] = 0;
   for (int round = 0; round <= P.n1; ++round) {
-    for (int c = tid; c < P.n2; c += kProjBS) min_unres[c] = INT_MAX;
-    if (tid == 0) s_unres = 0;
+    const int stamp = kStampMax - round % kStampMax, b = round & 1;
+    if (round % kStampMax == 0) {
+      __syncthreads();
+      for (int c = tid; c < P.n2; c += kProjBS) min_unres[c] = INT_MAX;
+    }
     __syncthreads();
     // every unresolved blocker announces itself on the features it may still take
     for (int i = tid; i < P.n1; i += kProjBS) {
       if (state[i] != 0 || !P.obs1[i]) continue;
-      const int n = P.ncand[i];
+      const int n = P.ncand[i], me = (stamp << 20) | i;
       if (!(n & kProjOverflow)) {
         for (int k = 0; k < n; ++k) {
           const int c = (int)(P.cand[(size_t)i * kProjCand + k] & 0xffffu);
-          if (taken_by[c] >= i) atomicMin(&min_unres[c], i);
+          if (taken_by[c] >= i) atomicMin(&min_unres[c], me);
         }
       } else {
         const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
         const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
         for_candidates(P, P.win[i], P.rng[i], [&](int c, int) {
           if (taken_by[c] < i) return;
-          if (hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)) <= P.max_dist) atomicMin(&min_unres[c], i);
+          if (hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)) <= P.max_dist) atomicMin(&min_unres[c], me);
         });
       }
     }
     __syncthreads();
+    // decide AND commit in one pass: a point whose best available feature no lower unresolved blocker can still take is final
+    // and occupies it at once.  What a concurrent work-item sees of that store does not matter: a HIGHER point that misses it
+    // picks the same feature, finds this point's announcement in front of it and waits a round; one that sees it takes its next
+    // choice, which is what the sequential loop would have given it; LOWER points never want a feature that becomes final here
+    // (their announcement would have held this point back).  Two blockers never become final on one feature in the same round.
     for (int i = tid; i < P.n1; i += kProjBS) {
       if (state[i] != 0) continue;
       const unsigned long long best = proj_best(P, taken_by, i);
       const int c = (int)(best & 0xffffu);
-      if (best == ~0ull) { state[i] = 2; P.choice[i] = -1; }           // everything viable is taken: no match
-      else if (min_unres[c] >= i) { state[i] = 2; P.choice[i] = c; }  // nobody in front of i can still take c
-      else atomicAdd(&s_unres, 1);
+      if (best == ~0ull) { state[i] = 1; P.choice[i] = -1; }           // everything viable is taken: no match
+      else if (!lower_unresolved(min_unres[c], stamp, i)) {              // nobody in front of i can still take c
+        state[i] = 1; P.choice[i] = c;
+        if (P.obs1[i]) taken_by[c] = i;
+      } else atomicAdd(&s_unres[b], 1);
     }
+    if (tid == 0) s_unres[b ^ 1] = 0;
     __syncthreads();
-    for (int i = tid; i < P.n1; i += kProjBS) {
-      if (state[i] != 2) continue;
-      state[i] = 1;
-      const int c = P.choice[i];
-      if (c >= 0 && P.obs1[i]) taken_by[c] = i;  // two blockers can never become final on one feature in the same round
-    }
-    __syncthreads();
-    if (s_unres == 0) break;
-    __syncthreads();
+    if (s_unres[b] == 0) break;
   }
 }
 
@@ -1037,10 +1045,10 @@ __device__ __forceinline__ void local_available(const ProjDev& P, const int32_t*
   });
 }
 
-// grid = 1, block = kProjBS; LDS as for k_proj_resolve
+// grid = 1, block = kProjBS; LDS, round stamps and the merged decide + commit pass as for k_proj_resolve
 template <bool LDS>
 __global__ __launch_bounds__(kProjBS) void k_local_resolve(ProjDev P) {
-  __shared__ int s_unres;
+  __shared__ int s_unres[2];
   __shared__ int32_t s_taken[LDS ? kResolveLdsN2 : 1], s_min[LDS ? kResolveLdsN2 : 1];
   __shared__ uint8_t s_state[LDS ? kResolveLdsN1 : 1];
   int32_t* taken_by = LDS ? s_taken : P.taken_by;
@@ -1050,38 +1058,40 @@ __global__ __launch_bounds__(kProjBS) void k_local_resolve(ProjDev P) {
   if (LDS) {
     for (int c = tid; c < P.n2; c += kProjBS) s_taken[c] = P.taken_by[c];
     for (int i = tid; i < P.n1; i += kProjBS) s_state[i] = P.state[i];
-    __syncthreads();
   }
+  if (tid < 2) s_unres[tid] = 0;
   for (int round = 0; round <= P.n1; ++round) {
-    for (int c = tid; c < P.n2; c += kProjBS) min_unres[c] = INT_MAX;
-    if (tid == 0) s_unres = 0;
+    const int stamp = kStampMax - round % kStampMax, b = round & 1;
+    if (round % kStampMax == 0) {
+      __syncthreads();
+      for (int c = tid; c < P.n2; c += kProjBS) min_unres[c] = INT_MAX;
+    }
     __syncthreads();
     for (int i = tid; i < P.n1; i += kProjBS) {
       if (state[i] != 0 || !P.obs1[i]) continue;
-      local_available(P, taken_by, i, [&](int dist, int, int c) { if (dist <= 100) atomicMin(&min_unres[c], i); });
+      const int me = (stamp << 20) | i;
+      local_available(P, taken_by, i, [&](int dist, int, int c) { if (dist <= 100) atomicMin(&min_unres[c], me); });
     }
     __syncthreads();
+    // (a settled point's available candidates carry no announcement of a lower point, so no lower point can occupy one of them in
+    // this pass; a higher point's store leaves taken_by[c] >= i: still available to i)
     for (int i = tid; i < P.n1; i += kProjBS) {
       if (state[i] != 0) continue;
       LocalScan sc;
       bool settled = true;
       local_available(P, taken_by, i, [&](int dist, int level, int c) {
         sc.visit(dist, level, c);
-        if (min_unres[c] < i) settled = false;  // somebody in front of i may still take this feature
+        if (lower_unresolved(min_unres[c], stamp, i)) settled = false;  // somebody in front of i may still take this feature
       });
-      if (settled) { state[i] = 2; P.choice[i] = sc.accept(P.nnratio); }
-      else atomicAdd(&s_unres, 1);
+      if (settled) {
+        const int c = sc.accept(P.nnratio);
+        state[i] = 1; P.choice[i] = c;
+        if (c >= 0 && P.obs1[i]) taken_by[c] = i;
+      } else atomicAdd(&s_unres[b], 1);
     }
+    if (tid == 0) s_unres[b ^ 1] = 0;
     __syncthreads();
-    for (int i = tid; i < P.n1; i += kProjBS) {
-      if (state[i] != 2) continue;
-      state[i] = 1;
-      const int c = P.choice[i];
-      if (c >= 0 && P.obs1[i]) taken_by[c] = i;
-    }
-    __syncthreads();
-    if (s_unres == 0) break;
-    __syncthreads();
+    if (s_unres[b] == 0) break;
   }
 }
 

@@ -61,4 +61,25 @@ def hamming_case(lib, rng):
     return "hamming %5d x %5d" % (na, nb)
 
 
-CASES = {"extractor": extractor_case, "low_contrast": low_contrast_case, "depth": depth_case, "hamming": hamming_case}
+def greedy_search_case(lib, rng):
+    """The sequential, blocking searches (SearchByProjection frame-to-frame and key-frame-to-frame, SearchLocalPoints): random
+    sizes on both sides of the resolve kernels' LDS limits, every motion / window, dense clusters that make long blocker chains -
+    many rounds of the round-based resolve with real concurrency between the work-items of a round."""
+    kind = int(rng.integers(0, 3))
+    n1 = int(rng.choice([40, 300, 1500, 2000, 3000, 6000, 12500]))
+    n2 = int(rng.choice([60, 500, 2000, 3000, 6100, 6200, 9000]))
+    seed = int(rng.integers(0, 100000))
+    if kind == 0:
+        motion, th = str(rng.choice(["forward", "backward", "none"])), float(rng.choice([7.0, 15.0, 30.0]))
+        n = pc.check_search_by_projection(lib, seed, motion, th, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), n1=n1, n2=n2)
+        return "SearchByProjection %5d -> %5d %s th %g: %d matches" % (n1, n2, motion, th, n)
+    if kind == 1:
+        th = float(rng.choice([1.0, 3.0, 5.0, 15.0]))
+        n = pc.check_search_local_points(lib, seed, th, float(rng.choice([0.7, 0.8, 0.9])), n1=n1, n2=n2)
+        return "SearchLocalPoints %5d -> %5d th %g: %d matches" % (n1, n2, th, n)
+    n = pc.check_search_by_projection_keyframe(lib, seed, float(rng.choice([3.0, 10.0, 15.0])), int(rng.choice([64, 100, 255])), True, n1=min(n1, 6000), n2=n2)
+    return "SearchByProjection(F, KF) %5d -> %5d: %d matches" % (min(n1, 6000), n2, n)
+
+
+CASES = {"extractor": extractor_case, "low_contrast": low_contrast_case, "depth": depth_case, "hamming": hamming_case,
+         "greedy_search": greedy_search_case}
