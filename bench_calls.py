@@ -87,6 +87,7 @@ def real_frames(lib, n=2, seq=7, nfeatures=2000, ini=12, mn=7, w=None, h=None):
         dm.CalculateDepthFromPcd(kps, kps, synth.lidar_scan(seq + i), w, h)
         # the frame's resident copy: straight from the extractor's and the depth module's device results (no PCIe)
         dev = F.DeviceFrame(len(kps) + 64, lib=lib).capture(ex, len(kps), dm)
+        dev.set_grid(np.array([0, 0, w, h, np.float32(64) / np.float32(w), np.float32(48) / np.float32(h)], np.float32))   # Frame::AssignFeaturesToGrid, once
         out.append(dict(xy=np.stack([kps["x"], kps["y"]], 1).astype(np.float32), desc=desc.copy(), octave=kps["octave"].astype(np.int32),
                         angle=kps["angle"].astype(np.float32), uright=dm.mvuRight.copy(), resident=dev))
     dm.close()

@@ -228,6 +228,7 @@ SYMBOLS = {
     "rgbl_device_frame_capture": (_I, [_V, _V, _I, _I, _V, _V, _V, _I]),
     "rgbl_device_frame_set_feature_vector": (_I, [_V, _I, _V, _V]),
     "rgbl_device_frame_size": (_I, [_V]),
+    "rgbl_device_frame_set_grid": (_I, [_V, _V]),
     "rgbl_device_frame_download": (_I, [_V, _V, _V, _V, _V]),
     "rgbl_bow_transform_frame": (_I, [_V, _V, _I, _V, _V, _I, C.POINTER(_I), _V, _V, _V, _I, C.POINTER(_I)]),
 }

@@ -121,6 +121,12 @@ struct rgbl_device_frame {
   float* d_xy = nullptr;
   int32_t* d_oct = nullptr;
   float* d_ur = nullptr;
+  // Frame::AssignFeaturesToGrid, kept with the frame (rgbl_device_frame_set_grid): the projection searches skip their grid build
+  uint32_t* d_cell_start = nullptr;   // 64 x 48 + 1
+  uint16_t* d_cell_items = nullptr;   // cap
+  int32_t* d_grid_scratch = nullptr;  // cap (what k_proj_grid initialises besides the grid)
+  float grid[6] = {0, 0, 0, 0, 0, 0};
+  bool has_grid = false;
   int32_t* d_fv = nullptr;      // node_off [n_nodes + 1] | node_feat [nf]
   int fv_cap = 0, n_nodes = -1, nf = 0;
   uint8_t* h_pin = nullptr;     // page-locked mirror of one upload

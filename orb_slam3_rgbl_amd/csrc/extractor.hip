@@ -1172,6 +1172,7 @@ int rgbl_device_frame_capture(rgbl_device_frame* f, rgbl_extractor* e, int frame
   RGBL_HIP(hipStreamWaitEvent(s, f->ready, 0));          // an upload of the frame's own still in flight
   if (ds && ds != s) RGBL_TRY(rgbl_stream_wait(s, ds));  // mvuRight is written on the depth handle's stream
   f->n = n;
+  f->has_grid = false;   // new keypoints: rgbl_device_frame_set_grid again
   if (n > 0) {
     const rgbl_keypoint* kp = e->d_out_kp + (size_t)frame * e->out_cap;
     hipLaunchKernelGGL(k_frame_capture, dim3((n + 255) / 256), dim3(256), 0, s, kp, e->d_out_desc + (size_t)frame * e->out_cap * 32, n, d_ur,

@@ -608,6 +608,7 @@ struct ProjDev {
   // scratch
   uint32_t* cell_start;      // kGridCells + 1
   uint16_t* cell_items;      // n2 feature indices grouped by grid cell
+  int init_taken;            // 1: the grid comes from a resident frame, the candidate kernel initialises taken_by
   int32_t* taken_by;         // n2: index of the blocker holding the feature (INT_MAX = free)
   int32_t* min_unres;        // n2
   int32_t* owner;            // n2: SearchForInitialization's vnMatches21
@@ -741,10 +742,19 @@ __global__ __launch_bounds__(kProjBS) void k_proj_grid(ProjDev P) {
   }
 }
 
+// With the grid taken from a resident frame nobody runs k_proj_grid: its other job - who holds a feature before the call - is
+// done by the candidate kernels' workgroups on the way (the resolve kernel behind them is the first reader).
+__device__ __forceinline__ void init_taken_by(const ProjDev& P) {
+  if (!P.init_taken) return;
+  for (int c = (int)(blockIdx.x * blockDim.x + threadIdx.x); c < P.n2; c += (int)(gridDim.x * blockDim.x))
+    P.taken_by[c] = (P.blocked2 && P.blocked2[c]) ? -1 : INT_MAX;
+}
+
 // grid = ceil(n1 / 4), block = 256 = one wave per LastFrame map point: projection and search window (ORBmatcher.cc:1696-1735,
 // computed by every lane alike), then its viable candidates by wave_candidates
 constexpr int kPointsPerBlock = 4;
 __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P) {
+  init_taken_by(P);
   const int i = blockIdx.x * kPointsPerBlock + wave_id();
   if (i >= P.n1) return;
   const int lane = lane_id();
@@ -991,6 +1001,7 @@ struct LocalScan {
 
 // grid = ceil(n1 / 4), block = 256 = one wave per map point
 __global__ __launch_bounds__(256) void k_local_candidates(ProjDev P) {
+  init_taken_by(P);
   const int i = blockIdx.x * kPointsPerBlock + wave_id();
   if (i >= P.n1) return;
   const int lane = lane_id();
@@ -1570,6 +1581,9 @@ void rgbl_device_frame_destroy(rgbl_device_frame* f) {
   if (f->stream) { (void)hipStreamSynchronize(f->stream); (void)hipStreamDestroy(f->stream); }
   if (f->block) (void)hipFree(f->block);
   if (f->d_fv) (void)hipFree(f->d_fv);
+  if (f->d_cell_start) (void)hipFree(f->d_cell_start);
+  if (f->d_cell_items) (void)hipFree(f->d_cell_items);
+  if (f->d_grid_scratch) (void)hipFree(f->d_grid_scratch);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
   delete f;
 }
@@ -1600,6 +1614,7 @@ int rgbl_device_frame_upload(rgbl_device_frame* f, int n, const uint8_t* desc, c
   RGBL_HIP(hipEventRecord(f->ready, f->stream));
   RGBL_HIP(hipStreamSynchronize(f->stream));   // the mirror is reused by the next upload; the caller's arrays are free at once anyway
   f->n = n;
+  f->has_grid = false;   // new keypoints: rgbl_device_frame_set_grid again
   return RGBL_OK;
 }
 
@@ -1624,6 +1639,29 @@ int rgbl_device_frame_set_feature_vector(rgbl_device_frame* f, int n_nodes, cons
   RGBL_HIP(hipEventRecord(f->ready, f->stream));
   RGBL_HIP(hipStreamSynchronize(f->stream));
   f->n_nodes = n_nodes; f->nf = nf;
+  return RGBL_OK;
+}
+
+int rgbl_device_frame_set_grid(rgbl_device_frame* f, const float grid[6]) {
+  if (!f || !grid) { set_error("device frame: null argument"); return RGBL_ERR_INVALID; }
+  RGBL_HIP(hipSetDevice(f->device));
+  if (!f->d_cell_start) {
+    RGBL_HIP(hipMalloc(&f->d_cell_start, sizeof(uint32_t) * (kGridCells + 1)));
+    RGBL_HIP(hipMalloc(&f->d_cell_items, sizeof(uint16_t) * (size_t)f->cap));
+    RGBL_HIP(hipMalloc(&f->d_grid_scratch, sizeof(int32_t) * (size_t)f->cap));
+  }
+  ProjDev P;
+  memset(&P, 0, sizeof(P));
+  P.n2 = f->n; P.xy2 = f->d_xy;
+  memcpy(P.grid, grid, sizeof(P.grid));
+  P.cell_start = f->d_cell_start; P.cell_items = f->d_cell_items; P.taken_by = f->d_grid_scratch;
+  RGBL_HIP(hipStreamWaitEvent(f->stream, f->ready, 0));   // the keypoints may still be on their way (capture)
+  hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, f->stream, P);
+  RGBL_HIP(hipGetLastError());
+  RGBL_HIP(hipEventRecord(f->ready, f->stream));
+  RGBL_HIP(hipStreamSynchronize(f->stream));
+  memcpy(f->grid, grid, sizeof(f->grid));
+  f->has_grid = true;
   return RGBL_OK;
 }
 
@@ -1986,11 +2024,27 @@ int put_frame2(HostCall& hc, ProjDev& P, const rgbl_device_frame* dev2, int n2, 
     if (want_ur) P.ur2 = dev2->d_ur;
     return RGBL_OK;
   }
+
   RGBL_TRY(hc.put(&P.xy2, xy2, (size_t)n2 * 2));
   RGBL_TRY(hc.put(&P.oct2, oct2, (size_t)n2));
   if (want_ur) RGBL_TRY(hc.put(&P.ur2, ur2, (size_t)n2));
   RGBL_TRY(hc.put(&P.desc2, desc2, (size_t)n2 * 32));
   return RGBL_OK;
+}
+
+// Frame::AssignFeaturesToGrid for the call: the resident frame's own grid when it has one for these image bounds
+// (rgbl_device_frame_set_grid), else k_proj_grid on the call's scratch.  P.grid, P.xy2, P.blocked2 must be set.
+void grid_for_call(rgbl_matcher* m, hipStream_t s, ProjDev& P, const rgbl_device_frame* dev2) {
+  if (dev2 && dev2->has_grid && memcmp(dev2->grid, P.grid, sizeof(P.grid)) == 0) {
+    P.cell_start = dev2->d_cell_start;
+    P.cell_items = dev2->d_cell_items;
+    P.init_taken = 1;
+    return;
+  }
+  P.init_taken = 0;
+  m->timer.begin("k_proj_grid", s);
+  hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
+  m->timer.end(s);
 }
 
 int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* out_nmatches) {
@@ -2041,9 +2095,7 @@ int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* o
   P.forward = in.forward; P.backward = in.backward;
   P.skip_behind = in.skip_behind; P.max_dist = in.max_dist;
   P.sim3_mode = in.sim3_mode;
-  m->timer.begin("k_proj_grid", s);
-  hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
-  m->timer.end(s);
+  grid_for_call(m, s, P, in.dev2);
   m->timer.begin("k_proj_candidates", s);
   hipLaunchKernelGGL(k_proj_candidates, dim3((n1 + kPointsPerBlock - 1) / kPointsPerBlock), dim3(256), 0, s, P);
   m->timer.end(s);
@@ -2212,9 +2264,7 @@ static int fuse_core(rgbl_matcher* m, const rgbl_fuse_input* in, int cam_frame, 
     P.scale[l] = l < in->n_levels ? in->scale_factors[l] : 1.f;
     Fz.inv_sigma2[l] = l < in->n_levels ? in->inv_level_sigma2[l] : 1.f;
   }
-  m->timer.begin("k_proj_grid", s);
-  hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
-  m->timer.end(s);
+  grid_for_call(m, s, P, in->device2);
   m->timer.begin("k_fuse_search", s);
   hipLaunchKernelGGL(k_fuse_search, dim3((n1 + 63) / 64), dim3(64), 0, s, P, Fz);
   m->timer.end(s);
@@ -2331,9 +2381,7 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
   P.th = in->th;
   P.nnratio = in->nnratio;
   for (int l = 0; l < kProjMaxLevels; ++l) P.scale[l] = l < in->n_levels ? in->scale_factors[l] : 1.f;
-  m->timer.begin("k_proj_grid", s);
-  hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
-  m->timer.end(s);
+  grid_for_call(m, s, P, in->device2);
   m->timer.begin("k_local_candidates", s);
   hipLaunchKernelGGL(k_local_candidates, dim3((n1 + kPointsPerBlock - 1) / kPointsPerBlock), dim3(256), 0, s, P);
   m->timer.end(s);
@@ -2398,9 +2446,7 @@ int rgbl_search_for_initialization(rgbl_matcher* m, const rgbl_initialization_in
   int v = 51;
   while (v <= 256 && !((float)v * in->nnratio > 50.0f)) ++v;
   P.max_dist = v - 1;
-  m->timer.begin("k_proj_grid", s);
-  hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
-  m->timer.end(s);
+  grid_for_call(m, s, P, nullptr);
   m->timer.begin("k_init_candidates", s);
   hipLaunchKernelGGL(k_init_candidates, dim3((n1 + 63) / 64), dim3(64), 0, s, P);
   m->timer.end(s);

@@ -362,6 +362,12 @@ class DeviceFrame:
         L.check(self.lib, self.lib.rgbl_device_frame_set_feature_vector(self.h, len(off) - 1, L.ptr(off), L.ptr(ft) if len(ft) else None))
         return self
 
+    def set_grid(self, grid):
+        """Frame::AssignFeaturesToGrid kept with the frame (grid = mnMinX, mnMinY, mnMaxX, mnMaxY, the two inverse cell sizes)."""
+        g = np.ascontiguousarray(grid, np.float32)
+        L.check(self.lib, self.lib.rgbl_device_frame_set_grid(self.h, L.ptr(g)))
+        return self
+
     def __len__(self):
         return self.lib.rgbl_device_frame_size(self.h)
 

@@ -172,7 +172,8 @@ void ORBextractor::UndistortKeyPoints(const std::vector<cv::KeyPoint>& mvKeys, c
   for (int i = 0; i < n; ++i) { mvKeysUn[i].pt.x = xy[2 * i]; mvKeysUn[i].pt.y = xy[2 * i + 1]; }
 }
 
-bool ORBextractor::CaptureDeviceFrame(rgbl_device_frame*& frame, int n, rgbl_depth* depth, const cv::Mat& K, const cv::Mat& mDistCoef) {
+bool ORBextractor::CaptureDeviceFrame(rgbl_device_frame*& frame, int n, rgbl_depth* depth, const cv::Mat& K, const cv::Mat& mDistCoef,
+                                      const float* grid6) {
   if (!mpHandle) { std::cerr << "[ORBextractor] CaptureDeviceFrame needs an extractor that has processed an image" << std::endl; return false; }
   if (frame && rgbl_device_frame_size(frame) < 0) return false;
   if (!frame && rgbl_device_frame_create(device, std::max(rgbl_extractor_max_keypoints(mpHandle), 1), &frame) != RGBL_OK) {
@@ -187,6 +188,10 @@ bool ORBextractor::CaptureDeviceFrame(rgbl_device_frame*& frame, int n, rgbl_dep
     for (int i = 0; i < nd; ++i) dist[i] = mDistCoef.at<float>(i);
   }
   if (rgbl_device_frame_capture(frame, mpHandle, 0, n, depth, und ? k : nullptr, und ? dist : nullptr, und ? nd : 0) != RGBL_OK) {
+    std::cerr << "[ORBextractor] " << rgbl_last_error() << std::endl;
+    return false;
+  }
+  if (grid6 && rgbl_device_frame_set_grid(frame, grid6) != RGBL_OK) {
     std::cerr << "[ORBextractor] " << rgbl_last_error() << std::endl;
     return false;
   }

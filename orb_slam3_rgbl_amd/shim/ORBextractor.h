@@ -50,8 +50,10 @@ class ORBextractor {
   // after CalculateDepthFromPcd (mvuRight), or NULL; K / mDistCoef as for UndistortKeyPoints (empty: mvKeysUn = mvKeys).
   // Device to device - nothing crosses PCIe.  `frame` is created on first use and reused (capacity grows as needed);
   // the owner (Frame / KeyFrame) destroys it with rgbl_device_frame_destroy.  Returns false (and says why) on failure.
+  // grid6 (optional) = Frame::mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv: the frame then keeps its
+  // AssignFeaturesToGrid as well and the projection searches skip theirs.
   bool CaptureDeviceFrame(rgbl_device_frame*& frame, int n, rgbl_depth* depth = nullptr, const cv::Mat& K = cv::Mat(),
-                          const cv::Mat& mDistCoef = cv::Mat());
+                          const cv::Mat& mDistCoef = cv::Mat(), const float* grid6 = nullptr);
 
   int inline GetLevels() { return nlevels; }
   float inline GetScaleFactor() { return scaleFactor; }

@@ -1486,9 +1486,10 @@ def check_device_frames(lib, n=900, seed=17, w=640, h=360, nfeatures=700):
     d1.close()
     d2.close()
     # the projection searches: the CurrentFrame / key frame resident, the map points from the host
-    def frame2(c, ur=True):
+    def frame2(c, ur=True, grid=True):
         f = F.DeviceFrame(len(c["kp2_xy"]), lib=lib)
-        return f.upload(c["desc2"], c["kp2_xy"], c["kp2_octave"], c["uright2"] if ur and "uright2" in c else None)
+        f.upload(c["desc2"], c["kp2_xy"], c["kp2_octave"], c["uright2"] if ur and "uright2" in c else None)
+        return f.set_grid(c["grid"]) if grid else f   # with its own AssignFeaturesToGrid: the calls skip their grid build
 
     def hollow2(c):
         z = {k: np.zeros_like(c[k]) for k in ("kp2_xy", "kp2_octave", "desc2") if k in c}
@@ -1496,13 +1497,19 @@ def check_device_frames(lib, n=900, seed=17, w=640, h=360, nfeatures=700):
             z["uright2"] = np.zeros_like(c["uright2"])
         return dict(c, **z)
     case = make_projection_case(n, n + 50, seed + 1, "forward")
-    f2 = frame2(case)
     mt = F.ORBmatcher(0.9, True, lib=lib)
-    for th in (7.0, 15.0):
-        want = O.search_by_projection(case, th, False, True)
-        got = mt.SearchByProjection(dict(hollow2(case), device2=f2), th, False)
-        assert got[1] == want[1] and np.array_equal(got[0], want[0]), "SearchByProjection on a resident CurrentFrame"
-    f2.close()
+    for with_grid in (False, True):
+        f2 = frame2(case, grid=with_grid)
+        for th in (7.0, 15.0):
+            want = O.search_by_projection(case, th, False, True)
+            got = mt.SearchByProjection(dict(hollow2(case), device2=f2), th, False)
+            assert got[1] == want[1] and np.array_equal(got[0], want[0]), "SearchByProjection on a resident CurrentFrame"
+        if with_grid:   # a grid for other image bounds is not used: the call builds its own
+            other = dict(case, grid=np.array([0, 0, 1300, 400, 64 / 1300.0, 48 / 400.0], np.float32))
+            want = O.search_by_projection(other, 7.0, False, True)
+            got = mt.SearchByProjection(dict(hollow2(other), device2=f2), 7.0, False)
+            assert got[1] == want[1] and np.array_equal(got[0], want[0]), "SearchByProjection with a grid of other bounds"
+        f2.close()
     case = make_relocalization_case(n, n + 50, seed + 2)
     valid, level = relocalization_prepass(case)
     f2 = frame2(case, ur=False)
@@ -1512,12 +1519,13 @@ def check_device_frames(lib, n=900, seed=17, w=640, h=360, nfeatures=700):
     f2.close()
     mt.close()
     case = make_local_points_case(n + 300, n, seed + 3)
-    f2 = frame2(case)
     mt = F.ORBmatcher(0.8, True, lib=lib)
     want = O.search_local_points(case, 1.0, 0.8)
-    got = mt.SearchLocalPoints(dict(hollow2(case), device2=f2), 1.0)
-    assert got[1] == want[1] and np.array_equal(got[0], want[0]), "SearchLocalPoints on a resident frame"
-    f2.close()
+    for with_grid in (False, True):
+        f2 = frame2(case, grid=with_grid)
+        got = mt.SearchLocalPoints(dict(hollow2(case), device2=f2), 1.0)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0]), "SearchLocalPoints on a resident frame"
+        f2.close()
     mt.close()
     case = make_fuse_case(n + 200, n, seed + 4)
     valid, level = fuse_prepass(case)
@@ -1566,6 +1574,7 @@ def check_device_frames(lib, n=900, seed=17, w=640, h=360, nfeatures=700):
     cap.capture(ex, len(kps), dm)
     frame = dict(xy=np.stack([kps["x"], kps["y"]], 1), desc=desc, octave=kps["octave"], angle=kps["angle"], uright=dm.mvuRight)
     case = make_local_points_case(1200, seed=seed + 6, w=w, h=h, frame2=frame)
+    cap.set_grid(case["grid"])
     mt = F.ORBmatcher(0.8, True, lib=lib)
     want = O.search_local_points(case, 3.0, 0.8)
     got = mt.SearchLocalPoints(dict(hollow2(case), device2=cap), 3.0)
