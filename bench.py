@@ -1039,7 +1039,8 @@ def main():
             except Exception as e:
                 out["extra"]["natural_texture"] = {"error": repr(e)}
             import bench_calls
-            for name, leg in (("cfg3_triangulation", bench_calls.triangulation_leg), ("tracking_calls", bench_calls.tracking_leg)):
+            for name, leg in (("cfg3_triangulation", bench_calls.triangulation_leg), ("tracking_calls", bench_calls.tracking_leg),
+                              ("mapping_calls", bench_calls.mapping_leg)):
                 try:
                     out["extra"][name] = leg(lib)
                 except Exception as e:   # the headline stands on its own

@@ -284,6 +284,98 @@ def tracking_leg(lib):
     return res
 
 
+def mapping_leg(lib):
+    """The matcher calls of the OTHER threads - LocalMapping (Fuse), relocalisation, loop closing (SearchByBoW between key frames),
+    monocular initialisation - measured the same way; they complete the list: every search routine of ORBmatcher has its latency
+    in the line.  (The reference's Fuse also does the Replace / AddObservation bookkeeping the drop-in class does on the host;
+    its time is the whole function's.)"""
+    from oracle import oracle_py as O
+    from oracle import ref_py as R
+    from orb_slam3_rgbl_amd import cases
+    from orb_slam3_rgbl_amd import frontend as F
+    ref = R.load_matcher()
+    res = {"what": "ORBmatcher calls of LocalMapping / Relocalization / LoopClosing / MonocularInitialization through the host-pointer C ABI, "
+                   "synthetic KITTI-size inputs (orb_slam3_rgbl_amd/cases.py), measured like extra.tracking_calls"}
+    # -- Fuse(pKF, vpMapPoints, 3.0): LocalMapping::SearchInNeighbors (LocalMapping.cc:737-879), twice per neighbour key frame
+    case = cases.make_fuse_case(2500, 2000, 91)
+    valid, level = cases.fuse_prepass(case)
+    mt = F.ORBmatcher(0.6, True, lib=lib)
+    call = mt.prepare_FuseSearch(dict(case, valid1=valid, level1=level), 3.0)
+    best, dist = call()
+    obest, on = O.fuse_search(case, 3.0)
+    ok = np.array_equal(best, obest)
+    ref_stat = None
+    if ref is not None:
+        keep = []
+        P = O.make_fuse_input(case, 3.0, keep)
+        state = np.random.default_rng(91).choice([0, 1, 2, 3], len(case["kp2_xy"]), p=[0.5, 0.2, 0.2, 0.1]).astype(np.uint8)
+        (rb, rnf, _), ref_stat = _ref_stats(lambda: R.fuse(ref, P, state))
+        seen = rb >= 0
+        ok = ok and rnf == on and np.array_equal(rb[seen], obest[seen])
+    gpu = _time_call(call)
+    kern, ktot = _kernel_us(mt, call)
+    res["fuse_search"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", n1=2500, n2=2000, fused=int(on),
+                                ref_lines="ORBmatcher.cc:1148-1338, LocalMapping.cc:737-879")
+    mt.close()
+    # -- SearchByProjection(CurrentFrame, pKF, sAlreadyFound, 10, 100): Tracking::Relocalization (Tracking.cc:3723-3752)
+    case = cases.make_relocalization_case(1500, 2000, 61)
+    valid, level = cases.relocalization_prepass(case)
+    mt = F.ORBmatcher(0.9, True, lib=lib)
+    call = mt.prepare_SearchByProjectionKeyFrame(dict(case, valid1=valid, level1=level), 10.0, 100)
+    m2, nm = call()
+    om, onm = O.search_by_projection_kf(case, 10.0, 100, True)
+    ok = nm == onm and np.array_equal(m2, om)
+    ref_stat = None
+    if ref is not None:
+        keep = []
+        P = O.make_kf_projection_input(case, 10.0, 100, True, keep)
+        (rm, rnm, _), ref_stat = _ref_stats(lambda: R.call_struct(ref, "ref_search_by_projection_kf", P, P.n2))
+        ok = ok and rnm == nm and np.array_equal(rm, m2)
+    gpu = _time_call(call)
+    kern, ktot = _kernel_us(mt, call)
+    res["search_by_projection_keyframe"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", n1=1500, n2=2000, matches=int(nm),
+                                                  ref_lines="ORBmatcher.cc:1889-2010, Tracking.cc:3723-3752")
+    mt.close()
+    # -- SearchByBoW(pKF1, pKF2, vpMatches12): LoopClosing (ORBmatcher(0.75 / 0.9, true))
+    kf1, kf2, *_ = cases.make_triangulation_case(2000, seed=81, n_nodes=100)
+    rng = np.random.default_rng(81)
+    kf1 = dict(kf1, has_mp=(rng.random(2000) < 0.8).astype(np.uint8))
+    kf2 = dict(kf2, has_mp=(rng.random(2000) < 0.8).astype(np.uint8))
+    mt = F.ORBmatcher(0.75, True, lib=lib)
+    call = mt.prepare_SearchByBoWKeyFrames(kf1, kf2)
+    m12, nm = call()
+    om, onm = O.search_by_bow_kf(kf1, kf2, 0.75, True)
+    ok = nm == onm and np.array_equal(m12, om)
+    ref_stat = None
+    if ref is not None:
+        (rm, rnm, _), ref_stat = _ref_stats(lambda: R.search_by_bow_kf(ref, kf1, kf2, 0.75, True))
+        ok = ok and rnm == nm and np.array_equal(rm, m12)
+    gpu = _time_call(call)
+    kern, ktot = _kernel_us(mt, call)
+    res["search_by_bow_keyframes"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", n1=2000, n2=2000, matches=int(nm),
+                                            ref_lines="ORBmatcher.cc:765-905, LoopClosing.cc")
+    mt.close()
+    # -- SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, 100): Tracking::MonocularInitialization (5 x nFeatures)
+    case = cases.make_initialization_case(5000, 61)
+    mt = F.ORBmatcher(0.9, True, lib=lib)
+    call = mt.prepare_SearchForInitialization(case, 100)
+    m12, prev, nm = call()
+    om, oprev, onm = O.search_for_initialization(case, 100, 0.9, True)
+    ok = nm == onm and np.array_equal(m12, om) and np.array_equal(prev.view(np.uint32), oprev.view(np.uint32))
+    ref_stat = None
+    if ref is not None:
+        keep = []
+        P = O.make_initialization_input(case, 100, 0.9, True, keep)
+        (rm, rprev, rnm, _), ref_stat = _ref_stats(lambda: R.search_for_initialization(ref, P, case["prev_matched"]))
+        ok = ok and rnm == nm and np.array_equal(rm, m12)
+    gpu = _time_call(call)
+    kern, ktot = _kernel_us(mt, call)
+    res["search_for_initialization"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", n1=5000, n2=int(len(case["kp2_xy"])),
+                                              matches=int(nm), ref_lines="ORBmatcher.cc:648-763, Tracking.cc:2526")
+    mt.close()
+    return res
+
+
 def stereo_pair(seq, w, h, frame=0, disparity_scale=1.0):
     """A rectified synthetic stereo pair (the generator of tests/parity_checks.stereo_pair): the right view is the scene shifted
     horizontally by a disparity that grows towards the bottom of the image, with its own sensor noise."""
@@ -301,7 +393,7 @@ def stereo_pair(seq, w, h, frame=0, disparity_scale=1.0):
 
 
 def run(lib):
-    return {"cfg3_triangulation": triangulation_leg(lib), "tracking_calls": tracking_leg(lib)}
+    return {"cfg3_triangulation": triangulation_leg(lib), "tracking_calls": tracking_leg(lib), "mapping_calls": mapping_leg(lib)}
 
 
 if __name__ == "__main__":

@@ -53,9 +53,15 @@ def load_matcher():
     lib.ref_search_triangulation.restype = C.c_int
     lib.ref_search_triangulation.argtypes = [C.POINTER(KfArrays), C.POINTER(KfArrays)] + [C.c_void_p] * 3 + [C.c_int] + \
         [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p] * 4
-    for name in ("ref_search_by_projection", "ref_search_local_points"):
+    for name in ("ref_search_by_projection", "ref_search_local_points", "ref_search_by_projection_kf"):
         getattr(lib, name).restype = C.c_int
         getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p]
+    lib.ref_fuse.restype = C.c_int
+    lib.ref_fuse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ref_search_for_initialization.restype = C.c_int
+    lib.ref_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ref_search_by_bow_kf.restype = C.c_int
+    lib.ref_search_by_bow_kf.argtypes = [C.POINTER(KfArrays), C.POINTER(KfArrays), C.c_float, C.c_int, C.c_void_p]
     lib.ref_search_by_bow.restype = C.c_int
     lib.ref_search_by_bow.argtypes = [C.POINTER(KfArrays), C.POINTER(KfArrays), C.c_float, C.c_int, C.c_void_p]
     return lib
@@ -115,6 +121,30 @@ def search_by_bow(lib, kf, frame, nnratio, check_orientation):
     m = np.zeros(a2.n, np.int32)
     nm = lib.ref_search_by_bow(C.byref(a1), C.byref(a2), C.c_float(nnratio), int(check_orientation), m.ctypes.data)
     return m, nm, lib.ref_last_call_seconds()
+
+
+def search_by_bow_kf(lib, kf1, kf2, nnratio, check_orientation):
+    keep = []
+    a1, a2 = kf_arrays(kf1, keep), kf_arrays(kf2, keep)
+    m = np.zeros(a1.n, np.int32)
+    nm = lib.ref_search_by_bow_kf(C.byref(a1), C.byref(a2), C.c_float(nnratio), int(check_orientation), m.ctypes.data)
+    return m, nm, lib.ref_last_call_seconds()
+
+
+def fuse(lib, P, kf_state2):
+    """ORBmatcher().Fuse(pKF, vpMapPoints, th) on an oracle_py fuse input block.  Returns (best feature per point as far as the
+    function left a trace, nFused, seconds)."""
+    best = np.zeros(P.n1, np.int32)
+    st = np.ascontiguousarray(kf_state2, np.uint8)
+    nf = lib.ref_fuse(C.byref(P), st.ctypes.data, best.ctypes.data)
+    return best, nf, lib.ref_last_call_seconds()
+
+
+def search_for_initialization(lib, P, prev_matched):
+    prev = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m = np.zeros(P.n1, np.int32)
+    nm = lib.ref_search_for_initialization(C.byref(P), prev.ctypes.data, m.ctypes.data)
+    return m, prev, nm, lib.ref_last_call_seconds()
 
 
 def voc_transform(lib, h, desc, levelsup):

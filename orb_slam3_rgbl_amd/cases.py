@@ -4,6 +4,7 @@ a LastFrame / CurrentFrame pair with map points (SearchByProjection), local map 
 so that what is timed is what is checked.  numpy only."""
 import numpy as np
 
+from . import frontend as F
 from . import synth
 
 
@@ -201,3 +202,139 @@ def make_local_points_case(n1=3000, n2=2000, seed=41, w=synth.KITTI_W, h=synth.K
                 view_cos1=np.where(rng.random(n1) < 0.5, 0.9995, 0.9).astype(np.float32), mp_desc1=mp_desc,
                 mp_observed1=(rng.random(n1) < 0.9).astype(np.uint8), kp2_xy=xy2, kp2_octave=oct2, uright2=uright2, desc2=desc2,
                 blocked2=blocked2, grid=grid, scale_factors=(1.2 ** np.arange(8)).astype(np.float32))
+
+
+def make_relocalization_case(n1=1500, n2=2000, seed=61):
+    """A key frame whose map points are searched in a frame with a (PnP-refined) pose: SearchByProjection(CurrentFrame, pKF,
+    sAlreadyFound, th, ORBdist).  Built on the Frame-to-Frame case: same clusters / duplicate targets; on top of it points
+    without a map point, bad and already-found ones, scale-invariance ranges that exclude some points, features of the
+    frame that hold a map point on entry, and points behind the camera (the overload does not test the sign of the depth)."""
+    c = make_projection_case(n1, n2, seed, "none")
+    rng = np.random.default_rng(seed + 1000)
+    qc, tc = c["Tcw_q"], c["Tcw_t"]
+    Rc = _rot(qc)
+    Ow = (-Rc.T @ tc.astype(np.float64))
+    dist = np.linalg.norm(c["world_pos1"].astype(np.float64) - Ow, axis=1)
+    # mfMaxDistance = dist * scale^level of the observation that made the point: predicted levels spread over the pyramid
+    lvl = c["octave1"].astype(np.int64)                          # near the octave of the feature the point aims at
+    max_d = (dist * 1.2 ** lvl * rng.uniform(0.85, 1.0, n1)).astype(np.float32)
+    min_d = (max_d / np.float32(1.2 ** 7)).astype(np.float32)
+    far = rng.random(n1) < 0.05
+    max_d[far] = (dist[far] * 0.5).astype(np.float32)          # outside the invariance range (too far)
+    near = rng.random(n1) < 0.03
+    min_d[near] = (dist[near] * 2.0).astype(np.float32)        # too close
+    return dict(has_mp1=(rng.random(n1) < 0.85).astype(np.uint8), bad1=(rng.random(n1) < 0.05).astype(np.uint8),
+                found1=(rng.random(n1) < 0.15).astype(np.uint8), world_pos1=c["world_pos1"], mp_desc1=c["mp_desc1"],
+                min_dist1=min_d, max_dist1=max_d, angle1=c["angle1"], kp2_xy=c["kp2_xy"], kp2_octave=c["kp2_octave"],
+                kp2_angle=c["kp2_angle"], desc2=c["desc2"], occupied2=(rng.random(n2) < 0.1).astype(np.uint8),
+                grid=c["grid"], Tcw_q=qc, Tcw_t=tc, K=c["K"], scale_factors=c["scale_factors"],
+                log_scale_factor=np.float32(np.log(np.float32(1.2))))
+
+
+def relocalization_prepass(case):
+    """What the shim evaluates with the MapPoint objects, written with numpy float32 + the C library's logf
+    (F.ORBmatcher.PredictScale): must equal the oracle's prepass bit for bit."""
+    q, t = np.asarray(case["Tcw_q"], np.float32), np.asarray(case["Tcw_t"], np.float32)
+
+    def rotate(qv, p):  # Eigen QuaternionBase::_transformVector in float32
+        u = np.float32(2) * np.cross(qv[:3], p).astype(np.float32)
+        return (p + qv[3] * u + np.cross(qv[:3], u).astype(np.float32)).astype(np.float32)
+    qinv = np.array([-q[0], -q[1], -q[2], q[3]], np.float32)
+    Ow = rotate(qinv, (-t).astype(np.float32))
+    PO = (np.asarray(case["world_pos1"], np.float32) - Ow).astype(np.float32)
+    sq = (PO * PO).astype(np.float32)
+    dist = np.sqrt((sq[:, 0] + (sq[:, 1] + sq[:, 2]).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    max_inv = (np.float32(1.2) * case["max_dist1"]).astype(np.float32)
+    min_inv = (np.float32(0.8) * case["min_dist1"]).astype(np.float32)
+    valid = (case["has_mp1"] != 0) & (case["bad1"] == 0) & (case["found1"] == 0) & ~(dist < min_inv) & ~(dist > max_inv)
+    level = F.ORBmatcher.PredictScale(dist, case["max_dist1"], case["log_scale_factor"], len(case["scale_factors"]))
+    return valid.astype(np.uint8), np.where(valid, level, 0).astype(np.int32)
+
+
+def make_fuse_case(n1=2500, n2=2000, seed=91):
+    """Map points of neighbouring key frames projected into a key frame (LocalMapping::SearchInNeighbors -> ORBmatcher::Fuse):
+    built on the relocalisation case (same clusters, points behind the camera, invariance ranges) plus normals (some seen
+    under more than 60 degrees), points already in the key frame, stereo / mono key-frame features (both chi-square gates)."""
+    c = make_relocalization_case(n1, n2, seed)
+    base = make_projection_case(n1, n2, seed, "none")
+    rng = np.random.default_rng(seed + 2000)
+    q, t = c["Tcw_q"], c["Tcw_t"]
+    Rc = _rot(q)
+    Ow = (-Rc.T @ t.astype(np.float64)).astype(np.float32)
+    PO = c["world_pos1"].astype(np.float64) - Ow
+    dist = np.linalg.norm(PO, axis=1, keepdims=True)
+    normal = PO / np.maximum(dist, 1e-6) + rng.normal(0, 0.35, PO.shape)       # roughly towards the camera ...
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    flip = rng.random(n1) < 0.08
+    normal[flip] *= -1                                                           # ... some from behind
+    sf = c["scale_factors"]
+    return dict(has_mp1=c["has_mp1"], bad1=c["bad1"], in_kf1=(rng.random(n1) < 0.1).astype(np.uint8),
+                world_pos1=c["world_pos1"], normal1=normal.astype(np.float32), mp_desc1=c["mp_desc1"],
+                min_dist1=c["min_dist1"], max_dist1=c["max_dist1"], kp2_xy=c["kp2_xy"], kp2_octave=c["kp2_octave"],
+                uright2=base["uright2"], desc2=c["desc2"], grid=c["grid"], Tcw_q=q, Tcw_t=t, Ow=Ow, K=c["K"],
+                bf=np.float32(base["mbf"]), scale_factors=sf,
+                inv_level_sigma2=(np.float32(1.0) / (sf * sf).astype(np.float32)).astype(np.float32),
+                log_scale_factor=c["log_scale_factor"])
+
+
+def fuse_prepass(case):
+    """The tests of the Fuse loop that need the MapPoint object, numpy float32 + the C library's logf."""
+    Ow = np.asarray(case["Ow"], np.float32)
+    PO = (np.asarray(case["world_pos1"], np.float32) - Ow).astype(np.float32)
+    sq = (PO * PO).astype(np.float32)
+    dist = np.sqrt((sq[:, 0] + (sq[:, 1] + sq[:, 2]).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    Pn = np.asarray(case["normal1"], np.float32)
+    pr = (PO * Pn).astype(np.float32)
+    dot = (pr[:, 0] + (pr[:, 1] + pr[:, 2]).astype(np.float32)).astype(np.float32)
+    max_inv = (np.float32(1.2) * case["max_dist1"]).astype(np.float32)
+    min_inv = (np.float32(0.8) * case["min_dist1"]).astype(np.float32)
+    valid = ((case["has_mp1"] != 0) & (case["bad1"] == 0) & (case["in_kf1"] == 0) & ~(dist < min_inv) & ~(dist > max_inv) &
+             ~(dot.astype(np.float64) < 0.5 * dist.astype(np.float64)))
+    level = F.ORBmatcher.PredictScale(dist, case["max_dist1"], case["log_scale_factor"], len(case["scale_factors"]))
+    return valid.astype(np.uint8), np.where(valid, level, 0).astype(np.int32)
+
+
+def make_initialization_case(n1=5000, seed=61, w=synth.KITTI_W, h=synth.KITTI_H, motion=(14.0, -6.0)):
+    """Two monocular frames: F2's features are F1's moved by `motion` plus noise, descriptors with a few flipped bits;
+    vbPrevMatched = F1's positions (Tracking.cc:2493-2495).  Look-alike neighbours make the ratio test bite, and pairs of F1
+    features aim at one F2 feature with the later one closer, so that matches are taken over (vMatchedDistance)."""
+    rng = np.random.default_rng(seed)
+    xy1 = np.stack([rng.uniform(5, w - 5, n1), rng.uniform(5, h - 5, n1)], 1).astype(np.float32)
+    oct1 = rng.choice(8, n1, p=[0.45, 0.2, 0.1, 0.08, 0.06, 0.05, 0.03, 0.03]).astype(np.int32)
+    desc1 = synth.descriptors(n1, seed)
+    ang1 = rng.uniform(0, 360, n1).astype(np.float32)
+    n2 = n1
+    perm = rng.permutation(n1)                      # F2 feature j comes from F1 feature perm[j]
+    xy2 = (xy1[perm] + np.array(motion, np.float32) + rng.normal(0, 1.5, (n2, 2))).astype(np.float32)
+    oct2 = oct1[perm].copy()
+    oct2[rng.random(n2) < 0.1] = 1
+    rate = rng.choice([0.01, 0.04, 0.1, 0.3], n2, p=[0.3, 0.4, 0.2, 0.1])
+    desc2 = desc1[perm] ^ np.packbits(rng.random((n2, 256)) < rate[:, None], axis=1, bitorder="little")
+    dang = np.where(rng.random(n2) < 0.8, rng.normal(5, 3, n2), rng.uniform(0, 360, n2))
+    ang2 = np.mod(ang1[perm] - dang, 360).astype(np.float32)
+    # look-alike neighbours in F2 (second-best close to best)
+    ncl = n2 // 8
+    src = rng.integers(0, n2, ncl)
+    dst = rng.permutation(n2)[:ncl]
+    xy2[dst] = xy2[src] + rng.uniform(-20, 20, (ncl, 2)).astype(np.float32)
+    oct2[dst] = oct2[src]
+    desc2[dst] = desc2[src] ^ np.packbits(rng.random((ncl, 256)) < rng.choice([0.01, 0.06], ncl)[:, None], axis=1, bitorder="little")
+    # take-overs: F1 feature a (lower index) resembles what F1 feature b (higher index) matches even better
+    inv = np.empty(n1, np.int64)
+    inv[perm] = np.arange(n1)
+    pairs = rng.permutation(n1)[: 2 * (n1 // 10)].reshape(-1, 2)
+    a, b = pairs.min(1), pairs.max(1)
+    oct1[a] = 0; oct1[b] = 0
+    c = inv[b]
+    oct2[c] = 0
+    xy1[a] = xy1[b] + rng.uniform(-30, 30, (len(a), 2)).astype(np.float32)
+    desc2[c] = desc1[b] ^ np.packbits(rng.random((len(a), 256)) < 0.02, axis=1, bitorder="little")
+    desc1[a] = desc2[c] ^ np.packbits(rng.random((len(a), 256)) < rng.choice([0.03, 0.08], len(a))[:, None], axis=1, bitorder="little")
+    xy2[:, 0] = np.clip(xy2[:, 0], 1, w - 2)
+    xy2[:, 1] = np.clip(xy2[:, 1], 1, h - 2)
+    prev = xy1.copy()
+    prev[rng.random(n1) < 0.01] = np.float32(-500)   # window outside of the grid
+    gw, gh = np.float32(w), np.float32(h)
+    grid = np.array([0, 0, gw, gh, np.float32(64) / gw, np.float32(48) / gh], np.float32)
+    return dict(kp1_octave=oct1, kp1_angle=ang1, desc1=desc1, prev_matched=prev, kp2_xy=xy2, kp2_octave=oct2, kp2_angle=ang2,
+                desc2=desc2, grid=grid)

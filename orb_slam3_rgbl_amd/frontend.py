@@ -505,6 +505,9 @@ class ORBmatcher:
         return out
 
     def SearchByProjectionKeyFrame(self, kf, th, ORBdist):
+        return self.prepare_SearchByProjectionKeyFrame(kf, th, ORBdist)()
+
+    def prepare_SearchByProjectionKeyFrame(self, kf, th, ORBdist):
         """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1889-2010), the matcher
         of Tracking::Relocalization.  kf: dict with the key-frame map point arrays valid1 (has a good map point that is not in
         sAlreadyFound and whose distance to the camera centre is inside its scale-invariance range), world_pos1, mp_desc1,
@@ -533,10 +536,17 @@ class ORBmatcher:
         P.device2 = _dev(kf, "device2")
         match2 = np.zeros(P.n2, np.int32)
         n = C.c_int(0)
-        L.check(self.lib, self.lib.rgbl_search_by_projection_keyframe(self.h, C.byref(P), L.ptr(match2), C.byref(n)))
-        return match2, n.value
+        fn, h, pP, pm, pn = self.lib.rgbl_search_by_projection_keyframe, self.h, C.byref(P), L.ptr(match2), C.byref(n)
+
+        def call(_keep=keep):
+            L.check(self.lib, fn(h, pP, pm, pn))
+            return match2, n.value
+        return call
 
     def FuseSearch(self, case, th=3.0):
+        return self.prepare_FuseSearch(case, th)()
+
+    def prepare_FuseSearch(self, case, th=3.0):
         """The search of ORBmatcher::Fuse(pKF, vpMapPoints, th) (ORBmatcher.cc:1148-1338): for every candidate map point the
         key-frame feature it would be fused with (bestDist <= TH_LOW) or -1, and bestDist.  case: dict with valid1 (map point
         present, good, not yet in the key frame, inside its scale-invariance range, seen under less than 60 degrees),
@@ -565,8 +575,12 @@ class ORBmatcher:
         P.device2 = _dev(case, "device2")
         best = np.zeros(P.n1, np.int32)
         dist = np.zeros(P.n1, np.int32)
-        L.check(self.lib, self.lib.rgbl_fuse_search(self.h, C.byref(P), L.ptr(best), L.ptr(dist)))
-        return best, dist
+        fn, h, pP, pb, pd = self.lib.rgbl_fuse_search, self.h, C.byref(P), L.ptr(best), L.ptr(dist)
+
+        def call(_keep=keep):
+            L.check(self.lib, fn(h, pP, pb, pd))
+            return best, dist
+        return call
 
     def ComputeDistinctiveDescriptors(self, descriptor_lists):
         """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403) for a batch: descriptor_lists = one [n_i, 32] uint8 array
@@ -677,7 +691,11 @@ class ORBmatcher:
         return call
 
     def SearchForInitialization(self, case, windowSize=100):
-        """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:648-763).
+        return self.prepare_SearchForInitialization(case, windowSize)()
+
+    def prepare_SearchForInitialization(self, case, windowSize=100):
+        """(every call starts from the case's vbPrevMatched again)
+        ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:648-763).
         case: dict with kp1_octave, kp1_angle, desc1, prev_matched [n1,2] (vbPrevMatched), kp2_xy, kp2_octave, kp2_angle,
         desc2, grid[6].  Returns (vnMatches12, the updated vbPrevMatched, nmatches)."""
         keep = []
@@ -696,11 +714,17 @@ class ORBmatcher:
         for i in range(6):
             P.grid[i] = float(case["grid"][i])
         P.window_size, P.nnratio, P.check_orientation = int(windowSize), float(self.mfNNratio), int(self.mbCheckOrientation)
-        prev = np.ascontiguousarray(case["prev_matched"], np.float32).copy()
+        prev0 = np.ascontiguousarray(case["prev_matched"], np.float32)
+        prev = prev0.copy()
         m12 = np.zeros(P.n1, np.int32)
         n = C.c_int(0)
-        L.check(self.lib, self.lib.rgbl_search_for_initialization(self.h, C.byref(P), L.ptr(prev), L.ptr(m12), C.byref(n)))
-        return m12, prev, n.value
+        fn, h, pP, pp, pm, pn = self.lib.rgbl_search_for_initialization, self.h, C.byref(P), L.ptr(prev), L.ptr(m12), C.byref(n)
+
+        def call(_keep=keep):
+            prev[:] = prev0
+            L.check(self.lib, fn(h, pP, pp, pm, pn))
+            return m12, prev, n.value
+        return call
 
     @staticmethod
     def _view(kf, keep):
@@ -738,6 +762,9 @@ class ORBmatcher:
         return call
 
     def SearchByBoWKeyFrames(self, kf1, kf2):
+        return self.prepare_SearchByBoWKeyFrames(kf1, kf2)()
+
+    def prepare_SearchByBoWKeyFrames(self, kf1, kf2):
         """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (ORBmatcher.cc:765-905).  kf1 / kf2: dicts as for
         SearchForTriangulation, has_mp = map point present and not bad, angle = mvKeysUn[].angle.  Returns (per kf1 feature the
         kf2 feature whose map point it gets, or -1; nmatches)."""
@@ -745,9 +772,13 @@ class ORBmatcher:
         v1, v2 = self._view(kf1, keep), self._view(kf2, keep)
         m = np.full(v1.n, -1, np.int32)
         nm = C.c_int(0)
-        L.check(self.lib, self.lib.rgbl_search_by_bow_keyframes(self.h, C.byref(v1), C.byref(v2), float(self.mfNNratio),
-                                                                int(self.mbCheckOrientation), L.ptr(m), C.byref(nm)))
-        return m, nm.value
+        fn, h, p1, p2, r, o, pm, pn = (self.lib.rgbl_search_by_bow_keyframes, self.h, C.byref(v1), C.byref(v2), float(self.mfNNratio),
+                                       int(self.mbCheckOrientation), L.ptr(m), C.byref(nm))
+
+        def call(_keep=keep):
+            L.check(self.lib, fn(h, p1, p2, r, o, pm, pn))
+            return m, nm.value
+        return call
 
     def SearchForTriangulation(self, kf1, kf2, F12, ep, scale_factors2, level_sigma2_2, bOnlyStereo=False,
                                bCoarse=False):
