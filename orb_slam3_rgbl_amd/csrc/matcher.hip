@@ -1137,12 +1137,12 @@ __device__ __forceinline__ void init_available(const ProjDev& P, int i, F&& f) {
 }
 
 // grid = ceil(n1 / 64), block = 64
-__global__ __launch_bounds__(64) void k_init_candidates(ProjDev P) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_init_candidates(ProjDev P) {   // one wave per F1 feature (wave_candidates), grid = ceil(n1 / 4)
+  const int i = blockIdx.x * kPointsPerBlock + wave_id();
   if (i >= P.n1) return;
+  const int lane = lane_id();
   uint8_t st = 1;
   int n = 0;
-  P.choice[i] = -1;
   const float x = P.proj1[2 * i], y = P.proj1[2 * i + 1];
   if (P.oct1[i] == 0 && x == x && y == y) {  // level1 > 0: continue (:664-666)
     const float radius = P.th;
@@ -1153,23 +1153,17 @@ __global__ __launch_bounds__(64) void k_init_candidates(ProjDev P) {
     if (x0 < kGridCols && x1 >= 0 && y0 < kGridRows && y1 >= 0) {
       const float4 w = make_float4(x, y, radius, 0.f);
       const int4 rg = make_int4(x0 | (x1 << 8), y0 | (y1 << 8), 0, 0);  // minLevel = maxLevel = level1 = 0
-      P.win[i] = w;
-      P.rng[i] = rg;
       const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
       const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
-      int total = 0;
-      for_candidates(P, w, rg, [&](int c, int) {
-        const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
-        if (dist > P.max_dist) return;
-        if (total < kProjCand) P.cand[(size_t)i * kProjCand + total] = ((unsigned long long)dist << 32) | (unsigned)c;
-        ++total;
-      });
+      auto dist_of = [&](int c) { return hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)); };
+      const int total = wave_candidates(P, w, rg, P.cand + (size_t)i * kProjCand, [&](int c) { return dist_of(c) <= P.max_dist; },
+                                        [&](int c, int) { return ((unsigned long long)dist_of(c) << 32) | (unsigned)c; });
+      if (lane == 0) { P.win[i] = w; P.rng[i] = rg; }
       n = total <= kProjCand ? total : (kProjCand | kProjOverflow);
       st = total > 0 ? 0 : 1;
     }
   }
-  P.ncand[i] = (uint8_t)n;
-  P.state[i] = st;
+  if (lane == 0) { P.choice[i] = -1; P.ncand[i] = (uint8_t)n; P.state[i] = st; }
 }
 
 // grid = 1, block = kProjBS
@@ -2448,7 +2442,7 @@ int rgbl_search_for_initialization(rgbl_matcher* m, const rgbl_initialization_in
   P.max_dist = v - 1;
   grid_for_call(m, s, P, nullptr);
   m->timer.begin("k_init_candidates", s);
-  hipLaunchKernelGGL(k_init_candidates, dim3((n1 + 63) / 64), dim3(64), 0, s, P);
+  hipLaunchKernelGGL(k_init_candidates, dim3((n1 + kPointsPerBlock - 1) / kPointsPerBlock), dim3(256), 0, s, P);
   m->timer.end(s);
   m->timer.begin("k_init_resolve", s);
   hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(kProjBS), 0, s, P);
