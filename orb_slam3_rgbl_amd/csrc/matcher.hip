@@ -580,8 +580,15 @@ __global__ __launch_bounds__(256) void k_search_triangulation(TriDev T) {
 //                      rest try again.  The lowest unresolved index is final in every round, so the loop terminates,
 //                      and induction over the index shows the result is the sequential one.
 constexpr int kProjMaxLevels = 16;
-constexpr int kProjCand = 16;  // viable candidates kept per point; a point with more re-scans its window (kProjOverflow)
-constexpr int kProjOverflow = 0x80;
+constexpr int kProjCand = 16;  // viable candidates kept per point; a point with more re-scans its window (kRefOverflow)
+constexpr uint32_t kRefOverflow = 1u << 31;
+__host__ __device__ __forceinline__ int ref_n(uint32_t r) { return (int)((r >> 26) & 31u); }
+__host__ __device__ __forceinline__ uint32_t ref_start(uint32_t r) { return r & 0x3ffffffu; }
+// an entry of a point's candidate list as the resolve kernels read it
+__host__ __device__ __forceinline__ uint32_t cand_entry(int dist, int level, int c) { return ((uint32_t)dist << 20) | ((uint32_t)level << 16) | (uint32_t)c; }
+__host__ __device__ __forceinline__ int entry_dist(uint32_t e) { return (int)(e >> 20); }
+__host__ __device__ __forceinline__ int entry_level(uint32_t e) { return (int)((e >> 16) & 15u); }
+__host__ __device__ __forceinline__ int entry_feature(uint32_t e) { return (int)(e & 0xffffu); }
 struct ProjDev {
   int n1, n2;
   const uint8_t* valid1;
@@ -614,9 +621,10 @@ struct ProjDev {
   int32_t* owner;            // n2: SearchForInitialization's vnMatches21
   float4* win;               // n1: u, v, radius, ur (= u - mbf * invzc)
   int4* rng;                 // n1: cell x range, cell y range (lo | hi << 8), minLevel, maxLevel
-  unsigned long long* cand;  // n1 * kProjCand keys
-  uint8_t* ncand;            // n1: number of keys | kProjOverflow
-  uint8_t* state;            // n1: 0 unresolved, 1 resolved, 2 final this round
+  unsigned long long* cand;  // n1 keys: k_fuse_search's result (best key per point)
+  uint32_t* clist;           // n1 slots of kProjCand 32-bit entries (cand_entry): the points' candidate lists
+  uint32_t* cref;            // n1: where a point's list starts (i * kProjCand; the resolve kernels' LDS copy: where they packed it) | entries << 26 | kRefOverflow
+  uint8_t* state;            // n1: 0 unresolved, 1 resolved, 2 final this round (k_init_resolve); | kStateObs
   int32_t* choice;           // n1: best CurrentFrame feature or -1
 };
 constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;  // FRAME_GRID_COLS / ROWS (Frame.h:46-47)
@@ -700,46 +708,94 @@ __device__ __forceinline__ unsigned long long proj_key(int dist, int cell, int c
   return ((unsigned long long)dist << 32) | ((unsigned long long)cell << 16) | (unsigned)c;
 }
 
-// grid = 1, block = kProjBS
-__global__ __launch_bounds__(kProjBS) void k_proj_grid(ProjDev P) {
-  __shared__ uint32_t s_fill[kGridCells];
-  __shared__ uint32_t s_scan[kProjBS / 64 + 1];
+// The wave that walked a point's window hands its list to the resolve kernel (round 6: the resolve rounds were chains of dependent
+// global reads of 8-byte keys - ~8 us per round for a frame's 2000 points).  The keys the walk left in the wave's LDS slots
+// (traversal order) become 32-bit entries in the point's 16-entry slot of P.clist, 64 bytes the resolve kernel fetches with four
+// independent 16-byte loads per point and packs into LDS: its rounds never touch global memory.  (A dense list reserved with one
+// atomic per wave was tried first: ~3000 returning atomics on one address cost the candidate kernels 10 - 20 us.)
+// `sorted`: the entries are written in ascending key order (best-only searches: a point's choice is then the first entry still
+// available).  All 64 lanes call it; returns the point's cref word (wave-uniform).
+template <class Enc>
+__device__ __forceinline__ uint32_t publish_candidates(const ProjDev& P, int i, const unsigned long long* keys, int total, bool sorted, Enc&& enc) {
+  wave_sync();
+  const int lane = lane_id();
+  if (total > kProjCand) return kRefOverflow;
+  const int n = total;
+  const unsigned long long key = lane < n ? keys[lane] : ~0ull;
+  int rank = lane;
+  if (sorted) {
+    rank = 0;
+    for (int j = 0; j < n; ++j) rank += keys[j] < key ? 1 : 0;
+  }
+  const uint32_t start = (uint32_t)i * kProjCand;
+  if (lane < n) P.clist[start + rank] = enc(key);
+  return start | ((uint32_t)n << 26);
+}
+// what the candidate kernels leave in P.state: 0 = unresolved, 1 = resolved | kStateObs: the point blocks the feature it takes
+constexpr uint8_t kStateObs = 0x80;
+
+// grid = 1, block = kGridBS.  LDS = true (frames of up to kGridLdsN2 features): a feature's cell is computed once and kept in
+// LDS, the cells' item lists are built and put in ascending order there and leave with one coalesced pass - the first form ran
+// count, scatter and the per-cell ordering as chains of dependent global reads (20 us for a frame's 2000 features, round 6).
+constexpr int kGridBS = 1024, kGridLdsN2 = 8192;
+template <bool LDS>
+__global__ __launch_bounds__(kGridBS) void k_proj_grid(ProjDev P) {
+  __shared__ uint32_t s_fill[kGridCells], s_start[LDS ? kGridCells : 1];
+  __shared__ uint32_t s_scan[kGridBS / 64 + 1];
+  __shared__ uint16_t s_cell[LDS ? kGridLdsN2 : 1], s_items[LDS ? kGridLdsN2 : 1];
   const int tid = threadIdx.x;
-  for (int c = tid; c < kGridCells; c += kProjBS) s_fill[c] = 0;
-  __syncthreads();
-  for (int c = tid; c < P.n2; c += kProjBS) {
+  auto cell_of = [&](int c) {
     const int px = (int)roundf((P.xy2[2 * c] - P.grid[0]) * P.grid[4]), py = (int)roundf((P.xy2[2 * c + 1] - P.grid[1]) * P.grid[5]);
-    if (px >= 0 && px < kGridCols && py >= 0 && py < kGridRows) atomicAdd(&s_fill[px * kGridRows + py], 1u);
+    return (px >= 0 && px < kGridCols && py >= 0 && py < kGridRows) ? px * kGridRows + py : -1;
+  };
+  for (int c = tid; c < kGridCells; c += kGridBS) s_fill[c] = 0;
+  __syncthreads();
+  for (int c = tid; c < P.n2; c += kGridBS) {
+    const int cell = cell_of(c);
+    if (LDS) s_cell[c] = (uint16_t)cell;   // 0xffff: outside the grid
+    if (cell >= 0) atomicAdd(&s_fill[cell], 1u);
     P.taken_by[c] = (P.blocked2 && P.blocked2[c]) ? -1 : INT_MAX;  // -1: held by a point from before the call
   }
   __syncthreads();
   uint32_t carry = 0;
-  for (int c0 = 0; c0 < kGridCells; c0 += kProjBS) {
+  for (int c0 = 0; c0 < kGridCells; c0 += kGridBS) {
     const int c = c0 + tid;
     const uint32_t v = c < kGridCells ? s_fill[c] : 0u;
     uint32_t tot;
     const uint32_t ex = block_exclusive_scan<uint32_t>(v, s_scan, &tot);
     __syncthreads();
-    if (c < kGridCells) { P.cell_start[c] = carry + ex; s_fill[c] = carry + ex; }
+    if (c < kGridCells) {
+      P.cell_start[c] = carry + ex; s_fill[c] = carry + ex;
+      if (LDS) s_start[c] = carry + ex;
+    }
     carry += tot;
   }
   if (tid == 0) P.cell_start[kGridCells] = carry;
   __syncthreads();
-  for (int c = tid; c < P.n2; c += kProjBS) {
-    const int px = (int)roundf((P.xy2[2 * c] - P.grid[0]) * P.grid[4]), py = (int)roundf((P.xy2[2 * c + 1] - P.grid[1]) * P.grid[5]);
-    if (px >= 0 && px < kGridCols && py >= 0 && py < kGridRows) P.cell_items[atomicAdd(&s_fill[px * kGridRows + py], 1u)] = (uint16_t)c;
+  uint16_t* items = LDS ? s_items : P.cell_items;
+  for (int c = tid; c < P.n2; c += kGridBS) {
+    const int cell = LDS ? (s_cell[c] == 0xffffu ? -1 : (int)s_cell[c]) : cell_of(c);
+    if (cell >= 0) items[atomicAdd(&s_fill[cell], 1u)] = (uint16_t)c;
   }
   __syncthreads();
   // ascending feature index inside every cell = the push_back order of AssignFeaturesToGrid (cells hold a handful of items)
-  for (int cell = tid; cell < kGridCells; cell += kProjBS) {
-    const uint32_t b = P.cell_start[cell], e = s_fill[cell];
+  for (int cell = tid; cell < kGridCells; cell += kGridBS) {
+    const uint32_t b = LDS ? s_start[cell] : P.cell_start[cell], e = s_fill[cell];
     for (uint32_t i = b + 1; i < e; ++i) {
-      const uint16_t v = P.cell_items[i];
+      const uint16_t v = items[i];
       uint32_t j = i;
-      while (j > b && P.cell_items[j - 1] > v) { P.cell_items[j] = P.cell_items[j - 1]; --j; }
-      P.cell_items[j] = v;
+      while (j > b && items[j - 1] > v) { items[j] = items[j - 1]; --j; }
+      items[j] = v;
     }
   }
+  if (LDS) {
+    __syncthreads();
+    for (uint32_t k = tid; k < carry; k += kGridBS) P.cell_items[k] = s_items[k];
+  }
+}
+static void launch_proj_grid(const ProjDev& P, hipStream_t s) {
+  if (P.n2 <= kGridLdsN2) hipLaunchKernelGGL(k_proj_grid<true>, dim3(1), dim3(kGridBS), 0, s, P);
+  else hipLaunchKernelGGL(k_proj_grid<false>, dim3(1), dim3(kGridBS), 0, s, P);
 }
 
 // With the grid taken from a resident frame nobody runs k_proj_grid: its other job - who holds a feature before the call - is
@@ -754,12 +810,13 @@ __device__ __forceinline__ void init_taken_by(const ProjDev& P) {
 // computed by every lane alike), then its viable candidates by wave_candidates
 constexpr int kPointsPerBlock = 4;
 __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P) {
+  __shared__ unsigned long long s_keys[kPointsPerBlock][kProjCand];
   init_taken_by(P);
   const int i = blockIdx.x * kPointsPerBlock + wave_id();
   if (i >= P.n1) return;
   const int lane = lane_id();
   uint8_t st = 1;
-  int n = 0;
+  uint32_t ref = 0;
   if (P.valid1[i]) {
     float x, y, z;
     if (P.sim3_mode) {
@@ -798,28 +855,30 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P) {
         const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
         const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
         auto dist_of = [&](int c) { return hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)); };
-        const int total = wave_candidates(P, w, r, P.cand + (size_t)i * kProjCand, [&](int c) { return dist_of(c) <= P.max_dist; },
+        const int total = wave_candidates(P, w, r, s_keys[wave_id()], [&](int c) { return dist_of(c) <= P.max_dist; },
                                           [&](int c, int cell) { return proj_key(dist_of(c), cell, c); });
         if (lane == 0) { P.win[i] = w; P.rng[i] = r; }
-        n = total <= kProjCand ? total : (kProjCand | kProjOverflow);
+        ref = publish_candidates(P, i, s_keys[wave_id()], total, true,
+                                 [](unsigned long long key) { return cand_entry((int)(key >> 32), 0, (int)(key & 0xffffu)); });
         st = total > 0 ? 0 : 1;  // no viable candidate: bestDist > TH_HIGH whatever the others do
       }
     }
   }
-  if (lane == 0) { P.choice[i] = -1; P.ncand[i] = (uint8_t)n; P.state[i] = st; }
+  if (lane == 0) { P.choice[i] = -1; P.cref[i] = ref; P.state[i] = st | (P.obs1[i] ? kStateObs : 0); }
 }
 
-// smallest key of point i among the features not held by a lower-index blocker (~0 = none)
-__device__ __forceinline__ unsigned long long proj_best(const ProjDev& P, const int32_t* taken_by, int i) {
-  unsigned long long best = ~0ull;
-  const int n = P.ncand[i];
-  if (!(n & kProjOverflow)) {
-    for (int k = 0; k < n; ++k) {
-      const unsigned long long key = P.cand[(size_t)i * kProjCand + k];
-      if (taken_by[(int)(key & 0xffffu)] >= i && key < best) best = key;
+// the feature point i takes among those not held by a lower-index blocker: the smallest key (-1 = none)
+__device__ __forceinline__ int proj_best(const ProjDev& P, const int32_t* taken_by, const uint32_t* cref, const uint32_t* clist, int i) {
+  const uint32_t r = cref[i];
+  if (!(r & kRefOverflow)) {
+    const uint32_t* e = clist + ref_start(r);
+    for (int k = 0, n = ref_n(r); k < n; ++k) {   // ascending keys
+      const int c = entry_feature(e[k]);
+      if (taken_by[c] >= i) return c;
     }
-    return best;
+    return -1;
   }
+  unsigned long long best = ~0ull;
   const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
   const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
   for_candidates(P, P.win[i], P.rng[i], [&](int c, int cell) {
@@ -829,47 +888,95 @@ __device__ __forceinline__ unsigned long long proj_best(const ProjDev& P, const 
     const unsigned long long key = proj_key(dist, cell, c);
     if (key < best) best = key;
   });
-  return best;
+  return best == ~0ull ? -1 : (int)(best & 0xffffu);
 }
 
-// grid = 1, block = kProjBS.  LDS = true (frames of up to kResolveLdsN2 features, kResolveLdsN1 points: every KITTI-size call):
+// The resolve kernels' view of the lists: packed into LDS when the call's points (cref) and entries fit, else where the candidate kernels left them
+constexpr int kResolveLdsN2 = 6144, kResolveLdsN1 = 8192, kResolveLdsList = 16384;
+constexpr int kResolveBS = 1024;
+struct ListView { const uint32_t* cref; const uint32_t* clist; };
+template <bool LDS>
+__device__ __forceinline__ ListView stage_lists(const ProjDev& P, uint32_t* s_ref, uint32_t* s_list, int* s_total) {
+  ListView v{P.cref, P.clist};
+  if (LDS) {
+    const int tid = threadIdx.x, lane = lane_id();
+    if (tid == 0) *s_total = 0;
+    __syncthreads();
+    // where a point's entries go: any packing will do, so a wave's points take one range (one LDS atomic per wave and trip)
+    for (int i0 = 0; i0 < P.n1; i0 += kResolveBS) {
+      const int i = i0 + tid;
+      const uint32_t r = i < P.n1 ? P.cref[i] : 0u;
+      const int n = (r & kRefOverflow) ? 0 : ref_n(r);
+      const int incl = wave_inclusive_scan(n), tot = __shfl(incl, 63);
+      int base = 0;
+      if (lane == 0 && tot > 0) base = atomicAdd(s_total, tot);
+      base = __shfl(base, 0);
+      if (i < P.n1) s_ref[i] = (r & kRefOverflow) | ((uint32_t)n << 26) | (uint32_t)(base + incl - n);
+    }
+    __syncthreads();
+    if (*s_total <= kResolveLdsList) {
+      for (int i = tid; i < P.n1; i += kResolveBS) {
+        const uint32_t r = s_ref[i];
+        const int n = ref_n(r);
+        if (n == 0) continue;
+        const uint4* src = reinterpret_cast<const uint4*>(P.clist + (size_t)i * kProjCand);
+        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+        const uint32_t e[kProjCand] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        uint32_t* dst = s_list + ref_start(r);
+#pragma unroll
+        for (int k = 0; k < kProjCand; ++k)
+          if (k < n) dst[k] = e[k];
+      }
+      v.clist = s_list;
+    } else {
+      for (int i = tid; i < P.n1; i += kResolveBS) s_ref[i] = P.cref[i];
+    }
+    v.cref = s_ref;
+  }
+  return v;
+}
+
+// grid = 1, block = kResolveBS.  LDS = true (frames of up to kResolveLdsN2 features, kResolveLdsN1 points: every KITTI-size call):
 // who holds a feature, the lowest unresolved blocker per feature and the points' states live in LDS for the whole kernel - a
 // round is three passes over them, and with the arrays in global memory every pass was a chain of dependent ~1 us loads
 // (round 6: 8 rounds of 17 us for a frame's 2000 points).
-constexpr int kResolveLdsN2 = 6144, kResolveLdsN1 = 12288;
 // min_unres[c] = (stamp << 20 | lowest unresolved blocker that may still take c), stamp = kStampMax - round: a round's entries are
 // smaller than everything older rounds left behind, so the array is not cleared between rounds (one pass and one barrier per
 // round less); it is refilled with INT_MAX every kStampMax rounds (the worst case - a chain of n1 blockers - takes n1 rounds).
 constexpr int kStampMax = 2047;
 __device__ __forceinline__ bool lower_unresolved(int m, int stamp, int i) { return (m >> 20) == stamp && (m & 0xfffff) < i; }
 template <bool LDS>
-__global__ __launch_bounds__(kProjBS) void k_proj_resolve(ProjDev P) {
-  __shared__ int s_unres[2];
+__global__ __launch_bounds__(kResolveBS) void k_proj_resolve(ProjDev P) {
+  __shared__ int s_unres[2], s_total;
   __shared__ int32_t s_taken[LDS ? kResolveLdsN2 : 1], s_min[LDS ? kResolveLdsN2 : 1];
   __shared__ uint8_t s_state[LDS ? kResolveLdsN1 : 1];
   int32_t* taken_by = LDS ? s_taken : P.taken_by;
   int32_t* min_unres = LDS ? s_min : P.min_unres;
   uint8_t* state = LDS ? s_state : P.state;
+  __shared__ uint32_t s_ref[LDS ? kResolveLdsN1 : 1], s_list[LDS ? kResolveLdsList : 1];
   const int tid = threadIdx.x;
   if (LDS) {
-    for (int c = tid; c < P.n2; c += kProjBS) s_taken[c] = P.taken_by[c];
-    for (int i = tid; i < P.n1; i += kProjBS) s_state[i] = P.state[i];
+    for (int c = tid; c < P.n2; c += kResolveBS) s_taken[c] = P.taken_by[c];
+    for (int i = tid; i < P.n1; i += kResolveBS) s_state[i] = P.state[i];
   }
+  const ListView L = stage_lists<LDS>(P, s_ref, s_list, &s_total);
   if (tid < 2) s_unres[tid] = 0;
   for (int round = 0; round <= P.n1; ++round) {
     const int stamp = kStampMax - round % kStampMax, b = round & 1;
     if (round % kStampMax == 0) {
       __syncthreads();
-      for (int c = tid; c < P.n2; c += kProjBS) min_unres[c] = INT_MAX;
+      for (int c = tid; c < P.n2; c += kResolveBS) min_unres[c] = INT_MAX;
     }
     __syncthreads();
     // every unresolved blocker announces itself on the features it may still take
-    for (int i = tid; i < P.n1; i += kProjBS) {
-      if (state[i] != 0 || !P.obs1[i]) continue;
-      const int n = P.ncand[i], me = (stamp << 20) | i;
-      if (!(n & kProjOverflow)) {
-        for (int k = 0; k < n; ++k) {
-          const int c = (int)(P.cand[(size_t)i * kProjCand + k] & 0xffffu);
+    for (int i = tid; i < P.n1; i += kResolveBS) {
+      if (state[i] != kStateObs) continue;   // unresolved and a blocker
+      const uint32_t r = L.cref[i];
+      const int me = (stamp << 20) | i;
+      if (!(r & kRefOverflow)) {
+        const uint32_t* e = L.clist + ref_start(r);
+        for (int k = 0, n = ref_n(r); k < n; ++k) {
+          const int c = entry_feature(e[k]);
           if (taken_by[c] >= i) atomicMin(&min_unres[c], me);
         }
       } else {
@@ -887,14 +994,14 @@ __global__ __launch_bounds__(kProjBS) void k_proj_resolve(ProjDev P) {
     // picks the same feature, finds this point's announcement in front of it and waits a round; one that sees it takes its next
     // choice, which is what the sequential loop would have given it; LOWER points never want a feature that becomes final here
     // (their announcement would have held this point back).  Two blockers never become final on one feature in the same round.
-    for (int i = tid; i < P.n1; i += kProjBS) {
-      if (state[i] != 0) continue;
-      const unsigned long long best = proj_best(P, taken_by, i);
-      const int c = (int)(best & 0xffffu);
-      if (best == ~0ull) { state[i] = 1; P.choice[i] = -1; }           // everything viable is taken: no match
+    for (int i = tid; i < P.n1; i += kResolveBS) {
+      const uint8_t st = state[i];
+      if (st & 0x7f) continue;
+      const int c = proj_best(P, taken_by, L.cref, L.clist, i);
+      if (c < 0) { state[i] = st | 1; P.choice[i] = -1; }                // everything viable is taken: no match
       else if (!lower_unresolved(min_unres[c], stamp, i)) {              // nobody in front of i can still take c
-        state[i] = 1; P.choice[i] = c;
-        if (P.obs1[i]) taken_by[c] = i;
+        state[i] = st | 1; P.choice[i] = c;
+        if (st & kStateObs) taken_by[c] = i;
       } else atomicAdd(&s_unres[b], 1);
     }
     if (tid == 0) s_unres[b ^ 1] = 0;
@@ -1001,12 +1108,13 @@ struct LocalScan {
 
 // grid = ceil(n1 / 4), block = 256 = one wave per map point
 __global__ __launch_bounds__(256) void k_local_candidates(ProjDev P) {
+  __shared__ unsigned long long s_keys[kPointsPerBlock][kProjCand];
   init_taken_by(P);
   const int i = blockIdx.x * kPointsPerBlock + wave_id();
   if (i >= P.n1) return;
   const int lane = lane_id();
   uint8_t st = 1;
-  int n = 0;
+  uint32_t ref = 0;
   if (P.valid1[i]) {
     const int level = P.level1[i];
     float r = (double)P.viewcos1[i] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos: the literal is a double in the reference
@@ -1023,28 +1131,30 @@ __global__ __launch_bounds__(256) void k_local_candidates(ProjDev P) {
         const int4 rg = make_int4(x0 | (x1 << 8), y0 | (y1 << 8), level - 1, level);
         const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
         const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
-        const int total = wave_candidates(P, w, rg, P.cand + (size_t)i * kProjCand, [](int) { return true; }, [&](int c, int) {
+        const int total = wave_candidates(P, w, rg, s_keys[wave_id()], [](int) { return true; }, [&](int c, int) {
           const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
           return ((unsigned long long)dist << 32) | ((unsigned long long)P.oct2[c] << 16) | (unsigned)c;
         });
         if (lane == 0) { P.win[i] = w; P.rng[i] = rg; }
-        n = total <= kProjCand ? total : (kProjCand | kProjOverflow);
+        ref = publish_candidates(P, i, s_keys[wave_id()], total, false, [](unsigned long long key) {   // traversal order: the scan is replayed
+          return cand_entry((int)(key >> 32), (int)((key >> 16) & 0xffffu), (int)(key & 0xffffu));
+        });
         st = total > 0 ? 0 : 1;
       }
     }
   }
-  if (lane == 0) { P.choice[i] = -1; P.ncand[i] = (uint8_t)n; P.state[i] = st; }
+  if (lane == 0) { P.choice[i] = -1; P.cref[i] = ref; P.state[i] = st | (P.obs1[i] ? kStateObs : 0); }
 }
 
 // visits the candidates of point i that no lower-index blocker holds, in traversal order: f(dist, level, c)
 template <class F>
-__device__ __forceinline__ void local_available(const ProjDev& P, const int32_t* taken_by, int i, F&& f) {
-  const int n = P.ncand[i];
-  if (!(n & kProjOverflow)) {
-    for (int k = 0; k < n; ++k) {
-      const unsigned long long key = P.cand[(size_t)i * kProjCand + k];
-      const int c = (int)(key & 0xffffu);
-      if (taken_by[c] >= i) f((int)(key >> 32), (int)((key >> 16) & 0xffffu), c);
+__device__ __forceinline__ void local_available(const ProjDev& P, const int32_t* taken_by, const ListView& L, int i, F&& f) {
+  const uint32_t r = L.cref[i];
+  if (!(r & kRefOverflow)) {
+    const uint32_t* e = L.clist + ref_start(r);
+    for (int k = 0, n = ref_n(r); k < n; ++k) {
+      const int c = entry_feature(e[k]);
+      if (taken_by[c] >= i) f(entry_dist(e[k]), entry_level(e[k]), c);
     }
     return;
   }
@@ -1056,48 +1166,51 @@ __device__ __forceinline__ void local_available(const ProjDev& P, const int32_t*
   });
 }
 
-// grid = 1, block = kProjBS; LDS, round stamps and the merged decide + commit pass as for k_proj_resolve
+// grid = 1, block = kResolveBS; LDS, round stamps and the merged decide + commit pass as for k_proj_resolve
 template <bool LDS>
-__global__ __launch_bounds__(kProjBS) void k_local_resolve(ProjDev P) {
-  __shared__ int s_unres[2];
+__global__ __launch_bounds__(kResolveBS) void k_local_resolve(ProjDev P) {
+  __shared__ int s_unres[2], s_total;
   __shared__ int32_t s_taken[LDS ? kResolveLdsN2 : 1], s_min[LDS ? kResolveLdsN2 : 1];
   __shared__ uint8_t s_state[LDS ? kResolveLdsN1 : 1];
   int32_t* taken_by = LDS ? s_taken : P.taken_by;
   int32_t* min_unres = LDS ? s_min : P.min_unres;
   uint8_t* state = LDS ? s_state : P.state;
+  __shared__ uint32_t s_ref[LDS ? kResolveLdsN1 : 1], s_list[LDS ? kResolveLdsList : 1];
   const int tid = threadIdx.x;
   if (LDS) {
-    for (int c = tid; c < P.n2; c += kProjBS) s_taken[c] = P.taken_by[c];
-    for (int i = tid; i < P.n1; i += kProjBS) s_state[i] = P.state[i];
+    for (int c = tid; c < P.n2; c += kResolveBS) s_taken[c] = P.taken_by[c];
+    for (int i = tid; i < P.n1; i += kResolveBS) s_state[i] = P.state[i];
   }
+  const ListView L = stage_lists<LDS>(P, s_ref, s_list, &s_total);
   if (tid < 2) s_unres[tid] = 0;
   for (int round = 0; round <= P.n1; ++round) {
     const int stamp = kStampMax - round % kStampMax, b = round & 1;
     if (round % kStampMax == 0) {
       __syncthreads();
-      for (int c = tid; c < P.n2; c += kProjBS) min_unres[c] = INT_MAX;
+      for (int c = tid; c < P.n2; c += kResolveBS) min_unres[c] = INT_MAX;
     }
     __syncthreads();
-    for (int i = tid; i < P.n1; i += kProjBS) {
-      if (state[i] != 0 || !P.obs1[i]) continue;
+    for (int i = tid; i < P.n1; i += kResolveBS) {
+      if (state[i] != kStateObs) continue;   // unresolved and a blocker
       const int me = (stamp << 20) | i;
-      local_available(P, taken_by, i, [&](int dist, int, int c) { if (dist <= 100) atomicMin(&min_unres[c], me); });
+      local_available(P, taken_by, L, i, [&](int dist, int, int c) { if (dist <= 100) atomicMin(&min_unres[c], me); });
     }
     __syncthreads();
     // (a settled point's available candidates carry no announcement of a lower point, so no lower point can occupy one of them in
     // this pass; a higher point's store leaves taken_by[c] >= i: still available to i)
-    for (int i = tid; i < P.n1; i += kProjBS) {
-      if (state[i] != 0) continue;
+    for (int i = tid; i < P.n1; i += kResolveBS) {
+      const uint8_t st = state[i];
+      if (st & 0x7f) continue;
       LocalScan sc;
       bool settled = true;
-      local_available(P, taken_by, i, [&](int dist, int level, int c) {
+      local_available(P, taken_by, L, i, [&](int dist, int level, int c) {
         sc.visit(dist, level, c);
         if (lower_unresolved(min_unres[c], stamp, i)) settled = false;  // somebody in front of i may still take this feature
       });
       if (settled) {
         const int c = sc.accept(P.nnratio);
-        state[i] = 1; P.choice[i] = c;
-        if (c >= 0 && P.obs1[i]) taken_by[c] = i;
+        state[i] = st | 1; P.choice[i] = c;
+        if (c >= 0 && (st & kStateObs)) taken_by[c] = i;
       } else atomicAdd(&s_unres[b], 1);
     }
     if (tid == 0) s_unres[b ^ 1] = 0;
@@ -1119,11 +1232,11 @@ __global__ __launch_bounds__(kProjBS) void k_local_resolve(ProjDev P) {
 // one of its still-available candidates - two features that share one resolve in index order, exactly the order of the loop.
 template <class F>
 __device__ __forceinline__ void init_available(const ProjDev& P, int i, F&& f) {  // f(dist, c) in traversal order
-  const int n = P.ncand[i];
-  if (!(n & kProjOverflow)) {
-    for (int k = 0; k < n; ++k) {
-      const unsigned long long key = P.cand[(size_t)i * kProjCand + k];
-      const int c = (int)(key & 0xffffu), dist = (int)(key >> 32);
+  const uint32_t r = P.cref[i];
+  if (!(r & kRefOverflow)) {
+    const uint32_t* e = P.clist + ref_start(r);
+    for (int k = 0, n = ref_n(r); k < n; ++k) {
+      const int c = entry_feature(e[k]), dist = entry_dist(e[k]);
       if (P.taken_by[c] > dist) f(dist, c);  // vMatchedDistance[i2] <= dist: continue (:689-690)
     }
     return;
@@ -1138,11 +1251,12 @@ __device__ __forceinline__ void init_available(const ProjDev& P, int i, F&& f) {
 
 // grid = ceil(n1 / 64), block = 64
 __global__ __launch_bounds__(256) void k_init_candidates(ProjDev P) {   // one wave per F1 feature (wave_candidates), grid = ceil(n1 / 4)
+  __shared__ unsigned long long s_keys[kPointsPerBlock][kProjCand];
   const int i = blockIdx.x * kPointsPerBlock + wave_id();
   if (i >= P.n1) return;
   const int lane = lane_id();
   uint8_t st = 1;
-  int n = 0;
+  uint32_t ref = 0;
   const float x = P.proj1[2 * i], y = P.proj1[2 * i + 1];
   if (P.oct1[i] == 0 && x == x && y == y) {  // level1 > 0: continue (:664-666)
     const float radius = P.th;
@@ -1156,14 +1270,15 @@ __global__ __launch_bounds__(256) void k_init_candidates(ProjDev P) {   // one w
       const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
       const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
       auto dist_of = [&](int c) { return hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)); };
-      const int total = wave_candidates(P, w, rg, P.cand + (size_t)i * kProjCand, [&](int c) { return dist_of(c) <= P.max_dist; },
+      const int total = wave_candidates(P, w, rg, s_keys[wave_id()], [&](int c) { return dist_of(c) <= P.max_dist; },
                                         [&](int c, int) { return ((unsigned long long)dist_of(c) << 32) | (unsigned)c; });
       if (lane == 0) { P.win[i] = w; P.rng[i] = rg; }
-      n = total <= kProjCand ? total : (kProjCand | kProjOverflow);
+      ref = publish_candidates(P, i, s_keys[wave_id()], total, false,
+                               [](unsigned long long key) { return cand_entry((int)(key >> 32), 0, (int)(key & 0xffffu)); });
       st = total > 0 ? 0 : 1;
     }
   }
-  if (lane == 0) { P.choice[i] = -1; P.ncand[i] = (uint8_t)n; P.state[i] = st; }
+  if (lane == 0) { P.choice[i] = -1; P.cref[i] = ref; P.state[i] = st; }
 }
 
 // grid = 1, block = kProjBS
@@ -1650,7 +1765,7 @@ int rgbl_device_frame_set_grid(rgbl_device_frame* f, const float grid[6]) {
   memcpy(P.grid, grid, sizeof(P.grid));
   P.cell_start = f->d_cell_start; P.cell_items = f->d_cell_items; P.taken_by = f->d_grid_scratch;
   RGBL_HIP(hipStreamWaitEvent(f->stream, f->ready, 0));   // the keypoints may still be on their way (capture)
-  hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, f->stream, P);
+  launch_proj_grid(P, f->stream);
   RGBL_HIP(hipGetLastError());
   RGBL_HIP(hipEventRecord(f->ready, f->stream));
   RGBL_HIP(hipStreamSynchronize(f->stream));
@@ -2037,7 +2152,7 @@ void grid_for_call(rgbl_matcher* m, hipStream_t s, ProjDev& P, const rgbl_device
   }
   P.init_taken = 0;
   m->timer.begin("k_proj_grid", s);
-  hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(kProjBS), 0, s, P);
+  launch_proj_grid(P, s);
   m->timer.end(s);
 }
 
@@ -2052,7 +2167,7 @@ int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* o
   StreamDrain drain(m->stream);  // error returns included
   size_t need = pad256(n1) * 2 + pad256((size_t)n1 * 12) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 8) +
                 pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 3 + pad256(n2) +
-                pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 + pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) +
+                pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 + pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 4) + pad256((size_t)n1 * 4) + 256 +
                 pad256((size_t)(kGridCells + 1) * 4);
   HostCall hc;
   RGBL_TRY(hc.begin(m, need));
@@ -2076,8 +2191,8 @@ int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* o
   P.min_unres = hc.scratch<int32_t>(n2);
   P.win = hc.scratch<float4>(n1);
   P.rng = hc.scratch<int4>(n1);
-  P.cand = hc.scratch<unsigned long long>((size_t)n1 * kProjCand);
-  P.ncand = hc.scratch<uint8_t>(n1);
+  P.clist = hc.scratch<uint32_t>((size_t)n1 * kProjCand);
+  P.cref = hc.scratch<uint32_t>(n1);
   P.state = hc.scratch<uint8_t>(n1);
   memcpy(P.grid, in.grid, sizeof(P.grid));
   memcpy(P.q, in.Tcw_q, sizeof(P.q));
@@ -2094,8 +2209,8 @@ int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* o
   hipLaunchKernelGGL(k_proj_candidates, dim3((n1 + kPointsPerBlock - 1) / kPointsPerBlock), dim3(256), 0, s, P);
   m->timer.end(s);
   m->timer.begin("k_proj_resolve", s);
-  if (n2 <= kResolveLdsN2 && n1 <= kResolveLdsN1) hipLaunchKernelGGL(k_proj_resolve<true>, dim3(1), dim3(kProjBS), 0, s, P);
-  else hipLaunchKernelGGL(k_proj_resolve<false>, dim3(1), dim3(kProjBS), 0, s, P);
+  if (n2 <= kResolveLdsN2 && n1 <= kResolveLdsN1) hipLaunchKernelGGL(k_proj_resolve<true>, dim3(1), dim3(kResolveBS), 0, s, P);
+  else hipLaunchKernelGGL(k_proj_resolve<false>, dim3(1), dim3(kResolveBS), 0, s, P);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
   RGBL_TRY(hc.fetch());
@@ -2344,7 +2459,7 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
   StreamDrain drain(m->stream);  // error returns included
   size_t need = pad256(n1) * 2 + pad256((size_t)n1 * 12) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) * 2 + pad256((size_t)n2 * 8) +
                 pad256((size_t)n2 * 4) * 2 + pad256((size_t)n2 * 32) + pad256(n2) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 2 +
-                pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 + pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) +
+                pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 + pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 4) + pad256((size_t)n1 * 4) + 256 +
                 pad256((size_t)(kGridCells + 1) * 4);
   HostCall hc;
   RGBL_TRY(hc.begin(m, need));
@@ -2368,8 +2483,8 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
   P.min_unres = hc.scratch<int32_t>(n2);
   P.win = hc.scratch<float4>(n1);
   P.rng = hc.scratch<int4>(n1);
-  P.cand = hc.scratch<unsigned long long>((size_t)n1 * kProjCand);
-  P.ncand = hc.scratch<uint8_t>(n1);
+  P.clist = hc.scratch<uint32_t>((size_t)n1 * kProjCand);
+  P.cref = hc.scratch<uint32_t>(n1);
   P.state = hc.scratch<uint8_t>(n1);
   memcpy(P.grid, in->grid, sizeof(P.grid));
   P.th = in->th;
@@ -2380,8 +2495,8 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
   hipLaunchKernelGGL(k_local_candidates, dim3((n1 + kPointsPerBlock - 1) / kPointsPerBlock), dim3(256), 0, s, P);
   m->timer.end(s);
   m->timer.begin("k_local_resolve", s);
-  if (n2 <= kResolveLdsN2 && n1 <= kResolveLdsN1) hipLaunchKernelGGL(k_local_resolve<true>, dim3(1), dim3(kProjBS), 0, s, P);
-  else hipLaunchKernelGGL(k_local_resolve<false>, dim3(1), dim3(kProjBS), 0, s, P);
+  if (n2 <= kResolveLdsN2 && n1 <= kResolveLdsN1) hipLaunchKernelGGL(k_local_resolve<true>, dim3(1), dim3(kResolveBS), 0, s, P);
+  else hipLaunchKernelGGL(k_local_resolve<false>, dim3(1), dim3(kResolveBS), 0, s, P);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
   RGBL_TRY(hc.fetch());
@@ -2409,7 +2524,7 @@ int rgbl_search_for_initialization(rgbl_matcher* m, const rgbl_initialization_in
   StreamDrain drain(m->stream);  // error returns included
   size_t need = pad256((size_t)n1 * 8) + pad256((size_t)n1 * 32) + pad256((size_t)n1 * 4) + pad256((size_t)n2 * 8) + pad256((size_t)n2 * 4) +
                 pad256((size_t)n2 * 32) + pad256((size_t)n2 * 2) + pad256((size_t)n2 * 4) * 3 + pad256((size_t)n1 * 16) * 2 + pad256(n1) * 2 +
-                pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 8) + pad256((size_t)(kGridCells + 1) * 4);
+                pad256((size_t)n1 * 4) + pad256((size_t)n1 * kProjCand * 4) + pad256((size_t)n1 * 4) + 256 + pad256((size_t)(kGridCells + 1) * 4);
   HostCall hc;
   RGBL_TRY(hc.begin(m, need));
   hipStream_t s = hc.s;
@@ -2429,8 +2544,8 @@ int rgbl_search_for_initialization(rgbl_matcher* m, const rgbl_initialization_in
   P.min_unres = hc.scratch<int32_t>(n2);
   P.win = hc.scratch<float4>(n1);
   P.rng = hc.scratch<int4>(n1);
-  P.cand = hc.scratch<unsigned long long>((size_t)n1 * kProjCand);
-  P.ncand = hc.scratch<uint8_t>(n1);
+  P.clist = hc.scratch<uint32_t>((size_t)n1 * kProjCand);
+  P.cref = hc.scratch<uint32_t>(n1);
   P.state = hc.scratch<uint8_t>(n1);
   memcpy(P.grid, in->grid, sizeof(P.grid));
   P.th = (float)in->window_size;  // GetFeaturesInArea takes r as const float&

@@ -414,8 +414,10 @@ def test_device_resident_frames(emu_lib):
 
 
 def test_projection_searches_beyond_the_lds_resolve(emu_lib):
-    """Frames / point sets above kResolveLdsN2 / kResolveLdsN1 take the resolve kernels' global-memory form."""
-    assert pc.check_search_by_projection(emu_lib, 27, "forward", 15.0, False, True, n1=900, n2=6500) > 100
+    """Frames / point sets above kResolveLdsN2 / kResolveLdsN1 take the resolve kernels' global-memory form; a call whose candidate
+    lists exceed kResolveLdsList entries (25 640 here, many points beyond kProjCand as well) reads them where the candidate kernel left them."""
+    assert pc.check_search_local_points(emu_lib, 49, 6.0, 0.8, n1=6000, n2=3000) > 1000
+    assert pc.check_search_by_projection(emu_lib, 27, "forward", 15.0, False, True, n1=900, n2=8300) > 100
     assert pc.check_search_local_points(emu_lib, 48, 3.0, 0.8, n1=12400, n2=1500) > 100
 
 
