@@ -895,17 +895,22 @@ __device__ __forceinline__ int proj_best(const ProjDev& P, const int32_t* taken_
 constexpr int kResolveLdsN2 = 6144, kResolveLdsN1 = 8192, kResolveLdsList = 16384;
 constexpr int kResolveBS = 1024;
 struct ListView { const uint32_t* cref; const uint32_t* clist; };
+// (the copies of taken_by and state ride in the same trips: three independent loads per trip instead of three loops of dependent ones)
 template <bool LDS>
-__device__ __forceinline__ ListView stage_lists(const ProjDev& P, uint32_t* s_ref, uint32_t* s_list, int* s_total) {
+__device__ __forceinline__ ListView stage_lists(const ProjDev& P, int32_t* s_taken, uint8_t* s_state, uint32_t* s_ref, uint32_t* s_list, int* s_total) {
   ListView v{P.cref, P.clist};
   if (LDS) {
     const int tid = threadIdx.x, lane = lane_id();
     if (tid == 0) *s_total = 0;
     __syncthreads();
     // where a point's entries go: any packing will do, so a wave's points take one range (one LDS atomic per wave and trip)
-    for (int i0 = 0; i0 < P.n1; i0 += kResolveBS) {
+    for (int i0 = 0; i0 < P.n1 || i0 < P.n2; i0 += kResolveBS) {
       const int i = i0 + tid;
       const uint32_t r = i < P.n1 ? P.cref[i] : 0u;
+      const uint8_t st = i < P.n1 ? P.state[i] : (uint8_t)0;
+      const int32_t tk = i < P.n2 ? P.taken_by[i] : 0;
+      if (i < P.n1) s_state[i] = st;
+      if (i < P.n2) s_taken[i] = tk;
       const int n = (r & kRefOverflow) ? 0 : ref_n(r);
       const int incl = wave_inclusive_scan(n), tot = __shfl(incl, 63);
       int base = 0;
@@ -955,11 +960,7 @@ __global__ __launch_bounds__(kResolveBS) void k_proj_resolve(ProjDev P) {
   uint8_t* state = LDS ? s_state : P.state;
   __shared__ uint32_t s_ref[LDS ? kResolveLdsN1 : 1], s_list[LDS ? kResolveLdsList : 1];
   const int tid = threadIdx.x;
-  if (LDS) {
-    for (int c = tid; c < P.n2; c += kResolveBS) s_taken[c] = P.taken_by[c];
-    for (int i = tid; i < P.n1; i += kResolveBS) s_state[i] = P.state[i];
-  }
-  const ListView L = stage_lists<LDS>(P, s_ref, s_list, &s_total);
+  const ListView L = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
   if (tid < 2) s_unres[tid] = 0;
   for (int round = 0; round <= P.n1; ++round) {
     const int stamp = kStampMax - round % kStampMax, b = round & 1;
@@ -1024,10 +1025,14 @@ struct FuseDev {
   int chi2_gate;  // 1: the reprojection-error gates of Fuse(pKF, vpMapPoints, th)
 };
 
-// grid = ceil(n1 / 64), block = 64
-__global__ __launch_bounds__(64) void k_fuse_search(ProjDev P, FuseDev Fz) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
+// grid = ceil(n1 / 4), block = 256 = one wave per map point (round 6; a work-item per point walked ~100 dependent gathers: 30 us
+// for 2500 points): the window's cells go to the lanes in traversal order, a lane keeps the smallest (distance, cell, feature)
+// key of its cells - the cell number grows along the traversal, so the smallest key IS the reference's first minimum - and the
+// wave's minimum over (distance, cell) names the one lane that holds it.
+__global__ __launch_bounds__(256) void k_fuse_search(ProjDev P, FuseDev Fz) {
+  const int i = blockIdx.x * kPointsPerBlock + wave_id();
   if (i >= P.n1) return;
+  const int lane = lane_id();
   unsigned long long best = ~0ull;
   if (P.valid1[i]) {
     float x, y, z;
@@ -1053,38 +1058,40 @@ __global__ __launch_bounds__(64) void k_fuse_search(ProjDev P, FuseDev Fz) {
         if (x0 < kGridCols && x1 >= 0 && y0 < kGridRows && y1 >= 0) {
           const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
           const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
-          for (int ix = x0; ix <= x1; ++ix)
-            for (int iy = y0; iy <= y1; ++iy) {
-              const int cell = ix * kGridRows + iy;
-              const uint32_t kb = P.cell_start[cell], ke = P.cell_start[cell + 1];
-              for (uint32_t k = kb; k < ke; ++k) {
-                const int c = P.cell_items[k];
-                const float kpx = P.xy2[2 * c], kpy = P.xy2[2 * c + 1];
-                if (!(fabsf(kpx - u) < radius && fabsf(kpy - v) < radius)) continue;
-                const int kl = P.oct2[c];
-                if (kl < level - 1 || kl > level) continue;
-                // reprojection error gate, chi-square at 95 % with 3 / 2 degrees of freedom (:1262-1288)
-                const float ex = u - kpx, ey = v - kpy;
-                const float kpr = P.ur2 ? P.ur2[c] : -1.f;
-                if (!Fz.chi2_gate) {
-                } else if (kpr >= 0) {
-                  const float er = ur - kpr;
-                  const float e2 = ex * ex + ey * ey + er * er;
-                  if ((double)(e2 * Fz.inv_sigma2[kl]) > 7.8) continue;
-                } else {
-                  const float e2 = ex * ex + ey * ey;
-                  if ((double)(e2 * Fz.inv_sigma2[kl]) > 5.99) continue;
-                }
-                const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
-                const unsigned long long key = proj_key(dist, cell, c);
-                if (key < best) best = key;  // strict '<' over the traversal order
+          const int ny = y1 - y0 + 1, ncells = (x1 - x0 + 1) * ny;
+          for (int t = lane; t < ncells; t += 64) {
+            const int cell = (x0 + t / ny) * kGridRows + y0 + t % ny;
+            const uint32_t kb = P.cell_start[cell], ke = P.cell_start[cell + 1];
+            for (uint32_t k = kb; k < ke; ++k) {
+              const int c = P.cell_items[k];
+              const float kpx = P.xy2[2 * c], kpy = P.xy2[2 * c + 1];
+              if (!(fabsf(kpx - u) < radius && fabsf(kpy - v) < radius)) continue;
+              const int kl = P.oct2[c];
+              if (kl < level - 1 || kl > level) continue;
+              // reprojection error gate, chi-square at 95 % with 3 / 2 degrees of freedom (:1262-1288)
+              const float ex = u - kpx, ey = v - kpy;
+              const float kpr = P.ur2 ? P.ur2[c] : -1.f;
+              if (!Fz.chi2_gate) {
+              } else if (kpr >= 0) {
+                const float er = ur - kpr;
+                const float e2 = ex * ex + ey * ey + er * er;
+                if ((double)(e2 * Fz.inv_sigma2[kl]) > 7.8) continue;
+              } else {
+                const float e2 = ex * ex + ey * ey;
+                if ((double)(e2 * Fz.inv_sigma2[kl]) > 5.99) continue;
               }
+              const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
+              const unsigned long long key = proj_key(dist, cell, c);
+              if (key < best) best = key;  // strict '<' over the traversal order
             }
+          }
         }
       }
     }
   }
-  P.cand[i] = best;
+  // (distance << 16 | cell) of the wave's smallest key: a cell belongs to one lane, so exactly one lane matches - or all do, with ~0
+  const uint32_t m = wave_min_uniform((uint32_t)(best >> 16));
+  if ((uint32_t)(best >> 16) == m && (best != ~0ull || lane == 0)) P.cand[i] = best;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1177,11 +1184,7 @@ __global__ __launch_bounds__(kResolveBS) void k_local_resolve(ProjDev P) {
   uint8_t* state = LDS ? s_state : P.state;
   __shared__ uint32_t s_ref[LDS ? kResolveLdsN1 : 1], s_list[LDS ? kResolveLdsList : 1];
   const int tid = threadIdx.x;
-  if (LDS) {
-    for (int c = tid; c < P.n2; c += kResolveBS) s_taken[c] = P.taken_by[c];
-    for (int i = tid; i < P.n1; i += kResolveBS) s_state[i] = P.state[i];
-  }
-  const ListView L = stage_lists<LDS>(P, s_ref, s_list, &s_total);
+  const ListView L = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
   if (tid < 2) s_unres[tid] = 0;
   for (int round = 0; round <= P.n1; ++round) {
     const int stamp = kStampMax - round % kStampMax, b = round & 1;
@@ -2375,7 +2378,7 @@ static int fuse_core(rgbl_matcher* m, const rgbl_fuse_input* in, int cam_frame, 
   }
   grid_for_call(m, s, P, in->device2);
   m->timer.begin("k_fuse_search", s);
-  hipLaunchKernelGGL(k_fuse_search, dim3((n1 + 63) / 64), dim3(64), 0, s, P, Fz);
+  hipLaunchKernelGGL(k_fuse_search, dim3((n1 + kPointsPerBlock - 1) / kPointsPerBlock), dim3(256), 0, s, P, Fz);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
   RGBL_TRY(hc.fetch());
