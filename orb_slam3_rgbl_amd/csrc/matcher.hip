@@ -8,9 +8,9 @@
 //   k_hamming_bf          one query descriptor per lane (4 x u64 in VGPRs); the train descriptors are read
 //                         through wave-uniform addresses (scalar loads, broadcast to the 64 lanes), XOR +
 //                         v_bcnt popcount, running best / second-best with the reference's strict '<'.
-//   k_search_triangulation one workgroup per BoW node shared by both key-frames, one query feature per
-//                         work-item, the node's candidate bucket is walked in index order (ties -> later
-//                         candidate wins, as in the reference) with the eligibility masks and epipolar test.
+//   k_search_triangulation one workgroup per BoW node shared by both key-frames, both buckets staged in LDS, one
+//                         query feature per wave, the candidates over its lanes (ties -> later candidate wins, as
+//                         in the reference) with the eligibility masks and epipolar test.
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -519,46 +519,77 @@ struct TriDev {
 };
 
 // grid = number of node ids present in both feature vectors, block = 256.
+// A first-image feature keeps the LAST second-image feature of the node's bucket with the smallest distance <= TH_LOW among those that
+// pass the tests (":1075 if(dist>TH_LOW || dist>bestDist) continue" lets an equal distance replace the best) - the tests do not
+// depend on what was found before, and nothing is handed from one first-image feature to the next (vbMatched2 is never set in this
+// version, :1135): every pair is independent.  Round 6: a work-item per first-image feature walked the bucket through ~4 dependent
+// global loads per candidate (38 us for 2000 x 2000 features in ~100 nodes, 20 work-items of a workgroup busy).  Now both buckets
+// are staged in LDS by all 256 work-items at once (kTriCap entries each; longer buckets read the rest from global memory), a WAVE
+// takes a first-image feature, its lanes the candidates, and one DPP minimum over (distance << 26 | 2^26 - 1 - position) names the match.
+constexpr int kTriCap = 256;
+struct TriEntry {
+  unsigned long long d[4];
+  float x, y;
+  int32_t idx;
+  int32_t oct_flags;  // octave | stereo << 8 | skip << 9 (holds a map point, or not stereo under only_stereo)
+};
+__device__ __forceinline__ TriEntry tri_load(const TriDev& T, bool second, int idx) {
+  TriEntry e;
+  const unsigned long long* D = reinterpret_cast<const unsigned long long*>((second ? T.desc2 : T.desc1) + (size_t)idx * 32);
+  e.d[0] = D[0]; e.d[1] = D[1]; e.d[2] = D[2]; e.d[3] = D[3];
+  const float* xy = second ? T.xy2 : T.xy1;
+  e.x = xy[2 * idx]; e.y = xy[2 * idx + 1];
+  e.idx = idx;
+  const bool stereo = (second ? T.ur2 : T.ur1)[idx] >= 0;
+  const bool skip = (second ? T.mp2 : T.mp1)[idx] != 0 || (T.only_stereo && !stereo);
+  e.oct_flags = (second ? T.oct2[idx] : 0) | (stereo ? 0x100 : 0) | (skip ? 0x200 : 0);
+  return e;
+}
 __global__ __launch_bounds__(256) void k_search_triangulation(TriDev T) {
-  const int np = blockIdx.x;
+  __shared__ TriEntry s_1[kTriCap], s_2[kTriCap];
+  const int np = blockIdx.x, tid = threadIdx.x, lane = lane_id();
   const int a = T.pair_n1[np], b = T.pair_n2[np];
-  const int b1 = T.off1[a], e1 = T.off1[a + 1], b2 = T.off2[b], e2 = T.off2[b + 1];
-  for (int p = b1 + (int)threadIdx.x; p < e1; p += 256) {
-    const int idx1 = T.feat1[p];
-    if (T.mp1[idx1]) continue;
-    const bool stereo1 = T.ur1[idx1] >= 0;
-    if (T.only_stereo && !stereo1) continue;
-    const float x1 = T.xy1[2 * idx1], y1 = T.xy1[2 * idx1 + 1];
-    const unsigned long long* D1 = reinterpret_cast<const unsigned long long*>(T.desc1 + (size_t)idx1 * 32);
-    const unsigned long long q[4] = {D1[0], D1[1], D1[2], D1[3]};
+  const int b1 = T.off1[a], n1 = T.off1[a + 1] - b1, b2 = T.off2[b], n2 = T.off2[b + 1] - b2;
+  if (tid < n1) s_1[tid] = tri_load(T, false, T.feat1[b1 + tid]);
+  if (tid < n2) s_2[tid] = tri_load(T, true, T.feat2[b2 + tid]);
+  __syncthreads();
+  for (int p = wave_id(); p < n1; p += 4) {   // wave-uniform
+    TriEntry e1;
+    if (p < kTriCap) e1 = s_1[p]; else e1 = tri_load(T, false, T.feat1[b1 + p]);
+    if (e1.oct_flags & 0x200) continue;
+    const bool stereo1 = (e1.oct_flags & 0x100) != 0;
     // epipolar line of kp1 in image 2 (Pinhole.cpp:115-117), constant over the candidates
-    const float la = x1 * T.F[0] + y1 * T.F[3] + T.F[6];
-    const float lb = x1 * T.F[1] + y1 * T.F[4] + T.F[7];
-    const float lc = x1 * T.F[2] + y1 * T.F[5] + T.F[8];
+    const float la = e1.x * T.F[0] + e1.y * T.F[3] + T.F[6];
+    const float lb = e1.x * T.F[1] + e1.y * T.F[4] + T.F[7];
+    const float lc = e1.x * T.F[2] + e1.y * T.F[5] + T.F[8];
     const float den = la * la + lb * lb;
-    int best_dist = 50 /* TH_LOW */, best_idx2 = -1;
-    for (int qi = b2; qi < e2; ++qi) {
-      const int idx2 = T.feat2[qi];
-      if (T.mp2[idx2]) continue;
-      const bool stereo2 = T.ur2[idx2] >= 0;
-      if (T.only_stereo && !stereo2) continue;
-      const int dist = hamming256(q, reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)idx2 * 32));
-      if (dist > 50 || dist > best_dist) continue;
-      const float x2 = T.xy2[2 * idx2], y2 = T.xy2[2 * idx2 + 1];
-      const int oct2 = T.oct2[idx2];
-      if (!stereo1 && !stereo2) {
-        const float ex = T.ep[0] - x2, ey = T.ep[1] - y2;
+    uint32_t best = 0xffffffffu;
+    for (int j = lane; j < n2; j += 64) {
+      TriEntry e2;
+      if (j < kTriCap) e2 = s_2[j]; else e2 = tri_load(T, true, T.feat2[b2 + j]);
+      if (e2.oct_flags & 0x200) continue;
+      const int dist = hamming256(e1.d, e2.d);
+      if (dist > 50 /* TH_LOW */) continue;
+      const int oct2 = e2.oct_flags & 0xff;
+      if (!stereo1 && !(e2.oct_flags & 0x100)) {
+        const float ex = T.ep[0] - e2.x, ey = T.ep[1] - e2.y;
         if (ex * ex + ey * ey < 100 * T.scale2[oct2]) continue;
       }
       bool ok = T.coarse != 0;
       if (!ok && den != 0) {
-        const float num = la * x2 + lb * y2 + lc;
+        const float num = la * e2.x + lb * e2.y + lc;
         const float dsqr = __fdiv_rn(num * num, den);
         ok = (double)dsqr < 3.84 * (double)T.sigma2[oct2];  // 3.84 is a double literal in the reference
       }
-      if (ok) { best_idx2 = idx2; best_dist = dist; }
+      if (!ok) continue;
+      const uint32_t key = ((uint32_t)dist << 26) | (uint32_t)(0x3ffffff - j);   // dist <= 50: six bits
+      best = key < best ? key : best;
     }
-    if (best_idx2 >= 0) T.matches12[idx1] = best_idx2;
+    best = wave_min_uniform(best);
+    if (lane == 0 && best != 0xffffffffu) {
+      const int j = 0x3ffffff - (int)(best & 0x3ffffffu);
+      T.matches12[e1.idx] = j < kTriCap ? s_2[j].idx : T.feat2[b2 + j];
+    }
   }
 }
 

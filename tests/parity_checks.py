@@ -308,8 +308,8 @@ def check_matcher_known_answers(lib):
     m.close()
 
 
-def check_triangulation(lib, n=1500, seed=11):
-    kf1, kf2, K, R, t, ep, sf, s2 = make_triangulation_case(n, seed)
+def check_triangulation(lib, n=1500, seed=11, n_nodes=100):
+    kf1, kf2, K, R, t, ep, sf, s2 = make_triangulation_case(n, seed, n_nodes)
     total = 0
     for check_ori in (False, True):
         m = F.ORBmatcher(0.6, check_ori, lib=lib)

@@ -69,6 +69,7 @@ def test_matcher(emu_lib):
 
 def test_search_for_triangulation(emu_lib):
     pc.check_triangulation(emu_lib, 600, seed=11)
+    pc.check_triangulation(emu_lib, 700, seed=12, n_nodes=2)   # buckets beyond kTriCap: their tails are read from global memory
 
 
 def test_extractor_large_nodes_take_the_cooperative_split(emu_lib):

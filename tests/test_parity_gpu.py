@@ -162,6 +162,7 @@ def test_matcher_bf(gpu_lib):
 def test_search_for_triangulation(gpu_lib):
     pc.check_triangulation(gpu_lib, 2000, seed=11)
     pc.check_triangulation(gpu_lib, 8000, seed=12)
+    pc.check_triangulation(gpu_lib, 1500, seed=13, n_nodes=3)   # buckets beyond kTriCap: their tails are read from global memory
 
 
 def test_hamming_match_of_consecutive_frames_is_symmetric_property(gpu_lib):
