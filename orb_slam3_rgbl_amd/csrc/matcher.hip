@@ -1433,10 +1433,20 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
   const int a = T.pair_n1[np], b = T.pair_n2[np];
   const int b1 = T.off1[a], e1 = T.off1[a + 1], b2 = T.off2[b], n2 = T.off2[b + 1] - b2;
   for (int j = lane; j < n2; j += 64) s_taken[j] = (T.valid2 && !T.valid2[T.feat2[b2 + j]]) ? 1 : 0;
-  unsigned long long t0[4] = {0ull, 0ull, 0ull, 0ull};
-  if (lane < n2) {
-    const unsigned long long* D2 = reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)T.feat2[b2 + lane] * 32);
-    t0[0] = D2[0]; t0[1] = D2[1]; t0[2] = D2[2]; t0[3] = D2[3];
+  // the frame features at bucket positions lane, lane + 64, lane + 128, lane + 192 live in the lane's registers (index and
+  // descriptor): buckets of up to 256 features - a KITTI frame's largest hold ~150 - cost no global read inside the serial loop
+  constexpr int kRegTrips = 4;
+  unsigned long long t0[kRegTrips][4];
+  int my_idx2[kRegTrips];
+#pragma unroll
+  for (int r = 0; r < kRegTrips; ++r) {
+    my_idx2[r] = -1;
+    t0[r][0] = t0[r][1] = t0[r][2] = t0[r][3] = 0ull;
+    if (lane + 64 * r < n2) {
+      my_idx2[r] = T.feat2[b2 + lane + 64 * r];
+      const unsigned long long* D2 = reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)my_idx2[r] * 32);
+      t0[r][0] = D2[0]; t0[r][1] = D2[1]; t0[r][2] = D2[2]; t0[r][3] = D2[3];
+    }
   }
   for (int p0 = b1; p0 < e1; p0 += 64) {
     wave_sync();
@@ -1458,14 +1468,21 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
       const unsigned long long q[4] = {s_q[k][0], s_q[k][1], s_q[k][2], s_q[k][3]};
       uint32_t best = 0xffffffffu;  // dist << 16 | bucket position
       int second = 256;
-      if (lane < n2 && !s_taken[lane]) best = ((uint32_t)hamming256(q, t0) << 16) | (uint32_t)lane;
-      for (int j = lane + 64; j < n2; j += 64) {
-        if (s_taken[j]) continue;
-        const int idx2 = T.feat2[b2 + j];
-        const int dist = hamming256(q, reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)idx2 * 32));
+      auto visit = [&](int dist, int j) {
         const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)j;
         if (key < best) { if (best != 0xffffffffu) second = (int)(best >> 16); best = key; }
         else if (dist < second) second = dist;
+      };
+#pragma unroll
+      for (int r = 0; r < kRegTrips; ++r) {
+        if (64 * r >= n2) break;  // wave-uniform
+        const int j = lane + 64 * r;
+        if (j < n2 && !s_taken[j]) visit(hamming256(q, t0[r]), j);
+      }
+      for (int j = lane + 64 * kRegTrips; j < n2; j += 64) {
+        if (s_taken[j]) continue;
+        const int idx2 = T.feat2[b2 + j];
+        visit(hamming256(q, reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)idx2 * 32)), j);
       }
       // wave-wide: the smallest key, and the smallest distance among everything else
       const uint32_t wbest = wave_min_uniform(best);   // register-file DPP steps: the two reductions sit in the node's serial loop
@@ -1473,8 +1490,11 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
       if (wbest == 0xffffffffu) continue;
       const int best_dist = (int)(wbest >> 16), pos = (int)(wbest & 0xffffu);
       if (best_dist <= T.max_best && (float)best_dist < T.nnratio * (float)other) {
-        if (lane == 0) {
-          const int idx2 = T.feat2[b2 + pos];
+        if (lane == (pos & 63)) {   // the lane that holds the feature's index
+          int idx2 = -1;
+#pragma unroll
+          for (int r = 0; r < kRegTrips; ++r) idx2 = (pos >> 6) == r ? my_idx2[r] : idx2;
+          if (pos >= 64 * kRegTrips) idx2 = T.feat2[b2 + pos];
           s_taken[pos] = 1;
           T.match1[idx1] = idx2;
           T.match2[idx2] = idx1;

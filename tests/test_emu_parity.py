@@ -278,12 +278,12 @@ def test_extractor_replay(emu_lib):
     pc.check_extractor_replay(emu_lib, 360, 280, 400)
 
 
-@pytest.mark.parametrize("seed,ratio,ori,nodes", [(51, 0.7, True, 100), (53, 0.9, True, 30), (54, 0.6, False, 1)])
+@pytest.mark.parametrize("seed,ratio,ori,nodes", [(51, 0.7, True, 100), (53, 0.9, True, 30), (54, 0.6, False, 1), (55, 0.8, True, 5)])
 def test_search_by_bow(emu_lib, seed, ratio, ori, nodes):
     assert pc.check_search_by_bow(emu_lib, seed, ratio, ori, n=700, nodes=nodes) > 30
 
 
-@pytest.mark.parametrize("seed,ratio,ori,nodes", [(81, 0.75, True, 100), (82, 0.9, False, 30), (84, 0.8, True, 1)])
+@pytest.mark.parametrize("seed,ratio,ori,nodes", [(81, 0.75, True, 100), (82, 0.9, False, 30), (84, 0.8, True, 1), (85, 0.8, True, 6)])
 def test_search_by_bow_keyframes(emu_lib, seed, ratio, ori, nodes):
     assert pc.check_search_by_bow_keyframes(emu_lib, seed, ratio, ori, n=800, nodes=nodes) > 50
 

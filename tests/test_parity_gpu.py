@@ -258,12 +258,12 @@ def test_extractor_under_full_load(gpu_lib):
     pc.check_extractor_under_load(gpu_lib)
 
 
-@pytest.mark.parametrize("seed,ratio,ori,nodes", [(51, 0.7, True, 100), (52, 0.7, False, 100), (53, 0.9, True, 30), (54, 0.6, True, 1)])
+@pytest.mark.parametrize("seed,ratio,ori,nodes", [(51, 0.7, True, 100), (52, 0.7, False, 100), (53, 0.9, True, 30), (54, 0.6, True, 1), (55, 0.8, True, 12)])
 def test_search_by_bow(gpu_lib, seed, ratio, ori, nodes):
     assert pc.check_search_by_bow(gpu_lib, seed, ratio, ori, n=2000, nodes=nodes) > 100
 
 
-@pytest.mark.parametrize("seed,ratio,ori,nodes", [(81, 0.75, True, 100), (82, 0.9, False, 30), (84, 0.8, True, 1)])
+@pytest.mark.parametrize("seed,ratio,ori,nodes", [(81, 0.75, True, 100), (82, 0.9, False, 30), (84, 0.8, True, 1), (85, 0.8, True, 6)])
 def test_search_by_bow_keyframes(gpu_lib, seed, ratio, ori, nodes):
     assert pc.check_search_by_bow_keyframes(gpu_lib, seed, ratio, ori, n=2000, nodes=nodes) > 50
 
@@ -498,7 +498,7 @@ def test_bow_transform_on_a_vocabulary_of_orbvoc_size(gpu_lib):
     pick = leaves[rng.integers(0, len(leaves), 1500)]
     desc = np.ascontiguousarray(np.concatenate([pick ^ np.packbits(rng.random((len(pick), 256)) < 0.03, axis=1, bitorder="little"),
                                                 synth.descriptors(500, 5)]))
-    want = O.bow_transform(varr, desc, 4)
+    want = pc.O.bow_transform(varr, desc, 4)
     V = F.ORBVocabulary(lib=gpu_lib).from_arrays(varr)
     fr = F.DeviceFrame(len(desc), lib=gpu_lib).upload(desc, np.zeros((len(desc), 2), np.float32), np.zeros(len(desc), np.int32))
     for got in (V.transform(desc, 4), V.prepare_transform_frame(fr, 4)()):
