@@ -2839,29 +2839,39 @@ static int bow_transform_core(rgbl_vocabulary* v, const rgbl_device_frame* frame
   const double* weight = reinterpret_cast<const double*>(v->h_stage + cap * 32);
   const int32_t* word = reinterpret_cast<const int32_t*>(weight + n);
   const int32_t* node = word + n;
-  // the two std::map containers of the reference, as sorted (key, payload) runs
-  std::vector<std::pair<uint32_t, int> > wf, nf;  // (word | node, feature)
+  // the two std::map containers of the reference, as sorted (key << 32 | feature) runs: one unstable sort of 64-bit integers each
+  // (the feature index makes the keys distinct, so the order inside a word / node is the order of the features) on buffers the
+  // thread keeps - round 6: 2 x stable_sort of pairs in freshly grown vectors was ~25 us of a 72-us call
+  static thread_local std::vector<unsigned long long> wf, nf;
+  wf.clear(); nf.clear();
   for (int i = 0; i < n; ++i)
-    if (weight[i] > 0) { wf.push_back(std::make_pair((uint32_t)word[i], i)); nf.push_back(std::make_pair((uint32_t)node[i], i)); }
-  std::stable_sort(wf.begin(), wf.end(), [](const std::pair<uint32_t, int>& a, const std::pair<uint32_t, int>& b) { return a.first < b.first; });
-  std::stable_sort(nf.begin(), nf.end(), [](const std::pair<uint32_t, int>& a, const std::pair<uint32_t, int>& b) { return a.first < b.first; });
+    if (weight[i] > 0) {
+      wf.push_back(((unsigned long long)(uint32_t)word[i] << 32) | (uint32_t)i);
+      nf.push_back(((unsigned long long)(uint32_t)node[i] << 32) | (uint32_t)i);
+    }
+  std::sort(wf.begin(), wf.end());
+  std::sort(nf.begin(), nf.end());
   int nw = 0, nn = 0;
   for (size_t a = 0; a < wf.size();) {
     size_t b = a;
     double acc = 0.0;
     bool first = true;
-    for (; b < wf.size() && wf[b].first == wf[a].first; ++b) { acc = first ? weight[wf[b].second] : acc + weight[wf[b].second]; first = false; }
-    if (nw < cap_words && word_id && word_val) { word_id[nw] = wf[a].first; word_val[nw] = acc; }
+    for (; b < wf.size() && (wf[b] >> 32) == (wf[a] >> 32); ++b) {
+      const double w = weight[(uint32_t)wf[b]];
+      acc = first ? w : acc + w;
+      first = false;
+    }
+    if (nw < cap_words && word_id && word_val) { word_id[nw] = (uint32_t)(wf[a] >> 32); word_val[nw] = acc; }
     ++nw;
     a = b;
   }
   for (size_t a = 0; a < nf.size();) {
     size_t b = a;
-    while (b < nf.size() && nf[b].first == nf[a].first) ++b;
+    while (b < nf.size() && (nf[b] >> 32) == (nf[a] >> 32)) ++b;
     if (nn < cap_nodes && node_id && node_off && node_feat) {
-      node_id[nn] = nf[a].first;
+      node_id[nn] = (uint32_t)(nf[a] >> 32);
       node_off[nn] = (int32_t)a;
-      for (size_t q = a; q < b; ++q) node_feat[q] = (uint32_t)nf[q].second;
+      for (size_t q = a; q < b; ++q) node_feat[q] = (uint32_t)nf[q];
     }
     ++nn;
     a = b;
