@@ -81,5 +81,22 @@ def greedy_search_case(lib, rng):
     return "SearchByProjection(F, KF) %5d -> %5d: %d matches" % (min(n1, 6000), n2, n)
 
 
-CASES = {"extractor": extractor_case, "low_contrast": low_contrast_case, "depth": depth_case, "hamming": hamming_case,
+def node_search_case(lib, rng):
+    """The searches that work through the vocabulary nodes two FeatureVectors share (SearchForTriangulation, SearchByBoW x 2): random
+    feature counts and node counts, i.e. buckets on both sides of what the kernels keep in LDS (256) and in registers (64 / 256)."""
+    kind = int(rng.integers(0, 3))
+    n = int(rng.choice([60, 300, 700, 1500, 2000, 4000]))
+    nodes = int(rng.choice([1, 2, 5, 12, 30, 100, 400]))
+    seed = int(rng.integers(0, 100000))
+    if kind == 0:
+        m = pc.check_triangulation(lib, n, seed=seed, n_nodes=nodes, min_total=0)
+        return "SearchForTriangulation %5d features, %3d nodes: %d matches" % (n, nodes, m)
+    if kind == 1:
+        m = pc.check_search_by_bow(lib, seed, float(rng.choice([0.6, 0.7, 0.9])), bool(rng.integers(0, 2)), n=n, nodes=nodes)
+        return "SearchByBoW(KF, F) %5d features, %3d nodes: %d matches" % (n, nodes, m)
+    m = pc.check_search_by_bow_keyframes(lib, seed, float(rng.choice([0.75, 0.8, 0.9])), bool(rng.integers(0, 2)), n=n, nodes=nodes)
+    return "SearchByBoW(KF, KF) %5d features, %3d nodes: %d matches" % (n, nodes, m)
+
+
+CASES = {"node_search": node_search_case, "extractor": extractor_case, "low_contrast": low_contrast_case, "depth": depth_case, "hamming": hamming_case,
          "greedy_search": greedy_search_case}

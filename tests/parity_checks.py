@@ -308,7 +308,7 @@ def check_matcher_known_answers(lib):
     m.close()
 
 
-def check_triangulation(lib, n=1500, seed=11, n_nodes=100):
+def check_triangulation(lib, n=1500, seed=11, n_nodes=100, min_total=101):
     kf1, kf2, K, R, t, ep, sf, s2 = make_triangulation_case(n, seed, n_nodes)
     total = 0
     for check_ori in (False, True):
@@ -323,7 +323,7 @@ def check_triangulation(lib, n=1500, seed=11, n_nodes=100):
                 assert nm == onm == len(pairs)
                 total += nm
         m.close()
-    assert total > 100  # the case must actually produce matches
+    assert total >= min_total  # the case must actually produce matches
     return total
 
 

@@ -10,8 +10,8 @@ import pytest
 import fuzz_cases
 
 SEEDS = {"extractor": (1, 2, 3, 4), "low_contrast": (11, 12), "depth": (21, 22, 23, 24), "hamming": (31, 32, 33, 34),
-         "greedy_search": (41, 42, 43, 44, 45, 46)}
-PER_SEED = {"extractor": 3, "low_contrast": 2, "depth": 3, "hamming": 4, "greedy_search": 4}
+         "greedy_search": (41, 42, 43, 44, 45, 46), "node_search": (51, 52, 53, 54)}
+PER_SEED = {"extractor": 3, "low_contrast": 2, "depth": 3, "hamming": 4, "greedy_search": 4, "node_search": 4}
 
 
 @pytest.mark.gpu
