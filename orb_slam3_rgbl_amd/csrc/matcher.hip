@@ -659,7 +659,6 @@ struct ProjDev {
   int32_t* choice;           // n1: best CurrentFrame feature or -1
 };
 constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;  // FRAME_GRID_COLS / ROWS (Frame.h:46-47)
-constexpr int kProjBS = 512;
 
 __host__ __device__ __forceinline__ void quat_rotate(const float q[4], float px, float py, float pz, float* rx, float* ry, float* rz) {
   // Eigen QuaternionBase::_transformVector: uv = 2 (q.vec x p); p + w uv + q.vec x uv
@@ -1265,13 +1264,13 @@ __global__ __launch_bounds__(kResolveBS) void k_local_resolve(ProjDev P) {
 // taken_by = vMatchedDistance, owner = vnMatches21), and a feature is final once no unresolved lower-index feature shares
 // one of its still-available candidates - two features that share one resolve in index order, exactly the order of the loop.
 template <class F>
-__device__ __forceinline__ void init_available(const ProjDev& P, int i, F&& f) {  // f(dist, c) in traversal order
-  const uint32_t r = P.cref[i];
+__device__ __forceinline__ void init_available(const ProjDev& P, const int32_t* taken_by, const ListView& L, int i, F&& f) {  // f(dist, c) in traversal order
+  const uint32_t r = L.cref[i];
   if (!(r & kRefOverflow)) {
-    const uint32_t* e = P.clist + ref_start(r);
+    const uint32_t* e = L.clist + ref_start(r);
     for (int k = 0, n = ref_n(r); k < n; ++k) {
       const int c = entry_feature(e[k]), dist = entry_dist(e[k]);
-      if (P.taken_by[c] > dist) f(dist, c);  // vMatchedDistance[i2] <= dist: continue (:689-690)
+      if (taken_by[c] > dist) f(dist, c);  // vMatchedDistance[i2] <= dist: continue (:689-690)
     }
     return;
   }
@@ -1279,7 +1278,7 @@ __device__ __forceinline__ void init_available(const ProjDev& P, int i, F&& f) {
   const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
   for_candidates(P, P.win[i], P.rng[i], [&](int c, int) {
     const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
-    if (dist <= P.max_dist && P.taken_by[c] > dist) f(dist, c);
+    if (dist <= P.max_dist && taken_by[c] > dist) f(dist, c);
   });
 }
 
@@ -1315,45 +1314,54 @@ __global__ __launch_bounds__(256) void k_init_candidates(ProjDev P) {   // one w
   if (lane == 0) { P.choice[i] = -1; P.cref[i] = ref; P.state[i] = st; }
 }
 
-// grid = 1, block = kProjBS
-__global__ __launch_bounds__(kProjBS) void k_init_resolve(ProjDev P) {
-  __shared__ int s_unres;
+// grid = 1, block = kResolveBS; state, lists, round stamps and the merged decide + commit pass as for k_proj_resolve (taken_by holds
+// vMatchedDistance here).  Merging is safe for the same reason: two features that are final in one round share no available
+// candidate (the higher one would have found the lower one's announcement), and lowering vMatchedDistance[c] can only take c away
+// from features that were going to lose it to this one anyway - they wait behind its announcement.
+template <bool LDS>
+__global__ __launch_bounds__(kResolveBS) void k_init_resolve(ProjDev P) {
+  __shared__ int s_unres[2], s_total;
+  __shared__ int32_t s_taken[LDS ? kResolveLdsN2 : 1], s_min[LDS ? kResolveLdsN2 : 1];
+  __shared__ uint8_t s_state[LDS ? kResolveLdsN1 : 1];
+  __shared__ uint32_t s_ref[LDS ? kResolveLdsN1 : 1], s_list[LDS ? kResolveLdsList : 1];
+  int32_t* taken_by = LDS ? s_taken : P.taken_by;
+  int32_t* min_unres = LDS ? s_min : P.min_unres;
+  uint8_t* state = LDS ? s_state : P.state;
   const int tid = threadIdx.x;
-  for (int c = tid; c < P.n2; c += kProjBS) P.owner[c] = -1;
+  for (int c = tid; c < P.n2; c += kResolveBS) P.owner[c] = -1;
+  const ListView L = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
+  if (tid < 2) s_unres[tid] = 0;
   for (int round = 0; round <= P.n1; ++round) {
-    for (int c = tid; c < P.n2; c += kProjBS) P.min_unres[c] = INT_MAX;
-    if (tid == 0) s_unres = 0;
-    __syncthreads();
-    for (int i = tid; i < P.n1; i += kProjBS) {
-      if (P.state[i] != 0) continue;
-      init_available(P, i, [&](int, int c) { atomicMin(&P.min_unres[c], i); });
+    const int stamp = kStampMax - round % kStampMax, b = round & 1;
+    if (round % kStampMax == 0) {
+      __syncthreads();
+      for (int c = tid; c < P.n2; c += kResolveBS) min_unres[c] = INT_MAX;
     }
     __syncthreads();
-    for (int i = tid; i < P.n1; i += kProjBS) {
-      if (P.state[i] != 0) continue;
+    for (int i = tid; i < P.n1; i += kResolveBS) {
+      if (state[i] != 0) continue;
+      const int me = (stamp << 20) | i;
+      init_available(P, taken_by, L, i, [&](int, int c) { atomicMin(&min_unres[c], me); });
+    }
+    __syncthreads();
+    for (int i = tid; i < P.n1; i += kResolveBS) {
+      if (state[i] != 0) continue;
       int best = INT_MAX, best2 = INT_MAX, best_idx = -1;
       bool settled = true;
-      init_available(P, i, [&](int dist, int c) {
+      init_available(P, taken_by, L, i, [&](int dist, int c) {
         if (dist < best) { best2 = best; best = dist; best_idx = c; }  // :692-701
         else if (dist < best2) best2 = dist;
-        if (P.min_unres[c] < i) settled = false;
+        if (lower_unresolved(min_unres[c], stamp, i)) settled = false;
       });
-      if (!settled) { atomicAdd(&s_unres, 1); continue; }
+      if (!settled) { atomicAdd(&s_unres[b], 1); continue; }
       const bool ok = best <= 50 /* TH_LOW */ && (float)best < (float)best2 * P.nnratio;  // :704-706
-      P.state[i] = 2;
+      state[i] = 1;
       P.choice[i] = ok ? best_idx : -1;
-      P.win[i].w = __int_as_float(best);
+      if (ok) { taken_by[best_idx] = best; P.owner[best_idx] = i; }  // vMatchedDistance, vnMatches21 (:713-715)
     }
+    if (tid == 0) s_unres[b ^ 1] = 0;
     __syncthreads();
-    for (int i = tid; i < P.n1; i += kProjBS) {
-      if (P.state[i] != 2) continue;
-      P.state[i] = 1;
-      const int c = P.choice[i];
-      if (c >= 0) { P.taken_by[c] = __float_as_int(P.win[i].w); P.owner[c] = i; }  // vMatchedDistance, vnMatches21 (:713-715)
-    }
-    __syncthreads();
-    if (s_unres == 0) break;
-    __syncthreads();
+    if (s_unres[b] == 0) break;
   }
 }
 
@@ -2215,6 +2223,7 @@ int projection_core(rgbl_matcher* m, const ProjHost& in, int32_t* match2, int* o
   const int n1 = in.n1, n2 = in.n2;
   for (int i = 0; i < n2; ++i) match2[i] = -1;
   if (n1 == 0 || n2 == 0) return RGBL_OK;
+  if (n1 >= (1 << 20)) { set_error("at most 2^20 - 1 map points per call (a point's index travels in 20 bits of the resolve kernel's announcements)"); return RGBL_ERR_INVALID; }
   for (int i = 0; i < n1; ++i)
     if (in.valid1[i] && (in.oct1[i] < 0 || in.oct1[i] >= in.n_levels)) { set_error("octave out of range"); return RGBL_ERR_INVALID; }
   RGBL_HIP(hipSetDevice(m->device));
@@ -2503,6 +2512,7 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
     set_error("invalid argument (the frame may hold at most 65535 features, %d pyramid levels)", kProjMaxLevels);
     return RGBL_ERR_INVALID;
   }
+  if (in->n1 >= (1 << 20)) { set_error("at most 2^20 - 1 map points per call (a point's index travels in 20 bits of the resolve kernel's announcements)"); return RGBL_ERR_INVALID; }
   *out_nmatches = 0;
   const int n1 = in->n1, n2 = in->n2;
   for (int i = 0; i < n2; ++i) match2[i] = -1;
@@ -2564,8 +2574,8 @@ int rgbl_search_local_points(rgbl_matcher* m, const rgbl_local_points_input* in,
 
 int rgbl_search_for_initialization(rgbl_matcher* m, const rgbl_initialization_input* in, float* prev_matched, int32_t* matches12,
                                    int* out_nmatches) {
-  if (!m || !in || !out_nmatches || in->n1 < 0 || in->n2 < 0 || in->n2 > 65535 || (in->n1 > 0 && (!prev_matched || !matches12))) {
-    set_error("invalid argument (the second frame may hold at most 65535 features)");
+  if (!m || !in || !out_nmatches || in->n1 < 0 || in->n1 >= (1 << 20) || in->n2 < 0 || in->n2 > 65535 || (in->n1 > 0 && (!prev_matched || !matches12))) {
+    set_error("invalid argument (the second frame may hold at most 65535 features, the first 2^20 - 1)");
     return RGBL_ERR_INVALID;
   }
   *out_nmatches = 0;
@@ -2614,7 +2624,8 @@ int rgbl_search_for_initialization(rgbl_matcher* m, const rgbl_initialization_in
   hipLaunchKernelGGL(k_init_candidates, dim3((n1 + kPointsPerBlock - 1) / kPointsPerBlock), dim3(256), 0, s, P);
   m->timer.end(s);
   m->timer.begin("k_init_resolve", s);
-  hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(kProjBS), 0, s, P);
+  if (n2 <= kResolveLdsN2 && n1 <= kResolveLdsN1) hipLaunchKernelGGL(k_init_resolve<true>, dim3(1), dim3(kResolveBS), 0, s, P);
+  else hipLaunchKernelGGL(k_init_resolve<false>, dim3(1), dim3(kResolveBS), 0, s, P);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
   RGBL_TRY(hc.fetch());

@@ -420,6 +420,7 @@ def test_projection_searches_beyond_the_lds_resolve(emu_lib):
     assert pc.check_search_local_points(emu_lib, 49, 6.0, 0.8, n1=6000, n2=3000) > 1000
     assert pc.check_search_by_projection(emu_lib, 27, "forward", 15.0, False, True, n1=900, n2=8300) > 100
     assert pc.check_search_local_points(emu_lib, 48, 3.0, 0.8, n1=12400, n2=1500) > 100
+    assert pc.check_search_for_initialization(emu_lib, 66, 100, 0.9, True, n1=6500) > 300   # both frames beyond kResolveLdsN2
 
 
 def test_every_tuning_switch_is_bit_identical(emu_lib):
