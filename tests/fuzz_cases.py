@@ -14,9 +14,12 @@ from orb_slam3_rgbl_amd import synth
 def extractor_case(lib, rng):
     while True:
         w, h = int(rng.integers(200, 1400)), int(rng.integers(120, 700))
-        roots = round((w - 32) / max(h - 32, 1))
         nlevels = int(rng.integers(1, 9))
-        if 1 <= roots <= 16 and min(w, h) / 1.2 ** (nlevels - 1) >= 80:
+        # every level needs 1 .. 16 quad-tree roots (ORBextractor.cc:558: nIni = round(width / height) of the level's bordered area; the
+        # reference divides by zero for portrait levels, the library refuses them at create time) - the borders weigh more on the small levels
+        sizes = [(round(w / 1.2 ** l), round(h / 1.2 ** l)) for l in range(nlevels)]
+        if all(1 <= round((wl - 26) / max(hl - 26, 1) - 0.02) and round((wl - 26) / max(hl - 26, 1) + 0.02) <= 16 for wl, hl in sizes) and \
+                min(w, h) / 1.2 ** (nlevels - 1) >= 80:
             break
     nf = int(rng.choice([50, 300, 1000, 2000, 3500, 6000]))
     ini = int(rng.choice([12, 20]))
