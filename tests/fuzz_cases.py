@@ -15,10 +15,11 @@ def extractor_case(lib, rng):
     while True:
         w, h = int(rng.integers(200, 1400)), int(rng.integers(120, 700))
         nlevels = int(rng.integers(1, 9))
-        # every level needs 1 .. 16 quad-tree roots (ORBextractor.cc:558: nIni = round(width / height) of the level's bordered area; the
+        # every level needs 1 .. 16 quad-tree roots (ORBextractor.cc:558: nIni = round(width / height) of the level minus its 16-px frame; the
         # reference divides by zero for portrait levels, the library refuses them at create time) - the borders weigh more on the small levels
         sizes = [(round(w / 1.2 ** l), round(h / 1.2 ** l)) for l in range(nlevels)]
-        if all(1 <= round((wl - 26) / max(hl - 26, 1) - 0.02) and round((wl - 26) / max(hl - 26, 1) + 0.02) <= 16 for wl, hl in sizes) and \
+        # (the library rounds a level's size in fp32, cvRound(w * mvInvScaleFactor[l]): a pixel either way moves the ratio by up to 2 %)
+        if all(1 <= round((wl - 32) / max(hl - 32, 1) - 0.05) and round((wl - 32) / max(hl - 32, 1) + 0.05) <= 16 for wl, hl in sizes) and \
                 min(w, h) / 1.2 ** (nlevels - 1) >= 80:
             break
     nf = int(rng.choice([50, 300, 1000, 2000, 3500, 6000]))
