@@ -250,7 +250,10 @@ def tracking_leg(lib):
     ok = ok and rnm2 == nm and np.array_equal(rm2, om)
     resident = _time_call(rcall)
     res["search_by_bow"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", resident=resident, n1=int(len(prev["xy"])), n2=int(len(cur["xy"])),
-                                  matches=int(nm), nodes=int(len(kf["node_id"])), ref_lines="ORBmatcher.cc:223-425, Tracking.cc:2798-2810")
+                                  matches=int(nm), nodes=int(len(kf["node_id"])),
+                                  largest_bucket={"key_frame_features_with_a_map_point": int(max(kf["has_mp"][kf["node_feat"][a:b]].sum() for a, b in zip(kf["node_off"][:-1], kf["node_off"][1:]))),
+                                                  "key_frame": int(np.diff(kf["node_off"]).max()), "frame": int(np.diff(frm["node_off"]).max())},
+                                  ref_lines="ORBmatcher.cc:223-425, Tracking.cc:2798-2810")
     mt.close()
     V.close()
     # -- Frame::ComputeStereoMatches, one stereo pair per call (the extractions are not part of the timed call)

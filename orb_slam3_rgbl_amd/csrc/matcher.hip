@@ -1440,18 +1440,22 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
   const int np = blockIdx.x, lane = threadIdx.x;
   const int a = T.pair_n1[np], b = T.pair_n2[np];
   const int b1 = T.off1[a], e1 = T.off1[a + 1], b2 = T.off2[b], n2 = T.off2[b + 1] - b2;
-  for (int j = lane; j < n2; j += 64) s_taken[j] = (T.valid2 && !T.valid2[T.feat2[b2 + j]]) ? 1 : 0;
-  // the frame features at bucket positions lane, lane + 64, lane + 128, lane + 192 live in the lane's registers (index and
-  // descriptor): buckets of up to 256 features - a KITTI frame's largest hold ~150 - cost no global read inside the serial loop
+  // the frame features at bucket positions lane, lane + 64, lane + 128, lane + 192 live in the lane's registers (index,
+  // descriptor and whether the feature is taken): buckets of up to 256 features - a KITTI frame's largest hold ~150 - cost
+  // neither a global nor an LDS access inside the serial loop
   constexpr int kRegTrips = 4;
+  for (int j = lane + 64 * kRegTrips; j < n2; j += 64) s_taken[j] = (T.valid2 && !T.valid2[T.feat2[b2 + j]]) ? 1 : 0;   // beyond the register trips
   unsigned long long t0[kRegTrips][4];
   int my_idx2[kRegTrips];
+  bool gone[kRegTrips];   // taken, masked out, or no such position
 #pragma unroll
   for (int r = 0; r < kRegTrips; ++r) {
     my_idx2[r] = -1;
+    gone[r] = true;
     t0[r][0] = t0[r][1] = t0[r][2] = t0[r][3] = 0ull;
     if (lane + 64 * r < n2) {
       my_idx2[r] = T.feat2[b2 + lane + 64 * r];
+      gone[r] = T.valid2 && !T.valid2[my_idx2[r]];
       const unsigned long long* D2 = reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)my_idx2[r] * 32);
       t0[r][0] = D2[0]; t0[r][1] = D2[1]; t0[r][2] = D2[2]; t0[r][3] = D2[3];
     }
@@ -1470,10 +1474,17 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
     }
     wave_sync();
     const int cnt = imin(64, e1 - p0);
+    // the next key-frame feature's descriptor is fetched from LDS while the current one is worked on
+    int idx1_n = s_idx1[0];
+    unsigned long long qn[4] = {s_q[0][0], s_q[0][1], s_q[0][2], s_q[0][3]};
     for (int k = 0; k < cnt; ++k) {
-      const int idx1 = s_idx1[k];
+      const int idx1 = idx1_n;
+      const unsigned long long q[4] = {qn[0], qn[1], qn[2], qn[3]};
+      if (k + 1 < cnt) {
+        idx1_n = s_idx1[k + 1];
+        qn[0] = s_q[k + 1][0]; qn[1] = s_q[k + 1][1]; qn[2] = s_q[k + 1][2]; qn[3] = s_q[k + 1][3];
+      }
       if (idx1 < 0) continue;  // wave-uniform
-      const unsigned long long q[4] = {s_q[k][0], s_q[k][1], s_q[k][2], s_q[k][3]};
       uint32_t best = 0xffffffffu;  // dist << 16 | bucket position
       int second = 256;
       auto visit = [&](int dist, int j) {
@@ -1484,8 +1495,7 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
 #pragma unroll
       for (int r = 0; r < kRegTrips; ++r) {
         if (64 * r >= n2) break;  // wave-uniform
-        const int j = lane + 64 * r;
-        if (j < n2 && !s_taken[j]) visit(hamming256(q, t0[r]), j);
+        if (!gone[r]) visit(hamming256(q, t0[r]), lane + 64 * r);
       }
       for (int j = lane + 64 * kRegTrips; j < n2; j += 64) {
         if (s_taken[j]) continue;
@@ -1501,13 +1511,13 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
         if (lane == (pos & 63)) {   // the lane that holds the feature's index
           int idx2 = -1;
 #pragma unroll
-          for (int r = 0; r < kRegTrips; ++r) idx2 = (pos >> 6) == r ? my_idx2[r] : idx2;
-          if (pos >= 64 * kRegTrips) idx2 = T.feat2[b2 + pos];
-          s_taken[pos] = 1;
+          for (int r = 0; r < kRegTrips; ++r)
+            if ((pos >> 6) == r) { idx2 = my_idx2[r]; gone[r] = true; }
+          if (pos >= 64 * kRegTrips) { idx2 = T.feat2[b2 + pos]; s_taken[pos] = 1; }
           T.match1[idx1] = idx2;
           T.match2[idx2] = idx1;
         }
-        wave_sync();
+        if (pos >= 64 * kRegTrips) wave_sync();   // wave-uniform: the other lanes read s_taken
       }
     }
   }
