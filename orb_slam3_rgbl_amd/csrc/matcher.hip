@@ -1428,22 +1428,14 @@ struct BowDev {
 };
 constexpr int kBowBucket = 16384;  // frame features of one node tracked in LDS (one byte each)
 
-// grid = shared nodes, block = 64.  The node's key-frame features are taken one after the other (a frame feature taken by an
-// earlier one is gone for the later ones: ORBmatcher.cc:296-299), so what sits inside that serial loop decides the kernel's
-// time.  Round 6: the key-frame features' descriptors are staged in LDS 64 at a time and a lane keeps the descriptor of ITS
-// frame feature (bucket position = lane, every bucket of a KITTI frame's ~100 nodes fits) in registers - the loop body is LDS
-// reads and register work instead of three dependent global loads per key-frame feature (100 -> ~15 us for a frame pair).
-__global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
-  __shared__ uint8_t s_taken[kBowBucket];
-  __shared__ unsigned long long s_q[64][4];
-  __shared__ int s_idx1[64];
-  const int np = blockIdx.x, lane = threadIdx.x;
-  const int a = T.pair_n1[np], b = T.pair_n2[np];
-  const int b1 = T.off1[a], e1 = T.off1[a + 1], b2 = T.off2[b], n2 = T.off2[b + 1] - b2;
+// The node's work for a frame bucket of up to 64 * kRegTrips features (kRegTrips = 4: any size, positions from 256 on are read from
+// memory): instantiated per trip count so that a node pays for the lanes' registers it uses - the serial chain of the LARGEST node
+// is the kernel's time, and with one body for all sizes every step computed four trips' distances.
+template <int kRegTrips>
+__device__ __forceinline__ void bow_node(const BowDev& T, uint8_t* s_taken, unsigned long long (*s_q)[4], int* s_idx1, int lane, int b1, int e1, int b2, int n2) {
   // the frame features at bucket positions lane, lane + 64, lane + 128, lane + 192 live in the lane's registers (index,
-  // descriptor and whether the feature is taken): buckets of up to 256 features - a KITTI frame's largest hold ~150 - cost
+  // descriptor and whether the feature is taken): buckets of up to 256 features - a KITTI frame's largest hold ~100 - cost
   // neither a global nor an LDS access inside the serial loop
-  constexpr int kRegTrips = 4;
   for (int j = lane + 64 * kRegTrips; j < n2; j += 64) s_taken[j] = (T.valid2 && !T.valid2[T.feat2[b2 + j]]) ? 1 : 0;   // beyond the register trips
   unsigned long long t0[kRegTrips][4];
   int my_idx2[kRegTrips];
@@ -1486,25 +1478,29 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
       }
       if (idx1 < 0) continue;  // wave-uniform
       uint32_t best = 0xffffffffu;  // dist << 16 | bucket position
-      int second = 256;
-      auto visit = [&](int dist, int j) {
-        const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)j;
-        if (key < best) { if (best != 0xffffffffu) second = (int)(best >> 16); best = key; }
-        else if (dist < second) second = dist;
+      uint32_t second = 256;
+      // best / second-best without a branch (the loop body is what a node's serial chain is made of): the smaller key stays, the
+      // larger one's distance competes for second place - the key it displaces when it is the new best (second >= best's distance
+      // always), itself otherwise; an absent candidate is the key 0xffffffff and changes nothing
+      auto visit = [&](uint32_t key) {
+        const uint32_t lo = key < best ? key : best, hi = key < best ? best : key;
+        second = (hi >> 16) < second ? (hi >> 16) : second;
+        best = lo;
       };
 #pragma unroll
       for (int r = 0; r < kRegTrips; ++r) {
         if (64 * r >= n2) break;  // wave-uniform
-        if (!gone[r]) visit(hamming256(q, t0[r]), lane + 64 * r);
+        const uint32_t key = ((uint32_t)hamming256(q, t0[r]) << 16) | (uint32_t)(lane + 64 * r);
+        visit(gone[r] ? 0xffffffffu : key);
       }
       for (int j = lane + 64 * kRegTrips; j < n2; j += 64) {
         if (s_taken[j]) continue;
         const int idx2 = T.feat2[b2 + j];
-        visit(hamming256(q, reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)idx2 * 32)), j);
+        visit(((uint32_t)hamming256(q, reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)idx2 * 32)) << 16) | (uint32_t)j);
       }
       // wave-wide: the smallest key, and the smallest distance among everything else
       const uint32_t wbest = wave_min_uniform(best);   // register-file DPP steps: the two reductions sit in the node's serial loop
-      const int other = (int)wave_min_uniform((uint32_t)(best == wbest ? second : (best == 0xffffffffu ? 256 : (int)(best >> 16))));
+      const int other = (int)wave_min_uniform(best == wbest ? second : (best == 0xffffffffu ? 256u : best >> 16));
       if (wbest == 0xffffffffu) continue;
       const int best_dist = (int)(wbest >> 16), pos = (int)(wbest & 0xffffu);
       if (best_dist <= T.max_best && (float)best_dist < T.nnratio * (float)other) {
@@ -1521,6 +1517,24 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
       }
     }
   }
+}
+
+// grid = shared nodes, block = 64.  The node's key-frame features are taken one after the other (a frame feature taken by an
+// earlier one is gone for the later ones: ORBmatcher.cc:296-299), so what sits inside that serial loop decides the kernel's
+// time.  Round 6: the key-frame features' descriptors are staged in LDS 64 at a time and a lane keeps the descriptor of ITS
+// frame feature (bucket position = lane, every bucket of a KITTI frame's ~100 nodes fits) in registers - the loop body is LDS
+// reads and register work instead of three dependent global loads per key-frame feature (100 -> ~15 us for a frame pair).
+__global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
+  __shared__ uint8_t s_taken[kBowBucket];
+  __shared__ unsigned long long s_q[64][4];
+  __shared__ int s_idx1[64];
+  const int np = blockIdx.x, lane = threadIdx.x;
+  const int a = T.pair_n1[np], b = T.pair_n2[np];
+  const int b1 = T.off1[a], e1 = T.off1[a + 1], b2 = T.off2[b], n2 = T.off2[b + 1] - b2;
+  if (n2 <= 64) bow_node<1>(T, s_taken, s_q, s_idx1, lane, b1, e1, b2, n2);
+  else if (n2 <= 128) bow_node<2>(T, s_taken, s_q, s_idx1, lane, b1, e1, b2, n2);
+  else if (n2 <= 192) bow_node<3>(T, s_taken, s_q, s_idx1, lane, b1, e1, b2, n2);
+  else bow_node<4>(T, s_taken, s_q, s_idx1, lane, b1, e1, b2, n2);
 }
 
 }  // namespace rgbl
