@@ -922,7 +922,11 @@ __device__ __forceinline__ int proj_best(const ProjDev& P, const int32_t* taken_
 }
 
 // The resolve kernels' view of the lists: packed into LDS when the call's points (cref) and entries fit, else where the candidate kernels left them
-constexpr int kResolveLdsN2 = 6144, kResolveLdsN1 = 8192, kResolveLdsList = 16384;
+constexpr int kResolveLdsN2 = 6144, kResolveLdsN1 = 8192, kResolveLdsList = 12288;
+// From the second round on a round walks the LIST of the points the round before left unresolved (up to kUCap of them, else all points
+// again): a wave runs a point's chain of dependent LDS accesses as soon as ONE of its lanes holds an unresolved point, and the few
+// dozen points of the late rounds, scattered over all waves, cost every wave its full time - 3.5 us per round for a KITTI frame.
+constexpr int kUCap = 4096;
 constexpr int kResolveBS = 1024;
 struct ListView { const uint32_t* cref; const uint32_t* clist; };
 // (the copies of taken_by and state ride in the same trips: three independent loads per trip instead of three loops of dependent ones)
@@ -989,9 +993,12 @@ __global__ __launch_bounds__(kResolveBS) void k_proj_resolve(ProjDev P) {
   int32_t* min_unres = LDS ? s_min : P.min_unres;
   uint8_t* state = LDS ? s_state : P.state;
   __shared__ uint32_t s_ref[LDS ? kResolveLdsN1 : 1], s_list[LDS ? kResolveLdsList : 1];
+  __shared__ uint16_t s_ulist[2][LDS ? kUCap : 1];
   const int tid = threadIdx.x;
   const ListView L = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
   if (tid < 2) s_unres[tid] = 0;
+  bool use_list = false;
+  int n_walk = P.n1;   // points this round looks at: all, or the entries of s_ulist[b ^ 1]
   for (int round = 0; round <= P.n1; ++round) {
     const int stamp = kStampMax - round % kStampMax, b = round & 1;
     if (round % kStampMax == 0) {
@@ -1000,7 +1007,8 @@ __global__ __launch_bounds__(kResolveBS) void k_proj_resolve(ProjDev P) {
     }
     __syncthreads();
     // every unresolved blocker announces itself on the features it may still take
-    for (int i = tid; i < P.n1; i += kResolveBS) {
+    for (int t = tid; t < n_walk; t += kResolveBS) {
+      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
       if (state[i] != kStateObs) continue;   // unresolved and a blocker
       const uint32_t r = L.cref[i];
       const int me = (stamp << 20) | i;
@@ -1025,7 +1033,12 @@ __global__ __launch_bounds__(kResolveBS) void k_proj_resolve(ProjDev P) {
     // picks the same feature, finds this point's announcement in front of it and waits a round; one that sees it takes its next
     // choice, which is what the sequential loop would have given it; LOWER points never want a feature that becomes final here
     // (their announcement would have held this point back).  Two blockers never become final on one feature in the same round.
-    for (int i = tid; i < P.n1; i += kResolveBS) {
+    auto still_unresolved = [&](int i) {   // counted, and listed for the next round
+      const int pos = atomicAdd(&s_unres[b], 1);
+      if (LDS && pos < kUCap) s_ulist[b][pos] = (uint16_t)i;
+    };
+    for (int t = tid; t < n_walk; t += kResolveBS) {
+      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
       const uint8_t st = state[i];
       if (st & 0x7f) continue;
       const int c = proj_best(P, taken_by, L.cref, L.clist, i);
@@ -1033,11 +1046,14 @@ __global__ __launch_bounds__(kResolveBS) void k_proj_resolve(ProjDev P) {
       else if (!lower_unresolved(min_unres[c], stamp, i)) {              // nobody in front of i can still take c
         state[i] = st | 1; P.choice[i] = c;
         if (st & kStateObs) taken_by[c] = i;
-      } else atomicAdd(&s_unres[b], 1);
+      } else still_unresolved(i);
     }
     if (tid == 0) s_unres[b ^ 1] = 0;
     __syncthreads();
-    if (s_unres[b] == 0) break;
+    const int left = s_unres[b];
+    if (left == 0) break;
+    use_list = LDS && left <= kUCap;
+    n_walk = use_list ? left : P.n1;
   }
 }
 
@@ -1213,9 +1229,12 @@ __global__ __launch_bounds__(kResolveBS) void k_local_resolve(ProjDev P) {
   int32_t* min_unres = LDS ? s_min : P.min_unres;
   uint8_t* state = LDS ? s_state : P.state;
   __shared__ uint32_t s_ref[LDS ? kResolveLdsN1 : 1], s_list[LDS ? kResolveLdsList : 1];
+  __shared__ uint16_t s_ulist[2][LDS ? kUCap : 1];
   const int tid = threadIdx.x;
   const ListView L = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
   if (tid < 2) s_unres[tid] = 0;
+  bool use_list = false;
+  int n_walk = P.n1;   // points this round looks at: all, or the entries of s_ulist[b ^ 1]
   for (int round = 0; round <= P.n1; ++round) {
     const int stamp = kStampMax - round % kStampMax, b = round & 1;
     if (round % kStampMax == 0) {
@@ -1223,7 +1242,8 @@ __global__ __launch_bounds__(kResolveBS) void k_local_resolve(ProjDev P) {
       for (int c = tid; c < P.n2; c += kResolveBS) min_unres[c] = INT_MAX;
     }
     __syncthreads();
-    for (int i = tid; i < P.n1; i += kResolveBS) {
+    for (int t = tid; t < n_walk; t += kResolveBS) {
+      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
       if (state[i] != kStateObs) continue;   // unresolved and a blocker
       const int me = (stamp << 20) | i;
       local_available(P, taken_by, L, i, [&](int dist, int, int c) { if (dist <= 100) atomicMin(&min_unres[c], me); });
@@ -1231,7 +1251,8 @@ __global__ __launch_bounds__(kResolveBS) void k_local_resolve(ProjDev P) {
     __syncthreads();
     // (a settled point's available candidates carry no announcement of a lower point, so no lower point can occupy one of them in
     // this pass; a higher point's store leaves taken_by[c] >= i: still available to i)
-    for (int i = tid; i < P.n1; i += kResolveBS) {
+    for (int t = tid; t < n_walk; t += kResolveBS) {
+      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
       const uint8_t st = state[i];
       if (st & 0x7f) continue;
       LocalScan sc;
@@ -1244,11 +1265,17 @@ __global__ __launch_bounds__(kResolveBS) void k_local_resolve(ProjDev P) {
         const int c = sc.accept(P.nnratio);
         state[i] = st | 1; P.choice[i] = c;
         if (c >= 0 && (st & kStateObs)) taken_by[c] = i;
-      } else atomicAdd(&s_unres[b], 1);
+      } else {
+        const int pos = atomicAdd(&s_unres[b], 1);
+        if (LDS && pos < kUCap) s_ulist[b][pos] = (uint16_t)i;
+      }
     }
     if (tid == 0) s_unres[b ^ 1] = 0;
     __syncthreads();
-    if (s_unres[b] == 0) break;
+    const int left = s_unres[b];
+    if (left == 0) break;
+    use_list = LDS && left <= kUCap;
+    n_walk = use_list ? left : P.n1;
   }
 }
 
@@ -1324,6 +1351,7 @@ __global__ __launch_bounds__(kResolveBS) void k_init_resolve(ProjDev P) {
   __shared__ int32_t s_taken[LDS ? kResolveLdsN2 : 1], s_min[LDS ? kResolveLdsN2 : 1];
   __shared__ uint8_t s_state[LDS ? kResolveLdsN1 : 1];
   __shared__ uint32_t s_ref[LDS ? kResolveLdsN1 : 1], s_list[LDS ? kResolveLdsList : 1];
+  __shared__ uint16_t s_ulist[2][LDS ? kUCap : 1];
   int32_t* taken_by = LDS ? s_taken : P.taken_by;
   int32_t* min_unres = LDS ? s_min : P.min_unres;
   uint8_t* state = LDS ? s_state : P.state;
@@ -1331,6 +1359,8 @@ __global__ __launch_bounds__(kResolveBS) void k_init_resolve(ProjDev P) {
   for (int c = tid; c < P.n2; c += kResolveBS) P.owner[c] = -1;
   const ListView L = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
   if (tid < 2) s_unres[tid] = 0;
+  bool use_list = false;
+  int n_walk = P.n1;   // points this round looks at: all, or the entries of s_ulist[b ^ 1]
   for (int round = 0; round <= P.n1; ++round) {
     const int stamp = kStampMax - round % kStampMax, b = round & 1;
     if (round % kStampMax == 0) {
@@ -1338,13 +1368,15 @@ __global__ __launch_bounds__(kResolveBS) void k_init_resolve(ProjDev P) {
       for (int c = tid; c < P.n2; c += kResolveBS) min_unres[c] = INT_MAX;
     }
     __syncthreads();
-    for (int i = tid; i < P.n1; i += kResolveBS) {
+    for (int t = tid; t < n_walk; t += kResolveBS) {
+      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
       if (state[i] != 0) continue;
       const int me = (stamp << 20) | i;
       init_available(P, taken_by, L, i, [&](int, int c) { atomicMin(&min_unres[c], me); });
     }
     __syncthreads();
-    for (int i = tid; i < P.n1; i += kResolveBS) {
+    for (int t = tid; t < n_walk; t += kResolveBS) {
+      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
       if (state[i] != 0) continue;
       int best = INT_MAX, best2 = INT_MAX, best_idx = -1;
       bool settled = true;
@@ -1353,7 +1385,11 @@ __global__ __launch_bounds__(kResolveBS) void k_init_resolve(ProjDev P) {
         else if (dist < best2) best2 = dist;
         if (lower_unresolved(min_unres[c], stamp, i)) settled = false;
       });
-      if (!settled) { atomicAdd(&s_unres[b], 1); continue; }
+      if (!settled) {
+        const int pos = atomicAdd(&s_unres[b], 1);
+        if (LDS && pos < kUCap) s_ulist[b][pos] = (uint16_t)i;
+        continue;
+      }
       const bool ok = best <= 50 /* TH_LOW */ && (float)best < (float)best2 * P.nnratio;  // :704-706
       state[i] = 1;
       P.choice[i] = ok ? best_idx : -1;
@@ -1361,7 +1397,10 @@ __global__ __launch_bounds__(kResolveBS) void k_init_resolve(ProjDev P) {
     }
     if (tid == 0) s_unres[b ^ 1] = 0;
     __syncthreads();
-    if (s_unres[b] == 0) break;
+    const int left = s_unres[b];
+    if (left == 0) break;
+    use_list = LDS && left <= kUCap;
+    n_walk = use_list ? left : P.n1;
   }
 }
 
