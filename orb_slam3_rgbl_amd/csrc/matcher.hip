@@ -923,10 +923,7 @@ __device__ __forceinline__ int proj_best(const ProjDev& P, const int32_t* taken_
 
 // The resolve kernels' view of the lists: packed into LDS when the call's points (cref) and entries fit, else where the candidate kernels left them
 constexpr int kResolveLdsN2 = 6144, kResolveLdsN1 = 8192, kResolveLdsList = 12288;
-// From the second round on a round walks the LIST of the points the round before left unresolved (up to kUCap of them, else all points
-// again): a wave runs a point's chain of dependent LDS accesses as soon as ONE of its lanes holds an unresolved point, and the few
-// dozen points of the late rounds, scattered over all waves, cost every wave its full time - 3.5 us per round for a KITTI frame.
-constexpr int kUCap = 4096;
+constexpr int kUCap = 4096;   // unresolved points a round can hand to the next one as a list (resolve_rounds)
 constexpr int kResolveBS = 1024;
 struct ListView { const uint32_t* cref; const uint32_t* clist; };
 // (the copies of taken_by and state ride in the same trips: three independent loads per trip instead of three loops of dependent ones)
@@ -984,6 +981,63 @@ __device__ __forceinline__ ListView stage_lists(const ProjDev& P, int32_t* s_tak
 // round less); it is refilled with INT_MAX every kStampMax rounds (the worst case - a chain of n1 blockers - takes n1 rounds).
 constexpr int kStampMax = 2047;
 __device__ __forceinline__ bool lower_unresolved(int m, int stamp, int i) { return (m >> 20) == stamp && (m & 0xfffff) < i; }
+// The round loop of the three resolve kernels.  announce(i, stamp): point i, if it is an unresolved blocker, publishes itself on what it
+// may still take; decide(i, stamp): point i becomes final (and commits) or not - true while it stays unresolved.  Rounds: all points;
+// from the second round on the LIST of the points the round before left unresolved (up to kUCap of them) - a wave runs a point's chain
+// of dependent LDS accesses as soon as ONE of its lanes holds an unresolved point, and the few dozen points of the late rounds,
+// scattered over all waves, cost every wave its full time; and once at most 64 are left, ONE wave finishes them with wave-level
+// synchronisation only: what is left then is a chain of points waiting for each other, one short round per link (a KITTI frame: ~10
+// rounds, 3.5 us each while all 16 waves and three workgroup barriers took part in every one).
+template <bool LDS, class Announce, class Decide>
+__device__ __forceinline__ void resolve_rounds(int n1, int n2, int32_t* min_unres, int* s_unres, uint16_t (*s_ulist)[LDS ? kUCap : 1],
+                                               Announce&& announce, Decide&& decide) {
+  const int tid = threadIdx.x;
+  if (tid < 2) s_unres[tid] = 0;
+  bool use_list = false;
+  int n_walk = n1;   // points this round looks at: all, or the entries of s_ulist[b ^ 1]
+  int round = 0, left = 0;
+  for (; round <= n1; ++round) {
+    const int stamp = kStampMax - round % kStampMax, b = round & 1;
+    if (round % kStampMax == 0) {
+      __syncthreads();
+      for (int c = tid; c < n2; c += kResolveBS) min_unres[c] = INT_MAX;
+    }
+    __syncthreads();
+    for (int t = tid; t < n_walk; t += kResolveBS) announce(use_list ? (int)s_ulist[b ^ 1][t] : t, stamp);
+    __syncthreads();
+    for (int t = tid; t < n_walk; t += kResolveBS) {
+      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
+      if (decide(i, stamp)) {   // counted, and listed for the next round
+        const int pos = atomicAdd(&s_unres[b], 1);
+        if (LDS && pos < kUCap) s_ulist[b][pos] = (uint16_t)i;
+      }
+    }
+    if (tid == 0) s_unres[b ^ 1] = 0;
+    __syncthreads();
+    left = s_unres[b];
+    if (left == 0) return;
+    if (LDS && left <= 64) break;
+    use_list = LDS && left <= kUCap;
+    n_walk = use_list ? left : n1;
+  }
+  if (!LDS || wave_id() != 0) return;
+  const int lane = lane_id();
+  int mine = lane < left ? (int)s_ulist[round & 1][lane] : -1;
+  for (++round; round <= n1 + 1; ++round) {
+    const int stamp = kStampMax - round % kStampMax;
+    if (round % kStampMax == 0) {
+      wave_sync();
+      for (int c = lane; c < n2; c += 64) min_unres[c] = INT_MAX;
+    }
+    wave_sync();
+    if (mine >= 0) announce(mine, stamp);
+    wave_sync();
+    if (mine >= 0 && !decide(mine, stamp)) mine = -1;
+    wave_sync();
+    if (__ballot(mine >= 0) == 0ull) break;
+  }
+}
+
 template <bool LDS>
 __global__ __launch_bounds__(kResolveBS) void k_proj_resolve(ProjDev P) {
   __shared__ int s_unres[2], s_total;
@@ -994,67 +1048,43 @@ __global__ __launch_bounds__(kResolveBS) void k_proj_resolve(ProjDev P) {
   uint8_t* state = LDS ? s_state : P.state;
   __shared__ uint32_t s_ref[LDS ? kResolveLdsN1 : 1], s_list[LDS ? kResolveLdsList : 1];
   __shared__ uint16_t s_ulist[2][LDS ? kUCap : 1];
-  const int tid = threadIdx.x;
   const ListView L = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
-  if (tid < 2) s_unres[tid] = 0;
-  bool use_list = false;
-  int n_walk = P.n1;   // points this round looks at: all, or the entries of s_ulist[b ^ 1]
-  for (int round = 0; round <= P.n1; ++round) {
-    const int stamp = kStampMax - round % kStampMax, b = round & 1;
-    if (round % kStampMax == 0) {
-      __syncthreads();
-      for (int c = tid; c < P.n2; c += kResolveBS) min_unres[c] = INT_MAX;
-    }
-    __syncthreads();
-    // every unresolved blocker announces itself on the features it may still take
-    for (int t = tid; t < n_walk; t += kResolveBS) {
-      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
-      if (state[i] != kStateObs) continue;   // unresolved and a blocker
-      const uint32_t r = L.cref[i];
-      const int me = (stamp << 20) | i;
-      if (!(r & kRefOverflow)) {
-        const uint32_t* e = L.clist + ref_start(r);
-        for (int k = 0, n = ref_n(r); k < n; ++k) {
-          const int c = entry_feature(e[k]);
-          if (taken_by[c] >= i) atomicMin(&min_unres[c], me);
-        }
-      } else {
-        const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
-        const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
-        for_candidates(P, P.win[i], P.rng[i], [&](int c, int) {
-          if (taken_by[c] < i) return;
-          if (hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)) <= P.max_dist) atomicMin(&min_unres[c], me);
-        });
+  // every unresolved blocker announces itself on the features it may still take
+  auto announce = [&](int i, int stamp) {
+    if (state[i] != kStateObs) return;   // unresolved and a blocker
+    const uint32_t r = L.cref[i];
+    const int me = (stamp << 20) | i;
+    if (!(r & kRefOverflow)) {
+      const uint32_t* e = L.clist + ref_start(r);
+      for (int k = 0, n = ref_n(r); k < n; ++k) {
+        const int c = entry_feature(e[k]);
+        if (taken_by[c] >= i) atomicMin(&min_unres[c], me);
       }
+    } else {
+      const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
+      const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+      for_candidates(P, P.win[i], P.rng[i], [&](int c, int) {
+        if (taken_by[c] < i) return;
+        if (hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)) <= P.max_dist) atomicMin(&min_unres[c], me);
+      });
     }
-    __syncthreads();
-    // decide AND commit in one pass: a point whose best available feature no lower unresolved blocker can still take is final
-    // and occupies it at once.  What a concurrent work-item sees of that store does not matter: a HIGHER point that misses it
-    // picks the same feature, finds this point's announcement in front of it and waits a round; one that sees it takes its next
-    // choice, which is what the sequential loop would have given it; LOWER points never want a feature that becomes final here
-    // (their announcement would have held this point back).  Two blockers never become final on one feature in the same round.
-    auto still_unresolved = [&](int i) {   // counted, and listed for the next round
-      const int pos = atomicAdd(&s_unres[b], 1);
-      if (LDS && pos < kUCap) s_ulist[b][pos] = (uint16_t)i;
-    };
-    for (int t = tid; t < n_walk; t += kResolveBS) {
-      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
-      const uint8_t st = state[i];
-      if (st & 0x7f) continue;
-      const int c = proj_best(P, taken_by, L.cref, L.clist, i);
-      if (c < 0) { state[i] = st | 1; P.choice[i] = -1; }                // everything viable is taken: no match
-      else if (!lower_unresolved(min_unres[c], stamp, i)) {              // nobody in front of i can still take c
-        state[i] = st | 1; P.choice[i] = c;
-        if (st & kStateObs) taken_by[c] = i;
-      } else still_unresolved(i);
-    }
-    if (tid == 0) s_unres[b ^ 1] = 0;
-    __syncthreads();
-    const int left = s_unres[b];
-    if (left == 0) break;
-    use_list = LDS && left <= kUCap;
-    n_walk = use_list ? left : P.n1;
-  }
+  };
+  // decide AND commit in one pass: a point whose best available feature no lower unresolved blocker can still take is final
+  // and occupies it at once.  What a concurrent work-item sees of that store does not matter: a HIGHER point that misses it
+  // picks the same feature, finds this point's announcement in front of it and waits a round; one that sees it takes its next
+  // choice, which is what the sequential loop would have given it; LOWER points never want a feature that becomes final here
+  // (their announcement would have held this point back).  Two blockers never become final on one feature in the same round.
+  auto decide = [&](int i, int stamp) {
+    const uint8_t st = state[i];
+    if (st & 0x7f) return false;
+    const int c = proj_best(P, taken_by, L.cref, L.clist, i);
+    if (c < 0) { state[i] = st | 1; P.choice[i] = -1; return false; }   // everything viable is taken: no match
+    if (lower_unresolved(min_unres[c], stamp, i)) return true;           // somebody in front of i can still take c
+    state[i] = st | 1; P.choice[i] = c;
+    if (st & kStateObs) taken_by[c] = i;
+    return false;
+  };
+  resolve_rounds<LDS>(P.n1, P.n2, min_unres, s_unres, s_ulist, announce, decide);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1230,53 +1260,30 @@ __global__ __launch_bounds__(kResolveBS) void k_local_resolve(ProjDev P) {
   uint8_t* state = LDS ? s_state : P.state;
   __shared__ uint32_t s_ref[LDS ? kResolveLdsN1 : 1], s_list[LDS ? kResolveLdsList : 1];
   __shared__ uint16_t s_ulist[2][LDS ? kUCap : 1];
-  const int tid = threadIdx.x;
   const ListView L = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
-  if (tid < 2) s_unres[tid] = 0;
-  bool use_list = false;
-  int n_walk = P.n1;   // points this round looks at: all, or the entries of s_ulist[b ^ 1]
-  for (int round = 0; round <= P.n1; ++round) {
-    const int stamp = kStampMax - round % kStampMax, b = round & 1;
-    if (round % kStampMax == 0) {
-      __syncthreads();
-      for (int c = tid; c < P.n2; c += kResolveBS) min_unres[c] = INT_MAX;
-    }
-    __syncthreads();
-    for (int t = tid; t < n_walk; t += kResolveBS) {
-      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
-      if (state[i] != kStateObs) continue;   // unresolved and a blocker
-      const int me = (stamp << 20) | i;
-      local_available(P, taken_by, L, i, [&](int dist, int, int c) { if (dist <= 100) atomicMin(&min_unres[c], me); });
-    }
-    __syncthreads();
-    // (a settled point's available candidates carry no announcement of a lower point, so no lower point can occupy one of them in
-    // this pass; a higher point's store leaves taken_by[c] >= i: still available to i)
-    for (int t = tid; t < n_walk; t += kResolveBS) {
-      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
-      const uint8_t st = state[i];
-      if (st & 0x7f) continue;
-      LocalScan sc;
-      bool settled = true;
-      local_available(P, taken_by, L, i, [&](int dist, int level, int c) {
-        sc.visit(dist, level, c);
-        if (lower_unresolved(min_unres[c], stamp, i)) settled = false;  // somebody in front of i may still take this feature
-      });
-      if (settled) {
-        const int c = sc.accept(P.nnratio);
-        state[i] = st | 1; P.choice[i] = c;
-        if (c >= 0 && (st & kStateObs)) taken_by[c] = i;
-      } else {
-        const int pos = atomicAdd(&s_unres[b], 1);
-        if (LDS && pos < kUCap) s_ulist[b][pos] = (uint16_t)i;
-      }
-    }
-    if (tid == 0) s_unres[b ^ 1] = 0;
-    __syncthreads();
-    const int left = s_unres[b];
-    if (left == 0) break;
-    use_list = LDS && left <= kUCap;
-    n_walk = use_list ? left : P.n1;
-  }
+  auto announce = [&](int i, int stamp) {
+    if (state[i] != kStateObs) return;   // unresolved and a blocker
+    const int me = (stamp << 20) | i;
+    local_available(P, taken_by, L, i, [&](int dist, int, int c) { if (dist <= 100) atomicMin(&min_unres[c], me); });
+  };
+  // (a settled point's available candidates carry no announcement of a lower point, so no lower point can occupy one of them in
+  // this pass; a higher point's store leaves taken_by[c] >= i: still available to i)
+  auto decide = [&](int i, int stamp) {
+    const uint8_t st = state[i];
+    if (st & 0x7f) return false;
+    LocalScan sc;
+    bool settled = true;
+    local_available(P, taken_by, L, i, [&](int dist, int level, int c) {
+      sc.visit(dist, level, c);
+      if (lower_unresolved(min_unres[c], stamp, i)) settled = false;  // somebody in front of i may still take this feature
+    });
+    if (!settled) return true;
+    const int c = sc.accept(P.nnratio);
+    state[i] = st | 1; P.choice[i] = c;
+    if (c >= 0 && (st & kStateObs)) taken_by[c] = i;
+    return false;
+  };
+  resolve_rounds<LDS>(P.n1, P.n2, min_unres, s_unres, s_ulist, announce, decide);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1358,50 +1365,28 @@ __global__ __launch_bounds__(kResolveBS) void k_init_resolve(ProjDev P) {
   const int tid = threadIdx.x;
   for (int c = tid; c < P.n2; c += kResolveBS) P.owner[c] = -1;
   const ListView L = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
-  if (tid < 2) s_unres[tid] = 0;
-  bool use_list = false;
-  int n_walk = P.n1;   // points this round looks at: all, or the entries of s_ulist[b ^ 1]
-  for (int round = 0; round <= P.n1; ++round) {
-    const int stamp = kStampMax - round % kStampMax, b = round & 1;
-    if (round % kStampMax == 0) {
-      __syncthreads();
-      for (int c = tid; c < P.n2; c += kResolveBS) min_unres[c] = INT_MAX;
-    }
-    __syncthreads();
-    for (int t = tid; t < n_walk; t += kResolveBS) {
-      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
-      if (state[i] != 0) continue;
-      const int me = (stamp << 20) | i;
-      init_available(P, taken_by, L, i, [&](int, int c) { atomicMin(&min_unres[c], me); });
-    }
-    __syncthreads();
-    for (int t = tid; t < n_walk; t += kResolveBS) {
-      const int i = use_list ? (int)s_ulist[b ^ 1][t] : t;
-      if (state[i] != 0) continue;
-      int best = INT_MAX, best2 = INT_MAX, best_idx = -1;
-      bool settled = true;
-      init_available(P, taken_by, L, i, [&](int dist, int c) {
-        if (dist < best) { best2 = best; best = dist; best_idx = c; }  // :692-701
-        else if (dist < best2) best2 = dist;
-        if (lower_unresolved(min_unres[c], stamp, i)) settled = false;
-      });
-      if (!settled) {
-        const int pos = atomicAdd(&s_unres[b], 1);
-        if (LDS && pos < kUCap) s_ulist[b][pos] = (uint16_t)i;
-        continue;
-      }
-      const bool ok = best <= 50 /* TH_LOW */ && (float)best < (float)best2 * P.nnratio;  // :704-706
-      state[i] = 1;
-      P.choice[i] = ok ? best_idx : -1;
-      if (ok) { taken_by[best_idx] = best; P.owner[best_idx] = i; }  // vMatchedDistance, vnMatches21 (:713-715)
-    }
-    if (tid == 0) s_unres[b ^ 1] = 0;
-    __syncthreads();
-    const int left = s_unres[b];
-    if (left == 0) break;
-    use_list = LDS && left <= kUCap;
-    n_walk = use_list ? left : P.n1;
-  }
+  auto announce = [&](int i, int stamp) {
+    if (state[i] != 0) return;
+    const int me = (stamp << 20) | i;
+    init_available(P, taken_by, L, i, [&](int, int c) { atomicMin(&min_unres[c], me); });
+  };
+  auto decide = [&](int i, int stamp) {
+    if (state[i] != 0) return false;
+    int best = INT_MAX, best2 = INT_MAX, best_idx = -1;
+    bool settled = true;
+    init_available(P, taken_by, L, i, [&](int dist, int c) {
+      if (dist < best) { best2 = best; best = dist; best_idx = c; }  // :692-701
+      else if (dist < best2) best2 = dist;
+      if (lower_unresolved(min_unres[c], stamp, i)) settled = false;
+    });
+    if (!settled) return true;
+    const bool ok = best <= 50 /* TH_LOW */ && (float)best < (float)best2 * P.nnratio;  // :704-706
+    state[i] = 1;
+    P.choice[i] = ok ? best_idx : -1;
+    if (ok) { taken_by[best_idx] = best; P.owner[best_idx] = i; }  // vMatchedDistance, vnMatches21 (:713-715)
+    return false;
+  };
+  resolve_rounds<LDS>(P.n1, P.n2, min_unres, s_unres, s_ulist, announce, decide);
 }
 
 // ------------------------------------------------------------------------------------------------
