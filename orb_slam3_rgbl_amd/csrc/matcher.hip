@@ -1048,43 +1048,49 @@ __global__ __launch_bounds__(kResolveBS) void k_proj_resolve(ProjDev P) {
   uint8_t* state = LDS ? s_state : P.state;
   __shared__ uint32_t s_ref[LDS ? kResolveLdsN1 : 1], s_list[LDS ? kResolveLdsList : 1];
   __shared__ uint16_t s_ulist[2][LDS ? kUCap : 1];
-  const ListView L = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
-  // every unresolved blocker announces itself on the features it may still take
-  auto announce = [&](int i, int stamp) {
-    if (state[i] != kStateObs) return;   // unresolved and a blocker
-    const uint32_t r = L.cref[i];
-    const int me = (stamp << 20) | i;
-    if (!(r & kRefOverflow)) {
-      const uint32_t* e = L.clist + ref_start(r);
-      for (int k = 0, n = ref_n(r); k < n; ++k) {
-        const int c = entry_feature(e[k]);
-        if (taken_by[c] >= i) atomicMin(&min_unres[c], me);
+  const ListView staged = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
+  // Instantiated twice, for the lists in LDS and for the lists where the candidate kernel left them: with ONE pointer chosen at run
+  // time the entries were read with flat loads
+  auto run = [&](const ListView L) {
+    // every unresolved blocker announces itself on the features it may still take
+    auto announce = [&](int i, int stamp) {
+      if (state[i] != kStateObs) return;   // unresolved and a blocker
+      const uint32_t r = L.cref[i];
+      const int me = (stamp << 20) | i;
+      if (!(r & kRefOverflow)) {
+        const uint32_t* e = L.clist + ref_start(r);
+        for (int k = 0, n = ref_n(r); k < n; ++k) {
+          const int c = entry_feature(e[k]);
+          if (taken_by[c] >= i) atomicMin(&min_unres[c], me);
+        }
+      } else {
+        const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
+        const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+        for_candidates(P, P.win[i], P.rng[i], [&](int c, int) {
+          if (taken_by[c] < i) return;
+          if (hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)) <= P.max_dist) atomicMin(&min_unres[c], me);
+        });
       }
-    } else {
-      const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
-      const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
-      for_candidates(P, P.win[i], P.rng[i], [&](int c, int) {
-        if (taken_by[c] < i) return;
-        if (hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)) <= P.max_dist) atomicMin(&min_unres[c], me);
-      });
-    }
+    };
+    // decide AND commit in one pass: a point whose best available feature no lower unresolved blocker can still take is final
+    // and occupies it at once.  What a concurrent work-item sees of that store does not matter: a HIGHER point that misses it
+    // picks the same feature, finds this point's announcement in front of it and waits a round; one that sees it takes its next
+    // choice, which is what the sequential loop would have given it; LOWER points never want a feature that becomes final here
+    // (their announcement would have held this point back).  Two blockers never become final on one feature in the same round.
+    auto decide = [&](int i, int stamp) {
+      const uint8_t st = state[i];
+      if (st & 0x7f) return false;
+      const int c = proj_best(P, taken_by, L.cref, L.clist, i);
+      if (c < 0) { state[i] = st | 1; P.choice[i] = -1; return false; }   // everything viable is taken: no match
+      if (lower_unresolved(min_unres[c], stamp, i)) return true;           // somebody in front of i can still take c
+      state[i] = st | 1; P.choice[i] = c;
+      if (st & kStateObs) taken_by[c] = i;
+      return false;
+    };
+    resolve_rounds<LDS>(P.n1, P.n2, min_unres, s_unres, s_ulist, announce, decide);
   };
-  // decide AND commit in one pass: a point whose best available feature no lower unresolved blocker can still take is final
-  // and occupies it at once.  What a concurrent work-item sees of that store does not matter: a HIGHER point that misses it
-  // picks the same feature, finds this point's announcement in front of it and waits a round; one that sees it takes its next
-  // choice, which is what the sequential loop would have given it; LOWER points never want a feature that becomes final here
-  // (their announcement would have held this point back).  Two blockers never become final on one feature in the same round.
-  auto decide = [&](int i, int stamp) {
-    const uint8_t st = state[i];
-    if (st & 0x7f) return false;
-    const int c = proj_best(P, taken_by, L.cref, L.clist, i);
-    if (c < 0) { state[i] = st | 1; P.choice[i] = -1; return false; }   // everything viable is taken: no match
-    if (lower_unresolved(min_unres[c], stamp, i)) return true;           // somebody in front of i can still take c
-    state[i] = st | 1; P.choice[i] = c;
-    if (st & kStateObs) taken_by[c] = i;
-    return false;
-  };
-  resolve_rounds<LDS>(P.n1, P.n2, min_unres, s_unres, s_ulist, announce, decide);
+  if (LDS && staged.clist != P.clist) run(ListView{s_ref, s_list});
+  else run(ListView{LDS ? s_ref : P.cref, P.clist});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1260,30 +1266,36 @@ __global__ __launch_bounds__(kResolveBS) void k_local_resolve(ProjDev P) {
   uint8_t* state = LDS ? s_state : P.state;
   __shared__ uint32_t s_ref[LDS ? kResolveLdsN1 : 1], s_list[LDS ? kResolveLdsList : 1];
   __shared__ uint16_t s_ulist[2][LDS ? kUCap : 1];
-  const ListView L = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
-  auto announce = [&](int i, int stamp) {
-    if (state[i] != kStateObs) return;   // unresolved and a blocker
-    const int me = (stamp << 20) | i;
-    local_available(P, taken_by, L, i, [&](int dist, int, int c) { if (dist <= 100) atomicMin(&min_unres[c], me); });
+  const ListView staged = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
+  // Instantiated twice, for the lists in LDS and for the lists where the candidate kernel left them: with ONE pointer chosen at run
+  // time the entries were read with flat loads
+  auto run = [&](const ListView L) {
+    auto announce = [&](int i, int stamp) {
+      if (state[i] != kStateObs) return;   // unresolved and a blocker
+      const int me = (stamp << 20) | i;
+      local_available(P, taken_by, L, i, [&](int dist, int, int c) { if (dist <= 100) atomicMin(&min_unres[c], me); });
+    };
+    // (a settled point's available candidates carry no announcement of a lower point, so no lower point can occupy one of them in
+    // this pass; a higher point's store leaves taken_by[c] >= i: still available to i)
+    auto decide = [&](int i, int stamp) {
+      const uint8_t st = state[i];
+      if (st & 0x7f) return false;
+      LocalScan sc;
+      bool settled = true;
+      local_available(P, taken_by, L, i, [&](int dist, int level, int c) {
+        sc.visit(dist, level, c);
+        if (lower_unresolved(min_unres[c], stamp, i)) settled = false;  // somebody in front of i may still take this feature
+      });
+      if (!settled) return true;
+      const int c = sc.accept(P.nnratio);
+      state[i] = st | 1; P.choice[i] = c;
+      if (c >= 0 && (st & kStateObs)) taken_by[c] = i;
+      return false;
+    };
+    resolve_rounds<LDS>(P.n1, P.n2, min_unres, s_unres, s_ulist, announce, decide);
   };
-  // (a settled point's available candidates carry no announcement of a lower point, so no lower point can occupy one of them in
-  // this pass; a higher point's store leaves taken_by[c] >= i: still available to i)
-  auto decide = [&](int i, int stamp) {
-    const uint8_t st = state[i];
-    if (st & 0x7f) return false;
-    LocalScan sc;
-    bool settled = true;
-    local_available(P, taken_by, L, i, [&](int dist, int level, int c) {
-      sc.visit(dist, level, c);
-      if (lower_unresolved(min_unres[c], stamp, i)) settled = false;  // somebody in front of i may still take this feature
-    });
-    if (!settled) return true;
-    const int c = sc.accept(P.nnratio);
-    state[i] = st | 1; P.choice[i] = c;
-    if (c >= 0 && (st & kStateObs)) taken_by[c] = i;
-    return false;
-  };
-  resolve_rounds<LDS>(P.n1, P.n2, min_unres, s_unres, s_ulist, announce, decide);
+  if (LDS && staged.clist != P.clist) run(ListView{s_ref, s_list});
+  else run(ListView{LDS ? s_ref : P.cref, P.clist});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1364,29 +1376,35 @@ __global__ __launch_bounds__(kResolveBS) void k_init_resolve(ProjDev P) {
   uint8_t* state = LDS ? s_state : P.state;
   const int tid = threadIdx.x;
   for (int c = tid; c < P.n2; c += kResolveBS) P.owner[c] = -1;
-  const ListView L = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
-  auto announce = [&](int i, int stamp) {
-    if (state[i] != 0) return;
-    const int me = (stamp << 20) | i;
-    init_available(P, taken_by, L, i, [&](int, int c) { atomicMin(&min_unres[c], me); });
+  const ListView staged = stage_lists<LDS>(P, s_taken, s_state, s_ref, s_list, &s_total);
+  // Instantiated twice, for the lists in LDS and for the lists where the candidate kernel left them: with ONE pointer chosen at run
+  // time the entries were read with flat loads
+  auto run = [&](const ListView L) {
+    auto announce = [&](int i, int stamp) {
+      if (state[i] != 0) return;
+      const int me = (stamp << 20) | i;
+      init_available(P, taken_by, L, i, [&](int, int c) { atomicMin(&min_unres[c], me); });
+    };
+    auto decide = [&](int i, int stamp) {
+      if (state[i] != 0) return false;
+      int best = INT_MAX, best2 = INT_MAX, best_idx = -1;
+      bool settled = true;
+      init_available(P, taken_by, L, i, [&](int dist, int c) {
+        if (dist < best) { best2 = best; best = dist; best_idx = c; }  // :692-701
+        else if (dist < best2) best2 = dist;
+        if (lower_unresolved(min_unres[c], stamp, i)) settled = false;
+      });
+      if (!settled) return true;
+      const bool ok = best <= 50 /* TH_LOW */ && (float)best < (float)best2 * P.nnratio;  // :704-706
+      state[i] = 1;
+      P.choice[i] = ok ? best_idx : -1;
+      if (ok) { taken_by[best_idx] = best; P.owner[best_idx] = i; }  // vMatchedDistance, vnMatches21 (:713-715)
+      return false;
+    };
+    resolve_rounds<LDS>(P.n1, P.n2, min_unres, s_unres, s_ulist, announce, decide);
   };
-  auto decide = [&](int i, int stamp) {
-    if (state[i] != 0) return false;
-    int best = INT_MAX, best2 = INT_MAX, best_idx = -1;
-    bool settled = true;
-    init_available(P, taken_by, L, i, [&](int dist, int c) {
-      if (dist < best) { best2 = best; best = dist; best_idx = c; }  // :692-701
-      else if (dist < best2) best2 = dist;
-      if (lower_unresolved(min_unres[c], stamp, i)) settled = false;
-    });
-    if (!settled) return true;
-    const bool ok = best <= 50 /* TH_LOW */ && (float)best < (float)best2 * P.nnratio;  // :704-706
-    state[i] = 1;
-    P.choice[i] = ok ? best_idx : -1;
-    if (ok) { taken_by[best_idx] = best; P.owner[best_idx] = i; }  // vMatchedDistance, vnMatches21 (:713-715)
-    return false;
-  };
-  resolve_rounds<LDS>(P.n1, P.n2, min_unres, s_unres, s_ulist, announce, decide);
+  if (LDS && staged.clist != P.clist) run(ListView{s_ref, s_list});
+  else run(ListView{LDS ? s_ref : P.cref, P.clist});
 }
 
 // ------------------------------------------------------------------------------------------------
