@@ -698,13 +698,13 @@ __device__ __forceinline__ void for_candidates(const ProjDev& P, const float4& w
 }
 // The same walk by a whole WAVE (round 6: a work-item per point ran ~100 dependent gathers one after the other - 200 us for a
 // frame's 2000 points): the window's cells go to the lanes in traversal order (cell t of the walk: ix = x0 + t / ny,
-// iy = y0 + t % ny), 64 at a time, a lane takes its cell's features.  pred(c) says whether the feature is a candidate, the
-// candidates' ranks in traversal order come from one DPP prefix sum per 64 cells, key_of(c, cell) is evaluated for the first
-// kProjCand of them and stored at its rank: the list a single work-item would have written.  Returns the number of
-// candidates (wave-uniform).  All 64 lanes must call it.
-template <class Pred, class KeyOf>
-__device__ __forceinline__ int wave_candidates(const ProjDev& P, const float4& w, const int4& r, unsigned long long* list, Pred&& pred,
-                                               KeyOf&& key_of) {
+// iy = y0 + t % ny), 64 at a time, a lane takes its cell's features.  key_of(c, cell) is the feature's key, or ~0 when it is no
+// candidate; the candidates' ranks in traversal order come from one DPP prefix sum per 64 cells and the first kProjCand keys are
+// stored at their ranks: the list a single work-item would have written.  A lane keeps the first two keys of its cell in
+// registers (a cell of the 64 x 48 grid holds 0.7 features of a KITTI frame on average), so the cell is walked once; a cell with
+// more candidates is walked again.  Returns the number of candidates (wave-uniform).  All 64 lanes must call it.
+template <class KeyOf>
+__device__ __forceinline__ int wave_candidates(const ProjDev& P, const float4& w, const int4& r, unsigned long long* list, KeyOf&& key_of) {
   const int lane = lane_id();
   const int x0 = r.x & 0xff, x1 = r.x >> 8, y0 = r.y & 0xff, y1 = r.y >> 8, ny = y1 - y0 + 1, ncells = (x1 - x0 + 1) * ny;
   const bool check_levels = (r.z > 0) || (r.w >= 0);
@@ -718,18 +718,30 @@ __device__ __forceinline__ int wave_candidates(const ProjDev& P, const float4& w
       kb = P.cell_start[cell]; ke = P.cell_start[cell + 1];
     }
     int cnt = 0;
+    unsigned long long k0 = ~0ull, k1 = ~0ull;
     for (uint32_t k = kb; k < ke; ++k) {
       const int c = P.cell_items[k];
-      cnt += (window_accepts(P, w, r, check_levels, c) && pred(c)) ? 1 : 0;
+      const unsigned long long key = window_accepts(P, w, r, check_levels, c) ? key_of(c, cell) : ~0ull;
+      if (key != ~0ull) {
+        if (cnt == 0) k0 = key; else if (cnt == 1) k1 = key;
+        ++cnt;
+      }
     }
     const int incl = wave_inclusive_scan(cnt);
     int pos = base + incl - cnt;
     base += __shfl(incl, 63);
-    if (cnt > 0 && pos < kProjCand)
-      for (uint32_t k = kb; k < ke && pos < kProjCand; ++k) {
-        const int c = P.cell_items[k];
-        if (window_accepts(P, w, r, check_levels, c) && pred(c)) list[pos++] = key_of(c, cell);
+    if (cnt > 0 && pos < kProjCand) {
+      if (cnt <= 2) {
+        list[pos] = k0;
+        if (cnt == 2 && pos + 1 < kProjCand) list[pos + 1] = k1;
+      } else {
+        for (uint32_t k = kb; k < ke && pos < kProjCand; ++k) {
+          const int c = P.cell_items[k];
+          const unsigned long long key = window_accepts(P, w, r, check_levels, c) ? key_of(c, cell) : ~0ull;
+          if (key != ~0ull) list[pos++] = key;
+        }
       }
+    }
   }
   return base;
 }
@@ -787,18 +799,18 @@ __global__ __launch_bounds__(kGridBS) void k_proj_grid(ProjDev P) {
     P.taken_by[c] = (P.blocked2 && P.blocked2[c]) ? -1 : INT_MAX;  // -1: held by a point from before the call
   }
   __syncthreads();
-  uint32_t carry = 0;
-  for (int c0 = 0; c0 < kGridCells; c0 += kGridBS) {
-    const int c = c0 + tid;
-    const uint32_t v = c < kGridCells ? s_fill[c] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block_exclusive_scan<uint32_t>(v, s_scan, &tot);
-    __syncthreads();
-    if (c < kGridCells) {
-      P.cell_start[c] = carry + ex; s_fill[c] = carry + ex;
-      if (LDS) s_start[c] = carry + ex;
+  // a work-item owns three consecutive cells: ONE workgroup prefix sum for the 3072 cells (three chunks of 1024 took three)
+  static_assert(kGridCells == 3 * kGridBS, "three cells per work-item");
+  uint32_t carry;
+  {
+    const uint32_t v0 = s_fill[3 * tid], v1 = s_fill[3 * tid + 1], v2 = s_fill[3 * tid + 2];
+    const uint32_t ex = block_exclusive_scan<uint32_t>(v0 + v1 + v2, s_scan, &carry);
+    const uint32_t st[3] = {ex, ex + v0, ex + v0 + v1};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      P.cell_start[3 * tid + q] = st[q]; s_fill[3 * tid + q] = st[q];
+      if (LDS) s_start[3 * tid + q] = st[q];
     }
-    carry += tot;
   }
   if (tid == 0) P.cell_start[kGridCells] = carry;
   __syncthreads();
@@ -885,8 +897,10 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P) {
         const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
         const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
         auto dist_of = [&](int c) { return hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)); };
-        const int total = wave_candidates(P, w, r, s_keys[wave_id()], [&](int c) { return dist_of(c) <= P.max_dist; },
-                                          [&](int c, int cell) { return proj_key(dist_of(c), cell, c); });
+        const int total = wave_candidates(P, w, r, s_keys[wave_id()], [&](int c, int cell) {
+          const int dist = dist_of(c);
+          return dist <= P.max_dist ? proj_key(dist, cell, c) : ~0ull;
+        });
         if (lane == 0) { P.win[i] = w; P.rng[i] = r; }
         ref = publish_candidates(P, i, s_keys[wave_id()], total, true,
                                  [](unsigned long long key) { return cand_entry((int)(key >> 32), 0, (int)(key & 0xffffu)); });
@@ -1220,7 +1234,7 @@ __global__ __launch_bounds__(256) void k_local_candidates(ProjDev P) {
         const int4 rg = make_int4(x0 | (x1 << 8), y0 | (y1 << 8), level - 1, level);
         const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
         const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
-        const int total = wave_candidates(P, w, rg, s_keys[wave_id()], [](int) { return true; }, [&](int c, int) {
+        const int total = wave_candidates(P, w, rg, s_keys[wave_id()], [&](int c, int) {
           const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
           return ((unsigned long long)dist << 32) | ((unsigned long long)P.oct2[c] << 16) | (unsigned)c;
         });
@@ -1349,8 +1363,10 @@ __global__ __launch_bounds__(256) void k_init_candidates(ProjDev P) {   // one w
       const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
       const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
       auto dist_of = [&](int c) { return hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)); };
-      const int total = wave_candidates(P, w, rg, s_keys[wave_id()], [&](int c) { return dist_of(c) <= P.max_dist; },
-                                        [&](int c, int) { return ((unsigned long long)dist_of(c) << 32) | (unsigned)c; });
+      const int total = wave_candidates(P, w, rg, s_keys[wave_id()], [&](int c, int) {
+        const int dist = dist_of(c);
+        return dist <= P.max_dist ? (((unsigned long long)dist << 32) | (unsigned)c) : ~0ull;
+      });
       if (lane == 0) { P.win[i] = w; P.rng[i] = rg; }
       ref = publish_candidates(P, i, s_keys[wave_id()], total, false,
                                [](unsigned long long key) { return cand_entry((int)(key >> 32), 0, (int)(key & 0xffffu)); });
