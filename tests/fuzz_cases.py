@@ -54,7 +54,7 @@ def depth_case(lib, rng):
     ku, kv = int(rng.choice([3, 5, 7, 9])), int(rng.choice([3, 5, 7, 9]))
     method = int(rng.choice([F.UPS_INVERSE_DILATION] * 3 + [F.UPS_AVERAGE_FILTERING, F.UPS_NEAREST_NEIGHBOR_PIXEL]))
     n = pc.check_depth(lib, method, w=w, h=h, seed=int(rng.integers(0, 1000)), n_az=int(rng.integers(300, 2000)), kernel=(shape, ku, kv),
-                       n_kp=int(rng.integers(1, 2500)))
+                       n_kp=int(rng.integers(1, 2500)), min_hits=0)
     return "depth %4dx%-4d method %d kernel %d %dx%d -> %d keypoints with depth" % (w, h, method, shape, ku, kv, n)
 
 

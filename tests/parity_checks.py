@@ -146,7 +146,7 @@ def kitti_projection(lib):
 
 
 def check_depth(lib, method, w=synth.KITTI_W, h=synth.KITTI_H, seed=0, n_az=1900, kernel=(F.KERNEL_DIAMOND, 5, 7),
-                n_kp=1500):
+                n_kp=1500, min_hits=101):
     proj = kitti_projection(lib)
     if w != synth.KITTI_W:  # rescale the principal point so that the scan still hits the image
         K = synth.KITTI_K.copy()
@@ -168,7 +168,7 @@ def check_depth(lib, method, w=synth.KITTI_W, h=synth.KITTI_H, seed=0, n_az=1900
     d, ur, raw, proc = O.depth(P, cloud, w, h, kp_xy, kpun[:, 0])
     # projection + ordered scatter: bit-exact (stated tolerance in BASELINE.md is 1e-6 rel; we demand 0)
     assert np.array_equal(bits(dm.RawDepthMap), bits(raw)), "RawDepthMap"
-    assert (raw > 0).sum() > 100
+    assert (raw > 0).sum() >= min_hits   # the case must be worth its name (random shapes: a thin image may see a handful of points)
     if dm.ProcessedDepthMap is not None:
         a, b = dm.ProcessedDepthMap, proc
         assert np.array_equal(np.isnan(a), np.isnan(b))
