@@ -681,6 +681,17 @@ __device__ __forceinline__ bool window_accepts(const ProjDev& P, const float4& w
   if (ur > 0 && fabsf(w.w - ur) > w.z) return false;
   return true;
 }
+// the same tests on values the caller has loaded (wave_candidates requests a cell's features four at a time)
+__device__ __forceinline__ bool window_accepts_v(const float4& w, const int4& r, bool check_levels, int o, float x, float y, float ur) {
+  if (check_levels) {
+    if (o < r.z) return false;
+    if (r.w >= 0 && o > r.w) return false;
+  }
+  const float dx = x - w.x, dy = y - w.y;
+  if (!(fabsf(dx) < w.z && fabsf(dy) < w.z)) return false;
+  if (ur > 0 && fabsf(w.w - ur) > w.z) return false;
+  return true;
+}
 // visits the candidates of a point that pass those tests, in the reference's traversal order (one work-item walks the window)
 template <class F>
 __device__ __forceinline__ void for_candidates(const ProjDev& P, const float4& w, const int4& r, F&& f) {
@@ -719,13 +730,32 @@ __device__ __forceinline__ int wave_candidates(const ProjDev& P, const float4& w
     }
     int cnt = 0;
     unsigned long long k0 = ~0ull, k1 = ~0ull;
-    for (uint32_t k = kb; k < ke; ++k) {
-      const int c = P.cell_items[k];
-      const unsigned long long key = window_accepts(P, w, r, check_levels, c) ? key_of(c, cell) : ~0ull;
-      if (key != ~0ull) {
-        if (cnt == 0) k0 = key; else if (cnt == 1) k1 = key;
-        ++cnt;
+    // four features of the cell at a time: their indices, then their positions / octaves / stereo coordinates, then the keys (the
+    // descriptors) are requested back to back - device clock stamps: the walk was 12 000 of a wave's 17 000 cycles, three dependent
+    // global reads per feature one feature after the other, and the lane with the fullest cell sets the wave's time
+    for (uint32_t q0 = kb; q0 < ke; q0 += 4) {
+      const int m = (int)(ke - q0);
+      const int c0 = P.cell_items[q0], c1 = m > 1 ? (int)P.cell_items[q0 + 1] : c0, c2 = m > 2 ? (int)P.cell_items[q0 + 2] : c0,
+                c3 = m > 3 ? (int)P.cell_items[q0 + 3] : c0;
+      const int cs[4] = {c0, c1, c2, c3};
+      float fx[4], fy[4], fu[4];
+      int fo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        fx[j] = P.xy2[2 * cs[j]]; fy[j] = P.xy2[2 * cs[j] + 1];
+        fo[j] = check_levels ? P.oct2[cs[j]] : 0;
+        fu[j] = P.ur2 ? P.ur2[cs[j]] : -1.f;
       }
+      unsigned long long keys[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        keys[j] = (j < m && window_accepts_v(w, r, check_levels, fo[j], fx[j], fy[j], fu[j])) ? key_of(cs[j], cell) : ~0ull;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (keys[j] != ~0ull) {
+          if (cnt == 0) k0 = keys[j]; else if (cnt == 1) k1 = keys[j];
+          ++cnt;
+        }
     }
     const int incl = wave_inclusive_scan(cnt);
     int pos = base + incl - cnt;
