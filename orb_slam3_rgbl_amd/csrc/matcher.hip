@@ -889,12 +889,18 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P) {
   const int lane = lane_id();
   uint8_t st = 1;
   uint32_t ref = 0;
-  if (P.valid1[i]) {
+  // everything the point needs is requested up front (it was four dependent global reads: valid -> position -> octave -> descriptor)
+  const uint8_t valid = P.valid1[i];
+  const float wx = P.wpos1[3 * i], wy = P.wpos1[3 * i + 1], wz = P.wpos1[3 * i + 2];
+  const int oct_i = P.oct1[i];
+  const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
+  const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+  if (valid) {
     float x, y, z;
     if (P.sim3_mode) {
-      x = P.wpos1[3 * i]; y = P.wpos1[3 * i + 1]; z = P.wpos1[3 * i + 2];
+      x = wx; y = wy; z = wz;
     } else {
-      quat_rotate(P.q, P.wpos1[3 * i], P.wpos1[3 * i + 1], P.wpos1[3 * i + 2], &x, &y, &z);
+      quat_rotate(P.q, wx, wy, wz, &x, &y, &z);
       x += P.t[0]; y += P.t[1]; z += P.t[2];
     }
     const float invzc = (float)(1.0 / (double)z);
@@ -910,7 +916,7 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P) {
                                      : (!(P.skip_behind && invzc < 0) && u == u && v == v && !(u < P.grid[0] || u > P.grid[2]) &&
                                         !(v < P.grid[1] || v > P.grid[3]));
     if (in_view) {
-      const int oct = P.oct1[i];
+      const int oct = oct_i;
       const float radius = P.th * P.scale[oct];
       int min_level, max_level;
       if (P.sim3_mode) { min_level = oct - 1; max_level = oct; }
@@ -924,8 +930,6 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P) {
       if (x0 < kGridCols && x1 >= 0 && y0 < kGridRows && y1 >= 0) {
         const float4 w = make_float4(u, v, radius, u - P.mbf * invzc);
         const int4 r = make_int4(x0 | (x1 << 8), y0 | (y1 << 8), min_level, max_level);
-        const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
-        const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
         auto dist_of = [&](int c) { return hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32)); };
         const int total = wave_candidates(P, w, r, s_keys[wave_id()], [&](int c, int cell) {
           const int dist = dist_of(c);
@@ -1248,11 +1252,17 @@ __global__ __launch_bounds__(256) void k_local_candidates(ProjDev P) {
   const int lane = lane_id();
   uint8_t st = 1;
   uint32_t ref = 0;
-  if (P.valid1[i]) {
-    const int level = P.level1[i];
-    float r = (double)P.viewcos1[i] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos: the literal is a double in the reference
+  // (requested up front, as in k_proj_candidates)
+  const uint8_t valid = P.valid1[i];
+  const int level_i = P.level1[i];
+  const float viewcos = P.viewcos1[i], px = P.proj1[3 * i], py = P.proj1[3 * i + 1], pxr = P.proj1[3 * i + 2];
+  const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
+  const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
+  if (valid) {
+    const int level = level_i;
+    float r = (double)viewcos > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos: the literal is a double in the reference
     if (P.th != 1.0f) r *= P.th;
-    const float x = P.proj1[3 * i], y = P.proj1[3 * i + 1];
+    const float x = px, y = py;
     const float radius = r * P.scale[level];
     if (x == x && y == y) {
       const int x0 = imax(0, (int)floorf((x - P.grid[0] - radius) * P.grid[4]));
@@ -1260,10 +1270,8 @@ __global__ __launch_bounds__(256) void k_local_candidates(ProjDev P) {
       const int y0 = imax(0, (int)floorf((y - P.grid[1] - radius) * P.grid[5]));
       const int y1 = imin(kGridRows - 1, (int)ceilf((y - P.grid[1] + radius) * P.grid[5]));
       if (x0 < kGridCols && x1 >= 0 && y0 < kGridRows && y1 >= 0) {
-        const float4 w = make_float4(x, y, radius, P.proj1[3 * i + 2]);
+        const float4 w = make_float4(x, y, radius, pxr);
         const int4 rg = make_int4(x0 | (x1 << 8), y0 | (y1 << 8), level - 1, level);
-        const unsigned long long* D = reinterpret_cast<const unsigned long long*>(P.mpdesc1 + (size_t)i * 32);
-        const unsigned long long d[4] = {D[0], D[1], D[2], D[3]};
         const int total = wave_candidates(P, w, rg, s_keys[wave_id()], [&](int c, int) {
           const int dist = hamming256(d, reinterpret_cast<const unsigned long long*>(P.desc2 + (size_t)c * 32));
           return ((unsigned long long)dist << 32) | ((unsigned long long)P.oct2[c] << 16) | (unsigned)c;
