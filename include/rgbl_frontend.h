@@ -517,7 +517,7 @@ int rgbl_search_by_bow_keyframes(rgbl_matcher* h, const rgbl_keyframe_view* kf1,
  * Includes Frame::GetFeaturesInArea / AssignFeaturesToGrid / PosInGrid (src/Frame.cc:747-825, 475-506).  SURVEY.md 8(f) row f2.
  * CurrentFrame.mvpMapPoints is expected to be all NULL on entry, as Tracking.cc:2913 leaves it. */
 typedef struct {
-  int n1;                      /* LastFrame.N */
+  int n1;                      /* LastFrame.N (< 2^20) */
   const uint8_t* valid1;       /* LastFrame.mvpMapPoints[i] != NULL && !LastFrame.mvbOutlier[i] */
   const float* world_pos1;     /* pMP->GetWorldPos(), 3 floats per feature */
   const uint8_t* mp_desc1;     /* pMP->GetDescriptor(), 32 bytes per feature */
@@ -557,7 +557,7 @@ int rgbl_search_by_projection(rgbl_matcher* h, const rgbl_projection_input* in, 
  * valid1 and MapPoint::PredictScale (src/MapPoint.cc:531-546, a logf and a ceil); projection, window search, the greedy
  * assignment in key-frame index order and the rotation histogram are done here. */
 typedef struct {
-  int n1;                      /* pKF->GetMapPointMatches().size() */
+  int n1;                      /* pKF->GetMapPointMatches().size() (< 2^20) */
   const uint8_t* valid1;       /* pMP != NULL && !pMP->isBad() && !sAlreadyFound.count(pMP) &&
                                   minDistance <= |x3Dw - Ow| <= maxDistance (GetMin/MaxDistanceInvariance) */
   const float* world_pos1;     /* pMP->GetWorldPos(), 3 floats per point */
@@ -663,7 +663,7 @@ typedef struct {
 int rgbl_fuse_search(rgbl_matcher* h, const rgbl_fuse_input* in, int32_t* best_idx, int32_t* best_dist);
 
 typedef struct {
-  int n1;                      /* vpMapPoints.size() */
+  int n1;                      /* vpMapPoints.size() (< 2^20) */
   const uint8_t* valid1;       /* pMP->mbTrackInView && !(bFarPoints && pMP->mTrackDepth > thFarPoints) && !pMP->isBad() */
   const float* proj1;          /* pMP->mTrackProjX, mTrackProjY, mTrackProjXR: 3 floats per point */
   const int32_t* level1;       /* pMP->mnTrackScaleLevel */
@@ -693,7 +693,7 @@ int rgbl_search_local_points(rgbl_matcher* h, const rgbl_local_points_input* in,
  * Level-0 features of F1 look for their best / second-best F2 feature of level 0 inside a window around vbPrevMatched; a
  * feature takes a candidate over from an earlier one when it is strictly closer (vMatchedDistance), rotation histogram. */
 typedef struct {
-  int n1;                     /* F1.mvKeysUn.size() */
+  int n1;                     /* F1.mvKeysUn.size() (< 2^20) */
   const int32_t* kp1_octave;  /* F1.mvKeysUn[i].octave (>= 0) */
   const float* kp1_angle;     /* F1.mvKeysUn[i].angle */
   const uint8_t* desc1;       /* F1.mDescriptors */
