@@ -123,7 +123,8 @@ def test_extractor_fast_kernel_waves_per_cell(emu_lib, bs):
     # one wave per detection cell (what batches of 8 and more frames take) and two (single frames), each forced on both
     os.environ["RGBL_FAST_BS"] = bs
     try:
-        pc.check_extractor(emu_lib, 1241, 376, 2000, frames=(0,), seq=5, stages=True)
+        w, h, nf = (1241, 376, 2000) if bs == "64" else (700, 300, 1200)   # (the full KITTI frame once per group: CPU-suite time)
+        pc.check_extractor(emu_lib, w, h, nf, frames=(0,), seq=5, stages=True)
         pc.check_extractor_batch(emu_lib, 400, 300, 500, 8)
         pc.check_extractor_low_contrast(emu_lib)
         pc.check_extractor_dense_corners(emu_lib)
@@ -139,7 +140,8 @@ def test_extractor_quadtree_round_by_round(emu_lib):
     for env in ({"RGBL_OCTREE_HIST": "0"}, {"RGBL_OCTREE_LDSKEYS": "0"}, {"RGBL_OCTREE_LDSKEYS": "0", "RGBL_OCTREE_NCAP": "2048"}):
         os.environ.update(env)
         try:
-            pc.check_extractor(emu_lib, 1241, 376, 2000, frames=(0,), seq=5, stages=True)
+            w, h, nf = (1241, 376, 2000) if len(env) == 1 and "RGBL_OCTREE_HIST" in env else (700, 300, 1200)
+            pc.check_extractor(emu_lib, w, h, nf, frames=(0,), seq=5, stages=True)
             pc.check_extractor(emu_lib, 333, 217, 500, frames=(0,), nlevels=5, seq=4, stages=True)
             pc.check_extractor_batch(emu_lib, 400, 300, 500, 8)
             pc.check_extractor_empty_root(emu_lib)
@@ -156,7 +158,8 @@ def test_extractor_cell_compaction_kernel(emu_lib, compact):
     # per 256 cells); RGBL_COMPACT=1 forces it for single frames too, =0 keeps the per-cell reservation inside k_fast_cells
     os.environ["RGBL_COMPACT"] = compact
     try:
-        pc.check_extractor(emu_lib, 1241, 376, 2000, frames=(0,), seq=5, stages=True)
+        w, h, nf = (1241, 376, 2000) if compact == "1" else (700, 300, 1200)
+        pc.check_extractor(emu_lib, w, h, nf, frames=(0,), seq=5, stages=True)
         pc.check_extractor_batch(emu_lib, 400, 300, 500, 8)
         # 106 cell columns of 36 px (the last two of every row are skipped, ORBextractor.cc:810-822), 424 cells on level 0: two groups
         pc.check_extractor(emu_lib, 3840, 280, 1500, frames=(0,), nlevels=2, seq=12, stages=True)
