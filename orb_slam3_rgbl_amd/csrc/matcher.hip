@@ -1615,119 +1615,18 @@ __device__ __forceinline__ void bow_node(const BowDev& T, uint8_t* s_taken, unsi
   }
 }
 
-// The node resolved in ROUNDS instead of one key-frame feature after the other (the serial chain of the largest node was the
-// kernel's time: 74 dependent steps, 32 us for a KITTI frame pair).  The reference's loop takes the key-frame features of the node
-// in bucket order; feature k looks at the frame features no EARLIER key-frame feature has taken, keeps the first minimum and the
-// second smallest distance, and takes the first if it is <= max_best and beats the ratio.  Here: all distances of the node once, in
-// parallel, into LDS; then rounds in which every unresolved k finds its two smallest keys among the features no lower k holds,
-// announces itself on every feature it could still TAKE (distance <= max_best) - and is final once no lower unresolved k is
-// announced on either of its two: whatever those lower ones take later lies outside its two smallest and cannot change its decision,
-// and a feature a HIGHER k has taken already stays visible to it, as in the serial order (that higher k was final only because k
-// cannot take the feature).  The lowest unresolved k is final in every round; a KITTI pair takes two or three.
-// Nodes with up to kBowParK1 valid key-frame features, kBowParK2 frame features and kBowParD distances; larger ones: bow_node.
-constexpr int kBowParK1 = 256, kBowParK2 = 256, kBowParD = 16384;
-__device__ __forceinline__ bool bow_node_rounds(const BowDev& T, unsigned long long (*s_q)[4], uint16_t* s_D, int* s_k1, int* s_min, int16_t* s_holder,
-                                                int* s_cnt, uint32_t* s_scan, int b1, int e1, int b2, int n2) {
-  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  const int n1 = e1 - b1;
-  if (n1 > kBowParK1 || n2 > kBowParK2 || n2 == 0) return false;   // uniform
-  // the node's valid key-frame features, in bucket order
-  int idx1 = -1;
-  if (tid < n1) { idx1 = T.feat1[b1 + tid]; if (!T.valid1[idx1]) idx1 = -1; }
-  uint32_t n1v;
-  const uint32_t at = block_exclusive_scan<uint32_t>(idx1 >= 0 ? 1u : 0u, s_scan, &n1v);
-  const int pitch = n2 | 1;   // odd: the work-items of a wave walk different rows of s_D side by side
-  if ((int)n1v * pitch > kBowParD) return false;   // uniform
-  if (idx1 >= 0) {
-    s_k1[at] = idx1;
-    const unsigned long long* D1 = reinterpret_cast<const unsigned long long*>(T.desc1 + (size_t)idx1 * 32);
-    s_q[at][0] = D1[0]; s_q[at][1] = D1[1]; s_q[at][2] = D1[2]; s_q[at][3] = D1[3];
-  }
-  // frame side: position j = lane + 64 r in the lane's registers, as in bow_node
-  constexpr int kTrips = kBowParK2 / 64;
-  unsigned long long t0[kTrips][4];
-  int my_idx2 = -1;   // thread tid < n2 also keeps the index of position tid
-#pragma unroll
-  for (int r = 0; r < kTrips; ++r) {
-    t0[r][0] = t0[r][1] = t0[r][2] = t0[r][3] = 0ull;
-    if (lane + 64 * r < n2) {
-      const int i2 = T.feat2[b2 + lane + 64 * r];
-      const unsigned long long* D2 = reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)i2 * 32);
-      t0[r][0] = D2[0]; t0[r][1] = D2[1]; t0[r][2] = D2[2]; t0[r][3] = D2[3];
-    }
-  }
-  if (tid < n2) {
-    my_idx2 = T.feat2[b2 + tid];
-    s_holder[tid] = (T.valid2 && !T.valid2[my_idx2]) ? (int16_t)-1 : (int16_t)0x7fff;   // -1: not a candidate for anybody
-  }
-  __syncthreads();
-  // all distances: wave w takes the rows w, w + 4, ..
-  for (int k = wave; k < (int)n1v; k += 4) {
-    const unsigned long long q[4] = {s_q[k][0], s_q[k][1], s_q[k][2], s_q[k][3]};
-#pragma unroll
-    for (int r = 0; r < kTrips; ++r) {
-      if (64 * r >= n2) break;   // uniform
-      if (lane + 64 * r < n2) s_D[k * pitch + lane + 64 * r] = (uint16_t)hamming256(q, t0[r]);
-    }
-  }
-  const int k = tid;   // one work-item per valid key-frame feature from here on
-  bool unresolved = k < (int)n1v;
-  for (int round = 0; round <= (int)n1v; ++round) {
-    if (tid < n2) s_min[tid] = INT_MAX;
-    if (tid == 0) *s_cnt = 0;
-    __syncthreads();
-    uint32_t best = 0xffffffffu, second = 0xffffffffu;   // dist << 16 | position
-    if (unresolved) {
-      const uint16_t* row = s_D + k * pitch;
-      for (int j = 0; j < n2; ++j) {
-        if ((int)s_holder[j] < k) continue;   // held by an earlier key-frame feature (or masked out)
-        const uint32_t d = row[j];
-        const uint32_t key = (d << 16) | (uint32_t)j;
-        const uint32_t lo = key < best ? key : best, hi = key < best ? best : key;
-        second = hi < second ? hi : second;
-        best = lo;
-        if ((int)d <= T.max_best) atomicMin(&s_min[j], k);
-      }
-    }
-    __syncthreads();
-    if (unresolved) {
-      const bool wait = (best != 0xffffffffu && s_min[best & 0xffffu] < k) || (second != 0xffffffffu && s_min[second & 0xffffu] < k);
-      if (wait) atomicAdd(s_cnt, 1);
-      else {
-        unresolved = false;
-        const int best_dist = (int)(best >> 16), other = second == 0xffffffffu ? 256 : (int)(second >> 16);
-        if (best != 0xffffffffu && best_dist <= T.max_best && (float)best_dist < T.nnratio * (float)other) {
-          const int pos = (int)(best & 0xffffu), i1 = s_k1[k], i2 = T.feat2[b2 + pos];
-          s_holder[pos] = (int16_t)k;
-          T.match1[i1] = i2;
-          T.match2[i2] = i1;
-        }
-      }
-    }
-    __syncthreads();
-    if (*s_cnt == 0) break;
-    __syncthreads();
-  }
-  return true;
-}
-
-// grid = shared nodes, block = 256.  bow_node_rounds for the nodes it covers; else the first wave alone walks the node serially
-// (bow_node: the key-frame features one after the other, descriptors staged in LDS 64 at a time, the lane's frame features in
-// registers).
-__global__ __launch_bounds__(256) void k_search_by_bow(BowDev T) {
+// grid = shared nodes, block = 64.  The node's key-frame features are taken one after the other (a frame feature taken by an
+// earlier one is gone for the later ones: ORBmatcher.cc:296-299), so what sits inside that serial loop decides the kernel's
+// time.  Round 6: the key-frame features' descriptors are staged in LDS 64 at a time and a lane keeps the descriptor of ITS
+// frame feature (bucket position = lane, every bucket of a KITTI frame's ~100 nodes fits) in registers - the loop body is LDS
+// reads and register work instead of three dependent global loads per key-frame feature (100 -> ~15 us for a frame pair).
+__global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
   __shared__ uint8_t s_taken[kBowBucket];
-  __shared__ unsigned long long s_q[kBowParK1][4];
-  __shared__ int s_idx1[kBowParK1];
-  __shared__ uint16_t s_D[kBowParD];
-  __shared__ int s_min[kBowParK2], s_cnt;
-  __shared__ int16_t s_holder[kBowParK2];
-  __shared__ uint32_t s_scan[8];
-  const int np = blockIdx.x;
+  __shared__ unsigned long long s_q[64][4];
+  __shared__ int s_idx1[64];
+  const int np = blockIdx.x, lane = threadIdx.x;
   const int a = T.pair_n1[np], b = T.pair_n2[np];
   const int b1 = T.off1[a], e1 = T.off1[a + 1], b2 = T.off2[b], n2 = T.off2[b + 1] - b2;
-  if (bow_node_rounds(T, s_q, s_D, s_idx1, s_min, s_holder, &s_cnt, s_scan, b1, e1, b2, n2)) return;
-  if (wave_id() != 0) return;
-  const int lane = lane_id();
   if (n2 <= 64) bow_node<1>(T, s_taken, s_q, s_idx1, lane, b1, e1, b2, n2);
   else if (n2 <= 128) bow_node<2>(T, s_taken, s_q, s_idx1, lane, b1, e1, b2, n2);
   else if (n2 <= 192) bow_node<3>(T, s_taken, s_q, s_idx1, lane, b1, e1, b2, n2);
@@ -3197,7 +3096,7 @@ static int bow_core(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_ke
   T.nnratio = nnratio;
   T.max_best = max_best;
   m->timer.begin("k_search_by_bow", s);
-  hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(256), 0, s, T);
+  hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(64), 0, s, T);
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
   RGBL_TRY(hc.fetch());
