@@ -358,6 +358,23 @@ def mapping_leg(lib):
     res["search_by_bow_keyframes"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", n1=2000, n2=2000, matches=int(nm),
                                             ref_lines="ORBmatcher.cc:765-905, LoopClosing.cc")
     mt.close()
+    # -- SearchByBoW(pKF, F) on a two-camera frame (F.Nleft != -1: the fisheye rig's TrackReferenceKeyFrame / Relocalization)
+    kf, frm, n_left = cases.make_bow_rig_case(2000, 61, 100)
+    kf = dict(kf, has_mp=(np.random.default_rng(61).random(2000) < 0.7).astype(np.uint8))
+    mt = F.ORBmatcher(0.7, True, lib=lib)
+    call = mt.prepare_SearchByBoW(kf, frm, n_left)
+    m2, nm = call()
+    om, onm = O.search_by_bow(kf, frm, 0.7, True, n_left=n_left)
+    ok = nm == onm and np.array_equal(m2, om)
+    ref_stat = None
+    if ref is not None:
+        (rm, rnm, _), ref_stat = _ref_stats(lambda: R.search_by_bow_rig(ref, kf, -1, frm, n_left, 0.7, True))
+        ok = ok and rnm == nm and np.array_equal(rm, m2)
+    gpu = _time_call(call)
+    kern, ktot = _kernel_us(mt, call)
+    res["search_by_bow_two_camera_frame"] = _entry(gpu, kern, ktot, ref_stat, "bit-exact" if ok else "MISMATCH", n1=2000, n2=int(len(frm["desc"])), n_left=int(n_left),
+                                                   matches=int(nm), right_camera_matches=int((m2[n_left:] >= 0).sum()), ref_lines="ORBmatcher.cc:298-326, 357-386")
+    mt.close()
     # -- SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, 100): Tracking::MonocularInitialization (5 x nFeatures)
     case = cases.make_initialization_case(5000, 61)
     mt = F.ORBmatcher(0.9, True, lib=lib)

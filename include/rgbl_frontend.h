@@ -502,6 +502,15 @@ int rgbl_search_triangulation(rgbl_matcher* h, const rgbl_keyframe_view* kf1,
  * in vpMapPointMatches[i], or -1.  Host pointers, synchronous. */
 int rgbl_search_by_bow(rgbl_matcher* h, const rgbl_keyframe_view* kf, const rgbl_keyframe_view* frame, float nnratio,
                        int check_orientation, int32_t* match_f, int* out_nmatches);
+/* The same for a two-camera frame (F.Nleft != -1: the fisheye rig; src/ORBmatcher.cc:298-326 and 357-386).  frame_n_left =
+ * F.Nleft: the frame's features [0, frame_n_left) come from the left camera, the rest from the right one.  A key-frame feature
+ * keeps a best / second best among the node's left features and a best among its right ones; if the left best is <= TH_LOW the
+ * left one is taken under the ratio test and the right one whenever its own distance is <= TH_LOW (`|| true`, :359: no ratio
+ * test) - so one key-frame feature can appear twice in match_f.  kp_angle of both views: the angle of the key point the
+ * reference picks for that index (mvKeysUn / mvKeys / mvKeysRight, :335-343, :362-373).  frame_n_left = -1 is
+ * rgbl_search_by_bow. */
+int rgbl_search_by_bow_rig(rgbl_matcher* h, const rgbl_keyframe_view* kf, const rgbl_keyframe_view* frame, int frame_n_left,
+                           float nnratio, int check_orientation, int32_t* match_f, int* out_nmatches);
 
 /* int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (include/ORBmatcher.h:58,
  * src/ORBmatcher.cc:765-905; callers LoopClosing::DetectCommonRegionsFromBoW / DetectAndReffineSim3FromLastKF and

@@ -887,6 +887,63 @@ extern "C" int orc_search_by_bow(const orc_tri_input* in, float nnratio, int che
   return nmatches;
 }
 
+// ---- ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) for a two-camera frame (F.Nleft != -1), ORBmatcher.cc:298-326, 357-386 ----
+// n_left = F.Nleft.  kp1_angle / kp2_angle: the angle of the key point the reference reads for that index (:335-343, :362-373).
+extern "C" int orc_search_by_bow_rig(const orc_tri_input* in, int n_left, float nnratio, int check_orientation, int* match2) {
+  for (int i = 0; i < in->n2; ++i) match2[i] = -1;
+  std::vector<int> rot_hist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  int nmatches = 0;
+  int a = 0, b = 0;
+  while (a < in->nnodes1 && b < in->nnodes2) {
+    if (in->node_id1[a] < in->node_id2[b]) { ++a; continue; }
+    if (in->node_id1[a] > in->node_id2[b]) { ++b; continue; }
+    for (int p = in->node_off1[a]; p < in->node_off1[a + 1]; ++p) {
+      const int realIdxKF = in->node_feat1[p];
+      if (!in->has_mp1[realIdxKF]) continue;
+      const uint8_t* dKF = in->desc1 + 32 * (size_t)realIdxKF;
+      int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+      int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+      for (int q = in->node_off2[b]; q < in->node_off2[b + 1]; ++q) {
+        const int realIdxF = in->node_feat2[q];
+        if (match2[realIdxF] >= 0) continue;
+        const int dist = hamming256(dKF, in->desc2 + 32 * (size_t)realIdxF);
+        if (realIdxF < n_left && dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+        else if (realIdxF < n_left && dist < bestDist2) bestDist2 = dist;
+        if (realIdxF >= n_left && dist < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = dist; bestIdxFR = realIdxF; }
+        else if (realIdxF >= n_left && dist < bestDist2R) bestDist2R = dist;
+      }
+      if (bestDist1 <= TH_LOW) {
+        const int taken[2] = {(float)bestDist1 < nnratio * (float)bestDist2 ? bestIdxF : -1, bestDist1R <= TH_LOW ? bestIdxFR : -1};
+        for (int idx : taken) {
+          if (idx < 0) continue;
+          match2[idx] = realIdxKF;
+          if (check_orientation) {
+            float rot = in->kp1_angle[realIdxKF] - in->kp2_angle[idx];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rot_hist[bin].push_back(idx);
+          }
+          ++nmatches;
+        }
+      }
+    }
+    ++a;
+    ++b;
+  }
+  (void)0;
+  if (check_orientation) {
+    int i1 = -1, i2 = -1, i3 = -1;
+    three_maxima(rot_hist, HISTO_LENGTH, i1, i2, i3);
+    for (int i = 0; i < HISTO_LENGTH; ++i) {
+      if (i == i1 || i == i2 || i == i3) continue;
+      for (int idx : rot_hist[i]) { match2[idx] = -1; --nmatches; }
+    }
+  }
+  return nmatches;
+}
+
 // ---- ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), ORBmatcher.cc:648-763 ----
 // with Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) (src/Frame.cc:747-813) over AssignFeaturesToGrid's cells
 extern "C" int orc_search_for_initialization(const orc_initialization_input* in, float* prev_matched, int* matches12) {

@@ -346,6 +346,8 @@ def lib():
         L.orc_bow_descend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_search_by_bow.restype = C.c_int
         L.orc_search_by_bow.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+        L.orc_search_by_bow_rig.restype = C.c_int
+        L.orc_search_by_bow_rig.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orc_search_for_initialization.restype = C.c_int
         L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_search_local_points.restype = C.c_int
@@ -629,9 +631,10 @@ def fundamental(K1, K2, R12, t12):
     return F
 
 
-def search_by_bow(kf, frame, nnratio=0.7, check_orientation=True, keyframes=False):
+def search_by_bow(kf, frame, nnratio=0.7, check_orientation=True, keyframes=False, n_left=-1):
     """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches).  kf / frame: dicts as for search_triangulation (kf["has_mp"] = map
-    point present and not bad).  Returns (match per frame feature: key-frame feature index or -1, nmatches)."""
+    point present and not bad).  n_left = F.Nleft (-1: a single camera; else the two-camera branches, ORBmatcher.cc:298-386).
+    Returns (match per frame feature: key-frame feature index or -1, nmatches)."""
     keep = []
 
     def arr(v, dt):
@@ -656,6 +659,9 @@ def search_by_bow(kf, frame, nnratio=0.7, check_orientation=True, keyframes=Fals
         n = lib().orc_search_by_bow_kf(C.byref(T), C.c_float(nnratio), int(check_orientation), _p(m))
         return m, n
     m = np.zeros(T.n2, np.int32)
+    if n_left >= 0:
+        n = lib().orc_search_by_bow_rig(C.byref(T), int(n_left), C.c_float(nnratio), int(check_orientation), _p(m))
+        return m, n
     n = lib().orc_search_by_bow(C.byref(T), C.c_float(nnratio), int(check_orientation), _p(m))
     return m, n
 

@@ -376,6 +376,55 @@ extern "C" int ref_search_by_bow(const KfArrays* kfa, const KfArrays* fra, float
   return nm;
 }
 
+// The same on a two-camera frame (F.Nleft = n_left, F.mpCamera2 set: ORBmatcher.cc:298-326, 357-386).  The angles of the flat
+// arrays go where the reference reads them: F.mvKeys[i] for i < Nleft, F.mvKeysRight[i - Nleft] beyond; the key frame's into
+// mvKeysUn (kf_n_left < 0: pKF->mpCamera2 == nullptr) or mvKeys / mvKeysRight (kf_n_left >= 0).
+extern "C" int ref_search_by_bow_rig(const KfArrays* kfa, int kf_n_left, const KfArrays* fra, int n_left, float nnratio, int check_orientation,
+                                     int* match2) {
+  GeometricCamera cam, cam2;
+  std::vector<MapPoint> pts(kfa->n);
+  KeyFrame kf;
+  kf.N = kfa->n;
+  kf.mpCamera = &cam;
+  kf.mDescriptors = cv::Mat(kfa->n, 32, CV_8U);
+  if (kfa->n) memcpy(kf.mDescriptors.data, kfa->desc, (size_t)kfa->n * 32);
+  kf.mvpMapPoints.assign(kfa->n, nullptr);
+  if (kf_n_left >= 0) {
+    kf.mpCamera2 = &cam2;
+    kf.NLeft = kf_n_left;
+    kf.mvKeys.resize(kf_n_left);
+    kf.mvKeysRight.resize(kfa->n - kf_n_left);
+    for (int i = 0; i < kfa->n; ++i) (i < kf_n_left ? kf.mvKeys[i] : kf.mvKeysRight[i - kf_n_left]).angle = kfa->kp_angle[i];
+  } else {
+    kf.mvKeysUn.resize(kfa->n);
+    for (int i = 0; i < kfa->n; ++i) kf.mvKeysUn[i].angle = kfa->kp_angle[i];
+  }
+  for (int i = 0; i < kfa->n; ++i) {
+    if (kfa->has_mp[i] == 1) kf.mvpMapPoints[i] = &pts[i];
+    else if (kfa->has_mp[i] == 2) { pts[i].bad = true; kf.mvpMapPoints[i] = &pts[i]; }
+  }
+  for (int k = 0; k < kfa->nnodes; ++k)
+    kf.mFeatVec[(unsigned)kfa->node_id[k]] = std::vector<unsigned>(kfa->node_feat + kfa->node_off[k], kfa->node_feat + kfa->node_off[k + 1]);
+  Frame F;
+  F.N = fra->n;
+  F.Nleft = n_left;
+  F.mpCamera = &cam;
+  F.mpCamera2 = &cam2;
+  F.mvKeys.resize(n_left);
+  F.mvKeysRight.resize(fra->n - n_left);
+  for (int i = 0; i < fra->n; ++i) (i < n_left ? F.mvKeys[i] : F.mvKeysRight[i - n_left]).angle = fra->kp_angle[i];
+  F.mDescriptors = cv::Mat(fra->n, 32, CV_8U);
+  if (fra->n) memcpy(F.mDescriptors.data, fra->desc, (size_t)fra->n * 32);
+  for (int k = 0; k < fra->nnodes; ++k)
+    F.mFeatVec[(unsigned)fra->node_id[k]] = std::vector<unsigned>(fra->node_feat + fra->node_off[k], fra->node_feat + fra->node_off[k + 1]);
+  ORBmatcher matcher(nnratio, check_orientation != 0);
+  std::vector<MapPoint*> vpMapPointMatches;
+  int nm;
+  { CallTimer timed; nm = matcher.SearchByBoW(&kf, F, vpMapPointMatches); }
+  for (int i = 0; i < fra->n; ++i) match2[i] = vpMapPointMatches[i] ? (int)(vpMapPointMatches[i] - pts.data()) : -1;
+  return nm;
+}
+
 // ORBmatcher(nnratio, checkOri).SearchByBoW(pKF1, pKF2, vpMatches12) (ORBmatcher.cc:765-905); has_mp: 0 none, 1 good, 2 bad.
 extern "C" int ref_search_by_bow_kf(const KfArrays* a1, const KfArrays* a2, float nnratio, int check_orientation, int* match12) {
   GeometricCamera cam;

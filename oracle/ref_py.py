@@ -64,6 +64,8 @@ def load_matcher():
     lib.ref_search_by_bow_kf.argtypes = [C.POINTER(KfArrays), C.POINTER(KfArrays), C.c_float, C.c_int, C.c_void_p]
     lib.ref_search_by_bow.restype = C.c_int
     lib.ref_search_by_bow.argtypes = [C.POINTER(KfArrays), C.POINTER(KfArrays), C.c_float, C.c_int, C.c_void_p]
+    lib.ref_search_by_bow_rig.restype = C.c_int
+    lib.ref_search_by_bow_rig.argtypes = [C.POINTER(KfArrays), C.c_int, C.POINTER(KfArrays), C.c_int, C.c_float, C.c_int, C.c_void_p]
     return lib
 
 
@@ -120,6 +122,16 @@ def search_by_bow(lib, kf, frame, nnratio, check_orientation):
     a1, a2 = kf_arrays(kf, keep), kf_arrays(frame, keep)
     m = np.zeros(a2.n, np.int32)
     nm = lib.ref_search_by_bow(C.byref(a1), C.byref(a2), C.c_float(nnratio), int(check_orientation), m.ctypes.data)
+    return m, nm, lib.ref_last_call_seconds()
+
+
+def search_by_bow_rig(lib, kf, kf_n_left, frame, n_left, nnratio, check_orientation):
+    """The reference's SearchByBoW on a two-camera frame (F.Nleft = n_left, F.mpCamera2 set); kf_n_left >= 0: the key frame is a
+    two-camera one as well (pKF->mpCamera2 set, pKF->NLeft = kf_n_left)."""
+    keep = []
+    a1, a2 = kf_arrays(kf, keep), kf_arrays(frame, keep)
+    m = np.zeros(a2.n, np.int32)
+    nm = lib.ref_search_by_bow_rig(C.byref(a1), int(kf_n_left), C.byref(a2), int(n_left), C.c_float(nnratio), int(check_orientation), m.ctypes.data)
     return m, nm, lib.ref_last_call_seconds()
 
 

@@ -206,6 +206,7 @@ SYMBOLS = {
     "rgbl_search_triangulation": (_I, [_V, C.POINTER(KeyframeView), C.POINTER(KeyframeView),
                                        C.POINTER(TriangulationParams), _V, C.POINTER(_I)]),
     "rgbl_search_by_bow": (_I, [_V, _V, _V, _F, _I, _V, C.POINTER(_I)]),
+    "rgbl_search_by_bow_rig": (_I, [_V, _V, _V, _I, _F, _I, _V, C.POINTER(_I)]),
     "rgbl_search_by_bow_keyframes": (_I, [_V, _V, _V, _F, _I, _V, C.POINTER(_I)]),
     "rgbl_search_by_projection": (_I, [_V, _V, _V, C.POINTER(_I)]),
     "rgbl_search_local_points": (_I, [_V, _V, _V, C.POINTER(_I)]),

@@ -66,6 +66,31 @@ def make_triangulation_case(n=1500, seed=11, n_nodes=100):
     return kf1, kf2, K, R, t, ep, sf, (sf * sf).astype(np.float32)
 
 
+def make_bow_rig_case(n=1500, seed=11, n_nodes=100):
+    """A key frame and a TWO-CAMERA frame (F.Nleft != -1) for SearchByBoW: the frame of make_triangulation_case as the left
+    camera's features and a second, more strongly perturbed and shuffled copy of them as the right camera's; a right feature sits
+    in the vocabulary node of the left feature it was derived from.  Returns (kf, frame, Nleft)."""
+    kf, left, *_ = make_triangulation_case(n, seed, n_nodes)
+    rng = np.random.default_rng(seed + 1000)
+    n2 = len(left["desc"])
+    right_desc, perm = synth.perturbed_descriptors(left["desc"], flip_p=0.05, seed=seed + 3)
+    node_of = np.full(n2, -1, np.int64)   # position of the left feature's node in the frame's FeatureVector, -1: in none
+    for k in range(len(left["node_id"])):
+        node_of[left["node_feat"][left["node_off"][k]:left["node_off"][k + 1]]] = k
+    node_r = node_of[perm]
+    feat, off = [], [0]
+    for k in range(len(left["node_id"])):
+        feat.extend(left["node_feat"][left["node_off"][k]:left["node_off"][k + 1]])
+        feat.extend((np.nonzero(node_r == k)[0] + n2).tolist())   # ascending inside a node, as DBoW2 fills it
+        off.append(len(feat))
+    ang_r = (left["angle"][perm] + rng.normal(0, 10, n2)).astype(np.float32) % 360
+    frame = dict(desc=np.concatenate([left["desc"], right_desc]), xy=np.concatenate([left["xy"], left["xy"][perm]]),
+                 octave=np.concatenate([left["octave"], left["octave"][perm]]), angle=np.concatenate([left["angle"], ang_r]),
+                 uright=np.full(2 * n2, -1, np.float32), has_mp=np.zeros(2 * n2, np.uint8), node_id=left["node_id"],
+                 node_off=np.array(off, np.int32), node_feat=np.array(feat, np.int32))
+    return kf, frame, n2
+
+
 def _quat(axis, angle):
     axis = np.asarray(axis, np.float64)
     axis = axis / np.linalg.norm(axis)

@@ -1519,6 +1519,7 @@ struct BowDev {
   const int32_t *off1, *feat1, *off2, *feat2, *pair_n1, *pair_n2;
   float nnratio;
   int max_best;           // largest accepted best distance: TH_LOW ("<=", :315) or TH_LOW - 1 ("<", :854)
+  int n_left2;            // F.Nleft of a two-camera frame (k_search_by_bow_rig): features from n_left2 on belong to the right camera
   int32_t* match1;  // per key-frame feature: the frame feature it took, or -1
   int32_t* match2;  // per frame feature: the key-frame feature, or -1
 };
@@ -1631,6 +1632,107 @@ __global__ __launch_bounds__(64) void k_search_by_bow(BowDev T) {
   else if (n2 <= 128) bow_node<2>(T, s_taken, s_q, s_idx1, lane, b1, e1, b2, n2);
   else if (n2 <= 192) bow_node<3>(T, s_taken, s_q, s_idx1, lane, b1, e1, b2, n2);
   else bow_node<4>(T, s_taken, s_q, s_idx1, lane, b1, e1, b2, n2);
+}
+
+
+// Two-camera frames (F.Nleft != -1, ORBmatcher.cc:298-326, 357-386): a key-frame feature keeps a best / second best among the
+// node's LEFT frame features and a best among its RIGHT ones; the left one is taken under the usual tests, the right one - only if
+// the left best passed `<= TH_LOW` - whenever its own distance does (`|| true`: no ratio test).  Both are gone for the later
+// key-frame features.  One wave per node as above; the frame features of a lane live in registers for buckets of up to 256.
+__device__ __forceinline__ void bow_node_rig(const BowDev& T, uint8_t* s_taken, unsigned long long (*s_q)[4], int* s_idx1, int lane, int b1, int e1, int b2, int n2) {
+  constexpr int kRegTrips = 4;
+  for (int j = lane + 64 * kRegTrips; j < n2; j += 64) s_taken[j] = 0;
+  unsigned long long t0[kRegTrips][4];
+  int my_idx2[kRegTrips];
+  bool gone[kRegTrips], right[kRegTrips];
+#pragma unroll
+  for (int r = 0; r < kRegTrips; ++r) {
+    my_idx2[r] = -1;
+    gone[r] = true;
+    right[r] = false;
+    t0[r][0] = t0[r][1] = t0[r][2] = t0[r][3] = 0ull;
+    if (lane + 64 * r < n2) {
+      my_idx2[r] = T.feat2[b2 + lane + 64 * r];
+      gone[r] = false;
+      right[r] = my_idx2[r] >= T.n_left2;
+      const unsigned long long* D2 = reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)my_idx2[r] * 32);
+      t0[r][0] = D2[0]; t0[r][1] = D2[1]; t0[r][2] = D2[2]; t0[r][3] = D2[3];
+    }
+  }
+  for (int p0 = b1; p0 < e1; p0 += 64) {
+    wave_sync();
+    {
+      const int p = p0 + lane;
+      int idx1 = -1;
+      if (p < e1) { idx1 = T.feat1[p]; if (!T.valid1[idx1]) idx1 = -1; }
+      s_idx1[lane] = idx1;
+      if (idx1 >= 0) {
+        const unsigned long long* D1 = reinterpret_cast<const unsigned long long*>(T.desc1 + (size_t)idx1 * 32);
+        s_q[lane][0] = D1[0]; s_q[lane][1] = D1[1]; s_q[lane][2] = D1[2]; s_q[lane][3] = D1[3];
+      }
+    }
+    wave_sync();
+    const int cnt = imin(64, e1 - p0);
+    for (int k = 0; k < cnt; ++k) {
+      const int idx1 = s_idx1[k];
+      if (idx1 < 0) continue;  // wave-uniform
+      const unsigned long long q[4] = {s_q[k][0], s_q[k][1], s_q[k][2], s_q[k][3]};
+      uint32_t best = 0xffffffffu, second = 256;   // left camera: dist << 16 | bucket position, and the runner-up's distance
+      uint32_t best_r = 0xffffffffu;               // right camera: the first minimum is all that is used
+      auto visit = [&](uint32_t key, bool is_right) {
+        const uint32_t kl = is_right ? 0xffffffffu : key, kr = is_right ? key : 0xffffffffu;
+        const uint32_t lo = kl < best ? kl : best, hi = kl < best ? best : kl;
+        second = (hi >> 16) < second ? (hi >> 16) : second;
+        best = lo;
+        best_r = kr < best_r ? kr : best_r;
+      };
+#pragma unroll
+      for (int r = 0; r < kRegTrips; ++r) {
+        if (64 * r >= n2) break;  // wave-uniform
+        const uint32_t key = ((uint32_t)hamming256(q, t0[r]) << 16) | (uint32_t)(lane + 64 * r);
+        visit(gone[r] ? 0xffffffffu : key, right[r]);
+      }
+      for (int j = lane + 64 * kRegTrips; j < n2; j += 64) {
+        if (s_taken[j]) continue;
+        const int idx2 = T.feat2[b2 + j];
+        visit(((uint32_t)hamming256(q, reinterpret_cast<const unsigned long long*>(T.desc2 + (size_t)idx2 * 32)) << 16) | (uint32_t)j, idx2 >= T.n_left2);
+      }
+      const uint32_t wbest = wave_min_uniform(best);
+      const int other = (int)wave_min_uniform(best == wbest ? second : (best == 0xffffffffu ? 256u : best >> 16));
+      const uint32_t wbest_r = wave_min_uniform(best_r);
+      if (wbest == 0xffffffffu || (int)(wbest >> 16) > T.max_best) continue;   // :315: the right camera's match sits inside this test
+      const int best_dist = (int)(wbest >> 16);
+      const bool take_l = (float)best_dist < T.nnratio * (float)other;
+      const bool take_r = wbest_r != 0xffffffffu && (int)(wbest_r >> 16) <= T.max_best;
+      bool beyond = false;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        if (!(side == 0 ? take_l : take_r)) continue;   // wave-uniform
+        const int pos = (int)((side == 0 ? wbest : wbest_r) & 0xffffu);
+        if (lane == (pos & 63)) {
+          int idx2 = -1;
+#pragma unroll
+          for (int r = 0; r < kRegTrips; ++r)
+            if ((pos >> 6) == r) { idx2 = my_idx2[r]; gone[r] = true; }
+          if (pos >= 64 * kRegTrips) { idx2 = T.feat2[b2 + pos]; s_taken[pos] = 1; }
+          if (side == 0) T.match1[idx1] = idx2;   // the result is match2; match1 keeps the left camera's feature
+          T.match2[idx2] = idx1;
+        }
+        beyond = beyond || pos >= 64 * kRegTrips;
+      }
+      if (beyond) wave_sync();   // wave-uniform: the other lanes read s_taken
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_search_by_bow_rig(BowDev T) {
+  __shared__ uint8_t s_taken[kBowBucket];
+  __shared__ unsigned long long s_q[64][4];
+  __shared__ int s_idx1[64];
+  const int np = blockIdx.x, lane = threadIdx.x;
+  const int a = T.pair_n1[np], b = T.pair_n2[np];
+  const int b1 = T.off1[a], e1 = T.off1[a + 1], b2 = T.off2[b], n2 = T.off2[b + 1] - b2;
+  bow_node_rig(T, s_taken, s_q, s_idx1, lane, b1, e1, b2, n2);
 }
 
 }  // namespace rgbl
@@ -3036,7 +3138,7 @@ int rgbl_bow_transform_frame(rgbl_vocabulary* v, const rgbl_device_frame* frame,
 // inverse; pa / pb = the shared vocabulary nodes in merge order
 static int bow_core(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_keyframe_view* fr, float nnratio, bool second_needs_mp,
                     int max_best, std::vector<int32_t>& pa, std::vector<int32_t>& pb, std::vector<int32_t>& match1,
-                    std::vector<int32_t>& match2) {
+                    std::vector<int32_t>& match2, int n_left2 = -1) {
   const int n1 = kf->n, n2 = fr->n;
   match1.assign(n1, -1);
   match2.assign(n2, -1);
@@ -3095,8 +3197,14 @@ static int bow_core(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_ke
   RGBL_TRY(hc.upload());
   T.nnratio = nnratio;
   T.max_best = max_best;
-  m->timer.begin("k_search_by_bow", s);
-  hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(64), 0, s, T);
+  T.n_left2 = n_left2;
+  if (n_left2 >= 0) {
+    m->timer.begin("k_search_by_bow_rig", s);
+    hipLaunchKernelGGL(k_search_by_bow_rig, dim3(npairs), dim3(64), 0, s, T);
+  } else {
+    m->timer.begin("k_search_by_bow", s);
+    hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(64), 0, s, T);
+  }
   m->timer.end(s);
   RGBL_HIP(hipGetLastError());
   RGBL_TRY(hc.fetch());
@@ -3107,30 +3215,37 @@ static int bow_core(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_ke
 
 int rgbl_search_by_bow(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_keyframe_view* fr, float nnratio,
                        int check_orientation, int32_t* match_f, int* out_nmatches) {
-  if (!m || !kf || !fr || !match_f || !out_nmatches || kf->n < 0 || fr->n < 0) { set_error("invalid argument"); return RGBL_ERR_INVALID; }
+  return rgbl_search_by_bow_rig(m, kf, fr, -1, nnratio, check_orientation, match_f, out_nmatches);
+}
+
+// The same with F.Nleft (-1: a single camera): a key-frame feature may hand its map point to a left AND a right frame feature
+// (ORBmatcher.cc:298-326, 357-386), so the rotation histogram is filled from the frame's side - its bins' SIZES are all that
+// ComputeThreeMaxima reads (:403-421), and every matched frame feature is in exactly one bin.
+int rgbl_search_by_bow_rig(rgbl_matcher* m, const rgbl_keyframe_view* kf, const rgbl_keyframe_view* fr, int frame_n_left, float nnratio,
+                           int check_orientation, int32_t* match_f, int* out_nmatches) {
+  if (!m || !kf || !fr || !match_f || !out_nmatches || kf->n < 0 || fr->n < 0 || frame_n_left < -1 || frame_n_left > fr->n) {
+    set_error("invalid argument");
+    return RGBL_ERR_INVALID;
+  }
   *out_nmatches = 0;
   const int n2 = fr->n;
   for (int i = 0; i < n2; ++i) match_f[i] = -1;
   std::vector<int32_t> pa, pb, match1, match2;
-  RGBL_TRY(bow_core(m, kf, fr, nnratio, false, 50 /* <= TH_LOW */, pa, pb, match1, match2));
-  const int npairs = (int)pa.size();
+  RGBL_TRY(bow_core(m, kf, fr, nnratio, false, 50 /* <= TH_LOW */, pa, pb, match1, match2, frame_n_left));
   int nmatches = 0;
   for (int i = 0; i < n2; ++i) { match_f[i] = match2[i]; nmatches += match_f[i] >= 0; }
   if (check_orientation) {
-    // rotation histogram in the order the reference fills it: node by node, key-frame bucket order (ORBmatcher.cc:331-343)
     std::vector<int> hist[30];
     const float factor = 1.0f / 30;
-    for (int p = 0; p < npairs; ++p)
-      for (int q = kf->node_off[pa[p]]; q < kf->node_off[pa[p] + 1]; ++q) {
-        const int idx1 = kf->node_feat[q];
-        const int idx2 = match1[idx1];
-        if (idx2 < 0) continue;
-        float rot = kf->kp_angle[idx1] - fr->kp_angle[idx2];
-        if (rot < 0.0) rot += 360.0f;
-        int bin = (int)roundf(rot * factor);
-        if (bin == 30) bin = 0;
-        if (bin >= 0 && bin < 30) hist[bin].push_back(idx2);
-      }
+    for (int idx2 = 0; idx2 < n2; ++idx2) {
+      const int idx1 = match2[idx2];
+      if (idx1 < 0) continue;
+      float rot = kf->kp_angle[idx1] - fr->kp_angle[idx2];
+      if (rot < 0.0) rot += 360.0f;
+      int bin = (int)roundf(rot * factor);
+      if (bin == 30) bin = 0;
+      if (bin >= 0 && bin < 30) hist[bin].push_back(idx2);
+    }
     int i1, i2, i3;
     three_maxima(hist, 30, i1, i2, i3);
     for (int i = 0; i < 30; ++i) {

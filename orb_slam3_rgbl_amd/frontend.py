@@ -742,22 +742,23 @@ class ORBmatcher:
         v.device = _dev(kf, "device")
         return v
 
-    def SearchByBoW(self, kf, frame):
-        return self.prepare_SearchByBoW(kf, frame)()
+    def SearchByBoW(self, kf, frame, Nleft=-1):
+        return self.prepare_SearchByBoW(kf, frame, Nleft)()
 
-    def prepare_SearchByBoW(self, kf, frame):
+    def prepare_SearchByBoW(self, kf, frame, Nleft=-1):
         """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (ORBmatcher.cc:223-425).  kf / frame: dicts as for
-        SearchForTriangulation; kf["has_mp"] = map point present and not bad.  Returns (per frame feature the key-frame
-        feature whose map point it gets, or -1; nmatches)."""
+        SearchForTriangulation; kf["has_mp"] = map point present and not bad.  Nleft = F.Nleft: -1 for a single camera, else the
+        frame's features from Nleft on are the right camera's (the two-camera branches, :298-326, :357-386).  Returns (per frame
+        feature the key-frame feature whose map point it gets, or -1; nmatches)."""
         keep = []
         v1, v2 = self._view(kf, keep), self._view(frame, keep)
         m = np.full(v2.n, -1, np.int32)
         nm = C.c_int(0)
-        fn, h, p1, p2, r, o, pm, pn = (self.lib.rgbl_search_by_bow, self.h, C.byref(v1), C.byref(v2), float(self.mfNNratio),
-                                       int(self.mbCheckOrientation), L.ptr(m), C.byref(nm))
+        fn, h, p1, p2, nl, r, o, pm, pn = (self.lib.rgbl_search_by_bow_rig, self.h, C.byref(v1), C.byref(v2), int(Nleft), float(self.mfNNratio),
+                                           int(self.mbCheckOrientation), L.ptr(m), C.byref(nm))
 
         def call(_keep=keep):   # the closure owns the input arrays
-            L.check(self.lib, fn(h, p1, p2, r, o, pm, pn))
+            L.check(self.lib, fn(h, p1, p2, nl, r, o, pm, pn))
             return m, nm.value
         return call
 

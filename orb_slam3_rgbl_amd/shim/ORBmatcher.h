@@ -119,19 +119,17 @@ class ORBmatcher {
     const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
     vpMapPointMatches = std::vector<MapPointT*>(F.N, static_cast<MapPointT*>(NULL));
     if (!mpHandle) return 0;
-    if (F.Nleft != -1 || pKF->mpCamera2) {
-      std::cerr << "[ORBmatcher] SearchByBoW: fisheye stereo rigs are not covered by the device path" << std::endl;
-      return 0;
-    }
     Flat fk, ff;
     const int n1 = pKF->N, n2 = F.N;
     fk.xy.assign(2 * (size_t)n1, 0.f); fk.angle.resize(n1); fk.octave.assign(n1, 0); fk.has_mp.resize(n1);
     for (int i = 0; i < n1; ++i) {
-      fk.angle[i] = pKF->mvKeysUn[i].angle;
+      // the key point the reference reads the angle from, ORBmatcher.cc:335-338 / 362-365
+      fk.angle[i] = !pKF->mpCamera2 ? pKF->mvKeysUn[i].angle : (i >= pKF->NLeft) ? pKF->mvKeysRight[i - pKF->NLeft].angle : pKF->mvKeys[i].angle;
       fk.has_mp[i] = (vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad()) ? 1 : 0;
     }
     ff.xy.assign(2 * (size_t)n2, 0.f); ff.angle.resize(n2); ff.octave.assign(n2, 0); ff.has_mp.assign(n2, 0);
-    for (int i = 0; i < n2; ++i) ff.angle[i] = F.mvKeys[i].angle;
+    // :340-343 / :367-373: a two-camera frame's features from Nleft on are the right camera's key points
+    for (int i = 0; i < n2; ++i) ff.angle[i] = (F.Nleft != -1 && i >= F.Nleft) ? F.mvKeysRight[i - F.Nleft].angle : F.mvKeys[i].angle;
     FlattenFeatVec(pKF->mFeatVec, fk);
     FlattenFeatVec(F.mFeatVec, ff);
     std::vector<float> ur1(n1, -1.f), ur2(n2, -1.f);
@@ -139,7 +137,7 @@ class ORBmatcher {
     FillView(ff, n2, F.mDescriptors.template ptr<uint8_t>(), ur2.data());
     std::vector<int32_t> match(n2, -1);
     int nmatches = 0;
-    if (rgbl_search_by_bow(mpHandle, &fk.view, &ff.view, mfNNratio, mbCheckOrientation, match.data(), &nmatches) != RGBL_OK) {
+    if (rgbl_search_by_bow_rig(mpHandle, &fk.view, &ff.view, F.Nleft, mfNNratio, mbCheckOrientation, match.data(), &nmatches) != RGBL_OK) {
       std::cerr << "[ORBmatcher] " << rgbl_last_error() << std::endl;
       return 0;
     }

@@ -747,6 +747,26 @@ def check_search_by_bow(lib, seed=51, nnratio=0.7, check_ori=True, n=1500, nodes
     return nm
 
 
+def check_search_by_bow_rig(lib, seed=61, nnratio=0.7, check_ori=True, n=1500, nodes=100):
+    """SearchByBoW on a two-camera frame (F.Nleft != -1, ORBmatcher.cc:298-326, 357-386).  Returns (nmatches, map points that went
+    to a left AND a right feature)."""
+    from orb_slam3_rgbl_amd.cases import make_bow_rig_case
+    kf, fr, n_left = make_bow_rig_case(n, seed=seed, n_nodes=nodes)
+    rng = np.random.default_rng(seed)
+    kf = dict(kf, has_mp=(rng.random(n) < 0.7).astype(np.uint8))
+    mt = F.ORBmatcher(nnratio, check_ori, lib=lib)
+    m, nm = mt.SearchByBoW(kf, fr, n_left)
+    om, onm = O.search_by_bow(kf, fr, nnratio, check_ori, n_left=n_left)
+    assert nm == onm and np.array_equal(m, om), "SearchByBoW, two-camera frame (seed %d)" % seed
+    # Nleft = N: every feature is a left one - the single-camera result
+    m1, nm1 = mt.SearchByBoW(kf, fr, len(fr["desc"]))
+    om1, onm1 = O.search_by_bow(kf, fr, nnratio, check_ori)
+    assert nm1 == onm1 and np.array_equal(m1, om1)
+    mt.close()
+    both = np.intersect1d(m[:n_left][m[:n_left] >= 0], m[n_left:][m[n_left:] >= 0])
+    return nm, len(both)
+
+
 def check_search_by_bow_keyframes(lib, seed=81, nnratio=0.75, check_ori=True, n=1500, nodes=100):
     kf1, kf2, *_ = make_triangulation_case(n, seed=seed, n_nodes=nodes)
     rng = np.random.default_rng(seed)

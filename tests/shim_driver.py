@@ -171,6 +171,8 @@ def run_and_check(exe, tmp):
     dd = take(np.int32, 1)[0]
     nbow, n2b = take(np.int32, 2)
     bow_match = take(np.int32, n2b)
+    nrig = take(np.int32, 1)[0]
+    rig_match = take(np.int32, n2b)
     nproj, n2p = take(np.int32, 2)
     proj_match = take(np.int32, n2p)
     nloc, n2l = take(np.int32, 2)
@@ -280,3 +282,5 @@ def run_and_check(exe, tmp):
     assert dd == O.descriptor_distance(kf1["desc"][0], kf2["desc"][0])
     obm, obn = O.search_by_bow(kf1, kf2, 0.7, True)
     assert nbow == obn and np.array_equal(bow_match, obm) and nbow > 50
+    orm_, orn_ = O.search_by_bow(kf1, kf2, 0.7, True, n_left=len(kf2["desc"]) // 2)   # the frame's second half as a right camera's features
+    assert nrig == orn_ and np.array_equal(rig_match, orm_) and nrig > 50 and not np.array_equal(rig_match, bow_match)

@@ -40,7 +40,7 @@ struct Camera {
 struct MapPoint { bool isBad() { return false; } };
 struct KeyFrame {
   int N = 0, NLeft = -1, Nleft = -1;  // Nleft / mvKeys: the members SearchByBoW reads when a KeyFrame stands in for a Frame
-  std::vector<cv::KeyPoint> mvKeys;
+  std::vector<cv::KeyPoint> mvKeys, mvKeysRight;
   std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
   Camera* mpCamera = nullptr; Camera* mpCamera2 = nullptr;
   std::map<unsigned, std::vector<unsigned> > mFeatVec;

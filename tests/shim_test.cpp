@@ -350,6 +350,16 @@ int main(int argc, char** argv) {
     const int n2b = (int)vpMapPointMatches.size();
     wr(out, &nbow, 1); wr(out, &n2b, 1);
     for (int i = 0; i < n2b; ++i) { const int idx = vpMapPointMatches[i] ? (int)(vpMapPointMatches[i] - own.data()) : -1; wr(out, &idx, 1); }
+    // --- the same with a two-camera frame (F.Nleft != -1, ORBmatcher.cc:298-326, 357-386): the second half of the features as the right camera's
+    kf2.Nleft = kf2.N / 2;
+    kf2.mvKeys.assign(kf2.mvKeysUn.begin(), kf2.mvKeysUn.begin() + kf2.Nleft);
+    kf2.mvKeysRight.assign(kf2.mvKeysUn.begin() + kf2.Nleft, kf2.mvKeysUn.end());
+    const int nrig = bow.SearchByBoW(&kf1, kf2, vpMapPointMatches);
+    wr(out, &nrig, 1);
+    for (int i = 0; i < n2b; ++i) { const int idx = vpMapPointMatches[i] ? (int)(vpMapPointMatches[i] - own.data()) : -1; wr(out, &idx, 1); }
+    kf2.Nleft = -1;
+    kf2.mvKeys = kf2.mvKeysUn;
+    kf2.mvKeysRight.clear();
   }
   // --- as Tracking::TrackWithMotionModel (Tracking.cc:2913-2934): SearchByProjection(mCurrentFrame, mLastFrame, th, bMono)
   if (argc > 9) {

@@ -286,6 +286,13 @@ def test_search_by_bow(emu_lib, seed, ratio, ori, nodes):
     assert pc.check_search_by_bow(emu_lib, seed, ratio, ori, n=700, nodes=nodes) > 30
 
 
+@pytest.mark.parametrize("seed,ratio,ori,nodes", [(61, 0.7, True, 100), (62, 0.9, False, 30), (63, 0.6, True, 1), (64, 0.8, True, 4)])
+def test_search_by_bow_two_camera_frame(emu_lib, seed, ratio, ori, nodes):
+    """F.Nleft != -1 (ORBmatcher.cc:298-326, 357-386); nodes = 1 / 4: buckets beyond the 256 positions a wave keeps in registers."""
+    nm, both = pc.check_search_by_bow_rig(emu_lib, seed, ratio, ori, n=700, nodes=nodes)
+    assert nm > 60 and both > 10
+
+
 @pytest.mark.parametrize("seed,ratio,ori,nodes", [(81, 0.75, True, 100), (82, 0.9, False, 30), (84, 0.8, True, 1), (85, 0.8, True, 6)])
 def test_search_by_bow_keyframes(emu_lib, seed, ratio, ori, nodes):
     assert pc.check_search_by_bow_keyframes(emu_lib, seed, ratio, ori, n=800, nodes=nodes) > 50

@@ -263,6 +263,13 @@ def test_search_by_bow(gpu_lib, seed, ratio, ori, nodes):
     assert pc.check_search_by_bow(gpu_lib, seed, ratio, ori, n=2000, nodes=nodes) > 100
 
 
+@pytest.mark.parametrize("seed,ratio,ori,nodes", [(61, 0.7, True, 100), (62, 0.9, False, 30), (63, 0.6, True, 1), (64, 0.8, True, 4), (65, 0.7, True, 12)])
+def test_search_by_bow_two_camera_frame(gpu_lib, seed, ratio, ori, nodes):
+    """F.Nleft != -1 (ORBmatcher.cc:298-326, 357-386); nodes = 1 / 4: buckets beyond the 256 positions a wave keeps in registers."""
+    nm, both = pc.check_search_by_bow_rig(gpu_lib, seed, ratio, ori, n=2000, nodes=nodes)
+    assert nm > 100 and both > 20
+
+
 @pytest.mark.parametrize("seed,ratio,ori,nodes", [(81, 0.75, True, 100), (82, 0.9, False, 30), (84, 0.8, True, 1), (85, 0.8, True, 6)])
 def test_search_by_bow_keyframes(gpu_lib, seed, ratio, ori, nodes):
     assert pc.check_search_by_bow_keyframes(gpu_lib, seed, ratio, ori, n=2000, nodes=nodes) > 50

@@ -507,6 +507,32 @@ def test_reference_search_by_bow_agrees_with_oracle(refmatcher, seed, nnratio, c
     assert nm > 100
 
 
+@pytest.mark.parametrize("seed,nnratio,check_ori,nodes,kf_rig", [(61, 0.7, True, 100, False), (62, 0.7, False, 100, True), (63, 0.9, True, 30, True),
+                                                                 (64, 0.6, True, 1, False), (65, 0.8, True, 5, True)])
+def test_reference_search_by_bow_two_camera_frame_agrees_with_oracle(refmatcher, seed, nnratio, check_ori, nodes, kf_rig):
+    """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) with F.Nleft != -1 (ORBmatcher.cc:298-326, 357-386): the reference's own
+    lines on a stand-in two-camera Frame (and, kf_rig, a two-camera KeyFrame: the angle comes from mvKeys / mvKeysRight then)."""
+    from orb_slam3_rgbl_amd.cases import make_bow_rig_case
+    kf, fr, n_left = make_bow_rig_case(1500, seed=seed, n_nodes=nodes)
+    rng = np.random.default_rng(seed)
+    state = rng.choice([0, 1, 2], len(kf["desc"]), p=[0.25, 0.65, 0.1]).astype(np.uint8)   # none / good / bad map point
+    keep = []
+    a1 = kf_arrays(dict(kf, has_mp=state), keep)
+    a2 = kf_arrays(fr, keep)
+    m = np.zeros(a2.n, np.int32)
+    refmatcher.ref_search_by_bow_rig.restype = C.c_int
+    refmatcher.ref_search_by_bow_rig.argtypes = [C.POINTER(KfArrays), C.c_int, C.POINTER(KfArrays), C.c_int, C.c_float, C.c_int, C.c_void_p]
+    nm = refmatcher.ref_search_by_bow_rig(C.byref(a1), len(kf["desc"]) // 2 if kf_rig else -1, C.byref(a2), n_left, C.c_float(nnratio), int(check_ori),
+                                          m.ctypes.data)
+    om, onm = O.search_by_bow(dict(kf, has_mp=(state == 1).astype(np.uint8)), fr, nnratio, check_ori, n_left=n_left)
+    assert nm == onm and np.array_equal(m, om)
+    left, right = m[:n_left], m[n_left:]
+    both = np.intersect1d(left[left >= 0], right[right >= 0])
+    assert nm > 150 and len(both) > 30          # map points that went to a left AND a right feature
+    # the right camera's features are taken without a ratio test: more of them than a single-camera search of the same features finds
+    assert (right >= 0).sum() > 0
+
+
 @pytest.mark.parametrize("seed,th", [(91, 3.0), (92, 3.0), (93, 4.0), (94, 1.5)])
 def test_reference_fuse_agrees_with_oracle(refmatcher, seed, th):
     """The real ORBmatcher::Fuse(pKF, vpMapPoints, th) (LocalMapping::SearchInNeighbors: ORBmatcher().Fuse(pKFi, vpMapPointMatches),
