@@ -86,9 +86,9 @@ def greedy_search_case(lib, rng):
 
 
 def node_search_case(lib, rng):
-    """The searches that work through the vocabulary nodes two FeatureVectors share (SearchForTriangulation, SearchByBoW x 2): random
+    """The searches that work through the vocabulary nodes two FeatureVectors share (SearchForTriangulation, SearchByBoW x 3): random
     feature counts and node counts, i.e. buckets on both sides of what the kernels keep in LDS (256) and in registers (64 / 256)."""
-    kind = int(rng.integers(0, 3))
+    kind = int(rng.integers(0, 4))
     n = int(rng.choice([60, 300, 700, 1500, 2000, 4000]))
     nodes = int(rng.choice([1, 2, 5, 12, 30, 100, 400]))
     seed = int(rng.integers(0, 100000))
@@ -98,6 +98,9 @@ def node_search_case(lib, rng):
     if kind == 1:
         m = pc.check_search_by_bow(lib, seed, float(rng.choice([0.6, 0.7, 0.9])), bool(rng.integers(0, 2)), n=n, nodes=nodes)
         return "SearchByBoW(KF, F) %5d features, %3d nodes: %d matches" % (n, nodes, m)
+    if kind == 3:
+        m, both = pc.check_search_by_bow_rig(lib, seed, float(rng.choice([0.6, 0.7, 0.9])), bool(rng.integers(0, 2)), n=n, nodes=nodes)
+        return "SearchByBoW(KF, two-camera F) %5d features, %3d nodes: %d matches, %d map points on both cameras" % (n, nodes, m, both)
     m = pc.check_search_by_bow_keyframes(lib, seed, float(rng.choice([0.75, 0.8, 0.9])), bool(rng.integers(0, 2)), n=n, nodes=nodes)
     return "SearchByBoW(KF, KF) %5d features, %3d nodes: %d matches" % (n, nodes, m)
 
