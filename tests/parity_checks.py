@@ -762,6 +762,10 @@ def check_search_by_bow_rig(lib, seed=61, nnratio=0.7, check_ori=True, n=1500, n
     m1, nm1 = mt.SearchByBoW(kf, fr, len(fr["desc"]))
     om1, onm1 = O.search_by_bow(kf, fr, nnratio, check_ori)
     assert nm1 == onm1 and np.array_equal(m1, om1)
+    # Nleft = 0: no left feature, and the right camera's match sits inside the left one's test (:315) - nothing is matched
+    m0, nm0 = mt.SearchByBoW(kf, fr, 0)
+    om0, onm0 = O.search_by_bow(kf, fr, nnratio, check_ori, n_left=0)
+    assert nm0 == onm0 == 0 and np.array_equal(m0, om0) and not (m0 >= 0).any()
     mt.close()
     both = np.intersect1d(m[:n_left][m[:n_left] >= 0], m[n_left:][m[n_left:] >= 0])
     return nm, len(both)

@@ -36,6 +36,11 @@ elif which == "match":
     pc.check_search_for_initialization(lib, 61, 100, 0.9, True, n1=1500)
     import tempfile
     pc.check_bow_transform(lib, tempfile.mkdtemp(), 10, 3, 2, seed=1, n_feat=600)
+    pc.check_search_by_bow(lib, 51, 0.7, True, n=700, nodes=100)
+    pc.check_search_by_bow(lib, 54, 0.6, False, n=700, nodes=1)                # one bucket beyond the 256 register positions
+    pc.check_search_by_bow_keyframes(lib, 81, 0.75, True, n=800, nodes=30)
+    pc.check_search_by_bow_rig(lib, 61, 0.7, True, n=700, nodes=100)           # two-camera frame
+    pc.check_search_by_bow_rig(lib, 63, 0.6, True, n=700, nodes=1)
 elif which == "misc":
     pc.check_stereo_matches(lib, w=640, h=300, nfeatures=1200)
     pc.check_ingest_color(lib, 402, 300)
