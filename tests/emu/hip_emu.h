@@ -60,9 +60,19 @@ struct Rendezvous {
   unsigned gen = 0;
 };
 
+// Context switches: glibc's swapcontext / getcontext make a rt_sigprocmask system call each - with two switches per yield that
+// was more than half of the emulated suite's time (20 of 60 CPU minutes in the kernel).  On x86-64 without Address- / Thread-
+// Sanitizer (which follow swapcontext, not a hand-written switch) the fibers are switched by 14 instructions: the callee-saved
+// registers on the fiber's own stack, the stack pointers exchanged.  Everything else keeps ucontext.
+#if defined(__x86_64__) && !defined(__SANITIZE_ADDRESS__) && !defined(__SANITIZE_THREAD__) && !defined(HIPEMU_UCONTEXT)
+#define HIPEMU_FAST_SWITCH 1
+extern "C" void hipemu_switch(void** save_sp, void* const* load_sp);
+#endif
+
 struct Block;
 struct Fiber {
   ucontext_t ctx;
+  void* sp = nullptr;     // HIPEMU_FAST_SWITCH: the suspended fiber's stack pointer
   Block* blk = nullptr;
   int tid = 0;
   bool done = false;
@@ -73,6 +83,7 @@ struct Fiber {
 
 struct Block {
   ucontext_t sched;
+  void* sched_sp = nullptr;
   std::vector<Fiber> fibers;
   int nthreads = 0;
   int active = 0;               // fibers not yet finished
@@ -373,11 +384,41 @@ thread_local dim3 blockDim, gridDim;
 namespace hipemu {
 thread_local Block* g_blk = nullptr;
 
+#ifdef HIPEMU_FAST_SWITCH
+asm(R"(
+  .text
+  .globl hipemu_switch
+  .type hipemu_switch, @function
+hipemu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq (%rsi), %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+  .size hipemu_switch, .-hipemu_switch
+)");
+static inline void to_scheduler(Block* b, Fiber* f) { hipemu_switch(&f->sp, &b->sched_sp); }
+static inline void to_fiber(Block* b, Fiber* f) { hipemu_switch(&b->sched_sp, &f->sp); }
+#else
+static inline void to_scheduler(Block* b, Fiber* f) { swapcontext(&f->ctx, &b->sched); }
+static inline void to_fiber(Block* b, Fiber* f) { swapcontext(&b->sched, &f->ctx); }
+#endif
+
 void yield_to_scheduler() {
   Block* b = cur_block();
   Fiber* f = b->cur;
   HIPEMU_TSAN_SWITCH(b->tsan_sched);
-  swapcontext(&f->ctx, &b->sched);
+  to_scheduler(b, f);
 }
 
 static void fiber_entry() {
@@ -396,7 +437,8 @@ static void fiber_entry() {
   release(b->wbar[2 * w], b->wave_active[w]);
   release(b->wbar[2 * w + 1], b->wave_active[w]);
   HIPEMU_TSAN_SWITCH(b->tsan_sched);
-  swapcontext(&f->ctx, &b->sched);
+  to_scheduler(b, f);
+  __builtin_trap();   // a finished fiber is never resumed
 }
 
 static int order_mode() {
@@ -433,11 +475,22 @@ void run_block(Block& b, const dim3& block) {
     f.tidx.y = (t / block.x) % block.y;
     f.tidx.z = t / (block.x * block.y);
     ++b.wave_active[t >> 6];
+#ifdef HIPEMU_FAST_SWITCH
+    {
+      // what hipemu_switch pops on the first switch: six registers, then `ret` into fiber_entry with the stack as after a call
+      void** top = reinterpret_cast<void**>((reinterpret_cast<uintptr_t>(f.stack) + STACK) & ~(uintptr_t)15);
+      top[-1] = nullptr;                                  // fiber_entry's "return address" (it never returns)
+      top[-2] = reinterpret_cast<void*>(&fiber_entry);
+      for (int r = 3; r <= 8; ++r) top[-r] = nullptr;     // rbp, rbx, r12 - r15
+      f.sp = top - 8;
+    }
+#else
     getcontext(&f.ctx);
     f.ctx.uc_stack.ss_sp = f.stack;
     f.ctx.uc_stack.ss_size = STACK;
     f.ctx.uc_link = nullptr;
     makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+#endif
 #if defined(__SANITIZE_THREAD__)
     if (f.tsan) __tsan_destroy_fiber(f.tsan);   // a fresh context is a fresh fiber for the sanitizer
     f.tsan = __tsan_create_fiber(0);
@@ -462,7 +515,7 @@ void run_block(Block& b, const dim3& block) {
       b.cur = &f;
       threadIdx = f.tidx;
       HIPEMU_TSAN_SWITCH(f.tsan);
-      swapcontext(&b.sched, &f.ctx);
+      to_fiber(&b, &f);
       if (mode == 0 && b.phase != phase0) break;  // a rendezvous completed: flip the order
     }
   }
