@@ -1744,8 +1744,11 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // double-precision sin / cos, the keypoint record - is evaluated once with lane k working for keypoint k, instead of
 // being replicated over all lanes of a one-keypoint wave (it was two thirds of the issued instructions).
 // Four __ballot results per keypoint are descriptor bytes 0-7, 8-15, 16-23, 24-31.
-// grid = (ceil(kp_frame / (4 * kKpPerWave)), B), block = 256.
-constexpr int kKpPerWave = 4;
+// grid = (ceil(kp_frame / (4 * kKpPerWave)), B), block = 256 (128: 144.4 k, 512: 143.5 k against 146.5 k frames/s).
+// 8 since the end of round 6 (4 before: 10 registers of patch words per keypoint in flight; 2 / 4 / 6 / 8 / 12 / 16 on the KITTI step, twice each
+// on one box: 142.1 / 144.9 / 146.3 / 146.3 / 144.2 / 141.6 k frames/s, the kernel 1.38 / 1.26 / 1.25 / 1.23 / 1.21 / 1.35 ms; single frames
+// unchanged: 0.308 -> 0.309 ms through the drop-in classes).
+constexpr int kKpPerWave = 8;
 
 __device__ __forceinline__ int bcast_i(int v, int k) {  // value of lane k, wave-uniform (k is a constant after unrolling)
 #ifdef RGBL_EMU
